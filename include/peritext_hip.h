@@ -1,0 +1,221 @@
+/*
+ * peritext_hip.h — C ABI of the MI355X (gfx950) batch CRDT merge engine for Peritext's hot path.
+ *
+ * The reference (inkandswitch/peritext) has no FFI: its boundary is the TypeScript module API
+ *     Micromerge.applyChange(change)            reference/src/micromerge.ts:499
+ *     Micromerge.getTextWithFormatting(path)    reference/src/micromerge.ts:516 -> src/peritext.ts:337
+ * called per replica by bridge.ts:253/288 and by the test harness (test/micromerge.ts:54-79,
+ * test/fuzz.ts:198-205).  This header is what an N-API addon binds instead (INTEGRATION.md shows the
+ * stub): ONE call applies MANY replica op logs and materialises the formatted documents.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types; every function returns a ptx_status
+ *     (0 = ok) except the accessors; the last failure text is kept per context (ptx_last_error).
+ *   - a context owns one HIP stream and every device allocation made through it; contexts are
+ *     independent, one context must not be used from two threads at once.
+ *   - per-LOG failures (the reference's throw sites, micromerge.ts:503,:507,:752) do not abort the
+ *     batch: they are reported in ptx_log_result.status and that log's outputs are empty.
+ *
+ * Wire format of the op log (SoA, 32 bytes per op)
+ *   A batch holds n_logs replica-logs.  A replica-log is the sequence of internal Operations
+ *   (Change.ops flattened, micromerge.ts:60-71,:204-212) one replica applied, IN ITS APPLICATION
+ *   ORDER.  Ops of log l are rows log_off[l] .. log_off[l+1]-1 of nine columns:
+ *     op_id   u64  (counter << 32) | actorRank     "counter@actor" (micromerge.ts:488); actorRank =
+ *                  rank of the actor string in UTF-16 code-unit order among the doc's actors, which
+ *                  makes integer order == compareOpIds order (micromerge.ts:812-827)
+ *     ref_a   u64  insert: elemId it was inserted after, 0 = HEAD (:153, :348); delete: elemId (:165);
+ *                  mark: start.elemId (peritext.ts:17-21,:28)
+ *     ref_b   u64  mark: end.elemId (peritext.ts:30); otherwise 0
+ *     payload u32  insert: value id (index into the caller's string table); addMark link: url id;
+ *                  add/removeMark comment: DOC-LOCAL dense comment id whose numeric order equals the
+ *                  code-unit order of the id strings (peritext.ts:318 keeps the array sorted by id)
+ *     action  u8   PTX_ACT_*      mark_type u8  PTX_MARK_* (schema.ts:125 ALL_MARKS order)
+ *     side_a  u8   PTX_SIDE_* of start        side_b u8  PTX_SIDE_* of end
+ *   Ops on other objects than the text list (makeMap / set / del on the root map) are PTX_ACT_NOP.
+ *
+ * Output (all per log, canonical — two replicas have deep-equal getTextWithFormatting output iff
+ * their canonical outputs, and therefore their digests, are equal):
+ *     values     u32[n_visible]   value ids of the visible elements in document order
+ *     spans      {start, attr}[n_spans]   maximal runs of visible elements with equal marks
+ *                (peritext.ts:438-455): start = visible index of the first element, attr = flags<<28 | link url id
+ *     cintervals {id, start, end}[n_cintervals]  for every comment id the maximal visible ranges
+ *                [start,end) on which that comment is present, sorted by (id, start).  A span's
+ *                `comment` array is the set of ids whose interval covers it (present iff
+ *                PTX_ATTR_COMMENT is set — `comment: []` is a real state).
+ *     digest     2 x u64 multiset hash of the above (peritext_amd/canon.py, oracle/canon.js restate it)
+ *   Output rows of log l start at row log_off[l] of each output array (a log never produces more
+ *   rows than it has ops), so no cross-log compaction or device-side allocation is needed.
+ */
+#ifndef PERITEXT_HIP_H
+#define PERITEXT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTX_ABI_VERSION 1u
+
+/* Operation.action (micromerge.ts:150-212, peritext.ts:25-65) */
+enum {
+    PTX_ACT_MAKELIST = 0,   /* creates the text list; exactly one per log, ignored by the kernels */
+    PTX_ACT_INSERT = 1,     /* {action:"set", insert:true}  -> applyListInsert  micromerge.ts:614 */
+    PTX_ACT_DELETE = 2,     /* {action:"del", elemId}       -> applyListUpdate  micromerge.ts:677 */
+    PTX_ACT_ADDMARK = 3,    /* applyAddRemoveMark peritext.ts:154 */
+    PTX_ACT_REMOVEMARK = 4,
+    PTX_ACT_NOP = 5         /* op on another object (root map set/del/makeMap): no effect on the text */
+};
+
+/* markType, in ALL_MARKS order (schema.ts:125) */
+enum { PTX_MARK_STRONG = 0, PTX_MARK_EM = 1, PTX_MARK_COMMENT = 2, PTX_MARK_LINK = 3 };
+
+/* BoundaryPosition.type (peritext.ts:17-21) */
+enum { PTX_SIDE_BEFORE = 0, PTX_SIDE_AFTER = 1, PTX_SIDE_START_OF_TEXT = 2, PTX_SIDE_END_OF_TEXT = 3 };
+
+/* span attr: flags in the top 4 bits, link url id in the low 28 (0 when no link) */
+#define PTX_ATTR_STRONG 0x10000000u
+#define PTX_ATTR_EM 0x20000000u
+#define PTX_ATTR_LINK 0x40000000u
+#define PTX_ATTR_COMMENT 0x80000000u /* key `comment` present (possibly []) */
+#define PTX_ATTR_ID_MASK 0x0fffffffu
+
+typedef int32_t ptx_status;
+enum {
+    PTX_OK = 0,
+    /* per-log (ptx_log_result.status): mirror the reference's throw sites */
+    PTX_ERR_ELEM_NOT_FOUND = 1,  /* RangeError "List element not found"      micromerge.ts:752 */
+    PTX_ERR_SEQ_GAP = 2,         /* RangeError "Expected sequence number"    micromerge.ts:503 */
+    PTX_ERR_MISSING_DEP = 3,     /* RangeError "Missing dependency"          micromerge.ts:507 */
+    PTX_ERR_DUPLICATE_OP = 4,    /* same opId twice in one log (the seq check makes this impossible upstream) */
+    PTX_ERR_CAPACITY = 5,        /* log too large for the on-chip working set of this build */
+    PTX_ERR_BAD_OP = 6,          /* malformed row: unknown action / mark type / comment id not dense */
+    /* call-level */
+    PTX_ERR_INVALID_ARG = 100,
+    PTX_ERR_HIP = 101,           /* a HIP runtime call failed; see ptx_last_error */
+    PTX_ERR_NO_DEVICE = 102,
+    PTX_ERR_OOM = 103
+};
+
+/* One batch of replica-logs.  All pointers are HOST pointers for ptx_batch_upload /
+ * ptx_apply_materialize and DEVICE pointers for ptx_batch_wrap_device. */
+typedef struct ptx_batch {
+    uint32_t n_logs;
+    uint32_t reserved;
+    uint64_t n_ops;            /* == log_off[n_logs] */
+    const uint64_t* log_off;   /* [n_logs + 1] */
+    const uint64_t* op_id;     /* [n_ops] */
+    const uint64_t* ref_a;     /* [n_ops] */
+    const uint64_t* ref_b;     /* [n_ops] */
+    const uint32_t* payload;   /* [n_ops] */
+    const uint8_t* action;     /* [n_ops] */
+    const uint8_t* mark_type;  /* [n_ops] */
+    const uint8_t* side_a;     /* [n_ops] */
+    const uint8_t* side_b;     /* [n_ops] */
+    /* optional causal envelope (Change headers, micromerge.ts:60-71); NULL = skip causal admission.
+     * chg_off[l]..chg_off[l+1]-1 are the changes of log l in application order. */
+    const uint64_t* chg_off;   /* [n_logs + 1] or NULL */
+    const uint32_t* chg_actor; /* [n_changes] actorRank */
+    const uint32_t* chg_seq;   /* [n_changes] */
+    const uint32_t* chg_nops;  /* [n_changes] ops in the change (consecutive rows of the log) */
+    const uint32_t* chg_deps;  /* [n_changes * max_actors] deps[actorRank] (0 = none) */
+    uint32_t max_actors;       /* row stride of chg_deps */
+    uint32_t reserved2;
+} ptx_batch;
+
+typedef struct ptx_span {
+    uint32_t start; /* visible index of the first element of the span */
+    uint32_t attr;  /* PTX_ATTR_* | link url id */
+} ptx_span;
+
+typedef struct ptx_cinterval {
+    uint32_t id;    /* doc-local comment id */
+    uint32_t start; /* visible index, inclusive */
+    uint32_t end;   /* visible index, exclusive */
+} ptx_cinterval;
+
+typedef struct ptx_log_result {
+    uint32_t status;        /* PTX_OK or a per-log PTX_ERR_* */
+    uint32_t n_ops;         /* ops applied (the makeList and NOP rows excluded) */
+    uint32_t n_elems;       /* list elements incl. tombstones */
+    uint32_t n_visible;     /* rows of `values` */
+    uint32_t n_spans;       /* rows of `spans` */
+    uint32_t n_cintervals;  /* rows of `cintervals` */
+    uint32_t reserved[2];
+    uint64_t digest[2];
+} ptx_log_result;
+
+/* Host-side view of a result set (returned by ptx_result_download / ptx_apply_materialize).
+ * Row r of log l lives at index log_off[l] + r.  Owned by the library until ptx_result_free. */
+typedef struct ptx_result {
+    uint32_t n_logs;
+    uint32_t reserved;
+    uint64_t n_rows;                  /* == batch n_ops (row capacity of the three arrays) */
+    const ptx_log_result* logs;       /* [n_logs] */
+    const uint32_t* values;           /* [n_rows] */
+    const ptx_span* spans;            /* [n_rows] */
+    const ptx_cinterval* cintervals;  /* [n_rows] */
+    const uint32_t* elem_rank;        /* [n_rows] per op row: document position (incl. tombstones) of the
+                                         element an INSERT row created, 0xffffffff for other rows
+                                         (what findListElement(...).index would return, micromerge.ts:731) */
+    void* owner;
+} ptx_result;
+
+typedef struct ptx_ctx ptx_ctx;          /* device context: stream + allocations */
+typedef struct ptx_dbatch ptx_dbatch;    /* a batch resident in HBM */
+typedef struct ptx_dresult ptx_dresult;  /* result buffers resident in HBM */
+
+/* ---- lifecycle ---- */
+uint32_t ptx_abi_version(void);
+/* device_ordinal: HIP device index.  Fails with PTX_ERR_NO_DEVICE when no gfx950 GPU is visible:
+ * there is NO CPU fallback behind this ABI. */
+ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out);
+void ptx_destroy(ptx_ctx* ctx);
+const char* ptx_last_error(const ptx_ctx* ctx); /* ctx may be NULL: last ptx_create failure */
+
+/* ---- the drop-in call: replaces a loop of applyChange(...) + getTextWithFormatting(["text"]) ---- */
+/* Upload `batch` (host pointers), run the merge, download the results, synchronise. */
+ptx_status ptx_apply_materialize(ptx_ctx* ctx, const ptx_batch* batch, ptx_result* out);
+void ptx_result_free(ptx_result* res);
+
+/* ---- staged form (what bench.py and the multi-GPU driver use: inputs resident in HBM) ---- */
+ptx_status ptx_batch_upload(ptx_ctx* ctx, const ptx_batch* host, ptx_dbatch** out);
+/* Build a resident batch made of `copies` back-to-back copies of `host` (distinct HBM addresses,
+ * used to scale a synthetic batch to BASELINE sizes without regenerating it). */
+ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* host, uint32_t copies, ptx_dbatch** out);
+/* Adopt caller-owned DEVICE pointers (e.g. torch tensors' data_ptr); nothing is copied or freed. */
+ptx_status ptx_batch_wrap_device(ptx_ctx* ctx, const ptx_batch* device, ptx_dbatch** out);
+void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b);
+uint32_t ptx_batch_n_logs(const ptx_dbatch* b);
+uint64_t ptx_batch_n_ops(const ptx_dbatch* b);
+
+ptx_status ptx_result_alloc(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult** out);
+void ptx_dresult_free(ptx_ctx* ctx, ptx_dresult* r);
+
+/* Enqueue the merge of every log of `b` on the context's stream (asynchronous). */
+ptx_status ptx_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r);
+/* Same, `iters` times back to back, bracketed by HIP events on the context's stream:
+ * *ms_total = elapsed milliseconds of the `iters` launches (for roofline accounting). */
+ptx_status ptx_merge_timed(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, uint32_t iters, float* ms_total);
+ptx_status ptx_sync(ptx_ctx* ctx);
+
+ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_result* out);
+/* Only the per-log rows (status, counts, digests): [n_logs] ptx_log_result into caller memory. */
+ptx_status ptx_result_download_logs(ptx_ctx* ctx, const ptx_dresult* r, ptx_log_result* out, uint32_t n_logs);
+/* Device address of the per-log result rows (for a collective on the digests); never freed by the caller. */
+const ptx_log_result* ptx_dresult_logs_device(const ptx_dresult* r);
+/* Pack the digests of logs [first, first+count) as 2*count u64 into DEVICE memory `dst`
+ * (e.g. a torch tensor that is then all-gathered with RCCL), on the context's stream. */
+ptx_status ptx_pack_digests(ptx_ctx* ctx, const ptx_dresult* r, uint32_t first, uint32_t count, uint64_t* dst_device);
+
+/* ---- introspection ---- */
+/* Largest number of ops one log may have in this build/device (on-chip working set limit). */
+uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx);
+/* Name of the kernel the merge launches (to find it in a rocprofv3 trace). */
+const char* ptx_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PERITEXT_HIP_H */

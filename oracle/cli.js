@@ -1,0 +1,134 @@
+#!/usr/bin/env node
+"use strict"
+/*
+ * ORACLE CLI — TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Callers: tests/, __graft_entry__.smoke(),
+ * bench.py's cpu_baseline leg.
+ *
+ *   node oracle/cli.js gen   --config mini|config2..5 [--docs D] [--seed S] [--first F] [--ops N] [--replicas R]
+ *                            [--impl oracle|ref] --out FILE
+ *       PTXGEN traces + expected output.  FILE = {config, seed, docs:[{docIndex, seed, actors,
+ *       logs:[Change[] per replica], expected:[{spans, text} per replica]}]}
+ *   node oracle/cli.js apply --in FILE [--impl oracle|ref] --out FILE
+ *       FILE in  = {docs:[{logs:[Change[]...]}]} (e.g. a reference trace or a KAT);  every log is applied
+ *       to a FRESH replica with applyChange (micromerge.ts:499) and flattened (peritext.ts:337).
+ *       FILE out = {docs:[{expected:[{spans, text, error?}]}]}
+ *   node oracle/cli.js time  --in FILE [--impl oracle|ref] [--budget-ms T]
+ *       CPU baseline: time applyChange over every change of every log + getTextWithFormatting, one log
+ *       after another on this core until the budget is spent; prints one JSON line
+ *       {impl, logs, ops, seconds, ops_per_s}.
+ */
+const fs = require("fs")
+const path = require("path")
+const O = require("./peritext_oracle")
+const G = require("./ptxgen")
+
+const argv = process.argv.slice(2)
+const cmd = argv[0]
+const flag = (n, d) => (argv.indexOf(n) >= 0 ? argv[argv.indexOf(n) + 1] : d)
+
+function implClass(name) {
+    if (name === "ref") return require(path.join(__dirname, "_ref", "micromerge.js")).default
+    return O.Micromerge
+}
+function liveChange(change, impl) {
+    /* the reference compares ROOT/HEAD by Symbol identity: translate the portable strings back */
+    if (impl !== "ref") return change
+    const R = require(path.join(__dirname, "_ref", "micromerge.js"))
+    const ops = change.ops.map(op => {
+        const o = Object.assign({}, op)
+        if (o.obj === O.ROOT) o.obj = R.ROOT
+        if (o.elemId === O.HEAD) o.elemId = R.HEAD
+        return o
+    })
+    return Object.assign({}, change, { ops })
+}
+
+function applyLog(Impl, impl, log) {
+    const doc = new Impl("oracle-reader")
+    for (const c of log) doc.applyChange(liveChange(O.normalizeChange(c), impl))
+    return doc
+}
+function expectedOf(doc) {
+    let text = []
+    try {
+        text = (doc.root.text || []).slice()
+    } catch (e) {
+        text = []
+    }
+    let spans
+    try {
+        spans = doc.getTextWithFormatting(["text"])
+    } catch (e) {
+        return { spans: null, text, error: String(e.message) }
+    }
+    return { spans, text }
+}
+
+if (cmd === "gen") {
+    const name = flag("--config", "mini")
+    const cfg = Object.assign({}, G.CONFIGS[name])
+    if (!cfg.mix) throw new Error("unknown config " + name)
+    if (flag("--ops", null)) cfg.opsPerLog = parseInt(flag("--ops"), 10)
+    if (flag("--replicas", null)) cfg.replicas = parseInt(flag("--replicas"), 10)
+    const nDocs = parseInt(flag("--docs", "4"), 10)
+    const first = parseInt(flag("--first", "0"), 10)
+    const seed = parseInt(flag("--seed", "1"), 10)
+    const impl = flag("--impl", "oracle")
+    const Impl = implClass(impl)
+    const out = { config: name, cfg, seed, impl, docs: [] }
+    for (let d = first; d < first + nDocs; d++) {
+        const g = G.generateDoc(id => new Impl(id, { patches: false }), cfg, seed, d)
+        out.docs.push({
+            docIndex: d,
+            seed: g.seed,
+            actors: g.actors,
+            logs: g.logs,
+            expected: g.replicas.map(expectedOf),
+        })
+    }
+    fs.writeFileSync(flag("--out"), JSON.stringify(out))
+} else if (cmd === "apply") {
+    const impl = flag("--impl", "oracle")
+    const Impl = implClass(impl)
+    const input = JSON.parse(fs.readFileSync(flag("--in"), "utf8"))
+    const out = { impl, docs: [] }
+    for (const d of input.docs) {
+        const expected = []
+        for (const log of d.logs) {
+            try {
+                expected.push(expectedOf(applyLog(Impl, impl, log)))
+            } catch (e) {
+                expected.push({ spans: null, text: [], error: (e instanceof RangeError ? "RangeError: " : "Error: ") + e.message })
+            }
+        }
+        out.docs.push({ expected })
+    }
+    fs.writeFileSync(flag("--out"), JSON.stringify(out))
+} else if (cmd === "time") {
+    const impl = flag("--impl", "oracle")
+    const Impl = implClass(impl)
+    const budgetMs = parseFloat(flag("--budget-ms", "10000"))
+    const input = JSON.parse(fs.readFileSync(flag("--in"), "utf8"))
+    let logs = 0
+    let ops = 0
+    const t0 = process.hrtime.bigint()
+    let elapsed = 0
+    outer: for (const d of input.docs) {
+        for (const log of d.logs) {
+            const live = log.map(c => liveChange(O.normalizeChange(c), impl))
+            const s0 = process.hrtime.bigint()
+            const doc = new Impl("oracle-reader")
+            for (const c of live) doc.applyChange(c)
+            doc.getTextWithFormatting(["text"])
+            elapsed += Number(process.hrtime.bigint() - s0) / 1e6
+            logs++
+            for (const c of log) ops += c.ops.length
+            ops -= 1 /* the makeList */
+            if (Number(process.hrtime.bigint() - t0) / 1e6 > budgetMs) break outer
+        }
+    }
+    console.log(JSON.stringify({ impl, logs, ops, seconds: elapsed / 1e3, ops_per_s: ops / (elapsed / 1e3) }))
+} else {
+    console.error("usage: cli.js gen|apply|time ... (see header)")
+    process.exit(2)
+}

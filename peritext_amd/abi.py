@@ -1,0 +1,184 @@
+"""ctypes mirror of include/peritext_hip.h (the C ABI of libperitext_hip.so).
+
+The structures here must stay byte-identical to the header; tests/test_abi.py checks sizes and that
+every symbol the header declares is exported.  There is no CPU fallback: `load_library()` raises if
+the shared object is missing, and `ptx_create` fails when no gfx950 device is visible.
+"""
+import ctypes as C
+import os
+
+PTX_ABI_VERSION = 1
+
+# Operation.action (reference/src/micromerge.ts:150-212, src/peritext.ts:25-65)
+ACT_MAKELIST, ACT_INSERT, ACT_DELETE, ACT_ADDMARK, ACT_REMOVEMARK, ACT_NOP = range(6)
+# markType in ALL_MARKS order (reference/src/schema.ts:125)
+MARK_STRONG, MARK_EM, MARK_COMMENT, MARK_LINK = range(4)
+MARK_NAMES = ["strong", "em", "comment", "link"]
+# BoundaryPosition.type (reference/src/peritext.ts:17-21)
+SIDE_BEFORE, SIDE_AFTER, SIDE_START_OF_TEXT, SIDE_END_OF_TEXT = range(4)
+SIDE_NAMES = ["before", "after", "startOfText", "endOfText"]
+
+ATTR_STRONG = 0x10000000
+ATTR_EM = 0x20000000
+ATTR_LINK = 0x40000000
+ATTR_COMMENT = 0x80000000
+ATTR_ID_MASK = 0x0FFFFFFF
+
+PTX_OK = 0
+ERR_ELEM_NOT_FOUND = 1
+ERR_SEQ_GAP = 2
+ERR_MISSING_DEP = 3
+ERR_DUPLICATE_OP = 4
+ERR_CAPACITY = 5
+ERR_BAD_OP = 6
+ERR_INVALID_ARG = 100
+ERR_HIP = 101
+ERR_NO_DEVICE = 102
+ERR_OOM = 103
+
+STATUS_NAMES = {
+    0: "ok",
+    1: "RangeError: List element not found",
+    2: "RangeError: Expected sequence number",
+    3: "RangeError: Missing dependency",
+    4: "duplicate opId",
+    5: "log exceeds on-chip capacity",
+    6: "malformed op row",
+}
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+
+class ptx_batch(C.Structure):
+    _fields_ = [
+        ("n_logs", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("n_ops", C.c_uint64),
+        ("log_off", u64p),
+        ("op_id", u64p),
+        ("ref_a", u64p),
+        ("ref_b", u64p),
+        ("payload", u32p),
+        ("action", u8p),
+        ("mark_type", u8p),
+        ("side_a", u8p),
+        ("side_b", u8p),
+        ("chg_off", u64p),
+        ("chg_actor", u32p),
+        ("chg_seq", u32p),
+        ("chg_nops", u32p),
+        ("chg_deps", u32p),
+        ("max_actors", C.c_uint32),
+        ("reserved2", C.c_uint32),
+    ]
+
+
+class ptx_span(C.Structure):
+    _fields_ = [("start", C.c_uint32), ("attr", C.c_uint32)]
+
+
+class ptx_cinterval(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("start", C.c_uint32), ("end", C.c_uint32)]
+
+
+class ptx_log_result(C.Structure):
+    _fields_ = [
+        ("status", C.c_uint32),
+        ("n_ops", C.c_uint32),
+        ("n_elems", C.c_uint32),
+        ("n_visible", C.c_uint32),
+        ("n_spans", C.c_uint32),
+        ("n_cintervals", C.c_uint32),
+        ("reserved", C.c_uint32 * 2),
+        ("digest", C.c_uint64 * 2),
+    ]
+
+
+class ptx_result(C.Structure):
+    _fields_ = [
+        ("n_logs", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("n_rows", C.c_uint64),
+        ("logs", C.POINTER(ptx_log_result)),
+        ("values", u32p),
+        ("spans", C.POINTER(ptx_span)),
+        ("cintervals", C.POINTER(ptx_cinterval)),
+        ("elem_rank", u32p),
+        ("owner", C.c_void_p),
+    ]
+
+
+# numpy dtypes with the same layout
+import numpy as np  # noqa: E402
+
+LOG_RESULT_DTYPE = np.dtype(
+    [
+        ("status", "<u4"),
+        ("n_ops", "<u4"),
+        ("n_elems", "<u4"),
+        ("n_visible", "<u4"),
+        ("n_spans", "<u4"),
+        ("n_cintervals", "<u4"),
+        ("reserved", "<u4", (2,)),
+        ("digest", "<u8", (2,)),
+    ]
+)
+SPAN_DTYPE = np.dtype([("start", "<u4"), ("attr", "<u4")])
+CINTERVAL_DTYPE = np.dtype([("id", "<u4"), ("start", "<u4"), ("end", "<u4")])
+
+# every function include/peritext_hip.h declares: name -> (restype, argtypes)
+vp = C.c_void_p
+FUNCTIONS = {
+    "ptx_abi_version": (C.c_uint32, []),
+    "ptx_create": (C.c_int32, [C.c_int, C.c_uint32, C.POINTER(vp)]),
+    "ptx_destroy": (None, [vp]),
+    "ptx_last_error": (C.c_char_p, [vp]),
+    "ptx_apply_materialize": (C.c_int32, [vp, C.POINTER(ptx_batch), C.POINTER(ptx_result)]),
+    "ptx_result_free": (None, [C.POINTER(ptx_result)]),
+    "ptx_batch_upload": (C.c_int32, [vp, C.POINTER(ptx_batch), C.POINTER(vp)]),
+    "ptx_batch_upload_tiled": (C.c_int32, [vp, C.POINTER(ptx_batch), C.c_uint32, C.POINTER(vp)]),
+    "ptx_batch_wrap_device": (C.c_int32, [vp, C.POINTER(ptx_batch), C.POINTER(vp)]),
+    "ptx_batch_free": (None, [vp, vp]),
+    "ptx_batch_n_logs": (C.c_uint32, [vp]),
+    "ptx_batch_n_ops": (C.c_uint64, [vp]),
+    "ptx_result_alloc": (C.c_int32, [vp, vp, C.POINTER(vp)]),
+    "ptx_dresult_free": (None, [vp, vp]),
+    "ptx_merge": (C.c_int32, [vp, vp, vp]),
+    "ptx_merge_timed": (C.c_int32, [vp, vp, vp, C.c_uint32, C.POINTER(C.c_float)]),
+    "ptx_sync": (C.c_int32, [vp]),
+    "ptx_result_download": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_result)]),
+    "ptx_result_download_logs": (C.c_int32, [vp, vp, C.POINTER(ptx_log_result), C.c_uint32]),
+    "ptx_dresult_logs_device": (vp, [vp]),
+    "ptx_pack_digests": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "ptx_max_ops_per_log": (C.c_uint32, [vp]),
+    "ptx_kernel_name": (C.c_char_p, []),
+}
+
+LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libperitext_hip.so")
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libperitext_hip.so and type every export.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "peritext_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback for the merge path" % p
+        )
+    lib = C.CDLL(p)
+    for name, (res, args) in FUNCTIONS.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ptx_abi_version() != PTX_ABI_VERSION:
+        raise RuntimeError("peritext_amd: ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib

@@ -1,0 +1,254 @@
+"""Host-side wire codec: Peritext `Change` JSON  <->  the SoA op-log batch of include/peritext_hip.h.
+
+Input side mirrors the reference's types (reference/src/micromerge.ts:60-71 `Change`, :204-212
+`Operation`; src/peritext.ts:17-65 boundary positions and mark ops): a *replica log* is the list of
+`Change` objects one replica applied, in application order — exactly what a loop of
+`doc.applyChange(change)` (micromerge.ts:499) would be fed.  Output side rebuilds what
+`doc.getTextWithFormatting(["text"])` (micromerge.ts:516) returns: `FormatSpanWithText[]`.
+
+Encoding rules the wrapper owns:
+  * actor strings -> rank in UTF-16 code-unit order within the doc, so that integer order of
+    (counter << 32 | rank) equals compareOpIds (micromerge.ts:812-827, JS string `<`);
+  * ROOT / HEAD -> 0 (JSON drops the reference's Symbols: a `makeList` without `obj`, an inserting
+    `set` without `elemId`; the strings "_root"/"_head" are accepted too);
+  * inserted values (arbitrary strings, e.g. " is great!" at test/micromerge.ts:202) -> ids in one
+    batch-wide string table; link urls -> ids in one batch-wide table;
+  * comment ids -> DOC-LOCAL dense ranks in code-unit order (peritext.ts:318 keeps arrays id-sorted).
+"""
+import re
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import abi
+
+_ID_RE = re.compile(r"^([0-9]+)@(.*)$", re.S)
+ROOT = "_root"
+HEAD = "_head"
+
+
+def _u16key(s):
+    """Sort key reproducing JS string comparison (UTF-16 code units)."""
+    return s.encode("utf-16-be", "surrogatepass")
+
+
+def split_op_id(op_id):
+    m = _ID_RE.match(op_id)
+    if not m:
+        raise ValueError("Invalid operation ID: %r" % (op_id,))
+    return int(m.group(1)), m.group(2)
+
+
+@dataclass
+class Batch:
+    """A batch of replica logs in wire form plus the tables needed to decode the results."""
+
+    log_off: np.ndarray
+    op_id: np.ndarray
+    ref_a: np.ndarray
+    ref_b: np.ndarray
+    payload: np.ndarray
+    action: np.ndarray
+    mark_type: np.ndarray
+    side_a: np.ndarray
+    side_b: np.ndarray
+    # causal envelope (one row per Change)
+    chg_off: np.ndarray
+    chg_actor: np.ndarray
+    chg_seq: np.ndarray
+    chg_nops: np.ndarray
+    chg_deps: np.ndarray
+    max_actors: int
+    # decode tables
+    values: list = field(default_factory=list)  # value id -> string
+    urls: list = field(default_factory=list)  # url id -> string
+    log_doc: list = field(default_factory=list)  # log index -> doc index
+    doc_actors: list = field(default_factory=list)  # doc -> [actor strings in rank order]
+    doc_comments: list = field(default_factory=list)  # doc -> [comment id strings in rank order]
+
+    @property
+    def n_logs(self):
+        return len(self.log_off) - 1
+
+    @property
+    def n_ops(self):
+        return int(self.log_off[-1])
+
+    def counted_ops(self, log=None):
+        """Ops the metric counts: everything except makeList / NOP rows."""
+        a = self.action if log is None else self.action[int(self.log_off[log]) : int(self.log_off[log + 1])]
+        return int(np.count_nonzero((a != abi.ACT_MAKELIST) & (a != abi.ACT_NOP)))
+
+    def tile(self, copies):
+        """`copies` back-to-back copies of this batch (same content, distinct rows)."""
+        n = self.n_ops
+        offs = [self.log_off[:-1] + k * n for k in range(copies)]
+        log_off = np.concatenate(offs + [np.array([copies * n], dtype=np.uint64)]).astype(np.uint64)
+        nc = int(self.chg_off[-1])
+        chg_off = np.concatenate([self.chg_off[:-1] + k * nc for k in range(copies)] + [np.array([copies * nc], dtype=np.uint64)]).astype(np.uint64)
+        rep = lambda a: np.tile(a, copies)  # noqa: E731
+        return Batch(
+            log_off, rep(self.op_id), rep(self.ref_a), rep(self.ref_b), rep(self.payload), rep(self.action),
+            rep(self.mark_type), rep(self.side_a), rep(self.side_b), chg_off, rep(self.chg_actor), rep(self.chg_seq),
+            rep(self.chg_nops), rep(self.chg_deps), self.max_actors, self.values, self.urls,
+            self.log_doc * copies, self.doc_actors, self.doc_comments,
+        )
+
+
+def _pack(ctr, rank):
+    return (int(ctr) << 32) | int(rank)
+
+
+def encode_docs(docs):
+    """docs: list of docs; a doc is a list of replica logs; a replica log is a list of Change dicts.
+
+    All replicas of a doc share actor ranks and comment-id ranks, so their digests are comparable.
+    """
+    values, value_ix = [], {}
+    urls, url_ix = [], {}
+    cols = {k: [] for k in ("op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b")}
+    log_off = [0]
+    chg_off = [0]
+    chg_actor, chg_seq, chg_nops, chg_deps_rows = [], [], [], []
+    log_doc, doc_actors, doc_comments = [], [], []
+    max_actors = 1
+    for d, logs in enumerate(docs):
+        actors, comments = set(), set()
+        for log in logs:
+            for ch in log:
+                actors.add(ch["actor"])
+                for a in (ch.get("deps") or {}):
+                    actors.add(a)
+                for op in ch["ops"]:
+                    actors.add(split_op_id(op["opId"])[1])
+                    if op.get("markType") == "comment":
+                        comments.add(op["attrs"]["id"])
+        actor_list = sorted(actors, key=_u16key)
+        arank = {a: i for i, a in enumerate(actor_list)}
+        comment_list = sorted(comments, key=_u16key)
+        crank = {c: i for i, c in enumerate(comment_list)}
+        doc_actors.append(actor_list)
+        doc_comments.append(comment_list)
+        max_actors = max(max_actors, len(actor_list))
+
+        def enc_id(s):
+            if s is None or s == HEAD or s == ROOT:
+                return 0
+            ctr, actor = split_op_id(s)
+            return _pack(ctr, arank[actor])
+
+        for log in logs:
+            text_obj = None
+            nrows = 0
+            for ch in log:
+                chg_actor.append(arank[ch["actor"]])
+                chg_seq.append(int(ch["seq"]))
+                chg_nops.append(len(ch["ops"]))
+                chg_deps_rows.append({arank[a]: int(v) for a, v in (ch.get("deps") or {}).items()})
+                for op in ch["ops"]:
+                    act = op["action"]
+                    row = dict(op_id=enc_id(op["opId"]), ref_a=0, ref_b=0, payload=0, action=abi.ACT_NOP, mark_type=0, side_a=0, side_b=0)
+                    obj = op.get("obj")
+                    on_root = obj is None or obj == ROOT
+                    if act == "makeList" and on_root and op.get("key") == "text" and text_obj is None:
+                        row["action"] = abi.ACT_MAKELIST
+                        text_obj = op["opId"]
+                    elif text_obj is not None and obj == text_obj:
+                        if act == "set" and op.get("insert"):
+                            v = op["value"]
+                            if not isinstance(v, str):
+                                raise ValueError("Expected value inserted into text to be a string")
+                            if v not in value_ix:
+                                value_ix[v] = len(values)
+                                values.append(v)
+                            row.update(action=abi.ACT_INSERT, ref_a=enc_id(op.get("elemId")), payload=value_ix[v])
+                        elif act == "del" and "elemId" in op:
+                            row.update(action=abi.ACT_DELETE, ref_a=enc_id(op["elemId"]))
+                        elif act in ("addMark", "removeMark"):
+                            mt = abi.MARK_NAMES.index(op["markType"])
+                            st, en = op["start"], op["end"]
+                            row.update(
+                                action=abi.ACT_ADDMARK if act == "addMark" else abi.ACT_REMOVEMARK,
+                                mark_type=mt,
+                                side_a=abi.SIDE_NAMES.index(st["type"]),
+                                side_b=abi.SIDE_NAMES.index(en["type"]),
+                                ref_a=enc_id(st.get("elemId")),
+                                ref_b=enc_id(en.get("elemId")),
+                            )
+                            if mt == abi.MARK_LINK and act == "addMark":
+                                u = op["attrs"]["url"]
+                                if u not in url_ix:
+                                    url_ix[u] = len(urls)
+                                    urls.append(u)
+                                row["payload"] = url_ix[u]
+                            elif mt == abi.MARK_COMMENT:
+                                row["payload"] = crank[op["attrs"]["id"]]
+                    for k, v in row.items():
+                        cols[k].append(v)
+                    nrows += 1
+            log_off.append(log_off[-1] + nrows)
+            chg_off.append(len(chg_actor))
+            log_doc.append(d)
+    deps = np.zeros((len(chg_actor), max_actors), dtype=np.uint32)
+    for i, row in enumerate(chg_deps_rows):
+        for a, v in row.items():
+            deps[i, a] = v
+    u64 = lambda x: np.asarray(x, dtype=np.uint64)  # noqa: E731
+    return Batch(
+        log_off=u64(log_off), op_id=u64(cols["op_id"]), ref_a=u64(cols["ref_a"]), ref_b=u64(cols["ref_b"]),
+        payload=np.asarray(cols["payload"], dtype=np.uint32), action=np.asarray(cols["action"], dtype=np.uint8),
+        mark_type=np.asarray(cols["mark_type"], dtype=np.uint8), side_a=np.asarray(cols["side_a"], dtype=np.uint8),
+        side_b=np.asarray(cols["side_b"], dtype=np.uint8), chg_off=u64(chg_off),
+        chg_actor=np.asarray(chg_actor, dtype=np.uint32), chg_seq=np.asarray(chg_seq, dtype=np.uint32),
+        chg_nops=np.asarray(chg_nops, dtype=np.uint32), chg_deps=deps.reshape(-1), max_actors=max_actors,
+        values=values, urls=urls, log_doc=log_doc, doc_actors=doc_actors, doc_comments=doc_comments,
+    )
+
+
+@dataclass
+class Results:
+    """Host view of a merge result: numpy arrays, row r of log l at log_off[l] + r."""
+
+    logs: np.ndarray  # LOG_RESULT_DTYPE [n_logs]
+    values: np.ndarray  # u32 [n_rows]
+    spans: np.ndarray  # SPAN_DTYPE [n_rows]
+    cintervals: np.ndarray  # CINTERVAL_DTYPE [n_rows]
+    elem_rank: np.ndarray  # u32 [n_rows]
+
+
+def canonical_of_log(batch, res, log):
+    """(values u32[], spans [(start, attr)], cintervals [(id, s, e)]) of one log, as plain arrays."""
+    b = int(batch.log_off[log])
+    r = res.logs[log]
+    v = res.values[b : b + int(r["n_visible"])]
+    s = res.spans[b : b + int(r["n_spans"])]
+    c = res.cintervals[b : b + int(r["n_cintervals"])]
+    return v, s, c
+
+
+def decode_spans(batch, res, log):
+    """FormatSpanWithText[] of one log, i.e. what getTextWithFormatting(["text"]) returns
+    (reference/src/peritext.ts:35-38, :135-137).  Raises RangeError-like ValueError on a failed log."""
+    r = res.logs[log]
+    if int(r["status"]) != 0:
+        raise ValueError(abi.STATUS_NAMES.get(int(r["status"]), "error %d" % int(r["status"])))
+    v, s, c = canonical_of_log(batch, res, log)
+    comments = batch.doc_comments[batch.log_doc[log]]
+    out = []
+    n_vis = len(v)
+    for k in range(len(s)):
+        start = int(s[k]["start"])
+        end = int(s[k + 1]["start"]) if k + 1 < len(s) else n_vis
+        attr = int(s[k]["attr"])
+        marks = {}
+        if attr & abi.ATTR_STRONG:
+            marks["strong"] = {"active": True}
+        if attr & abi.ATTR_EM:
+            marks["em"] = {"active": True}
+        if attr & abi.ATTR_COMMENT:
+            ids = [int(ci["id"]) for ci in c if int(ci["start"]) <= start < int(ci["end"])]
+            marks["comment"] = [{"id": comments[i]} for i in sorted(ids)]
+        if attr & abi.ATTR_LINK:
+            marks["link"] = {"url": batch.urls[attr & abi.ATTR_ID_MASK]}
+        out.append({"text": "".join(batch.values[int(x)] for x in v[start:end]), "marks": marks})
+    return out

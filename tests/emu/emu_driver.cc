@@ -1,0 +1,44 @@
+/*
+ * Host emulation of the merge kernel's logic — TEST TOOLING ONLY (see merge_core.h header).
+ *
+ * Compiles peritext_amd/csrc/merge_core.h with -DPTX_EMU: every PTX_FOR becomes a sequential loop
+ * (optionally reversed, to expose any dependence on iteration order), barriers vanish, atomics are
+ * plain read-modify-writes.  Built into tests/emu/libperitext_emu.so by __graft_entry__.build() and
+ * loaded ONLY by the CPU test-suite (tests/test_emu_*.py).  It is deliberately NOT part of
+ * libperitext_hip.so and exports nothing the product ABI declares.
+ */
+#define PTX_EMU 1
+#include <stdlib.h>
+#include <string.h>
+int ptx_emu_reverse = 0;
+#include "../../peritext_amd/csrc/merge_core.h"
+
+extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans,
+                             ptx_cinterval* cints, uint32_t* rank, uint32_t lds_bytes, int reverse) {
+    PtxMergeArgs A;
+    A.log_off = b->log_off;
+    A.op_id = b->op_id;
+    A.ref_a = b->ref_a;
+    A.ref_b = b->ref_b;
+    A.payload = b->payload;
+    A.action = b->action;
+    A.mark_type = b->mark_type;
+    A.side_a = b->side_a;
+    A.side_b = b->side_b;
+    A.res = res;
+    A.out_values = values;
+    A.out_spans = spans;
+    A.out_cints = cints;
+    A.out_rank = rank;
+    A.n_logs = b->n_logs;
+    A.lds_bytes = lds_bytes;
+    uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)lds_bytes + 64);
+    if (!lds) return 1;
+    ptx_emu_reverse = reverse;
+    for (uint32_t l = 0; l < b->n_logs; ++l) {
+        memset(lds, 0xA5, lds_bytes); /* LDS is not zero-initialised on the GPU either */
+        ptx_merge_log(A, l, lds);
+    }
+    free(lds);
+    return 0;
+}

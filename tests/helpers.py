@@ -1,0 +1,148 @@
+"""Shared test plumbing: oracle invocation (node), the host emulation of the kernel logic, comparison."""
+import ctypes as C
+import functools
+import json
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+
+from peritext_amd import abi, canon, wire
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+NODE = shutil.which("node")
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libperitext_emu.so")
+LDS_BYTES = 160 * 1024
+
+
+def have_node():
+    return NODE is not None
+
+
+def run_node(args, timeout=600):
+    p = subprocess.run([NODE] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    if p.returncode != 0:
+        raise RuntimeError("node %s failed:\n%s\n%s" % (" ".join(args), p.stdout[-2000:], p.stderr[-2000:]))
+    return p.stdout
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_gen(config="mini", docs=4, seed=1, ops=None, replicas=None, first=0, impl="oracle"):
+    """PTXGEN traces + expected output from the oracle (or the erased reference with impl='ref')."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "gen.json")
+        args = ["oracle/cli.js", "gen", "--config", config, "--docs", str(docs), "--seed", str(seed), "--first", str(first), "--impl", impl, "--out", out]
+        if ops is not None:
+            args += ["--ops", str(ops)]
+        if replicas is not None:
+            args += ["--replicas", str(replicas)]
+        run_node(args)
+        with open(out) as f:
+            return json.load(f)
+
+
+def oracle_apply(docs_logs, impl="oracle"):
+    """Apply every log of every doc to a fresh oracle replica; returns [[{spans,text,error?}]]."""
+    with tempfile.TemporaryDirectory() as td:
+        inp, out = os.path.join(td, "in.json"), os.path.join(td, "out.json")
+        with open(inp, "w") as f:
+            json.dump({"docs": [{"logs": logs} for logs in docs_logs]}, f)
+        run_node(["oracle/cli.js", "apply", "--in", inp, "--impl", impl, "--out", out])
+        with open(out) as f:
+            return [d["expected"] for d in json.load(f)["docs"]]
+
+
+def batch_struct(b):
+    """ctypes ptx_batch pointing into the numpy columns of a wire.Batch (keep `b` alive)."""
+    s = abi.ptx_batch()
+    s.n_logs = b.n_logs
+    s.n_ops = b.n_ops
+    ptr = lambda a, t: a.ctypes.data_as(t)  # noqa: E731
+    s.log_off = ptr(b.log_off, abi.u64p)
+    s.op_id = ptr(b.op_id, abi.u64p)
+    s.ref_a = ptr(b.ref_a, abi.u64p)
+    s.ref_b = ptr(b.ref_b, abi.u64p)
+    s.payload = ptr(b.payload, abi.u32p)
+    s.action = ptr(b.action, abi.u8p)
+    s.mark_type = ptr(b.mark_type, abi.u8p)
+    s.side_a = ptr(b.side_a, abi.u8p)
+    s.side_b = ptr(b.side_b, abi.u8p)
+    s.chg_off = ptr(b.chg_off, abi.u64p)
+    s.chg_actor = ptr(b.chg_actor, abi.u32p)
+    s.chg_seq = ptr(b.chg_seq, abi.u32p)
+    s.chg_nops = ptr(b.chg_nops, abi.u32p)
+    s.chg_deps = ptr(b.chg_deps, abi.u32p)
+    s.max_actors = b.max_actors
+    return s
+
+
+@functools.lru_cache(maxsize=None)
+def _emu(path):
+    lib = C.CDLL(path)
+    lib.ptx_emu_merge.restype = C.c_int
+    lib.ptx_emu_merge.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    return lib
+
+
+def emu_merge(b, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB):
+    """Run the host emulation of the kernel logic (tests only) over a wire.Batch."""
+    n = max(b.n_ops, 1)
+    res = wire.Results(
+        logs=np.zeros(b.n_logs, dtype=abi.LOG_RESULT_DTYPE),
+        values=np.full(n, 0xDEADBEEF, dtype=np.uint32),
+        spans=np.zeros(n, dtype=abi.SPAN_DTYPE),
+        cintervals=np.zeros(n, dtype=abi.CINTERVAL_DTYPE),
+        elem_rank=np.zeros(n, dtype=np.uint32),
+    )
+    s = batch_struct(b)
+    rc = _emu(lib_path).ptx_emu_merge(
+        C.byref(s), res.logs.ctypes.data, res.values.ctypes.data, res.spans.ctypes.data, res.cintervals.ctypes.data,
+        res.elem_rank.ctypes.data, lds_bytes, reverse,
+    )
+    assert rc == 0
+    return res
+
+
+def norm_spans(spans):
+    """Order-insensitive form of FormatSpanWithText[] (deepStrictEqual ignores key order)."""
+    return [{"text": s["text"], "marks": json.loads(json.dumps(s["marks"], sort_keys=True))} for s in spans]
+
+
+def check_log(batch, res, log, expected):
+    """One log of a result against the oracle's {spans, text}: decoded JSON, raw canonical arrays, digest."""
+    r = res.logs[log]
+    assert int(r["status"]) == 0, "log %d status %d" % (log, int(r["status"]))
+    got = wire.decode_spans(batch, res, log)
+    assert norm_spans(got) == norm_spans(expected["spans"]), "log %d spans differ" % log
+    d = batch.log_doc[log]
+    value_ix = {v: i for i, v in enumerate(batch.values)}
+    url_ix = {u: i for i, u in enumerate(batch.urls)}
+    crank = {c: i for i, c in enumerate(batch.doc_comments[d])}
+    ev, es, ec = canon.canonical_from_spans(expected["spans"], expected["text"], value_ix, url_ix, crank)
+    v, s, c = wire.canonical_of_log(batch, res, log)
+    assert list(map(int, v)) == ev, "log %d values differ" % log
+    assert [(int(x["start"]), int(x["attr"])) for x in s] == es, "log %d span rows differ" % log
+    assert [(int(x["id"]), int(x["start"]), int(x["end"])) for x in c] == ec, "log %d comment intervals differ" % log
+    h = canon.digest(ev, es, ec, int(r["n_elems"]))
+    assert (int(r["digest"][0]), int(r["digest"][1])) == h, "log %d digest differs" % log
+
+
+def check_generated(gen, res_fn):
+    """Encode an oracle_gen() result, run `res_fn(batch)`, compare every replica log."""
+    docs = [d["logs"] for d in gen["docs"]]
+    batch = wire.encode_docs(docs)
+    res = res_fn(batch)
+    log = 0
+    for d in gen["docs"]:
+        for r, exp in enumerate(d["expected"]):
+            check_log(batch, res, log, exp)
+            log += 1
+    return batch, res
+
+
+def load_kat():
+    with open(os.path.join(GOLDEN, "kat_reference_tests.json")) as f:
+        return json.load(f)["cases"]
