@@ -45,6 +45,9 @@ const CONFIGS = {
     config3: { replicas: 1, opsPerLog: 1024, mix: [40, 20, 25, 15], markTypes: ["strong", "em"] },
     config4: { replicas: 3, opsPerLog: 4096, mix: [25, 25, 25, 25], markTypes: ["strong", "em", "link", "comment"] },
     config5: { replicas: 1, opsPerLog: 8192, mix: [20, 50, 20, 10], markTypes: ["link", "comment"] },
+    /* insert-heavy, all mark types: documents GROW (hundreds of visible chars, many overlapping marks
+       and comments) — stresses the mark sweep, which the tombstone-heavy BASELINE mixes barely touch */
+    rich: { replicas: 3, opsPerLog: 1024, mix: [55, 10, 20, 15], markTypes: ["strong", "em", "link", "comment"] },
     /* small all-features case used by unit tests and differential fuzzing */
     mini: { replicas: 3, opsPerLog: 96, mix: [25, 25, 25, 25], markTypes: ["strong", "em", "link", "comment"] },
 }

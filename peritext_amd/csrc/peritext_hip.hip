@@ -1,0 +1,541 @@
+/*
+ * peritext_hip.hip — gfx950 kernels + the C ABI of include/peritext_hip.h (libperitext_hip.so).
+ *
+ * Kernel: ptx_merge_kernel — ONE workgroup per replica-log; the whole log lives in LDS while the
+ * causal tree, tombstone scan, mark sweep and span RLE run (merge_core.h).  HBM traffic is the
+ * compulsory one: 32 B/op read once, outputs written once.  No MFMA: this is integer/indexing work
+ * bounded by LDS latency and HBM bandwidth.
+ *
+ * Host side: a context owns one HIP stream and its allocations; batches and results are explicit
+ * device-resident objects so that a benchmark can keep the op log in HBM and time only the merge.
+ * There is no CPU path in this library: without a gfx950 device ptx_create fails.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "merge_core.h"
+
+/* ------------------------------------------------------------------------------------------------ */
+/* kernels                                                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+
+extern "C" __global__ void __launch_bounds__(1024) ptx_merge_kernel(PtxMergeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
+    /* grid-stride over logs: the launch may cap the grid */
+    for (uint32_t log = blockIdx.x; log < A.n_logs; log += gridDim.x) {
+        ptx_merge_log(A, log, ptx_lds);
+        __syncthreads(); /* LDS is reused by the next log */
+    }
+}
+
+__global__ void ptx_pack_digests_kernel(const ptx_log_result* res, uint32_t first, uint32_t count, uint64_t* dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        dst[2 * i] = res[first + i].digest[0];
+        dst[2 * i + 1] = res[first + i].digest[1];
+    }
+}
+
+/* log_off of a tiled batch: copy k of log l starts at k * n_ops + log_off[l] */
+__global__ void ptx_tile_offsets_kernel(const uint64_t* src, uint64_t* dst, uint32_t n_logs, uint32_t copies, uint64_t n_ops) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = (uint64_t)n_logs * copies;
+    if (i < total) dst[i] = (i / n_logs) * n_ops + src[i % n_logs];
+    if (i == total) dst[i] = (uint64_t)copies * n_ops;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* host objects                                                                                     */
+/* ------------------------------------------------------------------------------------------------ */
+
+struct ptx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    int cu_count = 0;
+    size_t max_lds = 0;
+    int force_threads = 0; /* PTX_THREADS env override (tuning) */
+    int force_lds = 0;     /* PTX_LDS_BYTES env override (tuning) */
+};
+
+struct ptx_dbatch {
+    uint32_t n_logs = 0;
+    uint64_t n_ops = 0;
+    bool owns = true;
+    uint64_t *log_off = nullptr, *op_id = nullptr, *ref_a = nullptr, *ref_b = nullptr;
+    uint32_t* payload = nullptr;
+    uint8_t *action = nullptr, *mark_type = nullptr, *side_a = nullptr, *side_b = nullptr;
+    /* launch shape derived from the largest log */
+    uint32_t max_log_ops = 0;
+    uint32_t lds_bytes = 0;
+    uint32_t threads = 0;
+};
+
+struct ptx_dresult {
+    uint32_t n_logs = 0;
+    uint64_t n_rows = 0;
+    ptx_log_result* logs = nullptr;
+    uint32_t* values = nullptr;
+    ptx_span* spans = nullptr;
+    ptx_cinterval* cints = nullptr;
+    uint32_t* rank = nullptr;
+};
+
+static std::string g_create_err;
+
+static ptx_status fail(ptx_ctx* ctx, ptx_status st, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_err = msg;
+    return st;
+}
+
+#define PTX_HIP(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t _e = (call);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            return fail(ctx, _e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP,                 \
+                        std::string(#call) + ": " + hipGetErrorString(_e));                         \
+        }                                                                                           \
+    } while (0)
+
+/* Upper bound of the LDS working set of merge_core.h for a log with N rows, n inserts, K mark ops,
+ * Kc comment ops and an id keyspace of `ks` bits (mirrors the ptx_alloc calls there). */
+static uint64_t a16(uint64_t x) { return (x + 15) & ~15ull; }
+static uint64_t lds_need(uint64_t N, uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks) {
+    const uint64_t nw = (ks + 31) / 32;
+    uint64_t persist = a16(sizeof(PtxHdr)) + a16(N) + a16(2 * N) + a16(4 * ((N + 31) / 32 + 1)) + a16(2 * N) + a16(4 * (nw + 1)) + a16(2 * (nw + 1));
+    const uint64_t M = (N + 2) & ~1ull;
+    const uint64_t tree_phase = 3 * a16(2 * M) + a16(8 * M);
+    const uint64_t V = n; /* bound: every element visible */
+    uint64_t P2V = 1;
+    while (P2V < V) P2V <<= 1;
+    const uint64_t nwv = n / 32 + 1, nwq = V / 32 + 1;
+    uint64_t mark_phase = a16(4 * (nwv + 1)) + a16(2 * (nwv + 1)) + 4 * a16(2 * (K + 1)) + a16(8 * P2V) + a16(4 * (V + 1)) +
+                          2 * a16(4 * (nwq + 1)) + a16(2 * (nwq + 1));
+    if (Kc) mark_phase += 3 * a16(4 * (Kc + 1)) + a16(8 * (Kc + 1));
+    return persist + std::max(tree_phase, mark_phase);
+}
+
+static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t max_log_ops) {
+    b->max_log_ops = max_log_ops;
+    uint64_t lds = std::min<uint64_t>(std::max<uint64_t>(need, 4096), ctx->max_lds);
+    if (ctx->force_lds) lds = (uint64_t)ctx->force_lds;
+    b->lds_bytes = (uint32_t)lds;
+    uint32_t t = max_log_ops <= 1024 ? 256u : max_log_ops <= 2304 ? 512u : 1024u;
+    if (ctx->force_threads) t = (uint32_t)ctx->force_threads;
+    b->threads = t;
+}
+
+/* scan the host columns once: per-log counts -> exact LDS requirement of the batch */
+static uint64_t scan_host_batch(const ptx_batch* h, uint32_t* max_log_ops) {
+    uint64_t need = 0;
+    uint32_t mx = 0;
+    for (uint32_t l = 0; l < h->n_logs; ++l) {
+        const uint64_t b0 = h->log_off[l], b1 = h->log_off[l + 1];
+        uint64_t n = 0, K = 0, Kc = 0;
+        uint32_t mc = 0, ma = 0;
+        for (uint64_t i = b0; i < b1; ++i) {
+            const uint8_t a = h->action[i];
+            if (a == PTX_ACT_INSERT) n++;
+            else if (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) {
+                K++;
+                if (h->mark_type[i] == PTX_MARK_COMMENT) Kc++;
+            }
+            mc = std::max(mc, (uint32_t)(h->op_id[i] >> 32));
+            ma = std::max(ma, (uint32_t)h->op_id[i]);
+        }
+        uint32_t abits = 0;
+        while ((1u << abits) < ma + 1u) ++abits;
+        const uint64_t ks = ((uint64_t)mc + 1) << std::min(abits, 12u);
+        need = std::max(need, lds_need(b1 - b0, n, K, Kc, ks));
+        mx = std::max<uint32_t>(mx, (uint32_t)std::min<uint64_t>(b1 - b0, 0xFFFFFFFFull));
+    }
+    *max_log_ops = mx;
+    return need;
+}
+
+static ptx_status check_batch(ptx_ctx* ctx, const ptx_batch* h) {
+    if (!h) return fail(ctx, PTX_ERR_INVALID_ARG, "batch is NULL");
+    if (h->n_logs && !h->log_off) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off is NULL");
+    if (h->n_ops && (!h->op_id || !h->ref_a || !h->ref_b || !h->payload || !h->action || !h->mark_type || !h->side_a || !h->side_b))
+        return fail(ctx, PTX_ERR_INVALID_ARG, "an op column is NULL");
+    return PTX_OK;
+}
+
+template <class T>
+static hipError_t dalloc(T** p, uint64_t count) {
+    return hipMalloc((void**)p, std::max<uint64_t>(count, 1) * sizeof(T));
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* C ABI                                                                                            */
+/* ------------------------------------------------------------------------------------------------ */
+
+extern "C" {
+
+uint32_t ptx_abi_version(void) { return PTX_ABI_VERSION; }
+
+const char* ptx_kernel_name(void) { return "ptx_merge_kernel"; }
+
+const char* ptx_last_error(const ptx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
+    (void)flags;
+    if (!out) return fail(nullptr, PTX_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, PTX_ERR_NO_DEVICE, std::string("no HIP device visible (") + hipGetErrorString(e) + "); this library has no CPU fallback");
+    if (device_ordinal < 0 || device_ordinal >= count) return fail(nullptr, PTX_ERR_INVALID_ARG, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return fail(nullptr, PTX_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PTX_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only");
+    ptx_ctx* ctx = new ptx_ctx();
+    ctx->device = device_ordinal;
+    ctx->cu_count = prop.multiProcessorCount;
+    ctx->max_lds = 160 * 1024;
+    if (const char* s = getenv("PTX_THREADS")) ctx->force_threads = atoi(s);
+    if (const char* s = getenv("PTX_LDS_BYTES")) ctx->force_lds = atoi(s);
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, PTX_ERR_HIP, "stream/event creation failed");
+    }
+    /* one workgroup may use the CU's whole 160 KiB of LDS */
+    e = hipFuncSetAttribute((const void*)ptx_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
+    if (e != hipSuccess) {
+        std::string m = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e);
+        delete ctx;
+        return fail(nullptr, PTX_ERR_HIP, m);
+    }
+    *out = ctx;
+    return PTX_OK;
+}
+
+void ptx_destroy(ptx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx) {
+    /* largest N with lds_need(N, worst split) <= LDS; conservative closed form: ~33 B per row */
+    const uint64_t lds = ctx ? ctx->max_lds : 160 * 1024;
+    uint32_t lo = 0, hi = 65534;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) / 2;
+        const uint64_t worst = std::max(lds_need(mid, mid, 0, 0, 4ull * mid), lds_need(mid, mid / 2, mid / 2, mid / 2, 4ull * mid));
+        if (worst <= lds) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
+    if (!b) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (b->owns) {
+        (void)hipFree(b->log_off);
+        (void)hipFree(b->op_id);
+        (void)hipFree(b->ref_a);
+        (void)hipFree(b->ref_b);
+        (void)hipFree(b->payload);
+        (void)hipFree(b->action);
+        (void)hipFree(b->mark_type);
+        (void)hipFree(b->side_a);
+        (void)hipFree(b->side_b);
+    }
+    delete b;
+}
+
+uint32_t ptx_batch_n_logs(const ptx_dbatch* b) { return b ? b->n_logs : 0; }
+uint64_t ptx_batch_n_ops(const ptx_dbatch* b) { return b ? b->n_ops : 0; }
+
+ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t copies, ptx_dbatch** out) {
+    if (!ctx || !out) return PTX_ERR_INVALID_ARG;
+    *out = nullptr;
+    ptx_status st = check_batch(ctx, h);
+    if (st) return st;
+    if (copies == 0) return fail(ctx, PTX_ERR_INVALID_ARG, "copies must be >= 1");
+    if (h->n_logs && h->log_off[h->n_logs] != h->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off[n_logs] != n_ops");
+    if ((uint64_t)h->n_logs * copies > 0xFFFFFFFFull) return fail(ctx, PTX_ERR_INVALID_ARG, "too many logs");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    ptx_dbatch* b = new ptx_dbatch();
+    b->n_logs = h->n_logs * copies;
+    b->n_ops = h->n_ops * copies;
+    const uint64_t M = h->n_ops, T = b->n_ops;
+#define PTX_TRY(call)                                   \
+    do {                                                \
+        hipError_t _e = (call);                         \
+        if (_e != hipSuccess) {                         \
+            std::string m = std::string(#call) + ": " + hipGetErrorString(_e); \
+            ptx_batch_free(ctx, b);                     \
+            return fail(ctx, _e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, m); \
+        }                                               \
+    } while (0)
+    PTX_TRY(dalloc(&b->log_off, (uint64_t)b->n_logs + 1));
+    PTX_TRY(dalloc(&b->op_id, T));
+    PTX_TRY(dalloc(&b->ref_a, T));
+    PTX_TRY(dalloc(&b->ref_b, T));
+    PTX_TRY(dalloc(&b->payload, T));
+    PTX_TRY(dalloc(&b->action, T));
+    PTX_TRY(dalloc(&b->mark_type, T));
+    PTX_TRY(dalloc(&b->side_a, T));
+    PTX_TRY(dalloc(&b->side_b, T));
+    if (M) {
+        PTX_TRY(hipMemcpyAsync(b->op_id, h->op_id, M * 8, hipMemcpyHostToDevice, ctx->stream));
+        PTX_TRY(hipMemcpyAsync(b->ref_a, h->ref_a, M * 8, hipMemcpyHostToDevice, ctx->stream));
+        PTX_TRY(hipMemcpyAsync(b->ref_b, h->ref_b, M * 8, hipMemcpyHostToDevice, ctx->stream));
+        PTX_TRY(hipMemcpyAsync(b->payload, h->payload, M * 4, hipMemcpyHostToDevice, ctx->stream));
+        PTX_TRY(hipMemcpyAsync(b->action, h->action, M, hipMemcpyHostToDevice, ctx->stream));
+        PTX_TRY(hipMemcpyAsync(b->mark_type, h->mark_type, M, hipMemcpyHostToDevice, ctx->stream));
+        PTX_TRY(hipMemcpyAsync(b->side_a, h->side_a, M, hipMemcpyHostToDevice, ctx->stream));
+        PTX_TRY(hipMemcpyAsync(b->side_b, h->side_b, M, hipMemcpyHostToDevice, ctx->stream));
+        for (uint32_t k = 1; k < copies; ++k) { /* replicate inside HBM: distinct addresses per copy */
+            PTX_TRY(hipMemcpyAsync(b->op_id + k * M, b->op_id, M * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->ref_a + k * M, b->ref_a, M * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->ref_b + k * M, b->ref_b, M * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->payload + k * M, b->payload, M * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->action + k * M, b->action, M, hipMemcpyDeviceToDevice, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->mark_type + k * M, b->mark_type, M, hipMemcpyDeviceToDevice, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->side_a + k * M, b->side_a, M, hipMemcpyDeviceToDevice, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->side_b + k * M, b->side_b, M, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
+    {
+        uint64_t* tmp = nullptr;
+        PTX_TRY(dalloc(&tmp, (uint64_t)h->n_logs + 1));
+        hipError_t e1 = hipMemcpyAsync(tmp, h->log_off, ((uint64_t)h->n_logs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e1 == hipSuccess && h->n_logs) {
+            const uint64_t total = (uint64_t)b->n_logs + 1;
+            hipLaunchKernelGGL(ptx_tile_offsets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, tmp, b->log_off,
+                               h->n_logs, copies, M);
+            e1 = hipGetLastError();
+        } else if (e1 == hipSuccess) {
+            e1 = hipMemsetAsync(b->log_off, 0, 8, ctx->stream);
+        }
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+        PTX_TRY(e1);
+        PTX_TRY(e2);
+    }
+#undef PTX_TRY
+    uint32_t mx = 0;
+    const uint64_t need = scan_host_batch(h, &mx);
+    shape_launch(ctx, b, need, mx);
+    *out = b;
+    return PTX_OK;
+}
+
+ptx_status ptx_batch_upload(ptx_ctx* ctx, const ptx_batch* host, ptx_dbatch** out) { return ptx_batch_upload_tiled(ctx, host, 1, out); }
+
+ptx_status ptx_batch_wrap_device(ptx_ctx* ctx, const ptx_batch* d, ptx_dbatch** out) {
+    if (!ctx || !out) return PTX_ERR_INVALID_ARG;
+    *out = nullptr;
+    ptx_status st = check_batch(ctx, d);
+    if (st) return st;
+    ptx_dbatch* b = new ptx_dbatch();
+    b->owns = false;
+    b->n_logs = d->n_logs;
+    b->n_ops = d->n_ops;
+    b->log_off = (uint64_t*)d->log_off;
+    b->op_id = (uint64_t*)d->op_id;
+    b->ref_a = (uint64_t*)d->ref_a;
+    b->ref_b = (uint64_t*)d->ref_b;
+    b->payload = (uint32_t*)d->payload;
+    b->action = (uint8_t*)d->action;
+    b->mark_type = (uint8_t*)d->mark_type;
+    b->side_a = (uint8_t*)d->side_a;
+    b->side_b = (uint8_t*)d->side_b;
+    /* the columns are not host-readable: size the launch for the largest supported log */
+    shape_launch(ctx, b, ctx->max_lds, 65534);
+    *out = b;
+    return PTX_OK;
+}
+
+void ptx_dresult_free(ptx_ctx* ctx, ptx_dresult* r) {
+    if (!r) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipFree(r->logs);
+    (void)hipFree(r->values);
+    (void)hipFree(r->spans);
+    (void)hipFree(r->cints);
+    (void)hipFree(r->rank);
+    delete r;
+}
+
+ptx_status ptx_result_alloc(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult** out) {
+    if (!ctx || !b || !out) return PTX_ERR_INVALID_ARG;
+    *out = nullptr;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    ptx_dresult* r = new ptx_dresult();
+    r->n_logs = b->n_logs;
+    r->n_rows = b->n_ops;
+    hipError_t e = dalloc(&r->logs, r->n_logs);
+    if (e == hipSuccess) e = dalloc(&r->values, r->n_rows);
+    if (e == hipSuccess) e = dalloc(&r->spans, r->n_rows);
+    if (e == hipSuccess) e = dalloc(&r->cints, r->n_rows);
+    if (e == hipSuccess) e = dalloc(&r->rank, r->n_rows);
+    if (e != hipSuccess) {
+        std::string m = std::string("result allocation: ") + hipGetErrorString(e);
+        ptx_dresult_free(ctx, r);
+        return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, m);
+    }
+    *out = r;
+    return PTX_OK;
+}
+
+static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r) {
+    if (b->n_logs == 0) return PTX_OK;
+    PtxMergeArgs A;
+    A.log_off = b->log_off;
+    A.op_id = b->op_id;
+    A.ref_a = b->ref_a;
+    A.ref_b = b->ref_b;
+    A.payload = b->payload;
+    A.action = b->action;
+    A.mark_type = b->mark_type;
+    A.side_a = b->side_a;
+    A.side_b = b->side_b;
+    A.res = r->logs;
+    A.out_values = r->values;
+    A.out_spans = r->spans;
+    A.out_cints = r->cints;
+    A.out_rank = r->rank;
+    A.n_logs = b->n_logs;
+    A.lds_bytes = b->lds_bytes;
+    /* one workgroup per log; far more workgroups than the 256 CUs so the dispatcher load-balances */
+    const uint32_t grid = b->n_logs;
+    hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_merge_kernel launch: ") + hipGetErrorString(e));
+    return PTX_OK;
+}
+
+ptx_status ptx_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r) {
+    if (!ctx || !b || !r) return PTX_ERR_INVALID_ARG;
+    if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_merge(ctx, b, r);
+}
+
+ptx_status ptx_merge_timed(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, uint32_t iters, float* ms_total) {
+    if (!ctx || !b || !r || !ms_total) return PTX_ERR_INVALID_ARG;
+    if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (uint32_t i = 0; i < iters; ++i) {
+        ptx_status st = launch_merge(ctx, b, r);
+        if (st) return st;
+    }
+    PTX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    PTX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    PTX_HIP(ctx, hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return PTX_OK;
+}
+
+ptx_status ptx_sync(ptx_ctx* ctx) {
+    if (!ctx) return PTX_ERR_INVALID_ARG;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PTX_OK;
+}
+
+struct ptx_host_result {
+    std::vector<ptx_log_result> logs;
+    std::vector<uint32_t> values;
+    std::vector<ptx_span> spans;
+    std::vector<ptx_cinterval> cints;
+    std::vector<uint32_t> rank;
+};
+
+void ptx_result_free(ptx_result* res) {
+    if (!res) return;
+    delete (ptx_host_result*)res->owner;
+    memset(res, 0, sizeof(*res));
+}
+
+ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_result* out) {
+    if (!ctx || !b || !r || !out) return PTX_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    ptx_host_result* h = new ptx_host_result();
+    h->logs.resize(std::max<uint64_t>(r->n_logs, 1));
+    h->values.resize(std::max<uint64_t>(r->n_rows, 1));
+    h->spans.resize(std::max<uint64_t>(r->n_rows, 1));
+    h->cints.resize(std::max<uint64_t>(r->n_rows, 1));
+    h->rank.resize(std::max<uint64_t>(r->n_rows, 1));
+    hipError_t e = hipSuccess;
+    if (r->n_logs) e = hipMemcpyAsync(h->logs.data(), r->logs, r->n_logs * sizeof(ptx_log_result), hipMemcpyDeviceToHost, ctx->stream);
+    if (r->n_rows) {
+        if (e == hipSuccess) e = hipMemcpyAsync(h->values.data(), r->values, r->n_rows * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->spans.data(), r->spans, r->n_rows * sizeof(ptx_span), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->cints.data(), r->cints, r->n_rows * sizeof(ptx_cinterval), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->rank.data(), r->rank, r->n_rows * 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(ctx, PTX_ERR_HIP, std::string("result download: ") + hipGetErrorString(e));
+    }
+    out->n_logs = r->n_logs;
+    out->n_rows = r->n_rows;
+    out->logs = h->logs.data();
+    out->values = h->values.data();
+    out->spans = h->spans.data();
+    out->cintervals = h->cints.data();
+    out->elem_rank = h->rank.data();
+    out->owner = h;
+    return PTX_OK;
+}
+
+ptx_status ptx_result_download_logs(ptx_ctx* ctx, const ptx_dresult* r, ptx_log_result* out, uint32_t n_logs) {
+    if (!ctx || !r || (!out && n_logs)) return PTX_ERR_INVALID_ARG;
+    if (n_logs > r->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "n_logs exceeds the result");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_logs) PTX_HIP(ctx, hipMemcpyAsync(out, r->logs, (size_t)n_logs * sizeof(ptx_log_result), hipMemcpyDeviceToHost, ctx->stream));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PTX_OK;
+}
+
+const ptx_log_result* ptx_dresult_logs_device(const ptx_dresult* r) { return r ? r->logs : nullptr; }
+
+ptx_status ptx_pack_digests(ptx_ctx* ctx, const ptx_dresult* r, uint32_t first, uint32_t count, uint64_t* dst_device) {
+    if (!ctx || !r || (!dst_device && count)) return PTX_ERR_INVALID_ARG;
+    if ((uint64_t)first + count > r->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "digest range exceeds the result");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    if (count) {
+        hipLaunchKernelGGL(ptx_pack_digests_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, r->logs, first, count, dst_device);
+        PTX_HIP(ctx, hipGetLastError());
+    }
+    return PTX_OK;
+}
+
+ptx_status ptx_apply_materialize(ptx_ctx* ctx, const ptx_batch* batch, ptx_result* out) {
+    if (!ctx || !out) return PTX_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    ptx_dbatch* b = nullptr;
+    ptx_dresult* r = nullptr;
+    ptx_status st = ptx_batch_upload(ctx, batch, &b);
+    if (st == PTX_OK) st = ptx_result_alloc(ctx, b, &r);
+    if (st == PTX_OK) st = ptx_merge(ctx, b, r);
+    if (st == PTX_OK) st = ptx_result_download(ctx, b, r, out);
+    ptx_dresult_free(ctx, r);
+    ptx_batch_free(ctx, b);
+    return st;
+}
+
+} /* extern "C" */

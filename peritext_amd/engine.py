@@ -1,0 +1,152 @@
+"""Thin ctypes driver over the C ABI (include/peritext_hip.h).  Plumbing only: every merge goes
+through libperitext_hip.so on a gfx950 device; nothing here computes a result on the CPU."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, wire
+
+
+class PtxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("peritext_hip status %d: %s" % (status, message))
+        self.status = status
+
+
+def _batch_struct(b):
+    s = abi.ptx_batch()
+    s.n_logs = b.n_logs
+    s.n_ops = b.n_ops
+    p = lambda a, t: a.ctypes.data_as(t)  # noqa: E731
+    s.log_off = p(b.log_off, abi.u64p)
+    s.op_id = p(b.op_id, abi.u64p)
+    s.ref_a = p(b.ref_a, abi.u64p)
+    s.ref_b = p(b.ref_b, abi.u64p)
+    s.payload = p(b.payload, abi.u32p)
+    s.action = p(b.action, abi.u8p)
+    s.mark_type = p(b.mark_type, abi.u8p)
+    s.side_a = p(b.side_a, abi.u8p)
+    s.side_b = p(b.side_b, abi.u8p)
+    s.chg_off = p(b.chg_off, abi.u64p)
+    s.chg_actor = p(b.chg_actor, abi.u32p)
+    s.chg_seq = p(b.chg_seq, abi.u32p)
+    s.chg_nops = p(b.chg_nops, abi.u32p)
+    s.chg_deps = p(b.chg_deps, abi.u32p)
+    s.max_actors = b.max_actors
+    return s
+
+
+def _copy_result(res):
+    """ptx_result (library-owned host memory) -> wire.Results (numpy copies)."""
+    nl, nr = int(res.n_logs), int(res.n_rows)
+
+    def arr(ptr, dtype, n):
+        if n == 0:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(C.addressof(ptr.contents))
+        return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+    return wire.Results(
+        logs=arr(res.logs, abi.LOG_RESULT_DTYPE, nl),
+        values=arr(res.values, np.uint32, nr),
+        spans=arr(res.spans, abi.SPAN_DTYPE, nr),
+        cintervals=arr(res.cintervals, abi.CINTERVAL_DTYPE, nr),
+        elem_rank=arr(res.elem_rank, np.uint32, nr),
+    )
+
+
+class Engine:
+    """One device context (one HIP stream).  One Engine per process/GPU in multi-GPU runs."""
+
+    def __init__(self, device=0, lib_path=None):
+        self.lib = abi.load_library(lib_path)
+        ctx = C.c_void_p()
+        st = self.lib.ptx_create(device, 0, C.byref(ctx))
+        if st != 0:
+            raise PtxError(st, (self.lib.ptx_last_error(None) or b"").decode())
+        self.ctx = ctx
+        self.device = device
+
+    def _check(self, st):
+        if st != 0:
+            raise PtxError(st, (self.lib.ptx_last_error(self.ctx) or b"").decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.ptx_destroy(self.ctx)
+            self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- the drop-in call ----
+    def apply_materialize(self, batch):
+        """Upload, merge, download: wire.Batch -> wire.Results (ptx_apply_materialize)."""
+        s = _batch_struct(batch)
+        res = abi.ptx_result()
+        self._check(self.lib.ptx_apply_materialize(self.ctx, C.byref(s), C.byref(res)))
+        try:
+            return _copy_result(res)
+        finally:
+            self.lib.ptx_result_free(C.byref(res))
+
+    # ---- staged form ----
+    def upload(self, batch, copies=1):
+        s = _batch_struct(batch)
+        h = C.c_void_p()
+        self._check(self.lib.ptx_batch_upload_tiled(self.ctx, C.byref(s), copies, C.byref(h)))
+        return h
+
+    def free_batch(self, h):
+        self.lib.ptx_batch_free(self.ctx, h)
+
+    def alloc_result(self, dbatch):
+        h = C.c_void_p()
+        self._check(self.lib.ptx_result_alloc(self.ctx, dbatch, C.byref(h)))
+        return h
+
+    def free_result(self, h):
+        self.lib.ptx_dresult_free(self.ctx, h)
+
+    def merge(self, dbatch, dresult):
+        self._check(self.lib.ptx_merge(self.ctx, dbatch, dresult))
+
+    def merge_timed(self, dbatch, dresult, iters):
+        """Milliseconds (HIP events on the engine's stream) of `iters` back-to-back merges."""
+        ms = C.c_float()
+        self._check(self.lib.ptx_merge_timed(self.ctx, dbatch, dresult, iters, C.byref(ms)))
+        return float(ms.value)
+
+    def sync(self):
+        self._check(self.lib.ptx_sync(self.ctx))
+
+    def download(self, dbatch, dresult):
+        res = abi.ptx_result()
+        self._check(self.lib.ptx_result_download(self.ctx, dbatch, dresult, C.byref(res)))
+        try:
+            return _copy_result(res)
+        finally:
+            self.lib.ptx_result_free(C.byref(res))
+
+    def download_logs(self, dresult, n_logs):
+        out = np.zeros(n_logs, dtype=abi.LOG_RESULT_DTYPE)
+        self._check(self.lib.ptx_result_download_logs(self.ctx, dresult, out.ctypes.data_as(C.POINTER(abi.ptx_log_result)), n_logs))
+        return out
+
+    def pack_digests(self, dresult, first, count, dst_device_ptr):
+        self._check(self.lib.ptx_pack_digests(self.ctx, dresult, first, count, C.c_void_p(dst_device_ptr)))
+
+    def n_logs(self, dbatch):
+        return int(self.lib.ptx_batch_n_logs(dbatch))
+
+    def n_ops(self, dbatch):
+        return int(self.lib.ptx_batch_n_ops(dbatch))
+
+    def max_ops_per_log(self):
+        return int(self.lib.ptx_max_ops_per_log(self.ctx))
+
+    def kernel_name(self):
+        return self.lib.ptx_kernel_name().decode()

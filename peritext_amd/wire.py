@@ -121,6 +121,11 @@ def encode_docs(docs):
                     actors.add(a)
                 for op in ch["ops"]:
                     actors.add(split_op_id(op["opId"])[1])
+                    # ids that are only ever REFERENCED (possibly unknown elements) need a rank too
+                    refs = [op.get("elemId"), (op.get("start") or {}).get("elemId"), (op.get("end") or {}).get("elemId")]
+                    for ref in refs:
+                        if isinstance(ref, str) and ref not in (HEAD, ROOT):
+                            actors.add(split_op_id(ref)[1])
                     if op.get("markType") == "comment":
                         comments.add(op["attrs"]["id"])
         actor_list = sorted(actors, key=_u16key)

@@ -1,0 +1,146 @@
+"""Kernel LOGIC against the oracle on the CPU: peritext_amd/csrc/merge_core.h compiled with -DPTX_EMU
+(tests/emu, test tooling only).  The same source is what hipcc compiles into ptx_merge_kernel; the GPU
+tests (test_gpu_parity.py) repeat these comparisons through the C ABI on a real MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from peritext_amd import abi, wire
+
+pytestmark = pytest.mark.skipif(not os.path.exists(H.EMU_LIB), reason="tests/emu/libperitext_emu.so not built (run __graft_entry__.build())")
+
+GOLDEN_GEN = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json", "ptxgen_config4_600.json", "ptxgen_rich_700.json"]
+
+
+def _load(name):
+    with open(os.path.join(H.GOLDEN, name)) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_kat_literals(reverse):
+    """All 46 reference test cases: every replica log -> the reference's expectedResult literal."""
+    cases = H.load_kat()
+    batch = wire.encode_docs([[r["log"] for r in c["replicas"]] for c in cases])
+    res = H.emu_merge(batch, reverse=reverse)
+    log = 0
+    for c in cases:
+        for r in c["replicas"]:
+            want = c.get("expected", r["spans"])
+            assert H.norm_spans(wire.decode_spans(batch, res, log)) == H.norm_spans(want), c["title"]
+            log += 1
+
+
+@pytest.mark.parametrize("name", GOLDEN_GEN)
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_golden_ptxgen(name, reverse):
+    """Committed PTXGEN fixtures (oracle output): decoded spans, raw canonical rows and digests, in both
+    parallel-loop iteration orders (order independence = no intra-phase data race by construction)."""
+    H.check_generated(_load(name), lambda b: H.emu_merge(b, reverse=reverse))
+
+
+def test_reference_traces():
+    traces = _load("reference_traces.json")
+    batch = wire.encode_docs([t["logs"] for t in traces])
+    res = H.emu_merge(batch)
+    log = 0
+    for t in traces:
+        for _ in t["logs"]:
+            assert H.norm_spans(wire.decode_spans(batch, res, log)) == H.norm_spans(t["spans"]), t["name"]
+            log += 1
+
+
+def test_replica_digests_converge():
+    gen = _load("ptxgen_config4_600.json")
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    res = H.emu_merge(batch)
+    dg = res.logs["digest"].reshape(len(gen["docs"]), -1, 2)
+    assert (dg == dg[:, :1, :]).all()
+    assert len({tuple(x) for x in dg[:, 0, :].tolist()}) == len(gen["docs"])  # different docs, different digests
+
+
+def _mini_doc(ops_second_change, first_text="ABCDE"):
+    """A hand-written log: change 1 = makeList + text, change 2 = the given ops (opIds assigned here)."""
+    ops1 = [{"opId": "1@a", "action": "makeList", "obj": "_root", "key": "text"}]
+    prev = "_head"
+    for i, ch in enumerate(first_text):
+        ops1.append({"opId": "%d@a" % (i + 2), "action": "set", "obj": "1@a", "elemId": prev, "insert": True, "value": ch})
+        prev = "%d@a" % (i + 2)
+    c1 = {"actor": "a", "seq": 1, "deps": {}, "startOp": 1, "ops": ops1}
+    start = len(ops1) + 1
+    ops2 = []
+    for k, op in enumerate(ops_second_change):
+        o = dict(op)
+        o["opId"] = "%d@a" % (start + k)
+        o["obj"] = "1@a"
+        ops2.append(o)
+    c2 = {"actor": "a", "seq": 2, "deps": {"a": 1}, "startOp": start, "ops": ops2}
+    return [c1, c2]
+
+
+def test_edge_cases_against_oracle():
+    """Quirks of SURVEY.md Appendix A.6 that no reference test covers, each checked against the oracle:
+    removeMark comment -> `comment: []`; zero-width inclusive mark runs to the end; zero-width
+    non-inclusive mark is a no-op; unknown boundary element -> silent no-op; endOfText; empty document;
+    everything deleted."""
+    el = lambda i: "%d@a" % (i + 2)  # noqa: E731  element id of initial char i
+    docs = [
+        [_mini_doc([{"action": "removeMark", "markType": "comment", "attrs": {"id": "c1"}, "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(3)}}])],
+        [_mini_doc([{"action": "addMark", "markType": "strong", "start": {"type": "before", "elemId": el(2)}, "end": {"type": "before", "elemId": el(2)}}])],
+        [_mini_doc([{"action": "addMark", "markType": "link", "attrs": {"url": "u"}, "start": {"type": "before", "elemId": el(2)}, "end": {"type": "after", "elemId": el(1)}}])],
+        [_mini_doc([{"action": "addMark", "markType": "em", "start": {"type": "before", "elemId": "99@zz"}, "end": {"type": "endOfText"}}])],
+        [_mini_doc([{"action": "addMark", "markType": "em", "start": {"type": "before", "elemId": el(3)}, "end": {"type": "endOfText"}},
+                    {"action": "set", "insert": True, "elemId": el(4), "value": "!"}])],
+        [_mini_doc([], first_text="")],
+        [_mini_doc([{"action": "del", "elemId": el(i)} for i in range(5)] + [{"action": "del", "elemId": el(0)}])],
+        [_mini_doc([{"action": "addMark", "markType": "comment", "attrs": {"id": "c2"}, "start": {"type": "before", "elemId": el(0)}, "end": {"type": "after", "elemId": el(2)}},
+                    {"action": "addMark", "markType": "comment", "attrs": {"id": "c1"}, "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(4)}},
+                    {"action": "removeMark", "markType": "comment", "attrs": {"id": "c2"}, "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(1)}},
+                    {"action": "addMark", "markType": "comment", "attrs": {"id": "c2"}, "start": {"type": "before", "elemId": el(4)}, "end": {"type": "after", "elemId": el(4)}}])],
+    ]
+    if not H.have_node():
+        pytest.skip("node not installed")
+    expected = H.oracle_apply(docs)
+    batch = wire.encode_docs(docs)
+    for reverse in (0, 1):
+        res = H.emu_merge(batch, reverse=reverse)
+        for log, exp in enumerate(expected):
+            H.check_log(batch, res, log, exp[0])
+    assert expected[0][0]["spans"][1]["marks"] == {"comment": []}
+    assert expected[5][0]["spans"] == [] and expected[6][0]["spans"] == []
+
+
+def test_error_statuses_mirror_reference_throw_sites():
+    """Unknown insert parent / delete target -> PTX_ERR_ELEM_NOT_FOUND (RangeError 'List element not
+    found', micromerge.ts:752), also when the element only appears LATER in the log."""
+    docs = [
+        [_mini_doc([{"action": "set", "insert": True, "elemId": "77@zz", "value": "x"}])],
+        [_mini_doc([{"action": "del", "elemId": "77@zz"}])],
+        [_mini_doc([{"action": "del", "elemId": "9@a"}, {"action": "set", "insert": True, "elemId": "6@a", "value": "x"}, {"action": "set", "insert": True, "elemId": "6@a", "value": "y"}])],
+        [_mini_doc([{"action": "set", "insert": True, "elemId": "6@a", "value": "ok"}])],
+    ]
+    batch = wire.encode_docs(docs)
+    res = H.emu_merge(batch)
+    assert [int(s) for s in res.logs["status"]] == [abi.ERR_ELEM_NOT_FOUND] * 3 + [0]
+    if H.have_node():
+        exp = H.oracle_apply(docs)
+        assert all("List element not found" in e[0].get("error", "") for e in exp[:3]) and "error" not in exp[3][0]
+    with pytest.raises(ValueError, match="List element not found"):
+        wire.decode_spans(batch, res, 0)
+
+
+def test_capacity_status_when_lds_too_small():
+    gen = _load("ptxgen_config4_600.json")
+    batch = wire.encode_docs([gen["docs"][0]["logs"]])
+    res = H.emu_merge(batch, lds_bytes=4096)
+    assert (res.logs["status"] == abi.ERR_CAPACITY).all()
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node not installed")
+@pytest.mark.parametrize("config,docs,ops", [("mini", 25, None), ("config4", 1, None), ("rich", 2, None), ("config5", 1, 3000)])
+def test_live_oracle(config, docs, ops):
+    """Fresh seeds generated now by the oracle (incl. one FULL config #4 document: 3 replicas x 4096 ops)."""
+    H.check_generated(H.oracle_gen(config, docs, 77, ops), H.emu_merge)
