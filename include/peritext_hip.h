@@ -166,6 +166,9 @@ typedef struct ptx_ctx ptx_ctx;          /* device context: stream + allocations
 typedef struct ptx_dbatch ptx_dbatch;    /* a batch resident in HBM */
 typedef struct ptx_dresult ptx_dresult;  /* result buffers resident in HBM */
 
+/* ptx_create flags */
+#define PTX_FLAG_NO_ELEM_RANK 1u /* do not produce ptx_result.elem_rank (saves 4 B/op of HBM writes) */
+
 /* ---- lifecycle ---- */
 uint32_t ptx_abi_version(void);
 /* device_ordinal: HIP device index.  Fails with PTX_ERR_NO_DEVICE when no gfx950 GPU is visible:

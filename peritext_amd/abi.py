@@ -24,6 +24,8 @@ ATTR_LINK = 0x40000000
 ATTR_COMMENT = 0x80000000
 ATTR_ID_MASK = 0x0FFFFFFF
 
+FLAG_NO_ELEM_RANK = 1
+
 PTX_OK = 0
 ERR_ELEM_NOT_FOUND = 1
 ERR_SEQ_GAP = 2

@@ -625,7 +625,7 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                     ptx_digest_item(h1, h2, 1u, q, v, 0u);
                 }
             }
-            A.out_rank[base + x] = rr;
+            if (A.out_rank) A.out_rank[base + x] = rr;
         }
         ptx_digest_flush(H, h1, h2);
     }

@@ -63,6 +63,7 @@ struct ptx_ctx {
     size_t max_lds = 0;
     int force_threads = 0; /* PTX_THREADS env override (tuning) */
     int force_lds = 0;     /* PTX_LDS_BYTES env override (tuning) */
+    uint32_t flags = 0;
 };
 
 struct ptx_dbatch {
@@ -187,7 +188,6 @@ const char* ptx_kernel_name(void) { return "ptx_merge_kernel"; }
 const char* ptx_last_error(const ptx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
-    (void)flags;
     if (!out) return fail(nullptr, PTX_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     int count = 0;
@@ -201,6 +201,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
         return fail(nullptr, PTX_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only");
     ptx_ctx* ctx = new ptx_ctx();
     ctx->device = device_ordinal;
+    ctx->flags = flags;
     ctx->cu_count = prop.multiProcessorCount;
     ctx->max_lds = 160 * 1024;
     if (const char* s = getenv("PTX_THREADS")) ctx->force_threads = atoi(s);
@@ -388,7 +389,7 @@ ptx_status ptx_result_alloc(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult** out
     if (e == hipSuccess) e = dalloc(&r->values, r->n_rows);
     if (e == hipSuccess) e = dalloc(&r->spans, r->n_rows);
     if (e == hipSuccess) e = dalloc(&r->cints, r->n_rows);
-    if (e == hipSuccess) e = dalloc(&r->rank, r->n_rows);
+    if (e == hipSuccess && !(ctx->flags & PTX_FLAG_NO_ELEM_RANK)) e = dalloc(&r->rank, r->n_rows);
     if (e != hipSuccess) {
         std::string m = std::string("result allocation: ") + hipGetErrorString(e);
         ptx_dresult_free(ctx, r);
@@ -484,7 +485,7 @@ ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dres
         if (e == hipSuccess) e = hipMemcpyAsync(h->values.data(), r->values, r->n_rows * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h->spans.data(), r->spans, r->n_rows * sizeof(ptx_span), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h->cints.data(), r->cints, r->n_rows * sizeof(ptx_cinterval), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->rank.data(), r->rank, r->n_rows * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && r->rank) e = hipMemcpyAsync(h->rank.data(), r->rank, r->n_rows * 4, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -497,7 +498,7 @@ ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dres
     out->values = h->values.data();
     out->spans = h->spans.data();
     out->cintervals = h->cints.data();
-    out->elem_rank = h->rank.data();
+    out->elem_rank = r->rank ? h->rank.data() : nullptr;
     out->owner = h;
     return PTX_OK;
 }

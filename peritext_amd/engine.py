@@ -51,17 +51,17 @@ def _copy_result(res):
         values=arr(res.values, np.uint32, nr),
         spans=arr(res.spans, abi.SPAN_DTYPE, nr),
         cintervals=arr(res.cintervals, abi.CINTERVAL_DTYPE, nr),
-        elem_rank=arr(res.elem_rank, np.uint32, nr),
+        elem_rank=arr(res.elem_rank, np.uint32, nr) if res.elem_rank else np.zeros(0, dtype=np.uint32),
     )
 
 
 class Engine:
     """One device context (one HIP stream).  One Engine per process/GPU in multi-GPU runs."""
 
-    def __init__(self, device=0, lib_path=None):
+    def __init__(self, device=0, lib_path=None, flags=0):
         self.lib = abi.load_library(lib_path)
         ctx = C.c_void_p()
-        st = self.lib.ptx_create(device, 0, C.byref(ctx))
+        st = self.lib.ptx_create(device, flags, C.byref(ctx))
         if st != 0:
             raise PtxError(st, (self.lib.ptx_last_error(None) or b"").decode())
         self.ctx = ctx
