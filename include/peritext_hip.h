@@ -201,6 +201,11 @@ ptx_status ptx_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r);
 /* Same, `iters` times back to back, bracketed by HIP events on the context's stream:
  * *ms_total = elapsed milliseconds of the `iters` launches (for roofline accounting). */
 ptx_status ptx_merge_timed(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, uint32_t iters, float* ms_total);
+/* Diagnostic: run the merge once with per-phase cycle stamps (thread 0 of every workgroup) and return
+ * the shader-clock cycles summed over all workgroups per phase: cycles[k], k < n <= 16, phases in the
+ * order of merge_core.h (P1 classify, P2 index, P3a buckets, P3b child order, P3c tour+ranking, P4
+ * tombstones, P5a values+mark intervals, P5b LWW, P5c comments, P6 spans).  Not for timed runs. */
+ptx_status ptx_merge_phase_cycles(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, uint64_t* cycles, uint32_t n);
 ptx_status ptx_sync(ptx_ctx* ctx);
 
 ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_result* out);

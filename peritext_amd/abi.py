@@ -149,6 +149,7 @@ FUNCTIONS = {
     "ptx_dresult_free": (None, [vp, vp]),
     "ptx_merge": (C.c_int32, [vp, vp, vp]),
     "ptx_merge_timed": (C.c_int32, [vp, vp, vp, C.c_uint32, C.POINTER(C.c_float)]),
+    "ptx_merge_phase_cycles": (C.c_int32, [vp, vp, vp, u64p, C.c_uint32]),
     "ptx_sync": (C.c_int32, [vp]),
     "ptx_result_download": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_result)]),
     "ptx_result_download_logs": (C.c_int32, [vp, vp, C.POINTER(ptx_log_result), C.c_uint32]),

@@ -2,7 +2,8 @@
  * merge_core.h — the per-replica-log merge algorithm of the MI355X engine.
  *
  * One workgroup applies ONE replica op log and materialises its formatted document, entirely in
- * LDS: the op columns are read from HBM once, the outputs are written once.
+ * LDS: the op columns are read from HBM once (re-reads of a column are L2 hits), the outputs are
+ * written once.
  *
  * It replaces, for one log, the reference's sequential
  *     for change of log: doc.applyChange(change)        reference/src/micromerge.ts:499-514
@@ -10,23 +11,26 @@
  *         applyAddRemoveMark            reference/src/peritext.ts:154-249
  *     doc.getTextWithFormatting(["text"])               reference/src/peritext.ts:337-395, opsToMarks :294-326
  * with the order-independent closed form of SURVEY.md Appendix A.3/A.5/A.7:
- *   A  opId -> dense Lamport rank: a bitmap over (counter<<actorBits | actor) + popcount prefix
- *      (compareOpIds order, micromerge.ts:812-827); id -> op row lookup for every elemId reference
- *   B  RGA causal tree: element order = pre-order DFS, children by DESCENDING opId (equivalent to the
- *      skip loop at micromerge.ts:630-635): sort inserts by (parent, rank desc), link first-child /
- *      next-sibling, pre-order successor by pointer jumping, list ranking (Wyllie)
- *   C  tombstones: delete flags by target, popcount-prefix over "alive by rank" -> visible index
- *      (the `visible` counters of micromerge.ts:747-750)
- *   D  marks: boundary slots 2*rank+side -> element-rank interval -> visible interval; per visible
- *      char the max-opId covering op per non-multi mark type (LWW, peritext.ts:304-313) through a
- *      range-chmax tree; comments (allowMultiple, :314-321) as per-id presence intervals decided by
- *      the LAST-APPLIED covering op of that id
- *   E  spans = maximal runs of visible chars with equal marks (peritext.ts:438-455) + 128-bit digest
+ *   P1  classify the rows, reduce max counter / actor and the op counts
+ *   P2  element index: a bitmap over the insert ids (counter<<actorBits | actor) + popcount prefix
+ *       gives every list element a dense index e = its rank in compareOpIds order
+ *       (micromerge.ts:812-827) and turns every elemId reference into one 8-byte LDS read
+ *   P3  RGA causal tree: element order = pre-order DFS, children by DESCENDING opId (equivalent to
+ *       the skip loop at micromerge.ts:630-635).  Children are bucketed per parent (counting sort)
+ *       and ranked inside the bucket; the Euler tour of the tree is ranked by in-place pointer
+ *       jumping -> document position of every element
+ *   P4  tombstones: clear "alive" bits by document position, popcount prefix -> visible index
+ *       (the `visible` counters of micromerge.ts:747-750)
+ *   P5  marks: boundary slots 2*rank+side -> visible interval; per visible char the max-opId covering
+ *       op per non-multi mark type (LWW, peritext.ts:304-313) through a range-chmax tree; comments
+ *       (allowMultiple, :314-321) as per-id presence intervals decided by the LAST-APPLIED covering op
+ *   P6  spans = maximal runs of visible chars with equal marks (peritext.ts:438-455) + 128-bit digest
  *
  * The code is written as phases of `PTX_FOR` (a parallel loop over the workgroup) separated by
  * `PTX_SYNC()`; no iteration reads what another iteration of the same phase writes except through
- * commutative atomics.  That discipline lets the SAME source be compiled two ways:
- *   - by hipcc for gfx950 as the body of the kernel in merge_kernel.hip (the product), and
+ * commutative atomics (or, in the pointer-jumping rounds, through single-word reads of a value whose
+ * every intermediate state is valid).  That discipline lets the SAME source be compiled two ways:
+ *   - by hipcc for gfx950 as the body of the kernel in peritext_hip.hip (the product), and
  *   - by g++ with -DPTX_EMU as a single-threaded emulation used ONLY by the CPU test-suite
  *     (tests/emu) to check the kernel's logic where no GPU exists.  The emulation is not linked
  *     into libperitext_hip.so and is never a fallback for the product path.
@@ -45,9 +49,14 @@ extern int ptx_emu_reverse; /* 1: run every parallel loop backwards (order-indep
          ++_k, i = (ptx_emu_reverse ? _n - 1 - _k : _k))
 #define PTX_LEADER if (true)
 PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o & v; return o; }
 PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
+PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+/* append to a list: index of this element (valid only where pred) */
+PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }
+PTX_DEV uint64_t ptx_clock() { return 0; }
 #else
 #include <hip/hip_runtime.h>
 #define PTX_DEV __device__ __forceinline__
@@ -55,9 +64,24 @@ PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); 
 #define PTX_FOR(i, n) for (uint32_t i = threadIdx.x, _n = (n); i < _n; i += blockDim.x)
 #define PTX_LEADER if (threadIdx.x == 0)
 PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
 PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
+PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__popc(x); }
+/* wave-aggregated append: ONE LDS atomic per wave, lanes get consecutive slots.  May be called in
+ * divergent control flow (the ballot covers the active lanes only). */
+PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+    uint32_t b = 0;
+    if (lane == leader) b = atomicAdd(cursor, (uint32_t)__popcll(m));
+    b = (uint32_t)__shfl((int)b, (int)leader, 64);
+    return b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+PTX_DEV uint64_t ptx_clock() { return (uint64_t)__builtin_readcyclecounter(); }
 #endif
 
 /* kernel arguments: device pointers (host pointers under PTX_EMU) */
@@ -71,16 +95,27 @@ struct PtxMergeArgs {
     const uint8_t* mark_type;
     const uint8_t* side_a;
     const uint8_t* side_b;
+    /* causal envelope (optional: chg_off == nullptr skips causal admission) */
+    const uint64_t* chg_off;
+    const uint32_t* chg_actor;
+    const uint32_t* chg_seq;
+    const uint32_t* chg_nops;
+    const uint32_t* chg_deps;
     ptx_log_result* res;
     uint32_t* out_values;
     ptx_span* out_spans;
     ptx_cinterval* out_cints;
     uint32_t* out_rank;
+    unsigned long long* clocks; /* optional [PTX_NCLK]: per-phase cycle totals (profiling builds of the host) */
     uint32_t n_logs;
     uint32_t lds_bytes;
+    uint32_t max_actors;
+    uint32_t pad;
 };
 
-#define PTX_NONE 0xFFFFu
+#define PTX_END 0xFFFFu
+#define PTX_NCLK 16
+#define PTX_SMALL_BUCKET 8u
 
 /* ---- digest: 128-bit multiset hash of the canonical output (restated in peritext_amd/canon.py) ---- */
 PTX_DEV uint64_t ptx_fmix64(uint64_t x) {
@@ -100,16 +135,24 @@ PTX_DEV void ptx_digest_item(uint64_t& h1, uint64_t& h2, uint32_t tag, uint32_t 
 
 /* ---- LDS header ---- */
 struct PtxHdr {
-    uint32_t status;
+    uint32_t err;          /* min over ((row*2+level) << 4 | code) of every detected error; ~0 = none */
     uint32_t max_ctr, max_actor;
-    uint32_t n_ins, n_marks, n_applied;
-    uint32_t n_type[4]; /* mark ops per mark type */
-    uint32_t cur_a, cur_b;
+    uint32_t cur_i, cur_d, cur_m, cur_big;
     uint32_t V, S, I;
-    uint32_t pad;
-    uint32_t scan_tmp[36];
+    uint32_t pad[2];
+    unsigned long long cnt_a; /* n_ins | n_del << 16 | n_marks << 32 | n_applied << 48 */
+    unsigned long long cnt_t; /* mark ops per mark type, 16 bits each */
     unsigned long long h1, h2;
+    uint32_t scan_tmp[36];
+    unsigned long long clk[PTX_NCLK + 1];
 };
+
+#define PTX_NO_ERR 0xFFFFFFFFu
+/* the reference throws at the FIRST failing op in application order: keep the minimum position.
+ * level 0 = change-level check (seq / deps, micromerge.ts:501-509), 1 = op-level (:752) */
+PTX_DEV void ptx_raise(PtxHdr* H, uint32_t row, uint32_t level, uint32_t code) {
+    ptx_atomic_min(&H->err, ((row * 2u + level) << 4) | code);
+}
 
 PTX_DEV void ptx_digest_flush(PtxHdr* H, uint64_t h1, uint64_t h2) {
 #ifdef PTX_EMU
@@ -128,14 +171,36 @@ PTX_DEV void ptx_digest_flush(PtxHdr* H, uint64_t h1, uint64_t h2) {
 #endif
 }
 
-/* ---- block-wide exclusive scan of an LDS array, in place; returns the total (all threads call it) ---- */
-template <class T>
+/* sum / max over the workgroup into LDS words (every thread calls them) */
+PTX_DEV void ptx_reduce_add64(unsigned long long* dst, unsigned long long v) {
+#ifdef PTX_EMU
+    *dst += v;
+#else
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, v);
+#endif
+}
+PTX_DEV void ptx_reduce_max32(uint32_t* dst, uint32_t v) {
+#ifdef PTX_EMU
+    if (v > *dst) *dst = v;
+#else
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(dst, v);
+#endif
+}
+
+/* ---- block-wide exclusive scan of an LDS array (element k at a[k*STRIDE]), in place; returns the
+ *      total (all threads call it; ends with a barrier) ---- */
+template <class T, int STRIDE>
 PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in LDS */) {
 #ifdef PTX_EMU
     uint32_t run = 0;
     for (uint32_t j = 0; j < m; ++j) {
-        uint32_t v = a[j];
-        a[j] = (T)run;
+        uint32_t v = a[j * STRIDE];
+        a[j * STRIDE] = (T)run;
         run += v;
     }
     (void)tmp;
@@ -146,7 +211,7 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
     const uint32_t lo = tid * chunk < m ? tid * chunk : m;
     const uint32_t hi = lo + chunk < m ? lo + chunk : m;
     uint32_t sum = 0;
-    for (uint32_t j = lo; j < hi; ++j) sum += a[j];
+    for (uint32_t j = lo; j < hi; ++j) sum += a[j * STRIDE];
     uint32_t incl = sum;
     for (int d = 1; d < 64; d <<= 1) {
         uint32_t v = __shfl_up(incl, d, 64);
@@ -167,8 +232,8 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
     __syncthreads();
     uint32_t run = tmp[wave] + incl - sum;
     for (uint32_t j = lo; j < hi; ++j) {
-        uint32_t v = a[j];
-        a[j] = (T)run;
+        uint32_t v = a[j * STRIDE];
+        a[j * STRIDE] = (T)run;
         run += v;
     }
     const uint32_t total = tmp[35];
@@ -177,41 +242,46 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
 #endif
 }
 
-/* ---- bit-rank: bits[] + exclusive popcount prefix per 32-bit word ---- */
-struct PtxBitRank {
-    uint32_t* bits;
-    uint16_t* pre;
+/* ---- bit-rank: one 8-byte LDS word per 32 positions = {bits, exclusive popcount prefix} ---- */
+struct PtxBitWord {
+    uint32_t bits;
+    uint32_t pre;
 };
-PTX_DEV uint32_t ptx_bitrank(const PtxBitRank& b, uint32_t pos) { /* # set bits strictly below pos */
-    const uint32_t w = pos >> 5, s = pos & 31;
-    return (uint32_t)b.pre[w] + ptx_popc(b.bits[w] & ((1u << s) - 1u));
+PTX_DEV uint32_t ptx_bitrank(const PtxBitWord* b, uint32_t pos) { /* # set bits strictly below pos */
+    const PtxBitWord w = b[pos >> 5];
+    return w.pre + ptx_popc(w.bits & ((1u << (pos & 31)) - 1u));
+}
+/* rank of `pos` if its bit is set, else -1 */
+PTX_DEV int ptx_bitrank_if_set(const PtxBitWord* b, uint32_t pos) {
+    const PtxBitWord w = b[pos >> 5];
+    const uint32_t s = pos & 31;
+    if (!((w.bits >> s) & 1u)) return -1;
+    return (int)(w.pre + ptx_popc(w.bits & ((1u << s) - 1u)));
 }
 PTX_DEV bool ptx_bittest(const uint32_t* bits, uint32_t pos) { return (bits[pos >> 5] >> (pos & 31)) & 1u; }
 
-/* ---- opId -> row index ---- */
-struct PtxIdIndex {
-    PtxBitRank br;
-    uint16_t* by_rank;
+/* ---- elemId -> element index ---- */
+struct PtxElemIndex {
+    PtxBitWord* ib; /* bitmap over the keys of the INSERT ops */
     uint32_t abits, max_ctr, max_actor;
 };
-PTX_DEV bool ptx_id_key(const PtxIdIndex& ix, uint64_t id, uint32_t& key) {
+PTX_DEV bool ptx_id_key(const PtxElemIndex& ix, uint64_t id, uint32_t& key) {
     const uint32_t ctr = (uint32_t)(id >> 32), actor = (uint32_t)id;
     if (ctr == 0 || ctr > ix.max_ctr || actor > ix.max_actor) return false;
     key = (ctr << ix.abits) | actor;
     return true;
 }
-/* row of the op with this id inside the log, or -1 */
-PTX_DEV int ptx_id_lookup(const PtxIdIndex& ix, uint64_t id) {
+/* dense index (rank in compareOpIds order among the inserts) of the list element with this id, or -1 */
+PTX_DEV int ptx_elem_lookup(const PtxElemIndex& ix, uint64_t id) {
     uint32_t key;
     if (!ptx_id_key(ix, id, key)) return -1;
-    if (!ptx_bittest(ix.br.bits, key)) return -1;
-    return (int)ix.by_rank[ptx_bitrank(ix.br, key)];
+    return ptx_bitrank_if_set(ix.ib, key);
 }
 
 /* ---- LDS bump allocator ---- */
 struct PtxBump {
     uint8_t* base;
-    uint32_t off, cap;
+    uint32_t off, cap, high;
     bool overflow;
 };
 template <class T>
@@ -223,6 +293,7 @@ PTX_DEV T* ptx_alloc(PtxBump& b, uint32_t count) {
         return (T*)b.base; /* never dereferenced: callers bail out on overflow */
     }
     b.off += bytes;
+    if (b.off > b.high) b.high = b.off;
     return p;
 }
 
@@ -232,19 +303,55 @@ PTX_DEV uint32_t ptx_ceil_log2(uint32_t x) { /* smallest k with (1<<k) >= x, x>=
     return k;
 }
 
-PTX_DEV void ptx_write_result(const PtxMergeArgs& A, uint32_t log, PtxHdr* H, uint32_t status) {
+/* ---- LDS working set of ptx_merge_log (mirrors its ptx_alloc calls; used by the host to size the
+ *      launch and by the tests to check the bound).  N rows, n inserts, D deletes, K mark ops of
+ *      which Kc comment ops, id keyspace of ks bits. ---- */
+static inline uint64_t ptx_a16(uint64_t x) { return (x + 15) & ~15ull; }
+static inline uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
+    const uint64_t nw = (ks + 31) / 32;
+    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(N) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (n + D + K + 1)) +
+                             2 * ptx_a16(2 * (n + 1));
+    const uint64_t p2 = ptx_a16(4 * (nw + 1));
+    const uint64_t tree_phase = ptx_a16(4 * (n + 2)) + ptx_a16(2 * (n + 1)) + ptx_a16(4 * (2 * n + 2));
+    const uint64_t V = n; /* bound: every element visible */
+    uint64_t P2V = 1;
+    while (P2V < V) P2V <<= 1;
+    const uint64_t nwv = n / 32 + 1, nwq = V / 32 + 1;
+    uint64_t mark_phase = ptx_a16(8 * (nwv + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(4 * (K + 1)) + ptx_a16(8 * P2V) +
+                          ptx_a16(4 * (V + 1)) + ptx_a16(4 * (nwq + 1)) + ptx_a16(8 * (nwq + 1));
+    if (Kc) mark_phase += 3 * ptx_a16(4 * (Kc + 1)) + ptx_a16(8 * (Kc + 1));
+    uint64_t m = p2 > tree_phase ? p2 : tree_phase;
+    if (mark_phase > m) m = mark_phase;
+    return persist + m;
+}
+
+PTX_DEV void ptx_write_result(const PtxMergeArgs& A, uint32_t log, PtxHdr* H, uint32_t status, uint32_t lds_high) {
     PTX_LEADER {
+        const uint64_t ca = H->cnt_a;
         ptx_log_result r;
         r.status = status;
-        r.n_ops = status ? 0 : H->n_applied;
-        r.n_elems = status ? 0 : H->n_ins;
+        r.n_ops = status ? 0 : (uint32_t)(ca >> 48);
+        r.n_elems = status ? 0 : (uint32_t)(ca & 0xFFFFu);
         r.n_visible = status ? 0 : H->V;
         r.n_spans = status ? 0 : H->S;
         r.n_cintervals = status ? 0 : H->I;
-        r.reserved[0] = r.reserved[1] = 0;
+        r.reserved[0] = lds_high; /* LDS bytes this log needed (diagnostic; tests bound it by ptx_lds_need) */
+        r.reserved[1] = 0;
         r.digest[0] = status ? 0 : (uint64_t)H->h1;
         r.digest[1] = status ? 0 : (uint64_t)H->h2;
         A.res[log] = r;
+#ifndef PTX_EMU
+        if (A.clocks) {
+            H->clk[PTX_NCLK] = ptx_clock();
+            for (int k = 0; k < PTX_NCLK; ++k) {
+                /* phase k = time from stamp k to the next recorded stamp */
+                if (H->clk[k] == 0) continue;
+                int j = k + 1;
+                while (j < PTX_NCLK && H->clk[j] == 0) ++j;
+                atomicAdd(&A.clocks[k], H->clk[j] - H->clk[k]);
+            }
+        }
+#endif
     }
 }
 
@@ -310,18 +417,35 @@ PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
     return count;
 }
 
-/* Uniform early exit on a per-log error.  The status word is sampled between two barriers so that a
+/* Uniform early exit on a per-log error.  The error word is sampled between two barriers so that a
  * later phase's error write can never be seen by a thread that is still at this check point. */
-#define PTX_BAIL_IF_ERROR()                         \
-    do {                                            \
-        PTX_SYNC();                                 \
-        const uint32_t _st = H->status;             \
-        PTX_SYNC();                                 \
-        if (_st) {                                  \
-            ptx_write_result(A, log, H, _st);       \
-            return;                                 \
-        }                                           \
+#define PTX_BAIL_IF_ERROR()                                        \
+    do {                                                           \
+        PTX_SYNC();                                                \
+        const uint32_t _st = H->err;                               \
+        PTX_SYNC();                                                \
+        if (_st != PTX_NO_ERR) {                                   \
+            ptx_write_result(A, log, H, _st & 15u, bp.high);       \
+            return;                                                \
+        }                                                          \
     } while (0)
+
+#define PTX_BAIL_CAPACITY()                                        \
+    do {                                                           \
+        if (bp.overflow) {                                         \
+            ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);\
+            return;                                                \
+        }                                                          \
+    } while (0)
+
+#ifdef PTX_EMU
+#define PTX_STAMP(k) ((void)0)
+#else
+#define PTX_STAMP(k)                                               \
+    do {                                                           \
+        if (A.clocks && threadIdx.x == 0) H->clk[k] = ptx_clock(); \
+    } while (0)
+#endif
 
 /* ================================================================================================ */
 PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
@@ -329,17 +453,24 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     const uint64_t N64 = A.log_off[log + 1] - base;
     PtxHdr* H = (PtxHdr*)lds;
     PTX_LEADER {
-        H->status = 0;
+        H->err = PTX_NO_ERR;
         H->max_ctr = H->max_actor = 0;
-        H->n_ins = H->n_marks = H->n_applied = 0;
-        H->n_type[0] = H->n_type[1] = H->n_type[2] = H->n_type[3] = 0;
-        H->cur_a = H->cur_b = 0;
+        H->cur_i = H->cur_d = H->cur_m = H->cur_big = 0;
         H->V = H->S = H->I = 0;
+        H->cnt_a = H->cnt_t = 0;
         H->h1 = H->h2 = 0;
+        for (int k = 0; k <= PTX_NCLK; ++k) H->clk[k] = 0;
     }
+    PtxBump bp;
+    bp.base = lds;
+    bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
+    bp.cap = A.lds_bytes;
+    bp.high = bp.off;
+    bp.overflow = false;
     PTX_SYNC();
+    PTX_STAMP(0);
     if (N64 > 65534u) {
-        ptx_write_result(A, log, H, PTX_ERR_CAPACITY);
+        ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);
         return;
     }
     const uint32_t N = (uint32_t)N64;
@@ -348,25 +479,13 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     const uint64_t* ref_b = A.ref_b + base;
     const uint32_t* payload = A.payload + base;
 
-    PtxBump bp;
-    bp.base = lds;
-    bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
-    bp.cap = A.lds_bytes;
-    bp.overflow = false;
+    uint8_t* kind = ptx_alloc<uint8_t>(bp, N); /* action | mark_type << 4, per op row */
+    PTX_BAIL_CAPACITY();
 
-    uint8_t* kind = ptx_alloc<uint8_t>(bp, N);        /* action | mark_type << 4, per op row */
-    uint16_t* by_rank = ptx_alloc<uint16_t>(bp, N);   /* Lamport rank -> op row */
-    uint32_t* delbits = ptx_alloc<uint32_t>(bp, (N + 31) / 32 + 1); /* tombstone flag per op row */
-    uint16_t* rnk = ptx_alloc<uint16_t>(bp, N);       /* document position (incl. tombstones) per insert row */
-    if (bp.overflow) {
-        ptx_write_result(A, log, H, PTX_ERR_CAPACITY);
-        return;
-    }
-
-    /* ---- A0: load, classify, reduce ---- */
+    /* ---- P1: load, classify, reduce ---- */
     {
-        uint32_t mc = 0, ma = 0, ni = 0, nm = 0, nap = 0, bad = 0;
-        uint32_t nt0 = 0, nt1 = 0, nt2 = 0, nt3 = 0;
+        uint32_t mc = 0, ma = 0;
+        unsigned long long ca = 0, ct = 0;
         PTX_FOR(i, N) {
             const uint64_t id = op_id[i];
             const uint32_t ctr = (uint32_t)(id >> 32), act = (uint32_t)id;
@@ -374,332 +493,311 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
             kind[i] = (uint8_t)((a & 15u) | ((mt & 15u) << 4));
             mc = ctr > mc ? ctr : mc;
             ma = act > ma ? act : ma;
-            if (ctr == 0 || a > PTX_ACT_NOP) bad = 1;
-            if (a == PTX_ACT_INSERT) ni++;
-            if (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) {
-                nm++;
-                if (mt > 3) bad = 1;
-                else if (mt == 0) nt0++;
-                else if (mt == 1) nt1++;
-                else if (mt == 2) nt2++;
-                else nt3++;
+            if (ctr == 0 || a > PTX_ACT_NOP) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
+            if (a == PTX_ACT_INSERT) ca += 1ull;
+            else if (a == PTX_ACT_DELETE) ca += 1ull << 16;
+            else if (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) {
+                ca += 1ull << 32;
+                if (mt > 3) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
+                else ct += 1ull << (16 * mt);
             }
-            if (a != PTX_ACT_MAKELIST && a != PTX_ACT_NOP) nap++;
+            if (a != PTX_ACT_MAKELIST && a != PTX_ACT_NOP) ca += 1ull << 48;
+            if (A.out_rank) A.out_rank[base + i] = 0xFFFFFFFFu;
         }
-        PTX_FOR(w, (N + 31) / 32 + 1) delbits[w] = 0;
-        ptx_atomic_max(&H->max_ctr, mc);
-        ptx_atomic_max(&H->max_actor, ma);
-        ptx_atomic_add(&H->n_ins, ni);
-        ptx_atomic_add(&H->n_marks, nm);
-        ptx_atomic_add(&H->n_applied, nap);
-        ptx_atomic_add(&H->n_type[0], nt0);
-        ptx_atomic_add(&H->n_type[1], nt1);
-        ptx_atomic_add(&H->n_type[2], nt2);
-        ptx_atomic_add(&H->n_type[3], nt3);
-        if (bad) ptx_atomic_max(&H->status, PTX_ERR_BAD_OP);
+        ptx_reduce_max32(&H->max_ctr, mc);
+        ptx_reduce_max32(&H->max_actor, ma);
+        ptx_reduce_add64(&H->cnt_a, ca);
+        ptx_reduce_add64(&H->cnt_t, ct);
     }
     PTX_BAIL_IF_ERROR();
+    PTX_STAMP(1);
 
-    /* ---- A1..A3: Lamport rank of every op id ---- */
-    PtxIdIndex ix;
+    const uint32_t n = (uint32_t)(H->cnt_a & 0xFFFFu);         /* list elements (inserts) */
+    const uint32_t D = (uint32_t)((H->cnt_a >> 16) & 0xFFFFu); /* deletes */
+    const uint32_t K = (uint32_t)((H->cnt_a >> 32) & 0xFFFFu); /* mark ops */
+    const unsigned long long cnt_t = H->cnt_t; /* mark ops per mark type, 16 bits each */
+#define PTX_NTYPE(t) ((uint32_t)((cnt_t >> (16u * (t))) & 0xFFFFu))
+
+    PtxElemIndex ix;
     ix.max_ctr = H->max_ctr;
     ix.max_actor = H->max_actor;
     ix.abits = ptx_ceil_log2(ix.max_actor + 1);
-    ix.by_rank = by_rank;
-    if (ix.abits > 12 || ix.max_ctr >= (1u << 19)) { /* keyspace must stay far below 2^31 bits */
-        ptx_write_result(A, log, H, PTX_ERR_CAPACITY);
+    const uint32_t kbits = ptx_ceil_log2(K + 1);
+    if (ix.abits > 12 || ix.max_ctr >= (1u << 19) || n > 32766u) { /* keyspace far below 2^31 bits; 2n+1 tour nodes in 16 bits */
+        ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);
         return;
     }
     const uint32_t keyspace = (ix.max_ctr + 1u) << ix.abits;
-    const uint32_t nw = (keyspace + 31) / 32;
-    ix.br.bits = ptx_alloc<uint32_t>(bp, nw + 1);
-    ix.br.pre = ptx_alloc<uint16_t>(bp, nw + 1);
-    if (bp.overflow) {
-        ptx_write_result(A, log, H, PTX_ERR_CAPACITY);
+    if (((uint64_t)(keyspace + 1u) << kbits) > 0xFFFFFFFFull) { /* (key+1) << kbits | mark index in one u32 */
+        ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);
         return;
     }
-    PTX_FOR(w, nw + 1) ix.br.bits[w] = 0;
-    PTX_SYNC();
-    PTX_FOR(i, N) {
-        uint32_t key = 0;
-        ptx_id_key(ix, op_id[i], key);
-        const uint32_t bit = 1u << (key & 31);
-        if (ptx_atomic_or(&ix.br.bits[key >> 5], bit) & bit) ptx_atomic_max(&H->status, PTX_ERR_DUPLICATE_OP);
-    }
-    PTX_SYNC();
-    PTX_FOR(w, nw + 1) ix.br.pre[w] = (uint16_t)ptx_popc(ix.br.bits[w]);
-    PTX_SYNC();
-    ptx_scan_excl(ix.br.pre, nw + 1, H->scan_tmp);
-    PTX_BAIL_IF_ERROR();
-    PTX_FOR(i, N) {
-        uint32_t key = 0;
-        ptx_id_key(ix, op_id[i], key);
-        by_rank[ptx_bitrank(ix.br, key)] = (uint16_t)i;
-    }
-    PTX_SYNC();
-
-    const uint32_t n = H->n_ins;
+    const uint32_t nw = (keyspace + 31) / 32;
+    ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
+    uint16_t* list = ptx_alloc<uint16_t>(bp, n + D + K + 1); /* rows of the inserts | deletes | mark ops */
+    uint16_t* ilist = list;
+    uint16_t* dlist = list + n;
+    uint16_t* mlist = list + n + D;
+    uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1); /* element -> op row */
+    uint16_t* par = ptx_alloc<uint16_t>(bp, n + 1);    /* element -> parent element (n = HEAD); later: document position */
+    PTX_BAIL_CAPACITY();
     const uint32_t mark_lds = bp.off; /* everything above this mark is phase scratch */
 
-    /* ---- B: causal tree of the inserts, tombstone flags ---- */
+    /* ---- P2: id bitmaps, row lists ---- */
     {
-        const uint32_t M = (N + 2u) & ~1u; /* nodes: op rows 0..N-1 plus ROOT = N; even for alignment */
-        uint16_t* parent = ptx_alloc<uint16_t>(bp, M);
-        uint16_t* fc = ptx_alloc<uint16_t>(bp, M);
-        uint16_t* ns = ptx_alloc<uint16_t>(bp, M);
-        uint16_t* X = ptx_alloc<uint16_t>(bp, 4 * M); /* 4 work arrays; the sort keys alias them */
-        if (bp.overflow) {
-            ptx_write_result(A, log, H, PTX_ERR_CAPACITY);
-            return;
+        uint32_t* allbits = ptx_alloc<uint32_t>(bp, nw + 1); /* every op id: duplicate detection */
+        PTX_BAIL_CAPACITY();
+        PTX_FOR(w, nw + 1) {
+            PtxBitWord z;
+            z.bits = 0;
+            z.pre = 0;
+            ix.ib[w] = z;
+            allbits[w] = 0;
         }
-        uint16_t* X1 = X;
-        uint16_t* X2 = X + M;
-        uint16_t* X3 = X + 2 * M;
-        uint16_t* X4 = X + 3 * M;
-        uint32_t* keys = (uint32_t*)X;
-        uint32_t P2 = 1;
-        while (P2 < n) P2 <<= 1; /* 4*P2 < 8*N <= sizeof(X) */
-
-        PTX_FOR(i, N + 1) {
-            fc[i] = PTX_NONE;
-            ns[i] = PTX_NONE;
-        }
-        PTX_FOR(k, P2) keys[k] = 0xFFFFFFFFu;
         PTX_SYNC();
         PTX_FOR(i, N) {
+            uint32_t key = 0;
+            ptx_id_key(ix, op_id[i], key);
             const uint32_t a = kind[i] & 15u;
-            if (a == PTX_ACT_INSERT) {
-                const uint64_t ra = ref_a[i];
-                int p = (int)N;
-                if (ra != 0) {
-                    p = ptx_id_lookup(ix, ra);
-                    /* the reference element must already exist when the op is applied (micromerge.ts:752) */
-                    if (p < 0 || (uint32_t)p >= i || (kind[p] & 15u) != PTX_ACT_INSERT) {
-                        ptx_atomic_max(&H->status, PTX_ERR_ELEM_NOT_FOUND);
-                        p = (int)N;
-                    }
-                }
-                parent[i] = (uint16_t)p;
-                uint32_t key = 0;
-                ptx_id_key(ix, op_id[i], key);
-                const uint32_t r = ptx_bitrank(ix.br, key);
-                keys[ptx_atomic_add(&H->cur_a, 1u)] = ((uint32_t)p << 16) | (0xFFFFu - r);
-            } else if (a == PTX_ACT_DELETE) {
-                const int t = ptx_id_lookup(ix, ref_a[i]);
-                if (t < 0 || (uint32_t)t >= i || (kind[t] & 15u) != PTX_ACT_INSERT) {
-                    ptx_atomic_max(&H->status, PTX_ERR_ELEM_NOT_FOUND);
-                } else {
-                    ptx_atomic_or(&delbits[t >> 5], 1u << (t & 31));
-                }
-            }
-        }
-        PTX_BAIL_IF_ERROR();
-
-        /* siblings: ascending (parent, 0xFFFF - rank) == per parent, DESCENDING opId */
-        for (uint32_t k = 2; k <= P2; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                PTX_FOR(i, P2) {
-                    const uint32_t l = i ^ j;
-                    if (l > i) {
-                        const uint32_t x = keys[i], y = keys[l];
-                        const bool asc = (i & k) == 0;
-                        if ((x > y) == asc) {
-                            keys[i] = y;
-                            keys[l] = x;
-                        }
-                    }
-                }
-                PTX_SYNC();
-            }
-        }
-        PTX_FOR(k, n) {
-            const uint32_t key = keys[k];
-            const uint32_t p = key >> 16;
-            const uint32_t x = by_rank[0xFFFFu - (key & 0xFFFFu)];
-            if (k == 0 || (keys[k - 1] >> 16) != p) fc[p] = (uint16_t)x;
-            uint32_t nx = PTX_NONE;
-            if (k + 1 < n && (keys[k + 1] >> 16) == p) nx = by_rank[0xFFFFu - (keys[k + 1] & 0xFFFFu)];
-            ns[x] = (uint16_t)nx;
+            const uint32_t bit = 1u << (key & 31);
+            if (ptx_atomic_or(&allbits[key >> 5], bit) & bit) ptx_raise(H, i, 1, PTX_ERR_DUPLICATE_OP);
+            if (a == PTX_ACT_INSERT) ptx_atomic_or(&ix.ib[key >> 5].bits, bit);
+            const uint32_t ji = ptx_append(&H->cur_i, a == PTX_ACT_INSERT);
+            const uint32_t jd = ptx_append(&H->cur_d, a == PTX_ACT_DELETE);
+            const uint32_t jm = ptx_append(&H->cur_m, a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK);
+            if (a == PTX_ACT_INSERT) ilist[ji] = (uint16_t)i;
+            else if (a == PTX_ACT_DELETE) dlist[jd] = (uint16_t)i;
+            else if (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) mlist[jm] = (uint16_t)i;
         }
         PTX_SYNC();
+        PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
+        PTX_SYNC();
+        ptx_scan_excl<uint32_t, 2>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
+    }
+    PTX_BAIL_IF_ERROR();
+    bp.off = mark_lds;
+    PTX_STAMP(2);
 
-        if (n > 0) {
-            /* nearest ancestor-or-self that has a next sibling (ROOT is a fixed point) */
-            uint16_t* upA = X1;
-            uint16_t* upB = X2;
-            PTX_FOR(x, N + 1) {
-                if (x == N) upA[x] = (uint16_t)N;
-                else if ((kind[x] & 15u) == PTX_ACT_INSERT) upA[x] = ns[x] != PTX_NONE ? (uint16_t)x : parent[x];
+    /* ---- P3: causal tree of the inserts -> document position of every element ---- */
+    {
+        uint32_t* cnt = ptx_alloc<uint32_t>(bp, n + 2);     /* children per parent -> bucket starts -> bucket ends */
+        uint16_t* srt = ptx_alloc<uint16_t>(bp, n + 1);     /* children of every parent, descending opId, parents ascending */
+        uint32_t* L = ptx_alloc<uint32_t>(bp, 2 * n + 2);   /* Euler tour: next << 16 | weight */
+        PTX_BAIL_CAPACITY();
+        uint16_t* seg = (uint16_t*)L;   /* bucket members in arrival order (dead before L is built) */
+        uint16_t* big = seg + n + 1;    /* positions in seg of the members of large buckets */
+
+        PTX_FOR(p, n + 2) cnt[p] = 0;
+        PTX_SYNC();
+        PTX_FOR(j, n) {
+            const uint32_t i = ilist[j];
+            uint32_t key = 0;
+            ptx_id_key(ix, op_id[i], key);
+            const uint32_t e = ptx_bitrank(ix.ib, key);
+            row_of[e] = (uint16_t)i;
+            const uint64_t ra = ref_a[i];
+            uint32_t pe = n;
+            if (ra != 0) {
+                const int p = ptx_elem_lookup(ix, ra);
+                if (p < 0) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND); /* micromerge.ts:752 */
+                else pe = (uint32_t)p;
             }
-            PTX_SYNC();
-            for (uint32_t span = 1; span < n + 1; span <<= 1) {
-                PTX_FOR(x, N + 1) {
-                    if (x == N) upB[x] = (uint16_t)N;
-                    else if ((kind[x] & 15u) == PTX_ACT_INSERT) upB[x] = upA[upA[x]];
-                }
-                PTX_SYNC();
-                uint16_t* t = upA;
-                upA = upB;
-                upB = t;
+            par[e] = (uint16_t)pe;
+            ptx_atomic_add(&cnt[pe], 1u);
+        }
+        PTX_BAIL_IF_ERROR();
+        ptx_scan_excl<uint32_t, 1>(cnt, n + 2, H->scan_tmp); /* cnt[p] = first slot of p's children */
+        PTX_FOR(e, n) {
+            const uint32_t pe = par[e];
+            /* the reference element must already exist when the op is applied (micromerge.ts:752) */
+            if (pe < n && row_of[pe] >= row_of[e]) ptx_raise(H, row_of[e], 1, PTX_ERR_ELEM_NOT_FOUND);
+            seg[ptx_atomic_add(&cnt[pe], 1u)] = (uint16_t)e; /* now cnt[p] runs to the END of p's bucket */
+        }
+        PTX_BAIL_IF_ERROR();
+        PTX_STAMP(3);
+        /* rank inside the bucket: descending element index == descending opId */
+        PTX_FOR(j, n) {
+            const uint32_t x = seg[j];
+            const uint32_t p = par[x];
+            const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
+            const bool is_big = t - s > PTX_SMALL_BUCKET;
+            if (!is_big) {
+                uint32_t c = 0;
+                for (uint32_t k = s; k < t; ++k) c += seg[k] > x ? 1u : 0u;
+                srt[s + c] = (uint16_t)x;
             }
-            /* pre-order successor, then distance to the end of the list by pointer jumping */
-            uint16_t* nxA = X3;
-            uint16_t* dA = X4;
-            PTX_FOR(x, N) {
-                if ((kind[x] & 15u) == PTX_ACT_INSERT) {
-                    uint32_t s = fc[x];
-                    if (s == PTX_NONE) s = ns[upA[x]]; /* ns[ROOT] == NONE: end of list */
-                    nxA[x] = (uint16_t)s;
-                    dA[x] = s == PTX_NONE ? 0 : 1;
-                }
+            const uint32_t jb = ptx_append(&H->cur_big, is_big);
+            if (is_big) big[jb] = (uint16_t)j;
+        }
+        PTX_SYNC();
+        {
+            const uint32_t nb = H->cur_big;
+            PTX_FOR(b, nb) {
+                const uint32_t x = seg[big[b]];
+                const uint32_t p = par[x];
+                const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
+                uint32_t c = 0;
+                for (uint32_t k = s; k < t; ++k) c += seg[k] > x ? 1u : 0u;
+                srt[s + c] = (uint16_t)x;
             }
-            PTX_SYNC();
-            uint16_t* nxB = X1; /* the two `up` arrays are dead now: reuse them as the ping-pong halves */
-            uint16_t* dB = X2;
-            for (uint32_t span = 1; span < n; span <<= 1) {
-                PTX_FOR(x, N) {
-                    if ((kind[x] & 15u) == PTX_ACT_INSERT) {
-                        const uint32_t nx = nxA[x];
-                        if (nx != PTX_NONE) {
-                            dB[x] = (uint16_t)(dA[x] + dA[nx]);
-                            nxB[x] = nxA[nx];
-                        } else {
-                            dB[x] = dA[x];
-                            nxB[x] = PTX_NONE;
-                        }
+        }
+        PTX_SYNC();
+        PTX_STAMP(4);
+        /* Euler tour.  Nodes: enter(x) = x for x in [0,n] (n = HEAD), exit(x) = n+1+x for x in [0,n).
+         * weight 1 on enter(x<n): the suffix sum at enter(x) counts the elements from x to the end. */
+        PTX_FOR(j, n + 1) {
+            const uint32_t s = j ? cnt[j - 1] : 0u, t = cnt[j];
+            uint32_t nx = t > s ? (uint32_t)srt[s] : (j == n ? PTX_END : n + 1u + j);
+            const uint32_t mine = (nx << 16) | (j < n ? 1u : 0u);
+            uint32_t xo = 0, other = 0;
+            if (j < n) {
+                const uint32_t x = srt[j];
+                const uint32_t p = par[x];
+                const uint32_t nx2 = j + 1u < cnt[p] ? (uint32_t)srt[j + 1] : (p == n ? PTX_END : n + 1u + p);
+                xo = n + 1u + x;
+                other = nx2 << 16;
+            }
+            L[j] = mine;
+            if (j < n) L[xo] = other;
+        }
+        PTX_SYNC();
+        {
+            const uint32_t nodes = 2 * n + 1;
+            const uint32_t rounds = ptx_ceil_log2(nodes);
+            for (uint32_t r = 0; r < rounds; ++r) {
+                /* in-place pointer jumping: every intermediate {next, weight} word is a valid state
+                 * (weight = sum over [node, next)), so reading a word another thread already advanced
+                 * this round only makes the jump longer */
+                PTX_FOR(v, nodes) {
+                    const uint32_t a = L[v];
+                    const uint32_t nx = a >> 16;
+                    if (nx != PTX_END) {
+                        const uint32_t b = L[nx];
+                        L[v] = (b & 0xFFFF0000u) | ((a + b) & 0xFFFFu);
                     }
                 }
                 PTX_SYNC();
-                uint16_t* t = nxA;
-                nxA = nxB;
-                nxB = t;
-                t = dA;
-                dA = dB;
-                dB = t;
             }
-            PTX_FOR(x, N) {
-                if ((kind[x] & 15u) == PTX_ACT_INSERT) rnk[x] = (uint16_t)(n - 1u - dA[x]);
-            }
-            PTX_SYNC();
         }
+        PTX_FOR(e, n) par[e] = (uint16_t)(n - (L[e] & 0xFFFFu)); /* document position incl. tombstones */
+        PTX_SYNC();
     }
+    uint16_t* rnk = par;
     bp.off = mark_lds; /* release the tree scratch */
+    PTX_STAMP(5);
 
-    /* ---- C: tombstone-aware visible index ---- */
+    /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = n / 32 + 1; /* bit positions 0..n */
-    PtxBitRank alive;
-    alive.bits = ptx_alloc<uint32_t>(bp, nwv + 1);
-    alive.pre = ptx_alloc<uint16_t>(bp, nwv + 1);
-    const uint32_t K = H->n_marks;
-    uint16_t* mrk_op = ptx_alloc<uint16_t>(bp, K + 1);
+    PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
     uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
     uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
-    uint16_t* mrk_r = ptx_alloc<uint16_t>(bp, K + 1);
-    if (bp.overflow) {
-        ptx_write_result(A, log, H, PTX_ERR_CAPACITY);
-        return;
+    uint32_t* mrk_val = ptx_alloc<uint32_t>(bp, K + 1); /* (key + 1) << kbits | mark index: LWW order + who won */
+    PTX_BAIL_CAPACITY();
+    PTX_FOR(w, nwv + 1) {
+        PtxBitWord z;
+        const uint32_t lo = w * 32u;
+        z.bits = lo + 32u <= n ? 0xFFFFFFFFu : (lo < n ? (1u << (n - lo)) - 1u : 0u);
+        z.pre = 0;
+        alive[w] = z;
     }
-    PTX_FOR(w, nwv + 1) alive.bits[w] = 0;
     PTX_SYNC();
-    PTX_FOR(x, N) {
-        if ((kind[x] & 15u) == PTX_ACT_INSERT && !ptx_bittest(delbits, x)) {
-            const uint32_t r = rnk[x];
-            ptx_atomic_or(&alive.bits[r >> 5], 1u << (r & 31));
+    PTX_FOR(j, D) {
+        const uint32_t i = dlist[j];
+        const int t = ptx_elem_lookup(ix, ref_a[i]);
+        if (t < 0 || row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND); /* micromerge.ts:752 */
+        else {
+            const uint32_t r = rnk[t];
+            ptx_atomic_and(&alive[r >> 5].bits, ~(1u << (r & 31))); /* idempotent: micromerge.ts:693 */
         }
     }
+    PTX_BAIL_IF_ERROR();
+    PTX_FOR(w, nwv + 1) alive[w].pre = ptx_popc(alive[w].bits);
     PTX_SYNC();
-    PTX_FOR(w, nwv + 1) alive.pre[w] = (uint16_t)ptx_popc(alive.bits[w]);
-    PTX_SYNC();
-    const uint32_t V = ptx_scan_excl(alive.pre, nwv + 1, H->scan_tmp);
-    PTX_SYNC();
+    const uint32_t V = ptx_scan_excl<uint32_t, 2>(&alive[0].pre, nwv + 1, H->scan_tmp);
+    PTX_STAMP(6);
     {
         uint64_t h1 = 0, h2 = 0;
-        PTX_FOR(x, N) {
-            uint32_t rr = 0xFFFFFFFFu;
-            if ((kind[x] & 15u) == PTX_ACT_INSERT) {
-                rr = rnk[x];
-                if (!ptx_bittest(delbits, x)) {
-                    const uint32_t q = ptx_bitrank(alive, rr);
-                    const uint32_t v = payload[x];
-                    A.out_values[base + q] = v;
-                    ptx_digest_item(h1, h2, 1u, q, v, 0u);
-                }
+        PTX_FOR(e, n) {
+            const uint32_t r = rnk[e];
+            const PtxBitWord w = alive[r >> 5];
+            const uint32_t row = row_of[e];
+            if ((w.bits >> (r & 31)) & 1u) {
+                const uint32_t q = w.pre + ptx_popc(w.bits & ((1u << (r & 31)) - 1u));
+                const uint32_t v = payload[row];
+                A.out_values[base + q] = v;
+                ptx_digest_item(h1, h2, 1u, q, v, 0u);
             }
-            if (A.out_rank) A.out_rank[base + x] = rr;
+            if (A.out_rank) A.out_rank[base + row] = r;
         }
         ptx_digest_flush(H, h1, h2);
     }
 
-    /* ---- D1: every mark op -> visible interval [lo, hi) ---- */
-    PTX_FOR(i, N) {
-        const uint32_t a = kind[i] & 15u;
-        if (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) {
-            const uint32_t k = ptx_atomic_add(&H->cur_b, 1u);
-            const uint32_t sa = A.side_a[base + i], sb = A.side_b[base + i];
-            uint32_t lo = 0, hi = 0;
-            /* start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is
-               not in the list when the op is applied means the op never starts */
-            int js = -1;
-            if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
-                js = ptx_id_lookup(ix, ref_a[i]);
-                if (js >= 0 && ((uint32_t)js >= i || (kind[js] & 15u) != PTX_ACT_INSERT)) js = -1;
-            }
-            if (js >= 0) {
-                const uint32_t slot_a = 2u * rnk[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
-                uint32_t slot_b = 0xFFFFFFFFu; /* never reached: runs to the end of the text */
-                if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
-                    int je = ptx_id_lookup(ix, ref_b[i]);
-                    if (je >= 0 && ((uint32_t)je >= i || (kind[je] & 15u) != PTX_ACT_INSERT)) je = -1;
-                    if (je >= 0) slot_b = 2u * rnk[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
-                }
-                /* same slot: the start test fires first and the end is never seen */
-                if (slot_b == slot_a) slot_b = 0xFFFFFFFFu;
-                if (slot_b > slot_a) {
-                    const uint32_t lo_rank = (slot_a + 1u) >> 1;
-                    const uint32_t hi_rank = slot_b == 0xFFFFFFFFu ? n : (slot_b + 1u) >> 1;
-                    lo = ptx_bitrank(alive, lo_rank);
-                    hi = ptx_bitrank(alive, hi_rank);
-                }
-            }
-            uint32_t key = 0;
-            ptx_id_key(ix, op_id[i], key);
-            mrk_op[k] = (uint16_t)i;
-            mrk_lo[k] = (uint16_t)lo;
-            mrk_hi[k] = (uint16_t)hi;
-            mrk_r[k] = (uint16_t)ptx_bitrank(ix.br, key);
+    /* ---- P5a: every mark op -> visible interval [lo, hi) ---- */
+    PTX_FOR(k, K) {
+        const uint32_t i = mlist[k];
+        const uint32_t sa = A.side_a[base + i], sb = A.side_b[base + i];
+        uint32_t lo = 0, hi = 0;
+        /* start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is
+           not in the list when the op is applied means the op never starts */
+        int js = -1;
+        if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
+            js = ptx_elem_lookup(ix, ref_a[i]);
+            if (js >= 0 && row_of[js] >= i) js = -1;
         }
+        if (js >= 0) {
+            const uint32_t slot_a = 2u * rnk[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
+            uint32_t slot_b = 0xFFFFFFFFu; /* never reached: runs to the end of the text */
+            if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
+                int je = ptx_elem_lookup(ix, ref_b[i]);
+                if (je >= 0 && row_of[je] >= i) je = -1;
+                if (je >= 0) slot_b = 2u * rnk[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
+            }
+            /* same slot: the start test fires first and the end is never seen */
+            if (slot_b == slot_a) slot_b = 0xFFFFFFFFu;
+            if (slot_b > slot_a) {
+                const uint32_t lo_rank = (slot_a + 1u) >> 1;
+                const uint32_t hi_rank = slot_b == 0xFFFFFFFFu ? n : (slot_b + 1u) >> 1;
+                lo = ptx_bitrank(alive, lo_rank);
+                hi = ptx_bitrank(alive, hi_rank);
+            }
+        }
+        uint32_t key = 0;
+        ptx_id_key(ix, op_id[i], key);
+        mrk_lo[k] = (uint16_t)lo;
+        mrk_hi[k] = (uint16_t)hi;
+        mrk_val[k] = ((key + 1u) << kbits) | k;
     }
     PTX_SYNC();
+    PTX_STAMP(7);
 
-    /* ---- D2: per visible char, the winning op of each non-multi mark type (LWW by opId) ---- */
+    /* ---- P5b: per visible char, the winning op of each non-multi mark type (LWW by opId) ---- */
     uint32_t P2V = 1;
     while (P2V < V) P2V <<= 1;
     uint32_t* tree = ptx_alloc<uint32_t>(bp, 2 * P2V);
     uint32_t* attr = ptx_alloc<uint32_t>(bp, V + 1);
     const uint32_t nwq = V / 32 + 1;
     uint32_t* brkbits = ptx_alloc<uint32_t>(bp, nwq + 1);
-    PtxBitRank st;
-    st.bits = ptx_alloc<uint32_t>(bp, nwq + 1);
-    st.pre = ptx_alloc<uint16_t>(bp, nwq + 1);
-    if (bp.overflow) {
-        ptx_write_result(A, log, H, PTX_ERR_CAPACITY);
-        return;
-    }
+    PtxBitWord* st = ptx_alloc<PtxBitWord>(bp, nwq + 1);
+    PTX_BAIL_CAPACITY();
     PTX_FOR(q, V + 1) attr[q] = 0;
     PTX_FOR(w, nwq + 1) {
+        PtxBitWord z;
+        z.bits = 0;
+        z.pre = 0;
         brkbits[w] = 0;
-        st.bits[w] = 0;
+        st[w] = z;
     }
     PTX_SYNC();
+    const uint32_t kmask = (1u << kbits) - 1u;
     for (uint32_t pass = 0; pass < 4; ++pass) {
         /* pass = mark type; the comment pass only asks "is any comment op covering" (key present) */
-        if (V == 0 || H->n_type[pass] == 0) continue;
+        if (V == 0 || PTX_NTYPE(pass) == 0) continue;
         PTX_FOR(p, 2 * P2V) tree[p] = 0;
         PTX_SYNC();
         PTX_FOR(k, K) {
-            const uint32_t i = mrk_op[k];
+            const uint32_t i = mlist[k];
             if ((uint32_t)(kind[i] >> 4) == pass && mrk_lo[k] < mrk_hi[k]) {
-                ptx_tree_chmax(tree, P2V, mrk_lo[k], mrk_hi[k], pass == PTX_MARK_COMMENT ? 1u : (uint32_t)mrk_r[k] + 1u);
+                ptx_tree_chmax(tree, P2V, mrk_lo[k], mrk_hi[k], pass == PTX_MARK_COMMENT ? 1u : mrk_val[k]);
             }
         }
         PTX_SYNC();
@@ -709,7 +807,7 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                 if (pass == PTX_MARK_COMMENT) {
                     attr[q] |= PTX_ATTR_COMMENT;
                 } else {
-                    const uint32_t i = by_rank[w - 1u];
+                    const uint32_t i = mlist[w & kmask];
                     if ((kind[i] & 15u) == PTX_ACT_ADDMARK) {
                         if (pass == PTX_MARK_STRONG) attr[q] |= PTX_ATTR_STRONG;
                         else if (pass == PTX_MARK_EM) attr[q] |= PTX_ATTR_EM;
@@ -720,18 +818,16 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         }
         PTX_SYNC();
     }
+    PTX_STAMP(8);
 
-    /* ---- D3: comments: per id, presence intervals decided by the last-applied covering op ---- */
-    const uint32_t Kc = H->n_type[PTX_MARK_COMMENT];
+    /* ---- P5c: comments: per id, presence intervals decided by the last-applied covering op ---- */
+    const uint32_t Kc = PTX_NTYPE(PTX_MARK_COMMENT);
     if (Kc > 0) {
         uint32_t* ccnt = ptx_alloc<uint32_t>(bp, Kc + 1);
         uint32_t* ccur = ptx_alloc<uint32_t>(bp, Kc + 1);
         uint32_t* cicnt = ptx_alloc<uint32_t>(bp, Kc + 1);
         PtxCEntry* cent = ptx_alloc<PtxCEntry>(bp, Kc + 1);
-        if (bp.overflow) {
-            ptx_write_result(A, log, H, PTX_ERR_CAPACITY);
-            return;
-        }
+        PTX_BAIL_CAPACITY();
         PTX_FOR(c, Kc + 1) {
             ccnt[c] = 0;
             ccur[c] = 0;
@@ -739,18 +835,17 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         }
         PTX_SYNC();
         PTX_FOR(k, K) {
-            const uint32_t i = mrk_op[k];
+            const uint32_t i = mlist[k];
             if ((uint32_t)(kind[i] >> 4) == PTX_MARK_COMMENT) {
                 const uint32_t c = payload[i];
-                if (c >= Kc) ptx_atomic_max(&H->status, PTX_ERR_BAD_OP); /* ids must be dense per doc */
+                if (c >= Kc) ptx_raise(H, i, 1, PTX_ERR_BAD_OP); /* ids must be dense per doc */
                 else if (mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[c], 1u);
             }
         }
         PTX_BAIL_IF_ERROR();
-        ptx_scan_excl(ccnt, Kc + 1, H->scan_tmp); /* ccnt[c] = first entry of id c, ccnt[Kc] = total */
-        PTX_SYNC();
+        ptx_scan_excl<uint32_t, 1>(ccnt, Kc + 1, H->scan_tmp); /* ccnt[c] = first entry of id c, ccnt[Kc] = total */
         PTX_FOR(k, K) {
-            const uint32_t i = mrk_op[k];
+            const uint32_t i = mlist[k];
             if ((uint32_t)(kind[i] >> 4) == PTX_MARK_COMMENT && mrk_lo[k] < mrk_hi[k]) {
                 const uint32_t c = payload[i];
                 const uint32_t pos = ccnt[c] + ptx_atomic_add(&ccur[c], 1u);
@@ -767,8 +862,7 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
             cicnt[c] = ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {});
         }
         PTX_SYNC();
-        const uint32_t I = ptx_scan_excl(cicnt, Kc + 1, H->scan_tmp);
-        PTX_SYNC();
+        const uint32_t I = ptx_scan_excl<uint32_t, 1>(cicnt, Kc + 1, H->scan_tmp);
         PTX_LEADER { H->I = I; }
         {
             uint64_t h1 = 0, h2 = 0;
@@ -789,22 +883,23 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         }
         PTX_SYNC();
     }
+    PTX_STAMP(9);
 
-    /* ---- E: spans = maximal runs of equal marks over the visible chars ---- */
+    /* ---- P6: spans = maximal runs of equal marks over the visible chars ---- */
     PTX_FOR(q, V) {
         const bool is_start = q == 0 || attr[q] != attr[q - 1] || ptx_bittest(brkbits, q);
-        if (is_start) ptx_atomic_or(&st.bits[q >> 5], 1u << (q & 31));
+        if (is_start) ptx_atomic_or(&st[q >> 5].bits, 1u << (q & 31));
     }
     PTX_SYNC();
-    PTX_FOR(w, nwq + 1) st.pre[w] = (uint16_t)ptx_popc(st.bits[w]);
+    PTX_FOR(w, nwq + 1) st[w].pre = ptx_popc(st[w].bits);
     PTX_SYNC();
-    const uint32_t S = ptx_scan_excl(st.pre, nwq + 1, H->scan_tmp);
-    PTX_SYNC();
+    const uint32_t S = ptx_scan_excl<uint32_t, 2>(&st[0].pre, nwq + 1, H->scan_tmp);
     {
         uint64_t h1 = 0, h2 = 0;
         PTX_FOR(q, V) {
-            if (ptx_bittest(st.bits, q)) {
-                const uint32_t s = ptx_bitrank(st, q);
+            const PtxBitWord w = st[q >> 5];
+            if ((w.bits >> (q & 31)) & 1u) {
+                const uint32_t s = w.pre + ptx_popc(w.bits & ((1u << (q & 31)) - 1u));
                 ptx_span sp;
                 sp.start = q;
                 sp.attr = attr[q];
@@ -825,5 +920,6 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         H->h2 += h2;
     }
     PTX_SYNC();
-    ptx_write_result(A, log, H, PTX_OK);
+    PTX_STAMP(10);
+    ptx_write_result(A, log, H, PTX_OK, bp.high);
 }

@@ -64,6 +64,7 @@ struct ptx_ctx {
     int force_threads = 0; /* PTX_THREADS env override (tuning) */
     int force_lds = 0;     /* PTX_LDS_BYTES env override (tuning) */
     uint32_t flags = 0;
+    unsigned long long* clocks = nullptr; /* device [PTX_NCLK], non-null only while ptx_merge_phase_cycles runs */
 };
 
 struct ptx_dbatch {
@@ -106,30 +107,12 @@ static ptx_status fail(ptx_ctx* ctx, ptx_status st, const std::string& msg) {
         }                                                                                           \
     } while (0)
 
-/* Upper bound of the LDS working set of merge_core.h for a log with N rows, n inserts, K mark ops,
- * Kc comment ops and an id keyspace of `ks` bits (mirrors the ptx_alloc calls there). */
-static uint64_t a16(uint64_t x) { return (x + 15) & ~15ull; }
-static uint64_t lds_need(uint64_t N, uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks) {
-    const uint64_t nw = (ks + 31) / 32;
-    uint64_t persist = a16(sizeof(PtxHdr)) + a16(N) + a16(2 * N) + a16(4 * ((N + 31) / 32 + 1)) + a16(2 * N) + a16(4 * (nw + 1)) + a16(2 * (nw + 1));
-    const uint64_t M = (N + 2) & ~1ull;
-    const uint64_t tree_phase = 3 * a16(2 * M) + a16(8 * M);
-    const uint64_t V = n; /* bound: every element visible */
-    uint64_t P2V = 1;
-    while (P2V < V) P2V <<= 1;
-    const uint64_t nwv = n / 32 + 1, nwq = V / 32 + 1;
-    uint64_t mark_phase = a16(4 * (nwv + 1)) + a16(2 * (nwv + 1)) + 4 * a16(2 * (K + 1)) + a16(8 * P2V) + a16(4 * (V + 1)) +
-                          2 * a16(4 * (nwq + 1)) + a16(2 * (nwq + 1));
-    if (Kc) mark_phase += 3 * a16(4 * (Kc + 1)) + a16(8 * (Kc + 1));
-    return persist + std::max(tree_phase, mark_phase);
-}
-
 static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t max_log_ops) {
     b->max_log_ops = max_log_ops;
     uint64_t lds = std::min<uint64_t>(std::max<uint64_t>(need, 4096), ctx->max_lds);
     if (ctx->force_lds) lds = (uint64_t)ctx->force_lds;
     b->lds_bytes = (uint32_t)lds;
-    uint32_t t = max_log_ops <= 1024 ? 256u : max_log_ops <= 2304 ? 512u : 1024u;
+    uint32_t t = max_log_ops <= 512 ? 128u : 256u;
     if (ctx->force_threads) t = (uint32_t)ctx->force_threads;
     b->threads = t;
 }
@@ -140,11 +123,12 @@ static uint64_t scan_host_batch(const ptx_batch* h, uint32_t* max_log_ops) {
     uint32_t mx = 0;
     for (uint32_t l = 0; l < h->n_logs; ++l) {
         const uint64_t b0 = h->log_off[l], b1 = h->log_off[l + 1];
-        uint64_t n = 0, K = 0, Kc = 0;
+        uint64_t n = 0, Dn = 0, K = 0, Kc = 0;
         uint32_t mc = 0, ma = 0;
         for (uint64_t i = b0; i < b1; ++i) {
             const uint8_t a = h->action[i];
             if (a == PTX_ACT_INSERT) n++;
+            else if (a == PTX_ACT_DELETE) Dn++;
             else if (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) {
                 K++;
                 if (h->mark_type[i] == PTX_MARK_COMMENT) Kc++;
@@ -155,7 +139,7 @@ static uint64_t scan_host_batch(const ptx_batch* h, uint32_t* max_log_ops) {
         uint32_t abits = 0;
         while ((1u << abits) < ma + 1u) ++abits;
         const uint64_t ks = ((uint64_t)mc + 1) << std::min(abits, 12u);
-        need = std::max(need, lds_need(b1 - b0, n, K, Kc, ks));
+        need = std::max(need, ptx_lds_need(b1 - b0, n, Dn, K, Kc, ks));
         mx = std::max<uint32_t>(mx, (uint32_t)std::min<uint64_t>(b1 - b0, 0xFFFFFFFFull));
     }
     *max_log_ops = mx;
@@ -238,7 +222,7 @@ uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx) {
     uint32_t lo = 0, hi = 65534;
     while (lo < hi) {
         const uint32_t mid = (lo + hi + 1) / 2;
-        const uint64_t worst = std::max(lds_need(mid, mid, 0, 0, 4ull * mid), lds_need(mid, mid / 2, mid / 2, mid / 2, 4ull * mid));
+        const uint64_t worst = std::max(ptx_lds_need(mid, mid, 0, 0, 0, 4ull * mid), ptx_lds_need(mid, mid / 2, 0, mid / 2, mid / 2, 4ull * mid));
         if (worst <= lds) lo = mid;
         else hi = mid - 1;
     }
@@ -411,6 +395,11 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.mark_type = b->mark_type;
     A.side_a = b->side_a;
     A.side_b = b->side_b;
+    A.chg_off = nullptr;
+    A.chg_actor = A.chg_seq = A.chg_nops = A.chg_deps = nullptr;
+    A.max_actors = 0;
+    A.clocks = ctx->clocks;
+    A.pad = 0;
     A.res = r->logs;
     A.out_values = r->values;
     A.out_spans = r->spans;
@@ -445,6 +434,29 @@ ptx_status ptx_merge_timed(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, ui
     PTX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     PTX_HIP(ctx, hipEventSynchronize(ctx->ev1));
     PTX_HIP(ctx, hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return PTX_OK;
+}
+
+ptx_status ptx_merge_phase_cycles(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, uint64_t* cycles, uint32_t n) {
+    if (!ctx || !b || !r || !cycles) return PTX_ERR_INVALID_ARG;
+    if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long* d = nullptr;
+    PTX_HIP(ctx, hipMalloc((void**)&d, PTX_NCLK * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, PTX_NCLK * sizeof(unsigned long long), ctx->stream);
+    ptx_status st = PTX_OK;
+    if (e == hipSuccess) {
+        ctx->clocks = d;
+        st = launch_merge(ctx, b, r);
+        ctx->clocks = nullptr;
+    }
+    unsigned long long h[PTX_NCLK];
+    if (e == hipSuccess && st == PTX_OK) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (st) return st;
+    if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("phase cycles: ") + hipGetErrorString(e));
+    for (uint32_t k = 0; k < n; ++k) cycles[k] = k < PTX_NCLK ? (uint64_t)h[k] : 0;
     return PTX_OK;
 }
 

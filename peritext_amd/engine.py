@@ -120,6 +120,12 @@ class Engine:
         self._check(self.lib.ptx_merge_timed(self.ctx, dbatch, dresult, iters, C.byref(ms)))
         return float(ms.value)
 
+    def phase_cycles(self, dbatch, dresult, n=16):
+        """Diagnostic: shader-clock cycles per phase of merge_core.h, summed over all workgroups."""
+        out = (C.c_uint64 * n)()
+        self._check(self.lib.ptx_merge_phase_cycles(self.ctx, dbatch, dresult, out, n))
+        return [int(x) for x in out]
+
     def sync(self):
         self._check(self.lib.ptx_sync(self.ctx))
 

@@ -25,6 +25,11 @@ extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* 
     A.mark_type = b->mark_type;
     A.side_a = b->side_a;
     A.side_b = b->side_b;
+    A.chg_off = nullptr; /* causal admission is exercised through ptx_emu_merge_admit */
+    A.chg_actor = A.chg_seq = A.chg_nops = A.chg_deps = nullptr;
+    A.max_actors = b->max_actors;
+    A.clocks = nullptr;
+    A.pad = 0;
     A.res = res;
     A.out_values = values;
     A.out_spans = spans;
@@ -41,4 +46,9 @@ extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* 
     }
     free(lds);
     return 0;
+}
+
+/* LDS bound the host uses to size the launch (tests check it against the measured high-water mark) */
+extern "C" uint64_t ptx_emu_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
+    return ptx_lds_need(N, n, D, K, Kc, ks);
 }
