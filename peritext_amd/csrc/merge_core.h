@@ -57,6 +57,11 @@ PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); 
 /* append to a list: index of this element (valid only where pred) */
 PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }
 PTX_DEV uint64_t ptx_clock() { return 0; }
+#define PTX_G 1u
+PTX_DEV uint32_t ptx_group_sum(uint32_t c) { return c; }
+/* batched parallel loop: PTX_U iterations per step so that their loads are all in flight together */
+#define PTX_FORU(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_U)
+#define PTX_IX(i0, u) (ptx_emu_reverse ? _n - 1u - ((i0) + (uint32_t)(u)) : (i0) + (uint32_t)(u))
 #else
 #include <hip/hip_runtime.h>
 #define PTX_DEV __device__ __forceinline__
@@ -82,7 +87,17 @@ PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) {
     return b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 PTX_DEV uint64_t ptx_clock() { return (uint64_t)__builtin_readcyclecounter(); }
+#define PTX_G 8u /* lanes that share one member of a large child bucket */
+PTX_DEV uint32_t ptx_group_sum(uint32_t c) {
+    c += (uint32_t)__shfl_xor((int)c, 1, 64);
+    c += (uint32_t)__shfl_xor((int)c, 2, 64);
+    c += (uint32_t)__shfl_xor((int)c, 4, 64);
+    return c;
+}
+#define PTX_FORU(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = blockDim.x; i0 < _n; i0 += PTX_U * _T)
+#define PTX_IX(i0, u) ((i0) + (uint32_t)(u) * _T)
 #endif
+#define PTX_IN(i0, u) ((i0) + (uint32_t)(u) * _T < _n)
 
 /* kernel arguments: device pointers (host pointers under PTX_EMU) */
 struct PtxMergeArgs {
@@ -114,6 +129,11 @@ struct PtxMergeArgs {
 };
 
 #define PTX_END 0xFFFFu
+#define PTX_TILE_4 128u  /* visible chars up to which the four LWW trees are resident at once */
+#define PTX_TILE_1 512u  /* tile of the visible axis for longer documents (one tree, reused per mark type) */
+#ifndef PTX_U
+#define PTX_U 4 /* rows in flight per thread in the batched loops */
+#endif
 #define PTX_NCLK 16
 #define PTX_SMALL_BUCKET 8u
 
@@ -137,9 +157,10 @@ PTX_DEV void ptx_digest_item(uint64_t& h1, uint64_t& h2, uint32_t tag, uint32_t 
 struct PtxHdr {
     uint32_t err;          /* min over ((row*2+level) << 4 | code) of every detected error; ~0 = none */
     uint32_t max_ctr, max_actor;
-    uint32_t cur_i, cur_d, cur_m, cur_big;
+    uint32_t cur_i, cur_d, cur_big;
+    uint32_t cur_t[4]; /* per mark type */
     uint32_t V, S, I;
-    uint32_t pad[2];
+    uint32_t pad[1];
     unsigned long long cnt_a; /* n_ins | n_del << 16 | n_marks << 32 | n_applied << 48 */
     unsigned long long cnt_t; /* mark ops per mark type, 16 bits each */
     unsigned long long h1, h2;
@@ -308,20 +329,20 @@ PTX_DEV uint32_t ptx_ceil_log2(uint32_t x) { /* smallest k with (1<<k) >= x, x>=
  *      which Kc comment ops, id keyspace of ks bits. ---- */
 static inline uint64_t ptx_a16(uint64_t x) { return (x + 15) & ~15ull; }
 static inline uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
-    const uint64_t nw = (ks + 31) / 32;
-    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(N) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (n + D + K + 1)) +
-                             2 * ptx_a16(2 * (n + 1));
-    const uint64_t p2 = ptx_a16(4 * (nw + 1));
-    const uint64_t tree_phase = ptx_a16(4 * (n + 2)) + ptx_a16(2 * (n + 1)) + ptx_a16(4 * (2 * n + 2));
-    const uint64_t V = n; /* bound: every element visible */
-    uint64_t P2V = 1;
-    while (P2V < V) P2V <<= 1;
-    const uint64_t nwv = n / 32 + 1, nwq = V / 32 + 1;
-    uint64_t mark_phase = ptx_a16(8 * (nwv + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(4 * (K + 1)) + ptx_a16(8 * P2V) +
-                          ptx_a16(4 * (V + 1)) + ptx_a16(4 * (nwq + 1)) + ptx_a16(8 * (nwq + 1));
-    if (Kc) mark_phase += 3 * ptx_a16(4 * (Kc + 1)) + ptx_a16(8 * (Kc + 1));
-    uint64_t m = p2 > tree_phase ? p2 : tree_phase;
-    if (mark_phase > m) m = mark_phase;
+    const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
+    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (n + D + K + 1)) + ptx_a16(4 * (K / 32 + 2)) +
+                             2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1));
+    const uint64_t p2 = ptx_a16(4 * (nw + 1)) + ptx_a16(N);
+    const uint64_t p3 = ptx_a16(4 * (n + 2)) + ptx_a16(2 * (n + 1)) + ptx_a16(4 * (2 * n + 2));
+    const uint64_t comments = Kc ? 3 * ptx_a16(4 * (Kc + 1)) + ptx_a16(8 * (Kc + 1)) : 0;
+    const uint64_t T4 = PTX_TILE_4, T1 = PTX_TILE_1;
+    const uint64_t trees4 = ptx_a16(4 * 4 * 2 * T4) + ptx_a16(4 * (T4 + 1)) + ptx_a16(8 * (T4 / 32 + 2));
+    const uint64_t trees1 = ptx_a16(4 * 2 * T1) + ptx_a16(4 * (T1 + 1)) + ptx_a16(8 * (T1 / 32 + 2));
+    uint64_t trees = n > T4 ? (trees1 > trees4 ? trees1 : trees4) : trees4; /* V <= n */
+    const uint64_t p5 = ptx_a16(8 * (nwe + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(4 * (K + 1)) + ptx_a16(2 * (Kc + 1)) +
+                        ptx_a16(4 * (nwe + 1)) + (comments > trees ? comments : trees);
+    uint64_t m = p2 > p3 ? p2 : p3;
+    if (p5 > m) m = p5;
     return persist + m;
 }
 
@@ -455,7 +476,8 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     PTX_LEADER {
         H->err = PTX_NO_ERR;
         H->max_ctr = H->max_actor = 0;
-        H->cur_i = H->cur_d = H->cur_m = H->cur_big = 0;
+        H->cur_i = H->cur_d = H->cur_big = 0;
+        H->cur_t[0] = H->cur_t[1] = H->cur_t[2] = H->cur_t[3] = 0;
         H->V = H->S = H->I = 0;
         H->cnt_a = H->cnt_t = 0;
         H->h1 = H->h2 = 0;
@@ -478,31 +500,55 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     const uint64_t* ref_a = A.ref_a + base;
     const uint64_t* ref_b = A.ref_b + base;
     const uint32_t* payload = A.payload + base;
+    const uint8_t* action = A.action + base;
+    const uint8_t* mark_type = A.mark_type + base;
 
-    uint8_t* kind = ptx_alloc<uint8_t>(bp, N); /* action | mark_type << 4, per op row */
-    PTX_BAIL_CAPACITY();
+    /* kind[] (action | mark_type << 4 per row) lives at the TOP of the LDS window and only until the
+     * row lists are built (P2); everything else is bump-allocated from the bottom */
+    const uint32_t kind_bytes = (N + 15u) & ~15u;
+    if (bp.off + kind_bytes > A.lds_bytes) {
+        ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);
+        return;
+    }
+    uint8_t* kind = lds + A.lds_bytes - kind_bytes;
+    bp.cap = A.lds_bytes - kind_bytes;
 
     /* ---- P1: load, classify, reduce ---- */
     {
         uint32_t mc = 0, ma = 0;
         unsigned long long ca = 0, ct = 0;
-        PTX_FOR(i, N) {
-            const uint64_t id = op_id[i];
-            const uint32_t ctr = (uint32_t)(id >> 32), act = (uint32_t)id;
-            const uint32_t a = A.action[base + i], mt = A.mark_type[base + i];
-            kind[i] = (uint8_t)((a & 15u) | ((mt & 15u) << 4));
-            mc = ctr > mc ? ctr : mc;
-            ma = act > ma ? act : ma;
-            if (ctr == 0 || a > PTX_ACT_NOP) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
-            if (a == PTX_ACT_INSERT) ca += 1ull;
-            else if (a == PTX_ACT_DELETE) ca += 1ull << 16;
-            else if (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) {
-                ca += 1ull << 32;
-                if (mt > 3) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
-                else ct += 1ull << (16 * mt);
+        PTX_FORU(i0, N) {
+            uint64_t id[PTX_U];
+            uint32_t a[PTX_U], mt[PTX_U];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u) {
+                if (PTX_IN(i0, u)) {
+                    const uint32_t i = PTX_IX(i0, u);
+                    id[u] = op_id[i];
+                    a[u] = action[i];
+                    mt[u] = mark_type[i];
+                }
             }
-            if (a != PTX_ACT_MAKELIST && a != PTX_ACT_NOP) ca += 1ull << 48;
-            if (A.out_rank) A.out_rank[base + i] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u) {
+                if (PTX_IN(i0, u)) {
+                    const uint32_t i = PTX_IX(i0, u);
+                    const uint32_t ctr = (uint32_t)(id[u] >> 32), act = (uint32_t)id[u];
+                    kind[i] = (uint8_t)((a[u] & 15u) | ((mt[u] & 15u) << 4));
+                    mc = ctr > mc ? ctr : mc;
+                    ma = act > ma ? act : ma;
+                    if (ctr == 0 || a[u] > PTX_ACT_NOP) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
+                    if (a[u] == PTX_ACT_INSERT) ca += 1ull;
+                    else if (a[u] == PTX_ACT_DELETE) ca += 1ull << 16;
+                    else if (a[u] == PTX_ACT_ADDMARK || a[u] == PTX_ACT_REMOVEMARK) {
+                        ca += 1ull << 32;
+                        if (mt[u] > 3) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
+                        else ct += 1ull << (16 * mt[u]);
+                    }
+                    if (a[u] != PTX_ACT_MAKELIST && a[u] != PTX_ACT_NOP) ca += 1ull << 48;
+                    if (A.out_rank) A.out_rank[base + i] = 0xFFFFFFFFu;
+                }
+            }
         }
         ptx_reduce_max32(&H->max_ctr, mc);
         ptx_reduce_max32(&H->max_actor, ma);
@@ -515,8 +561,12 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     const uint32_t n = (uint32_t)(H->cnt_a & 0xFFFFu);         /* list elements (inserts) */
     const uint32_t D = (uint32_t)((H->cnt_a >> 16) & 0xFFFFu); /* deletes */
     const uint32_t K = (uint32_t)((H->cnt_a >> 32) & 0xFFFFu); /* mark ops */
-    const unsigned long long cnt_t = H->cnt_t; /* mark ops per mark type, 16 bits each */
+    const unsigned long long cnt_t = H->cnt_t;                 /* mark ops per mark type, 16 bits each */
 #define PTX_NTYPE(t) ((uint32_t)((cnt_t >> (16u * (t))) & 0xFFFFu))
+    /* mark ops are listed grouped by type: type t owns mark indices [moff_t, moff_{t+1}) */
+    const uint32_t moff1 = PTX_NTYPE(0), moff2 = moff1 + PTX_NTYPE(1), moff3 = moff2 + PTX_NTYPE(2);
+    const uint32_t Kc = PTX_NTYPE(PTX_MARK_COMMENT);
+#define PTX_TYPE_OF(k) (((k) >= moff1 ? 1u : 0u) + ((k) >= moff2 ? 1u : 0u) + ((k) >= moff3 ? 1u : 0u))
 
     PtxElemIndex ix;
     ix.max_ctr = H->max_ctr;
@@ -533,13 +583,16 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         return;
     }
     const uint32_t nw = (keyspace + 31) / 32;
+    const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
     ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
-    uint16_t* list = ptx_alloc<uint16_t>(bp, n + D + K + 1); /* rows of the inserts | deletes | mark ops */
+    uint16_t* list = ptx_alloc<uint16_t>(bp, n + D + K + 1); /* rows of the inserts | deletes | mark ops by type */
     uint16_t* ilist = list;
     uint16_t* dlist = list + n;
     uint16_t* mlist = list + n + D;
-    uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1); /* element -> op row */
-    uint16_t* par = ptx_alloc<uint16_t>(bp, n + 1);    /* element -> parent element (n = HEAD); later: document position */
+    uint32_t* addbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 2); /* mark index -> is an addMark */
+    uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1);         /* element -> op row */
+    uint16_t* par = ptx_alloc<uint16_t>(bp, n + 1);            /* element -> parent element (n = HEAD); later: document position */
+    uint32_t* delbits = ptx_alloc<uint32_t>(bp, nwe + 1);      /* element -> tombstone */
     PTX_BAIL_CAPACITY();
     const uint32_t mark_lds = bp.off; /* everything above this mark is phase scratch */
 
@@ -554,20 +607,44 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
             ix.ib[w] = z;
             allbits[w] = 0;
         }
+        PTX_FOR(w, (K >> 5) + 2) addbits[w] = 0;
+        PTX_FOR(w, nwe + 1) delbits[w] = 0;
         PTX_SYNC();
-        PTX_FOR(i, N) {
-            uint32_t key = 0;
-            ptx_id_key(ix, op_id[i], key);
-            const uint32_t a = kind[i] & 15u;
-            const uint32_t bit = 1u << (key & 31);
-            if (ptx_atomic_or(&allbits[key >> 5], bit) & bit) ptx_raise(H, i, 1, PTX_ERR_DUPLICATE_OP);
-            if (a == PTX_ACT_INSERT) ptx_atomic_or(&ix.ib[key >> 5].bits, bit);
-            const uint32_t ji = ptx_append(&H->cur_i, a == PTX_ACT_INSERT);
-            const uint32_t jd = ptx_append(&H->cur_d, a == PTX_ACT_DELETE);
-            const uint32_t jm = ptx_append(&H->cur_m, a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK);
-            if (a == PTX_ACT_INSERT) ilist[ji] = (uint16_t)i;
-            else if (a == PTX_ACT_DELETE) dlist[jd] = (uint16_t)i;
-            else if (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) mlist[jm] = (uint16_t)i;
+        PTX_FORU(i0, N) {
+            uint64_t id[PTX_U];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(i0, u)) id[u] = op_id[PTX_IX(i0, u)];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u) {
+                /* every lane runs the appends (wave ballots); lanes past the end contribute nothing */
+                const bool in = PTX_IN(i0, u);
+                const uint32_t i = in ? PTX_IX(i0, u) : 0u;
+                const uint32_t kd = in ? kind[i] : (uint32_t)PTX_ACT_NOP;
+                const uint32_t a = kd & 15u, mt = kd >> 4;
+                const bool is_ins = a == PTX_ACT_INSERT, is_del = a == PTX_ACT_DELETE;
+                const bool is_mark = a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK;
+                if (in) {
+                    uint32_t key = 0;
+                    ptx_id_key(ix, id[u], key);
+                    const uint32_t bit = 1u << (key & 31);
+                    if (ptx_atomic_or(&allbits[key >> 5], bit) & bit) ptx_raise(H, i, 1, PTX_ERR_DUPLICATE_OP);
+                    if (is_ins) ptx_atomic_or(&ix.ib[key >> 5].bits, bit);
+                }
+                const uint32_t ji = ptx_append(&H->cur_i, is_ins);
+                const uint32_t jd = ptx_append(&H->cur_d, is_del);
+                const uint32_t j0 = ptx_append(&H->cur_t[0], is_mark && mt == 0);
+                const uint32_t j1 = ptx_append(&H->cur_t[1], is_mark && mt == 1);
+                const uint32_t j2 = ptx_append(&H->cur_t[2], is_mark && mt == 2);
+                const uint32_t j3 = ptx_append(&H->cur_t[3], is_mark && mt == 3);
+                if (is_ins) ilist[ji] = (uint16_t)i;
+                else if (is_del) dlist[jd] = (uint16_t)i;
+                else if (is_mark) {
+                    const uint32_t k = mt == 0 ? j0 : mt == 1 ? moff1 + j1 : mt == 2 ? moff2 + j2 : moff3 + j3;
+                    mlist[k] = (uint16_t)i;
+                    if (a == PTX_ACT_ADDMARK) ptx_atomic_or(&addbits[k >> 5], 1u << (k & 31));
+                }
+            }
         }
         PTX_SYNC();
         PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
@@ -576,46 +653,108 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     }
     PTX_BAIL_IF_ERROR();
     bp.off = mark_lds;
+    bp.cap = A.lds_bytes; /* kind[] is dead from here on */
     PTX_STAMP(2);
 
     /* ---- P3: causal tree of the inserts -> document position of every element ---- */
     {
-        uint32_t* cnt = ptx_alloc<uint32_t>(bp, n + 2);     /* children per parent -> bucket starts -> bucket ends */
-        uint16_t* srt = ptx_alloc<uint16_t>(bp, n + 1);     /* children of every parent, descending opId, parents ascending */
-        uint32_t* L = ptx_alloc<uint32_t>(bp, 2 * n + 2);   /* Euler tour: next << 16 | weight */
+        uint32_t* cnt = ptx_alloc<uint32_t>(bp, n + 2);   /* children per parent -> bucket starts -> bucket ends */
+        uint16_t* srt = ptx_alloc<uint16_t>(bp, n + 1);   /* children of every parent, descending opId, parents ascending */
+        uint32_t* L = ptx_alloc<uint32_t>(bp, 2 * n + 2); /* Euler tour: next << 16 | weight */
         PTX_BAIL_CAPACITY();
-        uint16_t* seg = (uint16_t*)L;   /* bucket members in arrival order (dead before L is built) */
-        uint16_t* big = seg + n + 1;    /* positions in seg of the members of large buckets */
+        uint16_t* seg = (uint16_t*)L; /* bucket members in arrival order (dead before L is built) */
+        uint16_t* big = seg + n + 1;  /* positions in seg of the members of large buckets */
 
         PTX_FOR(p, n + 2) cnt[p] = 0;
         PTX_SYNC();
-        PTX_FOR(j, n) {
-            const uint32_t i = ilist[j];
-            uint32_t key = 0;
-            ptx_id_key(ix, op_id[i], key);
-            const uint32_t e = ptx_bitrank(ix.ib, key);
-            row_of[e] = (uint16_t)i;
-            const uint64_t ra = ref_a[i];
-            uint32_t pe = n;
-            if (ra != 0) {
-                const int p = ptx_elem_lookup(ix, ra);
-                if (p < 0) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND); /* micromerge.ts:752 */
-                else pe = (uint32_t)p;
-            }
-            par[e] = (uint16_t)pe;
-            ptx_atomic_add(&cnt[pe], 1u);
+        /* P3a: element index of every insert, its parent, children counts; tombstone flags */
+        PTX_FORU(j0, n) {
+            uint32_t i[PTX_U];
+            uint64_t id[PTX_U], ra[PTX_U];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(j0, u)) i[u] = ilist[PTX_IX(j0, u)];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(j0, u)) {
+                    id[u] = op_id[i[u]];
+                    ra[u] = ref_a[i[u]];
+                }
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(j0, u)) {
+                    uint32_t key = 0;
+                    ptx_id_key(ix, id[u], key);
+                    const uint32_t e = ptx_bitrank(ix.ib, key);
+                    row_of[e] = (uint16_t)i[u];
+                    uint32_t pe = n;
+                    if (ra[u] != 0) {
+                        const int p = ptx_elem_lookup(ix, ra[u]);
+                        if (p < 0) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND); /* micromerge.ts:752 */
+                        else pe = (uint32_t)p;
+                    }
+                    par[e] = (uint16_t)pe;
+                    ptx_atomic_add(&cnt[pe], 1u);
+                }
+        }
+        PTX_FORU(j0, D) {
+            uint32_t i[PTX_U];
+            uint64_t ra[PTX_U];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(j0, u)) i[u] = dlist[PTX_IX(j0, u)];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(j0, u)) ra[u] = ref_a[i[u]];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(j0, u)) {
+                    const int t = ptx_elem_lookup(ix, ra[u]);
+                    if (t < 0) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);             /* micromerge.ts:752 */
+                    else ptx_atomic_or(&delbits[t >> 5], 1u << ((uint32_t)t & 31u)); /* idempotent: micromerge.ts:693 */
+                }
         }
         PTX_BAIL_IF_ERROR();
         ptx_scan_excl<uint32_t, 1>(cnt, n + 2, H->scan_tmp); /* cnt[p] = first slot of p's children */
-        PTX_FOR(e, n) {
-            const uint32_t pe = par[e];
-            /* the reference element must already exist when the op is applied (micromerge.ts:752) */
-            if (pe < n && row_of[pe] >= row_of[e]) ptx_raise(H, row_of[e], 1, PTX_ERR_ELEM_NOT_FOUND);
-            seg[ptx_atomic_add(&cnt[pe], 1u)] = (uint16_t)e; /* now cnt[p] runs to the END of p's bucket */
+        /* P3b: scatter into the parent buckets; application-order checks now that row_of is complete */
+        PTX_FORU(e0, n) {
+            uint32_t pe[PTX_U], re[PTX_U], rp[PTX_U];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(e0, u)) {
+                    pe[u] = par[PTX_IX(e0, u)];
+                    re[u] = row_of[PTX_IX(e0, u)];
+                }
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(e0, u)) rp[u] = pe[u] < n ? (uint32_t)row_of[pe[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(e0, u)) {
+                    /* the reference element must already exist when the op is applied (micromerge.ts:752) */
+                    if (pe[u] < n && rp[u] >= re[u]) ptx_raise(H, re[u], 1, PTX_ERR_ELEM_NOT_FOUND);
+                    seg[ptx_atomic_add(&cnt[pe[u]], 1u)] = (uint16_t)PTX_IX(e0, u); /* now cnt[p] = END of p's bucket */
+                }
+        }
+        PTX_FORU(j0, D) {
+            uint32_t i[PTX_U];
+            uint64_t ra[PTX_U];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(j0, u)) i[u] = dlist[PTX_IX(j0, u)];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(j0, u)) ra[u] = ref_a[i[u]];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(j0, u)) {
+                    const int t = ptx_elem_lookup(ix, ra[u]);
+                    if (t >= 0 && row_of[t] >= i[u]) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);
+                }
         }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(3);
-        /* rank inside the bucket: descending element index == descending opId */
+        /* P3c: rank inside the bucket: descending element index == descending opId */
         PTX_FOR(j, n) {
             const uint32_t x = seg[j];
             const uint32_t p = par[x];
@@ -623,7 +762,12 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
             const bool is_big = t - s > PTX_SMALL_BUCKET;
             if (!is_big) {
                 uint32_t c = 0;
-                for (uint32_t k = s; k < t; ++k) c += seg[k] > x ? 1u : 0u;
+#pragma unroll
+                for (uint32_t d = 0; d < PTX_SMALL_BUCKET; ++d) {
+                    const uint32_t k = s + d;
+                    const uint32_t v = k < t ? (uint32_t)seg[k] : 0u;
+                    c += (k < t && v > x) ? 1u : 0u;
+                }
                 srt[s + c] = (uint16_t)x;
             }
             const uint32_t jb = ptx_append(&H->cur_big, is_big);
@@ -631,23 +775,26 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         }
         PTX_SYNC();
         {
+            /* large buckets: PTX_G lanes share one member and split its bucket */
             const uint32_t nb = H->cur_big;
-            PTX_FOR(b, nb) {
+            PTX_FOR(w, nb * PTX_G) {
+                const uint32_t b = w / PTX_G, g = w % PTX_G;
                 const uint32_t x = seg[big[b]];
                 const uint32_t p = par[x];
                 const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
                 uint32_t c = 0;
-                for (uint32_t k = s; k < t; ++k) c += seg[k] > x ? 1u : 0u;
-                srt[s + c] = (uint16_t)x;
+                for (uint32_t k = s + g; k < t; k += PTX_G) c += seg[k] > x ? 1u : 0u;
+                c = ptx_group_sum(c);
+                if (g == 0) srt[s + c] = (uint16_t)x;
             }
         }
         PTX_SYNC();
         PTX_STAMP(4);
-        /* Euler tour.  Nodes: enter(x) = x for x in [0,n] (n = HEAD), exit(x) = n+1+x for x in [0,n).
+        /* P3d: Euler tour.  Nodes: enter(x) = x for x in [0,n] (n = HEAD), exit(x) = n+1+x for x in [0,n).
          * weight 1 on enter(x<n): the suffix sum at enter(x) counts the elements from x to the end. */
         PTX_FOR(j, n + 1) {
             const uint32_t s = j ? cnt[j - 1] : 0u, t = cnt[j];
-            uint32_t nx = t > s ? (uint32_t)srt[s] : (j == n ? PTX_END : n + 1u + j);
+            const uint32_t nx = t > s ? (uint32_t)srt[s] : (j == n ? PTX_END : n + 1u + j);
             const uint32_t mine = (nx << 16) | (j < n ? 1u : 0u);
             uint32_t xo = 0, other = 0;
             if (j < n) {
@@ -668,13 +815,17 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                 /* in-place pointer jumping: every intermediate {next, weight} word is a valid state
                  * (weight = sum over [node, next)), so reading a word another thread already advanced
                  * this round only makes the jump longer */
-                PTX_FOR(v, nodes) {
-                    const uint32_t a = L[v];
-                    const uint32_t nx = a >> 16;
-                    if (nx != PTX_END) {
-                        const uint32_t b = L[nx];
-                        L[v] = (b & 0xFFFF0000u) | ((a + b) & 0xFFFFu);
-                    }
+                PTX_FORU(v0, nodes) {
+                    uint32_t a[PTX_U], b[PTX_U];
+#pragma unroll
+                    for (int u = 0; u < PTX_U; ++u)
+                        if (PTX_IN(v0, u)) a[u] = L[PTX_IX(v0, u)];
+#pragma unroll
+                    for (int u = 0; u < PTX_U; ++u)
+                        if (PTX_IN(v0, u)) b[u] = (a[u] >> 16) != PTX_END ? L[a[u] >> 16] : 0xFFFF0000u;
+#pragma unroll
+                    for (int u = 0; u < PTX_U; ++u)
+                        if (PTX_IN(v0, u) && (a[u] >> 16) != PTX_END) L[PTX_IX(v0, u)] = (b[u] & 0xFFFF0000u) | ((a[u] + b[u]) & 0xFFFFu);
                 }
                 PTX_SYNC();
             }
@@ -687,141 +838,126 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     PTX_STAMP(5);
 
     /* ---- P4: tombstones -> visible index ---- */
-    const uint32_t nwv = n / 32 + 1; /* bit positions 0..n */
+    const uint32_t nwv = nwe; /* bit positions 0..n by document position */
     PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
     uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
     uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
     uint32_t* mrk_val = ptx_alloc<uint32_t>(bp, K + 1); /* (key + 1) << kbits | mark index: LWW order + who won */
+    uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);    /* comment mark -> doc-local comment id */
+    uint32_t* brkbits = ptx_alloc<uint32_t>(bp, nwe + 1); /* visible positions where a comment interval starts/ends */
     PTX_BAIL_CAPACITY();
     PTX_FOR(w, nwv + 1) {
         PtxBitWord z;
-        const uint32_t lo = w * 32u;
-        z.bits = lo + 32u <= n ? 0xFFFFFFFFu : (lo < n ? (1u << (n - lo)) - 1u : 0u);
+        z.bits = 0;
         z.pre = 0;
         alive[w] = z;
+        brkbits[w] = 0;
     }
     PTX_SYNC();
-    PTX_FOR(j, D) {
-        const uint32_t i = dlist[j];
-        const int t = ptx_elem_lookup(ix, ref_a[i]);
-        if (t < 0 || row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND); /* micromerge.ts:752 */
-        else {
-            const uint32_t r = rnk[t];
-            ptx_atomic_and(&alive[r >> 5].bits, ~(1u << (r & 31))); /* idempotent: micromerge.ts:693 */
+    PTX_FOR(e, n) {
+        if (!ptx_bittest(delbits, e)) {
+            const uint32_t r = rnk[e];
+            ptx_atomic_or(&alive[r >> 5].bits, 1u << (r & 31));
         }
     }
-    PTX_BAIL_IF_ERROR();
+    PTX_SYNC();
     PTX_FOR(w, nwv + 1) alive[w].pre = ptx_popc(alive[w].bits);
     PTX_SYNC();
     const uint32_t V = ptx_scan_excl<uint32_t, 2>(&alive[0].pre, nwv + 1, H->scan_tmp);
     PTX_STAMP(6);
+
+    /* ---- P5a: visible values out; every mark op -> visible interval [lo, hi) ---- */
     {
         uint64_t h1 = 0, h2 = 0;
-        PTX_FOR(e, n) {
-            const uint32_t r = rnk[e];
-            const PtxBitWord w = alive[r >> 5];
-            const uint32_t row = row_of[e];
-            if ((w.bits >> (r & 31)) & 1u) {
-                const uint32_t q = w.pre + ptx_popc(w.bits & ((1u << (r & 31)) - 1u));
-                const uint32_t v = payload[row];
-                A.out_values[base + q] = v;
-                ptx_digest_item(h1, h2, 1u, q, v, 0u);
-            }
-            if (A.out_rank) A.out_rank[base + row] = r;
+        PTX_FORU(e0, n) {
+            uint32_t r[PTX_U], row[PTX_U], v[PTX_U];
+            PtxBitWord w[PTX_U];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(e0, u)) {
+                    r[u] = rnk[PTX_IX(e0, u)];
+                    row[u] = row_of[PTX_IX(e0, u)];
+                }
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(e0, u)) {
+                    w[u] = alive[r[u] >> 5];
+                    if ((w[u].bits >> (r[u] & 31)) & 1u) v[u] = payload[row[u]];
+                }
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u)
+                if (PTX_IN(e0, u)) {
+                    if ((w[u].bits >> (r[u] & 31)) & 1u) {
+                        const uint32_t q = w[u].pre + ptx_popc(w[u].bits & ((1u << (r[u] & 31)) - 1u));
+                        A.out_values[base + q] = v[u];
+                        ptx_digest_item(h1, h2, 1u, q, v[u], 0u);
+                    }
+                    if (A.out_rank) A.out_rank[base + row[u]] = r[u];
+                }
         }
         ptx_digest_flush(H, h1, h2);
     }
-
-    /* ---- P5a: every mark op -> visible interval [lo, hi) ---- */
-    PTX_FOR(k, K) {
-        const uint32_t i = mlist[k];
-        const uint32_t sa = A.side_a[base + i], sb = A.side_b[base + i];
-        uint32_t lo = 0, hi = 0;
-        /* start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is
-           not in the list when the op is applied means the op never starts */
-        int js = -1;
-        if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
-            js = ptx_elem_lookup(ix, ref_a[i]);
-            if (js >= 0 && row_of[js] >= i) js = -1;
-        }
-        if (js >= 0) {
-            const uint32_t slot_a = 2u * rnk[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
-            uint32_t slot_b = 0xFFFFFFFFu; /* never reached: runs to the end of the text */
-            if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
-                int je = ptx_elem_lookup(ix, ref_b[i]);
-                if (je >= 0 && row_of[je] >= i) je = -1;
-                if (je >= 0) slot_b = 2u * rnk[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
+    PTX_FORU(k0, K) {
+        uint32_t i[PTX_U], sa[PTX_U], sb[PTX_U], pl[PTX_U];
+        uint64_t id[PTX_U], ra[PTX_U], rb[PTX_U];
+#pragma unroll
+        for (int u = 0; u < PTX_U; ++u)
+            if (PTX_IN(k0, u)) i[u] = mlist[PTX_IX(k0, u)];
+#pragma unroll
+        for (int u = 0; u < PTX_U; ++u)
+            if (PTX_IN(k0, u)) {
+                id[u] = op_id[i[u]];
+                ra[u] = ref_a[i[u]];
+                rb[u] = ref_b[i[u]];
+                sa[u] = A.side_a[base + i[u]];
+                sb[u] = A.side_b[base + i[u]];
+                pl[u] = payload[i[u]];
             }
-            /* same slot: the start test fires first and the end is never seen */
-            if (slot_b == slot_a) slot_b = 0xFFFFFFFFu;
-            if (slot_b > slot_a) {
-                const uint32_t lo_rank = (slot_a + 1u) >> 1;
-                const uint32_t hi_rank = slot_b == 0xFFFFFFFFu ? n : (slot_b + 1u) >> 1;
-                lo = ptx_bitrank(alive, lo_rank);
-                hi = ptx_bitrank(alive, hi_rank);
-            }
-        }
-        uint32_t key = 0;
-        ptx_id_key(ix, op_id[i], key);
-        mrk_lo[k] = (uint16_t)lo;
-        mrk_hi[k] = (uint16_t)hi;
-        mrk_val[k] = ((key + 1u) << kbits) | k;
-    }
-    PTX_SYNC();
-    PTX_STAMP(7);
-
-    /* ---- P5b: per visible char, the winning op of each non-multi mark type (LWW by opId) ---- */
-    uint32_t P2V = 1;
-    while (P2V < V) P2V <<= 1;
-    uint32_t* tree = ptx_alloc<uint32_t>(bp, 2 * P2V);
-    uint32_t* attr = ptx_alloc<uint32_t>(bp, V + 1);
-    const uint32_t nwq = V / 32 + 1;
-    uint32_t* brkbits = ptx_alloc<uint32_t>(bp, nwq + 1);
-    PtxBitWord* st = ptx_alloc<PtxBitWord>(bp, nwq + 1);
-    PTX_BAIL_CAPACITY();
-    PTX_FOR(q, V + 1) attr[q] = 0;
-    PTX_FOR(w, nwq + 1) {
-        PtxBitWord z;
-        z.bits = 0;
-        z.pre = 0;
-        brkbits[w] = 0;
-        st[w] = z;
-    }
-    PTX_SYNC();
-    const uint32_t kmask = (1u << kbits) - 1u;
-    for (uint32_t pass = 0; pass < 4; ++pass) {
-        /* pass = mark type; the comment pass only asks "is any comment op covering" (key present) */
-        if (V == 0 || PTX_NTYPE(pass) == 0) continue;
-        PTX_FOR(p, 2 * P2V) tree[p] = 0;
-        PTX_SYNC();
-        PTX_FOR(k, K) {
-            const uint32_t i = mlist[k];
-            if ((uint32_t)(kind[i] >> 4) == pass && mrk_lo[k] < mrk_hi[k]) {
-                ptx_tree_chmax(tree, P2V, mrk_lo[k], mrk_hi[k], pass == PTX_MARK_COMMENT ? 1u : mrk_val[k]);
-            }
-        }
-        PTX_SYNC();
-        PTX_FOR(q, V) {
-            const uint32_t w = ptx_tree_query(tree, P2V, q);
-            if (w != 0) {
-                if (pass == PTX_MARK_COMMENT) {
-                    attr[q] |= PTX_ATTR_COMMENT;
-                } else {
-                    const uint32_t i = mlist[w & kmask];
-                    if ((kind[i] & 15u) == PTX_ACT_ADDMARK) {
-                        if (pass == PTX_MARK_STRONG) attr[q] |= PTX_ATTR_STRONG;
-                        else if (pass == PTX_MARK_EM) attr[q] |= PTX_ATTR_EM;
-                        else attr[q] |= PTX_ATTR_LINK | (payload[i] & PTX_ATTR_ID_MASK);
+#pragma unroll
+        for (int u = 0; u < PTX_U; ++u)
+            if (PTX_IN(k0, u)) {
+                const uint32_t k = PTX_IX(k0, u);
+                uint32_t lo = 0, hi = 0;
+                /* start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is
+                   not in the list when the op is applied means the op never starts */
+                int js = -1;
+                if (sa[u] == PTX_SIDE_BEFORE || sa[u] == PTX_SIDE_AFTER) {
+                    js = ptx_elem_lookup(ix, ra[u]);
+                    if (js >= 0 && row_of[js] >= i[u]) js = -1;
+                }
+                if (js >= 0) {
+                    const uint32_t slot_a = 2u * rnk[js] + (sa[u] == PTX_SIDE_AFTER ? 1u : 0u);
+                    uint32_t slot_b = 0xFFFFFFFFu; /* never reached: runs to the end of the text */
+                    if (sb[u] == PTX_SIDE_BEFORE || sb[u] == PTX_SIDE_AFTER) {
+                        int je = ptx_elem_lookup(ix, rb[u]);
+                        if (je >= 0 && row_of[je] >= i[u]) je = -1;
+                        if (je >= 0) slot_b = 2u * rnk[je] + (sb[u] == PTX_SIDE_AFTER ? 1u : 0u);
+                    }
+                    /* same slot: the start test fires first and the end is never seen */
+                    if (slot_b == slot_a) slot_b = 0xFFFFFFFFu;
+                    if (slot_b > slot_a) {
+                        const uint32_t lo_rank = (slot_a + 1u) >> 1;
+                        const uint32_t hi_rank = slot_b == 0xFFFFFFFFu ? n : (slot_b + 1u) >> 1;
+                        lo = ptx_bitrank(alive, lo_rank);
+                        hi = ptx_bitrank(alive, hi_rank);
                     }
                 }
+                uint32_t key = 0;
+                ptx_id_key(ix, id[u], key);
+                mrk_lo[k] = (uint16_t)lo;
+                mrk_hi[k] = (uint16_t)hi;
+                mrk_val[k] = ((key + 1u) << kbits) | k;
+                if (k >= moff2 && k < moff3) {
+                    if (pl[u] >= Kc) ptx_raise(H, i[u], 1, PTX_ERR_BAD_OP); /* comment ids must be dense per doc */
+                    cid[k - moff2] = (uint16_t)pl[u];
+                }
             }
-        }
-        PTX_SYNC();
     }
-    PTX_STAMP(8);
+    PTX_BAIL_IF_ERROR();
+    const uint32_t mark2_lds = bp.off;
+    PTX_STAMP(7);
 
     /* ---- P5c: comments: per id, presence intervals decided by the last-applied covering op ---- */
-    const uint32_t Kc = PTX_NTYPE(PTX_MARK_COMMENT);
     if (Kc > 0) {
         uint32_t* ccnt = ptx_alloc<uint32_t>(bp, Kc + 1);
         uint32_t* ccur = ptx_alloc<uint32_t>(bp, Kc + 1);
@@ -834,26 +970,22 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
             cicnt[c] = 0;
         }
         PTX_SYNC();
-        PTX_FOR(k, K) {
-            const uint32_t i = mlist[k];
-            if ((uint32_t)(kind[i] >> 4) == PTX_MARK_COMMENT) {
-                const uint32_t c = payload[i];
-                if (c >= Kc) ptx_raise(H, i, 1, PTX_ERR_BAD_OP); /* ids must be dense per doc */
-                else if (mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[c], 1u);
-            }
+        PTX_FOR(kc, Kc) {
+            const uint32_t k = moff2 + kc;
+            if (mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[cid[kc]], 1u);
         }
-        PTX_BAIL_IF_ERROR();
+        PTX_SYNC();
         ptx_scan_excl<uint32_t, 1>(ccnt, Kc + 1, H->scan_tmp); /* ccnt[c] = first entry of id c, ccnt[Kc] = total */
-        PTX_FOR(k, K) {
-            const uint32_t i = mlist[k];
-            if ((uint32_t)(kind[i] >> 4) == PTX_MARK_COMMENT && mrk_lo[k] < mrk_hi[k]) {
-                const uint32_t c = payload[i];
+        PTX_FOR(kc, Kc) {
+            const uint32_t k = moff2 + kc;
+            if (mrk_lo[k] < mrk_hi[k]) {
+                const uint32_t c = cid[kc];
                 const uint32_t pos = ccnt[c] + ptx_atomic_add(&ccur[c], 1u);
                 PtxCEntry e;
                 e.lo = mrk_lo[k];
                 e.hi = mrk_hi[k];
-                e.t = (uint16_t)i;
-                e.add = (kind[i] & 15u) == PTX_ACT_ADDMARK ? 1 : 0;
+                e.t = mlist[k]; /* application index = row in the log */
+                e.add = ptx_bittest(addbits, k) ? 1 : 0;
                 cent[pos] = e;
             }
         }
@@ -883,41 +1015,114 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         }
         PTX_SYNC();
     }
-    PTX_STAMP(9);
+    bp.off = mark2_lds; /* release the comment scratch */
+    PTX_STAMP(8);
 
-    /* ---- P6: spans = maximal runs of equal marks over the visible chars ---- */
-    PTX_FOR(q, V) {
-        const bool is_start = q == 0 || attr[q] != attr[q - 1] || ptx_bittest(brkbits, q);
-        if (is_start) ptx_atomic_or(&st[q >> 5].bits, 1u << (q & 31));
-    }
-    PTX_SYNC();
-    PTX_FOR(w, nwq + 1) st[w].pre = ptx_popc(st[w].bits);
-    PTX_SYNC();
-    const uint32_t S = ptx_scan_excl<uint32_t, 2>(&st[0].pre, nwq + 1, H->scan_tmp);
+    /* ---- P5b + P6: LWW winners per visible char, spans, digest — in tiles of the visible axis ----
+     * Short documents: one tile, four trees (one per mark type) updated and queried in one pass.
+     * Long documents: tiles of PTX_TILE_1 chars, one tree reused per mark type. */
     {
+        const bool four = V <= PTX_TILE_4;
+        uint32_t TV = 1;
+        if (four) {
+            while (TV < V) TV <<= 1;
+        } else {
+            TV = PTX_TILE_1;
+        }
+        const uint32_t ntree = four ? 4u : 1u;
+        uint32_t* tree = ptx_alloc<uint32_t>(bp, ntree * 2 * TV);
+        uint32_t* attr = ptx_alloc<uint32_t>(bp, TV + 1);
+        PtxBitWord* st = ptx_alloc<PtxBitWord>(bp, TV / 32 + 2);
+        PTX_BAIL_CAPACITY();
+        const uint32_t kmask = (1u << kbits) - 1u;
         uint64_t h1 = 0, h2 = 0;
-        PTX_FOR(q, V) {
-            const PtxBitWord w = st[q >> 5];
-            if ((w.bits >> (q & 31)) & 1u) {
-                const uint32_t s = w.pre + ptx_popc(w.bits & ((1u << (q & 31)) - 1u));
-                ptx_span sp;
-                sp.start = q;
-                sp.attr = attr[q];
-                A.out_spans[base + s] = sp;
-                ptx_digest_item(h1, h2, 2u, s, q, sp.attr);
+        uint32_t span_base = 0;
+        uint32_t prev_attr = 0; /* marks of the last char of the previous tile */
+        for (uint32_t t0 = 0; t0 < V; t0 += TV) {
+            const uint32_t tv = V - t0 < TV ? V - t0 : TV; /* chars in this tile */
+            PTX_FOR(q, tv + 1) attr[q] = 0;
+            PTX_FOR(w, TV / 32 + 2) {
+                PtxBitWord z;
+                z.bits = 0;
+                z.pre = 0;
+                st[w] = z;
             }
+            for (uint32_t g = 0; g < 4; g += ntree) {
+                /* mark types [g, g + ntree) */
+                const uint32_t k_lo = g == 0 ? 0u : g == 1 ? moff1 : g == 2 ? moff2 : moff3;
+                const uint32_t k_hi = four ? K : (g == 0 ? moff1 : g == 1 ? moff2 : g == 2 ? moff3 : K);
+                if (k_hi == k_lo) continue;
+                PTX_FOR(p, ntree * 2 * TV) tree[p] = 0;
+                PTX_SYNC();
+                PTX_FOR(kk, k_hi - k_lo) {
+                    const uint32_t k = k_lo + kk;
+                    uint32_t lo = mrk_lo[k], hi = mrk_hi[k];
+                    lo = lo > t0 ? lo - t0 : 0u;
+                    hi = hi > t0 ? (hi - t0 < tv ? hi - t0 : tv) : 0u;
+                    if (lo < hi) {
+                        const uint32_t ty = PTX_TYPE_OF(k);
+                        /* the comment tree only records "some comment op covers" (key `comment` present) */
+                        ptx_tree_chmax(tree + (four ? ty : 0u) * 2 * TV, TV, lo, hi, ty == PTX_MARK_COMMENT ? 1u : mrk_val[k]);
+                    }
+                }
+                PTX_SYNC();
+                PTX_FOR(q, tv) {
+                    uint32_t at = 0;
+                    for (uint32_t ty = g; ty < g + ntree; ++ty) {
+                        const uint32_t w = ptx_tree_query(tree + (four ? ty : 0u) * 2 * TV, TV, q);
+                        if (w == 0) continue;
+                        if (ty == PTX_MARK_COMMENT) at |= PTX_ATTR_COMMENT;
+                        else {
+                            const uint32_t k = w & kmask;
+                            if (ptx_bittest(addbits, k)) {
+                                if (ty == PTX_MARK_STRONG) at |= PTX_ATTR_STRONG;
+                                else if (ty == PTX_MARK_EM) at |= PTX_ATTR_EM;
+                                else at |= PTX_ATTR_LINK | (payload[mlist[k]] & PTX_ATTR_ID_MASK);
+                            }
+                        }
+                    }
+                    if (at) attr[q + 1] |= at; /* attr[0] = last char of the previous tile */
+                }
+                PTX_SYNC();
+            }
+            PTX_LEADER { attr[0] = prev_attr; }
+            PTX_SYNC();
+            /* spans = maximal runs of equal marks over the visible chars (peritext.ts:438-455) */
+            PTX_FOR(q, tv) {
+                const uint32_t gq = t0 + q;
+                const bool is_start = gq == 0 || attr[q + 1] != attr[q] || ptx_bittest(brkbits, gq);
+                if (is_start) ptx_atomic_or(&st[q >> 5].bits, 1u << (q & 31));
+            }
+            PTX_SYNC();
+            PTX_FOR(w, TV / 32 + 2) st[w].pre = ptx_popc(st[w].bits);
+            PTX_SYNC();
+            const uint32_t S_tile = ptx_scan_excl<uint32_t, 2>(&st[0].pre, TV / 32 + 2, H->scan_tmp);
+            PTX_FOR(q, tv) {
+                const PtxBitWord w = st[q >> 5];
+                if ((w.bits >> (q & 31)) & 1u) {
+                    const uint32_t s = span_base + w.pre + ptx_popc(w.bits & ((1u << (q & 31)) - 1u));
+                    ptx_span sp;
+                    sp.start = t0 + q;
+                    sp.attr = attr[q + 1];
+                    A.out_spans[base + s] = sp;
+                    ptx_digest_item(h1, h2, 2u, s, sp.start, sp.attr);
+                }
+            }
+            span_base += S_tile;
+            prev_attr = attr[tv];
+            PTX_SYNC();
         }
         ptx_digest_flush(H, h1, h2);
-    }
-    PTX_SYNC();
-    PTX_LEADER {
-        H->V = V;
-        H->S = S;
-        uint64_t h1 = 0, h2 = 0;
-        ptx_digest_item(h1, h2, 4u, 0u, V, S);
-        ptx_digest_item(h1, h2, 4u, 1u, H->I, n);
-        H->h1 += h1;
-        H->h2 += h2;
+        PTX_SYNC();
+        PTX_LEADER {
+            H->V = V;
+            H->S = span_base;
+            uint64_t g1 = 0, g2 = 0;
+            ptx_digest_item(g1, g2, 4u, 0u, V, span_base);
+            ptx_digest_item(g1, g2, 4u, 1u, H->I, n);
+            H->h1 += g1;
+            H->h2 += g2;
+        }
     }
     PTX_SYNC();
     PTX_STAMP(10);

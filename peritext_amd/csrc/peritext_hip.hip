@@ -25,14 +25,21 @@
 /* kernels                                                                                          */
 /* ------------------------------------------------------------------------------------------------ */
 
-extern "C" __global__ void __launch_bounds__(1024) ptx_merge_kernel(PtxMergeArgs A) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
-    /* grid-stride over logs: the launch may cap the grid */
-    for (uint32_t log = blockIdx.x; log < A.n_logs; log += gridDim.x) {
-        ptx_merge_log(A, log, ptx_lds);
-        __syncthreads(); /* LDS is reused by the next log */
+/* One body, several register budgets: __launch_bounds__(T, W) = at most T threads per workgroup and at
+ * least W waves per SIMD resident, i.e. the compiler must stay within 512/W VGPRs (MI355X_MICROARCH.md
+ * "Register files").  The host picks the variant whose budget matches the launch shape. */
+#define PTX_MERGE_KERNEL(name, T, W)                                                   \
+    extern "C" __global__ void __launch_bounds__(T, W) name(PtxMergeArgs A) {          \
+        extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];              \
+        /* grid-stride over logs: the launch may cap the grid */                       \
+        for (uint32_t log = blockIdx.x; log < A.n_logs; log += gridDim.x) {            \
+            ptx_merge_log(A, log, ptx_lds);                                            \
+            __syncthreads(); /* LDS is reused by the next log */                       \
+        }                                                                              \
     }
-}
+PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1)    /* <= 128 VGPRs: any launch shape */
+PTX_MERGE_KERNEL(ptx_merge_kernel_w6, 512, 6)  /* <= 80 VGPRs: 3 workgroups of 512 per CU */
+PTX_MERGE_KERNEL(ptx_merge_kernel_w8, 512, 8)  /* <= 64 VGPRs: 4 workgroups of 512 per CU */
 
 __global__ void ptx_pack_digests_kernel(const ptx_log_result* res, uint32_t first, uint32_t count, uint64_t* dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,6 +70,7 @@ struct ptx_ctx {
     size_t max_lds = 0;
     int force_threads = 0; /* PTX_THREADS env override (tuning) */
     int force_lds = 0;     /* PTX_LDS_BYTES env override (tuning) */
+    int variant = 0;       /* PTX_VARIANT env override (tuning): register-budget variant of the kernel */
     uint32_t flags = 0;
     unsigned long long* clocks = nullptr; /* device [PTX_NCLK], non-null only while ptx_merge_phase_cycles runs */
 };
@@ -196,7 +204,10 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
         return fail(nullptr, PTX_ERR_HIP, "stream/event creation failed");
     }
     /* one workgroup may use the CU's whole 160 KiB of LDS */
+    if (const char* sv = getenv("PTX_VARIANT")) ctx->variant = atoi(sv);
     e = hipFuncSetAttribute((const void*)ptx_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
     if (e != hipSuccess) {
         std::string m = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e);
         delete ctx;
@@ -409,7 +420,12 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.lds_bytes = b->lds_bytes;
     /* one workgroup per log; far more workgroups than the 256 CUs so the dispatcher load-balances */
     const uint32_t grid = b->n_logs;
-    hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
+    if (ctx->variant == 8 && b->threads <= 512)
+        hipLaunchKernelGGL(ptx_merge_kernel_w8, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
+    else if (ctx->variant == 6 && b->threads <= 512)
+        hipLaunchKernelGGL(ptx_merge_kernel_w6, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
+    else
+        hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_merge_kernel launch: ") + hipGetErrorString(e));
     return PTX_OK;

@@ -24,24 +24,32 @@ def main():
     ap.add_argument("--ops", type=int, default=None)
     ap.add_argument("--threads", default="128,256,512,1024")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--lib", default=None, help="experimental build of libperitext_hip.so")
+    ap.add_argument("--variants", default="0", help="PTX_VARIANT values to sweep (0 = 128-VGPR kernel, 6, 8)")
+    ap.add_argument("--no-phases", action="store_true")
     args = ap.parse_args()
+    if args.lib and not os.path.isabs(args.lib):
+        args.lib = os.path.join(ROOT, args.lib)
     docs = bench.gen_unique_docs(args.config, args.unique, 4242, ops=args.ops)
     batch = wire.encode_docs([d["logs"] for d in docs])
     copies = max(1, args.docs // args.unique)
     out = {"config": args.config, "logs": batch.n_logs * copies, "ops": batch.counted_ops() * copies, "shapes": []}
-    for t in [int(x) for x in args.threads.split(",")]:
+    for t, var in [(int(x), int(v)) for v in args.variants.split(",") for x in args.threads.split(",")]:
+        if var and t > 512:
+            continue
         os.environ["PTX_THREADS"] = str(t)
-        eng = Engine(0, flags=abi.FLAG_NO_ELEM_RANK)
+        os.environ["PTX_VARIANT"] = str(var)
+        eng = Engine(0, flags=abi.FLAG_NO_ELEM_RANK, lib_path=args.lib)
         db = eng.upload(batch, copies=copies)
         dr = eng.alloc_result(db)
         eng.merge(db, dr)
         eng.sync()
         ms = eng.merge_timed(db, dr, args.iters) / args.iters
-        cyc = eng.phase_cycles(db, dr)
+        cyc = [0] * 16 if args.no_phases else eng.phase_cycles(db, dr)
         logs = eng.download_logs(dr, eng.n_logs(db))
         assert int(logs["status"].max()) == 0
         tot = sum(cyc) or 1
-        row = {"threads": t, "ms": ms, "Gops_s": out["ops"] / ms / 1e6, "us_per_log_per_cu": ms * 1e3 * 256 / out["logs"],
+        row = {"lib": os.path.basename(args.lib or "default"), "variant": var, "threads": t, "ms": ms, "Gops_s": out["ops"] / ms / 1e6, "us_per_log_per_cu": ms * 1e3 * 256 / out["logs"],
                "lds_high": int(logs["reserved"][:, 0].max()), "cycles_per_log": tot / out["logs"],
                "phases": {PHASES[k] if k < len(PHASES) else str(k): round(cyc[k] / out["logs"]) for k in range(len(cyc)) if cyc[k]}}
         out["shapes"].append(row)

@@ -28,9 +28,10 @@ def main():
             cur = c.execute("select * from counters_collection limit 1")
             cols = [d[0] for d in cur.description]
             print("# columns: %s" % cols)
-            q = "select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"
+            namecol = "kernel_name" if "kernel_name" in cols else cols[0]
+            q = "select %s, counter_name, count(distinct dispatch_id), sum(value) from counters_collection where %s like 'ptx_merge%%' group by %s, counter_name" % (namecol, namecol, namecol)
             for r in c.execute(q):
-                print("%-40s %-24s n=%-5d sum=%.6g" % (str(r[0])[:40], r[1], r[2], r[3]))
+                print("%-40s %-28s dispatches=%-5d sum=%.6g per_dispatch=%.6g" % (str(r[0])[:40], r[1], r[2], r[3], r[3] / max(r[2], 1)))
         except Exception as e:  # noqa: BLE001
             print("# no counters: %s" % e)
 
