@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 1u
+#define PTX_ABI_VERSION 2u
 
 /* Operation.action (micromerge.ts:150-212, peritext.ts:25-65) */
 enum {
@@ -98,6 +98,19 @@ enum {
     PTX_ERR_OOM = 103
 };
 
+/* Per-log census, part of the wire format: it lets the kernel size its on-chip lists and id bitmaps
+ * before it has seen a row, so the op columns are streamed ONCE.  The encoder that flattens Change.ops
+ * (micromerge.ts:60-71) knows these numbers for free.  The kernel verifies them against the rows
+ * (a wrong header is PTX_ERR_BAD_OP, never a wrong result); a batch may omit them (log_hdr = NULL),
+ * then the library computes them with a small pre-pass kernel when the batch becomes resident. */
+typedef struct ptx_log_hdr {
+    uint32_t n_ins;       /* PTX_ACT_INSERT rows */
+    uint32_t n_del;       /* PTX_ACT_DELETE rows */
+    uint32_t n_mark[4];   /* add/removeMark rows per PTX_MARK_* */
+    uint32_t max_counter; /* largest counter of any op_id of the log */
+    uint32_t max_actor;   /* largest actorRank of any op_id of the log */
+} ptx_log_hdr;
+
 /* One batch of replica-logs.  All pointers are HOST pointers for ptx_batch_upload /
  * ptx_apply_materialize and DEVICE pointers for ptx_batch_wrap_device. */
 typedef struct ptx_batch {
@@ -122,6 +135,7 @@ typedef struct ptx_batch {
     const uint32_t* chg_deps;  /* [n_changes * max_actors] deps[actorRank] (0 = none) */
     uint32_t max_actors;       /* row stride of chg_deps */
     uint32_t reserved2;
+    const ptx_log_hdr* log_hdr; /* [n_logs] or NULL (the library computes it) */
 } ptx_batch;
 
 typedef struct ptx_span {

@@ -7,7 +7,7 @@ the shared object is missing, and `ptx_create` fails when no gfx950 device is vi
 import ctypes as C
 import os
 
-PTX_ABI_VERSION = 1
+PTX_ABI_VERSION = 2
 
 # Operation.action (reference/src/micromerge.ts:150-212, src/peritext.ts:25-65)
 ACT_MAKELIST, ACT_INSERT, ACT_DELETE, ACT_ADDMARK, ACT_REMOVEMARK, ACT_NOP = range(6)
@@ -53,6 +53,16 @@ u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 
 
+class ptx_log_hdr(C.Structure):
+    _fields_ = [
+        ("n_ins", C.c_uint32),
+        ("n_del", C.c_uint32),
+        ("n_mark", C.c_uint32 * 4),
+        ("max_counter", C.c_uint32),
+        ("max_actor", C.c_uint32),
+    ]
+
+
 class ptx_batch(C.Structure):
     _fields_ = [
         ("n_logs", C.c_uint32),
@@ -74,6 +84,7 @@ class ptx_batch(C.Structure):
         ("chg_deps", u32p),
         ("max_actors", C.c_uint32),
         ("reserved2", C.c_uint32),
+        ("log_hdr", C.POINTER(ptx_log_hdr)),
     ]
 
 
@@ -127,6 +138,7 @@ LOG_RESULT_DTYPE = np.dtype(
         ("digest", "<u8", (2,)),
     ]
 )
+LOG_HDR_DTYPE = np.dtype([("n_ins", "<u4"), ("n_del", "<u4"), ("n_mark", "<u4", (4,)), ("max_counter", "<u4"), ("max_actor", "<u4")])
 SPAN_DTYPE = np.dtype([("start", "<u4"), ("attr", "<u4")])
 CINTERVAL_DTYPE = np.dtype([("id", "<u4"), ("start", "<u4"), ("end", "<u4")])
 

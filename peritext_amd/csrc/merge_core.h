@@ -39,8 +39,13 @@
 #include <stdint.h>
 #include "../../include/peritext_hip.h"
 
+#ifndef PTX_U
+#define PTX_U 4 /* rows in flight per thread in the batched loops */
+#endif
+
 #ifdef PTX_EMU
 #include <string.h>
+#define PTX_HD static inline
 #define PTX_DEV static inline
 #define PTX_SYNC() ((void)0)
 extern int ptx_emu_reverse; /* 1: run every parallel loop backwards (order-independence check) */
@@ -53,6 +58,7 @@ PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { uint32_t o = *p; *p =
 PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
 /* append to a list: index of this element (valid only where pred) */
 PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }
@@ -64,6 +70,7 @@ PTX_DEV uint32_t ptx_group_sum(uint32_t c) { return c; }
 #define PTX_IX(i0, u) (ptx_emu_reverse ? _n - 1u - ((i0) + (uint32_t)(u)) : (i0) + (uint32_t)(u))
 #else
 #include <hip/hip_runtime.h>
+#define PTX_HD __host__ __device__ static inline
 #define PTX_DEV __device__ __forceinline__
 #define PTX_SYNC() __syncthreads()
 #define PTX_FOR(i, n) for (uint32_t i = threadIdx.x, _n = (n); i < _n; i += blockDim.x)
@@ -73,6 +80,7 @@ PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { return atomicAnd(p, v
 PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__popc(x); }
 /* wave-aggregated append: ONE LDS atomic per wave, lanes get consecutive slots.  May be called in
  * divergent control flow (the ballot covers the active lanes only). */
@@ -99,6 +107,63 @@ PTX_DEV uint32_t ptx_group_sum(uint32_t c) {
 #endif
 #define PTX_IN(i0, u) ((i0) + (uint32_t)(u) * _T < _n)
 
+/* ---- list slots for a batch of rows: rows of class c < 6 get consecutive slots from cursor[c], in ROW order
+ *      within the wave (lane-major, each lane holding PTX_U consecutive rows), so that the lists stay (nearly)
+ *      sorted by row and later gathers through them stay (nearly) coalesced.  One LDS atomic per wave and batch
+ *      (6 lanes, 6 distinct cursors); the ranking itself is a DPP prefix sum in registers.  Every lane of the
+ *      wave must call it (uniform control flow). ---- */
+#ifdef PTX_EMU
+PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slot) {
+    for (int u = 0; u < PTX_U; ++u) slot[u] = cls[u] < 6u ? cursor[cls[u]]++ : 0xFFFFFFFFu;
+}
+#else
+PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1,3 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2,3 */
+    return v;
+}
+PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slot) {
+    /* per-lane counts, 10 bits per class: classes 0..2 in w0, 3..5 in w1 (a wave holds at most 64 * PTX_U <= 1023 rows) */
+    uint32_t w0 = 0, w1 = 0, off[PTX_U];
+#pragma unroll
+    for (int u = 0; u < PTX_U; ++u) {
+        const uint32_t c = cls[u];
+        const uint32_t sh = (c >= 3u ? c - 3u : c) * 10u;
+        off[u] = ((c >= 3u ? w1 : w0) >> sh) & 1023u;
+        w0 += (c < 3u ? 1u : 0u) << sh;
+        w1 += (c >= 3u && c < 6u ? 1u : 0u) << sh;
+    }
+    const uint32_t i0 = ptx_wave_incl_scan(w0), i1 = ptx_wave_incl_scan(w1);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t basev = 0;
+    if (lane < 6u) {
+        const uint32_t cnt = ((lane >= 3u ? t1 : t0) >> ((lane >= 3u ? lane - 3u : lane) * 10u)) & 1023u;
+        basev = atomicAdd(&cursor[lane], cnt);
+    }
+    const uint32_t e0 = i0 - w0, e1 = i1 - w1; /* exclusive prefix over the lower lanes */
+#pragma unroll
+    for (int u = 0; u < PTX_U; ++u) {
+        const uint32_t c = cls[u];
+        const uint32_t sh = (c >= 3u ? c - 3u : c) * 10u;
+        const uint32_t b = (uint32_t)__shfl((int)basev, (int)(c & 7u), 64);
+        slot[u] = c < 6u ? b + (((c >= 3u ? e1 : e0) >> sh) & 1023u) + off[u] : 0xFFFFFFFFu;
+    }
+}
+#endif
+
+/* uniform loop over groups of PTX_U consecutive items: every thread runs every step (g may be past the end) */
+#ifdef PTX_EMU
+#define PTX_FORG(g, groups) \
+    for (uint32_t _ng = (groups), _k = 0, g = (ptx_emu_reverse ? _ng - 1 : 0); _k < _ng; ++_k, g = (ptx_emu_reverse ? _ng - 1 - _k : _k))
+#else
+#define PTX_FORG(g, groups) for (uint32_t _ng = (groups), _g0 = 0, g = threadIdx.x; _g0 < _ng; _g0 += blockDim.x, g += blockDim.x)
+#endif
+
 /* kernel arguments: device pointers (host pointers under PTX_EMU) */
 struct PtxMergeArgs {
     const uint64_t* log_off;
@@ -116,6 +181,7 @@ struct PtxMergeArgs {
     const uint32_t* chg_seq;
     const uint32_t* chg_nops;
     const uint32_t* chg_deps;
+    const ptx_log_hdr* log_hdr; /* [n_logs] per-log census (always present: the host computes it when the caller did not) */
     ptx_log_result* res;
     uint32_t* out_values;
     ptx_span* out_spans;
@@ -125,15 +191,13 @@ struct PtxMergeArgs {
     uint32_t n_logs;
     uint32_t lds_bytes;
     uint32_t max_actors;
-    uint32_t pad;
+    uint32_t stop_after; /* diagnostic: leave after the phase with this stamp index (0 = run everything) */
 };
 
 #define PTX_END 0xFFFFu
+#define PTX_S 8u         /* every PTX_S-th node of the Euler tour is a splitter of the list ranking */
 #define PTX_TILE_4 128u  /* visible chars up to which the four LWW trees are resident at once */
 #define PTX_TILE_1 512u  /* tile of the visible axis for longer documents (one tree, reused per mark type) */
-#ifndef PTX_U
-#define PTX_U 4 /* rows in flight per thread in the batched loops */
-#endif
 #define PTX_NCLK 16
 #define PTX_SMALL_BUCKET 8u
 
@@ -157,12 +221,10 @@ PTX_DEV void ptx_digest_item(uint64_t& h1, uint64_t& h2, uint32_t tag, uint32_t 
 struct PtxHdr {
     uint32_t err;          /* min over ((row*2+level) << 4 | code) of every detected error; ~0 = none */
     uint32_t max_ctr, max_actor;
-    uint32_t cur_i, cur_d, cur_big;
-    uint32_t cur_t[4]; /* per mark type */
+    uint32_t cur_big;
     uint32_t V, S, I;
-    uint32_t pad[1];
-    unsigned long long cnt_a; /* n_ins | n_del << 16 | n_marks << 32 | n_applied << 48 */
-    unsigned long long cnt_t; /* mark ops per mark type, 16 bits each */
+    uint32_t n_ins, n_applied;
+    uint32_t cur[8]; /* list cursors per row class (0 insert, 1 delete, 2..5 mark type 0..3, 6/7 unlisted rows) */
     unsigned long long h1, h2;
     uint32_t scan_tmp[36];
     unsigned long long clk[PTX_NCLK + 1];
@@ -327,13 +389,14 @@ PTX_DEV uint32_t ptx_ceil_log2(uint32_t x) { /* smallest k with (1<<k) >= x, x>=
 /* ---- LDS working set of ptx_merge_log (mirrors its ptx_alloc calls; used by the host to size the
  *      launch and by the tests to check the bound).  N rows, n inserts, D deletes, K mark ops of
  *      which Kc comment ops, id keyspace of ks bits. ---- */
-static inline uint64_t ptx_a16(uint64_t x) { return (x + 15) & ~15ull; }
-static inline uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
+PTX_HD uint64_t ptx_a16(uint64_t x) { return (x + 15) & ~15ull; }
+PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
+    (void)N;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
     const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (n + D + K + 1)) + ptx_a16(4 * (K / 32 + 2)) +
                              2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1));
-    const uint64_t p2 = ptx_a16(4 * (nw + 1)) + ptx_a16(N);
-    const uint64_t p3 = ptx_a16(4 * (n + 2)) + ptx_a16(2 * (n + 1)) + ptx_a16(4 * (2 * n + 2));
+    const uint64_t p2 = ptx_a16(4 * (nw + 1));
+    const uint64_t p3 = ptx_a16(4 * (n + 2)) + ptx_a16(2 * (n + 1)) + ptx_a16(4 * (2 * n + 2)) + ptx_a16(4 * ((2 * n) / PTX_S + 2));
     const uint64_t comments = Kc ? 3 * ptx_a16(4 * (Kc + 1)) + ptx_a16(8 * (Kc + 1)) : 0;
     const uint64_t T4 = PTX_TILE_4, T1 = PTX_TILE_1;
     const uint64_t trees4 = ptx_a16(4 * 4 * 2 * T4) + ptx_a16(4 * (T4 + 1)) + ptx_a16(8 * (T4 / 32 + 2));
@@ -345,14 +408,41 @@ static inline uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t
     if (p5 > m) m = p5;
     return persist + m;
 }
+/* the same from a log header */
+PTX_HD uint32_t ptx_abits_of(uint32_t max_actor) {
+    uint32_t k = 0;
+    while ((1u << k) < max_actor + 1u && k < 31) ++k;
+    return k;
+}
+PTX_HD uint64_t ptx_lds_need_hdr(uint64_t N, const ptx_log_hdr& h) {
+    const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
+    const uint32_t abits = ptx_abits_of(h.max_actor);
+    const uint64_t ks = ((uint64_t)h.max_counter + 1) << (abits > 12 ? 12 : abits);
+    return ptx_lds_need(N, h.n_ins, h.n_del, K, h.n_mark[PTX_MARK_COMMENT], ks);
+}
+
+/* census of one log, sequential (host side: the emulation driver; the device has ptx_census_kernel) */
+static inline void ptx_census_rows(const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type, uint64_t n_rows, ptx_log_hdr* out) {
+    ptx_log_hdr h;
+    h.n_ins = h.n_del = h.max_counter = h.max_actor = 0;
+    h.n_mark[0] = h.n_mark[1] = h.n_mark[2] = h.n_mark[3] = 0;
+    for (uint64_t i = 0; i < n_rows; ++i) {
+        const uint32_t ctr = (uint32_t)(op_id[i] >> 32), act = (uint32_t)op_id[i];
+        if (ctr > h.max_counter) h.max_counter = ctr;
+        if (act > h.max_actor) h.max_actor = act;
+        if (action[i] == PTX_ACT_INSERT) h.n_ins++;
+        else if (action[i] == PTX_ACT_DELETE) h.n_del++;
+        else if ((action[i] == PTX_ACT_ADDMARK || action[i] == PTX_ACT_REMOVEMARK) && mark_type[i] < 4) h.n_mark[mark_type[i]]++;
+    }
+    *out = h;
+}
 
 PTX_DEV void ptx_write_result(const PtxMergeArgs& A, uint32_t log, PtxHdr* H, uint32_t status, uint32_t lds_high) {
     PTX_LEADER {
-        const uint64_t ca = H->cnt_a;
         ptx_log_result r;
         r.status = status;
-        r.n_ops = status ? 0 : (uint32_t)(ca >> 48);
-        r.n_elems = status ? 0 : (uint32_t)(ca & 0xFFFFu);
+        r.n_ops = status ? 0 : H->n_applied;
+        r.n_elems = status ? 0 : H->n_ins;
         r.n_visible = status ? 0 : H->V;
         r.n_spans = status ? 0 : H->S;
         r.n_cintervals = status ? 0 : H->I;
@@ -465,6 +555,10 @@ PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
 #define PTX_STAMP(k)                                               \
     do {                                                           \
         if (A.clocks && threadIdx.x == 0) H->clk[k] = ptx_clock(); \
+        if ((k) != 0 && A.stop_after == (k)) {                     \
+            ptx_write_result(A, log, H, PTX_OK, bp.high);          \
+            return;                                                \
+        }                                                          \
     } while (0)
 #endif
 
@@ -476,10 +570,9 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     PTX_LEADER {
         H->err = PTX_NO_ERR;
         H->max_ctr = H->max_actor = 0;
-        H->cur_i = H->cur_d = H->cur_big = 0;
-        H->cur_t[0] = H->cur_t[1] = H->cur_t[2] = H->cur_t[3] = 0;
+        H->cur_big = 0;
+        H->n_ins = H->n_applied = 0;
         H->V = H->S = H->I = 0;
-        H->cnt_a = H->cnt_t = 0;
         H->h1 = H->h2 = 0;
         for (int k = 0; k <= PTX_NCLK; ++k) H->clk[k] = 0;
     }
@@ -502,76 +595,36 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     const uint32_t* payload = A.payload + base;
     const uint8_t* action = A.action + base;
     const uint8_t* mark_type = A.mark_type + base;
-
-    /* kind[] (action | mark_type << 4 per row) lives at the TOP of the LDS window and only until the
-     * row lists are built (P2); everything else is bump-allocated from the bottom */
-    const uint32_t kind_bytes = (N + 15u) & ~15u;
-    if (bp.off + kind_bytes > A.lds_bytes) {
-        ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);
+    if (N == 0) { /* a log with no rows: an empty document */
+        PTX_LEADER {
+            uint64_t g1 = 0, g2 = 0;
+            ptx_digest_item(g1, g2, 4u, 0u, 0u, 0u);
+            ptx_digest_item(g1, g2, 4u, 1u, 0u, 0u);
+            H->h1 += g1;
+            H->h2 += g2;
+        }
+        PTX_SYNC();
+        ptx_write_result(A, log, H, PTX_OK, bp.high);
         return;
     }
-    uint8_t* kind = lds + A.lds_bytes - kind_bytes;
-    bp.cap = A.lds_bytes - kind_bytes;
 
-    /* ---- P1: load, classify, reduce ---- */
-    {
-        uint32_t mc = 0, ma = 0;
-        unsigned long long ca = 0, ct = 0;
-        PTX_FORU(i0, N) {
-            uint64_t id[PTX_U];
-            uint32_t a[PTX_U], mt[PTX_U];
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u) {
-                if (PTX_IN(i0, u)) {
-                    const uint32_t i = PTX_IX(i0, u);
-                    id[u] = op_id[i];
-                    a[u] = action[i];
-                    mt[u] = mark_type[i];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u) {
-                if (PTX_IN(i0, u)) {
-                    const uint32_t i = PTX_IX(i0, u);
-                    const uint32_t ctr = (uint32_t)(id[u] >> 32), act = (uint32_t)id[u];
-                    kind[i] = (uint8_t)((a[u] & 15u) | ((mt[u] & 15u) << 4));
-                    mc = ctr > mc ? ctr : mc;
-                    ma = act > ma ? act : ma;
-                    if (ctr == 0 || a[u] > PTX_ACT_NOP) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
-                    if (a[u] == PTX_ACT_INSERT) ca += 1ull;
-                    else if (a[u] == PTX_ACT_DELETE) ca += 1ull << 16;
-                    else if (a[u] == PTX_ACT_ADDMARK || a[u] == PTX_ACT_REMOVEMARK) {
-                        ca += 1ull << 32;
-                        if (mt[u] > 3) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
-                        else ct += 1ull << (16 * mt[u]);
-                    }
-                    if (a[u] != PTX_ACT_MAKELIST && a[u] != PTX_ACT_NOP) ca += 1ull << 48;
-                    if (A.out_rank) A.out_rank[base + i] = 0xFFFFFFFFu;
-                }
-            }
-        }
-        ptx_reduce_max32(&H->max_ctr, mc);
-        ptx_reduce_max32(&H->max_actor, ma);
-        ptx_reduce_add64(&H->cnt_a, ca);
-        ptx_reduce_add64(&H->cnt_t, ct);
-    }
-    PTX_BAIL_IF_ERROR();
-    PTX_STAMP(1);
-
-    const uint32_t n = (uint32_t)(H->cnt_a & 0xFFFFu);         /* list elements (inserts) */
-    const uint32_t D = (uint32_t)((H->cnt_a >> 16) & 0xFFFFu); /* deletes */
-    const uint32_t K = (uint32_t)((H->cnt_a >> 32) & 0xFFFFu); /* mark ops */
-    const unsigned long long cnt_t = H->cnt_t;                 /* mark ops per mark type, 16 bits each */
-#define PTX_NTYPE(t) ((uint32_t)((cnt_t >> (16u * (t))) & 0xFFFFu))
-    /* mark ops are listed grouped by type: type t owns mark indices [moff_t, moff_{t+1}) */
-    const uint32_t moff1 = PTX_NTYPE(0), moff2 = moff1 + PTX_NTYPE(1), moff3 = moff2 + PTX_NTYPE(2);
-    const uint32_t Kc = PTX_NTYPE(PTX_MARK_COMMENT);
+    /* ---- the log header (census) sizes everything; the row pass below verifies it ---- */
+    const ptx_log_hdr hd = A.log_hdr[log];
+    const uint32_t n = hd.n_ins; /* list elements (inserts) */
+    const uint32_t D = hd.n_del; /* deletes */
+    const uint32_t moff1 = hd.n_mark[0], moff2 = moff1 + hd.n_mark[1], moff3 = moff2 + hd.n_mark[2];
+    const uint32_t Kc = hd.n_mark[PTX_MARK_COMMENT];
+    const uint32_t K = moff3 + hd.n_mark[3]; /* mark ops; listed grouped by type: type t owns [moff_t, moff_{t+1}) */
 #define PTX_TYPE_OF(k) (((k) >= moff1 ? 1u : 0u) + ((k) >= moff2 ? 1u : 0u) + ((k) >= moff3 ? 1u : 0u))
+    if ((uint64_t)n + D + K > N) {
+        ptx_write_result(A, log, H, PTX_ERR_BAD_OP, bp.high);
+        return;
+    }
 
     PtxElemIndex ix;
-    ix.max_ctr = H->max_ctr;
-    ix.max_actor = H->max_actor;
-    ix.abits = ptx_ceil_log2(ix.max_actor + 1);
+    ix.max_ctr = hd.max_counter;
+    ix.max_actor = hd.max_actor;
+    ix.abits = ptx_abits_of(ix.max_actor);
     const uint32_t kbits = ptx_ceil_log2(K + 1);
     if (ix.abits > 12 || ix.max_ctr >= (1u << 19) || n > 32766u) { /* keyspace far below 2^31 bits; 2n+1 tour nodes in 16 bits */
         ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);
@@ -596,7 +649,7 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     PTX_BAIL_CAPACITY();
     const uint32_t mark_lds = bp.off; /* everything above this mark is phase scratch */
 
-    /* ---- P2: id bitmaps, row lists ---- */
+    /* ---- P1: ONE pass over the rows: id bitmaps, row lists per class ---- */
     {
         uint32_t* allbits = ptx_alloc<uint32_t>(bp, nw + 1); /* every op id: duplicate detection */
         PTX_BAIL_CAPACITY();
@@ -609,51 +662,85 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         }
         PTX_FOR(w, (K >> 5) + 2) addbits[w] = 0;
         PTX_FOR(w, nwe + 1) delbits[w] = 0;
-        PTX_SYNC();
-        PTX_FORU(i0, N) {
-            uint64_t id[PTX_U];
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(i0, u)) id[u] = op_id[PTX_IX(i0, u)];
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u) {
-                /* every lane runs the appends (wave ballots); lanes past the end contribute nothing */
-                const bool in = PTX_IN(i0, u);
-                const uint32_t i = in ? PTX_IX(i0, u) : 0u;
-                const uint32_t kd = in ? kind[i] : (uint32_t)PTX_ACT_NOP;
-                const uint32_t a = kd & 15u, mt = kd >> 4;
-                const bool is_ins = a == PTX_ACT_INSERT, is_del = a == PTX_ACT_DELETE;
-                const bool is_mark = a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK;
-                if (in) {
-                    uint32_t key = 0;
-                    ptx_id_key(ix, id[u], key);
-                    const uint32_t bit = 1u << (key & 31);
-                    if (ptx_atomic_or(&allbits[key >> 5], bit) & bit) ptx_raise(H, i, 1, PTX_ERR_DUPLICATE_OP);
-                    if (is_ins) ptx_atomic_or(&ix.ib[key >> 5].bits, bit);
-                }
-                const uint32_t ji = ptx_append(&H->cur_i, is_ins);
-                const uint32_t jd = ptx_append(&H->cur_d, is_del);
-                const uint32_t j0 = ptx_append(&H->cur_t[0], is_mark && mt == 0);
-                const uint32_t j1 = ptx_append(&H->cur_t[1], is_mark && mt == 1);
-                const uint32_t j2 = ptx_append(&H->cur_t[2], is_mark && mt == 2);
-                const uint32_t j3 = ptx_append(&H->cur_t[3], is_mark && mt == 3);
-                if (is_ins) ilist[ji] = (uint16_t)i;
-                else if (is_del) dlist[jd] = (uint16_t)i;
-                else if (is_mark) {
-                    const uint32_t k = mt == 0 ? j0 : mt == 1 ? moff1 + j1 : mt == 2 ? moff2 + j2 : moff3 + j3;
-                    mlist[k] = (uint16_t)i;
-                    if (a == PTX_ACT_ADDMARK) ptx_atomic_or(&addbits[k >> 5], 1u << (k & 31));
-                }
-            }
+        const uint32_t dummy = n + D + K; /* spare list slot: rows that are listed nowhere write there */
+        PTX_LEADER {
+            /* list cursors start at the first slot of their class (0 insert, 1 delete, 2..5 mark type 0..3) */
+            H->cur[0] = 0;
+            H->cur[1] = n;
+            H->cur[2] = n + D;
+            H->cur[3] = n + D + moff1;
+            H->cur[4] = n + D + moff2;
+            H->cur[5] = n + D + moff3;
+            H->cur[6] = H->cur[7] = 0;
+            H->n_ins = n;
+            H->n_applied = n + D + K;
         }
         PTX_SYNC();
+        /* Branch-free row loop: every row does the same work; rows that are out of range, malformed or of no
+         * interest (makeList, NOP) use class 6/7 = a spare cursor, the spare list slot and OR 0 into the bitmaps. */
+        uint32_t badrow = 0xFFFFFFFFu; /* first malformed / duplicate row seen by this thread */
+        PTX_FORG(g, (N + PTX_U - 1u) / PTX_U) {
+            /* this thread's PTX_U consecutive rows; indices past the end are clamped, their effects masked */
+            uint64_t id[PTX_U];
+            uint32_t a[PTX_U], mt[PTX_U], cls[PTX_U], slot[PTX_U];
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u) {
+                const uint32_t r = g * PTX_U + (uint32_t)u;
+                const uint32_t i = r < N ? r : N - 1u;
+                id[u] = op_id[i];
+                a[u] = action[i];
+                mt[u] = mark_type[i];
+            }
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u) {
+                const uint32_t i = g * PTX_U + (uint32_t)u;
+                const bool in = i < N;
+                const uint32_t ctr = (uint32_t)(id[u] >> 32), act = (uint32_t)id[u];
+                /* action -> class through a nibble table: 0 makeList->6, 1 insert->0, 2 delete->1, 3/4 marks->2, 5 nop->6, else 7 */
+                uint32_t c = a[u] < 8u ? (0x77622106u >> (a[u] * 4u)) & 15u : 7u;
+                c = c == 2u ? (mt[u] < 4u ? 2u + mt[u] : 7u) : c;
+                const bool keybad = ctr - 1u >= ix.max_ctr || act > ix.max_actor; /* ctr == 0 or beyond the header's bounds */
+                badrow = in && (c == 7u || keybad) && i < badrow ? i : badrow;
+                cls[u] = (!in || keybad) ? 7u : c;
+            }
+            ptx_wave_slots(H->cur, cls, slot);
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u) {
+                const uint32_t i = g * PTX_U + (uint32_t)u;
+                const uint32_t c = cls[u];
+                const uint32_t key = c == 7u ? 0u : ((uint32_t)(id[u] >> 32) << ix.abits) | (uint32_t)id[u];
+                const uint32_t bit = c == 7u ? 0u : 1u << (key & 31);
+                const uint32_t old = ptx_atomic_or(&allbits[key >> 5], bit);
+                badrow = (old & bit) != 0u && i < badrow ? i : badrow; /* same opId twice */
+                ptx_atomic_or(&ix.ib[key >> 5].bits, c == 0u ? bit : 0u);
+                const uint32_t sl = slot[u] < dummy ? slot[u] : dummy;
+                list[sl] = (uint16_t)i;
+                const uint32_t k = c >= 2u && c < 6u && sl >= n + D ? sl - (n + D) : 0u;
+                ptx_atomic_or(&addbits[k >> 5], a[u] == PTX_ACT_ADDMARK && sl != dummy ? 1u << (k & 31) : 0u);
+                if (A.out_rank && i < N) A.out_rank[base + i] = 0xFFFFFFFFu; /* insert rows are overwritten in P5a */
+            }
+        }
+        if (badrow != 0xFFFFFFFFu) {
+            /* which of the two: re-test the row */
+            const uint64_t id = op_id[badrow];
+            const uint32_t ctr = (uint32_t)(id >> 32), act = (uint32_t)id, a = action[badrow], mt = mark_type[badrow];
+            const bool malformed = ctr == 0 || ctr > ix.max_ctr || act > ix.max_actor || a > PTX_ACT_NOP ||
+                                   ((a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) && mt > 3);
+            ptx_raise(H, badrow, 1, malformed ? PTX_ERR_BAD_OP : PTX_ERR_DUPLICATE_OP);
+        }
+        PTX_SYNC();
+        PTX_LEADER {
+            /* the header must be the exact census of the rows */
+            if (H->cur[0] != n || H->cur[1] != n + D || H->cur[2] != n + D + moff1 || H->cur[3] != n + D + moff2 || H->cur[4] != n + D + moff3 ||
+                H->cur[5] != n + D + K)
+                ptx_raise(H, 0, 0, PTX_ERR_BAD_OP);
+        }
         PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
         PTX_SYNC();
         ptx_scan_excl<uint32_t, 2>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
     }
     PTX_BAIL_IF_ERROR();
     bp.off = mark_lds;
-    bp.cap = A.lds_bytes; /* kind[] is dead from here on */
     PTX_STAMP(2);
 
     /* ---- P3: causal tree of the inserts -> document position of every element ---- */
@@ -661,13 +748,14 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         uint32_t* cnt = ptx_alloc<uint32_t>(bp, n + 2);   /* children per parent -> bucket starts -> bucket ends */
         uint16_t* srt = ptx_alloc<uint16_t>(bp, n + 1);   /* children of every parent, descending opId, parents ascending */
         uint32_t* L = ptx_alloc<uint32_t>(bp, 2 * n + 2); /* Euler tour: next << 16 | weight */
+        uint32_t* R = ptx_alloc<uint32_t>(bp, (2 * n) / PTX_S + 2); /* the splitters' list: next splitter << 16 | weight */
         PTX_BAIL_CAPACITY();
         uint16_t* seg = (uint16_t*)L; /* bucket members in arrival order (dead before L is built) */
         uint16_t* big = seg + n + 1;  /* positions in seg of the members of large buckets */
 
         PTX_FOR(p, n + 2) cnt[p] = 0;
         PTX_SYNC();
-        /* P3a: element index of every insert, its parent, children counts; tombstone flags */
+        /* P3a: element index of every insert, its parent, children counts */
         PTX_FORU(j0, n) {
             uint32_t i[PTX_U];
             uint64_t id[PTX_U], ra[PTX_U];
@@ -697,26 +785,9 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                     ptx_atomic_add(&cnt[pe], 1u);
                 }
         }
-        PTX_FORU(j0, D) {
-            uint32_t i[PTX_U];
-            uint64_t ra[PTX_U];
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(j0, u)) i[u] = dlist[PTX_IX(j0, u)];
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(j0, u)) ra[u] = ref_a[i[u]];
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(j0, u)) {
-                    const int t = ptx_elem_lookup(ix, ra[u]);
-                    if (t < 0) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);             /* micromerge.ts:752 */
-                    else ptx_atomic_or(&delbits[t >> 5], 1u << ((uint32_t)t & 31u)); /* idempotent: micromerge.ts:693 */
-                }
-        }
         PTX_BAIL_IF_ERROR();
         ptx_scan_excl<uint32_t, 1>(cnt, n + 2, H->scan_tmp); /* cnt[p] = first slot of p's children */
-        /* P3b: scatter into the parent buckets; application-order checks now that row_of is complete */
+        /* P3b: scatter into the parent buckets; tombstone flags; application-order checks now that row_of is complete */
         PTX_FORU(e0, n) {
             uint32_t pe[PTX_U], re[PTX_U], rp[PTX_U];
 #pragma unroll
@@ -748,8 +819,10 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
 #pragma unroll
             for (int u = 0; u < PTX_U; ++u)
                 if (PTX_IN(j0, u)) {
+                    /* the element must exist when the delete is applied (micromerge.ts:752); deleting twice is fine (:693) */
                     const int t = ptx_elem_lookup(ix, ra[u]);
-                    if (t >= 0 && row_of[t] >= i[u]) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);
+                    if (t < 0 || row_of[t] >= i[u]) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);
+                    else ptx_atomic_or(&delbits[t >> 5], 1u << ((uint32_t)t & 31u));
                 }
         }
         PTX_BAIL_IF_ERROR();
@@ -790,47 +863,67 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         }
         PTX_SYNC();
         PTX_STAMP(4);
-        /* P3d: Euler tour.  Nodes: enter(x) = x for x in [0,n] (n = HEAD), exit(x) = n+1+x for x in [0,n).
-         * weight 1 on enter(x<n): the suffix sum at enter(x) counts the elements from x to the end. */
+        /* P3d: Euler tour.  Nodes: 0 = enter(HEAD), x+1 = enter(x), n+1+x = exit(x) for x in [0,n), and the
+         * terminal node 2n+1.  weight 1 on enter(x): the suffix sum at enter(x) counts the elements from x
+         * to the end of the document, so position(x) = n - suffix(enter(x)). */
+        const uint32_t term = 2 * n + 1;
         PTX_FOR(j, n + 1) {
             const uint32_t s = j ? cnt[j - 1] : 0u, t = cnt[j];
-            const uint32_t nx = t > s ? (uint32_t)srt[s] : (j == n ? PTX_END : n + 1u + j);
+            const uint32_t nx = t > s ? (uint32_t)srt[s] + 1u : (j == n ? term : n + 1u + j);
             const uint32_t mine = (nx << 16) | (j < n ? 1u : 0u);
-            uint32_t xo = 0, other = 0;
+            uint32_t xo = term, other = term << 16;
             if (j < n) {
                 const uint32_t x = srt[j];
                 const uint32_t p = par[x];
-                const uint32_t nx2 = j + 1u < cnt[p] ? (uint32_t)srt[j + 1] : (p == n ? PTX_END : n + 1u + p);
+                const uint32_t nx2 = j + 1u < cnt[p] ? (uint32_t)srt[j + 1] + 1u : (p == n ? term : n + 1u + p);
                 xo = n + 1u + x;
                 other = nx2 << 16;
             }
-            L[j] = mine;
-            if (j < n) L[xo] = other;
+            L[j < n ? j + 1u : 0u] = mine;
+            L[xo] = other; /* j == n writes the terminal node */
         }
         PTX_SYNC();
+        /* List ranking, work-efficient: every PTX_S-th node is a splitter; a splitter walks to the next one
+         * summing weights (each tour node is visited once), the ~2n/PTX_S splitters are ranked by in-place
+         * pointer jumping, and a second walk hands the ranks out. */
         {
-            const uint32_t nodes = 2 * n + 1;
-            const uint32_t rounds = ptx_ceil_log2(nodes);
+            const uint32_t ns = (2 * n) / PTX_S + 1; /* splitters 0, S, 2S, ... <= 2n */
+            PTX_FOR(sp, ns) {
+                uint32_t a = L[sp * PTX_S];
+                uint32_t acc = a & 0xFFFFu, nx = a >> 16;
+                while (nx != term && (nx & (PTX_S - 1u)) != 0u) {
+                    a = L[nx];
+                    acc += a & 0xFFFFu;
+                    nx = a >> 16;
+                }
+                R[sp] = ((nx == term ? ns : nx / PTX_S) << 16) | acc;
+            }
+            PTX_LEADER { R[ns] = ns << 16; } /* terminal: points at itself with weight 0 */
+            PTX_SYNC();
+            const uint32_t rounds = ptx_ceil_log2(ns + 1);
             for (uint32_t r = 0; r < rounds; ++r) {
                 /* in-place pointer jumping: every intermediate {next, weight} word is a valid state
                  * (weight = sum over [node, next)), so reading a word another thread already advanced
                  * this round only makes the jump longer */
-                PTX_FORU(v0, nodes) {
-                    uint32_t a[PTX_U], b[PTX_U];
-#pragma unroll
-                    for (int u = 0; u < PTX_U; ++u)
-                        if (PTX_IN(v0, u)) a[u] = L[PTX_IX(v0, u)];
-#pragma unroll
-                    for (int u = 0; u < PTX_U; ++u)
-                        if (PTX_IN(v0, u)) b[u] = (a[u] >> 16) != PTX_END ? L[a[u] >> 16] : 0xFFFF0000u;
-#pragma unroll
-                    for (int u = 0; u < PTX_U; ++u)
-                        if (PTX_IN(v0, u) && (a[u] >> 16) != PTX_END) L[PTX_IX(v0, u)] = (b[u] & 0xFFFF0000u) | ((a[u] + b[u]) & 0xFFFFu);
+                PTX_FOR(sp, ns) {
+                    const uint32_t a = R[sp];
+                    const uint32_t b = R[a >> 16];
+                    R[sp] = (b & 0xFFFF0000u) | ((a + b) & 0xFFFFu);
                 }
                 PTX_SYNC();
             }
+            PTX_FOR(sp, ns) {
+                uint32_t v = sp * PTX_S;
+                uint32_t run = R[sp] & 0xFFFFu; /* elements from node v to the end */
+                for (;;) {
+                    const uint32_t a = L[v];
+                    if (v - 1u < n) par[v - 1u] = (uint16_t)(n - run); /* document position incl. tombstones */
+                    run -= a & 0xFFFFu;
+                    v = a >> 16;
+                    if (v == term || (v & (PTX_S - 1u)) == 0u) break;
+                }
+            }
         }
-        PTX_FOR(e, n) par[e] = (uint16_t)(n - (L[e] & 0xFFFFu)); /* document position incl. tombstones */
         PTX_SYNC();
     }
     uint16_t* rnk = par;

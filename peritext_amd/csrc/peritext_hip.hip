@@ -41,6 +41,65 @@ PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1)    /* <= 128 VGPRs: any launch shape
 PTX_MERGE_KERNEL(ptx_merge_kernel_w6, 512, 6)  /* <= 80 VGPRs: 3 workgroups of 512 per CU */
 PTX_MERGE_KERNEL(ptx_merge_kernel_w8, 512, 8)  /* <= 64 VGPRs: 4 workgroups of 512 per CU */
 
+/* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
+ * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
+__global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off, const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type,
+                                                          ptx_log_hdr* hdr, uint32_t* shape, int compute) {
+    __shared__ uint32_t sh[8];
+    const uint32_t log = blockIdx.x;
+    const uint64_t b0 = log_off[log], b1 = log_off[log + 1];
+    if (compute) {
+        if (threadIdx.x < 8) sh[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t c[6] = {0, 0, 0, 0, 0, 0}, mc = 0, ma = 0;
+        for (uint64_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) {
+            const uint64_t id = op_id[i];
+            const uint32_t a = action[i], mt = mark_type[i];
+            mc = max(mc, (uint32_t)(id >> 32));
+            ma = max(ma, (uint32_t)id);
+            c[0] += a == PTX_ACT_INSERT;
+            c[1] += a == PTX_ACT_DELETE;
+            const bool mk = a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK;
+            c[2] += mk && mt == 0;
+            c[3] += mk && mt == 1;
+            c[4] += mk && mt == 2;
+            c[5] += mk && mt == 3;
+        }
+        for (int k = 0; k < 6; ++k) {
+            uint32_t v = c[k];
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sh[k], v);
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            mc = max(mc, (uint32_t)__shfl_xor((int)mc, d, 64));
+            ma = max(ma, (uint32_t)__shfl_xor((int)ma, d, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&sh[6], mc);
+            atomicMax(&sh[7], ma);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ptx_log_hdr h;
+            h.n_ins = sh[0];
+            h.n_del = sh[1];
+            h.n_mark[0] = sh[2];
+            h.n_mark[1] = sh[3];
+            h.n_mark[2] = sh[4];
+            h.n_mark[3] = sh[5];
+            h.max_counter = sh[6];
+            h.max_actor = sh[7];
+            hdr[log] = h;
+        }
+    }
+    if (threadIdx.x == 0) {
+        const ptx_log_hdr h = hdr[log];
+        const uint64_t need = ptx_lds_need_hdr(b1 - b0, h);
+        atomicMax(&shape[0], (uint32_t)min(need, (uint64_t)0xFFFFFFFFu));
+        atomicMax(&shape[1], (uint32_t)min(b1 - b0, (uint64_t)0xFFFFFFFFu));
+    }
+}
+
 __global__ void ptx_pack_digests_kernel(const ptx_log_result* res, uint32_t first, uint32_t count, uint64_t* dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) {
@@ -70,6 +129,7 @@ struct ptx_ctx {
     size_t max_lds = 0;
     int force_threads = 0; /* PTX_THREADS env override (tuning) */
     int force_lds = 0;     /* PTX_LDS_BYTES env override (tuning) */
+    int stop_after = 0;    /* PTX_STOP_AFTER env (diagnostic): truncate the kernel after a phase, for per-phase PMC deltas */
     int variant = 0;       /* PTX_VARIANT env override (tuning): register-budget variant of the kernel */
     uint32_t flags = 0;
     unsigned long long* clocks = nullptr; /* device [PTX_NCLK], non-null only while ptx_merge_phase_cycles runs */
@@ -82,6 +142,7 @@ struct ptx_dbatch {
     uint64_t *log_off = nullptr, *op_id = nullptr, *ref_a = nullptr, *ref_b = nullptr;
     uint32_t* payload = nullptr;
     uint8_t *action = nullptr, *mark_type = nullptr, *side_a = nullptr, *side_b = nullptr;
+    ptx_log_hdr* log_hdr = nullptr; /* always owned: provided headers are copied, missing ones computed */
     /* launch shape derived from the largest log */
     uint32_t max_log_ops = 0;
     uint32_t lds_bytes = 0;
@@ -125,33 +186,26 @@ static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t ma
     b->threads = t;
 }
 
-/* scan the host columns once: per-log counts -> exact LDS requirement of the batch */
-static uint64_t scan_host_batch(const ptx_batch* h, uint32_t* max_log_ops) {
-    uint64_t need = 0;
-    uint32_t mx = 0;
-    for (uint32_t l = 0; l < h->n_logs; ++l) {
-        const uint64_t b0 = h->log_off[l], b1 = h->log_off[l + 1];
-        uint64_t n = 0, Dn = 0, K = 0, Kc = 0;
-        uint32_t mc = 0, ma = 0;
-        for (uint64_t i = b0; i < b1; ++i) {
-            const uint8_t a = h->action[i];
-            if (a == PTX_ACT_INSERT) n++;
-            else if (a == PTX_ACT_DELETE) Dn++;
-            else if (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) {
-                K++;
-                if (h->mark_type[i] == PTX_MARK_COMMENT) Kc++;
-            }
-            mc = std::max(mc, (uint32_t)(h->op_id[i] >> 32));
-            ma = std::max(ma, (uint32_t)h->op_id[i]);
+/* Census of a resident batch: headers (computed on the device unless the caller supplied them) and the
+ * launch shape.  `have_hdr`: b->log_hdr already holds the caller's headers. */
+static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
+    uint32_t* shape = nullptr;
+    uint32_t h[2] = {0, 0};
+    if (b->n_logs) {
+        PTX_HIP(ctx, hipMalloc((void**)&shape, 8));
+        hipError_t e = hipMemsetAsync(shape, 0, 8, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(ptx_census_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->log_off, b->op_id, b->action, b->mark_type, b->log_hdr,
+                               shape, have_hdr ? 0 : 1);
+            e = hipGetLastError();
         }
-        uint32_t abits = 0;
-        while ((1u << abits) < ma + 1u) ++abits;
-        const uint64_t ks = ((uint64_t)mc + 1) << std::min(abits, 12u);
-        need = std::max(need, ptx_lds_need(b1 - b0, n, Dn, K, Kc, ks));
-        mx = std::max<uint32_t>(mx, (uint32_t)std::min<uint64_t>(b1 - b0, 0xFFFFFFFFull));
+        if (e == hipSuccess) e = hipMemcpyAsync(h, shape, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(shape);
+        if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("census: ") + hipGetErrorString(e));
     }
-    *max_log_ops = mx;
-    return need;
+    shape_launch(ctx, b, h[0], h[1]);
+    return PTX_OK;
 }
 
 static ptx_status check_batch(ptx_ctx* ctx, const ptx_batch* h) {
@@ -205,6 +259,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     }
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     if (const char* sv = getenv("PTX_VARIANT")) ctx->variant = atoi(sv);
+    if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     e = hipFuncSetAttribute((const void*)ptx_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -233,7 +288,7 @@ uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx) {
     uint32_t lo = 0, hi = 65534;
     while (lo < hi) {
         const uint32_t mid = (lo + hi + 1) / 2;
-        const uint64_t worst = std::max(ptx_lds_need(mid, mid, 0, 0, 0, 4ull * mid), ptx_lds_need(mid, mid / 2, 0, mid / 2, mid / 2, 4ull * mid));
+        const uint64_t worst = std::max(ptx_lds_need(mid, mid, 0, 0, 0, 4ull * mid), ptx_lds_need(mid, mid / 3, mid / 3, mid / 3, mid / 3, 4ull * mid));
         if (worst <= lds) lo = mid;
         else hi = mid - 1;
     }
@@ -254,6 +309,7 @@ void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
         (void)hipFree(b->side_a);
         (void)hipFree(b->side_b);
     }
+    (void)hipFree(b->log_hdr);
     delete b;
 }
 
@@ -291,6 +347,12 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
     PTX_TRY(dalloc(&b->mark_type, T));
     PTX_TRY(dalloc(&b->side_a, T));
     PTX_TRY(dalloc(&b->side_b, T));
+    PTX_TRY(dalloc(&b->log_hdr, (uint64_t)b->n_logs));
+    if (h->log_hdr && h->n_logs) {
+        PTX_TRY(hipMemcpyAsync(b->log_hdr, h->log_hdr, (size_t)h->n_logs * sizeof(ptx_log_hdr), hipMemcpyHostToDevice, ctx->stream));
+        for (uint32_t k = 1; k < copies; ++k)
+            PTX_TRY(hipMemcpyAsync(b->log_hdr + (size_t)k * h->n_logs, b->log_hdr, (size_t)h->n_logs * sizeof(ptx_log_hdr), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     if (M) {
         PTX_TRY(hipMemcpyAsync(b->op_id, h->op_id, M * 8, hipMemcpyHostToDevice, ctx->stream));
         PTX_TRY(hipMemcpyAsync(b->ref_a, h->ref_a, M * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -329,9 +391,11 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
         PTX_TRY(e2);
     }
 #undef PTX_TRY
-    uint32_t mx = 0;
-    const uint64_t need = scan_host_batch(h, &mx);
-    shape_launch(ctx, b, need, mx);
+    st = census_and_shape(ctx, b, h->log_hdr != nullptr);
+    if (st) {
+        ptx_batch_free(ctx, b);
+        return st;
+    }
     *out = b;
     return PTX_OK;
 }
@@ -356,8 +420,19 @@ ptx_status ptx_batch_wrap_device(ptx_ctx* ctx, const ptx_batch* d, ptx_dbatch** 
     b->mark_type = (uint8_t*)d->mark_type;
     b->side_a = (uint8_t*)d->side_a;
     b->side_b = (uint8_t*)d->side_b;
-    /* the columns are not host-readable: size the launch for the largest supported log */
-    shape_launch(ctx, b, ctx->max_lds, 65534);
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = dalloc(&b->log_hdr, (uint64_t)b->n_logs);
+    if (e == hipSuccess && d->log_hdr && b->n_logs)
+        e = hipMemcpyAsync(b->log_hdr, d->log_hdr, (size_t)b->n_logs * sizeof(ptx_log_hdr), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        ptx_batch_free(ctx, b);
+        return fail(ctx, PTX_ERR_HIP, std::string("wrap: ") + hipGetErrorString(e));
+    }
+    st = census_and_shape(ctx, b, d->log_hdr != nullptr);
+    if (st) {
+        ptx_batch_free(ctx, b);
+        return st;
+    }
     *out = b;
     return PTX_OK;
 }
@@ -406,11 +481,12 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.mark_type = b->mark_type;
     A.side_a = b->side_a;
     A.side_b = b->side_b;
+    A.log_hdr = b->log_hdr;
     A.chg_off = nullptr;
     A.chg_actor = A.chg_seq = A.chg_nops = A.chg_deps = nullptr;
     A.max_actors = 0;
     A.clocks = ctx->clocks;
-    A.pad = 0;
+    A.stop_after = (uint32_t)ctx->stop_after;
     A.res = r->logs;
     A.out_values = r->values;
     A.out_spans = r->spans;

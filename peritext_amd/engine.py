@@ -33,6 +33,8 @@ def _batch_struct(b):
     s.chg_nops = p(b.chg_nops, abi.u32p)
     s.chg_deps = p(b.chg_deps, abi.u32p)
     s.max_actors = b.max_actors
+    if b.log_hdr is not None and len(b.log_hdr):
+        s.log_hdr = b.log_hdr.ctypes.data_as(C.POINTER(abi.ptx_log_hdr))
     return s
 
 

@@ -59,6 +59,8 @@ class Batch:
     chg_nops: np.ndarray
     chg_deps: np.ndarray
     max_actors: int
+    # per-log census (include/peritext_hip.h ptx_log_hdr); None = let the library compute it
+    log_hdr: np.ndarray = None
     # decode tables
     values: list = field(default_factory=list)  # value id -> string
     urls: list = field(default_factory=list)  # url id -> string
@@ -87,12 +89,35 @@ class Batch:
         nc = int(self.chg_off[-1])
         chg_off = np.concatenate([self.chg_off[:-1] + k * nc for k in range(copies)] + [np.array([copies * nc], dtype=np.uint64)]).astype(np.uint64)
         rep = lambda a: np.tile(a, copies)  # noqa: E731
+        hdr = None if self.log_hdr is None else np.tile(self.log_hdr, copies)
         return Batch(
             log_off, rep(self.op_id), rep(self.ref_a), rep(self.ref_b), rep(self.payload), rep(self.action),
             rep(self.mark_type), rep(self.side_a), rep(self.side_b), chg_off, rep(self.chg_actor), rep(self.chg_seq),
-            rep(self.chg_nops), rep(self.chg_deps), self.max_actors, self.values, self.urls,
+            rep(self.chg_nops), rep(self.chg_deps), self.max_actors, hdr, self.values, self.urls,
             self.log_doc * copies, self.doc_actors, self.doc_comments,
         )
+
+
+def census(log_off, op_id, action, mark_type):
+    """ptx_log_hdr rows (abi.LOG_HDR_DTYPE) of a batch: what the encoder knows for free about every log."""
+    n_logs = len(log_off) - 1
+    hdr = np.zeros(n_logs, dtype=abi.LOG_HDR_DTYPE)
+    if n_logs == 0 or len(op_id) == 0:
+        return hdr
+    lens = np.diff(log_off.astype(np.int64))
+    lix = np.repeat(np.arange(n_logs), lens)
+    hdr["n_ins"] = np.bincount(lix[action == abi.ACT_INSERT], minlength=n_logs)
+    hdr["n_del"] = np.bincount(lix[action == abi.ACT_DELETE], minlength=n_logs)
+    is_mark = (action == abi.ACT_ADDMARK) | (action == abi.ACT_REMOVEMARK)
+    for t in range(4):
+        hdr["n_mark"][:, t] = np.bincount(lix[is_mark & (mark_type == t)], minlength=n_logs)
+    mc = np.zeros(n_logs, dtype=np.uint32)
+    ma = np.zeros(n_logs, dtype=np.uint32)
+    np.maximum.at(mc, lix, (op_id >> np.uint64(32)).astype(np.uint32))
+    np.maximum.at(ma, lix, (op_id & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+    hdr["max_counter"] = mc
+    hdr["max_actor"] = ma
+    return hdr
 
 
 def _pack(ctr, rank):
@@ -199,7 +224,9 @@ def encode_docs(docs):
         for a, v in row.items():
             deps[i, a] = v
     u64 = lambda x: np.asarray(x, dtype=np.uint64)  # noqa: E731
+    hdr = census(u64(log_off), u64(cols["op_id"]), np.asarray(cols["action"], dtype=np.uint8), np.asarray(cols["mark_type"], dtype=np.uint8))
     return Batch(
+        log_hdr=hdr,
         log_off=u64(log_off), op_id=u64(cols["op_id"]), ref_a=u64(cols["ref_a"]), ref_b=u64(cols["ref_b"]),
         payload=np.asarray(cols["payload"], dtype=np.uint32), action=np.asarray(cols["action"], dtype=np.uint8),
         mark_type=np.asarray(cols["mark_type"], dtype=np.uint8), side_a=np.asarray(cols["side_a"], dtype=np.uint8),

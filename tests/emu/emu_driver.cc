@@ -29,7 +29,7 @@ extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* 
     A.chg_actor = A.chg_seq = A.chg_nops = A.chg_deps = nullptr;
     A.max_actors = b->max_actors;
     A.clocks = nullptr;
-    A.pad = 0;
+    A.stop_after = 0;
     A.res = res;
     A.out_values = values;
     A.out_spans = spans;
@@ -37,6 +37,17 @@ extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* 
     A.out_rank = rank;
     A.n_logs = b->n_logs;
     A.lds_bytes = lds_bytes;
+    ptx_log_hdr* hdr = nullptr;
+    if (b->log_hdr) {
+        A.log_hdr = b->log_hdr;
+    } else { /* what the library's census pre-pass does on the device */
+        hdr = (ptx_log_hdr*)calloc(b->n_logs ? b->n_logs : 1, sizeof(ptx_log_hdr));
+        for (uint32_t l = 0; l < b->n_logs; ++l) {
+            const uint64_t b0 = b->log_off[l], b1 = b->log_off[l + 1];
+            ptx_census_rows(b->op_id + b0, b->action + b0, b->mark_type + b0, b1 - b0, &hdr[l]);
+        }
+        A.log_hdr = hdr;
+    }
     uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)lds_bytes + 64);
     if (!lds) return 1;
     ptx_emu_reverse = reverse;
@@ -45,6 +56,7 @@ extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* 
         ptx_merge_log(A, l, lds);
     }
     free(lds);
+    free(hdr);
     return 0;
 }
 

@@ -144,3 +144,30 @@ def test_capacity_status_when_lds_too_small():
 def test_live_oracle(config, docs, ops):
     """Fresh seeds generated now by the oracle (incl. one FULL config #4 document: 3 replicas x 4096 ops)."""
     H.check_generated(H.oracle_gen(config, docs, 77, ops), H.emu_merge)
+
+
+def test_log_header_census_paths():
+    """The per-log header (ptx_log_hdr) is part of the wire format: a batch without it gets the library's own
+    census and the same results; a header that lies about the rows is PTX_ERR_BAD_OP, never a wrong answer."""
+    gen = _load("ptxgen_mini.json")
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    assert batch.log_hdr is not None and int(batch.log_hdr["n_ins"].sum()) == int((batch.action == abi.ACT_INSERT).sum())
+    with_hdr = H.emu_merge(batch)
+    hdr = batch.log_hdr
+    batch.log_hdr = None
+    without = H.emu_merge(batch)
+    assert (with_hdr.logs["digest"] == without.logs["digest"]).all() and (without.logs["status"] == 0).all()
+    for field, delta in (("n_ins", 1), ("n_del", -1), ("max_counter", -3)):
+        bad = hdr.copy()
+        bad[field][0] = max(0, int(bad[field][0]) + delta)
+        batch.log_hdr = bad
+        res = H.emu_merge(batch)
+        assert int(res.logs["status"][0]) == abi.ERR_BAD_OP, field
+        assert (res.logs["status"][1:] == 0).all()
+    bad = hdr.copy()
+    bad["n_mark"][0] = bad["n_mark"][0][::-1]
+    batch.log_hdr = bad
+    res = H.emu_merge(batch)
+    assert int(res.logs["status"][0]) in (abi.ERR_BAD_OP, 0)  # a palindromic census stays valid
+    if (hdr["n_mark"][0] != hdr["n_mark"][0][::-1]).any():
+        assert int(res.logs["status"][0]) == abi.ERR_BAD_OP

@@ -124,6 +124,24 @@ def test_elem_rank_is_document_position(eng):
             log += 1
 
 
+def test_log_header_census_paths(eng):
+    """Batches without ptx_log_hdr get the device census pre-pass; lying headers are rejected per log."""
+    gen = _load("ptxgen_mini.json")
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    a = eng.apply_materialize(batch)
+    hdr = batch.log_hdr
+    batch.log_hdr = None
+    b = eng.apply_materialize(batch)
+    assert (a.logs == b.logs).all() and (a.logs["status"] == 0).all()
+    bad = hdr.copy()
+    bad["n_ins"][0] += 1
+    bad["max_counter"][1] -= 2
+    batch.log_hdr = bad
+    c = eng.apply_materialize(batch)
+    assert [int(x) for x in c.logs["status"][:3]] == [abi.ERR_BAD_OP, abi.ERR_BAD_OP, 0]
+    assert (c.logs[2:] == a.logs[2:]).all()
+
+
 def test_error_statuses(eng):
     from test_emu_parity import _mini_doc
 

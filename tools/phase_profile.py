@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--lib", default=None, help="experimental build of libperitext_hip.so")
     ap.add_argument("--variants", default="0", help="PTX_VARIANT values to sweep (0 = 128-VGPR kernel, 6, 8)")
     ap.add_argument("--no-phases", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
     if args.lib and not os.path.isabs(args.lib):
         args.lib = os.path.join(ROOT, args.lib)
@@ -47,7 +48,7 @@ def main():
         ms = eng.merge_timed(db, dr, args.iters) / args.iters
         cyc = [0] * 16 if args.no_phases else eng.phase_cycles(db, dr)
         logs = eng.download_logs(dr, eng.n_logs(db))
-        assert int(logs["status"].max()) == 0
+        assert args.no_check or int(logs["status"].max()) == 0
         tot = sum(cyc) or 1
         row = {"lib": os.path.basename(args.lib or "default"), "variant": var, "threads": t, "ms": ms, "Gops_s": out["ops"] / ms / 1e6, "us_per_log_per_cu": ms * 1e3 * 256 / out["logs"],
                "lds_high": int(logs["reserved"][:, 0].max()), "cycles_per_log": tot / out["logs"],

@@ -12,6 +12,7 @@ run() { # name counters...
   timeout 300 rocprofv3 --pmc "$@" --kernel-trace -d $OUT/$name -- python $ROOT/tools/phase_profile.py --no-phases --iters 2 "${EXTRA[@]}" > $OUT/$name.log 2>&1
   local db=$(find $OUT/$name -name '*.db' | head -1)
   [ -n "$db" ] && python $ROOT/tools/prof_summary.py $db --pmc > $OUT/$name.txt 2>&1
+  rm -rf $OUT/$name
 }
 EXTRA=("$@")
 run insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES
