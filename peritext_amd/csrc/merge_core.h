@@ -40,7 +40,7 @@
 #include "../../include/peritext_hip.h"
 
 #ifndef PTX_U
-#define PTX_U 4 /* rows in flight per thread in the batched loops */
+#define PTX_U 2 /* rows in flight per thread in the batched loops */
 #endif
 
 #ifdef PTX_EMU
@@ -393,20 +393,21 @@ PTX_HD uint64_t ptx_a16(uint64_t x) { return (x + 15) & ~15ull; }
 PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
     (void)N;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
-    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (n + D + K + 1)) + ptx_a16(4 * (K / 32 + 2)) +
+    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (K + 1)) + ptx_a16(4 * (K / 32 + 2)) +
                              2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1));
-    const uint64_t p2 = ptx_a16(4 * (nw + 1));
-    const uint64_t p3 = ptx_a16(4 * (n + 2)) + ptx_a16(2 * (n + 1)) + ptx_a16(4 * (2 * n + 2)) + ptx_a16(4 * ((2 * n) / PTX_S + 2));
-    const uint64_t comments = Kc ? 3 * ptx_a16(4 * (Kc + 1)) + ptx_a16(8 * (Kc + 1)) : 0;
+    const uint64_t dr = (D + 2) / 2 > (2 * n) / PTX_S + 2 ? (D + 2) / 2 : (2 * n) / PTX_S + 2;
+    const uint64_t lists = ptx_a16(2 * (n + 1)) + ptx_a16(4 * dr);
+    const uint64_t p1a = lists + ptx_a16(4 * (nw + 1));
+    const uint64_t p3 = lists + ptx_a16(4 * (n + 2)) + ptx_a16(2 * (2 * n + 2));
+    const uint64_t p1 = p1a > p3 ? p1a : p3;
+    const uint64_t comments = Kc ? 2 * ptx_a16(4 * (Kc + 1)) + ptx_a16(8 * (Kc + 1)) : 0;
     const uint64_t T4 = PTX_TILE_4, T1 = PTX_TILE_1;
     const uint64_t trees4 = ptx_a16(4 * 4 * 2 * T4) + ptx_a16(4 * (T4 + 1)) + ptx_a16(8 * (T4 / 32 + 2));
     const uint64_t trees1 = ptx_a16(4 * 2 * T1) + ptx_a16(4 * (T1 + 1)) + ptx_a16(8 * (T1 / 32 + 2));
     uint64_t trees = n > T4 ? (trees1 > trees4 ? trees1 : trees4) : trees4; /* V <= n */
-    const uint64_t p5 = ptx_a16(8 * (nwe + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(4 * (K + 1)) + ptx_a16(2 * (Kc + 1)) +
-                        ptx_a16(4 * (nwe + 1)) + (comments > trees ? comments : trees);
-    uint64_t m = p2 > p3 ? p2 : p3;
-    if (p5 > m) m = p5;
-    return persist + m;
+    const uint64_t p5 = ptx_a16(8 * (nwe + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (nwe + 1)) +
+                        (comments > trees ? comments : trees);
+    return persist + (p1 > p5 ? p1 : p5);
 }
 /* the same from a log header */
 PTX_HD uint32_t ptx_abits_of(uint32_t max_actor) {
@@ -638,16 +639,23 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     const uint32_t nw = (keyspace + 31) / 32;
     const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
     ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
-    uint16_t* list = ptx_alloc<uint16_t>(bp, n + D + K + 1); /* rows of the inserts | deletes | mark ops by type */
-    uint16_t* ilist = list;
-    uint16_t* dlist = list + n;
-    uint16_t* mlist = list + n + D;
+    uint16_t* mlist = ptx_alloc<uint16_t>(bp, K + 1); /* rows of the mark ops, grouped by type; [K] = spare slot */
     uint32_t* addbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 2); /* mark index -> is an addMark */
     uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1);         /* element -> op row */
     uint16_t* par = ptx_alloc<uint16_t>(bp, n + 1);            /* element -> parent element (n = HEAD); later: document position */
     uint32_t* delbits = ptx_alloc<uint32_t>(bp, nwe + 1);      /* element -> tombstone */
     PTX_BAIL_CAPACITY();
     const uint32_t mark_lds = bp.off; /* everything above this mark is phase scratch */
+    /* scratch of P1..P3: rows of the inserts and of the deletes, the tree arrays (allocated here so that
+     * the row pass can fill the lists; the causal-tree phase reuses ilist's storage for `srt`) */
+    uint16_t* ilist = ptx_alloc<uint16_t>(bp, n + 1);
+    /* rows of the deletes; once they are applied (P3b) the same storage holds the splitters' list of the
+     * list ranking: next splitter << 16 | weight */
+    const uint32_t dr_words = ((D + 2) / 2 > (2 * n) / PTX_S + 2) ? (D + 2) / 2 : (2 * n) / PTX_S + 2;
+    uint32_t* R = ptx_alloc<uint32_t>(bp, dr_words);
+    uint16_t* dlist = (uint16_t*)R;
+    PTX_BAIL_CAPACITY();
+    const uint32_t tree_lds = bp.off;
 
     /* ---- P1: ONE pass over the rows: id bitmaps, row lists per class ---- */
     {
@@ -662,15 +670,14 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         }
         PTX_FOR(w, (K >> 5) + 2) addbits[w] = 0;
         PTX_FOR(w, nwe + 1) delbits[w] = 0;
-        const uint32_t dummy = n + D + K; /* spare list slot: rows that are listed nowhere write there */
         PTX_LEADER {
-            /* list cursors start at the first slot of their class (0 insert, 1 delete, 2..5 mark type 0..3) */
+            /* list cursors (class 0 insert -> ilist, 1 delete -> dlist, 2..5 mark type 0..3 -> mlist) */
             H->cur[0] = 0;
-            H->cur[1] = n;
-            H->cur[2] = n + D;
-            H->cur[3] = n + D + moff1;
-            H->cur[4] = n + D + moff2;
-            H->cur[5] = n + D + moff3;
+            H->cur[1] = 0;
+            H->cur[2] = 0;
+            H->cur[3] = moff1;
+            H->cur[4] = moff2;
+            H->cur[5] = moff3;
             H->cur[6] = H->cur[7] = 0;
             H->n_ins = n;
             H->n_applied = n + D + K;
@@ -713,10 +720,14 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                 const uint32_t old = ptx_atomic_or(&allbits[key >> 5], bit);
                 badrow = (old & bit) != 0u && i < badrow ? i : badrow; /* same opId twice */
                 ptx_atomic_or(&ix.ib[key >> 5].bits, c == 0u ? bit : 0u);
-                const uint32_t sl = slot[u] < dummy ? slot[u] : dummy;
-                list[sl] = (uint16_t)i;
-                const uint32_t k = c >= 2u && c < 6u && sl >= n + D ? sl - (n + D) : 0u;
-                ptx_atomic_or(&addbits[k >> 5], a[u] == PTX_ACT_ADDMARK && sl != dummy ? 1u << (k & 31) : 0u);
+                /* rows that are listed nowhere (and slots beyond what the header promised) go to the spare slot of mlist */
+                uint16_t* lst = c == 0u ? ilist : c == 1u ? dlist : mlist;
+                const uint32_t cap = c == 0u ? n : c == 1u ? D : K;
+                const bool listed = c < 6u && slot[u] < cap;
+                const uint32_t sl = listed ? slot[u] : (c == 0u ? n : c == 1u ? D : K);
+                lst[sl] = (uint16_t)i;
+                const uint32_t k = c >= 2u ? sl : 0u;
+                ptx_atomic_or(&addbits[k >> 5], a[u] == PTX_ACT_ADDMARK && listed ? 1u << (k & 31) : 0u);
                 if (A.out_rank && i < N) A.out_rank[base + i] = 0xFFFFFFFFu; /* insert rows are overwritten in P5a */
             }
         }
@@ -731,8 +742,7 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         PTX_SYNC();
         PTX_LEADER {
             /* the header must be the exact census of the rows */
-            if (H->cur[0] != n || H->cur[1] != n + D || H->cur[2] != n + D + moff1 || H->cur[3] != n + D + moff2 || H->cur[4] != n + D + moff3 ||
-                H->cur[5] != n + D + K)
+            if (H->cur[0] != n || H->cur[1] != D || H->cur[2] != moff1 || H->cur[3] != moff2 || H->cur[4] != moff3 || H->cur[5] != K)
                 ptx_raise(H, 0, 0, PTX_ERR_BAD_OP);
         }
         PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
@@ -740,18 +750,17 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         ptx_scan_excl<uint32_t, 2>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
     }
     PTX_BAIL_IF_ERROR();
-    bp.off = mark_lds;
+    bp.off = tree_lds;
     PTX_STAMP(2);
 
     /* ---- P3: causal tree of the inserts -> document position of every element ---- */
     {
         uint32_t* cnt = ptx_alloc<uint32_t>(bp, n + 2);   /* children per parent -> bucket starts -> bucket ends */
-        uint16_t* srt = ptx_alloc<uint16_t>(bp, n + 1);   /* children of every parent, descending opId, parents ascending */
-        uint32_t* L = ptx_alloc<uint32_t>(bp, 2 * n + 2); /* Euler tour: next << 16 | weight */
-        uint32_t* R = ptx_alloc<uint32_t>(bp, (2 * n) / PTX_S + 2); /* the splitters' list: next splitter << 16 | weight */
+        uint16_t* L = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* Euler tour: next node */
         PTX_BAIL_CAPACITY();
-        uint16_t* seg = (uint16_t*)L; /* bucket members in arrival order (dead before L is built) */
-        uint16_t* big = seg + n + 1;  /* positions in seg of the members of large buckets */
+        uint16_t* srt = ilist;       /* children of every parent, descending opId, parents ascending (ilist is dead after P3a) */
+        uint16_t* seg = L;           /* bucket members in arrival order (dead before L is built) */
+        uint16_t* big = seg + n + 1; /* positions in seg of the members of large buckets */
 
         PTX_FOR(p, n + 2) cnt[p] = 0;
         PTX_SYNC();
@@ -870,33 +879,30 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         PTX_FOR(j, n + 1) {
             const uint32_t s = j ? cnt[j - 1] : 0u, t = cnt[j];
             const uint32_t nx = t > s ? (uint32_t)srt[s] + 1u : (j == n ? term : n + 1u + j);
-            const uint32_t mine = (nx << 16) | (j < n ? 1u : 0u);
-            uint32_t xo = term, other = term << 16;
+            uint32_t xo = term, other = term;
             if (j < n) {
                 const uint32_t x = srt[j];
                 const uint32_t p = par[x];
-                const uint32_t nx2 = j + 1u < cnt[p] ? (uint32_t)srt[j + 1] + 1u : (p == n ? term : n + 1u + p);
+                other = j + 1u < cnt[p] ? (uint32_t)srt[j + 1] + 1u : (p == n ? term : n + 1u + p);
                 xo = n + 1u + x;
-                other = nx2 << 16;
             }
-            L[j < n ? j + 1u : 0u] = mine;
-            L[xo] = other; /* j == n writes the terminal node */
+            L[j < n ? j + 1u : 0u] = (uint16_t)nx;
+            L[xo] = (uint16_t)other; /* j == n writes the terminal node */
         }
         PTX_SYNC();
         /* List ranking, work-efficient: every PTX_S-th node is a splitter; a splitter walks to the next one
-         * summing weights (each tour node is visited once), the ~2n/PTX_S splitters are ranked by in-place
-         * pointer jumping, and a second walk hands the ranks out. */
+         * counting the enter nodes (weight 1: node ids 1..n) it passes (each tour node is visited once), the
+         * ~2n/PTX_S splitters are ranked by in-place pointer jumping, and a second walk hands the ranks out. */
         {
             const uint32_t ns = (2 * n) / PTX_S + 1; /* splitters 0, S, 2S, ... <= 2n */
             PTX_FOR(sp, ns) {
-                uint32_t a = L[sp * PTX_S];
-                uint32_t acc = a & 0xFFFFu, nx = a >> 16;
-                while (nx != term && (nx & (PTX_S - 1u)) != 0u) {
-                    a = L[nx];
-                    acc += a & 0xFFFFu;
-                    nx = a >> 16;
+                uint32_t v = sp * PTX_S, acc = 0;
+                for (;;) {
+                    acc += v - 1u < n ? 1u : 0u;
+                    v = L[v];
+                    if (v == term || (v & (PTX_S - 1u)) == 0u) break;
                 }
-                R[sp] = ((nx == term ? ns : nx / PTX_S) << 16) | acc;
+                R[sp] = ((v == term ? ns : v / PTX_S) << 16) | acc;
             }
             PTX_LEADER { R[ns] = ns << 16; } /* terminal: points at itself with weight 0 */
             PTX_SYNC();
@@ -916,10 +922,11 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                 uint32_t v = sp * PTX_S;
                 uint32_t run = R[sp] & 0xFFFFu; /* elements from node v to the end */
                 for (;;) {
-                    const uint32_t a = L[v];
-                    if (v - 1u < n) par[v - 1u] = (uint16_t)(n - run); /* document position incl. tombstones */
-                    run -= a & 0xFFFFu;
-                    v = a >> 16;
+                    if (v - 1u < n) {
+                        par[v - 1u] = (uint16_t)(n - run); /* document position incl. tombstones */
+                        --run;
+                    }
+                    v = L[v];
                     if (v == term || (v & (PTX_S - 1u)) == 0u) break;
                 }
             }
@@ -935,7 +942,6 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
     uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
     uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
-    uint32_t* mrk_val = ptx_alloc<uint32_t>(bp, K + 1); /* (key + 1) << kbits | mark index: LWW order + who won */
     uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);    /* comment mark -> doc-local comment id */
     uint32_t* brkbits = ptx_alloc<uint32_t>(bp, nwe + 1); /* visible positions where a comment interval starts/ends */
     PTX_BAIL_CAPACITY();
@@ -992,14 +998,13 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     }
     PTX_FORU(k0, K) {
         uint32_t i[PTX_U], sa[PTX_U], sb[PTX_U], pl[PTX_U];
-        uint64_t id[PTX_U], ra[PTX_U], rb[PTX_U];
+        uint64_t ra[PTX_U], rb[PTX_U];
 #pragma unroll
         for (int u = 0; u < PTX_U; ++u)
             if (PTX_IN(k0, u)) i[u] = mlist[PTX_IX(k0, u)];
 #pragma unroll
         for (int u = 0; u < PTX_U; ++u)
             if (PTX_IN(k0, u)) {
-                id[u] = op_id[i[u]];
                 ra[u] = ref_a[i[u]];
                 rb[u] = ref_b[i[u]];
                 sa[u] = A.side_a[base + i[u]];
@@ -1035,11 +1040,8 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                         hi = ptx_bitrank(alive, hi_rank);
                     }
                 }
-                uint32_t key = 0;
-                ptx_id_key(ix, id[u], key);
                 mrk_lo[k] = (uint16_t)lo;
                 mrk_hi[k] = (uint16_t)hi;
-                mrk_val[k] = ((key + 1u) << kbits) | k;
                 if (k >= moff2 && k < moff3) {
                     if (pl[u] >= Kc) ptx_raise(H, i[u], 1, PTX_ERR_BAD_OP); /* comment ids must be dense per doc */
                     cid[k - moff2] = (uint16_t)pl[u];
@@ -1054,13 +1056,12 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     if (Kc > 0) {
         uint32_t* ccnt = ptx_alloc<uint32_t>(bp, Kc + 1);
         uint32_t* ccur = ptx_alloc<uint32_t>(bp, Kc + 1);
-        uint32_t* cicnt = ptx_alloc<uint32_t>(bp, Kc + 1);
+        uint32_t* cicnt = ccur; /* intervals per id: reuses the scatter cursors once the entries are placed */
         PtxCEntry* cent = ptx_alloc<PtxCEntry>(bp, Kc + 1);
         PTX_BAIL_CAPACITY();
         PTX_FOR(c, Kc + 1) {
             ccnt[c] = 0;
             ccur[c] = 0;
-            cicnt[c] = 0;
         }
         PTX_SYNC();
         PTX_FOR(kc, Kc) {
@@ -1083,8 +1084,8 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
             }
         }
         PTX_SYNC();
-        PTX_FOR(c, Kc) {
-            cicnt[c] = ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {});
+        PTX_FOR(c, Kc + 1) {
+            cicnt[c] = c < Kc ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         }
         PTX_SYNC();
         const uint32_t I = ptx_scan_excl<uint32_t, 1>(cicnt, Kc + 1, H->scan_tmp);
@@ -1152,10 +1153,13 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                     uint32_t lo = mrk_lo[k], hi = mrk_hi[k];
                     lo = lo > t0 ? lo - t0 : 0u;
                     hi = hi > t0 ? (hi - t0 < tv ? hi - t0 : tv) : 0u;
-                    if (lo < hi) {
+                    if (lo < hi) { /* few marks still cover a visible char: the opId is re-read only for those */
                         const uint32_t ty = PTX_TYPE_OF(k);
-                        /* the comment tree only records "some comment op covers" (key `comment` present) */
-                        ptx_tree_chmax(tree + (four ? ty : 0u) * 2 * TV, TV, lo, hi, ty == PTX_MARK_COMMENT ? 1u : mrk_val[k]);
+                        uint32_t key = 0;
+                        ptx_id_key(ix, op_id[mlist[k]], key);
+                        /* LWW order = opId order; the low bits say who won.  The comment tree only records
+                         * "some comment op covers" (key `comment` present) */
+                        ptx_tree_chmax(tree + (four ? ty : 0u) * 2 * TV, TV, lo, hi, ty == PTX_MARK_COMMENT ? 1u : ((key + 1u) << kbits) | k);
                     }
                 }
                 PTX_SYNC();

@@ -31,15 +31,14 @@
 #define PTX_MERGE_KERNEL(name, T, W)                                                   \
     extern "C" __global__ void __launch_bounds__(T, W) name(PtxMergeArgs A) {          \
         extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];              \
-        /* grid-stride over logs: the launch may cap the grid */                       \
-        for (uint32_t log = blockIdx.x; log < A.n_logs; log += gridDim.x) {            \
-            ptx_merge_log(A, log, ptx_lds);                                            \
-            __syncthreads(); /* LDS is reused by the next log */                       \
-        }                                                                              \
+        /* one workgroup per log (grid == n_logs): no grid-stride loop, so that nothing is hoisted \
+           out of it and kept in registers for the whole kernel */                    \
+        if (blockIdx.x < A.n_logs) ptx_merge_log(A, blockIdx.x, ptx_lds);             \
     }
 PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1)    /* <= 128 VGPRs: any launch shape */
-PTX_MERGE_KERNEL(ptx_merge_kernel_w6, 512, 6)  /* <= 80 VGPRs: 3 workgroups of 512 per CU */
-PTX_MERGE_KERNEL(ptx_merge_kernel_w8, 512, 8)  /* <= 64 VGPRs: 4 workgroups of 512 per CU */
+PTX_MERGE_KERNEL(ptx_merge_kernel_w5, 256, 5)  /* <= 96 VGPRs: 5 workgroups of 256 per CU */
+PTX_MERGE_KERNEL(ptx_merge_kernel_w6, 256, 6)  /* <= 80 VGPRs: 6 workgroups of 256 per CU */
+PTX_MERGE_KERNEL(ptx_merge_kernel_w8, 256, 8)  /* <= 64 VGPRs: 8 workgroups of 256 per CU */
 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
@@ -130,7 +129,7 @@ struct ptx_ctx {
     int force_threads = 0; /* PTX_THREADS env override (tuning) */
     int force_lds = 0;     /* PTX_LDS_BYTES env override (tuning) */
     int stop_after = 0;    /* PTX_STOP_AFTER env (diagnostic): truncate the kernel after a phase, for per-phase PMC deltas */
-    int variant = 0;       /* PTX_VARIANT env override (tuning): register-budget variant of the kernel */
+    int variant = -1;      /* PTX_VARIANT env override (tuning): register-budget variant of the kernel */
     uint32_t flags = 0;
     unsigned long long* clocks = nullptr; /* device [PTX_NCLK], non-null only while ptx_merge_phase_cycles runs */
 };
@@ -261,6 +260,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     if (const char* sv = getenv("PTX_VARIANT")) ctx->variant = atoi(sv);
     if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     e = hipFuncSetAttribute((const void*)ptx_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
     if (e != hipSuccess) {
@@ -314,6 +314,10 @@ void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
 }
 
 uint32_t ptx_batch_n_logs(const ptx_dbatch* b) { return b ? b->n_logs : 0; }
+void ptx_batch_launch_shape(const ptx_dbatch* b, uint32_t* threads, uint32_t* lds_bytes) {
+    if (threads) *threads = b ? b->threads : 0;
+    if (lds_bytes) *lds_bytes = b ? b->lds_bytes : 0;
+}
 uint64_t ptx_batch_n_ops(const ptx_dbatch* b) { return b ? b->n_ops : 0; }
 
 ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t copies, ptx_dbatch** out) {
@@ -496,10 +500,16 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.lds_bytes = b->lds_bytes;
     /* one workgroup per log; far more workgroups than the 256 CUs so the dispatcher load-balances */
     const uint32_t grid = b->n_logs;
-    if (ctx->variant == 8 && b->threads <= 512)
+    /* register budget by launch shape: workgroups of <= 256 threads run the <= 80-VGPR build so that six of
+     * them fit a CU when their LDS does (PTX_VARIANT overrides, for tuning) */
+    int variant = ctx->variant >= 0 ? ctx->variant : (b->threads <= 256 ? 6 : 0);
+    if (b->threads > 256) variant = 0;
+    if (variant == 8)
         hipLaunchKernelGGL(ptx_merge_kernel_w8, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
-    else if (ctx->variant == 6 && b->threads <= 512)
+    else if (variant == 6)
         hipLaunchKernelGGL(ptx_merge_kernel_w6, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
+    else if (variant == 5)
+        hipLaunchKernelGGL(ptx_merge_kernel_w5, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
     else
         hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
     hipError_t e = hipGetLastError();

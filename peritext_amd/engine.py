@@ -153,6 +153,12 @@ class Engine:
     def n_ops(self, dbatch):
         return int(self.lib.ptx_batch_n_ops(dbatch))
 
+    def launch_shape(self, dbatch):
+        """(threads per workgroup, dynamic LDS bytes per workgroup) the library chose for this batch."""
+        t, l = C.c_uint32(), C.c_uint32()
+        self.lib.ptx_batch_launch_shape(dbatch, C.byref(t), C.byref(l))
+        return int(t.value), int(l.value)
+
     def max_ops_per_log(self):
         return int(self.lib.ptx_max_ops_per_log(self.ctx))
 

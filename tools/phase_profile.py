@@ -36,7 +36,7 @@ def main():
     copies = max(1, args.docs // args.unique)
     out = {"config": args.config, "logs": batch.n_logs * copies, "ops": batch.counted_ops() * copies, "shapes": []}
     for t, var in [(int(x), int(v)) for v in args.variants.split(",") for x in args.threads.split(",")]:
-        if var and t > 512:
+        if var and t > 256:
             continue
         os.environ["PTX_THREADS"] = str(t)
         os.environ["PTX_VARIANT"] = str(var)
@@ -51,7 +51,7 @@ def main():
         assert args.no_check or int(logs["status"].max()) == 0
         tot = sum(cyc) or 1
         row = {"lib": os.path.basename(args.lib or "default"), "variant": var, "threads": t, "ms": ms, "Gops_s": out["ops"] / ms / 1e6, "us_per_log_per_cu": ms * 1e3 * 256 / out["logs"],
-               "lds_high": int(logs["reserved"][:, 0].max()), "cycles_per_log": tot / out["logs"],
+               "lds_high": int(logs["reserved"][:, 0].max()), "launch": eng.launch_shape(db), "cycles_per_log": tot / out["logs"],
                "phases": {PHASES[k] if k < len(PHASES) else str(k): round(cyc[k] / out["logs"]) for k in range(len(cyc)) if cyc[k]}}
         out["shapes"].append(row)
         print(json.dumps(row), flush=True)
