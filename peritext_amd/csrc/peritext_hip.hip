@@ -228,7 +228,7 @@ extern "C" {
 
 uint32_t ptx_abi_version(void) { return PTX_ABI_VERSION; }
 
-const char* ptx_kernel_name(void) { return "ptx_merge_kernel"; }
+const char* ptx_kernel_name(void) { return "ptx_merge_kernel_w6"; } /* the build ptx_merge launches for workgroups of <= 256 threads */
 
 const char* ptx_last_error(const ptx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 

@@ -37,7 +37,7 @@ def test_native_library_is_loaded(eng):
     maps = open("/proc/self/maps").read()
     assert "libperitext_hip.so" in maps
     assert "libperitext_emu" not in maps  # the CPU emulation must never be in a GPU test process
-    assert eng.kernel_name() == "ptx_merge_kernel"
+    assert eng.kernel_name().startswith("ptx_merge_kernel")
     assert eng.max_ops_per_log() >= 4102
 
 
