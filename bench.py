@@ -12,7 +12,7 @@ The batch is `--unique` PTXGEN documents (SURVEY.md §8d generator, produced her
 change() through oracle/cli.js) tiled to 8192 docs inside HBM at distinct addresses.
 
 One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes of one launch
-(32 B per op row read + 4 B per visible value + 8 B per span + 12 B per comment interval + 48 B result
+(32 B per op row + 32 B header per log read, 4 B per visible value + 8 B per span + 12 B per comment interval + 48 B result
 row per log written) / the kernel's average launch duration measured with HIP events on the stream
 the kernel runs on.  `cpu_baseline` = the reference's own code (oracle/_ref, types erased) or, where
 that is absent, the oracle port, timed on this box's host cores on a bounded sample of the same logs.
@@ -133,7 +133,7 @@ def main():
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
 
-    from peritext_amd import abi, wire
+    from peritext_amd import abi, shard, wire
     from peritext_amd.engine import Engine
 
     # ---- workload: unique documents of this rank, tiled in HBM ----
@@ -169,12 +169,8 @@ def main():
             eng.merge(db, dr)
         eng.pack_digests(dr, 0, n_logs, digests.data_ptr())
         eng.sync()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, digests)  # the only collective on the path: digests only
-            d = gathered.view(world * n_docs, replicas, 2)
-        else:
-            d = digests.view(n_docs, replicas, 2)
-        conv = (d == d[:, :1, :]).all(dim=2).all(dim=1).sum()
+        # N > 1: the only collective on the path — RCCL all-gather of the digests (peritext_amd/shard.py)
+        conv, _ = shard.global_convergence(digests, replicas, dist if world > 1 else None, gathered)
         return ms
 
     for _ in range(args.warmup):
@@ -216,7 +212,7 @@ def main():
 
         # algorithmic bytes of ONE launch on this rank (with this ABI's row sizes)
         rows = eng.n_ops(db)
-        alg_bytes = 32 * rows + 4 * int(logs["n_visible"].sum()) + 8 * int(logs["n_spans"].sum()) + 12 * int(logs["n_cintervals"].sum()) + 48 * n_logs
+        alg_bytes = 32 * rows + 32 * n_logs + 4 * int(logs["n_visible"].sum()) + 8 * int(logs["n_spans"].sum()) + 12 * int(logs["n_cintervals"].sum()) + 48 * n_logs
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3)
         total_ops = ops_per_step * world * args.steps

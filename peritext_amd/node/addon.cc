@@ -1,0 +1,260 @@
+/*
+ * addon.cc — N-API binding of the C ABI in include/peritext_hip.h (the TypeScript/JS host's door to the GPU).
+ *
+ * The reference has no FFI: bridge.ts:253/288 and the test harness (test/micromerge.ts:54-79) call
+ * Micromerge.applyChange / getTextWithFormatting on JS objects.  This addon is what a maintainer adds instead
+ * (INTEGRATION.md): index.js flattens `Change[]` into the SoA op-log columns, this file hands their ArrayBuffers
+ * to ptx_apply_materialize and copies the canonical result rows back into typed arrays.  Nothing is computed
+ * here; libperitext_hip.so is dlopen()ed at run time, so the addon builds with plain g++ and no ROCm headers:
+ *     g++ -O2 -shared -fPIC -I/usr/include/node -Iinclude peritext_amd/node/addon.cc -ldl -o peritext_amd/node/peritext_node.node
+ *
+ * Exports:  open(libPath) -> abiVersion      create(device, flags) -> ctx (external)      destroy(ctx)
+ *           applyMaterialize(ctx, batch) -> {logs:Uint32Array(12/log), values:Uint32Array, spans:Uint32Array(2/row),
+ *                                            cintervals:Uint32Array(3/row), elemRank:Uint32Array|null}
+ *           maxOpsPerLog(ctx)  kernelName()  lastError(ctx|null)
+ * Errors of the library surface as JS exceptions (Error with the library's message); per-LOG failures stay in
+ * logs[12*l] (status) and are turned into RangeError by index.js, mirroring micromerge.ts:503,:507,:752.
+ */
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/peritext_hip.h"
+
+namespace {
+
+struct Lib {
+    void* handle = nullptr;
+    uint32_t (*abi_version)(void) = nullptr;
+    ptx_status (*create)(int, uint32_t, ptx_ctx**) = nullptr;
+    void (*destroy)(ptx_ctx*) = nullptr;
+    const char* (*last_error)(const ptx_ctx*) = nullptr;
+    ptx_status (*apply_materialize)(ptx_ctx*, const ptx_batch*, ptx_result*) = nullptr;
+    void (*result_free)(ptx_result*) = nullptr;
+    uint32_t (*max_ops_per_log)(const ptx_ctx*) = nullptr;
+    const char* (*kernel_name)(void) = nullptr;
+} L;
+
+#define NAPI_OK(call)                                                        \
+    do {                                                                     \
+        if ((call) != napi_ok) {                                             \
+            napi_throw_error(env, nullptr, "N-API call failed: " #call);     \
+            return nullptr;                                                  \
+        }                                                                    \
+    } while (0)
+
+napi_value throw_msg(napi_env env, const char* msg) {
+    napi_throw_error(env, nullptr, msg);
+    return nullptr;
+}
+
+template <class F>
+bool sym(F& fn, const char* name) {
+    fn = (F)dlsym(L.handle, name);
+    return fn != nullptr;
+}
+
+napi_value Open(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    char path[4096];
+    size_t len = 0;
+    if (argc < 1 || napi_get_value_string_utf8(env, argv[0], path, sizeof(path), &len) != napi_ok) return throw_msg(env, "open(libPath): string expected");
+    if (!L.handle) {
+        L.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!L.handle) {
+            char msg[4600];
+            snprintf(msg, sizeof(msg), "cannot load %s: %s (build it with __graft_entry__.build(); there is no CPU fallback)", path, dlerror());
+            return throw_msg(env, msg);
+        }
+        bool ok = sym(L.abi_version, "ptx_abi_version") && sym(L.create, "ptx_create") && sym(L.destroy, "ptx_destroy") &&
+                  sym(L.last_error, "ptx_last_error") && sym(L.apply_materialize, "ptx_apply_materialize") && sym(L.result_free, "ptx_result_free") &&
+                  sym(L.max_ops_per_log, "ptx_max_ops_per_log") && sym(L.kernel_name, "ptx_kernel_name");
+        if (!ok) {
+            dlclose(L.handle);
+            L.handle = nullptr;
+            return throw_msg(env, "libperitext_hip.so lacks a symbol include/peritext_hip.h declares");
+        }
+        if (L.abi_version() != PTX_ABI_VERSION) return throw_msg(env, "libperitext_hip.so ABI version mismatch");
+    }
+    napi_value v;
+    NAPI_OK(napi_create_uint32(env, L.abi_version(), &v));
+    return v;
+}
+
+napi_value Create(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    int32_t device = 0;
+    uint32_t flags = 0;
+    if (argc > 0) napi_get_value_int32(env, argv[0], &device);
+    if (argc > 1) napi_get_value_uint32(env, argv[1], &flags);
+    ptx_ctx* ctx = nullptr;
+    const ptx_status st = L.create(device, flags, &ctx);
+    if (st != PTX_OK) {
+        char msg[1024];
+        snprintf(msg, sizeof(msg), "ptx_create failed (status %d): %s", st, L.last_error(nullptr));
+        return throw_msg(env, msg);
+    }
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, ctx, nullptr, nullptr, &ext));
+    return ext;
+}
+
+ptx_ctx* ctx_of(napi_env env, napi_value v) {
+    void* p = nullptr;
+    if (napi_get_value_external(env, v, &p) != napi_ok) return nullptr;
+    return (ptx_ctx*)p;
+}
+
+napi_value Destroy(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc ? ctx_of(env, argv[0]) : nullptr;
+    if (ctx && L.handle) L.destroy(ctx);
+    return nullptr;
+}
+
+/* typed-array property -> raw pointer + element count; expected element size is checked */
+bool column(napi_env env, napi_value obj, const char* name, size_t elem, const void** ptr, size_t* count, bool optional = false) {
+    napi_value v;
+    bool has = false;
+    if (napi_has_named_property(env, obj, name, &has) != napi_ok || !has) {
+        *ptr = nullptr;
+        *count = 0;
+        return optional;
+    }
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok) return false;
+    bool is_ta = false;
+    napi_is_typedarray(env, v, &is_ta);
+    if (!is_ta) {
+        *ptr = nullptr;
+        *count = 0;
+        return optional;
+    }
+    napi_typedarray_type type;
+    size_t length = 0, offset = 0;
+    void* data = nullptr;
+    napi_value ab;
+    if (napi_get_typedarray_info(env, v, &type, &length, &data, &ab, &offset) != napi_ok) return false;
+    size_t es = 0;
+    switch (type) {
+        case napi_uint8_array: es = 1; break;
+        case napi_uint32_array: es = 4; break;
+        case napi_biguint64_array: es = 8; break;
+        default: return false;
+    }
+    if (es != elem) return false;
+    *ptr = data;
+    *count = length;
+    return true;
+}
+
+napi_value make_u32(napi_env env, const void* src, size_t count) {
+    napi_value ab, ta;
+    void* data = nullptr;
+    if (napi_create_arraybuffer(env, count * 4, &data, &ab) != napi_ok) return nullptr;
+    if (count) memcpy(data, src, count * 4);
+    if (napi_create_typedarray(env, napi_uint32_array, count, ab, 0, &ta) != napi_ok) return nullptr;
+    return ta;
+}
+
+napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    if (argc < 2) return throw_msg(env, "applyMaterialize(ctx, batch)");
+    ptx_ctx* ctx = ctx_of(env, argv[0]);
+    if (!ctx) return throw_msg(env, "applyMaterialize: bad context");
+    napi_value b = argv[1];
+    ptx_batch pb;
+    memset(&pb, 0, sizeof(pb));
+    size_t n_off = 0, n = 0, m = 0;
+    const void* p = nullptr;
+    if (!column(env, b, "logOff", 8, &p, &n_off)) return throw_msg(env, "batch.logOff must be a BigUint64Array");
+    pb.log_off = (const uint64_t*)p;
+    if (n_off == 0) return throw_msg(env, "batch.logOff needs n_logs + 1 entries");
+    pb.n_logs = (uint32_t)(n_off - 1);
+    pb.n_ops = pb.log_off[pb.n_logs];
+    struct Col { const char* name; size_t elem; const void** dst; } cols[] = {
+        {"opId", 8, (const void**)&pb.op_id},     {"refA", 8, (const void**)&pb.ref_a},         {"refB", 8, (const void**)&pb.ref_b},
+        {"payload", 4, (const void**)&pb.payload}, {"action", 1, (const void**)&pb.action},     {"markType", 1, (const void**)&pb.mark_type},
+        {"sideA", 1, (const void**)&pb.side_a},    {"sideB", 1, (const void**)&pb.side_b},
+    };
+    for (const Col& c : cols) {
+        if (!column(env, b, c.name, c.elem, c.dst, &n) || n != pb.n_ops) {
+            char msg[128];
+            snprintf(msg, sizeof(msg), "batch.%s: typed array of %zu-byte elements with n_ops entries expected", c.name, c.elem);
+            return throw_msg(env, msg);
+        }
+    }
+    /* optional: per-log census (8 u32 per log) — otherwise the library computes it on the device */
+    if (column(env, b, "logHdr", 4, &p, &m, true) && p) {
+        if (m != (size_t)pb.n_logs * 8) return throw_msg(env, "batch.logHdr: Uint32Array with 8 entries per log expected");
+        pb.log_hdr = (const ptx_log_hdr*)p;
+    }
+    ptx_result res;
+    const ptx_status st = L.apply_materialize(ctx, &pb, &res);
+    if (st != PTX_OK) {
+        char msg[1024];
+        snprintf(msg, sizeof(msg), "ptx_apply_materialize failed (status %d): %s", st, L.last_error(ctx));
+        return throw_msg(env, msg);
+    }
+    napi_value out;
+    NAPI_OK(napi_create_object(env, &out));
+    napi_value v;
+    static_assert(sizeof(ptx_log_result) == 48, "ptx_log_result layout");
+    v = make_u32(env, res.logs, (size_t)res.n_logs * 12);
+    if (v) napi_set_named_property(env, out, "logs", v);
+    v = make_u32(env, res.values, (size_t)res.n_rows);
+    if (v) napi_set_named_property(env, out, "values", v);
+    v = make_u32(env, res.spans, (size_t)res.n_rows * 2);
+    if (v) napi_set_named_property(env, out, "spans", v);
+    v = make_u32(env, res.cintervals, (size_t)res.n_rows * 3);
+    if (v) napi_set_named_property(env, out, "cintervals", v);
+    if (res.elem_rank) {
+        v = make_u32(env, res.elem_rank, (size_t)res.n_rows);
+        if (v) napi_set_named_property(env, out, "elemRank", v);
+    }
+    L.result_free(&res);
+    return out;
+}
+
+napi_value MaxOpsPerLog(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc ? ctx_of(env, argv[0]) : nullptr;
+    napi_value v;
+    NAPI_OK(napi_create_uint32(env, L.handle ? L.max_ops_per_log(ctx) : 0, &v));
+    return v;
+}
+
+napi_value KernelName(napi_env env, napi_callback_info) {
+    napi_value v;
+    NAPI_OK(napi_create_string_utf8(env, L.handle ? L.kernel_name() : "", NAPI_AUTO_LENGTH, &v));
+    return v;
+}
+
+napi_value Init(napi_env env, napi_value exports) {
+    struct { const char* name; napi_callback fn; } fns[] = {
+        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"maxOpsPerLog", MaxOpsPerLog}, {"kernelName", KernelName},
+    };
+    for (auto& f : fns) {
+        napi_value fn;
+        if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn) != napi_ok) return nullptr;
+        if (napi_set_named_property(env, exports, f.name, fn) != napi_ok) return nullptr;
+    }
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

@@ -1,0 +1,60 @@
+/**
+ * Types of the MI355X batch merge engine's TypeScript/JS host.  The hot-path types are the reference's own
+ * (reference/src/micromerge.ts:25-71,:133-212; src/peritext.ts:17-65,:35-38,:125-137): a maintainer can import
+ * them from the reference instead — they are restated here so that the package type-checks on its own.
+ */
+export type ActorId = string
+export type OperationId = string /** `${counter}@${actorId}` (micromerge.ts:35) */
+export type Clock = Record<ActorId, number>
+export type MarkType = "strong" | "em" | "comment" | "link"
+
+export type BoundaryPosition =
+    | { type: "before"; elemId: OperationId }
+    | { type: "after"; elemId: OperationId }
+    | { type: "startOfText" }
+    | { type: "endOfText" }
+
+export interface InsertOperation { opId: OperationId; action: "set"; obj: OperationId; elemId?: OperationId | "_head"; insert: true; value: string }
+export interface DeleteOperation { opId: OperationId; action: "del"; obj: OperationId; elemId: OperationId }
+export interface MakeListOperation { opId: OperationId; action: "makeList"; obj?: OperationId | "_root"; key: string }
+export interface AddMarkOperation { opId: OperationId; action: "addMark"; obj: OperationId; start: BoundaryPosition; end: BoundaryPosition; markType: MarkType; attrs?: { url?: string; id?: string } }
+export interface RemoveMarkOperation { opId: OperationId; action: "removeMark"; obj: OperationId; start: BoundaryPosition; end: BoundaryPosition; markType: MarkType; attrs?: { id?: string } }
+export type Operation = InsertOperation | DeleteOperation | MakeListOperation | AddMarkOperation | RemoveMarkOperation | { opId: OperationId; action: string; [k: string]: unknown }
+
+/** micromerge.ts:60-71 */
+export interface Change { actor: ActorId; seq: number; deps: Clock; startOp: number; ops: Operation[] }
+
+export type MarkMap = { strong?: { active: true }; em?: { active: true }; link?: { url: string }; comment?: Array<{ id: string }> }
+/** peritext.ts:35-38 */
+export interface FormatSpanWithText { text: string; marks: MarkMap }
+
+/** SoA op log of include/peritext_hip.h (one row per internal Operation, 32 bytes) + decode tables. */
+export interface WireBatch {
+    nLogs: number; nOps: number
+    logOff: BigUint64Array; opId: BigUint64Array; refA: BigUint64Array; refB: BigUint64Array
+    payload: Uint32Array; action: Uint8Array; markType: Uint8Array; sideA: Uint8Array; sideB: Uint8Array
+    logHdr?: Uint32Array
+    values: string[]; urls: string[]; logDoc: number[]; docActors: string[][]; docComments: string[][]
+}
+export interface WireResult { logs: Uint32Array; values: Uint32Array; spans: Uint32Array; cintervals: Uint32Array; elemRank?: Uint32Array }
+
+/** Per-replica handle with the reference's calls (Micromerge.applyChange :499, getTextWithFormatting :516). */
+export interface ReplicaHandle {
+    applyChange(change: Change): unknown[]
+    /** throws RangeError("List element not found" | …) exactly where the reference's applyChange would have thrown */
+    getTextWithFormatting(path: ["text"]): FormatSpanWithText[]
+}
+
+export class MergeEngine {
+    constructor(opts?: { device?: number; libPath?: string; addonPath?: string })
+    close(): void
+    applyMaterialize(batch: WireBatch): WireResult
+    /** docs -> replica logs -> changes in application order  =>  spans per replica log */
+    applyChanges(docs: Change[][][]): FormatSpanWithText[][][]
+    digests(docs: Change[][][]): Array<[bigint, bigint]>
+    replica(docId?: number | string): ReplicaHandle
+    flush(): void
+}
+export function encodeDocs(docs: Change[][][]): WireBatch
+export function decodeSpans(batch: WireBatch, res: WireResult, log: number): FormatSpanWithText[]
+export function census(batch: WireBatch): Uint32Array

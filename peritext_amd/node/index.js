@@ -1,0 +1,269 @@
+"use strict"
+/*
+ * peritext_amd/node — the JavaScript/TypeScript host of the MI355X batch merge engine (types: index.d.ts).
+ *
+ * It keeps the reference's surface for the hot path — `Change` in (reference/src/micromerge.ts:60-71),
+ * `FormatSpanWithText[]` out (src/peritext.ts:35-38) — but applies MANY replica op logs per call:
+ *
+ *     const { MergeEngine } = require("./peritext_amd/node")
+ *     const engine = new MergeEngine()                       // one GPU context (N-API addon -> libperitext_hip.so)
+ *     const spans = engine.applyChanges([[log1, log2], ...]) // docs -> replica logs -> Change[]  =>  spans per log
+ *
+ * and, for code written against the reference's per-replica calls, `engine.replica()` hands out objects with
+ * `applyChange(change)` (micromerge.ts:499) and `getTextWithFormatting(["text"])` (:516) that batch under the hood.
+ *
+ * Encoding rules (same as peritext_amd/wire.py; SURVEY.md §8b): actor strings -> rank in UTF-16 code-unit order
+ * per document so that integer order of (counter << 32 | rank) equals compareOpIds (micromerge.ts:812-827);
+ * ROOT/HEAD -> 0 (JSON drops the reference's Symbols; "_root"/"_head" are accepted too); inserted values and
+ * link urls -> ids in batch-wide string tables; comment ids -> doc-local dense ranks in code-unit order
+ * (peritext.ts:318 keeps the arrays id-sorted).  Nothing here computes a merge: without the addon or without a
+ * gfx950 device the constructor throws.
+ */
+const path = require("path")
+
+const ACT = { MAKELIST: 0, INSERT: 1, DELETE: 2, ADDMARK: 3, REMOVEMARK: 4, NOP: 5 }
+const MARK_NAMES = ["strong", "em", "comment", "link"] /* schema.ts:125 ALL_MARKS */
+const SIDE_NAMES = ["before", "after", "startOfText", "endOfText"] /* peritext.ts:17-21 */
+const ATTR = { STRONG: 0x10000000, EM: 0x20000000, LINK: 0x40000000, COMMENT: 0x80000000, ID_MASK: 0x0fffffff }
+const STATUS_MESSAGES = {
+    1: "List element not found" /* micromerge.ts:752 */,
+    2: "Expected sequence number" /* :503 */,
+    3: "Missing dependency" /* :507 */,
+    4: "duplicate opId",
+    5: "log exceeds on-chip capacity",
+    6: "malformed op row",
+}
+const ROOT = "_root"
+const HEAD = "_head"
+const ID_RE = /^([0-9]+)@([\s\S]*)$/
+
+function splitOpId(id) {
+    const m = ID_RE.exec(id)
+    if (!m) throw new Error("Invalid operation ID: " + id)
+    return [parseInt(m[1], 10), m[2]]
+}
+
+/** docs: Change[][][] (doc -> replica log -> changes in application order)  ->  SoA batch (include/peritext_hip.h). */
+function encodeDocs(docs) {
+    const values = [], valueIx = new Map()
+    const urls = [], urlIx = new Map()
+    const rows = { opId: [], refA: [], refB: [], payload: [], action: [], markType: [], sideA: [], sideB: [] }
+    const logOff = [0]
+    const logDoc = [], docActors = [], docComments = []
+    docs.forEach((logs, d) => {
+        const actors = new Set(), comments = new Set()
+        for (const log of logs)
+            for (const ch of log) {
+                actors.add(ch.actor)
+                for (const a of Object.keys(ch.deps || {})) actors.add(a)
+                for (const op of ch.ops) {
+                    actors.add(splitOpId(op.opId)[1])
+                    const refs = [op.elemId, op.start && op.start.elemId, op.end && op.end.elemId]
+                    for (const r of refs) if (typeof r === "string" && r !== HEAD && r !== ROOT) actors.add(splitOpId(r)[1])
+                    if (op.markType === "comment") comments.add(op.attrs.id)
+                }
+            }
+        const actorList = Array.from(actors).sort() /* default sort = UTF-16 code-unit order = JS `<` (micromerge.ts:826) */
+        const commentList = Array.from(comments).sort()
+        const arank = new Map(actorList.map((a, i) => [a, i]))
+        const crank = new Map(commentList.map((c, i) => [c, i]))
+        docActors.push(actorList)
+        docComments.push(commentList)
+        const encId = s => {
+            if (s === undefined || s === null || s === HEAD || s === ROOT || typeof s === "symbol") return 0n
+            const [ctr, actor] = splitOpId(s)
+            return (BigInt(ctr) << 32n) | BigInt(arank.get(actor))
+        }
+        for (const log of logs) {
+            let textObj = null, nrows = 0
+            for (const ch of log)
+                for (const op of ch.ops) {
+                    const row = { opId: encId(op.opId), refA: 0n, refB: 0n, payload: 0, action: ACT.NOP, markType: 0, sideA: 0, sideB: 0 }
+                    const onRoot = op.obj === undefined || op.obj === null || op.obj === ROOT || typeof op.obj === "symbol"
+                    if (op.action === "makeList" && onRoot && op.key === "text" && textObj === null) {
+                        row.action = ACT.MAKELIST
+                        textObj = op.opId
+                    } else if (textObj !== null && op.obj === textObj) {
+                        if (op.action === "set" && op.insert) {
+                            if (typeof op.value !== "string") throw new Error("Expected value inserted into text to be a string")
+                            if (!valueIx.has(op.value)) {
+                                valueIx.set(op.value, values.length)
+                                values.push(op.value)
+                            }
+                            row.action = ACT.INSERT
+                            row.refA = encId(op.elemId)
+                            row.payload = valueIx.get(op.value)
+                        } else if (op.action === "del" && op.elemId !== undefined) {
+                            row.action = ACT.DELETE
+                            row.refA = encId(op.elemId)
+                        } else if (op.action === "addMark" || op.action === "removeMark") {
+                            const mt = MARK_NAMES.indexOf(op.markType)
+                            row.action = op.action === "addMark" ? ACT.ADDMARK : ACT.REMOVEMARK
+                            row.markType = mt
+                            row.sideA = SIDE_NAMES.indexOf(op.start.type)
+                            row.sideB = SIDE_NAMES.indexOf(op.end.type)
+                            row.refA = encId(op.start.elemId)
+                            row.refB = encId(op.end.elemId)
+                            if (op.markType === "link" && op.action === "addMark") {
+                                const u = op.attrs.url
+                                if (!urlIx.has(u)) {
+                                    urlIx.set(u, urls.length)
+                                    urls.push(u)
+                                }
+                                row.payload = urlIx.get(u)
+                            } else if (op.markType === "comment") row.payload = crank.get(op.attrs.id)
+                        }
+                    }
+                    for (const k of Object.keys(rows)) rows[k].push(row[k])
+                    nrows++
+                }
+            logOff.push(logOff[logOff.length - 1] + nrows)
+            logDoc.push(d)
+        }
+    })
+    const nLogs = logOff.length - 1
+    const batch = {
+        nLogs,
+        nOps: logOff[nLogs],
+        logOff: BigUint64Array.from(logOff.map(BigInt)),
+        opId: BigUint64Array.from(rows.opId),
+        refA: BigUint64Array.from(rows.refA),
+        refB: BigUint64Array.from(rows.refB),
+        payload: Uint32Array.from(rows.payload),
+        action: Uint8Array.from(rows.action),
+        markType: Uint8Array.from(rows.markType),
+        sideA: Uint8Array.from(rows.sideA),
+        sideB: Uint8Array.from(rows.sideB),
+        values, urls, logDoc, docActors, docComments,
+    }
+    batch.logHdr = census(batch)
+    return batch
+}
+
+/** ptx_log_hdr rows (8 u32 per log: n_ins, n_del, n_mark[4], max_counter, max_actor) — what the encoder knows for free. */
+function census(batch) {
+    const hdr = new Uint32Array(batch.nLogs * 8)
+    for (let l = 0; l < batch.nLogs; l++) {
+        const b0 = Number(batch.logOff[l]), b1 = Number(batch.logOff[l + 1])
+        const h = hdr.subarray(l * 8, l * 8 + 8)
+        for (let i = b0; i < b1; i++) {
+            const a = batch.action[i]
+            if (a === ACT.INSERT) h[0]++
+            else if (a === ACT.DELETE) h[1]++
+            else if ((a === ACT.ADDMARK || a === ACT.REMOVEMARK) && batch.markType[i] < 4) h[2 + batch.markType[i]]++
+            const ctr = Number(batch.opId[i] >> 32n), act = Number(batch.opId[i] & 0xffffffffn)
+            if (ctr > h[6]) h[6] = ctr
+            if (act > h[7]) h[7] = act
+        }
+    }
+    return hdr
+}
+
+/** FormatSpanWithText[] of one log (what getTextWithFormatting(["text"]) returns, peritext.ts:337-395). */
+function decodeSpans(batch, res, log) {
+    const r = res.logs.subarray(12 * log, 12 * log + 12)
+    if (r[0] !== 0) throw new RangeError(STATUS_MESSAGES[r[0]] || "merge error " + r[0])
+    const b = Number(batch.logOff[log])
+    const nVisible = r[3], nSpans = r[4], nCints = r[5]
+    const comments = batch.docComments[batch.logDoc[log]]
+    const out = []
+    for (let k = 0; k < nSpans; k++) {
+        const start = res.spans[2 * (b + k)], attr = res.spans[2 * (b + k) + 1]
+        const end = k + 1 < nSpans ? res.spans[2 * (b + k + 1)] : nVisible
+        const marks = {}
+        if (attr & ATTR.STRONG) marks.strong = { active: true }
+        if (attr & ATTR.EM) marks.em = { active: true }
+        if ((attr & ATTR.COMMENT) !== 0) {
+            const ids = []
+            for (let c = 0; c < nCints; c++) {
+                const id = res.cintervals[3 * (b + c)], s = res.cintervals[3 * (b + c) + 1], e = res.cintervals[3 * (b + c) + 2]
+                if (s <= start && start < e) ids.push(id)
+            }
+            marks.comment = ids.sort((x, y) => x - y).map(i => ({ id: comments[i] }))
+        }
+        if (attr & ATTR.LINK) marks.link = { url: batch.urls[attr & ATTR.ID_MASK] }
+        let text = ""
+        for (let q = start; q < end; q++) text += batch.values[res.values[b + q]]
+        out.push({ text, marks })
+    }
+    return out
+}
+
+class MergeEngine {
+    /** opts: {device?: number, libPath?: string, addonPath?: string} */
+    constructor(opts) {
+        const o = opts || {}
+        this.addon = require(o.addonPath || path.join(__dirname, "peritext_node.node"))
+        this.addon.open(o.libPath || path.join(__dirname, "..", "lib", "libperitext_hip.so"))
+        this.ctx = this.addon.create(o.device || 0, 0) /* throws without a gfx950 device: there is no CPU fallback */
+        this.pending = []
+    }
+    close() {
+        if (this.ctx) this.addon.destroy(this.ctx)
+        this.ctx = null
+    }
+    /** Raw call: SoA batch -> result typed arrays (ptx_apply_materialize). */
+    applyMaterialize(batch) {
+        return this.addon.applyMaterialize(this.ctx, batch)
+    }
+    /** docs: Change[][][]  ->  FormatSpanWithText[][][] (doc -> replica -> spans).  A failed log throws RangeError like the reference. */
+    applyChanges(docs) {
+        const batch = encodeDocs(docs)
+        const res = this.applyMaterialize(batch)
+        let log = 0
+        return docs.map(logs => logs.map(() => decodeSpans(batch, res, log++)))
+    }
+    /** Per-document digests (2 x u64 as BigInt pairs) of every log: equal digests <=> deep-equal spans. */
+    digests(docs) {
+        const batch = encodeDocs(docs)
+        const res = this.applyMaterialize(batch)
+        const out = []
+        for (let l = 0; l < batch.nLogs; l++) {
+            const r = res.logs.subarray(12 * l, 12 * l + 12)
+            out.push([(BigInt(r[9]) << 32n) | BigInt(r[8]), (BigInt(r[11]) << 32n) | BigInt(r[10])])
+        }
+        return out
+    }
+    /** A replica handle with the reference's per-replica calls; all handles of one engine are merged in ONE launch. */
+    replica(docId) {
+        const self = this
+        const rep = { changes: [], spans: null, error: null, docId: docId === undefined ? this.pending.length : docId }
+        this.pending.push(rep)
+        return {
+            applyChange(change) {
+                rep.changes.push(change)
+                rep.spans = null
+                return [] /* incremental Patch[] are not produced by the batch path (SURVEY.md §8 f1) */
+            },
+            getTextWithFormatting(p) {
+                if (!Array.isArray(p) || p.length !== 1 || p[0] !== "text") throw new Error("Only the text list is supported: " + JSON.stringify(p))
+                if (rep.spans === null && rep.error === null) self.flush()
+                if (rep.error) throw rep.error
+                return rep.spans
+            },
+        }
+    }
+    flush() {
+        const byDoc = new Map()
+        for (const r of this.pending) {
+            if (!byDoc.has(r.docId)) byDoc.set(r.docId, [])
+            byDoc.get(r.docId).push(r)
+        }
+        const groups = Array.from(byDoc.values())
+        const batch = encodeDocs(groups.map(g => g.map(r => r.changes)))
+        const res = this.applyMaterialize(batch)
+        let log = 0
+        for (const g of groups)
+            for (const r of g) {
+                try {
+                    r.spans = decodeSpans(batch, res, log)
+                    r.error = null
+                } catch (e) {
+                    r.error = e
+                }
+                log++
+            }
+    }
+}
+
+module.exports = { MergeEngine, encodeDocs, decodeSpans, census, ACT, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }

@@ -1,0 +1,39 @@
+"""Multi-GPU layout of the hot path: documents shard across ranks, all replicas of a document stay
+on one rank, no data-path collective; the only exchange is an all-gather of the per-replica 128-bit digests so that
+every rank can state global convergence (the reference's `assert.deepStrictEqual(leftText, rightText)`,
+test/fuzz.ts:277-278, for the whole batch).  `torch.distributed` backend "nccl" is RCCL over xGMI on the GPU box;
+the same code runs over gloo on CPU tensors in the tests.  Plumbing only — merges happen in engine.py."""
+
+
+def doc_range(n_docs, rank, world):
+    """Contiguous block of documents owned by `rank`: [first, first + count).  Blocks differ by at most one doc."""
+    base, extra = divmod(n_docs, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def converged_docs(digests, replicas):
+    """digests: integer tensor [n_logs, 2] (two u64 halves reinterpreted as int64), logs grouped by document
+    (`replicas` consecutive logs per document).  Returns a 0-d tensor: documents whose replicas all agree."""
+    d = digests.view(-1, replicas, 2)
+    return (d == d[:, :1, :]).all(dim=2).all(dim=1).sum()
+
+
+def allgather_digests(digests, dist=None, out=None):
+    """All-gather of equally sized per-rank digest tensors -> [world * n_logs, 2] (rank-major).  `dist` is
+    torch.distributed (already initialised) or None for a single process."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return digests
+    import torch
+
+    world = dist.get_world_size()
+    if out is None:
+        out = torch.empty((world * digests.shape[0],) + tuple(digests.shape[1:]), dtype=digests.dtype, device=digests.device)
+    dist.all_gather_into_tensor(out, digests.contiguous())
+    return out
+
+
+def global_convergence(digests, replicas, dist=None, out=None):
+    """(converged documents, total documents) over all ranks, identical on every rank."""
+    g = allgather_digests(digests, dist, out)
+    return converged_docs(g, replicas), g.shape[0] // replicas

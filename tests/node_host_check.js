@@ -1,0 +1,58 @@
+"use strict"
+/*
+ * Test driver for the JS host (peritext_amd/node).  It does not import oracle/: expected values come from the
+ * committed golden fixtures.
+ *   node tests/node_host_check.js encode <fixture.json>   print sha256 of every encoded column (no GPU, no addon)
+ *   node tests/node_host_check.js load                    the addon loads and dlopens libperitext_hip.so (no GPU)
+ *   node tests/node_host_check.js run <fixture.json>...   GPU: applyChanges + the replica() surface vs the fixture's spans
+ */
+const fs = require("fs")
+const path = require("path")
+const crypto = require("crypto")
+const assert = require("assert")
+const host = require(path.join(__dirname, "..", "peritext_amd", "node"))
+
+const cmd = process.argv[2]
+const sha = ta => crypto.createHash("sha256").update(Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength)).digest("hex")
+const norm = spans => spans.map(s => ({ text: s.text, marks: JSON.parse(JSON.stringify(s.marks, Object.keys(s.marks).sort())) }))
+
+if (cmd === "encode") {
+    const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    const b = host.encodeDocs(gen.docs.map(d => d.logs))
+    const out = { nLogs: b.nLogs, nOps: b.nOps, values: b.values, urls: b.urls, docComments: b.docComments }
+    for (const k of ["logOff", "opId", "refA", "refB", "payload", "action", "markType", "sideA", "sideB", "logHdr"]) out[k] = sha(b[k])
+    console.log(JSON.stringify(out))
+} else if (cmd === "load") {
+    const addon = require(path.join(__dirname, "..", "peritext_amd", "node", "peritext_node.node"))
+    const v = addon.open(path.join(__dirname, "..", "peritext_amd", "lib", "libperitext_hip.so"))
+    assert.strictEqual(typeof addon.applyMaterialize, "function")
+    console.log(JSON.stringify({ abi: v, kernel: addon.kernelName(), exports: Object.keys(addon).sort() }))
+} else if (cmd === "run") {
+    const engine = new host.MergeEngine()
+    let logs = 0
+    for (const f of process.argv.slice(3)) {
+        const gen = JSON.parse(fs.readFileSync(f, "utf8"))
+        const got = engine.applyChanges(gen.docs.map(d => d.logs))
+        gen.docs.forEach((d, di) =>
+            d.expected.forEach((e, ri) => {
+                assert.deepStrictEqual(norm(got[di][ri]), norm(e.spans), f + " doc " + di + " replica " + ri)
+                logs++
+            })
+        )
+        /* the reference's per-replica surface, batched under the hood */
+        const reps = gen.docs[0].logs.map(() => engine.replica(0))
+        gen.docs[0].logs.forEach((log, ri) => log.forEach(ch => reps[ri].applyChange(ch)))
+        reps.forEach((r, ri) => assert.deepStrictEqual(norm(r.getTextWithFormatting(["text"])), norm(gen.docs[0].expected[ri].spans)))
+        engine.pending = []
+    }
+    /* a failed log throws RangeError like micromerge.ts:752 */
+    const bad = [[[{ actor: "a", seq: 1, deps: {}, startOp: 1, ops: [
+        { opId: "1@a", action: "makeList", obj: "_root", key: "text" },
+        { opId: "2@a", action: "set", obj: "1@a", elemId: "9@zz", insert: true, value: "x" }] }]]]
+    assert.throws(() => engine.applyChanges(bad), e => e instanceof RangeError && /List element not found/.test(e.message))
+    engine.close()
+    console.log(JSON.stringify({ ok: true, logs }))
+} else {
+    console.error("usage: encode|load|run")
+    process.exit(2)
+}

@@ -1,0 +1,62 @@
+"""The JavaScript/TypeScript host (peritext_amd/node): N-API addon + Change[] <-> SoA codec.
+
+CPU tests: the addon builds, loads and dlopens libperitext_hip.so with every symbol it binds; the JS encoder
+produces byte-identical op-log columns (and per-log headers) to the Python encoder on every committed fixture.
+GPU test: node drives the HIP path through the addon and reproduces the fixtures' spans, including the
+reference-style per-replica surface (applyChange / getTextWithFormatting) and its RangeError."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from peritext_amd import abi, wire
+
+ADDON = os.path.join(H.ROOT, "peritext_amd", "node", "peritext_node.node")
+DRIVER = os.path.join(H.ROOT, "tests", "node_host_check.js")
+FIXTURES = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json", "ptxgen_config4_600.json", "ptxgen_rich_700.json"]
+needs_node = pytest.mark.skipif(not H.have_node(), reason="node not installed")
+needs_addon = pytest.mark.skipif(not os.path.exists(ADDON), reason="N-API addon not built (run __graft_entry__.build())")
+
+
+def _node(*args, timeout=300):
+    p = subprocess.run([H.NODE, DRIVER] + list(args), cwd=H.ROOT, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@needs_node
+@needs_addon
+@pytest.mark.skipif(not os.path.exists(abi.LIB_PATH), reason="libperitext_hip.so not built")
+def test_addon_loads_and_binds_the_c_abi():
+    info = _node("load")
+    assert info["abi"] == abi.PTX_ABI_VERSION
+    assert info["kernel"].startswith("ptx_merge_kernel")
+    assert info["exports"] == ["applyMaterialize", "create", "destroy", "kernelName", "maxOpsPerLog", "open"]
+
+
+@needs_node
+@pytest.mark.parametrize("name", FIXTURES)
+def test_js_encoder_matches_python_encoder(name):
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    js = _node("encode", os.path.join(H.GOLDEN, name))
+    with open(os.path.join(H.GOLDEN, name)) as f:
+        gen = json.load(f)
+    b = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    assert js["nLogs"] == b.n_logs and js["nOps"] == b.n_ops
+    assert js["values"] == b.values and js["urls"] == b.urls and js["docComments"] == b.doc_comments
+    cols = {"logOff": b.log_off, "opId": b.op_id, "refA": b.ref_a, "refB": b.ref_b, "payload": b.payload, "action": b.action,
+            "markType": b.mark_type, "sideA": b.side_a, "sideB": b.side_b, "logHdr": b.log_hdr}
+    for k, a in cols.items():
+        assert js[k] == sha(a), k
+
+
+@pytest.mark.gpu
+@needs_node
+@needs_addon
+def test_node_host_drives_the_gpu_path():
+    out = _node("run", *[os.path.join(H.GOLDEN, n) for n in FIXTURES], timeout=600)
+    assert out["ok"] and out["logs"] == sum(len(d["expected"]) for n in FIXTURES for d in json.load(open(os.path.join(H.GOLDEN, n)))["docs"])
