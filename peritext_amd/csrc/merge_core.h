@@ -156,6 +156,33 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 }
 #endif
 
+/* Software-pipelined uniform loops: step st of `steps` handles group PTX_G_OF(st); the loads of step st+1 are
+ * issued before step st is processed (the caller keeps two register sets).  Every thread runs every step; a
+ * group index past the end means "no work" (its loads are clamped to valid addresses, its effects masked). */
+#ifdef PTX_EMU
+#define PTX_STEPS(groups) (groups)
+#define PTX_G_OF(st, steps) (ptx_emu_reverse ? ((st) < (steps) ? (steps) - 1u - (st) : (steps)) : (st))
+#else
+#define PTX_STEPS(groups) (((groups) + blockDim.x - 1u) / blockDim.x)
+#define PTX_G_OF(st, steps) (threadIdx.x + (st) * blockDim.x)
+#endif
+
+/* the same for loops over list items, PTX_U items per thread and step, lanes on consecutive items:
+ * step st, slot u handles item PTX_J_OF(st, u) (past the end = no work); PTX_JX maps it for the emulation's
+ * reversed order */
+#ifdef PTX_EMU
+#define PTX_JSTEPS_U(n, U) (((n) + (U)-1u) / (U))
+#define PTX_J_OF_U(st, u, U) ((st) * (U) + (uint32_t)(u))
+#define PTX_JX(j, n) (ptx_emu_reverse ? (n) - 1u - (j) : (j))
+#else
+#define PTX_JSTEPS_U(n, U) (((n) + (U)*blockDim.x - 1u) / ((U)*blockDim.x))
+#define PTX_J_OF_U(st, u, U) (((st) * (U) + (uint32_t)(u)) * blockDim.x + threadIdx.x)
+#define PTX_JX(j, n) (j)
+#endif
+#define PTX_JSTEPS(n) PTX_JSTEPS_U(n, PTX_U)
+#define PTX_J_OF(st, u) PTX_J_OF_U(st, u, PTX_U)
+#define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
+
 /* uniform loop over groups of PTX_U consecutive items: every thread runs every step (g may be past the end) */
 #ifdef PTX_EMU
 #define PTX_FORG(g, groups) \
@@ -686,18 +713,24 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         /* Branch-free row loop: every row does the same work; rows that are out of range, malformed or of no
          * interest (makeList, NOP) use class 6/7 = a spare cursor, the spare list slot and OR 0 into the bitmaps. */
         uint32_t badrow = 0xFFFFFFFFu; /* first malformed / duplicate row seen by this thread */
-        PTX_FORG(g, (N + PTX_U - 1u) / PTX_U) {
-            /* this thread's PTX_U consecutive rows; indices past the end are clamped, their effects masked */
-            uint64_t id[PTX_U];
-            uint32_t a[PTX_U], mt[PTX_U], cls[PTX_U], slot[PTX_U];
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u) {
-                const uint32_t r = g * PTX_U + (uint32_t)u;
-                const uint32_t i = r < N ? r : N - 1u;
-                id[u] = op_id[i];
-                a[u] = action[i];
-                mt[u] = mark_type[i];
-            }
+        const uint32_t p1_groups = (N + PTX_U - 1u) / PTX_U, p1_steps = PTX_STEPS(p1_groups);
+        uint64_t id[PTX_U], id_n[PTX_U];
+        uint32_t a[PTX_U], mt[PTX_U], a_n[PTX_U], mt_n[PTX_U];
+        /* this thread's PTX_U consecutive rows of a step; indices past the end are clamped, their effects masked */
+#define PTX_P1_LOAD(g_, id_, a_, mt_)                                   \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                 \
+        const uint32_t r_ = (g_) * PTX_U + (uint32_t)u;                 \
+        const uint32_t i_ = r_ < N ? r_ : N - 1u;                       \
+        id_[u] = op_id[i_];                                             \
+        a_[u] = action[i_];                                             \
+        mt_[u] = mark_type[i_];                                         \
+    }
+        PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a, mt)
+        for (uint32_t st = 0; st < p1_steps; ++st) {
+            const uint32_t g = PTX_G_OF(st, p1_steps);
+            const uint32_t gn = PTX_G_OF(st + 1u, p1_steps);
+            PTX_P1_LOAD(gn, id_n, a_n, mt_n) /* next step's rows are in flight while this step is processed */
+            uint32_t cls[PTX_U], slot[PTX_U];
 #pragma unroll
             for (int u = 0; u < PTX_U; ++u) {
                 const uint32_t i = g * PTX_U + (uint32_t)u;
@@ -730,7 +763,14 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                 ptx_atomic_or(&addbits[k >> 5], a[u] == PTX_ACT_ADDMARK && listed ? 1u << (k & 31) : 0u);
                 if (A.out_rank && i < N) A.out_rank[base + i] = 0xFFFFFFFFu; /* insert rows are overwritten in P5a */
             }
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u) {
+                id[u] = id_n[u];
+                a[u] = a_n[u];
+                mt[u] = mt_n[u];
+            }
         }
+#undef PTX_P1_LOAD
         if (badrow != 0xFFFFFFFFu) {
             /* which of the two: re-test the row */
             const uint64_t id = op_id[badrow];
@@ -765,34 +805,48 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         PTX_FOR(p, n + 2) cnt[p] = 0;
         PTX_SYNC();
         /* P3a: element index of every insert, its parent, children counts */
-        PTX_FORU(j0, n) {
-            uint32_t i[PTX_U];
-            uint64_t id[PTX_U], ra[PTX_U];
+        {
+            const uint32_t steps = PTX_JSTEPS(n);
+            uint32_t i[PTX_U], i_n[PTX_U];
+            uint64_t id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U];
+            /* rows of this thread's inserts of a step (list read, then the two column gathers) */
+#define PTX_P3A_LOAD(st_, i_, id_, ra_)                                     \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        const uint32_t j_ = PTX_J_OF(st_, u);                               \
+        const uint32_t r_ = ilist[j_ < n ? PTX_JX(j_, n) : 0u];             \
+        i_[u] = r_ < N ? r_ : N - 1u;                                       \
+    }                                                                       \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        id_[u] = op_id[i_[u]];                                              \
+        ra_[u] = ref_a[i_[u]];                                              \
+    }
+            PTX_P3A_LOAD(0u, i, id, ra)
+            for (uint32_t st = 0; st < steps; ++st) {
+                PTX_P3A_LOAD(st + 1u, i_n, id_n, ra_n) /* in flight while this step is processed */
 #pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(j0, u)) i[u] = ilist[PTX_IX(j0, u)];
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(j0, u)) {
-                    id[u] = op_id[i[u]];
-                    ra[u] = ref_a[i[u]];
-                }
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(j0, u)) {
-                    uint32_t key = 0;
-                    ptx_id_key(ix, id[u], key);
-                    const uint32_t e = ptx_bitrank(ix.ib, key);
-                    row_of[e] = (uint16_t)i[u];
-                    uint32_t pe = n;
-                    if (ra[u] != 0) {
-                        const int p = ptx_elem_lookup(ix, ra[u]);
-                        if (p < 0) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND); /* micromerge.ts:752 */
-                        else pe = (uint32_t)p;
+                for (int u = 0; u < PTX_U; ++u)
+                    if (PTX_J_OF(st, u) < n) {
+                        uint32_t key = 0;
+                        ptx_id_key(ix, id[u], key);
+                        const uint32_t e = ptx_bitrank(ix.ib, key);
+                        row_of[e] = (uint16_t)i[u];
+                        uint32_t pe = n;
+                        if (ra[u] != 0) {
+                            const int p = ptx_elem_lookup(ix, ra[u]);
+                            if (p < 0) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND); /* micromerge.ts:752 */
+                            else pe = (uint32_t)p;
+                        }
+                        par[e] = (uint16_t)pe;
+                        ptx_atomic_add(&cnt[pe], 1u);
                     }
-                    par[e] = (uint16_t)pe;
-                    ptx_atomic_add(&cnt[pe], 1u);
+#pragma unroll
+                for (int u = 0; u < PTX_U; ++u) {
+                    i[u] = i_n[u];
+                    id[u] = id_n[u];
+                    ra[u] = ra_n[u];
                 }
+            }
+#undef PTX_P3A_LOAD
         }
         PTX_BAIL_IF_ERROR();
         ptx_scan_excl<uint32_t, 1>(cnt, n + 2, H->scan_tmp); /* cnt[p] = first slot of p's children */
@@ -816,23 +870,35 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                     seg[ptx_atomic_add(&cnt[pe[u]], 1u)] = (uint16_t)PTX_IX(e0, u); /* now cnt[p] = END of p's bucket */
                 }
         }
-        PTX_FORU(j0, D) {
-            uint32_t i[PTX_U];
-            uint64_t ra[PTX_U];
+        {
+            const uint32_t steps = PTX_JSTEPS(D);
+            uint32_t i[PTX_U], i_n[PTX_U];
+            uint64_t ra[PTX_U], ra_n[PTX_U];
+#define PTX_DEL_LOAD(st_, i_, ra_)                                          \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        const uint32_t j_ = PTX_J_OF(st_, u);                               \
+        const uint32_t r_ = dlist[j_ < D ? PTX_JX(j_, D) : 0u];             \
+        i_[u] = r_ < N ? r_ : N - 1u;                                       \
+    }                                                                       \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) ra_[u] = ref_a[i_[u]];
+            PTX_DEL_LOAD(0u, i, ra)
+            for (uint32_t st = 0; st < steps; ++st) {
+                PTX_DEL_LOAD(st + 1u, i_n, ra_n)
 #pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(j0, u)) i[u] = dlist[PTX_IX(j0, u)];
+                for (int u = 0; u < PTX_U; ++u)
+                    if (PTX_J_OF(st, u) < D) {
+                        /* the element must exist when the delete is applied (micromerge.ts:752); deleting twice is fine (:693) */
+                        const int t = ptx_elem_lookup(ix, ra[u]);
+                        if (t < 0 || row_of[t] >= i[u]) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);
+                        else ptx_atomic_or(&delbits[t >> 5], 1u << ((uint32_t)t & 31u));
+                    }
 #pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(j0, u)) ra[u] = ref_a[i[u]];
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(j0, u)) {
-                    /* the element must exist when the delete is applied (micromerge.ts:752); deleting twice is fine (:693) */
-                    const int t = ptx_elem_lookup(ix, ra[u]);
-                    if (t < 0 || row_of[t] >= i[u]) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);
-                    else ptx_atomic_or(&delbits[t >> 5], 1u << ((uint32_t)t & 31u));
+                for (int u = 0; u < PTX_U; ++u) {
+                    i[u] = i_n[u];
+                    ra[u] = ra_n[u];
                 }
+            }
+#undef PTX_DEL_LOAD
         }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(3);
@@ -996,25 +1062,31 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         }
         ptx_digest_flush(H, h1, h2);
     }
-    PTX_FORU(k0, K) {
-        uint32_t i[PTX_U], sa[PTX_U], sb[PTX_U], pl[PTX_U];
-        uint64_t ra[PTX_U], rb[PTX_U];
+    {
+    const uint32_t m_steps = PTX_JSTEPS_U(K, PTX_UM);
+    uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
+    uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
+    /* rows of this thread's mark ops of a step (list read, then the five column gathers) */
+#define PTX_MARK_LOAD(st_, i_, ra_, rb_, sa_, sb_, pl_)                     \
+    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {                     \
+        const uint32_t j_ = PTX_J_OF_U(st_, u, PTX_UM);                               \
+        const uint32_t r_ = mlist[j_ < K ? PTX_JX(j_, K) : 0u];             \
+        i_[u] = r_ < N ? r_ : N - 1u;                                       \
+    }                                                                       \
+    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {                     \
+        ra_[u] = ref_a[i_[u]];                                              \
+        rb_[u] = ref_b[i_[u]];                                              \
+        sa_[u] = A.side_a[base + i_[u]];                                    \
+        sb_[u] = A.side_b[base + i_[u]];                                    \
+        pl_[u] = payload[i_[u]];                                            \
+    }
+    PTX_MARK_LOAD(0u, i, ra, rb, sa, sb, pl)
+    for (uint32_t st = 0; st < m_steps; ++st) {
+        PTX_MARK_LOAD(st + 1u, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* in flight while this step is processed */
 #pragma unroll
-        for (int u = 0; u < PTX_U; ++u)
-            if (PTX_IN(k0, u)) i[u] = mlist[PTX_IX(k0, u)];
-#pragma unroll
-        for (int u = 0; u < PTX_U; ++u)
-            if (PTX_IN(k0, u)) {
-                ra[u] = ref_a[i[u]];
-                rb[u] = ref_b[i[u]];
-                sa[u] = A.side_a[base + i[u]];
-                sb[u] = A.side_b[base + i[u]];
-                pl[u] = payload[i[u]];
-            }
-#pragma unroll
-        for (int u = 0; u < PTX_U; ++u)
-            if (PTX_IN(k0, u)) {
-                const uint32_t k = PTX_IX(k0, u);
+        for (int u = 0; u < (int)PTX_UM; ++u)
+            if (PTX_J_OF_U(st, u, PTX_UM) < K) {
+                const uint32_t k = PTX_JX(PTX_J_OF_U(st, u, PTX_UM), K);
                 uint32_t lo = 0, hi = 0;
                 /* start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is
                    not in the list when the op is applied means the op never starts */
@@ -1047,6 +1119,17 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                     cid[k - moff2] = (uint16_t)pl[u];
                 }
             }
+#pragma unroll
+        for (int u = 0; u < (int)PTX_UM; ++u) {
+            i[u] = i_n[u];
+            ra[u] = ra_n[u];
+            rb[u] = rb_n[u];
+            sa[u] = sa_n[u];
+            sb[u] = sb_n[u];
+            pl[u] = pl_n[u];
+        }
+    }
+#undef PTX_MARK_LOAD
     }
     PTX_BAIL_IF_ERROR();
     const uint32_t mark2_lds = bp.off;
