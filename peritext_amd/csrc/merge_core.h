@@ -113,8 +113,9 @@ PTX_DEV uint32_t ptx_group_sum(uint32_t c) {
  *      (6 lanes, 6 distinct cursors); the ranking itself is a DPP prefix sum in registers.  Every lane of the
  *      wave must call it (uniform control flow). ---- */
 #ifdef PTX_EMU
+template <int U>
 PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slot) {
-    for (int u = 0; u < PTX_U; ++u) slot[u] = cls[u] < 6u ? cursor[cls[u]]++ : 0xFFFFFFFFu;
+    for (int u = 0; u < U; ++u) slot[u] = cls[u] < 6u ? cursor[cls[u]]++ : 0xFFFFFFFFu;
 }
 #else
 PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v) {
@@ -126,11 +127,12 @@ PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2,3 */
     return v;
 }
+template <int U>
 PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slot) {
-    /* per-lane counts, 10 bits per class: classes 0..2 in w0, 3..5 in w1 (a wave holds at most 64 * PTX_U <= 1023 rows) */
-    uint32_t w0 = 0, w1 = 0, off[PTX_U];
+    /* per-lane counts, 10 bits per class: classes 0..2 in w0, 3..5 in w1 (a wave holds at most 64 * U <= 1023 rows) */
+    uint32_t w0 = 0, w1 = 0, off[U];
 #pragma unroll
-    for (int u = 0; u < PTX_U; ++u) {
+    for (int u = 0; u < U; ++u) {
         const uint32_t c = cls[u];
         const uint32_t sh = (c >= 3u ? c - 3u : c) * 10u;
         off[u] = ((c >= 3u ? w1 : w0) >> sh) & 1023u;
@@ -147,7 +149,7 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
     }
     const uint32_t e0 = i0 - w0, e1 = i1 - w1; /* exclusive prefix over the lower lanes */
 #pragma unroll
-    for (int u = 0; u < PTX_U; ++u) {
+    for (int u = 0; u < U; ++u) {
         const uint32_t c = cls[u];
         const uint32_t sh = (c >= 3u ? c - 3u : c) * 10u;
         const uint32_t b = (uint32_t)__shfl((int)basev, (int)(c & 7u), 64);
@@ -181,6 +183,12 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #endif
 #define PTX_JSTEPS(n) PTX_JSTEPS_U(n, PTX_U)
 #define PTX_J_OF(st, u) PTX_J_OF_U(st, u, PTX_U)
+#ifndef PTX_U1
+#define PTX_U1 2 /* consecutive rows per thread and step in the row pass P1 */
+#endif
+#ifndef PTX_P1_PREFETCH
+#define PTX_P1_PREFETCH 1 /* 1: double-buffer the row loads of P1 (costs PTX_U1 * 4 VGPRs) */
+#endif
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
 
 /* uniform loop over groups of PTX_U consecutive items: every thread runs every step (g may be past the end) */
@@ -226,7 +234,8 @@ struct PtxMergeArgs {
 #define PTX_TILE_4 128u  /* visible chars up to which the four LWW trees are resident at once */
 #define PTX_TILE_1 512u  /* tile of the visible axis for longer documents (one tree, reused per mark type) */
 #define PTX_NCLK 16
-#define PTX_SMALL_BUCKET 8u
+#define PTX_SMALL_BUCKET 8u  /* child buckets up to this size: one lane per member */
+#define PTX_HUGE_BUCKET 32u  /* beyond this size: bitmap ranking, one bucket at a time */
 
 /* ---- digest: 128-bit multiset hash of the canonical output (restated in peritext_amd/canon.py) ---- */
 PTX_DEV uint64_t ptx_fmix64(uint64_t x) {
@@ -248,7 +257,7 @@ PTX_DEV void ptx_digest_item(uint64_t& h1, uint64_t& h2, uint32_t tag, uint32_t 
 struct PtxHdr {
     uint32_t err;          /* min over ((row*2+level) << 4 | code) of every detected error; ~0 = none */
     uint32_t max_ctr, max_actor;
-    uint32_t cur_big;
+    uint32_t cur_big, cur_med, cur_huge;
     uint32_t V, S, I;
     uint32_t n_ins, n_applied;
     uint32_t cur[8]; /* list cursors per row class (0 insert, 1 delete, 2..5 mark type 0..3, 6/7 unlisted rows) */
@@ -420,12 +429,12 @@ PTX_HD uint64_t ptx_a16(uint64_t x) { return (x + 15) & ~15ull; }
 PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
     (void)N;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
-    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (K + 1)) + ptx_a16(4 * (K / 32 + 2)) +
+    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (K + 1)) +
                              2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1));
     const uint64_t dr = (D + 2) / 2 > (2 * n) / PTX_S + 2 ? (D + 2) / 2 : (2 * n) / PTX_S + 2;
     const uint64_t lists = ptx_a16(2 * (n + 1)) + ptx_a16(4 * dr);
     const uint64_t p1a = lists + ptx_a16(4 * (nw + 1));
-    const uint64_t p3 = lists + ptx_a16(4 * (n + 2)) + ptx_a16(2 * (2 * n + 2));
+    const uint64_t p3 = lists + ptx_a16(4 * (n + 2)) + ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2)) + ptx_a16(8 * (nwe + 2));
     const uint64_t p1 = p1a > p3 ? p1a : p3;
     const uint64_t comments = Kc ? 2 * ptx_a16(4 * (Kc + 1)) + ptx_a16(8 * (Kc + 1)) : 0;
     const uint64_t T4 = PTX_TILE_4, T1 = PTX_TILE_1;
@@ -482,6 +491,7 @@ PTX_DEV void ptx_write_result(const PtxMergeArgs& A, uint32_t log, PtxHdr* H, ui
 #ifndef PTX_EMU
         if (A.clocks) {
             H->clk[PTX_NCLK] = ptx_clock();
+#pragma nounroll
             for (int k = 0; k < PTX_NCLK; ++k) {
                 /* phase k = time from stamp k to the next recorded stamp */
                 if (H->clk[k] == 0) continue;
@@ -564,16 +574,16 @@ PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
         const uint32_t _st = H->err;                               \
         PTX_SYNC();                                                \
         if (_st != PTX_NO_ERR) {                                   \
-            ptx_write_result(A, log, H, _st & 15u, bp.high);       \
-            return;                                                \
+            lds_high = bp.high;                                    \
+            return _st & 15u;                                      \
         }                                                          \
     } while (0)
 
 #define PTX_BAIL_CAPACITY()                                        \
     do {                                                           \
         if (bp.overflow) {                                         \
-            ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);\
-            return;                                                \
+            lds_high = bp.high;                                    \
+            return PTX_ERR_CAPACITY;                               \
         }                                                          \
     } while (0)
 
@@ -584,21 +594,23 @@ PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
     do {                                                           \
         if (A.clocks && threadIdx.x == 0) H->clk[k] = ptx_clock(); \
         if ((k) != 0 && A.stop_after == (k)) {                     \
-            ptx_write_result(A, log, H, PTX_OK, bp.high);          \
-            return;                                                \
+            lds_high = bp.high;                                    \
+            return PTX_OK;                                         \
         }                                                          \
     } while (0)
 #endif
 
 /* ================================================================================================ */
-PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
+/* Applies log `log`; returns its status (PTX_OK or a per-log PTX_ERR_*) and the LDS high-water mark.  The caller
+ * writes the result row (ptx_write_result) — ONE copy of that code instead of one per early exit. */
+PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t* lds, uint32_t& lds_high) {
     const uint64_t base = A.log_off[log];
     const uint64_t N64 = A.log_off[log + 1] - base;
     PtxHdr* H = (PtxHdr*)lds;
     PTX_LEADER {
         H->err = PTX_NO_ERR;
         H->max_ctr = H->max_actor = 0;
-        H->cur_big = 0;
+        H->cur_big = H->cur_med = H->cur_huge = 0;
         H->n_ins = H->n_applied = 0;
         H->V = H->S = H->I = 0;
         H->h1 = H->h2 = 0;
@@ -613,8 +625,8 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     PTX_SYNC();
     PTX_STAMP(0);
     if (N64 > 65534u) {
-        ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);
-        return;
+        lds_high = bp.high;
+        return PTX_ERR_CAPACITY;
     }
     const uint32_t N = (uint32_t)N64;
     const uint64_t* op_id = A.op_id + base;
@@ -632,8 +644,8 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
             H->h2 += g2;
         }
         PTX_SYNC();
-        ptx_write_result(A, log, H, PTX_OK, bp.high);
-        return;
+        lds_high = bp.high;
+        return PTX_OK;
     }
 
     /* ---- the log header (census) sizes everything; the row pass below verifies it ---- */
@@ -645,8 +657,8 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     const uint32_t K = moff3 + hd.n_mark[3]; /* mark ops; listed grouped by type: type t owns [moff_t, moff_{t+1}) */
 #define PTX_TYPE_OF(k) (((k) >= moff1 ? 1u : 0u) + ((k) >= moff2 ? 1u : 0u) + ((k) >= moff3 ? 1u : 0u))
     if ((uint64_t)n + D + K > N) {
-        ptx_write_result(A, log, H, PTX_ERR_BAD_OP, bp.high);
-        return;
+        lds_high = bp.high;
+        return PTX_ERR_BAD_OP;
     }
 
     PtxElemIndex ix;
@@ -655,19 +667,18 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     ix.abits = ptx_abits_of(ix.max_actor);
     const uint32_t kbits = ptx_ceil_log2(K + 1);
     if (ix.abits > 12 || ix.max_ctr >= (1u << 19) || n > 32766u) { /* keyspace far below 2^31 bits; 2n+1 tour nodes in 16 bits */
-        ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);
-        return;
+        lds_high = bp.high;
+        return PTX_ERR_CAPACITY;
     }
     const uint32_t keyspace = (ix.max_ctr + 1u) << ix.abits;
     if (((uint64_t)(keyspace + 1u) << kbits) > 0xFFFFFFFFull) { /* (key+1) << kbits | mark index in one u32 */
-        ptx_write_result(A, log, H, PTX_ERR_CAPACITY, bp.high);
-        return;
+        lds_high = bp.high;
+        return PTX_ERR_CAPACITY;
     }
     const uint32_t nw = (keyspace + 31) / 32;
     const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
     ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
     uint16_t* mlist = ptx_alloc<uint16_t>(bp, K + 1); /* rows of the mark ops, grouped by type; [K] = spare slot */
-    uint32_t* addbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 2); /* mark index -> is an addMark */
     uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1);         /* element -> op row */
     uint16_t* par = ptx_alloc<uint16_t>(bp, n + 1);            /* element -> parent element (n = HEAD); later: document position */
     uint32_t* delbits = ptx_alloc<uint32_t>(bp, nwe + 1);      /* element -> tombstone */
@@ -695,7 +706,6 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
             ix.ib[w] = z;
             allbits[w] = 0;
         }
-        PTX_FOR(w, (K >> 5) + 2) addbits[w] = 0;
         PTX_FOR(w, nwe + 1) delbits[w] = 0;
         PTX_LEADER {
             /* list cursors (class 0 insert -> ilist, 1 delete -> dlist, 2..5 mark type 0..3 -> mlist) */
@@ -713,27 +723,37 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         /* Branch-free row loop: every row does the same work; rows that are out of range, malformed or of no
          * interest (makeList, NOP) use class 6/7 = a spare cursor, the spare list slot and OR 0 into the bitmaps. */
         uint32_t badrow = 0xFFFFFFFFu; /* first malformed / duplicate row seen by this thread */
-        const uint32_t p1_groups = (N + PTX_U - 1u) / PTX_U, p1_steps = PTX_STEPS(p1_groups);
-        uint64_t id[PTX_U], id_n[PTX_U];
-        uint32_t a[PTX_U], mt[PTX_U], a_n[PTX_U], mt_n[PTX_U];
-        /* this thread's PTX_U consecutive rows of a step; indices past the end are clamped, their effects masked */
+        const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
+        uint64_t id[PTX_U1];
+        uint32_t a[PTX_U1], mt[PTX_U1];
+#if PTX_P1_PREFETCH
+        uint64_t id_n[PTX_U1];
+        uint32_t a_n[PTX_U1], mt_n[PTX_U1];
+#endif
+        /* this thread's PTX_U1 consecutive rows of a step; indices past the end are clamped, their effects masked */
 #define PTX_P1_LOAD(g_, id_, a_, mt_)                                   \
-    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                 \
-        const uint32_t r_ = (g_) * PTX_U + (uint32_t)u;                 \
+    _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {                 \
+        const uint32_t r_ = (g_) * PTX_U1 + (uint32_t)u;                 \
         const uint32_t i_ = r_ < N ? r_ : N - 1u;                       \
         id_[u] = op_id[i_];                                             \
         a_[u] = action[i_];                                             \
         mt_[u] = mark_type[i_];                                         \
     }
+#if PTX_P1_PREFETCH
         PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a, mt)
+#endif
         for (uint32_t st = 0; st < p1_steps; ++st) {
             const uint32_t g = PTX_G_OF(st, p1_steps);
+#if PTX_P1_PREFETCH
             const uint32_t gn = PTX_G_OF(st + 1u, p1_steps);
             PTX_P1_LOAD(gn, id_n, a_n, mt_n) /* next step's rows are in flight while this step is processed */
-            uint32_t cls[PTX_U], slot[PTX_U];
+#else
+            PTX_P1_LOAD(g, id, a, mt)
+#endif
+            uint32_t cls[PTX_U1], slot[PTX_U1];
 #pragma unroll
-            for (int u = 0; u < PTX_U; ++u) {
-                const uint32_t i = g * PTX_U + (uint32_t)u;
+            for (int u = 0; u < PTX_U1; ++u) {
+                const uint32_t i = g * PTX_U1 + (uint32_t)u;
                 const bool in = i < N;
                 const uint32_t ctr = (uint32_t)(id[u] >> 32), act = (uint32_t)id[u];
                 /* action -> class through a nibble table: 0 makeList->6, 1 insert->0, 2 delete->1, 3/4 marks->2, 5 nop->6, else 7 */
@@ -743,10 +763,10 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                 badrow = in && (c == 7u || keybad) && i < badrow ? i : badrow;
                 cls[u] = (!in || keybad) ? 7u : c;
             }
-            ptx_wave_slots(H->cur, cls, slot);
+            ptx_wave_slots<PTX_U1>(H->cur, cls, slot);
 #pragma unroll
-            for (int u = 0; u < PTX_U; ++u) {
-                const uint32_t i = g * PTX_U + (uint32_t)u;
+            for (int u = 0; u < PTX_U1; ++u) {
+                const uint32_t i = g * PTX_U1 + (uint32_t)u;
                 const uint32_t c = cls[u];
                 const uint32_t key = c == 7u ? 0u : ((uint32_t)(id[u] >> 32) << ix.abits) | (uint32_t)id[u];
                 const uint32_t bit = c == 7u ? 0u : 1u << (key & 31);
@@ -759,16 +779,16 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                 const bool listed = c < 6u && slot[u] < cap;
                 const uint32_t sl = listed ? slot[u] : (c == 0u ? n : c == 1u ? D : K);
                 lst[sl] = (uint16_t)i;
-                const uint32_t k = c >= 2u ? sl : 0u;
-                ptx_atomic_or(&addbits[k >> 5], a[u] == PTX_ACT_ADDMARK && listed ? 1u << (k & 31) : 0u);
                 if (A.out_rank && i < N) A.out_rank[base + i] = 0xFFFFFFFFu; /* insert rows are overwritten in P5a */
             }
+#if PTX_P1_PREFETCH
 #pragma unroll
-            for (int u = 0; u < PTX_U; ++u) {
+            for (int u = 0; u < PTX_U1; ++u) {
                 id[u] = id_n[u];
                 a[u] = a_n[u];
                 mt[u] = mt_n[u];
             }
+#endif
         }
 #undef PTX_P1_LOAD
         if (badrow != 0xFFFFFFFFu) {
@@ -797,6 +817,9 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     {
         uint32_t* cnt = ptx_alloc<uint32_t>(bp, n + 2);   /* children per parent -> bucket starts -> bucket ends */
         uint16_t* L = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* Euler tour: next node */
+        PTX_BAIL_CAPACITY();
+        uint16_t* huge = ptx_alloc<uint16_t>(bp, n / PTX_HUGE_BUCKET + 2); /* parents with more than PTX_HUGE_BUCKET children */
+        PtxBitWord* hb = ptx_alloc<PtxBitWord>(bp, nwe + 2);                 /* members of one such bucket, by element index */
         PTX_BAIL_CAPACITY();
         uint16_t* srt = ilist;       /* children of every parent, descending opId, parents ascending (ilist is dead after P3a) */
         uint16_t* seg = L;           /* bucket members in arrival order (dead before L is built) */
@@ -902,38 +925,68 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
         }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(3);
-        /* P3c: rank inside the bucket: descending element index == descending opId */
+        /* P3c: rank inside the bucket: descending element index == descending opId.  Most elements are an only
+         * child (placed at once); buckets of 2..PTX_SMALL_BUCKET members are ranked by one lane per member scanning
+         * the bucket; up to PTX_HUGE_BUCKET members by PTX_G lanes per member; larger ones (typically the children
+         * of HEAD) through a bitmap over the element indices: rank = members with a larger index. */
         PTX_FOR(j, n) {
             const uint32_t x = seg[j];
             const uint32_t p = par[x];
             const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
-            const bool is_big = t - s > PTX_SMALL_BUCKET;
-            if (!is_big) {
-                uint32_t c = 0;
-#pragma unroll
-                for (uint32_t d = 0; d < PTX_SMALL_BUCKET; ++d) {
-                    const uint32_t k = s + d;
-                    const uint32_t v = k < t ? (uint32_t)seg[k] : 0u;
-                    c += (k < t && v > x) ? 1u : 0u;
-                }
-                srt[s + c] = (uint16_t)x;
-            }
+            const uint32_t m = t - s;
+            if (m == 1u) srt[s] = (uint16_t)x;
+            const bool is_med = m > 1u && m <= PTX_SMALL_BUCKET, is_big = m > PTX_SMALL_BUCKET && m <= PTX_HUGE_BUCKET;
+            const uint32_t jm = ptx_append(&H->cur_med, is_med);
             const uint32_t jb = ptx_append(&H->cur_big, is_big);
-            if (is_big) big[jb] = (uint16_t)j;
+            if (is_med) big[jm] = (uint16_t)j;              /* medium members from the front of the work list */
+            else if (is_big) big[n - 1u - jb] = (uint16_t)j; /* large members from its back */
+            /* the first member of a huge bucket announces its parent */
+            if (m > PTX_HUGE_BUCKET && j == s) huge[ptx_atomic_add(&H->cur_huge, 1u)] = (uint16_t)p;
         }
         PTX_SYNC();
         {
-            /* large buckets: PTX_G lanes share one member and split its bucket */
-            const uint32_t nb = H->cur_big;
+            const uint32_t nm = H->cur_med, nb = H->cur_big, nh = H->cur_huge;
+            PTX_FOR(b, nm) {
+                const uint32_t x = seg[big[b]];
+                const uint32_t p = par[x];
+                const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
+                uint32_t c = 0;
+                for (uint32_t k = s; k < t; ++k) c += seg[k] > x ? 1u : 0u;
+                srt[s + c] = (uint16_t)x;
+            }
             PTX_FOR(w, nb * PTX_G) {
                 const uint32_t b = w / PTX_G, g = w % PTX_G;
-                const uint32_t x = seg[big[b]];
+                const uint32_t x = seg[big[n - 1u - b]];
                 const uint32_t p = par[x];
                 const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
                 uint32_t c = 0;
                 for (uint32_t k = s + g; k < t; k += PTX_G) c += seg[k] > x ? 1u : 0u;
                 c = ptx_group_sum(c);
                 if (g == 0) srt[s + c] = (uint16_t)x;
+            }
+            for (uint32_t h = 0; h < nh; ++h) { /* uniform: nh comes from LDS after the barrier */
+                const uint32_t p = huge[h];
+                const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
+                PTX_FOR(w, nwe + 1) {
+                    PtxBitWord z;
+                    z.bits = 0;
+                    z.pre = 0;
+                    hb[w] = z;
+                }
+                PTX_SYNC();
+                PTX_FOR(k, t - s) {
+                    const uint32_t x = seg[s + k];
+                    ptx_atomic_or(&hb[x >> 5].bits, 1u << (x & 31));
+                }
+                PTX_SYNC();
+                PTX_FOR(w, nwe + 1) hb[w].pre = ptx_popc(hb[w].bits);
+                PTX_SYNC();
+                ptx_scan_excl<uint32_t, 2>(&hb[0].pre, nwe + 1, H->scan_tmp);
+                PTX_FOR(k, t - s) {
+                    const uint32_t x = seg[s + k];
+                    srt[s + (t - s - 1u - ptx_bitrank(hb, x))] = (uint16_t)x; /* members with a larger index come first */
+                }
+                PTX_SYNC();
             }
         }
         PTX_SYNC();
@@ -1162,7 +1215,7 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                 e.lo = mrk_lo[k];
                 e.hi = mrk_hi[k];
                 e.t = mlist[k]; /* application index = row in the log */
-                e.add = ptx_bittest(addbits, k) ? 1 : 0;
+                e.add = action[mlist[k]] == PTX_ACT_ADDMARK ? 1 : 0; /* re-read: few marks still cover a visible char */
                 cent[pos] = e;
             }
         }
@@ -1254,7 +1307,7 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
                         if (ty == PTX_MARK_COMMENT) at |= PTX_ATTR_COMMENT;
                         else {
                             const uint32_t k = w & kmask;
-                            if (ptx_bittest(addbits, k)) {
+                            if (action[mlist[k]] == PTX_ACT_ADDMARK) {
                                 if (ty == PTX_MARK_STRONG) at |= PTX_ATTR_STRONG;
                                 else if (ty == PTX_MARK_EM) at |= PTX_ATTR_EM;
                                 else at |= PTX_ATTR_LINK | (payload[mlist[k]] & PTX_ATTR_ID_MASK);
@@ -1306,5 +1359,13 @@ PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     }
     PTX_SYNC();
     PTX_STAMP(10);
-    ptx_write_result(A, log, H, PTX_OK, bp.high);
+    lds_high = bp.high;
+    return PTX_OK;
+}
+
+PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
+    uint32_t lds_high = 0;
+    const uint32_t status = ptx_merge_log_body(A, log, lds, lds_high);
+    PTX_SYNC();
+    ptx_write_result(A, log, (PtxHdr*)lds, status, lds_high);
 }

@@ -38,7 +38,7 @@
 PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1)    /* <= 128 VGPRs: any launch shape */
 PTX_MERGE_KERNEL(ptx_merge_kernel_w5, 256, 5)  /* <= 96 VGPRs: 5 workgroups of 256 per CU */
 PTX_MERGE_KERNEL(ptx_merge_kernel_w6, 256, 6)  /* <= 80 VGPRs: 6 workgroups of 256 per CU */
-PTX_MERGE_KERNEL(ptx_merge_kernel_w8, 256, 8)  /* <= 64 VGPRs: 8 workgroups of 256 per CU */
+PTX_MERGE_KERNEL(ptx_merge_kernel_w8, 512, 8)  /* <= 64 VGPRs: 8 waves per SIMD (8 x 256 or 4 x 512 threads per CU) */
 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
@@ -503,7 +503,7 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     /* register budget by launch shape: workgroups of <= 256 threads run the <= 80-VGPR build so that six of
      * them fit a CU when their LDS does (PTX_VARIANT overrides, for tuning) */
     int variant = ctx->variant >= 0 ? ctx->variant : (b->threads <= 256 ? 6 : 0);
-    if (b->threads > 256) variant = 0;
+    if (b->threads > 512 || (b->threads > 256 && variant != 8)) variant = 0;
     if (variant == 8)
         hipLaunchKernelGGL(ptx_merge_kernel_w8, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
     else if (variant == 6)

@@ -171,3 +171,27 @@ def test_log_header_census_paths():
     assert int(res.logs["status"][0]) in (abi.ERR_BAD_OP, 0)  # a palindromic census stays valid
     if (hdr["n_mark"][0] != hdr["n_mark"][0][::-1]).any():
         assert int(res.logs["status"][0]) == abi.ERR_BAD_OP
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_huge_sibling_bucket_prepends(reverse):
+    """70 inserts at index 0 (all children of HEAD: the bitmap-ranked bucket path) interleaved with children of
+    other elements, deletes and a mark — against a live oracle run."""
+    ops = []
+    for k in range(70):
+        ops.append({"action": "set", "insert": True, "elemId": "_head", "value": "abcdefghij"[k % 10]})
+        if k % 7 == 0:
+            ops.append({"action": "set", "insert": True, "elemId": "3@a", "value": "X"})  # siblings under 'B': a medium bucket
+        if k % 9 == 0:
+            ops.append({"action": "set", "insert": True, "elemId": "5@a", "value": "y"})
+    for k in range(11):
+        ops.append({"action": "set", "insert": True, "elemId": "4@a", "value": "m"})  # 11 siblings: the PTX_G-lane path
+    ops.append({"action": "del", "elemId": "4@a"})
+    ops.append({"action": "addMark", "markType": "strong", "start": {"type": "before", "elemId": "2@a"}, "end": {"type": "endOfText"}})
+    log = _mini_doc(ops)
+    batch = wire.encode_docs([[log]])
+    res = H.emu_merge(batch, reverse=reverse)
+    exp = H.oracle_apply([[log]])[0][0]
+    H.check_log(batch, res, 0, exp)
+    assert len(exp["text"]) == 5 + 70 + 10 + 8 + 11 - 1

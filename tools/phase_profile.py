@@ -36,7 +36,7 @@ def main():
     copies = max(1, args.docs // args.unique)
     out = {"config": args.config, "logs": batch.n_logs * copies, "ops": batch.counted_ops() * copies, "shapes": []}
     for t, var in [(int(x), int(v)) for v in args.variants.split(",") for x in args.threads.split(",")]:
-        if var and t > 256:
+        if var and t > (512 if var == 8 else 256):
             continue
         os.environ["PTX_THREADS"] = str(t)
         os.environ["PTX_VARIANT"] = str(var)
