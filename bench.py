@@ -12,7 +12,7 @@ The batch is `--unique` PTXGEN documents (SURVEY.md §8d generator, produced her
 change() through oracle/cli.js) tiled to 8192 docs inside HBM at distinct addresses.
 
 One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes of one launch
-(32 B per op row + 32 B header per log read, 4 B per visible value + 8 B per span + 12 B per comment interval + 48 B result
+(32 B per op row + 32 B header per log + the Change envelope when causal admission is on, read; 4 B per visible value + 8 B per span + 12 B per comment interval + 48 B result
 row per log written) / the kernel's average launch duration measured with HIP events on the stream
 the kernel runs on.  `cpu_baseline` = the reference's own code (oracle/_ref, types erased) or, where
 that is absent, the oracle port, timed on this box's host cores on a bounded sample of the same logs.
@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     ap.add_argument("--cpu-procs", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-admission", action="store_true", help="skip applyChange's causal admission (seq/deps) in the timed path")
     args = ap.parse_args()
 
     import torch
@@ -146,7 +147,7 @@ def main():
     replicas = len(docs[0]["logs"])
     batch = wire.encode_docs([d["logs"] for d in docs])
     ops_unique = batch.counted_ops()
-    eng = Engine(local, flags=abi.FLAG_NO_ELEM_RANK)
+    eng = Engine(local, flags=abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0))
     t_up = time.time()
     db = eng.upload(batch, copies=copies)
     eng.sync()
@@ -212,7 +213,21 @@ def main():
 
         # algorithmic bytes of ONE launch on this rank (with this ABI's row sizes)
         rows = eng.n_ops(db)
-        alg_bytes = 32 * rows + 32 * n_logs + 4 * int(logs["n_visible"].sum()) + 8 * int(logs["n_spans"].sum()) + 12 * int(logs["n_cintervals"].sum()) + 48 * n_logs
+        n_changes = int(batch.chg_off[-1]) * copies
+        env_bytes = 0 if args.no_admission else n_changes * (12 + 4 * batch.max_actors)  # chg_actor, chg_seq, chg_nops, chg_deps row
+        # the same launch without the admission phase (PTX_FLAG_NO_ADMISSION), for reference: a second engine on the same batch
+        ms_noadm = None
+        if not args.no_admission:
+            eng2 = Engine(local, flags=abi.FLAG_NO_ELEM_RANK | abi.FLAG_NO_ADMISSION)
+            db2 = eng2.upload(batch, copies=copies)
+            dr2 = eng2.alloc_result(db2)
+            eng2.merge(db2, dr2)
+            eng2.sync()
+            ms_noadm = eng2.merge_timed(db2, dr2, max(2, args.steps // 2)) / max(2, args.steps // 2)
+            eng2.free_result(dr2)
+            eng2.free_batch(db2)
+            eng2.close()
+        alg_bytes = env_bytes + 32 * rows + 32 * n_logs + 4 * int(logs["n_visible"].sum()) + 8 * int(logs["n_spans"].sum()) + 12 * int(logs["n_cintervals"].sum()) + 48 * n_logs
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3)
         total_ops = ops_per_step * world * args.steps
@@ -237,6 +252,8 @@ def main():
                 "ops_per_gpu_per_step": ops_per_step,
                 "op_log_bytes_per_gpu": 32 * rows,
                 "parallelism": "doc-sharded x%d, digests-only all-gather" % world,
+                "causal_admission": not args.no_admission,
+                "changes_per_gpu_per_step": n_changes,
             },
             "docs_converged_per_s": converged_docs * args.steps / elapsed,
             "docs_converged": converged_docs,
@@ -252,7 +269,10 @@ def main():
                 "kernel": eng.kernel_name(),
                 "kernel_ms_avg": k_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "envelope_bytes_per_launch": env_bytes,
             },
+            "without_admission": None if ms_noadm is None else {"kernel_ms": ms_noadm, "ops_per_s_1gpu": ops_per_step / (ms_noadm * 1e-3),
+                                                                "hbm_GBps": (alg_bytes - env_bytes) / (ms_noadm * 1e-3) / 1e9},
             "host": {"cores": cores, "gen_s": t_gen, "upload_s": t_up, "upload_GBps": 32 * rows / copies / max(t_up, 1e-9) / 1e9},
         }
         if not args.no_cpu:

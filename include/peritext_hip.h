@@ -127,6 +127,9 @@ typedef struct ptx_batch {
     const uint8_t* side_a;     /* [n_ops] */
     const uint8_t* side_b;     /* [n_ops] */
     /* optional causal envelope (Change headers, micromerge.ts:60-71); NULL = skip causal admission.
+     * When present (host batches: ptx_batch_upload / ptx_apply_materialize) the kernel admits every change
+     * exactly like applyChange (micromerge.ts:499-511): seq == clock[actor] + 1 (PTX_ERR_SEQ_GAP) and
+     * clock[a] >= deps[a] for all a (PTX_ERR_MISSING_DEP), 24 + 4*max_actors extra bytes read per change.
      * chg_off[l]..chg_off[l+1]-1 are the changes of log l in application order. */
     const uint64_t* chg_off;   /* [n_logs + 1] or NULL */
     const uint32_t* chg_actor; /* [n_changes] actorRank */
@@ -182,6 +185,7 @@ typedef struct ptx_dresult ptx_dresult;  /* result buffers resident in HBM */
 
 /* ptx_create flags */
 #define PTX_FLAG_NO_ELEM_RANK 1u /* do not produce ptx_result.elem_rank (saves 4 B/op of HBM writes) */
+#define PTX_FLAG_NO_ADMISSION 2u /* ignore the Change envelope (chg_*) even when the batch carries it: no seq / deps checks */
 
 /* ---- lifecycle ---- */
 uint32_t ptx_abi_version(void);

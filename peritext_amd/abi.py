@@ -25,6 +25,7 @@ ATTR_COMMENT = 0x80000000
 ATTR_ID_MASK = 0x0FFFFFFF
 
 FLAG_NO_ELEM_RANK = 1
+FLAG_NO_ADMISSION = 2
 
 PTX_OK = 0
 ERR_ELEM_NOT_FOUND = 1

@@ -189,6 +189,14 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #ifndef PTX_P1_PREFETCH
 #define PTX_P1_PREFETCH 1 /* 1: double-buffer the row loads of P1 (costs PTX_U1 * 4 VGPRs) */
 #endif
+#define PTX_UA 2 /* changes per thread in flight in the admission passes */
+#ifdef PTX_EMU
+#define PTX_FORA(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_UA)
+#else
+#define PTX_FORA(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = blockDim.x; i0 < _n; i0 += PTX_UA * _T)
+#endif
+#define PTX_INA(i0, u) PTX_IN(i0, u)
+#define PTX_IXA(i0, u) PTX_IX(i0, u)
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
 
 /* uniform loop over groups of PTX_U consecutive items: every thread runs every step (g may be past the end) */
@@ -255,7 +263,8 @@ PTX_DEV void ptx_digest_item(uint64_t& h1, uint64_t& h2, uint32_t tag, uint32_t 
 
 /* ---- LDS header ---- */
 struct PtxHdr {
-    uint32_t err;          /* min over ((row*2+level) << 4 | code) of every detected error; ~0 = none */
+    uint32_t err;          /* min over ((row*2+level) << 4 | code) of every detected op-level error; ~0 = none */
+    uint32_t adm;          /* the same for the change-level (causal admission) errors of P0 */
     uint32_t max_ctr, max_actor;
     uint32_t cur_big, cur_med, cur_huge;
     uint32_t V, S, I;
@@ -451,6 +460,10 @@ PTX_HD uint32_t ptx_abits_of(uint32_t max_actor) {
     while ((1u << k) < max_actor + 1u && k < 31) ++k;
     return k;
 }
+/* P0 scratch on top of the header: per-actor table starts + the (actor, seq) -> change table */
+PTX_HD uint64_t ptx_lds_need_admission(uint64_t n_changes, uint64_t max_actors) {
+    return ptx_a16(sizeof(PtxHdr)) + ptx_a16(4 * (max_actors + 2)) + ptx_a16(2 * (n_changes + 1));
+}
 PTX_HD uint64_t ptx_lds_need_hdr(uint64_t N, const ptx_log_hdr& h) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
     const uint32_t abits = ptx_abits_of(h.max_actor);
@@ -571,7 +584,8 @@ PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
 #define PTX_BAIL_IF_ERROR()                                        \
     do {                                                           \
         PTX_SYNC();                                                \
-        const uint32_t _st = H->err;                               \
+        uint32_t _st = H->err;                                     \
+        if (_st != PTX_NO_ERR && H->adm < _st) _st = H->adm; /* an earlier change failed admission first */ \
         PTX_SYNC();                                                \
         if (_st != PTX_NO_ERR) {                                   \
             lds_high = bp.high;                                    \
@@ -609,6 +623,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PtxHdr* H = (PtxHdr*)lds;
     PTX_LEADER {
         H->err = PTX_NO_ERR;
+        H->adm = PTX_NO_ERR;
         H->max_ctr = H->max_actor = 0;
         H->cur_big = H->cur_med = H->cur_huge = 0;
         H->n_ins = H->n_applied = 0;
@@ -646,6 +661,134 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_SYNC();
         lds_high = bp.high;
         return PTX_OK;
+    }
+
+    /* ---- P0: causal admission (micromerge.ts:499-511), when the batch carries the Change envelope ----
+     * Sequential rule: change c of actor a is admitted iff seq == clock[a] + 1 and clock[b] >= deps[b] for all b,
+     * where clock[b] counts the changes of b applied before c.  Closed form over the whole log: per actor the seqs
+     * are exactly 1, 2, ... in log order, and every dependency (b, d) names a change of b that sits EARLIER in the
+     * log.  tbl[first[a] + seq - 1] = index of that change makes both tests one LDS read each. */
+    if (A.chg_off) {
+        const uint64_t c0 = A.chg_off[log];
+        const uint64_t C64 = A.chg_off[log + 1] - c0;
+        const uint32_t na = A.max_actors;
+        if (C64 > 65534u || na == 0u || na > 4096u) {
+            lds_high = bp.high;
+            return C64 > 65534u ? PTX_ERR_CAPACITY : PTX_ERR_BAD_OP;
+        }
+        const uint32_t C = (uint32_t)C64;
+        const uint32_t* c_actor = A.chg_actor + c0;
+        const uint32_t* c_seq = A.chg_seq + c0;
+        const uint32_t* c_nops = A.chg_nops + c0;
+        const uint32_t* c_deps = A.chg_deps + c0 * na;
+        uint32_t* first = ptx_alloc<uint32_t>(bp, na + 2); /* changes per actor -> first table slot of the actor */
+        uint16_t* tbl = ptx_alloc<uint16_t>(bp, C + 1);     /* (actor, seq) -> change index */
+        PTX_BAIL_CAPACITY();
+        PTX_FOR(a, na + 2) first[a] = 0;
+        PTX_FOR(c, C + 1) tbl[c] = 0xFFFFu;
+        PTX_LEADER { H->cur[7] = 0; }
+        PTX_SYNC();
+        /* first row of change c, only needed to place an error: the reference throws at the first failing change */
+#define PTX_CHANGE_ROW(c_, row_)                                  \
+    do {                                                          \
+        uint32_t r_ = 0;                                          \
+        for (uint32_t q_ = 0; q_ < (c_); ++q_) r_ += c_nops[q_];  \
+        (row_) = r_ < 65535u ? r_ : 65535u;                       \
+    } while (0)
+        {
+            /* pass 1: changes per actor, rows covered (loads batched: PTX_UA changes per thread in flight) */
+            uint32_t rows = 0;
+            PTX_FORA(c0_, C) {
+                uint32_t a[PTX_UA], no[PTX_UA];
+#pragma unroll
+                for (int u = 0; u < PTX_UA; ++u) {
+                    const uint32_t c = PTX_INA(c0_, u) ? PTX_IXA(c0_, u) : C - 1u;
+                    a[u] = c_actor[c];
+                    no[u] = c_nops[c];
+                }
+#pragma unroll
+                for (int u = 0; u < PTX_UA; ++u)
+                    if (PTX_INA(c0_, u)) {
+                        rows += no[u];
+                        if (a[u] >= na) {
+                            uint32_t row;
+                            PTX_CHANGE_ROW(PTX_IXA(c0_, u), row);
+                            ptx_atomic_min(&H->adm, ((row * 2u) << 4) | PTX_ERR_BAD_OP);
+                        } else ptx_atomic_add(&first[a[u]], 1u);
+                    }
+            }
+            ptx_atomic_add(&H->cur[7], rows);
+        }
+        PTX_SYNC();
+        if (H->adm != PTX_NO_ERR || H->cur[7] != N) { /* malformed envelope; the changes must tile the rows of the log exactly */
+            lds_high = bp.high;
+            return PTX_ERR_BAD_OP;
+        }
+        ptx_scan_excl<uint32_t, 1>(first, na + 2, H->scan_tmp); /* first[a] .. first[a+1]: table slots of actor a */
+        PTX_FORA(c0_, C) {
+            uint32_t a[PTX_UA], sq[PTX_UA];
+#pragma unroll
+            for (int u = 0; u < PTX_UA; ++u) {
+                const uint32_t c = PTX_INA(c0_, u) ? PTX_IXA(c0_, u) : C - 1u;
+                a[u] = c_actor[c];
+                sq[u] = c_seq[c];
+            }
+#pragma unroll
+            for (int u = 0; u < PTX_UA; ++u)
+                if (PTX_INA(c0_, u)) {
+                    const uint32_t f = first[a[u]], cnt_a = first[a[u] + 1] - f;
+                    if (sq[u] - 1u < cnt_a) tbl[f + sq[u] - 1u] = (uint16_t)PTX_IXA(c0_, u); /* a second claimant of the slot is caught below */
+                }
+        }
+        PTX_SYNC();
+        PTX_FORA(c0_, C) {
+            uint32_t a[PTX_UA], sq[PTX_UA], dp[PTX_UA][4];
+#pragma unroll
+            for (int u = 0; u < PTX_UA; ++u) {
+                const uint32_t c = PTX_INA(c0_, u) ? PTX_IXA(c0_, u) : C - 1u;
+                a[u] = c_actor[c];
+                sq[u] = c_seq[c];
+#pragma unroll
+                for (uint32_t b = 0; b < 4; ++b) dp[u][b] = c_deps[(uint64_t)c * na + (b < na ? b : 0u)]; /* the first four deps travel with the batch */
+            }
+#pragma unroll
+            for (int u = 0; u < PTX_UA; ++u)
+                if (PTX_INA(c0_, u)) {
+                    const uint32_t c = PTX_IXA(c0_, u);
+                    const uint32_t f = first[a[u]], cnt_a = first[a[u] + 1] - f;
+                    /* seq == clock[a] + 1  (micromerge.ts:501-504) */
+                    const bool bad_seq = !(sq[u] - 1u < cnt_a) || tbl[f + sq[u] - 1u] != c || (sq[u] > 1u && tbl[f + sq[u] - 2u] >= c);
+                    bool bad_dep = false;
+                    if (!bad_seq) {
+                        /* clock[b] >= deps[b] for every actor  (micromerge.ts:505-509) */
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t d = b < na ? dp[u][b] : 0u;
+                            if (d != 0u) {
+                                const uint32_t fb = first[b], cnt_b = first[b + 1] - fb;
+                                if (!(d <= cnt_b) || tbl[fb + d - 1u] >= c) bad_dep = true;
+                            }
+                        }
+                        for (uint32_t b = 4; b < na; ++b) {
+                            const uint32_t d = c_deps[(uint64_t)c * na + b];
+                            if (d != 0u) {
+                                const uint32_t fb = first[b], cnt_b = first[b + 1] - fb;
+                                if (!(d <= cnt_b) || tbl[fb + d - 1u] >= c) bad_dep = true;
+                            }
+                        }
+                    }
+                    if (bad_seq || bad_dep) {
+                        uint32_t row;
+                        PTX_CHANGE_ROW(c, row);
+                        ptx_atomic_min(&H->adm, ((row * 2u) << 4) | (bad_seq ? PTX_ERR_SEQ_GAP : PTX_ERR_MISSING_DEP));
+                    }
+                }
+        }
+#undef PTX_CHANGE_ROW
+        /* a failed admission stays pending in H->adm: an op-level error of an EARLIER row (found by the phases
+         * below, which still run) wins over it, exactly as in a sequential replay */
+        PTX_SYNC();
+        bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
     }
 
     /* ---- the log header (census) sizes everything; the row pass below verifies it ---- */
@@ -1185,6 +1328,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_MARK_LOAD
     }
     PTX_BAIL_IF_ERROR();
+    if (H->adm != PTX_NO_ERR) { /* no op-level error anywhere: the failed admission is the log's error */
+        lds_high = bp.high;
+        return H->adm & 15u;
+    }
     const uint32_t mark2_lds = bp.off;
     PTX_STAMP(7);
 

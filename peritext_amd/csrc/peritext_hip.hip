@@ -43,7 +43,7 @@ PTX_MERGE_KERNEL(ptx_merge_kernel_w8, 512, 8)  /* <= 64 VGPRs: 8 waves per SIMD 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
 __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off, const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type,
-                                                          ptx_log_hdr* hdr, uint32_t* shape, int compute) {
+                                                          ptx_log_hdr* hdr, uint32_t* shape, int compute, const uint64_t* chg_off, uint32_t max_actors) {
     __shared__ uint32_t sh[8];
     const uint32_t log = blockIdx.x;
     const uint64_t b0 = log_off[log], b1 = log_off[log + 1];
@@ -93,7 +93,8 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
     }
     if (threadIdx.x == 0) {
         const ptx_log_hdr h = hdr[log];
-        const uint64_t need = ptx_lds_need_hdr(b1 - b0, h);
+        uint64_t need = ptx_lds_need_hdr(b1 - b0, h);
+        if (chg_off) need = max(need, ptx_lds_need_admission(chg_off[log + 1] - chg_off[log], max_actors));
         atomicMax(&shape[0], (uint32_t)min(need, (uint64_t)0xFFFFFFFFu));
         atomicMax(&shape[1], (uint32_t)min(b1 - b0, (uint64_t)0xFFFFFFFFu));
     }
@@ -142,6 +143,11 @@ struct ptx_dbatch {
     uint32_t* payload = nullptr;
     uint8_t *action = nullptr, *mark_type = nullptr, *side_a = nullptr, *side_b = nullptr;
     ptx_log_hdr* log_hdr = nullptr; /* always owned: provided headers are copied, missing ones computed */
+    /* Change envelope for causal admission (owned copies; null when the batch came without it) */
+    uint64_t* chg_off = nullptr;
+    uint32_t *chg_actor = nullptr, *chg_seq = nullptr, *chg_nops = nullptr, *chg_deps = nullptr;
+    uint32_t max_actors = 0;
+    uint64_t n_changes = 0;
     /* launch shape derived from the largest log */
     uint32_t max_log_ops = 0;
     uint32_t lds_bytes = 0;
@@ -195,7 +201,7 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
         hipError_t e = hipMemsetAsync(shape, 0, 8, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(ptx_census_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->log_off, b->op_id, b->action, b->mark_type, b->log_hdr,
-                               shape, have_hdr ? 0 : 1);
+                               shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(h, shape, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -310,6 +316,11 @@ void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
         (void)hipFree(b->side_b);
     }
     (void)hipFree(b->log_hdr);
+    (void)hipFree(b->chg_off);
+    (void)hipFree(b->chg_actor);
+    (void)hipFree(b->chg_seq);
+    (void)hipFree(b->chg_nops);
+    (void)hipFree(b->chg_deps);
     delete b;
 }
 
@@ -356,6 +367,37 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
         PTX_TRY(hipMemcpyAsync(b->log_hdr, h->log_hdr, (size_t)h->n_logs * sizeof(ptx_log_hdr), hipMemcpyHostToDevice, ctx->stream));
         for (uint32_t k = 1; k < copies; ++k)
             PTX_TRY(hipMemcpyAsync(b->log_hdr + (size_t)k * h->n_logs, b->log_hdr, (size_t)h->n_logs * sizeof(ptx_log_hdr), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    const bool have_env = h->chg_off && h->chg_actor && h->chg_seq && h->chg_nops && h->chg_deps && h->max_actors && h->n_logs;
+    if (have_env) {
+        const uint64_t NC = h->chg_off[h->n_logs];
+        b->max_actors = h->max_actors;
+        b->n_changes = NC * copies;
+        PTX_TRY(dalloc(&b->chg_off, (uint64_t)b->n_logs + 1));
+        PTX_TRY(dalloc(&b->chg_actor, NC * copies));
+        PTX_TRY(dalloc(&b->chg_seq, NC * copies));
+        PTX_TRY(dalloc(&b->chg_nops, NC * copies));
+        PTX_TRY(dalloc(&b->chg_deps, NC * copies * h->max_actors));
+        for (uint32_t k = 0; k < copies && NC; ++k) {
+            const hipMemcpyKind kd = k ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+            PTX_TRY(hipMemcpyAsync(b->chg_actor + k * NC, k ? (const void*)b->chg_actor : (const void*)h->chg_actor, NC * 4, kd, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->chg_seq + k * NC, k ? (const void*)b->chg_seq : (const void*)h->chg_seq, NC * 4, kd, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->chg_nops + k * NC, k ? (const void*)b->chg_nops : (const void*)h->chg_nops, NC * 4, kd, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->chg_deps + k * NC * h->max_actors, k ? (const void*)b->chg_deps : (const void*)h->chg_deps, NC * 4 * h->max_actors, kd,
+                                   ctx->stream));
+        }
+        uint64_t* tmpc = nullptr;
+        PTX_TRY(dalloc(&tmpc, (uint64_t)h->n_logs + 1));
+        hipError_t ec = hipMemcpyAsync(tmpc, h->chg_off, ((uint64_t)h->n_logs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (ec == hipSuccess) {
+            const uint64_t total = (uint64_t)b->n_logs + 1;
+            hipLaunchKernelGGL(ptx_tile_offsets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, tmpc, b->chg_off, h->n_logs, copies, NC);
+            ec = hipGetLastError();
+        }
+        hipError_t ec2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmpc);
+        PTX_TRY(ec);
+        PTX_TRY(ec2);
     }
     if (M) {
         PTX_TRY(hipMemcpyAsync(b->op_id, h->op_id, M * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -486,9 +528,13 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.side_a = b->side_a;
     A.side_b = b->side_b;
     A.log_hdr = b->log_hdr;
-    A.chg_off = nullptr;
-    A.chg_actor = A.chg_seq = A.chg_nops = A.chg_deps = nullptr;
-    A.max_actors = 0;
+    const bool admit = b->chg_off && !(ctx->flags & PTX_FLAG_NO_ADMISSION);
+    A.chg_off = admit ? b->chg_off : nullptr;
+    A.chg_actor = b->chg_actor;
+    A.chg_seq = b->chg_seq;
+    A.chg_nops = b->chg_nops;
+    A.chg_deps = b->chg_deps;
+    A.max_actors = b->max_actors;
     A.clocks = ctx->clocks;
     A.stop_after = (uint32_t)ctx->stop_after;
     A.res = r->logs;

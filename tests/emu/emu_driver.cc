@@ -13,8 +13,21 @@
 int ptx_emu_reverse = 0;
 #include "../../peritext_amd/csrc/merge_core.h"
 
+static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
+                          uint32_t lds_bytes, int reverse, int admission);
+
 extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans,
                              ptx_cinterval* cints, uint32_t* rank, uint32_t lds_bytes, int reverse) {
+    return emu_merge_impl(b, res, values, spans, cints, rank, lds_bytes, reverse, 0);
+}
+/* the same with causal admission over the batch's Change envelope (chg_* columns) */
+extern "C" int ptx_emu_merge_admit(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans,
+                                   ptx_cinterval* cints, uint32_t* rank, uint32_t lds_bytes, int reverse) {
+    return emu_merge_impl(b, res, values, spans, cints, rank, lds_bytes, reverse, 1);
+}
+
+static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
+                          uint32_t lds_bytes, int reverse, int admission) {
     PtxMergeArgs A;
     A.log_off = b->log_off;
     A.op_id = b->op_id;
@@ -25,8 +38,11 @@ extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* 
     A.mark_type = b->mark_type;
     A.side_a = b->side_a;
     A.side_b = b->side_b;
-    A.chg_off = nullptr; /* causal admission is exercised through ptx_emu_merge_admit */
-    A.chg_actor = A.chg_seq = A.chg_nops = A.chg_deps = nullptr;
+    A.chg_off = admission ? b->chg_off : nullptr;
+    A.chg_actor = b->chg_actor;
+    A.chg_seq = b->chg_seq;
+    A.chg_nops = b->chg_nops;
+    A.chg_deps = b->chg_deps;
     A.max_actors = b->max_actors;
     A.clocks = nullptr;
     A.stop_after = 0;

@@ -84,12 +84,13 @@ def batch_struct(b):
 @functools.lru_cache(maxsize=None)
 def _emu(path):
     lib = C.CDLL(path)
-    lib.ptx_emu_merge.restype = C.c_int
-    lib.ptx_emu_merge.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    for fn in (lib.ptx_emu_merge, lib.ptx_emu_merge_admit):
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
     return lib
 
 
-def emu_merge(b, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB):
+def emu_merge(b, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB, admission=False):
     """Run the host emulation of the kernel logic (tests only) over a wire.Batch."""
     n = max(b.n_ops, 1)
     res = wire.Results(
@@ -100,7 +101,7 @@ def emu_merge(b, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB):
         elem_rank=np.zeros(n, dtype=np.uint32),
     )
     s = batch_struct(b)
-    rc = _emu(lib_path).ptx_emu_merge(
+    rc = (_emu(lib_path).ptx_emu_merge_admit if admission else _emu(lib_path).ptx_emu_merge)(
         C.byref(s), res.logs.ctypes.data, res.values.ctypes.data, res.spans.ctypes.data, res.cintervals.ctypes.data,
         res.elem_rank.ctypes.data, lds_bytes, reverse,
     )

@@ -142,6 +142,39 @@ def test_log_header_census_paths(eng):
     assert (c.logs[2:] == a.logs[2:]).all()
 
 
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_causal_admission_on_device(eng):
+    """applyChange's admission rule (seq contiguity + deps, micromerge.ts:499-511) runs in the kernel whenever the
+    batch carries the Change envelope: mutated logs fail with the reference's RangeError class (live oracle replay),
+    intact logs are untouched, and PTX_FLAG_NO_ADMISSION switches the check off."""
+    import copy
+
+    from peritext_amd.engine import Engine
+    from test_emu_parity import _expected_status
+
+    gen = _load("ptxgen_mini.json")
+    base = gen["docs"][0]["logs"][1]
+    drop = copy.deepcopy(base)
+    del drop[3]
+    skip = copy.deepcopy(base)
+    skip[5]["seq"] += 1
+    dep = copy.deepcopy(base)
+    other = [a for a in {c["actor"] for c in dep} if a != dep[2]["actor"]][0]
+    dep[2]["deps"][other] = 10 ** 6
+    logs = [drop, skip, dep, base]
+    exp = H.oracle_apply([[l] for l in logs])
+    want = [_expected_status(e[0]) for e in exp]
+    assert want == [abi.ERR_SEQ_GAP, abi.ERR_SEQ_GAP, abi.ERR_MISSING_DEP, 0]
+    batch = wire.encode_docs([[l] for l in logs])
+    res = eng.apply_materialize(batch)
+    assert [int(x) for x in res.logs["status"]] == want
+    H.check_log(batch, res, 3, exp[3][0])
+    with Engine(0, flags=abi.FLAG_NO_ADMISSION) as e2:
+        res2 = e2.apply_materialize(batch)
+        assert int(res2.logs["status"][1]) == 0 and int(res2.logs["status"][2]) == 0  # envelope ignored: the ops themselves are fine
+        assert (res2.logs[3] == res.logs[3])
+
+
 def test_error_statuses(eng):
     from test_emu_parity import _mini_doc
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--variants", default="0", help="PTX_VARIANT values to sweep (0 = 128-VGPR kernel, 6, 8)")
     ap.add_argument("--no-phases", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--flags", type=int, default=abi.FLAG_NO_ELEM_RANK, help="ptx_create flags (1 no elem_rank, 2 no admission)")
     args = ap.parse_args()
     if args.lib and not os.path.isabs(args.lib):
         args.lib = os.path.join(ROOT, args.lib)
@@ -40,7 +41,7 @@ def main():
             continue
         os.environ["PTX_THREADS"] = str(t)
         os.environ["PTX_VARIANT"] = str(var)
-        eng = Engine(0, flags=abi.FLAG_NO_ELEM_RANK, lib_path=args.lib)
+        eng = Engine(0, flags=args.flags, lib_path=args.lib)
         db = eng.upload(batch, copies=copies)
         dr = eng.alloc_result(db)
         eng.merge(db, dr)
