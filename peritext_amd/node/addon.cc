@@ -200,6 +200,27 @@ napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
         if (m != (size_t)pb.n_logs * 8) return throw_msg(env, "batch.logHdr: Uint32Array with 8 entries per log expected");
         pb.log_hdr = (const ptx_log_hdr*)p;
     }
+    /* optional: the Change envelope -> causal admission on the device (all five columns + maxActors, or none) */
+    {
+        size_t n_co = 0, n_a = 0, n_s = 0, n_n = 0, n_d = 0;
+        const void *co = nullptr, *ca = nullptr, *cs = nullptr, *cn = nullptr, *cd = nullptr;
+        uint32_t max_actors = 0;
+        napi_value mv;
+        bool has = false;
+        if (napi_has_named_property(env, b, "maxActors", &has) == napi_ok && has && napi_get_named_property(env, b, "maxActors", &mv) == napi_ok)
+            napi_get_value_uint32(env, mv, &max_actors);
+        if (max_actors && column(env, b, "chgOff", 8, &co, &n_co, true) && co && column(env, b, "chgActor", 4, &ca, &n_a, true) &&
+            column(env, b, "chgSeq", 4, &cs, &n_s, true) && column(env, b, "chgNops", 4, &cn, &n_n, true) && column(env, b, "chgDeps", 4, &cd, &n_d, true)) {
+            const uint64_t nc = n_co == (size_t)pb.n_logs + 1 ? ((const uint64_t*)co)[pb.n_logs] : ~0ull;
+            if (nc != n_a || nc != n_s || nc != n_n || nc * max_actors != n_d) return throw_msg(env, "batch.chg*: inconsistent Change envelope columns");
+            pb.chg_off = (const uint64_t*)co;
+            pb.chg_actor = (const uint32_t*)ca;
+            pb.chg_seq = (const uint32_t*)cs;
+            pb.chg_nops = (const uint32_t*)cn;
+            pb.chg_deps = (const uint32_t*)cd;
+            pb.max_actors = max_actors;
+        }
+    }
     ptx_result res;
     const ptx_status st = L.apply_materialize(ctx, &pb, &res);
     if (st != PTX_OK) {

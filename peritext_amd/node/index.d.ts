@@ -34,6 +34,8 @@ export interface WireBatch {
     logOff: BigUint64Array; opId: BigUint64Array; refA: BigUint64Array; refB: BigUint64Array
     payload: Uint32Array; action: Uint8Array; markType: Uint8Array; sideA: Uint8Array; sideB: Uint8Array
     logHdr?: Uint32Array
+    /** Change envelope (micromerge.ts:60-71) -> applyChange's causal admission runs on the device */
+    chgOff?: BigUint64Array; chgActor?: Uint32Array; chgSeq?: Uint32Array; chgNops?: Uint32Array; chgDeps?: Uint32Array; maxActors?: number
     values: string[]; urls: string[]; logDoc: number[]; docActors: string[][]; docComments: string[][]
 }
 export interface WireResult { logs: Uint32Array; values: Uint32Array; spans: Uint32Array; cintervals: Uint32Array; elemRank?: Uint32Array }

@@ -49,6 +49,8 @@ function encodeDocs(docs) {
     const urls = [], urlIx = new Map()
     const rows = { opId: [], refA: [], refB: [], payload: [], action: [], markType: [], sideA: [], sideB: [] }
     const logOff = [0]
+    const chgOff = [0], chgActor = [], chgSeq = [], chgNops = [], chgDepsRows = []
+    let maxActors = 1
     const logDoc = [], docActors = [], docComments = []
     docs.forEach((logs, d) => {
         const actors = new Set(), comments = new Set()
@@ -69,6 +71,7 @@ function encodeDocs(docs) {
         const crank = new Map(commentList.map((c, i) => [c, i]))
         docActors.push(actorList)
         docComments.push(commentList)
+        maxActors = Math.max(maxActors, actorList.length)
         const encId = s => {
             if (s === undefined || s === null || s === HEAD || s === ROOT || typeof s === "symbol") return 0n
             const [ctr, actor] = splitOpId(s)
@@ -76,7 +79,12 @@ function encodeDocs(docs) {
         }
         for (const log of logs) {
             let textObj = null, nrows = 0
-            for (const ch of log)
+            for (const ch of log) {
+                /* the Change envelope (micromerge.ts:60-71): what applyChange's admission checks (:499-511) */
+                chgActor.push(arank.get(ch.actor))
+                chgSeq.push(ch.seq)
+                chgNops.push(ch.ops.length)
+                chgDepsRows.push(Object.keys(ch.deps || {}).map(a => [arank.get(a), ch.deps[a]]))
                 for (const op of ch.ops) {
                     const row = { opId: encId(op.opId), refA: 0n, refB: 0n, payload: 0, action: ACT.NOP, markType: 0, sideA: 0, sideB: 0 }
                     const onRoot = op.obj === undefined || op.obj === null || op.obj === ROOT || typeof op.obj === "symbol"
@@ -117,7 +125,9 @@ function encodeDocs(docs) {
                     for (const k of Object.keys(rows)) rows[k].push(row[k])
                     nrows++
                 }
+            }
             logOff.push(logOff[logOff.length - 1] + nrows)
+            chgOff.push(chgActor.length)
             logDoc.push(d)
         }
     })
@@ -134,8 +144,15 @@ function encodeDocs(docs) {
         markType: Uint8Array.from(rows.markType),
         sideA: Uint8Array.from(rows.sideA),
         sideB: Uint8Array.from(rows.sideB),
+        chgOff: BigUint64Array.from(chgOff.map(BigInt)),
+        chgActor: Uint32Array.from(chgActor),
+        chgSeq: Uint32Array.from(chgSeq),
+        chgNops: Uint32Array.from(chgNops),
+        chgDeps: new Uint32Array(chgActor.length * maxActors),
+        maxActors,
         values, urls, logDoc, docActors, docComments,
     }
+    chgDepsRows.forEach((row, i) => row.forEach(([a, v]) => { batch.chgDeps[i * maxActors + a] = v }))
     batch.logHdr = census(batch)
     return batch
 }

@@ -20,7 +20,8 @@ if (cmd === "encode") {
     const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
     const b = host.encodeDocs(gen.docs.map(d => d.logs))
     const out = { nLogs: b.nLogs, nOps: b.nOps, values: b.values, urls: b.urls, docComments: b.docComments }
-    for (const k of ["logOff", "opId", "refA", "refB", "payload", "action", "markType", "sideA", "sideB", "logHdr"]) out[k] = sha(b[k])
+    for (const k of ["logOff", "opId", "refA", "refB", "payload", "action", "markType", "sideA", "sideB", "logHdr", "chgOff", "chgActor", "chgSeq", "chgNops", "chgDeps"]) out[k] = sha(b[k])
+    out.maxActors = b.maxActors
     console.log(JSON.stringify(out))
 } else if (cmd === "load") {
     const addon = require(path.join(__dirname, "..", "peritext_amd", "node", "peritext_node.node"))
@@ -50,6 +51,13 @@ if (cmd === "encode") {
         { opId: "1@a", action: "makeList", obj: "_root", key: "text" },
         { opId: "2@a", action: "set", obj: "1@a", elemId: "9@zz", insert: true, value: "x" }] }]]]
     assert.throws(() => engine.applyChanges(bad), e => e instanceof RangeError && /List element not found/.test(e.message))
+    /* causal admission: a dropped change -> RangeError "Expected sequence number" (micromerge.ts:503) */
+    {
+        const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+        const log = gen.docs[0].logs[1].slice()
+        log.splice(3, 1)
+        assert.throws(() => engine.applyChanges([[log]]), e => e instanceof RangeError && /Expected sequence number|Missing dependency/.test(e.message))
+    }
     engine.close()
     console.log(JSON.stringify({ ok: true, logs }))
 } else {

@@ -49,7 +49,9 @@ def test_js_encoder_matches_python_encoder(name):
     assert js["nLogs"] == b.n_logs and js["nOps"] == b.n_ops
     assert js["values"] == b.values and js["urls"] == b.urls and js["docComments"] == b.doc_comments
     cols = {"logOff": b.log_off, "opId": b.op_id, "refA": b.ref_a, "refB": b.ref_b, "payload": b.payload, "action": b.action,
-            "markType": b.mark_type, "sideA": b.side_a, "sideB": b.side_b, "logHdr": b.log_hdr}
+            "markType": b.mark_type, "sideA": b.side_a, "sideB": b.side_b, "logHdr": b.log_hdr,
+            "chgOff": b.chg_off, "chgActor": b.chg_actor, "chgSeq": b.chg_seq, "chgNops": b.chg_nops, "chgDeps": b.chg_deps}
+    assert js["maxActors"] == b.max_actors
     for k, a in cols.items():
         assert js[k] == sha(a), k
 
