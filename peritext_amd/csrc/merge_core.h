@@ -189,6 +189,28 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #ifndef PTX_P1_PREFETCH
 #define PTX_P1_PREFETCH 1 /* 1: double-buffer the row loads of P1 (costs PTX_U1 * 4 VGPRs) */
 #endif
+/* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
+ * emulation plays three one-lane waves in turn */
+#ifdef PTX_EMU
+#define PTX_WS 1u
+#define PTX_NWAVES 3u
+#define PTX_FOR_WAVE(w, lane) for (uint32_t w = 0, lane = 0; w < PTX_NWAVES; ++w)
+PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v) { return v; }
+PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return incl; }
+PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return v; }
+#else
+#define PTX_WS 64u
+#define PTX_NWAVES (blockDim.x >> 6)
+#define PTX_FOR_WAVE(w, lane) for (uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, _once = 1; _once; _once = 0)
+PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
+PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl_scan(v)); }
+#endif
+#ifdef PTX_EMU
+#define PTX_NTHREADS 5u /* the emulation splits per-thread runs five ways so that the run/prefix logic is exercised */
+#else
+#define PTX_NTHREADS blockDim.x
+#endif
+#define PTX_MAX_THREADS 1024u
 #define PTX_UA 2 /* changes per thread in flight in the admission passes */
 #ifdef PTX_EMU
 #define PTX_FORA(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_UA)
@@ -462,6 +484,7 @@ PTX_HD uint32_t ptx_abits_of(uint32_t max_actor) {
 }
 /* P0 scratch on top of the header: per-actor table starts + the (actor, seq) -> change table */
 PTX_HD uint64_t ptx_lds_need_admission(uint64_t n_changes, uint64_t max_actors) {
+    if (max_actors <= 4) return ptx_a16(sizeof(PtxHdr)) + 2 * ptx_a16(4 * (1024 / 64 + 2)); /* the carried vector clock: per-wave totals */
     return ptx_a16(sizeof(PtxHdr)) + ptx_a16(4 * (max_actors + 2)) + ptx_a16(2 * (n_changes + 1));
 }
 PTX_HD uint64_t ptx_lds_need_hdr(uint64_t N, const ptx_log_hdr& h) {
@@ -681,13 +704,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         const uint32_t* c_seq = A.chg_seq + c0;
         const uint32_t* c_nops = A.chg_nops + c0;
         const uint32_t* c_deps = A.chg_deps + c0 * na;
-        uint32_t* first = ptx_alloc<uint32_t>(bp, na + 2); /* changes per actor -> first table slot of the actor */
-        uint16_t* tbl = ptx_alloc<uint16_t>(bp, C + 1);     /* (actor, seq) -> change index */
-        PTX_BAIL_CAPACITY();
-        PTX_FOR(a, na + 2) first[a] = 0;
-        PTX_FOR(c, C + 1) tbl[c] = 0xFFFFu;
-        PTX_LEADER { H->cur[7] = 0; }
-        PTX_SYNC();
         /* first row of change c, only needed to place an error: the reference throws at the first failing change */
 #define PTX_CHANGE_ROW(c_, row_)                                  \
     do {                                                          \
@@ -695,6 +711,104 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         for (uint32_t q_ = 0; q_ < (c_); ++q_) r_ += c_nops[q_];  \
         (row_) = r_ < 65535u ? r_ : 65535u;                       \
     } while (0)
+        if (na <= 4u) {
+            /* Up to four actors (the usual case): the vector clock itself is carried along the log.  Every WAVE owns
+             * a contiguous segment of the changes and walks it 64 changes at a time (coalesced loads); inside a step
+             * the clock before each change is a DPP prefix sum of one-hot counts, 16 bits per actor (actors 0,1 in one
+             * word, 2,3 in the other: no carries, a log has < 65535 changes); the clock before a wave's segment is
+             * the sum of the earlier waves' totals.  seq == clock[actor] + 1 and deps[b] <= clock[b]
+             * (micromerge.ts:501-509) are then plain compares. */
+            uint32_t* wt01 = ptx_alloc<uint32_t>(bp, PTX_MAX_THREADS / 64 + 2);
+            uint32_t* wt23 = ptx_alloc<uint32_t>(bp, PTX_MAX_THREADS / 64 + 2);
+            PTX_BAIL_CAPACITY();
+            PTX_LEADER { H->cur[7] = 0; }
+            PTX_SYNC();
+            const uint32_t nwv_ = PTX_NWAVES;
+            const uint32_t seg = ((C + nwv_ - 1u) / nwv_ + PTX_WS - 1u) / PTX_WS * PTX_WS; /* changes per wave, whole steps */
+            PTX_FOR_WAVE(w, lane) {
+                const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
+                uint32_t t01 = 0, t23 = 0, rows = 0, badc = 0xFFFFFFFFu;
+                for (uint32_t cb = lo; cb < hi; cb += PTX_WS) {
+                    const uint32_t c = cb + lane;
+                    const bool in = c < hi;
+                    const uint32_t a = c_actor[in ? c : hi - 1u], no = c_nops[in ? c : hi - 1u];
+                    rows += in ? no : 0u;
+                    if (in && a >= na) badc = c < badc ? c : badc;
+                    t01 += in && a < 2u ? 1u << (16u * a) : 0u;
+                    t23 += in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
+                }
+                t01 = ptx_wave_total(t01);
+                t23 = ptx_wave_total(t23);
+                if (lane == 0u) {
+                    wt01[w] = t01;
+                    wt23[w] = t23;
+                }
+                ptx_atomic_add(&H->cur[7], rows);
+                if (badc != 0xFFFFFFFFu) {
+                    uint32_t row;
+                    PTX_CHANGE_ROW(badc, row);
+                    ptx_atomic_min(&H->adm, ((row * 2u) << 4) | PTX_ERR_BAD_OP);
+                }
+            }
+            PTX_SYNC();
+            if (H->adm != PTX_NO_ERR || H->cur[7] != N) { /* malformed envelope; the changes must tile the rows of the log exactly */
+                lds_high = bp.high;
+                return PTX_ERR_BAD_OP;
+            }
+            PTX_FOR_WAVE(w, lane) {
+                const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
+                uint32_t b01 = 0, b23 = 0; /* the clock before this wave's segment */
+                for (uint32_t q = 0; q < w; ++q) {
+                    b01 += wt01[q];
+                    b23 += wt23[q];
+                }
+                /* the six loads of the NEXT step are in flight while this step is checked */
+                uint32_t a = 0, sq = 0, d[4] = {0, 0, 0, 0}, a_n, sq_n, d_n[4];
+#define PTX_ADM_LOAD(cb_, a_, sq_, d_)                                                      \
+    {                                                                                       \
+        const uint32_t c_ = (cb_) + lane < hi ? (cb_) + lane : (hi ? hi - 1u : 0u);         \
+        a_ = c_actor[c_];                                                                   \
+        sq_ = c_seq[c_];                                                                    \
+        _Pragma("unroll") for (uint32_t b = 0; b < 4; ++b) d_[b] = c_deps[(uint64_t)c_ * na + (b < na ? b : 0u)]; \
+    }
+                if (lo < hi) PTX_ADM_LOAD(lo, a, sq, d)
+                for (uint32_t cb = lo; cb < hi; cb += PTX_WS) {
+                    const uint32_t c = cb + lane;
+                    const bool in = c < hi;
+                    PTX_ADM_LOAD(cb + PTX_WS, a_n, sq_n, d_n)
+                    const uint32_t o01 = in && a < 2u ? 1u << (16u * a) : 0u, o23 = in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
+                    const uint32_t i01 = ptx_wave_incl_scan(o01), i23 = ptx_wave_incl_scan(o23);
+                    const uint32_t w01 = b01 + i01 - o01, w23 = b23 + i23 - o23; /* the clock before change c */
+                    const uint32_t clk[4] = {w01 & 0xFFFFu, w01 >> 16, w23 & 0xFFFFu, w23 >> 16};
+                    const uint32_t mine = a == 0u ? clk[0] : a == 1u ? clk[1] : a == 2u ? clk[2] : clk[3];
+                    const bool bad_seq = sq != mine + 1u;
+                    bool bad_dep = false;
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) bad_dep = bad_dep || (b < na && d[b] > clk[b]);
+                    if (in && (bad_seq || bad_dep)) {
+                        uint32_t row;
+                        PTX_CHANGE_ROW(c, row);
+                        ptx_atomic_min(&H->adm, ((row * 2u) << 4) | (bad_seq ? PTX_ERR_SEQ_GAP : PTX_ERR_MISSING_DEP));
+                    }
+                    b01 += ptx_wave_last(i01);
+                    b23 += ptx_wave_last(i23);
+                    a = a_n;
+                    sq = sq_n;
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) d[b] = d_n[b];
+                }
+#undef PTX_ADM_LOAD
+            }
+            PTX_SYNC();
+            bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
+        } else {
+        uint32_t* first = ptx_alloc<uint32_t>(bp, na + 2); /* changes per actor -> first table slot of the actor */
+        uint16_t* tbl = ptx_alloc<uint16_t>(bp, C + 1);     /* (actor, seq) -> change index */
+        PTX_BAIL_CAPACITY();
+        PTX_FOR(a, na + 2) first[a] = 0;
+        PTX_FOR(c, C + 1) tbl[c] = 0xFFFFu;
+        PTX_LEADER { H->cur[7] = 0; }
+        PTX_SYNC();
         {
             /* pass 1: changes per actor, rows covered (loads batched: PTX_UA changes per thread in flight) */
             uint32_t rows = 0;
@@ -789,6 +903,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * below, which still run) wins over it, exactly as in a sequential replay */
         PTX_SYNC();
         bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
+        } /* na > 4 */
     }
 
     /* ---- the log header (census) sizes everything; the row pass below verifies it ---- */
