@@ -73,7 +73,7 @@ PTX_DEV uint32_t ptx_group_sum(uint32_t c) { return c; }
 #define PTX_HD __host__ __device__ static inline
 #define PTX_DEV __device__ __forceinline__
 #define PTX_SYNC() __syncthreads()
-#define PTX_FOR(i, n) for (uint32_t i = threadIdx.x, _n = (n); i < _n; i += blockDim.x)
+#define PTX_FOR(i, n) _Pragma("nounroll") for (uint32_t i = threadIdx.x, _n = (n); i < _n; i += blockDim.x)
 #define PTX_LEADER if (threadIdx.x == 0)
 PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
@@ -192,6 +192,7 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 /* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
  * emulation plays three one-lane waves in turn */
 #ifdef PTX_EMU
+#define PTX_WAVE_FIRST(g) (g)
 #define PTX_WS 1u
 #define PTX_NWAVES 3u
 #define PTX_FOR_WAVE(w, lane) for (uint32_t w = 0, lane = 0; w < PTX_NWAVES; ++w)
@@ -199,6 +200,7 @@ PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v) { return v; }
 PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return incl; }
 PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return v; }
 #else
+#define PTX_WAVE_FIRST(g) ((g) - (threadIdx.x & 63u)) /* index handled by lane 0 of this wave */
 #define PTX_WS 64u
 #define PTX_NWAVES (blockDim.x >> 6)
 #define PTX_FOR_WAVE(w, lane) for (uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, _once = 1; _once; _once = 0)
@@ -211,7 +213,7 @@ PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl
 #define PTX_NTHREADS blockDim.x
 #endif
 #define PTX_MAX_THREADS 1024u
-#define PTX_UA 2 /* changes per thread in flight in the admission passes */
+#define PTX_UA 1 /* changes per thread in flight in the (rare) many-actor admission passes */
 #ifdef PTX_EMU
 #define PTX_FORA(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_UA)
 #else
@@ -640,6 +642,7 @@ PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
 /* ================================================================================================ */
 /* Applies log `log`; returns its status (PTX_OK or a per-log PTX_ERR_*) and the LDS high-water mark.  The caller
  * writes the result row (ptx_write_result) — ONE copy of that code instead of one per early exit. */
+template <bool kManyActors>
 PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t* lds, uint32_t& lds_high) {
     const uint64_t base = A.log_off[log];
     const uint64_t N64 = A.log_off[log + 1] - base;
@@ -801,7 +804,14 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
             PTX_SYNC();
             bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
+        } else if constexpr (!kManyActors) {
+            /* this build of the kernel carries only the <= 4-actor admission; the host launches the other one */
+            lds_high = bp.high;
+            return PTX_ERR_CAPACITY;
         } else {
+        /* More than four actors (rare): tbl[first[a] + seq - 1] = index of the change (a, seq) makes "the seqs of an
+         * actor are 1, 2, ... in log order" and "dependency (b, d) sits earlier in the log" one LDS read each.  Kept
+         * deliberately plain (one change per thread and step, serial prefix by the leader). */
         uint32_t* first = ptx_alloc<uint32_t>(bp, na + 2); /* changes per actor -> first table slot of the actor */
         uint16_t* tbl = ptx_alloc<uint16_t>(bp, C + 1);     /* (actor, seq) -> change index */
         PTX_BAIL_CAPACITY();
@@ -809,94 +819,54 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_FOR(c, C + 1) tbl[c] = 0xFFFFu;
         PTX_LEADER { H->cur[7] = 0; }
         PTX_SYNC();
-        {
-            /* pass 1: changes per actor, rows covered (loads batched: PTX_UA changes per thread in flight) */
-            uint32_t rows = 0;
-            PTX_FORA(c0_, C) {
-                uint32_t a[PTX_UA], no[PTX_UA];
-#pragma unroll
-                for (int u = 0; u < PTX_UA; ++u) {
-                    const uint32_t c = PTX_INA(c0_, u) ? PTX_IXA(c0_, u) : C - 1u;
-                    a[u] = c_actor[c];
-                    no[u] = c_nops[c];
-                }
-#pragma unroll
-                for (int u = 0; u < PTX_UA; ++u)
-                    if (PTX_INA(c0_, u)) {
-                        rows += no[u];
-                        if (a[u] >= na) {
-                            uint32_t row;
-                            PTX_CHANGE_ROW(PTX_IXA(c0_, u), row);
-                            ptx_atomic_min(&H->adm, ((row * 2u) << 4) | PTX_ERR_BAD_OP);
-                        } else ptx_atomic_add(&first[a[u]], 1u);
-                    }
-            }
-            ptx_atomic_add(&H->cur[7], rows);
+        PTX_FOR(c, C) {
+            const uint32_t a = c_actor[c];
+            ptx_atomic_add(&H->cur[7], c_nops[c]);
+            if (a >= na) {
+                uint32_t row;
+                PTX_CHANGE_ROW(c, row);
+                ptx_atomic_min(&H->adm, ((row * 2u) << 4) | PTX_ERR_BAD_OP);
+            } else ptx_atomic_add(&first[a], 1u);
         }
         PTX_SYNC();
         if (H->adm != PTX_NO_ERR || H->cur[7] != N) { /* malformed envelope; the changes must tile the rows of the log exactly */
             lds_high = bp.high;
             return PTX_ERR_BAD_OP;
         }
-        ptx_scan_excl<uint32_t, 1>(first, na + 2, H->scan_tmp); /* first[a] .. first[a+1]: table slots of actor a */
-        PTX_FORA(c0_, C) {
-            uint32_t a[PTX_UA], sq[PTX_UA];
-#pragma unroll
-            for (int u = 0; u < PTX_UA; ++u) {
-                const uint32_t c = PTX_INA(c0_, u) ? PTX_IXA(c0_, u) : C - 1u;
-                a[u] = c_actor[c];
-                sq[u] = c_seq[c];
+        PTX_LEADER {
+            uint32_t run = 0;
+            for (uint32_t a = 0; a < na + 2u; ++a) {
+                const uint32_t v = first[a];
+                first[a] = run;
+                run += v;
             }
-#pragma unroll
-            for (int u = 0; u < PTX_UA; ++u)
-                if (PTX_INA(c0_, u)) {
-                    const uint32_t f = first[a[u]], cnt_a = first[a[u] + 1] - f;
-                    if (sq[u] - 1u < cnt_a) tbl[f + sq[u] - 1u] = (uint16_t)PTX_IXA(c0_, u); /* a second claimant of the slot is caught below */
-                }
         }
         PTX_SYNC();
-        PTX_FORA(c0_, C) {
-            uint32_t a[PTX_UA], sq[PTX_UA], dp[PTX_UA][4];
-#pragma unroll
-            for (int u = 0; u < PTX_UA; ++u) {
-                const uint32_t c = PTX_INA(c0_, u) ? PTX_IXA(c0_, u) : C - 1u;
-                a[u] = c_actor[c];
-                sq[u] = c_seq[c];
-#pragma unroll
-                for (uint32_t b = 0; b < 4; ++b) dp[u][b] = c_deps[(uint64_t)c * na + (b < na ? b : 0u)]; /* the first four deps travel with the batch */
-            }
-#pragma unroll
-            for (int u = 0; u < PTX_UA; ++u)
-                if (PTX_INA(c0_, u)) {
-                    const uint32_t c = PTX_IXA(c0_, u);
-                    const uint32_t f = first[a[u]], cnt_a = first[a[u] + 1] - f;
-                    /* seq == clock[a] + 1  (micromerge.ts:501-504) */
-                    const bool bad_seq = !(sq[u] - 1u < cnt_a) || tbl[f + sq[u] - 1u] != c || (sq[u] > 1u && tbl[f + sq[u] - 2u] >= c);
-                    bool bad_dep = false;
-                    if (!bad_seq) {
-                        /* clock[b] >= deps[b] for every actor  (micromerge.ts:505-509) */
-#pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) {
-                            const uint32_t d = b < na ? dp[u][b] : 0u;
-                            if (d != 0u) {
-                                const uint32_t fb = first[b], cnt_b = first[b + 1] - fb;
-                                if (!(d <= cnt_b) || tbl[fb + d - 1u] >= c) bad_dep = true;
-                            }
-                        }
-                        for (uint32_t b = 4; b < na; ++b) {
-                            const uint32_t d = c_deps[(uint64_t)c * na + b];
-                            if (d != 0u) {
-                                const uint32_t fb = first[b], cnt_b = first[b + 1] - fb;
-                                if (!(d <= cnt_b) || tbl[fb + d - 1u] >= c) bad_dep = true;
-                            }
-                        }
-                    }
-                    if (bad_seq || bad_dep) {
-                        uint32_t row;
-                        PTX_CHANGE_ROW(c, row);
-                        ptx_atomic_min(&H->adm, ((row * 2u) << 4) | (bad_seq ? PTX_ERR_SEQ_GAP : PTX_ERR_MISSING_DEP));
-                    }
+        PTX_FOR(c, C) {
+            const uint32_t a = c_actor[c], sq = c_seq[c];
+            const uint32_t f = first[a], cnt_a = first[a + 1] - f;
+            if (sq - 1u < cnt_a) tbl[f + sq - 1u] = (uint16_t)c; /* a second claimant of the slot is caught below */
+        }
+        PTX_SYNC();
+        PTX_FOR(c, C) {
+            const uint32_t a = c_actor[c], sq = c_seq[c];
+            const uint32_t f = first[a], cnt_a = first[a + 1] - f;
+            /* seq == clock[a] + 1  (micromerge.ts:501-504) */
+            const bool bad_seq = !(sq - 1u < cnt_a) || tbl[f + sq - 1u] != c || (sq > 1u && tbl[f + sq - 2u] >= c);
+            bool bad_dep = false;
+            /* clock[b] >= deps[b] for every actor  (micromerge.ts:505-509) */
+            for (uint32_t b = 0; b < na && !bad_seq; ++b) {
+                const uint32_t d = c_deps[(uint64_t)c * na + b];
+                if (d != 0u) {
+                    const uint32_t fb = first[b], cnt_b = first[b + 1] - fb;
+                    if (!(d <= cnt_b) || tbl[fb + d - 1u] >= c) bad_dep = true;
                 }
+            }
+            if (bad_seq || bad_dep) {
+                uint32_t row;
+                PTX_CHANGE_ROW(c, row);
+                ptx_atomic_min(&H->adm, ((row * 2u) << 4) | (bad_seq ? PTX_ERR_SEQ_GAP : PTX_ERR_MISSING_DEP));
+            }
         }
 #undef PTX_CHANGE_ROW
         /* a failed admission stays pending in H->adm: an op-level error of an EARLIER row (found by the phases
@@ -1002,6 +972,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #endif
         for (uint32_t st = 0; st < p1_steps; ++st) {
             const uint32_t g = PTX_G_OF(st, p1_steps);
+            if (PTX_WAVE_FIRST(g) >= p1_groups) continue; /* this wave has no row left in this step (wave-uniform) */
 #if PTX_P1_PREFETCH
             const uint32_t gn = PTX_G_OF(st + 1u, p1_steps);
             PTX_P1_LOAD(gn, id_n, a_n, mt_n) /* next step's rows are in flight while this step is processed */
@@ -1028,8 +999,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 const uint32_t c = cls[u];
                 const uint32_t key = c == 7u ? 0u : ((uint32_t)(id[u] >> 32) << ix.abits) | (uint32_t)id[u];
                 const uint32_t bit = c == 7u ? 0u : 1u << (key & 31);
-                const uint32_t old = ptx_atomic_or(&allbits[key >> 5], bit);
-                badrow = (old & bit) != 0u && i < badrow ? i : badrow; /* same opId twice */
+                ptx_atomic_or(&allbits[key >> 5], bit); /* duplicates are counted after the pass (no return value needed here) */
                 ptx_atomic_or(&ix.ib[key >> 5].bits, c == 0u ? bit : 0u);
                 /* rows that are listed nowhere (and slots beyond what the header promised) go to the spare slot of mlist */
                 uint16_t* lst = c == 0u ? ilist : c == 1u ? dlist : mlist;
@@ -1053,9 +1023,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             /* which of the two: re-test the row */
             const uint64_t id = op_id[badrow];
             const uint32_t ctr = (uint32_t)(id >> 32), act = (uint32_t)id, a = action[badrow], mt = mark_type[badrow];
-            const bool malformed = ctr == 0 || ctr > ix.max_ctr || act > ix.max_actor || a > PTX_ACT_NOP ||
-                                   ((a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) && mt > 3);
-            ptx_raise(H, badrow, 1, malformed ? PTX_ERR_BAD_OP : PTX_ERR_DUPLICATE_OP);
+            (void)id; (void)ctr; (void)act; (void)a; (void)mt;
+            ptx_raise(H, badrow, 1, PTX_ERR_BAD_OP);
         }
         PTX_SYNC();
         PTX_LEADER {
@@ -1063,7 +1032,29 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             if (H->cur[0] != n || H->cur[1] != D || H->cur[2] != moff1 || H->cur[3] != moff2 || H->cur[4] != moff3 || H->cur[5] != K)
                 ptx_raise(H, 0, 0, PTX_ERR_BAD_OP);
         }
-        PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
+        {
+            uint32_t distinct = 0;
+            PTX_FOR(w, nw + 1) {
+                ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
+                distinct += ptx_popc(allbits[w]);
+            }
+            ptx_atomic_add(&H->cur[6], distinct); /* cur[6] (the cursor of unlisted rows) is free again */
+        }
+        PTX_SYNC();
+        if (H->err == PTX_NO_ERR && H->cur[6] != N) {
+            /* some opId occurs twice (every row had a well-formed id, so N distinct ids were expected): find the
+             * first repeated row with a second, returning pass over a cleared bitmap — the rare path */
+            PTX_SYNC();
+            PTX_FOR(w, nw + 1) allbits[w] = 0;
+            PTX_SYNC();
+            PTX_FOR(i, N) {
+                uint32_t key = 0;
+                ptx_id_key(ix, op_id[i], key);
+                const uint32_t bit = 1u << (key & 31);
+                if (ptx_atomic_or(&allbits[key >> 5], bit) & bit) ptx_raise(H, i, 1, PTX_ERR_DUPLICATE_OP);
+            }
+            /* (which of two equal ids is "the repeat" depends on the race; the status is what is reported) */
+        }
         PTX_SYNC();
         ptx_scan_excl<uint32_t, 2>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
     }
@@ -1625,9 +1616,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     return PTX_OK;
 }
 
+/* kManyActors: include the admission path for batches with more than four actors per document (it costs ~35
+ * VGPRs, i.e. two waves per SIMD, so it lives in its own build of the kernel) */
+template <bool kManyActors>
 PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     uint32_t lds_high = 0;
-    const uint32_t status = ptx_merge_log_body(A, log, lds, lds_high);
+    const uint32_t status = ptx_merge_log_body<kManyActors>(A, log, lds, lds_high);
     PTX_SYNC();
     ptx_write_result(A, log, (PtxHdr*)lds, status, lds_high);
 }

@@ -28,17 +28,18 @@
 /* One body, several register budgets: __launch_bounds__(T, W) = at most T threads per workgroup and at
  * least W waves per SIMD resident, i.e. the compiler must stay within 512/W VGPRs (MI355X_MICROARCH.md
  * "Register files").  The host picks the variant whose budget matches the launch shape. */
-#define PTX_MERGE_KERNEL(name, T, W)                                                   \
+#define PTX_MERGE_KERNEL(name, T, W, MANY)                                               \
     extern "C" __global__ void __launch_bounds__(T, W) name(PtxMergeArgs A) {          \
         extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];              \
         /* one workgroup per log (grid == n_logs): no grid-stride loop, so that nothing is hoisted \
            out of it and kept in registers for the whole kernel */                    \
-        if (blockIdx.x < A.n_logs) ptx_merge_log(A, blockIdx.x, ptx_lds);             \
+        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY>(A, blockIdx.x, ptx_lds);       \
     }
-PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1)    /* <= 128 VGPRs: any launch shape */
-PTX_MERGE_KERNEL(ptx_merge_kernel_w5, 256, 5)  /* <= 96 VGPRs: 5 workgroups of 256 per CU */
-PTX_MERGE_KERNEL(ptx_merge_kernel_w6, 256, 6)  /* <= 80 VGPRs: 6 workgroups of 256 per CU */
-PTX_MERGE_KERNEL(ptx_merge_kernel_w8, 512, 8)  /* <= 64 VGPRs: 8 waves per SIMD (8 x 256 or 4 x 512 threads per CU) */
+PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false)   /* any launch shape */
+PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true) /* + causal admission for documents with more than four actors */
+PTX_MERGE_KERNEL(ptx_merge_kernel_w5, 256, 5, false)  /* <= 96 VGPRs: 5 workgroups of 256 per CU */
+PTX_MERGE_KERNEL(ptx_merge_kernel_w6, 256, 6, false)  /* <= 80 VGPRs: 6 workgroups of 256 per CU */
+PTX_MERGE_KERNEL(ptx_merge_kernel_w8, 512, 8, false)  /* <= 64 VGPRs: 8 waves per SIMD (8 x 256 or 4 x 512 threads per CU) */
 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
@@ -266,6 +267,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     if (const char* sv = getenv("PTX_VARIANT")) ctx->variant = atoi(sv);
     if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     e = hipFuncSetAttribute((const void*)ptx_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -550,7 +552,9 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
      * them fit a CU when their LDS does (PTX_VARIANT overrides, for tuning) */
     int variant = ctx->variant >= 0 ? ctx->variant : (b->threads <= 256 ? 6 : 0);
     if (b->threads > 512 || (b->threads > 256 && variant != 8)) variant = 0;
-    if (variant == 8)
+    if (admit && b->max_actors > 4)
+        hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
+    else if (variant == 8)
         hipLaunchKernelGGL(ptx_merge_kernel_w8, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
     else if (variant == 6)
         hipLaunchKernelGGL(ptx_merge_kernel_w6, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);

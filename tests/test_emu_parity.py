@@ -266,3 +266,38 @@ def test_causal_admission_rejects_like_the_reference():
             if k == "dup_change" and g == abi.ERR_DUPLICATE_OP:
                 continue  # the engine's own structural check fires before the reference's seq check would
             assert g == w, (k, g, w, exp[kinds.index(k)][0].get("error") if k in kinds else None)
+
+
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_duplicate_op_id_is_reported(reverse):
+    """Two rows with one opId: the count of distinct ids falls short of the row count and the (rare-path) second
+    pass names it PTX_ERR_DUPLICATE_OP; the neighbouring log is untouched."""
+    dup = _mini_doc([{"action": "set", "insert": True, "elemId": "6@a", "value": "x"}, {"action": "del", "elemId": "3@a"}])
+    dup[1]["ops"][1]["opId"] = dup[1]["ops"][0]["opId"]
+    ok = _mini_doc([{"action": "set", "insert": True, "elemId": "6@a", "value": "x"}])
+    batch = wire.encode_docs([[dup], [ok]])
+    res = H.emu_merge(batch, reverse=reverse)
+    assert [int(x) for x in res.logs["status"]] == [abi.ERR_DUPLICATE_OP, 0]
+    assert wire.decode_spans(batch, res, 1) == [{"text": "ABCDEx", "marks": {}}]
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_many_actor_documents_admission_table_path():
+    """Six replicas per document (> 4 actors): the admission falls back from the carried vector clock to the
+    (actor, seq) -> change table; valid logs pass, a dropped change is a sequence gap."""
+    gen = H.oracle_gen("mini", 2, 3, None, 6)
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    assert batch.max_actors > 4
+    res = H.emu_merge(batch, admission=True)
+    log = 0
+    for d in gen["docs"]:
+        for exp in d["expected"]:
+            H.check_log(batch, res, log, exp)
+            log += 1
+    broken = [c for c in gen["docs"][0]["logs"][2]]
+    del broken[4]
+    exp = H.oracle_apply([[broken]])[0][0]
+    b2 = wire.encode_docs([[broken], gen["docs"][0]["logs"]])
+    r2 = H.emu_merge(b2, admission=True)
+    assert int(r2.logs["status"][0]) == _expected_status(exp) != 0
+    assert (r2.logs["status"][1:] == 0).all()

@@ -175,6 +175,19 @@ def test_causal_admission_on_device(eng):
         assert (res2.logs[3]["digest"] == res.logs[3]["digest"]).all() and int(res2.logs[3]["status"]) == 0
 
 
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_many_actor_documents(eng):
+    """> 4 actors per document: the library launches the kernel build that carries the table-based admission."""
+    gen = H.oracle_gen("mini", 2, 3, None, 6)
+    batch, res = H.check_generated(gen, eng.apply_materialize)
+    assert batch.max_actors > 4
+    broken = [c for c in gen["docs"][0]["logs"][2]]
+    del broken[4]
+    b2 = wire.encode_docs([[broken], gen["docs"][0]["logs"]])
+    r2 = eng.apply_materialize(b2)
+    assert int(r2.logs["status"][0]) in (abi.ERR_SEQ_GAP, abi.ERR_MISSING_DEP) and (r2.logs["status"][1:] == 0).all()
+
+
 def test_error_statuses(eng):
     from test_emu_parity import _mini_doc
 
