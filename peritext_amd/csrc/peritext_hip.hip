@@ -187,7 +187,9 @@ static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t ma
     uint64_t lds = std::min<uint64_t>(std::max<uint64_t>(need, 4096), ctx->max_lds);
     if (ctx->force_lds) lds = (uint64_t)ctx->force_lds;
     b->lds_bytes = (uint32_t)lds;
-    uint32_t t = max_log_ops <= 512 ? 128u : 256u;
+    /* threads per log, measured on MI355X (profiles/): fewer waves per log = fewer per-wave fixed costs, more logs per CU;
+     * 256-op logs peak at 64 threads, 1K at 128, 4K at 256, 8K at 512 */
+    uint32_t t = max_log_ops <= 512 ? 64u : max_log_ops <= 2048 ? 128u : max_log_ops <= 6144 ? 256u : 512u;
     if (ctx->force_threads) t = (uint32_t)ctx->force_threads;
     b->threads = t;
 }
@@ -550,7 +552,7 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     const uint32_t grid = b->n_logs;
     /* register budget by launch shape: workgroups of <= 256 threads run the <= 80-VGPR build so that six of
      * them fit a CU when their LDS does (PTX_VARIANT overrides, for tuning) */
-    int variant = ctx->variant >= 0 ? ctx->variant : (b->threads <= 256 ? 6 : 0);
+    int variant = ctx->variant >= 0 ? ctx->variant : (b->threads <= 256 ? 6 : b->threads <= 512 ? 8 : 0);
     if (b->threads > 512 || (b->threads > 256 && variant != 8)) variant = 0;
     if (admit && b->max_actors > 4)
         hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
