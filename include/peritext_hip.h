@@ -81,6 +81,10 @@ enum { PTX_SIDE_BEFORE = 0, PTX_SIDE_AFTER = 1, PTX_SIDE_START_OF_TEXT = 2, PTX_
 #define PTX_ATTR_COMMENT 0x80000000u /* key `comment` present (possibly []) */
 #define PTX_ATTR_ID_MASK 0x0fffffffu
 
+/* elem_rank: bit 31 marks a tombstone, the low 31 bits are the document position */
+#define PTX_RANK_TOMBSTONE 0x80000000u
+#define PTX_RANK_MASK 0x7fffffffu
+
 typedef int32_t ptx_status;
 enum {
     PTX_OK = 0,
@@ -174,8 +178,10 @@ typedef struct ptx_result {
     const ptx_span* spans;            /* [n_rows] */
     const ptx_cinterval* cintervals;  /* [n_rows] */
     const uint32_t* elem_rank;        /* [n_rows] per op row: document position (incl. tombstones) of the
-                                         element an INSERT row created, 0xffffffff for other rows
-                                         (what findListElement(...).index would return, micromerge.ts:731) */
+                                         element an INSERT row created (what findListElement(...).index
+                                         would return, micromerge.ts:731), | PTX_RANK_TOMBSTONE when the
+                                         element is deleted; 0xffffffff for other rows.  Enough to resolve
+                                         cursors (getCursor / resolveCursor, micromerge.ts:465-477) on the host */
     void* owner;
 } ptx_result;
 

@@ -92,11 +92,23 @@ if (cmd === "gen") {
     const Impl = implClass(impl)
     const input = JSON.parse(fs.readFileSync(flag("--in"), "utf8"))
     const out = { impl, docs: [] }
+    const wantCursors = argv.indexOf("--cursors") >= 0
     for (const d of input.docs) {
         const expected = []
         for (const log of d.logs) {
             try {
-                expected.push(expectedOf(applyLog(Impl, impl, log)))
+                const doc = applyLog(Impl, impl, log)
+                const e = expectedOf(doc)
+                if (wantCursors) {
+                    /* micromerge.ts:465-477: getCursor for every visible index, resolveCursor for every element ever inserted */
+                    e.cursorAt = e.text.map((_, i) => doc.getCursor(["text"], i).elemId)
+                    e.cursorResolve = {}
+                    const objectId = e.text.length ? doc.getCursor(["text"], 0).objectId : null
+                    for (const c of log)
+                        for (const op of c.ops)
+                            if (op.action === "set" && op.insert && objectId !== null) e.cursorResolve[op.opId] = doc.resolveCursor({ objectId, elemId: op.opId })
+                }
+                expected.push(e)
             } catch (e) {
                 expected.push({ spans: null, text: [], error: (e instanceof RangeError ? "RangeError: " : "Error: ") + e.message })
             }

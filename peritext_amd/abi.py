@@ -23,6 +23,8 @@ ATTR_EM = 0x20000000
 ATTR_LINK = 0x40000000
 ATTR_COMMENT = 0x80000000
 ATTR_ID_MASK = 0x0FFFFFFF
+RANK_TOMBSTONE = 0x80000000
+RANK_MASK = 0x7FFFFFFF
 
 FLAG_NO_ELEM_RANK = 1
 FLAG_NO_ADMISSION = 2

@@ -1359,7 +1359,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         A.out_values[base + q] = v[u];
                         ptx_digest_item(h1, h2, 1u, q, v[u], 0u);
                     }
-                    if (A.out_rank) A.out_rank[base + row[u]] = r[u];
+                    if (A.out_rank) A.out_rank[base + row[u]] = r[u] | (((w[u].bits >> (r[u] & 31)) & 1u) ? 0u : PTX_RANK_TOMBSTONE);
                 }
         }
         ptx_digest_flush(H, h1, h2);

@@ -284,3 +284,69 @@ def decode_spans(batch, res, log):
             marks["link"] = {"url": batch.urls[attr & abi.ATTR_ID_MASK]}
         out.append({"text": "".join(batch.values[int(x)] for x in v[start:end]), "marks": marks})
     return out
+
+
+def _elements(batch, res, log):
+    """(op_id, rank, deleted) of every list element of a log, from the elem_rank output column."""
+    b0, b1 = int(batch.log_off[log]), int(batch.log_off[log + 1])
+    rk = res.elem_rank[b0:b1]
+    ins = np.flatnonzero(batch.action[b0:b1] == abi.ACT_INSERT)
+    return batch.op_id[b0:b1][ins], (rk[ins] & abi.RANK_MASK).astype(np.int64), (rk[ins] & abi.RANK_TOMBSTONE) != 0
+
+
+def resolve_cursor(batch, res, log, elem_id):
+    """Micromerge.resolveCursor (reference/src/micromerge.ts:475-477): visible index of a cursor's element =
+    visible elements before it (the element itself may be a tombstone).  Raises like findListElement (:752)."""
+    d = batch.log_doc[log]
+    ctr, actor = split_op_id(elem_id)
+    if actor not in batch.doc_actors[d]:
+        raise ValueError("List element not found")
+    want = np.uint64(_pack(ctr, batch.doc_actors[d].index(actor)))
+    ids, rank, dead = _elements(batch, res, log)
+    hit = np.flatnonzero(ids == want)
+    if len(hit) == 0:
+        raise ValueError("List element not found")
+    r = rank[hit[0]]
+    return int(np.count_nonzero((rank < r) & ~dead))
+
+
+def get_cursor(batch, res, log, index):
+    """Micromerge.getCursor (reference/src/micromerge.ts:465-473): the elemId of the visible element at `index`."""
+    d = batch.log_doc[log]
+    ids, rank, dead = _elements(batch, res, log)
+    alive = np.flatnonzero(~dead)
+    order = alive[np.argsort(rank[alive])]
+    if not 0 <= index < len(order):
+        raise ValueError("List index out of bounds: %d" % index)
+    v = int(ids[order[index]])
+    return "%d@%s" % (v >> 32, batch.doc_actors[d][v & 0xFFFFFFFF])
+
+
+# ---- on-disk form of a batch (SURVEY.md §5 "checkpoint / resume": the reference only has JSON.stringify dumps of
+# Change objects, test/fuzz.ts:16-20; replaying a saved op log = re-running the merge) ----
+_COLUMNS = ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_actor", "chg_seq", "chg_nops", "chg_deps")
+
+
+def save_batch(path, batch):
+    """Write a Batch as one .npz: the SoA columns as they go to the device + the decode tables as JSON."""
+    import json
+
+    meta = {"format": "peritext-soa-oplog", "abi": abi.PTX_ABI_VERSION, "max_actors": batch.max_actors, "values": batch.values, "urls": batch.urls,
+            "log_doc": batch.log_doc, "doc_actors": batch.doc_actors, "doc_comments": batch.doc_comments}
+    arrays = {k: getattr(batch, k) for k in _COLUMNS}
+    if batch.log_hdr is not None:
+        arrays["log_hdr"] = batch.log_hdr
+    np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta).encode("utf-8"), dtype=np.uint8), **arrays)
+
+
+def load_batch(path):
+    import json
+
+    with np.load(path) as z:
+        meta = json.loads(bytes(z["meta"]).decode("utf-8"))
+        if meta.get("format") != "peritext-soa-oplog" or meta.get("abi") != abi.PTX_ABI_VERSION:
+            raise ValueError("not a peritext SoA op-log file of ABI %d" % abi.PTX_ABI_VERSION)
+        cols = {k: z[k] for k in _COLUMNS}
+        hdr = z["log_hdr"] if "log_hdr" in z.files else None
+    return Batch(log_hdr=hdr, max_actors=int(meta["max_actors"]), values=meta["values"], urls=meta["urls"], log_doc=meta["log_doc"],
+                 doc_actors=meta["doc_actors"], doc_comments=meta["doc_comments"], **cols)

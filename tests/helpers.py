@@ -44,13 +44,13 @@ def oracle_gen(config="mini", docs=4, seed=1, ops=None, replicas=None, first=0, 
             return json.load(f)
 
 
-def oracle_apply(docs_logs, impl="oracle"):
+def oracle_apply(docs_logs, impl="oracle", cursors=False):
     """Apply every log of every doc to a fresh oracle replica; returns [[{spans,text,error?}]]."""
     with tempfile.TemporaryDirectory() as td:
         inp, out = os.path.join(td, "in.json"), os.path.join(td, "out.json")
         with open(inp, "w") as f:
             json.dump({"docs": [{"logs": logs} for logs in docs_logs]}, f)
-        run_node(["oracle/cli.js", "apply", "--in", inp, "--impl", impl, "--out", out])
+        run_node(["oracle/cli.js", "apply", "--in", inp, "--impl", impl, "--out", out] + (["--cursors"] if cursors else []))
         with open(out) as f:
             return [d["expected"] for d in json.load(f)["docs"]]
 

@@ -301,3 +301,39 @@ def test_many_actor_documents_admission_table_path():
     r2 = H.emu_merge(b2, admission=True)
     assert int(r2.logs["status"][0]) == _expected_status(exp) != 0
     assert (r2.logs["status"][1:] == 0).all()
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_cursors_from_elem_rank():
+    """getCursor / resolveCursor (micromerge.ts:465-477) resolved on the host from the elem_rank column (document
+    position + tombstone flag) — every visible index and every element ever inserted, against the oracle."""
+    gen = _load("ptxgen_mini.json")
+    docs = [d["logs"] for d in gen["docs"][:3]]
+    exp = H.oracle_apply(docs, cursors=True)
+    batch = wire.encode_docs(docs)
+    res = H.emu_merge(batch)
+    log = 0
+    for d in exp:
+        for e in d:
+            assert [wire.get_cursor(batch, res, log, i) for i in range(len(e["text"]))] == e["cursorAt"]
+            for elem, idx in e["cursorResolve"].items():
+                assert wire.resolve_cursor(batch, res, log, elem) == idx, elem
+            with pytest.raises(ValueError):
+                wire.get_cursor(batch, res, log, len(e["text"]))
+            log += 1
+
+
+def test_batch_file_round_trip(tmp_path):
+    """The SoA op log is the checkpoint format: save, load, replay -> identical columns and identical digests."""
+    gen = _load("ptxgen_config3_512.json")
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    p = str(tmp_path / "oplog.npz")
+    wire.save_batch(p, batch)
+    back = wire.load_batch(p)
+    for k in ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_actor", "chg_seq", "chg_nops", "chg_deps", "log_hdr"):
+        a, b = getattr(batch, k), getattr(back, k)
+        assert a.dtype == b.dtype and (a == b).all(), k
+    assert (back.values, back.urls, back.doc_comments, back.max_actors) == (batch.values, batch.urls, batch.doc_comments, batch.max_actors)
+    r1, r2 = H.emu_merge(batch, admission=True), H.emu_merge(back, admission=True)
+    assert (r1.logs["digest"] == r2.logs["digest"]).all() and (r2.logs["status"] == 0).all()
+    assert wire.decode_spans(back, r2, 0) == wire.decode_spans(batch, r1, 0)

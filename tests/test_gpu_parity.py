@@ -111,7 +111,8 @@ def test_elem_rank_is_document_position(eng):
     for d in gen["docs"]:
         for exp in d["expected"]:
             b0, b1 = int(batch.log_off[log]), int(batch.log_off[log + 1])
-            rk = res.elem_rank[b0:b1]
+            rk = res.elem_rank[b0:b1].copy()
+            rk[rk != 0xFFFFFFFF] &= abi.RANK_MASK
             ins = np.flatnonzero(batch.action[b0:b1] == abi.ACT_INSERT)
             assert sorted(rk[ins].tolist()) == list(range(len(ins)))  # a permutation of 0..n-1
             assert (rk[np.setdiff1d(np.arange(b1 - b0), ins)] == 0xFFFFFFFF).all()
