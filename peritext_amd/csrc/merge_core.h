@@ -415,12 +415,12 @@ PTX_DEV bool ptx_bittest(const uint32_t* bits, uint32_t pos) { return (bits[pos 
 /* ---- elemId -> element index ---- */
 struct PtxElemIndex {
     PtxBitWord* ib; /* bitmap over the keys of the INSERT ops */
-    uint32_t abits, max_ctr, max_actor;
+    uint32_t na1, max_ctr, max_actor; /* key = counter * na1 + actor, na1 = max_actor + 1: a dense id keyspace */
 };
 PTX_DEV bool ptx_id_key(const PtxElemIndex& ix, uint64_t id, uint32_t& key) {
     const uint32_t ctr = (uint32_t)(id >> 32), actor = (uint32_t)id;
     if (ctr == 0 || ctr > ix.max_ctr || actor > ix.max_actor) return false;
-    key = (ctr << ix.abits) | actor;
+    key = ctr * ix.na1 + actor;
     return true;
 }
 /* dense index (rank in compareOpIds order among the inserts) of the list element with this id, or -1 */
@@ -449,6 +449,18 @@ PTX_DEV T* ptx_alloc(PtxBump& b, uint32_t count) {
     return p;
 }
 
+/* allocate from the recycled region `bd` while it has room, else from the top of the bump `bp` */
+template <class T>
+PTX_DEV T* ptx_alloc2(PtxBump& bd, PtxBump& bp, uint32_t count) {
+    const uint32_t bytes = (uint32_t)(((uint64_t)count * sizeof(T) + 15u) & ~15ull);
+    if ((uint64_t)bd.off + bytes <= bd.cap) {
+        T* p = (T*)(bd.base + bd.off);
+        bd.off += bytes;
+        return p;
+    }
+    return ptx_alloc<T>(bp, count);
+}
+
 PTX_DEV uint32_t ptx_ceil_log2(uint32_t x) { /* smallest k with (1<<k) >= x, x>=1 */
     uint32_t k = 0;
     while ((1u << k) < x) ++k;
@@ -459,31 +471,38 @@ PTX_DEV uint32_t ptx_ceil_log2(uint32_t x) { /* smallest k with (1<<k) >= x, x>=
  *      launch and by the tests to check the bound).  N rows, n inserts, D deletes, K mark ops of
  *      which Kc comment ops, id keyspace of ks bits. ---- */
 PTX_HD uint64_t ptx_a16(uint64_t x) { return (x + 15) & ~15ull; }
+/* bytes that do not fit the recycled region when arrays of the given sizes are placed first-fit in order */
+PTX_HD uint64_t ptx_overflow3(uint64_t free_bytes, uint64_t s0, uint64_t s1, uint64_t s2) {
+    uint64_t over = 0;
+    const uint64_t sz[3] = {ptx_a16(s0), ptx_a16(s1), ptx_a16(s2)};
+    for (int i = 0; i < 3; ++i) {
+        if (sz[i] <= free_bytes) free_bytes -= sz[i];
+        else over += sz[i];
+    }
+    return over;
+}
 PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
     (void)N;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
-    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (K + 1)) +
-                             2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1));
-    const uint64_t dr = (D + 2) / 2 > (2 * n) / PTX_S + 2 ? (D + 2) / 2 : (2 * n) / PTX_S + 2;
-    const uint64_t lists = ptx_a16(2 * (n + 1)) + ptx_a16(4 * dr);
-    const uint64_t p1a = lists + ptx_a16(4 * (nw + 1));
-    const uint64_t p3 = lists + ptx_a16(4 * (n + 2)) + ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2)) + ptx_a16(8 * (nwe + 2));
-    const uint64_t p1 = p1a > p3 ? p1a : p3;
-    const uint64_t comments = Kc ? 2 * ptx_a16(4 * (Kc + 1)) + ptx_a16(8 * (Kc + 1)) : 0;
+    const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P5a */
+    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(2 * (K + 1)) + elem;
+    const uint64_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
+    const uint64_t lists = ptx_a16(2 * (n + 1)) + ptx_a16(2 * l_len);
+    const uint64_t p1 = lists + ptx_a16(4 * (nw + 1));
+    const uint64_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
+    const uint64_t p3 = lists + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
+    const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kc + 1), 4 * (Kc + 1), 8 * (Kc + 1)) : 0;
     const uint64_t T4 = PTX_TILE_4, T1 = PTX_TILE_1;
-    const uint64_t trees4 = ptx_a16(4 * 4 * 2 * T4) + ptx_a16(4 * (T4 + 1)) + ptx_a16(8 * (T4 / 32 + 2));
-    const uint64_t trees1 = ptx_a16(4 * 2 * T1) + ptx_a16(4 * (T1 + 1)) + ptx_a16(8 * (T1 / 32 + 2));
-    uint64_t trees = n > T4 ? (trees1 > trees4 ? trees1 : trees4) : trees4; /* V <= n */
-    const uint64_t p5 = ptx_a16(8 * (nwe + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (nwe + 1)) +
-                        (comments > trees ? comments : trees);
-    return persist + (p1 > p5 ? p1 : p5);
+    const uint64_t trees4 = ptx_overflow3(elem, 4 * 4 * 2 * T4, 4 * (T4 + 1), 8 * (T4 / 32 + 2));
+    const uint64_t trees1 = n > T4 ? ptx_overflow3(elem, 4 * 2 * T1, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
+    uint64_t tail = comments > trees4 ? comments : trees4;
+    if (trees1 > tail) tail = trees1;
+    const uint64_t p5 = ptx_a16(8 * (nwe + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (nwe + 1)) + tail;
+    uint64_t m = p1 > p3 ? p1 : p3;
+    if (p5 > m) m = p5;
+    return persist + m;
 }
 /* the same from a log header */
-PTX_HD uint32_t ptx_abits_of(uint32_t max_actor) {
-    uint32_t k = 0;
-    while ((1u << k) < max_actor + 1u && k < 31) ++k;
-    return k;
-}
 /* P0 scratch on top of the header: per-actor table starts + the (actor, seq) -> change table */
 PTX_HD uint64_t ptx_lds_need_admission(uint64_t n_changes, uint64_t max_actors) {
     if (max_actors <= 4) return ptx_a16(sizeof(PtxHdr)) + 2 * ptx_a16(4 * (1024 / 64 + 2)); /* the carried vector clock: per-wave totals */
@@ -491,8 +510,7 @@ PTX_HD uint64_t ptx_lds_need_admission(uint64_t n_changes, uint64_t max_actors) 
 }
 PTX_HD uint64_t ptx_lds_need_hdr(uint64_t N, const ptx_log_hdr& h) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
-    const uint32_t abits = ptx_abits_of(h.max_actor);
-    const uint64_t ks = ((uint64_t)h.max_counter + 1) << (abits > 12 ? 12 : abits);
+    const uint64_t ks = ((uint64_t)h.max_counter + 1) * ((uint64_t)(h.max_actor > 4095u ? 4095u : h.max_actor) + 1);
     return ptx_lds_need(N, h.n_ins, h.n_del, K, h.n_mark[PTX_MARK_COMMENT], ks);
 }
 
@@ -892,34 +910,34 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PtxElemIndex ix;
     ix.max_ctr = hd.max_counter;
     ix.max_actor = hd.max_actor;
-    ix.abits = ptx_abits_of(ix.max_actor);
+    ix.na1 = ix.max_actor + 1u;
     const uint32_t kbits = ptx_ceil_log2(K + 1);
-    if (ix.abits > 12 || ix.max_ctr >= (1u << 19) || n > 32766u) { /* keyspace far below 2^31 bits; 2n+1 tour nodes in 16 bits */
+    if (ix.max_actor > 4095u || ix.max_ctr >= (1u << 19) || n > 32766u) { /* keyspace far below 2^31 bits; 2n+1 tour nodes in 16 bits */
         lds_high = bp.high;
         return PTX_ERR_CAPACITY;
     }
-    const uint32_t keyspace = (ix.max_ctr + 1u) << ix.abits;
+    const uint32_t keyspace = (ix.max_ctr + 1u) * ix.na1;
     if (((uint64_t)(keyspace + 1u) << kbits) > 0xFFFFFFFFull) { /* (key+1) << kbits | mark index in one u32 */
         lds_high = bp.high;
         return PTX_ERR_CAPACITY;
     }
     const uint32_t nw = (keyspace + 31) / 32;
     const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
-    ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
     uint16_t* mlist = ptx_alloc<uint16_t>(bp, K + 1); /* rows of the mark ops, grouped by type; [K] = spare slot */
+    /* element-side state: dead once the mark intervals are known (P5a), then reused as scratch of the tail phases */
+    const uint32_t elem_lds = bp.off;
+    ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
     uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1);         /* element -> op row */
     uint16_t* par = ptx_alloc<uint16_t>(bp, n + 1);            /* element -> parent element (n = HEAD); later: document position */
     uint32_t* delbits = ptx_alloc<uint32_t>(bp, nwe + 1);      /* element -> tombstone */
     PTX_BAIL_CAPACITY();
     const uint32_t mark_lds = bp.off; /* everything above this mark is phase scratch */
-    /* scratch of P1..P3: rows of the inserts and of the deletes, the tree arrays (allocated here so that
-     * the row pass can fill the lists; the causal-tree phase reuses ilist's storage for `srt`) */
+    /* scratch of P1..P3: rows of the inserts (later `srt`), then ONE array that is first the row list of the deletes
+     * (its tail), then the bucket work lists `seg` | `big`, then the Euler tour `L` */
     uint16_t* ilist = ptx_alloc<uint16_t>(bp, n + 1);
-    /* rows of the deletes; once they are applied (P3b) the same storage holds the splitters' list of the
-     * list ranking: next splitter << 16 | weight */
-    const uint32_t dr_words = ((D + 2) / 2 > (2 * n) / PTX_S + 2) ? (D + 2) / 2 : (2 * n) / PTX_S + 2;
-    uint32_t* R = ptx_alloc<uint32_t>(bp, dr_words);
-    uint16_t* dlist = (uint16_t*)R;
+    const uint32_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
+    uint16_t* L = ptx_alloc<uint16_t>(bp, l_len);
+    uint16_t* dlist = L + n + 1; /* read until P3b; `seg` = L[0 .. n] is written meanwhile, `big` (same place as dlist) only after */
     PTX_BAIL_CAPACITY();
     const uint32_t tree_lds = bp.off;
 
@@ -997,7 +1015,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             for (int u = 0; u < PTX_U1; ++u) {
                 const uint32_t i = g * PTX_U1 + (uint32_t)u;
                 const uint32_t c = cls[u];
-                const uint32_t key = c == 7u ? 0u : ((uint32_t)(id[u] >> 32) << ix.abits) | (uint32_t)id[u];
+                const uint32_t key = c == 7u ? 0u : (uint32_t)(id[u] >> 32) * ix.na1 + (uint32_t)id[u];
                 const uint32_t bit = c == 7u ? 0u : 1u << (key & 31);
                 ptx_atomic_or(&allbits[key >> 5], bit); /* duplicates are counted after the pass (no return value needed here) */
                 ptx_atomic_or(&ix.ib[key >> 5].bits, c == 0u ? bit : 0u);
@@ -1064,17 +1082,20 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
     /* ---- P3: causal tree of the inserts -> document position of every element ---- */
     {
-        uint32_t* cnt = ptx_alloc<uint32_t>(bp, n + 2);   /* children per parent -> bucket starts -> bucket ends */
-        uint16_t* L = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* Euler tour: next node */
-        PTX_BAIL_CAPACITY();
+        /* children per parent -> bucket starts -> bucket ends; 16-bit counters, two per atomically updated word */
+        uint32_t* cntw = ptx_alloc<uint32_t>(bp, (n + 2 + 1) / 2 + 1);
+        uint16_t* cnt = (uint16_t*)cntw;
+        /* the splitters' list of the list ranking (next splitter << 16 | weight); before that the bitmap of one huge bucket */
+        const uint32_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
+        uint32_t* R = ptx_alloc<uint32_t>(bp, r_words);
+        PtxBitWord* hb = (PtxBitWord*)R;
         uint16_t* huge = ptx_alloc<uint16_t>(bp, n / PTX_HUGE_BUCKET + 2); /* parents with more than PTX_HUGE_BUCKET children */
-        PtxBitWord* hb = ptx_alloc<PtxBitWord>(bp, nwe + 2);                 /* members of one such bucket, by element index */
         PTX_BAIL_CAPACITY();
         uint16_t* srt = ilist;       /* children of every parent, descending opId, parents ascending (ilist is dead after P3a) */
         uint16_t* seg = L;           /* bucket members in arrival order (dead before L is built) */
         uint16_t* big = seg + n + 1; /* positions in seg of the members of large buckets */
 
-        PTX_FOR(p, n + 2) cnt[p] = 0;
+        PTX_FOR(p, (n + 2 + 1) / 2 + 1) cntw[p] = 0;
         PTX_SYNC();
         /* P3a: element index of every insert, its parent, children counts */
         {
@@ -1109,7 +1130,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                             else pe = (uint32_t)p;
                         }
                         par[e] = (uint16_t)pe;
-                        ptx_atomic_add(&cnt[pe], 1u);
+                        ptx_atomic_add(&cntw[pe >> 1], 1u << (16u * (pe & 1u)));
                     }
 #pragma unroll
                 for (int u = 0; u < PTX_U; ++u) {
@@ -1121,7 +1142,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_P3A_LOAD
         }
         PTX_BAIL_IF_ERROR();
-        ptx_scan_excl<uint32_t, 1>(cnt, n + 2, H->scan_tmp); /* cnt[p] = first slot of p's children */
+        ptx_scan_excl<uint16_t, 1>(cnt, n + 2, H->scan_tmp); /* cnt[p] = first slot of p's children */
         /* P3b: scatter into the parent buckets; tombstone flags; application-order checks now that row_of is complete */
         PTX_FORU(e0, n) {
             uint32_t pe[PTX_U], re[PTX_U], rp[PTX_U];
@@ -1139,7 +1160,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 if (PTX_IN(e0, u)) {
                     /* the reference element must already exist when the op is applied (micromerge.ts:752) */
                     if (pe[u] < n && rp[u] >= re[u]) ptx_raise(H, re[u], 1, PTX_ERR_ELEM_NOT_FOUND);
-                    seg[ptx_atomic_add(&cnt[pe[u]], 1u)] = (uint16_t)PTX_IX(e0, u); /* now cnt[p] = END of p's bucket */
+                    /* now cnt[p] = END of p's bucket (no carry between the halves: a counter never exceeds n < 32767) */
+                    seg[(ptx_atomic_add(&cntw[pe[u] >> 1], 1u << (16u * (pe[u] & 1u))) >> (16u * (pe[u] & 1u))) & 0xFFFFu] = (uint16_t)PTX_IX(e0, u);
                 }
         }
         {
@@ -1439,14 +1461,22 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         return H->adm & 15u;
     }
     const uint32_t mark2_lds = bp.off;
+    /* the element-side arrays (id bitmap, row_of, positions, tombstones) are dead now: their storage is the first
+     * choice for the scratch of the tail phases */
+    PtxBump bd;
+    bd.base = lds;
+    bd.off = elem_lds;
+    bd.cap = mark_lds;
+    bd.high = 0;
+    bd.overflow = false;
     PTX_STAMP(7);
 
     /* ---- P5c: comments: per id, presence intervals decided by the last-applied covering op ---- */
     if (Kc > 0) {
-        uint32_t* ccnt = ptx_alloc<uint32_t>(bp, Kc + 1);
-        uint32_t* ccur = ptx_alloc<uint32_t>(bp, Kc + 1);
+        uint32_t* ccnt = ptx_alloc2<uint32_t>(bd, bp, Kc + 1);
+        uint32_t* ccur = ptx_alloc2<uint32_t>(bd, bp, Kc + 1);
         uint32_t* cicnt = ccur; /* intervals per id: reuses the scatter cursors once the entries are placed */
-        PtxCEntry* cent = ptx_alloc<PtxCEntry>(bp, Kc + 1);
+        PtxCEntry* cent = ptx_alloc2<PtxCEntry>(bd, bp, Kc + 1);
         PTX_BAIL_CAPACITY();
         PTX_FOR(c, Kc + 1) {
             ccnt[c] = 0;
@@ -1499,6 +1529,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_SYNC();
     }
     bp.off = mark2_lds; /* release the comment scratch */
+    bd.off = elem_lds;
     PTX_STAMP(8);
 
     /* ---- P5b + P6: LWW winners per visible char, spans, digest — in tiles of the visible axis ----
@@ -1513,9 +1544,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             TV = PTX_TILE_1;
         }
         const uint32_t ntree = four ? 4u : 1u;
-        uint32_t* tree = ptx_alloc<uint32_t>(bp, ntree * 2 * TV);
-        uint32_t* attr = ptx_alloc<uint32_t>(bp, TV + 1);
-        PtxBitWord* st = ptx_alloc<PtxBitWord>(bp, TV / 32 + 2);
+        uint32_t* tree = ptx_alloc2<uint32_t>(bd, bp, ntree * 2 * TV);
+        uint32_t* attr = ptx_alloc2<uint32_t>(bd, bp, TV + 1);
+        PtxBitWord* st = ptx_alloc2<PtxBitWord>(bd, bp, TV / 32 + 2);
         PTX_BAIL_CAPACITY();
         const uint32_t kmask = (1u << kbits) - 1u;
         uint64_t h1 = 0, h2 = 0;

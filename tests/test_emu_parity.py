@@ -135,7 +135,7 @@ def test_error_statuses_mirror_reference_throw_sites():
 def test_capacity_status_when_lds_too_small():
     gen = _load("ptxgen_config4_600.json")
     batch = wire.encode_docs([gen["docs"][0]["logs"]])
-    res = H.emu_merge(batch, lds_bytes=4096)
+    res = H.emu_merge(batch, lds_bytes=2048)
     assert (res.logs["status"] == abi.ERR_CAPACITY).all()
 
 
@@ -337,3 +337,23 @@ def test_batch_file_round_trip(tmp_path):
     r1, r2 = H.emu_merge(batch, admission=True), H.emu_merge(back, admission=True)
     assert (r1.logs["digest"] == r2.logs["digest"]).all() and (r2.logs["status"] == 0).all()
     assert wire.decode_spans(back, r2, 0) == wire.decode_spans(batch, r1, 0)
+
+
+@pytest.mark.parametrize("name", GOLDEN_GEN)
+def test_lds_bound_covers_the_high_water_mark(name):
+    """The host sizes the launch with ptx_lds_need (from the log headers); the kernel reports the LDS it really used
+    (ptx_log_result.reserved[0]).  The bound must cover it — and stay tight, it decides how many logs share a CU."""
+    import ctypes as C
+
+    lib = H._emu(H.EMU_LIB)
+    lib.ptx_emu_lds_need.restype = C.c_uint64
+    lib.ptx_emu_lds_need.argtypes = [C.c_uint64] * 6
+    gen = _load(name)
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    res = H.emu_merge(batch)
+    for log in range(batch.n_logs):
+        h = batch.log_hdr[log]
+        need = lib.ptx_emu_lds_need(int(batch.log_off[log + 1] - batch.log_off[log]), int(h["n_ins"]), int(h["n_del"]), int(h["n_mark"].sum()),
+                                    int(h["n_mark"][2]), (int(h["max_counter"]) + 1) * (int(h["max_actor"]) + 1))
+        used = int(res.logs["reserved"][log][0])
+        assert used <= need <= used + 6144, (log, used, need)  # slack = the LWW trees sized for V = n
