@@ -364,31 +364,22 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
     const uint32_t hi = lo + chunk < m ? lo + chunk : m;
     uint32_t sum = 0;
     for (uint32_t j = lo; j < hi; ++j) sum += a[j * STRIDE];
-    uint32_t incl = sum;
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t v = __shfl_up(incl, d, 64);
-        if ((int)lane >= d) incl += v;
-    }
+    const uint32_t incl = ptx_wave_incl_scan(sum); /* DPP prefix sum: no LDS traffic */
     if (lane == 63) tmp[wave] = incl;
     __syncthreads();
-    if (wave == 0) {
-        uint32_t w = lane < nwaves ? tmp[lane] : 0;
-        uint32_t wi = w;
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t v = __shfl_up(wi, d, 64);
-            if ((int)lane >= d) wi += v;
-        }
-        if (lane < nwaves) tmp[lane] = wi - w;
-        if (lane == 63) tmp[35] = wi;
+    uint32_t wbase = 0, total = 0;
+#pragma nounroll
+    for (uint32_t w = 0; w < nwaves; ++w) { /* a workgroup has at most 16 waves: every thread sums the few wave totals itself */
+        const uint32_t t = tmp[w];
+        wbase += w < wave ? t : 0u;
+        total += t;
     }
-    __syncthreads();
-    uint32_t run = tmp[wave] + incl - sum;
+    uint32_t run = wbase + incl - sum;
     for (uint32_t j = lo; j < hi; ++j) {
         uint32_t v = a[j * STRIDE];
         a[j * STRIDE] = (T)run;
         run += v;
     }
-    const uint32_t total = tmp[35];
     __syncthreads();
     return total;
 #endif
