@@ -73,7 +73,10 @@ PTX_DEV uint32_t ptx_group_sum(uint32_t c) { return c; }
 #define PTX_HD __host__ __device__ static inline
 #define PTX_DEV __device__ __forceinline__
 #define PTX_SYNC() __syncthreads()
-#define PTX_FOR(i, n) _Pragma("nounroll") for (uint32_t i = threadIdx.x, _n = (n); i < _n; i += blockDim.x)
+/* threads per workgroup: a compile-time constant in the builds specialised for the usual launch shapes (kThreads != 0:
+ * the per-phase loop bounds and strides then fold, which removes a quarter of the scalar instructions), else blockDim.x */
+#define PTX_BLOCKDIM (kThreads ? kThreads : blockDim.x)
+#define PTX_FOR(i, n) _Pragma("nounroll") for (uint32_t i = threadIdx.x, _n = (n); i < _n; i += PTX_BLOCKDIM)
 #define PTX_LEADER if (threadIdx.x == 0)
 PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
@@ -102,7 +105,7 @@ PTX_DEV uint32_t ptx_group_sum(uint32_t c) {
     c += (uint32_t)__shfl_xor((int)c, 4, 64);
     return c;
 }
-#define PTX_FORU(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = blockDim.x; i0 < _n; i0 += PTX_U * _T)
+#define PTX_FORU(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = PTX_BLOCKDIM; i0 < _n; i0 += PTX_U * _T)
 #define PTX_IX(i0, u) ((i0) + (uint32_t)(u) * _T)
 #endif
 #define PTX_IN(i0, u) ((i0) + (uint32_t)(u) * _T < _n)
@@ -165,8 +168,8 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #define PTX_STEPS(groups) (groups)
 #define PTX_G_OF(st, steps) (ptx_emu_reverse ? ((st) < (steps) ? (steps) - 1u - (st) : (steps)) : (st))
 #else
-#define PTX_STEPS(groups) (((groups) + blockDim.x - 1u) / blockDim.x)
-#define PTX_G_OF(st, steps) (threadIdx.x + (st) * blockDim.x)
+#define PTX_STEPS(groups) (((groups) + PTX_BLOCKDIM - 1u) / PTX_BLOCKDIM)
+#define PTX_G_OF(st, steps) (threadIdx.x + (st) * PTX_BLOCKDIM)
 #endif
 
 /* the same for loops over list items, PTX_U items per thread and step, lanes on consecutive items:
@@ -177,8 +180,8 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #define PTX_J_OF_U(st, u, U) ((st) * (U) + (uint32_t)(u))
 #define PTX_JX(j, n) (ptx_emu_reverse ? (n) - 1u - (j) : (j))
 #else
-#define PTX_JSTEPS_U(n, U) (((n) + (U)*blockDim.x - 1u) / ((U)*blockDim.x))
-#define PTX_J_OF_U(st, u, U) (((st) * (U) + (uint32_t)(u)) * blockDim.x + threadIdx.x)
+#define PTX_JSTEPS_U(n, U) (((n) + (U)*PTX_BLOCKDIM - 1u) / ((U)*PTX_BLOCKDIM))
+#define PTX_J_OF_U(st, u, U) (((st) * (U) + (uint32_t)(u)) * PTX_BLOCKDIM + threadIdx.x)
 #define PTX_JX(j, n) (j)
 #endif
 #define PTX_JSTEPS(n) PTX_JSTEPS_U(n, PTX_U)
@@ -202,7 +205,7 @@ PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return v; }
 #else
 #define PTX_WAVE_FIRST(g) ((g) - (threadIdx.x & 63u)) /* index handled by lane 0 of this wave */
 #define PTX_WS 64u
-#define PTX_NWAVES (blockDim.x >> 6)
+#define PTX_NWAVES (PTX_BLOCKDIM >> 6)
 #define PTX_FOR_WAVE(w, lane) for (uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, _once = 1; _once; _once = 0)
 PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
 PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl_scan(v)); }
@@ -210,25 +213,27 @@ PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl
 #ifdef PTX_EMU
 #define PTX_NTHREADS 5u /* the emulation splits per-thread runs five ways so that the run/prefix logic is exercised */
 #else
-#define PTX_NTHREADS blockDim.x
+#define PTX_NTHREADS PTX_BLOCKDIM
 #endif
 #define PTX_MAX_THREADS 1024u
 #define PTX_UA 1 /* changes per thread in flight in the (rare) many-actor admission passes */
 #ifdef PTX_EMU
 #define PTX_FORA(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_UA)
 #else
-#define PTX_FORA(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = blockDim.x; i0 < _n; i0 += PTX_UA * _T)
+#define PTX_FORA(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = PTX_BLOCKDIM; i0 < _n; i0 += PTX_UA * _T)
 #endif
 #define PTX_INA(i0, u) PTX_IN(i0, u)
 #define PTX_IXA(i0, u) PTX_IX(i0, u)
+#ifndef PTX_UM
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
+#endif
 
 /* uniform loop over groups of PTX_U consecutive items: every thread runs every step (g may be past the end) */
 #ifdef PTX_EMU
 #define PTX_FORG(g, groups) \
     for (uint32_t _ng = (groups), _k = 0, g = (ptx_emu_reverse ? _ng - 1 : 0); _k < _ng; ++_k, g = (ptx_emu_reverse ? _ng - 1 - _k : _k))
 #else
-#define PTX_FORG(g, groups) for (uint32_t _ng = (groups), _g0 = 0, g = threadIdx.x; _g0 < _ng; _g0 += blockDim.x, g += blockDim.x)
+#define PTX_FORG(g, groups) for (uint32_t _ng = (groups), _g0 = 0, g = threadIdx.x; _g0 < _ng; _g0 += PTX_BLOCKDIM, g += PTX_BLOCKDIM)
 #endif
 
 /* kernel arguments: device pointers (host pointers under PTX_EMU) */
@@ -346,7 +351,7 @@ PTX_DEV void ptx_reduce_max32(uint32_t* dst, uint32_t v) {
 
 /* ---- block-wide exclusive scan of an LDS array (element k at a[k*STRIDE]), in place; returns the
  *      total (all threads call it; ends with a barrier) ---- */
-template <class T, int STRIDE>
+template <class T, int STRIDE, uint32_t kThreads>
 PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in LDS */) {
 #ifdef PTX_EMU
     uint32_t run = 0;
@@ -358,7 +363,7 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
     (void)tmp;
     return run;
 #else
-    const uint32_t T_ = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (T_ + 63) >> 6;
+    const uint32_t T_ = PTX_BLOCKDIM, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (T_ + 63) >> 6;
     const uint32_t chunk = (m + T_ - 1) / T_;
     const uint32_t lo = tid * chunk < m ? tid * chunk : m;
     const uint32_t hi = lo + chunk < m ? lo + chunk : m;
@@ -651,7 +656,7 @@ PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
 /* ================================================================================================ */
 /* Applies log `log`; returns its status (PTX_OK or a per-log PTX_ERR_*) and the LDS high-water mark.  The caller
  * writes the result row (ptx_write_result) — ONE copy of that code instead of one per early exit. */
-template <bool kManyActors>
+template <bool kManyActors, uint32_t kThreads>
 PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t* lds, uint32_t& lds_high) {
     const uint64_t base = A.log_off[log];
     const uint64_t N64 = A.log_off[log + 1] - base;
@@ -740,6 +745,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_FOR_WAVE(w, lane) {
                 const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
                 uint32_t t01 = 0, t23 = 0, rows = 0, badc = 0xFFFFFFFFu;
+#pragma nounroll
                 for (uint32_t cb = lo; cb < hi; cb += PTX_WS) {
                     const uint32_t c = cb + lane;
                     const bool in = c < hi;
@@ -784,6 +790,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         _Pragma("unroll") for (uint32_t b = 0; b < 4; ++b) d_[b] = c_deps[(uint64_t)c_ * na + (b < na ? b : 0u)]; \
     }
                 if (lo < hi) PTX_ADM_LOAD(lo, a, sq, d)
+#pragma nounroll
                 for (uint32_t cb = lo; cb < hi; cb += PTX_WS) {
                     const uint32_t c = cb + lane;
                     const bool in = c < hi;
@@ -979,6 +986,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #if PTX_P1_PREFETCH
         PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a, mt)
 #endif
+#pragma nounroll
         for (uint32_t st = 0; st < p1_steps; ++st) {
             const uint32_t g = PTX_G_OF(st, p1_steps);
             if (PTX_WAVE_FIRST(g) >= p1_groups) continue; /* this wave has no row left in this step (wave-uniform) */
@@ -1065,7 +1073,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             /* (which of two equal ids is "the repeat" depends on the race; the status is what is reported) */
         }
         PTX_SYNC();
-        ptx_scan_excl<uint32_t, 2>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
+        ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
     }
     PTX_BAIL_IF_ERROR();
     bp.off = tree_lds;
@@ -1105,6 +1113,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         ra_[u] = ref_a[i_[u]];                                              \
     }
             PTX_P3A_LOAD(0u, i, id, ra)
+#pragma nounroll
             for (uint32_t st = 0; st < steps; ++st) {
                 PTX_P3A_LOAD(st + 1u, i_n, id_n, ra_n) /* in flight while this step is processed */
 #pragma unroll
@@ -1133,7 +1142,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_P3A_LOAD
         }
         PTX_BAIL_IF_ERROR();
-        ptx_scan_excl<uint16_t, 1>(cnt, n + 2, H->scan_tmp); /* cnt[p] = first slot of p's children */
+        ptx_scan_excl<uint16_t, 1, kThreads>(cnt, n + 2, H->scan_tmp); /* cnt[p] = first slot of p's children */
         /* P3b: scatter into the parent buckets; tombstone flags; application-order checks now that row_of is complete */
         PTX_FORU(e0, n) {
             uint32_t pe[PTX_U], re[PTX_U], rp[PTX_U];
@@ -1167,6 +1176,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) ra_[u] = ref_a[i_[u]];
             PTX_DEL_LOAD(0u, i, ra)
+#pragma nounroll
             for (uint32_t st = 0; st < steps; ++st) {
                 PTX_DEL_LOAD(st + 1u, i_n, ra_n)
 #pragma unroll
@@ -1243,7 +1253,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 PTX_SYNC();
                 PTX_FOR(w, nwe + 1) hb[w].pre = ptx_popc(hb[w].bits);
                 PTX_SYNC();
-                ptx_scan_excl<uint32_t, 2>(&hb[0].pre, nwe + 1, H->scan_tmp);
+                ptx_scan_excl<uint32_t, 2, kThreads>(&hb[0].pre, nwe + 1, H->scan_tmp);
                 PTX_FOR(k, t - s) {
                     const uint32_t x = seg[s + k];
                     srt[s + (t - s - 1u - ptx_bitrank(hb, x))] = (uint16_t)x; /* members with a larger index come first */
@@ -1288,6 +1298,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_LEADER { R[ns] = ns << 16; } /* terminal: points at itself with weight 0 */
             PTX_SYNC();
             const uint32_t rounds = ptx_ceil_log2(ns + 1);
+#pragma nounroll
             for (uint32_t r = 0; r < rounds; ++r) {
                 /* in-place pointer jumping: every intermediate {next, weight} word is a valid state
                  * (weight = sum over [node, next)), so reading a word another thread already advanced
@@ -1343,7 +1354,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_SYNC();
     PTX_FOR(w, nwv + 1) alive[w].pre = ptx_popc(alive[w].bits);
     PTX_SYNC();
-    const uint32_t V = ptx_scan_excl<uint32_t, 2>(&alive[0].pre, nwv + 1, H->scan_tmp);
+    const uint32_t V = ptx_scan_excl<uint32_t, 2, kThreads>(&alive[0].pre, nwv + 1, H->scan_tmp);
     PTX_STAMP(6);
 
     /* ---- P5a: visible values out; every mark op -> visible interval [lo, hi) ---- */
@@ -1396,6 +1407,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         pl_[u] = payload[i_[u]];                                            \
     }
     PTX_MARK_LOAD(0u, i, ra, rb, sa, sb, pl)
+#pragma nounroll
     for (uint32_t st = 0; st < m_steps; ++st) {
         PTX_MARK_LOAD(st + 1u, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* in flight while this step is processed */
 #pragma unroll
@@ -1479,7 +1491,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             if (mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[cid[kc]], 1u);
         }
         PTX_SYNC();
-        ptx_scan_excl<uint32_t, 1>(ccnt, Kc + 1, H->scan_tmp); /* ccnt[c] = first entry of id c, ccnt[Kc] = total */
+        ptx_scan_excl<uint32_t, 1, kThreads>(ccnt, Kc + 1, H->scan_tmp); /* ccnt[c] = first entry of id c, ccnt[Kc] = total */
         PTX_FOR(kc, Kc) {
             const uint32_t k = moff2 + kc;
             if (mrk_lo[k] < mrk_hi[k]) {
@@ -1498,7 +1510,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             cicnt[c] = c < Kc ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         }
         PTX_SYNC();
-        const uint32_t I = ptx_scan_excl<uint32_t, 1>(cicnt, Kc + 1, H->scan_tmp);
+        const uint32_t I = ptx_scan_excl<uint32_t, 1, kThreads>(cicnt, Kc + 1, H->scan_tmp);
         PTX_LEADER { H->I = I; }
         {
             uint64_t h1 = 0, h2 = 0;
@@ -1543,6 +1555,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         uint64_t h1 = 0, h2 = 0;
         uint32_t span_base = 0;
         uint32_t prev_attr = 0; /* marks of the last char of the previous tile */
+#pragma nounroll
         for (uint32_t t0 = 0; t0 < V; t0 += TV) {
             const uint32_t tv = V - t0 < TV ? V - t0 : TV; /* chars in this tile */
             PTX_FOR(q, tv + 1) attr[q] = 0;
@@ -1552,6 +1565,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 z.pre = 0;
                 st[w] = z;
             }
+#pragma nounroll
             for (uint32_t g = 0; g < 4; g += ntree) {
                 /* mark types [g, g + ntree) */
                 const uint32_t k_lo = g == 0 ? 0u : g == 1 ? moff1 : g == 2 ? moff2 : moff3;
@@ -1604,7 +1618,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_SYNC();
             PTX_FOR(w, TV / 32 + 2) st[w].pre = ptx_popc(st[w].bits);
             PTX_SYNC();
-            const uint32_t S_tile = ptx_scan_excl<uint32_t, 2>(&st[0].pre, TV / 32 + 2, H->scan_tmp);
+            const uint32_t S_tile = ptx_scan_excl<uint32_t, 2, kThreads>(&st[0].pre, TV / 32 + 2, H->scan_tmp);
             PTX_FOR(q, tv) {
                 const PtxBitWord w = st[q >> 5];
                 if ((w.bits >> (q & 31)) & 1u) {
@@ -1640,10 +1654,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
 /* kManyActors: include the admission path for batches with more than four actors per document (it costs ~35
  * VGPRs, i.e. two waves per SIMD, so it lives in its own build of the kernel) */
-template <bool kManyActors>
+template <bool kManyActors, uint32_t kThreads>
 PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     uint32_t lds_high = 0;
-    const uint32_t status = ptx_merge_log_body<kManyActors>(A, log, lds, lds_high);
+    const uint32_t status = ptx_merge_log_body<kManyActors, kThreads>(A, log, lds, lds_high);
     PTX_SYNC();
     ptx_write_result(A, log, (PtxHdr*)lds, status, lds_high);
 }

@@ -27,19 +27,18 @@
 
 /* One body, several register budgets: __launch_bounds__(T, W) = at most T threads per workgroup and at
  * least W waves per SIMD resident, i.e. the compiler must stay within 512/W VGPRs (MI355X_MICROARCH.md
- * "Register files").  The host picks the variant whose budget matches the launch shape. */
-#define PTX_MERGE_KERNEL(name, T, W, MANY)                                               \
+ * "Register files"). */
+#define PTX_MERGE_KERNEL(name, T, W, MANY, KT)                                           \
     extern "C" __global__ void __launch_bounds__(T, W) name(PtxMergeArgs A) {          \
         extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];              \
         /* one workgroup per log (grid == n_logs): no grid-stride loop, so that nothing is hoisted \
            out of it and kept in registers for the whole kernel */                    \
-        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY>(A, blockIdx.x, ptx_lds);       \
+        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT>(A, blockIdx.x, ptx_lds);   \
     }
-PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false)   /* any launch shape */
-PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true) /* + causal admission for documents with more than four actors */
-PTX_MERGE_KERNEL(ptx_merge_kernel_w5, 256, 5, false)  /* <= 96 VGPRs: 5 workgroups of 256 per CU */
-PTX_MERGE_KERNEL(ptx_merge_kernel_w6, 256, 6, false)  /* <= 80 VGPRs: 6 workgroups of 256 per CU */
-PTX_MERGE_KERNEL(ptx_merge_kernel_w8, 512, 8, false)  /* <= 64 VGPRs: 8 waves per SIMD (8 x 256 or 4 x 512 threads per CU) */
+PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false, 0)     /* any launch shape (blockDim.x read at run time) */
+PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0) /* + causal admission for documents with more than four actors */
+/* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
+ * issue ~1 % fewer instructions but need twice the VGPRs unless PTX_U=1, so only the run-time-sized builds are shipped) */
 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
@@ -131,7 +130,6 @@ struct ptx_ctx {
     int force_threads = 0; /* PTX_THREADS env override (tuning) */
     int force_lds = 0;     /* PTX_LDS_BYTES env override (tuning) */
     int stop_after = 0;    /* PTX_STOP_AFTER env (diagnostic): truncate the kernel after a phase, for per-phase PMC deltas */
-    int variant = -1;      /* PTX_VARIANT env override (tuning): register-budget variant of the kernel */
     uint32_t flags = 0;
     unsigned long long* clocks = nullptr; /* device [PTX_NCLK], non-null only while ptx_merge_phase_cycles runs */
 };
@@ -237,7 +235,7 @@ extern "C" {
 
 uint32_t ptx_abi_version(void) { return PTX_ABI_VERSION; }
 
-const char* ptx_kernel_name(void) { return "ptx_merge_kernel_w6"; } /* the build ptx_merge launches for workgroups of <= 256 threads */
+const char* ptx_kernel_name(void) { return "ptx_merge_kernel"; }
 
 const char* ptx_last_error(const ptx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -266,13 +264,13 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
         return fail(nullptr, PTX_ERR_HIP, "stream/event creation failed");
     }
     /* one workgroup may use the CU's whole 160 KiB of LDS */
-    if (const char* sv = getenv("PTX_VARIANT")) ctx->variant = atoi(sv);
     if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
-    e = hipFuncSetAttribute((const void*)ptx_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ptx_merge_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
+    {
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many};
+        e = hipSuccess;
+        for (const void* k : kernels)
+            if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
+    }
     if (e != hipSuccess) {
         std::string m = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e);
         delete ctx;
@@ -550,18 +548,8 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.lds_bytes = b->lds_bytes;
     /* one workgroup per log; far more workgroups than the 256 CUs so the dispatcher load-balances */
     const uint32_t grid = b->n_logs;
-    /* register budget by launch shape: workgroups of <= 256 threads run the <= 80-VGPR build so that six of
-     * them fit a CU when their LDS does (PTX_VARIANT overrides, for tuning) */
-    int variant = ctx->variant >= 0 ? ctx->variant : (b->threads <= 256 ? 6 : b->threads <= 512 ? 8 : 0);
-    if (b->threads > 512 || (b->threads > 256 && variant != 8)) variant = 0;
     if (admit && b->max_actors > 4)
         hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
-    else if (variant == 8)
-        hipLaunchKernelGGL(ptx_merge_kernel_w8, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
-    else if (variant == 6)
-        hipLaunchKernelGGL(ptx_merge_kernel_w6, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
-    else if (variant == 5)
-        hipLaunchKernelGGL(ptx_merge_kernel_w5, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
     else
         hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
     hipError_t e = hipGetLastError();

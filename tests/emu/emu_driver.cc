@@ -69,7 +69,7 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     ptx_emu_reverse = reverse;
     for (uint32_t l = 0; l < b->n_logs; ++l) {
         memset(lds, 0xA5, lds_bytes); /* LDS is not zero-initialised on the GPU either */
-        ptx_merge_log<true>(A, l, lds);
+        ptx_merge_log<true, 0>(A, l, lds);
     }
     free(lds);
     free(hdr);
