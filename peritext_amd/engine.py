@@ -102,6 +102,23 @@ class Engine:
         self._check(self.lib.ptx_batch_upload_tiled(self.ctx, C.byref(s), copies, C.byref(h)))
         return h
 
+    def wrap_device(self, n_logs, n_ops, ptrs, log_hdr_ptr=0):
+        """Adopt caller-owned DEVICE columns (ptx_batch_wrap_device): `ptrs` maps the nine column names of
+        ptx_batch (log_off, op_id, ref_a, ref_b, payload, action, mark_type, side_a, side_b) to device addresses,
+        e.g. torch tensors' data_ptr().  Nothing is copied; the log headers are computed on the device unless
+        `log_hdr_ptr` (device address of n_logs ptx_log_hdr rows) is given."""
+        s = abi.ptx_batch()
+        s.n_logs = n_logs
+        s.n_ops = n_ops
+        for name, typ in (("log_off", abi.u64p), ("op_id", abi.u64p), ("ref_a", abi.u64p), ("ref_b", abi.u64p), ("payload", abi.u32p),
+                          ("action", abi.u8p), ("mark_type", abi.u8p), ("side_a", abi.u8p), ("side_b", abi.u8p)):
+            setattr(s, name, C.cast(C.c_void_p(int(ptrs[name])), typ))
+        if log_hdr_ptr:
+            s.log_hdr = C.cast(C.c_void_p(int(log_hdr_ptr)), C.POINTER(abi.ptx_log_hdr))
+        h = C.c_void_p()
+        self._check(self.lib.ptx_batch_wrap_device(self.ctx, C.byref(s), C.byref(h)))
+        return h
+
     def free_batch(self, h):
         self.lib.ptx_batch_free(self.ctx, h)
 

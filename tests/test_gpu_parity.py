@@ -101,6 +101,33 @@ def test_staged_api_equals_one_shot_and_tiling(eng):
         assert wire.decode_spans(tiled, got, log) == wire.decode_spans(batch, one, log % batch.n_logs)
 
 
+def test_wrap_device_columns(eng):
+    """ptx_batch_wrap_device: op columns that already live in HBM (here torch tensors) are merged in place — no
+    copy, log headers from the device census — with the same result rows as the upload path."""
+    import torch
+
+    gen = _load("ptxgen_config3_512.json")
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    want = eng.apply_materialize(batch)
+    cols = {}
+    for name in ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b"):
+        a = getattr(batch, name)
+        as_signed = {np.dtype("uint64"): np.int64, np.dtype("uint32"): np.int32, np.dtype("uint8"): np.uint8}[a.dtype]
+        cols[name] = torch.from_numpy(a.view(as_signed).copy()).cuda()
+    torch.cuda.synchronize()
+    db = eng.wrap_device(batch.n_logs, batch.n_ops, {k: v.data_ptr() for k, v in cols.items()})
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        got = eng.download(db, dr)
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
+    assert (got.logs["status"] == 0).all() and (got.logs["digest"] == want.logs["digest"]).all()
+    for log in range(batch.n_logs):
+        assert wire.decode_spans(batch, got, log) == wire.decode_spans(batch, want, log)
+
+
 def test_elem_rank_is_document_position(eng):
     """elem_rank of an insert row == findListElement(...).index in the oracle's final metadata order:
     checked through the property that visible elements sorted by rank spell the document text."""
