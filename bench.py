@@ -283,6 +283,7 @@ def main():
     eng.free_batch(db)
     eng.close()
     if world > 1:
+        dist.barrier()  # rank 0 is still busy with the CPU baseline leg: leave together
         dist.destroy_process_group()
 
 
