@@ -1281,16 +1281,22 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             L[xo] = (uint16_t)other; /* j == n writes the terminal node */
         }
         PTX_SYNC();
-        /* List ranking, work-efficient: every PTX_S-th node is a splitter; a splitter walks to the next one
-         * counting the enter nodes (weight 1: node ids 1..n) it passes (each tour node is visited once), the
-         * ~2n/PTX_S splitters are ranked by in-place pointer jumping, and a second walk hands the ranks out. */
+        /* List ranking, work-efficient: every PTX_S-th node is a splitter.  A splitter walks to the next one (each tour
+         * node is visited once), counts the enter nodes (weight 1: node ids 1..n) it passes and leaves on each of them
+         * its splitter and the count before it (in `L` and `par`, both dead by then); the ~2n/PTX_S splitters are
+         * ranked by in-place pointer jumping; one flat pass turns (splitter suffix, local count) into positions. */
         {
             const uint32_t ns = (2 * n) / PTX_S + 1; /* splitters 0, S, 2S, ... <= 2n */
             PTX_FOR(sp, ns) {
                 uint32_t v = sp * PTX_S, acc = 0;
                 for (;;) {
-                    acc += v - 1u < n ? 1u : 0u;
-                    v = L[v];
+                    const uint32_t nx = L[v];
+                    if (v - 1u < n) {
+                        par[v - 1u] = (uint16_t)acc; /* enter nodes of this segment strictly before v */
+                        L[v] = (uint16_t)sp;         /* only this walker ever reads L[v], and it just did */
+                        ++acc;
+                    }
+                    v = nx;
                     if (v == term || (v & (PTX_S - 1u)) == 0u) break;
                 }
                 R[sp] = ((v == term ? ns : v / PTX_S) << 16) | acc;
@@ -1310,18 +1316,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 }
                 PTX_SYNC();
             }
-            PTX_FOR(sp, ns) {
-                uint32_t v = sp * PTX_S;
-                uint32_t run = R[sp] & 0xFFFFu; /* elements from node v to the end */
-                for (;;) {
-                    if (v - 1u < n) {
-                        par[v - 1u] = (uint16_t)(n - run); /* document position incl. tombstones */
-                        --run;
-                    }
-                    v = L[v];
-                    if (v == term || (v & (PTX_S - 1u)) == 0u) break;
-                }
-            }
+            /* elements from x to the end of the document = suffix of x's splitter - enter nodes before x in its segment */
+            PTX_FOR(x, n) par[x] = (uint16_t)(n - ((R[L[x + 1u]] & 0xFFFFu) - (uint32_t)par[x])); /* document position incl. tombstones */
         }
         PTX_SYNC();
     }
