@@ -187,7 +187,7 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #define PTX_JSTEPS(n) PTX_JSTEPS_U(n, PTX_U)
 #define PTX_J_OF(st, u) PTX_J_OF_U(st, u, PTX_U)
 #ifndef PTX_U1
-#define PTX_U1 2 /* consecutive rows per thread and step in the row pass P1 */
+#define PTX_U1 3 /* consecutive rows per thread and step in the row pass P1 (measured: 2 -> 14.6, 3 -> 14.2, 4 -> 17 us per 4K-op log) */
 #endif
 #ifndef PTX_P1_PREFETCH
 #define PTX_P1_PREFETCH 1 /* 1: double-buffer the row loads of P1 (costs PTX_U1 * 4 VGPRs) */
@@ -267,7 +267,9 @@ struct PtxMergeArgs {
 };
 
 #define PTX_END 0xFFFFu
-#define PTX_S 8u         /* every PTX_S-th node of the Euler tour is a splitter of the list ranking */
+#ifndef PTX_S
+#define PTX_S 8u /* every PTX_S-th node of the Euler tour is a splitter of the list ranking */
+#endif
 #define PTX_TILE_4 128u  /* visible chars up to which the four LWW trees are resident at once */
 #define PTX_TILE_1 512u  /* tile of the visible axis for longer documents (one tree, reused per mark type) */
 #define PTX_NCLK 16
