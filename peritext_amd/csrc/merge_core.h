@@ -224,6 +224,9 @@ PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl
 #endif
 #define PTX_INA(i0, u) PTX_IN(i0, u)
 #define PTX_IXA(i0, u) PTX_IX(i0, u)
+#ifndef PTX_AC
+#define PTX_AC 2u /* consecutive changes per lane and step in the admission pass */
+#endif
 #ifndef PTX_UM
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
 #endif
@@ -743,19 +746,23 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_LEADER { H->cur[7] = 0; }
             PTX_SYNC();
             const uint32_t nwv_ = PTX_NWAVES;
-            const uint32_t seg = ((C + nwv_ - 1u) / nwv_ + PTX_WS - 1u) / PTX_WS * PTX_WS; /* changes per wave, whole steps */
+            const uint32_t step = PTX_WS * PTX_AC; /* changes per wave and step: PTX_AC consecutive changes per lane */
+            const uint32_t seg = ((C + nwv_ - 1u) / nwv_ + step - 1u) / step * step; /* changes per wave, whole steps */
             PTX_FOR_WAVE(w, lane) {
                 const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
                 uint32_t t01 = 0, t23 = 0, rows = 0, badc = 0xFFFFFFFFu;
 #pragma nounroll
-                for (uint32_t cb = lo; cb < hi; cb += PTX_WS) {
-                    const uint32_t c = cb + lane;
-                    const bool in = c < hi;
-                    const uint32_t a = c_actor[in ? c : hi - 1u], no = c_nops[in ? c : hi - 1u];
-                    rows += in ? no : 0u;
-                    if (in && a >= na) badc = c < badc ? c : badc;
-                    t01 += in && a < 2u ? 1u << (16u * a) : 0u;
-                    t23 += in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
+                for (uint32_t cb = lo; cb < hi; cb += step) {
+#pragma unroll
+                    for (uint32_t u = 0; u < PTX_AC; ++u) {
+                        const uint32_t c = cb + lane * PTX_AC + u;
+                        const bool in = c < hi;
+                        const uint32_t a = c_actor[in ? c : hi - 1u], no = c_nops[in ? c : hi - 1u];
+                        rows += in ? no : 0u;
+                        if (in && a >= na) badc = c < badc ? c : badc;
+                        t01 += in && a < 2u ? 1u << (16u * a) : 0u;
+                        t23 += in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
+                    }
                 }
                 t01 = ptx_wave_total(t01);
                 t23 = ptx_wave_total(t23);
@@ -782,41 +789,57 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     b01 += wt01[q];
                     b23 += wt23[q];
                 }
-                /* the six loads of the NEXT step are in flight while this step is checked */
-                uint32_t a = 0, sq = 0, d[4] = {0, 0, 0, 0}, a_n, sq_n, d_n[4];
-#define PTX_ADM_LOAD(cb_, a_, sq_, d_)                                                      \
-    {                                                                                       \
-        const uint32_t c_ = (cb_) + lane < hi ? (cb_) + lane : (hi ? hi - 1u : 0u);         \
-        a_ = c_actor[c_];                                                                   \
-        sq_ = c_seq[c_];                                                                    \
-        _Pragma("unroll") for (uint32_t b = 0; b < 4; ++b) d_[b] = c_deps[(uint64_t)c_ * na + (b < na ? b : 0u)]; \
+                /* the loads of the NEXT step are in flight while this step is checked */
+                uint32_t a[PTX_AC], sq[PTX_AC], d[PTX_AC][4], a_n[PTX_AC], sq_n[PTX_AC], d_n[PTX_AC][4];
+#define PTX_ADM_LOAD(cb_, a_, sq_, d_)                                                                  \
+    _Pragma("unroll") for (uint32_t u = 0; u < PTX_AC; ++u) {                                           \
+        const uint32_t c0_ = (cb_) + lane * PTX_AC + u;                                                 \
+        const uint32_t c_ = c0_ < hi ? c0_ : (hi ? hi - 1u : 0u);                                       \
+        a_[u] = c_actor[c_];                                                                            \
+        sq_[u] = c_seq[c_];                                                                             \
+        _Pragma("unroll") for (uint32_t b = 0; b < 4; ++b) d_[u][b] = c_deps[(uint64_t)c_ * na + (b < na ? b : 0u)]; \
     }
-                if (lo < hi) PTX_ADM_LOAD(lo, a, sq, d)
+                PTX_ADM_LOAD(lo, a, sq, d)
 #pragma nounroll
-                for (uint32_t cb = lo; cb < hi; cb += PTX_WS) {
-                    const uint32_t c = cb + lane;
-                    const bool in = c < hi;
-                    PTX_ADM_LOAD(cb + PTX_WS, a_n, sq_n, d_n)
-                    const uint32_t o01 = in && a < 2u ? 1u << (16u * a) : 0u, o23 = in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
-                    const uint32_t i01 = ptx_wave_incl_scan(o01), i23 = ptx_wave_incl_scan(o23);
-                    const uint32_t w01 = b01 + i01 - o01, w23 = b23 + i23 - o23; /* the clock before change c */
-                    const uint32_t clk[4] = {w01 & 0xFFFFu, w01 >> 16, w23 & 0xFFFFu, w23 >> 16};
-                    const uint32_t mine = a == 0u ? clk[0] : a == 1u ? clk[1] : a == 2u ? clk[2] : clk[3];
-                    const bool bad_seq = sq != mine + 1u;
-                    bool bad_dep = false;
+                for (uint32_t cb = lo; cb < hi; cb += step) {
+                    PTX_ADM_LOAD(cb + step, a_n, sq_n, d_n)
+                    uint32_t o01[PTX_AC], o23[PTX_AC], t01 = 0, t23 = 0;
 #pragma unroll
-                    for (uint32_t b = 0; b < 4; ++b) bad_dep = bad_dep || (b < na && d[b] > clk[b]);
-                    if (in && (bad_seq || bad_dep)) {
-                        uint32_t row;
-                        PTX_CHANGE_ROW(c, row);
-                        ptx_atomic_min(&H->adm, ((row * 2u) << 4) | (bad_seq ? PTX_ERR_SEQ_GAP : PTX_ERR_MISSING_DEP));
+                    for (uint32_t u = 0; u < PTX_AC; ++u) {
+                        const bool in = cb + lane * PTX_AC + u < hi;
+                        o01[u] = in && a[u] < 2u ? 1u << (16u * a[u]) : 0u;
+                        o23[u] = in && (a[u] & ~1u) == 2u ? 1u << (16u * (a[u] & 1u)) : 0u;
+                        t01 += o01[u];
+                        t23 += o23[u];
+                    }
+                    const uint32_t i01 = ptx_wave_incl_scan(t01), i23 = ptx_wave_incl_scan(t23);
+                    uint32_t w01 = b01 + i01 - t01, w23 = b23 + i23 - t23; /* the clock before this lane's first change */
+#pragma unroll
+                    for (uint32_t u = 0; u < PTX_AC; ++u) {
+                        const uint32_t c = cb + lane * PTX_AC + u;
+                        const uint32_t clk[4] = {w01 & 0xFFFFu, w01 >> 16, w23 & 0xFFFFu, w23 >> 16};
+                        const uint32_t mine = ((a[u] < 2u ? w01 : w23) >> (16u * (a[u] & 1u))) & 0xFFFFu;
+                        const bool bad_seq = sq[u] != mine + 1u;
+                        bool bad_dep = false;
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) bad_dep = bad_dep || (b < na && d[u][b] > clk[b]);
+                        if (c < hi && (bad_seq || bad_dep)) {
+                            uint32_t row;
+                            PTX_CHANGE_ROW(c, row);
+                            ptx_atomic_min(&H->adm, ((row * 2u) << 4) | (bad_seq ? PTX_ERR_SEQ_GAP : PTX_ERR_MISSING_DEP));
+                        }
+                        w01 += o01[u];
+                        w23 += o23[u];
                     }
                     b01 += ptx_wave_last(i01);
                     b23 += ptx_wave_last(i23);
-                    a = a_n;
-                    sq = sq_n;
 #pragma unroll
-                    for (uint32_t b = 0; b < 4; ++b) d[b] = d_n[b];
+                    for (uint32_t u = 0; u < PTX_AC; ++u) {
+                        a[u] = a_n[u];
+                        sq[u] = sq_n[u];
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) d[u][b] = d_n[u][b];
+                    }
                 }
 #undef PTX_ADM_LOAD
             }
