@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 2u
+#define PTX_ABI_VERSION 3u
 
 /* Operation.action (micromerge.ts:150-212, peritext.ts:25-65) */
 enum {
@@ -185,6 +185,41 @@ typedef struct ptx_result {
     void* owner;
 } ptx_result;
 
+/* ---- incremental patch streams (what applyChange RETURNS, micromerge.ts:499 -> Patch[]) ----
+ * One record per patch, in the replica's application order.  `row` = the op row of the log that produced it.
+ *   PTX_PATCH_MAKELIST        the makeList op itself                          micromerge.ts:575
+ *   PTX_PATCH_INSERT          a = visible index, b = marks of the new char (PTX_ATTR_* | link url id, as ptx_span.attr;
+ *                             PTX_ATTR_COMMENT = key `comment` present)       micromerge.ts:661-671, peritext.ts:328
+ *   PTX_PATCH_INSERT_COMMENT  follows its INSERT record: a = one doc-local comment id of the new char's marks
+ *                             (ids in no particular order; the reference lists them sorted by id string)
+ *   PTX_PATCH_DELETE          a = visible index, b = count (1)                micromerge.ts:696-703
+ *   PTX_PATCH_ADDMARK / PTX_PATCH_REMOVEMARK  a = startIndex, b = endIndex (visible, exclusive); markType and attrs
+ *                             are those of op `row`                           peritext.ts:251-281 */
+enum { PTX_PATCH_MAKELIST = 0, PTX_PATCH_INSERT = 1, PTX_PATCH_DELETE = 2, PTX_PATCH_ADDMARK = 3, PTX_PATCH_REMOVEMARK = 4, PTX_PATCH_INSERT_COMMENT = 5 };
+typedef struct ptx_patch {
+    uint32_t row;
+    uint32_t kind; /* PTX_PATCH_* */
+    uint32_t a;
+    uint32_t b;
+} ptx_patch;
+typedef struct ptx_patch_log {
+    uint32_t status;    /* PTX_OK, or the log's merge status (no stream for a log the reference would have thrown on),
+                           or PTX_ERR_CAPACITY (working set beyond the on-chip memory) */
+    uint32_t n_patches; /* records of this log */
+} ptx_patch_log;
+/* Host-side view of the patch streams of a batch: records of log l at patches[patch_off[l] .. patch_off[l] + logs[l].n_patches).
+ * Owned by the library until ptx_patches_free. */
+typedef struct ptx_patches {
+    uint32_t n_logs;
+    uint32_t launches;          /* kernel launches it took (2 when the first capacity guess was too small) */
+    float kernel_ms;            /* duration of the last launch (HIP events) */
+    uint32_t reserved;
+    const uint64_t* patch_off;  /* [n_logs + 1] */
+    const ptx_patch_log* logs;  /* [n_logs] */
+    const ptx_patch* patches;   /* [patch_off[n_logs]] */
+    void* owner;
+} ptx_patches;
+
 typedef struct ptx_ctx ptx_ctx;          /* device context: stream + allocations */
 typedef struct ptx_dbatch ptx_dbatch;    /* a batch resident in HBM */
 typedef struct ptx_dresult ptx_dresult;  /* result buffers resident in HBM */
@@ -243,6 +278,14 @@ const ptx_log_result* ptx_dresult_logs_device(const ptx_dresult* r);
 /* Pack the digests of logs [first, first+count) as 2*count u64 into DEVICE memory `dst`
  * (e.g. a torch tensor that is then all-gathered with RCCL), on the context's stream. */
 ptx_status ptx_pack_digests(ptx_ctx* ctx, const ptx_dresult* r, uint32_t first, uint32_t count, uint64_t* dst_device);
+
+/* ---- patch streams ---- */
+/* Replay every log of `b` in application order and return the Patch[] stream each applyChange would have returned.
+ * `r` must be the result of ptx_merge on the same batch, produced WITH elem_rank (no PTX_FLAG_NO_ELEM_RANK) and
+ * complete (the call synchronises).  Capacity is guessed (2 records per op) and the launch repeated once with exact
+ * sizes when a log produced more. */
+ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_patches* out);
+void ptx_patches_free(ptx_patches* p);
 
 /* ---- introspection ---- */
 /* Largest number of ops one log may have in this build/device (on-chip working set limit). */

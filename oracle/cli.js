@@ -8,7 +8,7 @@
  *                            [--impl oracle|ref] --out FILE
  *       PTXGEN traces + expected output.  FILE = {config, seed, docs:[{docIndex, seed, actors,
  *       logs:[Change[] per replica], expected:[{spans, text} per replica]}]}
- *   node oracle/cli.js apply --in FILE [--impl oracle|ref] --out FILE
+ *   node oracle/cli.js apply --in FILE [--impl oracle|ref] [--cursors] [--patches] --out FILE
  *       FILE in  = {docs:[{logs:[Change[]...]}]} (e.g. a reference trace or a KAT);  every log is applied
  *       to a FRESH replica with applyChange (micromerge.ts:499) and flattened (peritext.ts:337).
  *       FILE out = {docs:[{expected:[{spans, text, error?}]}]}
@@ -43,9 +43,13 @@ function liveChange(change, impl) {
     return Object.assign({}, change, { ops })
 }
 
-function applyLog(Impl, impl, log) {
+function applyLog(Impl, impl, log, patchSink) {
     const doc = new Impl("oracle-reader")
-    for (const c of log) doc.applyChange(liveChange(O.normalizeChange(c), impl))
+    for (const c of log) {
+        const patches = doc.applyChange(liveChange(O.normalizeChange(c), impl))
+        /* the makeList patch is the raw op (incl. a Symbol obj in the reference): keep only its action */
+        if (patchSink) for (const p of patches) patchSink.push(p.action === "makeList" ? { action: "makeList" } : p)
+    }
     return doc
 }
 function expectedOf(doc) {
@@ -93,12 +97,15 @@ if (cmd === "gen") {
     const input = JSON.parse(fs.readFileSync(flag("--in"), "utf8"))
     const out = { impl, docs: [] }
     const wantCursors = argv.indexOf("--cursors") >= 0
+    const wantPatches = argv.indexOf("--patches") >= 0
     for (const d of input.docs) {
         const expected = []
         for (const log of d.logs) {
             try {
-                const doc = applyLog(Impl, impl, log)
+                const patches = wantPatches ? [] : null
+                const doc = applyLog(Impl, impl, log, patches)
                 const e = expectedOf(doc)
+                if (wantPatches) e.patches = patches /* the concatenated returns of applyChange (micromerge.ts:499) */
                 if (wantCursors) {
                     /* micromerge.ts:465-477: getCursor for every visible index, resolveCursor for every element ever inserted */
                     e.cursorAt = e.text.map((_, i) => doc.getCursor(["text"], i).elemId)

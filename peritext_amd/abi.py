@@ -7,7 +7,7 @@ the shared object is missing, and `ptx_create` fails when no gfx950 device is vi
 import ctypes as C
 import os
 
-PTX_ABI_VERSION = 2
+PTX_ABI_VERSION = 3
 
 # Operation.action (reference/src/micromerge.ts:150-212, src/peritext.ts:25-65)
 ACT_MAKELIST, ACT_INSERT, ACT_DELETE, ACT_ADDMARK, ACT_REMOVEMARK, ACT_NOP = range(6)
@@ -126,6 +126,31 @@ class ptx_result(C.Structure):
     ]
 
 
+# Patch[] streams (what applyChange returns, reference/src/micromerge.ts:499)
+PATCH_MAKELIST, PATCH_INSERT, PATCH_DELETE, PATCH_ADDMARK, PATCH_REMOVEMARK, PATCH_INSERT_COMMENT = range(6)
+
+
+class ptx_patch(C.Structure):
+    _fields_ = [("row", C.c_uint32), ("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32)]
+
+
+class ptx_patch_log(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("n_patches", C.c_uint32)]
+
+
+class ptx_patches(C.Structure):
+    _fields_ = [
+        ("n_logs", C.c_uint32),
+        ("launches", C.c_uint32),
+        ("kernel_ms", C.c_float),
+        ("reserved", C.c_uint32),
+        ("patch_off", u64p),
+        ("logs", C.POINTER(ptx_patch_log)),
+        ("patches", C.POINTER(ptx_patch)),
+        ("owner", C.c_void_p),
+    ]
+
+
 # numpy dtypes with the same layout
 import numpy as np  # noqa: E402
 
@@ -144,6 +169,8 @@ LOG_RESULT_DTYPE = np.dtype(
 LOG_HDR_DTYPE = np.dtype([("n_ins", "<u4"), ("n_del", "<u4"), ("n_mark", "<u4", (4,)), ("max_counter", "<u4"), ("max_actor", "<u4")])
 SPAN_DTYPE = np.dtype([("start", "<u4"), ("attr", "<u4")])
 CINTERVAL_DTYPE = np.dtype([("id", "<u4"), ("start", "<u4"), ("end", "<u4")])
+PATCH_DTYPE = np.dtype([("row", "<u4"), ("kind", "<u4"), ("a", "<u4"), ("b", "<u4")])
+PATCH_LOG_DTYPE = np.dtype([("status", "<u4"), ("n_patches", "<u4")])
 
 # every function include/peritext_hip.h declares: name -> (restype, argtypes)
 vp = C.c_void_p
@@ -171,6 +198,8 @@ FUNCTIONS = {
     "ptx_result_download_logs": (C.c_int32, [vp, vp, C.POINTER(ptx_log_result), C.c_uint32]),
     "ptx_dresult_logs_device": (vp, [vp]),
     "ptx_pack_digests": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "ptx_replay_patches": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_patches)]),
+    "ptx_patches_free": (None, [C.POINTER(ptx_patches)]),
     "ptx_max_ops_per_log": (C.c_uint32, [vp]),
     "ptx_kernel_name": (C.c_char_p, []),
 }

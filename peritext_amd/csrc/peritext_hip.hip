@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "merge_core.h"
+#include "replay_core.h"
 
 /* ------------------------------------------------------------------------------------------------ */
 /* kernels                                                                                          */
@@ -39,6 +40,13 @@ PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false, 0)     /* any launch shape (b
 PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0) /* + causal admission for documents with more than four actors */
 /* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
  * issue ~1 % fewer instructions but need twice the VGPRs unless PTX_U=1, so only the run-time-sized builds are shipped) */
+
+/* Patch-stream replay (replay_core.h): one 64-thread workgroup (one wave) per log, sequential in application order */
+#define PTX_REPLAY_THREADS 64
+extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kernel(PtxReplayArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
+    if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS>(A, blockIdx.x, ptx_lds);
+}
 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
@@ -266,7 +274,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many, (const void*)ptx_replay_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -691,6 +699,127 @@ ptx_status ptx_apply_materialize(ptx_ctx* ctx, const ptx_batch* batch, ptx_resul
     ptx_dresult_free(ctx, r);
     ptx_batch_free(ctx, b);
     return st;
+}
+
+/* ---- patch streams ---- */
+struct ptx_host_patches {
+    std::vector<uint64_t> off;
+    std::vector<ptx_patch_log> logs;
+    std::vector<ptx_patch> patches;
+};
+
+void ptx_patches_free(ptx_patches* p) {
+    if (!p) return;
+    delete (ptx_host_patches*)p->owner;
+    memset(p, 0, sizeof(*p));
+}
+
+ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_patches* out) {
+    if (!ctx || !b || !r || !out) return PTX_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
+    if (!r->rank) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_replay_patches needs the elem_rank column (context created with PTX_FLAG_NO_ELEM_RANK)");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    ptx_host_patches* h = new ptx_host_patches();
+    const uint32_t L = b->n_logs;
+    h->off.assign((size_t)L + 1, 0);
+    h->logs.resize(std::max<uint32_t>(L, 1));
+    out->owner = h;
+    out->n_logs = L;
+    if (L == 0) {
+        h->patches.resize(1);
+        out->patch_off = h->off.data();
+        out->logs = h->logs.data();
+        out->patches = h->patches.data();
+        return PTX_OK;
+    }
+    /* launch shape from the log headers: LDS of the largest replay working set */
+    std::vector<ptx_log_hdr> hdr(L);
+    std::vector<uint64_t> log_off((size_t)L + 1);
+    hipError_t e = hipMemcpyAsync(hdr.data(), b->log_hdr, (size_t)L * sizeof(ptx_log_hdr), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(log_off.data(), b->log_off, ((size_t)L + 1) * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ptx_patches_free(out);
+        return fail(ctx, PTX_ERR_HIP, std::string("replay set-up: ") + hipGetErrorString(e));
+    }
+    uint64_t need = 0;
+    for (uint32_t l = 0; l < L; ++l) need = std::max<uint64_t>(need, ptx_replay_lds_need_hdr(hdr[l]));
+    const uint32_t lds_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, ctx->max_lds); /* larger logs report PTX_ERR_CAPACITY */
+    for (uint32_t l = 0; l < L; ++l) h->off[l + 1] = h->off[l] + 2 * (log_off[l + 1] - log_off[l]) + 16;
+
+    uint64_t* d_off = nullptr;
+    ptx_patch_log* d_logs = nullptr;
+    ptx_patch* d_patches = nullptr;
+    ptx_status st = PTX_OK;
+    auto release = [&]() {
+        (void)hipFree(d_off);
+        (void)hipFree(d_logs);
+        (void)hipFree(d_patches);
+        d_off = nullptr;
+        d_logs = nullptr;
+        d_patches = nullptr;
+    };
+    for (uint32_t attempt = 0; attempt < 2 && st == PTX_OK; ++attempt) {
+        const uint64_t total = h->off[L];
+        e = hipMalloc((void**)&d_off, ((size_t)L + 1) * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_logs, (size_t)L * sizeof(ptx_patch_log));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_patches, std::max<uint64_t>(total, 1) * sizeof(ptx_patch));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_off, h->off.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            PtxReplayArgs A;
+            A.log_off = b->log_off;
+            A.op_id = b->op_id;
+            A.ref_a = b->ref_a;
+            A.ref_b = b->ref_b;
+            A.payload = b->payload;
+            A.action = b->action;
+            A.mark_type = b->mark_type;
+            A.side_a = b->side_a;
+            A.side_b = b->side_b;
+            A.log_hdr = b->log_hdr;
+            A.res = r->logs;
+            A.elem_rank = r->rank;
+            A.patch_off = d_off;
+            A.patches = d_patches;
+            A.plogs = d_logs;
+            A.n_logs = L;
+            A.lds_bytes = lds_bytes;
+            (void)hipEventRecord(ctx->ev0, ctx->stream);
+            hipLaunchKernelGGL(ptx_replay_kernel, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);
+            e = hipGetLastError();
+            (void)hipEventRecord(ctx->ev1, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h->logs.data(), d_logs, (size_t)L * sizeof(ptx_patch_log), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) (void)hipEventElapsedTime(&out->kernel_ms, ctx->ev0, ctx->ev1);
+        if (e != hipSuccess) {
+            st = fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("ptx_replay_kernel: ") + hipGetErrorString(e));
+            break;
+        }
+        out->launches = attempt + 1;
+        bool over = false;
+        for (uint32_t l = 0; l < L; ++l) over = over || h->logs[l].n_patches > h->off[l + 1] - h->off[l];
+        if (!over || attempt == 1) {
+            h->patches.resize(std::max<uint64_t>(total, 1));
+            if (total) e = hipMemcpyAsync(h->patches.data(), d_patches, total * sizeof(ptx_patch), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) st = fail(ctx, PTX_ERR_HIP, std::string("patch download: ") + hipGetErrorString(e));
+            break;
+        }
+        /* some log produced more records than guessed: exact sizes, once more */
+        for (uint32_t l = 0; l < L; ++l) h->off[l + 1] = h->off[l] + std::max<uint64_t>(h->logs[l].n_patches, 1);
+        release();
+    }
+    release();
+    if (st != PTX_OK) {
+        ptx_patches_free(out);
+        return st;
+    }
+    out->patch_off = h->off.data();
+    out->logs = h->logs.data();
+    out->patches = h->patches.data();
+    return PTX_OK;
 }
 
 } /* extern "C" */

@@ -1,0 +1,453 @@
+/*
+ * replay_core.h — the incremental Patch[] stream of one replica log.
+ *
+ * What it replaces: the patches that `applyChange` (reference/src/micromerge.ts:499 -> applyOp :534) RETURNS, op by
+ * op, in the replica's application order:
+ *   insert  {action:"insert", index, values:[v], marks}      micromerge.ts:661-671, marks = getActiveMarksAtIndex
+ *                                                            (peritext.ts:328) = the closest defined slot to the left
+ *   delete  {action:"delete", index, count:1}                micromerge.ts:696-703 (nothing for a tombstone)
+ *   add/removeMark  one patch per run of boundary slots whose effective marks change
+ *                                                            peritext.ts:154-220, :251-281
+ *   makeList  the op itself                                  micromerge.ts:575
+ *
+ * How: ptx_merge_kernel has already produced the FINAL document position (rank incl. tombstones) of every element
+ * (`elem_rank`).  Because the RGA order of any two elements never changes once both exist, the state of the
+ * replica at application time t is the final order restricted to the elements inserted before t.  The log is therefore
+ * replayed in time order over arrays indexed by final rank / final boundary slot (slot = 2*rank + side):
+ *   present   bit per rank  {bits, running popcount prefix}: inserted and not deleted -> visible index = popcount below
+ *   defined   bit per slot : the reference's `markOpsBefore/After !== undefined` (peritext.ts:167-214): set at the start
+ *             and end slot of every applied mark op; patches break at every defined slot inside the op's range
+ *   win[3]    per defined slot: row of the max-opId covering op per non-multi mark type (opsToMarks, :304-313)
+ *   anyc      bit per slot : some comment op covers (the `comment: []` state)
+ *   comment ops: [start, end) slots + per-id chains in application order (the LAST-applied covering op of an id
+ *             decides its presence, :314-321)
+ * One 64-thread workgroup (one wave) per log: the replay is sequential in t, every step is a handful of wave-wide
+ * passes over bitmap words / the defined slots of the range.
+ *
+ * Compiled two ways like merge_core.h (hipcc: the product kernel; g++ -DPTX_EMU: CPU test tooling only).
+ */
+#pragma once
+#include "merge_core.h"
+
+#define PTX_SLOT_NONE 0xFFFFu /* start never matches / end never reached */
+
+struct PtxReplayArgs {
+    const uint64_t* log_off;
+    const uint64_t* op_id;
+    const uint64_t* ref_a;
+    const uint64_t* ref_b;
+    const uint32_t* payload;
+    const uint8_t* action;
+    const uint8_t* mark_type;
+    const uint8_t* side_a;
+    const uint8_t* side_b;
+    const ptx_log_hdr* log_hdr;
+    const ptx_log_result* res;  /* of ptx_merge on the same batch */
+    const uint32_t* elem_rank;  /* of ptx_merge on the same batch */
+    const uint64_t* patch_off;  /* [n_logs + 1] capacity offsets into `patches` */
+    ptx_patch* patches;
+    ptx_patch_log* plogs;
+    uint32_t n_logs;
+    uint32_t lds_bytes;
+};
+
+struct PtxReplayHdr {
+    uint32_t npatch;   /* patches produced so far (may run past the capacity: only the count is kept then) */
+    uint32_t ncom;     /* comment ops registered */
+    uint32_t tmp;      /* per-step scratch: max / counter */
+    uint32_t nvis;     /* visible length */
+    uint32_t scan_tmp[36];
+};
+
+PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks) {
+    const uint64_t nw = (ks + 31) / 32, nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
+    const uint64_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
+    return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(8 * nwe) + 2 * ptx_a16(4 * nws) +
+           ptx_a16(4 * (nws + 1)) + 3 * ptx_a16(2 * (2 * n + 2)) + 2 * ptx_a16(2 * segcap) +
+           6 * ptx_a16(2 * (Kc + 1)) + ptx_a16(Kc + 1);
+}
+PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h) {
+    const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
+    const uint64_t ks = ((uint64_t)h.max_counter + 1) * ((uint64_t)(h.max_actor > 4095u ? 4095u : h.max_actor) + 1);
+    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], ks);
+}
+
+/* one patch record; rows past the capacity are counted, not written */
+PTX_DEV void ptx_patch_put(const PtxReplayArgs& A, uint64_t pbase, uint32_t pcap, uint32_t idx, uint32_t row, uint32_t kind, uint32_t a, uint32_t b) {
+    if (idx < pcap) {
+        ptx_patch p;
+        p.row = row;
+        p.kind = kind;
+        p.a = a;
+        p.b = b;
+        A.patches[pbase + idx] = p;
+    }
+}
+
+template <uint32_t kThreads>
+PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) {
+    PtxReplayHdr* H = (PtxReplayHdr*)lds;
+    const uint64_t base = A.log_off[log];
+    const uint32_t N = (uint32_t)(A.log_off[log + 1] - base);
+    const uint64_t pbase = A.patch_off[log];
+    const uint32_t pcap = (uint32_t)(A.patch_off[log + 1] - pbase);
+    const uint64_t* op_id = A.op_id + base;
+    const uint64_t* ref_a = A.ref_a + base;
+    const uint64_t* ref_b = A.ref_b + base;
+    const uint32_t* payload = A.payload + base;
+    const uint8_t* action = A.action + base;
+    const uint8_t* mark_type = A.mark_type + base;
+    const uint8_t* side_a = A.side_a + base;
+    const uint8_t* side_b = A.side_b + base;
+    const uint32_t* erank = A.elem_rank + base;
+
+    const uint32_t merge_status = A.res[log].status;
+    if (merge_status != PTX_OK || N == 0) { /* the reference threw somewhere in this log: no stream (the status says why) */
+        PTX_LEADER {
+            ptx_patch_log pl;
+            pl.status = merge_status;
+            pl.n_patches = 0;
+            A.plogs[log] = pl;
+        }
+        return;
+    }
+    const ptx_log_hdr hd = A.log_hdr[log];
+    const uint32_t n = hd.n_ins, Kc = hd.n_mark[PTX_MARK_COMMENT];
+    const uint32_t K = hd.n_mark[0] + hd.n_mark[1] + hd.n_mark[2] + hd.n_mark[3];
+    PtxElemIndex ix;
+    ix.max_ctr = hd.max_counter;
+    ix.max_actor = hd.max_actor;
+    ix.na1 = ix.max_actor + 1u;
+    const uint32_t keyspace = (ix.max_ctr + 1u) * ix.na1;
+    const uint32_t nw = (keyspace + 31) / 32, nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
+    const uint32_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
+
+    PtxBump bp;
+    bp.base = lds;
+    bp.off = (uint32_t)ptx_a16(sizeof(PtxReplayHdr));
+    bp.cap = A.lds_bytes;
+    bp.high = bp.off;
+    bp.overflow = false;
+    ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
+    uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1);
+    uint16_t* rank_of = ptx_alloc<uint16_t>(bp, n + 1);
+    PtxBitWord* present = ptx_alloc<PtxBitWord>(bp, nwe);
+    uint32_t* defined = ptx_alloc<uint32_t>(bp, nws);
+    uint32_t* anyc = ptx_alloc<uint32_t>(bp, nws);
+    uint32_t* wcnt = ptx_alloc<uint32_t>(bp, nws + 1); /* defined slots of the range per word -> prefix */
+    uint16_t* win[3];
+    win[0] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* strong */
+    win[1] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* em */
+    win[2] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* link */
+    uint16_t* seg = ptx_alloc<uint16_t>(bp, segcap);      /* defined slots of the op's range, ascending */
+    uint16_t* seg_flag = ptx_alloc<uint16_t>(bp, segcap); /* 1 = emits a patch -> prefix = its place */
+    uint16_t* ca = ptx_alloc<uint16_t>(bp, Kc + 1);       /* comment op: first covered slot */
+    uint16_t* cb = ptx_alloc<uint16_t>(bp, Kc + 1);       /*             first slot not covered (PTX_SLOT_NONE = to the end) */
+    uint16_t* ccid = ptx_alloc<uint16_t>(bp, Kc + 1);
+    uint16_t* cprev = ptx_alloc<uint16_t>(bp, Kc + 1);    /* chain of the ops with the same id, application order */
+    uint16_t* cnext = ptx_alloc<uint16_t>(bp, Kc + 1);
+    uint16_t* ctail = ptx_alloc<uint16_t>(bp, Kc + 1);    /* per id: last registered op */
+    uint8_t* cadd = ptx_alloc<uint8_t>(bp, Kc + 1);
+    if (bp.overflow || ix.max_actor > 4095u || n > 32766u || N > 65534u) {
+        PTX_LEADER {
+            ptx_patch_log pl;
+            pl.status = PTX_ERR_CAPACITY;
+            pl.n_patches = 0;
+            A.plogs[log] = pl;
+        }
+        return;
+    }
+
+    /* ---- set-up: elemId -> element -> (row, final rank) ---- */
+    PTX_FOR(w, nw + 1) {
+        PtxBitWord z;
+        z.bits = 0;
+        z.pre = 0;
+        ix.ib[w] = z;
+    }
+    PTX_FOR(w, nwe) {
+        PtxBitWord z;
+        z.bits = 0;
+        z.pre = 0;
+        present[w] = z;
+    }
+    PTX_FOR(w, nws) {
+        defined[w] = 0;
+        anyc[w] = 0;
+    }
+    PTX_FOR(c, Kc + 1) ctail[c] = PTX_SLOT_NONE;
+    PTX_LEADER {
+        H->npatch = 0;
+        H->ncom = 0;
+        H->tmp = 0;
+        H->nvis = 0;
+    }
+    PTX_SYNC();
+    PTX_FOR(i, N) {
+        if (action[i] == PTX_ACT_INSERT) {
+            uint32_t key = 0;
+            if (ptx_id_key(ix, op_id[i], key)) ptx_atomic_or(&ix.ib[key >> 5].bits, 1u << (key & 31));
+        }
+    }
+    PTX_SYNC();
+    PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
+    PTX_SYNC();
+    ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
+    PTX_FOR(i, N) {
+        if (action[i] == PTX_ACT_INSERT) {
+            const int e = ptx_elem_lookup(ix, op_id[i]);
+            if (e >= 0 && (uint32_t)e < n) {
+                row_of[e] = (uint16_t)i;
+                rank_of[e] = (uint16_t)(erank[i] & PTX_RANK_MASK);
+            }
+        }
+    }
+    PTX_SYNC();
+
+    /* last defined slot strictly below `lim` -> H->tmp = slot + 1 (0 = none); every thread calls it */
+#define PTX_LAST_DEFINED_BELOW(lim_)                                                            \
+    do {                                                                                        \
+        PTX_LEADER { H->tmp = 0; }                                                              \
+        PTX_SYNC();                                                                             \
+        PTX_FOR(w_, ((lim_) + 31u) >> 5) {                                                      \
+            uint32_t m_ = defined[w_];                                                          \
+            if ((w_ << 5) + 32u > (lim_)) m_ &= (1u << ((lim_)&31u)) - 1u;                      \
+            if (m_) ptx_atomic_max(&H->tmp, (w_ << 5) + (31u - (uint32_t)__builtin_clz(m_)) + 1u); \
+        }                                                                                       \
+        PTX_SYNC();                                                                             \
+    } while (0)
+
+    /* make slot s_ a defined one: its state is that of the closest defined slot to the left (peritext.ts:176) */
+#define PTX_DEFINE_SLOT(s_)                                                                     \
+    do {                                                                                        \
+        if (!ptx_bittest(defined, (s_))) {                                                      \
+            PTX_LAST_DEFINED_BELOW(s_);                                                         \
+            PTX_LEADER {                                                                        \
+                const uint32_t l1_ = H->tmp;                                                    \
+                win[0][s_] = l1_ ? win[0][l1_ - 1u] : (uint16_t)0;                              \
+                win[1][s_] = l1_ ? win[1][l1_ - 1u] : (uint16_t)0;                              \
+                win[2][s_] = l1_ ? win[2][l1_ - 1u] : (uint16_t)0;                              \
+                if (l1_ && ptx_bittest(anyc, l1_ - 1u)) anyc[(s_) >> 5] |= 1u << ((s_)&31u);    \
+                defined[(s_) >> 5] |= 1u << ((s_)&31u);                                         \
+            }                                                                                   \
+            PTX_SYNC();                                                                         \
+        }                                                                                       \
+    } while (0)
+
+    /* ---- the replay, one op at a time ---- */
+#pragma nounroll
+    for (uint32_t t = 0; t < N; ++t) {
+        const uint32_t act = action[t];
+        if (act == PTX_ACT_MAKELIST) {
+            PTX_LEADER {
+                ptx_patch_put(A, pbase, pcap, H->npatch, t, PTX_PATCH_MAKELIST, 0u, 0u);
+                H->npatch += 1;
+            }
+            PTX_SYNC();
+        } else if (act == PTX_ACT_INSERT) {
+            const int e = ptx_elem_lookup(ix, op_id[t]);
+            const uint32_t r = rank_of[e];
+            PTX_LAST_DEFINED_BELOW(2u * r);
+            const uint32_t l1 = H->tmp; /* slot + 1 */
+            const uint32_t p0 = H->npatch;
+            PTX_SYNC();
+            PTX_LEADER {
+                uint32_t attr = 0;
+                if (l1) {
+                    const uint32_t l = l1 - 1u;
+                    const uint32_t ws = win[0][l], we = win[1][l], wl = win[2][l];
+                    if (ws && action[ws - 1u] == PTX_ACT_ADDMARK) attr |= PTX_ATTR_STRONG;
+                    if (we && action[we - 1u] == PTX_ACT_ADDMARK) attr |= PTX_ATTR_EM;
+                    if (wl && action[wl - 1u] == PTX_ACT_ADDMARK) attr |= PTX_ATTR_LINK | (payload[wl - 1u] & PTX_ATTR_ID_MASK);
+                    if (ptx_bittest(anyc, l)) attr |= PTX_ATTR_COMMENT;
+                }
+                ptx_patch_put(A, pbase, pcap, p0, t, PTX_PATCH_INSERT, ptx_bitrank(present, r), attr);
+                H->tmp = 0; /* comment ids of this patch */
+            }
+            PTX_SYNC();
+            if (l1 && ptx_bittest(anyc, l1 - 1u)) {
+                const uint32_t l = l1 - 1u, nc = H->ncom;
+                PTX_FOR(kc, nc) {
+                    if (cadd[kc] && ca[kc] <= l && l < cb[kc]) {
+                        bool last = true; /* no later-applied covering op of the same id */
+                        for (uint32_t y = cnext[kc]; y != PTX_SLOT_NONE; y = cnext[y])
+                            if (ca[y] <= l && l < cb[y]) {
+                                last = false;
+                                break;
+                            }
+                        if (last) ptx_patch_put(A, pbase, pcap, p0 + 1u + ptx_atomic_add(&H->tmp, 1u), t, PTX_PATCH_INSERT_COMMENT, ccid[kc], 0u);
+                    }
+                }
+                PTX_SYNC();
+            }
+            /* the element is visible from now on */
+            PTX_FOR(w, nwe) {
+                if (w == (r >> 5)) present[w].bits |= 1u << (r & 31);
+                else if (w > (r >> 5)) present[w].pre += 1;
+            }
+            PTX_LEADER {
+                H->npatch = p0 + 1u + H->tmp;
+                H->nvis += 1;
+            }
+            PTX_SYNC();
+        } else if (act == PTX_ACT_DELETE) {
+            const int e = ptx_elem_lookup(ix, ref_a[t]);
+            const uint32_t r = rank_of[e];
+            const bool was = (present[r >> 5].bits >> (r & 31)) & 1u;
+            PTX_SYNC();
+            if (was) {
+                PTX_LEADER {
+                    ptx_patch_put(A, pbase, pcap, H->npatch, t, PTX_PATCH_DELETE, ptx_bitrank(present, r), 1u);
+                    H->npatch += 1;
+                    H->nvis -= 1;
+                }
+                PTX_SYNC();
+                PTX_FOR(w, nwe) {
+                    if (w == (r >> 5)) present[w].bits &= ~(1u << (r & 31));
+                    else if (w > (r >> 5)) present[w].pre -= 1;
+                }
+                PTX_SYNC();
+            }
+        } else if ((act == PTX_ACT_ADDMARK || act == PTX_ACT_REMOVEMARK) && mark_type[t] < 4u) {
+            const uint32_t ty = mark_type[t], sa = side_a[t], sb = side_b[t];
+            /* boundary slots as the walk of peritext.ts:167-214 meets them (merge_core.h P5a has the same rules) */
+            uint32_t slot_a = PTX_SLOT_NONE, slot_b = PTX_SLOT_NONE;
+            if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
+                const int js = ptx_elem_lookup(ix, ref_a[t]);
+                if (js >= 0 && row_of[js] < t) slot_a = 2u * rank_of[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
+            }
+            if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
+                const int je = ptx_elem_lookup(ix, ref_b[t]);
+                if (je >= 0 && row_of[je] < t) slot_b = 2u * rank_of[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
+            }
+            if (slot_a != PTX_SLOT_NONE && slot_b == slot_a) slot_b = PTX_SLOT_NONE; /* the start test fires first (A.6-3) */
+            if (slot_a == PTX_SLOT_NONE || slot_b < slot_a) {
+                /* the end is met while the op has not started: its slot becomes a defined one (a copy of the state to
+                 * its left), the op covers nothing and the walk stops (peritext.ts:240-243) */
+                if (slot_b != PTX_SLOT_NONE) PTX_DEFINE_SLOT(slot_b);
+                continue;
+            }
+            PTX_DEFINE_SLOT(slot_a);
+            if (slot_b != PTX_SLOT_NONE) PTX_DEFINE_SLOT(slot_b); /* inherits the state BEFORE this op from inside the range */
+            /* the defined slots of [slot_a, lim), ascending */
+            const uint32_t lim = slot_b != PTX_SLOT_NONE ? slot_b : 2u * n;
+            const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5;
+#define PTX_RANGE_BITS(w_, m_)                                                       \
+    uint32_t m_ = defined[w_];                                                       \
+    if ((w_) == wlo) m_ &= ~((1u << (slot_a & 31u)) - 1u);                           \
+    if (((w_) << 5) + 32u > lim) m_ &= (lim & 31u) ? (1u << (lim & 31u)) - 1u : 0u;
+            PTX_FOR(wi, whi - wlo + 1u) {
+                const uint32_t w = wlo + wi;
+                uint32_t c = 0;
+                if (w < whi) {
+                    PTX_RANGE_BITS(w, m)
+                    c = ptx_popc(m);
+                }
+                wcnt[wi] = c;
+            }
+            PTX_SYNC();
+            const uint32_t S = ptx_scan_excl<uint32_t, 1, kThreads>(wcnt, whi - wlo + 1u, H->scan_tmp);
+            PTX_FOR(wi, whi - wlo) {
+                const uint32_t w = wlo + wi;
+                PTX_RANGE_BITS(w, m)
+                uint32_t o = wcnt[wi];
+                while (m) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    if (o < segcap) seg[o] = (uint16_t)((w << 5) + b);
+                    ++o;
+                }
+            }
+#undef PTX_RANGE_BITS
+            PTX_SYNC();
+            const uint32_t nvis = H->nvis, nc = H->ncom;
+            const uint32_t my_id = payload[t];
+            const uint64_t my_op = op_id[t];
+            /* per defined slot: did the effective marks change (peritext.ts:208), new state, visible index */
+            PTX_FOR(j, S) {
+                const uint32_t s = seg[j];
+                bool changed = false;
+                if (ty != PTX_MARK_COMMENT) {
+                    uint16_t* wt = win[ty == PTX_MARK_STRONG ? 0 : ty == PTX_MARK_EM ? 1 : 2];
+                    const uint32_t w = wt[s];
+                    bool wins = true, old_on = false;
+                    uint32_t old_val = 0;
+                    if (w) {
+                        wins = my_op > op_id[w - 1u]; /* compareOpIds: counter, then actor (ranks keep the string order) */
+                        old_on = action[w - 1u] == PTX_ACT_ADDMARK;
+                        old_val = ty == PTX_MARK_LINK ? payload[w - 1u] & PTX_ATTR_ID_MASK : 0u;
+                    }
+                    if (wins) {
+                        const bool new_on = act == PTX_ACT_ADDMARK;
+                        const uint32_t new_val = ty == PTX_MARK_LINK ? my_id & PTX_ATTR_ID_MASK : 0u;
+                        changed = new_on != old_on || (new_on && new_val != old_val);
+                        wt[s] = (uint16_t)(t + 1u);
+                    }
+                } else {
+                    /* the last-applied covering op with this id (this op is not registered yet) */
+                    int state = -1; /* -1 none, 0 removed, 1 present */
+                    for (uint32_t y = my_id < Kc ? ctail[my_id] : PTX_SLOT_NONE; y != PTX_SLOT_NONE; y = cprev[y])
+                        if (ca[y] <= s && s < cb[y]) {
+                            state = cadd[y] ? 1 : 0;
+                            break;
+                        }
+                    const bool any = ptx_bittest(anyc, s);
+                    changed = act == PTX_ACT_ADDMARK ? state != 1 : (state == 1 || !any); /* remove on no comment key: undefined -> [] */
+                }
+                seg_flag[j] = changed ? 1u : 0u;
+            }
+            PTX_SYNC();
+            if (ty == PTX_MARK_COMMENT) {
+                PTX_FOR(j, S) {
+                    const uint32_t s = seg[j];
+                    ptx_atomic_or(&anyc[s >> 5], 1u << (s & 31));
+                }
+            }
+            /* a changed slot opens a patch that the next defined slot (or the end of the range / text) closes;
+             * zero-width ones are dropped (peritext.ts:269-281) */
+            const uint32_t v_end = slot_b != PTX_SLOT_NONE ? ptx_bitrank(present, (slot_b + 1u) >> 1) : nvis;
+#define PTX_VIS_AT(s_) ptx_bitrank(present, ((uint32_t)(s_) + 1u) >> 1) /* visible index at a boundary slot */
+            PTX_FOR(j, S) {
+                const uint32_t ve = j + 1u < S ? PTX_VIS_AT(seg[j + 1u]) : v_end;
+                seg_flag[j] = (seg_flag[j] && ve > PTX_VIS_AT(seg[j])) ? 1u : 0u;
+            }
+            PTX_LEADER { seg_flag[S] = 0; }
+            PTX_SYNC();
+            const uint32_t P = ptx_scan_excl<uint16_t, 1, kThreads>(seg_flag, S + 1u, H->scan_tmp);
+            const uint32_t p0 = H->npatch;
+            PTX_FOR(j, S) {
+                if (seg_flag[j + 1u] != seg_flag[j]) {
+                    const uint32_t ve = j + 1u < S ? PTX_VIS_AT(seg[j + 1u]) : v_end;
+                    ptx_patch_put(A, pbase, pcap, p0 + seg_flag[j], t, act == PTX_ACT_ADDMARK ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT(seg[j]), ve);
+                }
+            }
+#undef PTX_VIS_AT
+            PTX_SYNC();
+            PTX_LEADER {
+                H->npatch = p0 + P;
+                if (ty == PTX_MARK_COMMENT && my_id < Kc && nc < Kc) {
+                    ca[nc] = (uint16_t)slot_a;
+                    cb[nc] = (uint16_t)slot_b;
+                    ccid[nc] = (uint16_t)my_id;
+                    cadd[nc] = act == PTX_ACT_ADDMARK ? 1 : 0;
+                    cnext[nc] = PTX_SLOT_NONE;
+                    const uint32_t prev = ctail[my_id];
+                    cprev[nc] = (uint16_t)prev;
+                    if (prev != PTX_SLOT_NONE) cnext[prev] = (uint16_t)nc;
+                    ctail[my_id] = (uint16_t)nc;
+                    H->ncom = nc + 1u;
+                }
+            }
+            PTX_SYNC();
+        }
+    }
+#undef PTX_LAST_DEFINED_BELOW
+#undef PTX_DEFINE_SLOT
+    PTX_SYNC();
+    PTX_LEADER {
+        ptx_patch_log pl;
+        pl.status = H->npatch > pcap ? (uint32_t)PTX_ERR_CAPACITY : (uint32_t)PTX_OK;
+        pl.n_patches = H->npatch;
+        A.plogs[log] = pl;
+    }
+}

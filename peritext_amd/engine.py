@@ -156,6 +156,21 @@ class Engine:
         finally:
             self.lib.ptx_result_free(C.byref(res))
 
+    def replay_patches(self, dbatch, dresult):
+        """The Patch[] stream every applyChange of every log would have returned (reference/src/micromerge.ts:499),
+        as wire.Patches; `dresult` = the merge of the same batch (engine created without FLAG_NO_ELEM_RANK)."""
+        p = abi.ptx_patches()
+        self._check(self.lib.ptx_replay_patches(self.ctx, dbatch, dresult, C.byref(p)))
+        try:
+            n = int(p.n_logs)
+            off = np.ctypeslib.as_array(p.patch_off, shape=(n + 1,)).copy() if n else np.zeros(1, dtype=np.uint64)
+            logs = np.frombuffer(C.string_at(p.logs, n * C.sizeof(abi.ptx_patch_log)), dtype=abi.PATCH_LOG_DTYPE).copy() if n else np.zeros(0, dtype=abi.PATCH_LOG_DTYPE)
+            total = int(off[n]) if n else 0
+            rows = np.frombuffer(C.string_at(p.patches, total * C.sizeof(abi.ptx_patch)), dtype=abi.PATCH_DTYPE).copy() if total else np.zeros(0, dtype=abi.PATCH_DTYPE)
+            return wire.Patches(patch_off=off, logs=logs, patches=rows, kernel_ms=float(p.kernel_ms), launches=int(p.launches))
+        finally:
+            self.lib.ptx_patches_free(C.byref(p))
+
     def download_logs(self, dresult, n_logs):
         out = np.zeros(n_logs, dtype=abi.LOG_RESULT_DTYPE)
         self._check(self.lib.ptx_result_download_logs(self.ctx, dresult, out.ctypes.data_as(C.POINTER(abi.ptx_log_result)), n_logs))

@@ -286,6 +286,77 @@ def decode_spans(batch, res, log):
     return out
 
 
+class Patches:
+    """Patch streams of a batch (ptx_replay_patches): records of log l = patches[patch_off[l] : patch_off[l] + logs[l].n_patches]."""
+
+    def __init__(self, patch_off, logs, patches, kernel_ms=0.0, launches=1):
+        self.patch_off, self.logs, self.patches, self.kernel_ms, self.launches = patch_off, logs, patches, kernel_ms, launches
+
+    def of_log(self, log):
+        b0 = int(self.patch_off[log])
+        return self.patches[b0:b0 + int(self.logs[log]["n_patches"])]
+
+
+def _marks_of_attr(batch, attr, comment_ids, comments):
+    marks = {}
+    if attr & abi.ATTR_STRONG:
+        marks["strong"] = {"active": True}
+    if attr & abi.ATTR_EM:
+        marks["em"] = {"active": True}
+    if attr & abi.ATTR_COMMENT:
+        marks["comment"] = [{"id": comments[i]} for i in sorted(comment_ids)]
+    if attr & abi.ATTR_LINK:
+        marks["link"] = {"url": batch.urls[attr & abi.ATTR_ID_MASK]}
+    return marks
+
+
+def decode_patches(batch, pat, log, with_rows=False):
+    """Patch[] of one log in application order, in the reference's shapes (reference/src/micromerge.ts:214-222 Patch,
+    :661-671 insert, :696-703 delete, src/peritext.ts:251-281 add/removeMark).  The makeList patch (the op itself,
+    micromerge.ts:575) is reduced to {"action": "makeList"}.  Raises on a log without a stream.
+    with_rows: add "_row" (the op row that produced the patch) and, on comment patches, "_commentId" — the reference's
+    removeMark patch does not say WHICH comment went away (peritext.ts:262 attaches attrs to addMark only)."""
+    st = int(pat.logs[log]["status"])
+    if st != 0:
+        raise ValueError(abi.STATUS_NAMES.get(st, "error %d" % st))
+    b0 = int(batch.log_off[log])
+    comments = batch.doc_comments[batch.log_doc[log]]
+    rows = pat.of_log(log)
+    out = []
+    k = 0
+    while k < len(rows):
+        r = rows[k]
+        kind, row, a, b = int(r["kind"]), int(r["row"]), int(r["a"]), int(r["b"])
+        k += 1
+        if kind == abi.PATCH_MAKELIST:
+            out.append({"action": "makeList"})
+        elif kind == abi.PATCH_INSERT:
+            ids = []
+            while k < len(rows) and int(rows[k]["kind"]) == abi.PATCH_INSERT_COMMENT:
+                ids.append(int(rows[k]["a"]))
+                k += 1
+            out.append({"path": ["text"], "action": "insert", "index": a, "values": [batch.values[int(batch.payload[b0 + row])]],
+                        "marks": _marks_of_attr(batch, b, ids, comments)})
+        elif kind == abi.PATCH_DELETE:
+            out.append({"path": ["text"], "action": "delete", "index": a, "count": b})
+        elif kind in (abi.PATCH_ADDMARK, abi.PATCH_REMOVEMARK):
+            mt = int(batch.mark_type[b0 + row])
+            p = {"action": "addMark" if kind == abi.PATCH_ADDMARK else "removeMark", "markType": abi.MARK_NAMES[mt], "path": ["text"],
+                 "startIndex": a, "endIndex": b}
+            if kind == abi.PATCH_ADDMARK and mt == abi.MARK_LINK:
+                p["attrs"] = {"url": batch.urls[int(batch.payload[b0 + row]) & abi.ATTR_ID_MASK]}
+            elif kind == abi.PATCH_ADDMARK and mt == abi.MARK_COMMENT:
+                p["attrs"] = {"id": comments[int(batch.payload[b0 + row])]}
+            if with_rows and mt == abi.MARK_COMMENT:
+                p["_commentId"] = comments[int(batch.payload[b0 + row])]
+            out.append(p)
+        else:
+            raise ValueError("unknown patch kind %d" % kind)
+        if with_rows:
+            out[-1]["_row"] = row
+    return out
+
+
 def _elements(batch, res, log):
     """(op_id, rank, deleted) of every list element of a log, from the elem_rank output column."""
     b0, b1 = int(batch.log_off[log]), int(batch.log_off[log + 1])

@@ -12,6 +12,7 @@
 #include <string.h>
 int ptx_emu_reverse = 0;
 #include "../../peritext_amd/csrc/merge_core.h"
+#include "../../peritext_amd/csrc/replay_core.h"
 
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
                           uint32_t lds_bytes, int reverse, int admission);
@@ -80,3 +81,48 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
 extern "C" uint64_t ptx_emu_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
     return ptx_lds_need(N, n, D, K, Kc, ks);
 }
+
+/* patch-stream replay (replay_core.h) over the merge results `res` / `rank` of the same batch; patch_off = capacity
+ * offsets [n_logs + 1] */
+extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint64_t* patch_off, ptx_patch* patches,
+                              ptx_patch_log* plogs, uint32_t lds_bytes, int reverse) {
+    PtxReplayArgs A;
+    A.log_off = b->log_off;
+    A.op_id = b->op_id;
+    A.ref_a = b->ref_a;
+    A.ref_b = b->ref_b;
+    A.payload = b->payload;
+    A.action = b->action;
+    A.mark_type = b->mark_type;
+    A.side_a = b->side_a;
+    A.side_b = b->side_b;
+    A.res = res;
+    A.elem_rank = rank;
+    A.patch_off = patch_off;
+    A.patches = patches;
+    A.plogs = plogs;
+    A.n_logs = b->n_logs;
+    A.lds_bytes = lds_bytes;
+    ptx_log_hdr* hdr = nullptr;
+    if (b->log_hdr) {
+        A.log_hdr = b->log_hdr;
+    } else {
+        hdr = (ptx_log_hdr*)calloc(b->n_logs ? b->n_logs : 1, sizeof(ptx_log_hdr));
+        for (uint32_t l = 0; l < b->n_logs; ++l) {
+            const uint64_t b0 = b->log_off[l], b1 = b->log_off[l + 1];
+            ptx_census_rows(b->op_id + b0, b->action + b0, b->mark_type + b0, b1 - b0, &hdr[l]);
+        }
+        A.log_hdr = hdr;
+    }
+    uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)lds_bytes + 64);
+    if (!lds) return 1;
+    ptx_emu_reverse = reverse;
+    for (uint32_t l = 0; l < b->n_logs; ++l) {
+        memset(lds, 0xA5, lds_bytes);
+        ptx_replay_log<0>(A, l, lds);
+    }
+    free(lds);
+    free(hdr);
+    return 0;
+}
+extern "C" uint64_t ptx_emu_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks) { return ptx_replay_lds_need(n, K, Kc, ks); }

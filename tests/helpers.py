@@ -44,13 +44,13 @@ def oracle_gen(config="mini", docs=4, seed=1, ops=None, replicas=None, first=0, 
             return json.load(f)
 
 
-def oracle_apply(docs_logs, impl="oracle", cursors=False):
+def oracle_apply(docs_logs, impl="oracle", cursors=False, patches=False):
     """Apply every log of every doc to a fresh oracle replica; returns [[{spans,text,error?}]]."""
     with tempfile.TemporaryDirectory() as td:
         inp, out = os.path.join(td, "in.json"), os.path.join(td, "out.json")
         with open(inp, "w") as f:
             json.dump({"docs": [{"logs": logs} for logs in docs_logs]}, f)
-        run_node(["oracle/cli.js", "apply", "--in", inp, "--impl", impl, "--out", out] + (["--cursors"] if cursors else []))
+        run_node(["oracle/cli.js", "apply", "--in", inp, "--impl", impl, "--out", out] + (["--cursors"] if cursors else []) + (["--patches"] if patches else []))
         with open(out) as f:
             return [d["expected"] for d in json.load(f)["docs"]]
 
@@ -87,6 +87,8 @@ def _emu(path):
     for fn in (lib.ptx_emu_merge, lib.ptx_emu_merge_admit):
         fn.restype = C.c_int
         fn.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    lib.ptx_emu_replay.restype = C.c_int
+    lib.ptx_emu_replay.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
     return lib
 
 
@@ -107,6 +109,107 @@ def emu_merge(b, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB, admission=Fal
     )
     assert rc == 0
     return res
+
+
+def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=None):
+    """Patch streams from the host emulation of replay_core.h (tests only): wire.Patches."""
+    n_logs = b.n_logs
+    sizes = np.diff(b.log_off.astype(np.int64))
+    caps = (2 * sizes + 16) if cap is None else np.full(n_logs, cap, dtype=np.int64)
+    off = np.zeros(n_logs + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(caps)
+    logs = np.zeros(n_logs, dtype=abi.PATCH_LOG_DTYPE)
+    rows = np.zeros(max(int(off[-1]), 1), dtype=abi.PATCH_DTYPE)
+    s = batch_struct(b)
+    lib = _emu(lib_path)
+    launches = 0
+    while True:
+        rc = lib.ptx_emu_replay(C.byref(s), res.logs.ctypes.data, res.elem_rank.ctypes.data, off.ctypes.data, rows.ctypes.data, logs.ctypes.data, lds_bytes, reverse)
+        assert rc == 0
+        launches += 1
+        produced = logs["n_patches"].astype(np.int64)
+        if launches == 2 or cap is not None or not np.any(produced > caps):
+            break
+        caps = np.maximum(produced, 1)  # what ptx_replay_patches does: once more with exact sizes
+        off[1:] = np.cumsum(caps)
+        rows = np.zeros(max(int(off[-1]), 1), dtype=abi.PATCH_DTYPE)
+    return wire.Patches(patch_off=off, logs=logs, patches=rows, launches=launches)
+
+
+def mini_doc(ops_second_change, first_text="ABCDE"):
+    """A hand-written log: change 1 = makeList + text, change 2 = the given ops (opIds assigned here)."""
+    ops1 = [{"opId": "1@a", "action": "makeList", "obj": "_root", "key": "text"}]
+    prev = "_head"
+    for i, ch in enumerate(first_text):
+        ops1.append({"opId": "%d@a" % (i + 2), "action": "set", "obj": "1@a", "elemId": prev, "insert": True, "value": ch})
+        prev = "%d@a" % (i + 2)
+    c1 = {"actor": "a", "seq": 1, "deps": {}, "startOp": 1, "ops": ops1}
+    start = len(ops1) + 1
+    ops2 = []
+    for k, op in enumerate(ops_second_change):
+        o = dict(op)
+        o["opId"] = "%d@a" % (start + k)
+        o["obj"] = "1@a"
+        ops2.append(o)
+    c2 = {"actor": "a", "seq": 2, "deps": {"a": 1}, "startOp": start, "ops": ops2}
+    return [c1, c2]
+
+
+def norm_patches(patches):
+    return [json.loads(json.dumps(p, sort_keys=True)) for p in patches]
+
+
+def check_patch_streams(batch, pat, expected_per_doc):
+    log = 0
+    for exp in expected_per_doc:
+        for e in exp:
+            got = norm_patches(wire.decode_patches(batch, pat, log))
+            want = norm_patches(e["patches"])
+            assert len(got) == len(want), "log %d: %d patches, expected %d" % (log, len(got), len(want))
+            for i, (x, y) in enumerate(zip(got, want)):
+                assert x == y, "log %d patch %d: %r != %r" % (log, i, x, y)
+            log += 1
+    return log
+
+
+def accumulate_patches(patches):
+    """reference/test/accumulatePatches.ts restated: replay a patch stream per character -> FormatSpanWithText[].
+    One deliberate difference: the reference's checker handles `removeMark comment` by deleting the whole `comment`
+    key (every id; its own fuzzer never removes comments, and the patch does not even carry the id).  Here the id comes
+    from the op row behind the patch ("_commentId", wire.decode_patches(with_rows=True)) and only that id is removed,
+    keeping the (possibly empty) list — what the replica itself holds (peritext.ts:318-320)."""
+    chars = []
+    for p in patches:
+        a = p["action"]
+        if a == "insert":
+            for k, ch in enumerate(p["values"]):
+                chars.insert(p["index"] + k, [ch, json.loads(json.dumps(p["marks"]))])
+        elif a == "delete":
+            del chars[p["index"]:p["index"] + p["count"]]
+        elif a == "addMark":
+            for i in range(p["startIndex"], p["endIndex"]):
+                m = chars[i][1]
+                if p["markType"] != "comment":
+                    m[p["markType"]] = dict(p.get("attrs") or {"active": True})
+                else:
+                    cur = m.get("comment")
+                    if cur is None:
+                        m["comment"] = [dict(p["attrs"])]
+                    elif not any(c["id"] == p["attrs"]["id"] for c in cur):
+                        m["comment"] = sorted(cur + [dict(p["attrs"])], key=lambda c: c["id"])
+        elif a == "removeMark":
+            for i in range(p["startIndex"], p["endIndex"]):
+                if p["markType"] == "comment":
+                    chars[i][1]["comment"] = [c for c in chars[i][1].get("comment", []) if c["id"] != p["_commentId"]]
+                else:
+                    chars[i][1].pop(p["markType"], None)
+    spans = []
+    for ch, m in chars:
+        if spans and spans[-1]["marks"] == m:
+            spans[-1]["text"] += ch
+        else:
+            spans.append({"text": ch, "marks": json.loads(json.dumps(m))})
+    return spans
 
 
 def norm_spans(spans):

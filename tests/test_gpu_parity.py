@@ -277,3 +277,87 @@ def test_baseline_size_properties(eng):
     for log in (0, 17 * batch.n_logs + 5, copies * batch.n_logs - 1):
         d, r = divmod(log % batch.n_logs, 3)
         H.check_log(tiled, got, log, gen["docs"][d]["expected"][r])
+
+
+# ---- Patch[] streams: ptx_replay_patches through the C ABI ----
+PATCH_GOLDEN = ["patches_mini.json", "patches_rich_300.json"]
+
+
+def _streams(eng, batch):
+    db = eng.upload(batch)
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        eng.sync()
+        res = eng.download(db, dr)
+        return res, eng.replay_patches(db, dr)
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
+
+
+@pytest.mark.parametrize("name", PATCH_GOLDEN)
+def test_golden_patch_streams(eng, name):
+    """Fixtures made by the reference itself (oracle/gen_patch_golden.js --impl ref): every patch every applyChange
+    returns, in order, deep-equal."""
+    g = _load(name)
+    assert g["impl"] == "ref"
+    batch = wire.encode_docs([d["logs"] for d in g["docs"]])
+    res, pat = _streams(eng, batch)
+    assert H.check_patch_streams(batch, pat, [d["expected"] for d in g["docs"]]) == batch.n_logs
+    assert pat.kernel_ms > 0
+    if name == "patches_rich_300.json":
+        assert pat.launches == 2  # more than two records per op: the library sized the second launch exactly
+
+
+def test_patch_streams_kat_traces_and_failed_logs(eng):
+    if not H.have_node():
+        pytest.skip("node not installed")
+    cases = H.load_kat()
+    bad = H.mini_doc([{"action": "del", "elemId": "77@zz"}])
+    docs = [[r["log"] for r in c["replicas"]] for c in cases] + [t["logs"] for t in _load("reference_traces.json")]
+    expected = H.oracle_apply(docs, patches=True)
+    batch = wire.encode_docs(docs + [[bad]])
+    res, pat = _streams(eng, batch)
+    H.check_patch_streams(batch, pat, expected)
+    last = batch.n_logs - 1
+    assert int(pat.logs[last]["status"]) == abi.ERR_ELEM_NOT_FOUND and int(pat.logs[last]["n_patches"]) == 0
+    with pytest.raises(ValueError, match="List element not found"):
+        wire.decode_patches(batch, pat, last)
+
+
+@pytest.mark.parametrize("config,docs,ops,seed", [("mini", 8, None, 31), ("rich", 1, 800, 32), ("config4", 1, None, 33), ("config5", 1, 1500, 34)])
+def test_patch_streams_live_oracle_and_accumulate(eng, config, docs, ops, seed):
+    """Fresh PTXGEN documents (config4: full 4 096-op logs): streams equal the oracle's, and replaying a stream per
+    character (reference/test/accumulatePatches.ts) gives the batch result of the same log."""
+    if not H.have_node():
+        pytest.skip("node not installed")
+    g = H.oracle_gen(config, seed=seed, docs=docs, ops=ops)
+    dl = [d["logs"] for d in g["docs"]]
+    expected = H.oracle_apply(dl, patches=True)
+    batch = wire.encode_docs(dl)
+    res, pat = _streams(eng, batch)
+    H.check_patch_streams(batch, pat, expected)
+    for log in range(batch.n_logs):
+        got = H.accumulate_patches(wire.decode_patches(batch, pat, log, with_rows=True))
+        assert H.norm_spans(got) == H.norm_spans(wire.decode_spans(batch, res, log)), "log %d" % log
+
+
+def test_patch_streams_need_elem_rank_and_handle_empty(eng):
+    from peritext_amd.engine import Engine, PtxError
+
+    batch = wire.encode_docs([[H.mini_doc([])]])
+    e2 = Engine(0, flags=abi.FLAG_NO_ELEM_RANK)
+    try:
+        db = e2.upload(batch)
+        dr = e2.alloc_result(db)
+        e2.merge(db, dr)
+        with pytest.raises(PtxError, match="elem_rank"):
+            e2.replay_patches(db, dr)
+        e2.free_result(dr)
+        e2.free_batch(db)
+    finally:
+        e2.close()
+    empty = wire.encode_docs([])
+    res, pat = _streams(eng, empty)
+    assert len(pat.logs) == 0 and len(pat.patches) == 0
