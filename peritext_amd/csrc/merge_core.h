@@ -168,7 +168,10 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #define PTX_STEPS(groups) (groups)
 #define PTX_G_OF(st, steps) (ptx_emu_reverse ? ((st) < (steps) ? (steps) - 1u - (st) : (steps)) : (st))
 #else
-#define PTX_STEPS(groups) (((groups) + PTX_BLOCKDIM - 1u) / PTX_BLOCKDIM)
+/* x / threads-per-workgroup without a division: the host passes magic = floor(2^32 / T) + 1, exact for x * T < 2^32
+ * (x is a row count + T here; a uniform integer division costs ~25 instructions per wave, and a log has a dozen) */
+#define PTX_DIV_T(x) (kThreads ? (uint32_t)(x) / (kThreads ? kThreads : 1u) : (uint32_t)__umulhi((uint32_t)(x), A.div_magic))
+#define PTX_STEPS(groups) PTX_DIV_T((groups) + PTX_BLOCKDIM - 1u)
 #define PTX_G_OF(st, steps) (threadIdx.x + (st) * PTX_BLOCKDIM)
 #endif
 
@@ -180,7 +183,7 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #define PTX_J_OF_U(st, u, U) ((st) * (U) + (uint32_t)(u))
 #define PTX_JX(j, n) (ptx_emu_reverse ? (n) - 1u - (j) : (j))
 #else
-#define PTX_JSTEPS_U(n, U) (((n) + (U)*PTX_BLOCKDIM - 1u) / ((U)*PTX_BLOCKDIM))
+#define PTX_JSTEPS_U(n, U) ((PTX_DIV_T((n) + PTX_BLOCKDIM - 1u) + (U)-1u) / (U)) /* = ceil(n / (U * T)) */
 #define PTX_J_OF_U(st, u, U) (((st) * (U) + (uint32_t)(u)) * PTX_BLOCKDIM + threadIdx.x)
 #define PTX_JX(j, n) (j)
 #endif
@@ -267,6 +270,7 @@ struct PtxMergeArgs {
     uint32_t lds_bytes;
     uint32_t max_actors;
     uint32_t stop_after; /* diagnostic: leave after the phase with this stamp index (0 = run everything) */
+    uint32_t div_magic;  /* floor(2^32 / threads per workgroup) + 1, see PTX_DIV_T */
 };
 
 #define PTX_END 0xFFFFu
@@ -357,7 +361,7 @@ PTX_DEV void ptx_reduce_max32(uint32_t* dst, uint32_t v) {
 /* ---- block-wide exclusive scan of an LDS array (element k at a[k*STRIDE]), in place; returns the
  *      total (all threads call it; ends with a barrier) ---- */
 template <class T, int STRIDE, uint32_t kThreads>
-PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in LDS */) {
+PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in LDS */, uint32_t div_magic = 0 /* as PTX_DIV_T; needed when kThreads == 0 */) {
 #ifdef PTX_EMU
     uint32_t run = 0;
     for (uint32_t j = 0; j < m; ++j) {
@@ -366,10 +370,11 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
         run += v;
     }
     (void)tmp;
+    (void)div_magic;
     return run;
 #else
     const uint32_t T_ = PTX_BLOCKDIM, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (T_ + 63) >> 6;
-    const uint32_t chunk = (m + T_ - 1) / T_;
+    const uint32_t chunk = kThreads ? (m + T_ - 1) / (kThreads ? kThreads : 1u) : (uint32_t)__umulhi(m + T_ - 1, div_magic);
     const uint32_t lo = tid * chunk < m ? tid * chunk : m;
     const uint32_t hi = lo + chunk < m ? lo + chunk : m;
     uint32_t sum = 0;
@@ -531,6 +536,7 @@ static inline void ptx_census_rows(const uint64_t* op_id, const uint8_t* action,
     *out = h;
 }
 
+template <bool kDiag>
 PTX_DEV void ptx_write_result(const PtxMergeArgs& A, uint32_t log, PtxHdr* H, uint32_t status, uint32_t lds_high) {
     PTX_LEADER {
         ptx_log_result r;
@@ -546,7 +552,7 @@ PTX_DEV void ptx_write_result(const PtxMergeArgs& A, uint32_t log, PtxHdr* H, ui
         r.digest[1] = status ? 0 : (uint64_t)H->h2;
         A.res[log] = r;
 #ifndef PTX_EMU
-        if (A.clocks) {
+        if (kDiag && A.clocks) {
             H->clk[PTX_NCLK] = ptx_clock();
 #pragma nounroll
             for (int k = 0; k < PTX_NCLK; ++k) {
@@ -648,20 +654,23 @@ PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
 #ifdef PTX_EMU
 #define PTX_STAMP(k) ((void)0)
 #else
-#define PTX_STAMP(k)                                               \
-    do {                                                           \
-        if (A.clocks && threadIdx.x == 0) H->clk[k] = ptx_clock(); \
-        if ((k) != 0 && A.stop_after == (k)) {                     \
-            lds_high = bp.high;                                    \
-            return PTX_OK;                                         \
-        }                                                          \
+/* only in the diagnostic build of the kernel (kDiag): phase cycle stamps and the early exit of the per-phase PMC runs */
+#define PTX_STAMP(k)                                                   \
+    do {                                                               \
+        if (kDiag) {                                                   \
+            if (A.clocks && threadIdx.x == 0) H->clk[k] = ptx_clock(); \
+            if ((k) != 0 && A.stop_after == (k)) {                     \
+                lds_high = bp.high;                                    \
+                return PTX_OK;                                         \
+            }                                                          \
+        }                                                              \
     } while (0)
 #endif
 
 /* ================================================================================================ */
 /* Applies log `log`; returns its status (PTX_OK or a per-log PTX_ERR_*) and the LDS high-water mark.  The caller
  * writes the result row (ptx_write_result) — ONE copy of that code instead of one per early exit. */
-template <bool kManyActors, uint32_t kThreads>
+template <bool kManyActors, uint32_t kThreads, bool kDiag>
 PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t* lds, uint32_t& lds_high) {
     const uint64_t base = A.log_off[log];
     const uint64_t N64 = A.log_off[log + 1] - base;
@@ -1098,7 +1107,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             /* (which of two equal ids is "the repeat" depends on the race; the status is what is reported) */
         }
         PTX_SYNC();
-        ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
+        ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp, A.div_magic);
     }
     PTX_BAIL_IF_ERROR();
     bp.off = tree_lds;
@@ -1167,7 +1176,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_P3A_LOAD
         }
         PTX_BAIL_IF_ERROR();
-        ptx_scan_excl<uint16_t, 1, kThreads>(cnt, n + 2, H->scan_tmp); /* cnt[p] = first slot of p's children */
+        ptx_scan_excl<uint16_t, 1, kThreads>(cnt, n + 2, H->scan_tmp, A.div_magic); /* cnt[p] = first slot of p's children */
         /* P3b: scatter into the parent buckets; tombstone flags; application-order checks now that row_of is complete */
         PTX_FORU(e0, n) {
             uint32_t pe[PTX_U], re[PTX_U], rp[PTX_U];
@@ -1278,7 +1287,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 PTX_SYNC();
                 PTX_FOR(w, nwe + 1) hb[w].pre = ptx_popc(hb[w].bits);
                 PTX_SYNC();
-                ptx_scan_excl<uint32_t, 2, kThreads>(&hb[0].pre, nwe + 1, H->scan_tmp);
+                ptx_scan_excl<uint32_t, 2, kThreads>(&hb[0].pre, nwe + 1, H->scan_tmp, A.div_magic);
                 PTX_FOR(k, t - s) {
                     const uint32_t x = seg[s + k];
                     srt[s + (t - s - 1u - ptx_bitrank(hb, x))] = (uint16_t)x; /* members with a larger index come first */
@@ -1375,7 +1384,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_SYNC();
     PTX_FOR(w, nwv + 1) alive[w].pre = ptx_popc(alive[w].bits);
     PTX_SYNC();
-    const uint32_t V = ptx_scan_excl<uint32_t, 2, kThreads>(&alive[0].pre, nwv + 1, H->scan_tmp);
+    const uint32_t V = ptx_scan_excl<uint32_t, 2, kThreads>(&alive[0].pre, nwv + 1, H->scan_tmp, A.div_magic);
     PTX_STAMP(6);
 
     /* ---- P5a: visible values out; every mark op -> visible interval [lo, hi) ---- */
@@ -1512,7 +1521,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             if (mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[cid[kc]], 1u);
         }
         PTX_SYNC();
-        ptx_scan_excl<uint32_t, 1, kThreads>(ccnt, Kc + 1, H->scan_tmp); /* ccnt[c] = first entry of id c, ccnt[Kc] = total */
+        ptx_scan_excl<uint32_t, 1, kThreads>(ccnt, Kc + 1, H->scan_tmp, A.div_magic); /* ccnt[c] = first entry of id c, ccnt[Kc] = total */
         PTX_FOR(kc, Kc) {
             const uint32_t k = moff2 + kc;
             if (mrk_lo[k] < mrk_hi[k]) {
@@ -1531,7 +1540,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             cicnt[c] = c < Kc ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         }
         PTX_SYNC();
-        const uint32_t I = ptx_scan_excl<uint32_t, 1, kThreads>(cicnt, Kc + 1, H->scan_tmp);
+        const uint32_t I = ptx_scan_excl<uint32_t, 1, kThreads>(cicnt, Kc + 1, H->scan_tmp, A.div_magic);
         PTX_LEADER { H->I = I; }
         {
             uint64_t h1 = 0, h2 = 0;
@@ -1639,7 +1648,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_SYNC();
             PTX_FOR(w, TV / 32 + 2) st[w].pre = ptx_popc(st[w].bits);
             PTX_SYNC();
-            const uint32_t S_tile = ptx_scan_excl<uint32_t, 2, kThreads>(&st[0].pre, TV / 32 + 2, H->scan_tmp);
+            const uint32_t S_tile = ptx_scan_excl<uint32_t, 2, kThreads>(&st[0].pre, TV / 32 + 2, H->scan_tmp, A.div_magic);
             PTX_FOR(q, tv) {
                 const PtxBitWord w = st[q >> 5];
                 if ((w.bits >> (q & 31)) & 1u) {
@@ -1675,10 +1684,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
 /* kManyActors: include the admission path for batches with more than four actors per document (it costs ~35
  * VGPRs, i.e. two waves per SIMD, so it lives in its own build of the kernel) */
-template <bool kManyActors, uint32_t kThreads>
+template <bool kManyActors, uint32_t kThreads, bool kDiag = false>
 PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     uint32_t lds_high = 0;
-    const uint32_t status = ptx_merge_log_body<kManyActors, kThreads>(A, log, lds, lds_high);
+    const uint32_t status = ptx_merge_log_body<kManyActors, kThreads, kDiag>(A, log, lds, lds_high);
     PTX_SYNC();
-    ptx_write_result(A, log, (PtxHdr*)lds, status, lds_high);
+    ptx_write_result<kDiag>(A, log, (PtxHdr*)lds, status, lds_high);
 }

@@ -29,15 +29,16 @@
 /* One body, several register budgets: __launch_bounds__(T, W) = at most T threads per workgroup and at
  * least W waves per SIMD resident, i.e. the compiler must stay within 512/W VGPRs (MI355X_MICROARCH.md
  * "Register files"). */
-#define PTX_MERGE_KERNEL(name, T, W, MANY, KT)                                           \
+#define PTX_MERGE_KERNEL(name, T, W, MANY, KT, DIAG)                                     \
     extern "C" __global__ void __launch_bounds__(T, W) name(PtxMergeArgs A) {          \
         extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];              \
         /* one workgroup per log (grid == n_logs): no grid-stride loop, so that nothing is hoisted \
            out of it and kept in registers for the whole kernel */                    \
-        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT>(A, blockIdx.x, ptx_lds);   \
+        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT, DIAG>(A, blockIdx.x, ptx_lds); \
     }
-PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false, 0)     /* any launch shape (blockDim.x read at run time) */
-PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0) /* + causal admission for documents with more than four actors */
+PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false, 0, false)     /* any launch shape (blockDim.x read at run time) */
+PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false) /* + causal admission for documents with more than four actors */
+PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, 1, true, 0, true)  /* + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
 /* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
  * issue ~1 % fewer instructions but need twice the VGPRs unless PTX_U=1, so only the run-time-sized builds are shipped) */
 
@@ -194,8 +195,8 @@ static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t ma
     if (ctx->force_lds) lds = (uint64_t)ctx->force_lds;
     b->lds_bytes = (uint32_t)lds;
     /* threads per log, measured on MI355X (profiles/): fewer waves per log = fewer per-wave fixed costs, more logs per CU;
-     * 256-op logs peak at 64 threads, 1K at 128, 4K at 256, 8K at 512 */
-    uint32_t t = max_log_ops <= 512 ? 64u : max_log_ops <= 2048 ? 128u : max_log_ops <= 6144 ? 256u : 512u;
+     * 256-op logs peak at 64 threads, 1K at 128, 4K at 192 (3 waves x 7 logs per CU: 60.3 vs 58.7 G ops/s at 256), 8K at 512 */
+    uint32_t t = max_log_ops <= 512 ? 64u : max_log_ops <= 2048 ? 128u : max_log_ops <= 4608 ? 192u : max_log_ops <= 6144 ? 256u : 512u;
     if (ctx->force_threads) t = (uint32_t)ctx->force_threads;
     b->threads = t;
 }
@@ -274,7 +275,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many, (const void*)ptx_replay_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -554,9 +555,12 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.out_rank = r->rank;
     A.n_logs = b->n_logs;
     A.lds_bytes = b->lds_bytes;
+    A.div_magic = (uint32_t)(0x100000000ull / b->threads) + 1u;
     /* one workgroup per log; far more workgroups than the 256 CUs so the dispatcher load-balances */
     const uint32_t grid = b->n_logs;
-    if (admit && b->max_actors > 4)
+    if (ctx->clocks || ctx->stop_after)
+        hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
+    else if (admit && b->max_actors > 4)
         hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
     else
         hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);

@@ -47,6 +47,7 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     A.max_actors = b->max_actors;
     A.clocks = nullptr;
     A.stop_after = 0;
+    A.div_magic = 0;
     A.res = res;
     A.out_values = values;
     A.out_spans = spans;
