@@ -30,6 +30,8 @@
 #include "merge_core.h"
 
 #define PTX_SLOT_NONE 0xFFFFu /* start never matches / end never reached */
+#define PTX_RCHUNK 64u
+enum { PTX_RK_SKIP = 0, PTX_RK_MAKELIST = 1, PTX_RK_INSERT = 2, PTX_RK_DELETE = 3, PTX_RK_MARK = 4 };
 
 struct PtxReplayArgs {
     const uint64_t* log_off;
@@ -63,7 +65,8 @@ PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_
     const uint64_t nw = (ks + 31) / 32, nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
     const uint64_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
     return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(8 * nwe) + 2 * ptx_a16(4 * nws) +
-           ptx_a16(4 * (nws + 1)) + 3 * ptx_a16(2 * (2 * n + 2)) + 2 * ptx_a16(2 * segcap) +
+           ptx_a16(4 * (nws + 1)) + 3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * segcap) + ptx_a16(8 * ((segcap >> 5) + 2)) + 3 * ptx_a16(4 * nws) +
+           ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
            6 * ptx_a16(2 * (Kc + 1)) + ptx_a16(Kc + 1);
 }
 PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h) {
@@ -139,8 +142,18 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     win[0] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* strong */
     win[1] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* em */
     win[2] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* link */
+    uint32_t* won[3]; /* per slot: the winner of the type is an addMark (saves re-reading its action from HBM) */
+    won[0] = ptx_alloc<uint32_t>(bp, nws);
+    won[1] = ptx_alloc<uint32_t>(bp, nws);
+    won[2] = ptx_alloc<uint32_t>(bp, nws);
+    /* the next PTX_RCHUNK rows, resolved in parallel (element lookups, boundary slots) before they are replayed in order */
+    uint64_t* c_id = ptx_alloc<uint64_t>(bp, PTX_RCHUNK);
+    uint32_t* c_pay = ptx_alloc<uint32_t>(bp, PTX_RCHUNK);
+    uint16_t* c_a = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* insert / delete: final rank; mark: start slot */
+    uint16_t* c_b = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* mark: end slot */
+    uint8_t* c_kind = ptx_alloc<uint8_t>(bp, PTX_RCHUNK);  /* PTX_RK_* | mark type << 4 | addMark << 6 */
     uint16_t* seg = ptx_alloc<uint16_t>(bp, segcap);      /* defined slots of the op's range, ascending */
-    uint16_t* seg_flag = ptx_alloc<uint16_t>(bp, segcap); /* 1 = emits a patch -> prefix = its place */
+    PtxBitWord* cf = ptx_alloc<PtxBitWord>(bp, (segcap >> 5) + 2); /* bit j: slot seg[j] opens a patch; prefix = its place */
     uint16_t* ca = ptx_alloc<uint16_t>(bp, Kc + 1);       /* comment op: first covered slot */
     uint16_t* cb = ptx_alloc<uint16_t>(bp, Kc + 1);       /*             first slot not covered (PTX_SLOT_NONE = to the end) */
     uint16_t* ccid = ptx_alloc<uint16_t>(bp, Kc + 1);
@@ -174,6 +187,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     PTX_FOR(w, nws) {
         defined[w] = 0;
         anyc[w] = 0;
+        won[0][w] = 0;
+        won[1][w] = 0;
+        won[2][w] = 0;
     }
     PTX_FOR(c, Kc + 1) ctail[c] = PTX_SLOT_NONE;
     PTX_LEADER {
@@ -228,25 +244,61 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 win[1][s_] = l1_ ? win[1][l1_ - 1u] : (uint16_t)0;                              \
                 win[2][s_] = l1_ ? win[2][l1_ - 1u] : (uint16_t)0;                              \
                 if (l1_ && ptx_bittest(anyc, l1_ - 1u)) anyc[(s_) >> 5] |= 1u << ((s_)&31u);    \
+                for (int ty_ = 0; ty_ < 3; ++ty_)                                               \
+                    if (l1_ && ptx_bittest(won[ty_], l1_ - 1u)) won[ty_][(s_) >> 5] |= 1u << ((s_)&31u); \
                 defined[(s_) >> 5] |= 1u << ((s_)&31u);                                         \
             }                                                                                   \
             PTX_SYNC();                                                                         \
         }                                                                                       \
     } while (0)
 
-    /* ---- the replay, one op at a time ---- */
+    /* ---- the replay: PTX_RCHUNK rows are resolved in parallel, then applied one at a time ---- */
 #pragma nounroll
-    for (uint32_t t = 0; t < N; ++t) {
-        const uint32_t act = action[t];
-        if (act == PTX_ACT_MAKELIST) {
+    for (uint32_t t0 = 0; t0 < N; t0 += PTX_RCHUNK) {
+    const uint32_t chunk_n = N - t0 < PTX_RCHUNK ? N - t0 : PTX_RCHUNK;
+    PTX_FOR(i, chunk_n) {
+        const uint32_t tt = t0 + i, a_ = action[tt];
+        uint32_t kind = PTX_RK_SKIP, va = PTX_SLOT_NONE, vb = PTX_SLOT_NONE;
+        if (a_ == PTX_ACT_MAKELIST) {
+            kind = PTX_RK_MAKELIST;
+        } else if (a_ == PTX_ACT_INSERT || a_ == PTX_ACT_DELETE) {
+            const int e = ptx_elem_lookup(ix, a_ == PTX_ACT_INSERT ? op_id[tt] : ref_a[tt]);
+            if (e >= 0) { /* always, in a log the merge accepted */
+                kind = a_ == PTX_ACT_INSERT ? PTX_RK_INSERT : PTX_RK_DELETE;
+                va = rank_of[e];
+            }
+        } else if ((a_ == PTX_ACT_ADDMARK || a_ == PTX_ACT_REMOVEMARK) && mark_type[tt] < 4u) {
+            /* boundary slots as the walk of peritext.ts:167-214 meets them (merge_core.h P5a has the same rules) */
+            const uint32_t sa = side_a[tt], sb = side_b[tt];
+            if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
+                const int js = ptx_elem_lookup(ix, ref_a[tt]);
+                if (js >= 0 && row_of[js] < tt) va = 2u * rank_of[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
+            }
+            if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
+                const int je = ptx_elem_lookup(ix, ref_b[tt]);
+                if (je >= 0 && row_of[je] < tt) vb = 2u * rank_of[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
+            }
+            kind = PTX_RK_MARK | ((uint32_t)mark_type[tt] << 4) | (a_ == PTX_ACT_ADDMARK ? 64u : 0u);
+        }
+        c_kind[i] = (uint8_t)kind;
+        c_a[i] = (uint16_t)va;
+        c_b[i] = (uint16_t)vb;
+        c_pay[i] = payload[tt];
+        c_id[i] = op_id[tt];
+    }
+    PTX_SYNC();
+#pragma nounroll
+    for (uint32_t ci = 0; ci < chunk_n; ++ci) {
+        const uint32_t t = t0 + ci;
+        const uint32_t kind = c_kind[ci] & 15u;
+        if (kind == PTX_RK_MAKELIST) {
             PTX_LEADER {
                 ptx_patch_put(A, pbase, pcap, H->npatch, t, PTX_PATCH_MAKELIST, 0u, 0u);
                 H->npatch += 1;
             }
             PTX_SYNC();
-        } else if (act == PTX_ACT_INSERT) {
-            const int e = ptx_elem_lookup(ix, op_id[t]);
-            const uint32_t r = rank_of[e];
+        } else if (kind == PTX_RK_INSERT) {
+            const uint32_t r = c_a[ci];
             PTX_LAST_DEFINED_BELOW(2u * r);
             const uint32_t l1 = H->tmp; /* slot + 1 */
             const uint32_t p0 = H->npatch;
@@ -255,10 +307,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 uint32_t attr = 0;
                 if (l1) {
                     const uint32_t l = l1 - 1u;
-                    const uint32_t ws = win[0][l], we = win[1][l], wl = win[2][l];
-                    if (ws && action[ws - 1u] == PTX_ACT_ADDMARK) attr |= PTX_ATTR_STRONG;
-                    if (we && action[we - 1u] == PTX_ACT_ADDMARK) attr |= PTX_ATTR_EM;
-                    if (wl && action[wl - 1u] == PTX_ACT_ADDMARK) attr |= PTX_ATTR_LINK | (payload[wl - 1u] & PTX_ATTR_ID_MASK);
+                    if (ptx_bittest(won[0], l)) attr |= PTX_ATTR_STRONG;
+                    if (ptx_bittest(won[1], l)) attr |= PTX_ATTR_EM;
+                    if (ptx_bittest(won[2], l)) attr |= PTX_ATTR_LINK | (payload[win[2][l] - 1u] & PTX_ATTR_ID_MASK);
                     if (ptx_bittest(anyc, l)) attr |= PTX_ATTR_COMMENT;
                 }
                 ptx_patch_put(A, pbase, pcap, p0, t, PTX_PATCH_INSERT, ptx_bitrank(present, r), attr);
@@ -290,9 +341,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 H->nvis += 1;
             }
             PTX_SYNC();
-        } else if (act == PTX_ACT_DELETE) {
-            const int e = ptx_elem_lookup(ix, ref_a[t]);
-            const uint32_t r = rank_of[e];
+        } else if (kind == PTX_RK_DELETE) {
+            const uint32_t r = c_a[ci];
             const bool was = (present[r >> 5].bits >> (r & 31)) & 1u;
             PTX_SYNC();
             if (was) {
@@ -308,18 +358,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 }
                 PTX_SYNC();
             }
-        } else if ((act == PTX_ACT_ADDMARK || act == PTX_ACT_REMOVEMARK) && mark_type[t] < 4u) {
-            const uint32_t ty = mark_type[t], sa = side_a[t], sb = side_b[t];
-            /* boundary slots as the walk of peritext.ts:167-214 meets them (merge_core.h P5a has the same rules) */
-            uint32_t slot_a = PTX_SLOT_NONE, slot_b = PTX_SLOT_NONE;
-            if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
-                const int js = ptx_elem_lookup(ix, ref_a[t]);
-                if (js >= 0 && row_of[js] < t) slot_a = 2u * rank_of[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
-            }
-            if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
-                const int je = ptx_elem_lookup(ix, ref_b[t]);
-                if (je >= 0 && row_of[je] < t) slot_b = 2u * rank_of[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
-            }
+        } else if (kind == PTX_RK_MARK) {
+            const uint32_t ty = (c_kind[ci] >> 4) & 3u, act = (c_kind[ci] & 64u) ? (uint32_t)PTX_ACT_ADDMARK : (uint32_t)PTX_ACT_REMOVEMARK;
+            uint32_t slot_a = c_a[ci], slot_b = c_b[ci];
             if (slot_a != PTX_SLOT_NONE && slot_b == slot_a) slot_b = PTX_SLOT_NONE; /* the start test fires first (A.6-3) */
             if (slot_a == PTX_SLOT_NONE || slot_b < slot_a) {
                 /* the end is met while the op has not started: its slot becomes a defined one (a copy of the state to
@@ -361,27 +402,39 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
 #undef PTX_RANGE_BITS
             PTX_SYNC();
             const uint32_t nvis = H->nvis, nc = H->ncom;
-            const uint32_t my_id = payload[t];
-            const uint64_t my_op = op_id[t];
+            const uint32_t cfw = (S >> 5) + 1u; /* words of the patch-opening bitmap (+1 for the total) */
+            PTX_FOR(w, cfw + 1u) {
+                PtxBitWord z;
+                z.bits = 0;
+                z.pre = 0;
+                cf[w] = z;
+            }
+            /* a changed slot opens a patch that the next defined slot (or the end of the range / text) closes;
+             * zero-width ones are dropped (peritext.ts:269-281) */
+            const uint32_t v_end = slot_b != PTX_SLOT_NONE ? ptx_bitrank(present, (slot_b + 1u) >> 1) : nvis;
+#define PTX_VIS_AT(s_) ptx_bitrank(present, ((uint32_t)(s_) + 1u) >> 1) /* visible index at a boundary slot */
+            PTX_SYNC();
+            const uint32_t my_id = c_pay[ci];
+            const uint64_t my_op = c_id[ci];
             /* per defined slot: did the effective marks change (peritext.ts:208), new state, visible index */
             PTX_FOR(j, S) {
                 const uint32_t s = seg[j];
                 bool changed = false;
                 if (ty != PTX_MARK_COMMENT) {
                     uint16_t* wt = win[ty == PTX_MARK_STRONG ? 0 : ty == PTX_MARK_EM ? 1 : 2];
+                    uint32_t* wo = won[ty == PTX_MARK_STRONG ? 0 : ty == PTX_MARK_EM ? 1 : 2];
                     const uint32_t w = wt[s];
-                    bool wins = true, old_on = false;
-                    uint32_t old_val = 0;
-                    if (w) {
-                        wins = my_op > op_id[w - 1u]; /* compareOpIds: counter, then actor (ranks keep the string order) */
-                        old_on = action[w - 1u] == PTX_ACT_ADDMARK;
-                        old_val = ty == PTX_MARK_LINK ? payload[w - 1u] & PTX_ATTR_ID_MASK : 0u;
-                    }
+                    const bool old_on = ptx_bittest(wo, s);
+                    const bool wins = !w || my_op > op_id[w - 1u]; /* compareOpIds: counter, then actor (ranks keep the string order) */
                     if (wins) {
                         const bool new_on = act == PTX_ACT_ADDMARK;
-                        const uint32_t new_val = ty == PTX_MARK_LINK ? my_id & PTX_ATTR_ID_MASK : 0u;
-                        changed = new_on != old_on || (new_on && new_val != old_val);
+                        changed = new_on != old_on;
+                        if (new_on && old_on && ty == PTX_MARK_LINK) changed = (my_id & PTX_ATTR_ID_MASK) != (payload[w - 1u] & PTX_ATTR_ID_MASK);
                         wt[s] = (uint16_t)(t + 1u);
+                        if (new_on != old_on) {
+                            if (new_on) ptx_atomic_or(&wo[s >> 5], 1u << (s & 31));
+                            else ptx_atomic_and(&wo[s >> 5], ~(1u << (s & 31)));
+                        }
                     }
                 } else {
                     /* the last-applied covering op with this id (this op is not registered yet) */
@@ -394,7 +447,10 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     const bool any = ptx_bittest(anyc, s);
                     changed = act == PTX_ACT_ADDMARK ? state != 1 : (state == 1 || !any); /* remove on no comment key: undefined -> [] */
                 }
-                seg_flag[j] = changed ? 1u : 0u;
+                if (changed) {
+                    const uint32_t ve = j + 1u < S ? PTX_VIS_AT(seg[j + 1u]) : v_end;
+                    if (ve > PTX_VIS_AT(s)) ptx_atomic_or(&cf[j >> 5].bits, 1u << (j & 31));
+                }
             }
             PTX_SYNC();
             if (ty == PTX_MARK_COMMENT) {
@@ -403,22 +459,14 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     ptx_atomic_or(&anyc[s >> 5], 1u << (s & 31));
                 }
             }
-            /* a changed slot opens a patch that the next defined slot (or the end of the range / text) closes;
-             * zero-width ones are dropped (peritext.ts:269-281) */
-            const uint32_t v_end = slot_b != PTX_SLOT_NONE ? ptx_bitrank(present, (slot_b + 1u) >> 1) : nvis;
-#define PTX_VIS_AT(s_) ptx_bitrank(present, ((uint32_t)(s_) + 1u) >> 1) /* visible index at a boundary slot */
-            PTX_FOR(j, S) {
-                const uint32_t ve = j + 1u < S ? PTX_VIS_AT(seg[j + 1u]) : v_end;
-                seg_flag[j] = (seg_flag[j] && ve > PTX_VIS_AT(seg[j])) ? 1u : 0u;
-            }
-            PTX_LEADER { seg_flag[S] = 0; }
+            PTX_FOR(w, cfw) cf[w].pre = ptx_popc(cf[w].bits);
             PTX_SYNC();
-            const uint32_t P = ptx_scan_excl<uint16_t, 1, kThreads>(seg_flag, S + 1u, H->scan_tmp);
+            const uint32_t P = ptx_scan_excl<uint32_t, 2, kThreads>(&cf[0].pre, cfw + 1u, H->scan_tmp);
             const uint32_t p0 = H->npatch;
             PTX_FOR(j, S) {
-                if (seg_flag[j + 1u] != seg_flag[j]) {
+                if ((cf[j >> 5].bits >> (j & 31)) & 1u) {
                     const uint32_t ve = j + 1u < S ? PTX_VIS_AT(seg[j + 1u]) : v_end;
-                    ptx_patch_put(A, pbase, pcap, p0 + seg_flag[j], t, act == PTX_ACT_ADDMARK ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT(seg[j]), ve);
+                    ptx_patch_put(A, pbase, pcap, p0 + ptx_bitrank(cf, j), t, act == PTX_ACT_ADDMARK ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT(seg[j]), ve);
                 }
             }
 #undef PTX_VIS_AT
@@ -440,6 +488,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             }
             PTX_SYNC();
         }
+    }
+    PTX_SYNC(); /* the chunk buffers are rewritten next */
     }
 #undef PTX_LAST_DEFINED_BELOW
 #undef PTX_DEFINE_SLOT

@@ -8,6 +8,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -38,7 +40,8 @@ def main():
     n_logs = batch.n_logs * copies
     ops = batch.counted_ops() * copies
     n_pat = int(pat.logs["n_patches"].sum())
-    assert int(pat.logs["status"].max()) == 0
+    bad = np.flatnonzero(pat.logs["status"] != 0)
+    assert len(bad) == 0, "logs without a stream: %s status %s n_patches %s launches %d" % (bad[:8], pat.logs["status"][bad[:8]], pat.logs["n_patches"][bad[:8]], pat.launches)
     out = {"config": args.config, "logs": n_logs, "ops": ops, "patches": n_pat, "launches": pat.launches, "kernel_ms": pat.kernel_ms,
            "ops_per_s": ops / pat.kernel_ms * 1e3, "patches_per_s": n_pat / pat.kernel_ms * 1e3, "us_per_log": pat.kernel_ms * 1e3 / n_logs,
            "wall_s_incl_download": wall}
