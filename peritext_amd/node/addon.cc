@@ -35,6 +35,16 @@ struct Lib {
     void (*result_free)(ptx_result*) = nullptr;
     uint32_t (*max_ops_per_log)(const ptx_ctx*) = nullptr;
     const char* (*kernel_name)(void) = nullptr;
+    /* staged form, used when the caller also wants the Patch[] streams */
+    ptx_status (*batch_upload)(ptx_ctx*, const ptx_batch*, ptx_dbatch**) = nullptr;
+    void (*batch_free)(ptx_ctx*, ptx_dbatch*) = nullptr;
+    ptx_status (*result_alloc)(ptx_ctx*, const ptx_dbatch*, ptx_dresult**) = nullptr;
+    void (*dresult_free)(ptx_ctx*, ptx_dresult*) = nullptr;
+    ptx_status (*merge)(ptx_ctx*, const ptx_dbatch*, ptx_dresult*) = nullptr;
+    ptx_status (*sync)(ptx_ctx*) = nullptr;
+    ptx_status (*result_download)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, ptx_result*) = nullptr;
+    ptx_status (*replay_patches)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, ptx_patches*) = nullptr;
+    void (*patches_free)(ptx_patches*) = nullptr;
 } L;
 
 #define NAPI_OK(call)                                                        \
@@ -72,7 +82,10 @@ napi_value Open(napi_env env, napi_callback_info info) {
         }
         bool ok = sym(L.abi_version, "ptx_abi_version") && sym(L.create, "ptx_create") && sym(L.destroy, "ptx_destroy") &&
                   sym(L.last_error, "ptx_last_error") && sym(L.apply_materialize, "ptx_apply_materialize") && sym(L.result_free, "ptx_result_free") &&
-                  sym(L.max_ops_per_log, "ptx_max_ops_per_log") && sym(L.kernel_name, "ptx_kernel_name");
+                  sym(L.max_ops_per_log, "ptx_max_ops_per_log") && sym(L.kernel_name, "ptx_kernel_name") && sym(L.batch_upload, "ptx_batch_upload") &&
+                  sym(L.batch_free, "ptx_batch_free") && sym(L.result_alloc, "ptx_result_alloc") && sym(L.dresult_free, "ptx_dresult_free") &&
+                  sym(L.merge, "ptx_merge") && sym(L.sync, "ptx_sync") && sym(L.result_download, "ptx_result_download") &&
+                  sym(L.replay_patches, "ptx_replay_patches") && sym(L.patches_free, "ptx_patches_free");
         if (!ok) {
             dlclose(L.handle);
             L.handle = nullptr;
@@ -167,10 +180,12 @@ napi_value make_u32(napi_env env, const void* src, size_t count) {
 
 napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
     if (!L.handle) return throw_msg(env, "call open(libPath) first");
-    size_t argc = 2;
-    napi_value argv[2];
+    size_t argc = 3;
+    napi_value argv[3];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-    if (argc < 2) return throw_msg(env, "applyMaterialize(ctx, batch)");
+    if (argc < 2) return throw_msg(env, "applyMaterialize(ctx, batch[, wantPatches])");
+    bool want_patches = false;
+    if (argc > 2) napi_get_value_bool(env, argv[2], &want_patches);
     ptx_ctx* ctx = ctx_of(env, argv[0]);
     if (!ctx) return throw_msg(env, "applyMaterialize: bad context");
     napi_value b = argv[1];
@@ -222,7 +237,27 @@ napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
         }
     }
     ptx_result res;
-    const ptx_status st = L.apply_materialize(ctx, &pb, &res);
+    ptx_patches pat;
+    memset(&pat, 0, sizeof(pat));
+    ptx_status st;
+    if (!want_patches) {
+        st = L.apply_materialize(ctx, &pb, &res);
+    } else {
+        /* the same in stages, the results stay in HBM for the replay that produces what every applyChange returns */
+        ptx_dbatch* db = nullptr;
+        ptx_dresult* dr = nullptr;
+        st = L.batch_upload(ctx, &pb, &db);
+        if (st == PTX_OK) st = L.result_alloc(ctx, db, &dr);
+        if (st == PTX_OK) st = L.merge(ctx, db, dr);
+        if (st == PTX_OK) st = L.sync(ctx);
+        if (st == PTX_OK) st = L.result_download(ctx, db, dr, &res);
+        if (st == PTX_OK) {
+            st = L.replay_patches(ctx, db, dr, &pat);
+            if (st != PTX_OK) L.result_free(&res);
+        }
+        if (dr) L.dresult_free(ctx, dr);
+        if (db) L.batch_free(ctx, db);
+    }
     if (st != PTX_OK) {
         char msg[1024];
         snprintf(msg, sizeof(msg), "ptx_apply_materialize failed (status %d): %s", st, L.last_error(ctx));
@@ -245,6 +280,21 @@ napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
         if (v) napi_set_named_property(env, out, "elemRank", v);
     }
     L.result_free(&res);
+    if (want_patches) {
+        static_assert(sizeof(ptx_patch) == 16 && sizeof(ptx_patch_log) == 8, "ptx_patch layout");
+        napi_value ab, ta;
+        void* data = nullptr;
+        const size_t n_off = (size_t)pat.n_logs + 1;
+        if (napi_create_arraybuffer(env, n_off * 8, &data, &ab) == napi_ok && napi_create_typedarray(env, napi_biguint64_array, n_off, ab, 0, &ta) == napi_ok) {
+            memcpy(data, pat.patch_off, n_off * 8);
+            napi_set_named_property(env, out, "patchOff", ta);
+        }
+        v = make_u32(env, pat.logs, (size_t)pat.n_logs * 2);
+        if (v) napi_set_named_property(env, out, "patchLogs", v);
+        v = make_u32(env, pat.patches, (size_t)pat.patch_off[pat.n_logs] * 4);
+        if (v) napi_set_named_property(env, out, "patches", v);
+        L.patches_free(&pat);
+    }
     return out;
 }
 

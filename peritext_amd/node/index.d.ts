@@ -38,11 +38,26 @@ export interface WireBatch {
     chgOff?: BigUint64Array; chgActor?: Uint32Array; chgSeq?: Uint32Array; chgNops?: Uint32Array; chgDeps?: Uint32Array; maxActors?: number
     values: string[]; urls: string[]; logDoc: number[]; docActors: string[][]; docComments: string[][]
 }
-export interface WireResult { logs: Uint32Array; values: Uint32Array; spans: Uint32Array; cintervals: Uint32Array; elemRank?: Uint32Array }
+export interface WireResult {
+    logs: Uint32Array; values: Uint32Array; spans: Uint32Array; cintervals: Uint32Array; elemRank?: Uint32Array
+    /** with applyMaterialize(batch, true): ptx_patches (patch_off, {status, n_patches} per log, 4 u32 per record) */
+    patchOff?: BigUint64Array; patchLogs?: Uint32Array; patches?: Uint32Array
+}
+
+/** micromerge.ts:214-222 — what applyChange returns (the makeList patch, the raw op upstream, is {action: "makeList"}) */
+export type Patch =
+    | { action: "makeList" }
+    | { path: ["text"]; action: "insert"; index: number; values: string[]; marks: MarkMap }
+    | { path: ["text"]; action: "delete"; index: number; count: number }
+    | { path: ["text"]; action: "addMark"; markType: MarkType; startIndex: number; endIndex: number; attrs?: { url?: string; id?: string } }
+    | { path: ["text"]; action: "removeMark"; markType: MarkType; startIndex: number; endIndex: number }
 
 /** Per-replica handle with the reference's calls (Micromerge.applyChange :499, getTextWithFormatting :516). */
 export interface ReplicaHandle {
-    applyChange(change: Change): unknown[]
+    /** queues the change (all handles of an engine are merged in one launch); returns [] — see getPatches() */
+    applyChange(change: Change): Patch[]
+    /** entry c = the Patch[] the reference's applyChange(c-th change) returns */
+    getPatches(): Patch[][]
     /** throws RangeError("List element not found" | …) exactly where the reference's applyChange would have thrown */
     getTextWithFormatting(path: ["text"]): FormatSpanWithText[]
 }
@@ -50,13 +65,16 @@ export interface ReplicaHandle {
 export class MergeEngine {
     constructor(opts?: { device?: number; libPath?: string; addonPath?: string })
     close(): void
-    applyMaterialize(batch: WireBatch): WireResult
+    applyMaterialize(batch: WireBatch, wantPatches?: boolean): WireResult
     /** docs -> replica logs -> changes in application order  =>  spans per replica log */
     applyChanges(docs: Change[][][]): FormatSpanWithText[][][]
+    /** spans as applyChanges + patches[doc][replica][change] = what applyChange(change) returns (micromerge.ts:499) */
+    applyChangesWithPatches(docs: Change[][][]): { spans: FormatSpanWithText[][][]; patches: Patch[][][][] }
     digests(docs: Change[][][]): Array<[bigint, bigint]>
     replica(docId?: number | string): ReplicaHandle
-    flush(): void
+    flush(wantPatches?: boolean): void
 }
 export function encodeDocs(docs: Change[][][]): WireBatch
 export function decodeSpans(batch: WireBatch, res: WireResult, log: number): FormatSpanWithText[]
+export function decodePatches(batch: WireBatch, res: WireResult, log: number): Patch[][]
 export function census(batch: WireBatch): Uint32Array

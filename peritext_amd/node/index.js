@@ -206,6 +206,58 @@ function decodeSpans(batch, res, log) {
     return out
 }
 
+const PATCH = { MAKELIST: 0, INSERT: 1, DELETE: 2, ADDMARK: 3, REMOVEMARK: 4, INSERT_COMMENT: 5 }
+
+/**
+ * Patch[][] of one log: entry c = what applyChange(change c) returned (micromerge.ts:499 -> Patch[]), in the
+ * reference's shapes (insert :661-671, delete :696-703, add/removeMark peritext.ts:251-281; the makeList patch, the
+ * raw op in the reference, is reduced to {action: "makeList"}).  `res` must come from applyMaterialize(batch, true).
+ */
+function decodePatches(batch, res, log) {
+    const st = res.patchLogs[2 * log], n = res.patchLogs[2 * log + 1]
+    if (st !== 0) throw new RangeError(STATUS_MESSAGES[st] || "merge error " + st)
+    const b = Number(batch.logOff[log]), p0 = Number(res.patchOff[log])
+    const comments = batch.docComments[batch.logDoc[log]]
+    /* op row -> index of its change within the log */
+    const c0 = Number(batch.chgOff[log]), c1 = Number(batch.chgOff[log + 1])
+    const out = []
+    const firstRow = []
+    let row = 0
+    for (let c = c0; c < c1; c++) {
+        firstRow.push(row)
+        row += batch.chgNops[c]
+        out.push([])
+    }
+    let cur = 0
+    for (let k = 0; k < n; k++) {
+        const at = 4 * (p0 + k)
+        const r = res.patches[at], kind = res.patches[at + 1], a = res.patches[at + 2], v = res.patches[at + 3]
+        while (cur + 1 < firstRow.length && firstRow[cur + 1] <= r) cur++
+        let patch
+        if (kind === PATCH.MAKELIST) patch = { action: "makeList" }
+        else if (kind === PATCH.INSERT) {
+            const marks = {}
+            if (v & ATTR.STRONG) marks.strong = { active: true }
+            if (v & ATTR.EM) marks.em = { active: true }
+            if ((v & ATTR.COMMENT) !== 0) {
+                const ids = []
+                while (k + 1 < n && res.patches[4 * (p0 + k + 1) + 1] === PATCH.INSERT_COMMENT) ids.push(res.patches[4 * (p0 + ++k) + 2])
+                marks.comment = ids.sort((x, y) => x - y).map(i => ({ id: comments[i] }))
+            }
+            if (v & ATTR.LINK) marks.link = { url: batch.urls[v & ATTR.ID_MASK] }
+            patch = { path: ["text"], action: "insert", index: a, values: [batch.values[batch.payload[b + r]]], marks }
+        } else if (kind === PATCH.DELETE) patch = { path: ["text"], action: "delete", index: a, count: v }
+        else if (kind === PATCH.ADDMARK || kind === PATCH.REMOVEMARK) {
+            const mt = batch.markType[b + r]
+            patch = { action: kind === PATCH.ADDMARK ? "addMark" : "removeMark", markType: MARK_NAMES[mt], path: ["text"], startIndex: a, endIndex: v }
+            if (kind === PATCH.ADDMARK && MARK_NAMES[mt] === "link") patch.attrs = { url: batch.urls[batch.payload[b + r] & ATTR.ID_MASK] }
+            else if (kind === PATCH.ADDMARK && MARK_NAMES[mt] === "comment") patch.attrs = { id: comments[batch.payload[b + r]] }
+        } else throw new Error("unknown patch kind " + kind)
+        out[cur].push(patch)
+    }
+    return out
+}
+
 class MergeEngine {
     /** opts: {device?: number, libPath?: string, addonPath?: string} */
     constructor(opts) {
@@ -220,8 +272,19 @@ class MergeEngine {
         this.ctx = null
     }
     /** Raw call: SoA batch -> result typed arrays (ptx_apply_materialize). */
-    applyMaterialize(batch) {
-        return this.addon.applyMaterialize(this.ctx, batch)
+    applyMaterialize(batch, wantPatches) {
+        return this.addon.applyMaterialize(this.ctx, batch, !!wantPatches)
+    }
+    /** docs: Change[][][] -> {spans: FormatSpanWithText[][][], patches: Patch[][][][]} — patches[d][r][c] is what replica r of
+     *  document d would have returned from applyChange(change c) (ptx_replay_patches). */
+    applyChangesWithPatches(docs) {
+        const batch = encodeDocs(docs)
+        const res = this.applyMaterialize(batch, true)
+        let log = 0, log2 = 0
+        return {
+            spans: docs.map(logs => logs.map(() => decodeSpans(batch, res, log++))),
+            patches: docs.map(logs => logs.map(() => decodePatches(batch, res, log2++))),
+        }
     }
     /** docs: Change[][][]  ->  FormatSpanWithText[][][] (doc -> replica -> spans).  A failed log throws RangeError like the reference. */
     applyChanges(docs) {
@@ -244,13 +307,20 @@ class MergeEngine {
     /** A replica handle with the reference's per-replica calls; all handles of one engine are merged in ONE launch. */
     replica(docId) {
         const self = this
-        const rep = { changes: [], spans: null, error: null, docId: docId === undefined ? this.pending.length : docId }
+        const rep = { changes: [], spans: null, patches: null, error: null, docId: docId === undefined ? this.pending.length : docId }
         this.pending.push(rep)
         return {
             applyChange(change) {
                 rep.changes.push(change)
                 rep.spans = null
-                return [] /* incremental Patch[] are not produced by the batch path (SURVEY.md §8 f1) */
+                rep.patches = null
+                return [] /* the call is only queued: the patches it would have returned come from getPatches() */
+            },
+            /** Patch[][]: entry c = what applyChange(c-th change) returns in the reference (one launch for all handles). */
+            getPatches() {
+                if (rep.patches === null && rep.error === null) self.flush(true)
+                if (rep.error) throw rep.error
+                return rep.patches
             },
             getTextWithFormatting(p) {
                 if (!Array.isArray(p) || p.length !== 1 || p[0] !== "text") throw new Error("Only the text list is supported: " + JSON.stringify(p))
@@ -260,7 +330,7 @@ class MergeEngine {
             },
         }
     }
-    flush() {
+    flush(wantPatches) {
         const byDoc = new Map()
         for (const r of this.pending) {
             if (!byDoc.has(r.docId)) byDoc.set(r.docId, [])
@@ -268,12 +338,13 @@ class MergeEngine {
         }
         const groups = Array.from(byDoc.values())
         const batch = encodeDocs(groups.map(g => g.map(r => r.changes)))
-        const res = this.applyMaterialize(batch)
+        const res = this.applyMaterialize(batch, wantPatches)
         let log = 0
         for (const g of groups)
             for (const r of g) {
                 try {
                     r.spans = decodeSpans(batch, res, log)
+                    if (wantPatches) r.patches = decodePatches(batch, res, log)
                     r.error = null
                 } catch (e) {
                     r.error = e
@@ -283,4 +354,4 @@ class MergeEngine {
     }
 }
 
-module.exports = { MergeEngine, encodeDocs, decodeSpans, census, ACT, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }
+module.exports = { MergeEngine, encodeDocs, decodeSpans, decodePatches, PATCH, census, ACT, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }

@@ -60,7 +60,32 @@ if (cmd === "encode") {
     }
     engine.close()
     console.log(JSON.stringify({ ok: true, logs }))
+} else if (cmd === "patches") {
+    /* GPU: the Patch[] every applyChange returns (fixtures made by the reference itself, oracle/gen_patch_golden.js) */
+    const engine = new host.MergeEngine()
+    let logs = 0, patches = 0
+    for (const f of process.argv.slice(3)) {
+        const gen = JSON.parse(fs.readFileSync(f, "utf8"))
+        const got = engine.applyChangesWithPatches(gen.docs.map(d => d.logs))
+        gen.docs.forEach((d, di) =>
+            d.expected.forEach((e, ri) => {
+                assert.deepStrictEqual(norm(got.spans[di][ri]), norm(e.spans))
+                assert.strictEqual(got.patches[di][ri].length, d.logs[ri].length, "one Patch[] per applied change")
+                const flat = [].concat(...got.patches[di][ri])
+                assert.deepStrictEqual(flat, e.patches, f + " doc " + di + " replica " + ri)
+                logs++
+                patches += flat.length
+            })
+        )
+        /* per-replica handles: getPatches() = the returns of the queued applyChange calls */
+        const reps = gen.docs[0].logs.map(() => engine.replica(0))
+        gen.docs[0].logs.forEach((log, ri) => log.forEach(ch => assert.deepStrictEqual(reps[ri].applyChange(ch), [])))
+        reps.forEach((r, ri) => assert.deepStrictEqual([].concat(...r.getPatches()), gen.docs[0].expected[ri].patches))
+        engine.pending = []
+    }
+    engine.close()
+    console.log(JSON.stringify({ ok: true, logs, patches }))
 } else {
-    console.error("usage: encode|load|run")
+    console.error("usage: encode|load|run|patches")
     process.exit(2)
 }

@@ -62,3 +62,15 @@ def test_js_encoder_matches_python_encoder(name):
 def test_node_host_drives_the_gpu_path():
     out = _node("run", *[os.path.join(H.GOLDEN, n) for n in FIXTURES], timeout=600)
     assert out["ok"] and out["logs"] == sum(len(d["expected"]) for n in FIXTURES for d in json.load(open(os.path.join(H.GOLDEN, n)))["docs"])
+
+
+@pytest.mark.gpu
+@needs_node
+@needs_addon
+def test_node_host_patch_streams():
+    """applyChangesWithPatches / replica().getPatches(): what every applyChange returns, against the fixtures the
+    reference itself produced."""
+    names = ["patches_mini.json", "patches_rich_300.json"]
+    out = _node("patches", *[os.path.join(H.GOLDEN, n) for n in names], timeout=600)
+    want = [e for n in names for d in json.load(open(os.path.join(H.GOLDEN, n)))["docs"] for e in d["expected"]]
+    assert out["ok"] and out["logs"] == len(want) and out["patches"] == sum(len(e["patches"]) for e in want)
