@@ -798,6 +798,20 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     b01 += wt01[q];
                     b23 += wt23[q];
                 }
+                /* the deps row of a change: one 16-byte load (rows are na <= 4 words, the library pads its copy of the
+                 * column so that reading four words at the last row stays inside the allocation); words past na are
+                 * not compared */
+#ifdef PTX_EMU
+#define PTX_ADM_DEPS(dst_, c_) \
+    for (uint32_t b = 0; b < 4; ++b) dst_[b] = c_deps[(uint64_t)(c_) * na + (b < na ? b : 0u)];
+#else
+#define PTX_ADM_DEPS(dst_, c_)                                                         \
+    {                                                                                  \
+        struct __attribute__((packed, aligned(4))) PtxDeps4 { uint32_t v[4]; };        \
+        const PtxDeps4 q_ = *(const PtxDeps4*)(c_deps + (uint64_t)(c_) * na);          \
+        dst_[0] = q_.v[0]; dst_[1] = q_.v[1]; dst_[2] = q_.v[2]; dst_[3] = q_.v[3];    \
+    }
+#endif
                 /* the loads of the NEXT step are in flight while this step is checked */
                 uint32_t a[PTX_AC], sq[PTX_AC], d[PTX_AC][4], a_n[PTX_AC], sq_n[PTX_AC], d_n[PTX_AC][4];
 #define PTX_ADM_LOAD(cb_, a_, sq_, d_)                                                                  \
@@ -806,23 +820,26 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         const uint32_t c_ = c0_ < hi ? c0_ : (hi ? hi - 1u : 0u);                                       \
         a_[u] = c_actor[c_];                                                                            \
         sq_[u] = c_seq[c_];                                                                             \
-        _Pragma("unroll") for (uint32_t b = 0; b < 4; ++b) d_[u][b] = c_deps[(uint64_t)c_ * na + (b < na ? b : 0u)]; \
+        PTX_ADM_DEPS(d_[u], c_)                                                                         \
     }
                 PTX_ADM_LOAD(lo, a, sq, d)
 #pragma nounroll
                 for (uint32_t cb = lo; cb < hi; cb += step) {
                     PTX_ADM_LOAD(cb + step, a_n, sq_n, d_n)
-                    uint32_t o01[PTX_AC], o23[PTX_AC], t01 = 0, t23 = 0;
+                    /* inside a step a wave sees at most 64 * PTX_AC < 256 changes: the four per-actor counts fit one
+                     * word, 8 bits each -> ONE prefix sum per step */
+                    static_assert(PTX_WS * PTX_AC < 256u, "per-step actor counts must fit 8 bits");
+                    uint32_t o01[PTX_AC], o23[PTX_AC], t8 = 0;
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
                         const bool in = cb + lane * PTX_AC + u < hi;
                         o01[u] = in && a[u] < 2u ? 1u << (16u * a[u]) : 0u;
                         o23[u] = in && (a[u] & ~1u) == 2u ? 1u << (16u * (a[u] & 1u)) : 0u;
-                        t01 += o01[u];
-                        t23 += o23[u];
+                        t8 += in && a[u] < 4u ? 1u << (8u * a[u]) : 0u;
                     }
-                    const uint32_t i01 = ptx_wave_incl_scan(t01), i23 = ptx_wave_incl_scan(t23);
-                    uint32_t w01 = b01 + i01 - t01, w23 = b23 + i23 - t23; /* the clock before this lane's first change */
+                    const uint32_t i8 = ptx_wave_incl_scan(t8), e8 = i8 - t8;
+                    /* the clock before this lane's first change */
+                    uint32_t w01 = b01 + ((e8 & 0xFFu) | ((e8 & 0xFF00u) << 8)), w23 = b23 + (((e8 >> 16) & 0xFFu) | ((e8 >> 24) << 16));
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
                         const uint32_t c = cb + lane * PTX_AC + u;
@@ -840,8 +857,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         w01 += o01[u];
                         w23 += o23[u];
                     }
-                    b01 += ptx_wave_last(i01);
-                    b23 += ptx_wave_last(i23);
+                    const uint32_t s8 = ptx_wave_last(i8);
+                    b01 += (s8 & 0xFFu) | ((s8 & 0xFF00u) << 8);
+                    b23 += ((s8 >> 16) & 0xFFu) | ((s8 >> 24) << 16);
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
                         a[u] = a_n[u];
@@ -851,6 +869,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     }
                 }
 #undef PTX_ADM_LOAD
+#undef PTX_ADM_DEPS
             }
             PTX_SYNC();
             bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);

@@ -388,7 +388,7 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
         PTX_TRY(dalloc(&b->chg_actor, NC * copies));
         PTX_TRY(dalloc(&b->chg_seq, NC * copies));
         PTX_TRY(dalloc(&b->chg_nops, NC * copies));
-        PTX_TRY(dalloc(&b->chg_deps, NC * copies * h->max_actors));
+        PTX_TRY(dalloc(&b->chg_deps, NC * copies * h->max_actors + 4)); /* + 4: the kernel reads a deps row as one 16-byte load */
         for (uint32_t k = 0; k < copies && NC; ++k) {
             const hipMemcpyKind kd = k ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
             PTX_TRY(hipMemcpyAsync(b->chg_actor + k * NC, k ? (const void*)b->chg_actor : (const void*)h->chg_actor, NC * 4, kd, ctx->stream));
