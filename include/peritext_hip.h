@@ -287,6 +287,46 @@ ptx_status ptx_pack_digests(ptx_ctx* ctx, const ptx_dresult* r, uint32_t first, 
 ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_patches* out);
 void ptx_patches_free(ptx_patches* p);
 
+/* ---- on-device change(): op logs generated in HBM ----
+ * The workload of the reference's fuzzer (test/fuzz.ts:115-205) in its seeded form PTXGEN (oracle/ptxgen.js): per
+ * document `replicas` replicas; every step a random replica makes one change() (micromerge.ts:308-441: insert /
+ * delete / addMark / removeMark given by visible indexes, resolved to element ids incl. lookAfterTombstones :762-805
+ * and changeMark peritext.ts:458-501), then two random replicas exchange what the other lacks with applyChange (:499),
+ * retrying in the reference's order on the causal RangeError; a full sync ends the document.  Document `first_doc + i`
+ * of seed `seed` is, change for change, the one oracle/ptxgen.js generates for (seed, first_doc + i).
+ * String tables of a generated batch are fixed: insert payload = the character's code, link payload = letter index of
+ * "<A-Z>.com", comment payload = rank of "comment-<k>" in string order among the document's n_comments ids,
+ * actors "doc1".."doc<replicas>". */
+typedef struct ptx_gen_config {
+    uint32_t replicas;      /* 1..4 */
+    uint32_t ops_per_log;   /* ops of every replica log (the makeList row comes on top) */
+    uint32_t mix[4];        /* percent of insert, delete, addMark, removeMark steps */
+    uint32_t n_mark_types;  /* 0..4 */
+    uint8_t mark_types[4];  /* PTX_MARK_* the mark steps draw from, in the workload's order */
+    uint32_t seed;
+    uint32_t first_doc;
+    uint32_t n_docs;
+    uint32_t list_cap;      /* list elements (incl. tombstones) per replica the on-chip state holds; 0 = ops_per_log + 8 (always enough) */
+    char initial_text[16];  /* NUL-terminated ASCII; "" = "ABCDE" (generateDocs.ts:11-42) */
+} ptx_gen_config;
+typedef struct ptx_gen_info {
+    uint32_t n_docs;
+    float kernel_ms;            /* duration of the generator launch (HIP events) */
+    const uint32_t* n_comments; /* [n_docs] */
+    void* owner;
+} ptx_gen_info;
+/* Generate n_docs documents (n_docs * replicas logs, document-major) as a resident batch, envelope and headers
+ * included, ready for ptx_merge.  PTX_ERR_CAPACITY: some document outgrew list_cap (or the LDS). */
+ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** out, ptx_gen_info* info);
+void ptx_gen_info_free(ptx_gen_info* info);
+/* Copy a resident batch back to the host (columns, envelope, headers; library-owned until ptx_host_batch_free). */
+typedef struct ptx_host_batch {
+    ptx_batch b;
+    void* owner;
+} ptx_host_batch;
+ptx_status ptx_batch_download(ptx_ctx* ctx, const ptx_dbatch* b, ptx_host_batch* out);
+void ptx_host_batch_free(ptx_host_batch* hb);
+
 /* ---- introspection ---- */
 /* Largest number of ops one log may have in this build/device (on-chip working set limit). */
 uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx);

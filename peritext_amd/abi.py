@@ -151,6 +151,29 @@ class ptx_patches(C.Structure):
     ]
 
 
+class ptx_gen_config(C.Structure):
+    _fields_ = [
+        ("replicas", C.c_uint32),
+        ("ops_per_log", C.c_uint32),
+        ("mix", C.c_uint32 * 4),
+        ("n_mark_types", C.c_uint32),
+        ("mark_types", C.c_uint8 * 4),
+        ("seed", C.c_uint32),
+        ("first_doc", C.c_uint32),
+        ("n_docs", C.c_uint32),
+        ("list_cap", C.c_uint32),
+        ("initial_text", C.c_char * 16),
+    ]
+
+
+class ptx_gen_info(C.Structure):
+    _fields_ = [("n_docs", C.c_uint32), ("kernel_ms", C.c_float), ("n_comments", u32p), ("owner", C.c_void_p)]
+
+
+class ptx_host_batch(C.Structure):
+    _fields_ = [("b", ptx_batch), ("owner", C.c_void_p)]
+
+
 # numpy dtypes with the same layout
 import numpy as np  # noqa: E402
 
@@ -200,6 +223,10 @@ FUNCTIONS = {
     "ptx_pack_digests": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp]),
     "ptx_replay_patches": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_patches)]),
     "ptx_patches_free": (None, [C.POINTER(ptx_patches)]),
+    "ptx_generate": (C.c_int32, [vp, C.POINTER(ptx_gen_config), C.POINTER(vp), C.POINTER(ptx_gen_info)]),
+    "ptx_gen_info_free": (None, [C.POINTER(ptx_gen_info)]),
+    "ptx_batch_download": (C.c_int32, [vp, vp, C.POINTER(ptx_host_batch)]),
+    "ptx_host_batch_free": (None, [C.POINTER(ptx_host_batch)]),
     "ptx_max_ops_per_log": (C.c_uint32, [vp]),
     "ptx_kernel_name": (C.c_char_p, []),
 }

@@ -1,0 +1,583 @@
+/*
+ * gen_core.h — on-device `change()`: index-based InputOperations -> id-based ops, one document per wave.
+ *
+ * What it replaces: `Micromerge.change` (reference/src/micromerge.ts:308-441) with `getListElementId` incl.
+ * `lookAfterTombstones` (:762-805) and `changeMark` (src/peritext.ts:458-501), driven by the workload of the reference's
+ * own fuzzer (test/fuzz.ts:115-205: random insert / delete / addMark / removeMark on a random replica, pairwise syncs with
+ * `applyChange` and retry on the causal RangeError, final full sync) in its seeded restatement PTXGEN
+ * (oracle/ptxgen.js: mulberry32 draws, same decision order).  Output = the replica logs in application order as the SoA
+ * op-log columns + Change envelope of include/peritext_hip.h, written straight into HBM: a generated batch goes to
+ * ptx_merge without ever visiting the host.
+ *
+ * State per replica, in LDS: the element list in document order, one u32 per element
+ *   key = counter << 2 | actor   (integer order == compareOpIds order, micromerge.ts:812-827; actors "doc1".."doc4")
+ *   bit 30 = tombstone, bit 31 = the element's `after` slot is a defined one (markOpsAfter !== undefined: set when a
+ *   non-inclusive mark op ends on it, peritext.ts:240) — what `lookAfterTombstones` looks at.
+ * plus clock / maxOp / visible length.  Marks need no other state to GENERATE ops.
+ * Everything is uniform control flow over one wave; the list primitives (find an id, select the k-th visible element,
+ * skip / shift on insert) are 64-wide ballots.  The emulation (PTX_EMU) builds the same ballots lane by lane.
+ */
+#pragma once
+#include "merge_core.h"
+
+#define PTX_GEN_MAX_R 4u
+#define PTX_GK_DEAD 0x40000000u
+#define PTX_GK_AFTER 0x80000000u
+#define PTX_GK_KEY 0x3FFFFFFFu
+
+/* one made change: where its rows sit in its author's log + what applyChange checks */
+struct PtxGenChange {
+    uint32_t rowoff;
+    uint32_t nops_start; /* nops << 24 | startOp */
+    uint32_t deps01;     /* deps[0] | deps[1] << 16 */
+    uint32_t deps23;
+};
+
+struct PtxGenArgs {
+    uint32_t n_docs, first_doc, seed;
+    uint32_t R, ops_per_log;
+    uint32_t mix0, mix01, mix012; /* cumulative percent thresholds: insert | delete | addMark | removeMark */
+    uint32_t n_mark_types;
+    uint8_t mark_types[4];        /* PTX_MARK_* in the config's order */
+    uint32_t init_len;
+    uint8_t init_text[16];
+    uint32_t rows_per_log;        /* ops_per_log + 1 (the makeList) */
+    uint32_t list_cap;            /* elements per replica list the LDS holds */
+    uint32_t lds_bytes;
+    /* outputs: log l = doc * R + r owns rows [l * rows_per_log, (l + 1) * rows_per_log) of every column and the same
+     * range of the envelope columns (compacted afterwards by the host library) */
+    uint64_t* op_id;
+    uint64_t* ref_a;
+    uint64_t* ref_b;
+    uint32_t* payload;
+    uint8_t* action;
+    uint8_t* mark_type;
+    uint8_t* side_a;
+    uint8_t* side_b;
+    uint32_t* chg_actor;
+    uint32_t* chg_seq;
+    uint32_t* chg_nops;
+    uint32_t* chg_deps;   /* stride R */
+    uint32_t* n_changes;  /* [n_docs * R] */
+    uint32_t* n_comments; /* [n_docs] comment ids "comment-0" .. "comment-(C-1)" the document uses */
+    uint32_t* status;     /* [n_docs] PTX_OK / PTX_ERR_CAPACITY */
+    /* scratch in HBM, per document: change table [R][rows_per_log] and known-comment lists [R][rows_per_log] */
+    PtxGenChange* ctab;
+    uint16_t* known;
+};
+
+struct PtxGenHdr {
+    uint32_t n[PTX_GEN_MAX_R];      /* list length incl. tombstones */
+    uint32_t vis[PTX_GEN_MAX_R];    /* visible length */
+    uint32_t clock[PTX_GEN_MAX_R][PTX_GEN_MAX_R];
+    uint32_t max_op[PTX_GEN_MAX_R];
+    uint32_t rows[PTX_GEN_MAX_R];   /* rows written to the replica's log */
+    uint32_t chgs[PTX_GEN_MAX_R];   /* changes written to its envelope */
+    uint32_t nknown[PTX_GEN_MAX_R];
+    uint32_t plo[PTX_GEN_MAX_R], phi[PTX_GEN_MAX_R]; /* pending changes of a delivery, per actor */
+    uint32_t tmp;
+    uint32_t overflow;
+    uint32_t scan_tmp[36];
+};
+
+PTX_HD uint64_t ptx_gen_lds_need(uint64_t R, uint64_t list_cap, uint64_t rows_per_log) {
+    return ptx_a16(sizeof(PtxGenHdr)) + ptx_a16(4 * R * ((list_cap + 64 + 3) & ~3ull)) + ptx_a16(4 * (list_cap + 64)) + ptx_a16(4 * ((rows_per_log >> 5) + 2)) + ptx_a16(2 * (rows_per_log + 1));
+}
+
+/* ---- 64-wide ballot over lanes: `expr` may use `lane_` ---- */
+#ifdef PTX_EMU
+#define PTX_BALLOT64(mask_, lane_, expr)                 \
+    uint64_t mask_ = 0;                                  \
+    for (uint32_t lane_ = 0; lane_ < 64u; ++lane_)       \
+        if (expr) mask_ |= 1ull << lane_;
+#define PTX_LANE0 true
+#define PTX_GEN_FOR(i, n) for (uint32_t i = 0, _gn = (n); i < _gn; ++i)
+#else
+#define PTX_BALLOT64(mask_, lane_, expr)                 \
+    uint64_t mask_;                                      \
+    {                                                    \
+        const uint32_t lane_ = threadIdx.x & 63u;        \
+        mask_ = __ballot(expr);                          \
+    }
+#define PTX_LANE0 (threadIdx.x == 0)
+#define PTX_GEN_FOR(i, n) for (uint32_t i = threadIdx.x, _gn = (n); i < _gn; i += 64u)
+#endif
+PTX_DEV uint32_t ptx_ffs64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }      /* m != 0 */
+PTX_DEV uint32_t ptx_fls64(uint64_t m) { return 63u - (uint32_t)__builtin_clzll(m); } /* m != 0 */
+PTX_DEV uint32_t ptx_select64(uint64_t m, uint32_t k) { /* position of the k-th (0-based) set bit; popcount(m) > k */
+    for (uint32_t i = 0; i < k; ++i) m &= m - 1ull;
+    return ptx_ffs64(m);
+}
+
+/* mulberry32 (oracle/ptxgen.js:31-40) and randInt = floor(next() * n / 2^32) */
+PTX_DEV uint32_t ptx_gen_rand(uint32_t& a, uint32_t n) {
+    a += 0x6d2b79f5u;
+    uint32_t t = a;
+    t = (t ^ (t >> 15)) * (t | 1u);
+    t ^= t + (t ^ (t >> 7)) * (t | 61u);
+    const uint32_t x = t ^ (t >> 14);
+    return (uint32_t)(((uint64_t)x * (uint64_t)n) >> 32);
+}
+
+/* position of the element with this key, or 0xFFFFFFFF */
+PTX_DEV uint32_t ptx_gen_find(const uint32_t* lst, uint32_t n, uint32_t key) {
+    for (uint32_t base = 0; base < n; base += 64u) {
+        PTX_BALLOT64(m, l, base + l < n && (lst[base + l] & PTX_GK_KEY) == key)
+        if (m) return base + ptx_ffs64(m);
+    }
+    return 0xFFFFFFFFu;
+}
+/* position of the visible element number `index` (getListElementId's walk, micromerge.ts:771-777), or 0xFFFFFFFF */
+PTX_DEV uint32_t ptx_gen_select(const uint32_t* lst, uint32_t n, uint32_t index) {
+    uint32_t seen = 0;
+    for (uint32_t base = 0; base < n; base += 64u) {
+        PTX_BALLOT64(m, l, base + l < n && !(lst[base + l] & PTX_GK_DEAD))
+        const uint32_t c = (uint32_t)__builtin_popcountll(m);
+        if (index < seen + c) return base + ptx_select64(m, index - seen);
+        seen += c;
+    }
+    return 0xFFFFFFFFu;
+}
+/* lookAfterTombstones (micromerge.ts:778-793): from the visible element at `pos`, over the directly following
+ * tombstones: the LAST one whose `after` slot is a defined one, else the element itself */
+PTX_DEV uint32_t ptx_gen_after_tombstones(const uint32_t* lst, uint32_t n, uint32_t pos) {
+    uint32_t pick = pos;
+    for (uint32_t base = pos + 1u; base < n; base += 64u) {
+        PTX_BALLOT64(alive, l, base + l >= n || !(lst[base + l] & PTX_GK_DEAD))
+        PTX_BALLOT64(marked, l2, base + l2 < n && (lst[base + l2] & PTX_GK_DEAD) && (lst[base + l2] & PTX_GK_AFTER))
+        const uint64_t below = alive ? ((1ull << ptx_ffs64(alive)) - 1ull) : ~0ull; /* the tombstones before the next visible element */
+        if (marked & below) pick = base + ptx_fls64(marked & below);
+        if (alive) break;
+    }
+    return pick;
+}
+
+#ifdef PTX_EMU
+#define PTX_MEM inline
+#else
+#define PTX_MEM __device__ __forceinline__
+#endif
+
+/* one op row */
+struct PtxGenRow {
+    uint64_t op_id, ref_a, ref_b;
+    uint32_t payload;
+    uint8_t action, mark_type, side_a, side_b;
+};
+PTX_DEV uint32_t ptx_gen_key_of(uint64_t id) { return ((uint32_t)(id >> 32) << 2) | ((uint32_t)id & 3u); } /* 0 for HEAD (id 0) */
+PTX_DEV uint64_t ptx_gen_id_of(uint32_t key) { return ((uint64_t)(key >> 2) << 32) | (uint64_t)(key & 3u); }
+
+PTX_DEV uint32_t ptx_gen_dep(const PtxGenChange& c, uint32_t b) { return ((b < 2u ? c.deps01 : c.deps23) >> (16u * (b & 1u))) & 0xFFFFu; }
+/* is the decimal string of j smaller than that of k (string order, j != k) */
+PTX_DEV uint32_t ptx_gen_digits(uint32_t v) {
+    uint32_t n = 1;
+    while (v >= 10u) {
+        v /= 10u;
+        ++n;
+    }
+    return n;
+}
+PTX_DEV bool ptx_gen_str_less(uint32_t j, uint32_t k) {
+    const uint32_t nj = ptx_gen_digits(j), nk = ptx_gen_digits(k);
+    if (nj == nk) return j < k;
+    if (nj < nk) {
+        uint32_t kp = k;
+        for (uint32_t q = nj; q < nk; ++q) kp /= 10u;
+        return j != kp ? j < kp : true; /* a proper prefix sorts first */
+    }
+    uint32_t jp = j;
+    for (uint32_t q = nk; q < nj; ++q) jp /= 10u;
+    return jp != k ? jp < k : false;
+}
+
+template <uint32_t kThreads>
+struct PtxGenDoc {
+    const PtxGenArgs& A;
+    PtxGenHdr* H;
+    uint32_t* lst0;      /* replica r's list = lst0 + r * lst_stride (no pointer table: nothing of this kernel lives in scratch) */
+    uint32_t lst_stride;
+    uint32_t* tmpbuf;
+    uint32_t* done;   /* pending-change bitmap of a delivery */
+    uint16_t* crank;  /* comment counter -> doc-local rank */
+    uint64_t row0;    /* first row of replica 0's log */
+    PtxGenChange* ctab;
+    uint16_t* known;
+    uint32_t cap;
+
+    PTX_MEM uint64_t log_base(uint32_t r) const { return row0 + (uint64_t)r * A.rows_per_log; }
+    PTX_MEM uint32_t* lst(uint32_t r) const { return lst0 + (uint64_t)r * lst_stride; }
+
+    /* applyOp on replica r's list (micromerge.ts:614-640 insert, :677-695 delete; for marks only the `after` flag) */
+    PTX_MEM void apply(uint32_t r, const PtxGenRow& o) {
+        uint32_t* L = lst(r);
+        const uint32_t n = H->n[r];
+        if (o.action == PTX_ACT_INSERT) {
+            const uint32_t key = ptx_gen_key_of(o.op_id);
+            uint32_t at = 0;
+            if (o.ref_a != 0) at = ptx_gen_find(L, n, ptx_gen_key_of(o.ref_a)) + 1u; /* the reference element exists (causal delivery) */
+            /* skip the elements with a greater id (concurrent inserts at the same spot, :630-635) */
+            for (;;) {
+                PTX_BALLOT64(stop, l, at + l >= n || (L[at + l] & PTX_GK_KEY) < key)
+                if (stop) {
+                    at += ptx_ffs64(stop);
+                    break;
+                }
+                at += 64u;
+            }
+            if (n + 1u > cap) {
+                if (PTX_LANE0) H->overflow = 1;
+                PTX_SYNC();
+                return;
+            }
+            const uint32_t cnt = n - at;
+            PTX_GEN_FOR(i, cnt) tmpbuf[i] = L[at + i];
+            PTX_SYNC();
+            PTX_GEN_FOR(i, cnt) L[at + 1u + i] = tmpbuf[i];
+            if (PTX_LANE0) {
+                L[at] = key;
+                H->n[r] = n + 1u;
+                H->vis[r] += 1u;
+            }
+            PTX_SYNC();
+        } else if (o.action == PTX_ACT_DELETE) {
+            const uint32_t p = ptx_gen_find(L, n, ptx_gen_key_of(o.ref_a));
+            if (PTX_LANE0 && p != 0xFFFFFFFFu && !(L[p] & PTX_GK_DEAD)) {
+                L[p] |= PTX_GK_DEAD;
+                H->vis[r] -= 1u;
+            }
+            PTX_SYNC();
+        } else if ((o.action == PTX_ACT_ADDMARK || o.action == PTX_ACT_REMOVEMARK) && o.side_b == PTX_SIDE_AFTER) {
+            const uint32_t p = ptx_gen_find(L, n, ptx_gen_key_of(o.ref_b));
+            if (PTX_LANE0 && p != 0xFFFFFFFFu) L[p] |= PTX_GK_AFTER;
+            PTX_SYNC();
+        }
+    }
+
+    PTX_MEM void write_row(uint32_t r, const PtxGenRow& o) {
+        const uint32_t k = H->rows[r];
+        if (PTX_LANE0 && k < A.rows_per_log) {
+            const uint64_t at = log_base(r) + k;
+            A.op_id[at] = o.op_id;
+            A.ref_a[at] = o.ref_a;
+            A.ref_b[at] = o.ref_b;
+            A.payload[at] = o.payload;
+            A.action[at] = o.action;
+            A.mark_type[at] = o.mark_type;
+            A.side_a[at] = o.side_a;
+            A.side_b[at] = o.side_b;
+        }
+        PTX_SYNC();
+        if (PTX_LANE0) H->rows[r] = k + 1u;
+        PTX_SYNC();
+    }
+    PTX_MEM PtxGenRow read_row(uint32_t r, uint32_t k) const {
+        const uint64_t at = log_base(r) + k;
+        PtxGenRow o;
+        o.op_id = A.op_id[at];
+        o.ref_a = A.ref_a[at];
+        o.ref_b = A.ref_b[at];
+        o.payload = A.payload[at];
+        o.action = A.action[at];
+        o.mark_type = A.mark_type[at];
+        o.side_a = A.side_a[at];
+        o.side_b = A.side_b[at];
+        return o;
+    }
+    /* envelope entry of a change applied by replica r + what `record` keeps (ptxgen.js:98-107) */
+    PTX_MEM void record(uint32_t r, uint32_t actor, uint32_t seq, const PtxGenChange& c) {
+        const uint32_t k = H->chgs[r], nops = c.nops_start >> 24;
+        if (PTX_LANE0 && k < A.rows_per_log) {
+            const uint64_t at = log_base(r) + k;
+            A.chg_actor[at] = actor;
+            A.chg_seq[at] = seq;
+            A.chg_nops[at] = nops;
+            for (uint32_t b = 0; b < A.R; ++b) A.chg_deps[at * A.R + b] = ptx_gen_dep(c, b);
+            H->chgs[r] = k + 1u;
+        }
+        PTX_SYNC();
+    }
+    PTX_MEM void note_comment(uint32_t r, const PtxGenRow& o) {
+        if (o.action == PTX_ACT_ADDMARK && o.mark_type == PTX_MARK_COMMENT) {
+            if (PTX_LANE0) {
+                const uint32_t k = H->nknown[r];
+                if (k < A.rows_per_log) known[(uint64_t)r * A.rows_per_log + k] = (uint16_t)o.payload;
+                H->nknown[r] = k + 1u;
+            }
+            PTX_SYNC();
+        }
+    }
+
+    /* applyChange of change (actor, s) on replica dst (micromerge.ts:499-514): false = the causal RangeError */
+    PTX_MEM bool deliver_one(uint32_t dst, uint32_t actor, uint32_t s) {
+        const PtxGenChange c = ctab[(uint64_t)actor * A.rows_per_log + s];
+        if (s + 1u != H->clock[dst][actor] + 1u) return false;
+        for (uint32_t b = 0; b < A.R; ++b)
+            if (H->clock[dst][b] < ptx_gen_dep(c, b)) return false;
+        const uint32_t nops = c.nops_start >> 24, start = c.nops_start & 0xFFFFFFu;
+        for (uint32_t k = 0; k < nops; ++k) {
+            const PtxGenRow o = read_row(actor, c.rowoff + k);
+            apply(dst, o);
+            write_row(dst, o);
+            note_comment(dst, o);
+        }
+        if (PTX_LANE0) {
+            H->clock[dst][actor] = s + 1u;
+            const uint32_t last = start + nops - 1u;
+            if (last > H->max_op[dst]) H->max_op[dst] = last;
+        }
+        PTX_SYNC();
+        record(dst, actor, s + 1u, c);
+        return true;
+    }
+    /* deliver to dst everything src has applied and dst has not (ptxgen.js:122-147): the pending queue with its
+     * push-back-on-failure discipline = repeated passes, in order, over the not-yet-applied entries */
+    PTX_MEM void deliver(uint32_t src, uint32_t dst) {
+        uint32_t total = 0;
+        for (uint32_t a = 0; a < A.R; ++a) {
+            const uint32_t l = H->clock[dst][a], h = H->clock[src][a] > l ? H->clock[src][a] : l;
+            total += h - l;
+        }
+        if (total == 0) return;
+        PTX_SYNC();
+        if (PTX_LANE0)
+            for (uint32_t a = 0; a < A.R; ++a) { /* the pending list is fixed when the delivery starts */
+                const uint32_t l = H->clock[dst][a];
+                H->plo[a] = l;
+                H->phi[a] = H->clock[src][a] > l ? H->clock[src][a] : l;
+            }
+        PTX_GEN_FOR(w, (total >> 5) + 1u) done[w] = 0;
+        PTX_SYNC();
+        uint32_t remaining = total;
+        for (uint32_t pass = 0; remaining && pass <= total; ++pass) {
+            uint32_t idx = 0;
+            for (uint32_t a = 0; a < A.R; ++a)
+                for (uint32_t s = H->plo[a]; s < H->phi[a]; ++s, ++idx) {
+                    if ((done[idx >> 5] >> (idx & 31)) & 1u) continue;
+                    if (deliver_one(dst, a, s)) {
+                        if (PTX_LANE0) done[idx >> 5] |= 1u << (idx & 31);
+                        PTX_SYNC();
+                        --remaining;
+                    }
+                }
+        }
+    }
+
+    /* one emitted op of change(): id = maxOp + 1, applied locally at once (micromerge.ts:483-493) */
+    PTX_MEM void emit(uint32_t k, PtxGenRow o, uint32_t& nops) {
+        const uint32_t ctr = H->max_op[k] + 1u;
+        PTX_SYNC();
+        if (PTX_LANE0) H->max_op[k] = ctr;
+        PTX_SYNC();
+        o.op_id = ((uint64_t)ctr << 32) | k;
+        apply(k, o);
+        write_row(k, o);
+        note_comment(k, o);
+        ++nops;
+    }
+};
+
+template <uint32_t kThreads>
+PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) {
+    PtxGenHdr* H = (PtxGenHdr*)lds;
+    const uint32_t R = A.R, N = A.rows_per_log;
+    PtxBump bp;
+    bp.base = lds;
+    bp.off = (uint32_t)ptx_a16(sizeof(PtxGenHdr));
+    bp.cap = A.lds_bytes;
+    bp.high = bp.off;
+    bp.overflow = false;
+    PtxGenDoc<kThreads> G{A, H, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, A.list_cap};
+    G.lst_stride = (A.list_cap + 64u + 3u) & ~3u;
+    G.lst0 = ptx_alloc<uint32_t>(bp, G.lst_stride * R);
+    G.tmpbuf = ptx_alloc<uint32_t>(bp, A.list_cap + 64);
+    G.done = ptx_alloc<uint32_t>(bp, (N >> 5) + 2);
+    G.crank = ptx_alloc<uint16_t>(bp, N + 1);
+    G.row0 = (uint64_t)doc_local * R * N;
+    G.ctab = A.ctab + (uint64_t)doc_local * R * N;
+    G.known = A.known + (uint64_t)doc_local * R * N;
+    if (bp.overflow || R == 0 || R > PTX_GEN_MAX_R || N > 0xFFFFFFu) {
+        if (PTX_LANE0) {
+            A.status[doc_local] = PTX_ERR_CAPACITY;
+            A.n_comments[doc_local] = 0;
+            for (uint32_t r = 0; r < R && r < PTX_GEN_MAX_R; ++r) A.n_changes[doc_local * R + r] = 0;
+        }
+        return;
+    }
+    if (PTX_LANE0) {
+        for (uint32_t r = 0; r < PTX_GEN_MAX_R; ++r) {
+            H->n[r] = H->vis[r] = H->max_op[r] = H->rows[r] = H->chgs[r] = H->nknown[r] = 0;
+            for (uint32_t a = 0; a < PTX_GEN_MAX_R; ++a) H->clock[r][a] = 0;
+        }
+        H->overflow = 0;
+        H->tmp = 0;
+    }
+    PTX_SYNC();
+
+    /* docSeed (ptxgen.js:62-64) */
+    uint32_t rng = (0x5eed0000u + (A.first_doc + doc_local)) ^ (A.seed * 0x9e3779b1u);
+    uint32_t comment_counter = 0;
+
+    /* one change() of replica k: `body` emits the ops */
+#define PTX_GEN_CHANGE_BEGIN(k_)                                                                 \
+    const uint32_t ck_ = (k_);                                                                   \
+    uint32_t nops_ = 0;                                                                          \
+    PtxGenChange c_;                                                                             \
+    c_.deps01 = H->clock[ck_][0] | (H->clock[ck_][1] << 16);                                     \
+    c_.deps23 = H->clock[ck_][2] | (H->clock[ck_][3] << 16);                                     \
+    c_.rowoff = H->rows[ck_];                                                                    \
+    const uint32_t seq_ = H->clock[ck_][ck_] + 1u, start_ = H->max_op[ck_] + 1u;                 \
+    PTX_SYNC();                                                                                  \
+    if (PTX_LANE0) H->clock[ck_][ck_] = seq_;                                                    \
+    PTX_SYNC();
+#define PTX_GEN_CHANGE_END()                                                                     \
+    c_.nops_start = (nops_ << 24) | start_;                                                      \
+    if (PTX_LANE0) G.ctab[(uint64_t)ck_ * N + (seq_ - 1u)] = c_;                                 \
+    PTX_SYNC();                                                                                  \
+    G.record(ck_, ck_, seq_, c_);
+
+    /* generateDocs (ptxgen.js:109-121): doc1 creates the list + the initial text, everybody applies it */
+    {
+        PTX_GEN_CHANGE_BEGIN(0u)
+        PtxGenRow o;
+        o.op_id = 0;
+        o.ref_a = o.ref_b = 0;
+        o.payload = 0;
+        o.action = PTX_ACT_MAKELIST;
+        o.mark_type = o.side_a = o.side_b = 0;
+        G.emit(0u, o, nops_);
+        uint64_t ref = 0;
+        for (uint32_t i = 0; i < A.init_len; ++i) {
+            o.action = PTX_ACT_INSERT;
+            o.ref_a = ref;
+            o.payload = A.init_text[i];
+            G.emit(0u, o, nops_);
+            ref = ((uint64_t)H->max_op[0] << 32) | 0u;
+        }
+        PTX_GEN_CHANGE_END()
+    }
+    for (uint32_t i = 1; i < R; ++i) G.deliver_one(i, 0u, 0u);
+    uint32_t ops_so_far = A.init_len;
+
+    while (ops_so_far < A.ops_per_log && !H->overflow) {
+        const uint32_t k = ptx_gen_rand(rng, R);
+        const uint32_t len = H->vis[k];
+        const uint32_t budget = A.ops_per_log - ops_so_far;
+        const uint32_t x = ptx_gen_rand(rng, 100u);
+        uint32_t kind = x < A.mix0 ? 0u : x < A.mix01 ? 1u : x < A.mix012 ? 2u : 3u;
+        if (kind == 1u && len < 2u) kind = 0u;
+        if (kind >= 2u && (len < 1u || A.n_mark_types == 0u)) kind = 0u;
+        PTX_GEN_CHANGE_BEGIN(k)
+        PtxGenRow o;
+        o.op_id = 0;
+        o.ref_a = o.ref_b = 0;
+        o.payload = 0;
+        o.mark_type = o.side_a = o.side_b = 0;
+        if (kind == 0u) {
+            /* insert (micromerge.ts:335-345): after the element at index-1, past its tombstones */
+            const uint32_t index = ptx_gen_rand(rng, len + 1u);
+            uint32_t nvals = 1u + ptx_gen_rand(rng, 2u);
+            if (nvals > budget) nvals = budget;
+            uint64_t ref = 0;
+            if (index != 0u) {
+                const uint32_t p = ptx_gen_select(G.lst(k), H->n[k], index - 1u);
+                ref = ptx_gen_id_of(G.lst(k)[ptx_gen_after_tombstones(G.lst(k), H->n[k], p)] & PTX_GK_KEY);
+            }
+            for (uint32_t v = 0; v < nvals; ++v) {
+                const uint32_t h = ptx_gen_rand(rng, 16u);
+                o.action = PTX_ACT_INSERT;
+                o.ref_a = ref;
+                o.payload = h < 10u ? 48u + h : 87u + h; /* "0123456789abcdef" */
+                G.emit(k, o, nops_);
+                ref = ((uint64_t)H->max_op[k] << 32) | k;
+            }
+        } else if (kind == 1u) {
+            /* delete (micromerge.ts:346-352): always the same visible index */
+            const uint32_t index = 1u + ptx_gen_rand(rng, len - 1u);
+            const uint32_t room = len - index;
+            uint32_t count = 1u + ptx_gen_rand(rng, room < 3u ? room : 3u);
+            if (count > budget) count = budget;
+            for (uint32_t q = 0; q < count; ++q) {
+                const uint32_t p = ptx_gen_select(G.lst(k), H->n[k], index);
+                o.action = PTX_ACT_DELETE;
+                o.ref_a = ptx_gen_id_of(G.lst(k)[p] & PTX_GK_KEY);
+                G.emit(k, o, nops_);
+            }
+        } else {
+            /* changeMark (peritext.ts:458-501) */
+            const uint32_t start_index = ptx_gen_rand(rng, len);
+            const uint32_t end_index = start_index + 1u + ptx_gen_rand(rng, len - start_index);
+            const uint32_t mt = A.mark_types[ptx_gen_rand(rng, A.n_mark_types)];
+            bool add = kind == 2u;
+            uint32_t pay = 0;
+            if (mt == PTX_MARK_LINK) {
+                const uint32_t u = ptx_gen_rand(rng, 26u); /* drawn for removeMark too */
+                if (add) pay = u;
+            } else if (mt == PTX_MARK_COMMENT) {
+                if (!add && H->nknown[k] == 0u) add = true;
+                if (add) pay = comment_counter++;
+                else pay = G.known[(uint64_t)k * N + ptx_gen_rand(rng, H->nknown[k])];
+            }
+            const bool inclusive = mt == PTX_MARK_STRONG || mt == PTX_MARK_EM; /* schema.ts:45-96 */
+            o.action = add ? PTX_ACT_ADDMARK : PTX_ACT_REMOVEMARK;
+            o.mark_type = (uint8_t)mt;
+            o.payload = pay;
+            o.side_a = PTX_SIDE_BEFORE;
+            o.ref_a = ptx_gen_id_of(G.lst(k)[ptx_gen_select(G.lst(k), H->n[k], start_index)] & PTX_GK_KEY);
+            if (inclusive && end_index >= len) {
+                o.side_b = PTX_SIDE_END_OF_TEXT;
+                o.ref_b = 0;
+            } else if (inclusive) {
+                o.side_b = PTX_SIDE_BEFORE;
+                o.ref_b = ptx_gen_id_of(G.lst(k)[ptx_gen_select(G.lst(k), H->n[k], end_index)] & PTX_GK_KEY);
+            } else {
+                o.side_b = PTX_SIDE_AFTER;
+                o.ref_b = ptx_gen_id_of(G.lst(k)[ptx_gen_select(G.lst(k), H->n[k], end_index - 1u)] & PTX_GK_KEY);
+            }
+            G.emit(k, o, nops_);
+        }
+        PTX_GEN_CHANGE_END()
+        ops_so_far += nops_;
+        if (R > 1u) {
+            const uint32_t left = ptx_gen_rand(rng, R);
+            uint32_t right = ptx_gen_rand(rng, R - 1u);
+            if (right >= left) ++right;
+            G.deliver(left, right);
+            G.deliver(right, left);
+        }
+    }
+    /* final full sync (ptxgen.js:203-206) */
+    for (uint32_t round = 0; round < R + 1u; ++round)
+        for (uint32_t i = 0; i < R; ++i)
+            for (uint32_t j = 0; j < R; ++j)
+                if (i != j) G.deliver(i, j);
+#undef PTX_GEN_CHANGE_BEGIN
+#undef PTX_GEN_CHANGE_END
+
+    /* comment ids "comment-<k>": the wire format wants their rank in string order inside the document
+     * (peritext.ts:318 keeps comment arrays id-sorted): decimal strings compared digit by digit */
+    const uint32_t C = comment_counter;
+    PTX_GEN_FOR(kk, C) {
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < C; ++j) rank += j != kk && ptx_gen_str_less(j, kk) ? 1u : 0u;
+        G.crank[kk] = (uint16_t)rank;
+    }
+    PTX_SYNC();
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint64_t b0 = G.log_base(r);
+        const uint32_t nr = H->rows[r] < N ? H->rows[r] : N;
+        PTX_GEN_FOR(i, nr) {
+            if (A.mark_type[b0 + i] == PTX_MARK_COMMENT && (A.action[b0 + i] == PTX_ACT_ADDMARK || A.action[b0 + i] == PTX_ACT_REMOVEMARK))
+                A.payload[b0 + i] = G.crank[A.payload[b0 + i]];
+        }
+    }
+    PTX_SYNC();
+    if (PTX_LANE0) {
+        bool bad = H->overflow != 0;
+        for (uint32_t r = 0; r < R; ++r) {
+            A.n_changes[doc_local * R + r] = H->chgs[r];
+            if (H->rows[r] != N || H->chgs[r] > N) bad = true;
+        }
+        A.n_comments[doc_local] = C;
+        A.status[doc_local] = bad ? (uint32_t)PTX_ERR_CAPACITY : (uint32_t)PTX_OK;
+    }
+}

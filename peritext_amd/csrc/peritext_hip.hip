@@ -21,6 +21,7 @@
 
 #include "merge_core.h"
 #include "replay_core.h"
+#include "gen_core.h"
 
 /* ------------------------------------------------------------------------------------------------ */
 /* kernels                                                                                          */
@@ -47,6 +48,28 @@ PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, 1, true, 0, true)  /* + phase cycl
 extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kernel(PtxReplayArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS>(A, blockIdx.x, ptx_lds);
+}
+
+/* On-device change() / PTXGEN (gen_core.h): one 64-thread workgroup (one wave) per document */
+extern "C" __global__ void __launch_bounds__(64) ptx_gen_kernel(PtxGenArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
+    if (blockIdx.x < A.n_docs) ptx_gen_doc<64>(A, blockIdx.x, ptx_lds);
+}
+/* envelope of a generated batch: capacity layout (rows_per_log entries per log) -> compact */
+__global__ void ptx_gen_compact_kernel(const uint64_t* chg_off, uint32_t rows_per_log, uint32_t R, const uint32_t* sa, const uint32_t* ss, const uint32_t* sn,
+                                       const uint32_t* sd, uint32_t* da, uint32_t* ds, uint32_t* dn, uint32_t* dd) {
+    const uint32_t log = blockIdx.x;
+    const uint64_t c0 = chg_off[log], c1 = chg_off[log + 1], s0 = (uint64_t)log * rows_per_log;
+    for (uint64_t i = threadIdx.x; i < c1 - c0; i += blockDim.x) {
+        da[c0 + i] = sa[s0 + i];
+        ds[c0 + i] = ss[s0 + i];
+        dn[c0 + i] = sn[s0 + i];
+        for (uint32_t b = 0; b < R; ++b) dd[(c0 + i) * R + b] = sd[(s0 + i) * R + b];
+    }
+}
+__global__ void ptx_regular_offsets_kernel(uint64_t* dst, uint32_t n, uint64_t stride) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) dst[i] = (uint64_t)i * stride;
 }
 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
@@ -275,7 +298,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel, (const void*)ptx_gen_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -823,6 +846,275 @@ ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresu
     out->patch_off = h->off.data();
     out->logs = h->logs.data();
     out->patches = h->patches.data();
+    return PTX_OK;
+}
+
+/* ---- on-device change() ---- */
+struct ptx_host_gen {
+    std::vector<uint32_t> n_comments;
+};
+void ptx_gen_info_free(ptx_gen_info* info) {
+    if (!info) return;
+    delete (ptx_host_gen*)info->owner;
+    memset(info, 0, sizeof(*info));
+}
+
+ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** out, ptx_gen_info* info) {
+    if (!ctx || !cfg || !out) return PTX_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (info) memset(info, 0, sizeof(*info));
+    if (cfg->replicas < 1 || cfg->replicas > PTX_GEN_MAX_R || cfg->n_mark_types > 4 || cfg->ops_per_log < 1 || cfg->ops_per_log > 65533u ||
+        cfg->mix[0] + cfg->mix[1] + cfg->mix[2] + cfg->mix[3] != 100u)
+        return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_generate: 1..4 replicas, at most 65533 ops per log, mix percentages summing to 100");
+    const size_t tl = strnlen(cfg->initial_text, sizeof(cfg->initial_text));
+    const char* text = tl ? cfg->initial_text : "ABCDE";
+    const uint32_t init_len = (uint32_t)(tl ? tl : 5);
+    if (init_len > cfg->ops_per_log || tl >= sizeof(cfg->initial_text)) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_generate: initial text too long");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t R = cfg->replicas, N = cfg->ops_per_log + 1u, D = cfg->n_docs;
+    if ((uint64_t)D * R > 0xFFFFFFFFull) return fail(ctx, PTX_ERR_INVALID_ARG, "too many logs");
+    ptx_dbatch* b = new ptx_dbatch();
+    b->n_logs = D * R;
+    b->n_ops = (uint64_t)b->n_logs * N;
+    b->max_actors = R;
+    const uint64_t T = b->n_ops;
+    uint32_t *cap_actor = nullptr, *cap_seq = nullptr, *cap_nops = nullptr, *cap_deps = nullptr, *d_nchg = nullptr, *d_ncom = nullptr, *d_status = nullptr;
+    PtxGenChange* d_ctab = nullptr;
+    uint16_t* d_known = nullptr;
+    auto drop = [&]() {
+        (void)hipFree(cap_actor);
+        (void)hipFree(cap_seq);
+        (void)hipFree(cap_nops);
+        (void)hipFree(cap_deps);
+        (void)hipFree(d_nchg);
+        (void)hipFree(d_ncom);
+        (void)hipFree(d_status);
+        (void)hipFree(d_ctab);
+        (void)hipFree(d_known);
+    };
+#define PTX_TRYG(call)                                  \
+    do {                                                \
+        hipError_t _e = (call);                         \
+        if (_e != hipSuccess) {                         \
+            std::string m = std::string(#call) + ": " + hipGetErrorString(_e); \
+            drop();                                     \
+            ptx_batch_free(ctx, b);                     \
+            return fail(ctx, _e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, m); \
+        }                                               \
+    } while (0)
+    PTX_TRYG(dalloc(&b->log_off, (uint64_t)b->n_logs + 1));
+    PTX_TRYG(dalloc(&b->op_id, T));
+    PTX_TRYG(dalloc(&b->ref_a, T));
+    PTX_TRYG(dalloc(&b->ref_b, T));
+    PTX_TRYG(dalloc(&b->payload, T));
+    PTX_TRYG(dalloc(&b->action, T));
+    PTX_TRYG(dalloc(&b->mark_type, T));
+    PTX_TRYG(dalloc(&b->side_a, T));
+    PTX_TRYG(dalloc(&b->side_b, T));
+    PTX_TRYG(dalloc(&b->log_hdr, (uint64_t)b->n_logs));
+    PTX_TRYG(dalloc(&b->chg_off, (uint64_t)b->n_logs + 1));
+    PTX_TRYG(dalloc(&cap_actor, T));
+    PTX_TRYG(dalloc(&cap_seq, T));
+    PTX_TRYG(dalloc(&cap_nops, T));
+    PTX_TRYG(dalloc(&cap_deps, T * R));
+    PTX_TRYG(dalloc(&d_nchg, (uint64_t)b->n_logs));
+    PTX_TRYG(dalloc(&d_ncom, (uint64_t)D));
+    PTX_TRYG(dalloc(&d_status, (uint64_t)D));
+    PTX_TRYG(dalloc(&d_ctab, T));
+    PTX_TRYG(dalloc(&d_known, T));
+    if (D == 0) {
+        drop();
+        PTX_TRYG(hipMemsetAsync(b->log_off, 0, 8, ctx->stream));
+        PTX_TRYG(hipMemsetAsync(b->chg_off, 0, 8, ctx->stream));
+        PTX_TRYG(hipStreamSynchronize(ctx->stream));
+        shape_launch(ctx, b, 0, 0);
+        *out = b;
+        return PTX_OK;
+    }
+    PtxGenArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n_docs = D;
+    A.first_doc = cfg->first_doc;
+    A.seed = cfg->seed;
+    A.R = R;
+    A.ops_per_log = cfg->ops_per_log;
+    A.mix0 = cfg->mix[0];
+    A.mix01 = cfg->mix[0] + cfg->mix[1];
+    A.mix012 = cfg->mix[0] + cfg->mix[1] + cfg->mix[2];
+    A.n_mark_types = cfg->n_mark_types;
+    memcpy(A.mark_types, cfg->mark_types, 4);
+    A.init_len = init_len;
+    memcpy(A.init_text, text, init_len);
+    A.rows_per_log = N;
+    A.list_cap = cfg->list_cap ? cfg->list_cap : N + 8u;
+    const uint64_t need = ptx_gen_lds_need(R, A.list_cap, N);
+    if (need > ctx->max_lds) {
+        drop();
+        ptx_batch_free(ctx, b);
+        return fail(ctx, PTX_ERR_CAPACITY, "ptx_generate: list_cap x replicas exceeds the LDS of a CU; pass a smaller list_cap");
+    }
+    A.lds_bytes = (uint32_t)((need + 255) & ~255ull);
+    A.op_id = b->op_id;
+    A.ref_a = b->ref_a;
+    A.ref_b = b->ref_b;
+    A.payload = b->payload;
+    A.action = b->action;
+    A.mark_type = b->mark_type;
+    A.side_a = b->side_a;
+    A.side_b = b->side_b;
+    A.chg_actor = cap_actor;
+    A.chg_seq = cap_seq;
+    A.chg_nops = cap_nops;
+    A.chg_deps = cap_deps;
+    A.n_changes = d_nchg;
+    A.n_comments = d_ncom;
+    A.status = d_status;
+    A.ctab = d_ctab;
+    A.known = d_known;
+    hipLaunchKernelGGL(ptx_regular_offsets_kernel, dim3((b->n_logs + 256) / 256), dim3(256), 0, ctx->stream, b->log_off, b->n_logs, (uint64_t)N);
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
+    hipLaunchKernelGGL(ptx_gen_kernel, dim3(D), dim3(64), A.lds_bytes, ctx->stream, A);
+    PTX_TRYG(hipGetLastError());
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    std::vector<uint32_t> nchg(b->n_logs), status(D);
+    ptx_host_gen* hg = new ptx_host_gen();
+    hg->n_comments.resize(D);
+    hipError_t e = hipMemcpyAsync(nchg.data(), d_nchg, (size_t)b->n_logs * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(status.data(), d_status, (size_t)D * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hg->n_comments.data(), d_ncom, (size_t)D * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    float ms = 0;
+    if (e == hipSuccess) (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    uint32_t failed = 0;
+    for (uint32_t d = 0; d < D && e == hipSuccess; ++d) failed += status[d] != PTX_OK;
+    if (e != hipSuccess || failed) {
+        delete hg;
+        drop();
+        ptx_batch_free(ctx, b);
+        if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_gen_kernel: ") + hipGetErrorString(e));
+        return fail(ctx, PTX_ERR_CAPACITY, std::to_string(failed) + " generated document(s) outgrew list_cap");
+    }
+    /* compact the envelope */
+    std::vector<uint64_t> coff((size_t)b->n_logs + 1, 0);
+    for (uint32_t l = 0; l < b->n_logs; ++l) coff[l + 1] = coff[l] + nchg[l];
+    const uint64_t NC = coff[b->n_logs];
+    b->n_changes = NC;
+    auto fin = [&](hipError_t err) { /* error after this point */
+        delete hg;
+        drop();
+        ptx_batch_free(ctx, b);
+        return fail(ctx, err == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("ptx_generate: ") + hipGetErrorString(err));
+    };
+    e = dalloc(&b->chg_actor, NC);
+    if (e == hipSuccess) e = dalloc(&b->chg_seq, NC);
+    if (e == hipSuccess) e = dalloc(&b->chg_nops, NC);
+    if (e == hipSuccess) e = dalloc(&b->chg_deps, NC * R + 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->chg_off, coff.data(), ((size_t)b->n_logs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return fin(e);
+    hipLaunchKernelGGL(ptx_gen_compact_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->chg_off, N, R, cap_actor, cap_seq, cap_nops, cap_deps, b->chg_actor,
+                       b->chg_seq, b->chg_nops, b->chg_deps);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fin(e);
+    drop();
+    const ptx_status st = census_and_shape(ctx, b, false);
+    if (st != PTX_OK) {
+        delete hg;
+        ptx_batch_free(ctx, b);
+        return st;
+    }
+    if (info) {
+        info->n_docs = D;
+        info->kernel_ms = ms;
+        info->n_comments = hg->n_comments.data();
+        info->owner = hg;
+    } else {
+        delete hg;
+    }
+    *out = b;
+    return PTX_OK;
+#undef PTX_TRYG
+}
+
+struct ptx_host_batch_store {
+    std::vector<uint64_t> log_off, op_id, ref_a, ref_b, chg_off;
+    std::vector<uint32_t> payload, chg_actor, chg_seq, chg_nops, chg_deps;
+    std::vector<uint8_t> action, mark_type, side_a, side_b;
+    std::vector<ptx_log_hdr> hdr;
+};
+void ptx_host_batch_free(ptx_host_batch* hb) {
+    if (!hb) return;
+    delete (ptx_host_batch_store*)hb->owner;
+    memset(hb, 0, sizeof(*hb));
+}
+ptx_status ptx_batch_download(ptx_ctx* ctx, const ptx_dbatch* b, ptx_host_batch* out) {
+    if (!ctx || !b || !out) return PTX_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    ptx_host_batch_store* s = new ptx_host_batch_store();
+    const uint64_t T = b->n_ops, L = b->n_logs, NC = b->chg_off ? b->n_changes : 0;
+    s->log_off.resize(L + 1);
+    s->op_id.resize(std::max<uint64_t>(T, 1));
+    s->ref_a.resize(std::max<uint64_t>(T, 1));
+    s->ref_b.resize(std::max<uint64_t>(T, 1));
+    s->payload.resize(std::max<uint64_t>(T, 1));
+    s->action.resize(std::max<uint64_t>(T, 1));
+    s->mark_type.resize(std::max<uint64_t>(T, 1));
+    s->side_a.resize(std::max<uint64_t>(T, 1));
+    s->side_b.resize(std::max<uint64_t>(T, 1));
+    s->hdr.resize(std::max<uint64_t>(L, 1));
+    hipError_t e = hipMemcpyAsync(s->log_off.data(), b->log_off, (L + 1) * 8, hipMemcpyDeviceToHost, ctx->stream);
+    auto dl = [&](void* dst, const void* src, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    };
+    dl(s->op_id.data(), b->op_id, T * 8);
+    dl(s->ref_a.data(), b->ref_a, T * 8);
+    dl(s->ref_b.data(), b->ref_b, T * 8);
+    dl(s->payload.data(), b->payload, T * 4);
+    dl(s->action.data(), b->action, T);
+    dl(s->mark_type.data(), b->mark_type, T);
+    dl(s->side_a.data(), b->side_a, T);
+    dl(s->side_b.data(), b->side_b, T);
+    dl(s->hdr.data(), b->log_hdr, L * sizeof(ptx_log_hdr));
+    if (b->chg_off) {
+        s->chg_off.resize(L + 1);
+        s->chg_actor.resize(std::max<uint64_t>(NC, 1));
+        s->chg_seq.resize(std::max<uint64_t>(NC, 1));
+        s->chg_nops.resize(std::max<uint64_t>(NC, 1));
+        s->chg_deps.resize(std::max<uint64_t>(NC * b->max_actors, 1));
+        dl(s->chg_off.data(), b->chg_off, (L + 1) * 8);
+        dl(s->chg_actor.data(), b->chg_actor, NC * 4);
+        dl(s->chg_seq.data(), b->chg_seq, NC * 4);
+        dl(s->chg_nops.data(), b->chg_nops, NC * 4);
+        dl(s->chg_deps.data(), b->chg_deps, NC * b->max_actors * 4);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        delete s;
+        return fail(ctx, PTX_ERR_HIP, std::string("batch download: ") + hipGetErrorString(e));
+    }
+    ptx_batch& h = out->b;
+    h.n_logs = b->n_logs;
+    h.n_ops = T;
+    h.log_off = s->log_off.data();
+    h.op_id = s->op_id.data();
+    h.ref_a = s->ref_a.data();
+    h.ref_b = s->ref_b.data();
+    h.payload = s->payload.data();
+    h.action = s->action.data();
+    h.mark_type = s->mark_type.data();
+    h.side_a = s->side_a.data();
+    h.side_b = s->side_b.data();
+    h.log_hdr = s->hdr.data();
+    if (b->chg_off) {
+        h.chg_off = s->chg_off.data();
+        h.chg_actor = s->chg_actor.data();
+        h.chg_seq = s->chg_seq.data();
+        h.chg_nops = s->chg_nops.data();
+        h.chg_deps = s->chg_deps.data();
+        h.max_actors = b->max_actors;
+    }
+    out->owner = s;
     return PTX_OK;
 }
 

@@ -171,6 +171,51 @@ class Engine:
         finally:
             self.lib.ptx_patches_free(C.byref(p))
 
+    def generate(self, replicas, ops_per_log, mix, mark_types, n_docs, seed, first_doc=0, list_cap=0, initial_text=""):
+        """On-device change(): n_docs PTXGEN documents (oracle/ptxgen.js, i.e. the workload of reference/test/fuzz.ts)
+        generated straight into HBM.  Returns (resident batch handle, {"kernel_ms", "n_comments"})."""
+        cfg = abi.ptx_gen_config()
+        cfg.replicas, cfg.ops_per_log, cfg.n_mark_types = replicas, ops_per_log, len(mark_types)
+        for i in range(4):
+            cfg.mix[i] = mix[i]
+        for i, t in enumerate(mark_types):
+            cfg.mark_types[i] = t
+        cfg.seed, cfg.first_doc, cfg.n_docs, cfg.list_cap = seed, first_doc, n_docs, list_cap
+        cfg.initial_text = initial_text.encode("ascii")
+        h = C.c_void_p()
+        info = abi.ptx_gen_info()
+        self._check(self.lib.ptx_generate(self.ctx, C.byref(cfg), C.byref(h), C.byref(info)))
+        try:
+            nc = np.ctypeslib.as_array(info.n_comments, shape=(n_docs,)).copy() if n_docs else np.zeros(0, dtype=np.uint32)
+            return h, {"kernel_ms": float(info.kernel_ms), "n_comments": nc}
+        finally:
+            self.lib.ptx_gen_info_free(C.byref(info))
+
+    def download_batch(self, dbatch, values=None, urls=None, log_doc=None, doc_actors=None, doc_comments=None):
+        """Copy a resident batch back as a wire.Batch (the decode tables are the caller's: a generated batch uses
+        wire.GEN_VALUES / GEN_URLS / generated_tables)."""
+        hb = abi.ptx_host_batch()
+        self._check(self.lib.ptx_batch_download(self.ctx, dbatch, C.byref(hb)))
+        try:
+            b = hb.b
+            L, T = int(b.n_logs), int(b.n_ops)
+
+            def arr(ptr, dtype, n):
+                return np.frombuffer(C.string_at(ptr, n * np.dtype(dtype).itemsize), dtype=dtype).copy() if n else np.zeros(0, dtype=dtype)
+
+            log_off = arr(b.log_off, np.uint64, L + 1)
+            has_env = bool(b.chg_off)
+            chg_off = arr(b.chg_off, np.uint64, L + 1) if has_env else None
+            NC = int(chg_off[-1]) if has_env else 0
+            return wire.Batch(
+                log_off, arr(b.op_id, np.uint64, T), arr(b.ref_a, np.uint64, T), arr(b.ref_b, np.uint64, T), arr(b.payload, np.uint32, T),
+                arr(b.action, np.uint8, T), arr(b.mark_type, np.uint8, T), arr(b.side_a, np.uint8, T), arr(b.side_b, np.uint8, T),
+                chg_off, arr(b.chg_actor, np.uint32, NC) if has_env else None, arr(b.chg_seq, np.uint32, NC) if has_env else None,
+                arr(b.chg_nops, np.uint32, NC) if has_env else None, arr(b.chg_deps, np.uint32, NC * int(b.max_actors)) if has_env else None,
+                int(b.max_actors), arr(b.log_hdr, abi.LOG_HDR_DTYPE, L), values or [], urls or [], log_doc or [], doc_actors or [], doc_comments or [])
+        finally:
+            self.lib.ptx_host_batch_free(C.byref(hb))
+
     def download_logs(self, dresult, n_logs):
         out = np.zeros(n_logs, dtype=abi.LOG_RESULT_DTYPE)
         self._check(self.lib.ptx_result_download_logs(self.ctx, dresult, out.ctypes.data_as(C.POINTER(abi.ptx_log_result)), n_logs))

@@ -286,6 +286,79 @@ def decode_spans(batch, res, log):
     return out
 
 
+def decode_changes(batch, log):
+    """Change[] of one log — the inverse of encode_docs for the ops of the text list (reference/src/micromerge.ts:60-71
+    Change, :150-212 Operation, src/peritext.ts:25-65 mark ops), in the JSON-portable form of the traces
+    (ROOT / HEAD as "_root" / "_head").  Needs the Change envelope; ops on other objects (PTX_ACT_NOP) cannot be restored."""
+    if batch.chg_off is None:
+        raise ValueError("the batch carries no Change envelope")
+    d = batch.log_doc[log]
+    actors, comments = batch.doc_actors[d], batch.doc_comments[d]
+    b0 = int(batch.log_off[log])
+    c0, c1 = int(batch.chg_off[log]), int(batch.chg_off[log + 1])
+
+    def oid(v):
+        v = int(v)
+        return "%d@%s" % (v >> 32, actors[v & 0xFFFFFFFF])
+
+    text_obj = None
+    out = []
+    row = b0
+    for c in range(c0, c1):
+        nops = int(batch.chg_nops[c])
+        deps = {}
+        for a in range(batch.max_actors):
+            v = int(batch.chg_deps[c * batch.max_actors + a])
+            if v:
+                deps[actors[a]] = v
+        ops = []
+        for i in range(row, row + nops):
+            act = int(batch.action[i])
+            op = {"opId": oid(batch.op_id[i])}
+            if act == abi.ACT_MAKELIST:
+                op.update(action="makeList", obj=ROOT, key="text")
+                text_obj = op["opId"]
+            elif act == abi.ACT_INSERT:
+                ref = int(batch.ref_a[i])
+                op.update(action="set", obj=text_obj, elemId=oid(ref) if ref else HEAD, insert=True, value=batch.values[int(batch.payload[i])])
+            elif act == abi.ACT_DELETE:
+                op.update(action="del", obj=text_obj, elemId=oid(batch.ref_a[i]))
+            elif act in (abi.ACT_ADDMARK, abi.ACT_REMOVEMARK):
+                mt = int(batch.mark_type[i])
+                sa, sb = int(batch.side_a[i]), int(batch.side_b[i])
+                start = {"type": abi.SIDE_NAMES[sa]}
+                if sa in (abi.SIDE_BEFORE, abi.SIDE_AFTER):
+                    start["elemId"] = oid(batch.ref_a[i])
+                end = {"type": abi.SIDE_NAMES[sb]}
+                if sb in (abi.SIDE_BEFORE, abi.SIDE_AFTER):
+                    end["elemId"] = oid(batch.ref_b[i])
+                op.update(action="addMark" if act == abi.ACT_ADDMARK else "removeMark", obj=text_obj, start=start, end=end, markType=abi.MARK_NAMES[mt])
+                if mt == abi.MARK_LINK and act == abi.ACT_ADDMARK:
+                    op["attrs"] = {"url": batch.urls[int(batch.payload[i])]}
+                elif mt == abi.MARK_COMMENT:
+                    op["attrs"] = {"id": comments[int(batch.payload[i])]}
+            else:
+                raise ValueError("row %d of log %d is not an op of the text list" % (i - b0, log))
+            ops.append(op)
+        start_op = int(batch.op_id[row]) >> 32 if nops else 0
+        out.append({"actor": actors[int(batch.chg_actor[c])], "seq": int(batch.chg_seq[c]), "deps": deps, "startOp": start_op, "ops": ops})
+        row += nops
+    return out
+
+
+# ---- batches made by the on-device generator (ptx_generate / gen_core.h): fixed string tables ----
+GEN_VALUES = [chr(i) for i in range(128)]               # payload of an insert = the character's code
+GEN_URLS = [chr(65 + i) + ".com" for i in range(26)]    # payload of a link addMark = the letter
+
+
+def generated_tables(n_docs, replicas, n_comments):
+    """Decode tables of a generated batch: actors "doc1".., comment ids "comment-<k>" ranked in string order."""
+    actors = [["doc%d" % (i + 1) for i in range(replicas)] for _ in range(n_docs)]
+    comments = [sorted(("comment-%d" % k for k in range(int(c))), key=_u16key) for c in n_comments]
+    log_doc = [d for d in range(n_docs) for _ in range(replicas)]
+    return actors, comments, log_doc
+
+
 class Patches:
     """Patch streams of a batch (ptx_replay_patches): records of log l = patches[patch_off[l] : patch_off[l] + logs[l].n_patches]."""
 

@@ -13,6 +13,7 @@
 int ptx_emu_reverse = 0;
 #include "../../peritext_amd/csrc/merge_core.h"
 #include "../../peritext_amd/csrc/replay_core.h"
+#include "../../peritext_amd/csrc/gen_core.h"
 
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
                           uint32_t lds_bytes, int reverse, int admission);
@@ -127,3 +128,24 @@ extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, con
     return 0;
 }
 extern "C" uint64_t ptx_emu_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks) { return ptx_replay_lds_need(n, K, Kc, ks); }
+
+/* on-device change() / PTXGEN (gen_core.h): generate n_docs documents into caller-allocated capacity-layout columns
+ * (rows_per_log rows per log, R logs per doc); the envelope is left at capacity stride, n_changes says how much is used */
+extern "C" int ptx_emu_generate(PtxGenArgs* A, int reverse) {
+    A->lds_bytes = 160 * 1024;
+    A->ctab = (PtxGenChange*)calloc((size_t)A->n_docs * A->R * A->rows_per_log + 1, sizeof(PtxGenChange));
+    A->known = (uint16_t*)calloc((size_t)A->n_docs * A->R * A->rows_per_log + 1, sizeof(uint16_t));
+    uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)A->lds_bytes + 64);
+    if (!lds || !A->ctab || !A->known) return 1;
+    ptx_emu_reverse = reverse;
+    for (uint32_t d = 0; d < A->n_docs; ++d) {
+        memset(lds, 0xA5, A->lds_bytes);
+        ptx_gen_doc<0>(*A, d, lds);
+    }
+    free(lds);
+    free(A->ctab);
+    free(A->known);
+    A->ctab = nullptr;
+    A->known = nullptr;
+    return 0;
+}

@@ -252,3 +252,72 @@ def check_generated(gen, res_fn):
 def load_kat():
     with open(os.path.join(GOLDEN, "kat_reference_tests.json")) as f:
         return json.load(f)["cases"]
+
+
+# ---- on-device change() / PTXGEN (peritext_amd/csrc/gen_core.h) through the host emulation ----
+class _GenArgs(C.Structure):
+    _fields_ = [("n_docs", C.c_uint32), ("first_doc", C.c_uint32), ("seed", C.c_uint32), ("R", C.c_uint32), ("ops_per_log", C.c_uint32),
+                ("mix0", C.c_uint32), ("mix01", C.c_uint32), ("mix012", C.c_uint32), ("n_mark_types", C.c_uint32), ("mark_types", C.c_uint8 * 4),
+                ("init_len", C.c_uint32), ("init_text", C.c_uint8 * 16), ("rows_per_log", C.c_uint32), ("list_cap", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("op_id", C.c_void_p), ("ref_a", C.c_void_p), ("ref_b", C.c_void_p), ("payload", C.c_void_p), ("action", C.c_void_p),
+                ("mark_type", C.c_void_p), ("side_a", C.c_void_p), ("side_b", C.c_void_p), ("chg_actor", C.c_void_p), ("chg_seq", C.c_void_p),
+                ("chg_nops", C.c_void_p), ("chg_deps", C.c_void_p), ("n_changes", C.c_void_p), ("n_comments", C.c_void_p), ("status", C.c_void_p),
+                ("ctab", C.c_void_p), ("known", C.c_void_p)]
+
+
+def gen_config(name, ops=None, replicas=None):
+    """The PTXGEN workload definitions (oracle/ptxgen.js CONFIGS) as the generator's parameters."""
+    cfgs = {
+        "config2": (1, 256, [70, 30, 0, 0], []), "config3": (1, 1024, [40, 20, 25, 15], ["strong", "em"]),
+        "config4": (3, 4096, [25, 25, 25, 25], ["strong", "em", "link", "comment"]), "config5": (1, 8192, [20, 50, 20, 10], ["link", "comment"]),
+        "rich": (3, 1024, [55, 10, 20, 15], ["strong", "em", "link", "comment"]), "mini": (3, 96, [25, 25, 25, 25], ["strong", "em", "link", "comment"]),
+    }
+    r, n, mix, marks = cfgs[name]
+    return {"replicas": replicas or r, "ops_per_log": ops or n, "mix": mix, "mark_types": [abi.MARK_NAMES.index(m) for m in marks]}
+
+
+def batch_from_generated(cfg, n_docs, cols, env, n_changes, n_comments):
+    """Assemble a wire.Batch from the generator's capacity-layout output (the envelope is compacted here)."""
+    R, N = cfg["replicas"], cfg["ops_per_log"] + 1
+    n_logs = n_docs * R
+    log_off = (np.arange(n_logs + 1, dtype=np.uint64) * np.uint64(N)).astype(np.uint64)
+    keep = np.concatenate([np.arange(l * N, l * N + int(n_changes[l])) for l in range(n_logs)]) if n_logs else np.zeros(0, dtype=np.int64)
+    chg_off = np.zeros(n_logs + 1, dtype=np.uint64)
+    chg_off[1:] = np.cumsum(n_changes.astype(np.uint64))
+    actors, comments, log_doc = wire.generated_tables(n_docs, R, n_comments)
+    return wire.Batch(log_off, cols["op_id"], cols["ref_a"], cols["ref_b"], cols["payload"], cols["action"], cols["mark_type"], cols["side_a"], cols["side_b"],
+                      chg_off, env["chg_actor"][keep], env["chg_seq"][keep], env["chg_nops"][keep], env["chg_deps"].reshape(-1, R)[keep].reshape(-1), R,
+                      None, wire.GEN_VALUES, wire.GEN_URLS, log_doc, actors, comments)
+
+
+def emu_generate(cfg, n_docs, seed, first_doc=0, list_cap=None, reverse=0, lib_path=EMU_LIB):
+    """PTXGEN documents made by the host emulation of gen_core.h (tests only): (wire.Batch, status per doc)."""
+    R, N = cfg["replicas"], cfg["ops_per_log"] + 1
+    rows = max(n_docs * R * N, 1)
+    cols = {"op_id": np.zeros(rows, np.uint64), "ref_a": np.zeros(rows, np.uint64), "ref_b": np.zeros(rows, np.uint64), "payload": np.zeros(rows, np.uint32),
+            "action": np.zeros(rows, np.uint8), "mark_type": np.zeros(rows, np.uint8), "side_a": np.zeros(rows, np.uint8), "side_b": np.zeros(rows, np.uint8)}
+    env = {"chg_actor": np.zeros(rows, np.uint32), "chg_seq": np.zeros(rows, np.uint32), "chg_nops": np.zeros(rows, np.uint32), "chg_deps": np.zeros(rows * R, np.uint32)}
+    n_changes = np.zeros(max(n_docs * R, 1), np.uint32)
+    n_comments = np.zeros(max(n_docs, 1), np.uint32)
+    status = np.zeros(max(n_docs, 1), np.uint32)
+    a = _GenArgs()
+    a.n_docs, a.first_doc, a.seed, a.R, a.ops_per_log = n_docs, first_doc, seed, R, cfg["ops_per_log"]
+    m = cfg["mix"]
+    a.mix0, a.mix01, a.mix012 = m[0], m[0] + m[1], m[0] + m[1] + m[2]
+    a.n_mark_types = len(cfg["mark_types"])
+    for i, t in enumerate(cfg["mark_types"]):
+        a.mark_types[i] = t
+    text = cfg.get("initial_text", "ABCDE")
+    a.init_len = len(text)
+    for i, ch in enumerate(text):
+        a.init_text[i] = ord(ch)
+    a.rows_per_log = N
+    a.list_cap = list_cap or N + 8
+    for k, v in list(cols.items()) + list(env.items()):
+        setattr(a, k, v.ctypes.data)
+    a.n_changes, a.n_comments, a.status = n_changes.ctypes.data, n_comments.ctypes.data, status.ctypes.data
+    lib = C.CDLL(lib_path)
+    lib.ptx_emu_generate.restype = C.c_int
+    lib.ptx_emu_generate.argtypes = [C.POINTER(_GenArgs), C.c_int]
+    assert lib.ptx_emu_generate(C.byref(a), reverse) == 0
+    return batch_from_generated(cfg, n_docs, cols, env, n_changes[:n_docs * R], n_comments[:n_docs]), status[:n_docs]

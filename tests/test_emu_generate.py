@@ -1,0 +1,81 @@
+"""On-device change(): the generator logic of peritext_amd/csrc/gen_core.h compiled with -DPTX_EMU (tests/emu,
+test tooling only) against the oracle's PTXGEN (oracle/ptxgen.js — Micromerge.change of reference/src/micromerge.ts:308-441
+driven by the workload of reference/test/fuzz.ts): every Change of every replica log deep-equal (actor, seq, deps, startOp,
+ops with their element ids, boundary positions and attrs), on every committed PTXGEN fixture and on fresh seeds.  The GPU
+tests (test_gpu_parity.py) repeat it through ptx_generate on a real MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from peritext_amd import abi, wire
+
+pytestmark = pytest.mark.skipif(not os.path.exists(H.EMU_LIB), reason="tests/emu/libperitext_emu.so not built (run __graft_entry__.build())")
+
+norm = lambda x: json.loads(json.dumps(x, sort_keys=True))  # noqa: E731
+
+
+def check_generated_logs(batch, docs_logs):
+    log = 0
+    for logs in docs_logs:
+        for want in logs:
+            got = wire.decode_changes(batch, log)
+            assert len(got) == len(want), "log %d: %d changes, expected %d" % (log, len(got), len(want))
+            for i, (x, y) in enumerate(zip(got, want)):
+                assert norm(x) == norm(y), "log %d change %d: %r != %r" % (log, i, x, y)
+            log += 1
+    assert log == batch.n_logs
+
+
+@pytest.mark.parametrize("name,cfg", [("ptxgen_mini.json", "mini"), ("ptxgen_config2.json", "config2"), ("ptxgen_config3_512.json", "config3"),
+                                       ("ptxgen_config4_600.json", "config4"), ("ptxgen_rich_700.json", "rich")])
+def test_generator_reproduces_the_committed_ptxgen_fixtures(name, cfg):
+    """The fixtures hold the Change logs the oracle's change() produced (seed, config and ops in the file): the generator,
+    given only (config, seed, document index), must produce the same logs."""
+    with open(os.path.join(H.GOLDEN, name)) as f:
+        g = json.load(f)
+    c = H.gen_config(cfg, ops=g["cfg"]["opsPerLog"], replicas=g["cfg"]["replicas"])
+    first = g["docs"][0]["docIndex"]
+    batch, status = H.emu_generate(c, len(g["docs"]), g["seed"], first_doc=first)
+    assert not status.any()
+    check_generated_logs(batch, [d["logs"] for d in g["docs"]])
+
+
+def test_decode_changes_inverts_encode_docs():
+    with open(os.path.join(H.GOLDEN, "ptxgen_rich_700.json")) as f:
+        g = json.load(f)
+    docs = [d["logs"] for d in g["docs"]]
+    check_generated_logs(wire.encode_docs(docs), docs)
+
+
+@pytest.mark.parametrize("cfg,docs,ops,seed", [("mini", 24, None, 77), ("rich", 2, None, 78), ("config4", 1, None, 79), ("config5", 1, 2000, 80)])
+def test_generator_against_live_oracle_and_merge(cfg, docs, ops, seed):
+    """Fresh seeds (config4: full 4 096-op logs): same logs as the oracle; and the generated batch, merged, gives the spans the
+    oracle's replicas hold — the whole device pipeline generate -> merge against the reference's change + getTextWithFormatting."""
+    if not H.have_node():
+        pytest.skip("node not installed")
+    g = H.oracle_gen(cfg, seed=seed, docs=docs, ops=ops)
+    batch, status = H.emu_generate(H.gen_config(cfg, ops=ops), docs, seed)
+    assert not status.any()
+    check_generated_logs(batch, [d["logs"] for d in g["docs"]])
+    res = H.emu_merge(batch, lds_bytes=160 * 1024, admission=True)
+    log = 0
+    for d in g["docs"]:
+        for exp in d["expected"]:
+            assert int(res.logs[log]["status"]) == 0
+            assert H.norm_spans(wire.decode_spans(batch, res, log)) == H.norm_spans(exp["spans"]), "log %d" % log
+            log += 1
+
+
+def test_generator_capacity_and_single_replica():
+    c = H.gen_config("mini")
+    batch, status = H.emu_generate(c, 2, 5, list_cap=8)  # lists outgrow 8 elements
+    assert (status == abi.ERR_CAPACITY).all()
+    c1 = H.gen_config("config2", ops=64)
+    batch, status = H.emu_generate(c1, 3, 9)
+    assert not status.any() and batch.n_logs == 3 and int(batch.log_off[-1]) == 3 * 65
+    if H.have_node():
+        g = H.oracle_gen("config2", seed=9, docs=3, ops=64)
+        check_generated_logs(batch, [d["logs"] for d in g["docs"]])

@@ -361,3 +361,77 @@ def test_patch_streams_need_elem_rank_and_handle_empty(eng):
     empty = wire.encode_docs([])
     res, pat = _streams(eng, empty)
     assert len(pat.logs) == 0 and len(pat.patches) == 0
+
+
+# ---- on-device change(): ptx_generate through the C ABI ----
+def _generate(eng, cfg, n_docs, seed, first_doc=0, list_cap=0):
+    h, info = eng.generate(cfg["replicas"], cfg["ops_per_log"], cfg["mix"], cfg["mark_types"], n_docs, seed, first_doc=first_doc, list_cap=list_cap)
+    actors, comments, log_doc = wire.generated_tables(n_docs, cfg["replicas"], info["n_comments"])
+    batch = eng.download_batch(h, wire.GEN_VALUES, wire.GEN_URLS, log_doc, actors, comments)
+    return h, batch, info
+
+
+def _check_changes(batch, docs_logs):
+    norm = lambda x: json.loads(json.dumps(x, sort_keys=True))  # noqa: E731
+    log = 0
+    for logs in docs_logs:
+        for want in logs:
+            got = wire.decode_changes(batch, log)
+            assert len(got) == len(want), "log %d: %d changes, expected %d" % (log, len(got), len(want))
+            for i, (x, y) in enumerate(zip(got, want)):
+                assert norm(x) == norm(y), "log %d change %d" % (log, i)
+            log += 1
+    assert log == batch.n_logs
+
+
+@pytest.mark.parametrize("name,cfg", [("ptxgen_mini.json", "mini"), ("ptxgen_config3_512.json", "config3"), ("ptxgen_config4_600.json", "config4"),
+                                       ("ptxgen_rich_700.json", "rich")])
+def test_generate_reproduces_the_ptxgen_fixtures_and_merges_them(eng, name, cfg):
+    """Given only (config, seed, document index) the device produces, change for change, the logs the oracle's change() made
+    (committed fixtures); the resident batch then merges to the fixtures' spans without visiting the host."""
+    g = _load(name)
+    c = H.gen_config(cfg, ops=g["cfg"]["opsPerLog"], replicas=g["cfg"]["replicas"])
+    h, batch, info = _generate(eng, c, len(g["docs"]), g["seed"], first_doc=g["docs"][0]["docIndex"])
+    try:
+        assert info["kernel_ms"] > 0
+        _check_changes(batch, [d["logs"] for d in g["docs"]])
+        dr = eng.alloc_result(h)
+        eng.merge(h, dr)
+        eng.sync()
+        res = eng.download(h, dr)
+        eng.free_result(dr)
+        log = 0
+        for d in g["docs"]:
+            digests = set()
+            for exp in d["expected"]:
+                assert int(res.logs[log]["status"]) == 0
+                assert H.norm_spans(wire.decode_spans(batch, res, log)) == H.norm_spans(exp["spans"]), "log %d" % log
+                digests.add((int(res.logs[log]["digest"][0]), int(res.logs[log]["digest"][1])))
+                log += 1
+            assert len(digests) == 1  # the replicas of a document converge
+    finally:
+        eng.free_batch(h)
+
+
+def test_generate_full_config4_document_against_live_oracle(eng):
+    if not H.have_node():
+        pytest.skip("node not installed")
+    g = H.oracle_gen("config4", seed=41, docs=1)
+    h, batch, info = _generate(eng, H.gen_config("config4"), 1, 41)
+    try:
+        _check_changes(batch, [d["logs"] for d in g["docs"]])
+    finally:
+        eng.free_batch(h)
+
+
+def test_generate_capacity_and_arguments(eng):
+    from peritext_amd.engine import PtxError
+
+    c = H.gen_config("mini")
+    with pytest.raises(PtxError, match="list_cap"):
+        _generate(eng, c, 4, 5, list_cap=8)
+    with pytest.raises(PtxError, match="replicas"):
+        eng.generate(5, 16, [25, 25, 25, 25], [0], 1, 1)
+    h, batch, info = _generate(eng, c, 0, 1)
+    assert batch.n_logs == 0
+    eng.free_batch(h)
