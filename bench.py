@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-admission", action="store_true", help="skip applyChange's causal admission (seq/deps) in the timed path")
+    ap.add_argument("--device-gen", action="store_true", help="generate the op logs on the GPU (ptx_generate: on-device change(), every document distinct) "
+                    "instead of tiling --unique oracle-generated documents")
+    ap.add_argument("--list-cap", type=int, default=2048, help="--device-gen: list elements per replica held on chip")
     args = ap.parse_args()
 
     import torch
@@ -137,25 +140,51 @@ def main():
     from peritext_amd import abi, shard, wire
     from peritext_amd.engine import Engine
 
-    # ---- workload: unique documents of this rank, tiled in HBM ----
-    assert args.docs_per_gpu % args.unique == 0, "--docs-per-gpu must be a multiple of --unique"
-    copies = args.docs_per_gpu // args.unique
     cores = os.cpu_count() or 8
-    t_gen = time.time()
-    docs = gen_unique_docs(args.config, args.unique, args.seed + 7919 * rank, ops=args.ops, procs=max(1, cores // max(world, 1)))
-    t_gen = time.time() - t_gen
-    replicas = len(docs[0]["logs"])
-    batch = wire.encode_docs([d["logs"] for d in docs])
-    ops_unique = batch.counted_ops()
     eng = Engine(local, flags=abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0))
-    t_up = time.time()
-    db = eng.upload(batch, copies=copies)
-    eng.sync()
-    t_up = time.time() - t_up
+    gen_info = None
+    if args.device_gen:
+        # ---- workload made on the device: on-device change() (ptx_generate), every document of every rank distinct ----
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import helpers
+
+        gcfg = helpers.gen_config(args.config, ops=args.ops)
+        gen_args = (gcfg["replicas"], gcfg["ops_per_log"], gcfg["mix"], gcfg["mark_types"])
+        t_gen = time.time()
+        db, gen_info = eng.generate(*gen_args, args.docs_per_gpu, args.seed, first_doc=rank * args.docs_per_gpu, list_cap=args.list_cap)
+        t_gen = time.time() - t_gen
+        t_up, copies, replicas = 0.0, 1, gcfg["replicas"]
+        n_logs = eng.n_logs(db)
+        ops_per_step = n_logs * gcfg["ops_per_log"]
+        n_changes_rank = eng.n_changes(db)
+        max_actors = replicas
+        # a few documents of the same stream on the host, for the oracle check and the CPU baseline leg
+        n_host = min(args.cpu_procs, args.docs_per_gpu)
+        hb, hinfo = eng.generate(*gen_args, n_host, args.seed, first_doc=rank * args.docs_per_gpu, list_cap=args.list_cap)
+        actors_t, comments_t, log_doc_t = wire.generated_tables(n_host, replicas, hinfo["n_comments"])
+        host_batch = eng.download_batch(hb, wire.GEN_VALUES, wire.GEN_URLS, log_doc_t, actors_t, comments_t)
+        eng.free_batch(hb)
+        docs = [{"logs": [wire.decode_changes(host_batch, d * replicas + r) for r in range(replicas)]} for d in range(n_host)]
+    else:
+        # ---- workload: unique documents of this rank, tiled in HBM ----
+        assert args.docs_per_gpu % args.unique == 0, "--docs-per-gpu must be a multiple of --unique"
+        copies = args.docs_per_gpu // args.unique
+        t_gen = time.time()
+        docs = gen_unique_docs(args.config, args.unique, args.seed + 7919 * rank, ops=args.ops, procs=max(1, cores // max(world, 1)))
+        t_gen = time.time() - t_gen
+        replicas = len(docs[0]["logs"])
+        batch = wire.encode_docs([d["logs"] for d in docs])
+        ops_unique = batch.counted_ops()
+        t_up = time.time()
+        db = eng.upload(batch, copies=copies)
+        eng.sync()
+        t_up = time.time() - t_up
+        n_logs = eng.n_logs(db)
+        ops_per_step = ops_unique * copies  # counted ops (makeList rows excluded), this rank
+        n_changes_rank = int(batch.chg_off[-1]) * copies
+        max_actors = batch.max_actors
     dr = eng.alloc_result(db)
-    n_logs = eng.n_logs(db)
     n_docs = n_logs // replicas
-    ops_per_step = ops_unique * copies  # counted ops (makeList rows excluded), this rank
     digests = torch.empty((n_logs, 2), dtype=torch.int64, device="cuda")
     gathered = torch.empty((world * n_logs, 2), dtype=torch.int64, device="cuda") if world > 1 else None
     conv = torch.zeros((), dtype=torch.int64, device="cuda")
@@ -208,18 +237,22 @@ def main():
 
         one = wire.encode_docs([docs[0]["logs"]])
         res1 = eng.apply_materialize(one)
+        expected0 = docs[0]["expected"] if "expected" in docs[0] else helpers.oracle_apply([docs[0]["logs"]])[0]
         for r_ in range(replicas):
-            helpers.check_log(one, res1, r_, docs[0]["expected"][r_])
+            helpers.check_log(one, res1, r_, expected0[r_])
 
         # algorithmic bytes of ONE launch on this rank (with this ABI's row sizes)
         rows = eng.n_ops(db)
-        n_changes = int(batch.chg_off[-1]) * copies
-        env_bytes = 0 if args.no_admission else n_changes * (12 + 4 * batch.max_actors)  # chg_actor, chg_seq, chg_nops, chg_deps row
+        n_changes = n_changes_rank
+        env_bytes = 0 if args.no_admission else n_changes * (12 + 4 * max_actors)  # chg_actor, chg_seq, chg_nops, chg_deps row
         # the same launch without the admission phase (PTX_FLAG_NO_ADMISSION), for reference: a second engine on the same batch
         ms_noadm = None
         if not args.no_admission:
             eng2 = Engine(local, flags=abi.FLAG_NO_ELEM_RANK | abi.FLAG_NO_ADMISSION)
-            db2 = eng2.upload(batch, copies=copies)
+            if args.device_gen:
+                db2, _ = eng2.generate(*gen_args, args.docs_per_gpu, args.seed, first_doc=rank * args.docs_per_gpu, list_cap=args.list_cap)
+            else:
+                db2 = eng2.upload(batch, copies=copies)
             dr2 = eng2.alloc_result(db2)
             eng2.merge(db2, dr2)
             eng2.sync()
@@ -243,7 +276,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32/u64 integer (opIds u64, indices u16/u32 in LDS)",
-            "data": "synthetic: PTXGEN (seeded restatement of reference/test/fuzz.ts) via the oracle's change(); %d unique docs per GPU tiled x%d in HBM" % (args.unique, copies),
+            "data": ("synthetic: PTXGEN (seeded restatement of reference/test/fuzz.ts) generated ON THE DEVICE by ptx_generate (on-device change()); "
+                     "%d distinct docs per GPU, none repeated" % n_docs) if args.device_gen else
+                    "synthetic: PTXGEN (seeded restatement of reference/test/fuzz.ts) via the oracle's change(); %d unique docs per GPU tiled x%d in HBM" % (args.unique, copies),
             "config": {
                 "workload": "BASELINE config #4 shard: %d docs x %d replicas x %d ops per GPU (64K docs x 3 x 4096 at 8 GPUs)"
                 % (n_docs, replicas, (args.ops or {"config4": 4096, "config3": 1024, "config2": 256, "config5": 8192, "rich": 1024, "mini": 96}[args.config])),
@@ -273,7 +308,10 @@ def main():
             },
             "without_admission": None if ms_noadm is None else {"kernel_ms": ms_noadm, "ops_per_s_1gpu": ops_per_step / (ms_noadm * 1e-3),
                                                                 "hbm_GBps": (alg_bytes - env_bytes) / (ms_noadm * 1e-3) / 1e9},
+            "launch": dict(zip(("threads_per_log", "lds_bytes_per_log"), eng.launch_shape(db))),
             "host": {"cores": cores, "gen_s": t_gen, "upload_s": t_up, "upload_GBps": 32 * rows / copies / max(t_up, 1e-9) / 1e9},
+            "device_gen": None if gen_info is None else {"kernel_ms": gen_info["kernel_ms"], "ops_generated_per_s": ops_per_step / (gen_info["kernel_ms"] * 1e-3),
+                                                        "launch_shape": list(eng.launch_shape(db))},
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(docs, args.cpu_budget_s, min(args.cpu_procs, cores))

@@ -251,8 +251,11 @@ ptx_status ptx_batch_wrap_device(ptx_ctx* ctx, const ptx_batch* device, ptx_dbat
 void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b);
 uint32_t ptx_batch_n_logs(const ptx_dbatch* b);
 uint64_t ptx_batch_n_ops(const ptx_dbatch* b);
+uint64_t ptx_batch_n_changes(const ptx_dbatch* b); /* rows of the Change envelope (0 = the batch has none) */
 /* Launch shape the library derived from the batch's log headers: threads per workgroup (= per log) and
- * dynamic LDS bytes per workgroup (the largest log's working set; it sets how many logs share a CU). */
+ * dynamic LDS bytes per workgroup (the largest log's working set; it sets how many logs share a CU).  When at most a
+ * tenth of the logs need more LDS than would let one more log share a CU, those are merged in a second launch of
+ * their own and the figure reported here is that of the main launch. */
 void ptx_batch_launch_shape(const ptx_dbatch* b, uint32_t* threads, uint32_t* lds_bytes);
 
 ptx_status ptx_result_alloc(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult** out);

@@ -210,6 +210,7 @@ FUNCTIONS = {
     "ptx_batch_free": (None, [vp, vp]),
     "ptx_batch_n_logs": (C.c_uint32, [vp]),
     "ptx_batch_n_ops": (C.c_uint64, [vp]),
+    "ptx_batch_n_changes": (C.c_uint64, [vp]),
     "ptx_batch_launch_shape": (None, [vp, u32p, u32p]),
     "ptx_result_alloc": (C.c_int32, [vp, vp, C.POINTER(vp)]),
     "ptx_dresult_free": (None, [vp, vp]),

@@ -271,6 +271,7 @@ struct PtxMergeArgs {
     uint32_t max_actors;
     uint32_t stop_after; /* diagnostic: leave after the phase with this stamp index (0 = run everything) */
     uint32_t div_magic;  /* floor(2^32 / threads per workgroup) + 1, see PTX_DIV_T */
+    const uint32_t* log_index; /* optional: workgroup i handles log log_index[i] (launches over a subset of the logs) */
 };
 
 #define PTX_END 0xFFFFu

@@ -35,7 +35,7 @@
         extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];              \
         /* one workgroup per log (grid == n_logs): no grid-stride loop, so that nothing is hoisted \
            out of it and kept in registers for the whole kernel */                    \
-        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT, DIAG>(A, blockIdx.x, ptx_lds); \
+        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT, DIAG>(A, A.log_index ? A.log_index[blockIdx.x] : blockIdx.x, ptx_lds); \
     }
 PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false, 0, false)     /* any launch shape (blockDim.x read at run time) */
 PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false) /* + causal admission for documents with more than four actors */
@@ -75,7 +75,8 @@ __global__ void ptx_regular_offsets_kernel(uint64_t* dst, uint32_t n, uint64_t s
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
 __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off, const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type,
-                                                          ptx_log_hdr* hdr, uint32_t* shape, int compute, const uint64_t* chg_off, uint32_t max_actors) {
+                                                          ptx_log_hdr* hdr, uint32_t* shape, int compute, const uint64_t* chg_off, uint32_t max_actors,
+                                                          uint32_t* need_per_log) {
     __shared__ uint32_t sh[8];
     const uint32_t log = blockIdx.x;
     const uint64_t b0 = log_off[log], b1 = log_off[log + 1];
@@ -128,6 +129,7 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
         uint64_t need = ptx_lds_need_hdr(b1 - b0, h);
         if (chg_off) need = max(need, ptx_lds_need_admission(chg_off[log + 1] - chg_off[log], max_actors));
         atomicMax(&shape[0], (uint32_t)min(need, (uint64_t)0xFFFFFFFFu));
+        need_per_log[log] = (uint32_t)min(need, (uint64_t)0xFFFFFFFFu);
         atomicMax(&shape[1], (uint32_t)min(b1 - b0, (uint64_t)0xFFFFFFFFu));
     }
 }
@@ -183,6 +185,12 @@ struct ptx_dbatch {
     uint32_t max_log_ops = 0;
     uint32_t lds_bytes = 0;
     uint32_t threads = 0;
+    /* split launch: when a few logs need more LDS than the rest, they would cost EVERY log a share of the CU (the
+     * dynamic LDS size is per launch): the logs are then merged in two launches, `log_index` = the logs of the main
+     * group followed by the rest */
+    uint32_t* log_index = nullptr;
+    uint32_t n_main = 0;     /* 0 = one launch over all logs */
+    uint32_t lds_main = 0;
 };
 
 struct ptx_dresult {
@@ -227,22 +235,54 @@ static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t ma
 /* Census of a resident batch: headers (computed on the device unless the caller supplied them) and the
  * launch shape.  `have_hdr`: b->log_hdr already holds the caller's headers. */
 static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
-    uint32_t* shape = nullptr;
+    uint32_t *shape = nullptr, *d_need = nullptr;
     uint32_t h[2] = {0, 0};
+    std::vector<uint32_t> need;
     if (b->n_logs) {
         PTX_HIP(ctx, hipMalloc((void**)&shape, 8));
-        hipError_t e = hipMemsetAsync(shape, 0, 8, ctx->stream);
+        hipError_t e = hipMalloc((void**)&d_need, (size_t)b->n_logs * 4);
+        if (e == hipSuccess) e = hipMemsetAsync(shape, 0, 8, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(ptx_census_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->log_off, b->op_id, b->action, b->mark_type, b->log_hdr,
-                               shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors);
+                               shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors, d_need);
             e = hipGetLastError();
         }
+        need.resize(b->n_logs);
         if (e == hipSuccess) e = hipMemcpyAsync(h, shape, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(need.data(), d_need, (size_t)b->n_logs * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         (void)hipFree(shape);
+        (void)hipFree(d_need);
         if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("census: ") + hipGetErrorString(e));
     }
     shape_launch(ctx, b, h[0], h[1]);
+    /* Would one more log fit a CU if the launch were sized for all but a few logs?  LDS is allocated in 512-byte
+     * granules; k logs share a CU when each needs at most floor(LDS / k) rounded down to a granule. */
+    (void)hipFree(b->log_index);
+    b->log_index = nullptr;
+    b->n_main = 0;
+    if (b->n_logs >= 64 && !ctx->force_lds && b->lds_bytes >= 4096) {
+        const uint64_t gran = 512, lds_now = (b->lds_bytes + gran - 1) / gran * gran;
+        const uint64_t k_now = std::max<uint64_t>(ctx->max_lds / lds_now, 1);
+        const uint64_t bound = ctx->max_lds / (k_now + 1) / gran * gran; /* per-log LDS at which k_now + 1 logs share a CU */
+        uint32_t fit = 0, max_fit = 0;
+        for (uint32_t l = 0; l < b->n_logs; ++l)
+            if (need[l] <= bound) {
+                ++fit;
+                max_fit = std::max(max_fit, need[l]);
+            }
+        if (fit < b->n_logs && (uint64_t)fit * 10 >= (uint64_t)b->n_logs * 9 && k_now < 16) {
+            std::vector<uint32_t> idx(b->n_logs);
+            uint32_t p = 0, q = fit;
+            for (uint32_t l = 0; l < b->n_logs; ++l) (need[l] <= bound ? idx[p++] : idx[q++]) = l;
+            hipError_t e = hipMalloc((void**)&b->log_index, (size_t)b->n_logs * 4);
+            if (e == hipSuccess) e = hipMemcpyAsync(b->log_index, idx.data(), (size_t)b->n_logs * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("launch split: ") + hipGetErrorString(e));
+            b->n_main = fit;
+            b->lds_main = (uint32_t)std::max<uint64_t>(max_fit, 4096);
+        }
+    }
     return PTX_OK;
 }
 
@@ -350,6 +390,7 @@ void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
         (void)hipFree(b->side_b);
     }
     (void)hipFree(b->log_hdr);
+    (void)hipFree(b->log_index);
     (void)hipFree(b->chg_off);
     (void)hipFree(b->chg_actor);
     (void)hipFree(b->chg_seq);
@@ -361,9 +402,10 @@ void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
 uint32_t ptx_batch_n_logs(const ptx_dbatch* b) { return b ? b->n_logs : 0; }
 void ptx_batch_launch_shape(const ptx_dbatch* b, uint32_t* threads, uint32_t* lds_bytes) {
     if (threads) *threads = b ? b->threads : 0;
-    if (lds_bytes) *lds_bytes = b ? b->lds_bytes : 0;
+    if (lds_bytes) *lds_bytes = b ? (b->n_main ? b->lds_main : b->lds_bytes) : 0;
 }
 uint64_t ptx_batch_n_ops(const ptx_dbatch* b) { return b ? b->n_ops : 0; }
+uint64_t ptx_batch_n_changes(const ptx_dbatch* b) { return b && b->chg_off ? b->n_changes : 0; }
 
 ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t copies, ptx_dbatch** out) {
     if (!ctx || !out) return PTX_ERR_INVALID_ARG;
@@ -579,14 +621,25 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.n_logs = b->n_logs;
     A.lds_bytes = b->lds_bytes;
     A.div_magic = (uint32_t)(0x100000000ull / b->threads) + 1u;
-    /* one workgroup per log; far more workgroups than the 256 CUs so the dispatcher load-balances */
-    const uint32_t grid = b->n_logs;
-    if (ctx->clocks || ctx->stop_after)
-        hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
-    else if (admit && b->max_actors > 4)
-        hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
-    else
-        hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), b->lds_bytes, ctx->stream, A);
+    A.log_index = nullptr;
+    /* one workgroup per log; far more workgroups than the 256 CUs so the dispatcher load-balances.  Two launches when a
+     * few logs need more LDS than the rest (census_and_shape): first the many at their size, then the few at theirs. */
+    for (int part = 0; part < (b->n_main ? 2 : 1); ++part) {
+        uint32_t grid = b->n_logs, lds = b->lds_bytes;
+        if (b->n_main) {
+            A.log_index = b->log_index + (part ? b->n_main : 0);
+            grid = part ? b->n_logs - b->n_main : b->n_main;
+            lds = part ? b->lds_bytes : b->lds_main;
+            A.n_logs = grid;
+            A.lds_bytes = lds;
+        }
+        if (ctx->clocks || ctx->stop_after)
+            hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), lds, ctx->stream, A);
+        else if (admit && b->max_actors > 4)
+            hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, ctx->stream, A);
+        else
+            hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, ctx->stream, A);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_merge_kernel launch: ") + hipGetErrorString(e));
     return PTX_OK;

@@ -230,6 +230,9 @@ class Engine:
     def n_ops(self, dbatch):
         return int(self.lib.ptx_batch_n_ops(dbatch))
 
+    def n_changes(self, dbatch):
+        return int(self.lib.ptx_batch_n_changes(dbatch))
+
     def launch_shape(self, dbatch):
         """(threads per workgroup, dynamic LDS bytes per workgroup) the library chose for this batch."""
         t, l = C.c_uint32(), C.c_uint32()

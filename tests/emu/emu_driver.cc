@@ -49,6 +49,7 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     A.clocks = nullptr;
     A.stop_after = 0;
     A.div_magic = 0;
+    A.log_index = nullptr;
     A.res = res;
     A.out_values = values;
     A.out_spans = spans;
