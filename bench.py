@@ -8,8 +8,10 @@ The op columns are resident in HBM before the timed region starts (PCIe upload i
 
 Workload (config.workload): BASELINE config #4 — 64K docs x 3 replicas x 4096 ops sharded over 8 GPUs =
 8192 docs x 3 replicas per GPU ("weak" scaling: per-GPU work is fixed, N GPUs process N x 8192 docs).
-The batch is `--unique` PTXGEN documents (SURVEY.md §8d generator, produced here by the oracle's own
-change() through oracle/cli.js) tiled to 8192 docs inside HBM at distinct addresses.
+The batch is PTXGEN documents (SURVEY.md §8d generator = the workload of reference/test/fuzz.ts, seeded), by default
+GENERATED ON THE DEVICE (ptx_generate: on-device change(), every document of every rank distinct; change for change
+the documents oracle/ptxgen.js makes — rank 0 re-checks one against the oracle in every run).  --oracle-gen takes
+`--unique` documents from the oracle's own change() on the host instead and tiles them to 8192 docs in HBM.
 
 One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes of one launch
 (32 B per op row + 32 B header per log + the Change envelope when causal admission is on, read; 4 B per visible value + 8 B per span + 12 B per comment interval + 48 B result
@@ -116,10 +118,11 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-admission", action="store_true", help="skip applyChange's causal admission (seq/deps) in the timed path")
-    ap.add_argument("--device-gen", action="store_true", help="generate the op logs on the GPU (ptx_generate: on-device change(), every document distinct) "
-                    "instead of tiling --unique oracle-generated documents")
+    ap.add_argument("--oracle-gen", action="store_true", help="take the op logs from the oracle's generator on the host (--unique documents per GPU, "
+                    "tiled in HBM) instead of generating them on the GPU (ptx_generate: on-device change(), every document distinct; the default)")
     ap.add_argument("--list-cap", type=int, default=2048, help="--device-gen: list elements per replica held on chip")
     args = ap.parse_args()
+    args.device_gen = not args.oracle_gen
 
     import torch
 

@@ -435,3 +435,29 @@ def test_generate_capacity_and_arguments(eng):
     h, batch, info = _generate(eng, c, 0, 1)
     assert batch.n_logs == 0
     eng.free_batch(h)
+
+
+def test_split_launch_when_a_few_logs_need_more_lds(eng):
+    """A batch of many small logs and a few large ones is merged in two launches (the dynamic LDS size is per launch: sized for
+    the large logs it would cost every log a share of the CU); results are those of the oracle for every log of both groups."""
+    big, small = _load("ptxgen_rich_2600.json"), _load("ptxgen_config4_600.json")
+    docs = [d for d in big["docs"]] + [d for _ in range(12) for d in small["docs"]]
+    batch = wire.encode_docs([d["logs"] for d in docs])
+    db = eng.upload(batch)
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        eng.sync()
+        res = eng.download(db, dr)
+        threads, lds_main = eng.launch_shape(db)
+        lds_high = res.logs["reserved"][:, 0]
+        n_big = sum(len(d["logs"]) for d in big["docs"])
+        assert int(lds_high[:n_big].max()) > lds_main >= int(lds_high[n_big:].max()), "the large logs ran in a launch of their own"
+        log = 0
+        for d in docs:
+            for exp in d["expected"]:
+                H.check_log(batch, res, log, exp)
+                log += 1
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
