@@ -303,7 +303,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
                 "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING,
-                "traffic": None,
+                "traffic": None,  # PMC counters cannot be read from inside the timed run; measured separately for this command:
+                "traffic_profile": "profiles/r01_x_v40_hbm_traffic_pmc.txt: FETCH_SIZE + WRITE_SIZE per launch = 0.96 x the algorithmic bytes",
                 "kernel": eng.kernel_name(),
                 "kernel_ms_avg": k_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
