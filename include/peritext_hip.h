@@ -248,6 +248,13 @@ ptx_status ptx_batch_upload(ptx_ctx* ctx, const ptx_batch* host, ptx_dbatch** ou
 ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* host, uint32_t copies, ptx_dbatch** out);
 /* Adopt caller-owned DEVICE pointers (e.g. torch tensors' data_ptr); nothing is copied or freed. */
 ptx_status ptx_batch_wrap_device(ptx_ctx* ctx, const ptx_batch* device, ptx_dbatch** out);
+/* Streaming append: a NEW resident batch whose log l = log l of `base` followed by log l of `more` (host
+ * pointers; the changes that arrived since, in application order; same n_logs, empty logs allowed).  Rows are copied
+ * device to device; `base` stays valid.  `more` must be encoded with the tables of `base` (actor ranks, comment ranks,
+ * value / url ids) — comment ids are doc-local dense ranks below the log's number of comment ops, so a log that will see
+ * further comment ids is only mergeable once they have arrived; both batches carry the Change envelope with the same
+ * max_actors, or neither does. */
+ptx_status ptx_batch_append(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_batch* more, ptx_dbatch** out);
 void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b);
 uint32_t ptx_batch_n_logs(const ptx_dbatch* b);
 uint64_t ptx_batch_n_ops(const ptx_dbatch* b);

@@ -207,6 +207,7 @@ FUNCTIONS = {
     "ptx_batch_upload": (C.c_int32, [vp, C.POINTER(ptx_batch), C.POINTER(vp)]),
     "ptx_batch_upload_tiled": (C.c_int32, [vp, C.POINTER(ptx_batch), C.c_uint32, C.POINTER(vp)]),
     "ptx_batch_wrap_device": (C.c_int32, [vp, C.POINTER(ptx_batch), C.POINTER(vp)]),
+    "ptx_batch_append": (C.c_int32, [vp, vp, C.POINTER(ptx_batch), C.POINTER(vp)]),
     "ptx_batch_free": (None, [vp, vp]),
     "ptx_batch_n_logs": (C.c_uint32, [vp]),
     "ptx_batch_n_ops": (C.c_uint64, [vp]),

@@ -72,6 +72,49 @@ __global__ void ptx_regular_offsets_kernel(uint64_t* dst, uint32_t n, uint64_t s
     if (i <= n) dst[i] = (uint64_t)i * stride;
 }
 
+/* streaming append: new log l = old log l followed by the appended rows of log l */
+__global__ void ptx_append_offsets_kernel(const uint64_t* a, const uint64_t* b, uint64_t* dst, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) dst[i] = a[i] + b[i];
+}
+template <class T>
+__device__ void ptx_append_col(const T* a, uint64_t a0, uint64_t na, const T* b, uint64_t b0, uint64_t nb, T* dst, uint64_t d0, uint64_t width) {
+    for (uint64_t i = threadIdx.x; i < na * width; i += blockDim.x) dst[d0 * width + i] = a[a0 * width + i];
+    for (uint64_t i = threadIdx.x; i < nb * width; i += blockDim.x) dst[(d0 + na) * width + i] = b[b0 * width + i];
+}
+struct PtxAppendCols {
+    const uint64_t *op_id, *ref_a, *ref_b;
+    const uint32_t* payload;
+    const uint8_t *action, *mark_type, *side_a, *side_b;
+    const uint32_t *chg_actor, *chg_seq, *chg_nops, *chg_deps;
+};
+struct PtxAppendDst {
+    uint64_t *op_id, *ref_a, *ref_b;
+    uint32_t* payload;
+    uint8_t *action, *mark_type, *side_a, *side_b;
+    uint32_t *chg_actor, *chg_seq, *chg_nops, *chg_deps;
+};
+__global__ void ptx_append_rows_kernel(PtxAppendCols A, const uint64_t* a_off, const uint64_t* a_coff, PtxAppendCols B, const uint64_t* b_off, const uint64_t* b_coff,
+                                       PtxAppendDst D, const uint64_t* d_off, const uint64_t* d_coff, uint32_t max_actors) {
+    const uint32_t l = blockIdx.x;
+    const uint64_t a0 = a_off[l], na = a_off[l + 1] - a0, b0 = b_off[l], nb = b_off[l + 1] - b0, d0 = d_off[l];
+    ptx_append_col(A.op_id, a0, na, B.op_id, b0, nb, D.op_id, d0, 1);
+    ptx_append_col(A.ref_a, a0, na, B.ref_a, b0, nb, D.ref_a, d0, 1);
+    ptx_append_col(A.ref_b, a0, na, B.ref_b, b0, nb, D.ref_b, d0, 1);
+    ptx_append_col(A.payload, a0, na, B.payload, b0, nb, D.payload, d0, 1);
+    ptx_append_col(A.action, a0, na, B.action, b0, nb, D.action, d0, 1);
+    ptx_append_col(A.mark_type, a0, na, B.mark_type, b0, nb, D.mark_type, d0, 1);
+    ptx_append_col(A.side_a, a0, na, B.side_a, b0, nb, D.side_a, d0, 1);
+    ptx_append_col(A.side_b, a0, na, B.side_b, b0, nb, D.side_b, d0, 1);
+    if (a_coff) {
+        const uint64_t ac0 = a_coff[l], nac = a_coff[l + 1] - ac0, bc0 = b_coff[l], nbc = b_coff[l + 1] - bc0, dc0 = d_coff[l];
+        ptx_append_col(A.chg_actor, ac0, nac, B.chg_actor, bc0, nbc, D.chg_actor, dc0, 1);
+        ptx_append_col(A.chg_seq, ac0, nac, B.chg_seq, bc0, nbc, D.chg_seq, dc0, 1);
+        ptx_append_col(A.chg_nops, ac0, nac, B.chg_nops, bc0, nbc, D.chg_nops, dc0, 1);
+        ptx_append_col(A.chg_deps, ac0, nac, B.chg_deps, bc0, nbc, D.chg_deps, dc0, (uint64_t)max_actors);
+    }
+}
+
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
 __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off, const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type,
@@ -523,6 +566,80 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
 }
 
 ptx_status ptx_batch_upload(ptx_ctx* ctx, const ptx_batch* host, ptx_dbatch** out) { return ptx_batch_upload_tiled(ctx, host, 1, out); }
+
+ptx_status ptx_batch_append(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_batch* more, ptx_dbatch** out) {
+    if (!ctx || !base || !out) return PTX_ERR_INVALID_ARG;
+    *out = nullptr;
+    ptx_status st = check_batch(ctx, more);
+    if (st) return st;
+    if (more->n_logs != base->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_batch_append: `more` must have the logs of `base` (empty ones allowed)");
+    const bool env = base->chg_off != nullptr;
+    const bool more_env = more->chg_off && more->chg_actor && more->chg_seq && more->chg_nops && more->chg_deps && more->max_actors;
+    if (env != more_env || (env && more->max_actors != base->max_actors))
+        return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_batch_append: both batches carry the Change envelope with the same max_actors, or neither does");
+    ptx_dbatch* m = nullptr;
+    st = ptx_batch_upload(ctx, more, &m);
+    if (st) return st;
+    ptx_dbatch* b = new ptx_dbatch();
+    b->n_logs = base->n_logs;
+    b->n_ops = base->n_ops + m->n_ops;
+    b->max_actors = base->max_actors;
+    b->n_changes = env ? base->n_changes + m->n_changes : 0;
+    const uint64_t T = b->n_ops, NC = b->n_changes, L = b->n_logs;
+#define PTX_TRYA(call)                                  \
+    do {                                                \
+        hipError_t _e = (call);                         \
+        if (_e != hipSuccess) {                         \
+            std::string msg = std::string(#call) + ": " + hipGetErrorString(_e); \
+            ptx_batch_free(ctx, m);                     \
+            ptx_batch_free(ctx, b);                     \
+            return fail(ctx, _e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, msg); \
+        }                                               \
+    } while (0)
+    PTX_TRYA(dalloc(&b->log_off, L + 1));
+    PTX_TRYA(dalloc(&b->op_id, T));
+    PTX_TRYA(dalloc(&b->ref_a, T));
+    PTX_TRYA(dalloc(&b->ref_b, T));
+    PTX_TRYA(dalloc(&b->payload, T));
+    PTX_TRYA(dalloc(&b->action, T));
+    PTX_TRYA(dalloc(&b->mark_type, T));
+    PTX_TRYA(dalloc(&b->side_a, T));
+    PTX_TRYA(dalloc(&b->side_b, T));
+    PTX_TRYA(dalloc(&b->log_hdr, L));
+    if (env) {
+        PTX_TRYA(dalloc(&b->chg_off, L + 1));
+        PTX_TRYA(dalloc(&b->chg_actor, NC));
+        PTX_TRYA(dalloc(&b->chg_seq, NC));
+        PTX_TRYA(dalloc(&b->chg_nops, NC));
+        PTX_TRYA(dalloc(&b->chg_deps, NC * b->max_actors + 4));
+    }
+    if (L) {
+        const unsigned blocks = (unsigned)((L + 1 + 255) / 256);
+        hipLaunchKernelGGL(ptx_append_offsets_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base->log_off, m->log_off, b->log_off, (uint32_t)L);
+        if (env) hipLaunchKernelGGL(ptx_append_offsets_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base->chg_off, m->chg_off, b->chg_off, (uint32_t)L);
+        PtxAppendCols A = {base->op_id, base->ref_a, base->ref_b, base->payload, base->action, base->mark_type, base->side_a, base->side_b,
+                           base->chg_actor, base->chg_seq, base->chg_nops, base->chg_deps};
+        PtxAppendCols B = {m->op_id, m->ref_a, m->ref_b, m->payload, m->action, m->mark_type, m->side_a, m->side_b, m->chg_actor, m->chg_seq, m->chg_nops, m->chg_deps};
+        PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_actor, b->chg_seq, b->chg_nops, b->chg_deps};
+        hipLaunchKernelGGL(ptx_append_rows_kernel, dim3((unsigned)L), dim3(256), 0, ctx->stream, A, base->log_off, env ? base->chg_off : nullptr, B, m->log_off,
+                           env ? m->chg_off : nullptr, D, b->log_off, env ? b->chg_off : nullptr, b->max_actors);
+        PTX_TRYA(hipGetLastError());
+        PTX_TRYA(hipStreamSynchronize(ctx->stream));
+    } else {
+        PTX_TRYA(hipMemsetAsync(b->log_off, 0, 8, ctx->stream));
+        if (env) PTX_TRYA(hipMemsetAsync(b->chg_off, 0, 8, ctx->stream));
+        PTX_TRYA(hipStreamSynchronize(ctx->stream));
+    }
+#undef PTX_TRYA
+    ptx_batch_free(ctx, m);
+    st = census_and_shape(ctx, b, false);
+    if (st != PTX_OK) {
+        ptx_batch_free(ctx, b);
+        return st;
+    }
+    *out = b;
+    return PTX_OK;
+}
 
 ptx_status ptx_batch_wrap_device(ptx_ctx* ctx, const ptx_batch* d, ptx_dbatch** out) {
     if (!ctx || !out) return PTX_ERR_INVALID_ARG;

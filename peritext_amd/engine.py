@@ -119,6 +119,13 @@ class Engine:
         self._check(self.lib.ptx_batch_wrap_device(self.ctx, C.byref(s), C.byref(h)))
         return h
 
+    def append(self, dbatch, more):
+        """Streaming append: a new resident batch whose log l = log l of `dbatch` + log l of the wire.Batch `more`."""
+        s = _batch_struct(more)
+        h = C.c_void_p()
+        self._check(self.lib.ptx_batch_append(self.ctx, dbatch, C.byref(s), C.byref(h)))
+        return h
+
     def free_batch(self, h):
         self.lib.ptx_batch_free(self.ctx, h)
 

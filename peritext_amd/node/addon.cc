@@ -45,6 +45,11 @@ struct Lib {
     ptx_status (*result_download)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, ptx_result*) = nullptr;
     ptx_status (*replay_patches)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, ptx_patches*) = nullptr;
     void (*patches_free)(ptx_patches*) = nullptr;
+    /* on-device change(): op logs generated in HBM */
+    ptx_status (*generate)(ptx_ctx*, const ptx_gen_config*, ptx_dbatch**, ptx_gen_info*) = nullptr;
+    void (*gen_info_free)(ptx_gen_info*) = nullptr;
+    ptx_status (*batch_download)(ptx_ctx*, const ptx_dbatch*, ptx_host_batch*) = nullptr;
+    void (*host_batch_free)(ptx_host_batch*) = nullptr;
 } L;
 
 #define NAPI_OK(call)                                                        \
@@ -85,7 +90,8 @@ napi_value Open(napi_env env, napi_callback_info info) {
                   sym(L.max_ops_per_log, "ptx_max_ops_per_log") && sym(L.kernel_name, "ptx_kernel_name") && sym(L.batch_upload, "ptx_batch_upload") &&
                   sym(L.batch_free, "ptx_batch_free") && sym(L.result_alloc, "ptx_result_alloc") && sym(L.dresult_free, "ptx_dresult_free") &&
                   sym(L.merge, "ptx_merge") && sym(L.sync, "ptx_sync") && sym(L.result_download, "ptx_result_download") &&
-                  sym(L.replay_patches, "ptx_replay_patches") && sym(L.patches_free, "ptx_patches_free");
+                  sym(L.replay_patches, "ptx_replay_patches") && sym(L.patches_free, "ptx_patches_free") && sym(L.generate, "ptx_generate") &&
+                  sym(L.gen_info_free, "ptx_gen_info_free") && sym(L.batch_download, "ptx_batch_download") && sym(L.host_batch_free, "ptx_host_batch_free");
         if (!ok) {
             dlclose(L.handle);
             L.handle = nullptr;
@@ -298,6 +304,143 @@ napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
     return out;
 }
 
+napi_value make_typed(napi_env env, napi_typedarray_type type, size_t elem, const void* src, size_t count) {
+    napi_value ab, ta;
+    void* data = nullptr;
+    if (napi_create_arraybuffer(env, count * elem, &data, &ab) != napi_ok) return nullptr;
+    if (count && src) memcpy(data, src, count * elem);
+    if (napi_create_typedarray(env, type, count, ab, 0, &ta) != napi_ok) return nullptr;
+    return ta;
+}
+uint32_t u32_prop(napi_env env, napi_value obj, const char* name, uint32_t dflt) {
+    napi_value v;
+    bool has = false;
+    uint32_t out = dflt;
+    if (napi_has_named_property(env, obj, name, &has) == napi_ok && has && napi_get_named_property(env, obj, name, &v) == napi_ok) napi_get_value_uint32(env, v, &out);
+    return out;
+}
+
+/* generate(ctx, cfg): ptx_generate (on-device change(), the fuzzer workload) + merge of what it made, all resident; returns the
+ * op-log columns (ptx_batch_download), the comment-id counts per document and the merge result */
+napi_value Generate(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc > 1 ? ctx_of(env, argv[0]) : nullptr;
+    if (!ctx) return throw_msg(env, "generate(ctx, cfg)");
+    napi_value c = argv[1];
+    ptx_gen_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.replicas = u32_prop(env, c, "replicas", 1);
+    cfg.ops_per_log = u32_prop(env, c, "opsPerLog", 0);
+    cfg.seed = u32_prop(env, c, "seed", 1);
+    cfg.first_doc = u32_prop(env, c, "firstDoc", 0);
+    cfg.n_docs = u32_prop(env, c, "nDocs", 1);
+    cfg.list_cap = u32_prop(env, c, "listCap", 0);
+    napi_value arr;
+    uint32_t len = 0;
+    if (napi_get_named_property(env, c, "mix", &arr) != napi_ok || napi_get_array_length(env, arr, &len) != napi_ok || len != 4) return throw_msg(env, "cfg.mix: [insert, delete, addMark, removeMark] percent");
+    for (uint32_t i = 0; i < 4; ++i) {
+        napi_value e;
+        napi_get_element(env, arr, i, &e);
+        napi_get_value_uint32(env, e, &cfg.mix[i]);
+    }
+    if (napi_get_named_property(env, c, "markTypes", &arr) != napi_ok || napi_get_array_length(env, arr, &len) != napi_ok || len > 4) return throw_msg(env, "cfg.markTypes: up to four PTX_MARK_* codes");
+    cfg.n_mark_types = len;
+    for (uint32_t i = 0; i < len; ++i) {
+        napi_value e;
+        uint32_t t = 0;
+        napi_get_element(env, arr, i, &e);
+        napi_get_value_uint32(env, e, &t);
+        cfg.mark_types[i] = (uint8_t)t;
+    }
+    {
+        napi_value tv;
+        bool has = false;
+        size_t tl = 0;
+        if (napi_has_named_property(env, c, "initialText", &has) == napi_ok && has && napi_get_named_property(env, c, "initialText", &tv) == napi_ok)
+            napi_get_value_string_utf8(env, tv, cfg.initial_text, sizeof(cfg.initial_text), &tl);
+    }
+    ptx_dbatch* db = nullptr;
+    ptx_dresult* dr = nullptr;
+    ptx_gen_info gi;
+    ptx_host_batch hb;
+    ptx_result res;
+    memset(&hb, 0, sizeof(hb));
+    ptx_status st = L.generate(ctx, &cfg, &db, &gi);
+    if (st != PTX_OK) {
+        char msg[1024];
+        snprintf(msg, sizeof(msg), "ptx_generate failed (status %d): %s", st, L.last_error(ctx));
+        return throw_msg(env, msg);
+    }
+    st = L.batch_download(ctx, db, &hb);
+    if (st == PTX_OK) st = L.result_alloc(ctx, db, &dr);
+    if (st == PTX_OK) st = L.merge(ctx, db, dr);
+    if (st == PTX_OK) st = L.sync(ctx);
+    bool have_res = false;
+    if (st == PTX_OK) {
+        st = L.result_download(ctx, db, dr, &res);
+        have_res = st == PTX_OK;
+    }
+    if (dr) L.dresult_free(ctx, dr);
+    L.batch_free(ctx, db);
+    if (st != PTX_OK) {
+        char msg[1024];
+        snprintf(msg, sizeof(msg), "generate: merge of the generated batch failed (status %d): %s", st, L.last_error(ctx));
+        if (hb.owner) L.host_batch_free(&hb);
+        L.gen_info_free(&gi);
+        return throw_msg(env, msg);
+    }
+    napi_value out, batch, result, v;
+    NAPI_OK(napi_create_object(env, &out));
+    NAPI_OK(napi_create_object(env, &batch));
+    NAPI_OK(napi_create_object(env, &result));
+    const ptx_batch& b = hb.b;
+    const size_t Lg = b.n_logs, T = (size_t)b.n_ops, NC = b.chg_off ? (size_t)b.chg_off[Lg] : 0;
+    struct { const char* name; napi_typedarray_type type; size_t elem; const void* src; size_t count; } cols[] = {
+        {"logOff", napi_biguint64_array, 8, b.log_off, Lg + 1}, {"opId", napi_biguint64_array, 8, b.op_id, T}, {"refA", napi_biguint64_array, 8, b.ref_a, T},
+        {"refB", napi_biguint64_array, 8, b.ref_b, T}, {"payload", napi_uint32_array, 4, b.payload, T}, {"action", napi_uint8_array, 1, b.action, T},
+        {"markType", napi_uint8_array, 1, b.mark_type, T}, {"sideA", napi_uint8_array, 1, b.side_a, T}, {"sideB", napi_uint8_array, 1, b.side_b, T},
+        {"logHdr", napi_uint32_array, 4, b.log_hdr, Lg * 8}, {"chgOff", napi_biguint64_array, 8, b.chg_off, Lg + 1}, {"chgActor", napi_uint32_array, 4, b.chg_actor, NC},
+        {"chgSeq", napi_uint32_array, 4, b.chg_seq, NC}, {"chgNops", napi_uint32_array, 4, b.chg_nops, NC}, {"chgDeps", napi_uint32_array, 4, b.chg_deps, NC * b.max_actors},
+    };
+    for (auto& col : cols) {
+        v = make_typed(env, col.type, col.elem, col.src, col.count);
+        if (v) napi_set_named_property(env, batch, col.name, v);
+    }
+    napi_create_uint32(env, b.max_actors, &v);
+    napi_set_named_property(env, batch, "maxActors", v);
+    napi_create_uint32(env, b.n_logs, &v);
+    napi_set_named_property(env, batch, "nLogs", v);
+    napi_create_double(env, (double)b.n_ops, &v);
+    napi_set_named_property(env, batch, "nOps", v);
+    napi_set_named_property(env, out, "batch", batch);
+    v = make_u32(env, gi.n_comments, gi.n_docs);
+    if (v) napi_set_named_property(env, out, "nComments", v);
+    napi_create_double(env, (double)gi.kernel_ms, &v);
+    napi_set_named_property(env, out, "kernelMs", v);
+    if (have_res) {
+        v = make_u32(env, res.logs, (size_t)res.n_logs * 12);
+        if (v) napi_set_named_property(env, result, "logs", v);
+        v = make_u32(env, res.values, (size_t)res.n_rows);
+        if (v) napi_set_named_property(env, result, "values", v);
+        v = make_u32(env, res.spans, (size_t)res.n_rows * 2);
+        if (v) napi_set_named_property(env, result, "spans", v);
+        v = make_u32(env, res.cintervals, (size_t)res.n_rows * 3);
+        if (v) napi_set_named_property(env, result, "cintervals", v);
+        if (res.elem_rank) {
+            v = make_u32(env, res.elem_rank, (size_t)res.n_rows);
+            if (v) napi_set_named_property(env, result, "elemRank", v);
+        }
+        L.result_free(&res);
+        napi_set_named_property(env, out, "result", result);
+    }
+    L.host_batch_free(&hb);
+    L.gen_info_free(&gi);
+    return out;
+}
+
 napi_value MaxOpsPerLog(napi_env env, napi_callback_info info) {
     size_t argc = 1;
     napi_value argv[1];
@@ -316,7 +459,7 @@ napi_value KernelName(napi_env env, napi_callback_info) {
 
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
-        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"maxOpsPerLog", MaxOpsPerLog}, {"kernelName", KernelName},
+        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"generate", Generate}, {"maxOpsPerLog", MaxOpsPerLog}, {"kernelName", KernelName},
     };
     for (auto& f : fns) {
         napi_value fn;

@@ -70,6 +70,9 @@ export class MergeEngine {
     applyChanges(docs: Change[][][]): FormatSpanWithText[][][]
     /** spans as applyChanges + patches[doc][replica][change] = what applyChange(change) returns (micromerge.ts:499) */
     applyChangesWithPatches(docs: Change[][][]): { spans: FormatSpanWithText[][][]; patches: Patch[][][][] }
+    /** on-device change(): edit histories generated on the GPU (ptx_generate; the documents of oracle/ptxgen.js for the same seed) and merged there */
+    generate(cfg: { replicas: number; opsPerLog: number; mix: [number, number, number, number]; markTypes: MarkType[]; seed: number; nDocs: number; firstDoc?: number; listCap?: number; initialText?: string }):
+        { docs: Change[][][]; spans: FormatSpanWithText[][][]; kernelMs: number; batch: WireBatch }
     digests(docs: Change[][][]): Array<[bigint, bigint]>
     replica(docId?: number | string): ReplicaHandle
     flush(wantPatches?: boolean): void
@@ -77,4 +80,5 @@ export class MergeEngine {
 export function encodeDocs(docs: Change[][][]): WireBatch
 export function decodeSpans(batch: WireBatch, res: WireResult, log: number): FormatSpanWithText[]
 export function decodePatches(batch: WireBatch, res: WireResult, log: number): Patch[][]
+export function decodeChanges(batch: WireBatch, log: number): Change[]
 export function census(batch: WireBatch): Uint32Array

@@ -206,6 +206,52 @@ function decodeSpans(batch, res, log) {
     return out
 }
 
+/**
+ * Change[] of one log — the inverse of encodeDocs for the ops of the text list (micromerge.ts:60-71 Change, :150-212
+ * Operation, peritext.ts:25-65 mark ops) in the JSON-portable form of the traces ("_root" / "_head").
+ */
+function decodeChanges(batch, log) {
+    const d = batch.logDoc[log]
+    const actors = batch.docActors[d], comments = batch.docComments[d]
+    const oid = v => String(v >> 32n) + "@" + actors[Number(v & 0xffffffffn)]
+    const out = []
+    let row = Number(batch.logOff[log])
+    let textObj = null
+    for (let c = Number(batch.chgOff[log]); c < Number(batch.chgOff[log + 1]); c++) {
+        const nops = batch.chgNops[c]
+        const deps = {}
+        for (let a = 0; a < batch.maxActors; a++) {
+            const v = batch.chgDeps[c * batch.maxActors + a]
+            if (v) deps[actors[a]] = v
+        }
+        const ops = []
+        for (let i = row; i < row + nops; i++) {
+            const act = batch.action[i]
+            const op = { opId: oid(batch.opId[i]) }
+            if (act === ACT.MAKELIST) {
+                Object.assign(op, { action: "makeList", obj: ROOT, key: "text" })
+                textObj = op.opId
+            } else if (act === ACT.INSERT) {
+                Object.assign(op, { action: "set", obj: textObj, elemId: batch.refA[i] ? oid(batch.refA[i]) : HEAD, insert: true, value: batch.values[batch.payload[i]] })
+            } else if (act === ACT.DELETE) {
+                Object.assign(op, { action: "del", obj: textObj, elemId: oid(batch.refA[i]) })
+            } else if (act === ACT.ADDMARK || act === ACT.REMOVEMARK) {
+                const mt = MARK_NAMES[batch.markType[i]]
+                const start = { type: SIDE_NAMES[batch.sideA[i]] }, end = { type: SIDE_NAMES[batch.sideB[i]] }
+                if (batch.sideA[i] < 2) start.elemId = oid(batch.refA[i])
+                if (batch.sideB[i] < 2) end.elemId = oid(batch.refB[i])
+                Object.assign(op, { action: act === ACT.ADDMARK ? "addMark" : "removeMark", obj: textObj, start, end, markType: mt })
+                if (mt === "link" && act === ACT.ADDMARK) op.attrs = { url: batch.urls[batch.payload[i]] }
+                else if (mt === "comment") op.attrs = { id: comments[batch.payload[i]] }
+            } else throw new Error("row " + i + " is not an op of the text list")
+            ops.push(op)
+        }
+        out.push({ actor: actors[batch.chgActor[c]], seq: batch.chgSeq[c], deps, startOp: nops ? Number(batch.opId[row] >> 32n) : 0, ops })
+        row += nops
+    }
+    return out
+}
+
 const PATCH = { MAKELIST: 0, INSERT: 1, DELETE: 2, ADDMARK: 3, REMOVEMARK: 4, INSERT_COMMENT: 5 }
 
 /**
@@ -286,6 +332,34 @@ class MergeEngine {
             patches: docs.map(logs => logs.map(() => decodePatches(batch, res, log2++))),
         }
     }
+    /**
+     * On-device change(): whole edit histories made on the GPU (ptx_generate — Micromerge.change, micromerge.ts:308-441, under the
+     * workload of the reference's fuzzer test/fuzz.ts:115-205 in its seeded form oracle/ptxgen.js) and merged there.
+     * cfg: {replicas, opsPerLog, mix: [insert, delete, addMark, removeMark] percent, markTypes: MarkType[], seed, nDocs, firstDoc?, listCap?, initialText?}
+     * Returns {docs: Change[][][] (doc -> replica -> changes in application order), spans: FormatSpanWithText[][][], kernelMs}.
+     */
+    generate(cfg) {
+        const raw = this.addon.generate(this.ctx, Object.assign({}, cfg, { markTypes: (cfg.markTypes || []).map(m => MARK_NAMES.indexOf(m)) }))
+        const batch = raw.batch
+        const R = cfg.replicas, nDocs = cfg.nDocs
+        /* the fixed string tables of a generated batch (include/peritext_hip.h ptx_generate) */
+        batch.values = Array.from({ length: 128 }, (_, i) => String.fromCharCode(i))
+        batch.urls = Array.from({ length: 26 }, (_, i) => String.fromCharCode(65 + i) + ".com")
+        batch.logDoc = []
+        batch.docActors = []
+        batch.docComments = []
+        for (let d = 0; d < nDocs; d++) {
+            for (let r = 0; r < R; r++) batch.logDoc.push(d)
+            batch.docActors.push(Array.from({ length: R }, (_, i) => "doc" + (i + 1)))
+            batch.docComments.push(Array.from({ length: raw.nComments[d] }, (_, k) => "comment-" + k).sort()) /* UTF-16 order = the wire ranks */
+        }
+        const docs = [], spans = []
+        for (let d = 0; d < nDocs; d++) {
+            docs.push(Array.from({ length: R }, (_, r) => decodeChanges(batch, d * R + r)))
+            spans.push(Array.from({ length: R }, (_, r) => decodeSpans(batch, raw.result, d * R + r)))
+        }
+        return { docs, spans, kernelMs: raw.kernelMs, batch }
+    }
     /** docs: Change[][][]  ->  FormatSpanWithText[][][] (doc -> replica -> spans).  A failed log throws RangeError like the reference. */
     applyChanges(docs) {
         const batch = encodeDocs(docs)
@@ -354,4 +428,4 @@ class MergeEngine {
     }
 }
 
-module.exports = { MergeEngine, encodeDocs, decodeSpans, decodePatches, PATCH, census, ACT, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }
+module.exports = { MergeEngine, encodeDocs, decodeSpans, decodePatches, decodeChanges, PATCH, census, ACT, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }

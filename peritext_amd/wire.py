@@ -286,6 +286,33 @@ def decode_spans(batch, res, log):
     return out
 
 
+def split_batch(batch, first_changes):
+    """Cut every log after its first `first_changes[l]` changes: (head, tail) Batches sharing the tables of `batch` — what a
+    replica had applied at some point, and what arrived since (the input of Engine.append / ptx_batch_append)."""
+    parts = ([], [])
+    rows = ([0], [0])
+    chgs = ([0], [0])
+    for l in range(batch.n_logs):
+        b0, b1 = int(batch.log_off[l]), int(batch.log_off[l + 1])
+        c0, c1 = int(batch.chg_off[l]), int(batch.chg_off[l + 1])
+        k = min(max(int(first_changes[l]), 0), c1 - c0)
+        cut = b0 + int(batch.chg_nops[c0:c0 + k].sum())
+        for part, (r0, r1, q0, q1) in enumerate(((b0, cut, c0, c0 + k), (cut, b1, c0 + k, c1))):
+            parts[part].append((r0, r1, q0, q1))
+            rows[part].append(rows[part][-1] + r1 - r0)
+            chgs[part].append(chgs[part][-1] + q1 - q0)
+    out = []
+    for part in (0, 1):
+        ridx = np.concatenate([np.arange(r0, r1) for r0, r1, _, _ in parts[part]]).astype(np.int64) if parts[part] else np.zeros(0, dtype=np.int64)
+        cidx = np.concatenate([np.arange(q0, q1) for _, _, q0, q1 in parts[part]]).astype(np.int64) if parts[part] else np.zeros(0, dtype=np.int64)
+        out.append(Batch(
+            np.asarray(rows[part], dtype=np.uint64), batch.op_id[ridx], batch.ref_a[ridx], batch.ref_b[ridx], batch.payload[ridx], batch.action[ridx],
+            batch.mark_type[ridx], batch.side_a[ridx], batch.side_b[ridx], np.asarray(chgs[part], dtype=np.uint64), batch.chg_actor[cidx],
+            batch.chg_seq[cidx], batch.chg_nops[cidx], batch.chg_deps.reshape(-1, batch.max_actors)[cidx].reshape(-1), batch.max_actors, None,
+            batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments))
+    return out[0], out[1]
+
+
 def decode_changes(batch, log):
     """Change[] of one log — the inverse of encode_docs for the ops of the text list (reference/src/micromerge.ts:60-71
     Change, :150-212 Operation, src/peritext.ts:25-65 mark ops), in the JSON-portable form of the traces

@@ -85,7 +85,33 @@ if (cmd === "encode") {
     }
     engine.close()
     console.log(JSON.stringify({ ok: true, logs, patches }))
+} else if (cmd === "decode") {
+    /* no GPU: decodeChanges inverts encodeDocs */
+    const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    const docs = gen.docs.map(d => d.logs)
+    const b = host.encodeDocs(docs)
+    let log = 0
+    docs.forEach(logs => logs.forEach(l => assert.deepStrictEqual(host.decodeChanges(b, log++), l)))
+    console.log(JSON.stringify({ ok: true, logs: log }))
+} else if (cmd === "generate") {
+    /* GPU: on-device change() reproduces the committed PTXGEN fixtures (config + seed in the file) and merges them to their spans */
+    const engine = new host.MergeEngine()
+    let logs = 0
+    for (const f of process.argv.slice(3)) {
+        const gen = JSON.parse(fs.readFileSync(f, "utf8"))
+        const c = gen.cfg
+        const got = engine.generate({ replicas: c.replicas, opsPerLog: c.opsPerLog, mix: c.mix, markTypes: c.markTypes, seed: gen.seed, nDocs: gen.docs.length, firstDoc: gen.docs[0].docIndex })
+        gen.docs.forEach((d, di) =>
+            d.logs.forEach((l, ri) => {
+                assert.deepStrictEqual(got.docs[di][ri], l, f + " doc " + di + " replica " + ri)
+                assert.deepStrictEqual(norm(got.spans[di][ri]), norm(d.expected[ri].spans))
+                logs++
+            })
+        )
+    }
+    engine.close()
+    console.log(JSON.stringify({ ok: true, logs }))
 } else {
-    console.error("usage: encode|load|run|patches")
+    console.error("usage: encode|load|run|patches|decode|generate")
     process.exit(2)
 }

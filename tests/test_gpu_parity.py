@@ -461,3 +461,41 @@ def test_split_launch_when_a_few_logs_need_more_lds(eng):
     finally:
         eng.free_result(dr)
         eng.free_batch(db)
+
+
+def test_streaming_append_to_resident_logs(eng):
+    """the changes that arrived since are appended to the resident logs device to device; the grown batch is, column for
+    column, the batch of the whole logs, and merges to the oracle's spans with the same digests and Patch[] streams."""
+    g = _load("ptxgen_rich_700.json")
+    docs = [d["logs"] for d in g["docs"]]
+    full = wire.encode_docs(docs)
+    nch = np.diff(full.chg_off.astype(np.int64))
+    head, tail = wire.split_batch(full, nch * 2 // 3)
+    assert 0 < head.n_ops < full.n_ops and head.n_ops + tail.n_ops == full.n_ops
+    db_full = eng.upload(full)
+    db_head = eng.upload(head)
+    db_grown = eng.append(db_head, tail)
+    try:
+        assert eng.n_ops(db_grown) == full.n_ops and eng.n_changes(db_grown) == int(full.chg_off[-1])
+        got = eng.download_batch(db_grown)
+        for k in ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_actor", "chg_seq", "chg_nops", "chg_deps"):
+            assert np.array_equal(getattr(got, k), getattr(full, k)), k
+        assert np.array_equal(got.log_hdr, full.log_hdr)
+        out = {}
+        for name, db in (("full", db_full), ("grown", db_grown)):
+            dr = eng.alloc_result(db)
+            eng.merge(db, dr)
+            eng.sync()
+            out[name] = (eng.download(db, dr), eng.replay_patches(db, dr))
+            eng.free_result(dr)
+        assert np.array_equal(out["grown"][0].logs["digest"], out["full"][0].logs["digest"])
+        log = 0
+        for d in g["docs"]:
+            for exp in d["expected"]:
+                H.check_log(full, out["grown"][0], log, exp)
+                a, b = wire.decode_patches(full, out["full"][1], log), wire.decode_patches(full, out["grown"][1], log)
+                assert H.norm_patches(a) == H.norm_patches(b)
+                log += 1
+    finally:
+        for h in (db_full, db_head, db_grown):
+            eng.free_batch(h)

@@ -35,7 +35,7 @@ def test_addon_loads_and_binds_the_c_abi():
     info = _node("load")
     assert info["abi"] == abi.PTX_ABI_VERSION
     assert info["kernel"].startswith("ptx_merge_kernel")
-    assert info["exports"] == ["applyMaterialize", "create", "destroy", "kernelName", "maxOpsPerLog", "open"]
+    assert info["exports"] == ["applyMaterialize", "create", "destroy", "generate", "kernelName", "maxOpsPerLog", "open"]
 
 
 @needs_node
@@ -74,3 +74,20 @@ def test_node_host_patch_streams():
     out = _node("patches", *[os.path.join(H.GOLDEN, n) for n in names], timeout=600)
     want = [e for n in names for d in json.load(open(os.path.join(H.GOLDEN, n)))["docs"] for e in d["expected"]]
     assert out["ok"] and out["logs"] == len(want) and out["patches"] == sum(len(e["patches"]) for e in want)
+
+
+@needs_node
+@pytest.mark.parametrize("name", ["ptxgen_mini.json", "ptxgen_rich_700.json"])
+def test_js_decode_changes_inverts_the_encoder(name):
+    out = _node("decode", os.path.join(H.GOLDEN, name))
+    assert out["ok"] and out["logs"] > 0
+
+
+@pytest.mark.gpu
+@needs_node
+@needs_addon
+def test_node_host_generates_on_the_device():
+    """engine.generate(): on-device change() through N-API — the logs of the committed PTXGEN fixtures, deep-equal, and their spans."""
+    names = ["ptxgen_mini.json", "ptxgen_config4_600.json"]
+    out = _node("generate", *[os.path.join(H.GOLDEN, n) for n in names], timeout=600)
+    assert out["ok"] and out["logs"] == sum(len(d["logs"]) for n in names for d in json.load(open(os.path.join(H.GOLDEN, n)))["docs"])
