@@ -81,4 +81,6 @@ export function encodeDocs(docs: Change[][][]): WireBatch
 export function decodeSpans(batch: WireBatch, res: WireResult, log: number): FormatSpanWithText[]
 export function decodePatches(batch: WireBatch, res: WireResult, log: number): Patch[][]
 export function decodeChanges(batch: WireBatch, log: number): Change[]
+/** bridge.ts:394-414 prosemirrorDocFromCRDT, as the Node.toJSON() form of the document (parity unpinned: no ProseMirror in the build image) */
+export function prosemirrorDocFromSpans(spans: FormatSpanWithText[]): { type: "doc"; content: Array<{ type: "paragraph"; content?: Array<{ type: "text"; text: string; marks?: Array<{ type: MarkType; attrs?: Record<string, string> }> }> }> }
 export function census(batch: WireBatch): Uint32Array

@@ -252,6 +252,33 @@ function decodeChanges(batch, log) {
     return out
 }
 
+/**
+ * prosemirrorDocFromCRDT (reference/src/bridge.ts:394-414 with getProsemirrorMarksForMarkMap :369-391) as the JSON that
+ * prosemirror-model's Node.toJSON() gives for the document it builds: doc > paragraph > text nodes, one per span, marks
+ * in ALL_MARKS order (= schema rank order, schema.ts:125,:146-149), attrs only where the mark spec has some (comment
+ * {id}, link {url}; strong / em carry none, schema.ts:45-96).  prosemirror-model is not available in this image: this
+ * follows its documented toJSON shape, PARITY UNPINNED.
+ */
+function prosemirrorDocFromSpans(spans) {
+    const text = spans.filter(s => s.text !== "").map(s => {
+        const marks = []
+        for (const t of MARK_NAMES) {
+            const v = s.marks[t]
+            if (v === undefined) continue
+            if (Array.isArray(v)) for (const one of v) marks.push({ type: t, attrs: { id: one.id } })
+            else if (t === "link") marks.push({ type: t, attrs: { url: v.url } })
+            else marks.push({ type: t })
+        }
+        const node = { type: "text" }
+        if (marks.length) node.marks = marks
+        node.text = s.text
+        return node
+    })
+    const paragraph = { type: "paragraph" }
+    if (text.length) paragraph.content = text
+    return { type: "doc", content: [paragraph] }
+}
+
 const PATCH = { MAKELIST: 0, INSERT: 1, DELETE: 2, ADDMARK: 3, REMOVEMARK: 4, INSERT_COMMENT: 5 }
 
 /**
@@ -428,4 +455,4 @@ class MergeEngine {
     }
 }
 
-module.exports = { MergeEngine, encodeDocs, decodeSpans, decodePatches, decodeChanges, PATCH, census, ACT, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }
+module.exports = { MergeEngine, encodeDocs, decodeSpans, decodePatches, decodeChanges, prosemirrorDocFromSpans, PATCH, census, ACT, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }

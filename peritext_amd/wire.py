@@ -457,6 +457,36 @@ def decode_patches(batch, pat, log, with_rows=False):
     return out
 
 
+def prosemirror_doc(spans):
+    """prosemirrorDocFromCRDT (reference/src/bridge.ts:394-414, marks :369-391) as the JSON prosemirror-model's Node.toJSON() gives:
+    doc > paragraph > one text node per span, marks in ALL_MARKS order (schema.ts:125), attrs only for comment {id} and link {url}.
+    ProseMirror is not available in this image: restated from its documented toJSON shape, PARITY UNPINNED."""
+    text = []
+    for s in spans:
+        if s["text"] == "":
+            continue
+        marks = []
+        for t in abi.MARK_NAMES:
+            v = s["marks"].get(t)
+            if v is None:
+                continue
+            if isinstance(v, list):
+                marks += [{"type": t, "attrs": {"id": one["id"]}} for one in v]
+            elif t == "link":
+                marks.append({"type": t, "attrs": {"url": v["url"]}})
+            else:
+                marks.append({"type": t})
+        node = {"type": "text"}
+        if marks:
+            node["marks"] = marks
+        node["text"] = s["text"]
+        text.append(node)
+    paragraph = {"type": "paragraph"}
+    if text:
+        paragraph["content"] = text
+    return {"type": "doc", "content": [paragraph]}
+
+
 def _elements(batch, res, log):
     """(op_id, rank, deleted) of every list element of a log, from the elem_rank output column."""
     b0, b1 = int(batch.log_off[log]), int(batch.log_off[log + 1])

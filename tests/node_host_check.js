@@ -85,6 +85,10 @@ if (cmd === "encode") {
     }
     engine.close()
     console.log(JSON.stringify({ ok: true, logs, patches }))
+} else if (cmd === "pmdoc") {
+    /* no GPU: ProseMirror doc JSON of every expected span list of a fixture */
+    const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    console.log(JSON.stringify(gen.docs.map(d => d.expected.map(e => host.prosemirrorDocFromSpans(e.spans)))))
 } else if (cmd === "decode") {
     /* no GPU: decodeChanges inverts encodeDocs */
     const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))

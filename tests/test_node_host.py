@@ -91,3 +91,27 @@ def test_node_host_generates_on_the_device():
     names = ["ptxgen_mini.json", "ptxgen_config4_600.json"]
     out = _node("generate", *[os.path.join(H.GOLDEN, n) for n in names], timeout=600)
     assert out["ok"] and out["logs"] == sum(len(d["logs"]) for n in names for d in json.load(open(os.path.join(H.GOLDEN, n)))["docs"])
+
+
+@needs_node
+def test_prosemirror_doc_json_js_equals_python_and_has_the_bridge_shape():
+    """spans -> ProseMirror doc (bridge.ts:394-414) as Node.toJSON() JSON; the JS and Python hosts agree, the
+    shape is the bridge's (one paragraph, one text node per span, marks in schema order, attrs only for comment and link)."""
+    name = os.path.join(H.GOLDEN, "ptxgen_rich_700.json")
+    js = _node("pmdoc", name)
+    with open(name) as f:
+        gen = json.load(f)
+    py = [[wire.prosemirror_doc(e["spans"]) for e in d["expected"]] for d in gen["docs"]]
+    assert js == py
+    doc = py[0][0]
+    assert doc["type"] == "doc" and [p["type"] for p in doc["content"]] == ["paragraph"]
+    nodes = doc["content"][0]["content"]
+    assert "".join(n["text"] for n in nodes) == "".join(s["text"] for s in gen["docs"][0]["expected"][0]["spans"])
+    order = {t: i for i, t in enumerate(abi.MARK_NAMES)}
+    for n in nodes:
+        ranks = [order[m["type"]] for m in n.get("marks", [])]
+        assert ranks == sorted(ranks)
+        for m in n.get("marks", []):
+            assert ("attrs" in m) == (m["type"] in ("comment", "link"))
+    assert wire.prosemirror_doc([]) == {"type": "doc", "content": [{"type": "paragraph"}]}
+    assert wire.prosemirror_doc([{"text": "", "marks": {}}]) == {"type": "doc", "content": [{"type": "paragraph"}]}
