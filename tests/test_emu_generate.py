@@ -79,3 +79,18 @@ def test_generator_capacity_and_single_replica():
     if H.have_node():
         g = H.oracle_gen("config2", seed=9, docs=3, ops=64)
         check_generated_logs(batch, [d["logs"] for d in g["docs"]])
+
+
+@pytest.mark.parametrize("cfg,replicas,ops,docs,seed", [("mini", 2, None, 8, 91), ("mini", 4, 160, 6, 92), ("rich", 4, 400, 2, 93), ("config3", 2, 300, 3, 94)])
+def test_generator_other_replica_counts(cfg, replicas, ops, docs, seed):
+    """2 and 4 replicas (the sync pairs, the pending-queue order and the deps rows change with R)."""
+    if not H.have_node():
+        pytest.skip("node not installed")
+    g = H.oracle_gen(cfg, seed=seed, docs=docs, ops=ops, replicas=replicas)
+    batch, status = H.emu_generate(H.gen_config(cfg, ops=ops, replicas=replicas), docs, seed)
+    assert not status.any()
+    check_generated_logs(batch, [d["logs"] for d in g["docs"]])
+    res = H.emu_merge(batch, lds_bytes=160 * 1024, admission=True)
+    assert not res.logs["status"].any()
+    d = res.logs["digest"].reshape(docs, replicas, 2)
+    assert (d == d[:, :1, :]).all()  # every replica of a document converges
