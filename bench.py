@@ -148,10 +148,9 @@ def main():
     gen_info = None
     if args.device_gen:
         # ---- workload made on the device: on-device change() (ptx_generate), every document of every rank distinct ----
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import helpers
+        from peritext_amd import workloads
 
-        gcfg = helpers.gen_config(args.config, ops=args.ops)
+        gcfg = workloads.gen_config(args.config, ops=args.ops)
         gen_args = (gcfg["replicas"], gcfg["ops_per_log"], gcfg["mix"], gcfg["mark_types"])
         t_gen = time.time()
         db, gen_info = eng.generate(*gen_args, args.docs_per_gpu, args.seed, first_doc=rank * args.docs_per_gpu, list_cap=args.list_cap)

@@ -266,14 +266,10 @@ class _GenArgs(C.Structure):
 
 
 def gen_config(name, ops=None, replicas=None):
-    """The PTXGEN workload definitions (oracle/ptxgen.js CONFIGS) as the generator's parameters."""
-    cfgs = {
-        "config2": (1, 256, [70, 30, 0, 0], []), "config3": (1, 1024, [40, 20, 25, 15], ["strong", "em"]),
-        "config4": (3, 4096, [25, 25, 25, 25], ["strong", "em", "link", "comment"]), "config5": (1, 8192, [20, 50, 20, 10], ["link", "comment"]),
-        "rich": (3, 1024, [55, 10, 20, 15], ["strong", "em", "link", "comment"]), "mini": (3, 96, [25, 25, 25, 25], ["strong", "em", "link", "comment"]),
-    }
-    r, n, mix, marks = cfgs[name]
-    return {"replicas": replicas or r, "ops_per_log": ops or n, "mix": mix, "mark_types": [abi.MARK_NAMES.index(m) for m in marks]}
+    """The PTXGEN workload definitions as the generator's parameters (peritext_amd/workloads.py; oracle side: oracle/ptxgen.js CONFIGS)."""
+    from peritext_amd import workloads
+
+    return workloads.gen_config(name, ops=ops, replicas=replicas)
 
 
 def batch_from_generated(cfg, n_docs, cols, env, n_changes, n_comments):

@@ -9,9 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import helpers as H  # noqa: E402
-from peritext_amd import abi  # noqa: E402
+from peritext_amd import abi, workloads as H  # noqa: E402
 from peritext_amd.engine import Engine  # noqa: E402
 
 
