@@ -5,6 +5,7 @@
  * bench.py's cpu_baseline leg.
  *
  *   node oracle/cli.js gen   --config mini|config2..5 [--docs D] [--seed S] [--first F] [--ops N] [--replicas R]
+ *                            [--mix i,d,a,r] [--marks strong,em,...] [--initial-text T]
  *                            [--impl oracle|ref] --out FILE
  *       PTXGEN traces + expected output.  FILE = {config, seed, docs:[{docIndex, seed, actors,
  *       logs:[Change[] per replica], expected:[{spans, text} per replica]}]}
@@ -74,6 +75,9 @@ if (cmd === "gen") {
     if (!cfg.mix) throw new Error("unknown config " + name)
     if (flag("--ops", null)) cfg.opsPerLog = parseInt(flag("--ops"), 10)
     if (flag("--replicas", null)) cfg.replicas = parseInt(flag("--replicas"), 10)
+    if (flag("--mix", null)) cfg.mix = flag("--mix").split(",").map(x => parseInt(x, 10)) /* percent: insert,delete,addMark,removeMark */
+    if (flag("--marks", null) !== null) cfg.markTypes = flag("--marks") === "" ? [] : flag("--marks").split(",")
+    if (flag("--initial-text", null) !== null) cfg.initialText = flag("--initial-text")
     const nDocs = parseInt(flag("--docs", "4"), 10)
     const first = parseInt(flag("--first", "0"), 10)
     const seed = parseInt(flag("--seed", "1"), 10)

@@ -30,7 +30,7 @@ def run_node(args, timeout=600):
 
 
 @functools.lru_cache(maxsize=None)
-def oracle_gen(config="mini", docs=4, seed=1, ops=None, replicas=None, first=0, impl="oracle"):
+def oracle_gen(config="mini", docs=4, seed=1, ops=None, replicas=None, first=0, impl="oracle", mix=None, marks=None, initial_text=None):
     """PTXGEN traces + expected output from the oracle (or the erased reference with impl='ref')."""
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "gen.json")
@@ -39,6 +39,12 @@ def oracle_gen(config="mini", docs=4, seed=1, ops=None, replicas=None, first=0, 
             args += ["--ops", str(ops)]
         if replicas is not None:
             args += ["--replicas", str(replicas)]
+        if mix is not None:
+            args += ["--mix", ",".join(str(x) for x in mix)]
+        if marks is not None:
+            args += ["--marks", ",".join(marks)]
+        if initial_text is not None:
+            args += ["--initial-text", initial_text]
         run_node(args)
         with open(out) as f:
             return json.load(f)

@@ -94,3 +94,25 @@ def test_generator_other_replica_counts(cfg, replicas, ops, docs, seed):
     assert not res.logs["status"].any()
     d = res.logs["digest"].reshape(docs, replicas, 2)
     assert (d == d[:, :1, :]).all()  # every replica of a document converges
+
+
+def test_generator_random_workloads():
+    """Seeded random workload definitions (mix, mark types and their order, replicas, log length, initial text): the device
+    logic and the oracle's change() must agree on every one."""
+    if not H.have_node():
+        pytest.skip("node not installed")
+    rng = np.random.default_rng(20240923)
+    all_marks = ["strong", "em", "comment", "link"]
+    for trial in range(10):
+        cuts = np.sort(rng.integers(0, 101, size=3))
+        mix = [int(cuts[0]), int(cuts[1] - cuts[0]), int(cuts[2] - cuts[1]), int(100 - cuts[2])]
+        marks = [all_marks[i] for i in rng.permutation(4)[: int(rng.integers(0, 5))]]
+        replicas = int(rng.integers(1, 5))
+        ops = int(rng.integers(20, 260))
+        text = "".join(chr(int(c)) for c in rng.integers(97, 123, size=int(rng.integers(1, 9))))
+        seed = int(rng.integers(1, 1 << 30))
+        g = H.oracle_gen("mini", seed=seed, docs=3, ops=ops, replicas=replicas, mix=tuple(mix), marks=tuple(marks), initial_text=text)
+        cfg = {"replicas": replicas, "ops_per_log": ops, "mix": mix, "mark_types": [abi.MARK_NAMES.index(m) for m in marks], "initial_text": text}
+        batch, status = H.emu_generate(cfg, 3, seed)
+        assert not status.any(), (trial, cfg)
+        check_generated_logs(batch, [d["logs"] for d in g["docs"]])

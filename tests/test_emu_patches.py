@@ -155,3 +155,26 @@ def test_replay_lds_bound():
     # a config-4 log (1250 inserts, 1600 marks, 400 comment ops, 8.7 k ids) replays within a quarter of the LDS of a CU
     assert lib.ptx_emu_replay_lds_need(1250, 1600, 400, 8736) < 40 * 1024
     assert lib.ptx_emu_replay_lds_need(0, 0, 0, 0) < 2048
+
+
+def test_patch_streams_random_workloads():
+    """Seeded random workload definitions (mix, mark types, replicas, log length): patch streams equal the oracle's, in both
+    iteration orders of the emulated parallel loops."""
+    if not H.have_node():
+        pytest.skip("node not installed")
+    rng = np.random.default_rng(7_2024)
+    all_marks = ["strong", "em", "comment", "link"]
+    for trial in range(8):
+        cuts = np.sort(rng.integers(0, 101, size=3))
+        mix = (int(cuts[0]), int(cuts[1] - cuts[0]), int(cuts[2] - cuts[1]), int(100 - cuts[2]))
+        marks = tuple(all_marks[i] for i in rng.permutation(4)[: int(rng.integers(1, 5))])
+        replicas = int(rng.integers(1, 5))
+        ops = int(rng.integers(30, 400))
+        g = H.oracle_gen("mini", seed=int(rng.integers(1, 1 << 30)), docs=2, ops=ops, replicas=replicas, mix=mix, marks=marks)
+        dl = [d["logs"] for d in g["docs"]]
+        expected = H.oracle_apply(dl, patches=True)
+        batch = wire.encode_docs(dl)
+        for reverse in (0, 1):
+            res = H.emu_merge(batch, lds_bytes=160 * 1024, reverse=reverse)
+            pat = H.emu_replay(batch, res, reverse=reverse)
+            _check_streams(batch, pat, expected)
