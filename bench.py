@@ -312,7 +312,7 @@ def main():
             "without_admission": None if ms_noadm is None else {"kernel_ms": ms_noadm, "ops_per_s_1gpu": ops_per_step / (ms_noadm * 1e-3),
                                                                 "hbm_GBps": (alg_bytes - env_bytes) / (ms_noadm * 1e-3) / 1e9},
             "launch": dict(zip(("threads_per_log", "lds_bytes_per_log"), eng.launch_shape(db))),
-            "host": {"cores": cores, "gen_s": t_gen, "upload_s": t_up, "upload_GBps": 32 * rows / copies / max(t_up, 1e-9) / 1e9},
+            "host": {"cores": cores, "gen_s": t_gen, "upload_s": t_up, "upload_GBps": None if args.device_gen else 32 * rows / copies / max(t_up, 1e-9) / 1e9},
             "device_gen": None if gen_info is None else {"kernel_ms": gen_info["kernel_ms"], "ops_generated_per_s": ops_per_step / (gen_info["kernel_ms"] * 1e-3),
                                                         "launch_shape": list(eng.launch_shape(db))},
         }
