@@ -161,12 +161,14 @@ def main():
         n_changes_rank = eng.n_changes(db)
         max_actors = replicas
         # a few documents of the same stream on the host, for the oracle check and the CPU baseline leg
-        n_host = min(args.cpu_procs, args.docs_per_gpu)
-        hb, hinfo = eng.generate(*gen_args, n_host, args.seed, first_doc=rank * args.docs_per_gpu, list_cap=args.list_cap)
-        actors_t, comments_t, log_doc_t = wire.generated_tables(n_host, replicas, hinfo["n_comments"])
-        host_batch = eng.download_batch(hb, wire.GEN_VALUES, wire.GEN_URLS, log_doc_t, actors_t, comments_t)
-        eng.free_batch(hb)
-        docs = [{"logs": [wire.decode_changes(host_batch, d * replicas + r) for r in range(replicas)]} for d in range(n_host)]
+        docs = []
+        if rank == 0:
+            n_host = min(args.cpu_procs, args.docs_per_gpu)
+            hb, hinfo = eng.generate(*gen_args, n_host, args.seed, first_doc=rank * args.docs_per_gpu, list_cap=args.list_cap)
+            actors_t, comments_t, log_doc_t = wire.generated_tables(n_host, replicas, hinfo["n_comments"])
+            host_batch = eng.download_batch(hb, wire.GEN_VALUES, wire.GEN_URLS, log_doc_t, actors_t, comments_t)
+            eng.free_batch(hb)
+            docs = [{"logs": [wire.decode_changes(host_batch, d * replicas + r) for r in range(replicas)]} for d in range(n_host)]
     else:
         # ---- workload: unique documents of this rank, tiled in HBM ----
         assert args.docs_per_gpu % args.unique == 0, "--docs-per-gpu must be a multiple of --unique"
