@@ -48,10 +48,13 @@
 #define PTX_HD static inline
 #define PTX_DEV static inline
 #define PTX_SYNC() ((void)0)
-extern int ptx_emu_reverse; /* 1: run every parallel loop backwards (order-independence check) */
+extern int ptx_emu_reverse; /* order of every emulated parallel loop: 0 forward, 1 backward, 2 a fixed pseudo-random permutation (order-independence checks) */
+static inline uint32_t ptx_emu_ix(uint32_t k, uint32_t n) { /* k-th iteration runs index ...; 104729 is a prime above any loop length here */
+    return ptx_emu_reverse == 0 ? k : ptx_emu_reverse == 1 ? n - 1u - k : (uint32_t)(((uint64_t)k * 104729ull + 7ull) % (n ? n : 1u));
+}
 #define PTX_FOR(i, n)                                                                              \
-    for (uint32_t _n = (n), _k = 0, i = (ptx_emu_reverse ? _n - 1 : 0); _k < _n;                  \
-         ++_k, i = (ptx_emu_reverse ? _n - 1 - _k : _k))
+    for (uint32_t _n = (n), _k = 0, i = (_n ? ptx_emu_ix(0, _n) : 0); _k < _n;                    \
+         ++_k, i = (_k < _n ? ptx_emu_ix(_k, _n) : 0))
 #define PTX_LEADER if (true)
 PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o & v; return o; }
@@ -67,7 +70,7 @@ PTX_DEV uint64_t ptx_clock() { return 0; }
 PTX_DEV uint32_t ptx_group_sum(uint32_t c) { return c; }
 /* batched parallel loop: PTX_U iterations per step so that their loads are all in flight together */
 #define PTX_FORU(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_U)
-#define PTX_IX(i0, u) (ptx_emu_reverse ? _n - 1u - ((i0) + (uint32_t)(u)) : (i0) + (uint32_t)(u))
+#define PTX_IX(i0, u) ((i0) + (uint32_t)(u) < _n ? ptx_emu_ix((i0) + (uint32_t)(u), _n) : (i0) + (uint32_t)(u))
 #else
 #include <hip/hip_runtime.h>
 #define PTX_HD __host__ __device__ static inline
@@ -166,7 +169,7 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
  * group index past the end means "no work" (its loads are clamped to valid addresses, its effects masked). */
 #ifdef PTX_EMU
 #define PTX_STEPS(groups) (groups)
-#define PTX_G_OF(st, steps) (ptx_emu_reverse ? ((st) < (steps) ? (steps) - 1u - (st) : (steps)) : (st))
+#define PTX_G_OF(st, steps) ((st) < (steps) ? ptx_emu_ix((st), (steps)) : (steps) + ((st) - (steps)))
 #else
 /* x / threads-per-workgroup without a division: the host passes magic = floor(2^32 / T) + 1, exact for x * T < 2^32
  * (x is a row count + T here; a uniform integer division costs ~25 instructions per wave, and a log has a dozen) */
@@ -181,7 +184,7 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #ifdef PTX_EMU
 #define PTX_JSTEPS_U(n, U) (((n) + (U)-1u) / (U))
 #define PTX_J_OF_U(st, u, U) ((st) * (U) + (uint32_t)(u))
-#define PTX_JX(j, n) (ptx_emu_reverse ? (n) - 1u - (j) : (j))
+#define PTX_JX(j, n) ((j) < (n) ? ptx_emu_ix((j), (n)) : (j))
 #else
 #define PTX_JSTEPS_U(n, U) ((PTX_DIV_T((n) + PTX_BLOCKDIM - 1u) + (U)-1u) / (U)) /* = ceil(n / (U * T)) */
 #define PTX_J_OF_U(st, u, U) (((st) * (U) + (uint32_t)(u)) * PTX_BLOCKDIM + threadIdx.x)
@@ -237,7 +240,7 @@ PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl
 /* uniform loop over groups of PTX_U consecutive items: every thread runs every step (g may be past the end) */
 #ifdef PTX_EMU
 #define PTX_FORG(g, groups) \
-    for (uint32_t _ng = (groups), _k = 0, g = (ptx_emu_reverse ? _ng - 1 : 0); _k < _ng; ++_k, g = (ptx_emu_reverse ? _ng - 1 - _k : _k))
+    for (uint32_t _ng = (groups), _k = 0, g = (_ng ? ptx_emu_ix(0, _ng) : 0); _k < _ng; ++_k, g = (_k < _ng ? ptx_emu_ix(_k, _ng) : 0))
 #else
 #define PTX_FORG(g, groups) for (uint32_t _ng = (groups), _g0 = 0, g = threadIdx.x; _g0 < _ng; _g0 += PTX_BLOCKDIM, g += PTX_BLOCKDIM)
 #endif

@@ -20,7 +20,7 @@ def _load(name):
         return json.load(f)
 
 
-@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("reverse", [0, 1, 2])
 def test_kat_literals(reverse):
     """All 46 reference test cases: every replica log -> the reference's expectedResult literal."""
     cases = H.load_kat()
@@ -35,10 +35,11 @@ def test_kat_literals(reverse):
 
 
 @pytest.mark.parametrize("name", GOLDEN_GEN)
-@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("reverse", [0, 1, 2])
 def test_golden_ptxgen(name, reverse):
     """Committed PTXGEN fixtures (oracle output): decoded spans, raw canonical rows and digests, in both
-    parallel-loop iteration orders (order independence = no intra-phase data race by construction)."""
+    parallel-loop iteration orders — forward, backward, a pseudo-random permutation (order independence = no intra-phase data
+    race by construction)."""
     H.check_generated(_load(name), lambda b: H.emu_merge(b, reverse=reverse))
 
 
@@ -174,7 +175,7 @@ def test_log_header_census_paths():
 
 
 @pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
-@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("reverse", [0, 1, 2])
 def test_huge_sibling_bucket_prepends(reverse):
     """70 inserts at index 0 (all children of HEAD: the bitmap-ranked bucket path) interleaved with children of
     other elements, deletes and a mark — against a live oracle run."""
@@ -268,7 +269,7 @@ def test_causal_admission_rejects_like_the_reference():
             assert g == w, (k, g, w, exp[kinds.index(k)][0].get("error") if k in kinds else None)
 
 
-@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("reverse", [0, 1, 2])
 def test_duplicate_op_id_is_reported(reverse):
     """Two rows with one opId: the count of distinct ids falls short of the row count and the (rare-path) second
     pass names it PTX_ERR_DUPLICATE_OP; the neighbouring log is untouched."""

@@ -27,7 +27,7 @@ accumulate = H.accumulate_patches
 
 
 @pytest.mark.parametrize("name", PATCH_GOLDEN)
-@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("reverse", [0, 1, 2])
 def test_golden_patch_streams(name, reverse):
     """Fixtures produced by the reference itself: every patch of every replica log, in order, deep-equal."""
     g = _load(name)
