@@ -11,14 +11,16 @@
  *         applyAddRemoveMark            reference/src/peritext.ts:154-249
  *     doc.getTextWithFormatting(["text"])               reference/src/peritext.ts:337-395, opsToMarks :294-326
  * with the order-independent closed form of SURVEY.md Appendix A.3/A.5/A.7:
- *   P1  classify the rows, reduce max counter / actor and the op counts
- *   P2  element index: a bitmap over the insert ids (counter<<actorBits | actor) + popcount prefix
- *       gives every list element a dense index e = its rank in compareOpIds order
+ *   P0  (batches with the Change envelope) applyChange's causal admission: seq == clock[actor] + 1 and
+ *       deps <= clock for every change, the vector clock carried along the log as a wave prefix sum
+ *   P1  ONE pass over the rows (sized by the per-log header, which it verifies): row lists per class in
+ *       row order, and the element index: a bitmap over the insert ids (counter * actors + actor) +
+ *       popcount prefix gives every list element a dense index e = its rank in compareOpIds order
  *       (micromerge.ts:812-827) and turns every elemId reference into one 8-byte LDS read
  *   P3  RGA causal tree: element order = pre-order DFS, children by DESCENDING opId (equivalent to
  *       the skip loop at micromerge.ts:630-635).  Children are bucketed per parent (counting sort)
- *       and ranked inside the bucket; the Euler tour of the tree is ranked by in-place pointer
- *       jumping -> document position of every element
+ *       and ranked inside the bucket; the Euler tour of the tree is ranked work-efficiently (splitter
+ *       walks + in-place pointer jumping over the splitters) -> document position of every element
  *   P4  tombstones: clear "alive" bits by document position, popcount prefix -> visible index
  *       (the `visible` counters of micromerge.ts:747-750)
  *   P5  marks: boundary slots 2*rank+side -> visible interval; per visible char the max-opId covering
