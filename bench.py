@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--no-admission", action="store_true", help="skip applyChange's causal admission (seq/deps) in the timed path")
     ap.add_argument("--oracle-gen", action="store_true", help="take the op logs from the oracle's generator on the host (--unique documents per GPU, "
                     "tiled in HBM) instead of generating them on the GPU (ptx_generate: on-device change(), every document distinct; the default)")
+    ap.add_argument("--fused-step", action="store_true", help="EXPERIMENTAL (not yet measured): run the engine on a torch stream and count the converged "
+                    "documents with one library kernel, so that a step has no host-side synchronisation")
     ap.add_argument("--list-cap", type=int, default=2048, help="--device-gen: list elements per replica held on chip")
     args = ap.parse_args()
     args.device_gen = not args.oracle_gen
@@ -193,9 +195,34 @@ def main():
     gathered = torch.empty((world * n_logs, 2), dtype=torch.int64, device="cuda") if world > 1 else None
     conv = torch.zeros((), dtype=torch.int64, device="cuda")
 
+    fused_stream = None
+    fused_events = []
+    if args.fused_step:
+        # experimental: everything of a step on ONE stream (torch's), no host sync inside the step; the kernel's duration comes
+        # from torch events around the launch, which now see the stream the kernel runs on
+        fused_stream = torch.cuda.Stream()
+        eng.set_stream(fused_stream.cuda_stream)
+        conv_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+
     def step(timed):
         """One pass of the hot path.  Returns the kernel's launch duration in ms when `timed`."""
         nonlocal conv
+        if fused_stream is not None:
+            with torch.cuda.stream(fused_stream):
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(fused_stream)
+                eng.merge(db, dr)
+                if timed:
+                    e1.record(fused_stream)
+                    fused_events.append((e0, e1))
+                if world == 1:
+                    eng.count_converged(dr, replicas, conv_dev.data_ptr())
+                    conv = conv_dev[0]
+                else:
+                    eng.pack_digests(dr, 0, n_logs, digests.data_ptr())
+                    conv, _ = shard.global_convergence(digests, replicas, dist, gathered)
+            return None
         ms = None
         if timed:
             ms = eng.merge_timed(db, dr, 1)  # HIP events on the engine's stream around the one launch
@@ -224,6 +251,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if fused_stream is not None:
+        kernel_ms = [a.elapsed_time(b) for a, b in fused_events]
+        eng.set_stream(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -292,6 +322,7 @@ def main():
                 "op_log_bytes_per_gpu": 32 * rows,
                 "parallelism": "doc-sharded x%d, digests-only all-gather" % world,
                 "causal_admission": not args.no_admission,
+                "fused_step": bool(args.fused_step),
                 "changes_per_gpu_per_step": n_changes,
             },
             "docs_converged_per_s": converged_docs * args.steps / elapsed,

@@ -279,6 +279,13 @@ ptx_status ptx_merge_timed(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, ui
  * tombstones, P5a values+mark intervals, P5b LWW, P5c comments, P6 spans).  Not for timed runs. */
 ptx_status ptx_merge_phase_cycles(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, uint64_t* cycles, uint32_t n);
 ptx_status ptx_sync(ptx_ctx* ctx);
+/* Run the context's launches and copies on the caller's HIP stream (e.g. torch's current stream: everything stays
+ * stream-ordered with the caller's own kernels and no host-side synchronisation is needed between them).  `hip_stream`
+ * = a hipStream_t; NULL returns to the context's own stream.  The stream stays the caller's. */
+ptx_status ptx_set_stream(ptx_ctx* ctx, void* hip_stream);
+/* Documents whose `replicas` consecutive logs all have the same digest (= converged, test/fuzz.ts:277-278), counted on the
+ * device: *count_device (a u64 in DEVICE memory) is overwritten.  n_logs must be a multiple of `replicas`. */
+ptx_status ptx_count_converged(ptx_ctx* ctx, const ptx_dresult* r, uint32_t replicas, uint64_t* count_device);
 
 ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_result* out);
 /* Only the per-log rows (status, counts, digests): [n_logs] ptx_log_result into caller memory. */

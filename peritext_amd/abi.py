@@ -219,6 +219,8 @@ FUNCTIONS = {
     "ptx_merge_timed": (C.c_int32, [vp, vp, vp, C.c_uint32, C.POINTER(C.c_float)]),
     "ptx_merge_phase_cycles": (C.c_int32, [vp, vp, vp, u64p, C.c_uint32]),
     "ptx_sync": (C.c_int32, [vp]),
+    "ptx_set_stream": (C.c_int32, [vp, vp]),
+    "ptx_count_converged": (C.c_int32, [vp, vp, C.c_uint32, vp]),
     "ptx_result_download": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_result)]),
     "ptx_result_download_logs": (C.c_int32, [vp, vp, C.POINTER(ptx_log_result), C.c_uint32]),
     "ptx_dresult_logs_device": (vp, [vp]),

@@ -177,6 +177,18 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
     }
 }
 
+__global__ void ptx_count_converged_kernel(const ptx_log_result* res, uint32_t n_docs, uint32_t replicas, unsigned long long* out) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    bool same = d < n_docs;
+    if (same) {
+        const ptx_log_result* r = res + (uint64_t)d * replicas;
+        same = r[0].status == PTX_OK;
+        for (uint32_t k = 1; k < replicas && same; ++k) same = r[k].status == PTX_OK && r[k].digest[0] == r[0].digest[0] && r[k].digest[1] == r[0].digest[1];
+    }
+    const unsigned long long m = __ballot(same);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
 __global__ void ptx_pack_digests_kernel(const ptx_log_result* res, uint32_t first, uint32_t count, uint64_t* dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) {
@@ -199,7 +211,8 @@ __global__ void ptx_tile_offsets_kernel(const uint64_t* src, uint64_t* dst, uint
 
 struct ptx_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     /* the stream in use: own_stream, or the caller's (ptx_set_stream) */
+    hipStream_t own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     int cu_count = 0;
@@ -378,6 +391,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
         delete ctx;
         return fail(nullptr, PTX_ERR_HIP, "stream/event creation failed");
     }
+    ctx->own_stream = ctx->stream;
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     {
@@ -401,7 +415,7 @@ void ptx_destroy(ptx_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -804,6 +818,27 @@ ptx_status ptx_merge_phase_cycles(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult
     if (st) return st;
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("phase cycles: ") + hipGetErrorString(e));
     for (uint32_t k = 0; k < n; ++k) cycles[k] = k < PTX_NCLK ? (uint64_t)h[k] : 0;
+    return PTX_OK;
+}
+
+ptx_status ptx_set_stream(ptx_ctx* ctx, void* hip_stream) {
+    if (!ctx) return PTX_ERR_INVALID_ARG;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); /* nothing of this context is left in flight on the stream it leaves */
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PTX_OK;
+}
+
+ptx_status ptx_count_converged(ptx_ctx* ctx, const ptx_dresult* r, uint32_t replicas, uint64_t* count_device) {
+    if (!ctx || !r || !count_device || replicas == 0) return PTX_ERR_INVALID_ARG;
+    if (r->n_logs % replicas) return fail(ctx, PTX_ERR_INVALID_ARG, "n_logs is not a multiple of replicas");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, hipMemsetAsync(count_device, 0, 8, ctx->stream));
+    const uint32_t n_docs = r->n_logs / replicas;
+    if (n_docs) {
+        hipLaunchKernelGGL(ptx_count_converged_kernel, dim3((n_docs + 255) / 256), dim3(256), 0, ctx->stream, r->logs, n_docs, replicas, (unsigned long long*)count_device);
+        PTX_HIP(ctx, hipGetLastError());
+    }
     return PTX_OK;
 }
 

@@ -152,6 +152,14 @@ class Engine:
         self._check(self.lib.ptx_merge_phase_cycles(self.ctx, dbatch, dresult, out, n))
         return [int(x) for x in out]
 
+    def set_stream(self, hip_stream):
+        """Run this engine on the caller's HIP stream (an int: e.g. torch.cuda.current_stream().cuda_stream); 0 = its own again."""
+        self._check(self.lib.ptx_set_stream(self.ctx, C.c_void_p(hip_stream or None)))
+
+    def count_converged(self, dresult, replicas, count_device_ptr):
+        """Documents whose `replicas` logs all carry the same digest, into a u64 in device memory (stream-ordered, no host sync)."""
+        self._check(self.lib.ptx_count_converged(self.ctx, dresult, replicas, C.c_void_p(count_device_ptr)))
+
     def sync(self):
         self._check(self.lib.ptx_sync(self.ctx))
 
