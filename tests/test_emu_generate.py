@@ -116,3 +116,35 @@ def test_generator_random_workloads():
         batch, status = H.emu_generate(cfg, 3, seed)
         assert not status.any(), (trial, cfg)
         check_generated_logs(batch, [d["logs"] for d in g["docs"]])
+
+
+def test_generator_list_capacity_is_exact():
+    """list_cap = the largest element count any replica reaches is enough; one less is reported, never silently wrong."""
+    c = H.gen_config("mini")
+    batch, status = H.emu_generate(c, 6, 21)
+    assert not status.any()
+    hdr = wire.census(batch.log_off, batch.op_id, batch.action, batch.mark_type)
+    per_doc = hdr["n_ins"].reshape(6, c["replicas"]).max(axis=1)
+    need = int(per_doc.max())
+    ok, st_ok = H.emu_generate(c, 6, 21, list_cap=need)
+    assert not st_ok.any() and np.array_equal(ok.op_id, batch.op_id)
+    _, st_small = H.emu_generate(c, 6, 21, list_cap=need - 1)
+    assert [int(s) for s in st_small] == [abi.ERR_CAPACITY if int(n) == need else 0 for n in per_doc]
+
+
+def test_replay_of_a_batch_without_headers_and_of_a_generated_batch():
+    """The patch replay derives the log headers itself when the batch has none, and runs on generator output (fixed string
+    tables) as on encoder output."""
+    if not H.have_node():
+        pytest.skip("node not installed")
+    g = H.oracle_gen("mini", seed=61, docs=5)
+    dl = [d["logs"] for d in g["docs"]]
+    expected = H.oracle_apply(dl, patches=True)
+    enc = wire.encode_docs(dl)
+    enc.log_hdr = None
+    gen, status = H.emu_generate(H.gen_config("mini"), 5, 61)
+    assert not status.any()
+    for batch in (enc, gen):
+        res = H.emu_merge(batch)
+        pat = H.emu_replay(batch, res)
+        H.check_patch_streams(batch, pat, expected)
