@@ -27,8 +27,9 @@
  *                  mark: start.elemId (peritext.ts:17-21,:28)
  *     ref_b   u64  mark: end.elemId (peritext.ts:30); otherwise 0
  *     payload u32  insert: value id (index into the caller's string table); addMark link: url id;
- *                  add/removeMark comment: DOC-LOCAL dense comment id whose numeric order equals the
- *                  code-unit order of the id strings (peritext.ts:318 keeps the array sorted by id)
+ *                  add/removeMark comment: DOC-LOCAL comment id (rank among the document's comment ids, shared by
+ *                  all replicas of the document) whose numeric order equals the code-unit order of the id strings
+ *                  (peritext.ts:318 keeps the array sorted by id)
  *     action  u8   PTX_ACT_*      mark_type u8  PTX_MARK_* (schema.ts:125 ALL_MARKS order)
  *     side_a  u8   PTX_SIDE_* of start        side_b u8  PTX_SIDE_* of end
  *   Ops on other objects than the text list (makeMap / set / del on the root map) are PTX_ACT_NOP.
@@ -56,7 +57,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 3u
+#define PTX_ABI_VERSION 4u
 
 /* Operation.action (micromerge.ts:150-212, peritext.ts:25-65) */
 enum {
@@ -94,7 +95,7 @@ enum {
     PTX_ERR_MISSING_DEP = 3,     /* RangeError "Missing dependency"          micromerge.ts:507 */
     PTX_ERR_DUPLICATE_OP = 4,    /* same opId twice in one log (the seq check makes this impossible upstream) */
     PTX_ERR_CAPACITY = 5,        /* log too large for the on-chip working set of this build */
-    PTX_ERR_BAD_OP = 6,          /* malformed row: unknown action / mark type / comment id not dense */
+    PTX_ERR_BAD_OP = 6,          /* malformed row: unknown action / mark type / comment id beyond the header's n_comment_ids */
     /* call-level */
     PTX_ERR_INVALID_ARG = 100,
     PTX_ERR_HIP = 101,           /* a HIP runtime call failed; see ptx_last_error */
@@ -113,6 +114,11 @@ typedef struct ptx_log_hdr {
     uint32_t n_mark[4];   /* add/removeMark rows per PTX_MARK_* */
     uint32_t max_counter; /* largest counter of any op_id of the log */
     uint32_t max_actor;   /* largest actorRank of any op_id of the log */
+    uint32_t n_comment_ids; /* comment payloads of the log are < n_comment_ids: largest doc-local comment id the log uses + 1
+                               (0 without comment ops).  Comment ids are ranks over ALL replicas of the document, so a replica
+                               that has seen only some of the comments still carries the document's ranks (an upper bound
+                               is accepted: it only sizes the per-id tables) */
+    uint32_t reserved;
 } ptx_log_hdr;
 
 /* One batch of replica-logs.  All pointers are HOST pointers for ptx_batch_upload /
@@ -251,9 +257,7 @@ ptx_status ptx_batch_wrap_device(ptx_ctx* ctx, const ptx_batch* device, ptx_dbat
 /* Streaming append: a NEW resident batch whose log l = log l of `base` followed by log l of `more` (host
  * pointers; the changes that arrived since, in application order; same n_logs, empty logs allowed).  Rows are copied
  * device to device; `base` stays valid.  `more` must be encoded with the tables of `base` (actor ranks, comment ranks,
- * value / url ids) — comment ids are doc-local dense ranks below the log's number of comment ops, so a log that will see
- * further comment ids is only mergeable once they have arrived; both batches carry the Change envelope with the same
- * max_actors, or neither does. */
+ * value / url ids); both batches carry the Change envelope with the same max_actors, or neither does. */
 ptx_status ptx_batch_append(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_batch* more, ptx_dbatch** out);
 void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b);
 uint32_t ptx_batch_n_logs(const ptx_dbatch* b);

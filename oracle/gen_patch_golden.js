@@ -8,6 +8,9 @@
  *
  *   node oracle/gen_patch_golden.js --config mini --docs 6 --seed 11 [--ops N] [--impl oracle|ref] --out tests/golden/patches_mini.json
  *
+ *   node oracle/gen_patch_golden.js --from tests/golden/ptxgen_config5_8192.json [--impl ref] --out tests/golden/patches_config5_8192.json
+ *       the streams of an EXISTING fixture's logs; the logs are not repeated: FILE = {from, impl, docs:[{expected:[{patches}]}]}
+ *
  * --impl ref uses the type-erased build of the reference itself (oracle/_ref, see build_ref.js): that is how the
  * committed fixtures were made.  FILE = {config, seed, impl, docs:[{logs, expected:[{spans, text, patches}]}]}
  */
@@ -23,6 +26,13 @@ const tmp = fs.mkdtempSync(path.join(os.tmpdir(), "ptxpatch-"))
 const gen = path.join(tmp, "gen.json")
 const out = path.join(tmp, "out.json")
 const impl = flag("--impl", "ref")
+if (flag("--from", null)) {
+    execFileSync(process.execPath, [cli, "apply", "--in", flag("--from"), "--impl", impl, "--patches", "--out", out])
+    const a = JSON.parse(fs.readFileSync(out, "utf8"))
+    const docs = a.docs.map(d => ({ expected: d.expected.map(e => ({ patches: e.patches })) }))
+    fs.writeFileSync(flag("--out"), JSON.stringify({ from: path.basename(flag("--from")), impl, docs }))
+    process.exit(0)
+}
 const genArgs = [cli, "gen", "--config", flag("--config", "mini"), "--docs", flag("--docs", "4"), "--seed", flag("--seed", "1"), "--out", gen]
 if (flag("--ops", null)) genArgs.push("--ops", flag("--ops"))
 execFileSync(process.execPath, genArgs)

@@ -7,7 +7,7 @@ the shared object is missing, and `ptx_create` fails when no gfx950 device is vi
 import ctypes as C
 import os
 
-PTX_ABI_VERSION = 3
+PTX_ABI_VERSION = 4
 
 # Operation.action (reference/src/micromerge.ts:150-212, src/peritext.ts:25-65)
 ACT_MAKELIST, ACT_INSERT, ACT_DELETE, ACT_ADDMARK, ACT_REMOVEMARK, ACT_NOP = range(6)
@@ -63,6 +63,8 @@ class ptx_log_hdr(C.Structure):
         ("n_mark", C.c_uint32 * 4),
         ("max_counter", C.c_uint32),
         ("max_actor", C.c_uint32),
+        ("n_comment_ids", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -189,7 +191,8 @@ LOG_RESULT_DTYPE = np.dtype(
         ("digest", "<u8", (2,)),
     ]
 )
-LOG_HDR_DTYPE = np.dtype([("n_ins", "<u4"), ("n_del", "<u4"), ("n_mark", "<u4", (4,)), ("max_counter", "<u4"), ("max_actor", "<u4")])
+LOG_HDR_DTYPE = np.dtype([("n_ins", "<u4"), ("n_del", "<u4"), ("n_mark", "<u4", (4,)), ("max_counter", "<u4"), ("max_actor", "<u4"),
+                          ("n_comment_ids", "<u4"), ("reserved", "<u4")])
 SPAN_DTYPE = np.dtype([("start", "<u4"), ("attr", "<u4")])
 CINTERVAL_DTYPE = np.dtype([("id", "<u4"), ("start", "<u4"), ("end", "<u4")])
 PATCH_DTYPE = np.dtype([("row", "<u4"), ("kind", "<u4"), ("a", "<u4"), ("b", "<u4")])

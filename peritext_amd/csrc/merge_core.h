@@ -481,7 +481,7 @@ PTX_DEV uint32_t ptx_ceil_log2(uint32_t x) { /* smallest k with (1<<k) >= x, x>=
 
 /* ---- LDS working set of ptx_merge_log (mirrors its ptx_alloc calls; used by the host to size the
  *      launch and by the tests to check the bound).  N rows, n inserts, D deletes, K mark ops of
- *      which Kc comment ops, id keyspace of ks bits. ---- */
+ *      which Kc comment ops over Kid comment ids, id keyspace of ks bits. ---- */
 PTX_HD uint64_t ptx_a16(uint64_t x) { return (x + 15) & ~15ull; }
 /* bytes that do not fit the recycled region when arrays of the given sizes are placed first-fit in order */
 PTX_HD uint64_t ptx_overflow3(uint64_t free_bytes, uint64_t s0, uint64_t s1, uint64_t s2) {
@@ -493,7 +493,7 @@ PTX_HD uint64_t ptx_overflow3(uint64_t free_bytes, uint64_t s0, uint64_t s1, uin
     }
     return over;
 }
-PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
+PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) {
     (void)N;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
     const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P5a */
@@ -503,7 +503,7 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     const uint64_t p1 = lists + ptx_a16(4 * (nw + 1));
     const uint64_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
     const uint64_t p3 = lists + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
-    const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kc + 1), 4 * (Kc + 1), 8 * (Kc + 1)) : 0;
+    const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0;
     const uint64_t T4 = PTX_TILE_4, T1 = PTX_TILE_1;
     const uint64_t trees4 = ptx_overflow3(elem, 4 * 4 * 2 * T4, 4 * (T4 + 1), 8 * (T4 / 32 + 2));
     const uint64_t trees1 = n > T4 ? ptx_overflow3(elem, 4 * 2 * T1, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
@@ -523,13 +523,13 @@ PTX_HD uint64_t ptx_lds_need_admission(uint64_t n_changes, uint64_t max_actors) 
 PTX_HD uint64_t ptx_lds_need_hdr(uint64_t N, const ptx_log_hdr& h) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
     const uint64_t ks = ((uint64_t)h.max_counter + 1) * ((uint64_t)(h.max_actor > 4095u ? 4095u : h.max_actor) + 1);
-    return ptx_lds_need(N, h.n_ins, h.n_del, K, h.n_mark[PTX_MARK_COMMENT], ks);
+    return ptx_lds_need(N, h.n_ins, h.n_del, K, h.n_mark[PTX_MARK_COMMENT], ks, h.n_comment_ids);
 }
 
 /* census of one log, sequential (host side: the emulation driver; the device has ptx_census_kernel) */
-static inline void ptx_census_rows(const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type, uint64_t n_rows, ptx_log_hdr* out) {
+static inline void ptx_census_rows(const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type, const uint32_t* payload, uint64_t n_rows, ptx_log_hdr* out) {
     ptx_log_hdr h;
-    h.n_ins = h.n_del = h.max_counter = h.max_actor = 0;
+    h.n_ins = h.n_del = h.max_counter = h.max_actor = h.n_comment_ids = h.reserved = 0;
     h.n_mark[0] = h.n_mark[1] = h.n_mark[2] = h.n_mark[3] = 0;
     for (uint64_t i = 0; i < n_rows; ++i) {
         const uint32_t ctr = (uint32_t)(op_id[i] >> 32), act = (uint32_t)op_id[i];
@@ -537,7 +537,10 @@ static inline void ptx_census_rows(const uint64_t* op_id, const uint8_t* action,
         if (act > h.max_actor) h.max_actor = act;
         if (action[i] == PTX_ACT_INSERT) h.n_ins++;
         else if (action[i] == PTX_ACT_DELETE) h.n_del++;
-        else if ((action[i] == PTX_ACT_ADDMARK || action[i] == PTX_ACT_REMOVEMARK) && mark_type[i] < 4) h.n_mark[mark_type[i]]++;
+        else if ((action[i] == PTX_ACT_ADDMARK || action[i] == PTX_ACT_REMOVEMARK) && mark_type[i] < 4) {
+            h.n_mark[mark_type[i]]++;
+            if (mark_type[i] == PTX_MARK_COMMENT && payload[i] >= h.n_comment_ids) h.n_comment_ids = payload[i] == 0xFFFFFFFFu ? payload[i] : payload[i] + 1u;
+        }
     }
     *out = h;
 }
@@ -957,6 +960,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     const uint32_t D = hd.n_del; /* deletes */
     const uint32_t moff1 = hd.n_mark[0], moff2 = moff1 + hd.n_mark[1], moff3 = moff2 + hd.n_mark[2];
     const uint32_t Kc = hd.n_mark[PTX_MARK_COMMENT];
+    /* comment ids are doc-local ranks over ALL replicas of the document: a log that has seen only some of the comments
+     * still carries the document's ranks, so the per-id tables are sized by the id space, not by the log's comment ops */
+    const uint32_t Kid = Kc ? hd.n_comment_ids : 0u;
     const uint32_t K = moff3 + hd.n_mark[3]; /* mark ops; listed grouped by type: type t owns [moff_t, moff_{t+1}) */
 #define PTX_TYPE_OF(k) (((k) >= moff1 ? 1u : 0u) + ((k) >= moff2 ? 1u : 0u) + ((k) >= moff3 ? 1u : 0u))
     if ((uint64_t)n + D + K > N) {
@@ -969,7 +975,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     ix.max_actor = hd.max_actor;
     ix.na1 = ix.max_actor + 1u;
     const uint32_t kbits = ptx_ceil_log2(K + 1);
-    if (ix.max_actor > 4095u || ix.max_ctr >= (1u << 19) || n > 32766u) { /* keyspace far below 2^31 bits; 2n+1 tour nodes in 16 bits */
+    if (ix.max_actor > 4095u || ix.max_ctr >= (1u << 19) || n > 32766u || Kid > 65535u) { /* keyspace far below 2^31 bits; 2n+1 tour nodes in 16 bits */
         lds_high = bp.high;
         return PTX_ERR_CAPACITY;
     }
@@ -1497,8 +1503,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 mrk_lo[k] = (uint16_t)lo;
                 mrk_hi[k] = (uint16_t)hi;
                 if (k >= moff2 && k < moff3) {
-                    if (pl[u] >= Kc) ptx_raise(H, i[u], 1, PTX_ERR_BAD_OP); /* comment ids must be dense per doc */
-                    cid[k - moff2] = (uint16_t)pl[u];
+                    if (pl[u] >= Kid) ptx_raise(H, i[u], 1, PTX_ERR_BAD_OP); /* beyond the id space the header declares */
+                    cid[k - moff2] = (uint16_t)(pl[u] < Kid ? pl[u] : 0u);
                 }
             }
 #pragma unroll
@@ -1531,12 +1537,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
     /* ---- P5c: comments: per id, presence intervals decided by the last-applied covering op ---- */
     if (Kc > 0) {
-        uint32_t* ccnt = ptx_alloc2<uint32_t>(bd, bp, Kc + 1);
-        uint32_t* ccur = ptx_alloc2<uint32_t>(bd, bp, Kc + 1);
+        uint32_t* ccnt = ptx_alloc2<uint32_t>(bd, bp, Kid + 1);
+        uint32_t* ccur = ptx_alloc2<uint32_t>(bd, bp, Kid + 1);
         uint32_t* cicnt = ccur; /* intervals per id: reuses the scatter cursors once the entries are placed */
         PtxCEntry* cent = ptx_alloc2<PtxCEntry>(bd, bp, Kc + 1);
         PTX_BAIL_CAPACITY();
-        PTX_FOR(c, Kc + 1) {
+        PTX_FOR(c, Kid + 1) {
             ccnt[c] = 0;
             ccur[c] = 0;
         }
@@ -1546,7 +1552,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             if (mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[cid[kc]], 1u);
         }
         PTX_SYNC();
-        ptx_scan_excl<uint32_t, 1, kThreads>(ccnt, Kc + 1, H->scan_tmp, A.div_magic); /* ccnt[c] = first entry of id c, ccnt[Kc] = total */
+        ptx_scan_excl<uint32_t, 1, kThreads>(ccnt, Kid + 1, H->scan_tmp, A.div_magic); /* ccnt[c] = first entry of id c, ccnt[Kid] = total */
         PTX_FOR(kc, Kc) {
             const uint32_t k = moff2 + kc;
             if (mrk_lo[k] < mrk_hi[k]) {
@@ -1561,15 +1567,15 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
         }
         PTX_SYNC();
-        PTX_FOR(c, Kc + 1) {
-            cicnt[c] = c < Kc ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
+        PTX_FOR(c, Kid + 1) {
+            cicnt[c] = c < Kid ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         }
         PTX_SYNC();
-        const uint32_t I = ptx_scan_excl<uint32_t, 1, kThreads>(cicnt, Kc + 1, H->scan_tmp, A.div_magic);
+        const uint32_t I = ptx_scan_excl<uint32_t, 1, kThreads>(cicnt, Kid + 1, H->scan_tmp, A.div_magic);
         PTX_LEADER { H->I = I; }
         {
             uint64_t h1 = 0, h2 = 0;
-            PTX_FOR(c, Kc) {
+            PTX_FOR(c, Kid) {
                 uint32_t row = cicnt[c];
                 ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [&](uint32_t s, uint32_t e) {
                     ptx_cinterval ci;

@@ -118,15 +118,15 @@ __global__ void ptx_append_rows_kernel(PtxAppendCols A, const uint64_t* a_off, c
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
 __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off, const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type,
-                                                          ptx_log_hdr* hdr, uint32_t* shape, int compute, const uint64_t* chg_off, uint32_t max_actors,
+                                                          const uint32_t* payload, ptx_log_hdr* hdr, uint32_t* shape, int compute, const uint64_t* chg_off, uint32_t max_actors,
                                                           uint32_t* need_per_log) {
-    __shared__ uint32_t sh[8];
+    __shared__ uint32_t sh[9];
     const uint32_t log = blockIdx.x;
     const uint64_t b0 = log_off[log], b1 = log_off[log + 1];
     if (compute) {
-        if (threadIdx.x < 8) sh[threadIdx.x] = 0;
+        if (threadIdx.x < 9) sh[threadIdx.x] = 0;
         __syncthreads();
-        uint32_t c[6] = {0, 0, 0, 0, 0, 0}, mc = 0, ma = 0;
+        uint32_t c[6] = {0, 0, 0, 0, 0, 0}, mc = 0, ma = 0, mid = 0;
         for (uint64_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) {
             const uint64_t id = op_id[i];
             const uint32_t a = action[i], mt = mark_type[i];
@@ -139,6 +139,10 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
             c[3] += mk && mt == 1;
             c[4] += mk && mt == 2;
             c[5] += mk && mt == 3;
+            if (mk && mt == PTX_MARK_COMMENT) { /* the document's comment-id space as this log has seen it */
+                const uint32_t pl = payload[i];
+                mid = max(mid, pl == 0xFFFFFFFFu ? pl : pl + 1u);
+            }
         }
         for (int k = 0; k < 6; ++k) {
             uint32_t v = c[k];
@@ -148,10 +152,12 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
         for (int d = 32; d >= 1; d >>= 1) {
             mc = max(mc, (uint32_t)__shfl_xor((int)mc, d, 64));
             ma = max(ma, (uint32_t)__shfl_xor((int)ma, d, 64));
+            mid = max(mid, (uint32_t)__shfl_xor((int)mid, d, 64));
         }
         if ((threadIdx.x & 63) == 0) {
             atomicMax(&sh[6], mc);
             atomicMax(&sh[7], ma);
+            atomicMax(&sh[8], mid);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -164,6 +170,8 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
             h.n_mark[3] = sh[5];
             h.max_counter = sh[6];
             h.max_actor = sh[7];
+            h.n_comment_ids = sh[8];
+            h.reserved = 0;
             hdr[log] = h;
         }
     }
@@ -299,7 +307,7 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
         hipError_t e = hipMalloc((void**)&d_need, (size_t)b->n_logs * 4);
         if (e == hipSuccess) e = hipMemsetAsync(shape, 0, 8, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(ptx_census_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->log_off, b->op_id, b->action, b->mark_type, b->log_hdr,
+            hipLaunchKernelGGL(ptx_census_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->log_off, b->op_id, b->action, b->mark_type, b->payload, b->log_hdr,
                                shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors, d_need);
             e = hipGetLastError();
         }
@@ -425,7 +433,7 @@ uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx) {
     uint32_t lo = 0, hi = 65534;
     while (lo < hi) {
         const uint32_t mid = (lo + hi + 1) / 2;
-        const uint64_t worst = std::max(ptx_lds_need(mid, mid, 0, 0, 0, 4ull * mid), ptx_lds_need(mid, mid / 3, mid / 3, mid / 3, mid / 3, 4ull * mid));
+        const uint64_t worst = std::max(ptx_lds_need(mid, mid, 0, 0, 0, 4ull * mid, 0), ptx_lds_need(mid, mid / 3, mid / 3, mid / 3, mid / 3, 4ull * mid, mid / 3));
         if (worst <= lds) lo = mid;
         else hi = mid - 1;
     }

@@ -61,18 +61,18 @@ struct PtxReplayHdr {
     uint32_t scan_tmp[36];
 };
 
-PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks) {
+PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) {
     const uint64_t nw = (ks + 31) / 32, nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
     const uint64_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
     return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(8 * nwe) + 2 * ptx_a16(4 * nws) +
            ptx_a16(4 * (nws + 1)) + 3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * segcap) + ptx_a16(8 * ((segcap >> 5) + 2)) + 3 * ptx_a16(4 * nws) +
            ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
-           6 * ptx_a16(2 * (Kc + 1)) + ptx_a16(Kc + 1);
+           5 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
 }
 PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
     const uint64_t ks = ((uint64_t)h.max_counter + 1) * ((uint64_t)(h.max_actor > 4095u ? 4095u : h.max_actor) + 1);
-    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], ks);
+    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], ks, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u);
 }
 
 /* one patch record; rows past the capacity are counted, not written */
@@ -116,6 +116,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     }
     const ptx_log_hdr hd = A.log_hdr[log];
     const uint32_t n = hd.n_ins, Kc = hd.n_mark[PTX_MARK_COMMENT];
+    const uint32_t Kid = Kc ? hd.n_comment_ids : 0u; /* id space of the document's comments as this log has seen it */
     const uint32_t K = hd.n_mark[0] + hd.n_mark[1] + hd.n_mark[2] + hd.n_mark[3];
     PtxElemIndex ix;
     ix.max_ctr = hd.max_counter;
@@ -159,9 +160,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint16_t* ccid = ptx_alloc<uint16_t>(bp, Kc + 1);
     uint16_t* cprev = ptx_alloc<uint16_t>(bp, Kc + 1);    /* chain of the ops with the same id, application order */
     uint16_t* cnext = ptx_alloc<uint16_t>(bp, Kc + 1);
-    uint16_t* ctail = ptx_alloc<uint16_t>(bp, Kc + 1);    /* per id: last registered op */
+    uint16_t* ctail = ptx_alloc<uint16_t>(bp, Kid + 1);   /* per id: last registered op */
     uint8_t* cadd = ptx_alloc<uint8_t>(bp, Kc + 1);
-    if (bp.overflow || ix.max_actor > 4095u || n > 32766u || N > 65534u) {
+    if (bp.overflow || ix.max_actor > 4095u || n > 32766u || N > 65534u || Kid > 65535u) {
         PTX_LEADER {
             ptx_patch_log pl;
             pl.status = PTX_ERR_CAPACITY;
@@ -191,7 +192,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         won[1][w] = 0;
         won[2][w] = 0;
     }
-    PTX_FOR(c, Kc + 1) ctail[c] = PTX_SLOT_NONE;
+    PTX_FOR(c, Kid + 1) ctail[c] = PTX_SLOT_NONE;
     PTX_LEADER {
         H->npatch = 0;
         H->ncom = 0;
@@ -439,7 +440,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 } else {
                     /* the last-applied covering op with this id (this op is not registered yet) */
                     int state = -1; /* -1 none, 0 removed, 1 present */
-                    for (uint32_t y = my_id < Kc ? ctail[my_id] : PTX_SLOT_NONE; y != PTX_SLOT_NONE; y = cprev[y])
+                    for (uint32_t y = my_id < Kid ? ctail[my_id] : PTX_SLOT_NONE; y != PTX_SLOT_NONE; y = cprev[y])
                         if (ca[y] <= s && s < cb[y]) {
                             state = cadd[y] ? 1 : 0;
                             break;
@@ -473,7 +474,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             PTX_SYNC();
             PTX_LEADER {
                 H->npatch = p0 + P;
-                if (ty == PTX_MARK_COMMENT && my_id < Kc && nc < Kc) {
+                if (ty == PTX_MARK_COMMENT && my_id < Kid && nc < Kc) {
                     ca[nc] = (uint16_t)slot_a;
                     cb[nc] = (uint16_t)slot_b;
                     ccid[nc] = (uint16_t)my_id;

@@ -216,9 +216,9 @@ napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
             return throw_msg(env, msg);
         }
     }
-    /* optional: per-log census (8 u32 per log) — otherwise the library computes it on the device */
+    /* optional: per-log census (sizeof(ptx_log_hdr) / 4 = 10 u32 per log) — otherwise the library computes it on the device */
     if (column(env, b, "logHdr", 4, &p, &m, true) && p) {
-        if (m != (size_t)pb.n_logs * 8) return throw_msg(env, "batch.logHdr: Uint32Array with 8 entries per log expected");
+        if (m != (size_t)pb.n_logs * (sizeof(ptx_log_hdr) / 4)) return throw_msg(env, "batch.logHdr: Uint32Array with 10 entries per log expected");
         pb.log_hdr = (const ptx_log_hdr*)p;
     }
     /* optional: the Change envelope -> causal admission on the device (all five columns + maxActors, or none) */
@@ -402,7 +402,7 @@ napi_value Generate(napi_env env, napi_callback_info info) {
         {"logOff", napi_biguint64_array, 8, b.log_off, Lg + 1}, {"opId", napi_biguint64_array, 8, b.op_id, T}, {"refA", napi_biguint64_array, 8, b.ref_a, T},
         {"refB", napi_biguint64_array, 8, b.ref_b, T}, {"payload", napi_uint32_array, 4, b.payload, T}, {"action", napi_uint8_array, 1, b.action, T},
         {"markType", napi_uint8_array, 1, b.mark_type, T}, {"sideA", napi_uint8_array, 1, b.side_a, T}, {"sideB", napi_uint8_array, 1, b.side_b, T},
-        {"logHdr", napi_uint32_array, 4, b.log_hdr, Lg * 8}, {"chgOff", napi_biguint64_array, 8, b.chg_off, Lg + 1}, {"chgActor", napi_uint32_array, 4, b.chg_actor, NC},
+        {"logHdr", napi_uint32_array, 4, b.log_hdr, Lg * (sizeof(ptx_log_hdr) / 4)}, {"chgOff", napi_biguint64_array, 8, b.chg_off, Lg + 1}, {"chgActor", napi_uint32_array, 4, b.chg_actor, NC},
         {"chgSeq", napi_uint32_array, 4, b.chg_seq, NC}, {"chgNops", napi_uint32_array, 4, b.chg_nops, NC}, {"chgDeps", napi_uint32_array, 4, b.chg_deps, NC * b.max_actors},
     };
     for (auto& col : cols) {

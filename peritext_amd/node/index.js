@@ -157,17 +157,22 @@ function encodeDocs(docs) {
     return batch
 }
 
-/** ptx_log_hdr rows (8 u32 per log: n_ins, n_del, n_mark[4], max_counter, max_actor) — what the encoder knows for free. */
+/** ptx_log_hdr rows (LOG_HDR_WORDS u32 per log: n_ins, n_del, n_mark[4], max_counter, max_actor, n_comment_ids, reserved) — what the
+ *  encoder knows for free.  n_comment_ids = largest doc-local comment id the log uses + 1 (ids are ranks over the whole document). */
+const LOG_HDR_WORDS = 10
 function census(batch) {
-    const hdr = new Uint32Array(batch.nLogs * 8)
+    const hdr = new Uint32Array(batch.nLogs * LOG_HDR_WORDS)
     for (let l = 0; l < batch.nLogs; l++) {
         const b0 = Number(batch.logOff[l]), b1 = Number(batch.logOff[l + 1])
-        const h = hdr.subarray(l * 8, l * 8 + 8)
+        const h = hdr.subarray(l * LOG_HDR_WORDS, (l + 1) * LOG_HDR_WORDS)
         for (let i = b0; i < b1; i++) {
             const a = batch.action[i]
             if (a === ACT.INSERT) h[0]++
             else if (a === ACT.DELETE) h[1]++
-            else if ((a === ACT.ADDMARK || a === ACT.REMOVEMARK) && batch.markType[i] < 4) h[2 + batch.markType[i]]++
+            else if ((a === ACT.ADDMARK || a === ACT.REMOVEMARK) && batch.markType[i] < 4) {
+                h[2 + batch.markType[i]]++
+                if (batch.markType[i] === 2 && batch.payload[i] + 1 > h[8]) h[8] = batch.payload[i] + 1
+            }
             const ctr = Number(batch.opId[i] >> 32n), act = Number(batch.opId[i] & 0xffffffffn)
             if (ctr > h[6]) h[6] = ctr
             if (act > h[7]) h[7] = act

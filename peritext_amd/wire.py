@@ -98,7 +98,7 @@ class Batch:
         )
 
 
-def census(log_off, op_id, action, mark_type):
+def census(log_off, op_id, action, mark_type, payload=None):
     """ptx_log_hdr rows (abi.LOG_HDR_DTYPE) of a batch: what the encoder knows for free about every log."""
     n_logs = len(log_off) - 1
     hdr = np.zeros(n_logs, dtype=abi.LOG_HDR_DTYPE)
@@ -117,6 +117,12 @@ def census(log_off, op_id, action, mark_type):
     np.maximum.at(ma, lix, (op_id & np.uint64(0xFFFFFFFF)).astype(np.uint32))
     hdr["max_counter"] = mc
     hdr["max_actor"] = ma
+    if payload is not None:
+        # comment ids are ranks over the whole document: a log's id space = its largest comment payload + 1
+        is_c = is_mark & (mark_type == abi.MARK_COMMENT)
+        nid = np.zeros(n_logs, dtype=np.uint32)
+        np.maximum.at(nid, lix[is_c], payload[is_c].astype(np.uint32) + np.uint32(1))
+        hdr["n_comment_ids"] = nid
     return hdr
 
 
@@ -224,7 +230,8 @@ def encode_docs(docs):
         for a, v in row.items():
             deps[i, a] = v
     u64 = lambda x: np.asarray(x, dtype=np.uint64)  # noqa: E731
-    hdr = census(u64(log_off), u64(cols["op_id"]), np.asarray(cols["action"], dtype=np.uint8), np.asarray(cols["mark_type"], dtype=np.uint8))
+    hdr = census(u64(log_off), u64(cols["op_id"]), np.asarray(cols["action"], dtype=np.uint8), np.asarray(cols["mark_type"], dtype=np.uint8),
+                 np.asarray(cols["payload"], dtype=np.uint32))
     return Batch(
         log_hdr=hdr,
         log_off=u64(log_off), op_id=u64(cols["op_id"]), ref_a=u64(cols["ref_a"]), ref_b=u64(cols["ref_b"]),

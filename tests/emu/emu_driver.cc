@@ -64,7 +64,7 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
         hdr = (ptx_log_hdr*)calloc(b->n_logs ? b->n_logs : 1, sizeof(ptx_log_hdr));
         for (uint32_t l = 0; l < b->n_logs; ++l) {
             const uint64_t b0 = b->log_off[l], b1 = b->log_off[l + 1];
-            ptx_census_rows(b->op_id + b0, b->action + b0, b->mark_type + b0, b1 - b0, &hdr[l]);
+            ptx_census_rows(b->op_id + b0, b->action + b0, b->mark_type + b0, b->payload + b0, b1 - b0, &hdr[l]);
         }
         A.log_hdr = hdr;
     }
@@ -81,8 +81,8 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
 }
 
 /* LDS bound the host uses to size the launch (tests check it against the measured high-water mark) */
-extern "C" uint64_t ptx_emu_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks) {
-    return ptx_lds_need(N, n, D, K, Kc, ks);
+extern "C" uint64_t ptx_emu_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) {
+    return ptx_lds_need(N, n, D, K, Kc, ks, Kid);
 }
 
 /* patch-stream replay (replay_core.h) over the merge results `res` / `rank` of the same batch; patch_off = capacity
@@ -113,7 +113,7 @@ extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, con
         hdr = (ptx_log_hdr*)calloc(b->n_logs ? b->n_logs : 1, sizeof(ptx_log_hdr));
         for (uint32_t l = 0; l < b->n_logs; ++l) {
             const uint64_t b0 = b->log_off[l], b1 = b->log_off[l + 1];
-            ptx_census_rows(b->op_id + b0, b->action + b0, b->mark_type + b0, b1 - b0, &hdr[l]);
+            ptx_census_rows(b->op_id + b0, b->action + b0, b->mark_type + b0, b->payload + b0, b1 - b0, &hdr[l]);
         }
         A.log_hdr = hdr;
     }
@@ -128,7 +128,7 @@ extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, con
     free(hdr);
     return 0;
 }
-extern "C" uint64_t ptx_emu_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks) { return ptx_replay_lds_need(n, K, Kc, ks); }
+extern "C" uint64_t ptx_emu_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) { return ptx_replay_lds_need(n, K, Kc, ks, Kid); }
 
 /* on-device change() / PTXGEN (gen_core.h): generate n_docs documents into caller-allocated capacity-layout columns
  * (rows_per_log rows per log, R logs per doc); the envelope is left at capacity stride, n_changes says how much is used */

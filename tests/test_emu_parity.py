@@ -114,6 +114,61 @@ def test_edge_cases_against_oracle():
     assert expected[5][0]["spans"] == [] and expected[6][0]["spans"] == []
 
 
+def _unsynced_docs():
+    """Replicas that have NOT seen the same changes: every prefix of a replica log is itself a valid log.  The comment ids of
+    a document are ranked over all its replicas, so such a log uses ranks beyond its own number of comment ops."""
+    gen = _load("ptxgen_mini.json")
+    docs = []
+    for d in gen["docs"][:6]:
+        logs = []
+        for k, log in enumerate(d["logs"]):
+            for frac in (3, 2):
+                logs.append(log[: max(1, len(log) * (k + 1) // (frac * len(d["logs"])))])
+        logs.append(d["logs"][0])
+        docs.append(logs)
+    # two replicas that each know ONE comment the other has not seen
+    el = lambda i: "%d@a" % (i + 2)  # noqa: E731
+    base = _mini_doc([])
+    ca = {"actor": "b", "seq": 1, "deps": {"a": 2}, "startOp": 8, "ops": [{"opId": "8@b", "obj": "1@a", "action": "addMark", "markType": "comment", "attrs": {"id": "A"},
+                                                                             "start": {"type": "before", "elemId": el(0)}, "end": {"type": "after", "elemId": el(2)}}]}
+    cb = {"actor": "c", "seq": 1, "deps": {"a": 2}, "startOp": 8, "ops": [{"opId": "8@c", "obj": "1@a", "action": "addMark", "markType": "comment", "attrs": {"id": "B"},
+                                                                             "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(4)}}]}
+    docs.append([base + [ca], base + [cb], base + [ca, cb], base + [cb, ca]])
+    return docs
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_unsynced_replicas_with_different_comment_sets():
+    """a replica that has seen only SOME of the document's comments still carries the document's comment
+    ranks; its log must merge (the per-id tables are sized by the header's n_comment_ids, not by its comment-op count)."""
+    docs = _unsynced_docs()
+    expected = H.oracle_apply(docs)
+    batch = wire.encode_docs(docs)
+    kc = batch.log_hdr["n_mark"][:, abi.MARK_COMMENT]
+    assert (batch.log_hdr["n_comment_ids"] > kc).any(), "the fixture must contain logs whose id space exceeds their comment ops"
+    for admission in (False, True):
+        res = H.emu_merge(batch, admission=admission)
+        log = 0
+        for exp in expected:
+            for e in exp:
+                H.check_log(batch, res, log, e)
+                log += 1
+    pat = H.emu_replay(batch, res)
+    H.check_patch_streams(batch, pat, H.oracle_apply(docs, patches=True))
+    # without a header the library's census finds the same id space
+    hdr = batch.log_hdr
+    batch.log_hdr = None
+    res2 = H.emu_merge(batch)
+    assert (res2.logs["digest"] == res.logs["digest"]).all() and (res2.logs["status"] == 0).all()
+    # a header that understates the id space is rejected, never silently wrong
+    bad = hdr.copy()
+    l = int(np.flatnonzero(hdr["n_comment_ids"] > 1)[0])
+    bad["n_comment_ids"][l] -= 1
+    batch.log_hdr = bad
+    res3 = H.emu_merge(batch)
+    assert int(res3.logs["status"][l]) == abi.ERR_BAD_OP and (np.delete(res3.logs["status"], l) == 0).all()
+
+
 def test_error_statuses_mirror_reference_throw_sites():
     """Unknown insert parent / delete target -> PTX_ERR_ELEM_NOT_FOUND (RangeError 'List element not
     found', micromerge.ts:752), also when the element only appears LATER in the log."""
@@ -348,13 +403,13 @@ def test_lds_bound_covers_the_high_water_mark(name):
 
     lib = H._emu(H.EMU_LIB)
     lib.ptx_emu_lds_need.restype = C.c_uint64
-    lib.ptx_emu_lds_need.argtypes = [C.c_uint64] * 6
+    lib.ptx_emu_lds_need.argtypes = [C.c_uint64] * 7
     gen = _load(name)
     batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
     res = H.emu_merge(batch)
     for log in range(batch.n_logs):
         h = batch.log_hdr[log]
         need = lib.ptx_emu_lds_need(int(batch.log_off[log + 1] - batch.log_off[log]), int(h["n_ins"]), int(h["n_del"]), int(h["n_mark"].sum()),
-                                    int(h["n_mark"][2]), (int(h["max_counter"]) + 1) * (int(h["max_actor"]) + 1))
+                                    int(h["n_mark"][2]), (int(h["max_counter"]) + 1) * (int(h["max_actor"]) + 1), int(h["n_comment_ids"]))
         used = int(res.logs["reserved"][log][0])
         assert used <= need <= used + 6144, (log, used, need)  # slack = the LWW trees sized for V = n

@@ -151,10 +151,10 @@ def test_replay_lds_bound():
     import ctypes as C
     lib = C.CDLL(H.EMU_LIB)
     lib.ptx_emu_replay_lds_need.restype = C.c_uint64
-    lib.ptx_emu_replay_lds_need.argtypes = [C.c_uint64] * 4
+    lib.ptx_emu_replay_lds_need.argtypes = [C.c_uint64] * 5
     # a config-4 log (1250 inserts, 1600 marks, 400 comment ops, 8.7 k ids) replays within a quarter of the LDS of a CU
-    assert lib.ptx_emu_replay_lds_need(1250, 1600, 400, 8736) < 40 * 1024
-    assert lib.ptx_emu_replay_lds_need(0, 0, 0, 0) < 2048
+    assert lib.ptx_emu_replay_lds_need(1250, 1600, 400, 8736, 400) < 40 * 1024
+    assert lib.ptx_emu_replay_lds_need(0, 0, 0, 0, 0) < 2048
 
 
 def test_patch_streams_random_workloads():
