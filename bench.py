@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — whole-node throughput of the Peritext hot path on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one resident batch: apply every replica op log of the batch and
-materialise its formatted document (ptx_merge = ONE launch of ptx_merge_kernel), pack the per-replica
-digests, (N>1: RCCL all-gather of the digests over xGMI), count converged documents on the device.
-The op columns are resident in HBM before the timed region starts (PCIe upload is reported separately).
+A "step" = one pass of the hot path over one resident batch: apply every replica op log of the batch (causal admission of
+every Change included, micromerge.ts:499-511) and materialise its formatted document (ptx_merge = ONE launch of
+ptx_merge_kernel), then count the converged documents on the device (N>1: after the all-gather of the per-replica digests
+over RCCL/xGMI — the only collective on the path).  The op columns are resident in HBM before the timed region starts.
 
-Workload (config.workload): BASELINE config #4 — 64K docs x 3 replicas x 4096 ops sharded over 8 GPUs =
-8192 docs x 3 replicas per GPU ("weak" scaling: per-GPU work is fixed, N GPUs process N x 8192 docs).
-The batch is PTXGEN documents (SURVEY.md §8d generator = the workload of reference/test/fuzz.ts, seeded), by default
-GENERATED ON THE DEVICE (ptx_generate: on-device change(), every document of every rank distinct; change for change
-the documents oracle/ptxgen.js makes — rank 0 re-checks one against the oracle in every run).  --oracle-gen takes
-`--unique` documents from the oracle's own change() on the host instead and tiles them to 8192 docs in HBM.
+Workload (config.workload): BASELINE config #4 — 65 536 docs x 3 replicas x 4 096 ops, PTXGEN documents (the
+workload of reference/test/fuzz.ts, seeded) GENERATED ON THE DEVICE (ptx_generate: on-device change(), every document
+distinct).  `--gpus N` shards the 65 536 documents over N ranks in contiguous blocks ("strong" scaling: the total work is
+fixed, rank r owns documents [r*65536/N, (r+1)*65536/N)); at N=1 the whole 64K-doc batch (25.8 GB of op log) is on one GPU.
+`--docs-per-gpu D` fixes the per-rank share instead (the 8 192-doc shard of round 1 = --docs-per-gpu 8192).
 
-One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes of one launch
-(32 B per op row + 32 B header per log + the Change envelope when causal admission is on, read; 4 B per visible value + 8 B per span + 12 B per comment interval + 48 B result
-row per log written) / the kernel's average launch duration measured with HIP events on the stream
-the kernel runs on.  `cpu_baseline` = the reference's own code (oracle/_ref, types erased) or, where
-that is absent, the oracle port, timed on this box's host cores on a bounded sample of the same logs.
+One JSON line on stdout (rank 0):
+  roofline.achieved = SURVEY.md §8(d) algorithmic bytes of one launch, B_alg = sum over logs of 32*N + 4*V + 8*S + 16*T + 16
+      (N rows of the log, V visible values, S span rows, T = comment-interval rows — what this ABI writes in place of a
+      mark-state table — and the 128-bit digest), divided by the kernel's average launch duration measured with HIP events on
+      the stream the kernel runs on.  The Change envelope that causal admission reads on top is NOT in B_alg; the figure
+      that includes it is reported separately (roofline.with_envelope).
+  roofline.traffic  = HBM bytes per launch from the PMC counters of the same command (profiles/r02_hbm_traffic.json, made by
+      tools/pmc_traffic.sh on the GPU box: separate --pmc passes for FETCH_SIZE / WRITE_SIZE, calibrated as
+      MI355X_MICROARCH.md prescribes); null when that file does not describe this workload.
+  parity            = --check-docs random documents of the RESIDENT batch checked against the reference's own code run on the
+      host cores (decoded spans, raw rows, digests); the same host run is the cpu_baseline (whole logs, no truncation).
 """
 import argparse
 import json
@@ -33,107 +38,97 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK = 8.0e12  # B/s, MI355X spec (guide: 6.29e12 measured copy ceiling)
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md; 6.29e12 measured copy ceiling)
 HBM_COPY_CEILING = 6.29e12
+OPS = {"config4": 4096, "config3": 1024, "config2": 256, "config5": 8192, "rich": 1024, "mini": 96}
 
 
-def gen_unique_docs(config, n_docs, seed, ops=None, procs=None):
-    """PTXGEN documents from the oracle CLI, `procs` node processes in parallel; returns list of doc dicts."""
+def reference_run(docs_logs, procs):
+    """Apply every replica log of `docs_logs` ([doc][replica] -> Change[]) with the reference's own code (oracle/_ref, types
+    erased; the restated oracle where that is absent) on the host cores: one node process per core, whole logs.
+    Returns (expected [doc][replica] -> {spans, text}, cpu_baseline dict)."""
     node = shutil.which("node")
     if node is None:
-        raise RuntimeError("bench.py needs node (the oracle/generator runtime) on this box")
-    procs = max(1, min(procs or (os.cpu_count() or 8), n_docs, 64))
-    td = tempfile.mkdtemp(prefix="ptxbench_")
-    per = (n_docs + procs - 1) // procs
-    jobs = []
-    for p in range(procs):
-        first = p * per
-        cnt = min(per, n_docs - first)
-        if cnt <= 0:
-            break
-        out = os.path.join(td, "g%d.json" % p)
-        cmd = [node, os.path.join(ROOT, "oracle", "cli.js"), "gen", "--config", config, "--docs", str(cnt), "--first", str(first), "--seed", str(seed), "--out", out]
-        if ops:
-            cmd += ["--ops", str(ops)]
-        jobs.append((subprocess.Popen(cmd, cwd=ROOT), out))
-    docs = []
-    for pr, out in jobs:
-        if pr.wait() != 0:
-            raise RuntimeError("oracle generator failed")
-        with open(out) as f:
-            docs += json.load(f)["docs"]
-    shutil.rmtree(td, ignore_errors=True)
-    return docs
-
-
-def cpu_baseline(docs, budget_s, procs):
-    """Time the reference's CPU path (applyChange over the whole log + getTextWithFormatting) on a sample:
-    one node process per core, each on its own documents, each stopping after `budget_s`."""
-    node = shutil.which("node")
+        raise RuntimeError("bench.py needs node (the oracle runtime) on this box for the parity guard and the CPU baseline")
     impl = "ref" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "micromerge.js")) else "oracle"
-    procs = max(1, min(procs, len(docs)))
-    td = tempfile.mkdtemp(prefix="ptxcpu_")
+    flat = [(d, r) for d in range(len(docs_logs)) for r in range(len(docs_logs[d]))]
+    procs = max(1, min(procs, len(flat)))
+    td = tempfile.mkdtemp(prefix="ptxref_")
     jobs = []
-    for p in range(procs):
-        mine = docs[p::procs]
-        inp = os.path.join(td, "in%d.json" % p)
-        with open(inp, "w") as f:
-            json.dump({"docs": [{"logs": d["logs"]} for d in mine]}, f)
-        cmd = [node, os.path.join(ROOT, "oracle", "cli.js"), "time", "--in", inp, "--impl", impl, "--budget-ms", str(int(budget_s * 1000))]
-        jobs.append(subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True))
     t0 = time.time()
-    rows = []
-    for pr in jobs:
-        out, _ = pr.communicate()
-        rows.append(json.loads(out.strip().splitlines()[-1]))
+    for p in range(procs):
+        mine = flat[p::procs]
+        inp, out = os.path.join(td, "in%d.json" % p), os.path.join(td, "out%d.json" % p)
+        with open(inp, "w") as f:
+            json.dump({"docs": [{"logs": [docs_logs[d][r]]} for d, r in mine]}, f)
+        cmd = [node, os.path.join(ROOT, "oracle", "cli.js"), "apply", "--in", inp, "--impl", impl, "--timing", "--out", out]
+        jobs.append((subprocess.Popen(cmd, cwd=ROOT), mine, out))
+    expected = [[None] * len(logs) for logs in docs_logs]
+    rates, ops, secs = [], 0, 0.0
+    for pr, mine, out in jobs:
+        if pr.wait() != 0:
+            raise RuntimeError("reference run failed")
+        with open(out) as f:
+            o = json.load(f)
+        for (d, r), e in zip(mine, o["docs"]):
+            expected[d][r] = e["expected"][0]
+        t = o["timing"]
+        ops += t["ops"]
+        secs += t["seconds"]
+        if t["seconds"] > 0:
+            rates.append(t["ops"] / t["seconds"])
     wall = time.time() - t0
     shutil.rmtree(td, ignore_errors=True)
-    ops = sum(r["ops"] for r in rows)
-    logs = sum(r["logs"] for r in rows)
-    cut = sum(r.get("truncated_logs", 0) for r in rows)
-    per_core = [r["ops_per_s"] for r in rows if r["seconds"] > 0]
-    return {
-        "value": float(sum(per_core)),
+    cpu = {
+        "value": float(sum(rates)),
         "unit": "ops/s",
-        "cores": len(rows),
+        "cores": procs,
         "kind": "reference" if impl == "ref" else "port",
-        "per_core_ops_per_s": float(np.mean(per_core)) if per_core else 0.0,
-        "sample": "%d whole + %d deadline-truncated replica logs (%d ops) of the same PTXGEN documents, applyChange over every change + "
-        "getTextWithFormatting, one node process per core, %.0f s budget each, %.1f s wall; per-op cost grows along a log, so truncated "
-        "logs OVERSTATE the CPU rate" % (logs, cut, ops, budget_s, wall),
+        "per_core_ops_per_s": float(np.mean(rates)) if rates else 0.0,
+        "sample": "%d whole replica logs (%d ops) of %d documents drawn at random from the resident batch: applyChange over every change + "
+                  "getTextWithFormatting, one node process per core, %.1f s wall (%.1f core-seconds)" % (len(flat), ops, len(docs_logs), wall, secs),
     }
+    return expected, cpu
+
+
+def load_traffic(n_logs, rows):
+    """PMC-measured HBM bytes per launch of this command, if profiles/ holds them for this very workload."""
+    p = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        t = json.load(f)
+    if t.get("n_logs") != n_logs or t.get("rows") != rows:
+        return None
+    return t
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="config4")
-    ap.add_argument("--docs-per-gpu", type=int, default=8192)
-    ap.add_argument("--unique", type=int, default=64, help="unique PTXGEN documents per GPU (tiled to --docs-per-gpu)")
+    ap.add_argument("--docs", type=int, default=65536, help="documents of the whole job (sharded over --gpus ranks)")
+    ap.add_argument("--docs-per-gpu", type=int, default=0, help="fix the per-rank share instead (weak scaling), e.g. 8192 = the config-#4 shard of one of 8 GPUs")
     ap.add_argument("--ops", type=int, default=None, help="override ops per log (debug only; makes the number non-BASELINE)")
     ap.add_argument("--seed", type=int, default=2024)
-    ap.add_argument("--cpu-budget-s", type=float, default=30.0)
-    ap.add_argument("--cpu-procs", type=int, default=16)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--check-docs", type=int, default=64, help="random documents of the resident batch checked against the reference on the host")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="host processes of the reference run (0 = one per core)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the reference run: no parity guard against the oracle, no cpu_baseline")
     ap.add_argument("--no-admission", action="store_true", help="skip applyChange's causal admission (seq/deps) in the timed path")
-    ap.add_argument("--oracle-gen", action="store_true", help="take the op logs from the oracle's generator on the host (--unique documents per GPU, "
-                    "tiled in HBM) instead of generating them on the GPU (ptx_generate: on-device change(), every document distinct; the default)")
-    ap.add_argument("--fused-step", action="store_true", help="EXPERIMENTAL (not yet measured): run the engine on a torch stream and count the converged "
-                    "documents with one library kernel, so that a step has no host-side synchronisation")
-    ap.add_argument("--list-cap", type=int, default=2048, help="--device-gen: list elements per replica held on chip")
+    ap.add_argument("--sustain-s", type=float, default=5.0, help="extra leg: back-to-back steps for at least this many seconds (clocks / thermals)")
+    ap.add_argument("--host-sync-step", action="store_true", help="the round-1 step: engine on its own stream, a host-side sync between merge and digest check")
+    ap.add_argument("--list-cap", type=int, default=2048, help="list elements per replica the generator holds on chip")
     args = ap.parse_args()
-    args.device_gen = not args.oracle_gen
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
     torch.cuda.set_device(local)
     dist = None
@@ -142,192 +137,200 @@ def main():
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
 
-    from peritext_amd import abi, shard, wire
+    from peritext_amd import abi, shard, wire, workloads
     from peritext_amd.engine import Engine
 
     cores = os.cpu_count() or 8
-    eng = Engine(local, flags=abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0))
-    gen_info = None
-    if args.device_gen:
-        # ---- workload made on the device: on-device change() (ptx_generate), every document of every rank distinct ----
-        from peritext_amd import workloads
-
-        gcfg = workloads.gen_config(args.config, ops=args.ops)
-        gen_args = (gcfg["replicas"], gcfg["ops_per_log"], gcfg["mix"], gcfg["mark_types"])
-        t_gen = time.time()
-        db, gen_info = eng.generate(*gen_args, args.docs_per_gpu, args.seed, first_doc=rank * args.docs_per_gpu, list_cap=args.list_cap)
-        t_gen = time.time() - t_gen
-        t_up, copies, replicas = 0.0, 1, gcfg["replicas"]
-        n_logs = eng.n_logs(db)
-        ops_per_step = n_logs * gcfg["ops_per_log"]
-        n_changes_rank = eng.n_changes(db)
-        max_actors = replicas
-        # a few documents of the same stream on the host, for the oracle check and the CPU baseline leg
-        docs = []
-        if rank == 0:
-            n_host = min(args.cpu_procs, args.docs_per_gpu)
-            hb, hinfo = eng.generate(*gen_args, n_host, args.seed, first_doc=rank * args.docs_per_gpu, list_cap=args.list_cap)
-            actors_t, comments_t, log_doc_t = wire.generated_tables(n_host, replicas, hinfo["n_comments"])
-            host_batch = eng.download_batch(hb, wire.GEN_VALUES, wire.GEN_URLS, log_doc_t, actors_t, comments_t)
-            eng.free_batch(hb)
-            docs = [{"logs": [wire.decode_changes(host_batch, d * replicas + r) for r in range(replicas)]} for d in range(n_host)]
+    weak = args.docs_per_gpu > 0
+    if weak:
+        first_doc, n_docs = rank * args.docs_per_gpu, args.docs_per_gpu
+        total_docs = args.docs_per_gpu * world
     else:
-        # ---- workload: unique documents of this rank, tiled in HBM ----
-        assert args.docs_per_gpu % args.unique == 0, "--docs-per-gpu must be a multiple of --unique"
-        copies = args.docs_per_gpu // args.unique
-        t_gen = time.time()
-        docs = gen_unique_docs(args.config, args.unique, args.seed + 7919 * rank, ops=args.ops, procs=max(1, cores // max(world, 1)))
-        t_gen = time.time() - t_gen
-        replicas = len(docs[0]["logs"])
-        batch = wire.encode_docs([d["logs"] for d in docs])
-        ops_unique = batch.counted_ops()
-        t_up = time.time()
-        db = eng.upload(batch, copies=copies)
-        eng.sync()
-        t_up = time.time() - t_up
-        n_logs = eng.n_logs(db)
-        ops_per_step = ops_unique * copies  # counted ops (makeList rows excluded), this rank
-        n_changes_rank = int(batch.chg_off[-1]) * copies
-        max_actors = batch.max_actors
-    dr = eng.alloc_result(db)
-    n_docs = n_logs // replicas
-    digests = torch.empty((n_logs, 2), dtype=torch.int64, device="cuda")
-    gathered = torch.empty((world * n_logs, 2), dtype=torch.int64, device="cuda") if world > 1 else None
-    conv = torch.zeros((), dtype=torch.int64, device="cuda")
+        first_doc, n_docs = shard.doc_range(args.docs, rank, world)
+        total_docs = args.docs
+    eng = Engine(local, flags=abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0))
+    gcfg = workloads.gen_config(args.config, ops=args.ops)
+    gen_args = (gcfg["replicas"], gcfg["ops_per_log"], gcfg["mix"], gcfg["mark_types"])
+    replicas = gcfg["replicas"]
 
-    fused_stream = None
-    fused_events = []
-    if args.fused_step:
-        # experimental: everything of a step on ONE stream (torch's), no host sync inside the step; the kernel's duration comes
-        # from torch events around the launch, which now see the stream the kernel runs on
-        fused_stream = torch.cuda.Stream()
-        eng.set_stream(fused_stream.cuda_stream)
-        conv_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+    # ---- the workload, made on the device: on-device change() (ptx_generate), every document of every rank distinct ----
+    t_gen = time.time()
+    db, gen_info = eng.generate(*gen_args, n_docs, args.seed, first_doc=first_doc, list_cap=args.list_cap)
+    t_gen = time.time() - t_gen
+    n_logs = eng.n_logs(db)
+    rows = eng.n_ops(db)
+    ops_per_step = n_logs * gcfg["ops_per_log"]
+    n_changes = eng.n_changes(db)
+    dr = eng.alloc_result(db)
+    digests = torch.empty((n_logs, 2), dtype=torch.int64, device="cuda")
+    counts = [n_logs_r * replicas for n_logs_r in ([shard.doc_range(args.docs, r, world)[1] for r in range(world)] if not weak else [n_docs] * world)]
+    gathered = torch.empty((sum(counts), 2), dtype=torch.int64, device="cuda") if world > 1 else None
+    conv_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+    conv = conv_dev[0]
+
+    stream = None
+    if not args.host_sync_step:
+        # everything of a step on ONE stream (torch's): no host-side synchronisation inside the step
+        stream = torch.cuda.Stream()
+        eng.set_stream(stream.cuda_stream)
+    events = []
 
     def step(timed):
-        """One pass of the hot path.  Returns the kernel's launch duration in ms when `timed`."""
+        """One pass of the hot path.  The kernel's launch duration comes from events on the stream the kernel runs on."""
         nonlocal conv
-        if fused_stream is not None:
-            with torch.cuda.stream(fused_stream):
+        if stream is not None:
+            with torch.cuda.stream(stream):
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(fused_stream)
+                    e0.record(stream)
                 eng.merge(db, dr)
                 if timed:
-                    e1.record(fused_stream)
-                    fused_events.append((e0, e1))
+                    e1.record(stream)
+                    events.append((e0, e1))
                 if world == 1:
                     eng.count_converged(dr, replicas, conv_dev.data_ptr())
                     conv = conv_dev[0]
                 else:
                     eng.pack_digests(dr, 0, n_logs, digests.data_ptr())
-                    conv, _ = shard.global_convergence(digests, replicas, dist, gathered)
+                    conv, _ = shard.global_convergence(digests, replicas, dist, gathered, counts)
             return None
-        ms = None
-        if timed:
-            ms = eng.merge_timed(db, dr, 1)  # HIP events on the engine's stream around the one launch
-        else:
-            eng.merge(db, dr)
+        ms = eng.merge_timed(db, dr, 1) if timed else eng.merge(db, dr)  # HIP events on the engine's own stream
         eng.pack_digests(dr, 0, n_logs, digests.data_ptr())
         eng.sync()
-        # N > 1: the only collective on the path — RCCL all-gather of the digests (peritext_amd/shard.py)
-        conv, _ = shard.global_convergence(digests, replicas, dist if world > 1 else None, gathered)
+        conv, _ = shard.global_convergence(digests, replicas, dist if world > 1 else None, gathered, counts)
         return ms
+
+    def fence():
+        torch.cuda.synchronize()
+        eng.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    eng.sync()
+    fence()
     t0 = time.perf_counter()
-    kernel_ms = []
-    for _ in range(args.steps):
-        kernel_ms.append(step(True))
-    torch.cuda.synchronize()
-    eng.sync()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    kernel_ms = [step(True) for _ in range(args.steps)]
+    fence()
     elapsed = time.perf_counter() - t0
-    if fused_stream is not None:
-        kernel_ms = [a.elapsed_time(b) for a, b in fused_events]
-        eng.set_stream(0)
+    if stream is not None:
+        kernel_ms = [a.elapsed_time(b) for a, b in events]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     converged_docs = int(conv.item())
 
-    # ---- parity guard inside the bench: every log ok; rank 0 re-checks one document against the oracle ----
+    # ---- sustained leg: the same step back to back for >= --sustain-s seconds (is the rate a cold-boost burst?) ----
+    sustained = None
+    if args.sustain_s > 0:
+        n_sus = max(args.steps, int(args.sustain_s / max(elapsed / args.steps, 1e-6)) + 1)
+        if world > 1:
+            t = torch.tensor([n_sus], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n_sus = int(t.item())
+        events.clear()
+        fence()
+        ts = time.perf_counter()
+        sus_ms = [step(True) for _ in range(n_sus)]
+        fence()
+        sus_elapsed = time.perf_counter() - ts
+        if stream is not None:
+            sus_ms = [a.elapsed_time(b) for a, b in events]
+        if world > 1:
+            t = torch.tensor([sus_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sus_elapsed = float(t.item())
+        third = max(1, n_sus // 3)
+        sustained = {"seconds": sus_elapsed, "steps": n_sus, "ops_per_s": None,  # filled below (whole-job ops)
+                     "kernel_ms_avg": float(np.mean(sus_ms)), "kernel_ms_first_third": float(np.mean(sus_ms[:third])), "kernel_ms_last_third": float(np.mean(sus_ms[-third:]))}
+    if stream is not None:
+        eng.set_stream(0)
+
+    # ---- every log ok, every document converged ----
     logs = eng.download_logs(dr, n_logs)
     assert int(logs["status"].max()) == 0, "a log failed"
     assert int(logs["n_ops"].sum()) == ops_per_step
+    dg = logs["digest"].reshape(-1, replicas, 2)
+    assert (dg == dg[:, :1, :]).all(), "replicas of a document must converge"
+    assert converged_docs == total_docs, "device count of converged documents disagrees"
 
+    total_ops_per_step = ops_per_step * world if weak else sum(counts) * gcfg["ops_per_log"]
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import helpers
 
-        one = wire.encode_docs([docs[0]["logs"]])
-        res1 = eng.apply_materialize(one)
-        expected0 = docs[0]["expected"] if "expected" in docs[0] else helpers.oracle_apply([docs[0]["logs"]])[0]
-        for r_ in range(replicas):
-            helpers.check_log(one, res1, r_, expected0[r_])
+        # ---- parity guard: random documents of the RESIDENT batch against the reference run on the host cores ----
+        parity, cpu = None, None
+        if not args.no_cpu:
+            rng = np.random.default_rng(args.seed)
+            pick = sorted(int(x) for x in rng.choice(n_docs, size=min(args.check_docs, n_docs), replace=False))
+            ones, docs_logs = [], []
+            for d in pick:
+                hb, hinfo = eng.generate(*gen_args, 1, args.seed, first_doc=first_doc + d, list_cap=args.list_cap)
+                actors_t, comments_t, log_doc_t = wire.generated_tables(1, replicas, hinfo["n_comments"])
+                one = eng.download_batch(hb, wire.GEN_VALUES, wire.GEN_URLS, log_doc_t, actors_t, comments_t)
+                eng.free_batch(hb)
+                ones.append(one)
+                docs_logs.append([wire.decode_changes(one, r) for r in range(replicas)])
+            expected, cpu = reference_run(docs_logs, args.cpu_procs or cores)
+            for d, one, exp in zip(pick, ones, expected):
+                sub = eng.download_range(db, dr, d * replicas, replicas)  # the rows the timed launches wrote for this document
+                for r in range(replicas):
+                    helpers.check_log(one, sub, r, exp[r])
+            parity = {"documents_checked": len(pick), "replica_logs_checked": len(pick) * replicas, "against": cpu["kind"],
+                      "what": "decoded spans, raw value/span/comment-interval rows and 128-bit digests of the resident batch's result rows"}
 
-        # algorithmic bytes of ONE launch on this rank (SURVEY.md §8d, with this ABI's row sizes)
-        rows = eng.n_ops(db)
-        n_changes = n_changes_rank
-        env_bytes = 0 if args.no_admission else n_changes * (12 + 4 * max_actors)  # chg_actor, chg_seq, chg_nops, chg_deps row
-        # the same launch without the admission phase (PTX_FLAG_NO_ADMISSION), for reference: a second engine on the same batch
+        # ---- roofline (SURVEY.md §8d): B_alg = sum over logs of 32*N + 4*V + 8*S + 16*T + 16 ----
+        V, S, T = int(logs["n_visible"].sum()), int(logs["n_spans"].sum()), int(logs["n_cintervals"].sum())
+        alg_bytes = 32 * rows + 4 * V + 8 * S + 16 * T + 16 * n_logs
+        env_bytes = 0 if args.no_admission else abi.envelope_bytes(n_changes, replicas)
+        k_ms = float(np.mean(kernel_ms))
+        achieved = alg_bytes / (k_ms * 1e-3)
+        # the same launch without the admission phase (PTX_FLAG_NO_ADMISSION), for reference: a second context on the same resident batch
         ms_noadm = None
         if not args.no_admission:
             eng2 = Engine(local, flags=abi.FLAG_NO_ELEM_RANK | abi.FLAG_NO_ADMISSION)
-            if args.device_gen:
-                db2, _ = eng2.generate(*gen_args, args.docs_per_gpu, args.seed, first_doc=rank * args.docs_per_gpu, list_cap=args.list_cap)
-            else:
-                db2 = eng2.upload(batch, copies=copies)
-            dr2 = eng2.alloc_result(db2)
-            eng2.merge(db2, dr2)
+            eng2.merge(db, dr)
             eng2.sync()
-            ms_noadm = eng2.merge_timed(db2, dr2, max(2, args.steps // 2)) / max(2, args.steps // 2)
-            eng2.free_result(dr2)
-            eng2.free_batch(db2)
+            it = max(2, args.steps // 2)
+            ms_noadm = eng2.merge_timed(db, dr, it) / it
             eng2.close()
-        alg_bytes = env_bytes + 32 * rows + 32 * n_logs + 4 * int(logs["n_visible"].sum()) + 8 * int(logs["n_spans"].sum()) + 12 * int(logs["n_cintervals"].sum()) + 48 * n_logs
-        k_ms = float(np.mean(kernel_ms))
-        achieved = alg_bytes / (k_ms * 1e-3)
-        total_ops = ops_per_step * world * args.steps
+        traffic = load_traffic(n_logs, rows)
+        threads, lds = eng.launch_shape(db)
         out = {
             "metric": "CRDT ops applied+materialised per second (whole node)",
-            "value": total_ops / elapsed,
+            "value": total_ops_per_step * args.steps / elapsed,
             "unit": "ops/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
-            "dtype": "u32/u64 integer (opIds u64, indices u16/u32 in LDS)",
-            "data": ("synthetic: PTXGEN (seeded restatement of reference/test/fuzz.ts) generated ON THE DEVICE by ptx_generate (on-device change()); "
-                     "%d distinct docs per GPU, none repeated" % n_docs) if args.device_gen else
-                    "synthetic: PTXGEN (seeded restatement of reference/test/fuzz.ts) via the oracle's change(); %d unique docs per GPU tiled x%d in HBM" % (args.unique, copies),
+            "dtype": "u64/u32 integer (opIds u64; indices u16/u32 in LDS)",
+            "data": "synthetic: PTXGEN (seeded restatement of reference/test/fuzz.ts) generated ON THE DEVICE by ptx_generate (on-device change()); "
+                    "%d distinct docs on this GPU, %d in the job, none repeated" % (n_docs, total_docs),
             "config": {
-                "workload": "BASELINE config #4 shard: %d docs x %d replicas x %d ops per GPU (64K docs x 3 x 4096 at 8 GPUs)"
-                % (n_docs, replicas, (args.ops or {"config4": 4096, "config3": 1024, "config2": 256, "config5": 8192, "rich": 1024, "mini": 96}[args.config])),
+                "workload": "BASELINE config #4: %d docs x %d replicas x %d ops (%s)" % (
+                    total_docs, replicas, gcfg["ops_per_log"],
+                    "the whole 64K-doc batch on one GPU" if world == 1 and total_docs == 65536 else "%d docs per GPU on %d GPUs, doc-sharded" % (n_docs, world)),
                 "ptxgen_config": args.config,
-                "replica_logs_per_gpu": n_logs,
-                "ops_per_gpu_per_step": ops_per_step,
-                "op_log_bytes_per_gpu": 32 * rows,
+                "docs_total": total_docs,
+                "docs_this_gpu": n_docs,
+                "replica_logs_this_gpu": n_logs,
+                "ops_this_gpu_per_step": ops_per_step,
+                "op_log_bytes_this_gpu": 32 * rows,
+                "changes_this_gpu": n_changes,
                 "parallelism": "doc-sharded x%d, digests-only all-gather" % world,
                 "causal_admission": not args.no_admission,
-                "fused_step": bool(args.fused_step),
-                "changes_per_gpu_per_step": n_changes,
+                "step": "merge + device-side convergence count, one stream, no host sync" if stream is not None else "merge, host sync, digest check",
             },
             "docs_converged_per_s": converged_docs * args.steps / elapsed,
             "docs_converged": converged_docs,
-            "docs_total": n_docs * world,
+            "docs_total": total_docs,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved / 1e9,
@@ -335,29 +338,35 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
                 "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING,
-                "traffic": None,  # PMC counters cannot be read from inside the timed run; measured separately for this command:
-                "traffic_profile": "profiles/r01_x_v40_hbm_traffic_pmc.txt: FETCH_SIZE + WRITE_SIZE per launch = 0.96 x the algorithmic bytes",
+                "traffic": None if traffic is None else traffic["hbm_bytes_per_launch"],
+                "traffic_over_algorithmic": None if traffic is None else traffic["hbm_bytes_per_launch"] / alg_bytes,
+                "traffic_source": None if traffic is None else traffic.get("source"),
                 "kernel": eng.kernel_name(),
                 "kernel_ms_avg": k_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "envelope_bytes_per_launch": env_bytes,
+                "formula": "sum over logs of 32*N + 4*V + 8*S + 16*T + 16 (SURVEY 8d; T = comment-interval rows)",
+                "with_envelope": {"envelope_bytes_per_launch": env_bytes, "GBps": (alg_bytes + env_bytes) / (k_ms * 1e-3) / 1e9,
+                                  "frac": (alg_bytes + env_bytes) / (k_ms * 1e-3) / HBM_PEAK},
             },
             "without_admission": None if ms_noadm is None else {"kernel_ms": ms_noadm, "ops_per_s_1gpu": ops_per_step / (ms_noadm * 1e-3),
-                                                                "hbm_GBps": (alg_bytes - env_bytes) / (ms_noadm * 1e-3) / 1e9},
-            "launch": dict(zip(("threads_per_log", "lds_bytes_per_log"), eng.launch_shape(db))),
-            "host": {"cores": cores, "gen_s": t_gen, "upload_s": t_up, "upload_GBps": None if args.device_gen else 32 * rows / copies / max(t_up, 1e-9) / 1e9},
-            "device_gen": None if gen_info is None else {"kernel_ms": gen_info["kernel_ms"], "ops_generated_per_s": ops_per_step / (gen_info["kernel_ms"] * 1e-3),
-                                                        "launch_shape": list(eng.launch_shape(db))},
+                                                                "hbm_GBps": alg_bytes / (ms_noadm * 1e-3) / 1e9, "frac": alg_bytes / (ms_noadm * 1e-3) / HBM_PEAK},
+            "sustained": sustained,
+            "parity": parity,
+            "launch": {"threads_per_log": threads, "lds_bytes_per_log": lds},
+            "host": {"cores": cores, "gen_s": t_gen},
+            "device_gen": {"kernel_ms": gen_info["kernel_ms"], "ops_generated_per_s": ops_per_step / (gen_info["kernel_ms"] * 1e-3)},
         }
-        if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(docs, args.cpu_budget_s, min(args.cpu_procs, cores))
+        if sustained is not None:
+            sustained["ops_per_s"] = total_ops_per_step * sustained["steps"] / sustained["seconds"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
     eng.free_result(dr)
     eng.free_batch(db)
     eng.close()
     if world > 1:
-        dist.barrier()  # rank 0 is still busy with the CPU baseline leg: leave together
+        dist.barrier()  # rank 0 is still busy with the reference run: leave together
         dist.destroy_process_group()
 
 

@@ -282,6 +282,11 @@ ptx_status ptx_merge_timed(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, ui
  * order of merge_core.h (P1 classify, P2 index, P3a buckets, P3b child order, P3c tour+ranking, P4
  * tombstones, P5a values+mark intervals, P5b LWW, P5c comments, P6 spans).  Not for timed runs. */
 ptx_status ptx_merge_phase_cycles(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, uint64_t* cycles, uint32_t n);
+/* Diagnostic (profiling runs only): stream every op column — and the Change envelope when the batch has one — exactly once
+ * with the element widths the merge kernel uses (kernel `ptx_calib_stream_kernel`); *bytes_read = the bytes that stream is,
+ * 32 per op row + the envelope.  It calibrates the HBM-traffic PMC counters on a known byte count in this library's own
+ * access pattern (tools/pmc_traffic.sh).  Synchronises. */
+ptx_status ptx_calib_stream(ptx_ctx* ctx, const ptx_dbatch* b, uint64_t* bytes_read);
 ptx_status ptx_sync(ptx_ctx* ctx);
 /* Run the context's launches and copies on the caller's HIP stream (e.g. torch's current stream: everything stays
  * stream-ordered with the caller's own kernels and no host-side synchronisation is needed between them).  `hip_stream`
@@ -292,6 +297,9 @@ ptx_status ptx_set_stream(ptx_ctx* ctx, void* hip_stream);
 ptx_status ptx_count_converged(ptx_ctx* ctx, const ptx_dresult* r, uint32_t replicas, uint64_t* count_device);
 
 ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_result* out);
+/* The same for the logs [first_log, first_log + n_logs) only (e.g. a sample of a large resident batch): out->n_logs = n_logs,
+ * out->n_rows = their rows, row r of the k-th log of the range at index (log_off[first_log + k] - log_off[first_log]) + r. */
+ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, uint32_t first_log, uint32_t n_logs, ptx_result* out);
 /* Only the per-log rows (status, counts, digests): [n_logs] ptx_log_result into caller memory. */
 ptx_status ptx_result_download_logs(ptx_ctx* ctx, const ptx_dresult* r, ptx_log_result* out, uint32_t n_logs);
 /* Device address of the per-log result rows (for a collective on the digests); never freed by the caller. */

@@ -9,10 +9,11 @@
  *                            [--impl oracle|ref] --out FILE
  *       PTXGEN traces + expected output.  FILE = {config, seed, docs:[{docIndex, seed, actors,
  *       logs:[Change[] per replica], expected:[{spans, text} per replica]}]}
- *   node oracle/cli.js apply --in FILE [--impl oracle|ref] [--cursors] [--patches] --out FILE
+ *   node oracle/cli.js apply --in FILE [--impl oracle|ref] [--cursors] [--patches] [--timing] --out FILE
  *       FILE in  = {docs:[{logs:[Change[]...]}]} (e.g. a reference trace or a KAT);  every log is applied
  *       to a FRESH replica with applyChange (micromerge.ts:499) and flattened (peritext.ts:337).
- *       FILE out = {docs:[{expected:[{spans, text, error?}]}]}
+ *       FILE out = {docs:[{expected:[{spans, text, error?}]}]}; --timing adds timing: {seconds, ops, logs} = the time spent in
+ *       applyChange over every change + getTextWithFormatting of every log (the CPU-baseline leg of bench.py: whole logs)
  *   node oracle/cli.js time  --in FILE [--impl oracle|ref] [--budget-ms T]
  *       CPU baseline: time applyChange over every change of every log + getTextWithFormatting, one log
  *       after another on this core until the budget is spent; prints one JSON line
@@ -102,13 +103,18 @@ if (cmd === "gen") {
     const out = { impl, docs: [] }
     const wantCursors = argv.indexOf("--cursors") >= 0
     const wantPatches = argv.indexOf("--patches") >= 0
+    const timing = { seconds: 0, ops: 0, logs: 0 }
     for (const d of input.docs) {
         const expected = []
         for (const log of d.logs) {
             try {
                 const patches = wantPatches ? [] : null
+                const s0 = process.hrtime.bigint()
                 const doc = applyLog(Impl, impl, log, patches)
                 const e = expectedOf(doc)
+                timing.seconds += Number(process.hrtime.bigint() - s0) / 1e9
+                timing.ops += log.reduce((a, c) => a + c.ops.length, 0) - 1 /* the makeList */
+                timing.logs += 1
                 if (wantPatches) e.patches = patches /* the concatenated returns of applyChange (micromerge.ts:499) */
                 if (wantCursors) {
                     /* micromerge.ts:465-477: getCursor for every visible index, resolveCursor for every element ever inserted */
@@ -126,6 +132,7 @@ if (cmd === "gen") {
         }
         out.docs.push({ expected })
     }
+    if (argv.indexOf("--timing") >= 0) out.timing = timing
     fs.writeFileSync(flag("--out"), JSON.stringify(out))
 } else if (cmd === "time") {
     const impl = flag("--impl", "oracle")

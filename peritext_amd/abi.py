@@ -51,6 +51,13 @@ STATUS_NAMES = {
     6: "malformed op row",
 }
 
+
+
+def envelope_bytes(n_changes, max_actors):
+    """Bytes of the Change envelope the admission phase reads: chg_actor, chg_seq, chg_nops (u32 each) + a chg_deps row."""
+    return n_changes * (12 + 4 * max_actors)
+
+
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
@@ -221,10 +228,12 @@ FUNCTIONS = {
     "ptx_merge": (C.c_int32, [vp, vp, vp]),
     "ptx_merge_timed": (C.c_int32, [vp, vp, vp, C.c_uint32, C.POINTER(C.c_float)]),
     "ptx_merge_phase_cycles": (C.c_int32, [vp, vp, vp, u64p, C.c_uint32]),
+    "ptx_calib_stream": (C.c_int32, [vp, vp, u64p]),
     "ptx_sync": (C.c_int32, [vp]),
     "ptx_set_stream": (C.c_int32, [vp, vp]),
     "ptx_count_converged": (C.c_int32, [vp, vp, C.c_uint32, vp]),
     "ptx_result_download": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_result)]),
+    "ptx_result_download_range": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(ptx_result)]),
     "ptx_result_download_logs": (C.c_int32, [vp, vp, C.POINTER(ptx_log_result), C.c_uint32]),
     "ptx_dresult_logs_device": (vp, [vp]),
     "ptx_pack_digests": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp]),

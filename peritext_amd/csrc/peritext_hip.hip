@@ -119,10 +119,18 @@ __global__ void ptx_append_rows_kernel(PtxAppendCols A, const uint64_t* a_off, c
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
 __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off, const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type,
                                                           const uint32_t* payload, ptx_log_hdr* hdr, uint32_t* shape, int compute, const uint64_t* chg_off, uint32_t max_actors,
-                                                          uint32_t* need_per_log) {
+                                                          uint32_t* need_per_log, uint64_t n_ops) {
     __shared__ uint32_t sh[9];
     const uint32_t log = blockIdx.x;
     const uint64_t b0 = log_off[log], b1 = log_off[log + 1];
+    if (b1 < b0 || b1 > n_ops || (log == 0 && b0 != 0) || (log + 1 == gridDim.x && b1 != n_ops)) {
+        /* offsets that decrease or leave the columns (a wrapped device batch is not checked on the host): no row is touched */
+        if (threadIdx.x == 0) {
+            atomicMax(&shape[2], 1u);
+            need_per_log[log] = 0;
+        }
+        return;
+    }
     if (compute) {
         if (threadIdx.x < 9) sh[threadIdx.x] = 0;
         __syncthreads();
@@ -183,6 +191,25 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
         need_per_log[log] = (uint32_t)min(need, (uint64_t)0xFFFFFFFFu);
         atomicMax(&shape[1], (uint32_t)min(b1 - b0, (uint64_t)0xFFFFFFFFu));
     }
+}
+
+/* Calibration stream for the HBM-traffic counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE is exact only for some access widths:
+ * calibrate on a known byte count in your own access pattern): every op column and envelope column is read exactly once with
+ * the element widths the merge kernel uses (8 B / 4 B / 1 B per lane, consecutive lanes on consecutive rows). */
+__global__ void __launch_bounds__(256) ptx_calib_stream_kernel(const uint64_t* op_id, const uint64_t* ref_a, const uint64_t* ref_b, const uint32_t* payload, const uint8_t* action,
+                                                                const uint8_t* mark_type, const uint8_t* side_a, const uint8_t* side_b, uint64_t n_rows,
+                                                                const uint32_t* chg_actor, const uint32_t* chg_seq, const uint32_t* chg_nops, const uint32_t* chg_deps,
+                                                                uint64_t n_changes, uint32_t max_actors, unsigned long long* sum) {
+    unsigned long long acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += stride)
+        acc += op_id[i] + ref_a[i] + ref_b[i] + payload[i] + action[i] + mark_type[i] + side_a[i] + side_b[i];
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_changes; c += stride) {
+        acc += chg_actor[c] + chg_seq[c] + chg_nops[c];
+        for (uint32_t b = 0; b < max_actors; ++b) acc += chg_deps[c * max_actors + b];
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
 }
 
 __global__ void ptx_count_converged_kernel(const ptx_log_result* res, uint32_t n_docs, uint32_t replicas, unsigned long long* out) {
@@ -267,7 +294,7 @@ struct ptx_dresult {
     uint32_t* rank = nullptr;
 };
 
-static std::string g_create_err;
+static thread_local std::string g_create_err;
 
 static ptx_status fail(ptx_ctx* ctx, ptx_status st, const std::string& msg) {
     if (ctx) ctx->err = msg;
@@ -300,24 +327,25 @@ static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t ma
  * launch shape.  `have_hdr`: b->log_hdr already holds the caller's headers. */
 static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
     uint32_t *shape = nullptr, *d_need = nullptr;
-    uint32_t h[2] = {0, 0};
+    uint32_t h[3] = {0, 0, 0};
     std::vector<uint32_t> need;
     if (b->n_logs) {
-        PTX_HIP(ctx, hipMalloc((void**)&shape, 8));
+        PTX_HIP(ctx, hipMalloc((void**)&shape, 12));
         hipError_t e = hipMalloc((void**)&d_need, (size_t)b->n_logs * 4);
-        if (e == hipSuccess) e = hipMemsetAsync(shape, 0, 8, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(shape, 0, 12, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(ptx_census_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->log_off, b->op_id, b->action, b->mark_type, b->payload, b->log_hdr,
-                               shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors, d_need);
+                               shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors, d_need, b->n_ops);
             e = hipGetLastError();
         }
         need.resize(b->n_logs);
-        if (e == hipSuccess) e = hipMemcpyAsync(h, shape, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h, shape, 12, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(need.data(), d_need, (size_t)b->n_logs * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         (void)hipFree(shape);
         (void)hipFree(d_need);
         if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("census: ") + hipGetErrorString(e));
+        if (h[2]) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off must run from 0 to n_ops without decreasing");
     }
     shape_launch(ctx, b, h[0], h[1]);
     /* Would one more log fit a CU if the launch were sized for all but a few logs?  LDS is allocated in 512-byte
@@ -355,6 +383,21 @@ static ptx_status check_batch(ptx_ctx* ctx, const ptx_batch* h) {
     if (h->n_logs && !h->log_off) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off is NULL");
     if (h->n_ops && (!h->op_id || !h->ref_a || !h->ref_b || !h->payload || !h->action || !h->mark_type || !h->side_a || !h->side_b))
         return fail(ctx, PTX_ERR_INVALID_ARG, "an op column is NULL");
+    return PTX_OK;
+}
+
+/* offsets of a HOST batch: start at 0, never decrease, end at the row / change count (the kernels index the columns and
+ * the result rows with them) */
+static ptx_status check_host_offsets(ptx_ctx* ctx, const ptx_batch* h) {
+    if (!h->n_logs) return PTX_OK;
+    if (h->log_off[0] != 0 || h->log_off[h->n_logs] != h->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off must run from 0 to n_ops");
+    for (uint32_t l = 0; l < h->n_logs; ++l)
+        if (h->log_off[l + 1] < h->log_off[l]) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off decreases");
+    if (h->chg_off && h->chg_actor && h->chg_seq && h->chg_nops && h->chg_deps && h->max_actors) {
+        if (h->chg_off[0] != 0) return fail(ctx, PTX_ERR_INVALID_ARG, "chg_off must start at 0");
+        for (uint32_t l = 0; l < h->n_logs; ++l)
+            if (h->chg_off[l + 1] < h->chg_off[l]) return fail(ctx, PTX_ERR_INVALID_ARG, "chg_off decreases");
+    }
     return PTX_OK;
 }
 
@@ -478,7 +521,8 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
     ptx_status st = check_batch(ctx, h);
     if (st) return st;
     if (copies == 0) return fail(ctx, PTX_ERR_INVALID_ARG, "copies must be >= 1");
-    if (h->n_logs && h->log_off[h->n_logs] != h->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off[n_logs] != n_ops");
+    st = check_host_offsets(ctx, h);
+    if (st) return st;
     if ((uint64_t)h->n_logs * copies > 0xFFFFFFFFull) return fail(ctx, PTX_ERR_INVALID_ARG, "too many logs");
     PTX_HIP(ctx, hipSetDevice(ctx->device));
     ptx_dbatch* b = new ptx_dbatch();
@@ -850,6 +894,25 @@ ptx_status ptx_count_converged(ptx_ctx* ctx, const ptx_dresult* r, uint32_t repl
     return PTX_OK;
 }
 
+ptx_status ptx_calib_stream(ptx_ctx* ctx, const ptx_dbatch* b, uint64_t* bytes_read) {
+    if (!ctx || !b || !bytes_read) return PTX_ERR_INVALID_ARG;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long* d = nullptr;
+    PTX_HIP(ctx, hipMalloc((void**)&d, 8));
+    hipError_t e = hipMemsetAsync(d, 0, 8, ctx->stream);
+    const bool env = b->chg_off != nullptr;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ptx_calib_stream_kernel, dim3(256 * 32), dim3(256), 0, ctx->stream, b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a,
+                           b->side_b, b->n_ops, b->chg_actor, b->chg_seq, b->chg_nops, b->chg_deps, env ? b->n_changes : 0, b->max_actors, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("calibration stream: ") + hipGetErrorString(e));
+    *bytes_read = 32 * b->n_ops + (env ? b->n_changes * (12 + 4ull * b->max_actors) : 0);
+    return PTX_OK;
+}
+
 ptx_status ptx_sync(ptx_ctx* ctx) {
     if (!ctx) return PTX_ERR_INVALID_ARG;
     PTX_HIP(ctx, hipSetDevice(ctx->device));
@@ -871,31 +934,41 @@ void ptx_result_free(ptx_result* res) {
     memset(res, 0, sizeof(*res));
 }
 
-ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_result* out) {
+ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, uint32_t first_log, uint32_t n_logs, ptx_result* out) {
     if (!ctx || !b || !r || !out) return PTX_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
+    if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
+    if ((uint64_t)first_log + n_logs > r->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "log range exceeds the result");
     PTX_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t lo[2] = {0, 0};
+    if (r->n_logs) {
+        PTX_HIP(ctx, hipMemcpyAsync(&lo[0], b->log_off + first_log, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PTX_HIP(ctx, hipMemcpyAsync(&lo[1], b->log_off + first_log + n_logs, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (lo[1] < lo[0] || lo[1] > r->n_rows) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off is not monotonic");
+    const uint64_t r0 = lo[0], nr = lo[1] - lo[0];
     ptx_host_result* h = new ptx_host_result();
-    h->logs.resize(std::max<uint64_t>(r->n_logs, 1));
-    h->values.resize(std::max<uint64_t>(r->n_rows, 1));
-    h->spans.resize(std::max<uint64_t>(r->n_rows, 1));
-    h->cints.resize(std::max<uint64_t>(r->n_rows, 1));
-    h->rank.resize(std::max<uint64_t>(r->n_rows, 1));
+    h->logs.resize(std::max<uint64_t>(n_logs, 1));
+    h->values.resize(std::max<uint64_t>(nr, 1));
+    h->spans.resize(std::max<uint64_t>(nr, 1));
+    h->cints.resize(std::max<uint64_t>(nr, 1));
+    h->rank.resize(std::max<uint64_t>(nr, 1));
     hipError_t e = hipSuccess;
-    if (r->n_logs) e = hipMemcpyAsync(h->logs.data(), r->logs, r->n_logs * sizeof(ptx_log_result), hipMemcpyDeviceToHost, ctx->stream);
-    if (r->n_rows) {
-        if (e == hipSuccess) e = hipMemcpyAsync(h->values.data(), r->values, r->n_rows * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->spans.data(), r->spans, r->n_rows * sizeof(ptx_span), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->cints.data(), r->cints, r->n_rows * sizeof(ptx_cinterval), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && r->rank) e = hipMemcpyAsync(h->rank.data(), r->rank, r->n_rows * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (n_logs) e = hipMemcpyAsync(h->logs.data(), r->logs + first_log, (size_t)n_logs * sizeof(ptx_log_result), hipMemcpyDeviceToHost, ctx->stream);
+    if (nr) {
+        if (e == hipSuccess) e = hipMemcpyAsync(h->values.data(), r->values + r0, nr * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->spans.data(), r->spans + r0, nr * sizeof(ptx_span), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->cints.data(), r->cints + r0, nr * sizeof(ptx_cinterval), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && r->rank) e = hipMemcpyAsync(h->rank.data(), r->rank + r0, nr * 4, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         delete h;
         return fail(ctx, PTX_ERR_HIP, std::string("result download: ") + hipGetErrorString(e));
     }
-    out->n_logs = r->n_logs;
-    out->n_rows = r->n_rows;
+    out->n_logs = n_logs;
+    out->n_rows = nr;
     out->logs = h->logs.data();
     out->values = h->values.data();
     out->spans = h->spans.data();
@@ -903,6 +976,11 @@ ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dres
     out->elem_rank = r->rank ? h->rank.data() : nullptr;
     out->owner = h;
     return PTX_OK;
+}
+
+ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_result* out) {
+    if (!r) return PTX_ERR_INVALID_ARG;
+    return ptx_result_download_range(ctx, b, r, 0, r->n_logs, out);
 }
 
 ptx_status ptx_result_download_logs(ptx_ctx* ctx, const ptx_dresult* r, ptx_log_result* out, uint32_t n_logs) {
@@ -1077,8 +1155,10 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     *out = nullptr;
     if (info) memset(info, 0, sizeof(*info));
     if (cfg->replicas < 1 || cfg->replicas > PTX_GEN_MAX_R || cfg->n_mark_types > 4 || cfg->ops_per_log < 1 || cfg->ops_per_log > 65533u ||
-        cfg->mix[0] + cfg->mix[1] + cfg->mix[2] + cfg->mix[3] != 100u)
+        cfg->mix[0] > 100u || cfg->mix[1] > 100u || cfg->mix[2] > 100u || cfg->mix[3] > 100u || cfg->mix[0] + cfg->mix[1] + cfg->mix[2] + cfg->mix[3] != 100u)
         return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_generate: 1..4 replicas, at most 65533 ops per log, mix percentages summing to 100");
+    for (uint32_t i = 0; i < cfg->n_mark_types; ++i)
+        if (cfg->mark_types[i] > PTX_MARK_LINK) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_generate: mark_types must be PTX_MARK_* values");
     const size_t tl = strnlen(cfg->initial_text, sizeof(cfg->initial_text));
     const char* text = tl ? cfg->initial_text : "ABCDE";
     const uint32_t init_len = (uint32_t)(tl ? tl : 5);
@@ -1094,7 +1174,7 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     uint32_t *cap_actor = nullptr, *cap_seq = nullptr, *cap_nops = nullptr, *cap_deps = nullptr, *d_nchg = nullptr, *d_ncom = nullptr, *d_status = nullptr;
     PtxGenChange* d_ctab = nullptr;
     uint16_t* d_known = nullptr;
-    auto drop = [&]() {
+    auto drop = [&]() { /* idempotent: a later failure path may call it again */
         (void)hipFree(cap_actor);
         (void)hipFree(cap_seq);
         (void)hipFree(cap_nops);
@@ -1104,6 +1184,9 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
         (void)hipFree(d_status);
         (void)hipFree(d_ctab);
         (void)hipFree(d_known);
+        cap_actor = cap_seq = cap_nops = cap_deps = d_nchg = d_ncom = d_status = nullptr;
+        d_ctab = nullptr;
+        d_known = nullptr;
     };
 #define PTX_TRYG(call)                                  \
     do {                                                \

@@ -27,12 +27,13 @@ def _batch_struct(b):
     s.mark_type = p(b.mark_type, abi.u8p)
     s.side_a = p(b.side_a, abi.u8p)
     s.side_b = p(b.side_b, abi.u8p)
-    s.chg_off = p(b.chg_off, abi.u64p)
-    s.chg_actor = p(b.chg_actor, abi.u32p)
-    s.chg_seq = p(b.chg_seq, abi.u32p)
-    s.chg_nops = p(b.chg_nops, abi.u32p)
-    s.chg_deps = p(b.chg_deps, abi.u32p)
-    s.max_actors = b.max_actors
+    if b.chg_off is not None:  # a batch without the Change envelope (e.g. downloaded from wrapped device columns): NULL = no admission
+        s.chg_off = p(b.chg_off, abi.u64p)
+        s.chg_actor = p(b.chg_actor, abi.u32p)
+        s.chg_seq = p(b.chg_seq, abi.u32p)
+        s.chg_nops = p(b.chg_nops, abi.u32p)
+        s.chg_deps = p(b.chg_deps, abi.u32p)
+        s.max_actors = b.max_actors
     if b.log_hdr is not None and len(b.log_hdr):
         s.log_hdr = b.log_hdr.ctypes.data_as(C.POINTER(abi.ptx_log_hdr))
     return s
@@ -160,12 +161,27 @@ class Engine:
         """Documents whose `replicas` logs all carry the same digest, into a u64 in device memory (stream-ordered, no host sync)."""
         self._check(self.lib.ptx_count_converged(self.ctx, dresult, replicas, C.c_void_p(count_device_ptr)))
 
+    def calib_stream(self, dbatch):
+        """Diagnostic: stream the batch's columns once (kernel ptx_calib_stream_kernel); returns the bytes that stream is."""
+        n = C.c_uint64()
+        self._check(self.lib.ptx_calib_stream(self.ctx, dbatch, C.byref(n)))
+        return int(n.value)
+
     def sync(self):
         self._check(self.lib.ptx_sync(self.ctx))
 
     def download(self, dbatch, dresult):
         res = abi.ptx_result()
         self._check(self.lib.ptx_result_download(self.ctx, dbatch, dresult, C.byref(res)))
+        try:
+            return _copy_result(res)
+        finally:
+            self.lib.ptx_result_free(C.byref(res))
+
+    def download_range(self, dbatch, dresult, first_log, n_logs):
+        """Result rows of logs [first_log, first_log + n_logs) only, rebased to row 0 (a sample of a large resident batch)."""
+        res = abi.ptx_result()
+        self._check(self.lib.ptx_result_download_range(self.ctx, dbatch, dresult, first_log, n_logs, C.byref(res)))
         try:
             return _copy_result(res)
         finally:

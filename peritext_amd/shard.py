@@ -19,21 +19,38 @@ def converged_docs(digests, replicas):
     return (d == d[:, :1, :]).all(dim=2).all(dim=1).sum()
 
 
-def allgather_digests(digests, dist=None, out=None):
-    """All-gather of equally sized per-rank digest tensors -> [world * n_logs, 2] (rank-major).  `dist` is
-    torch.distributed (already initialised) or None for a single process."""
+def allgather_digests(digests, dist=None, out=None, counts=None):
+    """All-gather of the per-rank digest tensors -> [sum(counts), 2] (rank-major).  `dist` is torch.distributed (already
+    initialised) or None for a single process.  `counts[r]` = rows of rank r (doc_range gives blocks that differ by one
+    document when the documents do not divide evenly): unequal blocks are gathered padded to the largest and compacted."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return digests
     import torch
 
     world = dist.get_world_size()
+    n = digests.shape[0]
+    if counts is None:
+        counts = [n] * world
+    assert len(counts) == world and counts[dist.get_rank()] == n, "counts must list every rank's rows"
+    tail = tuple(digests.shape[1:])
+    if all(c == n for c in counts):
+        if out is None:
+            out = torch.empty((world * n,) + tail, dtype=digests.dtype, device=digests.device)
+        dist.all_gather_into_tensor(out, digests.contiguous())
+        return out
+    width = max(counts)
+    mine = torch.zeros((width,) + tail, dtype=digests.dtype, device=digests.device)
+    mine[:n] = digests
+    padded = torch.empty((world * width,) + tail, dtype=digests.dtype, device=digests.device)
+    dist.all_gather_into_tensor(padded, mine)
+    parts = [padded[r * width:r * width + counts[r]] for r in range(world)]
     if out is None:
-        out = torch.empty((world * digests.shape[0],) + tuple(digests.shape[1:]), dtype=digests.dtype, device=digests.device)
-    dist.all_gather_into_tensor(out, digests.contiguous())
+        return torch.cat(parts)
+    torch.cat(parts, out=out)
     return out
 
 
-def global_convergence(digests, replicas, dist=None, out=None):
+def global_convergence(digests, replicas, dist=None, out=None, counts=None):
     """(converged documents, total documents) over all ranks, identical on every rank."""
-    g = allgather_digests(digests, dist, out)
+    g = allgather_digests(digests, dist, out, counts)
     return converged_docs(g, replicas), g.shape[0] // replicas

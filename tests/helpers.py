@@ -161,6 +161,79 @@ def mini_doc(ops_second_change, first_text="ABCDE"):
     return [c1, c2]
 
 
+
+# ---- hand-written logs shared by the emulation suite and its GPU twin (tests/test_gpu_edges.py) ----
+def edge_case_docs():
+    """Quirks of SURVEY.md Appendix A.6 that no reference test covers (one single-replica document each)."""
+    _mini_doc = mini_doc
+    el = lambda i: "%d@a" % (i + 2)  # noqa: E731  element id of initial char i
+    return [
+        [_mini_doc([{"action": "removeMark", "markType": "comment", "attrs": {"id": "c1"}, "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(3)}}])],
+        [_mini_doc([{"action": "addMark", "markType": "strong", "start": {"type": "before", "elemId": el(2)}, "end": {"type": "before", "elemId": el(2)}}])],
+        [_mini_doc([{"action": "addMark", "markType": "link", "attrs": {"url": "u"}, "start": {"type": "before", "elemId": el(2)}, "end": {"type": "after", "elemId": el(1)}}])],
+        [_mini_doc([{"action": "addMark", "markType": "em", "start": {"type": "before", "elemId": "99@zz"}, "end": {"type": "endOfText"}}])],
+        [_mini_doc([{"action": "addMark", "markType": "em", "start": {"type": "before", "elemId": el(3)}, "end": {"type": "endOfText"}},
+                    {"action": "set", "insert": True, "elemId": el(4), "value": "!"}])],
+        [_mini_doc([], first_text="")],
+        [_mini_doc([{"action": "del", "elemId": el(i)} for i in range(5)] + [{"action": "del", "elemId": el(0)}])],
+        [_mini_doc([{"action": "addMark", "markType": "comment", "attrs": {"id": "c2"}, "start": {"type": "before", "elemId": el(0)}, "end": {"type": "after", "elemId": el(2)}},
+                    {"action": "addMark", "markType": "comment", "attrs": {"id": "c1"}, "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(4)}},
+                    {"action": "removeMark", "markType": "comment", "attrs": {"id": "c2"}, "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(1)}},
+                    {"action": "addMark", "markType": "comment", "attrs": {"id": "c2"}, "start": {"type": "before", "elemId": el(4)}, "end": {"type": "after", "elemId": el(4)}}])],
+    ]
+
+
+def huge_bucket_log():
+    """70 inserts at index 0 (all children of HEAD: the bitmap-ranked bucket path) interleaved with children of other elements,
+    deletes and a mark."""
+    ops = []
+    for k in range(70):
+        ops.append({"action": "set", "insert": True, "elemId": "_head", "value": "abcdefghij"[k % 10]})
+        if k % 7 == 0:
+            ops.append({"action": "set", "insert": True, "elemId": "3@a", "value": "X"})  # siblings under 'B': a medium bucket
+        if k % 9 == 0:
+            ops.append({"action": "set", "insert": True, "elemId": "5@a", "value": "y"})
+    for k in range(11):
+        ops.append({"action": "set", "insert": True, "elemId": "4@a", "value": "m"})  # 11 siblings: the PTX_G-lane path
+    ops.append({"action": "del", "elemId": "4@a"})
+    ops.append({"action": "addMark", "markType": "strong", "start": {"type": "before", "elemId": "2@a"}, "end": {"type": "endOfText"}})
+    return mini_doc(ops)
+
+
+def unsynced_docs():
+    """Replicas that have NOT seen the same changes: every prefix of a replica log is itself a valid log.  The comment ids of
+    a document are ranked over all its replicas, so such a log uses ranks beyond its own number of comment ops."""
+    with open(os.path.join(GOLDEN, "ptxgen_mini.json")) as f:
+        gen = json.load(f)
+    docs = []
+    for d in gen["docs"][:6]:
+        logs = []
+        for k, log in enumerate(d["logs"]):
+            for frac in (3, 2):
+                logs.append(log[: max(1, len(log) * (k + 1) // (frac * len(d["logs"])))])
+        logs.append(d["logs"][0])
+        docs.append(logs)
+    # two replicas that each know ONE comment the other has not seen
+    el = lambda i: "%d@a" % (i + 2)  # noqa: E731
+    base = mini_doc([])
+    ca = {"actor": "b", "seq": 1, "deps": {"a": 2}, "startOp": 8, "ops": [{"opId": "8@b", "obj": "1@a", "action": "addMark", "markType": "comment", "attrs": {"id": "A"},
+                                                                             "start": {"type": "before", "elemId": el(0)}, "end": {"type": "after", "elemId": el(2)}}]}
+    cb = {"actor": "c", "seq": 1, "deps": {"a": 2}, "startOp": 8, "ops": [{"opId": "8@c", "obj": "1@a", "action": "addMark", "markType": "comment", "attrs": {"id": "B"},
+                                                                             "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(4)}}]}
+    docs.append([base + [ca], base + [cb], base + [ca, cb], base + [cb, ca]])
+    return docs
+
+
+
+
+def duplicate_op_docs():
+    """[a log with one opId on two rows, a well-formed neighbour]."""
+    dup = mini_doc([{"action": "set", "insert": True, "elemId": "6@a", "value": "x"}, {"action": "del", "elemId": "3@a"}])
+    dup[1]["ops"][1]["opId"] = dup[1]["ops"][0]["opId"]
+    ok = mini_doc([{"action": "set", "insert": True, "elemId": "6@a", "value": "x"}])
+    return [[dup], [ok]]
+
+
 def norm_patches(patches):
     return [json.loads(json.dumps(p, sort_keys=True)) for p in patches]
 

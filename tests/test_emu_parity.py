@@ -12,7 +12,8 @@ from peritext_amd import abi, wire
 
 pytestmark = pytest.mark.skipif(not os.path.exists(H.EMU_LIB), reason="tests/emu/libperitext_emu.so not built (run __graft_entry__.build())")
 
-GOLDEN_GEN = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json", "ptxgen_config4_600.json", "ptxgen_rich_700.json", "ptxgen_rich_2600.json"]
+GOLDEN_GEN = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json", "ptxgen_config4_600.json", "ptxgen_rich_700.json", "ptxgen_rich_2600.json",
+              "ptxgen_config5_8192.json", "ptxgen_mini_10actors.json"]
 
 
 def _load(name):
@@ -63,23 +64,7 @@ def test_replica_digests_converge():
     assert len({tuple(x) for x in dg[:, 0, :].tolist()}) == len(gen["docs"])  # different docs, different digests
 
 
-def _mini_doc(ops_second_change, first_text="ABCDE"):
-    """A hand-written log: change 1 = makeList + text, change 2 = the given ops (opIds assigned here)."""
-    ops1 = [{"opId": "1@a", "action": "makeList", "obj": "_root", "key": "text"}]
-    prev = "_head"
-    for i, ch in enumerate(first_text):
-        ops1.append({"opId": "%d@a" % (i + 2), "action": "set", "obj": "1@a", "elemId": prev, "insert": True, "value": ch})
-        prev = "%d@a" % (i + 2)
-    c1 = {"actor": "a", "seq": 1, "deps": {}, "startOp": 1, "ops": ops1}
-    start = len(ops1) + 1
-    ops2 = []
-    for k, op in enumerate(ops_second_change):
-        o = dict(op)
-        o["opId"] = "%d@a" % (start + k)
-        o["obj"] = "1@a"
-        ops2.append(o)
-    c2 = {"actor": "a", "seq": 2, "deps": {"a": 1}, "startOp": start, "ops": ops2}
-    return [c1, c2]
+_mini_doc = H.mini_doc
 
 
 def test_edge_cases_against_oracle():
@@ -87,21 +72,7 @@ def test_edge_cases_against_oracle():
     removeMark comment -> `comment: []`; zero-width inclusive mark runs to the end; zero-width
     non-inclusive mark is a no-op; unknown boundary element -> silent no-op; endOfText; empty document;
     everything deleted."""
-    el = lambda i: "%d@a" % (i + 2)  # noqa: E731  element id of initial char i
-    docs = [
-        [_mini_doc([{"action": "removeMark", "markType": "comment", "attrs": {"id": "c1"}, "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(3)}}])],
-        [_mini_doc([{"action": "addMark", "markType": "strong", "start": {"type": "before", "elemId": el(2)}, "end": {"type": "before", "elemId": el(2)}}])],
-        [_mini_doc([{"action": "addMark", "markType": "link", "attrs": {"url": "u"}, "start": {"type": "before", "elemId": el(2)}, "end": {"type": "after", "elemId": el(1)}}])],
-        [_mini_doc([{"action": "addMark", "markType": "em", "start": {"type": "before", "elemId": "99@zz"}, "end": {"type": "endOfText"}}])],
-        [_mini_doc([{"action": "addMark", "markType": "em", "start": {"type": "before", "elemId": el(3)}, "end": {"type": "endOfText"}},
-                    {"action": "set", "insert": True, "elemId": el(4), "value": "!"}])],
-        [_mini_doc([], first_text="")],
-        [_mini_doc([{"action": "del", "elemId": el(i)} for i in range(5)] + [{"action": "del", "elemId": el(0)}])],
-        [_mini_doc([{"action": "addMark", "markType": "comment", "attrs": {"id": "c2"}, "start": {"type": "before", "elemId": el(0)}, "end": {"type": "after", "elemId": el(2)}},
-                    {"action": "addMark", "markType": "comment", "attrs": {"id": "c1"}, "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(4)}},
-                    {"action": "removeMark", "markType": "comment", "attrs": {"id": "c2"}, "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(1)}},
-                    {"action": "addMark", "markType": "comment", "attrs": {"id": "c2"}, "start": {"type": "before", "elemId": el(4)}, "end": {"type": "after", "elemId": el(4)}}])],
-    ]
+    docs = H.edge_case_docs()
     if not H.have_node():
         pytest.skip("node not installed")
     expected = H.oracle_apply(docs)
@@ -114,34 +85,11 @@ def test_edge_cases_against_oracle():
     assert expected[5][0]["spans"] == [] and expected[6][0]["spans"] == []
 
 
-def _unsynced_docs():
-    """Replicas that have NOT seen the same changes: every prefix of a replica log is itself a valid log.  The comment ids of
-    a document are ranked over all its replicas, so such a log uses ranks beyond its own number of comment ops."""
-    gen = _load("ptxgen_mini.json")
-    docs = []
-    for d in gen["docs"][:6]:
-        logs = []
-        for k, log in enumerate(d["logs"]):
-            for frac in (3, 2):
-                logs.append(log[: max(1, len(log) * (k + 1) // (frac * len(d["logs"])))])
-        logs.append(d["logs"][0])
-        docs.append(logs)
-    # two replicas that each know ONE comment the other has not seen
-    el = lambda i: "%d@a" % (i + 2)  # noqa: E731
-    base = _mini_doc([])
-    ca = {"actor": "b", "seq": 1, "deps": {"a": 2}, "startOp": 8, "ops": [{"opId": "8@b", "obj": "1@a", "action": "addMark", "markType": "comment", "attrs": {"id": "A"},
-                                                                             "start": {"type": "before", "elemId": el(0)}, "end": {"type": "after", "elemId": el(2)}}]}
-    cb = {"actor": "c", "seq": 1, "deps": {"a": 2}, "startOp": 8, "ops": [{"opId": "8@c", "obj": "1@a", "action": "addMark", "markType": "comment", "attrs": {"id": "B"},
-                                                                             "start": {"type": "before", "elemId": el(1)}, "end": {"type": "after", "elemId": el(4)}}]}
-    docs.append([base + [ca], base + [cb], base + [ca, cb], base + [cb, ca]])
-    return docs
-
-
 @pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
 def test_unsynced_replicas_with_different_comment_sets():
     """a replica that has seen only SOME of the document's comments still carries the document's comment
     ranks; its log must merge (the per-id tables are sized by the header's n_comment_ids, not by its comment-op count)."""
-    docs = _unsynced_docs()
+    docs = H.unsynced_docs()
     expected = H.oracle_apply(docs)
     batch = wire.encode_docs(docs)
     kc = batch.log_hdr["n_mark"][:, abi.MARK_COMMENT]
@@ -167,6 +115,24 @@ def test_unsynced_replicas_with_different_comment_sets():
     batch.log_hdr = bad
     res3 = H.emu_merge(batch)
     assert int(res3.logs["status"][l]) == abi.ERR_BAD_OP and (np.delete(res3.logs["status"], l) == 0).all()
+
+
+def test_edge_fixture_made_by_the_reference():
+    """tests/golden/edge_cases_ref.json (tests/make_edge_golden.py: the type-erased reference itself) pins the hand-written
+    logs for the GPU twins; here the emulation and — when node is present — the restated oracle are held against it."""
+    g = _load("edge_cases_ref.json")
+    docs = H.edge_case_docs()
+    batch = wire.encode_docs(docs)
+    res = H.emu_merge(batch)
+    for log, exp in enumerate(g["edge"]):
+        H.check_log(batch, res, log, exp[0])
+    b2 = wire.encode_docs([[H.huge_bucket_log()]])
+    H.check_log(b2, H.emu_merge(b2), 0, g["huge_bucket"][0][0])
+    if H.have_node():
+        live = H.oracle_apply(docs)
+        assert [[H.norm_spans(e["spans"]) for e in d] for d in live] == [[H.norm_spans(e["spans"]) for e in d] for d in g["edge"]]
+        live_u = H.oracle_apply(H.unsynced_docs(), patches=True)
+        assert json.loads(json.dumps(live_u, sort_keys=True)) == json.loads(json.dumps(g["unsynced"], sort_keys=True))
 
 
 def test_error_statuses_mirror_reference_throw_sites():
@@ -234,18 +200,7 @@ def test_log_header_census_paths():
 def test_huge_sibling_bucket_prepends(reverse):
     """70 inserts at index 0 (all children of HEAD: the bitmap-ranked bucket path) interleaved with children of
     other elements, deletes and a mark — against a live oracle run."""
-    ops = []
-    for k in range(70):
-        ops.append({"action": "set", "insert": True, "elemId": "_head", "value": "abcdefghij"[k % 10]})
-        if k % 7 == 0:
-            ops.append({"action": "set", "insert": True, "elemId": "3@a", "value": "X"})  # siblings under 'B': a medium bucket
-        if k % 9 == 0:
-            ops.append({"action": "set", "insert": True, "elemId": "5@a", "value": "y"})
-    for k in range(11):
-        ops.append({"action": "set", "insert": True, "elemId": "4@a", "value": "m"})  # 11 siblings: the PTX_G-lane path
-    ops.append({"action": "del", "elemId": "4@a"})
-    ops.append({"action": "addMark", "markType": "strong", "start": {"type": "before", "elemId": "2@a"}, "end": {"type": "endOfText"}})
-    log = _mini_doc(ops)
+    log = H.huge_bucket_log()
     batch = wire.encode_docs([[log]])
     res = H.emu_merge(batch, reverse=reverse)
     exp = H.oracle_apply([[log]])[0][0]

@@ -12,7 +12,8 @@ from peritext_amd import abi, canon, wire
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN_GEN = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json", "ptxgen_config4_600.json", "ptxgen_rich_700.json", "ptxgen_rich_2600.json"]
+GOLDEN_GEN = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json", "ptxgen_config4_600.json", "ptxgen_rich_700.json", "ptxgen_rich_2600.json",
+              "ptxgen_config5_8192.json", "ptxgen_mini_10actors.json"]
 
 
 @pytest.fixture(scope="module")

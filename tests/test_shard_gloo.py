@@ -32,19 +32,20 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("corrupt", [0, 1])
-def test_world_size_2_gloo_digest_allgather(corrupt):
+@pytest.mark.parametrize("corrupt,n_docs", [(0, 12), (1, 12), (1, 11)])
+def test_world_size_2_gloo_digest_allgather(corrupt, n_docs):
+    """n_docs = 11: the two ranks own 6 and 5 documents — unequal all-gather blocks (gathered padded, then compacted)."""
     fixture = "ptxgen_mini.json"  # 12 documents x 3 replicas
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(H.ROOT, "tests", "gloo_worker.py"), fixture, str(corrupt)]
+           os.path.join(H.ROOT, "tests", "gloo_worker.py"), fixture, str(corrupt), str(n_docs)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     p = subprocess.run(cmd, cwd=H.ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     rows = [json.loads(m) for m in re.findall(r"RESULT (\{[^{}]*\})", p.stdout)]  # two ranks may share a line
     assert sorted(r["rank"] for r in rows) == [0, 1]
-    n_docs = len(json.load(open(os.path.join(H.GOLDEN, fixture)))["docs"])
+    assert n_docs <= len(json.load(open(os.path.join(H.GOLDEN, fixture)))["docs"])
     for r in rows:
         assert r["world"] == 2 and r["total"] == n_docs
         assert r["converged"] == n_docs - corrupt  # every rank sees the same global count
-    assert sum(r["count"] for r in rows) == n_docs and {r["first"] for r in rows} == {0, n_docs // 2}
+    assert sum(r["count"] for r in rows) == n_docs and {r["first"] for r in rows} == {0, (n_docs + 1) // 2}
     assert sum(r["local_converged"] for r in rows) == n_docs - corrupt

@@ -29,7 +29,8 @@ def main():
             cols = [d[0] for d in cur.description]
             print("# columns: %s" % cols)
             namecol = "kernel_name" if "kernel_name" in cols else cols[0]
-            q = "select %s, counter_name, count(distinct dispatch_id), sum(value) from counters_collection where %s like 'ptx_merge%%' group by %s, counter_name" % (namecol, namecol, namecol)
+            like = "ptx_%" if "--all" in sys.argv else "ptx_merge%"
+            q = "select %s, counter_name, count(distinct dispatch_id), sum(value) from counters_collection where %s like '%s' group by %s, counter_name" % (namecol, namecol, like, namecol)
             for r in c.execute(q):
                 print("%-40s %-28s dispatches=%-5d sum=%.6g per_dispatch=%.6g" % (str(r[0])[:40], r[1], r[2], r[3], r[3] / max(r[2], 1)))
         except Exception as e:  # noqa: BLE001

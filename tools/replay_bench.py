@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the patch-stream replay (ptx_replay_kernel) on a PTXGEN batch (GPU box only).
-    python tools/replay_bench.py [--config config4] [--unique 8] [--docs 2048] [--check]
+    python tools/replay_bench.py [--config config4] [--docs 2048] [--check 2]
 Prints one JSON line: ops replayed per second, patches per second, kernel ms (HIP events inside the library)."""
 import argparse
 import json
@@ -13,32 +13,28 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import bench  # noqa: E402
-from peritext_amd import wire  # noqa: E402
+from peritext_amd import wire, workloads  # noqa: E402
 from peritext_amd.engine import Engine  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="config4")
-    ap.add_argument("--unique", type=int, default=8)
     ap.add_argument("--docs", type=int, default=2048)
     ap.add_argument("--ops", type=int, default=None)
-    ap.add_argument("--check", action="store_true", help="compare the streams of the unique documents with the oracle's")
+    ap.add_argument("--check", type=int, default=0, help="compare the streams of the first CHECK documents with the oracle's (needs node)")
     args = ap.parse_args()
-    docs = bench.gen_unique_docs(args.config, args.unique, 4242, ops=args.ops)
-    batch = wire.encode_docs([d["logs"] for d in docs])
-    copies = max(1, args.docs // args.unique)
+    c = workloads.gen_config(args.config, ops=args.ops)
     eng = Engine(0)
-    db = eng.upload(batch, copies=copies)
+    db, info = eng.generate(c["replicas"], c["ops_per_log"], c["mix"], c["mark_types"], args.docs, 4242, list_cap=2048)
     dr = eng.alloc_result(db)
     eng.merge(db, dr)
     eng.sync()
     t0 = time.time()
     pat = eng.replay_patches(db, dr)
     wall = time.time() - t0
-    n_logs = batch.n_logs * copies
-    ops = batch.counted_ops() * copies
+    n_logs = eng.n_logs(db)
+    ops = n_logs * c["ops_per_log"]
     n_pat = int(pat.logs["n_patches"].sum())
     bad = np.flatnonzero(pat.logs["status"] != 0)
     assert len(bad) == 0, "logs without a stream: %s status %s n_patches %s launches %d" % (bad[:8], pat.logs["status"][bad[:8]], pat.logs["n_patches"][bad[:8]], pat.launches)
@@ -47,8 +43,13 @@ def main():
            "wall_s_incl_download": wall}
     if args.check:
         import helpers as H
-        exp = H.oracle_apply([d["logs"] for d in docs], patches=True)
-        H.check_patch_streams(batch, pat, exp)  # the first copy of every unique document
+        hb, hinfo = eng.generate(c["replicas"], c["ops_per_log"], c["mix"], c["mark_types"], args.check, 4242, list_cap=2048)
+        actors_t, comments_t, log_doc_t = wire.generated_tables(args.check, c["replicas"], hinfo["n_comments"])
+        batch = eng.download_batch(hb, wire.GEN_VALUES, wire.GEN_URLS, log_doc_t, actors_t, comments_t)
+        eng.free_batch(hb)
+        docs_logs = [[wire.decode_changes(batch, d * c["replicas"] + r) for r in range(c["replicas"])] for d in range(args.check)]
+        exp = H.oracle_apply(docs_logs, patches=True)
+        H.check_patch_streams(batch, pat, exp)  # the first documents of the resident batch (same rows, same offsets)
         out["checked_logs"] = batch.n_logs
     print(json.dumps(out), flush=True)
     eng.free_result(dr)

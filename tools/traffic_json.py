@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Turn the two PMC passes of tools/pmc_traffic.sh into profiles/r02_hbm_traffic.json (what bench.py reports as roofline.traffic).
+FETCH_SIZE / WRITE_SIZE are in KB; the read side is calibrated on ptx_calib_stream_kernel, whose byte count is known."""
+import json
+import re
+import sys
+
+out = sys.argv[1]
+
+
+def per_dispatch(path, kernel, counter):
+    for line in open(path):
+        if line.startswith(kernel) and (" " + counter + " ") in line:
+            m = re.search(r"per_dispatch=([0-9.e+]+)", line)
+            return float(m.group(1))
+    return None
+
+
+run = None
+for line in open(out + "/fetch.log"):
+    if line.startswith("TRAFFIC_RUN "):
+        run = json.loads(line[len("TRAFFIC_RUN "):])
+f_merge = per_dispatch(out + "/fetch.txt", "ptx_merge_kernel", "FETCH_SIZE")
+f_calib = per_dispatch(out + "/fetch.txt", "ptx_calib_stream_kernel", "FETCH_SIZE")
+w_merge = per_dispatch(out + "/write.txt", "ptx_merge_kernel", "WRITE_SIZE")
+factor = run["calib_known_bytes"] / (f_calib * 1024.0)  # true bytes per counted byte on the read side
+fetch = f_merge * 1024.0 * factor
+write = w_merge * 1024.0
+print(json.dumps({
+    "n_logs": run["n_logs"], "rows": run["rows"], "n_changes": run["n_changes"],
+    "fetch_size_kb_per_launch": f_merge, "write_size_kb_per_launch": w_merge,
+    "calibration": {"kernel": "ptx_calib_stream_kernel", "known_bytes": run["calib_known_bytes"], "fetch_size_kb": f_calib, "true_bytes_per_counted_byte": factor},
+    "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
+    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over tools/traffic_run.py; read side calibrated on a known byte count",
+}))
