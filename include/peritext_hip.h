@@ -96,6 +96,7 @@ enum {
     PTX_ERR_DUPLICATE_OP = 4,    /* same opId twice in one log (the seq check makes this impossible upstream) */
     PTX_ERR_CAPACITY = 5,        /* log too large for the on-chip working set of this build */
     PTX_ERR_BAD_OP = 6,          /* malformed row: unknown action / mark type / comment id beyond the header's n_comment_ids */
+    PTX_ERR_INDEX_OOB = 7,       /* RangeError "List index out of bounds"    micromerge.ts:804 (ptx_change only) */
     /* call-level */
     PTX_ERR_INVALID_ARG = 100,
     PTX_ERR_HIP = 101,           /* a HIP runtime call failed; see ptx_last_error */
@@ -348,6 +349,46 @@ typedef struct ptx_gen_info {
  * included, ready for ptx_merge.  PTX_ERR_CAPACITY: some document outgrew list_cap (or the LDS). */
 ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** out, ptx_gen_info* info);
 void ptx_gen_info_free(ptx_gen_info* info);
+/* ---- change(): caller-supplied InputOperations made into Changes on the device ----
+ * Replaces `doc.change(ops: InputOperation[])` (micromerge.ts:308-441; InputOperation :133-148) for MANY replicas at once:
+ * log l of `base` is a replica's op log as applied so far, the InputOperations of log l are resolved against THAT replica's
+ * state (getListElementId incl. lookAfterTombstones :762-805, changeMark peritext.ts:458-501) into id-based ops and returned as
+ * new Changes {actor, seq = clock + 1, deps = the clock before, startOp = maxOp + 1, ops} — one Change per entry of chg_off.
+ * Columns (HOST pointers), one row per InputOperation:
+ *   action      PTX_IN_INSERT {index, values}   PTX_IN_DELETE {index, count}   PTX_IN_ADDMARK / PTX_IN_REMOVEMARK {startIndex,
+ *               endIndex, markType, attrs}      PTX_IN_MAKELIST {key: "text"} (only on a log without one)
+ *   index       insert / delete: index            marks: startIndex
+ *   count       insert: number of values          delete: count        marks: endIndex
+ *   payload     insert: position of its first value in `values`        link: url id        comment: doc-local comment id
+ *   mark_type   PTX_MARK_*
+ * `actor[l]` = actorRank of the replica behind log l (ranks as in the op ids of `base`).  Ids follow the tables of `base`: a new
+ * comment id must already have its rank (the caller encodes the document with the ids it is about to use). */
+enum { PTX_IN_INSERT = 0, PTX_IN_DELETE = 1, PTX_IN_ADDMARK = 2, PTX_IN_REMOVEMARK = 3, PTX_IN_MAKELIST = 4 };
+typedef struct ptx_input_ops {
+    uint32_t n_logs;            /* == logs of the base batch */
+    uint32_t max_actors;        /* actors of a document = row stride of the deps the new Changes carry (must equal the base
+                                   batch's when that carries the envelope) */
+    const uint64_t* chg_off;    /* [n_logs + 1] Changes to make per log (a log may make none) */
+    const uint64_t* op_off;     /* [n_changes + 1] InputOperations per Change */
+    const uint8_t* action;      /* [n_input_ops] PTX_IN_* */
+    const uint8_t* mark_type;   /* [n_input_ops] */
+    const uint32_t* index;      /* [n_input_ops] */
+    const uint32_t* count;      /* [n_input_ops] */
+    const uint32_t* payload;    /* [n_input_ops] */
+    const uint32_t* values;     /* [n_values] value ids of the inserts */
+    uint64_t n_values;
+    const uint32_t* actor;      /* [n_logs] */
+} ptx_input_ops;
+/* `merged` = ptx_merge of `base` WITH elem_rank, complete (the call synchronises).  *made = a resident batch of n_logs logs
+ * holding ONLY the new Changes (rows + envelope + headers), ready for ptx_batch_append_device / ptx_batch_download.
+ * status_out[l] (caller memory, [n_logs]): PTX_OK, the log's merge status (a broken replica cannot make changes),
+ * PTX_ERR_INDEX_OOB (the reference's RangeError, micromerge.ts:804), PTX_ERR_BAD_OP (no text list / a second makeList /
+ * unknown action) or PTX_ERR_CAPACITY; a failed log makes NO change (the reference leaves the replica half-mutated: the ops
+ * before the throw stay applied although no Change was returned — not reproduced). */
+ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* merged, const ptx_input_ops* in, ptx_dbatch** made, uint32_t* status_out);
+/* Streaming append with `more` already resident (e.g. the output of ptx_change): log l of *out = log l of `base` + log l of `more`. */
+ptx_status ptx_batch_append_device(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dbatch* more, ptx_dbatch** out);
+
 /* Copy a resident batch back to the host (columns, envelope, headers; library-owned until ptx_host_batch_free). */
 typedef struct ptx_host_batch {
     ptx_batch b;

@@ -14,6 +14,11 @@
  *       to a FRESH replica with applyChange (micromerge.ts:499) and flattened (peritext.ts:337).
  *       FILE out = {docs:[{expected:[{spans, text, error?}]}]}; --timing adds timing: {seconds, ops, logs} = the time spent in
  *       applyChange over every change + getTextWithFormatting of every log (the CPU-baseline leg of bench.py: whole logs)
+ *   node oracle/cli.js change --in FILE [--impl oracle|ref] --out FILE
+ *       FILE in  = {replicas:[{actor, log: Change[], calls: InputOperation[][]}]}: a replica `actor` is rebuilt from its log with
+ *       applyChange (its own changes included; `seq` is then set to its clock entry — a replica is never rebuilt like that
+ *       upstream), then every entry of `calls` is one doc.change(ops) (micromerge.ts:308).
+ *       FILE out = {replicas:[{changes: Change[], error?}]}
  *   node oracle/cli.js time  --in FILE [--impl oracle|ref] [--budget-ms T]
  *       CPU baseline: time applyChange over every change of every log + getTextWithFormatting, one log
  *       after another on this core until the budget is spent; prints one JSON line
@@ -134,6 +139,34 @@ if (cmd === "gen") {
     }
     if (argv.indexOf("--timing") >= 0) out.timing = timing
     fs.writeFileSync(flag("--out"), JSON.stringify(out))
+} else if (cmd === "change") {
+    const impl = flag("--impl", "oracle")
+    const Impl = implClass(impl)
+    const input = JSON.parse(fs.readFileSync(flag("--in"), "utf8"))
+    const out = { impl, replicas: [] }
+    const R = impl === "ref" ? require(path.join(__dirname, "_ref", "micromerge.js")) : null
+    for (const rep of input.replicas) {
+        const changes = []
+        try {
+            const doc = new Impl(rep.actor)
+            for (const c of rep.log) doc.applyChange(liveChange(O.normalizeChange(c), impl))
+            doc.seq = doc.clock[rep.actor] || 0
+            for (const ops of rep.calls) {
+                const r = doc.change(ops)
+                /* portable form: ROOT / HEAD as strings */
+                const c = JSON.parse(JSON.stringify(r.change))
+                r.change.ops.forEach((op, i) => {
+                    if (op.obj === O.ROOT || (R && op.obj === R.ROOT)) c.ops[i].obj = O.ROOT
+                    if (op.elemId === O.HEAD || (R && op.elemId === R.HEAD)) c.ops[i].elemId = O.HEAD
+                })
+                changes.push(c)
+            }
+            out.replicas.push({ changes })
+        } catch (e) {
+            out.replicas.push({ changes, error: (e instanceof RangeError ? "RangeError: " : "Error: ") + e.message })
+        }
+    }
+    fs.writeFileSync(flag("--out"), JSON.stringify(out))
 } else if (cmd === "time") {
     const impl = flag("--impl", "oracle")
     const Impl = implClass(impl)
@@ -172,6 +205,6 @@ if (cmd === "gen") {
     }
     console.log(JSON.stringify({ impl, logs, truncated_logs: truncated, ops, seconds: elapsed / 1e3, ops_per_s: ops / (elapsed / 1e3) }))
 } else {
-    console.error("usage: cli.js gen|apply|time ... (see header)")
+    console.error("usage: cli.js gen|apply|change|time ... (see header)")
     process.exit(2)
 }

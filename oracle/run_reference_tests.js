@@ -16,7 +16,13 @@
  * testConcurrentWrites case — these become tests/golden/kat_reference_tests.json, the golden
  * vectors the HIP path is checked against on the GPU box (where /root/reference does not exist).
  *
- * Usage: node oracle/run_reference_tests.js [--ref /root/reference] [--dump tests/golden/kat_reference_tests.json]
+ * With --dump-scripts <file> it records, per test case, every Micromerge.change(ops) / applyChange(change) call in call order:
+ * {replica, kind: "change", ops: InputOperation[], change: the Change it returned} | {replica, kind: "apply", change} —
+ * tests/golden/kat_change_scripts.json, the known answers of the on-device change() (ptx_change): made with --impl ref the
+ * Changes are the reference's own.
+ *
+ * Usage: node oracle/run_reference_tests.js [--ref /root/reference] [--impl oracle|ref] [--dump tests/golden/kat_reference_tests.json]
+ *                                           [--dump-scripts tests/golden/kat_change_scripts.json]
  * Exit code 0 iff every case passed.
  */
 const fs = require("fs")
@@ -34,6 +40,7 @@ function flag(name, dflt) {
 }
 const refRoot = flag("--ref", "/root/reference")
 const dumpPath = flag("--dump", null)
+const scriptsPath = flag("--dump-scripts", null)
 /* --impl oracle (default) | ref : `ref` binds the shims to the type-erased reference in oracle/_ref instead */
 const impl = flag("--impl", "oracle")
 const Impl = impl === "ref" ? require("./_ref/micromerge").default : O.Micromerge
@@ -84,6 +91,7 @@ function eraseTypes(src) {
 /* ---- shims ---- */
 const results = []
 const dump = []
+const scripts = []
 let current = null
 
 function wrapDoc(doc) {
@@ -91,14 +99,18 @@ function wrapDoc(doc) {
     const log = []
     const change0 = doc.change.bind(doc)
     const apply0 = doc.applyChange.bind(doc)
+    const me = current ? current.replicas.length : 0
+    const events = current ? current.events : []
     doc.change = ops => {
         const r = change0(ops)
         log.push(JSON.parse(JSON.stringify(r.change)))
+        events.push({ replica: me, kind: "change", ops: JSON.parse(JSON.stringify(ops)), change: JSON.parse(JSON.stringify(r.change)) })
         return r
     }
     doc.applyChange = c => {
         const r = apply0(c)
         log.push(JSON.parse(JSON.stringify(c)))
+        events.push({ replica: me, kind: "apply", change: JSON.parse(JSON.stringify(c)) })
         return r
     }
     if (current) current.replicas.push({ doc, log })
@@ -139,7 +151,7 @@ function describe(title, body) {
 describe.only = describe
 function it(title, body) {
     const full = prefix.concat([title]).join(" / ")
-    current = { title: full, replicas: [], spec: null }
+    current = { title: full, replicas: [], spec: null, events: [] }
     let ok = true
     let err = null
     try {
@@ -162,6 +174,7 @@ function it(title, body) {
             entry.replicas.push({ actor: r.doc.actorId, log: r.log, spans })
         }
         dump.push(entry)
+        scripts.push({ title: full, actors: current.replicas.map(r => r.doc.actorId), events: current.events, spans: entry.replicas.map(r => r.spans) })
     }
     current = null
 }
@@ -193,5 +206,16 @@ if (dumpPath && failed === 0) {
     }
     fs.writeFileSync(dumpPath, JSON.stringify(doc) + "\n")
     console.log("wrote " + dumpPath)
+}
+if (scriptsPath && failed === 0) {
+    const doc = {
+        generated_by: "oracle/run_reference_tests.js --dump-scripts" + (impl === "ref" ? " --impl ref" : ""),
+        impl,
+        source: "reference/test/micromerge.ts: every Micromerge.change(InputOperation[]) / applyChange call of every `it` case, in call order",
+        n_cases: scripts.length,
+        cases: scripts,
+    }
+    fs.writeFileSync(scriptsPath, JSON.stringify(doc) + "\n")
+    console.log("wrote " + scriptsPath)
 }
 process.exit(failed === 0 ? 0 : 1)

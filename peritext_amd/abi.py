@@ -36,6 +36,7 @@ ERR_MISSING_DEP = 3
 ERR_DUPLICATE_OP = 4
 ERR_CAPACITY = 5
 ERR_BAD_OP = 6
+ERR_INDEX_OOB = 7
 ERR_INVALID_ARG = 100
 ERR_HIP = 101
 ERR_NO_DEVICE = 102
@@ -49,6 +50,7 @@ STATUS_NAMES = {
     4: "duplicate opId",
     5: "log exceeds on-chip capacity",
     6: "malformed op row",
+    7: "RangeError: List index out of bounds",
 }
 
 
@@ -179,6 +181,27 @@ class ptx_gen_info(C.Structure):
     _fields_ = [("n_docs", C.c_uint32), ("kernel_ms", C.c_float), ("n_comments", u32p), ("owner", C.c_void_p)]
 
 
+# InputOperation.action of ptx_change (reference/src/micromerge.ts:133-148)
+IN_INSERT, IN_DELETE, IN_ADDMARK, IN_REMOVEMARK, IN_MAKELIST = range(5)
+
+
+class ptx_input_ops(C.Structure):
+    _fields_ = [
+        ("n_logs", C.c_uint32),
+        ("max_actors", C.c_uint32),
+        ("chg_off", u64p),
+        ("op_off", u64p),
+        ("action", u8p),
+        ("mark_type", u8p),
+        ("index", u32p),
+        ("count", u32p),
+        ("payload", u32p),
+        ("values", u32p),
+        ("n_values", C.c_uint64),
+        ("actor", u32p),
+    ]
+
+
 class ptx_host_batch(C.Structure):
     _fields_ = [("b", ptx_batch), ("owner", C.c_void_p)]
 
@@ -241,6 +264,8 @@ FUNCTIONS = {
     "ptx_patches_free": (None, [C.POINTER(ptx_patches)]),
     "ptx_generate": (C.c_int32, [vp, C.POINTER(ptx_gen_config), C.POINTER(vp), C.POINTER(ptx_gen_info)]),
     "ptx_gen_info_free": (None, [C.POINTER(ptx_gen_info)]),
+    "ptx_change": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_input_ops), C.POINTER(vp), u32p]),
+    "ptx_batch_append_device": (C.c_int32, [vp, vp, vp, C.POINTER(vp)]),
     "ptx_batch_download": (C.c_int32, [vp, vp, C.POINTER(ptx_host_batch)]),
     "ptx_host_batch_free": (None, [C.POINTER(ptx_host_batch)]),
     "ptx_max_ops_per_log": (C.c_uint32, [vp]),

@@ -1,0 +1,358 @@
+/*
+ * change_core.h — `Micromerge.change(InputOperation[])` on the device for CALLER-SUPPLIED input operations.
+ *
+ * What it replaces, per replica: `doc.change(ops)` (reference/src/micromerge.ts:308-441) — index-based
+ * InputOperations (:133-148: insert {index, values}, delete {index, count}, addMark / removeMark {startIndex, endIndex,
+ * markType, attrs}, makeList {key: "text"}) resolved against the replica's CURRENT state into id-based Operations:
+ *   insert  after the element at index-1, past the tombstones whose `after` slot is a defined one
+ *           (getListElementId with lookAfterTombstones, :762-805), one op per value, each after the previous (:335-345)
+ *   delete  `count` single deletes at the same visible index (:346-352)
+ *   marks   start = before(elem[startIndex]); end = endOfText / before(elem[endIndex]) for the inclusive types
+ *           (strong, em: schema.ts:45-96), after(elem[endIndex-1]) for link / comment  (changeMark, peritext.ts:458-501)
+ * every op applied locally at once (makeNewOp :483-493: opId = ++maxOp @ actor), the Change = {actor, seq = clock+1,
+ * deps = the clock before, startOp, ops}.  A bad index is the reference's RangeError "List index out of bounds" (:804).
+ *
+ * The replica's current state comes from its op log, already merged by ptx_merge_kernel: `elem_rank` gives every element's
+ * document position and tombstone flag; which `after` slots are defined ones (markOpsAfter !== undefined) follows from the
+ * mark ops of the log in closed form (applyAddRemoveMark's walk, peritext.ts:167-214: an op's end slot is written whenever its
+ * element exists — unless it is the very slot the op starts on —, its start slot unless the end was met first); the clock is
+ * the per-actor change count of the log's envelope; maxOp the largest counter of the log (Lamport, micromerge.ts:511).
+ *
+ * One 64-thread workgroup (one wave) per replica log, the element list in document order in LDS (one u32 per element:
+ * dense element index | tombstone | after-defined), sequential over the InputOperations — the list primitives are the
+ * 64-wide ballots of gen_core.h.  Compiled two ways like merge_core.h (hipcc: the product; g++ -DPTX_EMU: CPU tests).
+ */
+#pragma once
+#include "gen_core.h"
+
+#define PTX_CE_MASK 0x0000FFFFu /* element index inside a list word (bits 30 / 31: PTX_GK_DEAD / PTX_GK_AFTER) */
+
+struct PtxChangeArgs {
+    /* the base batch (resident) and its merge result */
+    const uint64_t* log_off;
+    const uint64_t* op_id;
+    const uint64_t* ref_a;
+    const uint64_t* ref_b;
+    const uint8_t* action;
+    const uint8_t* mark_type;
+    const uint8_t* side_a;
+    const uint8_t* side_b;
+    const ptx_log_hdr* log_hdr;
+    const ptx_log_result* res;
+    const uint32_t* elem_rank;
+    const uint64_t* chg_off;   /* base envelope: the replica's clock = changes per actor */
+    const uint32_t* chg_actor;
+    uint32_t max_actors;
+    /* the InputOperations: log l makes changes [in_chg_off[l], in_chg_off[l+1]); change c holds input ops [in_op_off[c], in_op_off[c+1]) */
+    const uint64_t* in_chg_off;
+    const uint64_t* in_op_off;
+    const uint8_t* in_action;
+    const uint8_t* in_mark_type;
+    const uint32_t* in_index;
+    const uint32_t* in_count;
+    const uint32_t* in_payload;
+    const uint32_t* in_values;
+    const uint32_t* actor;     /* [n_logs] actorRank of the replica behind log l */
+    /* output, capacity layout: log l owns rows [out_off[l], out_off[l+1]) and envelope rows [in_chg_off[l], in_chg_off[l+1]) */
+    const uint64_t* out_off;
+    uint64_t* o_op_id;
+    uint64_t* o_ref_a;
+    uint64_t* o_ref_b;
+    uint32_t* o_payload;
+    uint8_t* o_action;
+    uint8_t* o_mark_type;
+    uint8_t* o_side_a;
+    uint8_t* o_side_b;
+    uint32_t* o_chg_actor;
+    uint32_t* o_chg_seq;
+    uint32_t* o_chg_nops;
+    uint32_t* o_chg_deps;      /* stride max_actors */
+    uint32_t* status;          /* [n_logs] PTX_OK / PTX_ERR_* */
+    uint32_t* rows_made;       /* [n_logs] rows written (0 on error) */
+    uint32_t* chgs_made;       /* [n_logs] */
+    uint32_t n_logs;
+    uint32_t lds_bytes;
+};
+
+struct PtxChangeHdr {
+    uint32_t n;        /* list length incl. tombstones */
+    uint32_t vis;      /* visible length */
+    uint32_t max_op;
+    uint32_t rows;     /* rows written */
+    uint32_t has_list; /* the log holds the makeList of the text */
+    uint32_t err;
+    uint32_t scan_tmp[36];
+};
+
+/* LDS of one log: n elements now, `grow` inserts to come, id keyspace of ks bits, na actors */
+PTX_HD uint64_t ptx_change_lds_need(uint64_t n, uint64_t grow, uint64_t ks, uint64_t na) {
+    const uint64_t nw = (ks + 31) / 32, cap = n + grow + 64;
+    return ptx_a16(sizeof(PtxChangeHdr)) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (n + 1)) + 2 * ptx_a16(4 * cap) + ptx_a16(4 * (grow + 1)) + ptx_a16(4 * (na + 1));
+}
+
+template <uint32_t kThreads>
+PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) {
+    PtxChangeHdr* H = (PtxChangeHdr*)lds;
+    const uint64_t base = A.log_off[log];
+    const uint32_t N = (uint32_t)(A.log_off[log + 1] - base);
+    const uint64_t* op_id = A.op_id + base;
+    const uint32_t* erank = A.elem_rank + base;
+    const uint64_t ch0 = A.in_chg_off[log], ch1 = A.in_chg_off[log + 1];
+    const uint64_t out0 = A.out_off[log];
+    const uint32_t out_cap = (uint32_t)(A.out_off[log + 1] - out0);
+    const uint32_t me = A.actor[log], na = A.max_actors;
+
+#define PTX_CHANGE_FAIL(code_)                        \
+    do {                                              \
+        PTX_SYNC();                                   \
+        PTX_LEADER {                                  \
+            A.status[log] = (code_);                  \
+            A.rows_made[log] = 0;                     \
+            A.chgs_made[log] = 0;                     \
+        }                                             \
+        return;                                       \
+    } while (0)
+
+    if (ch1 == ch0) { /* nothing to do for this replica */
+        PTX_LEADER {
+            A.status[log] = PTX_OK;
+            A.rows_made[log] = 0;
+            A.chgs_made[log] = 0;
+        }
+        return;
+    }
+    const uint32_t merge_status = A.res[log].status;
+    if (merge_status != PTX_OK) PTX_CHANGE_FAIL(merge_status); /* the replica itself is broken: nothing can be built on it */
+    if (me >= na) PTX_CHANGE_FAIL(PTX_ERR_BAD_OP);
+
+    const ptx_log_hdr hd = A.log_hdr[log];
+    const uint32_t n0 = N ? hd.n_ins : 0u;
+    uint32_t grow = 0; /* list elements this call adds */
+    for (uint64_t q = A.in_op_off[ch0]; q < A.in_op_off[ch1]; ++q) grow += A.in_action[q] == PTX_IN_INSERT ? A.in_count[q] : 0u;
+    PtxElemIndex ix;
+    ix.max_ctr = N ? hd.max_counter : 0u;
+    ix.max_actor = N ? hd.max_actor : 0u;
+    ix.na1 = ix.max_actor + 1u;
+    const uint32_t keyspace = (ix.max_ctr + 1u) * ix.na1;
+    const uint32_t nw = (keyspace + 31) / 32;
+    const uint32_t cap = n0 + grow + 64u;
+    PtxBump bp;
+    bp.base = lds;
+    bp.off = (uint32_t)ptx_a16(sizeof(PtxChangeHdr));
+    bp.cap = A.lds_bytes;
+    bp.high = bp.off;
+    bp.overflow = false;
+    ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
+    uint16_t* row_of = ptx_alloc<uint16_t>(bp, n0 + 1);
+    uint32_t* L = ptx_alloc<uint32_t>(bp, cap);      /* document order: element index | PTX_GK_DEAD | PTX_GK_AFTER */
+    uint32_t* tmpbuf = ptx_alloc<uint32_t>(bp, cap);
+    uint32_t* newctr = ptx_alloc<uint32_t>(bp, grow + 1); /* counter of the j-th element made here (its index is n0 + j) */
+    uint32_t* clock = ptx_alloc<uint32_t>(bp, na + 1);
+    if (bp.overflow || ix.max_actor > 4095u || n0 + grow > 32766u || N > 65534u || ix.max_ctr + out_cap >= (1u << 19)) PTX_CHANGE_FAIL(PTX_ERR_CAPACITY);
+
+    /* ---- the replica's state from its merged log ---- */
+    PTX_FOR(w, nw + 1) {
+        PtxBitWord z;
+        z.bits = 0;
+        z.pre = 0;
+        ix.ib[w] = z;
+    }
+    PTX_FOR(a, na + 1) clock[a] = 0;
+    PTX_LEADER {
+        H->n = n0;
+        H->vis = N ? A.res[log].n_visible : 0u;
+        H->max_op = ix.max_ctr;
+        H->rows = 0;
+        H->has_list = 0;
+        H->err = 0;
+    }
+    PTX_SYNC();
+    PTX_FOR(i, N) {
+        const uint32_t a = A.action[base + i];
+        if (a == PTX_ACT_INSERT) {
+            uint32_t key = 0;
+            if (ptx_id_key(ix, op_id[i], key)) ptx_atomic_or(&ix.ib[key >> 5].bits, 1u << (key & 31));
+        } else if (a == PTX_ACT_MAKELIST) {
+            H->has_list = 1;
+        }
+    }
+    if (A.chg_off) {
+        const uint64_t c0 = A.chg_off[log], c1 = A.chg_off[log + 1];
+        PTX_FOR(c, (uint32_t)(c1 - c0)) {
+            const uint32_t a = A.chg_actor[c0 + c];
+            if (a < na) ptx_atomic_add(&clock[a], 1u);
+        }
+    }
+    PTX_SYNC();
+    PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
+    PTX_SYNC();
+    ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
+    PTX_FOR(i, N) {
+        if (A.action[base + i] == PTX_ACT_INSERT) {
+            const int e = ptx_elem_lookup(ix, op_id[i]);
+            if (e >= 0 && (uint32_t)e < n0) {
+                row_of[e] = (uint16_t)i;
+                const uint32_t rk = erank[i];
+                L[rk & PTX_RANK_MASK] = (uint32_t)e | ((rk & PTX_RANK_TOMBSTONE) ? PTX_GK_DEAD : 0u);
+            }
+        }
+    }
+    PTX_SYNC();
+    /* which `after` slots are defined ones: the walk of applyAddRemoveMark in closed form (positions never change once both
+     * elements exist, so final ranks decide "the end is met before the start") */
+    PTX_FOR(i, N) {
+        const uint32_t a = A.action[base + i];
+        if ((a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) && A.mark_type[base + i] < 4u) {
+            const uint32_t sa = A.side_a[base + i], sb = A.side_b[base + i];
+            int js = -1, je = -1;
+            if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
+                js = ptx_elem_lookup(ix, A.ref_a[base + i]);
+                if (js >= 0 && row_of[js] >= i) js = -1; /* not in the list when the op was applied */
+            }
+            if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
+                je = ptx_elem_lookup(ix, A.ref_b[base + i]);
+                if (je >= 0 && row_of[je] >= i) je = -1;
+            }
+            const uint32_t slot_a = js >= 0 ? 2u * (erank[row_of[js]] & PTX_RANK_MASK) + (sa == PTX_SIDE_AFTER ? 1u : 0u) : 0xFFFFFFFFu;
+            const uint32_t slot_b = je >= 0 ? 2u * (erank[row_of[je]] & PTX_RANK_MASK) + (sb == PTX_SIDE_AFTER ? 1u : 0u) : 0xFFFFFFFFu;
+            const bool end_first = je >= 0 && (js < 0 || slot_b < slot_a);
+            const bool start_written = js >= 0 && !end_first;
+            const bool end_written = je >= 0 && slot_b != slot_a;
+            if (start_written && (slot_a & 1u)) ptx_atomic_or(&L[slot_a >> 1], PTX_GK_AFTER);
+            if (end_written && (slot_b & 1u)) ptx_atomic_or(&L[slot_b >> 1], PTX_GK_AFTER);
+        }
+    }
+    PTX_SYNC();
+
+    /* id of the element behind a list word */
+#define PTX_CE_ID(word_) (((word_) & PTX_CE_MASK) < n0 ? op_id[row_of[(word_) & PTX_CE_MASK]] : (((uint64_t)newctr[((word_) & PTX_CE_MASK) - n0] << 32) | me))
+    /* one id-based op of the change under construction: row + local application bookkeeping */
+#define PTX_CE_EMIT(act_, mt_, ra_, rb_, sa_, sb_, pay_)                        \
+    do {                                                                        \
+        const uint32_t k_ = H->rows, ctr_ = H->max_op + 1u;                     \
+        PTX_SYNC();                                                             \
+        PTX_LEADER {                                                            \
+            if (k_ < out_cap) {                                                 \
+                const uint64_t at_ = out0 + k_;                                 \
+                A.o_op_id[at_] = ((uint64_t)ctr_ << 32) | me;                   \
+                A.o_ref_a[at_] = (ra_);                                         \
+                A.o_ref_b[at_] = (rb_);                                         \
+                A.o_payload[at_] = (pay_);                                      \
+                A.o_action[at_] = (uint8_t)(act_);                              \
+                A.o_mark_type[at_] = (uint8_t)(mt_);                            \
+                A.o_side_a[at_] = (uint8_t)(sa_);                               \
+                A.o_side_b[at_] = (uint8_t)(sb_);                               \
+            }                                                                   \
+            H->rows = k_ + 1u;                                                  \
+            H->max_op = ctr_;                                                   \
+        }                                                                       \
+        PTX_SYNC();                                                             \
+        ++nops;                                                                 \
+    } while (0)
+
+    uint32_t made = 0, new_elems = 0;
+    for (uint64_t c = ch0; c < ch1; ++c) {
+        /* the Change header: deps = the clock before the change, seq = own clock + 1 (micromerge.ts:314-327) */
+        const uint32_t seq = clock[me] + 1u;
+        PTX_SYNC();
+        PTX_FOR(b, na) A.o_chg_deps[c * na + b] = clock[b];
+        PTX_SYNC();
+        PTX_LEADER { clock[me] = seq; }
+        PTX_SYNC();
+        uint32_t nops = 0;
+        for (uint64_t q = A.in_op_off[c]; q < A.in_op_off[c + 1]; ++q) {
+            const uint32_t act = A.in_action[q], idx = A.in_index[q], cnt = A.in_count[q], pay = A.in_payload[q], mt = A.in_mark_type[q];
+            if (act == PTX_IN_MAKELIST) {
+                if (H->has_list) PTX_CHANGE_FAIL(PTX_ERR_BAD_OP); /* one text list per document */
+                PTX_CE_EMIT(PTX_ACT_MAKELIST, 0, 0ull, 0ull, 0, 0, 0u);
+                PTX_LEADER { H->has_list = 1; }
+                PTX_SYNC();
+                continue;
+            }
+            if (!H->has_list || act > PTX_IN_MAKELIST) PTX_CHANGE_FAIL(PTX_ERR_BAD_OP); /* "Child not found: text" / unknown action */
+            const uint32_t n = H->n, vis = H->vis;
+            if (act == PTX_IN_INSERT) {
+                uint64_t ref = 0;
+                uint32_t at = 0;
+                if (idx != 0u) {
+                    const uint32_t p = ptx_gen_select(L, n, idx - 1u);
+                    if (p == 0xFFFFFFFFu) PTX_CHANGE_FAIL(PTX_ERR_INDEX_OOB); /* micromerge.ts:804 */
+                    const uint32_t p2 = ptx_gen_after_tombstones(L, n, p);
+                    ref = PTX_CE_ID(L[p2]);
+                    at = p2 + 1u;
+                }
+                for (uint32_t v = 0; v < cnt; ++v) {
+                    /* the new element has the largest id of the replica: nothing to skip (micromerge.ts:630), it lands right after its reference */
+                    const uint32_t nn = H->n, tail = nn - at;
+                    PTX_GEN_FOR(i, tail) tmpbuf[i] = L[at + i];
+                    PTX_SYNC();
+                    PTX_GEN_FOR(i, tail) L[at + 1u + i] = tmpbuf[i];
+                    PTX_LEADER {
+                        L[at] = n0 + new_elems;
+                        newctr[new_elems] = H->max_op + 1u;
+                        H->n = nn + 1u;
+                        H->vis += 1u;
+                    }
+                    PTX_SYNC();
+                    PTX_CE_EMIT(PTX_ACT_INSERT, 0, ref, 0ull, 0, 0, A.in_values[pay + v]);
+                    ref = ((uint64_t)H->max_op << 32) | me;
+                    ++new_elems;
+                    ++at;
+                }
+            } else if (act == PTX_IN_DELETE) {
+                for (uint32_t v = 0; v < cnt; ++v) { /* always the same visible index (micromerge.ts:346-352) */
+                    const uint32_t p = ptx_gen_select(L, H->n, idx);
+                    if (p == 0xFFFFFFFFu) PTX_CHANGE_FAIL(PTX_ERR_INDEX_OOB);
+                    const uint64_t target = PTX_CE_ID(L[p]);
+                    PTX_LEADER {
+                        L[p] |= PTX_GK_DEAD;
+                        H->vis -= 1u;
+                    }
+                    PTX_SYNC();
+                    PTX_CE_EMIT(PTX_ACT_DELETE, 0, target, 0ull, 0, 0, 0u);
+                }
+            } else { /* changeMark (peritext.ts:458-501): idx = startIndex, cnt = endIndex */
+                if (mt > PTX_MARK_LINK) PTX_CHANGE_FAIL(PTX_ERR_BAD_OP);
+                const uint32_t ps = ptx_gen_select(L, n, idx);
+                if (ps == 0xFFFFFFFFu) PTX_CHANGE_FAIL(PTX_ERR_INDEX_OOB);
+                const uint64_t ra = PTX_CE_ID(L[ps]);
+                const bool inclusive = mt == PTX_MARK_STRONG || mt == PTX_MARK_EM; /* schema.ts:45-96 */
+                uint64_t rb = 0;
+                uint32_t sb = PTX_SIDE_END_OF_TEXT;
+                if (inclusive) {
+                    if (cnt < vis) {
+                        const uint32_t pe = ptx_gen_select(L, n, cnt);
+                        if (pe == 0xFFFFFFFFu) PTX_CHANGE_FAIL(PTX_ERR_INDEX_OOB);
+                        rb = PTX_CE_ID(L[pe]);
+                        sb = PTX_SIDE_BEFORE;
+                    }
+                } else {
+                    const uint32_t pe = cnt == 0u ? 0xFFFFFFFFu : ptx_gen_select(L, n, cnt - 1u); /* index -1 is out of bounds */
+                    if (pe == 0xFFFFFFFFu) PTX_CHANGE_FAIL(PTX_ERR_INDEX_OOB);
+                    rb = PTX_CE_ID(L[pe]);
+                    sb = PTX_SIDE_AFTER;
+                    PTX_LEADER { L[pe] |= PTX_GK_AFTER; } /* its end slot is a defined one from now on (peritext.ts:240) */
+                    PTX_SYNC();
+                }
+                PTX_CE_EMIT(act == PTX_IN_ADDMARK ? PTX_ACT_ADDMARK : PTX_ACT_REMOVEMARK, mt, ra, rb, PTX_SIDE_BEFORE, sb,
+                            (mt == PTX_MARK_COMMENT || (mt == PTX_MARK_LINK && act == PTX_IN_ADDMARK)) ? pay : 0u);
+            }
+        }
+        PTX_LEADER {
+            A.o_chg_actor[c] = me;
+            A.o_chg_seq[c] = seq;
+            A.o_chg_nops[c] = nops;
+        }
+        ++made;
+    }
+#undef PTX_CE_EMIT
+#undef PTX_CE_ID
+    PTX_SYNC();
+    if (H->rows != out_cap) PTX_CHANGE_FAIL(PTX_ERR_INVALID_ARG); /* the host sized the rows from the same InputOperations */
+    PTX_LEADER {
+        A.status[log] = PTX_OK;
+        A.rows_made[log] = H->rows;
+        A.chgs_made[log] = made;
+    }
+#undef PTX_CHANGE_FAIL
+}

@@ -22,6 +22,7 @@
 #include "merge_core.h"
 #include "replay_core.h"
 #include "gen_core.h"
+#include "change_core.h"
 
 /* ------------------------------------------------------------------------------------------------ */
 /* kernels                                                                                          */
@@ -55,6 +56,12 @@ extern "C" __global__ void __launch_bounds__(64) ptx_gen_kernel(PtxGenArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_docs) ptx_gen_doc<64>(A, blockIdx.x, ptx_lds);
 }
+/* change() for caller-supplied InputOperations (change_core.h): one 64-thread workgroup (one wave) per replica log */
+extern "C" __global__ void __launch_bounds__(64) ptx_change_kernel(PtxChangeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
+    if (blockIdx.x < A.n_logs) ptx_change_log<64>(A, blockIdx.x, ptx_lds);
+}
+
 /* envelope of a generated batch: capacity layout (rows_per_log entries per log) -> compact */
 __global__ void ptx_gen_compact_kernel(const uint64_t* chg_off, uint32_t rows_per_log, uint32_t R, const uint32_t* sa, const uint32_t* ss, const uint32_t* sn,
                                        const uint32_t* sd, uint32_t* da, uint32_t* ds, uint32_t* dn, uint32_t* dd) {
@@ -113,6 +120,26 @@ __global__ void ptx_append_rows_kernel(PtxAppendCols A, const uint64_t* a_off, c
         ptx_append_col(A.chg_nops, ac0, nac, B.chg_nops, bc0, nbc, D.chg_nops, dc0, 1);
         ptx_append_col(A.chg_deps, ac0, nac, B.chg_deps, bc0, nbc, D.chg_deps, dc0, (uint64_t)max_actors);
     }
+}
+
+/* the first rows[l] rows (chgs[l] envelope rows) of every log of a capacity-layout batch -> a compact batch */
+__global__ void ptx_take_rows_kernel(PtxAppendCols S, const uint64_t* s_off, const uint64_t* s_coff, const uint32_t* rows, const uint32_t* chgs, PtxAppendDst D,
+                                     const uint64_t* d_off, const uint64_t* d_coff, uint32_t max_actors) {
+    const uint32_t l = blockIdx.x;
+    const uint64_t s0 = s_off[l], d0 = d_off[l], nr = rows[l];
+    ptx_append_col(S.op_id, s0, nr, S.op_id, 0, 0, D.op_id, d0, 1);
+    ptx_append_col(S.ref_a, s0, nr, S.ref_a, 0, 0, D.ref_a, d0, 1);
+    ptx_append_col(S.ref_b, s0, nr, S.ref_b, 0, 0, D.ref_b, d0, 1);
+    ptx_append_col(S.payload, s0, nr, S.payload, 0, 0, D.payload, d0, 1);
+    ptx_append_col(S.action, s0, nr, S.action, 0, 0, D.action, d0, 1);
+    ptx_append_col(S.mark_type, s0, nr, S.mark_type, 0, 0, D.mark_type, d0, 1);
+    ptx_append_col(S.side_a, s0, nr, S.side_a, 0, 0, D.side_a, d0, 1);
+    ptx_append_col(S.side_b, s0, nr, S.side_b, 0, 0, D.side_b, d0, 1);
+    const uint64_t sc0 = s_coff[l], dc0 = d_coff[l], nc = chgs[l];
+    ptx_append_col(S.chg_actor, sc0, nc, S.chg_actor, 0, 0, D.chg_actor, dc0, 1);
+    ptx_append_col(S.chg_seq, sc0, nc, S.chg_seq, 0, 0, D.chg_seq, dc0, 1);
+    ptx_append_col(S.chg_nops, sc0, nc, S.chg_nops, 0, 0, D.chg_nops, dc0, 1);
+    ptx_append_col(S.chg_deps, sc0, nc, S.chg_deps, 0, 0, D.chg_deps, dc0, (uint64_t)max_actors);
 }
 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
@@ -446,7 +473,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel, (const void*)ptx_gen_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -633,31 +660,29 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
 
 ptx_status ptx_batch_upload(ptx_ctx* ctx, const ptx_batch* host, ptx_dbatch** out) { return ptx_batch_upload_tiled(ctx, host, 1, out); }
 
-ptx_status ptx_batch_append(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_batch* more, ptx_dbatch** out) {
-    if (!ctx || !base || !out) return PTX_ERR_INVALID_ARG;
+ptx_status ptx_batch_append_device(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dbatch* m, ptx_dbatch** out) {
+    if (!ctx || !base || !m || !out) return PTX_ERR_INVALID_ARG;
     *out = nullptr;
-    ptx_status st = check_batch(ctx, more);
-    if (st) return st;
-    if (more->n_logs != base->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_batch_append: `more` must have the logs of `base` (empty ones allowed)");
-    const bool env = base->chg_off != nullptr;
-    const bool more_env = more->chg_off && more->chg_actor && more->chg_seq && more->chg_nops && more->chg_deps && more->max_actors;
-    if (env != more_env || (env && more->max_actors != base->max_actors))
+    if (m->n_logs != base->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_batch_append: `more` must have the logs of `base` (empty ones allowed)");
+    /* a base without a single row has no envelope to speak of: it takes the one of `more` */
+    const bool base_env = base->chg_off != nullptr, more_env = m->chg_off != nullptr;
+    const bool env = more_env && (base_env || base->n_ops == 0);
+    if ((base_env && base->n_ops && !more_env) || (more_env && !env) || (env && base_env && base->n_changes && m->max_actors != base->max_actors))
         return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_batch_append: both batches carry the Change envelope with the same max_actors, or neither does");
-    ptx_dbatch* m = nullptr;
-    st = ptx_batch_upload(ctx, more, &m);
-    if (st) return st;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
     ptx_dbatch* b = new ptx_dbatch();
     b->n_logs = base->n_logs;
     b->n_ops = base->n_ops + m->n_ops;
-    b->max_actors = base->max_actors;
-    b->n_changes = env ? base->n_changes + m->n_changes : 0;
+    b->max_actors = env ? m->max_actors : 0;
+    b->n_changes = env ? (base_env ? base->n_changes : 0) + m->n_changes : 0;
     const uint64_t T = b->n_ops, NC = b->n_changes, L = b->n_logs;
+    uint64_t* zero_off = nullptr; /* stands in for the envelope offsets of an envelope-less empty base */
 #define PTX_TRYA(call)                                  \
     do {                                                \
         hipError_t _e = (call);                         \
         if (_e != hipSuccess) {                         \
             std::string msg = std::string(#call) + ": " + hipGetErrorString(_e); \
-            ptx_batch_free(ctx, m);                     \
+            (void)hipFree(zero_off);                    \
             ptx_batch_free(ctx, b);                     \
             return fail(ctx, _e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, msg); \
         }                                               \
@@ -678,16 +703,21 @@ ptx_status ptx_batch_append(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_batc
         PTX_TRYA(dalloc(&b->chg_seq, NC));
         PTX_TRYA(dalloc(&b->chg_nops, NC));
         PTX_TRYA(dalloc(&b->chg_deps, NC * b->max_actors + 4));
+        if (!base_env) {
+            PTX_TRYA(dalloc(&zero_off, L + 1));
+            PTX_TRYA(hipMemsetAsync(zero_off, 0, (L + 1) * 8, ctx->stream));
+        }
     }
     if (L) {
+        const uint64_t* base_coff = base_env ? base->chg_off : zero_off;
         const unsigned blocks = (unsigned)((L + 1 + 255) / 256);
         hipLaunchKernelGGL(ptx_append_offsets_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base->log_off, m->log_off, b->log_off, (uint32_t)L);
-        if (env) hipLaunchKernelGGL(ptx_append_offsets_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base->chg_off, m->chg_off, b->chg_off, (uint32_t)L);
+        if (env) hipLaunchKernelGGL(ptx_append_offsets_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base_coff, m->chg_off, b->chg_off, (uint32_t)L);
         PtxAppendCols A = {base->op_id, base->ref_a, base->ref_b, base->payload, base->action, base->mark_type, base->side_a, base->side_b,
                            base->chg_actor, base->chg_seq, base->chg_nops, base->chg_deps};
         PtxAppendCols B = {m->op_id, m->ref_a, m->ref_b, m->payload, m->action, m->mark_type, m->side_a, m->side_b, m->chg_actor, m->chg_seq, m->chg_nops, m->chg_deps};
         PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_actor, b->chg_seq, b->chg_nops, b->chg_deps};
-        hipLaunchKernelGGL(ptx_append_rows_kernel, dim3((unsigned)L), dim3(256), 0, ctx->stream, A, base->log_off, env ? base->chg_off : nullptr, B, m->log_off,
+        hipLaunchKernelGGL(ptx_append_rows_kernel, dim3((unsigned)L), dim3(256), 0, ctx->stream, A, base->log_off, env ? base_coff : nullptr, B, m->log_off,
                            env ? m->chg_off : nullptr, D, b->log_off, env ? b->chg_off : nullptr, b->max_actors);
         PTX_TRYA(hipGetLastError());
         PTX_TRYA(hipStreamSynchronize(ctx->stream));
@@ -697,14 +727,28 @@ ptx_status ptx_batch_append(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_batc
         PTX_TRYA(hipStreamSynchronize(ctx->stream));
     }
 #undef PTX_TRYA
-    ptx_batch_free(ctx, m);
-    st = census_and_shape(ctx, b, false);
+    (void)hipFree(zero_off);
+    const ptx_status st = census_and_shape(ctx, b, false);
     if (st != PTX_OK) {
         ptx_batch_free(ctx, b);
         return st;
     }
     *out = b;
     return PTX_OK;
+}
+
+ptx_status ptx_batch_append(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_batch* more, ptx_dbatch** out) {
+    if (!ctx || !base || !out) return PTX_ERR_INVALID_ARG;
+    *out = nullptr;
+    ptx_status st = check_batch(ctx, more);
+    if (st) return st;
+    if (more->n_logs != base->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_batch_append: `more` must have the logs of `base` (empty ones allowed)");
+    ptx_dbatch* m = nullptr;
+    st = ptx_batch_upload(ctx, more, &m);
+    if (st) return st;
+    st = ptx_batch_append_device(ctx, base, m, out);
+    ptx_batch_free(ctx, m);
+    return st;
 }
 
 ptx_status ptx_batch_wrap_device(ptx_ctx* ctx, const ptx_batch* d, ptx_dbatch** out) {
@@ -1330,6 +1374,217 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     *out = b;
     return PTX_OK;
 #undef PTX_TRYG
+}
+
+/* ---- change(): caller-supplied InputOperations ---- */
+ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* merged, const ptx_input_ops* in, ptx_dbatch** made, uint32_t* status_out) {
+    if (!ctx || !base || !merged || !in || !made || !status_out) return PTX_ERR_INVALID_ARG;
+    *made = nullptr;
+    const uint32_t L = base->n_logs;
+    if (in->n_logs != L) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: the InputOperations must name every log of the base batch (a log may make no change)");
+    if (merged->n_logs != L || merged->n_rows != base->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: `merged` is not the result of this batch");
+    if (!merged->rank) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change needs the elem_rank column (context created with PTX_FLAG_NO_ELEM_RANK)");
+    if (L && (!in->chg_off || !in->op_off || !in->actor)) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: chg_off / op_off / actor is NULL");
+    if (base->n_ops && !base->chg_off) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change needs the Change envelope of the base batch (the replicas' clocks)");
+    const uint32_t na = base->chg_off && base->n_changes ? base->max_actors : in->max_actors;
+    if (na == 0 || na > 4096u || (base->chg_off && base->n_changes && in->max_actors && in->max_actors != base->max_actors))
+        return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: max_actors must be 1..4096 and equal to the base batch's");
+    const uint64_t NC = L ? in->chg_off[L] : 0;
+    const uint64_t NI = NC ? in->op_off[NC] : 0;
+    if (L && in->chg_off[0] != 0) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: chg_off must start at 0");
+    for (uint32_t l = 0; l < L; ++l)
+        if (in->chg_off[l + 1] < in->chg_off[l]) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: chg_off decreases");
+    if (NC && in->op_off[0] != 0) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: op_off must start at 0");
+    for (uint64_t c = 0; c < NC; ++c)
+        if (in->op_off[c + 1] < in->op_off[c]) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: op_off decreases");
+    if (NI && (!in->action || !in->mark_type || !in->index || !in->count || !in->payload)) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: an InputOperation column is NULL");
+    /* rows every log will make (known up front: one per inserted value, per deleted element, per mark, per makeList) */
+    std::vector<uint64_t> out_off((size_t)L + 1, 0);
+    std::vector<uint32_t> grow(L, 0);
+    for (uint32_t l = 0; l < L; ++l) {
+        uint64_t rows = 0;
+        for (uint64_t q = in->op_off[in->chg_off[l]]; q < in->op_off[in->chg_off[l + 1]]; ++q) {
+            const uint8_t a = in->action[q];
+            if (a == PTX_IN_INSERT) {
+                if ((uint64_t)in->payload[q] + in->count[q] > in->n_values || (in->count[q] && !in->values)) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: an insert points outside `values`");
+                rows += in->count[q];
+                grow[l] += in->count[q];
+            } else if (a == PTX_IN_DELETE) rows += in->count[q];
+            else rows += 1;
+            if (rows > 65534u) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_change: more than 65534 ops for one log");
+        }
+        out_off[l + 1] = out_off[l] + rows;
+    }
+    const uint64_t T = out_off[L];
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    /* launch shape: the LDS of the largest working set among the logs that make a change */
+    std::vector<ptx_log_hdr> hdr(std::max<uint32_t>(L, 1));
+    std::vector<uint64_t> log_off((size_t)L + 1, 0);
+    if (L) {
+        PTX_HIP(ctx, hipMemcpyAsync(hdr.data(), base->log_hdr, (size_t)L * sizeof(ptx_log_hdr), hipMemcpyDeviceToHost, ctx->stream));
+        PTX_HIP(ctx, hipMemcpyAsync(log_off.data(), base->log_off, ((size_t)L + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    uint64_t need = 4096;
+    for (uint32_t l = 0; l < L; ++l)
+        if (in->chg_off[l + 1] > in->chg_off[l]) {
+            const bool rows = log_off[l + 1] > log_off[l];
+            const uint64_t ks = rows ? ((uint64_t)hdr[l].max_counter + 1) * ((uint64_t)std::min<uint32_t>(hdr[l].max_actor, 4095u) + 1) : 1;
+            need = std::max<uint64_t>(need, ptx_change_lds_need(rows ? hdr[l].n_ins : 0, grow[l], ks, na));
+        }
+    const uint32_t lds_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, ctx->max_lds); /* larger logs report PTX_ERR_CAPACITY */
+
+    ptx_dbatch* cap = new ptx_dbatch(); /* the kernel's capacity-layout output, owned here */
+    ptx_dbatch* b = nullptr;
+    uint64_t *d_in_chg = nullptr, *d_in_op = nullptr, *d_out_off = nullptr, *d_doff = nullptr, *d_dcoff = nullptr;
+    uint8_t *d_in_action = nullptr, *d_in_mt = nullptr;
+    uint32_t *d_in_index = nullptr, *d_in_count = nullptr, *d_in_payload = nullptr, *d_in_values = nullptr, *d_actor = nullptr, *d_status = nullptr, *d_rows = nullptr, *d_chgs = nullptr;
+    auto drop = [&]() {
+        ptx_batch_free(ctx, cap);
+        cap = nullptr;
+        for (void* p : {(void*)d_in_chg, (void*)d_in_op, (void*)d_out_off, (void*)d_doff, (void*)d_dcoff, (void*)d_in_action, (void*)d_in_mt, (void*)d_in_index, (void*)d_in_count,
+                        (void*)d_in_payload, (void*)d_in_values, (void*)d_actor, (void*)d_status, (void*)d_rows, (void*)d_chgs})
+            (void)hipFree(p);
+        d_in_chg = d_in_op = d_out_off = d_doff = d_dcoff = nullptr;
+        d_in_action = d_in_mt = nullptr;
+        d_in_index = d_in_count = d_in_payload = d_in_values = d_actor = d_status = d_rows = d_chgs = nullptr;
+    };
+#define PTX_TRYC(call)                                  \
+    do {                                                \
+        hipError_t _e = (call);                         \
+        if (_e != hipSuccess) {                         \
+            std::string msg = std::string(#call) + ": " + hipGetErrorString(_e); \
+            drop();                                     \
+            ptx_batch_free(ctx, b);                     \
+            return fail(ctx, _e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, msg); \
+        }                                               \
+    } while (0)
+    auto up = [&](auto** dst, const auto* src, uint64_t count) -> hipError_t {
+        hipError_t e = dalloc(dst, count);
+        if (e == hipSuccess && count) e = hipMemcpyAsync(*dst, src, count * sizeof(**dst), hipMemcpyHostToDevice, ctx->stream);
+        return e;
+    };
+    PTX_TRYC(up(&d_in_chg, in->chg_off, (uint64_t)L + 1));
+    PTX_TRYC(up(&d_in_op, in->op_off, NC + 1));
+    PTX_TRYC(up(&d_out_off, out_off.data(), (uint64_t)L + 1));
+    PTX_TRYC(up(&d_in_action, in->action, NI));
+    PTX_TRYC(up(&d_in_mt, in->mark_type, NI));
+    PTX_TRYC(up(&d_in_index, in->index, NI));
+    PTX_TRYC(up(&d_in_count, in->count, NI));
+    PTX_TRYC(up(&d_in_payload, in->payload, NI));
+    PTX_TRYC(up(&d_in_values, in->values, in->n_values));
+    PTX_TRYC(up(&d_actor, in->actor, L));
+    PTX_TRYC(dalloc(&d_status, L));
+    PTX_TRYC(dalloc(&d_rows, L));
+    PTX_TRYC(dalloc(&d_chgs, L));
+    PTX_TRYC(dalloc(&cap->op_id, T));
+    PTX_TRYC(dalloc(&cap->ref_a, T));
+    PTX_TRYC(dalloc(&cap->ref_b, T));
+    PTX_TRYC(dalloc(&cap->payload, T));
+    PTX_TRYC(dalloc(&cap->action, T));
+    PTX_TRYC(dalloc(&cap->mark_type, T));
+    PTX_TRYC(dalloc(&cap->side_a, T));
+    PTX_TRYC(dalloc(&cap->side_b, T));
+    PTX_TRYC(dalloc(&cap->chg_actor, NC));
+    PTX_TRYC(dalloc(&cap->chg_seq, NC));
+    PTX_TRYC(dalloc(&cap->chg_nops, NC));
+    PTX_TRYC(dalloc(&cap->chg_deps, NC * na + 4));
+    std::vector<uint32_t> rows_made(std::max<uint32_t>(L, 1)), chgs_made(std::max<uint32_t>(L, 1));
+    if (L) {
+        PtxChangeArgs A;
+        memset(&A, 0, sizeof(A));
+        A.log_off = base->log_off;
+        A.op_id = base->op_id;
+        A.ref_a = base->ref_a;
+        A.ref_b = base->ref_b;
+        A.action = base->action;
+        A.mark_type = base->mark_type;
+        A.side_a = base->side_a;
+        A.side_b = base->side_b;
+        A.log_hdr = base->log_hdr;
+        A.res = merged->logs;
+        A.elem_rank = merged->rank;
+        A.chg_off = base->chg_off;
+        A.chg_actor = base->chg_actor;
+        A.max_actors = na;
+        A.in_chg_off = d_in_chg;
+        A.in_op_off = d_in_op;
+        A.in_action = d_in_action;
+        A.in_mark_type = d_in_mt;
+        A.in_index = d_in_index;
+        A.in_count = d_in_count;
+        A.in_payload = d_in_payload;
+        A.in_values = d_in_values;
+        A.actor = d_actor;
+        A.out_off = d_out_off;
+        A.o_op_id = cap->op_id;
+        A.o_ref_a = cap->ref_a;
+        A.o_ref_b = cap->ref_b;
+        A.o_payload = cap->payload;
+        A.o_action = cap->action;
+        A.o_mark_type = cap->mark_type;
+        A.o_side_a = cap->side_a;
+        A.o_side_b = cap->side_b;
+        A.o_chg_actor = cap->chg_actor;
+        A.o_chg_seq = cap->chg_seq;
+        A.o_chg_nops = cap->chg_nops;
+        A.o_chg_deps = cap->chg_deps;
+        A.status = d_status;
+        A.rows_made = d_rows;
+        A.chgs_made = d_chgs;
+        A.n_logs = L;
+        A.lds_bytes = lds_bytes;
+        hipLaunchKernelGGL(ptx_change_kernel, dim3(L), dim3(64), lds_bytes, ctx->stream, A);
+        PTX_TRYC(hipGetLastError());
+        PTX_TRYC(hipMemcpyAsync(status_out, d_status, (size_t)L * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PTX_TRYC(hipMemcpyAsync(rows_made.data(), d_rows, (size_t)L * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PTX_TRYC(hipMemcpyAsync(chgs_made.data(), d_chgs, (size_t)L * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PTX_TRYC(hipStreamSynchronize(ctx->stream));
+    }
+    /* the batch of what was made: failed logs contribute nothing */
+    std::vector<uint64_t> doff((size_t)L + 1, 0), dcoff((size_t)L + 1, 0);
+    for (uint32_t l = 0; l < L; ++l) {
+        doff[l + 1] = doff[l] + rows_made[l];
+        dcoff[l + 1] = dcoff[l] + chgs_made[l];
+    }
+    b = new ptx_dbatch();
+    b->n_logs = L;
+    b->n_ops = doff[L];
+    b->max_actors = na;
+    b->n_changes = dcoff[L];
+    PTX_TRYC(up(&b->log_off, doff.data(), (uint64_t)L + 1));
+    PTX_TRYC(up(&b->chg_off, dcoff.data(), (uint64_t)L + 1));
+    PTX_TRYC(dalloc(&b->op_id, b->n_ops));
+    PTX_TRYC(dalloc(&b->ref_a, b->n_ops));
+    PTX_TRYC(dalloc(&b->ref_b, b->n_ops));
+    PTX_TRYC(dalloc(&b->payload, b->n_ops));
+    PTX_TRYC(dalloc(&b->action, b->n_ops));
+    PTX_TRYC(dalloc(&b->mark_type, b->n_ops));
+    PTX_TRYC(dalloc(&b->side_a, b->n_ops));
+    PTX_TRYC(dalloc(&b->side_b, b->n_ops));
+    PTX_TRYC(dalloc(&b->log_hdr, (uint64_t)L));
+    PTX_TRYC(dalloc(&b->chg_actor, b->n_changes));
+    PTX_TRYC(dalloc(&b->chg_seq, b->n_changes));
+    PTX_TRYC(dalloc(&b->chg_nops, b->n_changes));
+    PTX_TRYC(dalloc(&b->chg_deps, b->n_changes * na + 4));
+    if (L) {
+        PtxAppendCols S = {cap->op_id, cap->ref_a, cap->ref_b, cap->payload, cap->action, cap->mark_type, cap->side_a, cap->side_b,
+                           cap->chg_actor, cap->chg_seq, cap->chg_nops, cap->chg_deps};
+        PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_actor, b->chg_seq, b->chg_nops, b->chg_deps};
+        hipLaunchKernelGGL(ptx_take_rows_kernel, dim3(L), dim3(64), 0, ctx->stream, S, d_out_off, d_in_chg, d_rows, d_chgs, D, b->log_off, b->chg_off, na);
+        PTX_TRYC(hipGetLastError());
+        PTX_TRYC(hipStreamSynchronize(ctx->stream));
+    }
+#undef PTX_TRYC
+    drop();
+    const ptx_status st = census_and_shape(ctx, b, false);
+    if (st != PTX_OK) {
+        ptx_batch_free(ctx, b);
+        return st;
+    }
+    *made = b;
+    return PTX_OK;
 }
 
 struct ptx_host_batch_store {

@@ -127,6 +127,28 @@ class Engine:
         self._check(self.lib.ptx_batch_append(self.ctx, dbatch, C.byref(s), C.byref(h)))
         return h
 
+    def append_device(self, dbatch, more_dbatch):
+        """The same with `more` already resident (e.g. the batch Engine.change made)."""
+        h = C.c_void_p()
+        self._check(self.lib.ptx_batch_append_device(self.ctx, dbatch, more_dbatch, C.byref(h)))
+        return h
+
+    def change(self, dbatch, dresult, ops):
+        """Micromerge.change for many replicas at once (ptx_change): `ops` = wire.InputOps (index-based InputOperations per
+        log, grouped into the Changes to make) resolved against the replica states `dresult` = merge of `dbatch` holds.
+        Returns (resident batch of the new Changes only, status per log as a numpy array)."""
+        s = abi.ptx_input_ops()
+        s.n_logs, s.max_actors = len(ops.chg_off) - 1, ops.max_actors
+        p = lambda a, t: a.ctypes.data_as(t)  # noqa: E731
+        s.chg_off, s.op_off = p(ops.chg_off, abi.u64p), p(ops.op_off, abi.u64p)
+        s.action, s.mark_type = p(ops.action, abi.u8p), p(ops.mark_type, abi.u8p)
+        s.index, s.count, s.payload = p(ops.index, abi.u32p), p(ops.count, abi.u32p), p(ops.payload, abi.u32p)
+        s.values, s.n_values, s.actor = p(ops.values, abi.u32p), len(ops.values), p(ops.actor, abi.u32p)
+        status = np.zeros(max(s.n_logs, 1), dtype=np.uint32)
+        h = C.c_void_p()
+        self._check(self.lib.ptx_change(self.ctx, dbatch, dresult, C.byref(s), C.byref(h), status.ctypes.data_as(abi.u32p)))
+        return h, status[: s.n_logs]
+
     def free_batch(self, h):
         self.lib.ptx_batch_free(self.ctx, h)
 

@@ -130,10 +130,13 @@ def _pack(ctr, rank):
     return (int(ctr) << 32) | int(rank)
 
 
-def encode_docs(docs):
+def encode_docs(docs, extra_actors=None, extra_comments=None):
     """docs: list of docs; a doc is a list of replica logs; a replica log is a list of Change dicts.
 
     All replicas of a doc share actor ranks and comment-id ranks, so their digests are comparable.
+    extra_actors / extra_comments: per doc, actor names / comment ids that get a rank although no change of the batch uses them
+    yet (replicas about to make their first change, comment ids a later InputOperation will introduce: ranks are positions in
+    the document's sorted id list, so they must be reserved before the rows that use them are made).
     """
     values, value_ix = [], {}
     urls, url_ix = [], {}
@@ -159,6 +162,8 @@ def encode_docs(docs):
                             actors.add(split_op_id(ref)[1])
                     if op.get("markType") == "comment":
                         comments.add(op["attrs"]["id"])
+        actors.update((extra_actors or [[]] * len(docs))[d])
+        comments.update((extra_comments or [[]] * len(docs))[d])
         actor_list = sorted(actors, key=_u16key)
         arank = {a: i for i, a in enumerate(actor_list)}
         comment_list = sorted(comments, key=_u16key)
@@ -245,6 +250,81 @@ def encode_docs(docs):
 
 
 @dataclass
+class InputOps:
+    """Index-based InputOperations (reference/src/micromerge.ts:133-148) as the columns of ptx_input_ops: per log the Changes
+    to make, per Change its input ops."""
+
+    chg_off: np.ndarray
+    op_off: np.ndarray
+    action: np.ndarray
+    mark_type: np.ndarray
+    index: np.ndarray
+    count: np.ndarray
+    payload: np.ndarray
+    values: np.ndarray
+    actor: np.ndarray
+    max_actors: int
+
+
+def encode_input_ops(batch, per_log, actors):
+    """per_log[l] = list of change() calls of the replica behind log l, each a list of InputOperation dicts in the reference's
+    shape ({path, action: "insert", index, values} / {action: "delete", index, count} / {action: "addMark" | "removeMark",
+    startIndex, endIndex, markType, attrs?} / {path: [], action: "makeList", key: "text"}); actors[l] = that replica's actor id.
+    New inserted strings / urls extend batch.values / batch.urls; comment ids and actors must already have their rank in
+    `batch` (encode_docs(..., extra_actors=, extra_comments=))."""
+    value_ix = {v: i for i, v in enumerate(batch.values)}
+    url_ix = {u: i for i, u in enumerate(batch.urls)}
+    chg_off, op_off = [0], [0]
+    action, mark_type, index, count, payload, values, actor = [], [], [], [], [], [], []
+    for l, calls in enumerate(per_log):
+        d = batch.log_doc[l]
+        actor.append(batch.doc_actors[d].index(actors[l]))
+        crank = {c: i for i, c in enumerate(batch.doc_comments[d])}
+        for ops in calls:
+            for op in ops:
+                a = op["action"]
+                if a == "makeList":
+                    if list(op.get("path", [])) != [] or op.get("key") != "text":
+                        raise ValueError("only the text list of the root map is supported")
+                    row = (abi.IN_MAKELIST, 0, 0, 0, 0)
+                elif list(op.get("path", [])) != ["text"]:
+                    raise ValueError("Only the text list is supported: %r" % (op.get("path"),))
+                elif a == "insert":
+                    first = len(values)
+                    for v in op["values"]:
+                        if not isinstance(v, str):
+                            raise ValueError("Expected value inserted into text to be a string")
+                        if v not in value_ix:
+                            value_ix[v] = len(batch.values)
+                            batch.values.append(v)
+                        values.append(value_ix[v])
+                    row = (abi.IN_INSERT, 0, int(op["index"]), len(op["values"]), first)
+                elif a == "delete":
+                    row = (abi.IN_DELETE, 0, int(op["index"]), int(op["count"]), 0)
+                elif a in ("addMark", "removeMark"):
+                    mt = abi.MARK_NAMES.index(op["markType"])
+                    pl = 0
+                    if mt == abi.MARK_LINK and a == "addMark":
+                        u = op["attrs"]["url"]
+                        if u not in url_ix:
+                            url_ix[u] = len(batch.urls)
+                            batch.urls.append(u)
+                        pl = url_ix[u]
+                    elif mt == abi.MARK_COMMENT:
+                        pl = crank[op["attrs"]["id"]]
+                    row = (abi.IN_ADDMARK if a == "addMark" else abi.IN_REMOVEMARK, mt, int(op["startIndex"]), int(op["endIndex"]), pl)
+                else:
+                    raise ValueError("unsupported InputOperation action %r" % (a,))
+                for lst, v in zip((action, mark_type, index, count, payload), row):
+                    lst.append(v)
+            op_off.append(len(action))
+        chg_off.append(len(op_off) - 1)
+    u32 = lambda x: np.asarray(x, dtype=np.uint32)  # noqa: E731
+    return InputOps(np.asarray(chg_off, dtype=np.uint64), np.asarray(op_off, dtype=np.uint64), np.asarray(action, dtype=np.uint8), np.asarray(mark_type, dtype=np.uint8),
+                    u32(index), u32(count), u32(payload), u32(values), u32(actor), max(batch.max_actors, max((len(a) for a in batch.doc_actors), default=1)))
+
+
+@dataclass
 class Results:
     """Host view of a merge result: numpy arrays, row r of log l at log_off[l] + r."""
 
@@ -320,10 +400,11 @@ def split_batch(batch, first_changes):
     return out[0], out[1]
 
 
-def decode_changes(batch, log):
+def decode_changes(batch, log, text_obj=None):
     """Change[] of one log — the inverse of encode_docs for the ops of the text list (reference/src/micromerge.ts:60-71
     Change, :150-212 Operation, src/peritext.ts:25-65 mark ops), in the JSON-portable form of the traces
-    (ROOT / HEAD as "_root" / "_head").  Needs the Change envelope; ops on other objects (PTX_ACT_NOP) cannot be restored."""
+    (ROOT / HEAD as "_root" / "_head").  Needs the Change envelope; ops on other objects (PTX_ACT_NOP) cannot be restored.
+    text_obj: opId of the text list when the log does not hold its makeList (a batch of newly made Changes only)."""
     if batch.chg_off is None:
         raise ValueError("the batch carries no Change envelope")
     d = batch.log_doc[log]
@@ -335,7 +416,6 @@ def decode_changes(batch, log):
         v = int(v)
         return "%d@%s" % (v >> 32, actors[v & 0xFFFFFFFF])
 
-    text_obj = None
     out = []
     row = b0
     for c in range(c0, c1):

@@ -14,6 +14,7 @@ int ptx_emu_reverse = 0;
 #include "../../peritext_amd/csrc/merge_core.h"
 #include "../../peritext_amd/csrc/replay_core.h"
 #include "../../peritext_amd/csrc/gen_core.h"
+#include "../../peritext_amd/csrc/change_core.h"
 
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
                           uint32_t lds_bytes, int reverse, int admission);
@@ -148,5 +149,71 @@ extern "C" int ptx_emu_generate(PtxGenArgs* A, int reverse) {
     free(A->known);
     A->ctab = nullptr;
     A->known = nullptr;
+    return 0;
+}
+
+/* change() for caller-supplied InputOperations (change_core.h) over the merge results `res` / `rank` of the base batch;
+ * the caller allocates the capacity-layout output (out_off = rows per log, known from the InputOperations) */
+extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const ptx_input_ops* in, const uint64_t* out_off, uint64_t* o_op_id,
+                              uint64_t* o_ref_a, uint64_t* o_ref_b, uint32_t* o_payload, uint8_t* o_action, uint8_t* o_mark_type, uint8_t* o_side_a, uint8_t* o_side_b,
+                              uint32_t* o_chg_actor, uint32_t* o_chg_seq, uint32_t* o_chg_nops, uint32_t* o_chg_deps, uint32_t* status, uint32_t* rows_made,
+                              uint32_t* chgs_made, uint32_t lds_bytes, int reverse) {
+    PtxChangeArgs A;
+    memset(&A, 0, sizeof(A));
+    A.log_off = b->log_off;
+    A.op_id = b->op_id;
+    A.ref_a = b->ref_a;
+    A.ref_b = b->ref_b;
+    A.action = b->action;
+    A.mark_type = b->mark_type;
+    A.side_a = b->side_a;
+    A.side_b = b->side_b;
+    A.res = res;
+    A.elem_rank = rank;
+    A.chg_off = b->chg_off;
+    A.chg_actor = b->chg_actor;
+    A.max_actors = in->max_actors;
+    A.in_chg_off = in->chg_off;
+    A.in_op_off = in->op_off;
+    A.in_action = in->action;
+    A.in_mark_type = in->mark_type;
+    A.in_index = in->index;
+    A.in_count = in->count;
+    A.in_payload = in->payload;
+    A.in_values = in->values;
+    A.actor = in->actor;
+    A.out_off = out_off;
+    A.o_op_id = o_op_id;
+    A.o_ref_a = o_ref_a;
+    A.o_ref_b = o_ref_b;
+    A.o_payload = o_payload;
+    A.o_action = o_action;
+    A.o_mark_type = o_mark_type;
+    A.o_side_a = o_side_a;
+    A.o_side_b = o_side_b;
+    A.o_chg_actor = o_chg_actor;
+    A.o_chg_seq = o_chg_seq;
+    A.o_chg_nops = o_chg_nops;
+    A.o_chg_deps = o_chg_deps;
+    A.status = status;
+    A.rows_made = rows_made;
+    A.chgs_made = chgs_made;
+    A.n_logs = b->n_logs;
+    A.lds_bytes = lds_bytes;
+    ptx_log_hdr* hdr = (ptx_log_hdr*)calloc(b->n_logs ? b->n_logs : 1, sizeof(ptx_log_hdr));
+    for (uint32_t l = 0; l < b->n_logs; ++l) {
+        const uint64_t b0 = b->log_off[l], b1 = b->log_off[l + 1];
+        ptx_census_rows(b->op_id + b0, b->action + b0, b->mark_type + b0, b->payload + b0, b1 - b0, &hdr[l]);
+    }
+    A.log_hdr = hdr;
+    uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)lds_bytes + 64);
+    if (!lds) return 1;
+    ptx_emu_reverse = reverse;
+    for (uint32_t l = 0; l < b->n_logs; ++l) {
+        memset(lds, 0xA5, lds_bytes);
+        ptx_change_log<0>(A, l, lds);
+    }
+    free(lds);
+    free(hdr);
     return 0;
 }

@@ -61,6 +61,35 @@ def oracle_apply(docs_logs, impl="oracle", cursors=False, patches=False):
             return [d["expected"] for d in json.load(f)["docs"]]
 
 
+def oracle_change(docs_logs, calls, actors, impl="oracle"):
+    """doc.change(ops) on replicas rebuilt from their logs (oracle/cli.js change): calls[l] = list of change() calls of the
+    replica behind log l (document-major order), actors[l] its actor id.  Returns the Changes made, flat in log order (one list
+    entry per call); an error of the oracle is raised."""
+    reps, l = [], 0
+    for logs in docs_logs:
+        for log in logs:
+            reps.append({"actor": actors[l], "log": log, "calls": calls[l]})
+            l += 1
+    with tempfile.TemporaryDirectory() as td:
+        inp, out = os.path.join(td, "in.json"), os.path.join(td, "out.json")
+        with open(inp, "w") as f:
+            json.dump({"replicas": reps}, f)
+        run_node(["oracle/cli.js", "change", "--in", inp, "--impl", impl, "--out", out])
+        with open(out) as f:
+            res = json.load(f)["replicas"]
+    flat = []
+    for r in res:
+        if "error" in r:
+            raise RuntimeError(r["error"])
+        flat += r["changes"]
+    return flat
+
+
+def _load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
 def batch_struct(b):
     """ctypes ptx_batch pointing into the numpy columns of a wire.Batch (keep `b` alive)."""
     s = abi.ptx_batch()
@@ -140,6 +169,90 @@ def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=No
         off[1:] = np.cumsum(caps)
         rows = np.zeros(max(int(off[-1]), 1), dtype=abi.PATCH_DTYPE)
     return wire.Patches(patch_off=off, logs=logs, patches=rows, launches=launches)
+
+
+def input_ops_struct(ops):
+    s = abi.ptx_input_ops()
+    s.n_logs, s.max_actors = len(ops.chg_off) - 1, ops.max_actors
+    p = lambda a, t: a.ctypes.data_as(t)  # noqa: E731
+    s.chg_off, s.op_off = p(ops.chg_off, abi.u64p), p(ops.op_off, abi.u64p)
+    s.action, s.mark_type = p(ops.action, abi.u8p), p(ops.mark_type, abi.u8p)
+    s.index, s.count, s.payload = p(ops.index, abi.u32p), p(ops.count, abi.u32p), p(ops.payload, abi.u32p)
+    s.values, s.n_values, s.actor = p(ops.values, abi.u32p), len(ops.values), p(ops.actor, abi.u32p)
+    return s
+
+
+def rows_of_input_ops(ops):
+    """Rows every log will make: one per inserted value, per deleted element, per mark, per makeList."""
+    per_op = np.where(ops.action == abi.IN_INSERT, ops.count, np.where(ops.action == abi.IN_DELETE, ops.count, 1)).astype(np.uint64)
+    cum = np.concatenate([[0], np.cumsum(per_op)]).astype(np.uint64)
+    op_of_log = ops.op_off[ops.chg_off.astype(np.int64)].astype(np.int64)
+    return cum[op_of_log]
+
+
+def made_batch(batch, ops, cols, env, rows_made, chgs_made, out_off):
+    """Compact the capacity-layout output of a change() kernel into a wire.Batch of the new Changes (tables of `batch`)."""
+    n_logs = batch.n_logs
+    na = ops.max_actors
+    keep = np.concatenate([np.arange(int(out_off[l]), int(out_off[l]) + int(rows_made[l])) for l in range(n_logs)] + [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+    ckeep = np.concatenate([np.arange(int(ops.chg_off[l]), int(ops.chg_off[l]) + int(chgs_made[l])) for l in range(n_logs)] + [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+    log_off = np.zeros(n_logs + 1, dtype=np.uint64)
+    log_off[1:] = np.cumsum(rows_made[:n_logs].astype(np.uint64))
+    chg_off = np.zeros(n_logs + 1, dtype=np.uint64)
+    chg_off[1:] = np.cumsum(chgs_made[:n_logs].astype(np.uint64))
+    return wire.Batch(log_off, cols["op_id"][keep], cols["ref_a"][keep], cols["ref_b"][keep], cols["payload"][keep], cols["action"][keep], cols["mark_type"][keep],
+                      cols["side_a"][keep], cols["side_b"][keep], chg_off, env["chg_actor"][ckeep], env["chg_seq"][ckeep], env["chg_nops"][ckeep],
+                      env["chg_deps"].reshape(-1, na)[ckeep].reshape(-1), na, None, batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments)
+
+
+def emu_change(batch, res, ops, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB):
+    """change() for caller-supplied InputOperations through the host emulation of change_core.h (tests only):
+    (wire.Batch of the new Changes, status per log)."""
+    n_logs = batch.n_logs
+    out_off = rows_of_input_ops(ops)
+    T, NC, na = max(int(out_off[-1]), 1), max(int(ops.chg_off[-1]), 1), ops.max_actors
+    cols = {"op_id": np.zeros(T, np.uint64), "ref_a": np.zeros(T, np.uint64), "ref_b": np.zeros(T, np.uint64), "payload": np.zeros(T, np.uint32),
+            "action": np.zeros(T, np.uint8), "mark_type": np.zeros(T, np.uint8), "side_a": np.zeros(T, np.uint8), "side_b": np.zeros(T, np.uint8)}
+    env = {"chg_actor": np.zeros(NC, np.uint32), "chg_seq": np.zeros(NC, np.uint32), "chg_nops": np.zeros(NC, np.uint32), "chg_deps": np.zeros(NC * na, np.uint32)}
+    status, rows_made, chgs_made = (np.zeros(max(n_logs, 1), np.uint32) for _ in range(3))
+    lib = C.CDLL(lib_path)
+    lib.ptx_emu_change.restype = C.c_int
+    s, si = batch_struct(batch), input_ops_struct(ops)
+    vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    rc = lib.ptx_emu_change(C.byref(s), vp(res.logs), vp(res.elem_rank), C.byref(si), vp(out_off), vp(cols["op_id"]), vp(cols["ref_a"]), vp(cols["ref_b"]), vp(cols["payload"]),
+                            vp(cols["action"]), vp(cols["mark_type"]), vp(cols["side_a"]), vp(cols["side_b"]), vp(env["chg_actor"]), vp(env["chg_seq"]), vp(env["chg_nops"]),
+                            vp(env["chg_deps"]), vp(status), vp(rows_made), vp(chgs_made), C.c_uint32(lds_bytes), C.c_int(reverse))
+    assert rc == 0
+    return made_batch(batch, ops, cols, env, rows_made, chgs_made, out_off), status[:n_logs]
+
+
+def concat_batches(base, more):
+    """Host-side twin of ptx_batch_append: log l of the result = log l of `base` followed by log l of `more` (same tables)."""
+    rows, chgs = [], []
+    for l in range(base.n_logs):
+        rows += [("b", int(base.log_off[l]), int(base.log_off[l + 1])), ("m", int(more.log_off[l]), int(more.log_off[l + 1]))]
+        chgs += [("b", int(base.chg_off[l]), int(base.chg_off[l + 1])), ("m", int(more.chg_off[l]), int(more.chg_off[l + 1]))]
+    na = max(base.max_actors, more.max_actors)
+
+    def cat(name, parts, width=1, reshape=None):
+        out = []
+        for src, a, b in parts:
+            arr = getattr(base if src == "b" else more, name)
+            if reshape:
+                w = (base if src == "b" else more).max_actors
+                arr = arr.reshape(-1, w) if len(arr) else arr.reshape(0, w)
+                blk = np.zeros((b - a, na), dtype=np.uint32)
+                blk[:, :w] = arr[a:b]
+                out.append(blk.reshape(-1))
+            else:
+                out.append(arr[a:b])
+        return np.concatenate(out) if out else np.zeros(0)
+
+    log_off = base.log_off + more.log_off
+    chg_off = base.chg_off + more.chg_off
+    return wire.Batch(log_off.astype(np.uint64), cat("op_id", rows), cat("ref_a", rows), cat("ref_b", rows), cat("payload", rows), cat("action", rows), cat("mark_type", rows),
+                      cat("side_a", rows), cat("side_b", rows), chg_off.astype(np.uint64), cat("chg_actor", chgs), cat("chg_seq", chgs), cat("chg_nops", chgs),
+                      cat("chg_deps", chgs, reshape=True).astype(np.uint32), na, None, base.values, base.urls, base.log_doc, base.doc_actors, base.doc_comments)
 
 
 def mini_doc(ops_second_change, first_text="ABCDE"):
