@@ -21,8 +21,9 @@ One JSON line on stdout (rank 0):
   roofline.traffic  = HBM bytes per launch from the PMC counters of the same command (profiles/r02_hbm_traffic.json, made by
       tools/pmc_traffic.sh on the GPU box: separate --pmc passes for FETCH_SIZE / WRITE_SIZE, calibrated as
       MI355X_MICROARCH.md prescribes); null when that file does not describe this workload.
-  parity            = --check-docs random documents of the RESIDENT batch checked against the reference's own code run on the
-      host cores (decoded spans, raw rows, digests); the same host run is the cpu_baseline (whole logs, no truncation).
+  parity            = --check-docs random documents of the RESIDENT batch checked against the oracle run on the host cores on
+      WHOLE logs (decoded spans, raw rows, digests of the rows the timed launches wrote).
+  cpu_baseline      = the reference's own code (oracle/_ref) on the same sampled logs, one process per core, time-boxed.
 """
 import argparse
 import json
@@ -43,52 +44,83 @@ HBM_COPY_CEILING = 6.29e12
 OPS = {"config4": 4096, "config3": 1024, "config2": 256, "config5": 8192, "rich": 1024, "mini": 96}
 
 
-def reference_run(docs_logs, procs):
-    """Apply every replica log of `docs_logs` ([doc][replica] -> Change[]) with the reference's own code (oracle/_ref, types
-    erased; the restated oracle where that is absent) on the host cores: one node process per core, whole logs.
-    Returns (expected [doc][replica] -> {spans, text}, cpu_baseline dict)."""
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
+
+
+T0 = time.time()
+
+
+def _node_jobs(parts, extra, inputs):
+    """One node process per part: oracle/cli.js <extra...> --in part.json; returns the parsed outputs in part order."""
     node = shutil.which("node")
     if node is None:
         raise RuntimeError("bench.py needs node (the oracle runtime) on this box for the parity guard and the CPU baseline")
+    td = tempfile.mkdtemp(prefix="ptxref_")
+    jobs = []
+    for p, mine in enumerate(parts):
+        inp, out = os.path.join(td, "in%d.json" % p), os.path.join(td, "out%d.json" % p)
+        with open(inp, "w") as f:
+            json.dump({"docs": [{"logs": [inputs[d][r]]} for d, r in mine]}, f)
+        cmd = [node, os.path.join(ROOT, "oracle", "cli.js")] + extra + ["--in", inp]
+        if extra[0] == "apply":
+            jobs.append((subprocess.Popen(cmd + ["--out", out], cwd=ROOT), out))
+        else:
+            jobs.append((subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True), None))
+    outs = []
+    for pr, out in jobs:
+        if out is not None:
+            if pr.wait() != 0:
+                raise RuntimeError("oracle run failed")
+            with open(out) as f:
+                outs.append(json.load(f))
+        else:
+            o, _ = pr.communicate()
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+    shutil.rmtree(td, ignore_errors=True)
+    return outs
+
+
+def oracle_expected(docs_logs, procs):
+    """Expected {spans, text} of every replica log ([doc][replica] -> Change[]): whole logs through the oracle (oracle/
+    peritext_oracle.js, the restatement the test-suite pins against the reference; its Patch[] bookkeeping — a pure speed
+    switch — is off: the reference itself needs minutes per 4 096-op log), one node process per core."""
+    flat = [(d, r) for d in range(len(docs_logs)) for r in range(len(docs_logs[d]))]
+    procs = max(1, min(procs, len(flat)))
+    parts = [flat[p::procs] for p in range(procs)]
+    outs = _node_jobs(parts, ["apply", "--impl", "oracle", "--no-patches"], docs_logs)
+    expected = [[None] * len(logs) for logs in docs_logs]
+    for mine, o in zip(parts, outs):
+        for (d, r), e in zip(mine, o["docs"]):
+            expected[d][r] = e["expected"][0]
+    return expected
+
+
+def cpu_baseline(docs_logs, budget_s, procs):
+    """The reference's own code (oracle/_ref, types erased; the restated oracle where that is absent) timed on the host cores:
+    applyChange over the changes of a replica log + getTextWithFormatting, one node process per core, each on its own log of
+    the sampled documents, each stopping after `budget_s` (a whole 4 096-op log takes the reference minutes)."""
     impl = "ref" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "micromerge.js")) else "oracle"
     flat = [(d, r) for d in range(len(docs_logs)) for r in range(len(docs_logs[d]))]
     procs = max(1, min(procs, len(flat)))
-    td = tempfile.mkdtemp(prefix="ptxref_")
-    jobs = []
+    parts = [flat[p::procs] for p in range(procs)]
     t0 = time.time()
-    for p in range(procs):
-        mine = flat[p::procs]
-        inp, out = os.path.join(td, "in%d.json" % p), os.path.join(td, "out%d.json" % p)
-        with open(inp, "w") as f:
-            json.dump({"docs": [{"logs": [docs_logs[d][r]]} for d, r in mine]}, f)
-        cmd = [node, os.path.join(ROOT, "oracle", "cli.js"), "apply", "--in", inp, "--impl", impl, "--timing", "--out", out]
-        jobs.append((subprocess.Popen(cmd, cwd=ROOT), mine, out))
-    expected = [[None] * len(logs) for logs in docs_logs]
-    rates, ops, secs = [], 0, 0.0
-    for pr, mine, out in jobs:
-        if pr.wait() != 0:
-            raise RuntimeError("reference run failed")
-        with open(out) as f:
-            o = json.load(f)
-        for (d, r), e in zip(mine, o["docs"]):
-            expected[d][r] = e["expected"][0]
-        t = o["timing"]
-        ops += t["ops"]
-        secs += t["seconds"]
-        if t["seconds"] > 0:
-            rates.append(t["ops"] / t["seconds"])
+    rows = _node_jobs(parts, ["time", "--impl", impl, "--budget-ms", str(int(budget_s * 1000))], docs_logs)
     wall = time.time() - t0
-    shutil.rmtree(td, ignore_errors=True)
-    cpu = {
-        "value": float(sum(rates)),
+    ops = sum(r["ops"] for r in rows)
+    whole = sum(r["logs"] for r in rows)
+    cut = sum(r.get("truncated_logs", 0) for r in rows)
+    per_core = [r["ops_per_s"] for r in rows if r["seconds"] > 0]
+    return {
+        "value": float(sum(per_core)),
         "unit": "ops/s",
-        "cores": procs,
+        "cores": len(rows),
         "kind": "reference" if impl == "ref" else "port",
-        "per_core_ops_per_s": float(np.mean(rates)) if rates else 0.0,
-        "sample": "%d whole replica logs (%d ops) of %d documents drawn at random from the resident batch: applyChange over every change + "
-                  "getTextWithFormatting, one node process per core, %.1f s wall (%.1f core-seconds)" % (len(flat), ops, len(docs_logs), wall, secs),
+        "per_core_ops_per_s": float(np.mean(per_core)) if per_core else 0.0,
+        "sample": "%d whole + %d deadline-truncated replica logs (%d ops) of documents drawn at random from the resident batch: applyChange over every "
+                  "change + getTextWithFormatting, one node process per core, %.0f s budget each, %.1f s wall; the per-op cost GROWS along a log, so "
+                  "truncated logs OVERSTATE the CPU rate (a whole 4 096-op log takes the reference ~4 min)" % (whole, cut, ops, budget_s, wall),
     }
-    return expected, cpu
 
 
 def load_traffic(n_logs, rows):
@@ -114,7 +146,8 @@ def main():
     ap.add_argument("--ops", type=int, default=None, help="override ops per log (debug only; makes the number non-BASELINE)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--check-docs", type=int, default=64, help="random documents of the resident batch checked against the reference on the host")
-    ap.add_argument("--cpu-procs", type=int, default=0, help="host processes of the reference run (0 = one per core)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="host processes of the oracle / reference runs (0 = one per core)")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="seconds every process of the cpu_baseline leg runs the reference")
     ap.add_argument("--no-cpu", action="store_true", help="skip the reference run: no parity guard against the oracle, no cpu_baseline")
     ap.add_argument("--no-admission", action="store_true", help="skip applyChange's causal admission (seq/deps) in the timed path")
     ap.add_argument("--sustain-s", type=float, default=5.0, help="extra leg: back-to-back steps for at least this many seconds (clocks / thermals)")
@@ -154,6 +187,7 @@ def main():
     replicas = gcfg["replicas"]
 
     # ---- the workload, made on the device: on-device change() (ptx_generate), every document of every rank distinct ----
+    log("generating %d documents on the device" % n_docs)
     t_gen = time.time()
     db, gen_info = eng.generate(*gen_args, n_docs, args.seed, first_doc=first_doc, list_cap=args.list_cap)
     t_gen = time.time() - t_gen
@@ -207,9 +241,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("warmup")
     for _ in range(args.warmup):
         step(False)
     fence()
+    log("timed region: %d steps" % args.steps)
     t0 = time.perf_counter()
     kernel_ms = [step(True) for _ in range(args.steps)]
     fence()
@@ -224,6 +260,7 @@ def main():
 
     # ---- sustained leg: the same step back to back for >= --sustain-s seconds (is the rate a cold-boost burst?) ----
     sustained = None
+    log("sustained leg")
     if args.sustain_s > 0:
         n_sus = max(args.steps, int(args.sustain_s / max(elapsed / args.steps, 1e-6)) + 1)
         if world > 1:
@@ -248,6 +285,7 @@ def main():
     if stream is not None:
         eng.set_stream(0)
 
+    log("checks")
     # ---- every log ok, every document converged ----
     logs = eng.download_logs(dr, n_logs)
     assert int(logs["status"].max()) == 0, "a log failed"
@@ -274,13 +312,16 @@ def main():
                 eng.free_batch(hb)
                 ones.append(one)
                 docs_logs.append([wire.decode_changes(one, r) for r in range(replicas)])
-            expected, cpu = reference_run(docs_logs, args.cpu_procs or cores)
+            log("parity guard: %d documents through the oracle on the host" % len(pick))
+            expected = oracle_expected(docs_logs, args.cpu_procs or cores)
             for d, one, exp in zip(pick, ones, expected):
                 sub = eng.download_range(db, dr, d * replicas, replicas)  # the rows the timed launches wrote for this document
                 for r in range(replicas):
                     helpers.check_log(one, sub, r, exp[r])
-            parity = {"documents_checked": len(pick), "replica_logs_checked": len(pick) * replicas, "against": cpu["kind"],
+            parity = {"documents_checked": len(pick), "replica_logs_checked": len(pick) * replicas, "against": "oracle/peritext_oracle.js (whole logs)",
                       "what": "decoded spans, raw value/span/comment-interval rows and 128-bit digests of the resident batch's result rows"}
+            log("cpu baseline: the reference on the host cores, %.0f s" % args.cpu_budget_s)
+            cpu = cpu_baseline(docs_logs, args.cpu_budget_s, args.cpu_procs or cores)
 
         # ---- roofline: B_alg = sum over logs of 32*N + 4*V + 8*S + 16*T + 16 ----
         V, S, T = int(logs["n_visible"].sum()), int(logs["n_spans"].sum()), int(logs["n_cintervals"].sum())

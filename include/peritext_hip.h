@@ -82,6 +82,12 @@ enum { PTX_SIDE_BEFORE = 0, PTX_SIDE_AFTER = 1, PTX_SIDE_START_OF_TEXT = 2, PTX_
 #define PTX_ATTR_COMMENT 0x80000000u /* key `comment` present (possibly []) */
 #define PTX_ATTR_ID_MASK 0x0fffffffu
 
+/* Change envelope: chg_hdr word and chg_env row stride (u16 entries, a multiple of 4 so that rows are 8-byte aligned) */
+#define PTX_CHG_ACTOR_SHIFT 20u
+#define PTX_CHG_NOPS 0x000FFFFFu
+#define PTX_ENV_STRIDE(max_actors) ((1u + (uint32_t)(max_actors) + 3u) & ~3u)
+#define PTX_ENV_SATURATED 65535u
+
 /* elem_rank: bit 31 marks a tombstone, the low 31 bits are the document position */
 #define PTX_RANK_TOMBSTONE 0x80000000u
 #define PTX_RANK_MASK 0x7fffffffu
@@ -140,14 +146,14 @@ typedef struct ptx_batch {
     /* optional causal envelope (Change headers, micromerge.ts:60-71); NULL = skip causal admission.
      * When present (host batches: ptx_batch_upload / ptx_apply_materialize) the kernel admits every change
      * exactly like applyChange (micromerge.ts:499-511): seq == clock[actor] + 1 (PTX_ERR_SEQ_GAP) and
-     * clock[a] >= deps[a] for all a (PTX_ERR_MISSING_DEP), 24 + 4*max_actors extra bytes read per change.
-     * chg_off[l]..chg_off[l+1]-1 are the changes of log l in application order. */
+     * clock[a] >= deps[a] for all a (PTX_ERR_MISSING_DEP); 4 + 2 * PTX_ENV_STRIDE(max_actors) extra bytes are read per
+     * change (12 B up to three actors).  chg_off[l]..chg_off[l+1]-1 are the changes of log l in application order. */
     const uint64_t* chg_off;   /* [n_logs + 1] or NULL */
-    const uint32_t* chg_actor; /* [n_changes] actorRank */
-    const uint32_t* chg_seq;   /* [n_changes] */
-    const uint32_t* chg_nops;  /* [n_changes] ops in the change (consecutive rows of the log) */
-    const uint32_t* chg_deps;  /* [n_changes * max_actors] deps[actorRank] (0 = none) */
-    uint32_t max_actors;       /* row stride of chg_deps */
+    const uint32_t* chg_hdr;   /* [n_changes] actorRank << PTX_CHG_ACTOR_SHIFT | ops in the change (consecutive rows of the log) */
+    const uint16_t* chg_env;   /* [n_changes * PTX_ENV_STRIDE(max_actors)] one row per change: seq, deps[0 .. max_actors) (0 = none),
+                                  zero padding.  16-bit: a log holds at most 65 533 changes; larger values saturate at 65 535, which
+                                  can never be admitted — the same RangeError as the true value */
+    uint32_t max_actors;       /* actors of a document (deps entries per change) */
     uint32_t reserved2;
     const ptx_log_hdr* log_hdr; /* [n_logs] or NULL (the library computes it) */
 } ptx_batch;
@@ -170,7 +176,9 @@ typedef struct ptx_log_result {
     uint32_t n_visible;     /* rows of `values` */
     uint32_t n_spans;       /* rows of `spans` */
     uint32_t n_cintervals;  /* rows of `cintervals` */
-    uint32_t reserved[2];
+    uint32_t reserved[2];   /* [0] diagnostic: LDS bytes the log needed; [1] on a per-row failure (status 1-4, 6): the row of the log at
+                               which the reference's sequential replay would have thrown (the first op of the change for seq / deps
+                               failures), else 0xffffffff */
     uint64_t digest[2];
 } ptx_log_result;
 

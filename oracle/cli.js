@@ -9,7 +9,7 @@
  *                            [--impl oracle|ref] --out FILE
  *       PTXGEN traces + expected output.  FILE = {config, seed, docs:[{docIndex, seed, actors,
  *       logs:[Change[] per replica], expected:[{spans, text} per replica]}]}
- *   node oracle/cli.js apply --in FILE [--impl oracle|ref] [--cursors] [--patches] [--timing] --out FILE
+ *   node oracle/cli.js apply --in FILE [--impl oracle|ref] [--cursors] [--patches] [--timing] [--no-patches] --out FILE
  *       FILE in  = {docs:[{logs:[Change[]...]}]} (e.g. a reference trace or a KAT);  every log is applied
  *       to a FRESH replica with applyChange (micromerge.ts:499) and flattened (peritext.ts:337).
  *       FILE out = {docs:[{expected:[{spans, text, error?}]}]}; --timing adds timing: {seconds, ops, logs} = the time spent in
@@ -51,7 +51,9 @@ function liveChange(change, impl) {
 }
 
 function applyLog(Impl, impl, log, patchSink) {
-    const doc = new Impl("oracle-reader")
+    /* --no-patches: the oracle's pure speed switch (opts.patches === false skips the Patch[] bookkeeping, not a single state
+       transition); the reference has no such switch and ignores it */
+    const doc = argv.indexOf("--no-patches") >= 0 && impl !== "ref" ? new Impl("oracle-reader", { patches: false }) : new Impl("oracle-reader")
     for (const c of log) {
         const patches = doc.applyChange(liveChange(O.normalizeChange(c), impl))
         /* the makeList patch is the raw op (incl. a Symbol obj in the reference): keep only its action */

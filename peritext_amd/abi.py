@@ -55,12 +55,23 @@ STATUS_NAMES = {
 
 
 
+CHG_ACTOR_SHIFT = 20
+CHG_NOPS = 0x000FFFFF
+ENV_SATURATED = 65535
+
+
+def env_stride(max_actors):
+    """u16 entries of one chg_env row (PTX_ENV_STRIDE): seq + deps[max_actors], padded to a multiple of 4."""
+    return (1 + int(max_actors) + 3) & ~3
+
+
 def envelope_bytes(n_changes, max_actors):
-    """Bytes of the Change envelope the admission phase reads: chg_actor, chg_seq, chg_nops (u32 each) + a chg_deps row."""
-    return n_changes * (12 + 4 * max_actors)
+    """Bytes of the Change envelope the admission phase reads: chg_hdr (u32) + one chg_env row (u16 x env_stride) per change."""
+    return n_changes * (4 + 2 * env_stride(max_actors))
 
 
 u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 
@@ -92,10 +103,8 @@ class ptx_batch(C.Structure):
         ("side_a", u8p),
         ("side_b", u8p),
         ("chg_off", u64p),
-        ("chg_actor", u32p),
-        ("chg_seq", u32p),
-        ("chg_nops", u32p),
-        ("chg_deps", u32p),
+        ("chg_hdr", u32p),
+        ("chg_env", u16p),
         ("max_actors", C.c_uint32),
         ("reserved2", C.c_uint32),
         ("log_hdr", C.POINTER(ptx_log_hdr)),

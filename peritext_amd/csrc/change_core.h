@@ -41,7 +41,7 @@ struct PtxChangeArgs {
     const ptx_log_result* res;
     const uint32_t* elem_rank;
     const uint64_t* chg_off;   /* base envelope: the replica's clock = changes per actor */
-    const uint32_t* chg_actor;
+    const uint32_t* chg_hdr;
     uint32_t max_actors;
     /* the InputOperations: log l makes changes [in_chg_off[l], in_chg_off[l+1]); change c holds input ops [in_op_off[c], in_op_off[c+1]) */
     const uint64_t* in_chg_off;
@@ -63,10 +63,8 @@ struct PtxChangeArgs {
     uint8_t* o_mark_type;
     uint8_t* o_side_a;
     uint8_t* o_side_b;
-    uint32_t* o_chg_actor;
-    uint32_t* o_chg_seq;
-    uint32_t* o_chg_nops;
-    uint32_t* o_chg_deps;      /* stride max_actors */
+    uint32_t* o_chg_hdr;
+    uint16_t* o_chg_env;       /* rows of PTX_ENV_STRIDE(max_actors) */
     uint32_t* status;          /* [n_logs] PTX_OK / PTX_ERR_* */
     uint32_t* rows_made;       /* [n_logs] rows written (0 on error) */
     uint32_t* chgs_made;       /* [n_logs] */
@@ -179,7 +177,7 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
     if (A.chg_off) {
         const uint64_t c0 = A.chg_off[log], c1 = A.chg_off[log + 1];
         PTX_FOR(c, (uint32_t)(c1 - c0)) {
-            const uint32_t a = A.chg_actor[c0 + c];
+            const uint32_t a = A.chg_hdr[c0 + c] >> PTX_CHG_ACTOR_SHIFT;
             if (a < na) ptx_atomic_add(&clock[a], 1u);
         }
     }
@@ -255,7 +253,8 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
         /* the Change header: deps = the clock before the change, seq = own clock + 1 (micromerge.ts:314-327) */
         const uint32_t seq = clock[me] + 1u;
         PTX_SYNC();
-        PTX_FOR(b, na) A.o_chg_deps[c * na + b] = clock[b];
+        const uint32_t es = PTX_ENV_STRIDE(na);
+        PTX_FOR(b, es - 1u) A.o_chg_env[c * es + 1u + b] = (uint16_t)(b < na ? (clock[b] < PTX_ENV_SATURATED ? clock[b] : PTX_ENV_SATURATED) : 0u);
         PTX_SYNC();
         PTX_LEADER { clock[me] = seq; }
         PTX_SYNC();
@@ -339,9 +338,8 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
             }
         }
         PTX_LEADER {
-            A.o_chg_actor[c] = me;
-            A.o_chg_seq[c] = seq;
-            A.o_chg_nops[c] = nops;
+            A.o_chg_hdr[c] = (me << PTX_CHG_ACTOR_SHIFT) | nops;
+            A.o_chg_env[c * es] = (uint16_t)(seq < PTX_ENV_SATURATED ? seq : PTX_ENV_SATURATED);
         }
         ++made;
     }

@@ -54,10 +54,8 @@ struct PtxGenArgs {
     uint8_t* mark_type;
     uint8_t* side_a;
     uint8_t* side_b;
-    uint32_t* chg_actor;
-    uint32_t* chg_seq;
-    uint32_t* chg_nops;
-    uint32_t* chg_deps;   /* stride R */
+    uint32_t* chg_hdr;    /* actor << PTX_CHG_ACTOR_SHIFT | nops */
+    uint16_t* chg_env;    /* rows of PTX_ENV_STRIDE(R) u16: seq, deps[R] */
     uint32_t* n_changes;  /* [n_docs * R] */
     uint32_t* n_comments; /* [n_docs] comment ids "comment-0" .. "comment-(C-1)" the document uses */
     uint32_t* status;     /* [n_docs] PTX_OK / PTX_ERR_CAPACITY */
@@ -288,10 +286,9 @@ struct PtxGenDoc {
         const uint32_t k = H->chgs[r], nops = c.nops_start >> 24;
         if (PTX_LANE0 && k < A.rows_per_log) {
             const uint64_t at = log_base(r) + k;
-            A.chg_actor[at] = actor;
-            A.chg_seq[at] = seq;
-            A.chg_nops[at] = nops;
-            for (uint32_t b = 0; b < A.R; ++b) A.chg_deps[at * A.R + b] = ptx_gen_dep(c, b);
+            const uint32_t es = PTX_ENV_STRIDE(A.R);
+            A.chg_hdr[at] = (actor << PTX_CHG_ACTOR_SHIFT) | nops;
+            for (uint32_t b = 0; b < es; ++b) A.chg_env[at * es + b] = (uint16_t)(b == 0 ? seq : b <= A.R ? ptx_gen_dep(c, b - 1u) : 0u);
             H->chgs[r] = k + 1u;
         }
         PTX_SYNC();

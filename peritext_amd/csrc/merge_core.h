@@ -233,7 +233,7 @@ PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl
 #define PTX_INA(i0, u) PTX_IN(i0, u)
 #define PTX_IXA(i0, u) PTX_IX(i0, u)
 #ifndef PTX_AC
-#define PTX_AC 2u /* consecutive changes per lane and step in the admission pass */
+#define PTX_AC 4u /* consecutive changes per lane and step in the admission pass (one 16-byte load of headers, two of envelope rows) */
 #endif
 #ifndef PTX_UM
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
@@ -260,10 +260,8 @@ struct PtxMergeArgs {
     const uint8_t* side_b;
     /* causal envelope (optional: chg_off == nullptr skips causal admission) */
     const uint64_t* chg_off;
-    const uint32_t* chg_actor;
-    const uint32_t* chg_seq;
-    const uint32_t* chg_nops;
-    const uint32_t* chg_deps;
+    const uint32_t* chg_hdr;  /* actor << 20 | nops */
+    const uint16_t* chg_env;  /* rows of PTX_ENV_STRIDE(max_actors) u16: seq, deps[...] */
     const ptx_log_hdr* log_hdr; /* [n_logs] per-log census (always present: the host computes it when the caller did not) */
     ptx_log_result* res;
     uint32_t* out_values;
@@ -350,6 +348,14 @@ PTX_DEV void ptx_reduce_add64(unsigned long long* dst, unsigned long long v) {
 #else
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(dst, v);
+#endif
+}
+PTX_DEV void ptx_reduce_add32(uint32_t* dst, uint32_t v) { /* every lane of the wave calls it: one LDS atomic per wave */
+#ifdef PTX_EMU
+    *dst += v;
+#else
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
 #endif
 }
 PTX_DEV void ptx_reduce_max32(uint32_t* dst, uint32_t v) {
@@ -517,7 +523,7 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
 /* the same from a log header */
 /* P0 scratch on top of the header: per-actor table starts + the (actor, seq) -> change table */
 PTX_HD uint64_t ptx_lds_need_admission(uint64_t n_changes, uint64_t max_actors) {
-    if (max_actors <= 4) return ptx_a16(sizeof(PtxHdr)) + 2 * ptx_a16(4 * (1024 / 64 + 2)); /* the carried vector clock: per-wave totals */
+    if (max_actors <= 3) return ptx_a16(sizeof(PtxHdr)) + 2 * ptx_a16(4 * (1024 / 64 + 2)); /* the carried vector clock: per-wave totals */
     return ptx_a16(sizeof(PtxHdr)) + ptx_a16(4 * (max_actors + 2)) + ptx_a16(2 * (n_changes + 1));
 }
 PTX_HD uint64_t ptx_lds_need_hdr(uint64_t N, const ptx_log_hdr& h) {
@@ -556,7 +562,9 @@ PTX_DEV void ptx_write_result(const PtxMergeArgs& A, uint32_t log, PtxHdr* H, ui
         r.n_spans = status ? 0 : H->S;
         r.n_cintervals = status ? 0 : H->I;
         r.reserved[0] = lds_high; /* LDS bytes this log needed (diagnostic; tests bound it by ptx_lds_need) */
-        r.reserved[1] = 0;
+        /* the row at which a sequential replay would have thrown (first op of the change for seq / deps failures) */
+        const uint32_t ew = H->err < H->adm ? H->err : H->adm;
+        r.reserved[1] = status && ew != PTX_NO_ERR ? ew >> 5 : 0xFFFFFFFFu;
         r.digest[0] = status ? 0 : (uint64_t)H->h1;
         r.digest[1] = status ? 0 : (uint64_t)H->h2;
         A.res[log] = r;
@@ -728,56 +736,81 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
     /* ---- P0: causal admission (micromerge.ts:499-511), when the batch carries the Change envelope ----
      * Sequential rule: change c of actor a is admitted iff seq == clock[a] + 1 and clock[b] >= deps[b] for all b,
-     * where clock[b] counts the changes of b applied before c.  Closed form over the whole log: per actor the seqs
-     * are exactly 1, 2, ... in log order, and every dependency (b, d) names a change of b that sits EARLIER in the
-     * log.  tbl[first[a] + seq - 1] = index of that change makes both tests one LDS read each. */
+     * where clock[b] counts the changes of b applied before c.  Envelope per change: chg_hdr = actor << 20 | nops and one
+     * chg_env row of u16 {seq, deps[0 .. max_actors)} (values saturate at 65535: a log holds at most 65533 changes, so a
+     * saturated value can never be admitted — the same error as the true one). */
     if (A.chg_off) {
         const uint64_t c0 = A.chg_off[log];
         const uint64_t C64 = A.chg_off[log + 1] - c0;
         const uint32_t na = A.max_actors;
-        if (C64 > 65534u || na == 0u || na > 4096u) {
+        if (C64 > 65533u || na == 0u || na > 4096u) {
             lds_high = bp.high;
-            return C64 > 65534u ? PTX_ERR_CAPACITY : PTX_ERR_BAD_OP;
+            return C64 > 65533u ? PTX_ERR_CAPACITY : PTX_ERR_BAD_OP;
         }
         const uint32_t C = (uint32_t)C64;
-        const uint32_t* c_actor = A.chg_actor + c0;
-        const uint32_t* c_seq = A.chg_seq + c0;
-        const uint32_t* c_nops = A.chg_nops + c0;
-        const uint32_t* c_deps = A.chg_deps + c0 * na;
+        const uint32_t estride = PTX_ENV_STRIDE(na);
+        const uint32_t* c_hdr = A.chg_hdr + c0;
+        const uint16_t* c_env = A.chg_env + c0 * estride;
         /* first row of change c, only needed to place an error: the reference throws at the first failing change */
-#define PTX_CHANGE_ROW(c_, row_)                                  \
-    do {                                                          \
-        uint32_t r_ = 0;                                          \
-        for (uint32_t q_ = 0; q_ < (c_); ++q_) r_ += c_nops[q_];  \
-        (row_) = r_ < 65535u ? r_ : 65535u;                       \
+#define PTX_CHANGE_ROW(c_, row_)                                              \
+    do {                                                                      \
+        uint32_t r_ = 0;                                                      \
+        for (uint32_t q_ = 0; q_ < (c_); ++q_) r_ += c_hdr[q_] & PTX_CHG_NOPS; \
+        (row_) = r_ < 65535u ? r_ : 65535u;                                   \
     } while (0)
-        if (na <= 4u) {
-            /* Up to four actors (the usual case): the vector clock itself is carried along the log.  Every WAVE owns
-             * a contiguous segment of the changes and walks it 64 changes at a time (coalesced loads); inside a step
-             * the clock before each change is a DPP prefix sum of one-hot counts, 16 bits per actor (actors 0,1 in one
-             * word, 2,3 in the other: no carries, a log has < 65535 changes); the clock before a wave's segment is
-             * the sum of the earlier waves' totals.  seq == clock[actor] + 1 and deps[b] <= clock[b]
-             * (micromerge.ts:501-509) are then plain compares. */
+        if (na <= 3u) {
+            /* Up to three actors (the usual case; envelope rows of 8 bytes): the vector clock itself is carried along the log.  Every WAVE owns a
+             * contiguous segment of the changes and walks it 64 * PTX_AC changes at a time, PTX_AC consecutive changes per
+             * lane, read with 16-byte loads (4 headers / 2 envelope rows each); inside a step the clock before each change
+             * is a DPP prefix sum of one-hot counts, 16 bits per actor (actors 0,1 in one word, 2,3 in the other); the
+             * clock before a wave's segment is the sum of the earlier waves' totals (pass A: headers only).  seq ==
+             * clock[actor] + 1 and deps[b] <= clock[b] (micromerge.ts:501-509) are then plain compares (pass B). */
             uint32_t* wt01 = ptx_alloc<uint32_t>(bp, PTX_MAX_THREADS / 64 + 2);
             uint32_t* wt23 = ptx_alloc<uint32_t>(bp, PTX_MAX_THREADS / 64 + 2);
             PTX_BAIL_CAPACITY();
             PTX_LEADER { H->cur[7] = 0; }
             PTX_SYNC();
             const uint32_t nwv_ = PTX_NWAVES;
-            const uint32_t step = PTX_WS * PTX_AC; /* changes per wave and step: PTX_AC consecutive changes per lane */
+            const uint32_t step = PTX_WS * PTX_AC; /* changes per wave and step */
             const uint32_t seg = ((C + nwv_ - 1u) / nwv_ + step - 1u) / step * step; /* changes per wave, whole steps */
+            /* PTX_AC consecutive headers / envelope rows of a lane; indices past `hi` are clamped, their effects masked.
+             * The library pads its copies of both columns, so the 16-byte loads may run past the last change. */
+#ifdef PTX_EMU
+#define PTX_ADM_HDRS(dst_, cl_) \
+    for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) dst_[u_] = c_hdr[(cl_) + u_ < C ? (cl_) + u_ : C - 1u];
+#define PTX_ADM_ENVS(dst_, cl_)                                                              \
+    for (uint32_t u_ = 0; u_ < PTX_AC; ++u_)                                                 \
+        for (uint32_t b_ = 0; b_ < 4u; ++b_) dst_[u_][b_] = c_env[(uint64_t)((cl_) + u_ < C ? (cl_) + u_ : C - 1u) * 4u + b_];
+#else
+#define PTX_ADM_HDRS(dst_, cl_)                                                              \
+    {                                                                                        \
+        struct __attribute__((packed, aligned(4))) PtxH4 { uint32_t v[PTX_AC]; };            \
+        const PtxH4 q_ = *(const PtxH4*)(c_hdr + (cl_));                                     \
+        _Pragma("unroll") for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) dst_[u_] = q_.v[u_];      \
+    }
+#define PTX_ADM_ENVS(dst_, cl_)                                                              \
+    {                                                                                        \
+        struct __attribute__((packed, aligned(4))) PtxE4 { uint16_t v[PTX_AC][4]; };         \
+        const PtxE4 q_ = *(const PtxE4*)(c_env + (uint64_t)(cl_) * 4u);                      \
+        _Pragma("unroll") for (uint32_t u_ = 0; u_ < PTX_AC; ++u_)                           \
+            _Pragma("unroll") for (uint32_t b_ = 0; b_ < 4u; ++b_) dst_[u_][b_] = q_.v[u_][b_]; \
+    }
+#endif
+            /* pass A: per-wave totals of changes per actor, rows per log, actor range */
             PTX_FOR_WAVE(w, lane) {
                 const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
                 uint32_t t01 = 0, t23 = 0, rows = 0, badc = 0xFFFFFFFFu;
-#pragma nounroll
+#pragma unroll 2
                 for (uint32_t cb = lo; cb < hi; cb += step) {
+                    uint32_t h[PTX_AC];
+                    const uint32_t cl = cb + lane * PTX_AC;
+                    PTX_ADM_HDRS(h, cl < hi ? cl : hi - 1u)
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
-                        const uint32_t c = cb + lane * PTX_AC + u;
-                        const bool in = c < hi;
-                        const uint32_t a = c_actor[in ? c : hi - 1u], no = c_nops[in ? c : hi - 1u];
-                        rows += in ? no : 0u;
-                        if (in && a >= na) badc = c < badc ? c : badc;
+                        const bool in = cl + u < hi;
+                        const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
+                        rows += in ? h[u] & PTX_CHG_NOPS : 0u;
+                        if (in && a >= na) badc = cl + u < badc ? cl + u : badc;
                         t01 += in && a < 2u ? 1u << (16u * a) : 0u;
                         t23 += in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
                     }
@@ -788,7 +821,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     wt01[w] = t01;
                     wt23[w] = t23;
                 }
-                ptx_atomic_add(&H->cur[7], rows);
+                ptx_reduce_add32(&H->cur[7], rows);
                 if (badc != 0xFFFFFFFFu) {
                     uint32_t row;
                     PTX_CHANGE_ROW(badc, row);
@@ -800,6 +833,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 lds_high = bp.high;
                 return PTX_ERR_BAD_OP;
             }
+            /* pass B: the checks; the loads of the NEXT step are in flight while this step is checked */
             PTX_FOR_WAVE(w, lane) {
                 const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
                 uint32_t b01 = 0, b23 = 0; /* the clock before this wave's segment */
@@ -807,57 +841,42 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     b01 += wt01[q];
                     b23 += wt23[q];
                 }
-                /* the deps row of a change: one 16-byte load (rows are na <= 4 words, the library pads its copy of the
-                 * column so that reading four words at the last row stays inside the allocation); words past na are
-                 * not compared */
-#ifdef PTX_EMU
-#define PTX_ADM_DEPS(dst_, c_) \
-    for (uint32_t b = 0; b < 4; ++b) dst_[b] = c_deps[(uint64_t)(c_) * na + (b < na ? b : 0u)];
-#else
-#define PTX_ADM_DEPS(dst_, c_)                                                         \
-    {                                                                                  \
-        struct __attribute__((packed, aligned(4))) PtxDeps4 { uint32_t v[4]; };        \
-        const PtxDeps4 q_ = *(const PtxDeps4*)(c_deps + (uint64_t)(c_) * na);          \
-        dst_[0] = q_.v[0]; dst_[1] = q_.v[1]; dst_[2] = q_.v[2]; dst_[3] = q_.v[3];    \
+                uint32_t h[PTX_AC], h_n[PTX_AC];
+                uint16_t e[PTX_AC][4], e_n[PTX_AC][4];
+#define PTX_ADM_LOAD(cb_, h_, e_)                                           \
+    {                                                                       \
+        const uint32_t cl0_ = (cb_) + lane * PTX_AC;                        \
+        const uint32_t cl_ = cl0_ < hi ? cl0_ : (hi ? hi - 1u : 0u);        \
+        PTX_ADM_HDRS(h_, cl_)                                               \
+        PTX_ADM_ENVS(e_, cl_)                                               \
     }
-#endif
-                /* the loads of the NEXT step are in flight while this step is checked */
-                uint32_t a[PTX_AC], sq[PTX_AC], d[PTX_AC][4], a_n[PTX_AC], sq_n[PTX_AC], d_n[PTX_AC][4];
-#define PTX_ADM_LOAD(cb_, a_, sq_, d_)                                                                  \
-    _Pragma("unroll") for (uint32_t u = 0; u < PTX_AC; ++u) {                                           \
-        const uint32_t c0_ = (cb_) + lane * PTX_AC + u;                                                 \
-        const uint32_t c_ = c0_ < hi ? c0_ : (hi ? hi - 1u : 0u);                                       \
-        a_[u] = c_actor[c_];                                                                            \
-        sq_[u] = c_seq[c_];                                                                             \
-        PTX_ADM_DEPS(d_[u], c_)                                                                         \
-    }
-                PTX_ADM_LOAD(lo, a, sq, d)
+                PTX_ADM_LOAD(lo, h, e)
 #pragma nounroll
                 for (uint32_t cb = lo; cb < hi; cb += step) {
-                    PTX_ADM_LOAD(cb + step, a_n, sq_n, d_n)
-                    /* inside a step a wave sees at most 64 * PTX_AC < 256 changes: the four per-actor counts fit one
-                     * word, 8 bits each -> ONE prefix sum per step */
-                    static_assert(PTX_WS * PTX_AC < 256u, "per-step actor counts must fit 8 bits");
-                    uint32_t o01[PTX_AC], o23[PTX_AC], t8 = 0;
+                    PTX_ADM_LOAD(cb + step, h_n, e_n)
+                    const uint32_t cl = cb + lane * PTX_AC;
+                    uint32_t o01[PTX_AC], o23[PTX_AC], t01 = 0, t23 = 0;
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
-                        const bool in = cb + lane * PTX_AC + u < hi;
-                        o01[u] = in && a[u] < 2u ? 1u << (16u * a[u]) : 0u;
-                        o23[u] = in && (a[u] & ~1u) == 2u ? 1u << (16u * (a[u] & 1u)) : 0u;
-                        t8 += in && a[u] < 4u ? 1u << (8u * a[u]) : 0u;
+                        const bool in = cl + u < hi;
+                        const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
+                        o01[u] = in && a < 2u ? 1u << (16u * a) : 0u;
+                        o23[u] = in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
+                        t01 += o01[u];
+                        t23 += o23[u];
                     }
-                    const uint32_t i8 = ptx_wave_incl_scan(t8), e8 = i8 - t8;
-                    /* the clock before this lane's first change */
-                    uint32_t w01 = b01 + ((e8 & 0xFFu) | ((e8 & 0xFF00u) << 8)), w23 = b23 + (((e8 >> 16) & 0xFFu) | ((e8 >> 24) << 16));
+                    const uint32_t i01 = ptx_wave_incl_scan(t01), i23 = ptx_wave_incl_scan(t23);
+                    uint32_t w01 = b01 + i01 - t01, w23 = b23 + i23 - t23; /* the clock before this lane's first change */
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
-                        const uint32_t c = cb + lane * PTX_AC + u;
-                        const uint32_t clk[4] = {w01 & 0xFFFFu, w01 >> 16, w23 & 0xFFFFu, w23 >> 16};
-                        const uint32_t mine = ((a[u] < 2u ? w01 : w23) >> (16u * (a[u] & 1u))) & 0xFFFFu;
-                        const bool bad_seq = sq[u] != mine + 1u;
+                        const uint32_t c = cl + u;
+                        const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
+                        const uint32_t clk[3] = {w01 & 0xFFFFu, w01 >> 16, w23 & 0xFFFFu};
+                        const uint32_t mine = ((a < 2u ? w01 : w23) >> (16u * (a & 1u))) & 0xFFFFu;
+                        const bool bad_seq = (uint32_t)e[u][0] != mine + 1u;
                         bool bad_dep = false;
 #pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) bad_dep = bad_dep || (b < na && d[u][b] > clk[b]);
+                        for (uint32_t b = 0; b < 3; ++b) bad_dep = bad_dep || (b < na && (uint32_t)e[u][1u + b] > clk[b]);
                         if (c < hi && (bad_seq || bad_dep)) {
                             uint32_t row;
                             PTX_CHANGE_ROW(c, row);
@@ -866,28 +885,27 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         w01 += o01[u];
                         w23 += o23[u];
                     }
-                    const uint32_t s8 = ptx_wave_last(i8);
-                    b01 += (s8 & 0xFFu) | ((s8 & 0xFF00u) << 8);
-                    b23 += ((s8 >> 16) & 0xFFu) | ((s8 >> 24) << 16);
+                    b01 += ptx_wave_last(i01);
+                    b23 += ptx_wave_last(i23);
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
-                        a[u] = a_n[u];
-                        sq[u] = sq_n[u];
+                        h[u] = h_n[u];
 #pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) d[u][b] = d_n[u][b];
+                        for (uint32_t b = 0; b < 4; ++b) e[u][b] = e_n[u][b];
                     }
                 }
 #undef PTX_ADM_LOAD
-#undef PTX_ADM_DEPS
             }
+#undef PTX_ADM_HDRS
+#undef PTX_ADM_ENVS
             PTX_SYNC();
             bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
         } else if constexpr (!kManyActors) {
-            /* this build of the kernel carries only the <= 4-actor admission; the host launches the other one */
+            /* this build of the kernel carries only the <= 3-actor admission; the host launches the other one */
             lds_high = bp.high;
             return PTX_ERR_CAPACITY;
         } else {
-        /* More than four actors (rare): tbl[first[a] + seq - 1] = index of the change (a, seq) makes "the seqs of an
+        /* More than three actors (rare): tbl[first[a] + seq - 1] = index of the change (a, seq) makes "the seqs of an
          * actor are 1, 2, ... in log order" and "dependency (b, d) sits earlier in the log" one LDS read each.  Kept
          * deliberately plain (one change per thread and step, serial prefix by the leader). */
         uint32_t* first = ptx_alloc<uint32_t>(bp, na + 2); /* changes per actor -> first table slot of the actor */
@@ -898,8 +916,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_LEADER { H->cur[7] = 0; }
         PTX_SYNC();
         PTX_FOR(c, C) {
-            const uint32_t a = c_actor[c];
-            ptx_atomic_add(&H->cur[7], c_nops[c]);
+            const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT;
+            ptx_atomic_add(&H->cur[7], c_hdr[c] & PTX_CHG_NOPS);
             if (a >= na) {
                 uint32_t row;
                 PTX_CHANGE_ROW(c, row);
@@ -921,20 +939,20 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_SYNC();
         PTX_FOR(c, C) {
-            const uint32_t a = c_actor[c], sq = c_seq[c];
+            const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT, sq = c_env[(uint64_t)c * estride];
             const uint32_t f = first[a], cnt_a = first[a + 1] - f;
             if (sq - 1u < cnt_a) tbl[f + sq - 1u] = (uint16_t)c; /* a second claimant of the slot is caught below */
         }
         PTX_SYNC();
         PTX_FOR(c, C) {
-            const uint32_t a = c_actor[c], sq = c_seq[c];
+            const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT, sq = c_env[(uint64_t)c * estride];
             const uint32_t f = first[a], cnt_a = first[a + 1] - f;
             /* seq == clock[a] + 1  (micromerge.ts:501-504) */
             const bool bad_seq = !(sq - 1u < cnt_a) || tbl[f + sq - 1u] != c || (sq > 1u && tbl[f + sq - 2u] >= c);
             bool bad_dep = false;
             /* clock[b] >= deps[b] for every actor  (micromerge.ts:505-509) */
             for (uint32_t b = 0; b < na && !bad_seq; ++b) {
-                const uint32_t d = c_deps[(uint64_t)c * na + b];
+                const uint32_t d = c_env[(uint64_t)c * estride + 1u + b];
                 if (d != 0u) {
                     const uint32_t fb = first[b], cnt_b = first[b + 1] - fb;
                     if (!(d <= cnt_b) || tbl[fb + d - 1u] >= c) bad_dep = true;
@@ -946,13 +964,14 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 ptx_atomic_min(&H->adm, ((row * 2u) << 4) | (bad_seq ? PTX_ERR_SEQ_GAP : PTX_ERR_MISSING_DEP));
             }
         }
-#undef PTX_CHANGE_ROW
         /* a failed admission stays pending in H->adm: an op-level error of an EARLIER row (found by the phases
          * below, which still run) wins over it, exactly as in a sequential replay */
         PTX_SYNC();
         bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
-        } /* na > 4 */
+        } /* na > 3 */
+#undef PTX_CHANGE_ROW
     }
+
 
     /* ---- the log header (census) sizes everything; the row pass below verifies it ---- */
     const ptx_log_hdr hd = A.log_hdr[log];

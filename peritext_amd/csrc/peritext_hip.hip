@@ -39,7 +39,7 @@
         if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT, DIAG>(A, A.log_index ? A.log_index[blockIdx.x] : blockIdx.x, ptx_lds); \
     }
 PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false, 0, false)     /* any launch shape (blockDim.x read at run time) */
-PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false) /* + causal admission for documents with more than four actors */
+PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false) /* + causal admission for documents with more than three actors */
 PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, 1, true, 0, true)  /* + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
 /* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
  * issue ~1 % fewer instructions but need twice the VGPRs unless PTX_U=1, so only the run-time-sized builds are shipped) */
@@ -63,16 +63,11 @@ extern "C" __global__ void __launch_bounds__(64) ptx_change_kernel(PtxChangeArgs
 }
 
 /* envelope of a generated batch: capacity layout (rows_per_log entries per log) -> compact */
-__global__ void ptx_gen_compact_kernel(const uint64_t* chg_off, uint32_t rows_per_log, uint32_t R, const uint32_t* sa, const uint32_t* ss, const uint32_t* sn,
-                                       const uint32_t* sd, uint32_t* da, uint32_t* ds, uint32_t* dn, uint32_t* dd) {
-    const uint32_t log = blockIdx.x;
+__global__ void ptx_gen_compact_kernel(const uint64_t* chg_off, uint32_t rows_per_log, uint32_t R, const uint32_t* sh, const uint16_t* se, uint32_t* dh, uint16_t* de) {
+    const uint32_t log = blockIdx.x, es = PTX_ENV_STRIDE(R);
     const uint64_t c0 = chg_off[log], c1 = chg_off[log + 1], s0 = (uint64_t)log * rows_per_log;
-    for (uint64_t i = threadIdx.x; i < c1 - c0; i += blockDim.x) {
-        da[c0 + i] = sa[s0 + i];
-        ds[c0 + i] = ss[s0 + i];
-        dn[c0 + i] = sn[s0 + i];
-        for (uint32_t b = 0; b < R; ++b) dd[(c0 + i) * R + b] = sd[(s0 + i) * R + b];
-    }
+    for (uint64_t i = threadIdx.x; i < c1 - c0; i += blockDim.x) dh[c0 + i] = sh[s0 + i];
+    for (uint64_t i = threadIdx.x; i < (c1 - c0) * es; i += blockDim.x) de[c0 * es + i] = se[s0 * es + i];
 }
 __global__ void ptx_regular_offsets_kernel(uint64_t* dst, uint32_t n, uint64_t stride) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,13 +88,15 @@ struct PtxAppendCols {
     const uint64_t *op_id, *ref_a, *ref_b;
     const uint32_t* payload;
     const uint8_t *action, *mark_type, *side_a, *side_b;
-    const uint32_t *chg_actor, *chg_seq, *chg_nops, *chg_deps;
+    const uint32_t* chg_hdr;
+    const uint16_t* chg_env;
 };
 struct PtxAppendDst {
     uint64_t *op_id, *ref_a, *ref_b;
     uint32_t* payload;
     uint8_t *action, *mark_type, *side_a, *side_b;
-    uint32_t *chg_actor, *chg_seq, *chg_nops, *chg_deps;
+    uint32_t* chg_hdr;
+    uint16_t* chg_env;
 };
 __global__ void ptx_append_rows_kernel(PtxAppendCols A, const uint64_t* a_off, const uint64_t* a_coff, PtxAppendCols B, const uint64_t* b_off, const uint64_t* b_coff,
                                        PtxAppendDst D, const uint64_t* d_off, const uint64_t* d_coff, uint32_t max_actors) {
@@ -115,10 +112,8 @@ __global__ void ptx_append_rows_kernel(PtxAppendCols A, const uint64_t* a_off, c
     ptx_append_col(A.side_b, a0, na, B.side_b, b0, nb, D.side_b, d0, 1);
     if (a_coff) {
         const uint64_t ac0 = a_coff[l], nac = a_coff[l + 1] - ac0, bc0 = b_coff[l], nbc = b_coff[l + 1] - bc0, dc0 = d_coff[l];
-        ptx_append_col(A.chg_actor, ac0, nac, B.chg_actor, bc0, nbc, D.chg_actor, dc0, 1);
-        ptx_append_col(A.chg_seq, ac0, nac, B.chg_seq, bc0, nbc, D.chg_seq, dc0, 1);
-        ptx_append_col(A.chg_nops, ac0, nac, B.chg_nops, bc0, nbc, D.chg_nops, dc0, 1);
-        ptx_append_col(A.chg_deps, ac0, nac, B.chg_deps, bc0, nbc, D.chg_deps, dc0, (uint64_t)max_actors);
+        ptx_append_col(A.chg_hdr, ac0, nac, B.chg_hdr, bc0, nbc, D.chg_hdr, dc0, 1);
+        ptx_append_col(A.chg_env, ac0, nac, B.chg_env, bc0, nbc, D.chg_env, dc0, (uint64_t)PTX_ENV_STRIDE(max_actors));
     }
 }
 
@@ -136,10 +131,8 @@ __global__ void ptx_take_rows_kernel(PtxAppendCols S, const uint64_t* s_off, con
     ptx_append_col(S.side_a, s0, nr, S.side_a, 0, 0, D.side_a, d0, 1);
     ptx_append_col(S.side_b, s0, nr, S.side_b, 0, 0, D.side_b, d0, 1);
     const uint64_t sc0 = s_coff[l], dc0 = d_coff[l], nc = chgs[l];
-    ptx_append_col(S.chg_actor, sc0, nc, S.chg_actor, 0, 0, D.chg_actor, dc0, 1);
-    ptx_append_col(S.chg_seq, sc0, nc, S.chg_seq, 0, 0, D.chg_seq, dc0, 1);
-    ptx_append_col(S.chg_nops, sc0, nc, S.chg_nops, 0, 0, D.chg_nops, dc0, 1);
-    ptx_append_col(S.chg_deps, sc0, nc, S.chg_deps, 0, 0, D.chg_deps, dc0, (uint64_t)max_actors);
+    ptx_append_col(S.chg_hdr, sc0, nc, S.chg_hdr, 0, 0, D.chg_hdr, dc0, 1);
+    ptx_append_col(S.chg_env, sc0, nc, S.chg_env, 0, 0, D.chg_env, dc0, (uint64_t)PTX_ENV_STRIDE(max_actors));
 }
 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
@@ -225,15 +218,17 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
  * the element widths the merge kernel uses (8 B / 4 B / 1 B per lane, consecutive lanes on consecutive rows). */
 __global__ void __launch_bounds__(256) ptx_calib_stream_kernel(const uint64_t* op_id, const uint64_t* ref_a, const uint64_t* ref_b, const uint32_t* payload, const uint8_t* action,
                                                                 const uint8_t* mark_type, const uint8_t* side_a, const uint8_t* side_b, uint64_t n_rows,
-                                                                const uint32_t* chg_actor, const uint32_t* chg_seq, const uint32_t* chg_nops, const uint32_t* chg_deps,
-                                                                uint64_t n_changes, uint32_t max_actors, unsigned long long* sum) {
+                                                                const uint32_t* chg_hdr, const uint16_t* chg_env, uint64_t n_changes, uint32_t max_actors,
+                                                                unsigned long long* sum) {
     unsigned long long acc = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += stride)
         acc += op_id[i] + ref_a[i] + ref_b[i] + payload[i] + action[i] + mark_type[i] + side_a[i] + side_b[i];
+    const uint32_t es = PTX_ENV_STRIDE(max_actors);
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_changes; c += stride) {
-        acc += chg_actor[c] + chg_seq[c] + chg_nops[c];
-        for (uint32_t b = 0; b < max_actors; ++b) acc += chg_deps[c * max_actors + b];
+        acc += chg_hdr[c];
+        const uint2* row = (const uint2*)(chg_env + c * es); /* 8 bytes per lane, as the admission pass reads them */
+        for (uint32_t b = 0; b < es / 4u; ++b) acc += row[b].x + row[b].y;
     }
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
@@ -271,6 +266,10 @@ __global__ void ptx_tile_offsets_kernel(const uint64_t* src, uint64_t* dst, uint
 /* host objects                                                                                     */
 /* ------------------------------------------------------------------------------------------------ */
 
+/* rows by which the library over-allocates its copies of the envelope columns: the admission pass reads PTX_AC headers /
+ * envelope rows of a lane with one wide load each, also at the last change of the batch */
+#define PTX_ENV_PAD 8u
+
 struct ptx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;     /* the stream in use: own_stream, or the caller's (ptx_set_stream) */
@@ -296,7 +295,8 @@ struct ptx_dbatch {
     ptx_log_hdr* log_hdr = nullptr; /* always owned: provided headers are copied, missing ones computed */
     /* Change envelope for causal admission (owned copies; null when the batch came without it) */
     uint64_t* chg_off = nullptr;
-    uint32_t *chg_actor = nullptr, *chg_seq = nullptr, *chg_nops = nullptr, *chg_deps = nullptr;
+    uint32_t* chg_hdr = nullptr;
+    uint16_t* chg_env = nullptr;
     uint32_t max_actors = 0;
     uint64_t n_changes = 0;
     /* launch shape derived from the largest log */
@@ -420,7 +420,7 @@ static ptx_status check_host_offsets(ptx_ctx* ctx, const ptx_batch* h) {
     if (h->log_off[0] != 0 || h->log_off[h->n_logs] != h->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off must run from 0 to n_ops");
     for (uint32_t l = 0; l < h->n_logs; ++l)
         if (h->log_off[l + 1] < h->log_off[l]) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off decreases");
-    if (h->chg_off && h->chg_actor && h->chg_seq && h->chg_nops && h->chg_deps && h->max_actors) {
+    if (h->chg_off && h->chg_hdr && h->chg_env && h->max_actors) {
         if (h->chg_off[0] != 0) return fail(ctx, PTX_ERR_INVALID_ARG, "chg_off must start at 0");
         for (uint32_t l = 0; l < h->n_logs; ++l)
             if (h->chg_off[l + 1] < h->chg_off[l]) return fail(ctx, PTX_ERR_INVALID_ARG, "chg_off decreases");
@@ -527,10 +527,8 @@ void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
     (void)hipFree(b->log_hdr);
     (void)hipFree(b->log_index);
     (void)hipFree(b->chg_off);
-    (void)hipFree(b->chg_actor);
-    (void)hipFree(b->chg_seq);
-    (void)hipFree(b->chg_nops);
-    (void)hipFree(b->chg_deps);
+    (void)hipFree(b->chg_hdr);
+    (void)hipFree(b->chg_env);
     delete b;
 }
 
@@ -580,23 +578,19 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
         for (uint32_t k = 1; k < copies; ++k)
             PTX_TRY(hipMemcpyAsync(b->log_hdr + (size_t)k * h->n_logs, b->log_hdr, (size_t)h->n_logs * sizeof(ptx_log_hdr), hipMemcpyDeviceToDevice, ctx->stream));
     }
-    const bool have_env = h->chg_off && h->chg_actor && h->chg_seq && h->chg_nops && h->chg_deps && h->max_actors && h->n_logs;
+    const bool have_env = h->chg_off && h->chg_hdr && h->chg_env && h->max_actors && h->n_logs;
     if (have_env) {
         const uint64_t NC = h->chg_off[h->n_logs];
         b->max_actors = h->max_actors;
         b->n_changes = NC * copies;
         PTX_TRY(dalloc(&b->chg_off, (uint64_t)b->n_logs + 1));
-        PTX_TRY(dalloc(&b->chg_actor, NC * copies));
-        PTX_TRY(dalloc(&b->chg_seq, NC * copies));
-        PTX_TRY(dalloc(&b->chg_nops, NC * copies));
-        PTX_TRY(dalloc(&b->chg_deps, NC * copies * h->max_actors + 4)); /* + 4: the kernel reads a deps row as one 16-byte load */
+        const uint64_t ES = PTX_ENV_STRIDE(h->max_actors);
+        PTX_TRY(dalloc(&b->chg_hdr, NC * copies + PTX_ENV_PAD)); /* padding: the admission pass reads headers and rows with 16-byte loads */
+        PTX_TRY(dalloc(&b->chg_env, (NC * copies + PTX_ENV_PAD) * ES));
         for (uint32_t k = 0; k < copies && NC; ++k) {
             const hipMemcpyKind kd = k ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-            PTX_TRY(hipMemcpyAsync(b->chg_actor + k * NC, k ? (const void*)b->chg_actor : (const void*)h->chg_actor, NC * 4, kd, ctx->stream));
-            PTX_TRY(hipMemcpyAsync(b->chg_seq + k * NC, k ? (const void*)b->chg_seq : (const void*)h->chg_seq, NC * 4, kd, ctx->stream));
-            PTX_TRY(hipMemcpyAsync(b->chg_nops + k * NC, k ? (const void*)b->chg_nops : (const void*)h->chg_nops, NC * 4, kd, ctx->stream));
-            PTX_TRY(hipMemcpyAsync(b->chg_deps + k * NC * h->max_actors, k ? (const void*)b->chg_deps : (const void*)h->chg_deps, NC * 4 * h->max_actors, kd,
-                                   ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->chg_hdr + k * NC, k ? (const void*)b->chg_hdr : (const void*)h->chg_hdr, NC * 4, kd, ctx->stream));
+            PTX_TRY(hipMemcpyAsync(b->chg_env + k * NC * ES, k ? (const void*)b->chg_env : (const void*)h->chg_env, NC * ES * 2, kd, ctx->stream));
         }
         uint64_t* tmpc = nullptr;
         PTX_TRY(dalloc(&tmpc, (uint64_t)h->n_logs + 1));
@@ -699,10 +693,8 @@ ptx_status ptx_batch_append_device(ptx_ctx* ctx, const ptx_dbatch* base, const p
     PTX_TRYA(dalloc(&b->log_hdr, L));
     if (env) {
         PTX_TRYA(dalloc(&b->chg_off, L + 1));
-        PTX_TRYA(dalloc(&b->chg_actor, NC));
-        PTX_TRYA(dalloc(&b->chg_seq, NC));
-        PTX_TRYA(dalloc(&b->chg_nops, NC));
-        PTX_TRYA(dalloc(&b->chg_deps, NC * b->max_actors + 4));
+        PTX_TRYA(dalloc(&b->chg_hdr, NC + PTX_ENV_PAD));
+        PTX_TRYA(dalloc(&b->chg_env, (NC + PTX_ENV_PAD) * PTX_ENV_STRIDE(b->max_actors)));
         if (!base_env) {
             PTX_TRYA(dalloc(&zero_off, L + 1));
             PTX_TRYA(hipMemsetAsync(zero_off, 0, (L + 1) * 8, ctx->stream));
@@ -714,9 +706,9 @@ ptx_status ptx_batch_append_device(ptx_ctx* ctx, const ptx_dbatch* base, const p
         hipLaunchKernelGGL(ptx_append_offsets_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base->log_off, m->log_off, b->log_off, (uint32_t)L);
         if (env) hipLaunchKernelGGL(ptx_append_offsets_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base_coff, m->chg_off, b->chg_off, (uint32_t)L);
         PtxAppendCols A = {base->op_id, base->ref_a, base->ref_b, base->payload, base->action, base->mark_type, base->side_a, base->side_b,
-                           base->chg_actor, base->chg_seq, base->chg_nops, base->chg_deps};
-        PtxAppendCols B = {m->op_id, m->ref_a, m->ref_b, m->payload, m->action, m->mark_type, m->side_a, m->side_b, m->chg_actor, m->chg_seq, m->chg_nops, m->chg_deps};
-        PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_actor, b->chg_seq, b->chg_nops, b->chg_deps};
+                           base->chg_hdr, base->chg_env};
+        PtxAppendCols B = {m->op_id, m->ref_a, m->ref_b, m->payload, m->action, m->mark_type, m->side_a, m->side_b, m->chg_hdr, m->chg_env};
+        PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_hdr, b->chg_env};
         hipLaunchKernelGGL(ptx_append_rows_kernel, dim3((unsigned)L), dim3(256), 0, ctx->stream, A, base->log_off, env ? base_coff : nullptr, B, m->log_off,
                            env ? m->chg_off : nullptr, D, b->log_off, env ? b->chg_off : nullptr, b->max_actors);
         PTX_TRYA(hipGetLastError());
@@ -833,10 +825,8 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.log_hdr = b->log_hdr;
     const bool admit = b->chg_off && !(ctx->flags & PTX_FLAG_NO_ADMISSION);
     A.chg_off = admit ? b->chg_off : nullptr;
-    A.chg_actor = b->chg_actor;
-    A.chg_seq = b->chg_seq;
-    A.chg_nops = b->chg_nops;
-    A.chg_deps = b->chg_deps;
+    A.chg_hdr = b->chg_hdr;
+    A.chg_env = b->chg_env;
     A.max_actors = b->max_actors;
     A.clocks = ctx->clocks;
     A.stop_after = (uint32_t)ctx->stop_after;
@@ -862,7 +852,7 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
         }
         if (ctx->clocks || ctx->stop_after)
             hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), lds, ctx->stream, A);
-        else if (admit && b->max_actors > 4)
+        else if (admit && b->max_actors > 3)
             hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, ctx->stream, A);
         else
             hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, ctx->stream, A);
@@ -947,13 +937,13 @@ ptx_status ptx_calib_stream(ptx_ctx* ctx, const ptx_dbatch* b, uint64_t* bytes_r
     const bool env = b->chg_off != nullptr;
     if (e == hipSuccess) {
         hipLaunchKernelGGL(ptx_calib_stream_kernel, dim3(256 * 32), dim3(256), 0, ctx->stream, b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a,
-                           b->side_b, b->n_ops, b->chg_actor, b->chg_seq, b->chg_nops, b->chg_deps, env ? b->n_changes : 0, b->max_actors, d);
+                           b->side_b, b->n_ops, b->chg_hdr, b->chg_env, env ? b->n_changes : 0, b->max_actors, d);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("calibration stream: ") + hipGetErrorString(e));
-    *bytes_read = 32 * b->n_ops + (env ? b->n_changes * (12 + 4ull * b->max_actors) : 0);
+    *bytes_read = 32 * b->n_ops + (env ? b->n_changes * (4 + 2ull * PTX_ENV_STRIDE(b->max_actors)) : 0);
     return PTX_OK;
 }
 
@@ -1215,20 +1205,20 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     b->n_ops = (uint64_t)b->n_logs * N;
     b->max_actors = R;
     const uint64_t T = b->n_ops;
-    uint32_t *cap_actor = nullptr, *cap_seq = nullptr, *cap_nops = nullptr, *cap_deps = nullptr, *d_nchg = nullptr, *d_ncom = nullptr, *d_status = nullptr;
+    uint32_t *cap_hdr = nullptr, *d_nchg = nullptr, *d_ncom = nullptr, *d_status = nullptr;
+    uint16_t* cap_env = nullptr;
     PtxGenChange* d_ctab = nullptr;
     uint16_t* d_known = nullptr;
     auto drop = [&]() { /* idempotent: a later failure path may call it again */
-        (void)hipFree(cap_actor);
-        (void)hipFree(cap_seq);
-        (void)hipFree(cap_nops);
-        (void)hipFree(cap_deps);
+        (void)hipFree(cap_hdr);
+        (void)hipFree(cap_env);
         (void)hipFree(d_nchg);
         (void)hipFree(d_ncom);
         (void)hipFree(d_status);
         (void)hipFree(d_ctab);
         (void)hipFree(d_known);
-        cap_actor = cap_seq = cap_nops = cap_deps = d_nchg = d_ncom = d_status = nullptr;
+        cap_hdr = d_nchg = d_ncom = d_status = nullptr;
+        cap_env = nullptr;
         d_ctab = nullptr;
         d_known = nullptr;
     };
@@ -1253,10 +1243,8 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     PTX_TRYG(dalloc(&b->side_b, T));
     PTX_TRYG(dalloc(&b->log_hdr, (uint64_t)b->n_logs));
     PTX_TRYG(dalloc(&b->chg_off, (uint64_t)b->n_logs + 1));
-    PTX_TRYG(dalloc(&cap_actor, T));
-    PTX_TRYG(dalloc(&cap_seq, T));
-    PTX_TRYG(dalloc(&cap_nops, T));
-    PTX_TRYG(dalloc(&cap_deps, T * R));
+    PTX_TRYG(dalloc(&cap_hdr, T));
+    PTX_TRYG(dalloc(&cap_env, T * PTX_ENV_STRIDE(R)));
     PTX_TRYG(dalloc(&d_nchg, (uint64_t)b->n_logs));
     PTX_TRYG(dalloc(&d_ncom, (uint64_t)D));
     PTX_TRYG(dalloc(&d_status, (uint64_t)D));
@@ -1302,10 +1290,8 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     A.mark_type = b->mark_type;
     A.side_a = b->side_a;
     A.side_b = b->side_b;
-    A.chg_actor = cap_actor;
-    A.chg_seq = cap_seq;
-    A.chg_nops = cap_nops;
-    A.chg_deps = cap_deps;
+    A.chg_hdr = cap_hdr;
+    A.chg_env = cap_env;
     A.n_changes = d_nchg;
     A.n_comments = d_ncom;
     A.status = d_status;
@@ -1345,14 +1331,11 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
         ptx_batch_free(ctx, b);
         return fail(ctx, err == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("ptx_generate: ") + hipGetErrorString(err));
     };
-    e = dalloc(&b->chg_actor, NC);
-    if (e == hipSuccess) e = dalloc(&b->chg_seq, NC);
-    if (e == hipSuccess) e = dalloc(&b->chg_nops, NC);
-    if (e == hipSuccess) e = dalloc(&b->chg_deps, NC * R + 4);
+    e = dalloc(&b->chg_hdr, NC + PTX_ENV_PAD);
+    if (e == hipSuccess) e = dalloc(&b->chg_env, (NC + PTX_ENV_PAD) * PTX_ENV_STRIDE(R));
     if (e == hipSuccess) e = hipMemcpyAsync(b->chg_off, coff.data(), ((size_t)b->n_logs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) return fin(e);
-    hipLaunchKernelGGL(ptx_gen_compact_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->chg_off, N, R, cap_actor, cap_seq, cap_nops, cap_deps, b->chg_actor,
-                       b->chg_seq, b->chg_nops, b->chg_deps);
+    hipLaunchKernelGGL(ptx_gen_compact_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->chg_off, N, R, cap_hdr, cap_env, b->chg_hdr, b->chg_env);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fin(e);
@@ -1486,10 +1469,8 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
     PTX_TRYC(dalloc(&cap->mark_type, T));
     PTX_TRYC(dalloc(&cap->side_a, T));
     PTX_TRYC(dalloc(&cap->side_b, T));
-    PTX_TRYC(dalloc(&cap->chg_actor, NC));
-    PTX_TRYC(dalloc(&cap->chg_seq, NC));
-    PTX_TRYC(dalloc(&cap->chg_nops, NC));
-    PTX_TRYC(dalloc(&cap->chg_deps, NC * na + 4));
+    PTX_TRYC(dalloc(&cap->chg_hdr, NC));
+    PTX_TRYC(dalloc(&cap->chg_env, NC * PTX_ENV_STRIDE(na)));
     std::vector<uint32_t> rows_made(std::max<uint32_t>(L, 1)), chgs_made(std::max<uint32_t>(L, 1));
     if (L) {
         PtxChangeArgs A;
@@ -1506,7 +1487,7 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
         A.res = merged->logs;
         A.elem_rank = merged->rank;
         A.chg_off = base->chg_off;
-        A.chg_actor = base->chg_actor;
+        A.chg_hdr = base->chg_hdr;
         A.max_actors = na;
         A.in_chg_off = d_in_chg;
         A.in_op_off = d_in_op;
@@ -1526,10 +1507,8 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
         A.o_mark_type = cap->mark_type;
         A.o_side_a = cap->side_a;
         A.o_side_b = cap->side_b;
-        A.o_chg_actor = cap->chg_actor;
-        A.o_chg_seq = cap->chg_seq;
-        A.o_chg_nops = cap->chg_nops;
-        A.o_chg_deps = cap->chg_deps;
+        A.o_chg_hdr = cap->chg_hdr;
+        A.o_chg_env = cap->chg_env;
         A.status = d_status;
         A.rows_made = d_rows;
         A.chgs_made = d_chgs;
@@ -1564,14 +1543,12 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
     PTX_TRYC(dalloc(&b->side_a, b->n_ops));
     PTX_TRYC(dalloc(&b->side_b, b->n_ops));
     PTX_TRYC(dalloc(&b->log_hdr, (uint64_t)L));
-    PTX_TRYC(dalloc(&b->chg_actor, b->n_changes));
-    PTX_TRYC(dalloc(&b->chg_seq, b->n_changes));
-    PTX_TRYC(dalloc(&b->chg_nops, b->n_changes));
-    PTX_TRYC(dalloc(&b->chg_deps, b->n_changes * na + 4));
+    PTX_TRYC(dalloc(&b->chg_hdr, b->n_changes + PTX_ENV_PAD));
+    PTX_TRYC(dalloc(&b->chg_env, (b->n_changes + PTX_ENV_PAD) * PTX_ENV_STRIDE(na)));
     if (L) {
         PtxAppendCols S = {cap->op_id, cap->ref_a, cap->ref_b, cap->payload, cap->action, cap->mark_type, cap->side_a, cap->side_b,
-                           cap->chg_actor, cap->chg_seq, cap->chg_nops, cap->chg_deps};
-        PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_actor, b->chg_seq, b->chg_nops, b->chg_deps};
+                           cap->chg_hdr, cap->chg_env};
+        PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_hdr, b->chg_env};
         hipLaunchKernelGGL(ptx_take_rows_kernel, dim3(L), dim3(64), 0, ctx->stream, S, d_out_off, d_in_chg, d_rows, d_chgs, D, b->log_off, b->chg_off, na);
         PTX_TRYC(hipGetLastError());
         PTX_TRYC(hipStreamSynchronize(ctx->stream));
@@ -1589,7 +1566,8 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
 
 struct ptx_host_batch_store {
     std::vector<uint64_t> log_off, op_id, ref_a, ref_b, chg_off;
-    std::vector<uint32_t> payload, chg_actor, chg_seq, chg_nops, chg_deps;
+    std::vector<uint32_t> payload, chg_hdr;
+    std::vector<uint16_t> chg_env;
     std::vector<uint8_t> action, mark_type, side_a, side_b;
     std::vector<ptx_log_hdr> hdr;
 };
@@ -1629,15 +1607,12 @@ ptx_status ptx_batch_download(ptx_ctx* ctx, const ptx_dbatch* b, ptx_host_batch*
     dl(s->hdr.data(), b->log_hdr, L * sizeof(ptx_log_hdr));
     if (b->chg_off) {
         s->chg_off.resize(L + 1);
-        s->chg_actor.resize(std::max<uint64_t>(NC, 1));
-        s->chg_seq.resize(std::max<uint64_t>(NC, 1));
-        s->chg_nops.resize(std::max<uint64_t>(NC, 1));
-        s->chg_deps.resize(std::max<uint64_t>(NC * b->max_actors, 1));
+        const uint64_t ES = PTX_ENV_STRIDE(b->max_actors);
+        s->chg_hdr.resize(std::max<uint64_t>(NC, 1));
+        s->chg_env.resize(std::max<uint64_t>(NC * ES, 1));
         dl(s->chg_off.data(), b->chg_off, (L + 1) * 8);
-        dl(s->chg_actor.data(), b->chg_actor, NC * 4);
-        dl(s->chg_seq.data(), b->chg_seq, NC * 4);
-        dl(s->chg_nops.data(), b->chg_nops, NC * 4);
-        dl(s->chg_deps.data(), b->chg_deps, NC * b->max_actors * 4);
+        dl(s->chg_hdr.data(), b->chg_hdr, NC * 4);
+        dl(s->chg_env.data(), b->chg_env, NC * ES * 2);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -1659,10 +1634,8 @@ ptx_status ptx_batch_download(ptx_ctx* ctx, const ptx_dbatch* b, ptx_host_batch*
     h.log_hdr = s->hdr.data();
     if (b->chg_off) {
         h.chg_off = s->chg_off.data();
-        h.chg_actor = s->chg_actor.data();
-        h.chg_seq = s->chg_seq.data();
-        h.chg_nops = s->chg_nops.data();
-        h.chg_deps = s->chg_deps.data();
+        h.chg_hdr = s->chg_hdr.data();
+        h.chg_env = s->chg_env.data();
         h.max_actors = b->max_actors;
     }
     out->owner = s;

@@ -11,7 +11,7 @@
  * Exports:  open(libPath) -> abiVersion      create(device, flags) -> ctx (external)      destroy(ctx)
  *           applyMaterialize(ctx, batch) -> {logs:Uint32Array(12/log), values:Uint32Array, spans:Uint32Array(2/row),
  *                                            cintervals:Uint32Array(3/row), elemRank:Uint32Array|null}
- *           maxOpsPerLog(ctx)  kernelName()  lastError(ctx|null)
+ *           generate(ctx, cfg)  change(ctx, batch, inputOps) -> {batch, status}  maxOpsPerLog(ctx)  kernelName()
  * Errors of the library surface as JS exceptions (Error with the library's message); per-LOG failures stay in
  * logs[12*l] (status) and are turned into RangeError by index.js, mirroring micromerge.ts:503,:507,:752.
  */
@@ -50,6 +50,8 @@ struct Lib {
     void (*gen_info_free)(ptx_gen_info*) = nullptr;
     ptx_status (*batch_download)(ptx_ctx*, const ptx_dbatch*, ptx_host_batch*) = nullptr;
     void (*host_batch_free)(ptx_host_batch*) = nullptr;
+    /* change(): caller-supplied InputOperations */
+    ptx_status (*change)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, const ptx_input_ops*, ptx_dbatch**, uint32_t*) = nullptr;
 } L;
 
 #define NAPI_OK(call)                                                        \
@@ -91,7 +93,7 @@ napi_value Open(napi_env env, napi_callback_info info) {
                   sym(L.batch_free, "ptx_batch_free") && sym(L.result_alloc, "ptx_result_alloc") && sym(L.dresult_free, "ptx_dresult_free") &&
                   sym(L.merge, "ptx_merge") && sym(L.sync, "ptx_sync") && sym(L.result_download, "ptx_result_download") &&
                   sym(L.replay_patches, "ptx_replay_patches") && sym(L.patches_free, "ptx_patches_free") && sym(L.generate, "ptx_generate") &&
-                  sym(L.gen_info_free, "ptx_gen_info_free") && sym(L.batch_download, "ptx_batch_download") && sym(L.host_batch_free, "ptx_host_batch_free");
+                  sym(L.gen_info_free, "ptx_gen_info_free") && sym(L.batch_download, "ptx_batch_download") && sym(L.host_batch_free, "ptx_host_batch_free") && sym(L.change, "ptx_change");
         if (!ok) {
             dlclose(L.handle);
             L.handle = nullptr;
@@ -165,6 +167,7 @@ bool column(napi_env env, napi_value obj, const char* name, size_t elem, const v
     size_t es = 0;
     switch (type) {
         case napi_uint8_array: es = 1; break;
+        case napi_uint16_array: es = 2; break;
         case napi_uint32_array: es = 4; break;
         case napi_biguint64_array: es = 8; break;
         default: return false;
@@ -184,24 +187,15 @@ napi_value make_u32(napi_env env, const void* src, size_t count) {
     return ta;
 }
 
-napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
-    if (!L.handle) return throw_msg(env, "call open(libPath) first");
-    size_t argc = 3;
-    napi_value argv[3];
-    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-    if (argc < 2) return throw_msg(env, "applyMaterialize(ctx, batch[, wantPatches])");
-    bool want_patches = false;
-    if (argc > 2) napi_get_value_bool(env, argv[2], &want_patches);
-    ptx_ctx* ctx = ctx_of(env, argv[0]);
-    if (!ctx) return throw_msg(env, "applyMaterialize: bad context");
-    napi_value b = argv[1];
-    ptx_batch pb;
+/* JS WireBatch (typed arrays, index.d.ts) -> ptx_batch pointing into their ArrayBuffers; false + pending exception on a malformed one */
+bool read_batch(napi_env env, napi_value b, ptx_batch* out) {
+    ptx_batch& pb = *out;
     memset(&pb, 0, sizeof(pb));
     size_t n_off = 0, n = 0, m = 0;
     const void* p = nullptr;
-    if (!column(env, b, "logOff", 8, &p, &n_off)) return throw_msg(env, "batch.logOff must be a BigUint64Array");
+    if (!column(env, b, "logOff", 8, &p, &n_off)) return throw_msg(env, "batch.logOff must be a BigUint64Array"), false;
     pb.log_off = (const uint64_t*)p;
-    if (n_off == 0) return throw_msg(env, "batch.logOff needs n_logs + 1 entries");
+    if (n_off == 0) return throw_msg(env, "batch.logOff needs n_logs + 1 entries"), false;
     pb.n_logs = (uint32_t)(n_off - 1);
     pb.n_ops = pb.log_off[pb.n_logs];
     struct Col { const char* name; size_t elem; const void** dst; } cols[] = {
@@ -213,35 +207,84 @@ napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
         if (!column(env, b, c.name, c.elem, c.dst, &n) || n != pb.n_ops) {
             char msg[128];
             snprintf(msg, sizeof(msg), "batch.%s: typed array of %zu-byte elements with n_ops entries expected", c.name, c.elem);
-            return throw_msg(env, msg);
+            return throw_msg(env, msg), false;
         }
     }
     /* optional: per-log census (sizeof(ptx_log_hdr) / 4 = 10 u32 per log) — otherwise the library computes it on the device */
     if (column(env, b, "logHdr", 4, &p, &m, true) && p) {
-        if (m != (size_t)pb.n_logs * (sizeof(ptx_log_hdr) / 4)) return throw_msg(env, "batch.logHdr: Uint32Array with 10 entries per log expected");
+        if (m != (size_t)pb.n_logs * (sizeof(ptx_log_hdr) / 4)) return throw_msg(env, "batch.logHdr: Uint32Array with 10 entries per log expected"), false;
         pb.log_hdr = (const ptx_log_hdr*)p;
     }
-    /* optional: the Change envelope -> causal admission on the device (all five columns + maxActors, or none) */
+    /* optional: the Change envelope -> causal admission on the device (chgOff + chgHdr + chgEnv + maxActors, or none) */
     {
-        size_t n_co = 0, n_a = 0, n_s = 0, n_n = 0, n_d = 0;
-        const void *co = nullptr, *ca = nullptr, *cs = nullptr, *cn = nullptr, *cd = nullptr;
+        size_t n_co = 0, n_h = 0, n_e = 0;
+        const void *co = nullptr, *ch = nullptr, *ce = nullptr;
         uint32_t max_actors = 0;
         napi_value mv;
         bool has = false;
         if (napi_has_named_property(env, b, "maxActors", &has) == napi_ok && has && napi_get_named_property(env, b, "maxActors", &mv) == napi_ok)
             napi_get_value_uint32(env, mv, &max_actors);
-        if (max_actors && column(env, b, "chgOff", 8, &co, &n_co, true) && co && column(env, b, "chgActor", 4, &ca, &n_a, true) &&
-            column(env, b, "chgSeq", 4, &cs, &n_s, true) && column(env, b, "chgNops", 4, &cn, &n_n, true) && column(env, b, "chgDeps", 4, &cd, &n_d, true)) {
+        if (max_actors && column(env, b, "chgOff", 8, &co, &n_co, true) && co && column(env, b, "chgHdr", 4, &ch, &n_h, true) && ch &&
+            column(env, b, "chgEnv", 2, &ce, &n_e, true) && ce) {
             const uint64_t nc = n_co == (size_t)pb.n_logs + 1 ? ((const uint64_t*)co)[pb.n_logs] : ~0ull;
-            if (nc != n_a || nc != n_s || nc != n_n || nc * max_actors != n_d) return throw_msg(env, "batch.chg*: inconsistent Change envelope columns");
+            if (nc != n_h || nc * PTX_ENV_STRIDE(max_actors) != n_e) return throw_msg(env, "batch.chg*: inconsistent Change envelope columns"), false;
             pb.chg_off = (const uint64_t*)co;
-            pb.chg_actor = (const uint32_t*)ca;
-            pb.chg_seq = (const uint32_t*)cs;
-            pb.chg_nops = (const uint32_t*)cn;
-            pb.chg_deps = (const uint32_t*)cd;
+            pb.chg_hdr = (const uint32_t*)ch;
+            pb.chg_env = (const uint16_t*)ce;
             pb.max_actors = max_actors;
         }
     }
+    return true;
+}
+
+
+napi_value make_typed(napi_env env, napi_typedarray_type type, size_t elem, const void* src, size_t count) {
+    napi_value ab, ta;
+    void* data = nullptr;
+    if (napi_create_arraybuffer(env, count * elem, &data, &ab) != napi_ok) return nullptr;
+    if (count && src) memcpy(data, src, count * elem);
+    if (napi_create_typedarray(env, type, count, ab, 0, &ta) != napi_ok) return nullptr;
+    return ta;
+}
+
+/* ptx_batch in host memory -> JS WireBatch columns (copies) */
+napi_value batch_to_js(napi_env env, const ptx_batch& b) {
+    napi_value batch, v;
+    if (napi_create_object(env, &batch) != napi_ok) return nullptr;
+    const size_t Lg = b.n_logs, T = (size_t)b.n_ops, NC = b.chg_off ? (size_t)b.chg_off[Lg] : 0;
+    struct { const char* name; napi_typedarray_type type; size_t elem; const void* src; size_t count; } cols[] = {
+        {"logOff", napi_biguint64_array, 8, b.log_off, Lg + 1}, {"opId", napi_biguint64_array, 8, b.op_id, T}, {"refA", napi_biguint64_array, 8, b.ref_a, T},
+        {"refB", napi_biguint64_array, 8, b.ref_b, T}, {"payload", napi_uint32_array, 4, b.payload, T}, {"action", napi_uint8_array, 1, b.action, T},
+        {"markType", napi_uint8_array, 1, b.mark_type, T}, {"sideA", napi_uint8_array, 1, b.side_a, T}, {"sideB", napi_uint8_array, 1, b.side_b, T},
+        {"logHdr", napi_uint32_array, 4, b.log_hdr, Lg * (sizeof(ptx_log_hdr) / 4)}, {"chgOff", napi_biguint64_array, 8, b.chg_off, Lg + 1},
+        {"chgHdr", napi_uint32_array, 4, b.chg_hdr, NC}, {"chgEnv", napi_uint16_array, 2, b.chg_env, NC * PTX_ENV_STRIDE(b.max_actors)},
+    };
+    for (auto& col : cols) {
+        if (!col.src && col.count) continue;
+        v = make_typed(env, col.type, col.elem, col.src, col.count);
+        if (v) napi_set_named_property(env, batch, col.name, v);
+    }
+    napi_create_uint32(env, b.max_actors, &v);
+    napi_set_named_property(env, batch, "maxActors", v);
+    napi_create_uint32(env, b.n_logs, &v);
+    napi_set_named_property(env, batch, "nLogs", v);
+    napi_create_double(env, (double)b.n_ops, &v);
+    napi_set_named_property(env, batch, "nOps", v);
+    return batch;
+}
+
+napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    if (argc < 2) return throw_msg(env, "applyMaterialize(ctx, batch[, wantPatches])");
+    bool want_patches = false;
+    if (argc > 2) napi_get_value_bool(env, argv[2], &want_patches);
+    ptx_ctx* ctx = ctx_of(env, argv[0]);
+    if (!ctx) return throw_msg(env, "applyMaterialize: bad context");
+    ptx_batch pb;
+    if (!read_batch(env, argv[1], &pb)) return nullptr;
     ptx_result res;
     ptx_patches pat;
     memset(&pat, 0, sizeof(pat));
@@ -304,14 +347,6 @@ napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
     return out;
 }
 
-napi_value make_typed(napi_env env, napi_typedarray_type type, size_t elem, const void* src, size_t count) {
-    napi_value ab, ta;
-    void* data = nullptr;
-    if (napi_create_arraybuffer(env, count * elem, &data, &ab) != napi_ok) return nullptr;
-    if (count && src) memcpy(data, src, count * elem);
-    if (napi_create_typedarray(env, type, count, ab, 0, &ta) != napi_ok) return nullptr;
-    return ta;
-}
 uint32_t u32_prop(napi_env env, napi_value obj, const char* name, uint32_t dflt) {
     napi_value v;
     bool has = false;
@@ -394,27 +429,9 @@ napi_value Generate(napi_env env, napi_callback_info info) {
     }
     napi_value out, batch, result, v;
     NAPI_OK(napi_create_object(env, &out));
-    NAPI_OK(napi_create_object(env, &batch));
     NAPI_OK(napi_create_object(env, &result));
-    const ptx_batch& b = hb.b;
-    const size_t Lg = b.n_logs, T = (size_t)b.n_ops, NC = b.chg_off ? (size_t)b.chg_off[Lg] : 0;
-    struct { const char* name; napi_typedarray_type type; size_t elem; const void* src; size_t count; } cols[] = {
-        {"logOff", napi_biguint64_array, 8, b.log_off, Lg + 1}, {"opId", napi_biguint64_array, 8, b.op_id, T}, {"refA", napi_biguint64_array, 8, b.ref_a, T},
-        {"refB", napi_biguint64_array, 8, b.ref_b, T}, {"payload", napi_uint32_array, 4, b.payload, T}, {"action", napi_uint8_array, 1, b.action, T},
-        {"markType", napi_uint8_array, 1, b.mark_type, T}, {"sideA", napi_uint8_array, 1, b.side_a, T}, {"sideB", napi_uint8_array, 1, b.side_b, T},
-        {"logHdr", napi_uint32_array, 4, b.log_hdr, Lg * (sizeof(ptx_log_hdr) / 4)}, {"chgOff", napi_biguint64_array, 8, b.chg_off, Lg + 1}, {"chgActor", napi_uint32_array, 4, b.chg_actor, NC},
-        {"chgSeq", napi_uint32_array, 4, b.chg_seq, NC}, {"chgNops", napi_uint32_array, 4, b.chg_nops, NC}, {"chgDeps", napi_uint32_array, 4, b.chg_deps, NC * b.max_actors},
-    };
-    for (auto& col : cols) {
-        v = make_typed(env, col.type, col.elem, col.src, col.count);
-        if (v) napi_set_named_property(env, batch, col.name, v);
-    }
-    napi_create_uint32(env, b.max_actors, &v);
-    napi_set_named_property(env, batch, "maxActors", v);
-    napi_create_uint32(env, b.n_logs, &v);
-    napi_set_named_property(env, batch, "nLogs", v);
-    napi_create_double(env, (double)b.n_ops, &v);
-    napi_set_named_property(env, batch, "nOps", v);
+    batch = batch_to_js(env, hb.b);
+    if (!batch) return throw_msg(env, "generate: cannot build the batch object");
     napi_set_named_property(env, out, "batch", batch);
     v = make_u32(env, gi.n_comments, gi.n_docs);
     if (v) napi_set_named_property(env, out, "nComments", v);
@@ -441,6 +458,77 @@ napi_value Generate(napi_env env, napi_callback_info info) {
     return out;
 }
 
+/* change(ctx, batch, inputOps): Micromerge.change for many replicas (ptx_change).  `batch` = the replica logs applied so far
+ * (WireBatch with the Change envelope), inputOps = {chgOff, opOff: BigUint64Array, action, markType: Uint8Array, index, count,
+ * payload, values, actor: Uint32Array, maxActors}.  Upload, merge, ptx_change, download of what was made.
+ * Returns {batch: WireBatch columns of the new Changes only, status: Uint32Array per log}. */
+napi_value Change(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc > 2 ? ctx_of(env, argv[0]) : nullptr;
+    if (!ctx) return throw_msg(env, "change(ctx, batch, inputOps)");
+    ptx_batch pb;
+    if (!read_batch(env, argv[1], &pb)) return nullptr;
+    napi_value io = argv[2];
+    ptx_input_ops in;
+    memset(&in, 0, sizeof(in));
+    size_t n_co = 0, n_oo = 0, n = 0, n_ops = 0, n_act = 0;
+    const void* p = nullptr;
+    if (!column(env, io, "chgOff", 8, &p, &n_co) || n_co != (size_t)pb.n_logs + 1) return throw_msg(env, "inputOps.chgOff: BigUint64Array with n_logs + 1 entries expected");
+    in.chg_off = (const uint64_t*)p;
+    if (!column(env, io, "opOff", 8, &p, &n_oo) || n_oo != (size_t)in.chg_off[pb.n_logs] + 1) return throw_msg(env, "inputOps.opOff: BigUint64Array with n_changes + 1 entries expected");
+    in.op_off = (const uint64_t*)p;
+    n_ops = (size_t)in.op_off[n_oo - 1];
+    struct Col { const char* name; size_t elem; const void** dst; } cols[] = {
+        {"action", 1, (const void**)&in.action}, {"markType", 1, (const void**)&in.mark_type}, {"index", 4, (const void**)&in.index},
+        {"count", 4, (const void**)&in.count},   {"payload", 4, (const void**)&in.payload},
+    };
+    for (const Col& c : cols)
+        if (!column(env, io, c.name, c.elem, c.dst, &n) || n != n_ops) return throw_msg(env, "inputOps: a column does not have one entry per InputOperation");
+    if (!column(env, io, "values", 4, &p, &n)) return throw_msg(env, "inputOps.values must be a Uint32Array");
+    in.values = (const uint32_t*)p;
+    in.n_values = n;
+    if (!column(env, io, "actor", 4, &p, &n_act) || n_act != pb.n_logs) return throw_msg(env, "inputOps.actor: Uint32Array with one entry per log expected");
+    in.actor = (const uint32_t*)p;
+    in.n_logs = pb.n_logs;
+    in.max_actors = u32_prop(env, io, "maxActors", pb.max_actors);
+    ptx_dbatch *db = nullptr, *made = nullptr;
+    ptx_dresult* dr = nullptr;
+    ptx_host_batch hb;
+    memset(&hb, 0, sizeof(hb));
+    napi_value status_arr = nullptr;
+    void* status_data = nullptr;
+    {
+        napi_value ab;
+        if (napi_create_arraybuffer(env, (size_t)pb.n_logs * 4, &status_data, &ab) != napi_ok ||
+            napi_create_typedarray(env, napi_uint32_array, pb.n_logs, ab, 0, &status_arr) != napi_ok)
+            return throw_msg(env, "change: cannot allocate the status array");
+    }
+    ptx_status st = L.batch_upload(ctx, &pb, &db);
+    if (st == PTX_OK) st = L.result_alloc(ctx, db, &dr);
+    if (st == PTX_OK) st = L.merge(ctx, db, dr);
+    if (st == PTX_OK) st = L.sync(ctx);
+    if (st == PTX_OK) st = L.change(ctx, db, dr, &in, &made, (uint32_t*)status_data);
+    if (st == PTX_OK) st = L.batch_download(ctx, made, &hb);
+    if (dr) L.dresult_free(ctx, dr);
+    if (db) L.batch_free(ctx, db);
+    if (made) L.batch_free(ctx, made);
+    if (st != PTX_OK) {
+        char msg[1024];
+        snprintf(msg, sizeof(msg), "ptx_change failed (status %d): %s", st, L.last_error(ctx));
+        if (hb.owner) L.host_batch_free(&hb);
+        return throw_msg(env, msg);
+    }
+    napi_value out, batch = batch_to_js(env, hb.b);
+    L.host_batch_free(&hb);
+    if (!batch || napi_create_object(env, &out) != napi_ok) return throw_msg(env, "change: cannot build the result object");
+    napi_set_named_property(env, out, "batch", batch);
+    napi_set_named_property(env, out, "status", status_arr);
+    return out;
+}
+
 napi_value MaxOpsPerLog(napi_env env, napi_callback_info info) {
     size_t argc = 1;
     napi_value argv[1];
@@ -459,7 +547,7 @@ napi_value KernelName(napi_env env, napi_callback_info) {
 
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
-        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"generate", Generate}, {"maxOpsPerLog", MaxOpsPerLog}, {"kernelName", KernelName},
+        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"generate", Generate}, {"change", Change}, {"maxOpsPerLog", MaxOpsPerLog}, {"kernelName", KernelName},
     };
     for (auto& f : fns) {
         napi_value fn;

@@ -21,6 +21,14 @@ export interface AddMarkOperation { opId: OperationId; action: "addMark"; obj: O
 export interface RemoveMarkOperation { opId: OperationId; action: "removeMark"; obj: OperationId; start: BoundaryPosition; end: BoundaryPosition; markType: MarkType; attrs?: { id?: string } }
 export type Operation = InsertOperation | DeleteOperation | MakeListOperation | AddMarkOperation | RemoveMarkOperation | { opId: OperationId; action: string; [k: string]: unknown }
 
+/** micromerge.ts:133-148 — what Micromerge.change(ops) takes: index-based operations on the text list (the only path this host serves) */
+export type InputOperation =
+    | { path: []; action: "makeList"; key: "text" }
+    | { path: ["text"]; action: "insert"; index: number; values: string[] }
+    | { path: ["text"]; action: "delete"; index: number; count: number }
+    | { path: ["text"]; action: "addMark"; startIndex: number; endIndex: number; markType: MarkType; attrs?: { url?: string; id?: string } }
+    | { path: ["text"]; action: "removeMark"; startIndex: number; endIndex: number; markType: MarkType; attrs?: { id?: string } }
+
 /** micromerge.ts:60-71 */
 export interface Change { actor: ActorId; seq: number; deps: Clock; startOp: number; ops: Operation[] }
 
@@ -35,7 +43,11 @@ export interface WireBatch {
     payload: Uint32Array; action: Uint8Array; markType: Uint8Array; sideA: Uint8Array; sideB: Uint8Array
     logHdr?: Uint32Array
     /** Change envelope (micromerge.ts:60-71) -> applyChange's causal admission runs on the device */
-    chgOff?: BigUint64Array; chgActor?: Uint32Array; chgSeq?: Uint32Array; chgNops?: Uint32Array; chgDeps?: Uint32Array; maxActors?: number
+    chgOff?: BigUint64Array; maxActors?: number
+    /** what the device reads: chgHdr = actorRank << 20 | nops, chgEnv rows of ((1 + maxActors + 3) & ~3) u16 = seq, deps[...] */
+    chgHdr?: Uint32Array; chgEnv?: Uint16Array
+    /** the same unpacked (filled by encodeDocs / unpackEnvelope; decodeChanges and decodePatches read these) */
+    chgActor?: Uint32Array; chgSeq?: Uint32Array; chgNops?: Uint32Array; chgDeps?: Uint32Array
     values: string[]; urls: string[]; logDoc: number[]; docActors: string[][]; docComments: string[][]
 }
 export interface WireResult {
@@ -53,9 +65,19 @@ export type Patch =
     | { path: ["text"]; action: "removeMark"; markType: MarkType; startIndex: number; endIndex: number }
 
 /** Per-replica handle with the reference's calls (Micromerge.applyChange :499, getTextWithFormatting :516). */
+/** the columns of ptx_input_ops (include/peritext_hip.h) */
+export interface WireInputOps {
+    chgOff: BigUint64Array; opOff: BigUint64Array; action: Uint8Array; markType: Uint8Array
+    index: Uint32Array; count: Uint32Array; payload: Uint32Array; values: Uint32Array; actor: Uint32Array; maxActors: number
+}
+
 export interface ReplicaHandle {
-    /** queues the change (all handles of an engine are merged in one launch); returns [] — see getPatches() */
+    /** causal admission (seq / deps) is checked HERE: throws RangeError like micromerge.ts:501-509 and leaves the replica untouched;
+     *  the change itself is queued (all handles of an engine are merged in one launch); returns [] — see getPatches() */
     applyChange(change: Change): Patch[]
+    /** Micromerge.change (micromerge.ts:308): InputOperations resolved against this replica's state on the device (ptx_change);
+     *  throws RangeError("List index out of bounds") like :804.  Needs engine.replica(docId, actorId). */
+    change(ops: InputOperation[]): { change: Change; patches: Patch[] }
     /** entry c = the Patch[] the reference's applyChange(c-th change) returns */
     getPatches(): Patch[][]
     /** throws RangeError("List element not found" | …) exactly where the reference's applyChange would have thrown */
@@ -74,13 +96,18 @@ export class MergeEngine {
     generate(cfg: { replicas: number; opsPerLog: number; mix: [number, number, number, number]; markTypes: MarkType[]; seed: number; nDocs: number; firstDoc?: number; listCap?: number; initialText?: string }):
         { docs: Change[][][]; spans: FormatSpanWithText[][][]; kernelMs: number; batch: WireBatch }
     digests(docs: Change[][][]): Array<[bigint, bigint]>
-    replica(docId?: number | string): ReplicaHandle
+    /** Micromerge.change for many replicas in one call: calls[d][r] = change() calls of replica r of document d */
+    changeMany(docs: Change[][][], calls: InputOperation[][][][], actors: ActorId[][], opts?: { extraComments?: string[][] }): { changes: Change[][][]; status: number[][] }
+    replica(docId?: number | string, actorId?: ActorId): ReplicaHandle
     flush(wantPatches?: boolean): void
 }
-export function encodeDocs(docs: Change[][][]): WireBatch
+export function encodeDocs(docs: Change[][][], opts?: { extraActors?: ActorId[][]; extraComments?: string[][] }): WireBatch
+export function encodeInputOps(batch: WireBatch, perLog: InputOperation[][][], actors: ActorId[]): WireInputOps
+export function packEnvelope(batch: WireBatch): WireBatch
+export function unpackEnvelope(batch: WireBatch): WireBatch
 export function decodeSpans(batch: WireBatch, res: WireResult, log: number): FormatSpanWithText[]
 export function decodePatches(batch: WireBatch, res: WireResult, log: number): Patch[][]
-export function decodeChanges(batch: WireBatch, log: number): Change[]
+export function decodeChanges(batch: WireBatch, log: number, textObjOfLog?: OperationId | null): Change[]
 /** bridge.ts:394-414 prosemirrorDocFromCRDT, as the Node.toJSON() form of the document (parity unpinned: no ProseMirror in the build image) */
 export function prosemirrorDocFromSpans(spans: FormatSpanWithText[]): { type: "doc"; content: Array<{ type: "paragraph"; content?: Array<{ type: "text"; text: string; marks?: Array<{ type: MarkType; attrs?: Record<string, string> }> }> }> }
 export function census(batch: WireBatch): Uint32Array

@@ -32,6 +32,40 @@ const STATUS_MESSAGES = {
     4: "duplicate opId",
     5: "log exceeds on-chip capacity",
     6: "malformed op row",
+    7: "List index out of bounds" /* :804 */,
+}
+const IN = { INSERT: 0, DELETE: 1, ADDMARK: 2, REMOVEMARK: 3, MAKELIST: 4 } /* ptx_input_ops.action */
+const CHG_ACTOR_SHIFT = 20, CHG_NOPS = 0x000fffff, ENV_SATURATED = 65535
+const envStride = maxActors => (1 + maxActors + 3) & ~3 /* PTX_ENV_STRIDE */
+
+/** chgActor / chgSeq / chgNops / chgDeps -> the packed envelope the device reads: chgHdr = actor << 20 | nops, chgEnv rows of
+ *  envStride(maxActors) u16 = seq, deps[...] (values saturate at 65535: such a change can never be admitted). */
+function packEnvelope(batch) {
+    const n = batch.chgActor.length, es = envStride(batch.maxActors)
+    batch.chgHdr = new Uint32Array(n)
+    batch.chgEnv = new Uint16Array(n * es)
+    for (let c = 0; c < n; c++) {
+        if (batch.chgActor[c] > 4095 || batch.chgNops[c] > CHG_NOPS) throw new RangeError("a document has at most 4096 actors and a change at most " + CHG_NOPS + " ops")
+        batch.chgHdr[c] = ((batch.chgActor[c] << CHG_ACTOR_SHIFT) | batch.chgNops[c]) >>> 0
+        batch.chgEnv[c * es] = Math.min(batch.chgSeq[c], ENV_SATURATED)
+        for (let a = 0; a < batch.maxActors; a++) batch.chgEnv[c * es + 1 + a] = Math.min(batch.chgDeps[c * batch.maxActors + a], ENV_SATURATED)
+    }
+    return batch
+}
+/** the inverse, for batches that come back from the device (generate / change) */
+function unpackEnvelope(batch) {
+    const n = batch.chgHdr ? batch.chgHdr.length : 0, es = envStride(batch.maxActors)
+    batch.chgActor = new Uint32Array(n)
+    batch.chgNops = new Uint32Array(n)
+    batch.chgSeq = new Uint32Array(n)
+    batch.chgDeps = new Uint32Array(n * batch.maxActors)
+    for (let c = 0; c < n; c++) {
+        batch.chgActor[c] = batch.chgHdr[c] >>> CHG_ACTOR_SHIFT
+        batch.chgNops[c] = batch.chgHdr[c] & CHG_NOPS
+        batch.chgSeq[c] = batch.chgEnv[c * es]
+        for (let a = 0; a < batch.maxActors; a++) batch.chgDeps[c * batch.maxActors + a] = batch.chgEnv[c * es + 1 + a]
+    }
+    return batch
 }
 const ROOT = "_root"
 const HEAD = "_head"
@@ -43,8 +77,12 @@ function splitOpId(id) {
     return [parseInt(m[1], 10), m[2]]
 }
 
-/** docs: Change[][][] (doc -> replica log -> changes in application order)  ->  SoA batch (include/peritext_hip.h). */
-function encodeDocs(docs) {
+/** docs: Change[][][] (doc -> replica log -> changes in application order)  ->  SoA batch (include/peritext_hip.h).
+ *  opts.extraActors / opts.extraComments: per document, actor names / comment ids that get a rank although no change uses them
+ *  yet (a replica about to make its first change, comment ids a later InputOperation introduces: ranks are positions in the
+ *  document's sorted id list, so they are reserved before the rows that use them exist). */
+function encodeDocs(docs, opts) {
+    const extraActors = (opts && opts.extraActors) || [], extraComments = (opts && opts.extraComments) || []
     const values = [], valueIx = new Map()
     const urls = [], urlIx = new Map()
     const rows = { opId: [], refA: [], refB: [], payload: [], action: [], markType: [], sideA: [], sideB: [] }
@@ -65,6 +103,8 @@ function encodeDocs(docs) {
                     if (op.markType === "comment") comments.add(op.attrs.id)
                 }
             }
+        for (const a of extraActors[d] || []) actors.add(a)
+        for (const c of extraComments[d] || []) comments.add(c)
         const actorList = Array.from(actors).sort() /* default sort = UTF-16 code-unit order = JS `<` (micromerge.ts:826) */
         const commentList = Array.from(comments).sort()
         const arank = new Map(actorList.map((a, i) => [a, i]))
@@ -153,8 +193,73 @@ function encodeDocs(docs) {
         values, urls, logDoc, docActors, docComments,
     }
     chgDepsRows.forEach((row, i) => row.forEach(([a, v]) => { batch.chgDeps[i * maxActors + a] = v }))
+    packEnvelope(batch)
     batch.logHdr = census(batch)
     return batch
+}
+
+/**
+ * InputOperation[] (micromerge.ts:133-148) of many replicas -> the columns of ptx_input_ops.  perLog[l] = the change() calls
+ * of the replica behind log l (each an InputOperation[]), actors[l] = its actor id.  New strings / urls extend batch.values /
+ * batch.urls; comment ids and actors must already have their rank in `batch` (encodeDocs opts).
+ */
+function encodeInputOps(batch, perLog, actors) {
+    const valueIx = new Map(batch.values.map((v, i) => [v, i])), urlIx = new Map(batch.urls.map((u, i) => [u, i]))
+    const chgOff = [0], opOff = [0], action = [], markType = [], index = [], count = [], payload = [], values = [], actor = []
+    perLog.forEach((calls, l) => {
+        const d = batch.logDoc[l]
+        const me = batch.docActors[d].indexOf(actors[l])
+        if (me < 0) throw new Error("actor " + actors[l] + " has no rank in this batch (encodeDocs opts.extraActors)")
+        actor.push(me)
+        const crank = new Map(batch.docComments[d].map((c, i) => [c, i]))
+        for (const ops of calls) {
+            for (const op of ops) {
+                let row
+                if (op.action === "makeList") {
+                    if ((op.path || []).length !== 0 || op.key !== "text") throw new Error("only the text list of the root map is supported")
+                    row = [IN.MAKELIST, 0, 0, 0, 0]
+                } else if (!Array.isArray(op.path) || op.path.length !== 1 || op.path[0] !== "text") {
+                    throw new Error("Only the text list is supported: " + JSON.stringify(op.path))
+                } else if (op.action === "insert") {
+                    const first = values.length
+                    for (const v of op.values) {
+                        if (typeof v !== "string") throw new Error("Expected value inserted into text to be a string")
+                        if (!valueIx.has(v)) {
+                            valueIx.set(v, batch.values.length)
+                            batch.values.push(v)
+                        }
+                        values.push(valueIx.get(v))
+                    }
+                    row = [IN.INSERT, 0, op.index, op.values.length, first]
+                } else if (op.action === "delete") row = [IN.DELETE, 0, op.index, op.count, 0]
+                else if (op.action === "addMark" || op.action === "removeMark") {
+                    const mt = MARK_NAMES.indexOf(op.markType)
+                    if (mt < 0) throw new Error("unknown mark type " + op.markType)
+                    let pl = 0
+                    if (op.markType === "link" && op.action === "addMark") {
+                        if (!urlIx.has(op.attrs.url)) {
+                            urlIx.set(op.attrs.url, batch.urls.length)
+                            batch.urls.push(op.attrs.url)
+                        }
+                        pl = urlIx.get(op.attrs.url)
+                    } else if (op.markType === "comment") {
+                        if (!crank.has(op.attrs.id)) throw new Error("comment id " + op.attrs.id + " has no rank in this batch (encodeDocs opts.extraComments)")
+                        pl = crank.get(op.attrs.id)
+                    }
+                    row = [op.action === "addMark" ? IN.ADDMARK : IN.REMOVEMARK, mt, op.startIndex, op.endIndex, pl]
+                } else throw new Error("unsupported InputOperation action " + op.action)
+                if (!(row[2] >= 0) || !(row[3] >= 0)) throw new RangeError("List index out of bounds: " + Math.min(row[2], row[3]))
+                action.push(row[0]); markType.push(row[1]); index.push(row[2]); count.push(row[3]); payload.push(row[4])
+            }
+            opOff.push(action.length)
+        }
+        chgOff.push(opOff.length - 1)
+    })
+    return {
+        chgOff: BigUint64Array.from(chgOff.map(BigInt)), opOff: BigUint64Array.from(opOff.map(BigInt)), action: Uint8Array.from(action), markType: Uint8Array.from(markType),
+        index: Uint32Array.from(index), count: Uint32Array.from(count), payload: Uint32Array.from(payload), values: Uint32Array.from(values), actor: Uint32Array.from(actor),
+        maxActors: Math.max(batch.maxActors, ...batch.docActors.map(a => a.length)),
+    }
 }
 
 /** ptx_log_hdr rows (LOG_HDR_WORDS u32 per log: n_ins, n_del, n_mark[4], max_counter, max_actor, n_comment_ids, reserved) — what the
@@ -215,13 +320,14 @@ function decodeSpans(batch, res, log) {
  * Change[] of one log — the inverse of encodeDocs for the ops of the text list (micromerge.ts:60-71 Change, :150-212
  * Operation, peritext.ts:25-65 mark ops) in the JSON-portable form of the traces ("_root" / "_head").
  */
-function decodeChanges(batch, log) {
+function decodeChanges(batch, log, textObjOfLog) {
+    if (!batch.chgActor) unpackEnvelope(batch)
     const d = batch.logDoc[log]
     const actors = batch.docActors[d], comments = batch.docComments[d]
     const oid = v => String(v >> 32n) + "@" + actors[Number(v & 0xffffffffn)]
     const out = []
     let row = Number(batch.logOff[log])
-    let textObj = null
+    let textObj = textObjOfLog === undefined ? null : textObjOfLog /* opId of the text list when this batch holds only newly made changes */
     for (let c = Number(batch.chgOff[log]); c < Number(batch.chgOff[log + 1]); c++) {
         const nops = batch.chgNops[c]
         const deps = {}
@@ -410,28 +516,97 @@ class MergeEngine {
         }
         return out
     }
-    /** A replica handle with the reference's per-replica calls; all handles of one engine are merged in ONE launch. */
-    replica(docId) {
+    /**
+     * Micromerge.change for many replicas in ONE call (ptx_change): docs = the replica logs applied so far (Change[][][]),
+     * calls[d][r] = the change() calls of replica r of document d (each an InputOperation[]; [] = none), actors[d][r] = its actor id.
+     * Returns {changes: Change[][][] (doc -> replica -> the Changes made, in call order), status: number[][]} — a replica whose
+     * status is not 0 made no change (STATUS_MESSAGES: 7 = the reference's RangeError "List index out of bounds").
+     */
+    changeMany(docs, calls, actors, opts) {
+        const batch = encodeDocs(docs, Object.assign({ extraActors: actors }, opts || {}))
+        const flatCalls = [], flatActors = []
+        docs.forEach((logs, d) => logs.forEach((_, r) => {
+            flatCalls.push(calls[d][r] || [])
+            flatActors.push(actors[d][r])
+        }))
+        const inputOps = encodeInputOps(batch, flatCalls, flatActors)
+        const raw = this.addon.change(this.ctx, batch, inputOps)
+        const made = Object.assign(raw.batch, { values: batch.values, urls: batch.urls, logDoc: batch.logDoc, docActors: batch.docActors, docComments: batch.docComments })
+        let log = 0
+        const changes = [], status = []
+        docs.forEach((logs, d) => {
+            changes.push([])
+            status.push([])
+            logs.forEach(changesOfLog => {
+                let textObj = null
+                for (const ch of changesOfLog) for (const op of ch.ops) if (op.action === "makeList" && textObj === null) textObj = op.opId
+                changes[d].push(decodeChanges(made, log, textObj))
+                status[d].push(raw.status[log])
+                log++
+            })
+        })
+        return { changes, status }
+    }
+    /**
+     * A replica handle with the reference's per-replica calls; all handles of one engine are merged in ONE launch.
+     * docId groups the replicas of a document (shared actor / comment ranks); actorId is needed for change().
+     */
+    replica(docId, actorId) {
         const self = this
-        const rep = { changes: [], spans: null, patches: null, error: null, docId: docId === undefined ? this.pending.length : docId }
+        const rep = { changes: [], clock: {}, spans: null, patches: null, error: null, docId: docId === undefined ? this.pending.length : docId, actorId }
         this.pending.push(rep)
+        const admit = change => {
+            /* applyChange's causal admission (micromerge.ts:499-511), here and now: throws like the reference and leaves the
+             * replica untouched, so a caller can retry out-of-order changes (reference/test/merge.ts:13-19) */
+            const last = rep.clock[change.actor] || 0
+            if (change.seq !== last + 1) throw new RangeError("Expected sequence number " + (last + 1) + ", got " + change.seq)
+            for (const a of Object.keys(change.deps || {}))
+                if (!rep.clock[a] || rep.clock[a] < change.deps[a]) throw new RangeError("Missing dependency: change " + change.deps[a] + " by actor " + a)
+            rep.clock[change.actor] = change.seq
+            rep.changes.push(change)
+            rep.spans = null
+            rep.patches = null
+        }
         return {
             applyChange(change) {
-                rep.changes.push(change)
-                rep.spans = null
-                rep.patches = null
+                admit(change)
                 return [] /* the call is only queued: the patches it would have returned come from getPatches() */
+            },
+            /** Micromerge.change(ops) (micromerge.ts:308): the InputOperations are resolved against this replica's state on the device;
+             *  returns {change, patches} like the reference (patches = what applying the change returned). */
+            change(ops) {
+                if (rep.actorId === undefined) throw new Error("engine.replica(docId, actorId): an actor id is needed to make changes")
+                const mates = self.pending.filter(r => r.docId === rep.docId)
+                const docs = [mates.map(r => r.changes)]
+                const comments = []
+                for (const op of ops) if (op.markType === "comment" && op.attrs && op.attrs.id !== undefined) comments.push(op.attrs.id)
+                const r = self.changeMany(docs, [mates.map(m => (m === rep ? [ops] : []))], [mates.map(m => (m.actorId === undefined ? rep.actorId : m.actorId))], { extraComments: [comments] })
+                const me = mates.indexOf(rep)
+                const st = r.status[0][me]
+                if (st !== 0) throw new RangeError(STATUS_MESSAGES[st] || "change error " + st)
+                const change = r.changes[0][me][0]
+                admit(change)
+                const patches = this.getPatches()
+                return { change, patches: patches[patches.length - 1] }
             },
             /** Patch[][]: entry c = what applyChange(c-th change) returns in the reference (one launch for all handles). */
             getPatches() {
                 if (rep.patches === null && rep.error === null) self.flush(true)
-                if (rep.error) throw rep.error
+                if (rep.error) {
+                    const e = rep.error
+                    rep.error = null /* reported once: the rejected change is no longer part of the log */
+                    throw e
+                }
                 return rep.patches
             },
             getTextWithFormatting(p) {
                 if (!Array.isArray(p) || p.length !== 1 || p[0] !== "text") throw new Error("Only the text list is supported: " + JSON.stringify(p))
                 if (rep.spans === null && rep.error === null) self.flush()
-                if (rep.error) throw rep.error
+                if (rep.error) {
+                    const e = rep.error
+                    rep.error = null
+                    throw e
+                }
                 return rep.spans
             },
         }
@@ -453,11 +628,29 @@ class MergeEngine {
                     if (wantPatches) r.patches = decodePatches(batch, res, log)
                     r.error = null
                 } catch (e) {
+                    /* an op of some change failed on the device (e.g. "List element not found", micromerge.ts:752): the reference
+                     * would have thrown out of that applyChange call.  The change is dropped from the log (ptx_log_result names the
+                     * row) so that later changes are not held hostage; the error surfaces once, at the next read. */
                     r.error = e
+                    r.spans = null
+                    r.patches = null
+                    const failRow = res.logs[12 * log + 7]
+                    if (failRow !== 0xffffffff) {
+                        let row = 0
+                        for (let c = 0; c < r.changes.length; c++) {
+                            const n = r.changes[c].ops.length
+                            if (failRow < row + n || (n === 0 && failRow === row)) {
+                                const gone = r.changes.splice(c, 1)[0]
+                                if (r.clock[gone.actor] === gone.seq) r.clock[gone.actor] = gone.seq - 1
+                                break
+                            }
+                            row += n
+                        }
+                    }
                 }
                 log++
             }
     }
 }
 
-module.exports = { MergeEngine, encodeDocs, decodeSpans, decodePatches, decodeChanges, prosemirrorDocFromSpans, PATCH, census, ACT, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }
+module.exports = { MergeEngine, encodeDocs, encodeInputOps, packEnvelope, unpackEnvelope, decodeSpans, decodePatches, decodeChanges, prosemirrorDocFromSpans, PATCH, census, ACT, IN, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }

@@ -52,12 +52,10 @@ class Batch:
     mark_type: np.ndarray
     side_a: np.ndarray
     side_b: np.ndarray
-    # causal envelope (one row per Change)
+    # causal envelope (one entry per Change): chg_hdr = actor << 20 | nops, chg_env rows of env_stride(max_actors) u16 = seq, deps[...]
     chg_off: np.ndarray
-    chg_actor: np.ndarray
-    chg_seq: np.ndarray
-    chg_nops: np.ndarray
-    chg_deps: np.ndarray
+    chg_hdr: np.ndarray
+    chg_env: np.ndarray
     max_actors: int
     # per-log census (include/peritext_hip.h ptx_log_hdr); None = let the library compute it
     log_hdr: np.ndarray = None
@@ -71,6 +69,24 @@ class Batch:
     @property
     def n_logs(self):
         return len(self.log_off) - 1
+
+    # the envelope's fields, unpacked (views for decoding and tests; the device reads chg_hdr / chg_env)
+    @property
+    def chg_actor(self):
+        return self.chg_hdr >> np.uint32(abi.CHG_ACTOR_SHIFT)
+
+    @property
+    def chg_nops(self):
+        return self.chg_hdr & np.uint32(abi.CHG_NOPS)
+
+    @property
+    def chg_seq(self):
+        return self.chg_env.reshape(-1, abi.env_stride(self.max_actors))[:, 0].astype(np.uint32)
+
+    @property
+    def chg_deps(self):
+        """[n_changes, max_actors]"""
+        return self.chg_env.reshape(-1, abi.env_stride(self.max_actors))[:, 1:1 + self.max_actors].astype(np.uint32)
 
     @property
     def n_ops(self):
@@ -92,8 +108,7 @@ class Batch:
         hdr = None if self.log_hdr is None else np.tile(self.log_hdr, copies)
         return Batch(
             log_off, rep(self.op_id), rep(self.ref_a), rep(self.ref_b), rep(self.payload), rep(self.action),
-            rep(self.mark_type), rep(self.side_a), rep(self.side_b), chg_off, rep(self.chg_actor), rep(self.chg_seq),
-            rep(self.chg_nops), rep(self.chg_deps), self.max_actors, hdr, self.values, self.urls,
+            rep(self.mark_type), rep(self.side_a), rep(self.side_b), chg_off, rep(self.chg_hdr), rep(self.chg_env), self.max_actors, hdr, self.values, self.urls,
             self.log_doc * copies, self.doc_actors, self.doc_comments,
         )
 
@@ -124,6 +139,22 @@ def census(log_off, op_id, action, mark_type, payload=None):
         np.maximum.at(nid, lix[is_c], payload[is_c].astype(np.uint32) + np.uint32(1))
         hdr["n_comment_ids"] = nid
     return hdr
+
+
+def pack_envelope(actor, seq, nops, deps, max_actors):
+    """(chg_hdr u32[n], chg_env u16[n * env_stride]) from per-change actor ranks, seqs, op counts and a [n, max_actors] deps
+    matrix.  seq / deps beyond 16 bits saturate at 65 535: a log holds at most 65 533 changes, so such a change can never be
+    admitted — the reference's RangeError either way."""
+    actor, nops = np.asarray(actor, dtype=np.uint64), np.asarray(nops, dtype=np.uint64)
+    if len(actor) and (int(actor.max()) > 4095 or int(nops.max()) > abi.CHG_NOPS):
+        raise ValueError("a document has at most 4096 actors and a change at most %d ops" % abi.CHG_NOPS)
+    hdr = ((actor << np.uint64(abi.CHG_ACTOR_SHIFT)) | nops).astype(np.uint32)
+    es = abi.env_stride(max_actors)
+    env = np.zeros((len(actor), es), dtype=np.uint16)
+    if len(actor):
+        env[:, 0] = np.minimum(np.asarray(seq, dtype=np.uint64), abi.ENV_SATURATED).astype(np.uint16)
+        env[:, 1:1 + max_actors] = np.minimum(np.asarray(deps, dtype=np.uint64).reshape(len(actor), max_actors), abi.ENV_SATURATED).astype(np.uint16)
+    return hdr, env.reshape(-1)
 
 
 def _pack(ctr, rank):
@@ -235,6 +266,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None):
         for a, v in row.items():
             deps[i, a] = v
     u64 = lambda x: np.asarray(x, dtype=np.uint64)  # noqa: E731
+    chg_hdr, chg_env = pack_envelope(chg_actor, chg_seq, chg_nops, deps, max_actors)
     hdr = census(u64(log_off), u64(cols["op_id"]), np.asarray(cols["action"], dtype=np.uint8), np.asarray(cols["mark_type"], dtype=np.uint8),
                  np.asarray(cols["payload"], dtype=np.uint32))
     return Batch(
@@ -243,8 +275,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None):
         payload=np.asarray(cols["payload"], dtype=np.uint32), action=np.asarray(cols["action"], dtype=np.uint8),
         mark_type=np.asarray(cols["mark_type"], dtype=np.uint8), side_a=np.asarray(cols["side_a"], dtype=np.uint8),
         side_b=np.asarray(cols["side_b"], dtype=np.uint8), chg_off=u64(chg_off),
-        chg_actor=np.asarray(chg_actor, dtype=np.uint32), chg_seq=np.asarray(chg_seq, dtype=np.uint32),
-        chg_nops=np.asarray(chg_nops, dtype=np.uint32), chg_deps=deps.reshape(-1), max_actors=max_actors,
+        chg_hdr=chg_hdr, chg_env=chg_env, max_actors=max_actors,
         values=values, urls=urls, log_doc=log_doc, doc_actors=doc_actors, doc_comments=doc_comments,
     )
 
@@ -394,8 +425,8 @@ def split_batch(batch, first_changes):
         cidx = np.concatenate([np.arange(q0, q1) for _, _, q0, q1 in parts[part]]).astype(np.int64) if parts[part] else np.zeros(0, dtype=np.int64)
         out.append(Batch(
             np.asarray(rows[part], dtype=np.uint64), batch.op_id[ridx], batch.ref_a[ridx], batch.ref_b[ridx], batch.payload[ridx], batch.action[ridx],
-            batch.mark_type[ridx], batch.side_a[ridx], batch.side_b[ridx], np.asarray(chgs[part], dtype=np.uint64), batch.chg_actor[cidx],
-            batch.chg_seq[cidx], batch.chg_nops[cidx], batch.chg_deps.reshape(-1, batch.max_actors)[cidx].reshape(-1), batch.max_actors, None,
+            batch.mark_type[ridx], batch.side_a[ridx], batch.side_b[ridx], np.asarray(chgs[part], dtype=np.uint64), batch.chg_hdr[cidx],
+            batch.chg_env.reshape(-1, abi.env_stride(batch.max_actors))[cidx].reshape(-1), batch.max_actors, None,
             batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments))
     return out[0], out[1]
 
@@ -418,11 +449,12 @@ def decode_changes(batch, log, text_obj=None):
 
     out = []
     row = b0
+    c_actor, c_nops, c_seq, c_deps = batch.chg_actor, batch.chg_nops, batch.chg_seq, batch.chg_deps
     for c in range(c0, c1):
-        nops = int(batch.chg_nops[c])
+        nops = int(c_nops[c])
         deps = {}
         for a in range(batch.max_actors):
-            v = int(batch.chg_deps[c * batch.max_actors + a])
+            v = int(c_deps[c, a])
             if v:
                 deps[actors[a]] = v
         ops = []
@@ -455,7 +487,7 @@ def decode_changes(batch, log, text_obj=None):
                 raise ValueError("row %d of log %d is not an op of the text list" % (i - b0, log))
             ops.append(op)
         start_op = int(batch.op_id[row]) >> 32 if nops else 0
-        out.append({"actor": actors[int(batch.chg_actor[c])], "seq": int(batch.chg_seq[c]), "deps": deps, "startOp": start_op, "ops": ops})
+        out.append({"actor": actors[int(c_actor[c])], "seq": int(c_seq[c]), "deps": deps, "startOp": start_op, "ops": ops})
         row += nops
     return out
 
@@ -612,7 +644,7 @@ def get_cursor(batch, res, log, index):
 
 # ---- on-disk form of a batch (SURVEY.md §5 "checkpoint / resume": the reference only has JSON.stringify dumps of
 # Change objects, test/fuzz.ts:16-20; replaying a saved op log = re-running the merge) ----
-_COLUMNS = ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_actor", "chg_seq", "chg_nops", "chg_deps")
+_COLUMNS = ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_hdr", "chg_env")
 
 
 def save_batch(path, batch):

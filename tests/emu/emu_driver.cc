@@ -42,10 +42,8 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     A.side_a = b->side_a;
     A.side_b = b->side_b;
     A.chg_off = admission ? b->chg_off : nullptr;
-    A.chg_actor = b->chg_actor;
-    A.chg_seq = b->chg_seq;
-    A.chg_nops = b->chg_nops;
-    A.chg_deps = b->chg_deps;
+    A.chg_hdr = b->chg_hdr;
+    A.chg_env = b->chg_env;
     A.max_actors = b->max_actors;
     A.clocks = nullptr;
     A.stop_after = 0;
@@ -156,8 +154,7 @@ extern "C" int ptx_emu_generate(PtxGenArgs* A, int reverse) {
  * the caller allocates the capacity-layout output (out_off = rows per log, known from the InputOperations) */
 extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const ptx_input_ops* in, const uint64_t* out_off, uint64_t* o_op_id,
                               uint64_t* o_ref_a, uint64_t* o_ref_b, uint32_t* o_payload, uint8_t* o_action, uint8_t* o_mark_type, uint8_t* o_side_a, uint8_t* o_side_b,
-                              uint32_t* o_chg_actor, uint32_t* o_chg_seq, uint32_t* o_chg_nops, uint32_t* o_chg_deps, uint32_t* status, uint32_t* rows_made,
-                              uint32_t* chgs_made, uint32_t lds_bytes, int reverse) {
+                              uint32_t* o_chg_hdr, uint16_t* o_chg_env, uint32_t* status, uint32_t* rows_made, uint32_t* chgs_made, uint32_t lds_bytes, int reverse) {
     PtxChangeArgs A;
     memset(&A, 0, sizeof(A));
     A.log_off = b->log_off;
@@ -171,7 +168,7 @@ extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, con
     A.res = res;
     A.elem_rank = rank;
     A.chg_off = b->chg_off;
-    A.chg_actor = b->chg_actor;
+    A.chg_hdr = b->chg_hdr;
     A.max_actors = in->max_actors;
     A.in_chg_off = in->chg_off;
     A.in_op_off = in->op_off;
@@ -191,10 +188,8 @@ extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, con
     A.o_mark_type = o_mark_type;
     A.o_side_a = o_side_a;
     A.o_side_b = o_side_b;
-    A.o_chg_actor = o_chg_actor;
-    A.o_chg_seq = o_chg_seq;
-    A.o_chg_nops = o_chg_nops;
-    A.o_chg_deps = o_chg_deps;
+    A.o_chg_hdr = o_chg_hdr;
+    A.o_chg_env = o_chg_env;
     A.status = status;
     A.rows_made = rows_made;
     A.chgs_made = chgs_made;

@@ -106,10 +106,8 @@ def batch_struct(b):
     s.side_a = ptr(b.side_a, abi.u8p)
     s.side_b = ptr(b.side_b, abi.u8p)
     s.chg_off = ptr(b.chg_off, abi.u64p)
-    s.chg_actor = ptr(b.chg_actor, abi.u32p)
-    s.chg_seq = ptr(b.chg_seq, abi.u32p)
-    s.chg_nops = ptr(b.chg_nops, abi.u32p)
-    s.chg_deps = ptr(b.chg_deps, abi.u32p)
+    s.chg_hdr = ptr(b.chg_hdr, abi.u32p)
+    s.chg_env = ptr(b.chg_env, abi.u16p)
     s.max_actors = b.max_actors
     if b.log_hdr is not None and len(b.log_hdr):
         s.log_hdr = b.log_hdr.ctypes.data_as(C.POINTER(abi.ptx_log_hdr))
@@ -201,8 +199,8 @@ def made_batch(batch, ops, cols, env, rows_made, chgs_made, out_off):
     chg_off = np.zeros(n_logs + 1, dtype=np.uint64)
     chg_off[1:] = np.cumsum(chgs_made[:n_logs].astype(np.uint64))
     return wire.Batch(log_off, cols["op_id"][keep], cols["ref_a"][keep], cols["ref_b"][keep], cols["payload"][keep], cols["action"][keep], cols["mark_type"][keep],
-                      cols["side_a"][keep], cols["side_b"][keep], chg_off, env["chg_actor"][ckeep], env["chg_seq"][ckeep], env["chg_nops"][ckeep],
-                      env["chg_deps"].reshape(-1, na)[ckeep].reshape(-1), na, None, batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments)
+                      cols["side_a"][keep], cols["side_b"][keep], chg_off, env["chg_hdr"][ckeep], env["chg_env"].reshape(-1, abi.env_stride(na))[ckeep].reshape(-1),
+                      na, None, batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments)
 
 
 def emu_change(batch, res, ops, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB):
@@ -213,15 +211,14 @@ def emu_change(batch, res, ops, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB
     T, NC, na = max(int(out_off[-1]), 1), max(int(ops.chg_off[-1]), 1), ops.max_actors
     cols = {"op_id": np.zeros(T, np.uint64), "ref_a": np.zeros(T, np.uint64), "ref_b": np.zeros(T, np.uint64), "payload": np.zeros(T, np.uint32),
             "action": np.zeros(T, np.uint8), "mark_type": np.zeros(T, np.uint8), "side_a": np.zeros(T, np.uint8), "side_b": np.zeros(T, np.uint8)}
-    env = {"chg_actor": np.zeros(NC, np.uint32), "chg_seq": np.zeros(NC, np.uint32), "chg_nops": np.zeros(NC, np.uint32), "chg_deps": np.zeros(NC * na, np.uint32)}
+    env = {"chg_hdr": np.zeros(NC, np.uint32), "chg_env": np.zeros(NC * abi.env_stride(na), np.uint16)}
     status, rows_made, chgs_made = (np.zeros(max(n_logs, 1), np.uint32) for _ in range(3))
     lib = C.CDLL(lib_path)
     lib.ptx_emu_change.restype = C.c_int
     s, si = batch_struct(batch), input_ops_struct(ops)
     vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
     rc = lib.ptx_emu_change(C.byref(s), vp(res.logs), vp(res.elem_rank), C.byref(si), vp(out_off), vp(cols["op_id"]), vp(cols["ref_a"]), vp(cols["ref_b"]), vp(cols["payload"]),
-                            vp(cols["action"]), vp(cols["mark_type"]), vp(cols["side_a"]), vp(cols["side_b"]), vp(env["chg_actor"]), vp(env["chg_seq"]), vp(env["chg_nops"]),
-                            vp(env["chg_deps"]), vp(status), vp(rows_made), vp(chgs_made), C.c_uint32(lds_bytes), C.c_int(reverse))
+                            vp(cols["action"]), vp(cols["mark_type"]), vp(cols["side_a"]), vp(cols["side_b"]), vp(env["chg_hdr"]), vp(env["chg_env"]), vp(status), vp(rows_made), vp(chgs_made), C.c_uint32(lds_bytes), C.c_int(reverse))
     assert rc == 0
     return made_batch(batch, ops, cols, env, rows_made, chgs_made, out_off), status[:n_logs]
 
@@ -234,25 +231,22 @@ def concat_batches(base, more):
         chgs += [("b", int(base.chg_off[l]), int(base.chg_off[l + 1])), ("m", int(more.chg_off[l]), int(more.chg_off[l + 1]))]
     na = max(base.max_actors, more.max_actors)
 
-    def cat(name, parts, width=1, reshape=None):
-        out = []
-        for src, a, b in parts:
-            arr = getattr(base if src == "b" else more, name)
-            if reshape:
-                w = (base if src == "b" else more).max_actors
-                arr = arr.reshape(-1, w) if len(arr) else arr.reshape(0, w)
-                blk = np.zeros((b - a, na), dtype=np.uint32)
-                blk[:, :w] = arr[a:b]
-                out.append(blk.reshape(-1))
-            else:
-                out.append(arr[a:b])
+    def cat(name, parts):
+        out = [getattr(base if src == "b" else more, name)[a:b] for src, a, b in parts]
         return np.concatenate(out) if out else np.zeros(0)
 
-    log_off = base.log_off + more.log_off
-    chg_off = base.chg_off + more.chg_off
-    return wire.Batch(log_off.astype(np.uint64), cat("op_id", rows), cat("ref_a", rows), cat("ref_b", rows), cat("payload", rows), cat("action", rows), cat("mark_type", rows),
-                      cat("side_a", rows), cat("side_b", rows), chg_off.astype(np.uint64), cat("chg_actor", chgs), cat("chg_seq", chgs), cat("chg_nops", chgs),
-                      cat("chg_deps", chgs, reshape=True).astype(np.uint32), na, None, base.values, base.urls, base.log_doc, base.doc_actors, base.doc_comments)
+    def cat_env(parts):
+        out = []
+        for src, a, b in parts:
+            x = base if src == "b" else more
+            out.append(wire.pack_envelope(x.chg_actor[a:b], x.chg_seq[a:b], x.chg_nops[a:b],
+                                          np.pad(x.chg_deps[a:b], ((0, 0), (0, na - x.max_actors))) if b > a else np.zeros((0, na), np.uint32), na))
+        return np.concatenate([h for h, _ in out]).astype(np.uint32), np.concatenate([e for _, e in out]).astype(np.uint16)
+
+    hdr, env = cat_env(chgs)
+    return wire.Batch((base.log_off + more.log_off).astype(np.uint64), cat("op_id", rows), cat("ref_a", rows), cat("ref_b", rows), cat("payload", rows), cat("action", rows),
+                      cat("mark_type", rows), cat("side_a", rows), cat("side_b", rows), (base.chg_off + more.chg_off).astype(np.uint64), hdr, env, na, None,
+                      base.values, base.urls, base.log_doc, base.doc_actors, base.doc_comments)
 
 
 def mini_doc(ops_second_change, first_text="ABCDE"):
@@ -452,8 +446,8 @@ class _GenArgs(C.Structure):
                 ("mix0", C.c_uint32), ("mix01", C.c_uint32), ("mix012", C.c_uint32), ("n_mark_types", C.c_uint32), ("mark_types", C.c_uint8 * 4),
                 ("init_len", C.c_uint32), ("init_text", C.c_uint8 * 16), ("rows_per_log", C.c_uint32), ("list_cap", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("op_id", C.c_void_p), ("ref_a", C.c_void_p), ("ref_b", C.c_void_p), ("payload", C.c_void_p), ("action", C.c_void_p),
-                ("mark_type", C.c_void_p), ("side_a", C.c_void_p), ("side_b", C.c_void_p), ("chg_actor", C.c_void_p), ("chg_seq", C.c_void_p),
-                ("chg_nops", C.c_void_p), ("chg_deps", C.c_void_p), ("n_changes", C.c_void_p), ("n_comments", C.c_void_p), ("status", C.c_void_p),
+                ("mark_type", C.c_void_p), ("side_a", C.c_void_p), ("side_b", C.c_void_p), ("chg_hdr", C.c_void_p), ("chg_env", C.c_void_p),
+                ("n_changes", C.c_void_p), ("n_comments", C.c_void_p), ("status", C.c_void_p),
                 ("ctab", C.c_void_p), ("known", C.c_void_p)]
 
 
@@ -474,7 +468,7 @@ def batch_from_generated(cfg, n_docs, cols, env, n_changes, n_comments):
     chg_off[1:] = np.cumsum(n_changes.astype(np.uint64))
     actors, comments, log_doc = wire.generated_tables(n_docs, R, n_comments)
     return wire.Batch(log_off, cols["op_id"], cols["ref_a"], cols["ref_b"], cols["payload"], cols["action"], cols["mark_type"], cols["side_a"], cols["side_b"],
-                      chg_off, env["chg_actor"][keep], env["chg_seq"][keep], env["chg_nops"][keep], env["chg_deps"].reshape(-1, R)[keep].reshape(-1), R,
+                      chg_off, env["chg_hdr"][keep], env["chg_env"].reshape(-1, abi.env_stride(R))[keep].reshape(-1), R,
                       None, wire.GEN_VALUES, wire.GEN_URLS, log_doc, actors, comments)
 
 
@@ -484,7 +478,7 @@ def emu_generate(cfg, n_docs, seed, first_doc=0, list_cap=None, reverse=0, lib_p
     rows = max(n_docs * R * N, 1)
     cols = {"op_id": np.zeros(rows, np.uint64), "ref_a": np.zeros(rows, np.uint64), "ref_b": np.zeros(rows, np.uint64), "payload": np.zeros(rows, np.uint32),
             "action": np.zeros(rows, np.uint8), "mark_type": np.zeros(rows, np.uint8), "side_a": np.zeros(rows, np.uint8), "side_b": np.zeros(rows, np.uint8)}
-    env = {"chg_actor": np.zeros(rows, np.uint32), "chg_seq": np.zeros(rows, np.uint32), "chg_nops": np.zeros(rows, np.uint32), "chg_deps": np.zeros(rows * R, np.uint32)}
+    env = {"chg_hdr": np.zeros(rows, np.uint32), "chg_env": np.zeros(rows * abi.env_stride(R), np.uint16)}
     n_changes = np.zeros(max(n_docs * R, 1), np.uint32)
     n_comments = np.zeros(max(n_docs, 1), np.uint32)
     status = np.zeros(max(n_docs, 1), np.uint32)

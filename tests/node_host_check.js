@@ -5,6 +5,9 @@
  *   node tests/node_host_check.js encode <fixture.json>   print sha256 of every encoded column (no GPU, no addon)
  *   node tests/node_host_check.js load                    the addon loads and dlopens libperitext_hip.so (no GPU)
  *   node tests/node_host_check.js run <fixture.json>...   GPU: applyChanges + the replica() surface vs the fixture's spans
+ *   node tests/node_host_check.js inputops <scripts.json> print sha256 of the InputOperation columns of every change() call (no GPU)
+ *   node tests/node_host_check.js change <scripts.json>   GPU: every change()/applyChange call of the reference's test file through
+ *                                                         replica().change / applyChange -> the reference's Changes and spans
  */
 const fs = require("fs")
 const path = require("path")
@@ -20,7 +23,7 @@ if (cmd === "encode") {
     const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
     const b = host.encodeDocs(gen.docs.map(d => d.logs))
     const out = { nLogs: b.nLogs, nOps: b.nOps, values: b.values, urls: b.urls, docComments: b.docComments }
-    for (const k of ["logOff", "opId", "refA", "refB", "payload", "action", "markType", "sideA", "sideB", "logHdr", "chgOff", "chgActor", "chgSeq", "chgNops", "chgDeps"]) out[k] = sha(b[k])
+    for (const k of ["logOff", "opId", "refA", "refB", "payload", "action", "markType", "sideA", "sideB", "logHdr", "chgOff", "chgActor", "chgSeq", "chgNops", "chgDeps", "chgHdr", "chgEnv"]) out[k] = sha(b[k])
     out.maxActors = b.maxActors
     console.log(JSON.stringify(out))
 } else if (cmd === "load") {
@@ -85,6 +88,91 @@ if (cmd === "encode") {
     }
     engine.close()
     console.log(JSON.stringify({ ok: true, logs, patches }))
+} else if (cmd === "inputops") {
+    /* no GPU: the InputOperations of the first change() call after generateDocs of every case, encoded against the state so far */
+    const g = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    const out = []
+    for (const c of g.cases) {
+        const logs = c.actors.map(() => [])
+        for (const e of c.events) {
+            if (e.kind === "apply") logs[e.replica].push(e.change)
+            else {
+                const comments = []
+                for (const ev of c.events) for (const op of ev.change.ops) if (op.markType === "comment") comments.push(op.attrs.id)
+                const b = host.encodeDocs([logs], { extraActors: [c.actors], extraComments: [comments] })
+                const io = host.encodeInputOps(b, c.actors.map((_, r) => (r === e.replica ? [e.ops] : [])), c.actors)
+                const row = { maxActors: io.maxActors }
+                for (const k of ["chgOff", "opOff", "action", "markType", "index", "count", "payload", "values", "actor"]) row[k] = sha(io[k])
+                out.push(row)
+                logs[e.replica].push(e.change)
+            }
+        }
+    }
+    console.log(JSON.stringify(out))
+} else if (cmd === "change") {
+    /* GPU: Micromerge.change(InputOperation[]) through replica().change — the reference's own calls, its own Changes */
+    const g = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    const engine = new host.MergeEngine()
+    const normChange = ch => ({
+        actor: ch.actor, seq: ch.seq, startOp: ch.ops.length ? ch.startOp : null,
+        deps: Object.keys(ch.deps).filter(k => ch.deps[k]).sort().reduce((o, k) => Object.assign(o, { [k]: ch.deps[k] }), {}),
+        ops: ch.ops.map(op => {
+            const o = {}
+            for (const k of Object.keys(op).sort()) if (!(k === "obj" && op[k] === host.ROOT) && !(k === "elemId" && op[k] === host.HEAD)) o[k] = op[k]
+            return JSON.parse(JSON.stringify(o))
+        }),
+    })
+    let calls = 0, cases = 0
+    for (const c of g.cases.slice(0, parseInt(process.argv[4] || "1000", 10))) {
+        engine.pending = []
+        const comments = []
+        for (const ev of c.events) for (const op of ev.change.ops) if (op.markType === "comment") comments.push(op.attrs.id)
+        const reps = c.actors.map(a => engine.replica(0, a))
+        for (const e of c.events) {
+            if (e.kind === "apply") reps[e.replica].applyChange(e.change)
+            else {
+                const r = reps[e.replica].change(e.ops)
+                assert.deepStrictEqual(normChange(r.change), normChange(e.change), c.title)
+                assert.ok(Array.isArray(r.patches))
+                calls++
+            }
+        }
+        reps.forEach((r, ri) => {
+            if (c.spans[ri] !== null) assert.deepStrictEqual(norm(r.getTextWithFormatting(["text"])), norm(c.spans[ri]), c.title)
+        })
+        cases++
+    }
+    /* applyChange throws synchronously and leaves the replica intact: the retry loop of reference/test/merge.ts:11-17 works */
+    {
+        engine.pending = []
+        const c = g.cases.find(x => x.events.filter(e => e.kind === "change").length >= 3)
+        const made = c.events.filter(e => e.kind === "change" && e.replica === 0).map(e => e.change)
+        const r = engine.replica(0, "reader")
+        const queue = made.slice().reverse()
+        let throws = 0
+        while (queue.length) {
+            const ch = queue.shift()
+            try {
+                r.applyChange(ch)
+            } catch (e) {
+                assert.ok(e instanceof RangeError && /Expected sequence number|Missing dependency/.test(e.message))
+                throws++
+                queue.push(ch)
+            }
+        }
+        assert.ok(throws > 0)
+        r.getTextWithFormatting(["text"])
+        /* an op-level failure surfaces once, the rejected change leaves the log, later changes go through */
+        engine.pending = []
+        const r2 = engine.replica(0, "reader")
+        r2.applyChange(made[0])
+        r2.applyChange({ actor: "zz", seq: 1, deps: {}, startOp: 900, ops: [{ opId: "900@zz", action: "del", obj: made[0].ops[0].opId, elemId: "777@nobody" }] })
+        assert.throws(() => r2.getTextWithFormatting(["text"]), e => e instanceof RangeError && /List element not found/.test(e.message))
+        const spans = r2.getTextWithFormatting(["text"])
+        assert.ok(spans.length >= 1)
+    }
+    engine.close()
+    console.log(JSON.stringify({ ok: true, cases, calls }))
 } else if (cmd === "pmdoc") {
     /* no GPU: ProseMirror doc JSON of every expected span list of a fixture */
     const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
@@ -116,6 +204,6 @@ if (cmd === "encode") {
     engine.close()
     console.log(JSON.stringify({ ok: true, logs }))
 } else {
-    console.error("usage: encode|load|run|patches|decode|generate")
+    console.error("usage: encode|load|run|patches|decode|generate|inputops|change")
     process.exit(2)
 }

@@ -341,7 +341,7 @@ def test_batch_file_round_trip(tmp_path):
     p = str(tmp_path / "oplog.npz")
     wire.save_batch(p, batch)
     back = wire.load_batch(p)
-    for k in ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_actor", "chg_seq", "chg_nops", "chg_deps", "log_hdr"):
+    for k in ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_hdr", "chg_env", "log_hdr"):
         a, b = getattr(batch, k), getattr(back, k)
         assert a.dtype == b.dtype and (a == b).all(), k
     assert (back.values, back.urls, back.doc_comments, back.max_actors) == (batch.values, batch.urls, batch.doc_comments, batch.max_actors)

@@ -196,7 +196,7 @@ def test_default_shapes_cover_256_and_512_threads(eng):
 def test_capacity_status_when_the_lds_window_is_too_small(monkeypatch):
     from peritext_amd.engine import Engine
 
-    monkeypatch.setenv("PTX_LDS_BYTES", "4096")
+    monkeypatch.setenv("PTX_LDS_BYTES", "2048")
     g = _load("ptxgen_config4_600.json")
     batch = wire.encode_docs([g["docs"][0]["logs"]])
     with Engine(0) as e:

@@ -479,7 +479,7 @@ def test_streaming_append_to_resident_logs(eng):
     try:
         assert eng.n_ops(db_grown) == full.n_ops and eng.n_changes(db_grown) == int(full.chg_off[-1])
         got = eng.download_batch(db_grown)
-        for k in ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_actor", "chg_seq", "chg_nops", "chg_deps"):
+        for k in ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_hdr", "chg_env"):
             assert np.array_equal(getattr(got, k), getattr(full, k)), k
         assert np.array_equal(got.log_hdr, full.log_hdr)
         out = {}

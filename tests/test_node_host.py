@@ -35,7 +35,7 @@ def test_addon_loads_and_binds_the_c_abi():
     info = _node("load")
     assert info["abi"] == abi.PTX_ABI_VERSION
     assert info["kernel"].startswith("ptx_merge_kernel")
-    assert info["exports"] == ["applyMaterialize", "create", "destroy", "generate", "kernelName", "maxOpsPerLog", "open"]
+    assert info["exports"] == ["applyMaterialize", "change", "create", "destroy", "generate", "kernelName", "maxOpsPerLog", "open"]
 
 
 @needs_node
@@ -50,7 +50,8 @@ def test_js_encoder_matches_python_encoder(name):
     assert js["values"] == b.values and js["urls"] == b.urls and js["docComments"] == b.doc_comments
     cols = {"logOff": b.log_off, "opId": b.op_id, "refA": b.ref_a, "refB": b.ref_b, "payload": b.payload, "action": b.action,
             "markType": b.mark_type, "sideA": b.side_a, "sideB": b.side_b, "logHdr": b.log_hdr,
-            "chgOff": b.chg_off, "chgActor": b.chg_actor, "chgSeq": b.chg_seq, "chgNops": b.chg_nops, "chgDeps": b.chg_deps}
+            "chgOff": b.chg_off, "chgActor": b.chg_actor, "chgSeq": b.chg_seq, "chgNops": b.chg_nops, "chgDeps": b.chg_deps,
+            "chgHdr": b.chg_hdr, "chgEnv": b.chg_env}
     assert js["maxActors"] == b.max_actors
     for k, a in cols.items():
         assert js[k] == sha(a), k
@@ -74,6 +75,40 @@ def test_node_host_patch_streams():
     out = _node("patches", *[os.path.join(H.GOLDEN, n) for n in names], timeout=600)
     want = [e for n in names for d in json.load(open(os.path.join(H.GOLDEN, n)))["docs"] for e in d["expected"]]
     assert out["ok"] and out["logs"] == len(want) and out["patches"] == sum(len(e["patches"]) for e in want)
+
+
+@needs_node
+def test_js_input_ops_encoder_matches_python():
+    """InputOperation[] -> ptx_input_ops columns: the JS host and the Python driver agree on every change() call of the
+    reference's test file (incl. the rank reservation for actors and comment ids that are not in the logs yet)."""
+    import change_script as CS
+
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    js = _node("inputops", os.path.join(H.GOLDEN, "kat_change_scripts.json"))
+    k = 0
+    for c in CS.load_scripts():
+        logs = [[] for _ in c["actors"]]
+        for e in c["events"]:
+            if e["kind"] == "change":
+                b = wire.encode_docs([logs], extra_actors=[c["actors"]], extra_comments=[CS.comment_ids(c)])
+                io = wire.encode_input_ops(b, [[e["ops"]] if r == e["replica"] else [] for r in range(len(c["actors"]))], c["actors"])
+                for name, col in (("chgOff", io.chg_off), ("opOff", io.op_off), ("action", io.action), ("markType", io.mark_type), ("index", io.index),
+                                  ("count", io.count), ("payload", io.payload), ("values", io.values), ("actor", io.actor)):
+                    assert js[k][name] == sha(col), (c["title"], name)
+                assert js[k]["maxActors"] == io.max_actors
+                k += 1
+            logs[e["replica"]].append(e["change"])
+    assert k == len(js) == 125
+
+
+@pytest.mark.gpu
+@needs_node
+@needs_addon
+def test_node_host_change_calls_of_the_reference_test_file():
+    """replica().change(InputOperation[]) / applyChange through N-API on the GPU: the 125 change() calls of reference/test/micromerge.ts
+    give the reference's Changes, the replicas end on its spans; applyChange throws synchronously like micromerge.ts:501-509."""
+    out = _node("change", os.path.join(H.GOLDEN, "kat_change_scripts.json"), timeout=900)
+    assert out["ok"] and out["cases"] == 46 and out["calls"] == 125
 
 
 @needs_node
