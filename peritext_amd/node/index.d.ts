@@ -64,13 +64,13 @@ export type Patch =
     | { path: ["text"]; action: "addMark"; markType: MarkType; startIndex: number; endIndex: number; attrs?: { url?: string; id?: string } }
     | { path: ["text"]; action: "removeMark"; markType: MarkType; startIndex: number; endIndex: number }
 
-/** Per-replica handle with the reference's calls (Micromerge.applyChange :499, getTextWithFormatting :516). */
 /** the columns of ptx_input_ops (include/peritext_hip.h) */
 export interface WireInputOps {
     chgOff: BigUint64Array; opOff: BigUint64Array; action: Uint8Array; markType: Uint8Array
     index: Uint32Array; count: Uint32Array; payload: Uint32Array; values: Uint32Array; actor: Uint32Array; maxActors: number
 }
 
+/** Per-replica handle with the reference's calls (Micromerge.applyChange :499, change :308, getTextWithFormatting :516). */
 export interface ReplicaHandle {
     /** causal admission (seq / deps) is checked HERE: throws RangeError like micromerge.ts:501-509 and leaves the replica untouched;
      *  the change itself is queued (all handles of an engine are merged in one launch); returns [] — see getPatches() */
