@@ -201,6 +201,13 @@ def main():
     gathered = torch.empty((sum(counts), 2), dtype=torch.int64, device="cuda") if world > 1 else None
     conv_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
     conv = conv_dev[0]
+    comm = None
+    if world > 1 and not args.host_sync_step:
+        # the digest all-gather lives in the C ABI (ptx_allgather_digests: RCCL bound inside libperitext_hip.so); torch.distributed
+        # only carries the 128-byte communicator id from rank 0 to the others
+        uid = torch.tensor(list(eng.comm_unique_id()) if rank == 0 else [0] * abi.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        comm = eng.comm_init(bytes(uid.cpu().tolist()), rank, world)
 
     stream = None
     if not args.host_sync_step:
@@ -223,10 +230,10 @@ def main():
                     events.append((e0, e1))
                 if world == 1:
                     eng.count_converged(dr, replicas, conv_dev.data_ptr())
-                    conv = conv_dev[0]
-                else:
-                    eng.pack_digests(dr, 0, n_logs, digests.data_ptr())
-                    conv, _ = shard.global_convergence(digests, replicas, dist, gathered, counts)
+                else:  # N > 1: the only collective on the path, all of it inside the library, on the same stream
+                    eng.allgather_digests(comm, dr, counts, gathered.data_ptr())
+                    eng.count_converged_digests(gathered.data_ptr(), sum(counts), replicas, conv_dev.data_ptr())
+                conv = conv_dev[0]
             return None
         ms = eng.merge_timed(db, dr, 1) if timed else eng.merge(db, dr)  # HIP events on the engine's own stream
         eng.pack_digests(dr, 0, n_logs, digests.data_ptr())
@@ -365,7 +372,7 @@ def main():
                 "ops_this_gpu_per_step": ops_per_step,
                 "op_log_bytes_this_gpu": 32 * rows,
                 "changes_this_gpu": n_changes,
-                "parallelism": "doc-sharded x%d, digests-only all-gather" % world,
+                "parallelism": "doc-sharded x%d, digests-only all-gather (ptx_allgather_digests: RCCL inside the C ABI)" % world,
                 "causal_admission": not args.no_admission,
                 "step": "merge + device-side convergence count, one stream, no host sync" if stream is not None else "merge, host sync, digest check",
             },
@@ -403,11 +410,14 @@ def main():
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
+    if world > 1:
+        dist.barrier()  # rank 0 is still busy with the oracle / reference runs: leave together
+    if comm is not None:
+        eng.comm_destroy(comm)
     eng.free_result(dr)
     eng.free_batch(db)
     eng.close()
-    if world > 1:
-        dist.barrier()  # rank 0 is still busy with the reference run: leave together
+    if world > 1:  # rank 0 is still busy with the reference run: leave together
         dist.destroy_process_group()
 
 

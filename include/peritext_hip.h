@@ -317,6 +317,26 @@ const ptx_log_result* ptx_dresult_logs_device(const ptx_dresult* r);
  * (e.g. a torch tensor that is then all-gathered with RCCL), on the context's stream. */
 ptx_status ptx_pack_digests(ptx_ctx* ctx, const ptx_dresult* r, uint32_t first, uint32_t count, uint64_t* dst_device);
 
+/* ---- multi-GPU: the digest all-gather (the reference's convergence assert, test/fuzz.ts:277-278, for a sharded batch) ----
+ * Documents shard across ranks (one process per GPU), every replica of a document on one rank; the only exchange is an
+ * all-gather of the per-replica 128-bit digests over RCCL (xGMI inside a node) so that every rank can state global convergence.
+ * RCCL is loaded at run time (librccl.so.1) by the first of these calls: a single-GPU host never needs it. */
+#define PTX_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+typedef struct ptx_comm ptx_comm;
+/* Rank 0 makes the id (ncclGetUniqueId) and hands it to the other ranks over the host's own channel. */
+ptx_status ptx_comm_unique_id(ptx_ctx* ctx, uint8_t id[PTX_COMM_ID_BYTES]);
+/* Collective over all ranks (ncclCommInitRank) on the context's device. */
+ptx_status ptx_comm_init(ptx_ctx* ctx, const uint8_t id[PTX_COMM_ID_BYTES], uint32_t rank, uint32_t n_ranks, ptx_comm** out);
+void ptx_comm_destroy(ptx_ctx* ctx, ptx_comm* comm);
+/* All-gather of the digests of every rank's result: counts[r] = replica logs of rank r (host array [n_ranks]; counts[rank] must be
+ * the logs of `r`), out_device = [sum(counts)] x 2 u64 in DEVICE memory, rank-major.  Enqueued on the context's stream; ranks
+ * whose blocks differ in size are gathered padded and compacted on the device. */
+ptx_status ptx_allgather_digests(ptx_ctx* ctx, ptx_comm* comm, const ptx_dresult* r, const uint32_t* counts, uint64_t* out_device);
+/* Documents whose `replicas` consecutive digest pairs are all equal, over a gathered digest array in DEVICE memory (n_logs pairs):
+ * *count_device (a u64 in DEVICE memory) is overwritten.  A failed log has the digest {0, 0} and never converges with a good one;
+ * per-log statuses stay with the rank that owns the log. */
+ptx_status ptx_count_converged_digests(ptx_ctx* ctx, const uint64_t* digests_device, uint64_t n_logs, uint32_t replicas, uint64_t* count_device);
+
 /* ---- patch streams ---- */
 /* Replay every log of `b` in application order and return the Patch[] stream each applyChange would have returned.
  * `r` must be the result of ptx_merge on the same batch, produced WITH elem_rank (no PTX_FLAG_NO_ELEM_RANK) and

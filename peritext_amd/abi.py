@@ -28,6 +28,7 @@ RANK_MASK = 0x7FFFFFFF
 
 FLAG_NO_ELEM_RANK = 1
 FLAG_NO_ADMISSION = 2
+COMM_ID_BYTES = 128
 
 PTX_OK = 0
 ERR_ELEM_NOT_FOUND = 1
@@ -269,6 +270,11 @@ FUNCTIONS = {
     "ptx_result_download_logs": (C.c_int32, [vp, vp, C.POINTER(ptx_log_result), C.c_uint32]),
     "ptx_dresult_logs_device": (vp, [vp]),
     "ptx_pack_digests": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "ptx_comm_unique_id": (C.c_int32, [vp, u8p]),
+    "ptx_comm_init": (C.c_int32, [vp, u8p, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+    "ptx_comm_destroy": (None, [vp, vp]),
+    "ptx_allgather_digests": (C.c_int32, [vp, vp, vp, u32p, vp]),
+    "ptx_count_converged_digests": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
     "ptx_replay_patches": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_patches)]),
     "ptx_patches_free": (None, [C.POINTER(ptx_patches)]),
     "ptx_generate": (C.c_int32, [vp, C.POINTER(ptx_gen_config), C.POINTER(vp), C.POINTER(ptx_gen_info)]),

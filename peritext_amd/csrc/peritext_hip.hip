@@ -10,7 +10,9 @@
  * device-resident objects so that a benchmark can keep the op log in HBM and time only the merge.
  * There is no CPU path in this library: without a gfx950 device ptx_create fails.
  */
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -244,6 +246,24 @@ __global__ void ptx_count_converged_kernel(const ptx_log_result* res, uint32_t n
     }
     const unsigned long long m = __ballot(same);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+__global__ void ptx_count_converged_digests_kernel(const uint64_t* dg, uint64_t n_docs, uint32_t replicas, unsigned long long* out) {
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool same = d < n_docs;
+    if (same) {
+        const uint64_t* p = dg + d * replicas * 2;
+        same = (p[0] | p[1]) != 0; /* {0, 0} = a failed log */
+        for (uint32_t k = 1; k < replicas && same; ++k) same = p[2 * k] == p[0] && p[2 * k + 1] == p[1];
+    }
+    const unsigned long long m = __ballot(same);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+/* rank-major padded blocks of `width` digest pairs -> the counts[r] valid pairs of every rank, back to back */
+__global__ void ptx_compact_digests_kernel(const uint64_t* padded, const uint64_t* first, const uint32_t* counts, uint32_t width, uint64_t* out) {
+    const uint32_t r = blockIdx.y;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < counts[r] * 2u; i += gridDim.x * blockDim.x) out[first[r] * 2 + i] = padded[(uint64_t)r * width * 2 + i];
 }
 
 __global__ void ptx_pack_digests_kernel(const ptx_log_result* res, uint32_t first, uint32_t count, uint64_t* dst) {
@@ -951,6 +971,155 @@ ptx_status ptx_sync(ptx_ctx* ctx) {
     if (!ctx) return PTX_ERR_INVALID_ARG;
     PTX_HIP(ctx, hipSetDevice(ctx->device));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PTX_OK;
+}
+
+/* ---- RCCL, bound at run time ---- */
+struct PtxRccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static PtxRccl g_rccl;
+static ptx_status rccl_load(ptx_ctx* ctx) {
+    if (g_rccl.handle) return PTX_OK;
+    /* the process may already hold RCCL (e.g. torch.distributed): the soname resolves to that copy */
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(ctx, PTX_ERR_HIP, std::string("RCCL is not available: ") + dlerror());
+    PtxRccl r;
+    r.handle = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) return fail(ctx, PTX_ERR_HIP, "librccl lacks an expected symbol");
+    g_rccl = r;
+    return PTX_OK;
+}
+#define PTX_NCCL(ctx, call)                                                                          \
+    do {                                                                                             \
+        ncclResult_t _r = (call);                                                                    \
+        if (_r != ncclSuccess) return fail(ctx, PTX_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+struct ptx_comm {
+    ncclComm_t comm = nullptr;
+    uint32_t rank = 0, n_ranks = 1;
+    /* scratch of the unequal-block path */
+    uint64_t *padded = nullptr, *mine = nullptr, *d_first = nullptr;
+    uint32_t* d_counts = nullptr;
+    uint32_t width = 0;
+};
+
+ptx_status ptx_comm_unique_id(ptx_ctx* ctx, uint8_t id[PTX_COMM_ID_BYTES]) {
+    if (!ctx || !id) return PTX_ERR_INVALID_ARG;
+    static_assert(sizeof(ncclUniqueId) == PTX_COMM_ID_BYTES, "ncclUniqueId size");
+    ptx_status st = rccl_load(ctx);
+    if (st) return st;
+    ncclUniqueId u;
+    PTX_NCCL(ctx, g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return PTX_OK;
+}
+
+ptx_status ptx_comm_init(ptx_ctx* ctx, const uint8_t id[PTX_COMM_ID_BYTES], uint32_t rank, uint32_t n_ranks, ptx_comm** out) {
+    if (!ctx || !id || !out || n_ranks == 0 || rank >= n_ranks) return PTX_ERR_INVALID_ARG;
+    *out = nullptr;
+    ptx_status st = rccl_load(ctx);
+    if (st) return st;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ptx_comm* c = new ptx_comm();
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, (int)n_ranks, u, (int)rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(ctx, PTX_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    }
+    *out = c;
+    return PTX_OK;
+}
+
+void ptx_comm_destroy(ptx_ctx* ctx, ptx_comm* c) {
+    if (!c) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    (void)hipFree(c->padded);
+    (void)hipFree(c->mine);
+    (void)hipFree(c->d_first);
+    (void)hipFree(c->d_counts);
+    delete c;
+}
+
+ptx_status ptx_allgather_digests(ptx_ctx* ctx, ptx_comm* c, const ptx_dresult* r, const uint32_t* counts, uint64_t* out_device) {
+    if (!ctx || !c || !r || !counts || !out_device) return PTX_ERR_INVALID_ARG;
+    if (counts[c->rank] != r->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_allgather_digests: counts[rank] must be the logs of this rank's result");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t width = 0;
+    bool equal = true;
+    for (uint32_t k = 0; k < c->n_ranks; ++k) {
+        width = std::max(width, counts[k]);
+        equal = equal && counts[k] == counts[0];
+    }
+    if (width == 0) return PTX_OK;
+    if (equal) {
+        /* the digests go out packed from a staging block of this rank's slice of the output itself */
+        uint64_t* mine = out_device + (uint64_t)c->rank * width * 2;
+        hipLaunchKernelGGL(ptx_pack_digests_kernel, dim3((width + 255) / 256), dim3(256), 0, ctx->stream, r->logs, 0u, width, mine);
+        PTX_HIP(ctx, hipGetLastError());
+        PTX_NCCL(ctx, g_rccl.AllGather(mine, out_device, (size_t)width * 2, ncclUint64, c->comm, ctx->stream));
+        return PTX_OK;
+    }
+    if (c->width < width) { /* (re)size the scratch of the padded path */
+        (void)hipFree(c->padded);
+        (void)hipFree(c->mine);
+        c->padded = c->mine = nullptr;
+        c->width = 0;
+        PTX_HIP(ctx, dalloc(&c->padded, (uint64_t)c->n_ranks * width * 2));
+        PTX_HIP(ctx, dalloc(&c->mine, (uint64_t)width * 2));
+        if (!c->d_first) PTX_HIP(ctx, dalloc(&c->d_first, (uint64_t)c->n_ranks));
+        if (!c->d_counts) PTX_HIP(ctx, dalloc(&c->d_counts, (uint64_t)c->n_ranks));
+        c->width = width;
+    }
+    std::vector<uint64_t> first(c->n_ranks, 0);
+    for (uint32_t k = 1; k < c->n_ranks; ++k) first[k] = first[k - 1] + counts[k - 1];
+    PTX_HIP(ctx, hipMemcpyAsync(c->d_first, first.data(), (size_t)c->n_ranks * 8, hipMemcpyHostToDevice, ctx->stream));
+    PTX_HIP(ctx, hipMemcpyAsync(c->d_counts, counts, (size_t)c->n_ranks * 4, hipMemcpyHostToDevice, ctx->stream));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); /* `first` is a stack-local vector */
+    PTX_HIP(ctx, hipMemsetAsync(c->mine, 0, (size_t)c->width * 16, ctx->stream));
+    if (r->n_logs) {
+        hipLaunchKernelGGL(ptx_pack_digests_kernel, dim3((r->n_logs + 255) / 256), dim3(256), 0, ctx->stream, r->logs, 0u, r->n_logs, c->mine);
+        PTX_HIP(ctx, hipGetLastError());
+    }
+    PTX_NCCL(ctx, g_rccl.AllGather(c->mine, c->padded, (size_t)c->width * 2, ncclUint64, c->comm, ctx->stream));
+    hipLaunchKernelGGL(ptx_compact_digests_kernel, dim3(std::min<uint32_t>((width * 2 + 255) / 256, 1024), c->n_ranks), dim3(256), 0, ctx->stream, c->padded, c->d_first,
+                       c->d_counts, c->width, out_device);
+    PTX_HIP(ctx, hipGetLastError());
+    return PTX_OK;
+}
+
+ptx_status ptx_count_converged_digests(ptx_ctx* ctx, const uint64_t* digests_device, uint64_t n_logs, uint32_t replicas, uint64_t* count_device) {
+    if (!ctx || !count_device || replicas == 0 || (!digests_device && n_logs)) return PTX_ERR_INVALID_ARG;
+    if (n_logs % replicas) return fail(ctx, PTX_ERR_INVALID_ARG, "n_logs is not a multiple of replicas");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, hipMemsetAsync(count_device, 0, 8, ctx->stream));
+    const uint64_t n_docs = n_logs / replicas;
+    if (n_docs) {
+        hipLaunchKernelGGL(ptx_count_converged_digests_kernel, dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, ctx->stream, digests_device, n_docs, replicas,
+                           (unsigned long long*)count_device);
+        PTX_HIP(ctx, hipGetLastError());
+    }
     return PTX_OK;
 }
 

@@ -187,6 +187,30 @@ class Engine:
         self._check(self.lib.ptx_calib_stream(self.ctx, dbatch, C.byref(n)))
         return int(n.value)
 
+    # ---- multi-GPU: the digest all-gather over RCCL, inside the library ----
+    def comm_unique_id(self):
+        """128 bytes (ncclUniqueId) rank 0 makes and hands to the other ranks."""
+        buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
+        self._check(self.lib.ptx_comm_unique_id(self.ctx, buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, n_ranks):
+        buf = (C.c_uint8 * abi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        self._check(self.lib.ptx_comm_init(self.ctx, buf, rank, n_ranks, C.byref(h)))
+        return h
+
+    def comm_destroy(self, comm):
+        self.lib.ptx_comm_destroy(self.ctx, comm)
+
+    def allgather_digests(self, comm, dresult, counts, out_device_ptr):
+        """Digests of every rank's result -> [sum(counts), 2] u64 at `out_device_ptr` (rank-major), on the engine's stream."""
+        c = np.ascontiguousarray(counts, dtype=np.uint32)
+        self._check(self.lib.ptx_allgather_digests(self.ctx, comm, dresult, c.ctypes.data_as(abi.u32p), C.c_void_p(out_device_ptr)))
+
+    def count_converged_digests(self, digests_device_ptr, n_logs, replicas, count_device_ptr):
+        self._check(self.lib.ptx_count_converged_digests(self.ctx, C.c_void_p(digests_device_ptr), n_logs, replicas, C.c_void_p(count_device_ptr)))
+
     def sync(self):
         self._check(self.lib.ptx_sync(self.ctx))
 

@@ -246,3 +246,36 @@ def test_set_stream_and_count_converged(eng):
         eng.free_batch(db)
     # back on its own stream the engine still works
     H.check_generated(_load("ptxgen_mini.json"), eng.apply_materialize)
+
+
+def test_digest_allgather_in_the_c_abi_single_rank(eng):
+    """ptx_comm_* / ptx_allgather_digests / ptx_count_converged_digests (SURVEY §8b,e): RCCL bound inside the library, here a
+    communicator of ONE rank (the box has one GPU; N ranks run the same code in bench.py --gpus N): the gathered array is this
+    rank's digests, the device count equals the host's."""
+    import torch
+
+    g = _load("ptxgen_config4_600.json")
+    docs = [d["logs"] for d in g["docs"]]
+    docs[2] = [docs[2][0], docs[2][1][:-2], docs[2][2]]  # one document that has not converged
+    batch = wire.encode_docs(docs)
+    replicas = 3
+    db = eng.upload(batch, copies=7)
+    dr = eng.alloc_result(db)
+    n_logs = eng.n_logs(db)
+    comm = eng.comm_init(eng.comm_unique_id(), 0, 1)
+    gathered = torch.zeros((n_logs, 2), dtype=torch.int64, device="cuda")
+    count = torch.full((1,), -1, dtype=torch.int64, device="cuda")
+    try:
+        eng.merge(db, dr)
+        eng.allgather_digests(comm, dr, [n_logs], gathered.data_ptr())
+        eng.count_converged_digests(gathered.data_ptr(), n_logs, replicas, count.data_ptr())
+        eng.sync()
+        logs = eng.download_logs(dr, n_logs)
+        assert (gathered.cpu().numpy().view(np.uint64) == logs["digest"]).all()
+        dg = logs["digest"].reshape(-1, replicas, 2)
+        want = int((dg == dg[:, :1, :]).all(axis=(1, 2)).sum())
+        assert want == 7 * (len(docs) - 1) and int(count.item()) == want
+    finally:
+        eng.comm_destroy(comm)
+        eng.free_result(dr)
+        eng.free_batch(db)
