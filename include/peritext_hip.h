@@ -337,6 +337,12 @@ ptx_status ptx_allgather_digests(ptx_ctx* ctx, ptx_comm* comm, const ptx_dresult
  * per-log statuses stay with the rank that owns the log. */
 ptx_status ptx_count_converged_digests(ptx_ctx* ctx, const uint64_t* digests_device, uint64_t n_logs, uint32_t replicas, uint64_t* count_device);
 
+/* Device memory for hosts that have no HIP binding of their own (the N-API addon): scratch for out_device / count_device above.
+ * ptx_device_read copies `bytes` back to the host after everything enqueued on the context's stream has completed. */
+ptx_status ptx_device_alloc(ptx_ctx* ctx, uint64_t bytes, void** out_device);
+void ptx_device_free(ptx_ctx* ctx, void* device);
+ptx_status ptx_device_read(ptx_ctx* ctx, const void* device, void* host, uint64_t bytes);
+
 /* ---- patch streams ---- */
 /* Replay every log of `b` in application order and return the Patch[] stream each applyChange would have returned.
  * `r` must be the result of ptx_merge on the same batch, produced WITH elem_rank (no PTX_FLAG_NO_ELEM_RANK) and

@@ -275,6 +275,9 @@ FUNCTIONS = {
     "ptx_comm_destroy": (None, [vp, vp]),
     "ptx_allgather_digests": (C.c_int32, [vp, vp, vp, u32p, vp]),
     "ptx_count_converged_digests": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
+    "ptx_device_alloc": (C.c_int32, [vp, C.c_uint64, C.POINTER(vp)]),
+    "ptx_device_free": (None, [vp, vp]),
+    "ptx_device_read": (C.c_int32, [vp, vp, vp, C.c_uint64]),
     "ptx_replay_patches": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_patches)]),
     "ptx_patches_free": (None, [C.POINTER(ptx_patches)]),
     "ptx_generate": (C.c_int32, [vp, C.POINTER(ptx_gen_config), C.POINTER(vp), C.POINTER(ptx_gen_info)]),

@@ -1123,6 +1123,25 @@ ptx_status ptx_count_converged_digests(ptx_ctx* ctx, const uint64_t* digests_dev
     return PTX_OK;
 }
 
+ptx_status ptx_device_alloc(ptx_ctx* ctx, uint64_t bytes, void** out_device) {
+    if (!ctx || !out_device) return PTX_ERR_INVALID_ARG;
+    *out_device = nullptr;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, hipMalloc(out_device, std::max<uint64_t>(bytes, 1)));
+    return PTX_OK;
+}
+void ptx_device_free(ptx_ctx* ctx, void* device) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipFree(device);
+}
+ptx_status ptx_device_read(ptx_ctx* ctx, const void* device, void* host, uint64_t bytes) {
+    if (!ctx || (bytes && (!device || !host))) return PTX_ERR_INVALID_ARG;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) PTX_HIP(ctx, hipMemcpyAsync(host, device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PTX_OK;
+}
+
 struct ptx_host_result {
     std::vector<ptx_log_result> logs;
     std::vector<uint32_t> values;

@@ -21,6 +21,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <string>
+#include <vector>
+
 #include "../../include/peritext_hip.h"
 
 namespace {
@@ -52,6 +55,16 @@ struct Lib {
     void (*host_batch_free)(ptx_host_batch*) = nullptr;
     /* change(): caller-supplied InputOperations */
     ptx_status (*change)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, const ptx_input_ops*, ptx_dbatch**, uint32_t*) = nullptr;
+    /* multi-GPU: the digest all-gather (RCCL inside the library) */
+    ptx_status (*comm_unique_id)(ptx_ctx*, uint8_t*) = nullptr;
+    ptx_status (*comm_init)(ptx_ctx*, const uint8_t*, uint32_t, uint32_t, ptx_comm**) = nullptr;
+    void (*comm_destroy)(ptx_ctx*, ptx_comm*) = nullptr;
+    ptx_status (*allgather_digests)(ptx_ctx*, ptx_comm*, const ptx_dresult*, const uint32_t*, uint64_t*) = nullptr;
+    ptx_status (*count_converged_digests)(ptx_ctx*, const uint64_t*, uint64_t, uint32_t, uint64_t*) = nullptr;
+    ptx_status (*result_download_logs)(ptx_ctx*, const ptx_dresult*, ptx_log_result*, uint32_t) = nullptr;
+    ptx_status (*device_alloc)(ptx_ctx*, uint64_t, void**) = nullptr;
+    void (*device_free)(ptx_ctx*, void*) = nullptr;
+    ptx_status (*device_read)(ptx_ctx*, const void*, void*, uint64_t) = nullptr;
 } L;
 
 #define NAPI_OK(call)                                                        \
@@ -93,7 +106,11 @@ napi_value Open(napi_env env, napi_callback_info info) {
                   sym(L.batch_free, "ptx_batch_free") && sym(L.result_alloc, "ptx_result_alloc") && sym(L.dresult_free, "ptx_dresult_free") &&
                   sym(L.merge, "ptx_merge") && sym(L.sync, "ptx_sync") && sym(L.result_download, "ptx_result_download") &&
                   sym(L.replay_patches, "ptx_replay_patches") && sym(L.patches_free, "ptx_patches_free") && sym(L.generate, "ptx_generate") &&
-                  sym(L.gen_info_free, "ptx_gen_info_free") && sym(L.batch_download, "ptx_batch_download") && sym(L.host_batch_free, "ptx_host_batch_free") && sym(L.change, "ptx_change");
+                  sym(L.gen_info_free, "ptx_gen_info_free") && sym(L.batch_download, "ptx_batch_download") && sym(L.host_batch_free, "ptx_host_batch_free") && sym(L.change, "ptx_change") &&
+                  sym(L.comm_unique_id, "ptx_comm_unique_id") && sym(L.comm_init, "ptx_comm_init") && sym(L.comm_destroy, "ptx_comm_destroy") &&
+                  sym(L.allgather_digests, "ptx_allgather_digests") && sym(L.count_converged_digests, "ptx_count_converged_digests") &&
+                  sym(L.result_download_logs, "ptx_result_download_logs") && sym(L.device_alloc, "ptx_device_alloc") && sym(L.device_free, "ptx_device_free") &&
+                  sym(L.device_read, "ptx_device_read");
         if (!ok) {
             dlclose(L.handle);
             L.handle = nullptr;
@@ -529,6 +546,109 @@ napi_value Change(napi_env env, napi_callback_info info) {
     return out;
 }
 
+/* commUniqueId(ctx) -> Uint8Array(128): rank 0 makes it, the host's own channel carries it to the other ranks */
+napi_value CommUniqueId(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc ? ctx_of(env, argv[0]) : nullptr;
+    if (!ctx) return throw_msg(env, "commUniqueId(ctx)");
+    uint8_t id[PTX_COMM_ID_BYTES];
+    if (L.comm_unique_id(ctx, id) != PTX_OK) return throw_msg(env, L.last_error(ctx));
+    return make_typed(env, napi_uint8_array, 1, id, PTX_COMM_ID_BYTES);
+}
+
+/* commInit(ctx, id: Uint8Array(128), rank, nRanks) -> comm (external); collective over all ranks */
+napi_value CommInit(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc > 3 ? ctx_of(env, argv[0]) : nullptr;
+    if (!ctx) return throw_msg(env, "commInit(ctx, id, rank, nRanks)");
+    napi_typedarray_type type;
+    size_t length = 0, offset = 0;
+    void* data = nullptr;
+    napi_value ab;
+    if (napi_get_typedarray_info(env, argv[1], &type, &length, &data, &ab, &offset) != napi_ok || type != napi_uint8_array || length != PTX_COMM_ID_BYTES)
+        return throw_msg(env, "commInit: id must be the Uint8Array(128) commUniqueId() made on rank 0");
+    uint32_t rank = 0, n = 1;
+    napi_get_value_uint32(env, argv[2], &rank);
+    napi_get_value_uint32(env, argv[3], &n);
+    ptx_comm* comm = nullptr;
+    if (L.comm_init(ctx, (const uint8_t*)data, rank, n, &comm) != PTX_OK) return throw_msg(env, L.last_error(ctx));
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, comm, nullptr, nullptr, &ext));
+    return ext;
+}
+
+napi_value CommDestroy(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc > 1 ? ctx_of(env, argv[0]) : nullptr;
+    void* p = nullptr;
+    if (ctx && L.handle && napi_get_value_external(env, argv[1], &p) == napi_ok && p) L.comm_destroy(ctx, (ptx_comm*)p);
+    return nullptr;
+}
+
+/* mergeAndGather(ctx, comm, batch, counts: Uint32Array(nRanks), replicas): this rank's replica logs are merged, the per-replica
+ * digests of ALL ranks gathered on the device (ptx_allgather_digests) and the converged documents of the whole job counted there.
+ * Returns {logs: Uint32Array (this rank's ptx_log_result rows), gathered: BigUint64Array (2 per replica log, rank-major), converged}. */
+napi_value MergeAndGather(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc > 4 ? ctx_of(env, argv[0]) : nullptr;
+    void* cp = nullptr;
+    if (!ctx || napi_get_value_external(env, argv[1], &cp) != napi_ok || !cp) return throw_msg(env, "mergeAndGather(ctx, comm, batch, counts, replicas)");
+    ptx_batch pb;
+    if (!read_batch(env, argv[2], &pb)) return nullptr;
+    napi_typedarray_type type;
+    size_t n_ranks = 0, offset = 0;
+    void* counts = nullptr;
+    napi_value ab;
+    if (napi_get_typedarray_info(env, argv[3], &type, &n_ranks, &counts, &ab, &offset) != napi_ok || type != napi_uint32_array || n_ranks == 0)
+        return throw_msg(env, "mergeAndGather: counts must be a Uint32Array with one entry per rank");
+    uint32_t replicas = 1;
+    napi_get_value_uint32(env, argv[4], &replicas);
+    uint64_t total = 0;
+    for (size_t k = 0; k < n_ranks; ++k) total += ((const uint32_t*)counts)[k];
+    ptx_dbatch* db = nullptr;
+    ptx_dresult* dr = nullptr;
+    void *d_gather = nullptr, *d_count = nullptr;
+    std::vector<ptx_log_result> logs(pb.n_logs ? pb.n_logs : 1);
+    std::vector<uint64_t> gathered(total * 2 + 1);
+    uint64_t converged = 0;
+    ptx_status st = L.batch_upload(ctx, &pb, &db);
+    if (st == PTX_OK) st = L.result_alloc(ctx, db, &dr);
+    if (st == PTX_OK) st = L.device_alloc(ctx, total * 16 + 16, &d_gather);
+    if (st == PTX_OK) st = L.device_alloc(ctx, 8, &d_count);
+    if (st == PTX_OK) st = L.merge(ctx, db, dr);
+    if (st == PTX_OK) st = L.allgather_digests(ctx, (ptx_comm*)cp, dr, (const uint32_t*)counts, (uint64_t*)d_gather);
+    if (st == PTX_OK) st = L.count_converged_digests(ctx, (const uint64_t*)d_gather, total, replicas, (uint64_t*)d_count);
+    if (st == PTX_OK) st = L.result_download_logs(ctx, dr, logs.data(), pb.n_logs);
+    if (st == PTX_OK) st = L.device_read(ctx, d_gather, gathered.data(), total * 16);
+    if (st == PTX_OK) st = L.device_read(ctx, d_count, &converged, 8);
+    std::string err = st != PTX_OK ? L.last_error(ctx) : "";
+    if (d_gather) L.device_free(ctx, d_gather);
+    if (d_count) L.device_free(ctx, d_count);
+    if (dr) L.dresult_free(ctx, dr);
+    if (db) L.batch_free(ctx, db);
+    if (st != PTX_OK) return throw_msg(env, ("mergeAndGather failed: " + err).c_str());
+    napi_value out, v;
+    NAPI_OK(napi_create_object(env, &out));
+    v = make_u32(env, logs.data(), (size_t)pb.n_logs * 12);
+    if (v) napi_set_named_property(env, out, "logs", v);
+    v = make_typed(env, napi_biguint64_array, 8, gathered.data(), (size_t)total * 2);
+    if (v) napi_set_named_property(env, out, "gathered", v);
+    napi_create_double(env, (double)converged, &v);
+    napi_set_named_property(env, out, "converged", v);
+    return out;
+}
+
 napi_value MaxOpsPerLog(napi_env env, napi_callback_info info) {
     size_t argc = 1;
     napi_value argv[1];
@@ -547,7 +667,8 @@ napi_value KernelName(napi_env env, napi_callback_info) {
 
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
-        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"generate", Generate}, {"change", Change}, {"maxOpsPerLog", MaxOpsPerLog}, {"kernelName", KernelName},
+        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"generate", Generate}, {"change", Change}, {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"mergeAndGather", MergeAndGather},
+        {"maxOpsPerLog", MaxOpsPerLog}, {"kernelName", KernelName},
     };
     for (auto& f : fns) {
         napi_value fn;

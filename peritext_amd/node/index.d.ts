@@ -96,6 +96,12 @@ export class MergeEngine {
     generate(cfg: { replicas: number; opsPerLog: number; mix: [number, number, number, number]; markTypes: MarkType[]; seed: number; nDocs: number; firstDoc?: number; listCap?: number; initialText?: string }):
         { docs: Change[][][]; spans: FormatSpanWithText[][][]; kernelMs: number; batch: WireBatch }
     digests(docs: Change[][][]): Array<[bigint, bigint]>
+    /** multi-GPU, one process per GPU: RCCL communicator (id made on rank 0, carried by the host's own channel) */
+    commUniqueId(): Uint8Array
+    commInit(id: Uint8Array, rank: number, nRanks: number): unknown
+    commDestroy(comm: unknown): void
+    /** merge this rank's documents, all-gather the digests of all ranks on the device (ptx_allgather_digests), count the converged documents of the job */
+    convergedDocs(docs: Change[][][], comm: unknown, counts: number[], replicas: number): { converged: number; total: number; digests: Array<[bigint, bigint]>; statuses: number[] }
     /** Micromerge.change for many replicas in one call: calls[d][r] = change() calls of replica r of document d */
     changeMany(docs: Change[][][], calls: InputOperation[][][][], actors: ActorId[][], opts?: { extraComments?: string[][] }): { changes: Change[][][]; status: number[][] }
     replica(docId?: number | string, actorId?: ActorId): ReplicaHandle

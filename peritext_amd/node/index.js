@@ -516,6 +516,33 @@ class MergeEngine {
         }
         return out
     }
+    /* ---- multi-GPU (one Node process per GPU): the digest all-gather over RCCL lives in the library (ptx_allgather_digests) ---- */
+    /** Uint8Array(128) made on rank 0; the host's own channel carries it to the other ranks */
+    commUniqueId() {
+        return this.addon.commUniqueId(this.ctx)
+    }
+    /** collective over all ranks; returns an opaque communicator */
+    commInit(id, rank, nRanks) {
+        return this.addon.commInit(this.ctx, id, rank, nRanks)
+    }
+    commDestroy(comm) {
+        this.addon.commDestroy(this.ctx, comm)
+    }
+    /**
+     * This rank's documents (Change[][][], `replicas` logs each) are merged, the digests of ALL ranks gathered on the device and the
+     * converged documents of the whole job counted there — the reference's `assert.deepStrictEqual(leftText, rightText)`
+     * (test/fuzz.ts:277-278) for a sharded batch.  counts[r] = replica logs of rank r.
+     * Returns {converged, total, digests: Array<[bigint, bigint]> of every rank (rank-major), statuses: number[] of this rank's logs}.
+     */
+    convergedDocs(docs, comm, counts, replicas) {
+        const batch = encodeDocs(docs)
+        const raw = this.addon.mergeAndGather(this.ctx, comm, batch, Uint32Array.from(counts), replicas)
+        const digests = []
+        for (let l = 0; 2 * l < raw.gathered.length; l++) digests.push([raw.gathered[2 * l], raw.gathered[2 * l + 1]])
+        const statuses = []
+        for (let l = 0; l < batch.nLogs; l++) statuses.push(raw.logs[12 * l])
+        return { converged: raw.converged, total: digests.length / replicas, digests, statuses }
+    }
     /**
      * Micromerge.change for many replicas in ONE call (ptx_change): docs = the replica logs applied so far (Change[][][]),
      * calls[d][r] = the change() calls of replica r of document d (each an InputOperation[]; [] = none), actors[d][r] = its actor id.

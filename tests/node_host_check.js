@@ -173,6 +173,23 @@ if (cmd === "encode") {
     }
     engine.close()
     console.log(JSON.stringify({ ok: true, cases, calls }))
+} else if (cmd === "comm") {
+    /* GPU: the digest all-gather of the C ABI through N-API, a communicator of one rank */
+    const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    const engine = new host.MergeEngine()
+    const docs = gen.docs.map(d => d.logs)
+    docs[1] = docs[1].map((l, r) => (r === 1 ? l.slice(0, l.length - 2) : l)) /* one document that has not converged */
+    const R = docs[0].length
+    const comm = engine.commInit(engine.commUniqueId(), 0, 1)
+    const got = engine.convergedDocs(docs, comm, [docs.length * R], R)
+    engine.commDestroy(comm)
+    const own = engine.digests(docs)
+    assert.deepStrictEqual(got.digests, own)
+    assert.strictEqual(got.total, docs.length)
+    assert.strictEqual(got.converged, docs.length - 1)
+    assert.ok(got.statuses.every(s => s === 0))
+    engine.close()
+    console.log(JSON.stringify({ ok: true, docs: docs.length, converged: got.converged }))
 } else if (cmd === "pmdoc") {
     /* no GPU: ProseMirror doc JSON of every expected span list of a fixture */
     const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))

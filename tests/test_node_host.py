@@ -35,7 +35,8 @@ def test_addon_loads_and_binds_the_c_abi():
     info = _node("load")
     assert info["abi"] == abi.PTX_ABI_VERSION
     assert info["kernel"].startswith("ptx_merge_kernel")
-    assert info["exports"] == ["applyMaterialize", "change", "create", "destroy", "generate", "kernelName", "maxOpsPerLog", "open"]
+    assert info["exports"] == ["applyMaterialize", "change", "commDestroy", "commInit", "commUniqueId", "create", "destroy", "generate", "kernelName", "maxOpsPerLog",
+                               "mergeAndGather", "open"]
 
 
 @needs_node
@@ -75,6 +76,15 @@ def test_node_host_patch_streams():
     out = _node("patches", *[os.path.join(H.GOLDEN, n) for n in names], timeout=600)
     want = [e for n in names for d in json.load(open(os.path.join(H.GOLDEN, n)))["docs"] for e in d["expected"]]
     assert out["ok"] and out["logs"] == len(want) and out["patches"] == sum(len(e["patches"]) for e in want)
+
+
+@pytest.mark.gpu
+@needs_node
+@needs_addon
+def test_node_host_digest_allgather():
+    """MergeEngine.commInit / convergedDocs: ptx_allgather_digests + ptx_count_converged_digests through N-API (one rank)."""
+    out = _node("comm", os.path.join(H.GOLDEN, "ptxgen_config4_600.json"), timeout=600)
+    assert out["ok"] and out["converged"] == out["docs"] - 1
 
 
 @needs_node
