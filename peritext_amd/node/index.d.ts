@@ -107,7 +107,7 @@ export class MergeEngine {
     replica(docId?: number | string, actorId?: ActorId): ReplicaHandle
     flush(wantPatches?: boolean): void
 }
-export function encodeDocs(docs: Change[][][], opts?: { extraActors?: ActorId[][]; extraComments?: string[][] }): WireBatch
+export function encodeDocs(docs: Change[][][], opts?: { extraActors?: ActorId[][]; extraComments?: string[][]; textObjs?: Array<OperationId | null> }): WireBatch
 export function encodeInputOps(batch: WireBatch, perLog: InputOperation[][][], actors: ActorId[]): WireInputOps
 export function packEnvelope(batch: WireBatch): WireBatch
 export function unpackEnvelope(batch: WireBatch): WireBatch

@@ -80,9 +80,11 @@ function splitOpId(id) {
 /** docs: Change[][][] (doc -> replica log -> changes in application order)  ->  SoA batch (include/peritext_hip.h).
  *  opts.extraActors / opts.extraComments: per document, actor names / comment ids that get a rank although no change uses them
  *  yet (a replica about to make its first change, comment ids a later InputOperation introduces: ranks are positions in the
- *  document's sorted id list, so they are reserved before the rows that use them exist). */
+ *  document's sorted id list, so they are reserved before the rows that use them exist).  opts.textObjs: per document the opId
+ *  of the text list when the logs of this batch do not hold its makeList (a batch of newly arrived changes only). */
 function encodeDocs(docs, opts) {
     const extraActors = (opts && opts.extraActors) || [], extraComments = (opts && opts.extraComments) || []
+    const textObjs = (opts && opts.textObjs) || [] /* per document: opId of the text list when the logs do not hold its makeList */
     const values = [], valueIx = new Map()
     const urls = [], urlIx = new Map()
     const rows = { opId: [], refA: [], refB: [], payload: [], action: [], markType: [], sideA: [], sideB: [] }
@@ -118,7 +120,7 @@ function encodeDocs(docs, opts) {
             return (BigInt(ctr) << 32n) | BigInt(arank.get(actor))
         }
         for (const log of logs) {
-            let textObj = null, nrows = 0
+            let textObj = textObjs[d] === undefined ? null : textObjs[d], nrows = 0
             for (const ch of log) {
                 /* the Change envelope (micromerge.ts:60-71): what applyChange's admission checks (:499-511) */
                 chgActor.push(arank.get(ch.actor))

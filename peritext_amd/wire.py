@@ -161,13 +161,15 @@ def _pack(ctr, rank):
     return (int(ctr) << 32) | int(rank)
 
 
-def encode_docs(docs, extra_actors=None, extra_comments=None):
+def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
     """docs: list of docs; a doc is a list of replica logs; a replica log is a list of Change dicts.
 
     All replicas of a doc share actor ranks and comment-id ranks, so their digests are comparable.
     extra_actors / extra_comments: per doc, actor names / comment ids that get a rank although no change of the batch uses them
     yet (replicas about to make their first change, comment ids a later InputOperation will introduce: ranks are positions in
     the document's sorted id list, so they must be reserved before the rows that use them are made).
+    text_objs: per doc, the opId of the text list when the logs of this batch do not hold its makeList (a batch of newly arrived
+    changes for Engine.append / ptx_batch_append); None = found in the log.
     """
     values, value_ix = [], {}
     urls, url_ix = [], {}
@@ -210,7 +212,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None):
             return _pack(ctr, arank[actor])
 
         for log in logs:
-            text_obj = None
+            text_obj = text_objs[d] if text_objs else None
             nrows = 0
             for ch in log:
                 chg_actor.append(arank[ch["actor"]])

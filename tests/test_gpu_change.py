@@ -128,7 +128,8 @@ def test_change_on_generated_replicas_and_empty_base(eng):
         ch = wire.decode_changes(made, d * cfg["replicas"], text_obj="1@doc1")
         assert len(ch) == 1 and ch[0]["actor"] == "doc1"
         deliver.append([ch] * cfg["replicas"])
-    more = wire.encode_docs(deliver, extra_actors=batch.doc_actors, extra_comments=batch.doc_comments)
+    more = wire.encode_docs(deliver, extra_actors=batch.doc_actors, extra_comments=batch.doc_comments, text_objs=["1@doc1"] * 16)
+    assert (more.action != abi.ACT_NOP).all()
     # same tables as the generated batch: value / url ids of a generated batch are fixed (wire.GEN_*), the encoder interns its own
     vmap = np.array([wire.GEN_VALUES.index(v) for v in more.values], dtype=np.uint32)
     ins = more.action == abi.ACT_INSERT

@@ -8,11 +8,13 @@ import sys
 out = sys.argv[1]
 
 
-def per_dispatch(path, kernel, counter):
+def per_launch(path, kernel, counter, launches):
+    """Counter sum of a kernel over the run / the launches tools/traffic_run.py made (a merge whose batch is split in two
+    dispatches — a few logs with a larger LDS window — counts as ONE launch)."""
     for line in open(path):
         if line.startswith(kernel) and (" " + counter + " ") in line:
-            m = re.search(r"per_dispatch=([0-9.e+]+)", line)
-            return float(m.group(1))
+            m = re.search(r"sum=([0-9.e+]+)", line)
+            return float(m.group(1)) / launches
     return None
 
 
@@ -20,9 +22,9 @@ run = None
 for line in open(out + "/fetch.log"):
     if line.startswith("TRAFFIC_RUN "):
         run = json.loads(line[len("TRAFFIC_RUN "):])
-f_merge = per_dispatch(out + "/fetch.txt", "ptx_merge_kernel", "FETCH_SIZE")
-f_calib = per_dispatch(out + "/fetch.txt", "ptx_calib_stream_kernel", "FETCH_SIZE")
-w_merge = per_dispatch(out + "/write.txt", "ptx_merge_kernel", "WRITE_SIZE")
+f_merge = per_launch(out + "/fetch.txt", "ptx_merge_kernel", "FETCH_SIZE", 3)
+f_calib = per_launch(out + "/fetch.txt", "ptx_calib_stream_kernel", "FETCH_SIZE", 2)
+w_merge = per_launch(out + "/write.txt", "ptx_merge_kernel", "WRITE_SIZE", 3)
 factor = run["calib_known_bytes"] / (f_calib * 1024.0)  # true bytes per counted byte on the read side
 fetch = f_merge * 1024.0 * factor
 write = w_merge * 1024.0
