@@ -383,6 +383,19 @@ typedef struct ptx_gen_info {
  * included, ready for ptx_merge.  PTX_ERR_CAPACITY: some document outgrew list_cap (or the LDS). */
 ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** out, ptx_gen_info* info);
 void ptx_gen_info_free(ptx_gen_info* info);
+/* ---- cursors: Micromerge.getCursor / resolveCursor (micromerge.ts:465-477) for many replicas ----
+ * Query q names a replica log and is either
+ *   PTX_CURSOR_RESOLVE  arg = the cursor's elemId (counter << 32 | actorRank)  ->  out = visible elements BEFORE that element
+ *                       (findListElement(...).visible, :731-755; the element itself may be a tombstone — a cursor survives the
+ *                       deletion of its character); PTX_ERR_ELEM_NOT_FOUND for an id that names no list element (:752)
+ *   PTX_CURSOR_GET      arg = a visible index  ->  out = elemId of the index-th visible element (getListElementId, :762-805);
+ *                       PTX_ERR_INDEX_OOB past the end (:804)
+ * `r` = ptx_merge of `b` WITH elem_rank, complete.  All arrays are HOST memory, one entry per query; status_out[q] may also be
+ * the log's merge status (a replica the reference threw on has no cursors) or PTX_ERR_CAPACITY.  The call synchronises. */
+enum { PTX_CURSOR_RESOLVE = 0, PTX_CURSOR_GET = 1 };
+ptx_status ptx_resolve_cursors(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, uint32_t n_queries, const uint32_t* q_log, const uint8_t* q_kind,
+                               const uint64_t* q_arg, uint64_t* out, uint32_t* status_out);
+
 /* ---- change(): caller-supplied InputOperations made into Changes on the device ----
  * Replaces `doc.change(ops: InputOperation[])` (micromerge.ts:308-441; InputOperation :133-148) for MANY replicas at once:
  * log l of `base` is a replica's op log as applied so far, the InputOperations of log l are resolved against THAT replica's

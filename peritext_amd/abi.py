@@ -193,6 +193,7 @@ class ptx_gen_info(C.Structure):
 
 # InputOperation.action of ptx_change (reference/src/micromerge.ts:133-148)
 IN_INSERT, IN_DELETE, IN_ADDMARK, IN_REMOVEMARK, IN_MAKELIST = range(5)
+CURSOR_RESOLVE, CURSOR_GET = 0, 1
 
 
 class ptx_input_ops(C.Structure):
@@ -282,6 +283,7 @@ FUNCTIONS = {
     "ptx_patches_free": (None, [C.POINTER(ptx_patches)]),
     "ptx_generate": (C.c_int32, [vp, C.POINTER(ptx_gen_config), C.POINTER(vp), C.POINTER(ptx_gen_info)]),
     "ptx_gen_info_free": (None, [C.POINTER(ptx_gen_info)]),
+    "ptx_resolve_cursors": (C.c_int32, [vp, vp, vp, C.c_uint32, u32p, u8p, u64p, u64p, u32p]),
     "ptx_change": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_input_ops), C.POINTER(vp), u32p]),
     "ptx_batch_append_device": (C.c_int32, [vp, vp, vp, C.POINTER(vp)]),
     "ptx_batch_download": (C.c_int32, [vp, vp, C.POINTER(ptx_host_batch)]),

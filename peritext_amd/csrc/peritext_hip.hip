@@ -25,6 +25,7 @@
 #include "replay_core.h"
 #include "gen_core.h"
 #include "change_core.h"
+#include "cursor_core.h"
 
 /* ------------------------------------------------------------------------------------------------ */
 /* kernels                                                                                          */
@@ -62,6 +63,13 @@ extern "C" __global__ void __launch_bounds__(64) ptx_gen_kernel(PtxGenArgs A) {
 extern "C" __global__ void __launch_bounds__(64) ptx_change_kernel(PtxChangeArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_logs) ptx_change_log<64>(A, blockIdx.x, ptx_lds);
+}
+
+/* cursor resolution (cursor_core.h): one workgroup per replica log that has queries */
+#define PTX_CURSOR_THREADS 128
+extern "C" __global__ void __launch_bounds__(PTX_CURSOR_THREADS) ptx_cursor_kernel(PtxCursorArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
+    if (blockIdx.x < A.n_groups) ptx_cursor_group<PTX_CURSOR_THREADS>(A, blockIdx.x, ptx_lds);
 }
 
 /* envelope of a generated batch: capacity layout (rows_per_log entries per log) -> compact */
@@ -493,7 +501,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -1545,6 +1553,85 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     *out = b;
     return PTX_OK;
 #undef PTX_TRYG
+}
+
+/* ---- cursors ---- */
+ptx_status ptx_resolve_cursors(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, uint32_t n_queries, const uint32_t* q_log, const uint8_t* q_kind,
+                               const uint64_t* q_arg, uint64_t* out, uint32_t* status_out) {
+    if (!ctx || !b || !r || (n_queries && (!q_log || !q_kind || !q_arg || !out || !status_out))) return PTX_ERR_INVALID_ARG;
+    if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_resolve_cursors: `r` is not the result of this batch");
+    if (!r->rank) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_resolve_cursors needs the elem_rank column (context created with PTX_FLAG_NO_ELEM_RANK)");
+    if (n_queries == 0) return PTX_OK;
+    for (uint32_t q = 0; q < n_queries; ++q)
+        if (q_log[q] >= b->n_logs || q_kind[q] > PTX_CURSOR_GET) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_resolve_cursors: a query names no log of the batch or an unknown kind");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    /* group the queries by log: one workgroup builds a log's index once and answers all of them */
+    std::vector<uint32_t> perm(n_queries);
+    for (uint32_t q = 0; q < n_queries; ++q) perm[q] = q;
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return q_log[x] < q_log[y]; });
+    std::vector<uint32_t> glog;
+    std::vector<uint64_t> goff;
+    for (uint32_t k = 0; k < n_queries; ++k)
+        if (k == 0 || q_log[perm[k]] != q_log[perm[k - 1]]) {
+            glog.push_back(q_log[perm[k]]);
+            goff.push_back(k);
+        }
+    goff.push_back(n_queries);
+    const uint32_t G = (uint32_t)glog.size();
+    std::vector<ptx_log_hdr> hdr(b->n_logs);
+    PTX_HIP(ctx, hipMemcpyAsync(hdr.data(), b->log_hdr, (size_t)b->n_logs * sizeof(ptx_log_hdr), hipMemcpyDeviceToHost, ctx->stream));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t need = 4096;
+    for (uint32_t l : glog) {
+        const uint64_t ks = ((uint64_t)hdr[l].max_counter + 1) * ((uint64_t)std::min<uint32_t>(hdr[l].max_actor, 4095u) + 1);
+        need = std::max<uint64_t>(need, ptx_cursor_lds_need(hdr[l].n_ins, ks));
+    }
+    const uint32_t lds_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, ctx->max_lds); /* larger logs report PTX_ERR_CAPACITY */
+    uint32_t *d_glog = nullptr, *d_perm = nullptr, *d_status = nullptr;
+    uint64_t *d_goff = nullptr, *d_arg = nullptr, *d_out = nullptr;
+    uint8_t* d_kind = nullptr;
+    auto drop = [&]() {
+        for (void* p : {(void*)d_glog, (void*)d_perm, (void*)d_status, (void*)d_goff, (void*)d_arg, (void*)d_out, (void*)d_kind}) (void)hipFree(p);
+    };
+    hipError_t e = dalloc(&d_glog, G);
+    if (e == hipSuccess) e = dalloc(&d_goff, (uint64_t)G + 1);
+    if (e == hipSuccess) e = dalloc(&d_perm, n_queries);
+    if (e == hipSuccess) e = dalloc(&d_kind, n_queries);
+    if (e == hipSuccess) e = dalloc(&d_arg, n_queries);
+    if (e == hipSuccess) e = dalloc(&d_out, n_queries);
+    if (e == hipSuccess) e = dalloc(&d_status, n_queries);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_glog, glog.data(), (size_t)G * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_goff, goff.data(), ((size_t)G + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_perm, perm.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_kind, q_kind, (size_t)n_queries, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_arg, q_arg, (size_t)n_queries * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        PtxCursorArgs A;
+        memset(&A, 0, sizeof(A));
+        A.log_off = b->log_off;
+        A.op_id = b->op_id;
+        A.action = b->action;
+        A.log_hdr = b->log_hdr;
+        A.res = r->logs;
+        A.elem_rank = r->rank;
+        A.q_group_log = d_glog;
+        A.q_group_off = d_goff;
+        A.q_perm = d_perm;
+        A.q_kind = d_kind;
+        A.q_arg = d_arg;
+        A.out = d_out;
+        A.status = d_status;
+        A.n_groups = G;
+        A.lds_bytes = lds_bytes;
+        hipLaunchKernelGGL(ptx_cursor_kernel, dim3(G), dim3(PTX_CURSOR_THREADS), lds_bytes, ctx->stream, A);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n_queries * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(status_out, d_status, (size_t)n_queries * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    drop();
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("ptx_resolve_cursors: ") + hipGetErrorString(e));
+    return PTX_OK;
 }
 
 /* ---- change(): caller-supplied InputOperations ---- */

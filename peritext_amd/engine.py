@@ -125,6 +125,20 @@ class Engine:
         self._check(self.lib.ptx_batch_append(self.ctx, dbatch, C.byref(s), C.byref(h)))
         return h
 
+    def resolve_cursors(self, dbatch, dresult, q_log, q_kind, q_arg):
+        """Micromerge.resolveCursor / getCursor (micromerge.ts:465-477) for many replicas on the device (ptx_resolve_cursors):
+        query q = (log, abi.CURSOR_RESOLVE, elemId as counter << 32 | actorRank) -> visible index, or (log, abi.CURSOR_GET, visible
+        index) -> elemId.  Returns (out u64[n], status u32[n])."""
+        ql = np.ascontiguousarray(q_log, dtype=np.uint32)
+        qk = np.ascontiguousarray(q_kind, dtype=np.uint8)
+        qa = np.ascontiguousarray(q_arg, dtype=np.uint64)
+        n = len(ql)
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        status = np.zeros(max(n, 1), dtype=np.uint32)
+        self._check(self.lib.ptx_resolve_cursors(self.ctx, dbatch, dresult, n, ql.ctypes.data_as(abi.u32p), qk.ctypes.data_as(abi.u8p), qa.ctypes.data_as(abi.u64p),
+                                                 out.ctypes.data_as(abi.u64p), status.ctypes.data_as(abi.u32p)))
+        return out[:n], status[:n]
+
     def append_device(self, dbatch, more_dbatch):
         """The same with `more` already resident (e.g. the batch Engine.change made)."""
         h = C.c_void_p()

@@ -15,6 +15,7 @@ int ptx_emu_reverse = 0;
 #include "../../peritext_amd/csrc/replay_core.h"
 #include "../../peritext_amd/csrc/gen_core.h"
 #include "../../peritext_amd/csrc/change_core.h"
+#include "../../peritext_amd/csrc/cursor_core.h"
 
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
                           uint32_t lds_bytes, int reverse, int admission);
@@ -207,6 +208,43 @@ extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, con
     for (uint32_t l = 0; l < b->n_logs; ++l) {
         memset(lds, 0xA5, lds_bytes);
         ptx_change_log<0>(A, l, lds);
+    }
+    free(lds);
+    free(hdr);
+    return 0;
+}
+
+/* cursor resolution (cursor_core.h) over the merge results of the batch; queries already grouped by log by the caller */
+extern "C" int ptx_emu_cursors(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, uint32_t n_groups, const uint32_t* g_log, const uint64_t* g_off,
+                               const uint32_t* perm, const uint8_t* kind, const uint64_t* arg, uint64_t* out, uint32_t* status, uint32_t lds_bytes, int reverse) {
+    PtxCursorArgs A;
+    memset(&A, 0, sizeof(A));
+    A.log_off = b->log_off;
+    A.op_id = b->op_id;
+    A.action = b->action;
+    A.res = res;
+    A.elem_rank = rank;
+    A.q_group_log = g_log;
+    A.q_group_off = g_off;
+    A.q_perm = perm;
+    A.q_kind = kind;
+    A.q_arg = arg;
+    A.out = out;
+    A.status = status;
+    A.n_groups = n_groups;
+    A.lds_bytes = lds_bytes;
+    ptx_log_hdr* hdr = (ptx_log_hdr*)calloc(b->n_logs ? b->n_logs : 1, sizeof(ptx_log_hdr));
+    for (uint32_t l = 0; l < b->n_logs; ++l) {
+        const uint64_t b0 = b->log_off[l], b1 = b->log_off[l + 1];
+        ptx_census_rows(b->op_id + b0, b->action + b0, b->mark_type + b0, b->payload + b0, b1 - b0, &hdr[l]);
+    }
+    A.log_hdr = hdr;
+    uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)lds_bytes + 64);
+    if (!lds) return 1;
+    ptx_emu_reverse = reverse;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        memset(lds, 0xA5, lds_bytes);
+        ptx_cursor_group<0>(A, g, lds);
     }
     free(lds);
     free(hdr);

@@ -223,6 +223,52 @@ def emu_change(batch, res, ops, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB
     return made_batch(batch, ops, cols, env, rows_made, chgs_made, out_off), status[:n_logs]
 
 
+def emu_cursors(batch, res, q_log, q_kind, q_arg, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB):
+    """Cursor queries through the host emulation of cursor_core.h (tests only): (out u64[n], status u32[n])."""
+    ql, qk, qa = np.asarray(q_log, np.uint32), np.asarray(q_kind, np.uint8), np.asarray(q_arg, np.uint64)
+    n = len(ql)
+    perm = np.argsort(ql, kind="stable").astype(np.uint32)
+    sl = ql[perm]
+    starts = np.flatnonzero(np.concatenate([[True], sl[1:] != sl[:-1]])) if n else np.zeros(0, np.int64)
+    g_log = sl[starts].astype(np.uint32)
+    g_off = np.concatenate([starts, [n]]).astype(np.uint64)
+    out, status = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint32)
+    lib = C.CDLL(lib_path)
+    lib.ptx_emu_cursors.restype = C.c_int
+    s = batch_struct(batch)
+    vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    rc = lib.ptx_emu_cursors(C.byref(s), vp(res.logs), vp(res.elem_rank), C.c_uint32(len(g_log)), vp(g_log), vp(g_off), vp(perm), vp(qk), vp(qa), vp(out), vp(status),
+                             C.c_uint32(lds_bytes), C.c_int(reverse))
+    assert rc == 0
+    return out[:n], status[:n]
+
+
+def cursor_queries(batch, expected_per_doc):
+    """Every getCursor(index) and resolveCursor(elemId) of an oracle `apply --cursors` output as device queries + the wanted answers."""
+    q_log, q_kind, q_arg, want = [], [], [], []
+    log = 0
+    for d in expected_per_doc:
+        for e in d:
+            actors = batch.doc_actors[batch.log_doc[log]]
+            enc = lambda s: (int(s.split("@")[0]) << 32) | actors.index(s.split("@", 1)[1])  # noqa: E731
+            for i, elem in enumerate(e["cursorAt"]):
+                q_log.append(log), q_kind.append(abi.CURSOR_GET), q_arg.append(i), want.append(enc(elem))
+            q_log.append(log), q_kind.append(abi.CURSOR_GET), q_arg.append(len(e["text"])), want.append(None)  # past the end
+            for elem, idx in e["cursorResolve"].items():
+                q_log.append(log), q_kind.append(abi.CURSOR_RESOLVE), q_arg.append(enc(elem)), want.append(idx)
+            q_log.append(log), q_kind.append(abi.CURSOR_RESOLVE), q_arg.append((999999 << 32) | 0), want.append(None)  # no such element
+            log += 1
+    return q_log, q_kind, q_arg, want
+
+
+def check_cursor_answers(q_kind, want, out, status):
+    for k, w, o, st in zip(q_kind, want, out, status):
+        if w is None:
+            assert int(st) == (abi.ERR_INDEX_OOB if k == abi.CURSOR_GET else abi.ERR_ELEM_NOT_FOUND)
+        else:
+            assert int(st) == 0 and int(o) == w
+
+
 def concat_batches(base, more):
     """Host-side twin of ptx_batch_append: log l of the result = log l of `base` followed by log l of `more` (same tables)."""
     rows, chgs = [], []

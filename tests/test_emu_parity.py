@@ -334,6 +334,26 @@ def test_cursors_from_elem_rank():
             log += 1
 
 
+@pytest.mark.parametrize("reverse", [0, 1, 2])
+def test_cursor_kernel_against_the_reference_fixture(reverse):
+    """cursor_core.h (ptx_resolve_cursors): every getCursor(index) and resolveCursor(elemId) of three documents against the
+    answers the reference itself gave (edge_cases_ref.json), plus the two RangeErrors (past the end, unknown element)."""
+    g = _load("edge_cases_ref.json")
+    gen = _load("ptxgen_mini.json")
+    docs = [d["logs"] for d in gen["docs"][:3]]
+    batch = wire.encode_docs(docs)
+    res = H.emu_merge(batch)
+    q_log, q_kind, q_arg, want = H.cursor_queries(batch, g["cursors"])
+    out, status = H.emu_cursors(batch, res, q_log, q_kind, q_arg, reverse=reverse)
+    H.check_cursor_answers(q_kind, want, out, status)
+    assert len(want) > 300
+    # a replica the reference threw on has no cursors: the queries carry its merge status
+    bad = wire.encode_docs([[H.mini_doc([{"action": "del", "elemId": "77@zz"}])]])
+    rb = H.emu_merge(bad)
+    o2, s2 = H.emu_cursors(bad, rb, [0], [abi.CURSOR_GET], [0])
+    assert int(s2[0]) == abi.ERR_ELEM_NOT_FOUND
+
+
 def test_batch_file_round_trip(tmp_path):
     """The SoA op log is the checkpoint format: save, load, replay -> identical columns and identical digests."""
     gen = _load("ptxgen_config3_512.json")

@@ -127,6 +127,44 @@ def test_cursors_from_elem_rank(eng, golden):
             log += 1
 
 
+def test_cursors_resolved_on_the_device(eng, golden):
+    """ptx_resolve_cursors: getCursor / resolveCursor (micromerge.ts:465-477) answered by the device for every visible
+    index and every element ever inserted of three documents — the reference's own answers — plus the two RangeErrors."""
+    gen = _load("ptxgen_mini.json")
+    docs = [d["logs"] for d in gen["docs"][:3]]
+    batch = wire.encode_docs(docs)
+    db = eng.upload(batch)
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        eng.sync()
+        q_log, q_kind, q_arg, want = H.cursor_queries(batch, golden["cursors"])
+        out, status = eng.resolve_cursors(db, dr, q_log, q_kind, q_arg)
+        H.check_cursor_answers(q_kind, want, out, status)
+        assert len(want) > 300
+        o0, s0 = eng.resolve_cursors(db, dr, [], [], [])
+        assert len(o0) == 0
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
+    # the 8 192-op config-5 log (512-thread merge shape, 3 112 elements, one visible): every element resolves to 0 or 1
+    g5 = _load("ptxgen_config5_8192.json")
+    b5 = wire.encode_docs([d["logs"] for d in g5["docs"]])
+    db = eng.upload(b5)
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        eng.sync()
+        res = eng.download(db, dr)
+        ins = np.flatnonzero(b5.action == abi.ACT_INSERT)
+        out, status = eng.resolve_cursors(db, dr, [0] * len(ins), [abi.CURSOR_RESOLVE] * len(ins), b5.op_id[ins])
+        assert (status == 0).all()
+        assert [int(x) for x in out] == [wire.resolve_cursor(b5, res, 0, "%d@doc1" % (int(i) >> 32)) for i in b5.op_id[ins]]
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
+
+
 def test_ten_actor_document_string_order(eng):
     """a1: "7@doc10" < "7@doc2" (compareOpIds compares actor STRINGS, micromerge.ts:826): a 10-replica fixture made by the
     reference; ranks follow the string order and the many-actor admission build runs."""
