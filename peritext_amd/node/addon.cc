@@ -62,6 +62,7 @@ struct Lib {
     ptx_status (*allgather_digests)(ptx_ctx*, ptx_comm*, const ptx_dresult*, const uint32_t*, uint64_t*) = nullptr;
     ptx_status (*count_converged_digests)(ptx_ctx*, const uint64_t*, uint64_t, uint32_t, uint64_t*) = nullptr;
     ptx_status (*result_download_logs)(ptx_ctx*, const ptx_dresult*, ptx_log_result*, uint32_t) = nullptr;
+    ptx_status (*resolve_cursors)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, uint32_t, const uint32_t*, const uint8_t*, const uint64_t*, uint64_t*, uint32_t*) = nullptr;
     ptx_status (*device_alloc)(ptx_ctx*, uint64_t, void**) = nullptr;
     void (*device_free)(ptx_ctx*, void*) = nullptr;
     ptx_status (*device_read)(ptx_ctx*, const void*, void*, uint64_t) = nullptr;
@@ -110,7 +111,7 @@ napi_value Open(napi_env env, napi_callback_info info) {
                   sym(L.comm_unique_id, "ptx_comm_unique_id") && sym(L.comm_init, "ptx_comm_init") && sym(L.comm_destroy, "ptx_comm_destroy") &&
                   sym(L.allgather_digests, "ptx_allgather_digests") && sym(L.count_converged_digests, "ptx_count_converged_digests") &&
                   sym(L.result_download_logs, "ptx_result_download_logs") && sym(L.device_alloc, "ptx_device_alloc") && sym(L.device_free, "ptx_device_free") &&
-                  sym(L.device_read, "ptx_device_read");
+                  sym(L.device_read, "ptx_device_read") && sym(L.resolve_cursors, "ptx_resolve_cursors");
         if (!ok) {
             dlclose(L.handle);
             L.handle = nullptr;
@@ -546,6 +547,43 @@ napi_value Change(napi_env env, napi_callback_info info) {
     return out;
 }
 
+/* cursors(ctx, batch, {log: Uint32Array, kind: Uint8Array, arg: BigUint64Array}): Micromerge.getCursor / resolveCursor for many replicas
+ * (ptx_resolve_cursors): upload, merge, resolve.  Returns {out: BigUint64Array, status: Uint32Array}, one entry per query. */
+napi_value Cursors(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc > 2 ? ctx_of(env, argv[0]) : nullptr;
+    if (!ctx) return throw_msg(env, "cursors(ctx, batch, queries)");
+    ptx_batch pb;
+    if (!read_batch(env, argv[1], &pb)) return nullptr;
+    const void *ql = nullptr, *qk = nullptr, *qa = nullptr;
+    size_t n = 0, n2 = 0, n3 = 0;
+    if (!column(env, argv[2], "log", 4, &ql, &n) || !column(env, argv[2], "kind", 1, &qk, &n2) || !column(env, argv[2], "arg", 8, &qa, &n3) || n != n2 || n != n3)
+        return throw_msg(env, "cursors: queries = {log: Uint32Array, kind: Uint8Array, arg: BigUint64Array} of one length");
+    std::vector<uint64_t> out(n ? n : 1);
+    std::vector<uint32_t> status(n ? n : 1);
+    ptx_dbatch* db = nullptr;
+    ptx_dresult* dr = nullptr;
+    ptx_status st = L.batch_upload(ctx, &pb, &db);
+    if (st == PTX_OK) st = L.result_alloc(ctx, db, &dr);
+    if (st == PTX_OK) st = L.merge(ctx, db, dr);
+    if (st == PTX_OK) st = L.sync(ctx);
+    if (st == PTX_OK) st = L.resolve_cursors(ctx, db, dr, (uint32_t)n, (const uint32_t*)ql, (const uint8_t*)qk, (const uint64_t*)qa, out.data(), status.data());
+    std::string err = st != PTX_OK ? L.last_error(ctx) : "";
+    if (dr) L.dresult_free(ctx, dr);
+    if (db) L.batch_free(ctx, db);
+    if (st != PTX_OK) return throw_msg(env, ("ptx_resolve_cursors failed: " + err).c_str());
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    v = make_typed(env, napi_biguint64_array, 8, out.data(), n);
+    if (v) napi_set_named_property(env, o, "out", v);
+    v = make_u32(env, status.data(), n);
+    if (v) napi_set_named_property(env, o, "status", v);
+    return o;
+}
+
 /* commUniqueId(ctx) -> Uint8Array(128): rank 0 makes it, the host's own channel carries it to the other ranks */
 napi_value CommUniqueId(napi_env env, napi_callback_info info) {
     if (!L.handle) return throw_msg(env, "call open(libPath) first");
@@ -667,7 +705,7 @@ napi_value KernelName(napi_env env, napi_callback_info) {
 
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
-        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"generate", Generate}, {"change", Change}, {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"mergeAndGather", MergeAndGather},
+        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"generate", Generate}, {"change", Change}, {"cursors", Cursors}, {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"mergeAndGather", MergeAndGather},
         {"maxOpsPerLog", MaxOpsPerLog}, {"kernelName", KernelName},
     };
     for (auto& f : fns) {

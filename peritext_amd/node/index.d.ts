@@ -78,6 +78,9 @@ export interface ReplicaHandle {
     /** Micromerge.change (micromerge.ts:308): InputOperations resolved against this replica's state on the device (ptx_change);
      *  throws RangeError("List index out of bounds") like :804.  Needs engine.replica(docId, actorId). */
     change(ops: InputOperation[]): { change: Change; patches: Patch[] }
+    /** micromerge.ts:465-477, resolved on the device (ptx_resolve_cursors); RangeError like :804 / :752 */
+    getCursor(path: ["text"], index: number): { objectId: OperationId | null; elemId: OperationId }
+    resolveCursor(cursor: { objectId?: OperationId | null; elemId: OperationId }): number
     /** entry c = the Patch[] the reference's applyChange(c-th change) returns */
     getPatches(): Patch[][]
     /** throws RangeError("List element not found" | …) exactly where the reference's applyChange would have thrown */

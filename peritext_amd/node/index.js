@@ -618,6 +618,20 @@ class MergeEngine {
                 const patches = this.getPatches()
                 return { change, patches: patches[patches.length - 1] }
             },
+            /** Micromerge.getCursor (micromerge.ts:465-473): {objectId, elemId} of the index-th visible character, resolved on the device */
+            getCursor(p, index) {
+                if (!Array.isArray(p) || p.length !== 1 || p[0] !== "text") throw new Error("Only the text list is supported: " + JSON.stringify(p))
+                if (!(index >= 0)) throw new RangeError("List index out of bounds: " + index)
+                const r = self.cursorQueries(rep, [[1, BigInt(index)]])
+                if (r.status[0] !== 0) throw new RangeError((STATUS_MESSAGES[r.status[0]] || "error " + r.status[0]) + ": " + index)
+                return { objectId: r.textObj, elemId: r.oid(r.out[0]) }
+            },
+            /** Micromerge.resolveCursor (:475-477): visible characters before the cursor's element (which may be deleted by now) */
+            resolveCursor(cursor) {
+                const r = self.cursorQueries(rep, [[0, cursor.elemId]])
+                if (r.status[0] !== 0) throw new RangeError((STATUS_MESSAGES[r.status[0]] || "error " + r.status[0]) + ": " + cursor.elemId)
+                return Number(r.out[0])
+            },
             /** Patch[][]: entry c = what applyChange(c-th change) returns in the reference (one launch for all handles). */
             getPatches() {
                 if (rep.patches === null && rep.error === null) self.flush(true)
@@ -639,6 +653,30 @@ class MergeEngine {
                 return rep.spans
             },
         }
+    }
+    /** queries: [kind (0 resolve, 1 get), elemId string | BigInt index] of one replica -> device answers (ptx_resolve_cursors) */
+    cursorQueries(rep, queries) {
+        const mates = this.pending.filter(r => r.docId === rep.docId)
+        const batch = encodeDocs([mates.map(r => r.changes)])
+        const log = mates.indexOf(rep)
+        const actors = batch.docActors[0]
+        let textObj = null
+        for (const ch of rep.changes) for (const op of ch.ops) if (op.action === "makeList" && textObj === null) textObj = op.opId
+        const q = { log: new Uint32Array(queries.length).fill(log), kind: new Uint8Array(queries.length), arg: new BigUint64Array(queries.length) }
+        const missing = []
+        queries.forEach(([kind, arg], k) => {
+            q.kind[k] = kind
+            if (kind === 1) q.arg[k] = arg
+            else {
+                const [ctr, actor] = splitOpId(arg)
+                const rank = actors.indexOf(actor)
+                if (rank < 0) missing.push(k) /* an actor this document has never seen: no such element */
+                q.arg[k] = rank < 0 ? 0n : (BigInt(ctr) << 32n) | BigInt(rank)
+            }
+        })
+        const r = this.addon.cursors(this.ctx, batch, q)
+        for (const k of missing) r.status[k] = 1
+        return { out: r.out, status: r.status, textObj, oid: v => String(v >> 32n) + "@" + actors[Number(v & 0xffffffffn)] }
     }
     flush(wantPatches) {
         const byDoc = new Map()

@@ -173,6 +173,35 @@ if (cmd === "encode") {
     }
     engine.close()
     console.log(JSON.stringify({ ok: true, cases, calls }))
+} else if (cmd === "cursors") {
+    /* GPU: replica().getCursor / resolveCursor against the answers the reference gave (tests/golden/edge_cases_ref.json) */
+    const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    const want = JSON.parse(fs.readFileSync(process.argv[4], "utf8")).cursors
+    const engine = new host.MergeEngine()
+    let checked = 0
+    want.forEach((doc, d) => {
+        engine.pending = []
+        const reps = gen.docs[d].logs.map(() => engine.replica(0))
+        gen.docs[d].logs.forEach((log, r) => log.forEach(ch => reps[r].applyChange(ch)))
+        doc.forEach((e, r) => {
+            const idx = [0, e.text.length >> 1, e.text.length - 1].filter(i => i >= 0 && i < e.text.length)
+            for (const i of idx) {
+                const c = reps[r].getCursor(["text"], i)
+                assert.strictEqual(c.elemId, e.cursorAt[i])
+                assert.strictEqual(reps[r].resolveCursor(c), i)
+                checked++
+            }
+            const elems = Object.keys(e.cursorResolve)
+            for (const el of [elems[0], elems[elems.length >> 1], elems[elems.length - 1]]) {
+                assert.strictEqual(reps[r].resolveCursor({ elemId: el }), e.cursorResolve[el])
+                checked++
+            }
+            assert.throws(() => reps[r].getCursor(["text"], e.text.length), er => er instanceof RangeError && /List index out of bounds/.test(er.message))
+            assert.throws(() => reps[r].resolveCursor({ elemId: "99999@nobody" }), er => er instanceof RangeError && /List element not found/.test(er.message))
+        })
+    })
+    engine.close()
+    console.log(JSON.stringify({ ok: true, checked }))
 } else if (cmd === "comm") {
     /* GPU: the digest all-gather of the C ABI through N-API, a communicator of one rank */
     const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))

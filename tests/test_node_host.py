@@ -35,7 +35,7 @@ def test_addon_loads_and_binds_the_c_abi():
     info = _node("load")
     assert info["abi"] == abi.PTX_ABI_VERSION
     assert info["kernel"].startswith("ptx_merge_kernel")
-    assert info["exports"] == ["applyMaterialize", "change", "commDestroy", "commInit", "commUniqueId", "create", "destroy", "generate", "kernelName", "maxOpsPerLog",
+    assert info["exports"] == ["applyMaterialize", "change", "commDestroy", "commInit", "commUniqueId", "create", "cursors", "destroy", "generate", "kernelName", "maxOpsPerLog",
                                "mergeAndGather", "open"]
 
 
@@ -76,6 +76,15 @@ def test_node_host_patch_streams():
     out = _node("patches", *[os.path.join(H.GOLDEN, n) for n in names], timeout=600)
     want = [e for n in names for d in json.load(open(os.path.join(H.GOLDEN, n)))["docs"] for e in d["expected"]]
     assert out["ok"] and out["logs"] == len(want) and out["patches"] == sum(len(e["patches"]) for e in want)
+
+
+@pytest.mark.gpu
+@needs_node
+@needs_addon
+def test_node_host_cursors():
+    """replica().getCursor / resolveCursor through N-API on the GPU against the reference's answers."""
+    out = _node("cursors", os.path.join(H.GOLDEN, "ptxgen_mini.json"), os.path.join(H.GOLDEN, "edge_cases_ref.json"), timeout=600)
+    assert out["ok"] and out["checked"] > 40
 
 
 @pytest.mark.gpu
