@@ -241,7 +241,9 @@ const ptFooter = `
 module.exports = { applyAddRemoveMark, opsToMarks, getActiveMarksAtIndex, getTextWithFormatting, addCharactersToSpans, changeMark }
 `
 
-/* ---- schema.ts: only the two flags the CRDT reads from markSpec (schema.ts:45-96) ---- */
+/* ---- schema.ts: the two flags the CRDT reads from markSpec (schema.ts:45-96) + what the ProseMirror doc build depends on
+ *      (bridge.ts:369-414): the attribute names of every mark type, ALL_MARKS (:125) and the key order of the schema's mark table
+ *      (demoMarkSpec :99-121 = markSpec + two demo-only types; ProseMirror ranks marks by that order) ---- */
 function buildSchema(src) {
     const spec = {}
     for (const t of ["strong", "em", "comment", "link"]) {
@@ -250,11 +252,24 @@ function buildSchema(src) {
         const inc = /inclusive:\s*(true|false)/.exec(m[1])
         const multi = /allowMultiple:\s*(true|false)/.exec(m[1])
         if (!inc || !multi) die("schema.ts: flags not found for " + t)
-        spec[t] = { inclusive: inc[1] === "true", allowMultiple: multi[1] === "true" }
+        const attrs = /attrs:\s*\{([\s\S]*?)\n        \},/.exec(m[1])
+        const names = attrs ? (attrs[1].match(/([A-Za-z_]+):\s*\{\}/g) || []).map(x => x.split(":")[0]) : []
+        spec[t] = { inclusive: inc[1] === "true", allowMultiple: multi[1] === "true", attrs: names }
     }
+    const all = /export const ALL_MARKS = \[([^\]]*)\]/.exec(src)
+    if (!all) die("schema.ts: ALL_MARKS not found")
+    const allMarks = (all[1].match(/"([a-z]+)"/g) || []).map(x => x.replace(/"/g, ""))
+    const specKeys = []
+    const body = /export const markSpec = \{([\s\S]*?)\n\} as const/.exec(src)
+    if (!body) die("schema.ts: markSpec body not found")
+    for (const m of body[1].matchAll ? body[1].matchAll(/\n    ([a-zA-Z]+): \{/g) : []) specKeys.push(m[1])
+    const demo = /export const demoMarkSpec = \{([\s\S]*?)\n\}\n/.exec(src)
+    if (!demo || !/\.\.\.markSpec,/.test(demo[1])) die("schema.ts: demoMarkSpec does not start with ...markSpec")
+    const demoKeys = []
+    for (const m of demo[1].matchAll(/\n    ([a-zA-Z]+): \{/g)) demoKeys.push(m[1])
     return (
-        '"use strict"\n/* GENERATED by oracle/build_ref.js from reference/src/schema.ts:45-96 (flags only). DO NOT COMMIT. */\n' +
-        "module.exports = { markSpec: " + JSON.stringify(spec) + " }\n"
+        '"use strict"\n/* GENERATED by oracle/build_ref.js from reference/src/schema.ts:45-125 (flags, attribute names, mark order). DO NOT COMMIT. */\n' +
+        "module.exports = { markSpec: " + JSON.stringify(spec) + ", ALL_MARKS: " + JSON.stringify(allMarks) + ", markRankOrder: " + JSON.stringify(specKeys.concat(demoKeys)) + " }\n"
     )
 }
 

@@ -369,11 +369,15 @@ function decodeChanges(batch, log, textObjOfLog) {
  * prosemirrorDocFromCRDT (reference/src/bridge.ts:394-414 with getProsemirrorMarksForMarkMap :369-391) as the JSON that
  * prosemirror-model's Node.toJSON() gives for the document it builds: doc > paragraph > text nodes, one per span, marks
  * in ALL_MARKS order (= schema rank order, schema.ts:125,:146-149), attrs only where the mark spec has some (comment
- * {id}, link {url}; strong / em carry none, schema.ts:45-96).  prosemirror-model is not available in this image: this
- * follows its documented toJSON shape, PARITY UNPINNED.
+ * {id}, link {url}; strong / em carry none, schema.ts:45-96), adjacent spans with equal ProseMirror marks joined.  What the
+ * reference's own source decides is pinned by tests/golden/pm_docs.json (oracle/gen_pm_golden.js reads the reference's schema.ts);
+ * prosemirror-model itself is not available in this image: its toJSON / joining rules are restated, PARITY UNPINNED for those.
  */
 function prosemirrorDocFromSpans(spans) {
-    const text = spans.filter(s => s.text !== "").map(s => {
+    if (spans.length === 1 && spans[0].text === "") return { type: "doc", content: [{ type: "paragraph" }] } /* bridge.ts:399-401 */
+    const text = []
+    for (const s of spans) {
+        if (s.text === "") throw new RangeError("Empty text nodes are not allowed") /* what prosemirror-model's schema.text("") throws */
         const marks = []
         for (const t of MARK_NAMES) {
             const v = s.marks[t]
@@ -382,11 +386,16 @@ function prosemirrorDocFromSpans(spans) {
             else if (t === "link") marks.push({ type: t, attrs: { url: v.url } })
             else marks.push({ type: t })
         }
+        const last = text[text.length - 1]
+        if (last && JSON.stringify(last.marks || []) === JSON.stringify(marks)) {
+            last.text += s.text /* Fragment.fromArray joins adjacent text nodes with the same marks */
+            continue
+        }
         const node = { type: "text" }
         if (marks.length) node.marks = marks
         node.text = s.text
-        return node
-    })
+        text.push(node)
+    }
     const paragraph = { type: "paragraph" }
     if (text.length) paragraph.content = text
     return { type: "doc", content: [paragraph] }

@@ -580,12 +580,18 @@ def decode_patches(batch, pat, log, with_rows=False):
 
 def prosemirror_doc(spans):
     """prosemirrorDocFromCRDT (reference/src/bridge.ts:394-414, marks :369-391) as the JSON prosemirror-model's Node.toJSON() gives:
-    doc > paragraph > one text node per span, marks in ALL_MARKS order (schema.ts:125), attrs only for comment {id} and link {url}.
-    ProseMirror is not available in this image: restated from its documented toJSON shape, PARITY UNPINNED."""
+    doc > paragraph > text nodes, marks in ALL_MARKS order (schema.ts:125; = the rank order of the schema's mark table), attrs only
+    for the types that declare some (comment {id}, link {url}; schema.ts:45-96), adjacent spans whose ProseMirror marks are equal
+    (e.g. `comment: []` next to no comment key) joined into one text node as Fragment.fromArray does, the single empty span of an
+    empty document -> an empty paragraph (:399-401).  The rules the reference's own source decides are pinned by
+    tests/golden/pm_docs.json (oracle/gen_pm_golden.js reads them from the reference's schema.ts); ProseMirror's toJSON / joining
+    rules are restated from its documented behaviour (not in this image): PARITY UNPINNED for those."""
+    if len(spans) == 1 and spans[0]["text"] == "":
+        return {"type": "doc", "content": [{"type": "paragraph"}]}
     text = []
     for s in spans:
         if s["text"] == "":
-            continue
+            raise ValueError("Empty text nodes are not allowed")  # what prosemirror-model's schema.text("") throws
         marks = []
         for t in abi.MARK_NAMES:
             v = s["marks"].get(t)
@@ -597,6 +603,9 @@ def prosemirror_doc(spans):
                 marks.append({"type": t, "attrs": {"url": v["url"]}})
             else:
                 marks.append({"type": t})
+        if text and text[-1].get("marks", []) == marks:
+            text[-1]["text"] += s["text"]
+            continue
         node = {"type": "text"}
         if marks:
             node["marks"] = marks

@@ -222,7 +222,8 @@ if (cmd === "encode") {
 } else if (cmd === "pmdoc") {
     /* no GPU: ProseMirror doc JSON of every expected span list of a fixture */
     const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
-    console.log(JSON.stringify(gen.docs.map(d => d.expected.map(e => host.prosemirrorDocFromSpans(e.spans)))))
+    if (gen.cases) console.log(JSON.stringify(gen.cases.map(c => host.prosemirrorDocFromSpans(c.spans)))) /* tests/golden/pm_docs.json */
+    else console.log(JSON.stringify(gen.docs.map(d => d.expected.map(e => host.prosemirrorDocFromSpans(e.spans)))))
 } else if (cmd === "decode") {
     /* no GPU: decodeChanges inverts encodeDocs */
     const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))

@@ -169,3 +169,18 @@ def test_prosemirror_doc_json_js_equals_python_and_has_the_bridge_shape():
             assert ("attrs" in m) == (m["type"] in ("comment", "link"))
     assert wire.prosemirror_doc([]) == {"type": "doc", "content": [{"type": "paragraph"}]}
     assert wire.prosemirror_doc([{"text": "", "marks": {}}]) == {"type": "doc", "content": [{"type": "paragraph"}]}
+
+
+@needs_node
+def test_prosemirror_doc_against_the_fixture_derived_from_the_reference_schema():
+    """tests/golden/pm_docs.json (oracle/gen_pm_golden.js): mark order, attribute names and the empty-document rule come from the
+    reference's schema.ts / bridge.ts; both hosts reproduce every case, incl. the joining of spans that differ only by `comment: []`."""
+    name = os.path.join(H.GOLDEN, "pm_docs.json")
+    with open(name) as f:
+        g = json.load(f)
+    assert g["schema"]["ALL_MARKS"] == abi.MARK_NAMES and g["schema"]["attrs"] == {"strong": [], "em": [], "comment": ["id"], "link": ["url"]}
+    want = [c["doc"] for c in g["cases"]]
+    assert [wire.prosemirror_doc(c["spans"]) for c in g["cases"]] == want
+    assert _node("pmdoc", name) == want
+    joined = [c for c in g["cases"] if c["spans"] and c["spans"][0]["marks"] == {"comment": []}][0]["doc"]
+    assert [n["text"] for n in joined["content"][0]["content"]] == ["abcd", "e"]
