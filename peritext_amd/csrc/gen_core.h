@@ -79,7 +79,7 @@ struct PtxGenHdr {
 };
 
 PTX_HD uint64_t ptx_gen_lds_need(uint64_t R, uint64_t list_cap, uint64_t rows_per_log) {
-    return ptx_a16(sizeof(PtxGenHdr)) + ptx_a16(4 * R * ((list_cap + 64 + 3) & ~3ull)) + ptx_a16(4 * (list_cap + 64)) + ptx_a16(4 * ((rows_per_log >> 5) + 2)) + ptx_a16(2 * (rows_per_log + 1));
+    return ptx_a16(sizeof(PtxGenHdr)) + ptx_a16(4 * R * ((list_cap + 64 + 3) & ~3ull)) + ptx_a16(4 * ((rows_per_log >> 5) + 2));
 }
 
 /* ---- 64-wide ballot over lanes: `expr` may use `lane_` ---- */
@@ -194,7 +194,6 @@ struct PtxGenDoc {
     PtxGenHdr* H;
     uint32_t* lst0;      /* replica r's list = lst0 + r * lst_stride (no pointer table: nothing of this kernel lives in scratch) */
     uint32_t lst_stride;
-    uint32_t* tmpbuf;
     uint32_t* done;   /* pending-change bitmap of a delivery */
     uint16_t* crank;  /* comment counter -> doc-local rank */
     uint64_t row0;    /* first row of replica 0's log */
@@ -227,10 +226,23 @@ struct PtxGenDoc {
                 PTX_SYNC();
                 return;
             }
-            const uint32_t cnt = n - at;
-            PTX_GEN_FOR(i, cnt) tmpbuf[i] = L[at + i];
-            PTX_SYNC();
-            PTX_GEN_FOR(i, cnt) L[at + 1u + i] = tmpbuf[i];
+            /* open the gap: the tail moves up by one, 64 elements at a time from the END (one wave: every lane has read its element
+             * before any lane writes, and a chunk only writes above what the chunks still to come read) */
+            for (uint32_t hi = n; hi > at;) {
+                const uint32_t lo = hi - at > 64u ? hi - 64u : at;
+#ifdef PTX_EMU
+                uint32_t chunk[64];
+                for (uint32_t i = lo; i < hi; ++i) chunk[i - lo] = L[i];
+                for (uint32_t i = lo; i < hi; ++i) L[i + 1u] = chunk[i - lo];
+#else
+                const uint32_t i = lo + (threadIdx.x & 63u);
+                const uint32_t v = i < hi ? L[i] : 0u;
+                PTX_SYNC();
+                if (i < hi) L[i + 1u] = v;
+#endif
+                PTX_SYNC();
+                hi = lo;
+            }
             if (PTX_LANE0) {
                 L[at] = key;
                 H->n[r] = n + 1u;
@@ -383,16 +395,15 @@ PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) 
     bp.cap = A.lds_bytes;
     bp.high = bp.off;
     bp.overflow = false;
-    PtxGenDoc<kThreads> G{A, H, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, A.list_cap};
+    PtxGenDoc<kThreads> G{A, H, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, A.list_cap};
     G.lst_stride = (A.list_cap + 64u + 3u) & ~3u;
     G.lst0 = ptx_alloc<uint32_t>(bp, G.lst_stride * R);
-    G.tmpbuf = ptx_alloc<uint32_t>(bp, A.list_cap + 64);
     G.done = ptx_alloc<uint32_t>(bp, (N >> 5) + 2);
-    G.crank = ptx_alloc<uint16_t>(bp, N + 1);
+    G.crank = (uint16_t*)G.lst0; /* needed once the documents are finished and the lists dead: R * stride * 4 >= 2 * (N + 1) is checked below */
     G.row0 = (uint64_t)doc_local * R * N;
     G.ctab = A.ctab + (uint64_t)doc_local * R * N;
     G.known = A.known + (uint64_t)doc_local * R * N;
-    if (bp.overflow || R == 0 || R > PTX_GEN_MAX_R || N > 0xFFFFFFu) {
+    if (bp.overflow || R == 0 || R > PTX_GEN_MAX_R || N > 0xFFFFFFu || (uint64_t)G.lst_stride * R * 4u < 2ull * (N + 1u)) {
         if (PTX_LANE0) {
             A.status[doc_local] = PTX_ERR_CAPACITY;
             A.n_comments[doc_local] = 0;
