@@ -542,8 +542,8 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     (void)N;
     (void)D;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
-    const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P5a */
-    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + 3 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (K / 32 + 1)) + elem;
+    const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P2b */
+    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + elem;
     const uint64_t p1 = ptx_a16(4 * (nw + 1));
     const uint64_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
     const uint64_t p3 = ptx_a16(2 * (n + 1)) + ptx_a16(2 * (2 * n + 2)) + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
@@ -553,7 +553,7 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     const uint64_t trees1 = n > T4 ? ptx_overflow3(elem, 4 * 2 * T1, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
     uint64_t tail = comments > trees4 ? comments : trees4;
     if (trees1 > tail) tail = trees1;
-    const uint64_t p5 = ptx_a16(8 * (nwe + 1)) + ptx_a16(4 * (nwe + 1)) + tail;
+    const uint64_t p5 = ptx_a16(8 * (nwe + 1)) + 3 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (K / 32 + 1)) + ptx_a16(4 * (nwe + 1)) + tail;
     uint64_t m = p1 > p3 ? p1 : p3;
     if (p5 > m) m = p5;
     return persist + m;
@@ -1043,14 +1043,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
     const uint32_t nw = (keyspace + 31) / 32;
     const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
-    uint16_t* mlist = ptx_alloc<uint16_t>(bp, K + 1); /* rows of the mark ops, grouped by type; [K] = spare slot */
-    /* per mark op, from the row pass P2 on: the element its start / end boundary names (element index << 1 | side-is-after;
-     * PTX_END = the op never starts / runs to the end of the text); P5a turns both in place into the visible interval [lo, hi) */
-    uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
-    uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
-    uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);             /* comment mark -> doc-local comment id */
-    uint32_t* maddbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 1);  /* mark op is an addMark */
-    /* element-side state: dead once the mark intervals are known (P5a), then reused as scratch of the tail phases */
+    /* element-side state: dead once the mark intervals are known (P2b), then reused as scratch of the tail phases */
     const uint32_t elem_lds = bp.off;
     ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
     uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1);         /* element -> op row */
@@ -1059,8 +1052,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_BAIL_CAPACITY();
     const uint32_t mark_lds = bp.off; /* everything above this mark is phase scratch */
 
-    /* ---- P1: first pass over the rows (op_id, action, mark_type: 10 of the 32 bytes of a row): the id bitmaps — every elemId
-     *      reference of the second pass needs the COMPLETE index of the inserts — and the census check ---- */
+    /* ---- P1: first pass over the rows (op_id, action, mark_type): the id bitmaps — every elemId reference of the later passes
+     *      needs the COMPLETE index of the inserts — and the census check.  All three row passes (P1, P2a, P2b) stream their
+     *      columns coalesced, consecutive rows on consecutive lanes; no phase gathers through a row list ---- */
     {
         uint32_t* allbits = ptx_alloc<uint32_t>(bp, nw + 1); /* every op id: duplicate detection */
         PTX_BAIL_CAPACITY();
@@ -1072,7 +1066,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             allbits[w] = 0;
         }
         PTX_FOR(w, nwe + 1) delbits[w] = 0;
-        PTX_FOR(w, (K >> 5) + 1) maddbits[w] = 0;
         PTX_LEADER {
             for (int c = 0; c < 8; ++c) H->cur[c] = 0; /* rows per class (0 insert, 1 delete, 2..5 mark type 0..3), counted below */
             H->n_ins = n;
@@ -1206,52 +1199,31 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
         PTX_FOR(p, (n + 2 + 1) / 2 + 1) cntw[p] = 0;
         PTX_FOR(t, n) dmin[t] = 0xFFFFFFFFu;
-        PTX_LEADER {
-            /* list cursors of the mark ops, grouped by type: type t owns mlist[moff_t .. moff_{t+1}) */
-            H->cur[0] = 0;
-            H->cur[1] = moff1;
-            H->cur[2] = moff2;
-            H->cur[3] = moff3;
-        }
         PTX_SYNC();
-        /* ---- P2: second pass over the rows, ALL columns, every byte of the op log read here exactly once and coalesced
-         *      (no phase after this one gathers through a row list): inserts -> element index, row, parent, child count;
-         *      deletes -> tombstone bit + earliest delete row of the element; marks -> list slot (row order within the wave),
-         *      boundary elements, add/remove flag, comment id ---- */
+        /* ---- P2a: second pass over the rows (op_id, ref_a, action): inserts -> element index, row, parent, child count;
+         *      deletes -> tombstone bit + earliest delete row of the element ---- */
         {
-            const uint32_t p2_groups = (N + PTX_U2 - 1u) / PTX_U2, p2_steps = PTX_STEPS(p2_groups);
-            uint64_t id[PTX_U2], ra[PTX_U2], rb[PTX_U2], id_n[PTX_U2], ra_n[PTX_U2], rb_n[PTX_U2];
-            uint32_t pl[PTX_U2], ab[PTX_U2], pl_n[PTX_U2], ab_n[PTX_U2]; /* ab = action | mark_type << 8 | side_a << 16 | side_b << 24 */
-#define PTX_P2_LOAD(g_, id_, ra_, rb_, pl_, ab_)                                              \
-    _Pragma("unroll") for (int u = 0; u < PTX_U2; ++u) {                                       \
-        const uint32_t r_ = (g_) * PTX_U2 + (uint32_t)u;                                       \
-        const uint32_t i_ = r_ < N ? r_ : N - 1u;                                             \
-        id_[u] = op_id[i_];                                                                   \
-        ra_[u] = ref_a[i_];                                                                   \
-        rb_[u] = ref_b[i_];                                                                   \
-        pl_[u] = payload[i_];                                                                 \
-        ab_[u] = (uint32_t)action[i_] | ((uint32_t)mark_type[i_] << 8) | ((uint32_t)A.side_a[base + i_] << 16) | ((uint32_t)A.side_b[base + i_] << 24); \
+            const uint32_t p2_groups = (N + PTX_U1 - 1u) / PTX_U1, p2_steps = PTX_STEPS(p2_groups);
+            uint64_t id[PTX_U1], ra[PTX_U1], id_n[PTX_U1], ra_n[PTX_U1];
+            uint32_t a[PTX_U1], a_n[PTX_U1];
+#define PTX_P2_LOAD(g_, id_, ra_, a_)                                    \
+    _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {                  \
+        const uint32_t r_ = (g_) * PTX_U1 + (uint32_t)u;                  \
+        const uint32_t i_ = r_ < N ? r_ : N - 1u;                        \
+        id_[u] = op_id[i_];                                              \
+        ra_[u] = ref_a[i_];                                              \
+        a_[u] = action[i_];                                              \
     }
-            PTX_P2_LOAD(PTX_G_OF(0u, p2_steps), id, ra, rb, pl, ab)
+            PTX_P2_LOAD(PTX_G_OF(0u, p2_steps), id, ra, a)
 #pragma nounroll
             for (uint32_t st = 0; st < p2_steps; ++st) {
                 const uint32_t g = PTX_G_OF(st, p2_steps);
                 if (PTX_WAVE_FIRST(g) >= p2_groups) continue; /* this wave has no row left in this step (wave-uniform) */
-                PTX_P2_LOAD(PTX_G_OF(st + 1u, p2_steps), id_n, ra_n, rb_n, pl_n, ab_n) /* in flight while this step is processed */
-                uint32_t mcls[PTX_U2], slot[PTX_U2];
+                PTX_P2_LOAD(PTX_G_OF(st + 1u, p2_steps), id_n, ra_n, a_n) /* in flight while this step is processed */
 #pragma unroll
-                for (int u = 0; u < PTX_U2; ++u) {
-                    const uint32_t i = g * PTX_U2 + (uint32_t)u;
-                    const uint32_t a = ab[u] & 0xFFu, mt = (ab[u] >> 8) & 0xFFu;
-                    mcls[u] = i < N && (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) && mt < 4u ? mt : 7u;
-                }
-                ptx_wave_slots4<PTX_U2>(H->cur, mcls, slot);
-#pragma unroll
-                for (int u = 0; u < PTX_U2; ++u) {
-                    const uint32_t i = g * PTX_U2 + (uint32_t)u;
-                    if (i >= N) continue;
-                    const uint32_t a = ab[u] & 0xFFu;
-                    if (a == PTX_ACT_INSERT) {
+                for (int u = 0; u < PTX_U1; ++u) {
+                    const uint32_t i = g * PTX_U1 + (uint32_t)u;
+                    if (i < N && a[u] == PTX_ACT_INSERT) {
                         uint32_t key = 0;
                         ptx_id_key(ix, id[u], key);
                         const uint32_t e = ptx_bitrank(ix.ib, key);
@@ -1264,7 +1236,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         }
                         par[e] = (uint16_t)pe;
                         ptx_atomic_add(&cntw[pe >> 1], 1u << (16u * (pe & 1u)));
-                    } else if (a == PTX_ACT_DELETE) {
+                    } else if (i < N && a[u] == PTX_ACT_DELETE) {
                         /* the element must exist when the delete is applied (micromerge.ts:752; checked against its row once every
                          * row is known); deleting twice is fine (:693) */
                         const int t = ptx_elem_lookup(ix, ra[u]);
@@ -1273,31 +1245,13 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                             ptx_atomic_or(&delbits[t >> 5], 1u << ((uint32_t)t & 31u));
                             ptx_atomic_min(&dmin[t], i);
                         }
-                    } else if (mcls[u] < 4u) {
-                        const uint32_t sa = (ab[u] >> 16) & 0xFFu, sb = ab[u] >> 24;
-                        const uint32_t k = slot[u] < K ? slot[u] : K; /* the census was verified: always a real slot */
-                        /* only before/after(elem) can ever match a slot (peritext.ts:236); whether the element is in the list
-                         * when the op is applied is decided in P5a, against its row */
-                        int js = -1, je = -1;
-                        if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) js = ptx_elem_lookup(ix, ra[u]);
-                        if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) je = ptx_elem_lookup(ix, rb[u]);
-                        mlist[k] = (uint16_t)i;
-                        mrk_lo[k] = js < 0 ? (uint16_t)PTX_END : (uint16_t)(((uint32_t)js << 1) | (sa == PTX_SIDE_AFTER ? 1u : 0u));
-                        mrk_hi[k] = je < 0 ? (uint16_t)PTX_END : (uint16_t)(((uint32_t)je << 1) | (sb == PTX_SIDE_AFTER ? 1u : 0u));
-                        if (a == PTX_ACT_ADDMARK) ptx_atomic_or(&maddbits[k >> 5], 1u << (k & 31u));
-                        if (mcls[u] == PTX_MARK_COMMENT) {
-                            if (pl[u] >= Kid) ptx_raise(H, i, 1, PTX_ERR_BAD_OP); /* beyond the id space the header declares */
-                            cid[k - moff2] = (uint16_t)(pl[u] < Kid ? pl[u] : 0u);
-                        }
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < PTX_U2; ++u) {
+                for (int u = 0; u < PTX_U1; ++u) {
                     id[u] = id_n[u];
                     ra[u] = ra_n[u];
-                    rb[u] = rb_n[u];
-                    pl[u] = pl_n[u];
-                    ab[u] = ab_n[u];
+                    a[u] = a_n[u];
                 }
             }
 #undef PTX_P2_LOAD
@@ -1464,6 +1418,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = nwe; /* bit positions 0..n by document position */
     PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
+    uint16_t* mlist = ptx_alloc<uint16_t>(bp, K + 1);           /* rows of the mark ops, grouped by type; [K] = spare slot */
+    uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);          /* their visible intervals [lo, hi) */
+    uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
+    uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);            /* comment mark -> doc-local comment id */
+    uint32_t* maddbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 1); /* mark op is an addMark */
     uint32_t* brkbits = ptx_alloc<uint32_t>(bp, nwe + 1); /* visible positions where a comment interval starts/ends */
     PTX_BAIL_CAPACITY();
     PTX_FOR(w, nwv + 1) {
@@ -1472,6 +1431,14 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         z.pre = 0;
         alive[w] = z;
         brkbits[w] = 0;
+    }
+    PTX_FOR(w, (K >> 5) + 1) maddbits[w] = 0;
+    PTX_LEADER {
+        /* list cursors of the mark ops, grouped by type: type t owns mlist[moff_t .. moff_{t+1}) */
+        H->cur[0] = 0;
+        H->cur[1] = moff1;
+        H->cur[2] = moff2;
+        H->cur[3] = moff3;
     }
     PTX_SYNC();
     PTX_FOR(e, n) {
@@ -1517,31 +1484,84 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         ptx_digest_flush(H, h1, h2);
     }
-    /* every mark op -> visible interval [lo, hi): LDS only (P2 left the boundary elements, the rows and the ranks are here) */
-    PTX_FOR(k, K) {
-        const uint32_t i = mlist[k];
-        const uint32_t vs = mrk_lo[k], ve = mrk_hi[k];
-        uint32_t lo = 0, hi = 0;
-        /* start: an element that is not in the list when the op is applied means the op never starts */
-        int js = vs == PTX_END ? -1 : (int)(vs >> 1);
-        if (js >= 0 && row_of[js] >= i) js = -1;
-        if (js >= 0) {
-            const uint32_t slot_a = 2u * rnk[js] + (vs & 1u);
-            uint32_t slot_b = 0xFFFFFFFFu; /* never reached: runs to the end of the text */
-            int je = ve == PTX_END ? -1 : (int)(ve >> 1);
-            if (je >= 0 && row_of[je] >= i) je = -1;
-            if (je >= 0) slot_b = 2u * rnk[je] + (ve & 1u);
-            /* same slot: the start test fires first and the end is never seen */
-            if (slot_b == slot_a) slot_b = 0xFFFFFFFFu;
-            if (slot_b > slot_a) {
-                const uint32_t lo_rank = (slot_a + 1u) >> 1;
-                const uint32_t hi_rank = slot_b == 0xFFFFFFFFu ? n : (slot_b + 1u) >> 1;
-                lo = ptx_bitrank(alive, lo_rank);
-                hi = ptx_bitrank(alive, hi_rank);
+    /* ---- P2b: third pass over the rows (ref_a, ref_b, payload, action, mark_type, side_a, side_b): every mark op -> list slot (row
+     *      order within the wave), visible interval [lo, hi) from its boundary slots 2 * rank + side, add/remove flag, comment id ---- */
+    {
+        const uint32_t p2_groups = (N + PTX_U2 - 1u) / PTX_U2, p2_steps = PTX_STEPS(p2_groups);
+        uint64_t ra[PTX_U2], rb[PTX_U2], ra_n[PTX_U2], rb_n[PTX_U2];
+        uint32_t pl[PTX_U2], ab[PTX_U2], pl_n[PTX_U2], ab_n[PTX_U2]; /* ab = action | mark_type << 8 | side_a << 16 | side_b << 24 */
+#define PTX_P2_LOAD(g_, ra_, rb_, pl_, ab_)                                                   \
+    _Pragma("unroll") for (int u = 0; u < PTX_U2; ++u) {                                       \
+        const uint32_t r_ = (g_) * PTX_U2 + (uint32_t)u;                                       \
+        const uint32_t i_ = r_ < N ? r_ : N - 1u;                                             \
+        ra_[u] = ref_a[i_];                                                                   \
+        rb_[u] = ref_b[i_];                                                                   \
+        pl_[u] = payload[i_];                                                                 \
+        ab_[u] = (uint32_t)action[i_] | ((uint32_t)mark_type[i_] << 8) | ((uint32_t)A.side_a[base + i_] << 16) | ((uint32_t)A.side_b[base + i_] << 24); \
+    }
+        PTX_P2_LOAD(PTX_G_OF(0u, p2_steps), ra, rb, pl, ab)
+#pragma nounroll
+        for (uint32_t st = 0; st < p2_steps; ++st) {
+            const uint32_t g = PTX_G_OF(st, p2_steps);
+            if (PTX_WAVE_FIRST(g) >= p2_groups) continue; /* this wave has no row left in this step (wave-uniform) */
+            PTX_P2_LOAD(PTX_G_OF(st + 1u, p2_steps), ra_n, rb_n, pl_n, ab_n) /* in flight while this step is processed */
+            uint32_t mcls[PTX_U2], slot[PTX_U2];
+#pragma unroll
+            for (int u = 0; u < PTX_U2; ++u) {
+                const uint32_t i = g * PTX_U2 + (uint32_t)u;
+                const uint32_t a = ab[u] & 0xFFu, mt = (ab[u] >> 8) & 0xFFu;
+                mcls[u] = i < N && (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) && mt < 4u ? mt : 7u;
+            }
+            ptx_wave_slots4<PTX_U2>(H->cur, mcls, slot);
+#pragma unroll
+            for (int u = 0; u < PTX_U2; ++u) {
+                if (mcls[u] >= 4u) continue;
+                const uint32_t i = g * PTX_U2 + (uint32_t)u;
+                const uint32_t sa = (ab[u] >> 16) & 0xFFu, sb = ab[u] >> 24;
+                const uint32_t k = slot[u] < K ? slot[u] : K; /* the census was verified: always a real slot */
+                uint32_t lo = 0, hi = 0;
+                /* start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is
+                   not in the list when the op is applied means the op never starts */
+                int js = -1;
+                if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
+                    js = ptx_elem_lookup(ix, ra[u]);
+                    if (js >= 0 && row_of[js] >= i) js = -1;
+                }
+                if (js >= 0) {
+                    const uint32_t slot_a = 2u * rnk[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
+                    uint32_t slot_b = 0xFFFFFFFFu; /* never reached: runs to the end of the text */
+                    if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
+                        int je = ptx_elem_lookup(ix, rb[u]);
+                        if (je >= 0 && row_of[je] >= i) je = -1;
+                        if (je >= 0) slot_b = 2u * rnk[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
+                    }
+                    /* same slot: the start test fires first and the end is never seen */
+                    if (slot_b == slot_a) slot_b = 0xFFFFFFFFu;
+                    if (slot_b > slot_a) {
+                        const uint32_t lo_rank = (slot_a + 1u) >> 1;
+                        const uint32_t hi_rank = slot_b == 0xFFFFFFFFu ? n : (slot_b + 1u) >> 1;
+                        lo = ptx_bitrank(alive, lo_rank);
+                        hi = ptx_bitrank(alive, hi_rank);
+                    }
+                }
+                mlist[k] = (uint16_t)i;
+                mrk_lo[k] = (uint16_t)lo;
+                mrk_hi[k] = (uint16_t)hi;
+                if ((ab[u] & 0xFFu) == PTX_ACT_ADDMARK) ptx_atomic_or(&maddbits[k >> 5], 1u << (k & 31u));
+                if (mcls[u] == PTX_MARK_COMMENT) {
+                    if (pl[u] >= Kid) ptx_raise(H, i, 1, PTX_ERR_BAD_OP); /* beyond the id space the header declares */
+                    cid[k - moff2] = (uint16_t)(pl[u] < Kid ? pl[u] : 0u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PTX_U2; ++u) {
+                ra[u] = ra_n[u];
+                rb[u] = rb_n[u];
+                pl[u] = pl_n[u];
+                ab[u] = ab_n[u];
             }
         }
-        mrk_lo[k] = (uint16_t)lo;
-        mrk_hi[k] = (uint16_t)hi;
+#undef PTX_P2_LOAD
     }
     PTX_BAIL_IF_ERROR();
     if (H->adm != PTX_NO_ERR) { /* no op-level error anywhere: the failed admission is the log's error */
