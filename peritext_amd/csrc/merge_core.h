@@ -166,42 +166,6 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 }
 #endif
 
-/* the same for the four mark-type classes only (class < 4; anything else gets no slot): one packed word, 8 bits per class
- * (a wave holds at most 64 * U <= 255 rows per step), ONE prefix sum, one LDS atomic on four lanes */
-#ifdef PTX_EMU
-template <int U>
-PTX_DEV void ptx_wave_slots4(uint32_t* cursor, const uint32_t* cls, uint32_t* slot) {
-    for (int u = 0; u < U; ++u) slot[u] = cls[u] < 4u ? cursor[cls[u]]++ : 0xFFFFFFFFu;
-}
-#else
-template <int U>
-PTX_DEV void ptx_wave_slots4(uint32_t* cursor, const uint32_t* cls, uint32_t* slot) {
-    static_assert(64 * U <= 255, "per-step class counts must fit 8 bits");
-    uint32_t w = 0, off[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t c = cls[u];
-        off[u] = (w >> ((c & 3u) * 8u)) & 255u;
-        w += c < 4u ? 1u << (c * 8u) : 0u;
-    }
-    const uint32_t inc = ptx_wave_incl_scan(w);
-    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t basev = 0;
-    if (lane < 4u) {
-        const uint32_t cnt = (tot >> (lane * 8u)) & 255u;
-        if (cnt) basev = atomicAdd(&cursor[lane], cnt);
-    }
-    const uint32_t exc = inc - w; /* exclusive prefix over the lower lanes */
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t c = cls[u];
-        const uint32_t b = (uint32_t)__shfl((int)basev, (int)(c & 3u), 64);
-        slot[u] = c < 4u ? b + ((exc >> (c * 8u)) & 255u) + off[u] : 0xFFFFFFFFu;
-    }
-}
-#endif
-
 /* Software-pipelined uniform loops: step st of `steps` handles group PTX_G_OF(st); the loads of step st+1 are
  * issued before step st is processed (the caller keeps two register sets).  Every thread runs every step; a
  * group index past the end means "no work" (its loads are clamped to valid addresses, its effects masked). */
@@ -232,9 +196,6 @@ PTX_DEV void ptx_wave_slots4(uint32_t* cursor, const uint32_t* cls, uint32_t* sl
 #define PTX_J_OF(st, u) PTX_J_OF_U(st, u, PTX_U)
 #ifndef PTX_U1
 #define PTX_U1 3 /* consecutive rows per thread and step in the row pass P1 (measured: 2 -> 14.6, 3 -> 14.2, 4 -> 17 us per 4K-op log) */
-#endif
-#ifndef PTX_U2
-#define PTX_U2 2 /* consecutive rows per thread and step in the all-columns row pass P2 (8 loads per row, the next step's in flight) */
 #endif
 #ifndef PTX_P1_PREFETCH
 #define PTX_P1_PREFETCH 1 /* 1: double-buffer the row loads of P1 (costs PTX_U1 * 4 VGPRs) */
@@ -540,20 +501,21 @@ PTX_HD uint64_t ptx_overflow3(uint64_t free_bytes, uint64_t s0, uint64_t s1, uin
 }
 PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) {
     (void)N;
-    (void)D;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
-    const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P2b */
-    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + elem;
-    const uint64_t p1 = ptx_a16(4 * (nw + 1));
+    const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P5a */
+    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(2 * (K + 1)) + elem;
+    const uint64_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
+    const uint64_t lists = ptx_a16(2 * (n + 1)) + ptx_a16(2 * l_len);
+    const uint64_t p1 = lists + ptx_a16(4 * (nw + 1));
     const uint64_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
-    const uint64_t p3 = ptx_a16(2 * (n + 1)) + ptx_a16(2 * (2 * n + 2)) + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
+    const uint64_t p3 = lists + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
     const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0;
     const uint64_t T4 = PTX_TILE_4, T1 = PTX_TILE_1;
     const uint64_t trees4 = ptx_overflow3(elem, 4 * 4 * 2 * T4, 4 * (T4 + 1), 8 * (T4 / 32 + 2));
     const uint64_t trees1 = n > T4 ? ptx_overflow3(elem, 4 * 2 * T1, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
     uint64_t tail = comments > trees4 ? comments : trees4;
     if (trees1 > tail) tail = trees1;
-    const uint64_t p5 = ptx_a16(8 * (nwe + 1)) + 3 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (K / 32 + 1)) + ptx_a16(4 * (nwe + 1)) + tail;
+    const uint64_t p5 = ptx_a16(8 * (nwe + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (nwe + 1)) + tail;
     uint64_t m = p1 > p3 ? p1 : p3;
     if (p5 > m) m = p5;
     return persist + m;
@@ -1043,7 +1005,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
     const uint32_t nw = (keyspace + 31) / 32;
     const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
-    /* element-side state: dead once the mark intervals are known (P2b), then reused as scratch of the tail phases */
+    uint16_t* mlist = ptx_alloc<uint16_t>(bp, K + 1); /* rows of the mark ops, grouped by type; [K] = spare slot */
+    /* element-side state: dead once the mark intervals are known (P5a), then reused as scratch of the tail phases */
     const uint32_t elem_lds = bp.off;
     ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
     uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1);         /* element -> op row */
@@ -1051,10 +1014,16 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     uint32_t* delbits = ptx_alloc<uint32_t>(bp, nwe + 1);      /* element -> tombstone */
     PTX_BAIL_CAPACITY();
     const uint32_t mark_lds = bp.off; /* everything above this mark is phase scratch */
+    /* scratch of P1..P3: rows of the inserts (later `srt`), then ONE array that is first the row list of the deletes
+     * (its tail), then the bucket work lists `seg` | `big`, then the Euler tour `L` */
+    uint16_t* ilist = ptx_alloc<uint16_t>(bp, n + 1);
+    const uint32_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
+    uint16_t* L = ptx_alloc<uint16_t>(bp, l_len);
+    uint16_t* dlist = L + n + 1; /* read until P3b; `seg` = L[0 .. n] is written meanwhile, `big` (same place as dlist) only after */
+    PTX_BAIL_CAPACITY();
+    const uint32_t tree_lds = bp.off;
 
-    /* ---- P1: first pass over the rows (op_id, action, mark_type): the id bitmaps — every elemId reference of the later passes
-     *      needs the COMPLETE index of the inserts — and the census check.  All three row passes (P1, P2a, P2b) stream their
-     *      columns coalesced, consecutive rows on consecutive lanes; no phase gathers through a row list ---- */
+    /* ---- P1: ONE pass over the rows: id bitmaps, row lists per class ---- */
     {
         uint32_t* allbits = ptx_alloc<uint32_t>(bp, nw + 1); /* every op id: duplicate detection */
         PTX_BAIL_CAPACITY();
@@ -1067,15 +1036,21 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_FOR(w, nwe + 1) delbits[w] = 0;
         PTX_LEADER {
-            for (int c = 0; c < 8; ++c) H->cur[c] = 0; /* rows per class (0 insert, 1 delete, 2..5 mark type 0..3), counted below */
+            /* list cursors (class 0 insert -> ilist, 1 delete -> dlist, 2..5 mark type 0..3 -> mlist) */
+            H->cur[0] = 0;
+            H->cur[1] = 0;
+            H->cur[2] = 0;
+            H->cur[3] = moff1;
+            H->cur[4] = moff2;
+            H->cur[5] = moff3;
+            H->cur[6] = H->cur[7] = 0;
             H->n_ins = n;
             H->n_applied = n + D + K;
         }
         PTX_SYNC();
         /* Branch-free row loop: every row does the same work; rows that are out of range, malformed or of no
-         * interest (makeList, NOP) are class 6/7 and OR 0 into the bitmaps. */
+         * interest (makeList, NOP) use class 6/7 = a spare cursor, the spare list slot and OR 0 into the bitmaps. */
         uint32_t badrow = 0xFFFFFFFFu; /* first malformed / duplicate row seen by this thread */
-        uint32_t c01 = 0, c23 = 0, c45 = 0; /* rows of this thread per class, 16 bits each (a thread sees < 65536 rows) */
         const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
         uint64_t id[PTX_U1];
         uint32_t a[PTX_U1], mt[PTX_U1];
@@ -1105,6 +1080,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #else
             PTX_P1_LOAD(g, id, a, mt)
 #endif
+            uint32_t cls[PTX_U1], slot[PTX_U1];
 #pragma unroll
             for (int u = 0; u < PTX_U1; ++u) {
                 const uint32_t i = g * PTX_U1 + (uint32_t)u;
@@ -1115,15 +1091,24 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 c = c == 2u ? (mt[u] < 4u ? 2u + mt[u] : 7u) : c;
                 const bool keybad = ctr - 1u >= ix.max_ctr || act > ix.max_actor; /* ctr == 0 or beyond the header's bounds */
                 badrow = in && (c == 7u || keybad) && i < badrow ? i : badrow;
-                c = (!in || keybad) ? 7u : c;
-                c01 += c < 2u ? 1u << (16u * c) : 0u;
-                c23 += (c & ~1u) == 2u ? 1u << (16u * (c & 1u)) : 0u;
-                c45 += (c & ~1u) == 4u ? 1u << (16u * (c & 1u)) : 0u;
-                const uint32_t key = c == 7u ? 0u : ctr * ix.na1 + act;
+                cls[u] = (!in || keybad) ? 7u : c;
+            }
+            ptx_wave_slots<PTX_U1>(H->cur, cls, slot);
+#pragma unroll
+            for (int u = 0; u < PTX_U1; ++u) {
+                const uint32_t i = g * PTX_U1 + (uint32_t)u;
+                const uint32_t c = cls[u];
+                const uint32_t key = c == 7u ? 0u : (uint32_t)(id[u] >> 32) * ix.na1 + (uint32_t)id[u];
                 const uint32_t bit = c == 7u ? 0u : 1u << (key & 31);
                 ptx_atomic_or(&allbits[key >> 5], bit); /* duplicates are counted after the pass (no return value needed here) */
                 ptx_atomic_or(&ix.ib[key >> 5].bits, c == 0u ? bit : 0u);
-                if (A.out_rank && in) A.out_rank[base + i] = 0xFFFFFFFFu; /* insert rows are overwritten in P5a */
+                /* rows that are listed nowhere (and slots beyond what the header promised) go to the spare slot of mlist */
+                uint16_t* lst = c == 0u ? ilist : c == 1u ? dlist : mlist;
+                const uint32_t cap = c == 0u ? n : c == 1u ? D : K;
+                const bool listed = c < 6u && slot[u] < cap;
+                const uint32_t sl = listed ? slot[u] : (c == 0u ? n : c == 1u ? D : K);
+                lst[sl] = (uint16_t)i;
+                if (A.out_rank && i < N) A.out_rank[base + i] = 0xFFFFFFFFu; /* insert rows are overwritten in P5a */
             }
 #if PTX_P1_PREFETCH
 #pragma unroll
@@ -1135,17 +1120,17 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #endif
         }
 #undef PTX_P1_LOAD
-        if (badrow != 0xFFFFFFFFu) ptx_raise(H, badrow, 1, PTX_ERR_BAD_OP);
-        ptx_reduce_add32(&H->cur[0], c01 & 0xFFFFu);
-        ptx_reduce_add32(&H->cur[1], c01 >> 16);
-        ptx_reduce_add32(&H->cur[2], c23 & 0xFFFFu);
-        ptx_reduce_add32(&H->cur[3], c23 >> 16);
-        ptx_reduce_add32(&H->cur[4], c45 & 0xFFFFu);
-        ptx_reduce_add32(&H->cur[5], c45 >> 16);
+        if (badrow != 0xFFFFFFFFu) {
+            /* which of the two: re-test the row */
+            const uint64_t id = op_id[badrow];
+            const uint32_t ctr = (uint32_t)(id >> 32), act = (uint32_t)id, a = action[badrow], mt = mark_type[badrow];
+            (void)id; (void)ctr; (void)act; (void)a; (void)mt;
+            ptx_raise(H, badrow, 1, PTX_ERR_BAD_OP);
+        }
         PTX_SYNC();
         PTX_LEADER {
             /* the header must be the exact census of the rows */
-            if (H->cur[0] != n || H->cur[1] != D || H->cur[2] != moff1 || H->cur[3] != moff2 - moff1 || H->cur[4] != moff3 - moff2 || H->cur[5] != K - moff3)
+            if (H->cur[0] != n || H->cur[1] != D || H->cur[2] != moff1 || H->cur[3] != moff2 || H->cur[4] != moff3 || H->cur[5] != K)
                 ptx_raise(H, 0, 0, PTX_ERR_BAD_OP);
         }
         {
@@ -1154,7 +1139,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
                 distinct += ptx_popc(allbits[w]);
             }
-            ptx_reduce_add32(&H->cur[6], distinct);
+            ptx_atomic_add(&H->cur[6], distinct); /* cur[6] (the cursor of unlisted rows) is free again */
         }
         PTX_SYNC();
         if (H->err == PTX_NO_ERR && H->cur[6] != N) {
@@ -1175,16 +1160,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp, A.div_magic);
     }
     PTX_BAIL_IF_ERROR();
-    bp.off = mark_lds;
+    bp.off = tree_lds;
     PTX_STAMP(2);
 
     /* ---- P3: causal tree of the inserts -> document position of every element ---- */
     {
-        uint16_t* srt = ptx_alloc<uint16_t>(bp, n + 1); /* children of every parent, descending opId, parents ascending */
-        /* ONE array that is first the earliest delete row per element (32-bit words), then the bucket work lists `seg` | `big`,
-         * then the Euler tour `L` */
-        uint16_t* L = ptx_alloc<uint16_t>(bp, 2 * n + 2);
-        uint32_t* dmin = (uint32_t*)L; /* [n] */
         /* children per parent -> bucket starts -> bucket ends; 16-bit counters, two per atomically updated word */
         uint32_t* cntw = ptx_alloc<uint32_t>(bp, (n + 2 + 1) / 2 + 1);
         uint16_t* cnt = (uint16_t*)cntw;
@@ -1194,77 +1174,60 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PtxBitWord* hb = (PtxBitWord*)R;
         uint16_t* huge = ptx_alloc<uint16_t>(bp, n / PTX_HUGE_BUCKET + 2); /* parents with more than PTX_HUGE_BUCKET children */
         PTX_BAIL_CAPACITY();
+        uint16_t* srt = ilist;       /* children of every parent, descending opId, parents ascending (ilist is dead after P3a) */
         uint16_t* seg = L;           /* bucket members in arrival order (dead before L is built) */
         uint16_t* big = seg + n + 1; /* positions in seg of the members of large buckets */
 
         PTX_FOR(p, (n + 2 + 1) / 2 + 1) cntw[p] = 0;
-        PTX_FOR(t, n) dmin[t] = 0xFFFFFFFFu;
         PTX_SYNC();
-        /* ---- P2a: second pass over the rows (op_id, ref_a, action): inserts -> element index, row, parent, child count;
-         *      deletes -> tombstone bit + earliest delete row of the element ---- */
+        /* P3a: element index of every insert, its parent, children counts */
         {
-            const uint32_t p2_groups = (N + PTX_U1 - 1u) / PTX_U1, p2_steps = PTX_STEPS(p2_groups);
-            uint64_t id[PTX_U1], ra[PTX_U1], id_n[PTX_U1], ra_n[PTX_U1];
-            uint32_t a[PTX_U1], a_n[PTX_U1];
-#define PTX_P2_LOAD(g_, id_, ra_, a_)                                    \
-    _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {                  \
-        const uint32_t r_ = (g_) * PTX_U1 + (uint32_t)u;                  \
-        const uint32_t i_ = r_ < N ? r_ : N - 1u;                        \
-        id_[u] = op_id[i_];                                              \
-        ra_[u] = ref_a[i_];                                              \
-        a_[u] = action[i_];                                              \
+            const uint32_t steps = PTX_JSTEPS(n);
+            uint32_t i[PTX_U], i_n[PTX_U];
+            uint64_t id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U];
+            /* rows of this thread's inserts of a step (list read, then the two column gathers) */
+#define PTX_P3A_LOAD(st_, i_, id_, ra_)                                     \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        const uint32_t j_ = PTX_J_OF(st_, u);                               \
+        const uint32_t r_ = ilist[j_ < n ? PTX_JX(j_, n) : 0u];             \
+        i_[u] = r_ < N ? r_ : N - 1u;                                       \
+    }                                                                       \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        id_[u] = op_id[i_[u]];                                              \
+        ra_[u] = ref_a[i_[u]];                                              \
     }
-            PTX_P2_LOAD(PTX_G_OF(0u, p2_steps), id, ra, a)
+            PTX_P3A_LOAD(0u, i, id, ra)
 #pragma nounroll
-            for (uint32_t st = 0; st < p2_steps; ++st) {
-                const uint32_t g = PTX_G_OF(st, p2_steps);
-                if (PTX_WAVE_FIRST(g) >= p2_groups) continue; /* this wave has no row left in this step (wave-uniform) */
-                PTX_P2_LOAD(PTX_G_OF(st + 1u, p2_steps), id_n, ra_n, a_n) /* in flight while this step is processed */
+            for (uint32_t st = 0; st < steps; ++st) {
+                PTX_P3A_LOAD(st + 1u, i_n, id_n, ra_n) /* in flight while this step is processed */
 #pragma unroll
-                for (int u = 0; u < PTX_U1; ++u) {
-                    const uint32_t i = g * PTX_U1 + (uint32_t)u;
-                    if (i < N && a[u] == PTX_ACT_INSERT) {
+                for (int u = 0; u < PTX_U; ++u)
+                    if (PTX_J_OF(st, u) < n) {
                         uint32_t key = 0;
                         ptx_id_key(ix, id[u], key);
                         const uint32_t e = ptx_bitrank(ix.ib, key);
-                        row_of[e] = (uint16_t)i;
+                        row_of[e] = (uint16_t)i[u];
                         uint32_t pe = n;
                         if (ra[u] != 0) {
                             const int p = ptx_elem_lookup(ix, ra[u]);
-                            if (p < 0) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND); /* micromerge.ts:752 */
+                            if (p < 0) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND); /* micromerge.ts:752 */
                             else pe = (uint32_t)p;
                         }
                         par[e] = (uint16_t)pe;
                         ptx_atomic_add(&cntw[pe >> 1], 1u << (16u * (pe & 1u)));
-                    } else if (i < N && a[u] == PTX_ACT_DELETE) {
-                        /* the element must exist when the delete is applied (micromerge.ts:752; checked against its row once every
-                         * row is known); deleting twice is fine (:693) */
-                        const int t = ptx_elem_lookup(ix, ra[u]);
-                        if (t < 0) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND);
-                        else {
-                            ptx_atomic_or(&delbits[t >> 5], 1u << ((uint32_t)t & 31u));
-                            ptx_atomic_min(&dmin[t], i);
-                        }
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < PTX_U1; ++u) {
+                for (int u = 0; u < PTX_U; ++u) {
+                    i[u] = i_n[u];
                     id[u] = id_n[u];
                     ra[u] = ra_n[u];
-                    a[u] = a_n[u];
                 }
             }
-#undef PTX_P2_LOAD
+#undef PTX_P3A_LOAD
         }
         PTX_BAIL_IF_ERROR();
-        /* application-order checks now that row_of is complete: an element must already exist when an op names it */
-        PTX_FOR(t, n) {
-            const uint32_t d = dmin[t];
-            if (d != 0xFFFFFFFFu && (uint32_t)row_of[t] >= d) ptx_raise(H, d, 1, PTX_ERR_ELEM_NOT_FOUND); /* its earliest delete fails first */
-        }
-        PTX_SYNC(); /* dmin is dead: `seg` takes its place */
         ptx_scan_excl<uint16_t, 1, kThreads>(cnt, n + 2, H->scan_tmp, A.div_magic); /* cnt[p] = first slot of p's children */
-        /* P3b: scatter into the parent buckets */
+        /* P3b: scatter into the parent buckets; tombstone flags; application-order checks now that row_of is complete */
         PTX_FORU(e0, n) {
             uint32_t pe[PTX_U], re[PTX_U], rp[PTX_U];
 #pragma unroll
@@ -1284,6 +1247,37 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     /* now cnt[p] = END of p's bucket (no carry between the halves: a counter never exceeds n < 32767) */
                     seg[(ptx_atomic_add(&cntw[pe[u] >> 1], 1u << (16u * (pe[u] & 1u))) >> (16u * (pe[u] & 1u))) & 0xFFFFu] = (uint16_t)PTX_IX(e0, u);
                 }
+        }
+        {
+            const uint32_t steps = PTX_JSTEPS(D);
+            uint32_t i[PTX_U], i_n[PTX_U];
+            uint64_t ra[PTX_U], ra_n[PTX_U];
+#define PTX_DEL_LOAD(st_, i_, ra_)                                          \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        const uint32_t j_ = PTX_J_OF(st_, u);                               \
+        const uint32_t r_ = dlist[j_ < D ? PTX_JX(j_, D) : 0u];             \
+        i_[u] = r_ < N ? r_ : N - 1u;                                       \
+    }                                                                       \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) ra_[u] = ref_a[i_[u]];
+            PTX_DEL_LOAD(0u, i, ra)
+#pragma nounroll
+            for (uint32_t st = 0; st < steps; ++st) {
+                PTX_DEL_LOAD(st + 1u, i_n, ra_n)
+#pragma unroll
+                for (int u = 0; u < PTX_U; ++u)
+                    if (PTX_J_OF(st, u) < D) {
+                        /* the element must exist when the delete is applied (micromerge.ts:752); deleting twice is fine (:693) */
+                        const int t = ptx_elem_lookup(ix, ra[u]);
+                        if (t < 0 || row_of[t] >= i[u]) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);
+                        else ptx_atomic_or(&delbits[t >> 5], 1u << ((uint32_t)t & 31u));
+                    }
+#pragma unroll
+                for (int u = 0; u < PTX_U; ++u) {
+                    i[u] = i_n[u];
+                    ra[u] = ra_n[u];
+                }
+            }
+#undef PTX_DEL_LOAD
         }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(3);
@@ -1418,11 +1412,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = nwe; /* bit positions 0..n by document position */
     PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
-    uint16_t* mlist = ptx_alloc<uint16_t>(bp, K + 1);           /* rows of the mark ops, grouped by type; [K] = spare slot */
-    uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);          /* their visible intervals [lo, hi) */
+    uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
     uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
-    uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);            /* comment mark -> doc-local comment id */
-    uint32_t* maddbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 1); /* mark op is an addMark */
+    uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);    /* comment mark -> doc-local comment id */
     uint32_t* brkbits = ptx_alloc<uint32_t>(bp, nwe + 1); /* visible positions where a comment interval starts/ends */
     PTX_BAIL_CAPACITY();
     PTX_FOR(w, nwv + 1) {
@@ -1431,14 +1423,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         z.pre = 0;
         alive[w] = z;
         brkbits[w] = 0;
-    }
-    PTX_FOR(w, (K >> 5) + 1) maddbits[w] = 0;
-    PTX_LEADER {
-        /* list cursors of the mark ops, grouped by type: type t owns mlist[moff_t .. moff_{t+1}) */
-        H->cur[0] = 0;
-        H->cur[1] = moff1;
-        H->cur[2] = moff2;
-        H->cur[3] = moff3;
     }
     PTX_SYNC();
     PTX_FOR(e, n) {
@@ -1484,56 +1468,47 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         ptx_digest_flush(H, h1, h2);
     }
-    /* ---- P2b: third pass over the rows (ref_a, ref_b, payload, action, mark_type, side_a, side_b): every mark op -> list slot (row
-     *      order within the wave), visible interval [lo, hi) from its boundary slots 2 * rank + side, add/remove flag, comment id ---- */
     {
-        const uint32_t p2_groups = (N + PTX_U2 - 1u) / PTX_U2, p2_steps = PTX_STEPS(p2_groups);
-        uint64_t ra[PTX_U2], rb[PTX_U2], ra_n[PTX_U2], rb_n[PTX_U2];
-        uint32_t pl[PTX_U2], ab[PTX_U2], pl_n[PTX_U2], ab_n[PTX_U2]; /* ab = action | mark_type << 8 | side_a << 16 | side_b << 24 */
-#define PTX_P2_LOAD(g_, ra_, rb_, pl_, ab_)                                                   \
-    _Pragma("unroll") for (int u = 0; u < PTX_U2; ++u) {                                       \
-        const uint32_t r_ = (g_) * PTX_U2 + (uint32_t)u;                                       \
-        const uint32_t i_ = r_ < N ? r_ : N - 1u;                                             \
-        ra_[u] = ref_a[i_];                                                                   \
-        rb_[u] = ref_b[i_];                                                                   \
-        pl_[u] = payload[i_];                                                                 \
-        ab_[u] = (uint32_t)action[i_] | ((uint32_t)mark_type[i_] << 8) | ((uint32_t)A.side_a[base + i_] << 16) | ((uint32_t)A.side_b[base + i_] << 24); \
+    const uint32_t m_steps = PTX_JSTEPS_U(K, PTX_UM);
+    uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
+    uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
+    /* rows of this thread's mark ops of a step (list read, then the five column gathers) */
+#define PTX_MARK_LOAD(st_, i_, ra_, rb_, sa_, sb_, pl_)                     \
+    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {                     \
+        const uint32_t j_ = PTX_J_OF_U(st_, u, PTX_UM);                               \
+        const uint32_t r_ = mlist[j_ < K ? PTX_JX(j_, K) : 0u];             \
+        i_[u] = r_ < N ? r_ : N - 1u;                                       \
+    }                                                                       \
+    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {                     \
+        ra_[u] = ref_a[i_[u]];                                              \
+        rb_[u] = ref_b[i_[u]];                                              \
+        sa_[u] = A.side_a[base + i_[u]];                                    \
+        sb_[u] = A.side_b[base + i_[u]];                                    \
+        pl_[u] = payload[i_[u]];                                            \
     }
-        PTX_P2_LOAD(PTX_G_OF(0u, p2_steps), ra, rb, pl, ab)
+    PTX_MARK_LOAD(0u, i, ra, rb, sa, sb, pl)
 #pragma nounroll
-        for (uint32_t st = 0; st < p2_steps; ++st) {
-            const uint32_t g = PTX_G_OF(st, p2_steps);
-            if (PTX_WAVE_FIRST(g) >= p2_groups) continue; /* this wave has no row left in this step (wave-uniform) */
-            PTX_P2_LOAD(PTX_G_OF(st + 1u, p2_steps), ra_n, rb_n, pl_n, ab_n) /* in flight while this step is processed */
-            uint32_t mcls[PTX_U2], slot[PTX_U2];
+    for (uint32_t st = 0; st < m_steps; ++st) {
+        PTX_MARK_LOAD(st + 1u, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* in flight while this step is processed */
 #pragma unroll
-            for (int u = 0; u < PTX_U2; ++u) {
-                const uint32_t i = g * PTX_U2 + (uint32_t)u;
-                const uint32_t a = ab[u] & 0xFFu, mt = (ab[u] >> 8) & 0xFFu;
-                mcls[u] = i < N && (a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) && mt < 4u ? mt : 7u;
-            }
-            ptx_wave_slots4<PTX_U2>(H->cur, mcls, slot);
-#pragma unroll
-            for (int u = 0; u < PTX_U2; ++u) {
-                if (mcls[u] >= 4u) continue;
-                const uint32_t i = g * PTX_U2 + (uint32_t)u;
-                const uint32_t sa = (ab[u] >> 16) & 0xFFu, sb = ab[u] >> 24;
-                const uint32_t k = slot[u] < K ? slot[u] : K; /* the census was verified: always a real slot */
+        for (int u = 0; u < (int)PTX_UM; ++u)
+            if (PTX_J_OF_U(st, u, PTX_UM) < K) {
+                const uint32_t k = PTX_JX(PTX_J_OF_U(st, u, PTX_UM), K);
                 uint32_t lo = 0, hi = 0;
                 /* start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is
                    not in the list when the op is applied means the op never starts */
                 int js = -1;
-                if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
+                if (sa[u] == PTX_SIDE_BEFORE || sa[u] == PTX_SIDE_AFTER) {
                     js = ptx_elem_lookup(ix, ra[u]);
-                    if (js >= 0 && row_of[js] >= i) js = -1;
+                    if (js >= 0 && row_of[js] >= i[u]) js = -1;
                 }
                 if (js >= 0) {
-                    const uint32_t slot_a = 2u * rnk[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
+                    const uint32_t slot_a = 2u * rnk[js] + (sa[u] == PTX_SIDE_AFTER ? 1u : 0u);
                     uint32_t slot_b = 0xFFFFFFFFu; /* never reached: runs to the end of the text */
-                    if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
+                    if (sb[u] == PTX_SIDE_BEFORE || sb[u] == PTX_SIDE_AFTER) {
                         int je = ptx_elem_lookup(ix, rb[u]);
-                        if (je >= 0 && row_of[je] >= i) je = -1;
-                        if (je >= 0) slot_b = 2u * rnk[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
+                        if (je >= 0 && row_of[je] >= i[u]) je = -1;
+                        if (je >= 0) slot_b = 2u * rnk[je] + (sb[u] == PTX_SIDE_AFTER ? 1u : 0u);
                     }
                     /* same slot: the start test fires first and the end is never seen */
                     if (slot_b == slot_a) slot_b = 0xFFFFFFFFu;
@@ -1544,24 +1519,24 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         hi = ptx_bitrank(alive, hi_rank);
                     }
                 }
-                mlist[k] = (uint16_t)i;
                 mrk_lo[k] = (uint16_t)lo;
                 mrk_hi[k] = (uint16_t)hi;
-                if ((ab[u] & 0xFFu) == PTX_ACT_ADDMARK) ptx_atomic_or(&maddbits[k >> 5], 1u << (k & 31u));
-                if (mcls[u] == PTX_MARK_COMMENT) {
-                    if (pl[u] >= Kid) ptx_raise(H, i, 1, PTX_ERR_BAD_OP); /* beyond the id space the header declares */
+                if (k >= moff2 && k < moff3) {
+                    if (pl[u] >= Kid) ptx_raise(H, i[u], 1, PTX_ERR_BAD_OP); /* beyond the id space the header declares */
                     cid[k - moff2] = (uint16_t)(pl[u] < Kid ? pl[u] : 0u);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < PTX_U2; ++u) {
-                ra[u] = ra_n[u];
-                rb[u] = rb_n[u];
-                pl[u] = pl_n[u];
-                ab[u] = ab_n[u];
-            }
+        for (int u = 0; u < (int)PTX_UM; ++u) {
+            i[u] = i_n[u];
+            ra[u] = ra_n[u];
+            rb[u] = rb_n[u];
+            sa[u] = sa_n[u];
+            sb[u] = sb_n[u];
+            pl[u] = pl_n[u];
         }
-#undef PTX_P2_LOAD
+    }
+#undef PTX_MARK_LOAD
     }
     PTX_BAIL_IF_ERROR();
     if (H->adm != PTX_NO_ERR) { /* no op-level error anywhere: the failed admission is the log's error */
@@ -1606,7 +1581,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 e.lo = mrk_lo[k];
                 e.hi = mrk_hi[k];
                 e.t = mlist[k]; /* application index = row in the log */
-                e.add = ptx_bittest(maddbits, k) ? 1 : 0;
+                e.add = action[mlist[k]] == PTX_ACT_ADDMARK ? 1 : 0; /* re-read: few marks still cover a visible char */
                 cent[pos] = e;
             }
         }
@@ -1701,7 +1676,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         if (ty == PTX_MARK_COMMENT) at |= PTX_ATTR_COMMENT;
                         else {
                             const uint32_t k = w & kmask;
-                            if (ptx_bittest(maddbits, k)) {
+                            if (action[mlist[k]] == PTX_ACT_ADDMARK) {
                                 if (ty == PTX_MARK_STRONG) at |= PTX_ATTR_STRONG;
                                 else if (ty == PTX_MARK_EM) at |= PTX_ATTR_EM;
                                 else at |= PTX_ATTR_LINK | (payload[mlist[k]] & PTX_ATTR_ID_MASK);
