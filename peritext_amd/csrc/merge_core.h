@@ -64,6 +64,7 @@ PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p =
 PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+PTX_DEV void ptx_atomic_or64(unsigned long long* p, unsigned long long v) { *p |= v; }
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
 /* append to a list: index of this element (valid only where pred) */
 PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }
@@ -89,6 +90,7 @@ PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v
 PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
+PTX_DEV void ptx_atomic_or64(unsigned long long* p, unsigned long long v) { (void)atomicOr(p, v); }
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__popc(x); }
 /* wave-aggregated append: ONE LDS atomic per wave, lanes get consecutive slots.  May be called in
  * divergent control flow (the ballot covers the active lanes only). */
@@ -198,7 +200,7 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #define PTX_U1 3 /* consecutive rows per thread and step in the row pass P1 (measured: 2 -> 14.6, 3 -> 14.2, 4 -> 17 us per 4K-op log) */
 #endif
 #ifndef PTX_P1_PREFETCH
-#define PTX_P1_PREFETCH 1 /* 1: double-buffer the row loads of P1 (costs PTX_U1 * 4 VGPRs) */
+#define PTX_P1_PREFETCH 1 /* row loads of P1: 1 = one step ahead (costs PTX_U1 * 4 VGPRs), 2 = two steps ahead (twice that) */
 #endif
 /* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
  * emulation plays three one-lane waves in turn */
@@ -503,10 +505,10 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     (void)N;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
     const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P5a */
-    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(2 * (K + 1)) + elem;
+    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(2 * (K + 1)) + ptx_a16(4 * (K / 32 + 1)) + elem;
     const uint64_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
     const uint64_t lists = ptx_a16(2 * (n + 1)) + ptx_a16(2 * l_len);
-    const uint64_t p1 = lists + ptx_a16(4 * (nw + 1));
+    const uint64_t p1 = lists;
     const uint64_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
     const uint64_t p3 = lists + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
     const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0;
@@ -1006,6 +1008,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     const uint32_t nw = (keyspace + 31) / 32;
     const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
     uint16_t* mlist = ptx_alloc<uint16_t>(bp, K + 1); /* rows of the mark ops, grouped by type; [K] = spare slot */
+    uint32_t* maddbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 1); /* mark op k is an addMark (the tail phases need no look back at `action`) */
     /* element-side state: dead once the mark intervals are known (P5a), then reused as scratch of the tail phases */
     const uint32_t elem_lds = bp.off;
     ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
@@ -1025,16 +1028,15 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
     /* ---- P1: ONE pass over the rows: id bitmaps, row lists per class ---- */
     {
-        uint32_t* allbits = ptx_alloc<uint32_t>(bp, nw + 1); /* every op id: duplicate detection */
-        PTX_BAIL_CAPACITY();
+        /* during this pass ib[w] = {ids of the inserts, ids of ALL ops (duplicate detection)}: one 8-byte LDS atomic per row */
         PTX_FOR(w, nw + 1) {
             PtxBitWord z;
             z.bits = 0;
             z.pre = 0;
             ix.ib[w] = z;
-            allbits[w] = 0;
         }
         PTX_FOR(w, nwe + 1) delbits[w] = 0;
+        PTX_FOR(w, (K >> 5) + 1) maddbits[w] = 0;
         PTX_LEADER {
             /* list cursors (class 0 insert -> ilist, 1 delete -> dlist, 2..5 mark type 0..3 -> mlist) */
             H->cur[0] = 0;
@@ -1058,6 +1060,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         uint64_t id_n[PTX_U1];
         uint32_t a_n[PTX_U1], mt_n[PTX_U1];
 #endif
+#if PTX_P1_PREFETCH > 1
+        uint64_t id_m[PTX_U1]; /* the step in between */
+        uint32_t a_m[PTX_U1], mt_m[PTX_U1];
+#endif
         /* this thread's PTX_U1 consecutive rows of a step; indices past the end are clamped, their effects masked */
 #define PTX_P1_LOAD(g_, id_, a_, mt_)                                   \
     _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {                 \
@@ -1070,13 +1076,16 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #if PTX_P1_PREFETCH
         PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a, mt)
 #endif
+#if PTX_P1_PREFETCH > 1
+        PTX_P1_LOAD(PTX_G_OF(1u, p1_steps), id_m, a_m, mt_m)
+#endif
 #pragma nounroll
         for (uint32_t st = 0; st < p1_steps; ++st) {
             const uint32_t g = PTX_G_OF(st, p1_steps);
             if (PTX_WAVE_FIRST(g) >= p1_groups) continue; /* this wave has no row left in this step (wave-uniform) */
 #if PTX_P1_PREFETCH
-            const uint32_t gn = PTX_G_OF(st + 1u, p1_steps);
-            PTX_P1_LOAD(gn, id_n, a_n, mt_n) /* next step's rows are in flight while this step is processed */
+            const uint32_t gn = PTX_G_OF(st + (uint32_t)PTX_P1_PREFETCH, p1_steps);
+            PTX_P1_LOAD(gn, id_n, a_n, mt_n) /* later steps' rows are in flight while this step is processed */
 #else
             PTX_P1_LOAD(g, id, a, mt)
 #endif
@@ -1100,17 +1109,28 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 const uint32_t c = cls[u];
                 const uint32_t key = c == 7u ? 0u : (uint32_t)(id[u] >> 32) * ix.na1 + (uint32_t)id[u];
                 const uint32_t bit = c == 7u ? 0u : 1u << (key & 31);
-                ptx_atomic_or(&allbits[key >> 5], bit); /* duplicates are counted after the pass (no return value needed here) */
-                ptx_atomic_or(&ix.ib[key >> 5].bits, c == 0u ? bit : 0u);
+                /* duplicates are counted after the pass (no return value needed here); rows without a usable id touch nothing */
+                if (bit) ptx_atomic_or64((unsigned long long*)&ix.ib[key >> 5], (unsigned long long)(c == 0u ? bit : 0u) | ((unsigned long long)bit << 32));
                 /* rows that are listed nowhere (and slots beyond what the header promised) go to the spare slot of mlist */
                 uint16_t* lst = c == 0u ? ilist : c == 1u ? dlist : mlist;
                 const uint32_t cap = c == 0u ? n : c == 1u ? D : K;
                 const bool listed = c < 6u && slot[u] < cap;
                 const uint32_t sl = listed ? slot[u] : (c == 0u ? n : c == 1u ? D : K);
                 lst[sl] = (uint16_t)i;
+                if (listed && c >= 2u && a[u] == PTX_ACT_ADDMARK) ptx_atomic_or(&maddbits[sl >> 5], 1u << (sl & 31u));
                 if (A.out_rank && i < N) A.out_rank[base + i] = 0xFFFFFFFFu; /* insert rows are overwritten in P5a */
             }
-#if PTX_P1_PREFETCH
+#if PTX_P1_PREFETCH > 1
+#pragma unroll
+            for (int u = 0; u < PTX_U1; ++u) {
+                id[u] = id_m[u];
+                a[u] = a_m[u];
+                mt[u] = mt_m[u];
+                id_m[u] = id_n[u];
+                a_m[u] = a_n[u];
+                mt_m[u] = mt_n[u];
+            }
+#elif PTX_P1_PREFETCH
 #pragma unroll
             for (int u = 0; u < PTX_U1; ++u) {
                 id[u] = id_n[u];
@@ -1135,10 +1155,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         {
             uint32_t distinct = 0;
-            PTX_FOR(w, nw + 1) {
-                ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
-                distinct += ptx_popc(allbits[w]);
-            }
+            PTX_FOR(w, nw + 1) distinct += ptx_popc(ix.ib[w].pre);
             ptx_atomic_add(&H->cur[6], distinct); /* cur[6] (the cursor of unlisted rows) is free again */
         }
         PTX_SYNC();
@@ -1146,16 +1163,18 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             /* some opId occurs twice (every row had a well-formed id, so N distinct ids were expected): find the
              * first repeated row with a second, returning pass over a cleared bitmap — the rare path */
             PTX_SYNC();
-            PTX_FOR(w, nw + 1) allbits[w] = 0;
+            PTX_FOR(w, nw + 1) ix.ib[w].pre = 0;
             PTX_SYNC();
             PTX_FOR(i, N) {
                 uint32_t key = 0;
                 ptx_id_key(ix, op_id[i], key);
                 const uint32_t bit = 1u << (key & 31);
-                if (ptx_atomic_or(&allbits[key >> 5], bit) & bit) ptx_raise(H, i, 1, PTX_ERR_DUPLICATE_OP);
+                if (ptx_atomic_or(&ix.ib[key >> 5].pre, bit) & bit) ptx_raise(H, i, 1, PTX_ERR_DUPLICATE_OP);
             }
             /* (which of two equal ids is "the repeat" depends on the race; the status is what is reported) */
         }
+        PTX_SYNC();
+        PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
         PTX_SYNC();
         ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp, A.div_magic);
     }
@@ -1581,7 +1600,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 e.lo = mrk_lo[k];
                 e.hi = mrk_hi[k];
                 e.t = mlist[k]; /* application index = row in the log */
-                e.add = action[mlist[k]] == PTX_ACT_ADDMARK ? 1 : 0; /* re-read: few marks still cover a visible char */
+                e.add = ptx_bittest(maddbits, k) ? 1 : 0;
                 cent[pos] = e;
             }
         }
@@ -1676,7 +1695,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         if (ty == PTX_MARK_COMMENT) at |= PTX_ATTR_COMMENT;
                         else {
                             const uint32_t k = w & kmask;
-                            if (action[mlist[k]] == PTX_ACT_ADDMARK) {
+                            if (ptx_bittest(maddbits, k)) {
                                 if (ty == PTX_MARK_STRONG) at |= PTX_ATTR_STRONG;
                                 else if (ty == PTX_MARK_EM) at |= PTX_ATTR_EM;
                                 else at |= PTX_ATTR_LINK | (payload[mlist[k]] & PTX_ATTR_ID_MASK);
