@@ -105,10 +105,11 @@ def batch_struct(b):
     s.mark_type = ptr(b.mark_type, abi.u8p)
     s.side_a = ptr(b.side_a, abi.u8p)
     s.side_b = ptr(b.side_b, abi.u8p)
-    s.chg_off = ptr(b.chg_off, abi.u64p)
-    s.chg_hdr = ptr(b.chg_hdr, abi.u32p)
-    s.chg_env = ptr(b.chg_env, abi.u16p)
-    s.max_actors = b.max_actors
+    if b.chg_off is not None:  # a batch without the Change envelope: NULL = no admission
+        s.chg_off = ptr(b.chg_off, abi.u64p)
+        s.chg_hdr = ptr(b.chg_hdr, abi.u32p)
+        s.chg_env = ptr(b.chg_env, abi.u16p)
+        s.max_actors = b.max_actors
     if b.log_hdr is not None and len(b.log_hdr):
         s.log_hdr = b.log_hdr.ctypes.data_as(C.POINTER(abi.ptx_log_hdr))
     return s
