@@ -212,6 +212,8 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v) { return v; }
 PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return incl; }
 PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return v; }
+PTX_DEV uint32_t ptx_wave_min(uint32_t v) { return v; }
+PTX_DEV uint32_t ptx_wave_max(uint32_t v) { return v; }
 #else
 #define PTX_WAVE_FIRST(g) ((g) - (threadIdx.x & 63u)) /* index handled by lane 0 of this wave */
 #define PTX_WS 64u
@@ -219,6 +221,20 @@ PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return v; }
 #define PTX_FOR_WAVE(w, lane) for (uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, _once = 1; _once; _once = 0)
 PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
 PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl_scan(v)); }
+PTX_DEV uint32_t ptx_wave_min(uint32_t v) { /* the same value in every lane */
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+PTX_DEV uint32_t ptx_wave_max(uint32_t v) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
 #endif
 #ifdef PTX_EMU
 #define PTX_NTHREADS 5u /* the emulation splits per-thread runs five ways so that the run/prefix logic is exercised */
@@ -525,7 +541,7 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
 /* the same from a log header */
 /* P0 scratch on top of the header: per-actor table starts + the (actor, seq) -> change table */
 PTX_HD uint64_t ptx_lds_need_admission(uint64_t n_changes, uint64_t max_actors) {
-    if (max_actors <= 3) return ptx_a16(sizeof(PtxHdr)) + 2 * ptx_a16(4 * (1024 / 64 + 2)); /* the carried vector clock: per-wave totals */
+    if (max_actors <= 3) return ptx_a16(sizeof(PtxHdr)) + 2 * ptx_a16(4 * (1024 / 64 + 2)) + ptx_a16(4 * 12 * (1024 / 64 + 1)); /* per-wave clock totals and check records */
     return ptx_a16(sizeof(PtxHdr)) + ptx_a16(4 * (max_actors + 2)) + ptx_a16(2 * (n_changes + 1));
 }
 PTX_HD uint64_t ptx_lds_need_hdr(uint64_t N, const ptx_log_hdr& h) {
@@ -765,8 +781,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
              * contiguous segment of the changes and walks it 64 * PTX_AC changes at a time, PTX_AC consecutive changes per
              * lane, read with 16-byte loads (4 headers / 2 envelope rows each); inside a step the clock before each change
              * is a DPP prefix sum of one-hot counts, 16 bits per actor (actors 0,1 in one word, 2,3 in the other); the
-             * clock before a wave's segment is the sum of the earlier waves' totals (pass A: headers only).  seq ==
-             * clock[actor] + 1 and deps[b] <= clock[b] (micromerge.ts:501-509) are then plain compares (pass B). */
+             * clock before a wave's segment is the sum of the earlier waves' totals.  seq == clock[actor] + 1 and
+             * deps[b] <= clock[b] (micromerge.ts:501-509) are then plain compares. */
             uint32_t* wt01 = ptx_alloc<uint32_t>(bp, PTX_MAX_THREADS / 64 + 2);
             uint32_t* wt23 = ptx_alloc<uint32_t>(bp, PTX_MAX_THREADS / 64 + 2);
             PTX_BAIL_CAPACITY();
@@ -798,51 +814,17 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             _Pragma("unroll") for (uint32_t b_ = 0; b_ < 4u; ++b_) dst_[u_][b_] = q_.v[u_][b_]; \
     }
 #endif
-            /* pass A: per-wave totals of changes per actor, rows per log, actor range */
+            /* FAST CHECK, one pass: every wave walks its segment with clocks RELATIVE to the segment's start (the loads of the next
+             * step in flight), and keeps per actor a the range [emin, emax] of  seq - 1 - relative clock  over its changes (all must
+             * equal the clock B[a] before the segment) and per actor b the maximum of  deps[b] - relative clock[b]  (must not exceed
+             * B[b]).  B is only known once every wave has counted its segment: the few per-wave numbers are validated after the
+             * pass.  A log that fails (rare) is walked again by the exact two-pass code below, which names the first failing change. */
+            uint32_t* wrec = ptx_alloc<uint32_t>(bp, (PTX_MAX_THREADS / 64 + 1) * 12u);
+            PTX_BAIL_CAPACITY();
             PTX_FOR_WAVE(w, lane) {
                 const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
-                uint32_t t01 = 0, t23 = 0, rows = 0, badc = 0xFFFFFFFFu;
-#pragma unroll 2
-                for (uint32_t cb = lo; cb < hi; cb += step) {
-                    uint32_t h[PTX_AC];
-                    const uint32_t cl = cb + lane * PTX_AC;
-                    PTX_ADM_HDRS(h, cl < hi ? cl : hi - 1u)
-#pragma unroll
-                    for (uint32_t u = 0; u < PTX_AC; ++u) {
-                        const bool in = cl + u < hi;
-                        const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
-                        rows += in ? h[u] & PTX_CHG_NOPS : 0u;
-                        if (in && a >= na) badc = cl + u < badc ? cl + u : badc;
-                        t01 += in && a < 2u ? 1u << (16u * a) : 0u;
-                        t23 += in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
-                    }
-                }
-                t01 = ptx_wave_total(t01);
-                t23 = ptx_wave_total(t23);
-                if (lane == 0u) {
-                    wt01[w] = t01;
-                    wt23[w] = t23;
-                }
-                ptx_reduce_add32(&H->cur[7], rows);
-                if (badc != 0xFFFFFFFFu) {
-                    uint32_t row;
-                    PTX_CHANGE_ROW(badc, row);
-                    ptx_atomic_min(&H->adm, ((row * 2u) << 4) | PTX_ERR_BAD_OP);
-                }
-            }
-            PTX_SYNC();
-            if (H->adm != PTX_NO_ERR || H->cur[7] != N) { /* malformed envelope; the changes must tile the rows of the log exactly */
-                lds_high = bp.high;
-                return PTX_ERR_BAD_OP;
-            }
-            /* pass B: the checks; the loads of the NEXT step are in flight while this step is checked */
-            PTX_FOR_WAVE(w, lane) {
-                const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
-                uint32_t b01 = 0, b23 = 0; /* the clock before this wave's segment */
-                for (uint32_t q = 0; q < w; ++q) {
-                    b01 += wt01[q];
-                    b23 += wt23[q];
-                }
+                uint32_t b01 = 0, b23 = 0, rows = 0, badc = 0xFFFFFFFFu;
+                uint32_t emin[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, emax[3] = {0u, 0u, 0u}, mx[3] = {0u, 0u, 0u};
                 uint32_t h[PTX_AC], h_n[PTX_AC];
                 uint16_t e[PTX_AC][4], e_n[PTX_AC][4];
 #define PTX_ADM_LOAD(cb_, h_, e_)                                           \
@@ -862,27 +844,28 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
                         const bool in = cl + u < hi;
                         const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
+                        rows += in ? h[u] & PTX_CHG_NOPS : 0u;
+                        if (in && a >= na) badc = cl + u < badc ? cl + u : badc;
                         o01[u] = in && a < 2u ? 1u << (16u * a) : 0u;
-                        o23[u] = in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
+                        o23[u] = in && a == 2u ? 1u : 0u;
                         t01 += o01[u];
                         t23 += o23[u];
                     }
                     const uint32_t i01 = ptx_wave_incl_scan(t01), i23 = ptx_wave_incl_scan(t23);
-                    uint32_t w01 = b01 + i01 - t01, w23 = b23 + i23 - t23; /* the clock before this lane's first change */
+                    uint32_t w01 = b01 + i01 - t01, w23 = b23 + i23 - t23; /* relative clock before this lane's first change */
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
-                        const uint32_t c = cl + u;
+                        const bool in = cl + u < hi;
                         const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
                         const uint32_t clk[3] = {w01 & 0xFFFFu, w01 >> 16, w23 & 0xFFFFu};
-                        const uint32_t mine = ((a < 2u ? w01 : w23) >> (16u * (a & 1u))) & 0xFFFFu;
-                        const bool bad_seq = (uint32_t)e[u][0] != mine + 1u;
-                        bool bad_dep = false;
+                        const uint32_t ev = (uint32_t)e[u][0] - 1u - (a < 3u ? clk[a < 3u ? a : 0u] : 0u);
 #pragma unroll
-                        for (uint32_t b = 0; b < 3; ++b) bad_dep = bad_dep || (b < na && (uint32_t)e[u][1u + b] > clk[b]);
-                        if (c < hi && (bad_seq || bad_dep)) {
-                            uint32_t row;
-                            PTX_CHANGE_ROW(c, row);
-                            ptx_atomic_min(&H->adm, ((row * 2u) << 4) | (bad_seq ? PTX_ERR_SEQ_GAP : PTX_ERR_MISSING_DEP));
+                        for (uint32_t b = 0; b < 3; ++b) {
+                            const bool mine = in && a == b;
+                            emin[b] = mine && ev < emin[b] ? ev : emin[b];
+                            emax[b] = mine && ev > emax[b] ? ev : emax[b];
+                            const uint32_t dv = (uint32_t)e[u][1u + b] + 0x10000u - clk[b];
+                            mx[b] = in && b < na && dv > mx[b] ? dv : mx[b];
                         }
                         w01 += o01[u];
                         w23 += o23[u];
@@ -897,6 +880,155 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     }
                 }
 #undef PTX_ADM_LOAD
+#pragma unroll
+                for (uint32_t b = 0; b < 3; ++b) {
+                    emin[b] = ptx_wave_min(emin[b]);
+                    emax[b] = ptx_wave_max(emax[b]);
+                    mx[b] = ptx_wave_max(mx[b]);
+                }
+                if (lane == 0u) {
+                    uint32_t* r = wrec + w * 12u;
+                    r[0] = b01;
+                    r[1] = b23;
+#pragma unroll
+                    for (uint32_t b = 0; b < 3; ++b) {
+                        r[2u + b] = emin[b];
+                        r[5u + b] = emax[b];
+                        r[8u + b] = mx[b];
+                    }
+                }
+                ptx_reduce_add32(&H->cur[7], rows);
+                if (badc != 0xFFFFFFFFu) {
+                    uint32_t row;
+                    PTX_CHANGE_ROW(badc, row);
+                    ptx_atomic_min(&H->adm, ((row * 2u) << 4) | PTX_ERR_BAD_OP);
+                }
+            }
+            PTX_SYNC();
+            if (H->adm != PTX_NO_ERR || H->cur[7] != N) { /* malformed envelope; the changes must tile the rows of the log exactly */
+                lds_high = bp.high;
+                return PTX_ERR_BAD_OP;
+            }
+            bool admitted = true; /* the same answer in every thread: wrec is complete */
+            {
+                uint32_t B[3] = {0u, 0u, 0u};
+                for (uint32_t w = 0; w < nwv_; ++w) {
+                    const uint32_t* r = wrec + w * 12u;
+#pragma unroll
+                    for (uint32_t b = 0; b < 3; ++b) {
+                        if (r[5u + b] >= r[2u + b] && (r[2u + b] != B[b] || r[5u + b] != B[b])) admitted = false; /* some seq != clock + 1 */
+                        if (r[8u + b] > B[b] + 0x10000u) admitted = false;                                           /* some dep > clock */
+                    }
+                    B[0] += r[0] & 0xFFFFu;
+                    B[1] += r[0] >> 16;
+                    B[2] += r[1] & 0xFFFFu;
+                }
+            }
+            if (!admitted) {
+                /* EXACT walk of a failing log: which change fails first, and how (the reference throws there) */
+                PTX_SYNC();
+                PTX_LEADER { H->cur[7] = 0; }
+                PTX_SYNC();
+            /* pass A: per-wave totals of changes per actor, rows per log, actor range */
+                PTX_FOR_WAVE(w, lane) {
+                    const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
+                    uint32_t t01 = 0, t23 = 0, rows = 0, badc = 0xFFFFFFFFu;
+#pragma nounroll
+                    for (uint32_t cb = lo; cb < hi; cb += step) {
+                        uint32_t h[PTX_AC];
+                        const uint32_t cl = cb + lane * PTX_AC;
+                        PTX_ADM_HDRS(h, cl < hi ? cl : hi - 1u)
+#pragma unroll
+                        for (uint32_t u = 0; u < PTX_AC; ++u) {
+                            const bool in = cl + u < hi;
+                            const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
+                            rows += in ? h[u] & PTX_CHG_NOPS : 0u;
+                            if (in && a >= na) badc = cl + u < badc ? cl + u : badc;
+                            t01 += in && a < 2u ? 1u << (16u * a) : 0u;
+                            t23 += in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
+                        }
+                    }
+                    t01 = ptx_wave_total(t01);
+                    t23 = ptx_wave_total(t23);
+                    if (lane == 0u) {
+                        wt01[w] = t01;
+                        wt23[w] = t23;
+                    }
+                    ptx_reduce_add32(&H->cur[7], rows);
+                    if (badc != 0xFFFFFFFFu) {
+                        uint32_t row;
+                        PTX_CHANGE_ROW(badc, row);
+                        ptx_atomic_min(&H->adm, ((row * 2u) << 4) | PTX_ERR_BAD_OP);
+                    }
+                }
+                PTX_SYNC();
+                if (H->adm != PTX_NO_ERR || H->cur[7] != N) { /* malformed envelope; the changes must tile the rows of the log exactly */
+                    lds_high = bp.high;
+                    return PTX_ERR_BAD_OP;
+                }
+                /* pass B: the checks; the loads of the NEXT step are in flight while this step is checked */
+                PTX_FOR_WAVE(w, lane) {
+                    const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
+                    uint32_t b01 = 0, b23 = 0; /* the clock before this wave's segment */
+                    for (uint32_t q = 0; q < w; ++q) {
+                        b01 += wt01[q];
+                        b23 += wt23[q];
+                    }
+                    uint32_t h[PTX_AC], h_n[PTX_AC];
+                    uint16_t e[PTX_AC][4], e_n[PTX_AC][4];
+#define PTX_ADM_LOAD(cb_, h_, e_)                                           \
+    {                                                                       \
+        const uint32_t cl0_ = (cb_) + lane * PTX_AC;                        \
+        const uint32_t cl_ = cl0_ < hi ? cl0_ : (hi ? hi - 1u : 0u);        \
+        PTX_ADM_HDRS(h_, cl_)                                               \
+        PTX_ADM_ENVS(e_, cl_)                                               \
+    }
+                    PTX_ADM_LOAD(lo, h, e)
+#pragma nounroll
+                    for (uint32_t cb = lo; cb < hi; cb += step) {
+                        PTX_ADM_LOAD(cb + step, h_n, e_n)
+                        const uint32_t cl = cb + lane * PTX_AC;
+                        uint32_t o01[PTX_AC], o23[PTX_AC], t01 = 0, t23 = 0;
+#pragma unroll
+                        for (uint32_t u = 0; u < PTX_AC; ++u) {
+                            const bool in = cl + u < hi;
+                            const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
+                            o01[u] = in && a < 2u ? 1u << (16u * a) : 0u;
+                            o23[u] = in && (a & ~1u) == 2u ? 1u << (16u * (a & 1u)) : 0u;
+                            t01 += o01[u];
+                            t23 += o23[u];
+                        }
+                        const uint32_t i01 = ptx_wave_incl_scan(t01), i23 = ptx_wave_incl_scan(t23);
+                        uint32_t w01 = b01 + i01 - t01, w23 = b23 + i23 - t23; /* the clock before this lane's first change */
+#pragma unroll
+                        for (uint32_t u = 0; u < PTX_AC; ++u) {
+                            const uint32_t c = cl + u;
+                            const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
+                            const uint32_t clk[3] = {w01 & 0xFFFFu, w01 >> 16, w23 & 0xFFFFu};
+                            const uint32_t mine = ((a < 2u ? w01 : w23) >> (16u * (a & 1u))) & 0xFFFFu;
+                            const bool bad_seq = (uint32_t)e[u][0] != mine + 1u;
+                            bool bad_dep = false;
+#pragma unroll
+                            for (uint32_t b = 0; b < 3; ++b) bad_dep = bad_dep || (b < na && (uint32_t)e[u][1u + b] > clk[b]);
+                            if (c < hi && (bad_seq || bad_dep)) {
+                                uint32_t row;
+                                PTX_CHANGE_ROW(c, row);
+                                ptx_atomic_min(&H->adm, ((row * 2u) << 4) | (bad_seq ? PTX_ERR_SEQ_GAP : PTX_ERR_MISSING_DEP));
+                            }
+                            w01 += o01[u];
+                            w23 += o23[u];
+                        }
+                        b01 += ptx_wave_last(i01);
+                        b23 += ptx_wave_last(i23);
+#pragma unroll
+                        for (uint32_t u = 0; u < PTX_AC; ++u) {
+                            h[u] = h_n[u];
+#pragma unroll
+                            for (uint32_t b = 0; b < 4; ++b) e[u][b] = e_n[u][b];
+                        }
+                    }
+#undef PTX_ADM_LOAD
+                }
             }
 #undef PTX_ADM_HDRS
 #undef PTX_ADM_ENVS

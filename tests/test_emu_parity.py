@@ -279,6 +279,50 @@ def test_causal_admission_rejects_like_the_reference():
             assert g == w, (k, g, w, exp[kinds.index(k)][0].get("error") if k in kinds else None)
 
 
+def _sequential_admission(batch, log):
+    """applyChange's admission rule (micromerge.ts:499-511) replayed on the envelope columns of one log: status of the first failing change."""
+    c0, c1 = int(batch.chg_off[log]), int(batch.chg_off[log + 1])
+    clock = [0] * batch.max_actors
+    actor, seq, deps = batch.chg_actor, batch.chg_seq, batch.chg_deps
+    for c in range(c0, c1):
+        a = int(actor[c])
+        if int(seq[c]) != clock[a] + 1:
+            return abi.ERR_SEQ_GAP
+        if any(int(deps[c, b]) > clock[b] for b in range(batch.max_actors)):
+            return abi.ERR_MISSING_DEP
+        clock[a] = int(seq[c])
+    return 0
+
+
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_admission_fast_check_agrees_with_a_sequential_replay(reverse):
+    """The one-pass admission check (relative clocks per wave, validated after the pass) must say pass / fail exactly like a
+    sequential replay, and the exact walk it falls back to must name the reference's error: 150 logs with one envelope word
+    perturbed at random (seq or a dependency, up or down, anywhere in the log), plus untouched ones."""
+    gen = _load("ptxgen_config4_600.json")
+    base = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    es = abi.env_stride(base.max_actors)
+    rng = np.random.default_rng(11 + reverse)
+    copies = 17
+    batch = base.tile(copies)
+    env = batch.chg_env.copy().reshape(-1, es)
+    touched = {}
+    for log in range(batch.n_logs):
+        if log % 9 == 0:
+            continue  # left intact
+        c = int(rng.integers(int(batch.chg_off[log]), int(batch.chg_off[log + 1])))
+        col = int(rng.integers(0, 1 + base.max_actors))
+        delta = int(rng.choice([-2, -1, 1, 2, 40000]))
+        env[c, col] = np.uint16(max(0, min(65535, int(env[c, col]) + delta)))
+        touched[log] = (c, col, delta)
+    batch.chg_env = env.reshape(-1)
+    res = H.emu_merge(batch, admission=True, reverse=reverse)
+    want = [_sequential_admission(batch, log) for log in range(batch.n_logs)]
+    got = [int(x) for x in res.logs["status"]]
+    assert got == want, [(l, touched.get(l), g, w) for l, (g, w) in enumerate(zip(got, want)) if g != w][:5]
+    assert want.count(0) > copies and want.count(abi.ERR_SEQ_GAP) > 10 and want.count(abi.ERR_MISSING_DEP) > 10
+
+
 @pytest.mark.parametrize("reverse", [0, 1, 2])
 def test_duplicate_op_id_is_reported(reverse):
     """Two rows with one opId: the count of distinct ids falls short of the row count and the (rare-path) second

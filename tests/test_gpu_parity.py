@@ -500,3 +500,28 @@ def test_streaming_append_to_resident_logs(eng):
     finally:
         for h in (db_full, db_head, db_grown):
             eng.free_batch(h)
+
+
+def test_admission_fast_check_agrees_with_a_sequential_replay(eng):
+    """GPU twin of the emulation test: the one-pass admission check (64-lane waves, 256 changes per wave step) against a sequential
+    replay of the envelope, on full config-4-sized logs with one envelope word perturbed at random, untouched logs in between."""
+    from test_emu_parity import _sequential_admission
+
+    h, info = eng.generate(3, 4096, [25, 25, 25, 25], [0, 1, 3, 2], 40, 123, list_cap=2048)
+    actors_t, comments_t, log_doc_t = wire.generated_tables(40, 3, info["n_comments"])
+    batch = eng.download_batch(h, wire.GEN_VALUES, wire.GEN_URLS, log_doc_t, actors_t, comments_t)
+    eng.free_batch(h)
+    es = abi.env_stride(batch.max_actors)
+    rng = np.random.default_rng(5)
+    env = batch.chg_env.copy().reshape(-1, es)
+    for log in range(batch.n_logs):
+        if log % 7 == 0:
+            continue
+        c = int(rng.integers(int(batch.chg_off[log]), int(batch.chg_off[log + 1])))
+        col = int(rng.integers(0, 1 + batch.max_actors))
+        env[c, col] = np.uint16(max(0, min(65535, int(env[c, col]) + int(rng.choice([-2, -1, 1, 2, 40000])))))
+    batch.chg_env = env.reshape(-1)
+    res = eng.apply_materialize(batch)
+    want = [_sequential_admission(batch, log) for log in range(batch.n_logs)]
+    assert [int(x) for x in res.logs["status"]] == want
+    assert want.count(0) >= 18 and want.count(abi.ERR_SEQ_GAP) > 5 and want.count(abi.ERR_MISSING_DEP) > 5
