@@ -242,6 +242,7 @@ PTX_DEV uint32_t ptx_wave_max(uint32_t v) {
 #define PTX_NTHREADS PTX_BLOCKDIM
 #endif
 #define PTX_MAX_THREADS 1024u
+#define PTX_BYTE_PAD 4u /* bytes the library allocates past the end of the action / mark_type columns (the row pass reads them a dword at a time) */
 #define PTX_UA 1 /* changes per thread in flight in the (rare) many-actor admission passes */
 #ifdef PTX_EMU
 #define PTX_FORA(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_UA)
@@ -1154,6 +1155,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     uint16_t* ilist = ptx_alloc<uint16_t>(bp, n + 1);
     const uint32_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
     uint16_t* L = ptx_alloc<uint16_t>(bp, l_len);
+    /* when every id key fits 16 bits (the usual case): key of the insert in slot s, written beside ilist[s] by P1, so that P3a
+     * needs no second look at the op_id column.  Lives in the head of L, which is free until P3b fills it as `seg`. */
+    const bool small_keys = keyspace <= 65536u;
+    uint16_t* klist = L;
     uint16_t* dlist = L + n + 1; /* read until P3b; `seg` = L[0 .. n] is written meanwhile, `big` (same place as dlist) only after */
     PTX_BAIL_CAPACITY();
     const uint32_t tree_lds = bp.off;
@@ -1186,30 +1191,45 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * interest (makeList, NOP) use class 6/7 = a spare cursor, the spare list slot and OR 0 into the bitmaps. */
         uint32_t badrow = 0xFFFFFFFFu; /* first malformed / duplicate row seen by this thread */
         const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
+        static_assert(PTX_U1 <= 4, "the action / mark type bytes of a thread's rows travel in one dword");
         uint64_t id[PTX_U1];
-        uint32_t a[PTX_U1], mt[PTX_U1];
+        uint32_t a4, mt4; /* action / mark type of the thread's PTX_U1 rows, one byte each */
 #if PTX_P1_PREFETCH
         uint64_t id_n[PTX_U1];
-        uint32_t a_n[PTX_U1], mt_n[PTX_U1];
+        uint32_t a4_n, mt4_n;
 #endif
 #if PTX_P1_PREFETCH > 1
         uint64_t id_m[PTX_U1]; /* the step in between */
-        uint32_t a_m[PTX_U1], mt_m[PTX_U1];
+        uint32_t a4_m, mt4_m;
 #endif
-        /* this thread's PTX_U1 consecutive rows of a step; indices past the end are clamped, their effects masked */
+        /* this thread's PTX_U1 consecutive rows of a step; indices past the end are clamped, their effects masked.  The two byte
+         * columns are read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
+#ifdef PTX_EMU
+#define PTX_P1_BYTES(col_, r0_, dst_)                                    \
+    dst_ = 0;                                                            \
+    for (uint32_t u_ = 0; u_ < PTX_U1; ++u_) dst_ |= (uint32_t)col_[(r0_) + u_ < N ? (r0_) + u_ : N - 1u] << (8u * u_);
+#else
+#define PTX_P1_BYTES(col_, r0_, dst_)                                    \
+    {                                                                    \
+        struct __attribute__((packed, aligned(1))) PtxB4 { uint32_t v; };  \
+        dst_ = ((const PtxB4*)(col_ + ((r0_) < N ? (r0_) : N - 1u)))->v; \
+    }
+#endif
 #define PTX_P1_LOAD(g_, id_, a_, mt_)                                   \
-    _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {                 \
-        const uint32_t r_ = (g_) * PTX_U1 + (uint32_t)u;                 \
-        const uint32_t i_ = r_ < N ? r_ : N - 1u;                       \
-        id_[u] = op_id[i_];                                             \
-        a_[u] = action[i_];                                             \
-        mt_[u] = mark_type[i_];                                         \
+    {                                                                   \
+        const uint32_t r0_ = (g_) * PTX_U1;                             \
+        _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {             \
+            const uint32_t r_ = r0_ + (uint32_t)u;                      \
+            id_[u] = op_id[r_ < N ? r_ : N - 1u];                       \
+        }                                                               \
+        PTX_P1_BYTES(action, r0_, a_)                                   \
+        PTX_P1_BYTES(mark_type, r0_, mt_)                               \
     }
 #if PTX_P1_PREFETCH
-        PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a, mt)
+        PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a4, mt4)
 #endif
 #if PTX_P1_PREFETCH > 1
-        PTX_P1_LOAD(PTX_G_OF(1u, p1_steps), id_m, a_m, mt_m)
+        PTX_P1_LOAD(PTX_G_OF(1u, p1_steps), id_m, a4_m, mt4_m)
 #endif
 #pragma nounroll
         for (uint32_t st = 0; st < p1_steps; ++st) {
@@ -1217,9 +1237,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             if (PTX_WAVE_FIRST(g) >= p1_groups) continue; /* this wave has no row left in this step (wave-uniform) */
 #if PTX_P1_PREFETCH
             const uint32_t gn = PTX_G_OF(st + (uint32_t)PTX_P1_PREFETCH, p1_steps);
-            PTX_P1_LOAD(gn, id_n, a_n, mt_n) /* later steps' rows are in flight while this step is processed */
+            PTX_P1_LOAD(gn, id_n, a4_n, mt4_n) /* later steps' rows are in flight while this step is processed */
 #else
-            PTX_P1_LOAD(g, id, a, mt)
+            PTX_P1_LOAD(g, id, a4, mt4)
 #endif
             uint32_t cls[PTX_U1], slot[PTX_U1];
 #pragma unroll
@@ -1228,8 +1248,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 const bool in = i < N;
                 const uint32_t ctr = (uint32_t)(id[u] >> 32), act = (uint32_t)id[u];
                 /* action -> class through a nibble table: 0 makeList->6, 1 insert->0, 2 delete->1, 3/4 marks->2, 5 nop->6, else 7 */
-                uint32_t c = a[u] < 8u ? (0x77622106u >> (a[u] * 4u)) & 15u : 7u;
-                c = c == 2u ? (mt[u] < 4u ? 2u + mt[u] : 7u) : c;
+                const uint32_t au = (a4 >> (8u * (uint32_t)u)) & 255u, mtu = (mt4 >> (8u * (uint32_t)u)) & 255u;
+                uint32_t c = au < 8u ? (0x77622106u >> (au * 4u)) & 15u : 7u;
+                c = c == 2u ? (mtu < 4u ? 2u + mtu : 7u) : c;
                 const bool keybad = ctr - 1u >= ix.max_ctr || act > ix.max_actor; /* ctr == 0 or beyond the header's bounds */
                 badrow = in && (c == 7u || keybad) && i < badrow ? i : badrow;
                 cls[u] = (!in || keybad) ? 7u : c;
@@ -1249,29 +1270,31 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 const bool listed = c < 6u && slot[u] < cap;
                 const uint32_t sl = listed ? slot[u] : (c == 0u ? n : c == 1u ? D : K);
                 lst[sl] = (uint16_t)i;
-                if (listed && c >= 2u && a[u] == PTX_ACT_ADDMARK) ptx_atomic_or(&maddbits[sl >> 5], 1u << (sl & 31u));
+                if (small_keys && c == 0u) klist[sl] = (uint16_t)key;
+                if (listed && c >= 2u && ((a4 >> (8u * (uint32_t)u)) & 255u) == PTX_ACT_ADDMARK) ptx_atomic_or(&maddbits[sl >> 5], 1u << (sl & 31u));
                 if (A.out_rank && i < N) A.out_rank[base + i] = 0xFFFFFFFFu; /* insert rows are overwritten in P5a */
             }
 #if PTX_P1_PREFETCH > 1
 #pragma unroll
             for (int u = 0; u < PTX_U1; ++u) {
                 id[u] = id_m[u];
-                a[u] = a_m[u];
-                mt[u] = mt_m[u];
                 id_m[u] = id_n[u];
-                a_m[u] = a_n[u];
-                mt_m[u] = mt_n[u];
             }
+            a4 = a4_m;
+            mt4 = mt4_m;
+            a4_m = a4_n;
+            mt4_m = mt4_n;
 #elif PTX_P1_PREFETCH
 #pragma unroll
             for (int u = 0; u < PTX_U1; ++u) {
                 id[u] = id_n[u];
-                a[u] = a_n[u];
-                mt[u] = mt_n[u];
             }
+            a4 = a4_n;
+            mt4 = mt4_n;
 #endif
         }
 #undef PTX_P1_LOAD
+#undef PTX_P1_BYTES
         if (badrow != 0xFFFFFFFFu) {
             /* which of the two: re-test the row */
             const uint64_t id = op_id[badrow];
@@ -1335,16 +1358,18 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         {
             const uint32_t steps = PTX_JSTEPS(n);
             uint32_t i[PTX_U], i_n[PTX_U];
-            uint64_t id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U];
-            /* rows of this thread's inserts of a step (list read, then the two column gathers) */
+            uint64_t id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
+            /* rows of this thread's inserts of a step (list read, then the column gathers) */
 #define PTX_P3A_LOAD(st_, i_, id_, ra_)                                     \
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
         const uint32_t j_ = PTX_J_OF(st_, u);                               \
-        const uint32_t r_ = ilist[j_ < n ? PTX_JX(j_, n) : 0u];             \
+        const uint32_t s_ = j_ < n ? PTX_JX(j_, n) : 0u;                    \
+        const uint32_t r_ = ilist[s_];                                      \
         i_[u] = r_ < N ? r_ : N - 1u;                                       \
+        if (small_keys) id_[u] = klist[s_];                                 \
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
-        id_[u] = op_id[i_[u]];                                              \
+        if (!small_keys) id_[u] = op_id[i_[u]];                             \
         ra_[u] = ref_a[i_[u]];                                              \
     }
             PTX_P3A_LOAD(0u, i, id, ra)
@@ -1354,8 +1379,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #pragma unroll
                 for (int u = 0; u < PTX_U; ++u)
                     if (PTX_J_OF(st, u) < n) {
-                        uint32_t key = 0;
-                        ptx_id_key(ix, id[u], key);
+                        uint32_t key = (uint32_t)id[u];
+                        if (!small_keys) ptx_id_key(ix, id[u], key);
                         const uint32_t e = ptx_bitrank(ix.ib, key);
                         row_of[e] = (uint16_t)i[u];
                         uint32_t pe = n;

@@ -598,8 +598,8 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
     PTX_TRY(dalloc(&b->ref_a, T));
     PTX_TRY(dalloc(&b->ref_b, T));
     PTX_TRY(dalloc(&b->payload, T));
-    PTX_TRY(dalloc(&b->action, T));
-    PTX_TRY(dalloc(&b->mark_type, T));
+    PTX_TRY(dalloc(&b->action, T + PTX_BYTE_PAD));
+    PTX_TRY(dalloc(&b->mark_type, T + PTX_BYTE_PAD));
     PTX_TRY(dalloc(&b->side_a, T));
     PTX_TRY(dalloc(&b->side_b, T));
     PTX_TRY(dalloc(&b->log_hdr, (uint64_t)b->n_logs));
@@ -716,8 +716,8 @@ ptx_status ptx_batch_append_device(ptx_ctx* ctx, const ptx_dbatch* base, const p
     PTX_TRYA(dalloc(&b->ref_a, T));
     PTX_TRYA(dalloc(&b->ref_b, T));
     PTX_TRYA(dalloc(&b->payload, T));
-    PTX_TRYA(dalloc(&b->action, T));
-    PTX_TRYA(dalloc(&b->mark_type, T));
+    PTX_TRYA(dalloc(&b->action, T + PTX_BYTE_PAD));
+    PTX_TRYA(dalloc(&b->mark_type, T + PTX_BYTE_PAD));
     PTX_TRYA(dalloc(&b->side_a, T));
     PTX_TRYA(dalloc(&b->side_b, T));
     PTX_TRYA(dalloc(&b->log_hdr, L));
@@ -1437,8 +1437,8 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     PTX_TRYG(dalloc(&b->ref_a, T));
     PTX_TRYG(dalloc(&b->ref_b, T));
     PTX_TRYG(dalloc(&b->payload, T));
-    PTX_TRYG(dalloc(&b->action, T));
-    PTX_TRYG(dalloc(&b->mark_type, T));
+    PTX_TRYG(dalloc(&b->action, T + PTX_BYTE_PAD));
+    PTX_TRYG(dalloc(&b->mark_type, T + PTX_BYTE_PAD));
     PTX_TRYG(dalloc(&b->side_a, T));
     PTX_TRYG(dalloc(&b->side_b, T));
     PTX_TRYG(dalloc(&b->log_hdr, (uint64_t)b->n_logs));
@@ -1817,8 +1817,8 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
     PTX_TRYC(dalloc(&b->ref_a, b->n_ops));
     PTX_TRYC(dalloc(&b->ref_b, b->n_ops));
     PTX_TRYC(dalloc(&b->payload, b->n_ops));
-    PTX_TRYC(dalloc(&b->action, b->n_ops));
-    PTX_TRYC(dalloc(&b->mark_type, b->n_ops));
+    PTX_TRYC(dalloc(&b->action, b->n_ops + PTX_BYTE_PAD));
+    PTX_TRYC(dalloc(&b->mark_type, b->n_ops + PTX_BYTE_PAD));
     PTX_TRYC(dalloc(&b->side_a, b->n_ops));
     PTX_TRYC(dalloc(&b->side_b, b->n_ops));
     PTX_TRYC(dalloc(&b->log_hdr, (uint64_t)L));
