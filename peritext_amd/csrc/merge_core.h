@@ -1354,31 +1354,42 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
         PTX_FOR(p, (n + 2 + 1) / 2 + 1) cntw[p] = 0;
         PTX_SYNC();
-        /* P3a: element index of every insert, its parent, children counts */
+        /* P3a: element index of every insert, its parent, children counts.  The deletes ride along: their gathers of ref_a hit
+         * the lines the inserts of the same stretch of the log have just brought in (one trip to HBM instead of two), and their
+         * round trips hide behind the inserts'.  What a delete cannot do yet is the application-order check (row_of is being
+         * written): the thread leaves the target element in the slot of `ilist` it has just consumed — same thread, same index,
+         * no hazard — and the check runs below, from LDS alone.  Deletes beyond slot n (more deletes than inserts) go the old way. */
+        const uint32_t d_fused = D < n + 1u ? D : n + 1u;
         {
-            const uint32_t steps = PTX_JSTEPS(n);
-            uint32_t i[PTX_U], i_n[PTX_U];
+            const uint32_t jmax = n > d_fused ? n : d_fused;
+            const uint32_t steps = PTX_JSTEPS(jmax);
+            uint32_t i[PTX_U], i_n[PTX_U], di[PTX_U], di_n[PTX_U];
             uint64_t id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
-            /* rows of this thread's inserts of a step (list read, then the column gathers) */
-#define PTX_P3A_LOAD(st_, i_, id_, ra_)                                     \
+            uint64_t dra[PTX_U], dra_n[PTX_U];
+            /* rows of this thread's inserts and deletes of a step (list reads, then the column gathers) */
+#define PTX_P3A_LOAD(st_, i_, id_, ra_, di_, dra_)                          \
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
         const uint32_t j_ = PTX_J_OF(st_, u);                               \
         const uint32_t s_ = j_ < n ? PTX_JX(j_, n) : 0u;                    \
         const uint32_t r_ = ilist[s_];                                      \
         i_[u] = r_ < N ? r_ : N - 1u;                                       \
         if (small_keys) id_[u] = klist[s_];                                 \
+        const uint32_t dr_ = dlist[j_ < d_fused ? PTX_JX(j_, D) : 0u];      \
+        di_[u] = dr_ < N ? dr_ : N - 1u;                                    \
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
         if (!small_keys) id_[u] = op_id[i_[u]];                             \
         ra_[u] = ref_a[i_[u]];                                              \
+        dra_[u] = ref_a[di_[u]];                                            \
     }
-            PTX_P3A_LOAD(0u, i, id, ra)
+            PTX_P3A_LOAD(0u, i, id, ra, di, dra)
 #pragma nounroll
             for (uint32_t st = 0; st < steps; ++st) {
-                PTX_P3A_LOAD(st + 1u, i_n, id_n, ra_n) /* in flight while this step is processed */
+                PTX_P3A_LOAD(st + 1u, i_n, id_n, ra_n, di_n, dra_n) /* in flight while this step is processed */
 #pragma unroll
-                for (int u = 0; u < PTX_U; ++u)
-                    if (PTX_J_OF(st, u) < n) {
+                for (int u = 0; u < PTX_U; ++u) {
+                    const uint32_t j = PTX_J_OF(st, u);
+                    if (j < n) {
                         uint32_t key = (uint32_t)id[u];
                         if (!small_keys) ptx_id_key(ix, id[u], key);
                         const uint32_t e = ptx_bitrank(ix.ib, key);
@@ -1392,11 +1403,21 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         par[e] = (uint16_t)pe;
                         ptx_atomic_add(&cntw[pe >> 1], 1u << (16u * (pe & 1u)));
                     }
+                    if (j < d_fused) {
+                        /* the element must exist when the delete is applied (micromerge.ts:752); deleting twice is fine (:693) */
+                        const int t = ptx_elem_lookup(ix, dra[u]);
+                        if (t < 0) ptx_raise(H, di[u], 1, PTX_ERR_ELEM_NOT_FOUND);
+                        else ptx_atomic_or(&delbits[(uint32_t)t >> 5], 1u << ((uint32_t)t & 31u));
+                        ilist[j < n ? PTX_JX(j, n) : j] = (uint16_t)(t < 0 ? 0xFFFF : t); /* j <= n; slot n is P1's spare */
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < PTX_U; ++u) {
                     i[u] = i_n[u];
                     id[u] = id_n[u];
                     ra[u] = ra_n[u];
+                    di[u] = di_n[u];
+                    dra[u] = dra_n[u];
                 }
             }
 #undef PTX_P3A_LOAD
@@ -1424,36 +1445,19 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     seg[(ptx_atomic_add(&cntw[pe[u] >> 1], 1u << (16u * (pe[u] & 1u))) >> (16u * (pe[u] & 1u))) & 0xFFFFu] = (uint16_t)PTX_IX(e0, u);
                 }
         }
-        {
-            const uint32_t steps = PTX_JSTEPS(D);
-            uint32_t i[PTX_U], i_n[PTX_U];
-            uint64_t ra[PTX_U], ra_n[PTX_U];
-#define PTX_DEL_LOAD(st_, i_, ra_)                                          \
-    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
-        const uint32_t j_ = PTX_J_OF(st_, u);                               \
-        const uint32_t r_ = dlist[j_ < D ? PTX_JX(j_, D) : 0u];             \
-        i_[u] = r_ < N ? r_ : N - 1u;                                       \
-    }                                                                       \
-    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) ra_[u] = ref_a[i_[u]];
-            PTX_DEL_LOAD(0u, i, ra)
-#pragma nounroll
-            for (uint32_t st = 0; st < steps; ++st) {
-                PTX_DEL_LOAD(st + 1u, i_n, ra_n)
-#pragma unroll
-                for (int u = 0; u < PTX_U; ++u)
-                    if (PTX_J_OF(st, u) < D) {
-                        /* the element must exist when the delete is applied (micromerge.ts:752); deleting twice is fine (:693) */
-                        const int t = ptx_elem_lookup(ix, ra[u]);
-                        if (t < 0 || row_of[t] >= i[u]) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);
-                        else ptx_atomic_or(&delbits[t >> 5], 1u << ((uint32_t)t & 31u));
-                    }
-#pragma unroll
-                for (int u = 0; u < PTX_U; ++u) {
-                    i[u] = i_n[u];
-                    ra[u] = ra_n[u];
-                }
+        /* the deletes' application-order check, now that row_of is complete: target element left in ilist by P3a */
+        PTX_FOR(j, d_fused) {
+            const uint32_t t = ilist[j < n ? PTX_JX(j, n) : j], i = dlist[PTX_JX(j, D)];
+            if (t != 0xFFFFu && row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND);
+        }
+        if (D > d_fused) { /* more deletes than inserts + 1: the rest, one gather each */
+            PTX_FOR(jj, D - d_fused) {
+                const uint32_t j = d_fused + jj;
+                const uint32_t r = dlist[PTX_JX(j, D)], i = r < N ? r : N - 1u;
+                const int t = ptx_elem_lookup(ix, ref_a[i]);
+                if (t < 0 || row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND);
+                else ptx_atomic_or(&delbits[(uint32_t)t >> 5], 1u << ((uint32_t)t & 31u));
             }
-#undef PTX_DEL_LOAD
         }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(3);

@@ -380,6 +380,19 @@ def unsynced_docs():
 
 
 
+def more_deletes_than_inserts_docs():
+    """Logs with more deletes than inserts + 1 (the same chars deleted again and again, which the reference allows,
+    micromerge.ts:693): [all fine -> "!", a late delete whose target is only inserted by the NEXT op, a late delete of an unknown
+    element].  The kernel resolves the first n + 1 deletes beside the inserts and the rest in a loop of their own."""
+    el = lambda i: "%d@a" % (i + 2)  # noqa: E731
+    dels = [{"action": "del", "elemId": el(i)} for i in range(5)] + [{"action": "del", "elemId": el(i)} for i in range(4)]
+    ok = mini_doc(dels + [{"action": "set", "insert": True, "elemId": el(4), "value": "!"}])
+    # ops of change 2 get ids 7, 8, ...: nine deletes (7..15), a delete of 17@a (16), the insert 17@a
+    later = mini_doc(dels + [{"action": "del", "elemId": "17@a"}, {"action": "set", "insert": True, "elemId": el(4), "value": "!"}])
+    unknown = mini_doc(dels + [{"action": "del", "elemId": "99@zz"}, {"action": "set", "insert": True, "elemId": el(4), "value": "!"}])
+    return [[ok], [later], [unknown]]
+
+
 def duplicate_op_docs():
     """[a log with one opId on two rows, a well-formed neighbour]."""
     dup = mini_doc([{"action": "set", "insert": True, "elemId": "6@a", "value": "x"}, {"action": "del", "elemId": "3@a"}])

@@ -135,6 +135,21 @@ def test_edge_fixture_made_by_the_reference():
         assert json.loads(json.dumps(live_u, sort_keys=True)) == json.loads(json.dumps(g["unsynced"], sort_keys=True))
 
 
+@pytest.mark.parametrize("reverse", [0, 1, 2])
+def test_more_deletes_than_inserts(reverse):
+    """The deletes beyond slot n (resolved in their own loop) and their application-order check."""
+    docs = H.more_deletes_than_inserts_docs()
+    batch = wire.encode_docs(docs)
+    res = H.emu_merge(batch, reverse=reverse)
+    assert [int(x) for x in res.logs["status"]] == [0, abi.ERR_ELEM_NOT_FOUND, abi.ERR_ELEM_NOT_FOUND]
+    assert wire.decode_spans(batch, res, 0) == [{"text": "!", "marks": {}}]
+    assert [int(x) for x in res.logs["reserved"][1:, 1]] == [15, 15]  # rows 0..14 = makeList, 5 inserts, 9 deletes
+    if H.have_node():
+        exp = H.oracle_apply(docs)
+        assert exp[0][0]["spans"] == [{"text": "!", "marks": {}}]
+        assert all("List element not found" in e[0].get("error", "") for e in exp[1:])
+
+
 def test_error_statuses_mirror_reference_throw_sites():
     """Unknown insert parent / delete target -> PTX_ERR_ELEM_NOT_FOUND (RangeError 'List element not
     found', micromerge.ts:752), also when the element only appears LATER in the log."""

@@ -85,6 +85,15 @@ def test_element_that_only_appears_later(eng):
     assert int(res.logs["status"][0]) == abi.ERR_ELEM_NOT_FOUND
 
 
+def test_more_deletes_than_inserts(eng):
+    """Twin of the emulation test: deletes beyond slot n are resolved in their own loop; order check of both kinds of deletes."""
+    batch = wire.encode_docs(H.more_deletes_than_inserts_docs())
+    res = eng.apply_materialize(batch)
+    assert [int(x) for x in res.logs["status"]] == [0, abi.ERR_ELEM_NOT_FOUND, abi.ERR_ELEM_NOT_FOUND]
+    assert wire.decode_spans(batch, res, 0) == [{"text": "!", "marks": {}}]
+    assert [int(x) for x in res.logs["reserved"][1:, 1]] == [15, 15]
+
+
 def test_unsynced_replicas_with_different_comment_sets(eng, golden):
     """replicas that have seen different subsets of the document's comments (prefixes of replica logs; two
     replicas that each know one comment the other lacks) — spans, digests and Patch[] streams."""
