@@ -82,24 +82,7 @@ PTX_HD uint64_t ptx_gen_lds_need(uint64_t R, uint64_t list_cap, uint64_t rows_pe
     return ptx_a16(sizeof(PtxGenHdr)) + ptx_a16(4 * R * ((list_cap + 64 + 3) & ~3ull)) + ptx_a16(4 * ((rows_per_log >> 5) + 2));
 }
 
-/* ---- 64-wide ballot over lanes: `expr` may use `lane_` ---- */
-#ifdef PTX_EMU
-#define PTX_BALLOT64(mask_, lane_, expr)                 \
-    uint64_t mask_ = 0;                                  \
-    for (uint32_t lane_ = 0; lane_ < 64u; ++lane_)       \
-        if (expr) mask_ |= 1ull << lane_;
-#define PTX_LANE0 true
-#define PTX_GEN_FOR(i, n) for (uint32_t i = 0, _gn = (n); i < _gn; ++i)
-#else
-#define PTX_BALLOT64(mask_, lane_, expr)                 \
-    uint64_t mask_;                                      \
-    {                                                    \
-        const uint32_t lane_ = threadIdx.x & 63u;        \
-        mask_ = __ballot(expr);                          \
-    }
-#define PTX_LANE0 (threadIdx.x == 0)
-#define PTX_GEN_FOR(i, n) for (uint32_t i = threadIdx.x, _gn = (n); i < _gn; i += 64u)
-#endif
+/* 64-wide ballots (PTX_BALLOT64), PTX_LANE0, PTX_GEN_FOR: ptx_platform_gfx950.h */
 PTX_DEV uint32_t ptx_ffs64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }      /* m != 0 */
 PTX_DEV uint32_t ptx_fls64(uint64_t m) { return 63u - (uint32_t)__builtin_clzll(m); } /* m != 0 */
 PTX_DEV uint32_t ptx_select64(uint64_t m, uint32_t k) { /* position of the k-th (0-based) set bit; popcount(m) > k */
@@ -150,11 +133,6 @@ PTX_DEV uint32_t ptx_gen_after_tombstones(const uint32_t* lst, uint32_t n, uint3
     return pick;
 }
 
-#ifdef PTX_EMU
-#define PTX_MEM inline
-#else
-#define PTX_MEM __device__ __forceinline__
-#endif
 
 /* one op row */
 struct PtxGenRow {
@@ -230,16 +208,7 @@ struct PtxGenDoc {
              * before any lane writes, and a chunk only writes above what the chunks still to come read) */
             for (uint32_t hi = n; hi > at;) {
                 const uint32_t lo = hi - at > 64u ? hi - 64u : at;
-#ifdef PTX_EMU
-                uint32_t chunk[64];
-                for (uint32_t i = lo; i < hi; ++i) chunk[i - lo] = L[i];
-                for (uint32_t i = lo; i < hi; ++i) L[i + 1u] = chunk[i - lo];
-#else
-                const uint32_t i = lo + (threadIdx.x & 63u);
-                const uint32_t v = i < hi ? L[i] : 0u;
-                PTX_SYNC();
-                if (i < hi) L[i + 1u] = v;
-#endif
+                ptx_shift_up64(L, lo, hi);
                 PTX_SYNC();
                 hi = lo;
             }

@@ -45,155 +45,7 @@
 #define PTX_U 2 /* rows in flight per thread in the batched loops */
 #endif
 
-#ifdef PTX_EMU
-#include <string.h>
-#define PTX_HD static inline
-#define PTX_DEV static inline
-#define PTX_SYNC() ((void)0)
-extern int ptx_emu_reverse; /* order of every emulated parallel loop: 0 forward, 1 backward, 2 a fixed pseudo-random permutation (order-independence checks) */
-static inline uint32_t ptx_emu_ix(uint32_t k, uint32_t n) { /* k-th iteration runs index ...; 104729 is a prime above any loop length here */
-    return ptx_emu_reverse == 0 ? k : ptx_emu_reverse == 1 ? n - 1u - k : (uint32_t)(((uint64_t)k * 104729ull + 7ull) % (n ? n : 1u));
-}
-#define PTX_FOR(i, n)                                                                              \
-    for (uint32_t _n = (n), _k = 0, i = (_n ? ptx_emu_ix(0, _n) : 0); _k < _n;                    \
-         ++_k, i = (_k < _n ? ptx_emu_ix(_k, _n) : 0))
-#define PTX_LEADER if (true)
-PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
-PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o & v; return o; }
-PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
-PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
-PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
-PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
-PTX_DEV void ptx_atomic_or64(unsigned long long* p, unsigned long long v) { *p |= v; }
-PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
-/* append to a list: index of this element (valid only where pred) */
-PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }
-PTX_DEV uint64_t ptx_clock() { return 0; }
-#define PTX_G 1u
-PTX_DEV uint32_t ptx_group_sum(uint32_t c) { return c; }
-/* batched parallel loop: PTX_U iterations per step so that their loads are all in flight together */
-#define PTX_FORU(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_U)
-#define PTX_IX(i0, u) ((i0) + (uint32_t)(u) < _n ? ptx_emu_ix((i0) + (uint32_t)(u), _n) : (i0) + (uint32_t)(u))
-#else
-#include <hip/hip_runtime.h>
-#define PTX_HD __host__ __device__ static inline
-#define PTX_DEV __device__ __forceinline__
-#define PTX_SYNC() __syncthreads()
-/* threads per workgroup: a compile-time constant in the builds specialised for the usual launch shapes (kThreads != 0:
- * the per-phase loop bounds and strides then fold, which removes a quarter of the scalar instructions), else blockDim.x */
-#define PTX_BLOCKDIM (kThreads ? kThreads : blockDim.x)
-#define PTX_FOR(i, n) _Pragma("nounroll") for (uint32_t i = threadIdx.x, _n = (n); i < _n; i += PTX_BLOCKDIM)
-#define PTX_LEADER if (threadIdx.x == 0)
-PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
-PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
-PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
-PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
-PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
-PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
-PTX_DEV void ptx_atomic_or64(unsigned long long* p, unsigned long long v) { (void)atomicOr(p, v); }
-PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__popc(x); }
-/* wave-aggregated append: ONE LDS atomic per wave, lanes get consecutive slots.  May be called in
- * divergent control flow (the ballot covers the active lanes only). */
-PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0) return 0u;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-    uint32_t b = 0;
-    if (lane == leader) b = atomicAdd(cursor, (uint32_t)__popcll(m));
-    b = (uint32_t)__shfl((int)b, (int)leader, 64);
-    return b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
-PTX_DEV uint64_t ptx_clock() { return (uint64_t)__builtin_readcyclecounter(); }
-#define PTX_G 8u /* lanes that share one member of a large child bucket */
-PTX_DEV uint32_t ptx_group_sum(uint32_t c) {
-    c += (uint32_t)__shfl_xor((int)c, 1, 64);
-    c += (uint32_t)__shfl_xor((int)c, 2, 64);
-    c += (uint32_t)__shfl_xor((int)c, 4, 64);
-    return c;
-}
-#define PTX_FORU(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = PTX_BLOCKDIM; i0 < _n; i0 += PTX_U * _T)
-#define PTX_IX(i0, u) ((i0) + (uint32_t)(u) * _T)
-#endif
 #define PTX_IN(i0, u) ((i0) + (uint32_t)(u) * _T < _n)
-
-/* ---- list slots for a batch of rows: rows of class c < 6 get consecutive slots from cursor[c], in ROW order
- *      within the wave (lane-major, each lane holding PTX_U consecutive rows), so that the lists stay (nearly)
- *      sorted by row and later gathers through them stay (nearly) coalesced.  One LDS atomic per wave and batch
- *      (6 lanes, 6 distinct cursors); the ranking itself is a DPP prefix sum in registers.  Every lane of the
- *      wave must call it (uniform control flow). ---- */
-#ifdef PTX_EMU
-template <int U>
-PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slot) {
-    for (int u = 0; u < U; ++u) slot[u] = cls[u] < 6u ? cursor[cls[u]]++ : 0xFFFFFFFFu;
-}
-#else
-PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1,3 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2,3 */
-    return v;
-}
-template <int U>
-PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slot) {
-    /* per-lane counts, 10 bits per class: classes 0..2 in w0, 3..5 in w1 (a wave holds at most 64 * U <= 1023 rows) */
-    uint32_t w0 = 0, w1 = 0, off[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t c = cls[u];
-        const uint32_t sh = (c >= 3u ? c - 3u : c) * 10u;
-        off[u] = ((c >= 3u ? w1 : w0) >> sh) & 1023u;
-        w0 += (c < 3u ? 1u : 0u) << sh;
-        w1 += (c >= 3u && c < 6u ? 1u : 0u) << sh;
-    }
-    const uint32_t i0 = ptx_wave_incl_scan(w0), i1 = ptx_wave_incl_scan(w1);
-    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t basev = 0;
-    if (lane < 6u) {
-        const uint32_t cnt = ((lane >= 3u ? t1 : t0) >> ((lane >= 3u ? lane - 3u : lane) * 10u)) & 1023u;
-        basev = atomicAdd(&cursor[lane], cnt);
-    }
-    const uint32_t e0 = i0 - w0, e1 = i1 - w1; /* exclusive prefix over the lower lanes */
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t c = cls[u];
-        const uint32_t sh = (c >= 3u ? c - 3u : c) * 10u;
-        const uint32_t b = (uint32_t)__shfl((int)basev, (int)(c & 7u), 64);
-        slot[u] = c < 6u ? b + (((c >= 3u ? e1 : e0) >> sh) & 1023u) + off[u] : 0xFFFFFFFFu;
-    }
-}
-#endif
-
-/* Software-pipelined uniform loops: step st of `steps` handles group PTX_G_OF(st); the loads of step st+1 are
- * issued before step st is processed (the caller keeps two register sets).  Every thread runs every step; a
- * group index past the end means "no work" (its loads are clamped to valid addresses, its effects masked). */
-#ifdef PTX_EMU
-#define PTX_STEPS(groups) (groups)
-#define PTX_G_OF(st, steps) ((st) < (steps) ? ptx_emu_ix((st), (steps)) : (steps) + ((st) - (steps)))
-#else
-/* x / threads-per-workgroup without a division: the host passes magic = floor(2^32 / T) + 1, exact for x * T < 2^32
- * (x is a row count + T here; a uniform integer division costs ~25 instructions per wave, and a log has a dozen) */
-#define PTX_DIV_T(x) (kThreads ? (uint32_t)(x) / (kThreads ? kThreads : 1u) : (uint32_t)__umulhi((uint32_t)(x), A.div_magic))
-#define PTX_STEPS(groups) PTX_DIV_T((groups) + PTX_BLOCKDIM - 1u)
-#define PTX_G_OF(st, steps) (threadIdx.x + (st) * PTX_BLOCKDIM)
-#endif
-
-/* the same for loops over list items, PTX_U items per thread and step, lanes on consecutive items:
- * step st, slot u handles item PTX_J_OF(st, u) (past the end = no work); PTX_JX maps it for the emulation's
- * reversed order */
-#ifdef PTX_EMU
-#define PTX_JSTEPS_U(n, U) (((n) + (U)-1u) / (U))
-#define PTX_J_OF_U(st, u, U) ((st) * (U) + (uint32_t)(u))
-#define PTX_JX(j, n) ((j) < (n) ? ptx_emu_ix((j), (n)) : (j))
-#else
-#define PTX_JSTEPS_U(n, U) ((PTX_DIV_T((n) + PTX_BLOCKDIM - 1u) + (U)-1u) / (U)) /* = ceil(n / (U * T)) */
-#define PTX_J_OF_U(st, u, U) (((st) * (U) + (uint32_t)(u)) * PTX_BLOCKDIM + threadIdx.x)
-#define PTX_JX(j, n) (j)
-#endif
 #define PTX_JSTEPS(n) PTX_JSTEPS_U(n, PTX_U)
 #define PTX_J_OF(st, u) PTX_J_OF_U(st, u, PTX_U)
 #ifndef PTX_U1
@@ -202,53 +54,9 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 #ifndef PTX_P1_PREFETCH
 #define PTX_P1_PREFETCH 1 /* row loads of P1: 1 = one step ahead (costs PTX_U1 * 4 VGPRs), 2 = two steps ahead (twice that) */
 #endif
-/* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
- * emulation plays three one-lane waves in turn */
-#ifdef PTX_EMU
-#define PTX_WAVE_FIRST(g) (g)
-#define PTX_WS 1u
-#define PTX_NWAVES 3u
-#define PTX_FOR_WAVE(w, lane) for (uint32_t w = 0, lane = 0; w < PTX_NWAVES; ++w)
-PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v) { return v; }
-PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return incl; }
-PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return v; }
-PTX_DEV uint32_t ptx_wave_min(uint32_t v) { return v; }
-PTX_DEV uint32_t ptx_wave_max(uint32_t v) { return v; }
-#else
-#define PTX_WAVE_FIRST(g) ((g) - (threadIdx.x & 63u)) /* index handled by lane 0 of this wave */
-#define PTX_WS 64u
-#define PTX_NWAVES (PTX_BLOCKDIM >> 6)
-#define PTX_FOR_WAVE(w, lane) for (uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, _once = 1; _once; _once = 0)
-PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
-PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl_scan(v)); }
-PTX_DEV uint32_t ptx_wave_min(uint32_t v) { /* the same value in every lane */
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-PTX_DEV uint32_t ptx_wave_max(uint32_t v) {
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-#endif
-#ifdef PTX_EMU
-#define PTX_NTHREADS 5u /* the emulation splits per-thread runs five ways so that the run/prefix logic is exercised */
-#else
-#define PTX_NTHREADS PTX_BLOCKDIM
-#endif
 #define PTX_MAX_THREADS 1024u
 #define PTX_BYTE_PAD 4u /* bytes the library allocates past the end of the action / mark_type columns (the row pass reads them a dword at a time) */
 #define PTX_UA 1 /* changes per thread in flight in the (rare) many-actor admission passes */
-#ifdef PTX_EMU
-#define PTX_FORA(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_UA)
-#else
-#define PTX_FORA(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = PTX_BLOCKDIM; i0 < _n; i0 += PTX_UA * _T)
-#endif
 #define PTX_INA(i0, u) PTX_IN(i0, u)
 #define PTX_IXA(i0, u) PTX_IX(i0, u)
 #ifndef PTX_AC
@@ -257,14 +65,15 @@ PTX_DEV uint32_t ptx_wave_max(uint32_t v) {
 #ifndef PTX_UM
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
 #endif
+#define PTX_NCLK 16
 
-/* uniform loop over groups of PTX_U consecutive items: every thread runs every step (g may be past the end) */
+/* the machine: gfx950 for the product; the CPU test-suite plays the workgroup with one host thread (tests/emu) */
 #ifdef PTX_EMU
-#define PTX_FORG(g, groups) \
-    for (uint32_t _ng = (groups), _k = 0, g = (_ng ? ptx_emu_ix(0, _ng) : 0); _k < _ng; ++_k, g = (_k < _ng ? ptx_emu_ix(_k, _ng) : 0))
+#include "../../tests/emu/ptx_platform_emu.h"
 #else
-#define PTX_FORG(g, groups) for (uint32_t _ng = (groups), _g0 = 0, g = threadIdx.x; _g0 < _ng; _g0 += PTX_BLOCKDIM, g += PTX_BLOCKDIM)
+#include "ptx_platform_gfx950.h"
 #endif
+
 
 /* kernel arguments: device pointers (host pointers under PTX_EMU) */
 struct PtxMergeArgs {
@@ -302,7 +111,6 @@ struct PtxMergeArgs {
 #endif
 #define PTX_TILE_4 128u  /* visible chars up to which the four LWW trees are resident at once */
 #define PTX_TILE_1 512u  /* tile of the visible axis for longer documents (one tree, reused per mark type) */
-#define PTX_NCLK 16
 #define PTX_SMALL_BUCKET 8u  /* child buckets up to this size: one lane per member */
 #define PTX_HUGE_BUCKET 32u  /* beyond this size: bitmap ranking, one bucket at a time */
 
@@ -343,93 +151,13 @@ PTX_DEV void ptx_raise(PtxHdr* H, uint32_t row, uint32_t level, uint32_t code) {
     ptx_atomic_min(&H->err, ((row * 2u + level) << 4) | code);
 }
 
+/* one LDS atomic per wave and half of the digest (a wave-level butterfly first) */
 PTX_DEV void ptx_digest_flush(PtxHdr* H, uint64_t h1, uint64_t h2) {
-#ifdef PTX_EMU
-    H->h1 += h1;
-    H->h2 += h2;
-#else
-    /* wave-level butterfly first: one LDS atomic per wave instead of per lane */
-    for (int d = 32; d >= 1; d >>= 1) {
-        h1 += (uint64_t)__shfl_xor((unsigned long long)h1, d, 64);
-        h2 += (uint64_t)__shfl_xor((unsigned long long)h2, d, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&H->h1, (unsigned long long)h1);
-        atomicAdd(&H->h2, (unsigned long long)h2);
-    }
-#endif
+    ptx_reduce_add64(&H->h1, (unsigned long long)h1);
+    ptx_reduce_add64(&H->h2, (unsigned long long)h2);
 }
 
-/* sum / max over the workgroup into LDS words (every thread calls them) */
-PTX_DEV void ptx_reduce_add64(unsigned long long* dst, unsigned long long v) {
-#ifdef PTX_EMU
-    *dst += v;
-#else
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(dst, v);
-#endif
-}
-PTX_DEV void ptx_reduce_add32(uint32_t* dst, uint32_t v) { /* every lane of the wave calls it: one LDS atomic per wave */
-#ifdef PTX_EMU
-    *dst += v;
-#else
-    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
-#endif
-}
-PTX_DEV void ptx_reduce_max32(uint32_t* dst, uint32_t v) {
-#ifdef PTX_EMU
-    if (v > *dst) *dst = v;
-#else
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o > v ? o : v;
-    }
-    if ((threadIdx.x & 63) == 0) atomicMax(dst, v);
-#endif
-}
 
-/* ---- block-wide exclusive scan of an LDS array (element k at a[k*STRIDE]), in place; returns the
- *      total (all threads call it; ends with a barrier) ---- */
-template <class T, int STRIDE, uint32_t kThreads>
-PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in LDS */, uint32_t div_magic = 0 /* as PTX_DIV_T; needed when kThreads == 0 */) {
-#ifdef PTX_EMU
-    uint32_t run = 0;
-    for (uint32_t j = 0; j < m; ++j) {
-        uint32_t v = a[j * STRIDE];
-        a[j * STRIDE] = (T)run;
-        run += v;
-    }
-    (void)tmp;
-    (void)div_magic;
-    return run;
-#else
-    const uint32_t T_ = PTX_BLOCKDIM, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (T_ + 63) >> 6;
-    const uint32_t chunk = kThreads ? (m + T_ - 1) / (kThreads ? kThreads : 1u) : (uint32_t)__umulhi(m + T_ - 1, div_magic);
-    const uint32_t lo = tid * chunk < m ? tid * chunk : m;
-    const uint32_t hi = lo + chunk < m ? lo + chunk : m;
-    uint32_t sum = 0;
-    for (uint32_t j = lo; j < hi; ++j) sum += a[j * STRIDE];
-    const uint32_t incl = ptx_wave_incl_scan(sum); /* DPP prefix sum: no LDS traffic */
-    if (lane == 63) tmp[wave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma nounroll
-    for (uint32_t w = 0; w < nwaves; ++w) { /* a workgroup has at most 16 waves: every thread sums the few wave totals itself */
-        const uint32_t t = tmp[w];
-        wbase += w < wave ? t : 0u;
-        total += t;
-    }
-    uint32_t run = wbase + incl - sum;
-    for (uint32_t j = lo; j < hi; ++j) {
-        uint32_t v = a[j * STRIDE];
-        a[j * STRIDE] = (T)run;
-        run += v;
-    }
-    __syncthreads();
-    return total;
-#endif
-}
 
 /* ---- bit-rank: one 8-byte LDS word per 32 positions = {bits, exclusive popcount prefix} ---- */
 struct PtxBitWord {
@@ -587,19 +315,7 @@ PTX_DEV void ptx_write_result(const PtxMergeArgs& A, uint32_t log, PtxHdr* H, ui
         r.digest[0] = status ? 0 : (uint64_t)H->h1;
         r.digest[1] = status ? 0 : (uint64_t)H->h2;
         A.res[log] = r;
-#ifndef PTX_EMU
-        if (kDiag && A.clocks) {
-            H->clk[PTX_NCLK] = ptx_clock();
-#pragma nounroll
-            for (int k = 0; k < PTX_NCLK; ++k) {
-                /* phase k = time from stamp k to the next recorded stamp */
-                if (H->clk[k] == 0) continue;
-                int j = k + 1;
-                while (j < PTX_NCLK && H->clk[j] == 0) ++j;
-                atomicAdd(&A.clocks[k], H->clk[j] - H->clk[k]);
-            }
-        }
-#endif
+        if (kDiag) ptx_flush_clocks(A.clocks, H->clk, PTX_NCLK);
     }
 }
 
@@ -687,21 +403,6 @@ PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
         }                                                          \
     } while (0)
 
-#ifdef PTX_EMU
-#define PTX_STAMP(k) ((void)0)
-#else
-/* only in the diagnostic build of the kernel (kDiag): phase cycle stamps and the early exit of the per-phase PMC runs */
-#define PTX_STAMP(k)                                                   \
-    do {                                                               \
-        if (kDiag) {                                                   \
-            if (A.clocks && threadIdx.x == 0) H->clk[k] = ptx_clock(); \
-            if ((k) != 0 && A.stop_after == (k)) {                     \
-                lds_high = bp.high;                                    \
-                return PTX_OK;                                         \
-            }                                                          \
-        }                                                              \
-    } while (0)
-#endif
 
 /* ================================================================================================ */
 /* Applies log `log`; returns its status (PTX_OK or a per-log PTX_ERR_*) and the LDS high-water mark.  The caller
@@ -792,29 +493,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             const uint32_t nwv_ = PTX_NWAVES;
             const uint32_t step = PTX_WS * PTX_AC; /* changes per wave and step */
             const uint32_t seg = ((C + nwv_ - 1u) / nwv_ + step - 1u) / step * step; /* changes per wave, whole steps */
-            /* PTX_AC consecutive headers / envelope rows of a lane; indices past `hi` are clamped, their effects masked.
-             * The library pads its copies of both columns, so the 16-byte loads may run past the last change. */
-#ifdef PTX_EMU
-#define PTX_ADM_HDRS(dst_, cl_) \
-    for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) dst_[u_] = c_hdr[(cl_) + u_ < C ? (cl_) + u_ : C - 1u];
-#define PTX_ADM_ENVS(dst_, cl_)                                                              \
-    for (uint32_t u_ = 0; u_ < PTX_AC; ++u_)                                                 \
-        for (uint32_t b_ = 0; b_ < 4u; ++b_) dst_[u_][b_] = c_env[(uint64_t)((cl_) + u_ < C ? (cl_) + u_ : C - 1u) * 4u + b_];
-#else
-#define PTX_ADM_HDRS(dst_, cl_)                                                              \
-    {                                                                                        \
-        struct __attribute__((packed, aligned(4))) PtxH4 { uint32_t v[PTX_AC]; };            \
-        const PtxH4 q_ = *(const PtxH4*)(c_hdr + (cl_));                                     \
-        _Pragma("unroll") for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) dst_[u_] = q_.v[u_];      \
-    }
-#define PTX_ADM_ENVS(dst_, cl_)                                                              \
-    {                                                                                        \
-        struct __attribute__((packed, aligned(4))) PtxE4 { uint16_t v[PTX_AC][4]; };         \
-        const PtxE4 q_ = *(const PtxE4*)(c_env + (uint64_t)(cl_) * 4u);                      \
-        _Pragma("unroll") for (uint32_t u_ = 0; u_ < PTX_AC; ++u_)                           \
-            _Pragma("unroll") for (uint32_t b_ = 0; b_ < 4u; ++b_) dst_[u_][b_] = q_.v[u_][b_]; \
-    }
-#endif
             /* FAST CHECK, one pass: every wave walks its segment with clocks RELATIVE to the segment's start (the loads of the next
              * step in flight), and keeps per actor a the range [emin, emax] of  seq - 1 - relative clock  over its changes (all must
              * equal the clock B[a] before the segment) and per actor b the maximum of  deps[b] - relative clock[b]  (must not exceed
@@ -1031,8 +709,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_ADM_LOAD
                 }
             }
-#undef PTX_ADM_HDRS
-#undef PTX_ADM_ENVS
             PTX_SYNC();
             bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
         } else if constexpr (!kManyActors) {
@@ -1204,17 +880,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #endif
         /* this thread's PTX_U1 consecutive rows of a step; indices past the end are clamped, their effects masked.  The two byte
          * columns are read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
-#ifdef PTX_EMU
-#define PTX_P1_BYTES(col_, r0_, dst_)                                    \
-    dst_ = 0;                                                            \
-    for (uint32_t u_ = 0; u_ < PTX_U1; ++u_) dst_ |= (uint32_t)col_[(r0_) + u_ < N ? (r0_) + u_ : N - 1u] << (8u * u_);
-#else
-#define PTX_P1_BYTES(col_, r0_, dst_)                                    \
-    {                                                                    \
-        struct __attribute__((packed, aligned(1))) PtxB4 { uint32_t v; };  \
-        dst_ = ((const PtxB4*)(col_ + ((r0_) < N ? (r0_) : N - 1u)))->v; \
-    }
-#endif
 #define PTX_P1_LOAD(g_, id_, a_, mt_)                                   \
     {                                                                   \
         const uint32_t r0_ = (g_) * PTX_U1;                             \
@@ -1294,7 +959,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #endif
         }
 #undef PTX_P1_LOAD
-#undef PTX_P1_BYTES
         if (badrow != 0xFFFFFFFFu) {
             /* which of the two: re-test the row */
             const uint64_t id = op_id[badrow];

@@ -1,0 +1,257 @@
+/*
+ * ptx_platform_gfx950.h — what the kernel sources (merge_core.h, replay_core.h, gen_core.h, change_core.h, cursor_core.h) need
+ * from the machine: the parallel-loop macros over a workgroup, LDS atomics, wave-level scans / reductions (DPP, shuffles, ballots),
+ * the block-wide scan, the wide loads of the row pass and of the admission walk, the phase stamps of the diagnostic build.
+ * This is the ONLY platform the product is built for: MI355X, gfx950, wave64.
+ *
+ * The CPU test-suite compiles the same kernel sources against tests/emu/ptx_platform_emu.h instead (one thread playing the
+ * workgroup, in three iteration orders) to check their logic where no GPU exists; merge_core.h picks the header, nothing else
+ * in csrc/ knows about the emulation.  Tunables (PTX_U, PTX_U1, PTX_AC ...) are defined by merge_core.h before this file.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#define PTX_HD __host__ __device__ static inline
+#define PTX_DEV __device__ __forceinline__
+#define PTX_SYNC() __syncthreads()
+/* threads per workgroup: a compile-time constant in the builds specialised for the usual launch shapes (kThreads != 0:
+ * the per-phase loop bounds and strides then fold, which removes a quarter of the scalar instructions), else blockDim.x */
+#define PTX_BLOCKDIM (kThreads ? kThreads : blockDim.x)
+#define PTX_FOR(i, n) _Pragma("nounroll") for (uint32_t i = threadIdx.x, _n = (n); i < _n; i += PTX_BLOCKDIM)
+#define PTX_LEADER if (threadIdx.x == 0)
+PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
+PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
+PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
+PTX_DEV void ptx_atomic_or64(unsigned long long* p, unsigned long long v) { (void)atomicOr(p, v); }
+PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__popc(x); }
+/* wave-aggregated append: ONE LDS atomic per wave, lanes get consecutive slots.  May be called in
+ * divergent control flow (the ballot covers the active lanes only). */
+PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+    uint32_t b = 0;
+    if (lane == leader) b = atomicAdd(cursor, (uint32_t)__popcll(m));
+    b = (uint32_t)__shfl((int)b, (int)leader, 64);
+    return b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+PTX_DEV uint64_t ptx_clock() { return (uint64_t)__builtin_readcyclecounter(); }
+#define PTX_G 8u /* lanes that share one member of a large child bucket */
+PTX_DEV uint32_t ptx_group_sum(uint32_t c) {
+    c += (uint32_t)__shfl_xor((int)c, 1, 64);
+    c += (uint32_t)__shfl_xor((int)c, 2, 64);
+    c += (uint32_t)__shfl_xor((int)c, 4, 64);
+    return c;
+}
+#define PTX_FORU(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = PTX_BLOCKDIM; i0 < _n; i0 += PTX_U * _T)
+#define PTX_IX(i0, u) ((i0) + (uint32_t)(u) * _T)
+
+/* ---- list slots for a batch of rows: rows of class c < 6 get consecutive slots from cursor[c], in ROW order
+ *      within the wave (lane-major, each lane holding PTX_U consecutive rows), so that the lists stay (nearly)
+ *      sorted by row and later gathers through them stay (nearly) coalesced.  One LDS atomic per wave and batch
+ *      (6 lanes, 6 distinct cursors); the ranking itself is a DPP prefix sum in registers.  Every lane of the
+ *      wave must call it (uniform control flow). ---- */
+PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1,3 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2,3 */
+    return v;
+}
+template <int U>
+PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slot) {
+    /* per-lane counts, 10 bits per class: classes 0..2 in w0, 3..5 in w1 (a wave holds at most 64 * U <= 1023 rows) */
+    uint32_t w0 = 0, w1 = 0, off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t c = cls[u];
+        const uint32_t sh = (c >= 3u ? c - 3u : c) * 10u;
+        off[u] = ((c >= 3u ? w1 : w0) >> sh) & 1023u;
+        w0 += (c < 3u ? 1u : 0u) << sh;
+        w1 += (c >= 3u && c < 6u ? 1u : 0u) << sh;
+    }
+    const uint32_t i0 = ptx_wave_incl_scan(w0), i1 = ptx_wave_incl_scan(w1);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t basev = 0;
+    if (lane < 6u) {
+        const uint32_t cnt = ((lane >= 3u ? t1 : t0) >> ((lane >= 3u ? lane - 3u : lane) * 10u)) & 1023u;
+        basev = atomicAdd(&cursor[lane], cnt);
+    }
+    const uint32_t e0 = i0 - w0, e1 = i1 - w1; /* exclusive prefix over the lower lanes */
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t c = cls[u];
+        const uint32_t sh = (c >= 3u ? c - 3u : c) * 10u;
+        const uint32_t b = (uint32_t)__shfl((int)basev, (int)(c & 7u), 64);
+        slot[u] = c < 6u ? b + (((c >= 3u ? e1 : e0) >> sh) & 1023u) + off[u] : 0xFFFFFFFFu;
+    }
+}
+
+/* Software-pipelined uniform loops: step st of `steps` handles group PTX_G_OF(st); the loads of step st+1 are
+ * issued before step st is processed (the caller keeps two register sets).  Every thread runs every step; a
+ * group index past the end means "no work" (its loads are clamped to valid addresses, its effects masked). */
+/* x / threads-per-workgroup without a division: the host passes magic = floor(2^32 / T) + 1, exact for x * T < 2^32
+ * (x is a row count + T here; a uniform integer division costs ~25 instructions per wave, and a log has a dozen) */
+#define PTX_DIV_T(x) (kThreads ? (uint32_t)(x) / (kThreads ? kThreads : 1u) : (uint32_t)__umulhi((uint32_t)(x), A.div_magic))
+#define PTX_STEPS(groups) PTX_DIV_T((groups) + PTX_BLOCKDIM - 1u)
+#define PTX_G_OF(st, steps) (threadIdx.x + (st) * PTX_BLOCKDIM)
+
+/* the same for loops over list items, PTX_U items per thread and step, lanes on consecutive items:
+ * step st, slot u handles item PTX_J_OF(st, u) (past the end = no work); PTX_JX maps it for the emulation's
+ * reversed order */
+#define PTX_JSTEPS_U(n, U) ((PTX_DIV_T((n) + PTX_BLOCKDIM - 1u) + (U)-1u) / (U)) /* = ceil(n / (U * T)) */
+#define PTX_J_OF_U(st, u, U) (((st) * (U) + (uint32_t)(u)) * PTX_BLOCKDIM + threadIdx.x)
+#define PTX_JX(j, n) (j)
+
+/* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
+ * emulation plays three one-lane waves in turn */
+#define PTX_WAVE_FIRST(g) ((g) - (threadIdx.x & 63u)) /* index handled by lane 0 of this wave */
+#define PTX_WS 64u
+#define PTX_NWAVES (PTX_BLOCKDIM >> 6)
+#define PTX_FOR_WAVE(w, lane) for (uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, _once = 1; _once; _once = 0)
+PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
+PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl_scan(v)); }
+PTX_DEV uint32_t ptx_wave_min(uint32_t v) { /* the same value in every lane */
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+PTX_DEV uint32_t ptx_wave_max(uint32_t v) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+#define PTX_NTHREADS PTX_BLOCKDIM
+
+#define PTX_FORA(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = PTX_BLOCKDIM; i0 < _n; i0 += PTX_UA * _T)
+
+/* uniform loop over groups of PTX_U consecutive items: every thread runs every step (g may be past the end) */
+#define PTX_FORG(g, groups) for (uint32_t _ng = (groups), _g0 = 0, g = threadIdx.x; _g0 < _ng; _g0 += PTX_BLOCKDIM, g += PTX_BLOCKDIM)
+
+/* sum / max over the workgroup into LDS words (every thread calls them) */
+PTX_DEV void ptx_reduce_add64(unsigned long long* dst, unsigned long long v) {
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, v);
+}
+
+PTX_DEV void ptx_reduce_add32(uint32_t* dst, uint32_t v) { /* every lane of the wave calls it: one LDS atomic per wave */
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
+
+PTX_DEV void ptx_reduce_max32(uint32_t* dst, uint32_t v) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(dst, v);
+}
+
+/* ---- block-wide exclusive scan of an LDS array (element k at a[k*STRIDE]), in place; returns the
+ *      total (all threads call it; ends with a barrier) ---- */
+template <class T, int STRIDE, uint32_t kThreads>
+PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in LDS */, uint32_t div_magic = 0 /* as PTX_DIV_T; needed when kThreads == 0 */) {
+    const uint32_t T_ = PTX_BLOCKDIM, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (T_ + 63) >> 6;
+    const uint32_t chunk = kThreads ? (m + T_ - 1) / (kThreads ? kThreads : 1u) : (uint32_t)__umulhi(m + T_ - 1, div_magic);
+    const uint32_t lo = tid * chunk < m ? tid * chunk : m;
+    const uint32_t hi = lo + chunk < m ? lo + chunk : m;
+    uint32_t sum = 0;
+    for (uint32_t j = lo; j < hi; ++j) sum += a[j * STRIDE];
+    const uint32_t incl = ptx_wave_incl_scan(sum); /* DPP prefix sum: no LDS traffic */
+    if (lane == 63) tmp[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma nounroll
+    for (uint32_t w = 0; w < nwaves; ++w) { /* a workgroup has at most 16 waves: every thread sums the few wave totals itself */
+        const uint32_t t = tmp[w];
+        wbase += w < wave ? t : 0u;
+        total += t;
+    }
+    uint32_t run = wbase + incl - sum;
+    for (uint32_t j = lo; j < hi; ++j) {
+        uint32_t v = a[j * STRIDE];
+        a[j * STRIDE] = (T)run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
+}
+
+/* diagnostic build only: phase k = time from stamp k to the next recorded stamp, summed over the logs */
+PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* clk, int nclk) {
+    if (!clocks) return;
+    clk[nclk] = ptx_clock();
+#pragma nounroll
+    for (int k = 0; k < nclk; ++k) {
+        if (clk[k] == 0) continue;
+        int j = k + 1;
+        while (j < nclk && clk[j] == 0) ++j;
+        atomicAdd(&clocks[k], clk[j] - clk[k]);
+    }
+}
+
+/* only in the diagnostic build of the kernel (kDiag): phase cycle stamps and the early exit of the per-phase PMC runs */
+#define PTX_STAMP(k)                                                   \
+    do {                                                               \
+        if (kDiag) {                                                   \
+            if (A.clocks && threadIdx.x == 0) H->clk[k] = ptx_clock(); \
+            if ((k) != 0 && A.stop_after == (k)) {                     \
+                lds_high = bp.high;                                    \
+                return PTX_OK;                                         \
+            }                                                          \
+        }                                                              \
+    } while (0)
+
+/* PTX_AC consecutive headers / envelope rows of a lane; indices past `hi` are clamped, their effects masked.
+ * The library pads its copies of both columns, so the 16-byte loads may run past the last change. */
+#define PTX_ADM_HDRS(dst_, cl_)                                                              \
+    {                                                                                        \
+        struct __attribute__((packed, aligned(4))) PtxH4 { uint32_t v[PTX_AC]; };            \
+        const PtxH4 q_ = *(const PtxH4*)(c_hdr + (cl_));                                     \
+        _Pragma("unroll") for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) dst_[u_] = q_.v[u_];      \
+    }
+#define PTX_ADM_ENVS(dst_, cl_)                                                              \
+    {                                                                                        \
+        struct __attribute__((packed, aligned(4))) PtxE4 { uint16_t v[PTX_AC][4]; };         \
+        const PtxE4 q_ = *(const PtxE4*)(c_env + (uint64_t)(cl_) * 4u);                      \
+        _Pragma("unroll") for (uint32_t u_ = 0; u_ < PTX_AC; ++u_)                           \
+            _Pragma("unroll") for (uint32_t b_ = 0; b_ < 4u; ++b_) dst_[u_][b_] = q_.v[u_][b_]; \
+    }
+
+/* the action / mark_type bytes of a thread's PTX_U1 consecutive rows from r0_ on, one byte each in dst_ (uses N): ONE unaligned
+ * 4-byte load; the library pads its copies of the byte columns by PTX_BYTE_PAD */
+#define PTX_P1_BYTES(col_, r0_, dst_)                                    \
+    {                                                                    \
+        struct __attribute__((packed, aligned(1))) PtxB4 { uint32_t v; };  \
+        dst_ = ((const PtxB4*)(col_ + ((r0_) < N ? (r0_) : N - 1u)))->v; \
+    }
+
+/* ---- gen_core.h / change_core.h: ONE wave per workgroup ---- */
+/* 64-wide ballot over lanes: `expr` may use `lane_` */
+#define PTX_BALLOT64(mask_, lane_, expr)                 \
+    uint64_t mask_;                                      \
+    {                                                    \
+        const uint32_t lane_ = threadIdx.x & 63u;        \
+        mask_ = __ballot(expr);                          \
+    }
+#define PTX_LANE0 (threadIdx.x == 0)
+#define PTX_GEN_FOR(i, n) for (uint32_t i = threadIdx.x, _gn = (n); i < _gn; i += 64u)
+#define PTX_MEM __device__ __forceinline__
+/* L[lo + 1 .. hi] = L[lo .. hi - 1] for hi - lo <= 64: every lane has read its element before any lane writes */
+PTX_DEV void ptx_shift_up64(uint32_t* L, uint32_t lo, uint32_t hi) {
+    const uint32_t i = lo + (threadIdx.x & 63u);
+    const uint32_t v = i < hi ? L[i] : 0u;
+    PTX_SYNC();
+    if (i < hi) L[i + 1u] = v;
+}

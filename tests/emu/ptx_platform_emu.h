@@ -1,0 +1,138 @@
+/*
+ * ptx_platform_emu.h — TEST INFRASTRUCTURE.  The interface of peritext_amd/csrc/ptx_platform_gfx950.h, played by ONE host
+ * thread: a "parallel" loop runs its iterations one after the other, in the order ptx_emu_reverse selects (forward, backward,
+ * a fixed pseudo-random permutation), so that tests/emu can check the kernels' logic — and its independence of the iteration
+ * order — in a container without a GPU.  Never linked into libperitext_hip.so; never a fallback of the product path.
+ */
+#pragma once
+#include <string.h>
+#define PTX_HD static inline
+#define PTX_DEV static inline
+#define PTX_SYNC() ((void)0)
+extern int ptx_emu_reverse; /* order of every emulated parallel loop: 0 forward, 1 backward, 2 a fixed pseudo-random permutation (order-independence checks) */
+static inline uint32_t ptx_emu_ix(uint32_t k, uint32_t n) { /* k-th iteration runs index ...; 104729 is a prime above any loop length here */
+    return ptx_emu_reverse == 0 ? k : ptx_emu_reverse == 1 ? n - 1u - k : (uint32_t)(((uint64_t)k * 104729ull + 7ull) % (n ? n : 1u));
+}
+#define PTX_FOR(i, n)                                                                              \
+    for (uint32_t _n = (n), _k = 0, i = (_n ? ptx_emu_ix(0, _n) : 0); _k < _n;                    \
+         ++_k, i = (_k < _n ? ptx_emu_ix(_k, _n) : 0))
+#define PTX_LEADER if (true)
+PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o & v; return o; }
+PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
+PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+PTX_DEV void ptx_atomic_or64(unsigned long long* p, unsigned long long v) { *p |= v; }
+PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+/* append to a list: index of this element (valid only where pred) */
+PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }
+PTX_DEV uint64_t ptx_clock() { return 0; }
+#define PTX_G 1u
+PTX_DEV uint32_t ptx_group_sum(uint32_t c) { return c; }
+/* batched parallel loop: PTX_U iterations per step so that their loads are all in flight together */
+#define PTX_FORU(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_U)
+#define PTX_IX(i0, u) ((i0) + (uint32_t)(u) < _n ? ptx_emu_ix((i0) + (uint32_t)(u), _n) : (i0) + (uint32_t)(u))
+
+/* ---- list slots for a batch of rows: rows of class c < 6 get consecutive slots from cursor[c], in ROW order
+ *      within the wave (lane-major, each lane holding PTX_U consecutive rows), so that the lists stay (nearly)
+ *      sorted by row and later gathers through them stay (nearly) coalesced.  One LDS atomic per wave and batch
+ *      (6 lanes, 6 distinct cursors); the ranking itself is a DPP prefix sum in registers.  Every lane of the
+ *      wave must call it (uniform control flow). ---- */
+template <int U>
+PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slot) {
+    for (int u = 0; u < U; ++u) slot[u] = cls[u] < 6u ? cursor[cls[u]]++ : 0xFFFFFFFFu;
+}
+
+/* Software-pipelined uniform loops: step st of `steps` handles group PTX_G_OF(st); the loads of step st+1 are
+ * issued before step st is processed (the caller keeps two register sets).  Every thread runs every step; a
+ * group index past the end means "no work" (its loads are clamped to valid addresses, its effects masked). */
+#define PTX_STEPS(groups) (groups)
+#define PTX_G_OF(st, steps) ((st) < (steps) ? ptx_emu_ix((st), (steps)) : (steps) + ((st) - (steps)))
+
+/* the same for loops over list items, PTX_U items per thread and step, lanes on consecutive items:
+ * step st, slot u handles item PTX_J_OF(st, u) (past the end = no work); PTX_JX maps it for the emulation's
+ * reversed order */
+#define PTX_JSTEPS_U(n, U) (((n) + (U)-1u) / (U))
+#define PTX_J_OF_U(st, u, U) ((st) * (U) + (uint32_t)(u))
+#define PTX_JX(j, n) ((j) < (n) ? ptx_emu_ix((j), (n)) : (j))
+
+/* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
+ * emulation plays three one-lane waves in turn */
+#define PTX_WAVE_FIRST(g) (g)
+#define PTX_WS 1u
+#define PTX_NWAVES 3u
+#define PTX_FOR_WAVE(w, lane) for (uint32_t w = 0, lane = 0; w < PTX_NWAVES; ++w)
+PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v) { return v; }
+PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return incl; }
+PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return v; }
+PTX_DEV uint32_t ptx_wave_min(uint32_t v) { return v; }
+PTX_DEV uint32_t ptx_wave_max(uint32_t v) { return v; }
+
+#define PTX_NTHREADS 5u /* the emulation splits per-thread runs five ways so that the run/prefix logic is exercised */
+
+#define PTX_FORA(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_UA)
+
+/* uniform loop over groups of PTX_U consecutive items: every thread runs every step (g may be past the end) */
+#define PTX_FORG(g, groups) \
+    for (uint32_t _ng = (groups), _k = 0, g = (_ng ? ptx_emu_ix(0, _ng) : 0); _k < _ng; ++_k, g = (_k < _ng ? ptx_emu_ix(_k, _ng) : 0))
+
+/* sum / max over the workgroup into LDS words (every thread calls them) */
+PTX_DEV void ptx_reduce_add64(unsigned long long* dst, unsigned long long v) {
+    *dst += v;
+}
+
+PTX_DEV void ptx_reduce_add32(uint32_t* dst, uint32_t v) { /* every lane of the wave calls it: one LDS atomic per wave */
+    *dst += v;
+}
+
+PTX_DEV void ptx_reduce_max32(uint32_t* dst, uint32_t v) {
+    if (v > *dst) *dst = v;
+}
+
+/* ---- block-wide exclusive scan of an LDS array (element k at a[k*STRIDE]), in place; returns the
+ *      total (all threads call it; ends with a barrier) ---- */
+template <class T, int STRIDE, uint32_t kThreads>
+PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in LDS */, uint32_t div_magic = 0 /* as PTX_DIV_T; needed when kThreads == 0 */) {
+    uint32_t run = 0;
+    for (uint32_t j = 0; j < m; ++j) {
+        uint32_t v = a[j * STRIDE];
+        a[j * STRIDE] = (T)run;
+        run += v;
+    }
+    (void)tmp;
+    (void)div_magic;
+    return run;
+}
+
+PTX_DEV void ptx_flush_clocks(unsigned long long*, unsigned long long*, int) {}
+
+/* phase stamps of the diagnostic build: nothing to stamp here */
+#define PTX_STAMP(k) ((void)0)
+
+/* PTX_AC consecutive headers / envelope rows of a lane; indices past `hi` are clamped, their effects masked.
+ * The library pads its copies of both columns, so the 16-byte loads may run past the last change. */
+#define PTX_ADM_HDRS(dst_, cl_) \
+    for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) dst_[u_] = c_hdr[(cl_) + u_ < C ? (cl_) + u_ : C - 1u];
+#define PTX_ADM_ENVS(dst_, cl_)                                                              \
+    for (uint32_t u_ = 0; u_ < PTX_AC; ++u_)                                                 \
+        for (uint32_t b_ = 0; b_ < 4u; ++b_) dst_[u_][b_] = c_env[(uint64_t)((cl_) + u_ < C ? (cl_) + u_ : C - 1u) * 4u + b_];
+
+/* the action / mark_type bytes of a thread's PTX_U1 consecutive rows from r0_ on, one byte each in dst_ (uses N) */
+#define PTX_P1_BYTES(col_, r0_, dst_)                                    \
+    dst_ = 0;                                                            \
+    for (uint32_t u_ = 0; u_ < PTX_U1; ++u_) dst_ |= (uint32_t)col_[(r0_) + u_ < N ? (r0_) + u_ : N - 1u] << (8u * u_);
+
+/* ---- gen_core.h / change_core.h: ONE wave per workgroup; the ballots are built lane by lane ---- */
+#define PTX_BALLOT64(mask_, lane_, expr)                 \
+    uint64_t mask_ = 0;                                  \
+    for (uint32_t lane_ = 0; lane_ < 64u; ++lane_)       \
+        if (expr) mask_ |= 1ull << lane_;
+#define PTX_LANE0 true
+#define PTX_GEN_FOR(i, n) for (uint32_t i = 0, _gn = (n); i < _gn; ++i)
+#define PTX_MEM inline
+PTX_DEV void ptx_shift_up64(uint32_t* L, uint32_t lo, uint32_t hi) {
+    uint32_t chunk[64];
+    for (uint32_t i = lo; i < hi; ++i) chunk[i - lo] = L[i];
+    for (uint32_t i = lo; i < hi; ++i) L[i + 1u] = chunk[i - lo];
+}

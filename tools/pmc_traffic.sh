@@ -1,7 +1,8 @@
 #!/bin/bash
-# HBM traffic of ptx_merge_kernel on the bench workload from rocprofv3 PMC counters, calibrated on a known byte count
-# (MI355X_MICROARCH.md "HBM"): separate passes for FETCH_SIZE and WRITE_SIZE (they do not fit one pass), --kernel-trace only.
-# Usage: tools/pmc_traffic.sh <tag> [traffic_run.py args]   ->  gpurun_out/traffic_<tag>/{fetch,write}.txt + hbm_traffic.json
+# HBM traffic of ptx_merge_kernel on the bench workload from rocprofv3 PMC counters (MI355X_MICROARCH.md "HBM"): separate passes,
+# --kernel-trace only.  Reads: FETCH_SIZE calibrated on a known byte count (gfx950 tallies 128-byte requests at 64) AND, exactly,
+# the L2's read requests by size (32 / 64 / 128 bytes); writes: WRITE_SIZE.
+# Usage: tools/pmc_traffic.sh <tag> [traffic_run.py args]   ->  gpurun_out/traffic_<tag>/{fetch,write,size}.txt + hbm_traffic.json
 set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -19,5 +20,6 @@ pass() {
 EXTRA=("$@")
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
+pass size TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
 python "$ROOT/tools/traffic_json.py" "$OUT" > "$OUT/hbm_traffic.json"
 cat "$OUT/hbm_traffic.json"
