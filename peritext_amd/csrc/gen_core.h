@@ -9,13 +9,18 @@
  * op-log columns + Change envelope of include/peritext_hip.h, written straight into HBM: a generated batch goes to
  * ptx_merge without ever visiting the host.
  *
- * State per replica, in LDS: the element list in document order, one u32 per element
- *   key = counter << 2 | actor   (integer order == compareOpIds order, micromerge.ts:812-827; actors "doc1".."doc4")
- *   bit 30 = tombstone, bit 31 = the element's `after` slot is a defined one (markOpsAfter !== undefined: set when a
- *   non-inclusive mark op ends on it, peritext.ts:240) — what `lookAfterTombstones` looks at.
+ * State per replica, in LDS: the element list in document order,
+ *   key = counter << 2 | actor   (integer order == compareOpIds order, micromerge.ts:812-827; actors "doc1".."doc4"), u16 while
+ *         the counters of the document stay below 2^14 (ptx_gen_small_keys), else u32: 16 bytes = 8 or 4 keys per lane and read
+ *   two bit planes by list position: `dead` = tombstone, `after` = the element's `after` slot is a defined one
+ *         (markOpsAfter !== undefined: set when a non-inclusive mark op ends on it, peritext.ts:240) — what `lookAfterTombstones`
+ *         looks at.  The k-th visible element is one popcount scan over the `dead` plane.
  * plus clock / maxOp / visible length.  Marks need no other state to GENERATE ops.
- * Everything is uniform control flow over one wave; the list primitives (find an id, select the k-th visible element,
- * skip / shift on insert) are 64-wide ballots.  The emulation (PTX_EMU) builds the same ballots lane by lane.
+ * Everything is uniform control flow over ONE wave: lanes talk through LDS with PTX_WSYNC (a compiler fence: the LDS serves a wave's
+ * accesses in order); the full barrier, which also waits for the wave's outstanding stores to HBM, only stands where rows, change
+ * records or comment ids written earlier are read back (deliver, the first change, `known`, the final remap).
+ * Uniform control flow throughout; the list primitives (find an id, select the k-th visible element, open a
+ * gap) live in ptx_platform_gfx950.h.  change_core.h keeps the older one-word-per-element form (ptx_gen_select & co below).
  */
 #pragma once
 #include "merge_core.h"
@@ -78,8 +83,14 @@ struct PtxGenHdr {
     uint32_t scan_tmp[36];
 };
 
+/* u16 keys while every counter of the document fits 14 bits (a document makes R * ops_per_log + 1 ops) */
+PTX_HD bool ptx_gen_small_keys(uint64_t R, uint64_t rows_per_log) { return R * rows_per_log + 8 < (1u << 14); }
+PTX_HD uint64_t ptx_gen_list_stride(uint64_t list_cap) { return (list_cap + 64 + 15) & ~15ull; } /* keys per replica: whole 16-byte blocks + slack */
+PTX_HD uint64_t ptx_gen_plane_words(uint64_t list_cap) { return (ptx_gen_list_stride(list_cap) >> 5) + 2; }
 PTX_HD uint64_t ptx_gen_lds_need(uint64_t R, uint64_t list_cap, uint64_t rows_per_log) {
-    return ptx_a16(sizeof(PtxGenHdr)) + ptx_a16(4 * R * ((list_cap + 64 + 3) & ~3ull)) + ptx_a16(4 * ((rows_per_log >> 5) + 2));
+    const uint64_t kb = ptx_gen_small_keys(R, rows_per_log) ? 2 : 4;
+    return ptx_a16(sizeof(PtxGenHdr)) + ptx_a16(kb * R * ptx_gen_list_stride(list_cap)) + 2 * ptx_a16(4 * R * ptx_gen_plane_words(list_cap)) +
+           ptx_a16(4 * ((rows_per_log >> 5) + 2));
 }
 
 /* 64-wide ballots (PTX_BALLOT64), PTX_LANE0, PTX_GEN_FOR: ptx_platform_gfx950.h */
@@ -166,12 +177,14 @@ PTX_DEV bool ptx_gen_str_less(uint32_t j, uint32_t k) {
     return jp != k ? jp < k : false;
 }
 
-template <uint32_t kThreads>
+template <uint32_t kThreads, class KeyT>
 struct PtxGenDoc {
     const PtxGenArgs& A;
     PtxGenHdr* H;
-    uint32_t* lst0;      /* replica r's list = lst0 + r * lst_stride (no pointer table: nothing of this kernel lives in scratch) */
-    uint32_t lst_stride;
+    KeyT* key0;          /* replica r's keys = key0 + r * lst_stride (no pointer table: nothing of this kernel lives in scratch) */
+    uint32_t* dead0;     /* its planes = dead0 / after0 + r * plane_words */
+    uint32_t* after0;
+    uint32_t lst_stride, plane_words;
     uint32_t* done;   /* pending-change bitmap of a delivery */
     uint16_t* crank;  /* comment counter -> doc-local rank */
     uint64_t row0;    /* first row of replica 0's log */
@@ -180,55 +193,55 @@ struct PtxGenDoc {
     uint32_t cap;
 
     PTX_MEM uint64_t log_base(uint32_t r) const { return row0 + (uint64_t)r * A.rows_per_log; }
-    PTX_MEM uint32_t* lst(uint32_t r) const { return lst0 + (uint64_t)r * lst_stride; }
+    PTX_MEM KeyT* keys(uint32_t r) const { return key0 + (uint64_t)r * lst_stride; }
+    PTX_MEM uint32_t* dead(uint32_t r) const { return dead0 + (uint64_t)r * plane_words; }
+    PTX_MEM uint32_t* after(uint32_t r) const { return after0 + (uint64_t)r * plane_words; }
+    /* id of the element at position p of replica r's list */
+    PTX_MEM uint64_t id_at(uint32_t r, uint32_t p) const { return ptx_gen_id_of(keys(r)[p]); }
 
     /* applyOp on replica r's list (micromerge.ts:614-640 insert, :677-695 delete; for marks only the `after` flag) */
     PTX_MEM void apply(uint32_t r, const PtxGenRow& o) {
-        uint32_t* L = lst(r);
+        KeyT* L = keys(r);
         const uint32_t n = H->n[r];
         if (o.action == PTX_ACT_INSERT) {
             const uint32_t key = ptx_gen_key_of(o.op_id);
             uint32_t at = 0;
-            if (o.ref_a != 0) at = ptx_gen_find(L, n, ptx_gen_key_of(o.ref_a)) + 1u; /* the reference element exists (causal delivery) */
+            if (o.ref_a != 0) at = ptx_list_find<KeyT>(L, n, ptx_gen_key_of(o.ref_a)) + 1u; /* the reference element exists (causal delivery) */
             /* skip the elements with a greater id (concurrent inserts at the same spot, :630-635) */
             for (;;) {
-                PTX_BALLOT64(stop, l, at + l >= n || (L[at + l] & PTX_GK_KEY) < key)
+                PTX_BALLOT64(stop, l, at + l >= n || (uint32_t)L[at + l] < key)
                 if (stop) {
                     at += ptx_ffs64(stop);
                     break;
                 }
                 at += 64u;
             }
-            if (n + 1u > cap) {
+            if (n + 1u > cap || key > (uint32_t)(KeyT)~(KeyT)0) { /* the list, or the key type, is too small for this document */
                 if (PTX_LANE0) H->overflow = 1;
-                PTX_SYNC();
+                PTX_WSYNC();
                 return;
             }
-            /* open the gap: the tail moves up by one, 64 elements at a time from the END (one wave: every lane has read its element
-             * before any lane writes, and a chunk only writes above what the chunks still to come read) */
-            for (uint32_t hi = n; hi > at;) {
-                const uint32_t lo = hi - at > 64u ? hi - 64u : at;
-                ptx_shift_up64(L, lo, hi);
-                PTX_SYNC();
-                hi = lo;
-            }
+            /* open the gap in the keys and in both planes (the new element is alive, its `after` slot undefined) */
+            ptx_list_shift_up<KeyT>(L, at, n);
+            ptx_plane_shift_up(dead(r), at, n);
+            ptx_plane_shift_up(after(r), at, n);
             if (PTX_LANE0) {
-                L[at] = key;
+                L[at] = (KeyT)key;
                 H->n[r] = n + 1u;
                 H->vis[r] += 1u;
             }
-            PTX_SYNC();
+            PTX_WSYNC();
         } else if (o.action == PTX_ACT_DELETE) {
-            const uint32_t p = ptx_gen_find(L, n, ptx_gen_key_of(o.ref_a));
-            if (PTX_LANE0 && p != 0xFFFFFFFFu && !(L[p] & PTX_GK_DEAD)) {
-                L[p] |= PTX_GK_DEAD;
+            const uint32_t p = ptx_list_find<KeyT>(L, n, ptx_gen_key_of(o.ref_a));
+            if (PTX_LANE0 && p != 0xFFFFFFFFu && !((dead(r)[p >> 5] >> (p & 31u)) & 1u)) {
+                dead(r)[p >> 5] |= 1u << (p & 31u);
                 H->vis[r] -= 1u;
             }
-            PTX_SYNC();
+            PTX_WSYNC();
         } else if ((o.action == PTX_ACT_ADDMARK || o.action == PTX_ACT_REMOVEMARK) && o.side_b == PTX_SIDE_AFTER) {
-            const uint32_t p = ptx_gen_find(L, n, ptx_gen_key_of(o.ref_b));
-            if (PTX_LANE0 && p != 0xFFFFFFFFu) L[p] |= PTX_GK_AFTER;
-            PTX_SYNC();
+            const uint32_t p = ptx_list_find<KeyT>(L, n, ptx_gen_key_of(o.ref_b));
+            if (PTX_LANE0 && p != 0xFFFFFFFFu) after(r)[p >> 5] |= 1u << (p & 31u);
+            PTX_WSYNC();
         }
     }
 
@@ -245,9 +258,9 @@ struct PtxGenDoc {
             A.side_a[at] = o.side_a;
             A.side_b[at] = o.side_b;
         }
-        PTX_SYNC();
+        PTX_WSYNC();
         if (PTX_LANE0) H->rows[r] = k + 1u;
-        PTX_SYNC();
+        PTX_WSYNC();
     }
     PTX_MEM PtxGenRow read_row(uint32_t r, uint32_t k) const {
         const uint64_t at = log_base(r) + k;
@@ -272,7 +285,7 @@ struct PtxGenDoc {
             for (uint32_t b = 0; b < es; ++b) A.chg_env[at * es + b] = (uint16_t)(b == 0 ? seq : b <= A.R ? ptx_gen_dep(c, b - 1u) : 0u);
             H->chgs[r] = k + 1u;
         }
-        PTX_SYNC();
+        PTX_WSYNC();
     }
     PTX_MEM void note_comment(uint32_t r, const PtxGenRow& o) {
         if (o.action == PTX_ACT_ADDMARK && o.mark_type == PTX_MARK_COMMENT) {
@@ -281,7 +294,7 @@ struct PtxGenDoc {
                 if (k < A.rows_per_log) known[(uint64_t)r * A.rows_per_log + k] = (uint16_t)o.payload;
                 H->nknown[r] = k + 1u;
             }
-            PTX_SYNC();
+            PTX_WSYNC();
         }
     }
 
@@ -303,7 +316,7 @@ struct PtxGenDoc {
             const uint32_t last = start + nops - 1u;
             if (last > H->max_op[dst]) H->max_op[dst] = last;
         }
-        PTX_SYNC();
+        PTX_WSYNC();
         record(dst, actor, s + 1u, c);
         return true;
     }
@@ -324,7 +337,7 @@ struct PtxGenDoc {
                 H->phi[a] = H->clock[src][a] > l ? H->clock[src][a] : l;
             }
         PTX_GEN_FOR(w, (total >> 5) + 1u) done[w] = 0;
-        PTX_SYNC();
+        PTX_WSYNC();
         uint32_t remaining = total;
         for (uint32_t pass = 0; remaining && pass <= total; ++pass) {
             uint32_t idx = 0;
@@ -333,7 +346,7 @@ struct PtxGenDoc {
                     if ((done[idx >> 5] >> (idx & 31)) & 1u) continue;
                     if (deliver_one(dst, a, s)) {
                         if (PTX_LANE0) done[idx >> 5] |= 1u << (idx & 31);
-                        PTX_SYNC();
+                        PTX_WSYNC();
                         --remaining;
                     }
                 }
@@ -343,9 +356,9 @@ struct PtxGenDoc {
     /* one emitted op of change(): id = maxOp + 1, applied locally at once (micromerge.ts:483-493) */
     PTX_MEM void emit(uint32_t k, PtxGenRow o, uint32_t& nops) {
         const uint32_t ctr = H->max_op[k] + 1u;
-        PTX_SYNC();
+        PTX_WSYNC();
         if (PTX_LANE0) H->max_op[k] = ctr;
-        PTX_SYNC();
+        PTX_WSYNC();
         o.op_id = ((uint64_t)ctr << 32) | k;
         apply(k, o);
         write_row(k, o);
@@ -354,8 +367,8 @@ struct PtxGenDoc {
     }
 };
 
-template <uint32_t kThreads>
-PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) {
+template <uint32_t kThreads, class KeyT>
+PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) {
     PtxGenHdr* H = (PtxGenHdr*)lds;
     const uint32_t R = A.R, N = A.rows_per_log;
     PtxBump bp;
@@ -364,15 +377,18 @@ PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) 
     bp.cap = A.lds_bytes;
     bp.high = bp.off;
     bp.overflow = false;
-    PtxGenDoc<kThreads> G{A, H, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, A.list_cap};
-    G.lst_stride = (A.list_cap + 64u + 3u) & ~3u;
-    G.lst0 = ptx_alloc<uint32_t>(bp, G.lst_stride * R);
+    PtxGenDoc<kThreads, KeyT> G{A, H, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, A.list_cap};
+    G.lst_stride = (uint32_t)ptx_gen_list_stride(A.list_cap);
+    G.plane_words = (uint32_t)ptx_gen_plane_words(A.list_cap);
+    G.key0 = ptx_alloc<KeyT>(bp, G.lst_stride * R);
+    G.dead0 = ptx_alloc<uint32_t>(bp, G.plane_words * R);
+    G.after0 = ptx_alloc<uint32_t>(bp, G.plane_words * R);
     G.done = ptx_alloc<uint32_t>(bp, (N >> 5) + 2);
-    G.crank = (uint16_t*)G.lst0; /* needed once the documents are finished and the lists dead: R * stride * 4 >= 2 * (N + 1) is checked below */
+    G.crank = (uint16_t*)G.key0; /* needed once the documents are finished and the lists dead: its size is checked below */
     G.row0 = (uint64_t)doc_local * R * N;
     G.ctab = A.ctab + (uint64_t)doc_local * R * N;
     G.known = A.known + (uint64_t)doc_local * R * N;
-    if (bp.overflow || R == 0 || R > PTX_GEN_MAX_R || N > 0xFFFFFFu || (uint64_t)G.lst_stride * R * 4u < 2ull * (N + 1u)) {
+    if (bp.overflow || R == 0 || R > PTX_GEN_MAX_R || N > 0xFFFFFFu || (uint64_t)G.lst_stride * R * sizeof(KeyT) < 2ull * (N + 1u)) {
         if (PTX_LANE0) {
             A.status[doc_local] = PTX_ERR_CAPACITY;
             A.n_comments[doc_local] = 0;
@@ -388,7 +404,11 @@ PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) 
         H->overflow = 0;
         H->tmp = 0;
     }
-    PTX_SYNC();
+    PTX_GEN_FOR(w, G.plane_words * R) {
+        G.dead0[w] = 0;
+        G.after0[w] = 0;
+    }
+    PTX_WSYNC();
 
     /* docSeed (ptxgen.js:62-64) */
     uint32_t rng = (0x5eed0000u + (A.first_doc + doc_local)) ^ (A.seed * 0x9e3779b1u);
@@ -403,13 +423,13 @@ PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) 
     c_.deps23 = H->clock[ck_][2] | (H->clock[ck_][3] << 16);                                     \
     c_.rowoff = H->rows[ck_];                                                                    \
     const uint32_t seq_ = H->clock[ck_][ck_] + 1u, start_ = H->max_op[ck_] + 1u;                 \
-    PTX_SYNC();                                                                                  \
+    PTX_WSYNC();                                                                                 \
     if (PTX_LANE0) H->clock[ck_][ck_] = seq_;                                                    \
-    PTX_SYNC();
+    PTX_WSYNC();
 #define PTX_GEN_CHANGE_END()                                                                     \
     c_.nops_start = (nops_ << 24) | start_;                                                      \
     if (PTX_LANE0) G.ctab[(uint64_t)ck_ * N + (seq_ - 1u)] = c_;                                 \
-    PTX_SYNC();                                                                                  \
+    PTX_WSYNC();                                                                                 \
     G.record(ck_, ck_, seq_, c_);
 
     /* generateDocs (ptxgen.js:109-121): doc1 creates the list + the initial text, everybody applies it */
@@ -432,6 +452,7 @@ PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) 
         }
         PTX_GEN_CHANGE_END()
     }
+    PTX_SYNC(); /* the first change is read back from HBM */
     for (uint32_t i = 1; i < R; ++i) G.deliver_one(i, 0u, 0u);
     uint32_t ops_so_far = A.init_len;
 
@@ -456,8 +477,8 @@ PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) 
             if (nvals > budget) nvals = budget;
             uint64_t ref = 0;
             if (index != 0u) {
-                const uint32_t p = ptx_gen_select(G.lst(k), H->n[k], index - 1u);
-                ref = ptx_gen_id_of(G.lst(k)[ptx_gen_after_tombstones(G.lst(k), H->n[k], p)] & PTX_GK_KEY);
+                const uint32_t p = ptx_plane_select0(G.dead(k), H->n[k], index - 1u);
+                ref = G.id_at(k, ptx_plane_after_tombstones(G.dead(k), G.after(k), H->n[k], p));
             }
             for (uint32_t v = 0; v < nvals; ++v) {
                 const uint32_t h = ptx_gen_rand(rng, 16u);
@@ -474,9 +495,9 @@ PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) 
             uint32_t count = 1u + ptx_gen_rand(rng, room < 3u ? room : 3u);
             if (count > budget) count = budget;
             for (uint32_t q = 0; q < count; ++q) {
-                const uint32_t p = ptx_gen_select(G.lst(k), H->n[k], index);
+                const uint32_t p = ptx_plane_select0(G.dead(k), H->n[k], index);
                 o.action = PTX_ACT_DELETE;
-                o.ref_a = ptx_gen_id_of(G.lst(k)[p] & PTX_GK_KEY);
+                o.ref_a = G.id_at(k, p);
                 G.emit(k, o, nops_);
             }
         } else {
@@ -492,23 +513,26 @@ PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) 
             } else if (mt == PTX_MARK_COMMENT) {
                 if (!add && H->nknown[k] == 0u) add = true;
                 if (add) pay = comment_counter++;
-                else pay = G.known[(uint64_t)k * N + ptx_gen_rand(rng, H->nknown[k])];
+                else {
+                    PTX_SYNC(); /* `known` is written by this wave (note_comment) */
+                    pay = G.known[(uint64_t)k * N + ptx_gen_rand(rng, H->nknown[k])];
+                }
             }
             const bool inclusive = mt == PTX_MARK_STRONG || mt == PTX_MARK_EM; /* schema.ts:45-96 */
             o.action = add ? PTX_ACT_ADDMARK : PTX_ACT_REMOVEMARK;
             o.mark_type = (uint8_t)mt;
             o.payload = pay;
             o.side_a = PTX_SIDE_BEFORE;
-            o.ref_a = ptx_gen_id_of(G.lst(k)[ptx_gen_select(G.lst(k), H->n[k], start_index)] & PTX_GK_KEY);
+            o.ref_a = G.id_at(k, ptx_plane_select0(G.dead(k), H->n[k], start_index));
             if (inclusive && end_index >= len) {
                 o.side_b = PTX_SIDE_END_OF_TEXT;
                 o.ref_b = 0;
             } else if (inclusive) {
                 o.side_b = PTX_SIDE_BEFORE;
-                o.ref_b = ptx_gen_id_of(G.lst(k)[ptx_gen_select(G.lst(k), H->n[k], end_index)] & PTX_GK_KEY);
+                o.ref_b = G.id_at(k, ptx_plane_select0(G.dead(k), H->n[k], end_index));
             } else {
                 o.side_b = PTX_SIDE_AFTER;
-                o.ref_b = ptx_gen_id_of(G.lst(k)[ptx_gen_select(G.lst(k), H->n[k], end_index - 1u)] & PTX_GK_KEY);
+                o.ref_b = G.id_at(k, ptx_plane_select0(G.dead(k), H->n[k], end_index - 1u));
             }
             G.emit(k, o, nops_);
         }
@@ -547,7 +571,7 @@ PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) 
                 A.payload[b0 + i] = G.crank[A.payload[b0 + i]];
         }
     }
-    PTX_SYNC();
+    PTX_WSYNC();
     if (PTX_LANE0) {
         bool bad = H->overflow != 0;
         for (uint32_t r = 0; r < R; ++r) {
@@ -557,4 +581,11 @@ PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) 
         A.n_comments[doc_local] = C;
         A.status[doc_local] = bad ? (uint32_t)PTX_ERR_CAPACITY : (uint32_t)PTX_OK;
     }
+}
+
+/* one document: the key width follows from the size of the document */
+template <uint32_t kThreads>
+PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) {
+    if (ptx_gen_small_keys(A.R, A.rows_per_log)) ptx_gen_doc_keyed<kThreads, uint16_t>(A, doc_local, lds);
+    else ptx_gen_doc_keyed<kThreads, uint32_t>(A, doc_local, lds);
 }

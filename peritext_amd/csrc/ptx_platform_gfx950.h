@@ -248,10 +248,157 @@ PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* cl
 #define PTX_LANE0 (threadIdx.x == 0)
 #define PTX_GEN_FOR(i, n) for (uint32_t i = threadIdx.x, _gn = (n); i < _gn; i += 64u)
 #define PTX_MEM __device__ __forceinline__
+/* lanes of ONE wave talking through LDS: the LDS serves a wave's accesses in issue order, so only the compiler has to be kept from
+ * moving or forwarding them — no s_barrier and, above all, no wait for the wave's outstanding stores to HBM (__syncthreads has one) */
+#define PTX_WSYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
 /* L[lo + 1 .. hi] = L[lo .. hi - 1] for hi - lo <= 64: every lane has read its element before any lane writes */
 PTX_DEV void ptx_shift_up64(uint32_t* L, uint32_t lo, uint32_t hi) {
     const uint32_t i = lo + (threadIdx.x & 63u);
     const uint32_t v = i < hi ? L[i] : 0u;
     PTX_SYNC();
     if (i < hi) L[i + 1u] = v;
+}
+
+/* ---- element lists of the one-wave kernels (gen_core.h): keys in document order (KeyT = u16 or u32, 16-byte aligned, read
+ *      16 bytes per lane) + one bit per position in planes.  Every lane of the wave calls these. ---- */
+template <class KeyT>
+PTX_DEV uint32_t ptx_list_key_at(const uint32_t (&w)[4], uint32_t j) { /* element j of a 16-byte block */
+    return sizeof(KeyT) == 2 ? (w[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu : w[j];
+}
+/* position of `key` among keys[0 .. n), or 0xFFFFFFFF (keys are unique) */
+template <class KeyT>
+PTX_DEV uint32_t ptx_list_find(const KeyT* keys, uint32_t n, uint32_t key) {
+    constexpr uint32_t W = 16u / (uint32_t)sizeof(KeyT);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = 0; base < n; base += 64u * W) {
+        const uint32_t i0 = base + lane * W;
+        uint32_t hit = 0xFFFFFFFFu;
+        if (i0 < n) {
+            const uint4 v = *(const uint4*)(keys + i0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t j = 0; j < W; ++j)
+                if (i0 + j < n && ptx_list_key_at<KeyT>(w, j) == key) hit = j;
+        }
+        const unsigned long long m = __ballot(hit != 0xFFFFFFFFu);
+        if (m) {
+            const uint32_t l = (uint32_t)__ffsll((long long)m) - 1u;
+            return base + l * W + (uint32_t)__shfl((int)hit, (int)l, 64);
+        }
+    }
+    return 0xFFFFFFFFu;
+}
+/* keys[at + 1 .. n] = keys[at .. n - 1] (keys[at] is left for the caller): whole 16-byte blocks, 64 of them per step, from the
+ * top down; a block's new content = its old one moved up by one key, the key that enters from below read separately */
+template <class KeyT>
+PTX_DEV void ptx_list_shift_up(KeyT* keys, uint32_t at, uint32_t n) {
+    constexpr uint32_t W = 16u / (uint32_t)sizeof(KeyT);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b_at = at / W, b_top = n / W; /* position n (the new last element) lives in block b_top */
+    for (uint32_t bh = b_top + 1u; bh > b_at;) {
+        const uint32_t bl = bh - b_at > 64u ? bh - 64u : b_at;
+        const uint32_t b = bl + lane;
+        const bool act = b < bh;
+        uint32_t w[4] = {0u, 0u, 0u, 0u}, prev = 0u;
+        if (act) {
+            const uint4 v = *(const uint4*)(keys + b * W);
+            w[0] = v.x;
+            w[1] = v.y;
+            w[2] = v.z;
+            w[3] = v.w;
+            if (b * W > at) prev = keys[b * W - 1u];
+        }
+        PTX_WSYNC(); /* every lane has read before any lane writes; a lower chunk is only rewritten after the chunks above it */
+        if (act) {
+            uint32_t o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (uint32_t j = 0; j < W; ++j) {
+                const uint32_t old_j = ptx_list_key_at<KeyT>(w, j), below = j ? ptx_list_key_at<KeyT>(w, j - 1u) : prev;
+                const uint32_t nj = b * W + j > at ? below : old_j;
+                if (sizeof(KeyT) == 2) o[j >> 1] |= nj << (16u * (j & 1u));
+                else o[j] = nj;
+            }
+            *(uint4*)(keys + b * W) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        PTX_WSYNC();
+        bh = bl;
+    }
+}
+/* the same for a bit plane: bits at + 1 .. n = old bits at .. n - 1, bit `at` = 0 */
+PTX_DEV void ptx_plane_shift_up(uint32_t* plane, uint32_t at, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w0 = at >> 5, w1 = n >> 5;
+    for (uint32_t wh = w1 + 1u; wh > w0;) {
+        const uint32_t wl = wh - w0 > 64u ? wh - 64u : w0;
+        const uint32_t w = wl + lane;
+        const bool act = w < wh;
+        const uint32_t cur = act ? plane[w] : 0u, prv = act && w > w0 ? plane[w - 1u] : 0u;
+        PTX_WSYNC();
+        if (act) {
+            const uint32_t low = (1u << (at & 31u)) - 1u;
+            plane[w] = w == w0 ? (cur & low) | ((cur & ~low) << 1) : (cur << 1) | (prv >> 31);
+        }
+        PTX_WSYNC();
+        wh = wl;
+    }
+}
+/* position of the k-th (0-based) ZERO bit of plane among positions [0, n), or 0xFFFFFFFF */
+PTX_DEV uint32_t ptx_plane_select0(const uint32_t* plane, uint32_t n, uint32_t k) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t seen = 0;
+    for (uint32_t bw = 0; (bw << 5) < n; bw += 64u) {
+        const uint32_t w = bw + lane;
+        uint32_t a = 0;
+        if ((w << 5) < n) {
+            a = ~plane[w];
+            if ((w << 5) + 32u > n) a &= (1u << (n & 31u)) - 1u;
+        }
+        const uint32_t c = ptx_popc(a), incl = ptx_wave_incl_scan(c), total = ptx_wave_last(incl);
+        if (k < seen + total) {
+            const unsigned long long m = __ballot(seen + incl > k);
+            const uint32_t l = (uint32_t)__ffsll((long long)m) - 1u;
+            uint32_t x = (uint32_t)__shfl((int)a, (int)l, 64);
+            const uint32_t before = seen + (uint32_t)__shfl((int)(incl - c), (int)l, 64);
+            for (uint32_t r = k - before; r; --r) x &= x - 1u;
+            return ((bw + l) << 5) + (uint32_t)__builtin_ctz(x);
+        }
+        seen += total;
+    }
+    return 0xFFFFFFFFu;
+}
+/* lookAfterTombstones on planes: from the visible element at `pos`, over the directly following tombstones (dead bits): the
+ * LAST one whose `after` bit is set, else pos.  Both planes are zero from position n on. */
+PTX_DEV uint32_t ptx_plane_after_tombstones(const uint32_t* dead, const uint32_t* after, uint32_t n, uint32_t pos) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w0 = pos >> 5;
+    uint32_t pick = pos;
+    for (uint32_t bw = w0; (bw << 5) < n; bw += 64u) {
+        const uint32_t w = bw + lane;
+        uint32_t d = 0, vm = 0;
+        if ((w << 5) < n) {
+            d = dead[w];
+            vm = (w << 5) + 32u <= n ? 0xFFFFFFFFu : (1u << (n & 31u)) - 1u;
+        }
+        const uint32_t above = w == w0 ? ~((2u << (pos & 31u)) - 1u) : 0xFFFFFFFFu; /* strictly above pos */
+        const uint32_t alive = ~d & vm & above;
+        uint32_t mk = (w << 5) < n ? d & after[w] & above : 0u;
+        const unsigned long long ma = __ballot(alive != 0u);
+        if (ma) { /* the next visible element ends the run of tombstones */
+            const uint32_t l = (uint32_t)__ffsll((long long)ma) - 1u;
+            const uint32_t nb = (uint32_t)__builtin_ctz((uint32_t)__shfl((int)alive, (int)l, 64));
+            if (lane > l) mk = 0;
+            if (lane == l) mk &= (1u << nb) - 1u;
+        }
+        const unsigned long long mm = __ballot(mk != 0u);
+        if (mm) {
+            const uint32_t l2 = 63u - (uint32_t)__builtin_clzll(mm);
+            pick = ((bw + l2) << 5) + 31u - (uint32_t)__builtin_clz((uint32_t)__shfl((int)mk, (int)l2, 64));
+        }
+        if (ma) break;
+    }
+    return pick;
 }

@@ -131,8 +131,41 @@ PTX_DEV void ptx_flush_clocks(unsigned long long*, unsigned long long*, int) {}
 #define PTX_LANE0 true
 #define PTX_GEN_FOR(i, n) for (uint32_t i = 0, _gn = (n); i < _gn; ++i)
 #define PTX_MEM inline
+#define PTX_WSYNC() ((void)0)
 PTX_DEV void ptx_shift_up64(uint32_t* L, uint32_t lo, uint32_t hi) {
     uint32_t chunk[64];
     for (uint32_t i = lo; i < hi; ++i) chunk[i - lo] = L[i];
     for (uint32_t i = lo; i < hi; ++i) L[i + 1u] = chunk[i - lo];
+}
+
+/* ---- element lists of the one-wave kernels (gen_core.h): plain loops ---- */
+template <class KeyT>
+PTX_DEV uint32_t ptx_list_find(const KeyT* keys, uint32_t n, uint32_t key) {
+    for (uint32_t i = 0; i < n; ++i)
+        if (keys[i] == key) return i;
+    return 0xFFFFFFFFu;
+}
+template <class KeyT>
+PTX_DEV void ptx_list_shift_up(KeyT* keys, uint32_t at, uint32_t n) {
+    for (uint32_t i = n; i > at; --i) keys[i] = keys[i - 1u];
+}
+PTX_DEV bool ptx_emu_bit(const uint32_t* plane, uint32_t i) { return (plane[i >> 5] >> (i & 31u)) & 1u; }
+PTX_DEV void ptx_emu_setbit(uint32_t* plane, uint32_t i, bool v) {
+    if (v) plane[i >> 5] |= 1u << (i & 31u);
+    else plane[i >> 5] &= ~(1u << (i & 31u));
+}
+PTX_DEV void ptx_plane_shift_up(uint32_t* plane, uint32_t at, uint32_t n) {
+    for (uint32_t i = n; i > at; --i) ptx_emu_setbit(plane, i, ptx_emu_bit(plane, i - 1u));
+    ptx_emu_setbit(plane, at, false);
+}
+PTX_DEV uint32_t ptx_plane_select0(const uint32_t* plane, uint32_t n, uint32_t k) {
+    for (uint32_t i = 0; i < n; ++i)
+        if (!ptx_emu_bit(plane, i) && k-- == 0u) return i;
+    return 0xFFFFFFFFu;
+}
+PTX_DEV uint32_t ptx_plane_after_tombstones(const uint32_t* dead, const uint32_t* after, uint32_t n, uint32_t pos) {
+    uint32_t pick = pos;
+    for (uint32_t i = pos + 1u; i < n && ptx_emu_bit(dead, i); ++i)
+        if (ptx_emu_bit(after, i)) pick = i;
+    return pick;
 }
