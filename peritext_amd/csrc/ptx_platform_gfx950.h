@@ -13,6 +13,15 @@
 #define PTX_HD __host__ __device__ static inline
 #define PTX_DEV __device__ __forceinline__
 #define PTX_SYNC() __syncthreads()
+/* lanes of ONE wave talking through LDS: the LDS serves a wave's accesses in issue order, so only the compiler has to be kept from
+ * moving or forwarding them — no s_barrier and, above all, no wait for the wave's outstanding stores to HBM (__syncthreads has one) */
+#define PTX_WSYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
+/* the barrier of a phase in a kernel that may run as ONE wave (kThreads == 64 known at compile time) */
+#define PTX_SYNC_T() do { if (kThreads == 64u) PTX_WSYNC(); else __syncthreads(); } while (0)
 /* threads per workgroup: a compile-time constant in the builds specialised for the usual launch shapes (kThreads != 0:
  * the per-phase loop bounds and strides then fold, which removes a quarter of the scalar instructions), else blockDim.x */
 #define PTX_BLOCKDIM (kThreads ? kThreads : blockDim.x)
@@ -170,7 +179,7 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
     for (uint32_t j = lo; j < hi; ++j) sum += a[j * STRIDE];
     const uint32_t incl = ptx_wave_incl_scan(sum); /* DPP prefix sum: no LDS traffic */
     if (lane == 63) tmp[wave] = incl;
-    __syncthreads();
+    PTX_SYNC_T();
     uint32_t wbase = 0, total = 0;
 #pragma nounroll
     for (uint32_t w = 0; w < nwaves; ++w) { /* a workgroup has at most 16 waves: every thread sums the few wave totals itself */
@@ -184,7 +193,7 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
         a[j * STRIDE] = (T)run;
         run += v;
     }
-    __syncthreads();
+    PTX_SYNC_T();
     return total;
 }
 
@@ -248,13 +257,6 @@ PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* cl
 #define PTX_LANE0 (threadIdx.x == 0)
 #define PTX_GEN_FOR(i, n) for (uint32_t i = threadIdx.x, _gn = (n); i < _gn; i += 64u)
 #define PTX_MEM __device__ __forceinline__
-/* lanes of ONE wave talking through LDS: the LDS serves a wave's accesses in issue order, so only the compiler has to be kept from
- * moving or forwarding them — no s_barrier and, above all, no wait for the wave's outstanding stores to HBM (__syncthreads has one) */
-#define PTX_WSYNC()                                              \
-    do {                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
-        __builtin_amdgcn_wave_barrier();                         \
-    } while (0)
 /* L[lo + 1 .. hi] = L[lo .. hi - 1] for hi - lo <= 64: every lane has read its element before any lane writes */
 PTX_DEV void ptx_shift_up64(uint32_t* L, uint32_t lo, uint32_t hi) {
     const uint32_t i = lo + (threadIdx.x & 63u);

@@ -22,7 +22,8 @@
  *   comment ops: [start, end) slots + per-id chains in application order (the LAST-applied covering op of an id
  *             decides its presence, :314-321)
  * One 64-thread workgroup (one wave) per log: the replay is sequential in t, every step is a handful of wave-wide
- * passes over bitmap words / the defined slots of the range.
+ * passes over bitmap words / the defined slots of the range.  As ONE wave the phases need no s_barrier and no wait for the patches
+ * just stored to HBM (nothing this kernel writes there is read back): PTX_SYNC_T is a compiler fence then.
  *
  * Compiled two ways like merge_core.h (hipcc: the product kernel; g++ -DPTX_EMU: CPU test tooling only).
  */
@@ -199,16 +200,16 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         H->tmp = 0;
         H->nvis = 0;
     }
-    PTX_SYNC();
+    PTX_SYNC_T();
     PTX_FOR(i, N) {
         if (action[i] == PTX_ACT_INSERT) {
             uint32_t key = 0;
             if (ptx_id_key(ix, op_id[i], key)) ptx_atomic_or(&ix.ib[key >> 5].bits, 1u << (key & 31));
         }
     }
-    PTX_SYNC();
+    PTX_SYNC_T();
     PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
-    PTX_SYNC();
+    PTX_SYNC_T();
     ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
     PTX_FOR(i, N) {
         if (action[i] == PTX_ACT_INSERT) {
@@ -219,19 +220,19 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             }
         }
     }
-    PTX_SYNC();
+    PTX_SYNC_T();
 
     /* last defined slot strictly below `lim` -> H->tmp = slot + 1 (0 = none); every thread calls it */
 #define PTX_LAST_DEFINED_BELOW(lim_)                                                            \
     do {                                                                                        \
         PTX_LEADER { H->tmp = 0; }                                                              \
-        PTX_SYNC();                                                                             \
+        PTX_SYNC_T();                                                                             \
         PTX_FOR(w_, ((lim_) + 31u) >> 5) {                                                      \
             uint32_t m_ = defined[w_];                                                          \
             if ((w_ << 5) + 32u > (lim_)) m_ &= (1u << ((lim_)&31u)) - 1u;                      \
             if (m_) ptx_atomic_max(&H->tmp, (w_ << 5) + (31u - (uint32_t)__builtin_clz(m_)) + 1u); \
         }                                                                                       \
-        PTX_SYNC();                                                                             \
+        PTX_SYNC_T();                                                                             \
     } while (0)
 
     /* make slot s_ a defined one: its state is that of the closest defined slot to the left (peritext.ts:176) */
@@ -249,7 +250,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     if (l1_ && ptx_bittest(won[ty_], l1_ - 1u)) won[ty_][(s_) >> 5] |= 1u << ((s_)&31u); \
                 defined[(s_) >> 5] |= 1u << ((s_)&31u);                                         \
             }                                                                                   \
-            PTX_SYNC();                                                                         \
+            PTX_SYNC_T();                                                                         \
         }                                                                                       \
     } while (0)
 
@@ -287,7 +288,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         c_pay[i] = payload[tt];
         c_id[i] = op_id[tt];
     }
-    PTX_SYNC();
+    PTX_SYNC_T();
 #pragma nounroll
     for (uint32_t ci = 0; ci < chunk_n; ++ci) {
         const uint32_t t = t0 + ci;
@@ -297,13 +298,13 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 ptx_patch_put(A, pbase, pcap, H->npatch, t, PTX_PATCH_MAKELIST, 0u, 0u);
                 H->npatch += 1;
             }
-            PTX_SYNC();
+            PTX_SYNC_T();
         } else if (kind == PTX_RK_INSERT) {
             const uint32_t r = c_a[ci];
             PTX_LAST_DEFINED_BELOW(2u * r);
             const uint32_t l1 = H->tmp; /* slot + 1 */
             const uint32_t p0 = H->npatch;
-            PTX_SYNC();
+            PTX_SYNC_T();
             PTX_LEADER {
                 uint32_t attr = 0;
                 if (l1) {
@@ -316,7 +317,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 ptx_patch_put(A, pbase, pcap, p0, t, PTX_PATCH_INSERT, ptx_bitrank(present, r), attr);
                 H->tmp = 0; /* comment ids of this patch */
             }
-            PTX_SYNC();
+            PTX_SYNC_T();
             if (l1 && ptx_bittest(anyc, l1 - 1u)) {
                 const uint32_t l = l1 - 1u, nc = H->ncom;
                 PTX_FOR(kc, nc) {
@@ -330,7 +331,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                         if (last) ptx_patch_put(A, pbase, pcap, p0 + 1u + ptx_atomic_add(&H->tmp, 1u), t, PTX_PATCH_INSERT_COMMENT, ccid[kc], 0u);
                     }
                 }
-                PTX_SYNC();
+                PTX_SYNC_T();
             }
             /* the element is visible from now on */
             PTX_FOR(w, nwe) {
@@ -341,23 +342,23 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 H->npatch = p0 + 1u + H->tmp;
                 H->nvis += 1;
             }
-            PTX_SYNC();
+            PTX_SYNC_T();
         } else if (kind == PTX_RK_DELETE) {
             const uint32_t r = c_a[ci];
             const bool was = (present[r >> 5].bits >> (r & 31)) & 1u;
-            PTX_SYNC();
+            PTX_SYNC_T();
             if (was) {
                 PTX_LEADER {
                     ptx_patch_put(A, pbase, pcap, H->npatch, t, PTX_PATCH_DELETE, ptx_bitrank(present, r), 1u);
                     H->npatch += 1;
                     H->nvis -= 1;
                 }
-                PTX_SYNC();
+                PTX_SYNC_T();
                 PTX_FOR(w, nwe) {
                     if (w == (r >> 5)) present[w].bits &= ~(1u << (r & 31));
                     else if (w > (r >> 5)) present[w].pre -= 1;
                 }
-                PTX_SYNC();
+                PTX_SYNC_T();
             }
         } else if (kind == PTX_RK_MARK) {
             const uint32_t ty = (c_kind[ci] >> 4) & 3u, act = (c_kind[ci] & 64u) ? (uint32_t)PTX_ACT_ADDMARK : (uint32_t)PTX_ACT_REMOVEMARK;
@@ -387,7 +388,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 }
                 wcnt[wi] = c;
             }
-            PTX_SYNC();
+            PTX_SYNC_T();
             const uint32_t S = ptx_scan_excl<uint32_t, 1, kThreads>(wcnt, whi - wlo + 1u, H->scan_tmp);
             PTX_FOR(wi, whi - wlo) {
                 const uint32_t w = wlo + wi;
@@ -401,7 +402,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 }
             }
 #undef PTX_RANGE_BITS
-            PTX_SYNC();
+            PTX_SYNC_T();
             const uint32_t nvis = H->nvis, nc = H->ncom;
             const uint32_t cfw = (S >> 5) + 1u; /* words of the patch-opening bitmap (+1 for the total) */
             PTX_FOR(w, cfw + 1u) {
@@ -414,7 +415,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
              * zero-width ones are dropped (peritext.ts:269-281) */
             const uint32_t v_end = slot_b != PTX_SLOT_NONE ? ptx_bitrank(present, (slot_b + 1u) >> 1) : nvis;
 #define PTX_VIS_AT(s_) ptx_bitrank(present, ((uint32_t)(s_) + 1u) >> 1) /* visible index at a boundary slot */
-            PTX_SYNC();
+            PTX_SYNC_T();
             const uint32_t my_id = c_pay[ci];
             const uint64_t my_op = c_id[ci];
             /* per defined slot: did the effective marks change (peritext.ts:208), new state, visible index */
@@ -453,7 +454,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     if (ve > PTX_VIS_AT(s)) ptx_atomic_or(&cf[j >> 5].bits, 1u << (j & 31));
                 }
             }
-            PTX_SYNC();
+            PTX_SYNC_T();
             if (ty == PTX_MARK_COMMENT) {
                 PTX_FOR(j, S) {
                     const uint32_t s = seg[j];
@@ -461,7 +462,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 }
             }
             PTX_FOR(w, cfw) cf[w].pre = ptx_popc(cf[w].bits);
-            PTX_SYNC();
+            PTX_SYNC_T();
             const uint32_t P = ptx_scan_excl<uint32_t, 2, kThreads>(&cf[0].pre, cfw + 1u, H->scan_tmp);
             const uint32_t p0 = H->npatch;
             PTX_FOR(j, S) {
@@ -471,7 +472,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 }
             }
 #undef PTX_VIS_AT
-            PTX_SYNC();
+            PTX_SYNC_T();
             PTX_LEADER {
                 H->npatch = p0 + P;
                 if (ty == PTX_MARK_COMMENT && my_id < Kid && nc < Kc) {
@@ -487,14 +488,14 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     H->ncom = nc + 1u;
                 }
             }
-            PTX_SYNC();
+            PTX_SYNC_T();
         }
     }
-    PTX_SYNC(); /* the chunk buffers are rewritten next */
+    PTX_SYNC_T(); /* the chunk buffers are rewritten next */
     }
 #undef PTX_LAST_DEFINED_BELOW
 #undef PTX_DEFINE_SLOT
-    PTX_SYNC();
+    PTX_SYNC_T();
     PTX_LEADER {
         ptx_patch_log pl;
         pl.status = H->npatch > pcap ? (uint32_t)PTX_ERR_CAPACITY : (uint32_t)PTX_OK;

@@ -9,6 +9,7 @@
 #define PTX_HD static inline
 #define PTX_DEV static inline
 #define PTX_SYNC() ((void)0)
+#define PTX_SYNC_T() ((void)0)
 extern int ptx_emu_reverse; /* order of every emulated parallel loop: 0 forward, 1 backward, 2 a fixed pseudo-random permutation (order-independence checks) */
 static inline uint32_t ptx_emu_ix(uint32_t k, uint32_t n) { /* k-th iteration runs index ...; 104729 is a prime above any loop length here */
     return ptx_emu_reverse == 0 ? k : ptx_emu_reverse == 1 ? n - 1u - k : (uint32_t)(((uint64_t)k * 104729ull + 7ull) % (n ? n : 1u));
