@@ -402,7 +402,8 @@ def main():
             "parity": parity,
             "launch": {"threads_per_log": threads, "lds_bytes_per_log": lds},
             "host": {"cores": cores, "gen_s": t_gen},
-            "device_gen": {"kernel_ms": gen_info["kernel_ms"], "ops_generated_per_s": ops_per_step / (gen_info["kernel_ms"] * 1e-3)},
+            "device_gen": {"kernel_ms": gen_info["kernel_ms"], "ops_generated_per_s": ops_per_step / (gen_info["kernel_ms"] * 1e-3),
+                           "list_cap": args.list_cap, "longest_list": int(logs["n_elems"].max())},
         }
         if sustained is not None:
             sustained["ops_per_s"] = total_ops_per_step * sustained["steps"] / sustained["seconds"]
