@@ -19,8 +19,8 @@ One JSON line on stdout (rank 0):
       the stream the kernel runs on.  The Change envelope that causal admission reads on top is NOT in B_alg; the figure
       that includes it is reported separately (roofline.with_envelope).
   roofline.traffic  = HBM bytes per launch from the PMC counters of the same command (profiles/r02_hbm_traffic.json, made by
-      tools/pmc_traffic.sh on the GPU box: separate --pmc passes for FETCH_SIZE / WRITE_SIZE, calibrated as
-      MI355X_MICROARCH.md prescribes); null when that file does not describe this workload.
+      tools/pmc_traffic.sh on the GPU box: separate --pmc passes; reads = the L2's read requests by size, cross-checked against
+      FETCH_SIZE calibrated as MI355X_MICROARCH.md prescribes; writes = WRITE_SIZE); null when that file does not describe this workload.
   parity            = --check-docs random documents of the RESIDENT batch checked against the oracle run on the host cores on
       WHOLE logs (decoded spans, raw rows, digests of the rows the timed launches wrote).
   cpu_baseline      = the reference's own code (oracle/_ref) on the same sampled logs, one process per core, time-boxed.
