@@ -211,6 +211,7 @@ PTX_DEV T* ptx_alloc(PtxBump& b, uint32_t count) {
     }
     b.off += bytes;
     if (b.off > b.high) b.high = b.off;
+    PTX_LDS_ALLOCATED(p, (uint64_t)count * sizeof(T), bytes);
     return p;
 }
 
@@ -221,6 +222,7 @@ PTX_DEV T* ptx_alloc2(PtxBump& bd, PtxBump& bp, uint32_t count) {
     if ((uint64_t)bd.off + bytes <= bd.cap) {
         T* p = (T*)(bd.base + bd.off);
         bd.off += bytes;
+        PTX_LDS_ALLOCATED(p, (uint64_t)count * sizeof(T), bytes);
         return p;
     }
     return ptx_alloc<T>(bp, count);

@@ -13,6 +13,7 @@
 #define PTX_HD __host__ __device__ static inline
 #define PTX_DEV __device__ __forceinline__
 #define PTX_SYNC() __syncthreads()
+#define PTX_LDS_ALLOCATED(p, used_bytes, total_bytes) ((void)0) /* a hook of the bump allocator (the CPU test-suite's sanitizer build marks the padding) */
 /* lanes of ONE wave talking through LDS: the LDS serves a wave's accesses in issue order, so only the compiler has to be kept from
  * moving or forwarding them — no s_barrier and, above all, no wait for the wave's outstanding stores to HBM (__syncthreads has one) */
 #define PTX_WSYNC()                                              \

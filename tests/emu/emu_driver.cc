@@ -12,6 +12,16 @@
 #include <string.h>
 int ptx_emu_reverse = 0;
 #include "../../peritext_amd/csrc/merge_core.h"
+
+/* LDS of the next log: not zero-initialised on the GPU either; a sanitizer build forgets the padding marks of the log before */
+static size_t ptx_emu_lds_size = 0;
+static void ptx_emu_lds_fill(uint8_t* lds, size_t bytes) {
+    if (bytes) ptx_emu_lds_size = bytes;
+#if defined(__SANITIZE_ADDRESS__)
+    ASAN_UNPOISON_MEMORY_REGION(lds, ptx_emu_lds_size);
+#endif
+    if (bytes) memset(lds, 0xA5, bytes);
+}
 #include "../../peritext_amd/csrc/replay_core.h"
 #include "../../peritext_amd/csrc/gen_core.h"
 #include "../../peritext_amd/csrc/change_core.h"
@@ -72,9 +82,10 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     if (!lds) return 1;
     ptx_emu_reverse = reverse;
     for (uint32_t l = 0; l < b->n_logs; ++l) {
-        memset(lds, 0xA5, lds_bytes); /* LDS is not zero-initialised on the GPU either */
+        ptx_emu_lds_fill(lds, lds_bytes); /* LDS is not zero-initialised on the GPU either */
         ptx_merge_log<true, 0>(A, l, lds);
     }
+    ptx_emu_lds_fill(lds, 0);
     free(lds);
     free(hdr);
     return 0;
@@ -121,9 +132,10 @@ extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, con
     if (!lds) return 1;
     ptx_emu_reverse = reverse;
     for (uint32_t l = 0; l < b->n_logs; ++l) {
-        memset(lds, 0xA5, lds_bytes);
+        ptx_emu_lds_fill(lds, lds_bytes);
         ptx_replay_log<0>(A, l, lds);
     }
+    ptx_emu_lds_fill(lds, 0);
     free(lds);
     free(hdr);
     return 0;
@@ -140,9 +152,10 @@ extern "C" int ptx_emu_generate(PtxGenArgs* A, int reverse) {
     if (!lds || !A->ctab || !A->known) return 1;
     ptx_emu_reverse = reverse;
     for (uint32_t d = 0; d < A->n_docs; ++d) {
-        memset(lds, 0xA5, A->lds_bytes);
+        ptx_emu_lds_fill(lds, A->lds_bytes);
         ptx_gen_doc<0>(*A, d, lds);
     }
+    ptx_emu_lds_fill(lds, 0);
     free(lds);
     free(A->ctab);
     free(A->known);
@@ -206,9 +219,10 @@ extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, con
     if (!lds) return 1;
     ptx_emu_reverse = reverse;
     for (uint32_t l = 0; l < b->n_logs; ++l) {
-        memset(lds, 0xA5, lds_bytes);
+        ptx_emu_lds_fill(lds, lds_bytes);
         ptx_change_log<0>(A, l, lds);
     }
+    ptx_emu_lds_fill(lds, 0);
     free(lds);
     free(hdr);
     return 0;
@@ -243,9 +257,10 @@ extern "C" int ptx_emu_cursors(const ptx_batch* b, const ptx_log_result* res, co
     if (!lds) return 1;
     ptx_emu_reverse = reverse;
     for (uint32_t g = 0; g < n_groups; ++g) {
-        memset(lds, 0xA5, lds_bytes);
+        ptx_emu_lds_fill(lds, lds_bytes);
         ptx_cursor_group<0>(A, g, lds);
     }
+    ptx_emu_lds_fill(lds, 0);
     free(lds);
     free(hdr);
     return 0;

@@ -9,6 +9,18 @@
 #define PTX_HD static inline
 #define PTX_DEV static inline
 #define PTX_SYNC() ((void)0)
+/* sanitizer build of the emulation (g++ -fsanitize=address): the padding behind every array of the LDS bump allocator is poisoned,
+ * so that an off-by-one of the kernel logic is reported instead of landing silently in the next array's slack */
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#define PTX_LDS_ALLOCATED(p, used_bytes, total_bytes)                                                       \
+    do {                                                                                                    \
+        ASAN_UNPOISON_MEMORY_REGION((p), (used_bytes));                                                     \
+        ASAN_POISON_MEMORY_REGION((const uint8_t*)(p) + (used_bytes), (total_bytes) - (used_bytes));        \
+    } while (0)
+#else
+#define PTX_LDS_ALLOCATED(p, used_bytes, total_bytes) ((void)0)
+#endif
 #define PTX_SYNC_T() ((void)0)
 extern int ptx_emu_reverse; /* order of every emulated parallel loop: 0 forward, 1 backward, 2 a fixed pseudo-random permutation (order-independence checks) */
 static inline uint32_t ptx_emu_ix(uint32_t k, uint32_t n) { /* k-th iteration runs index ...; 104729 is a prime above any loop length here */

@@ -14,7 +14,7 @@ from peritext_amd import abi, canon, wire
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 NODE = shutil.which("node")
-EMU_LIB = os.path.join(ROOT, "tests", "emu", "libperitext_emu.so")
+EMU_LIB = os.environ.get("PTX_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "libperitext_emu.so")
 LDS_BYTES = 160 * 1024
 
 
