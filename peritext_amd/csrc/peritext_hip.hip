@@ -305,6 +305,8 @@ struct ptx_ctx {
     hipStream_t stream = nullptr;     /* the stream in use: own_stream, or the caller's (ptx_set_stream) */
     hipStream_t own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t side = nullptr;       /* the second launch of a split batch (a few logs with a larger LDS window) runs beside the first */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     int cu_count = 0;
     size_t max_lds = 0;
@@ -495,7 +497,9 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     if (const char* s = getenv("PTX_THREADS")) ctx->force_threads = atoi(s);
     if (const char* s = getenv("PTX_LDS_BYTES")) ctx->force_lds = atoi(s);
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PTX_ERR_HIP, "stream/event creation failed");
     }
@@ -523,6 +527,12 @@ void ptx_destroy(ptx_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamDestroy(ctx->side);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -870,7 +880,14 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.div_magic = (uint32_t)(0x100000000ull / b->threads) + 1u;
     A.log_index = nullptr;
     /* one workgroup per log; far more workgroups than the 256 CUs so the dispatcher load-balances.  Two launches when a
-     * few logs need more LDS than the rest (census_and_shape): first the many at their size, then the few at theirs. */
+     * few logs need more LDS than the rest (census_and_shape): the many at their size, the few at theirs — the few on a side
+     * stream forked from and joined to the caller's, so that they run beside the many instead of after them. */
+    const bool diag = ctx->clocks || ctx->stop_after;
+    const bool fork = b->n_main && !diag && ctx->side;
+    if (fork) {
+        (void)hipEventRecord(ctx->ev_fork, ctx->stream);
+        (void)hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
+    }
     for (int part = 0; part < (b->n_main ? 2 : 1); ++part) {
         uint32_t grid = b->n_logs, lds = b->lds_bytes;
         if (b->n_main) {
@@ -880,14 +897,19 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
             A.n_logs = grid;
             A.lds_bytes = lds;
         }
-        if (ctx->clocks || ctx->stop_after)
-            hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), lds, ctx->stream, A);
+        hipStream_t st = part && fork ? ctx->side : ctx->stream;
+        if (diag)
+            hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), lds, st, A);
         else if (admit && b->max_actors > 3)
-            hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, ctx->stream, A);
+            hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);
         else if (part)
-            hipLaunchKernelGGL(ptx_merge_kernel_rest, dim3(grid), dim3(b->threads), lds, ctx->stream, A);
+            hipLaunchKernelGGL(ptx_merge_kernel_rest, dim3(grid), dim3(b->threads), lds, st, A);
         else
-            hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, ctx->stream, A);
+            hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, st, A);
+    }
+    if (fork) {
+        (void)hipEventRecord(ctx->ev_join, ctx->side);
+        (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_merge_kernel launch: ") + hipGetErrorString(e));
