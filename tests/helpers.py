@@ -393,6 +393,28 @@ def more_deletes_than_inserts_docs():
     return [[ok], [later], [unknown]]
 
 
+def shift_counters(docs, delta):
+    """The same documents with every op counter moved up by `delta` (opIds, element references, startOp): the histories stay
+    valid, the id key space of the kernel's element index grows past 16 bits (its 32-bit key paths)."""
+    def sid(x):
+        if isinstance(x, str) and "@" in x:
+            c, a = x.split("@", 1)
+            return "%d@%s" % (int(c) + delta, a)
+        return x
+
+    def sop(op):
+        o = dict(op)
+        for k in ("opId", "obj", "elemId"):
+            if k in o:
+                o[k] = sid(o[k])
+        for k in ("start", "end"):
+            if k in o and "elemId" in o[k]:
+                o[k] = dict(o[k], elemId=sid(o[k]["elemId"]))
+        return o
+
+    return [[[dict(c, startOp=c["startOp"] + delta, ops=[sop(o) for o in c["ops"]]) for c in log] for log in d] for d in docs]
+
+
 def duplicate_op_docs():
     """[a log with one opId on two rows, a well-formed neighbour]."""
     dup = mini_doc([{"action": "set", "insert": True, "elemId": "6@a", "value": "x"}, {"action": "del", "elemId": "3@a"}])

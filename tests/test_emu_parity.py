@@ -135,6 +135,21 @@ def test_edge_fixture_made_by_the_reference():
         assert json.loads(json.dumps(live_u, sort_keys=True)) == json.loads(json.dumps(g["unsynced"], sort_keys=True))
 
 
+def test_wide_id_keys_give_the_same_documents():
+    """Counters moved up by 70 000: the element index's key space no longer fits 16 bits (P3a re-reads op_id instead of using the
+    keys P1 left beside the insert list) — same spans, same statuses."""
+    gen = _load("ptxgen_mini.json")
+    docs = [d["logs"] for d in gen["docs"][:4]] + H.more_deletes_than_inserts_docs()
+    base = wire.encode_docs(docs)
+    wide = wire.encode_docs(H.shift_counters(docs, 70000))
+    assert int(wide.log_hdr["max_counter"].max()) > 70000
+    r0, r1 = H.emu_merge(base, admission=True), H.emu_merge(wide, admission=True)
+    assert (r0.logs["status"] == r1.logs["status"]).all()
+    for log in range(len(r0.logs["status"])):
+        if int(r0.logs["status"][log]) == 0:
+            assert wire.decode_spans(wide, r1, log) == wire.decode_spans(base, r0, log)
+
+
 @pytest.mark.parametrize("reverse", [0, 1, 2])
 def test_more_deletes_than_inserts(reverse):
     """The deletes beyond slot n (resolved in their own loop) and their application-order check."""

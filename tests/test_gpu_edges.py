@@ -85,6 +85,21 @@ def test_element_that_only_appears_later(eng):
     assert int(res.logs["status"][0]) == abi.ERR_ELEM_NOT_FOUND
 
 
+def test_wide_id_keys_give_the_same_documents(eng, golden):
+    """Twin of the emulation test: counters moved up by 70 000 (32-bit id keys in P3a), same documents."""
+    with open(os.path.join(H.GOLDEN, "ptxgen_mini.json")) as f:
+        gen = json.load(f)
+    docs = [d["logs"] for d in gen["docs"][:4]] + H.more_deletes_than_inserts_docs()
+    base, wide = wire.encode_docs(docs), wire.encode_docs(H.shift_counters(docs, 70000))
+    r0, r1 = eng.apply_materialize(base), eng.apply_materialize(wide)
+    assert (r0.logs["status"] == r1.logs["status"]).all()
+    for log in range(len(r0.logs["status"])):
+        if int(r0.logs["status"][log]) == 0:
+            assert wire.decode_spans(wide, r1, log) == wire.decode_spans(base, r0, log)
+    for log, exp in enumerate(e for d in gen["docs"][:4] for e in d["expected"]):
+        H.check_log(base, r0, log, exp)
+
+
 def test_more_deletes_than_inserts(eng):
     """Twin of the emulation test: deletes beyond slot n are resolved in their own loop; order check of both kinds of deletes."""
     batch = wire.encode_docs(H.more_deletes_than_inserts_docs())
