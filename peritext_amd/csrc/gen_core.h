@@ -384,11 +384,11 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
     G.dead0 = ptx_alloc<uint32_t>(bp, G.plane_words * R);
     G.after0 = ptx_alloc<uint32_t>(bp, G.plane_words * R);
     G.done = ptx_alloc<uint32_t>(bp, (N >> 5) + 2);
-    G.crank = (uint16_t*)G.key0; /* needed once the documents are finished and the lists dead: its size is checked below */
+    G.crank = (uint16_t*)G.key0; /* needed once the documents are finished and the lists (keys + planes, contiguous) dead: see the end */
     G.row0 = (uint64_t)doc_local * R * N;
     G.ctab = A.ctab + (uint64_t)doc_local * R * N;
     G.known = A.known + (uint64_t)doc_local * R * N;
-    if (bp.overflow || R == 0 || R > PTX_GEN_MAX_R || N > 0xFFFFFFu || (uint64_t)G.lst_stride * R * sizeof(KeyT) < 2ull * (N + 1u)) {
+    if (bp.overflow || R == 0 || R > PTX_GEN_MAX_R || N > 0xFFFFFFu) {
         if (PTX_LANE0) {
             A.status[doc_local] = PTX_ERR_CAPACITY;
             A.n_comments[doc_local] = 0;
@@ -557,7 +557,12 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
     /* comment ids "comment-<k>": the wire format wants their rank in string order inside the document
      * (peritext.ts:318 keeps comment arrays id-sorted): decimal strings compared digit by digit */
     const uint32_t C = comment_counter;
-    PTX_GEN_FOR(kk, C) {
+    const uint64_t crank_room = (uint64_t)((uint8_t*)(G.after0 + (uint64_t)G.plane_words * R) - (uint8_t*)G.key0) / 2u; /* u16 entries the dead lists hold */
+    if (C > crank_room) {
+        if (PTX_LANE0) H->overflow = 1;
+        PTX_WSYNC();
+    }
+    PTX_GEN_FOR(kk, C <= crank_room ? C : 0u) {
         uint32_t rank = 0;
         for (uint32_t j = 0; j < C; ++j) rank += j != kk && ptx_gen_str_less(j, kk) ? 1u : 0u;
         G.crank[kk] = (uint16_t)rank;
@@ -567,7 +572,7 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
         const uint64_t b0 = G.log_base(r);
         const uint32_t nr = H->rows[r] < N ? H->rows[r] : N;
         PTX_GEN_FOR(i, nr) {
-            if (A.mark_type[b0 + i] == PTX_MARK_COMMENT && (A.action[b0 + i] == PTX_ACT_ADDMARK || A.action[b0 + i] == PTX_ACT_REMOVEMARK))
+            if (C <= crank_room && A.mark_type[b0 + i] == PTX_MARK_COMMENT && (A.action[b0 + i] == PTX_ACT_ADDMARK || A.action[b0 + i] == PTX_ACT_REMOVEMARK))
                 A.payload[b0 + i] = G.crank[A.payload[b0 + i]];
         }
     }

@@ -118,9 +118,11 @@ def test_generator_random_workloads():
         check_generated_logs(batch, [d["logs"] for d in g["docs"]])
 
 
-def test_generator_list_capacity_is_exact():
-    """list_cap = the largest element count any replica reaches is enough; one less is reported, never silently wrong."""
-    c = H.gen_config("mini")
+@pytest.mark.parametrize("cfg,ops", [("mini", None), ("config5", 1500)])
+def test_generator_list_capacity_is_exact(cfg, ops):
+    """list_cap = the largest element count any replica reaches is enough; one less is reported, never silently wrong.  (config5:
+    ONE replica per document, comments — the comment ranks at the end live in the dead lists, which are small then.)"""
+    c = H.gen_config(cfg, ops=ops)
     batch, status = H.emu_generate(c, 6, 21)
     assert not status.any()
     hdr = wire.census(batch.log_off, batch.op_id, batch.action, batch.mark_type)
