@@ -39,6 +39,7 @@
  */
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/peritext_hip.h"
 
 #ifndef PTX_U
@@ -50,9 +51,6 @@
 #define PTX_J_OF(st, u) PTX_J_OF_U(st, u, PTX_U)
 #ifndef PTX_U1
 #define PTX_U1 3 /* consecutive rows per thread and step in the row pass P1 (measured: 2 -> 14.6, 3 -> 14.2, 4 -> 17 us per 4K-op log) */
-#endif
-#ifndef PTX_P1_PREFETCH
-#define PTX_P1_PREFETCH 1 /* row loads of P1: 1 = one step ahead (costs PTX_U1 * 4 VGPRs), 2 = two steps ahead (twice that) */
 #endif
 #define PTX_MAX_THREADS 1024u
 #define PTX_BYTE_PAD 4u /* bytes the library allocates past the end of the action / mark_type columns (the row pass reads them a dword at a time) */
@@ -255,7 +253,7 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(2 * (K + 1)) + ptx_a16(4 * (K / 32 + 1)) + elem;
     const uint64_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
     const uint64_t lists = ptx_a16(2 * (n + 1)) + ptx_a16(2 * l_len);
-    const uint64_t p1 = lists;
+    const uint64_t p1 = lists + 16; /* + the dump of the unlisted rows */
     const uint64_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
     const uint64_t p3 = lists + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
     const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0;
@@ -383,6 +381,69 @@ PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
     return count;
 }
 
+/* ---- P0, documents of up to three actors: one step of a wave's admission walk (PTX_AC consecutive changes per lane).
+ *      h = Change headers, e0 = seq | deps[0] << 16, e1 = deps[1] | deps[2] << 16 of the lane's changes; kTail: only the first
+ *      `nvalid` of them exist.  See the call site for the scheme. ---- */
+struct PtxAdmWave { /* the same in every lane of the wave */
+    uint32_t bx, by;   /* changes per actor before this step, relative to the segment: actor 0 << 16 | -, actor 1 | actor 2 << 16 */
+    uint32_t gx, gy;   /* G per actor, same packing */
+    uint32_t known;    /* bit b: G of actor b has been learned */
+};
+template <bool kTail>
+PTX_DEV void ptx_adm_step(PtxAdmWave& S, const uint32_t* h, const uint32_t* e0, const uint32_t* e1, uint32_t nvalid,
+                          uint32_t& mx0, uint32_t& mx1, uint32_t& bad, uint32_t& amax, uint32_t& hsum) {
+    uint32_t ohx[PTX_AC], ohy[PTX_AC], sel[PTX_AC], s[PTX_AC], tx = 0, ty = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < PTX_AC; ++u) {
+        const bool in = !kTail || u < nvalid;
+        const uint32_t hu = in ? h[u] : 0u;
+        amax = hu > amax ? hu : amax; /* the actor sits in the top bits */
+        hsum += hu;
+        const uint32_t a = hu >> PTX_CHG_ACTOR_SHIFT;
+        /* one-hot of the actor in the clock packing: actor 0 -> bit 16, 1 -> bit 32, 2 -> bit 48, a change of no actor (or of an
+         * actor the document does not have: the log fails through amax) counts nowhere that matters */
+        const uint64_t oh = in ? ptx_shl64(0x10000ull, a << 4) : 0ull;
+        ohx[u] = (uint32_t)oh;
+        ohy[u] = (uint32_t)(oh >> 32);
+        tx += ohx[u];
+        ty += ohy[u];
+        /* byte selector of the own actor's clock in {cy, cx}: bytes 2,3 / 4,5 / 6,7 */
+        sel[u] = in ? 0x0c0c0302u + a * 0x0202u : 0x0c0c0c0cu;
+    }
+    const uint32_t ix = ptx_wave_incl_scan(tx), iy = ptx_wave_incl_scan(ty);
+    uint32_t cx = S.bx + ix - tx, cy = S.by + iy - ty; /* relative clock before this lane's first change */
+#pragma unroll
+    for (uint32_t u = 0; u < PTX_AC; ++u) {
+        const bool in = !kTail || u < nvalid;
+        const uint32_t e0u = in ? e0[u] : 0u, e1u = in ? e1[u] : 0u;
+        s[u] = ptx_pk_subsat_u16(e0u, ptx_perm(cy, cx, sel[u]));   /* low half: seq (-) clock[actor] */
+        mx0 = ptx_pk_max_u16(mx0, ptx_pk_subsat_u16(e0u, cx));      /* high half: deps[0] (-) clock[0] */
+        mx1 = ptx_pk_max_u16(mx1, ptx_pk_subsat_u16(e1u, cy));      /* deps[1] (-) clock[1] | deps[2] (-) clock[2] */
+        cx += ohx[u];
+        cy += ohy[u];
+    }
+    if (S.known != 7u) { /* wave-uniform; normally only in the first step of a segment */
+        for (uint32_t b = 0; b < 3u; ++b) {
+            if ((S.known >> b) & 1u) continue;
+            for (uint32_t u = 0; u < PTX_AC; ++u) {
+                const bool mine = (!kTail || u < nvalid) && (h[u] >> PTX_CHG_ACTOR_SHIFT) == b;
+                uint32_t v = 0;
+                if (ptx_wave_pick(mine, s[u] & 0xFFFFu, v)) {
+                    if (b == 0u) S.gx = v << 16;
+                    else if (b == 1u) S.gy = (S.gy & 0xFFFF0000u) | v;
+                    else S.gy = (S.gy & 0xFFFFu) | (v << 16);
+                    S.known |= 1u << b;
+                    break;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < PTX_AC; ++u) bad |= (s[u] ^ ptx_perm(S.gy, S.gx, sel[u])) & 0xFFFFu;
+    S.bx += ptx_wave_last(ix);
+    S.by += ptx_wave_last(iy);
+}
+
 /* Uniform early exit on a per-log error.  The error word is sampled between two barriers so that a
  * later phase's error write can never be seen by a thread that is still at this check point. */
 #define PTX_BAIL_IF_ERROR()                                        \
@@ -496,117 +557,91 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             const uint32_t step = PTX_WS * PTX_AC; /* changes per wave and step */
             const uint32_t seg = ((C + nwv_ - 1u) / nwv_ + step - 1u) / step * step; /* changes per wave, whole steps */
             /* FAST CHECK, one pass: every wave walks its segment with clocks RELATIVE to the segment's start (the loads of the next
-             * step in flight), and keeps per actor a the range [emin, emax] of  seq - 1 - relative clock  over its changes (all must
-             * equal the clock B[a] before the segment) and per actor b the maximum of  deps[b] - relative clock[b]  (must not exceed
-             * B[b]).  B is only known once every wave has counted its segment: the few per-wave numbers are validated after the
-             * pass.  A log that fails (rare) is walked again by the exact two-pass code below, which names the first failing change. */
+             * step in flight).  For every change of actor a,  seq (-) relative clock[a]  must be one and the same number G[a] (then
+             * G[a] - 1 is the clock before the segment), and per actor b the maximum of  deps[b] (-) relative clock[b]  must not
+             * exceed the clock before the segment ((-) saturates at 0).  The clocks before the segments are only known once every
+             * wave has counted its own: the few per-wave numbers are validated after the pass.  A log that fails (rare) is walked
+             * again by the exact two-pass code below, which names the first failing change. */
             uint32_t* wrec = ptx_alloc<uint32_t>(bp, (PTX_MAX_THREADS / 64 + 1) * 12u);
             PTX_BAIL_CAPACITY();
             PTX_FOR_WAVE(w, lane) {
                 const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
-                uint32_t b01 = 0, b23 = 0, rows = 0, badc = 0xFFFFFFFFu;
-                uint32_t emin[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, emax[3] = {0u, 0u, 0u}, mx[3] = {0u, 0u, 0u};
-                uint32_t h[PTX_AC], h_n[PTX_AC];
-                uint16_t e[PTX_AC][4], e_n[PTX_AC][4];
-#define PTX_ADM_LOAD(cb_, h_, e_)                                           \
+                /* Relative clocks of the wave's segment, packed like the envelope row they are compared with (u16 seq, deps[0..3)):
+                 * cx = clock[0] << 16 (beside deps[0]; the half beside seq stays 0), cy = clock[1] | clock[2] << 16 (beside deps[1], deps[2]).
+                 * Per change a handful of packed 16-bit operations: the own actor's clock through a byte permute, seq (-) clock and
+                 * deps (-) clock as saturating packed subtractions, running packed maxima.  "All seq - clock of an actor are equal"
+                 * is checked against the value G of the FIRST change of that actor the wave meets (learned once per wave, scalar
+                 * code); G itself is validated against the true clock before the segment after the pass. */
+                PtxAdmWave S;
+                S.bx = S.by = S.gx = S.gy = S.known = 0u;
+                uint32_t mx0 = 0, mx1 = 0, bad = 0, amax = 0, hsum = 0;
+                uint32_t h[PTX_AC], h_n[PTX_AC], e0[PTX_AC], e1[PTX_AC], e0_n[PTX_AC], e1_n[PTX_AC];
+#define PTX_ADM_LOAD(cb_, h_, e0_, e1_)                                     \
     {                                                                       \
         const uint32_t cl0_ = (cb_) + lane * PTX_AC;                        \
         const uint32_t cl_ = cl0_ < hi ? cl0_ : (hi ? hi - 1u : 0u);        \
         PTX_ADM_HDRS(h_, cl_)                                               \
-        PTX_ADM_ENVS(e_, cl_)                                               \
+        PTX_ADM_ENVS32(e0_, e1_, cl_)                                       \
     }
-                PTX_ADM_LOAD(lo, h, e)
+                PTX_ADM_LOAD(lo, h, e0, e1)
 #pragma nounroll
                 for (uint32_t cb = lo; cb < hi; cb += step) {
-                    PTX_ADM_LOAD(cb + step, h_n, e_n)
-                    const uint32_t cl = cb + lane * PTX_AC;
-                    uint32_t o01[PTX_AC], o23[PTX_AC], t01 = 0, t23 = 0;
-#pragma unroll
-                    for (uint32_t u = 0; u < PTX_AC; ++u) {
-                        const bool in = cl + u < hi;
-                        const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
-                        rows += in ? h[u] & PTX_CHG_NOPS : 0u;
-                        if (in && a >= na) badc = cl + u < badc ? cl + u : badc;
-                        o01[u] = in && a < 2u ? 1u << (16u * a) : 0u;
-                        o23[u] = in && a == 2u ? 1u : 0u;
-                        t01 += o01[u];
-                        t23 += o23[u];
+                    PTX_ADM_LOAD(cb + step, h_n, e0_n, e1_n)
+                    if (cb + step <= hi) {
+                        ptx_adm_step<false>(S, h, e0, e1, PTX_AC, mx0, mx1, bad, amax, hsum);
+                    } else { /* the last, partial step of the segment: lanes past `hi` play changes of no actor */
+                        const uint32_t cl = cb + lane * PTX_AC;
+                        ptx_adm_step<true>(S, h, e0, e1, cl < hi ? hi - cl : 0u, mx0, mx1, bad, amax, hsum);
                     }
-                    const uint32_t i01 = ptx_wave_incl_scan(t01), i23 = ptx_wave_incl_scan(t23);
-                    uint32_t w01 = b01 + i01 - t01, w23 = b23 + i23 - t23; /* relative clock before this lane's first change */
-#pragma unroll
-                    for (uint32_t u = 0; u < PTX_AC; ++u) {
-                        const bool in = cl + u < hi;
-                        const uint32_t a = h[u] >> PTX_CHG_ACTOR_SHIFT;
-                        const uint32_t clk[3] = {w01 & 0xFFFFu, w01 >> 16, w23 & 0xFFFFu};
-                        const uint32_t ev = (uint32_t)e[u][0] - 1u - (a < 3u ? clk[a < 3u ? a : 0u] : 0u);
-#pragma unroll
-                        for (uint32_t b = 0; b < 3; ++b) {
-                            const bool mine = in && a == b;
-                            emin[b] = mine && ev < emin[b] ? ev : emin[b];
-                            emax[b] = mine && ev > emax[b] ? ev : emax[b];
-                            const uint32_t dv = (uint32_t)e[u][1u + b] + 0x10000u - clk[b];
-                            mx[b] = in && b < na && dv > mx[b] ? dv : mx[b];
-                        }
-                        w01 += o01[u];
-                        w23 += o23[u];
-                    }
-                    b01 += ptx_wave_last(i01);
-                    b23 += ptx_wave_last(i23);
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
                         h[u] = h_n[u];
-#pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) e[u][b] = e_n[u][b];
+                        e0[u] = e0_n[u];
+                        e1[u] = e1_n[u];
                     }
                 }
 #undef PTX_ADM_LOAD
-#pragma unroll
-                for (uint32_t b = 0; b < 3; ++b) {
-                    emin[b] = ptx_wave_min(emin[b]);
-                    emax[b] = ptx_wave_max(emax[b]);
-                    mx[b] = ptx_wave_max(mx[b]);
-                }
+                mx0 = ptx_wave_pk_max_u16(mx0);
+                mx1 = ptx_wave_pk_max_u16(mx1);
+                bad = ptx_wave_max(bad);
+                amax = ptx_wave_max(amax);
+                /* rows of the segment = sum of the headers' low 20 bits = sum of the headers - (actors << 20), modulo 2^32 */
+                hsum -= lane == 0u ? ((S.by & 0xFFFFu) + 2u * (S.by >> 16)) << PTX_CHG_ACTOR_SHIFT : 0u;
+                ptx_reduce_add32(&H->cur[7], hsum);
                 if (lane == 0u) {
                     uint32_t* r = wrec + w * 12u;
-                    r[0] = b01;
-                    r[1] = b23;
-#pragma unroll
-                    for (uint32_t b = 0; b < 3; ++b) {
-                        r[2u + b] = emin[b];
-                        r[5u + b] = emax[b];
-                        r[8u + b] = mx[b];
-                    }
-                }
-                ptx_reduce_add32(&H->cur[7], rows);
-                if (badc != 0xFFFFFFFFu) {
-                    uint32_t row;
-                    PTX_CHANGE_ROW(badc, row);
-                    ptx_atomic_min(&H->adm, ((row * 2u) << 4) | PTX_ERR_BAD_OP);
+                    r[0] = S.bx;
+                    r[1] = S.by;
+                    r[2] = S.gx;
+                    r[3] = S.gy;
+                    r[4] = S.known;
+                    r[5] = bad;
+                    r[6] = mx0;
+                    r[7] = mx1;
+                    r[8] = amax;
                 }
             }
             PTX_SYNC();
-            if (H->adm != PTX_NO_ERR || H->cur[7] != N) { /* malformed envelope; the changes must tile the rows of the log exactly */
-                lds_high = bp.high;
-                return PTX_ERR_BAD_OP;
-            }
-            bool admitted = true; /* the same answer in every thread: wrec is complete */
+            bool admitted = H->cur[7] == N; /* the same answer in every thread: wrec is complete.  The changes must tile the rows of the log exactly */
             {
                 uint32_t B[3] = {0u, 0u, 0u};
                 for (uint32_t w = 0; w < nwv_; ++w) {
                     const uint32_t* r = wrec + w * 12u;
+                    const uint32_t G[3] = {r[2] >> 16, r[3] & 0xFFFFu, r[3] >> 16}, M[3] = {r[6] >> 16, r[7] & 0xFFFFu, r[7] >> 16};
+                    if ((r[8] >> PTX_CHG_ACTOR_SHIFT) >= na || r[5] != 0u) admitted = false; /* an actor beyond the document's; two changes of an actor disagree on seq - clock */
 #pragma unroll
                     for (uint32_t b = 0; b < 3; ++b) {
-                        if (r[5u + b] >= r[2u + b] && (r[2u + b] != B[b] || r[5u + b] != B[b])) admitted = false; /* some seq != clock + 1 */
-                        if (r[8u + b] > B[b] + 0x10000u) admitted = false;                                           /* some dep > clock */
+                        if (((r[4] >> b) & 1u) && G[b] != B[b] + 1u) admitted = false; /* some seq != clock + 1 */
+                        if (b < na && M[b] > B[b]) admitted = false;                     /* some dep > clock */
                     }
-                    B[0] += r[0] & 0xFFFFu;
-                    B[1] += r[0] >> 16;
-                    B[2] += r[1] & 0xFFFFu;
+                    B[0] += r[0] >> 16;
+                    B[1] += r[1] & 0xFFFFu;
+                    B[2] += r[1] >> 16;
                 }
             }
             if (!admitted) {
                 /* EXACT walk of a failing log: which change fails first, and how (the reference throws there) */
+                PTX_NOTE_EXACT_WALK(); /* test / diagnostic hook: valid logs must never come here */
                 PTX_SYNC();
                 PTX_LEADER { H->cur[7] = 0; }
                 PTX_SYNC();
@@ -852,132 +887,131 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_FOR(w, nwe + 1) delbits[w] = 0;
         PTX_FOR(w, (K >> 5) + 1) maddbits[w] = 0;
+        if (A.out_rank) PTX_FOR(i, N) A.out_rank[base + i] = 0xFFFFFFFFu; /* the insert rows are overwritten in P5a */
+        /* The list cursors are ABSOLUTE: indices of 16-bit words from the start of the log's LDS window, so that a row's list slot
+         * is one number whatever its class (no per-row choice of a list).  Rows that are listed nowhere (makeList, NOP, malformed)
+         * land in a four-entry dump. */
+        uint16_t* const lds16 = (uint16_t*)lds;
+        uint16_t* dump = ptx_alloc<uint16_t>(bp, 4);
+        PTX_BAIL_CAPACITY();
+        const uint32_t i_at = (uint32_t)(ilist - lds16), d_at = (uint32_t)(dlist - lds16), m_at = (uint32_t)(mlist - lds16), dump_at = (uint32_t)(dump - lds16);
+        const uint32_t k_delta = (uint32_t)(klist - ilist);   /* the key of an insert sits this far behind its list entry */
+        const uint32_t top16 = A.lds_bytes / 2u - 1u;          /* last 16-bit word of the window */
         PTX_LEADER {
-            /* list cursors (class 0 insert -> ilist, 1 delete -> dlist, 2..5 mark type 0..3 -> mlist) */
-            H->cur[0] = 0;
-            H->cur[1] = 0;
-            H->cur[2] = 0;
-            H->cur[3] = moff1;
-            H->cur[4] = moff2;
-            H->cur[5] = moff3;
-            H->cur[6] = H->cur[7] = 0;
+            /* class 0 insert -> ilist, 1 delete -> dlist, 2..5 mark type 0..3 -> its range of mlist */
+            H->cur[0] = i_at;
+            H->cur[1] = d_at;
+            H->cur[2] = m_at;
+            H->cur[3] = m_at + moff1;
+            H->cur[4] = m_at + moff2;
+            H->cur[5] = m_at + moff3;
+            H->cur[6] = H->cur[7] = 0; /* cur[7]: some row is malformed */
             H->n_ins = n;
             H->n_applied = n + D + K;
         }
         PTX_SYNC();
-        /* Branch-free row loop: every row does the same work; rows that are out of range, malformed or of no
-         * interest (makeList, NOP) use class 6/7 = a spare cursor, the spare list slot and OR 0 into the bitmaps. */
-        uint32_t badrow = 0xFFFFFFFFu; /* first malformed / duplicate row seen by this thread */
-        const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
-        static_assert(PTX_U1 <= 4, "the action / mark type bytes of a thread's rows travel in one dword");
-        uint64_t id[PTX_U1];
-        uint32_t a4, mt4; /* action / mark type of the thread's PTX_U1 rows, one byte each */
-#if PTX_P1_PREFETCH
-        uint64_t id_n[PTX_U1];
-        uint32_t a4_n, mt4_n;
-#endif
-#if PTX_P1_PREFETCH > 1
-        uint64_t id_m[PTX_U1]; /* the step in between */
-        uint32_t a4_m, mt4_m;
-#endif
-        /* this thread's PTX_U1 consecutive rows of a step; indices past the end are clamped, their effects masked.  The two byte
-         * columns are read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
-#define PTX_P1_LOAD(g_, id_, a_, mt_)                                   \
-    {                                                                   \
-        const uint32_t r0_ = (g_) * PTX_U1;                             \
-        _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {             \
-            const uint32_t r_ = r0_ + (uint32_t)u;                      \
-            id_[u] = op_id[r_ < N ? r_ : N - 1u];                       \
-        }                                                               \
-        PTX_P1_BYTES(action, r0_, a_)                                   \
-        PTX_P1_BYTES(mark_type, r0_, mt_)                               \
+        /* Branch-free row loop, PTX_U1 consecutive rows per thread and step.  What the header promised is NOT re-checked per
+         * row: a list that overflows (more rows of a class than the header says) overwrites scratch of this log only — every
+         * store is kept inside the log's window — and the census check after the pass rejects the log; a row with a malformed
+         * action / mark type / op id only raises a flag here, and the (rare) pass below names the first such row. */
+        uint32_t err4 = 0, ctr_hi = 0, act_hi = 0; /* malformed class bytes; max counter - 1 and max actor met */
+        const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_full = N / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
+        static_assert(PTX_U1 == 3, "three class bytes per dword; the fourth byte read belongs to the next thread's first row");
+        uint64_t id[PTX_U1], id_n[PTX_U1];
+        uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
+        /* this thread's PTX_U1 consecutive rows of a step.  A wave whose rows all exist reads them from one address; the wave that
+         * holds the end of the log clamps every row index (effects of the rows past the end are masked).  The two byte columns are
+         * read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
+#define PTX_P1_LOAD(g_, id_, a_, mt_)                                       \
+    {                                                                       \
+        const uint32_t r0_ = (g_) * PTX_U1;                                 \
+        if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) {                       \
+            PTX_P1_IDS(id_, op_id + r0_)                                    \
+        } else {                                                            \
+            _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {            \
+                const uint32_t r_ = r0_ + (uint32_t)u;                      \
+                id_[u] = op_id[r_ < N ? r_ : N - 1u];                       \
+            }                                                               \
+        }                                                                   \
+        PTX_P1_BYTES(action, r0_, a_)                                       \
+        PTX_P1_BYTES(mark_type, r0_, mt_)                                   \
     }
-#if PTX_P1_PREFETCH
+        /* the work on one thread's rows; kMasked: only the first `nv` of them exist */
+        auto p1_rows = [&](auto masked, uint32_t g, uint32_t nv) {
+            constexpr bool kMasked = decltype(masked)::value;
+            const uint32_t r0 = g * PTX_U1;
+            const uint32_t live = kMasked ? (1u << (8u * nv)) - 1u : 0x00FFFFFFu; /* bytes of a4 / mt4 that are rows of this thread */
+            /* class of the rows, four bytes at a time (byte permutes as table look-ups):
+             * action 0 makeList -> 6, 1 insert -> 0, 2 delete -> 1, 3 / 4 add / removeMark -> 2 + mark type, 5 nop -> 6, else 7 */
+            const uint32_t k4 = ptx_perm(0x47470680u, 0x80010006u, a4 & 0x07070707u); /* 0x80: a mark op; 0x47: class 7, malformed */
+            const uint32_t mk = (k4 >> 7) & 0x01010101u;     /* 1 in the bytes of the mark ops */
+            const uint32_t mmask = ptx_mul24(mk, 255u);        /* 0xFF there (the three bytes that are this thread's rows) */
+            uint32_t c4 = ((k4 & ~mmask) | (((mt4 & 0x03030303u) + 0x02020202u) & mmask)) & 0x07070707u;
+            /* unknown action (6, 7, or beyond the table), mark type beyond 3: flagged; the row runs on under some class */
+            err4 |= ((k4 & 0x40404040u) | (a4 & 0xF8F8F8F8u) | (mt4 & 0xFCFCFCFCu & mmask)) & live;
+            if (kMasked) c4 = (c4 & live) | (0x07070707u & ~live);
+            const uint32_t add4 = a4 & mk & live; /* bit 0 tells PTX_ACT_ADDMARK (3) from PTX_ACT_REMOVEMARK (4) */
+            uint32_t slot[PTX_U1];
+            ptx_wave_slots4<PTX_U1>(H->cur, dump_at, c4, slot);
+#pragma unroll
+            for (int u = 0; u < PTX_U1; ++u) {
+                const uint32_t i = r0 + (uint32_t)u;
+                const bool in = !kMasked || (uint32_t)u < nv;
+                const uint32_t c = (c4 >> (8u * (uint32_t)u)) & 255u;
+                const uint32_t ctr = (uint32_t)(id[u] >> 32), act = (uint32_t)id[u];
+                if (in) {
+                    ctr_hi = ctr - 1u > ctr_hi ? ctr - 1u : ctr_hi; /* a counter of 0 wraps to the top */
+                    act_hi = act > act_hi ? act : act_hi;
+                }
+                /* both id bitmaps in one atomic; a key beyond the header's bounds (flagged above) is kept inside the bitmap */
+                const uint32_t key = ptx_min(ptx_mad24_su(ctr, ix.na1, act), keyspace - 1u);
+                const uint32_t bit = 1u << (key & 31u);
+                if (in) ptx_atomic_or64((unsigned long long*)&ix.ib[key >> 5], (unsigned long long)(c == 0u ? bit : 0u) | ((unsigned long long)bit << 32));
+                const uint32_t sl = ptx_min(slot[u], top16);
+                lds16[sl] = (uint16_t)i;
+                if (small_keys && c == 0u) lds16[ptx_min(sl + k_delta, top16)] = (uint16_t)key;
+                if ((add4 >> (8u * (uint32_t)u)) & 1u) {
+                    const uint32_t k = ptx_min(sl - m_at, K); /* K: the spare bit */
+                    ptx_atomic_or(&maddbits[k >> 5], 1u << (k & 31u));
+                }
+            }
+        };
         PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a4, mt4)
-#endif
-#if PTX_P1_PREFETCH > 1
-        PTX_P1_LOAD(PTX_G_OF(1u, p1_steps), id_m, a4_m, mt4_m)
-#endif
 #pragma nounroll
         for (uint32_t st = 0; st < p1_steps; ++st) {
             const uint32_t g = PTX_G_OF(st, p1_steps);
             if (PTX_WAVE_FIRST(g) >= p1_groups) continue; /* this wave has no row left in this step (wave-uniform) */
-#if PTX_P1_PREFETCH
-            const uint32_t gn = PTX_G_OF(st + (uint32_t)PTX_P1_PREFETCH, p1_steps);
-            PTX_P1_LOAD(gn, id_n, a4_n, mt4_n) /* later steps' rows are in flight while this step is processed */
-#else
-            PTX_P1_LOAD(g, id, a4, mt4)
-#endif
-            uint32_t cls[PTX_U1], slot[PTX_U1];
+            const uint32_t gn = PTX_G_OF(st + 1u, p1_steps);
+            PTX_P1_LOAD(gn, id_n, a4_n, mt4_n) /* the next step's rows are in flight while this step is processed */
+            if (PTX_WAVE_FIRST(g) + PTX_WS <= p1_full) p1_rows(std::false_type(), g, PTX_U1);
+            else p1_rows(std::true_type(), g, g * PTX_U1 < N ? (N - g * PTX_U1 < PTX_U1 ? N - g * PTX_U1 : PTX_U1) : 0u);
 #pragma unroll
-            for (int u = 0; u < PTX_U1; ++u) {
-                const uint32_t i = g * PTX_U1 + (uint32_t)u;
-                const bool in = i < N;
-                const uint32_t ctr = (uint32_t)(id[u] >> 32), act = (uint32_t)id[u];
-                /* action -> class through a nibble table: 0 makeList->6, 1 insert->0, 2 delete->1, 3/4 marks->2, 5 nop->6, else 7 */
-                const uint32_t au = (a4 >> (8u * (uint32_t)u)) & 255u, mtu = (mt4 >> (8u * (uint32_t)u)) & 255u;
-                uint32_t c = au < 8u ? (0x77622106u >> (au * 4u)) & 15u : 7u;
-                c = c == 2u ? (mtu < 4u ? 2u + mtu : 7u) : c;
-                const bool keybad = ctr - 1u >= ix.max_ctr || act > ix.max_actor; /* ctr == 0 or beyond the header's bounds */
-                badrow = in && (c == 7u || keybad) && i < badrow ? i : badrow;
-                cls[u] = (!in || keybad) ? 7u : c;
-            }
-            ptx_wave_slots<PTX_U1>(H->cur, cls, slot);
-#pragma unroll
-            for (int u = 0; u < PTX_U1; ++u) {
-                const uint32_t i = g * PTX_U1 + (uint32_t)u;
-                const uint32_t c = cls[u];
-                const uint32_t key = c == 7u ? 0u : (uint32_t)(id[u] >> 32) * ix.na1 + (uint32_t)id[u];
-                const uint32_t bit = c == 7u ? 0u : 1u << (key & 31);
-                /* duplicates are counted after the pass (no return value needed here); rows without a usable id touch nothing */
-                if (bit) ptx_atomic_or64((unsigned long long*)&ix.ib[key >> 5], (unsigned long long)(c == 0u ? bit : 0u) | ((unsigned long long)bit << 32));
-                /* rows that are listed nowhere (and slots beyond what the header promised) go to the spare slot of mlist */
-                uint16_t* lst = c == 0u ? ilist : c == 1u ? dlist : mlist;
-                const uint32_t cap = c == 0u ? n : c == 1u ? D : K;
-                const bool listed = c < 6u && slot[u] < cap;
-                const uint32_t sl = listed ? slot[u] : (c == 0u ? n : c == 1u ? D : K);
-                lst[sl] = (uint16_t)i;
-                if (small_keys && c == 0u) klist[sl] = (uint16_t)key;
-                if (listed && c >= 2u && ((a4 >> (8u * (uint32_t)u)) & 255u) == PTX_ACT_ADDMARK) ptx_atomic_or(&maddbits[sl >> 5], 1u << (sl & 31u));
-                if (A.out_rank && i < N) A.out_rank[base + i] = 0xFFFFFFFFu; /* insert rows are overwritten in P5a */
-            }
-#if PTX_P1_PREFETCH > 1
-#pragma unroll
-            for (int u = 0; u < PTX_U1; ++u) {
-                id[u] = id_m[u];
-                id_m[u] = id_n[u];
-            }
-            a4 = a4_m;
-            mt4 = mt4_m;
-            a4_m = a4_n;
-            mt4_m = mt4_n;
-#elif PTX_P1_PREFETCH
-#pragma unroll
-            for (int u = 0; u < PTX_U1; ++u) {
-                id[u] = id_n[u];
-            }
+            for (int u = 0; u < PTX_U1; ++u) id[u] = id_n[u];
             a4 = a4_n;
             mt4 = mt4_n;
-#endif
         }
 #undef PTX_P1_LOAD
-        if (badrow != 0xFFFFFFFFu) {
-            /* which of the two: re-test the row */
-            const uint64_t id = op_id[badrow];
-            const uint32_t ctr = (uint32_t)(id >> 32), act = (uint32_t)id, a = action[badrow], mt = mark_type[badrow];
-            (void)id; (void)ctr; (void)act; (void)a; (void)mt;
-            ptx_raise(H, badrow, 1, PTX_ERR_BAD_OP);
-        }
+        if (err4 != 0u || ctr_hi >= ix.max_ctr || act_hi > ix.max_actor) ptx_atomic_or(&H->cur[7], 1u);
         PTX_SYNC();
+        if (H->cur[7] != 0u) {
+            /* some row is malformed (unknown action or mark type, op id of counter 0 or beyond the header's bounds): the first one
+             * in log order is the log's error — the rare path, one row per thread and step */
+            PTX_FOR(i, N) {
+                const uint32_t ctr = (uint32_t)(op_id[i] >> 32), act = (uint32_t)op_id[i], a = action[i], mt = mark_type[i];
+                const bool mark = a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK;
+                if (a > 7u || a == 6u || a == 7u || (mark && mt > 3u) || ctr - 1u >= ix.max_ctr || act > ix.max_actor) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
+            }
+        }
         PTX_LEADER {
             /* the header must be the exact census of the rows */
-            if (H->cur[0] != n || H->cur[1] != D || H->cur[2] != moff1 || H->cur[3] != moff2 || H->cur[4] != moff3 || H->cur[5] != K)
+            if (H->cur[0] != i_at + n || H->cur[1] != d_at + D || H->cur[2] != m_at + moff1 || H->cur[3] != m_at + moff2 || H->cur[4] != m_at + moff3 ||
+                H->cur[5] != m_at + K)
                 ptx_raise(H, 0, 0, PTX_ERR_BAD_OP);
         }
         {
             uint32_t distinct = 0;
             PTX_FOR(w, nw + 1) distinct += ptx_popc(ix.ib[w].pre);
-            ptx_atomic_add(&H->cur[6], distinct); /* cur[6] (the cursor of unlisted rows) is free again */
+            ptx_atomic_add(&H->cur[6], distinct);
         }
         PTX_SYNC();
         if (H->err == PTX_NO_ERR && H->cur[6] != N) {

@@ -103,6 +103,79 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
     }
 }
 
+/* ---- packed 16-bit arithmetic and byte permutes of the admission walk and the row pass (v_pk_max_u16, v_pk_sub_u16 clamp,
+ *      v_perm_b32, v_lshlrev_b64 / v_lshrrev_b64) ---- */
+typedef uint16_t ptx_u16x2 __attribute__((ext_vector_type(2)));
+PTX_DEV uint32_t ptx_pk_max_u16(uint32_t a, uint32_t b) { /* per 16-bit half: max */
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ptx_u16x2, a), __builtin_bit_cast(ptx_u16x2, b)));
+}
+PTX_DEV uint32_t ptx_pk_subsat_u16(uint32_t a, uint32_t b) { /* per 16-bit half: a - b, 0 where b > a */
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ptx_u16x2, a), __builtin_bit_cast(ptx_u16x2, b)));
+}
+/* byte k of the result = byte sel.k of the eight bytes {hi, lo} (0..3 = lo, 4..7 = hi), 0x0c = the constant 0 */
+PTX_DEV uint32_t ptx_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+PTX_DEV uint64_t ptx_shl64(uint64_t x, uint32_t s) { return x << (s & 63u); } /* the hardware takes the low six bits of the amount */
+PTX_DEV uint64_t ptx_shr64(uint64_t x, uint32_t s) { return x >> (s & 63u); }
+/* the value of SOME lane whose `pred` holds (false: no lane's does); the same answer in every lane */
+PTX_DEV bool ptx_wave_pick(bool pred, uint32_t value, uint32_t& out) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return false;
+    out = (uint32_t)__builtin_amdgcn_readlane((int)value, (int)(__ffsll((long long)m) - 1));
+    return true;
+}
+PTX_DEV uint32_t ptx_wave_pk_max_u16(uint32_t v) { /* per 16-bit half, the same value in every lane */
+    for (int d = 32; d >= 1; d >>= 1) v = ptx_pk_max_u16(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+
+PTX_DEV uint32_t ptx_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); } /* the low 24 bits of both factors */
+PTX_DEV uint32_t ptx_mad24(uint32_t a, uint32_t b, uint32_t c) { /* (a & 0xFFFFFF) * (b & 0xFFFFFF) + c in ONE full-rate instruction */
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+PTX_DEV uint32_t ptx_mad24_su(uint32_t a, uint32_t b, uint32_t c) { /* the same with b the same in every lane (a scalar register) */
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+PTX_DEV uint32_t ptx_min(uint32_t a, uint32_t b) { return __builtin_elementwise_min(a, b); }
+/* List slots for the rows of a wave's step, U consecutive rows per lane, their classes (0..7) in the bytes of c4: rows of class
+ * c < 6 get consecutive values from cursor[c], in ROW order within the wave (lane-major), so that the lists stay (nearly) sorted
+ * by row and later gathers through them stay (nearly) coalesced; rows of class 6 / 7 get dump .. dump + 3.  One LDS atomic per
+ * wave and step (6 lanes, 6 distinct cursors); the ranking is a DPP prefix sum over counters of 10 bits per class packed in two
+ * words (classes 0..2 at bits 0 / 10 / 20, classes 3..5 at bits 32 / 42 / 52, the unlisted ones in the two bits left over, which
+ * may overflow).  Every lane of the wave must call it (uniform control flow). */
+template <int U>
+PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint32_t* slot) {
+    const uint32_t sh4 = ptx_perm(0x3E3E342Au, 0x20140A00u, c4); /* class -> bit position of its counter */
+    const uint32_t ix4 = c4 << 2;                                /* class -> byte address of lane `class` for ds_bpermute */
+    uint32_t wl[U], wh[U], tl = 0, th = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint64_t one = ptx_shl64(1ull, sh4 >> (8 * u));
+        wl[u] = tl;
+        wh[u] = th;
+        tl += (uint32_t)one;
+        th += (uint32_t)(one >> 32);
+    }
+    const uint32_t il = ptx_wave_incl_scan(tl), ih = ptx_wave_incl_scan(th);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)il, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)ih, 63);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t basev = dump;
+    if (lane < 6u) {
+        const uint32_t cnt = ((lane >= 3u ? t1 : t0) >> ((lane >= 3u ? lane - 3u : lane) * 10u)) & 1023u;
+        basev = atomicAdd(&cursor[lane], cnt);
+    }
+    const uint32_t el = il - tl, eh = ih - th; /* exclusive prefix over the lower lanes */
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint64_t x = ((uint64_t)(eh + wh[u]) << 32) | (uint64_t)(el + wl[u]);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ix4 >> (8 * u)) & 255u), (int)basev);
+        slot[u] = b + ((uint32_t)ptx_shr64(x, sh4 >> (8 * u)) & 1023u);
+    }
+}
+
 /* Software-pipelined uniform loops: step st of `steps` handles group PTX_G_OF(st); the loads of step st+1 are
  * issued before step st is processed (the caller keeps two register sets).  Every thread runs every step; a
  * group index past the end means "no work" (its loads are clamped to valid addresses, its effects masked). */
@@ -121,10 +194,11 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
 
 /* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
  * emulation plays three one-lane waves in turn */
-#define PTX_WAVE_FIRST(g) ((g) - (threadIdx.x & 63u)) /* index handled by lane 0 of this wave */
+#define PTX_WAVE_FIRST(g) ((uint32_t)__builtin_amdgcn_readfirstlane((int)((g) - (threadIdx.x & 63u)))) /* index handled by lane 0 of this wave (readfirstlane: the compiler then knows it is the same in every lane) */
 #define PTX_WS 64u
 #define PTX_NWAVES (PTX_BLOCKDIM >> 6)
-#define PTX_FOR_WAVE(w, lane) for (uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, _once = 1; _once; _once = 0)
+/* (the wave index through readfirstlane: the compiler then knows that what derives from it is the same in every lane) */
+#define PTX_FOR_WAVE(w, lane) for (uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u, _once = 1; _once; _once = 0)
 PTX_DEV uint32_t ptx_wave_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
 PTX_DEV uint32_t ptx_wave_total(uint32_t v) { return ptx_wave_last(ptx_wave_incl_scan(v)); }
 PTX_DEV uint32_t ptx_wave_min(uint32_t v) { /* the same value in every lane */
@@ -211,6 +285,13 @@ PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* cl
     }
 }
 
+/* logs whose one-pass admission check failed and were walked again: counted by the diagnostic build only (slot PTX_NCLK - 1 of the
+ * phase clocks; tools/phase_profile.py prints it) */
+#define PTX_NOTE_EXACT_WALK()                                                                              \
+    do {                                                                                                   \
+        if (kDiag && A.clocks && threadIdx.x == 0) atomicAdd(&A.clocks[PTX_NCLK - 1], 1ull);               \
+    } while (0)
+
 /* only in the diagnostic build of the kernel (kDiag): phase cycle stamps and the early exit of the per-phase PMC runs */
 #define PTX_STAMP(k)                                                   \
     do {                                                               \
@@ -231,6 +312,16 @@ PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* cl
         const PtxH4 q_ = *(const PtxH4*)(c_hdr + (cl_));                                     \
         _Pragma("unroll") for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) dst_[u_] = q_.v[u_];      \
     }
+/* the same rows as dwords: e0_ = seq | deps[0] << 16, e1_ = deps[1] | deps[2] << 16 (rows of four u16) */
+#define PTX_ADM_ENVS32(e0_, e1_, cl_)                                                        \
+    {                                                                                        \
+        struct __attribute__((packed, aligned(4))) PtxE8 { uint32_t v[PTX_AC][2]; };         \
+        const PtxE8 q_ = *(const PtxE8*)(c_env + (uint64_t)(cl_) * 4u);                      \
+        _Pragma("unroll") for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) {                         \
+            e0_[u_] = q_.v[u_][0];                                                           \
+            e1_[u_] = q_.v[u_][1];                                                           \
+        }                                                                                    \
+    }
 #define PTX_ADM_ENVS(dst_, cl_)                                                              \
     {                                                                                        \
         struct __attribute__((packed, aligned(4))) PtxE4 { uint16_t v[PTX_AC][4]; };         \
@@ -241,6 +332,13 @@ PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* cl
 
 /* the action / mark_type bytes of a thread's PTX_U1 consecutive rows from r0_ on, one byte each in dst_ (uses N): ONE unaligned
  * 4-byte load; the library pads its copies of the byte columns by PTX_BYTE_PAD */
+/* the ids of a thread's PTX_U1 consecutive rows, all of which exist: one address, loads of 16 + 8 bytes */
+#define PTX_P1_IDS(dst_, ptr_)                                                         \
+    {                                                                                  \
+        struct __attribute__((packed, aligned(8))) PtxId3 { uint64_t v[PTX_U1]; };     \
+        const PtxId3 q_ = *(const PtxId3*)(ptr_);                                      \
+        _Pragma("unroll") for (int u_ = 0; u_ < PTX_U1; ++u_) dst_[u_] = q_.v[u_];     \
+    }
 #define PTX_P1_BYTES(col_, r0_, dst_)                                    \
     {                                                                    \
         struct __attribute__((packed, aligned(1))) PtxB4 { uint32_t v; };  \

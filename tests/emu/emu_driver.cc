@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 int ptx_emu_reverse = 0;
+unsigned long long ptx_emu_exact_walks = 0;
+extern "C" unsigned long long ptx_emu_exact_walk_count() { return ptx_emu_exact_walks; }
 #include "../../peritext_amd/csrc/merge_core.h"
 
 /* LDS of the next log: not zero-initialised on the GPU either; a sanitizer build forgets the padding marks of the log before */

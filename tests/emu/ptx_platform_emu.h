@@ -57,6 +57,46 @@ PTX_DEV void ptx_wave_slots(uint32_t* cursor, const uint32_t* cls, uint32_t* slo
     for (int u = 0; u < U; ++u) slot[u] = cls[u] < 6u ? cursor[cls[u]]++ : 0xFFFFFFFFu;
 }
 
+/* ---- packed 16-bit arithmetic and byte permutes (plain C restatements of v_pk_max_u16, v_pk_sub_u16 clamp, v_perm_b32) ---- */
+PTX_DEV uint32_t ptx_pk_max_u16(uint32_t a, uint32_t b) {
+    const uint32_t l = (a & 0xFFFFu) > (b & 0xFFFFu) ? a & 0xFFFFu : b & 0xFFFFu, h = (a >> 16) > (b >> 16) ? a >> 16 : b >> 16;
+    return l | (h << 16);
+}
+PTX_DEV uint32_t ptx_pk_subsat_u16(uint32_t a, uint32_t b) {
+    const uint32_t l = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) - (b & 0xFFFFu) : 0u, h = (a >> 16) > (b >> 16) ? (a >> 16) - (b >> 16) : 0u;
+    return l | (h << 16);
+}
+PTX_DEV uint32_t ptx_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    const uint64_t pool = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t q = (sel >> (8 * k)) & 255u;
+        const uint32_t byte = q < 8u ? (uint32_t)(pool >> (8u * q)) & 255u : (q <= 12u ? 0u : 255u); /* 8..11 (sign fills) are never selected by the kernels */
+        r |= byte << (8 * k);
+    }
+    return r;
+}
+PTX_DEV uint64_t ptx_shl64(uint64_t x, uint32_t s) { return x << (s & 63u); }
+PTX_DEV uint64_t ptx_shr64(uint64_t x, uint32_t s) { return x >> (s & 63u); }
+PTX_DEV bool ptx_wave_pick(bool pred, uint32_t value, uint32_t& out) {
+    if (pred) out = value;
+    return pred;
+}
+PTX_DEV uint32_t ptx_wave_pk_max_u16(uint32_t v) { return v; }
+
+PTX_DEV uint32_t ptx_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+PTX_DEV uint32_t ptx_mad24(uint32_t a, uint32_t b, uint32_t c) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu) + c; }
+PTX_DEV uint32_t ptx_mad24_su(uint32_t a, uint32_t b, uint32_t c) { return ptx_mad24(a, b, c); }
+PTX_DEV uint32_t ptx_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+/* the same with the classes of the rows in the bytes of c4 and absolute cursors; rows of class 6 / 7 go to the dump */
+template <int U>
+PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint32_t* slot) {
+    for (int u = 0; u < U; ++u) {
+        const uint32_t c = (c4 >> (8 * u)) & 255u;
+        slot[u] = c < 6u ? cursor[c]++ : dump + (uint32_t)(u & 3);
+    }
+}
+
 /* Software-pipelined uniform loops: step st of `steps` handles group PTX_G_OF(st); the loads of step st+1 are
  * issued before step st is processed (the caller keeps two register sets).  Every thread runs every step; a
  * group index past the end means "no work" (its loads are clamped to valid addresses, its effects masked). */
@@ -120,6 +160,10 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
 
 PTX_DEV void ptx_flush_clocks(unsigned long long*, unsigned long long*, int) {}
 
+/* logs whose one-pass admission check failed and were walked again by the exact code (the tests assert that valid logs never are) */
+extern unsigned long long ptx_emu_exact_walks;
+#define PTX_NOTE_EXACT_WALK() (++ptx_emu_exact_walks)
+
 /* phase stamps of the diagnostic build: nothing to stamp here */
 #define PTX_STAMP(k) ((void)0)
 
@@ -127,11 +171,18 @@ PTX_DEV void ptx_flush_clocks(unsigned long long*, unsigned long long*, int) {}
  * The library pads its copies of both columns, so the 16-byte loads may run past the last change. */
 #define PTX_ADM_HDRS(dst_, cl_) \
     for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) dst_[u_] = c_hdr[(cl_) + u_ < C ? (cl_) + u_ : C - 1u];
+#define PTX_ADM_ENVS32(e0_, e1_, cl_)                                                                         \
+    for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) {                                                                \
+        const uint16_t* row_ = c_env + (uint64_t)((cl_) + u_ < C ? (cl_) + u_ : C - 1u) * 4u;                 \
+        e0_[u_] = (uint32_t)row_[0] | ((uint32_t)row_[1] << 16);                                              \
+        e1_[u_] = (uint32_t)row_[2] | ((uint32_t)row_[3] << 16);                                              \
+    }
 #define PTX_ADM_ENVS(dst_, cl_)                                                              \
     for (uint32_t u_ = 0; u_ < PTX_AC; ++u_)                                                 \
         for (uint32_t b_ = 0; b_ < 4u; ++b_) dst_[u_][b_] = c_env[(uint64_t)((cl_) + u_ < C ? (cl_) + u_ : C - 1u) * 4u + b_];
 
 /* the action / mark_type bytes of a thread's PTX_U1 consecutive rows from r0_ on, one byte each in dst_ (uses N) */
+#define PTX_P1_IDS(dst_, ptr_) for (uint32_t u_ = 0; u_ < PTX_U1; ++u_) dst_[u_] = (ptr_)[u_];
 #define PTX_P1_BYTES(col_, r0_, dst_)                                    \
     dst_ = 0;                                                            \
     for (uint32_t u_ = 0; u_ < PTX_U1; ++u_) dst_ |= (uint32_t)col_[(r0_) + u_ < N ? (r0_) + u_ : N - 1u] << (8u * u_);

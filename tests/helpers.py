@@ -145,6 +145,13 @@ def emu_merge(b, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB, admission=Fal
     return res
 
 
+def emu_exact_walks(lib_path=EMU_LIB):
+    """Logs (so far, in this process) whose one-pass admission check failed and were walked again by the exact code."""
+    f = _emu(lib_path).ptx_emu_exact_walk_count
+    f.restype = C.c_ulonglong
+    return int(f())
+
+
 def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=None):
     """Patch streams from the host emulation of replay_core.h (tests only): wire.Patches."""
     n_logs = b.n_logs

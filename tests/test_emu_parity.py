@@ -257,7 +257,9 @@ def test_causal_admission_accepts_valid_logs(name):
     batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
     plain = H.emu_merge(batch)
     for reverse in (0, 1):
+        walks = H.emu_exact_walks()
         adm = H.emu_merge(batch, admission=True, reverse=reverse)
+        assert H.emu_exact_walks() == walks, "a valid log failed the one-pass admission check"
         assert (adm.logs["status"] == 0).all()
         assert (adm.logs["digest"] == plain.logs["digest"]).all()
 
@@ -346,9 +348,11 @@ def test_admission_fast_check_agrees_with_a_sequential_replay(reverse):
         env[c, col] = np.uint16(max(0, min(65535, int(env[c, col]) + delta)))
         touched[log] = (c, col, delta)
     batch.chg_env = env.reshape(-1)
+    walks = H.emu_exact_walks()
     res = H.emu_merge(batch, admission=True, reverse=reverse)
     want = [_sequential_admission(batch, log) for log in range(batch.n_logs)]
     got = [int(x) for x in res.logs["status"]]
+    assert H.emu_exact_walks() - walks == len(want) - want.count(0), "the exact walk runs for the failing logs and only for them"
     assert got == want, [(l, touched.get(l), g, w) for l, (g, w) in enumerate(zip(got, want)) if g != w][:5]
     assert want.count(0) > copies and want.count(abi.ERR_SEQ_GAP) > 10 and want.count(abi.ERR_MISSING_DEP) > 10
 
