@@ -876,8 +876,52 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_BAIL_CAPACITY();
     const uint32_t tree_lds = bp.off;
 
+    /* P3a's loads, declared here because its first step is issued as soon as P1 has completed the lists (its latency then hides
+     * behind the duplicate check and the prefix scan of the id bitmap) */
+    const uint32_t d_fused = D < n + 1u ? D : n + 1u; /* deletes that ride along with the inserts in P3a */
+    uint32_t p3_i[PTX_U], p3_di[PTX_U];
+    uint64_t p3_id[PTX_U], p3_ra[PTX_U], p3_dra[PTX_U];
+    /* rows of this thread's inserts and deletes of a step (list reads, then the column gathers) */
+#define PTX_P3A_LOAD(st_, i_, id_, ra_, di_, dra_)                          \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        const uint32_t j_ = PTX_J_OF(st_, u);                               \
+        const uint32_t s_ = j_ < n ? PTX_JX(j_, n) : 0u;                    \
+        const uint32_t r_ = ilist[s_];                                      \
+        i_[u] = r_ < N ? r_ : N - 1u;                                       \
+        if (small_keys) id_[u] = klist[s_];                                 \
+        const uint32_t dr_ = dlist[j_ < d_fused ? PTX_JX(j_, D) : 0u];      \
+        di_[u] = dr_ < N ? dr_ : N - 1u;                                    \
+    }                                                                       \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        if (!small_keys) id_[u] = op_id[i_[u]];                             \
+        ra_[u] = ref_a[i_[u]];                                              \
+        dra_[u] = ref_a[di_[u]];                                            \
+    }
     /* ---- P1: ONE pass over the rows: id bitmaps, row lists per class ---- */
     {
+        uint32_t err4 = 0, ctr_hi = 0, act_hi = 0; /* malformed class bytes; max counter - 1 and max actor met */
+        const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_full = N / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
+        static_assert(PTX_U1 == 3, "three class bytes per dword; the fourth byte read belongs to the next thread's first row");
+        uint64_t id[PTX_U1], id_n[PTX_U1];
+        uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
+        /* this thread's PTX_U1 consecutive rows of a step.  A wave whose rows all exist reads them from one address; the wave that
+         * holds the end of the log clamps every row index (effects of the rows past the end are masked).  The two byte columns are
+         * read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
+#define PTX_P1_LOAD(g_, id_, a_, mt_)                                       \
+    {                                                                       \
+        const uint32_t r0_ = (g_) * PTX_U1;                                 \
+        if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) {                       \
+            PTX_P1_IDS(id_, op_id + r0_)                                    \
+        } else {                                                            \
+            _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {            \
+                const uint32_t r_ = r0_ + (uint32_t)u;                      \
+                id_[u] = op_id[r_ < N ? r_ : N - 1u];                       \
+            }                                                               \
+        }                                                                   \
+        PTX_P1_BYTES(action, r0_, a_)                                       \
+        PTX_P1_BYTES(mark_type, r0_, mt_)                                   \
+    }
+        PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a4, mt4) /* the first rows are on their way while the bitmaps are cleared */
         /* during this pass ib[w] = {ids of the inserts, ids of ALL ops (duplicate detection)}: one 8-byte LDS atomic per row */
         PTX_FOR(w, nw + 1) {
             PtxBitWord z;
@@ -914,28 +958,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * row: a list that overflows (more rows of a class than the header says) overwrites scratch of this log only — every
          * store is kept inside the log's window — and the census check after the pass rejects the log; a row with a malformed
          * action / mark type / op id only raises a flag here, and the (rare) pass below names the first such row. */
-        uint32_t err4 = 0, ctr_hi = 0, act_hi = 0; /* malformed class bytes; max counter - 1 and max actor met */
-        const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_full = N / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
-        static_assert(PTX_U1 == 3, "three class bytes per dword; the fourth byte read belongs to the next thread's first row");
-        uint64_t id[PTX_U1], id_n[PTX_U1];
-        uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
-        /* this thread's PTX_U1 consecutive rows of a step.  A wave whose rows all exist reads them from one address; the wave that
-         * holds the end of the log clamps every row index (effects of the rows past the end are masked).  The two byte columns are
-         * read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
-#define PTX_P1_LOAD(g_, id_, a_, mt_)                                       \
-    {                                                                       \
-        const uint32_t r0_ = (g_) * PTX_U1;                                 \
-        if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) {                       \
-            PTX_P1_IDS(id_, op_id + r0_)                                    \
-        } else {                                                            \
-            _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {            \
-                const uint32_t r_ = r0_ + (uint32_t)u;                      \
-                id_[u] = op_id[r_ < N ? r_ : N - 1u];                       \
-            }                                                               \
-        }                                                                   \
-        PTX_P1_BYTES(action, r0_, a_)                                       \
-        PTX_P1_BYTES(mark_type, r0_, mt_)                                   \
-    }
         /* the work on one thread's rows; kMasked: only the first `nv` of them exist */
         auto p1_rows = [&](auto masked, uint32_t g, uint32_t nv) {
             constexpr bool kMasked = decltype(masked)::value;
@@ -976,7 +998,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 }
             }
         };
-        PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a4, mt4)
 #pragma nounroll
         for (uint32_t st = 0; st < p1_steps; ++st) {
             const uint32_t g = PTX_G_OF(st, p1_steps);
@@ -993,6 +1014,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_P1_LOAD
         if (err4 != 0u || ctr_hi >= ix.max_ctr || act_hi > ix.max_actor) ptx_atomic_or(&H->cur[7], 1u);
         PTX_SYNC();
+        PTX_P3A_LOAD(0u, p3_i, p3_id, p3_ra, p3_di, p3_dra) /* the lists are complete: P3a's first step is on its way */
         if (H->cur[7] != 0u) {
             /* some row is malformed (unknown action or mark type, op id of counter 0 or beyond the header's bounds): the first one
              * in log order is the log's error — the rare path, one row per thread and step */
@@ -1059,30 +1081,20 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * round trips hide behind the inserts'.  What a delete cannot do yet is the application-order check (row_of is being
          * written): the thread leaves the target element in the slot of `ilist` it has just consumed — same thread, same index,
          * no hazard — and the check runs below, from LDS alone.  Deletes beyond slot n (more deletes than inserts) go the old way. */
-        const uint32_t d_fused = D < n + 1u ? D : n + 1u;
         {
             const uint32_t jmax = n > d_fused ? n : d_fused;
             const uint32_t steps = PTX_JSTEPS(jmax);
             uint32_t i[PTX_U], i_n[PTX_U], di[PTX_U], di_n[PTX_U];
             uint64_t id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
             uint64_t dra[PTX_U], dra_n[PTX_U];
-            /* rows of this thread's inserts and deletes of a step (list reads, then the column gathers) */
-#define PTX_P3A_LOAD(st_, i_, id_, ra_, di_, dra_)                          \
-    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
-        const uint32_t j_ = PTX_J_OF(st_, u);                               \
-        const uint32_t s_ = j_ < n ? PTX_JX(j_, n) : 0u;                    \
-        const uint32_t r_ = ilist[s_];                                      \
-        i_[u] = r_ < N ? r_ : N - 1u;                                       \
-        if (small_keys) id_[u] = klist[s_];                                 \
-        const uint32_t dr_ = dlist[j_ < d_fused ? PTX_JX(j_, D) : 0u];      \
-        di_[u] = dr_ < N ? dr_ : N - 1u;                                    \
-    }                                                                       \
-    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
-        if (!small_keys) id_[u] = op_id[i_[u]];                             \
-        ra_[u] = ref_a[i_[u]];                                              \
-        dra_[u] = ref_a[di_[u]];                                            \
-    }
-            PTX_P3A_LOAD(0u, i, id, ra, di, dra)
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u) { /* step 0 was loaded at the end of P1 */
+                i[u] = p3_i[u];
+                id[u] = p3_id[u];
+                ra[u] = p3_ra[u];
+                di[u] = p3_di[u];
+                dra[u] = p3_dra[u];
+            }
 #pragma nounroll
             for (uint32_t st = 0; st < steps; ++st) {
                 PTX_P3A_LOAD(st + 1u, i_n, id_n, ra_n, di_n, dra_n) /* in flight while this step is processed */
@@ -1289,6 +1301,28 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     bp.off = mark_lds; /* release the tree scratch */
     PTX_STAMP(5);
 
+    /* P5a's loads, issued here: the first step's gathers hide behind P4 and the values pass */
+    const uint32_t m_steps = PTX_JSTEPS_U(K, PTX_UM);
+    uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
+    uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
+    /* rows of this thread's mark ops of a step (list read, then the column gathers; the payload only of the comment ops — their
+     * id —, the others' is not needed before P5b, and then only the winners') */
+#define PTX_MARK_LOAD(st_, i_, ra_, rb_, sa_, sb_, pl_)                     \
+    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
+        const uint32_t j_ = PTX_J_OF_U(st_, u, PTX_UM);                     \
+        const uint32_t k_ = j_ < K ? PTX_JX(j_, K) : 0u;                    \
+        const uint32_t r_ = mlist[k_];                                      \
+        i_[u] = r_ < N ? r_ : N - 1u;                                       \
+        pl_[u] = k_ >= moff2 && k_ < moff3 ? 1u : 0u;                       \
+    }                                                                       \
+    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
+        ra_[u] = ref_a[i_[u]];                                              \
+        rb_[u] = ref_b[i_[u]];                                              \
+        sa_[u] = A.side_a[base + i_[u]];                                    \
+        sb_[u] = A.side_b[base + i_[u]];                                    \
+        if (pl_[u]) pl_[u] = payload[i_[u]];                                \
+    }
+    PTX_MARK_LOAD(0u, i, ra, rb, sa, sb, pl)
     /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = nwe; /* bit positions 0..n by document position */
     PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
@@ -1320,24 +1354,30 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     /* ---- P5a: visible values out; every mark op -> visible interval [lo, hi) ---- */
     {
         uint64_t h1 = 0, h2 = 0;
-        PTX_FORU(e0, n) {
-            uint32_t r[PTX_U], row[PTX_U], v[PTX_U];
-            PtxBitWord w[PTX_U];
+        /* software-pipelined like the other gather loops: the next step's position / row / alive word (LDS) and value (HBM, visible
+         * elements only) are on their way while this step's values are written */
+        const uint32_t v_steps = PTX_JSTEPS(n);
+        uint32_t r[PTX_U], row[PTX_U], v[PTX_U], r_n[PTX_U], row_n[PTX_U], v_n[PTX_U];
+        PtxBitWord w[PTX_U], w_n[PTX_U];
+#define PTX_VAL_LOAD(st_, r_, row_, w_, v_)                                 \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        const uint32_t j_ = PTX_J_OF(st_, u);                               \
+        const uint32_t e_ = j_ < n ? PTX_JX(j_, n) : 0u;                    \
+        r_[u] = rnk[e_];                                                    \
+        row_[u] = row_of[e_];                                               \
+    }                                                                       \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        w_[u] = alive[r_[u] >> 5];                                          \
+        v_[u] = 0;                                                          \
+        if (PTX_J_OF(st_, u) < n && ((w_[u].bits >> (r_[u] & 31)) & 1u)) v_[u] = payload[row_[u] < N ? row_[u] : N - 1u]; \
+    }
+        PTX_VAL_LOAD(0u, r, row, w, v)
+#pragma nounroll
+        for (uint32_t st = 0; st < v_steps; ++st) {
+            PTX_VAL_LOAD(st + 1u, r_n, row_n, w_n, v_n)
 #pragma unroll
             for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(e0, u)) {
-                    r[u] = rnk[PTX_IX(e0, u)];
-                    row[u] = row_of[PTX_IX(e0, u)];
-                }
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(e0, u)) {
-                    w[u] = alive[r[u] >> 5];
-                    if ((w[u].bits >> (r[u] & 31)) & 1u) v[u] = payload[row[u]];
-                }
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_IN(e0, u)) {
+                if (PTX_J_OF(st, u) < n) {
                     if ((w[u].bits >> (r[u] & 31)) & 1u) {
                         const uint32_t q = w[u].pre + ptx_popc(w[u].bits & ((1u << (r[u] & 31)) - 1u));
                         A.out_values[base + q] = v[u];
@@ -1345,28 +1385,18 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     }
                     if (A.out_rank) A.out_rank[base + row[u]] = r[u] | (((w[u].bits >> (r[u] & 31)) & 1u) ? 0u : PTX_RANK_TOMBSTONE);
                 }
+#pragma unroll
+            for (int u = 0; u < PTX_U; ++u) {
+                r[u] = r_n[u];
+                row[u] = row_n[u];
+                w[u] = w_n[u];
+                v[u] = v_n[u];
+            }
         }
+#undef PTX_VAL_LOAD
         ptx_digest_flush(H, h1, h2);
     }
     {
-    const uint32_t m_steps = PTX_JSTEPS_U(K, PTX_UM);
-    uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
-    uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
-    /* rows of this thread's mark ops of a step (list read, then the five column gathers) */
-#define PTX_MARK_LOAD(st_, i_, ra_, rb_, sa_, sb_, pl_)                     \
-    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {                     \
-        const uint32_t j_ = PTX_J_OF_U(st_, u, PTX_UM);                               \
-        const uint32_t r_ = mlist[j_ < K ? PTX_JX(j_, K) : 0u];             \
-        i_[u] = r_ < N ? r_ : N - 1u;                                       \
-    }                                                                       \
-    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {                     \
-        ra_[u] = ref_a[i_[u]];                                              \
-        rb_[u] = ref_b[i_[u]];                                              \
-        sa_[u] = A.side_a[base + i_[u]];                                    \
-        sb_[u] = A.side_b[base + i_[u]];                                    \
-        pl_[u] = payload[i_[u]];                                            \
-    }
-    PTX_MARK_LOAD(0u, i, ra, rb, sa, sb, pl)
 #pragma nounroll
     for (uint32_t st = 0; st < m_steps; ++st) {
         PTX_MARK_LOAD(st + 1u, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* in flight while this step is processed */
