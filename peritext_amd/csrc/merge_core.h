@@ -63,6 +63,15 @@
 #ifndef PTX_UM
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
 #endif
+#ifndef PTX_P1_AHEAD
+#define PTX_P1_AHEAD 1 /* steps of row loads in flight ahead of the one in work in P1 (1 or 2; measured: 2 is 2 % slower — more requests in flight only queue) */
+#endif
+#ifndef PTX_ADM_AHEAD
+#define PTX_ADM_AHEAD 1 /* the same for the admission walk */
+#endif
+#ifndef PTX_MARK_AHEAD
+#define PTX_MARK_AHEAD 1 /* steps of mark gathers in flight ahead of the one in work in P5a (1 or 2; measured: 2 is 1 % slower) */
+#endif
 #define PTX_NCLK 16
 
 /* the machine: gfx950 for the product; the CPU test-suite plays the workgroup with one host thread (tests/emu) */
@@ -105,7 +114,7 @@ struct PtxMergeArgs {
 
 #define PTX_END 0xFFFFu
 #ifndef PTX_S
-#define PTX_S 8u /* every PTX_S-th node of the Euler tour is a splitter of the list ranking */
+#define PTX_S 16u /* every PTX_S-th node of the Euler tour is a splitter of the list ranking (measured: 16 is 1 % faster than 8 and needs 0.6 KB less, 4 is 7 % slower) */
 #endif
 #define PTX_TILE_4 128u  /* visible chars up to which the four LWW trees are resident at once */
 #define PTX_TILE_1 512u  /* tile of the visible axis for longer documents (one tree, reused per mark type) */
@@ -576,6 +585,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 S.bx = S.by = S.gx = S.gy = S.known = 0u;
                 uint32_t mx0 = 0, mx1 = 0, bad = 0, amax = 0, hsum = 0;
                 uint32_t h[PTX_AC], h_n[PTX_AC], e0[PTX_AC], e1[PTX_AC], e0_n[PTX_AC], e1_n[PTX_AC];
+#if PTX_ADM_AHEAD > 1
+                uint32_t h_m[PTX_AC], e0_m[PTX_AC], e1_m[PTX_AC]; /* the step in between */
+#endif
 #define PTX_ADM_LOAD(cb_, h_, e0_, e1_)                                     \
     {                                                                       \
         const uint32_t cl0_ = (cb_) + lane * PTX_AC;                        \
@@ -584,9 +596,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_ADM_ENVS32(e0_, e1_, cl_)                                       \
     }
                 PTX_ADM_LOAD(lo, h, e0, e1)
+#if PTX_ADM_AHEAD > 1
+                PTX_ADM_LOAD(lo + step, h_m, e0_m, e1_m)
+#endif
 #pragma nounroll
                 for (uint32_t cb = lo; cb < hi; cb += step) {
-                    PTX_ADM_LOAD(cb + step, h_n, e0_n, e1_n)
+                    PTX_ADM_LOAD(cb + (uint32_t)PTX_ADM_AHEAD * step, h_n, e0_n, e1_n)
                     if (cb + step <= hi) {
                         ptx_adm_step<false>(S, h, e0, e1, PTX_AC, mx0, mx1, bad, amax, hsum);
                     } else { /* the last, partial step of the segment: lanes past `hi` play changes of no actor */
@@ -595,9 +610,18 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
+#if PTX_ADM_AHEAD > 1
+                        h[u] = h_m[u];
+                        e0[u] = e0_m[u];
+                        e1[u] = e1_m[u];
+                        h_m[u] = h_n[u];
+                        e0_m[u] = e0_n[u];
+                        e1_m[u] = e1_n[u];
+#else
                         h[u] = h_n[u];
                         e0[u] = e0_n[u];
                         e1[u] = e1_n[u];
+#endif
                     }
                 }
 #undef PTX_ADM_LOAD
@@ -904,6 +928,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         static_assert(PTX_U1 == 3, "three class bytes per dword; the fourth byte read belongs to the next thread's first row");
         uint64_t id[PTX_U1], id_n[PTX_U1];
         uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
+#if PTX_P1_AHEAD > 1
+        uint64_t id_m[PTX_U1]; /* the step in between */
+        uint32_t a4_m, mt4_m;
+#endif
         /* this thread's PTX_U1 consecutive rows of a step.  A wave whose rows all exist reads them from one address; the wave that
          * holds the end of the log clamps every row index (effects of the rows past the end are masked).  The two byte columns are
          * read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
@@ -922,6 +950,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_P1_BYTES(mark_type, r0_, mt_)                                   \
     }
         PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a4, mt4) /* the first rows are on their way while the bitmaps are cleared */
+#if PTX_P1_AHEAD > 1
+        PTX_P1_LOAD(PTX_G_OF(1u, p1_steps), id_m, a4_m, mt4_m)
+#endif
         /* during this pass ib[w] = {ids of the inserts, ids of ALL ops (duplicate detection)}: one 8-byte LDS atomic per row */
         PTX_FOR(w, nw + 1) {
             PtxBitWord z;
@@ -1002,14 +1033,26 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         for (uint32_t st = 0; st < p1_steps; ++st) {
             const uint32_t g = PTX_G_OF(st, p1_steps);
             if (PTX_WAVE_FIRST(g) >= p1_groups) continue; /* this wave has no row left in this step (wave-uniform) */
-            const uint32_t gn = PTX_G_OF(st + 1u, p1_steps);
-            PTX_P1_LOAD(gn, id_n, a4_n, mt4_n) /* the next step's rows are in flight while this step is processed */
+            const uint32_t gn = PTX_G_OF(st + (uint32_t)PTX_P1_AHEAD, p1_steps);
+            PTX_P1_LOAD(gn, id_n, a4_n, mt4_n) /* later steps' rows are in flight while this step is processed */
             if (PTX_WAVE_FIRST(g) + PTX_WS <= p1_full) p1_rows(std::false_type(), g, PTX_U1);
             else p1_rows(std::true_type(), g, g * PTX_U1 < N ? (N - g * PTX_U1 < PTX_U1 ? N - g * PTX_U1 : PTX_U1) : 0u);
+#if PTX_P1_AHEAD > 1
+#pragma unroll
+            for (int u = 0; u < PTX_U1; ++u) {
+                id[u] = id_m[u];
+                id_m[u] = id_n[u];
+            }
+            a4 = a4_m;
+            mt4 = mt4_m;
+            a4_m = a4_n;
+            mt4_m = mt4_n;
+#else
 #pragma unroll
             for (int u = 0; u < PTX_U1; ++u) id[u] = id_n[u];
             a4 = a4_n;
             mt4 = mt4_n;
+#endif
         }
 #undef PTX_P1_LOAD
         if (err4 != 0u || ctr_hi >= ix.max_ctr || act_hi > ix.max_actor) ptx_atomic_or(&H->cur[7], 1u);
@@ -1305,6 +1348,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     const uint32_t m_steps = PTX_JSTEPS_U(K, PTX_UM);
     uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
     uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
+#if PTX_MARK_AHEAD > 1
+    uint32_t i_m[PTX_UM], sa_m[PTX_UM], sb_m[PTX_UM], pl_m[PTX_UM]; /* the step in between */
+    uint64_t ra_m[PTX_UM], rb_m[PTX_UM];
+#endif
     /* rows of this thread's mark ops of a step (list read, then the column gathers; the payload only of the comment ops — their
      * id —, the others' is not needed before P5b, and then only the winners') */
 #define PTX_MARK_LOAD(st_, i_, ra_, rb_, sa_, sb_, pl_)                     \
@@ -1323,6 +1370,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         if (pl_[u]) pl_[u] = payload[i_[u]];                                \
     }
     PTX_MARK_LOAD(0u, i, ra, rb, sa, sb, pl)
+#if PTX_MARK_AHEAD > 1
+    PTX_MARK_LOAD(1u, i_m, ra_m, rb_m, sa_m, sb_m, pl_m)
+#endif
     /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = nwe; /* bit positions 0..n by document position */
     PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
@@ -1399,7 +1449,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     {
 #pragma nounroll
     for (uint32_t st = 0; st < m_steps; ++st) {
-        PTX_MARK_LOAD(st + 1u, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* in flight while this step is processed */
+        PTX_MARK_LOAD(st + (uint32_t)PTX_MARK_AHEAD, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* later steps' gathers are in flight while this step is processed */
 #pragma unroll
         for (int u = 0; u < (int)PTX_UM; ++u)
             if (PTX_J_OF_U(st, u, PTX_UM) < K) {
@@ -1438,12 +1488,27 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
 #pragma unroll
         for (int u = 0; u < (int)PTX_UM; ++u) {
+#if PTX_MARK_AHEAD > 1
+            i[u] = i_m[u];
+            ra[u] = ra_m[u];
+            rb[u] = rb_m[u];
+            sa[u] = sa_m[u];
+            sb[u] = sb_m[u];
+            pl[u] = pl_m[u];
+            i_m[u] = i_n[u];
+            ra_m[u] = ra_n[u];
+            rb_m[u] = rb_n[u];
+            sa_m[u] = sa_n[u];
+            sb_m[u] = sb_n[u];
+            pl_m[u] = pl_n[u];
+#else
             i[u] = i_n[u];
             ra[u] = ra_n[u];
             rb[u] = rb_n[u];
             sa[u] = sa_n[u];
             sb[u] = sb_n[u];
             pl[u] = pl_n[u];
+#endif
         }
     }
 #undef PTX_MARK_LOAD

@@ -306,21 +306,41 @@ PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* cl
 
 /* PTX_AC consecutive headers / envelope rows of a lane; indices past `hi` are clamped, their effects masked.
  * The library pads its copies of both columns, so the 16-byte loads may run past the last change. */
+#ifndef PTX_NT
+#define PTX_NT 0 /* 1: the columns that are read exactly once (Change envelope, op ids / action / mark type of the row pass) are loaded with the non-temporal hint */
+#endif
+typedef uint32_t ptx_u32x4 __attribute__((ext_vector_type(4)));
+typedef ptx_u32x4 ptx_u32x4_a4 __attribute__((aligned(4)));
+typedef uint64_t ptx_u64x2 __attribute__((ext_vector_type(2)));
+typedef ptx_u64x2 ptx_u64x2_a8 __attribute__((aligned(8)));
+typedef uint32_t ptx_u32_a1 __attribute__((aligned(1)));
+#if PTX_NT
+#define PTX_STREAM_LOAD(p_) __builtin_nontemporal_load(p_)
+#else
+#define PTX_STREAM_LOAD(p_) (*(p_))
+#endif
 #define PTX_ADM_HDRS(dst_, cl_)                                                              \
     {                                                                                        \
-        struct __attribute__((packed, aligned(4))) PtxH4 { uint32_t v[PTX_AC]; };            \
-        const PtxH4 q_ = *(const PtxH4*)(c_hdr + (cl_));                                     \
-        _Pragma("unroll") for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) dst_[u_] = q_.v[u_];      \
+        static_assert(PTX_AC == 4, "one 16-byte load of headers");                           \
+        const ptx_u32x4 q_ = PTX_STREAM_LOAD((const ptx_u32x4_a4*)(c_hdr + (cl_)));          \
+        dst_[0] = q_.x;                                                                      \
+        dst_[1] = q_.y;                                                                      \
+        dst_[2] = q_.z;                                                                      \
+        dst_[3] = q_.w;                                                                      \
     }
 /* the same rows as dwords: e0_ = seq | deps[0] << 16, e1_ = deps[1] | deps[2] << 16 (rows of four u16) */
 #define PTX_ADM_ENVS32(e0_, e1_, cl_)                                                        \
     {                                                                                        \
-        struct __attribute__((packed, aligned(4))) PtxE8 { uint32_t v[PTX_AC][2]; };         \
-        const PtxE8 q_ = *(const PtxE8*)(c_env + (uint64_t)(cl_) * 4u);                      \
-        _Pragma("unroll") for (uint32_t u_ = 0; u_ < PTX_AC; ++u_) {                         \
-            e0_[u_] = q_.v[u_][0];                                                           \
-            e1_[u_] = q_.v[u_][1];                                                           \
-        }                                                                                    \
+        const ptx_u32x4_a4* p_ = (const ptx_u32x4_a4*)(c_env + (uint64_t)(cl_) * 4u);        \
+        const ptx_u32x4 qa_ = PTX_STREAM_LOAD(p_), qb_ = PTX_STREAM_LOAD(p_ + 1);            \
+        e0_[0] = qa_.x;                                                                      \
+        e1_[0] = qa_.y;                                                                      \
+        e0_[1] = qa_.z;                                                                      \
+        e1_[1] = qa_.w;                                                                      \
+        e0_[2] = qb_.x;                                                                      \
+        e1_[2] = qb_.y;                                                                      \
+        e0_[3] = qb_.z;                                                                      \
+        e1_[3] = qb_.w;                                                                      \
     }
 #define PTX_ADM_ENVS(dst_, cl_)                                                              \
     {                                                                                        \
@@ -335,15 +355,14 @@ PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* cl
 /* the ids of a thread's PTX_U1 consecutive rows, all of which exist: one address, loads of 16 + 8 bytes */
 #define PTX_P1_IDS(dst_, ptr_)                                                         \
     {                                                                                  \
-        struct __attribute__((packed, aligned(8))) PtxId3 { uint64_t v[PTX_U1]; };     \
-        const PtxId3 q_ = *(const PtxId3*)(ptr_);                                      \
-        _Pragma("unroll") for (int u_ = 0; u_ < PTX_U1; ++u_) dst_[u_] = q_.v[u_];     \
+        static_assert(PTX_U1 == 3, "16 + 8 bytes");                                    \
+        const uint64_t* p_ = (ptr_);                                                   \
+        const ptx_u64x2 q_ = PTX_STREAM_LOAD((const ptx_u64x2_a8*)p_);                 \
+        dst_[0] = q_.x;                                                                \
+        dst_[1] = q_.y;                                                                \
+        dst_[2] = PTX_STREAM_LOAD(p_ + 2);                                             \
     }
-#define PTX_P1_BYTES(col_, r0_, dst_)                                    \
-    {                                                                    \
-        struct __attribute__((packed, aligned(1))) PtxB4 { uint32_t v; };  \
-        dst_ = ((const PtxB4*)(col_ + ((r0_) < N ? (r0_) : N - 1u)))->v; \
-    }
+#define PTX_P1_BYTES(col_, r0_, dst_) dst_ = PTX_STREAM_LOAD((const ptx_u32_a1*)(col_ + ((r0_) < N ? (r0_) : N - 1u)));
 
 /* ---- gen_core.h / change_core.h: ONE wave per workgroup ---- */
 /* 64-wide ballot over lanes: `expr` may use `lane_` */
