@@ -63,6 +63,9 @@
 #ifndef PTX_UM
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
 #endif
+#ifndef PTX_UB
+#define PTX_UB 2u /* mark ops per thread and step in the LWW pass P5b (one opId gather each, issued together) */
+#endif
 #ifndef PTX_P1_AHEAD
 #define PTX_P1_AHEAD 1 /* steps of row loads in flight ahead of the one in work in P1 (1 or 2; measured: 2 is 2 % slower — more requests in flight only queue) */
 #endif
@@ -1021,8 +1024,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 const uint32_t bit = 1u << (key & 31u);
                 if (in) ptx_atomic_or64((unsigned long long*)&ix.ib[key >> 5], (unsigned long long)(c == 0u ? bit : 0u) | ((unsigned long long)bit << 32));
                 const uint32_t sl = ptx_min(slot[u], top16);
-                lds16[sl] = (uint16_t)i;
-                if (small_keys && c == 0u) lds16[ptx_min(sl + k_delta, top16)] = (uint16_t)key;
+                PTX_LDS_WILD_STORE16(&lds16[sl], i); /* anywhere inside the window when the header understates the rows */
+                if (small_keys && c == 0u) PTX_LDS_WILD_STORE16(&lds16[ptx_min(sl + k_delta, top16)], key);
                 if ((add4 >> (8u * (uint32_t)u)) & 1u) {
                     const uint32_t k = ptx_min(sl - m_at, K); /* K: the spare bit */
                     ptx_atomic_or(&maddbits[k >> 5], 1u << (k & 31u));
@@ -1060,18 +1063,33 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_P3A_LOAD(0u, p3_i, p3_id, p3_ra, p3_di, p3_dra) /* the lists are complete: P3a's first step is on its way */
         if (H->cur[7] != 0u) {
             /* some row is malformed (unknown action or mark type, op id of counter 0 or beyond the header's bounds): the first one
-             * in log order is the log's error — the rare path, one row per thread and step */
+             * in log order is the log's error — the rare path, one row per thread and step.  The malformed rows were listed under
+             * some class by the pass above, so the census is taken again here, without them. */
+            uint32_t* cnt6 = H->scan_tmp;
+            PTX_LEADER {
+                for (int c = 0; c < 6; ++c) cnt6[c] = 0;
+            }
+            PTX_SYNC();
             PTX_FOR(i, N) {
                 const uint32_t ctr = (uint32_t)(op_id[i] >> 32), act = (uint32_t)op_id[i], a = action[i], mt = mark_type[i];
                 const bool mark = a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK;
-                if (a > 7u || a == 6u || a == 7u || (mark && mt > 3u) || ctr - 1u >= ix.max_ctr || act > ix.max_actor) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
+                if (a >= 6u || (mark && mt > 3u) || ctr - 1u >= ix.max_ctr || act > ix.max_actor) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
+                else if (a == PTX_ACT_INSERT) ptx_atomic_add(&cnt6[0], 1u);
+                else if (a == PTX_ACT_DELETE) ptx_atomic_add(&cnt6[1], 1u);
+                else if (mark) ptx_atomic_add(&cnt6[2u + mt], 1u);
             }
-        }
-        PTX_LEADER {
-            /* the header must be the exact census of the rows */
-            if (H->cur[0] != i_at + n || H->cur[1] != d_at + D || H->cur[2] != m_at + moff1 || H->cur[3] != m_at + moff2 || H->cur[4] != m_at + moff3 ||
-                H->cur[5] != m_at + K)
-                ptx_raise(H, 0, 0, PTX_ERR_BAD_OP);
+            PTX_SYNC();
+            PTX_LEADER {
+                if (cnt6[0] != n || cnt6[1] != D || cnt6[2] != moff1 || cnt6[3] != moff2 - moff1 || cnt6[4] != moff3 - moff2 || cnt6[5] != K - moff3)
+                    ptx_raise(H, 0, 0, PTX_ERR_BAD_OP);
+            }
+        } else {
+            PTX_LEADER {
+                /* the header must be the exact census of the rows */
+                if (H->cur[0] != i_at + n || H->cur[1] != d_at + D || H->cur[2] != m_at + moff1 || H->cur[3] != m_at + moff2 || H->cur[4] != m_at + moff3 ||
+                    H->cur[5] != m_at + K)
+                    ptx_raise(H, 0, 0, PTX_ERR_BAD_OP);
+            }
         }
         {
             uint32_t distinct = 0;
@@ -1628,19 +1646,40 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 if (k_hi == k_lo) continue;
                 PTX_FOR(p, ntree * 2 * TV) tree[p] = 0;
                 PTX_SYNC();
-                PTX_FOR(kk, k_hi - k_lo) {
-                    const uint32_t k = k_lo + kk;
-                    uint32_t lo = mrk_lo[k], hi = mrk_hi[k];
-                    lo = lo > t0 ? lo - t0 : 0u;
-                    hi = hi > t0 ? (hi - t0 < tv ? hi - t0 : tv) : 0u;
-                    if (lo < hi) { /* few marks still cover a visible char: the opId is re-read only for those */
-                        const uint32_t ty = PTX_TYPE_OF(k);
-                        uint32_t key = 0;
-                        ptx_id_key(ix, op_id[mlist[k]], key);
-                        /* LWW order = opId order; the low bits say who won.  The comment tree only records
-                         * "some comment op covers" (key `comment` present) */
-                        ptx_tree_chmax(tree + (four ? ty : 0u) * 2 * TV, TV, lo, hi, ty == PTX_MARK_COMMENT ? 1u : ((key + 1u) << kbits) | k);
+                /* PTX_UB mark ops per thread and step: the opIds of those that still cover a visible char (LWW order = opId order;
+                 * the comment tree only records "some comment op covers") are gathered together — one round trip to HBM per
+                 * step instead of one per op */
+                const uint32_t kn = k_hi - k_lo, b_steps = PTX_JSTEPS_U(kn, PTX_UB);
+#pragma nounroll
+                for (uint32_t st = 0; st < b_steps; ++st) {
+                    uint32_t kq[PTX_UB], lo[PTX_UB], hi[PTX_UB];
+                    uint64_t idq[PTX_UB];
+#pragma unroll
+                    for (int u = 0; u < (int)PTX_UB; ++u) {
+                        const uint32_t j = PTX_J_OF_U(st, u, PTX_UB);
+                        const uint32_t k = k_lo + (j < kn ? PTX_JX(j, kn) : 0u);
+                        uint32_t l = mrk_lo[k], h = mrk_hi[k];
+                        l = l > t0 ? l - t0 : 0u;
+                        h = h > t0 ? (h - t0 < tv ? h - t0 : tv) : 0u;
+                        if (j >= kn) l = h = 0u;
+                        kq[u] = k;
+                        lo[u] = l;
+                        hi[u] = h;
+                        idq[u] = 0;
+                        if (l < h && PTX_TYPE_OF(k) != PTX_MARK_COMMENT) {
+                            const uint32_t r = mlist[k];
+                            idq[u] = op_id[r < N ? r : N - 1u];
+                        }
                     }
+#pragma unroll
+                    for (int u = 0; u < (int)PTX_UB; ++u)
+                        if (lo[u] < hi[u]) {
+                            const uint32_t k = kq[u], ty = PTX_TYPE_OF(k);
+                            uint32_t key = 0;
+                            ptx_id_key(ix, idq[u], key);
+                            /* the low bits say who won */
+                            ptx_tree_chmax(tree + (four ? ty : 0u) * 2 * TV, TV, lo[u], hi[u], ty == PTX_MARK_COMMENT ? 1u : ((key + 1u) << kbits) | k);
+                        }
                 }
                 PTX_SYNC();
                 PTX_FOR(q, tv) {

@@ -14,6 +14,9 @@
 #define PTX_DEV __device__ __forceinline__
 #define PTX_SYNC() __syncthreads()
 #define PTX_LDS_ALLOCATED(p, used_bytes, total_bytes) ((void)0) /* a hook of the bump allocator (the CPU test-suite's sanitizer build marks the padding) */
+/* P1's list stores: inside the log's LDS window, but — when a header understates the rows of a class — not necessarily inside the list
+ * (the log is rejected afterwards); a hook for the CPU test-suite's sanitizer build, which poisons the padding between the arrays */
+#define PTX_LDS_WILD_STORE16(p, v) (*(p) = (uint16_t)(v))
 /* lanes of ONE wave talking through LDS: the LDS serves a wave's accesses in issue order, so only the compiler has to be kept from
  * moving or forwarding them — no s_barrier and, above all, no wait for the wave's outstanding stores to HBM (__syncthreads has one) */
 #define PTX_WSYNC()                                              \

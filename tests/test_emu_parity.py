@@ -466,3 +466,10 @@ def test_lds_bound_covers_the_high_water_mark(name):
                                     int(h["n_mark"][2]), (int(h["max_counter"]) + 1) * (int(h["max_actor"]) + 1), int(h["n_comment_ids"]))
         used = int(res.logs["reserved"][log][0])
         assert used <= need <= used + 6144, (log, used, need)  # slack = the LWW trees sized for V = n
+
+
+@pytest.mark.parametrize("reverse", [0, 1, 2])
+def test_malformed_rows_are_named(reverse):
+    """Unknown action / mark type, op ids of counter 0 or beyond the header's bounds, a header that promises fewer rows than the
+    log has (its lists overflow inside the log's window): PTX_ERR_BAD_OP with the first failing row, the other logs untouched."""
+    H.check_malformed_rows(lambda b: H.emu_merge(b, reverse=reverse))

@@ -341,3 +341,9 @@ def test_digest_allgather_in_the_c_abi_single_rank(eng):
         eng.comm_destroy(comm)
         eng.free_result(dr)
         eng.free_batch(db)
+
+
+def test_malformed_rows_are_named(eng):
+    """GPU twin: the row pass only flags malformed rows while it streams (and keeps every store inside the log's LDS window when a
+    header understates the rows); the first failing row is named by a second pass."""
+    H.check_malformed_rows(eng.apply_materialize)
