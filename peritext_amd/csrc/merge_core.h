@@ -63,6 +63,15 @@
 #ifndef PTX_UM
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
 #endif
+#ifndef PTX_KO
+#define PTX_KO 0 /* diagnostic builds only (tools/pmc_variants.sh): knock ONE gather stream out to see its share of the read requests — wrong results */
+#endif
+#ifndef PTX_HOIST_MARK
+#define PTX_HOIST_MARK 1 /* P5a's first gathers are issued ahead of P4 and the values pass (1 % faster; with the marks visited in row order it costs no extra read requests) */
+#endif
+#ifndef PTX_P1_WIDE
+#define PTX_P1_WIDE 1 /* P1 reads the ids of a thread's three rows from one address (16 + 8 bytes) where all of them exist */
+#endif
 #ifndef PTX_UB
 #define PTX_UB 2u /* mark ops per thread and step in the LWW pass P5b (one opId gather each, issued together) */
 #endif
@@ -454,6 +463,46 @@ PTX_DEV void ptx_adm_step(PtxAdmWave& S, const uint32_t* h, const uint32_t* e0, 
     for (uint32_t u = 0; u < PTX_AC; ++u) bad |= (s[u] ^ ptx_perm(S.gy, S.gx, sel[u])) & 0xFFFFu;
     S.bx += ptx_wave_last(ix);
     S.by += ptx_wave_last(iy);
+}
+
+/* ---- the mark ops of a log in ROW order although their list is grouped by mark type (four runs, each in row order): block b takes
+ *      the b-th slice of every run, so that the ops of a block come from one stretch of the log and their gathers of ref_a / ref_b /
+ *      sides / payload share cache lines (visiting run after run fetched every line of those columns once per run).  A block holds at
+ *      most PTX_JB_CAP ops; lane t of block b gets op k (false: none). ---- */
+struct PtxMarkBlocks {
+    uint32_t B;               /* blocks */
+    uint32_t off[4], sz[4];   /* first list slot and length of the run of mark type g */
+    uint32_t c[4];            /* ops of run g per block */
+};
+PTX_DEV PtxMarkBlocks ptx_mark_blocks(uint32_t moff1, uint32_t moff2, uint32_t moff3, uint32_t K, uint32_t cap) {
+    PtxMarkBlocks M;
+    M.off[0] = 0;
+    M.off[1] = moff1;
+    M.off[2] = moff2;
+    M.off[3] = moff3;
+    M.sz[0] = moff1;
+    M.sz[1] = moff2 - moff1;
+    M.sz[2] = moff3 - moff2;
+    M.sz[3] = K - moff3;
+    M.B = K ? (K + cap - 5u) / (cap - 4u) : 0u; /* ceil(K / (cap - 4)): then the four slices of a block, each rounded up, fit cap */
+    for (int g = 0; g < 4; ++g) M.c[g] = M.B ? (M.sz[g] + M.B - 1u) / M.B : 0u;
+    return M;
+}
+PTX_DEV bool ptx_mark_of(const PtxMarkBlocks& M, uint32_t b, uint32_t t, uint32_t& k) {
+    uint32_t o = 0;
+    bool found = false;
+    k = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t s0 = b * M.c[g], s = s0 < M.sz[g] ? s0 : M.sz[g];
+        const uint32_t e = s + M.c[g] < M.sz[g] ? s + M.c[g] : M.sz[g];
+        if (!found && t < o + (e - s)) {
+            k = M.off[g] + s + (t - o);
+            found = true;
+        }
+        o += e - s;
+    }
+    return found;
 }
 
 /* Uniform early exit on a per-log error.  The error word is sampled between two barriers so that a
@@ -922,7 +971,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
         if (!small_keys) id_[u] = op_id[i_[u]];                             \
         ra_[u] = ref_a[i_[u]];                                              \
-        dra_[u] = ref_a[di_[u]];                                            \
+        dra_[u] = PTX_KO == 4 ? ra_[u] : ref_a[di_[u]];                     \
     }
     /* ---- P1: ONE pass over the rows: id bitmaps, row lists per class ---- */
     {
@@ -941,7 +990,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #define PTX_P1_LOAD(g_, id_, a_, mt_)                                       \
     {                                                                       \
         const uint32_t r0_ = (g_) * PTX_U1;                                 \
-        if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) {                       \
+        if (PTX_P1_WIDE && PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) {        \
             PTX_P1_IDS(id_, op_id + r0_)                                    \
         } else {                                                            \
             _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {            \
@@ -1060,7 +1109,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_P1_LOAD
         if (err4 != 0u || ctr_hi >= ix.max_ctr || act_hi > ix.max_actor) ptx_atomic_or(&H->cur[7], 1u);
         PTX_SYNC();
+#ifndef PTX_NO_HOIST_P3A
         PTX_P3A_LOAD(0u, p3_i, p3_id, p3_ra, p3_di, p3_dra) /* the lists are complete: P3a's first step is on its way */
+#endif
         if (H->cur[7] != 0u) {
             /* some row is malformed (unknown action or mark type, op id of counter 0 or beyond the header's bounds): the first one
              * in log order is the log's error — the rare path, one row per thread and step.  The malformed rows were listed under
@@ -1148,6 +1199,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             uint32_t i[PTX_U], i_n[PTX_U], di[PTX_U], di_n[PTX_U];
             uint64_t id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
             uint64_t dra[PTX_U], dra_n[PTX_U];
+#ifdef PTX_NO_HOIST_P3A
+            PTX_P3A_LOAD(0u, p3_i, p3_id, p3_ra, p3_di, p3_dra)
+#endif
 #pragma unroll
             for (int u = 0; u < PTX_U; ++u) { /* step 0 was loaded at the end of P1 */
                 i[u] = p3_i[u];
@@ -1362,34 +1416,39 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     bp.off = mark_lds; /* release the tree scratch */
     PTX_STAMP(5);
 
-    /* P5a's loads, issued here: the first step's gathers hide behind P4 and the values pass */
-    const uint32_t m_steps = PTX_JSTEPS_U(K, PTX_UM);
+    /* P5a's loads: the first step's gathers are issued here, ahead of P4 and the values pass (PTX_HOIST_MARK) */
+    const PtxMarkBlocks MB = ptx_mark_blocks(moff1, moff2, moff3, K, PTX_JB_CAP);
+    const uint32_t m_steps = PTX_JB_STEPS(MB.B, PTX_UM);
+    uint32_t kq[PTX_UM], kq_n[PTX_UM]; /* the thread's mark ops of a step (0xFFFFFFFF: none) */
     uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
     uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
 #if PTX_MARK_AHEAD > 1
-    uint32_t i_m[PTX_UM], sa_m[PTX_UM], sb_m[PTX_UM], pl_m[PTX_UM]; /* the step in between */
+    uint32_t kq_m[PTX_UM], i_m[PTX_UM], sa_m[PTX_UM], sb_m[PTX_UM], pl_m[PTX_UM]; /* the step in between */
     uint64_t ra_m[PTX_UM], rb_m[PTX_UM];
 #endif
     /* rows of this thread's mark ops of a step (list read, then the column gathers; the payload only of the comment ops — their
      * id —, the others' is not needed before P5b, and then only the winners') */
-#define PTX_MARK_LOAD(st_, i_, ra_, rb_, sa_, sb_, pl_)                     \
+#define PTX_MARK_LOAD(st_, kq_, i_, ra_, rb_, sa_, sb_, pl_)                \
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
-        const uint32_t j_ = PTX_J_OF_U(st_, u, PTX_UM);                     \
-        const uint32_t k_ = j_ < K ? PTX_JX(j_, K) : 0u;                    \
+        uint32_t k_;                                                        \
+        const bool has_ = ptx_mark_of(MB, PTX_JB_BLOCK(st_, u, PTX_UM), PTX_JB_LANE(st_, u, PTX_UM), k_); \
+        kq_[u] = has_ ? k_ : 0xFFFFFFFFu;                                   \
         const uint32_t r_ = mlist[k_];                                      \
         i_[u] = r_ < N ? r_ : N - 1u;                                       \
-        pl_[u] = k_ >= moff2 && k_ < moff3 ? 1u : 0u;                       \
+        pl_[u] = has_ && k_ >= moff2 && k_ < moff3 ? 1u : 0u;               \
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
-        ra_[u] = ref_a[i_[u]];                                              \
         rb_[u] = ref_b[i_[u]];                                              \
+        ra_[u] = PTX_KO == 2 ? rb_[u] : ref_a[i_[u]];                       \
         sa_[u] = A.side_a[base + i_[u]];                                    \
         sb_[u] = A.side_b[base + i_[u]];                                    \
-        if (pl_[u]) pl_[u] = payload[i_[u]];                                \
+        if (pl_[u] && PTX_KO != 3) pl_[u] = payload[i_[u]];                 \
     }
-    PTX_MARK_LOAD(0u, i, ra, rb, sa, sb, pl)
+#if PTX_HOIST_MARK
+    PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl)
 #if PTX_MARK_AHEAD > 1
-    PTX_MARK_LOAD(1u, i_m, ra_m, rb_m, sa_m, sb_m, pl_m)
+    PTX_MARK_LOAD(1u, kq_m, i_m, ra_m, rb_m, sa_m, sb_m, pl_m)
+#endif
 #endif
     /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = nwe; /* bit positions 0..n by document position */
@@ -1437,7 +1496,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
         w_[u] = alive[r_[u] >> 5];                                          \
         v_[u] = 0;                                                          \
-        if (PTX_J_OF(st_, u) < n && ((w_[u].bits >> (r_[u] & 31)) & 1u)) v_[u] = payload[row_[u] < N ? row_[u] : N - 1u]; \
+        if (PTX_KO != 5 && PTX_J_OF(st_, u) < n && ((w_[u].bits >> (r_[u] & 31)) & 1u)) v_[u] = payload[row_[u] < N ? row_[u] : N - 1u]; \
     }
         PTX_VAL_LOAD(0u, r, row, w, v)
 #pragma nounroll
@@ -1465,13 +1524,19 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         ptx_digest_flush(H, h1, h2);
     }
     {
+#if !PTX_HOIST_MARK
+    PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl)
+#if PTX_MARK_AHEAD > 1
+    PTX_MARK_LOAD(1u, kq_m, i_m, ra_m, rb_m, sa_m, sb_m, pl_m)
+#endif
+#endif
 #pragma nounroll
     for (uint32_t st = 0; st < m_steps; ++st) {
-        PTX_MARK_LOAD(st + (uint32_t)PTX_MARK_AHEAD, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* later steps' gathers are in flight while this step is processed */
+        PTX_MARK_LOAD(st + (uint32_t)PTX_MARK_AHEAD, kq_n, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* later steps' gathers are in flight while this step is processed */
 #pragma unroll
         for (int u = 0; u < (int)PTX_UM; ++u)
-            if (PTX_J_OF_U(st, u, PTX_UM) < K) {
-                const uint32_t k = PTX_JX(PTX_J_OF_U(st, u, PTX_UM), K);
+            if (kq[u] != 0xFFFFFFFFu) {
+                const uint32_t k = kq[u];
                 uint32_t lo = 0, hi = 0;
                 /* start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is
                    not in the list when the op is applied means the op never starts */
@@ -1507,6 +1572,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #pragma unroll
         for (int u = 0; u < (int)PTX_UM; ++u) {
 #if PTX_MARK_AHEAD > 1
+            kq[u] = kq_m[u];
+            kq_m[u] = kq_n[u];
             i[u] = i_m[u];
             ra[u] = ra_m[u];
             rb[u] = rb_m[u];
@@ -1520,6 +1587,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             sb_m[u] = sb_n[u];
             pl_m[u] = pl_n[u];
 #else
+            kq[u] = kq_n[u];
             i[u] = i_n[u];
             ra[u] = ra_n[u];
             rb[u] = rb_n[u];
@@ -1649,26 +1717,33 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 /* PTX_UB mark ops per thread and step: the opIds of those that still cover a visible char (LWW order = opId order;
                  * the comment tree only records "some comment op covers") are gathered together — one round trip to HBM per
                  * step instead of one per op */
-                const uint32_t kn = k_hi - k_lo, b_steps = PTX_JSTEPS_U(kn, PTX_UB);
+                /* all four types at once: the ops in row order (blocks, as in P5a); one type at a time: its run is in row order */
+                const uint32_t kn = k_hi - k_lo, b_steps = four ? PTX_JB_STEPS(MB.B, PTX_UB) : PTX_JSTEPS_U(kn, PTX_UB);
 #pragma nounroll
                 for (uint32_t st = 0; st < b_steps; ++st) {
                     uint32_t kq[PTX_UB], lo[PTX_UB], hi[PTX_UB];
                     uint64_t idq[PTX_UB];
 #pragma unroll
                     for (int u = 0; u < (int)PTX_UB; ++u) {
-                        const uint32_t j = PTX_J_OF_U(st, u, PTX_UB);
-                        const uint32_t k = k_lo + (j < kn ? PTX_JX(j, kn) : 0u);
+                        uint32_t k;
+                        bool has;
+                        if (four) has = ptx_mark_of(MB, PTX_JB_BLOCK(st, u, PTX_UB), PTX_JB_LANE(st, u, PTX_UB), k);
+                        else {
+                            const uint32_t j = PTX_J_OF_U(st, u, PTX_UB);
+                            has = j < kn;
+                            k = k_lo + (has ? PTX_JX(j, kn) : 0u);
+                        }
                         uint32_t l = mrk_lo[k], h = mrk_hi[k];
                         l = l > t0 ? l - t0 : 0u;
                         h = h > t0 ? (h - t0 < tv ? h - t0 : tv) : 0u;
-                        if (j >= kn) l = h = 0u;
+                        if (!has) l = h = 0u;
                         kq[u] = k;
                         lo[u] = l;
                         hi[u] = h;
                         idq[u] = 0;
                         if (l < h && PTX_TYPE_OF(k) != PTX_MARK_COMMENT) {
                             const uint32_t r = mlist[k];
-                            idq[u] = op_id[r < N ? r : N - 1u];
+                            idq[u] = PTX_KO == 1 ? (uint64_t)r << 32 : op_id[r < N ? r : N - 1u];
                         }
                     }
 #pragma unroll

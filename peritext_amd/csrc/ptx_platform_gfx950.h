@@ -194,6 +194,11 @@ PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint3
 #define PTX_JSTEPS_U(n, U) ((PTX_DIV_T((n) + PTX_BLOCKDIM - 1u) + (U)-1u) / (U)) /* = ceil(n / (U * T)) */
 #define PTX_J_OF_U(st, u, U) (((st) * (U) + (uint32_t)(u)) * PTX_BLOCKDIM + threadIdx.x)
 #define PTX_JX(j, n) (j)
+/* loops over BLOCKS of items, U blocks per step: block b is handled by the whole workgroup, lane t of it by thread t */
+#define PTX_JB_CAP PTX_BLOCKDIM
+#define PTX_JB_STEPS(B, U) (((B) + (U)-1u) / (U))
+#define PTX_JB_BLOCK(st, u, U) ((st) * (U) + (uint32_t)(u))
+#define PTX_JB_LANE(st, u, U) (threadIdx.x)
 
 /* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
  * emulation plays three one-lane waves in turn */

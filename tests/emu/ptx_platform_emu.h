@@ -117,6 +117,11 @@ PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint3
 #define PTX_JSTEPS_U(n, U) (((n) + (U)-1u) / (U))
 #define PTX_J_OF_U(st, u, U) ((st) * (U) + (uint32_t)(u))
 #define PTX_JX(j, n) ((j) < (n) ? ptx_emu_ix((j), (n)) : (j))
+/* loops over BLOCKS of items: the emulation plays blocks of 8 lanes, one lane per step, in the selected order */
+#define PTX_JB_CAP 8u
+#define PTX_JB_STEPS(B, U) (((B) * PTX_JB_CAP + (U)-1u) / (U))
+#define PTX_JB_BLOCK(st, u, U) (((st) * (U) + (uint32_t)(u)) / PTX_JB_CAP)
+#define PTX_JB_LANE(st, u, U) (ptx_emu_ix(((st) * (U) + (uint32_t)(u)) % PTX_JB_CAP, PTX_JB_CAP))
 
 /* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
  * emulation plays three one-lane waves in turn */
