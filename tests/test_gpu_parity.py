@@ -204,6 +204,39 @@ def test_causal_admission_on_device(eng):
         assert (res2.logs[3]["digest"] == res.logs[3]["digest"]).all() and int(res2.logs[3]["status"]) == 0
 
 
+def test_admission_fast_check_passes_every_valid_log_on_the_device(eng):
+    """The one-pass admission check (packed 16-bit relative clocks per wave, the per-wave numbers validated after the pass) is the
+    part of P0 the CPU emulation cannot play (its waves have one lane): on the device no VALID log may fall back to the exact
+    walk — the diagnostic build counts those in slot 15 of the phase clocks — while every log with a perturbed envelope must."""
+    gen = _load("ptxgen_config4_600.json")
+    base = wire.encode_docs([d["logs"] for d in gen["docs"]]).tile(40)
+    db = eng.upload(base)
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        assert eng.phase_cycles(db, dr)[15] == 0
+        assert int(eng.download_logs(dr, base.n_logs)["status"].max()) == 0
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
+    es = abi.env_stride(base.max_actors)
+    rng = np.random.default_rng(5)
+    env = base.chg_env.copy().reshape(-1, es)
+    for log in range(base.n_logs):
+        c = int(rng.integers(int(base.chg_off[log]), int(base.chg_off[log + 1])))
+        env[c, 0] = np.uint16(int(env[c, 0]) + 1)  # every log: one seq too large
+    base.chg_env = env.reshape(-1)
+    db = eng.upload(base)
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        assert eng.phase_cycles(db, dr)[15] == base.n_logs
+        assert (eng.download_logs(dr, base.n_logs)["status"] == abi.ERR_SEQ_GAP).all()
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
+
+
 @pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
 def test_many_actor_documents(eng):
     """> 4 actors per document: the library launches the kernel build that carries the table-based admission."""
