@@ -115,6 +115,8 @@ struct PtxMergeArgs {
     ptx_span* out_spans;
     ptx_cinterval* out_cints;
     uint32_t* out_rank;
+    uint32_t* out_refs;  /* optional, with out_rank: per delete row the row of its target's insert, per mark row its boundary slots (start | end << 16,
+                            0xFFFF = none) as the walk of peritext.ts:167-214 meets them — what the patch-stream replay (replay_core.h) resolves rows with */
     unsigned long long* clocks; /* optional [PTX_NCLK]: per-phase cycle totals (profiling builds of the host) */
     uint32_t n_logs;
     uint32_t lds_bytes;
@@ -1276,6 +1278,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_FOR(j, d_fused) {
             const uint32_t t = ilist[j < n ? PTX_JX(j, n) : j], i = dlist[PTX_JX(j, D)];
             if (t != 0xFFFFu && row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND);
+            if (A.out_refs && t != 0xFFFFu && i < N) A.out_refs[base + i] = row_of[t];
         }
         if (D > d_fused) { /* more deletes than inserts + 1: the rest, one gather each */
             PTX_FOR(jj, D - d_fused) {
@@ -1283,7 +1286,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 const uint32_t r = dlist[PTX_JX(j, D)], i = r < N ? r : N - 1u;
                 const int t = ptx_elem_lookup(ix, ref_a[i]);
                 if (t < 0 || row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND);
-                else ptx_atomic_or(&delbits[(uint32_t)t >> 5], 1u << ((uint32_t)t & 31u));
+                else {
+                    ptx_atomic_or(&delbits[(uint32_t)t >> 5], 1u << ((uint32_t)t & 31u));
+                    if (A.out_refs) A.out_refs[base + i] = row_of[t];
+                }
             }
         }
         PTX_BAIL_IF_ERROR();
@@ -1564,6 +1570,16 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 }
                 mrk_lo[k] = (uint16_t)lo;
                 mrk_hi[k] = (uint16_t)hi;
+                if (A.out_refs) {
+                    /* both boundary slots, each on its own (the replay needs the end slot even where the op never starts) */
+                    uint32_t va = 0xFFFFu, vb = 0xFFFFu;
+                    if (js >= 0) va = 2u * rnk[js] + (sa[u] == PTX_SIDE_AFTER ? 1u : 0u);
+                    if (sb[u] == PTX_SIDE_BEFORE || sb[u] == PTX_SIDE_AFTER) {
+                        const int je = ptx_elem_lookup(ix, rb[u]);
+                        if (je >= 0 && row_of[je] < i[u]) vb = 2u * rnk[je] + (sb[u] == PTX_SIDE_AFTER ? 1u : 0u);
+                    }
+                    A.out_refs[base + i[u]] = va | (vb << 16);
+                }
                 if (k >= moff2 && k < moff3) {
                     if (pl[u] >= Kid) ptx_raise(H, i[u], 1, PTX_ERR_BAD_OP); /* beyond the id space the header declares */
                     cid[k - moff2] = (uint16_t)(pl[u] < Kid ? pl[u] : 0u);

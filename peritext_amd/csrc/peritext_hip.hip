@@ -351,6 +351,7 @@ struct ptx_dresult {
     ptx_span* spans = nullptr;
     ptx_cinterval* cints = nullptr;
     uint32_t* rank = nullptr;
+    uint32_t* refs = nullptr; /* with rank: resolved references of the delete / mark rows (PtxMergeArgs.out_refs), for ptx_replay_patches */
 };
 
 static thread_local std::string g_create_err;
@@ -826,6 +827,7 @@ void ptx_dresult_free(ptx_ctx* ctx, ptx_dresult* r) {
     (void)hipFree(r->spans);
     (void)hipFree(r->cints);
     (void)hipFree(r->rank);
+    (void)hipFree(r->refs);
     delete r;
 }
 
@@ -841,6 +843,7 @@ ptx_status ptx_result_alloc(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult** out
     if (e == hipSuccess) e = dalloc(&r->spans, r->n_rows);
     if (e == hipSuccess) e = dalloc(&r->cints, r->n_rows);
     if (e == hipSuccess && !(ctx->flags & PTX_FLAG_NO_ELEM_RANK)) e = dalloc(&r->rank, r->n_rows);
+    if (e == hipSuccess && !(ctx->flags & PTX_FLAG_NO_ELEM_RANK)) e = dalloc(&r->refs, r->n_rows);
     if (e != hipSuccess) {
         std::string m = std::string("result allocation: ") + hipGetErrorString(e);
         ptx_dresult_free(ctx, r);
@@ -875,6 +878,7 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.out_spans = r->spans;
     A.out_cints = r->cints;
     A.out_rank = r->rank;
+    A.out_refs = r->refs;
     A.n_logs = b->n_logs;
     A.lds_bytes = b->lds_bytes;
     A.div_magic = (uint32_t)(0x100000000ull / b->threads) + 1u;
@@ -1354,6 +1358,7 @@ ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresu
             A.log_hdr = b->log_hdr;
             A.res = r->logs;
             A.elem_rank = r->rank;
+            A.refs = r->refs;
             A.patch_off = d_off;
             A.patches = d_patches;
             A.plogs = d_logs;

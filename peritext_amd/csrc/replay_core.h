@@ -47,6 +47,7 @@ struct PtxReplayArgs {
     const ptx_log_hdr* log_hdr;
     const ptx_log_result* res;  /* of ptx_merge on the same batch */
     const uint32_t* elem_rank;  /* of ptx_merge on the same batch */
+    const uint32_t* refs;       /* of the same ptx_merge (PtxMergeArgs.out_refs): target row of every delete, boundary slots of every mark op */
     const uint64_t* patch_off;  /* [n_logs + 1] capacity offsets into `patches` */
     ptx_patch* patches;
     ptx_patch_log* plogs;
@@ -65,7 +66,8 @@ struct PtxReplayHdr {
 PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) {
     const uint64_t nw = (ks + 31) / 32, nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
     const uint64_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
-    return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(8 * nwe) + 2 * ptx_a16(4 * nws) +
+    (void)nw;
+    return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + 2 * ptx_a16(4 * nws) +
            ptx_a16(4 * (nws + 1)) + 3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * segcap) + ptx_a16(8 * ((segcap >> 5) + 2)) + 3 * ptx_a16(4 * nws) +
            ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
            5 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
@@ -96,14 +98,11 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     const uint64_t pbase = A.patch_off[log];
     const uint32_t pcap = (uint32_t)(A.patch_off[log + 1] - pbase);
     const uint64_t* op_id = A.op_id + base;
-    const uint64_t* ref_a = A.ref_a + base;
-    const uint64_t* ref_b = A.ref_b + base;
     const uint32_t* payload = A.payload + base;
     const uint8_t* action = A.action + base;
     const uint8_t* mark_type = A.mark_type + base;
-    const uint8_t* side_a = A.side_a + base;
-    const uint8_t* side_b = A.side_b + base;
     const uint32_t* erank = A.elem_rank + base;
+    const uint32_t* refs = A.refs + base;
 
     const uint32_t merge_status = A.res[log].status;
     if (merge_status != PTX_OK || N == 0) { /* the reference threw somewhere in this log: no stream (the status says why) */
@@ -119,12 +118,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     const uint32_t n = hd.n_ins, Kc = hd.n_mark[PTX_MARK_COMMENT];
     const uint32_t Kid = Kc ? hd.n_comment_ids : 0u; /* id space of the document's comments as this log has seen it */
     const uint32_t K = hd.n_mark[0] + hd.n_mark[1] + hd.n_mark[2] + hd.n_mark[3];
-    PtxElemIndex ix;
-    ix.max_ctr = hd.max_counter;
-    ix.max_actor = hd.max_actor;
-    ix.na1 = ix.max_actor + 1u;
-    const uint32_t keyspace = (ix.max_ctr + 1u) * ix.na1;
-    const uint32_t nw = (keyspace + 31) / 32, nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
+    const uint32_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
     const uint32_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
 
     PtxBump bp;
@@ -133,9 +127,6 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     bp.cap = A.lds_bytes;
     bp.high = bp.off;
     bp.overflow = false;
-    ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
-    uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1);
-    uint16_t* rank_of = ptx_alloc<uint16_t>(bp, n + 1);
     PtxBitWord* present = ptx_alloc<PtxBitWord>(bp, nwe);
     uint32_t* defined = ptx_alloc<uint32_t>(bp, nws);
     uint32_t* anyc = ptx_alloc<uint32_t>(bp, nws);
@@ -163,7 +154,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint16_t* cnext = ptx_alloc<uint16_t>(bp, Kc + 1);
     uint16_t* ctail = ptx_alloc<uint16_t>(bp, Kid + 1);   /* per id: last registered op */
     uint8_t* cadd = ptx_alloc<uint8_t>(bp, Kc + 1);
-    if (bp.overflow || ix.max_actor > 4095u || n > 32766u || N > 65534u || Kid > 65535u) {
+    if (bp.overflow || n > 32766u || N > 65534u || Kid > 65535u) {
         PTX_LEADER {
             ptx_patch_log pl;
             pl.status = PTX_ERR_CAPACITY;
@@ -173,13 +164,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         return;
     }
 
-    /* ---- set-up: elemId -> element -> (row, final rank) ---- */
-    PTX_FOR(w, nw + 1) {
-        PtxBitWord z;
-        z.bits = 0;
-        z.pre = 0;
-        ix.ib[w] = z;
-    }
+    /* ---- set-up (the rows come resolved from the merge: no element index here) ---- */
     PTX_FOR(w, nwe) {
         PtxBitWord z;
         z.bits = 0;
@@ -199,26 +184,6 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         H->ncom = 0;
         H->tmp = 0;
         H->nvis = 0;
-    }
-    PTX_SYNC_T();
-    PTX_FOR(i, N) {
-        if (action[i] == PTX_ACT_INSERT) {
-            uint32_t key = 0;
-            if (ptx_id_key(ix, op_id[i], key)) ptx_atomic_or(&ix.ib[key >> 5].bits, 1u << (key & 31));
-        }
-    }
-    PTX_SYNC_T();
-    PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
-    PTX_SYNC_T();
-    ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
-    PTX_FOR(i, N) {
-        if (action[i] == PTX_ACT_INSERT) {
-            const int e = ptx_elem_lookup(ix, op_id[i]);
-            if (e >= 0 && (uint32_t)e < n) {
-                row_of[e] = (uint16_t)i;
-                rank_of[e] = (uint16_t)(erank[i] & PTX_RANK_MASK);
-            }
-        }
     }
     PTX_SYNC_T();
 
@@ -263,23 +228,20 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         uint32_t kind = PTX_RK_SKIP, va = PTX_SLOT_NONE, vb = PTX_SLOT_NONE;
         if (a_ == PTX_ACT_MAKELIST) {
             kind = PTX_RK_MAKELIST;
-        } else if (a_ == PTX_ACT_INSERT || a_ == PTX_ACT_DELETE) {
-            const int e = ptx_elem_lookup(ix, a_ == PTX_ACT_INSERT ? op_id[tt] : ref_a[tt]);
-            if (e >= 0) { /* always, in a log the merge accepted */
-                kind = a_ == PTX_ACT_INSERT ? PTX_RK_INSERT : PTX_RK_DELETE;
-                va = rank_of[e];
+        } else if (a_ == PTX_ACT_INSERT) {
+            kind = PTX_RK_INSERT;
+            va = erank[tt] & PTX_RANK_MASK; /* final rank of the element */
+        } else if (a_ == PTX_ACT_DELETE) {
+            const uint32_t r = refs[tt]; /* the row that inserted the target (always one, in a log the merge accepted) */
+            if (r < N) {
+                kind = PTX_RK_DELETE;
+                va = erank[r] & PTX_RANK_MASK;
             }
         } else if ((a_ == PTX_ACT_ADDMARK || a_ == PTX_ACT_REMOVEMARK) && mark_type[tt] < 4u) {
-            /* boundary slots as the walk of peritext.ts:167-214 meets them (merge_core.h P5a has the same rules) */
-            const uint32_t sa = side_a[tt], sb = side_b[tt];
-            if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
-                const int js = ptx_elem_lookup(ix, ref_a[tt]);
-                if (js >= 0 && row_of[js] < tt) va = 2u * rank_of[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
-            }
-            if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
-                const int je = ptx_elem_lookup(ix, ref_b[tt]);
-                if (je >= 0 && row_of[je] < tt) vb = 2u * rank_of[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
-            }
+            /* boundary slots as the walk of peritext.ts:167-214 meets them: resolved by merge_core.h P5a */
+            const uint32_t v = refs[tt];
+            va = v & 0xFFFFu;
+            vb = v >> 16;
             kind = PTX_RK_MARK | ((uint32_t)mark_type[tt] << 4) | (a_ == PTX_ACT_ADDMARK ? 64u : 0u);
         }
         c_kind[i] = (uint8_t)kind;

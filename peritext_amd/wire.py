@@ -366,6 +366,7 @@ class Results:
     spans: np.ndarray  # SPAN_DTYPE [n_rows]
     cintervals: np.ndarray  # CINTERVAL_DTYPE [n_rows]
     elem_rank: np.ndarray  # u32 [n_rows]
+    ref_slots: np.ndarray = None  # u32 [n_rows], emulation only: the merge's resolved references of the delete / mark rows (the library keeps them on the device)
 
 
 def canonical_of_log(batch, res, log):

@@ -30,20 +30,26 @@ static void ptx_emu_lds_fill(uint8_t* lds, size_t bytes) {
 #include "../../peritext_amd/csrc/cursor_core.h"
 
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
-                          uint32_t lds_bytes, int reverse, int admission);
+                          uint32_t lds_bytes, int reverse, int admission, uint32_t* refs);
 
 extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans,
                              ptx_cinterval* cints, uint32_t* rank, uint32_t lds_bytes, int reverse) {
-    return emu_merge_impl(b, res, values, spans, cints, rank, lds_bytes, reverse, 0);
+    return emu_merge_impl(b, res, values, spans, cints, rank, lds_bytes, reverse, 0, nullptr);
 }
 /* the same with causal admission over the batch's Change envelope (chg_* columns) */
 extern "C" int ptx_emu_merge_admit(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans,
                                    ptx_cinterval* cints, uint32_t* rank, uint32_t lds_bytes, int reverse) {
-    return emu_merge_impl(b, res, values, spans, cints, rank, lds_bytes, reverse, 1);
+    return emu_merge_impl(b, res, values, spans, cints, rank, lds_bytes, reverse, 1, nullptr);
+}
+
+/* the same with the resolved references of the delete / mark rows (what ptx_replay_patches reads beside elem_rank) */
+extern "C" int ptx_emu_merge_refs(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
+                                  uint32_t* refs, uint32_t lds_bytes, int reverse, int admission) {
+    return emu_merge_impl(b, res, values, spans, cints, rank, lds_bytes, reverse, admission, refs);
 }
 
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
-                          uint32_t lds_bytes, int reverse, int admission) {
+                          uint32_t lds_bytes, int reverse, int admission, uint32_t* refs) {
     PtxMergeArgs A;
     A.log_off = b->log_off;
     A.op_id = b->op_id;
@@ -67,6 +73,7 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     A.out_spans = spans;
     A.out_cints = cints;
     A.out_rank = rank;
+    A.out_refs = refs;
     A.n_logs = b->n_logs;
     A.lds_bytes = lds_bytes;
     ptx_log_hdr* hdr = nullptr;
@@ -100,7 +107,7 @@ extern "C" uint64_t ptx_emu_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_
 
 /* patch-stream replay (replay_core.h) over the merge results `res` / `rank` of the same batch; patch_off = capacity
  * offsets [n_logs + 1] */
-extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint64_t* patch_off, ptx_patch* patches,
+extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint32_t* refs, const uint64_t* patch_off, ptx_patch* patches,
                               ptx_patch_log* plogs, uint32_t lds_bytes, int reverse) {
     PtxReplayArgs A;
     A.log_off = b->log_off;
@@ -114,6 +121,7 @@ extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, con
     A.side_b = b->side_b;
     A.res = res;
     A.elem_rank = rank;
+    A.refs = refs;
     A.patch_off = patch_off;
     A.patches = patches;
     A.plogs = plogs;

@@ -122,7 +122,9 @@ def _emu(path):
         fn.restype = C.c_int
         fn.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
     lib.ptx_emu_replay.restype = C.c_int
-    lib.ptx_emu_replay.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    lib.ptx_emu_replay.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    lib.ptx_emu_merge_refs.restype = C.c_int
+    lib.ptx_emu_merge_refs.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
     return lib
 
 
@@ -135,11 +137,12 @@ def emu_merge(b, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB, admission=Fal
         spans=np.zeros(n, dtype=abi.SPAN_DTYPE),
         cintervals=np.zeros(n, dtype=abi.CINTERVAL_DTYPE),
         elem_rank=np.zeros(n, dtype=np.uint32),
+        ref_slots=np.full(n, 0xFFFFFFFF, dtype=np.uint32),
     )
     s = batch_struct(b)
-    rc = (_emu(lib_path).ptx_emu_merge_admit if admission else _emu(lib_path).ptx_emu_merge)(
+    rc = _emu(lib_path).ptx_emu_merge_refs(
         C.byref(s), res.logs.ctypes.data, res.values.ctypes.data, res.spans.ctypes.data, res.cintervals.ctypes.data,
-        res.elem_rank.ctypes.data, lds_bytes, reverse,
+        res.elem_rank.ctypes.data, res.ref_slots.ctypes.data, lds_bytes, reverse, 1 if admission else 0,
     )
     assert rc == 0
     return res
@@ -165,7 +168,7 @@ def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=No
     lib = _emu(lib_path)
     launches = 0
     while True:
-        rc = lib.ptx_emu_replay(C.byref(s), res.logs.ctypes.data, res.elem_rank.ctypes.data, off.ctypes.data, rows.ctypes.data, logs.ctypes.data, lds_bytes, reverse)
+        rc = lib.ptx_emu_replay(C.byref(s), res.logs.ctypes.data, res.elem_rank.ctypes.data, res.ref_slots.ctypes.data, off.ctypes.data, rows.ctypes.data, logs.ctypes.data, lds_bytes, reverse)
         assert rc == 0
         launches += 1
         produced = logs["n_patches"].astype(np.int64)
