@@ -66,8 +66,16 @@ enum {
     PTX_ACT_DELETE = 2,     /* {action:"del", elemId}       -> applyListUpdate  micromerge.ts:677 */
     PTX_ACT_ADDMARK = 3,    /* applyAddRemoveMark peritext.ts:154 */
     PTX_ACT_REMOVEMARK = 4,
-    PTX_ACT_NOP = 5         /* op on another object (root map set/del/makeMap): no effect on the text */
+    PTX_ACT_NOP = 5,        /* an op the engine does not model: no effect */
+    /* ops on MAP objects (the root map or a nested map), micromerge.ts:572-602: last-writer-wins per (object, key).  No effect on the
+     * text path (ptx_merge ignores them); ptx_root_map resolves them.  ref_a = the map's object id (0 = the root map, else the opId
+     * of the makeMap that created it), ref_b = key id (batch-wide string table).  The text list's own PTX_ACT_MAKELIST row is such a
+     * write too (root map, its key in ref_b, kind PTX_MAPV_LIST). */
+    PTX_ACT_MAPSET = 6,     /* {action:"set", key, value} / makeMap / makeList: mark_type = PTX_MAPV_*, payload = value id (scalars) */
+    PTX_ACT_MAPDEL = 7      /* {action:"del", key} */
 };
+/* what a PTX_ACT_MAPSET row writes (its mark_type byte) / what ptx_root_entry.kind says */
+enum { PTX_MAPV_SCALAR = 0, PTX_MAPV_MAP = 1, PTX_MAPV_LIST = 2, PTX_MAPV_DELETED = 3 };
 
 /* markType, in ALL_MARKS order (schema.ts:125) */
 enum { PTX_MARK_STRONG = 0, PTX_MARK_EM = 1, PTX_MARK_COMMENT = 2, PTX_MARK_LINK = 3 };
@@ -350,6 +358,37 @@ ptx_status ptx_device_read(ptx_ctx* ctx, const void* device, void* host, uint64_
  * sizes when a log produced more. */
 ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_patches* out);
 void ptx_patches_free(ptx_patches* p);
+
+/* ---- the map objects of a replica: getRoot() (micromerge.ts:443-449) ----
+ * applyOp on a map object (micromerge.ts:572-602) keeps, per key, the op with the largest opId (compareOpIds): last writer wins;
+ * "del" removes the key, makeMap / makeList put a child object there.  ptx_root_map resolves, per replica log, every (object, key)
+ * the log's PTX_ACT_MAPSET / PTX_ACT_MAPDEL / PTX_ACT_MAKELIST rows write: one ptx_root_entry per pair = the winning row.  An op
+ * on an object that does not exist when it is applied (micromerge.ts:538-540 "Object does not exist"), or a key op on a list
+ * object, fails the log with PTX_ERR_ELEM_NOT_FOUND (first failing row in first_bad_row).  Entries of log l are
+ * entries[entry_off[l] .. entry_off[l] + logs[l].n_entries), in no particular order.  Owned by the library until ptx_root_maps_free. */
+typedef struct ptx_root_entry {
+    uint64_t obj;    /* the map: 0 = root, else the opId of its makeMap */
+    uint32_t key;    /* key id */
+    uint32_t row;    /* the winning row of the log (its op_id is the child's object id for PTX_MAPV_MAP / PTX_MAPV_LIST) */
+    uint32_t kind;   /* PTX_MAPV_*: PTX_MAPV_DELETED = the key is absent */
+    uint32_t value;  /* payload of the winning row (PTX_MAPV_SCALAR: value id) */
+} ptx_root_entry;
+typedef struct ptx_root_log {
+    uint32_t status;        /* PTX_OK, PTX_ERR_ELEM_NOT_FOUND, PTX_ERR_CAPACITY (more map ops than the on-chip table holds) */
+    uint32_t n_entries;
+    uint32_t first_bad_row; /* 0xFFFFFFFF when status == PTX_OK */
+    uint32_t reserved;
+} ptx_root_log;
+typedef struct ptx_root_maps {
+    uint32_t n_logs;
+    uint32_t reserved;
+    const uint64_t* entry_off;     /* [n_logs + 1] */
+    const ptx_root_log* logs;      /* [n_logs] */
+    const ptx_root_entry* entries;
+    void* owner;
+} ptx_root_maps;
+ptx_status ptx_root_map(ptx_ctx* ctx, const ptx_dbatch* b, ptx_root_maps* out);
+void ptx_root_maps_free(ptx_root_maps* m);
 
 /* ---- on-device change(): op logs generated in HBM ----
  * The workload of the reference's fuzzer (test/fuzz.ts:115-205) in its seeded form PTXGEN (oracle/ptxgen.js): per

@@ -61,6 +61,17 @@ function applyLog(Impl, impl, log, patchSink) {
     }
     return doc
 }
+/* getRoot() (micromerge.ts:443-449) as plain JSON: the list objects (the text) only as a marker */
+function rootOf(v) {
+    if (Array.isArray(v)) return { $list: true }
+    if (v && typeof v === "object") {
+        const o = {}
+        for (const k of Object.keys(v)) o[k] = rootOf(v[k])
+        return o
+    }
+    return v
+}
+
 function expectedOf(doc) {
     let text = []
     try {
@@ -110,6 +121,7 @@ if (cmd === "gen") {
     const out = { impl, docs: [] }
     const wantCursors = argv.indexOf("--cursors") >= 0
     const wantPatches = argv.indexOf("--patches") >= 0
+    const wantRoots = argv.indexOf("--roots") >= 0
     const timing = { seconds: 0, ops: 0, logs: 0 }
     for (const d of input.docs) {
         const expected = []
@@ -123,6 +135,7 @@ if (cmd === "gen") {
                 timing.ops += log.reduce((a, c) => a + c.ops.length, 0) - 1 /* the makeList */
                 timing.logs += 1
                 if (wantPatches) e.patches = patches /* the concatenated returns of applyChange (micromerge.ts:499) */
+                if (wantRoots) e.root = rootOf(doc.root)
                 if (wantCursors) {
                     /* micromerge.ts:465-477: getCursor for every visible index, resolveCursor for every element ever inserted */
                     e.cursorAt = e.text.map((_, i) => doc.getCursor(["text"], i).elemId)

@@ -10,7 +10,8 @@ import os
 PTX_ABI_VERSION = 4
 
 # Operation.action (reference/src/micromerge.ts:150-212, src/peritext.ts:25-65)
-ACT_MAKELIST, ACT_INSERT, ACT_DELETE, ACT_ADDMARK, ACT_REMOVEMARK, ACT_NOP = range(6)
+ACT_MAKELIST, ACT_INSERT, ACT_DELETE, ACT_ADDMARK, ACT_REMOVEMARK, ACT_NOP, ACT_MAPSET, ACT_MAPDEL = range(8)
+MAPV_SCALAR, MAPV_MAP, MAPV_LIST, MAPV_DELETED = range(4)  # what a map row writes / ptx_root_entry.kind
 # markType in ALL_MARKS order (reference/src/schema.ts:125)
 MARK_STRONG, MARK_EM, MARK_COMMENT, MARK_LINK = range(4)
 MARK_NAMES = ["strong", "em", "comment", "link"]
@@ -159,6 +160,25 @@ class ptx_patch_log(C.Structure):
     _fields_ = [("status", C.c_uint32), ("n_patches", C.c_uint32)]
 
 
+class ptx_root_entry(C.Structure):
+    _fields_ = [("obj", C.c_uint64), ("key", C.c_uint32), ("row", C.c_uint32), ("kind", C.c_uint32), ("value", C.c_uint32)]
+
+
+class ptx_root_log(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("n_entries", C.c_uint32), ("first_bad_row", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class ptx_root_maps(C.Structure):
+    _fields_ = [
+        ("n_logs", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("entry_off", C.POINTER(C.c_uint64)),
+        ("logs", C.POINTER(ptx_root_log)),
+        ("entries", C.POINTER(ptx_root_entry)),
+        ("owner", C.c_void_p),
+    ]
+
+
 class ptx_patches(C.Structure):
     _fields_ = [
         ("n_logs", C.c_uint32),
@@ -238,6 +258,8 @@ SPAN_DTYPE = np.dtype([("start", "<u4"), ("attr", "<u4")])
 CINTERVAL_DTYPE = np.dtype([("id", "<u4"), ("start", "<u4"), ("end", "<u4")])
 PATCH_DTYPE = np.dtype([("row", "<u4"), ("kind", "<u4"), ("a", "<u4"), ("b", "<u4")])
 PATCH_LOG_DTYPE = np.dtype([("status", "<u4"), ("n_patches", "<u4")])
+ROOT_ENTRY_DTYPE = np.dtype([("obj", "<u8"), ("key", "<u4"), ("row", "<u4"), ("kind", "<u4"), ("value", "<u4")])
+ROOT_LOG_DTYPE = np.dtype([("status", "<u4"), ("n_entries", "<u4"), ("first_bad_row", "<u4"), ("reserved", "<u4")])
 
 # every function include/peritext_hip.h declares: name -> (restype, argtypes)
 vp = C.c_void_p
@@ -281,6 +303,8 @@ FUNCTIONS = {
     "ptx_device_read": (C.c_int32, [vp, vp, vp, C.c_uint64]),
     "ptx_replay_patches": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_patches)]),
     "ptx_patches_free": (None, [C.POINTER(ptx_patches)]),
+    "ptx_root_map": (C.c_int32, [vp, vp, C.POINTER(ptx_root_maps)]),
+    "ptx_root_maps_free": (None, [C.POINTER(ptx_root_maps)]),
     "ptx_generate": (C.c_int32, [vp, C.POINTER(ptx_gen_config), C.POINTER(vp), C.POINTER(ptx_gen_info)]),
     "ptx_gen_info_free": (None, [C.POINTER(ptx_gen_info)]),
     "ptx_resolve_cursors": (C.c_int32, [vp, vp, vp, C.c_uint32, u32p, u8p, u64p, u64p, u32p]),

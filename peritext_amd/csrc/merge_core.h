@@ -1049,13 +1049,13 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             const uint32_t r0 = g * PTX_U1;
             const uint32_t live = kMasked ? (1u << (8u * nv)) - 1u : 0x00FFFFFFu; /* bytes of a4 / mt4 that are rows of this thread */
             /* class of the rows, four bytes at a time (byte permutes as table look-ups):
-             * action 0 makeList -> 6, 1 insert -> 0, 2 delete -> 1, 3 / 4 add / removeMark -> 2 + mark type, 5 nop -> 6, else 7 */
-            const uint32_t k4 = ptx_perm(0x47470680u, 0x80010006u, a4 & 0x07070707u); /* 0x80: a mark op; 0x47: class 7, malformed */
+             * action 0 makeList -> 6, 1 insert -> 0, 2 delete -> 1, 3 / 4 add / removeMark -> 2 + mark type, 5 nop / 6, 7 map ops -> 6 */
+            const uint32_t k4 = ptx_perm(0x06060680u, 0x80010006u, a4 & 0x07070707u); /* 0x80: a mark op; 6: listed nowhere (makeList, NOP, map ops) */
             const uint32_t mk = (k4 >> 7) & 0x01010101u;     /* 1 in the bytes of the mark ops */
             const uint32_t mmask = ptx_mul24(mk, 255u);        /* 0xFF there (the three bytes that are this thread's rows) */
             uint32_t c4 = ((k4 & ~mmask) | (((mt4 & 0x03030303u) + 0x02020202u) & mmask)) & 0x07070707u;
-            /* unknown action (6, 7, or beyond the table), mark type beyond 3: flagged; the row runs on under some class */
-            err4 |= ((k4 & 0x40404040u) | (a4 & 0xF8F8F8F8u) | (mt4 & 0xFCFCFCFCu & mmask)) & live;
+            /* unknown action (beyond the table), mark type beyond 3: flagged; the row runs on under some class */
+            err4 |= ((a4 & 0xF8F8F8F8u) | (mt4 & 0xFCFCFCFCu & mmask)) & live;
             if (kMasked) c4 = (c4 & live) | (0x07070707u & ~live);
             const uint32_t add4 = a4 & mk & live; /* bit 0 tells PTX_ACT_ADDMARK (3) from PTX_ACT_REMOVEMARK (4) */
             uint32_t slot[PTX_U1];
@@ -1126,7 +1126,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_FOR(i, N) {
                 const uint32_t ctr = (uint32_t)(op_id[i] >> 32), act = (uint32_t)op_id[i], a = action[i], mt = mark_type[i];
                 const bool mark = a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK;
-                if (a >= 6u || (mark && mt > 3u) || ctr - 1u >= ix.max_ctr || act > ix.max_actor) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
+                if (a >= 8u || (mark && mt > 3u) || ctr - 1u >= ix.max_ctr || act > ix.max_actor) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
                 else if (a == PTX_ACT_INSERT) ptx_atomic_add(&cnt6[0], 1u);
                 else if (a == PTX_ACT_DELETE) ptx_atomic_add(&cnt6[1], 1u);
                 else if (mark) ptx_atomic_add(&cnt6[2u + mt], 1u);

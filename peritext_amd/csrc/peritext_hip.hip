@@ -26,6 +26,7 @@
 #include "gen_core.h"
 #include "change_core.h"
 #include "cursor_core.h"
+#include "rootmap_core.h"
 
 /* ------------------------------------------------------------------------------------------------ */
 /* kernels                                                                                          */
@@ -65,6 +66,24 @@ extern "C" __global__ void __launch_bounds__(64) ptx_gen_kernel(PtxGenArgs A) {
 extern "C" __global__ void __launch_bounds__(64) ptx_change_kernel(PtxChangeArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_logs) ptx_change_log<64>(A, blockIdx.x, ptx_lds);
+}
+
+/* the map objects of a replica (rootmap_core.h): one wave per replica log; a first kernel counts the map rows (capacity of the entry rows) */
+extern "C" __global__ void __launch_bounds__(64) ptx_rootmap_kernel(PtxRootArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
+    if (blockIdx.x < A.n_logs) ptx_rootmap_log<64>(A, blockIdx.x, ptx_lds);
+}
+__global__ void ptx_rootmap_count_kernel(const uint64_t* log_off, const uint8_t* action, uint32_t n_logs, uint32_t* counts) {
+    const uint32_t log = blockIdx.x;
+    if (log >= n_logs) return;
+    const uint64_t b0 = log_off[log], b1 = log_off[log + 1];
+    uint32_t c = 0;
+    for (uint64_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) {
+        const uint32_t a = action[i];
+        c += (a == PTX_ACT_MAPSET || a == PTX_ACT_MAPDEL || a == PTX_ACT_MAKELIST) ? 1u : 0u;
+    }
+    c = ptx_wave_total(c); /* one wave per log */
+    if (threadIdx.x == 0) counts[log] = c;
 }
 
 /* cursor resolution (cursor_core.h): one workgroup per replica log that has queries */
@@ -1584,6 +1603,93 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     *out = b;
     return PTX_OK;
 #undef PTX_TRYG
+}
+
+/* ---- the map objects of a replica: getRoot() ---- */
+struct ptx_host_root_maps {
+    std::vector<uint64_t> off;
+    std::vector<ptx_root_log> logs;
+    std::vector<ptx_root_entry> entries;
+};
+void ptx_root_maps_free(ptx_root_maps* m) {
+    if (!m) return;
+    delete (ptx_host_root_maps*)m->owner;
+    memset(m, 0, sizeof(*m));
+}
+ptx_status ptx_root_map(ptx_ctx* ctx, const ptx_dbatch* b, ptx_root_maps* out) {
+    if (!ctx || !b || !out) return PTX_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    ptx_host_root_maps* h = new ptx_host_root_maps();
+    const uint32_t L = b->n_logs;
+    h->off.assign((size_t)L + 1, 0);
+    h->logs.resize(std::max<uint32_t>(L, 1));
+    h->entries.resize(1);
+    out->owner = h;
+    out->n_logs = L;
+    out->entry_off = h->off.data();
+    out->logs = h->logs.data();
+    out->entries = h->entries.data();
+    if (L == 0) return PTX_OK;
+    uint32_t* d_cnt = nullptr;
+    uint64_t* d_off = nullptr;
+    ptx_root_log* d_logs = nullptr;
+    ptx_root_entry* d_ent = nullptr;
+    auto release = [&]() {
+        (void)hipFree(d_cnt);
+        (void)hipFree(d_off);
+        (void)hipFree(d_logs);
+        (void)hipFree(d_ent);
+    };
+    std::vector<uint32_t> cnt(L);
+    hipError_t e = dalloc(&d_cnt, L);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ptx_rootmap_count_kernel, dim3(L), dim3(64), 0, ctx->stream, b->log_off, b->action, L, d_cnt);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, (size_t)L * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    uint32_t most = 0;
+    if (e == hipSuccess) {
+        for (uint32_t l = 0; l < L; ++l) {
+            h->off[l + 1] = h->off[l] + cnt[l];
+            most = std::max(most, cnt[l]);
+        }
+        const uint64_t total = h->off[L];
+        h->entries.resize(std::max<uint64_t>(total, 1));
+        out->entries = h->entries.data();
+        e = dalloc(&d_off, (uint64_t)L + 1);
+        if (e == hipSuccess) e = dalloc(&d_logs, L);
+        if (e == hipSuccess) e = dalloc(&d_ent, std::max<uint64_t>(total, 1));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_off, h->off.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) {
+        PtxRootArgs A;
+        A.log_off = b->log_off;
+        A.op_id = b->op_id;
+        A.ref_a = b->ref_a;
+        A.ref_b = b->ref_b;
+        A.payload = b->payload;
+        A.action = b->action;
+        A.mark_type = b->mark_type;
+        A.entry_off = d_off;
+        A.entries = d_ent;
+        A.rlogs = d_logs;
+        A.n_logs = L;
+        /* logs with more map ops than the LDS of a CU holds report PTX_ERR_CAPACITY */
+        A.lds_bytes = (uint32_t)std::min<uint64_t>((ptx_rootmap_lds_need(most) + 255) & ~255ull, ctx->max_lds);
+        hipLaunchKernelGGL(ptx_rootmap_kernel, dim3(L), dim3(64), A.lds_bytes, ctx->stream, A);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h->logs.data(), d_logs, (size_t)L * sizeof(ptx_root_log), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && h->off[L]) e = hipMemcpyAsync(h->entries.data(), d_ent, (size_t)h->off[L] * sizeof(ptx_root_entry), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release();
+    if (e != hipSuccess) {
+        ptx_root_maps_free(out);
+        return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("ptx_root_map: ") + hipGetErrorString(e));
+    }
+    return PTX_OK;
 }
 
 /* ---- cursors ---- */

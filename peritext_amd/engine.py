@@ -181,6 +181,20 @@ class Engine:
         self._check(self.lib.ptx_merge_timed(self.ctx, dbatch, dresult, iters, C.byref(ms)))
         return float(ms.value)
 
+    def root_map(self, dbatch):
+        """The map objects of every replica of a resident batch (ptx_root_map: getRoot(), micromerge.ts:443-449): wire.RootMaps."""
+        m = abi.ptx_root_maps()
+        self._check(self.lib.ptx_root_map(self.ctx, dbatch, C.byref(m)))
+        try:
+            n = int(m.n_logs)
+            off = np.ctypeslib.as_array(m.entry_off, shape=(n + 1,)).astype(np.uint64).copy()
+            logs = np.frombuffer(C.string_at(m.logs, max(n, 1) * C.sizeof(abi.ptx_root_log)), dtype=abi.ROOT_LOG_DTYPE)[:n].copy()
+            total = int(off[-1])
+            ent = np.frombuffer(C.string_at(m.entries, total * C.sizeof(abi.ptx_root_entry)), dtype=abi.ROOT_ENTRY_DTYPE).copy() if total else np.zeros(0, dtype=abi.ROOT_ENTRY_DTYPE)
+            return wire.RootMaps(entry_off=off, logs=logs, entries=ent)
+        finally:
+            self.lib.ptx_root_maps_free(C.byref(m))
+
     def phase_cycles(self, dbatch, dresult, n=16):
         """Diagnostic: shader-clock cycles per phase of merge_core.h, summed over all workgroups."""
         out = (C.c_uint64 * n)()

@@ -63,6 +63,9 @@ struct Lib {
     ptx_status (*count_converged_digests)(ptx_ctx*, const uint64_t*, uint64_t, uint32_t, uint64_t*) = nullptr;
     ptx_status (*result_download_logs)(ptx_ctx*, const ptx_dresult*, ptx_log_result*, uint32_t) = nullptr;
     ptx_status (*resolve_cursors)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, uint32_t, const uint32_t*, const uint8_t*, const uint64_t*, uint64_t*, uint32_t*) = nullptr;
+    /* the map objects of a replica: getRoot() */
+    ptx_status (*root_map)(ptx_ctx*, const ptx_dbatch*, ptx_root_maps*) = nullptr;
+    void (*root_maps_free)(ptx_root_maps*) = nullptr;
     ptx_status (*device_alloc)(ptx_ctx*, uint64_t, void**) = nullptr;
     void (*device_free)(ptx_ctx*, void*) = nullptr;
     ptx_status (*device_read)(ptx_ctx*, const void*, void*, uint64_t) = nullptr;
@@ -110,7 +113,7 @@ napi_value Open(napi_env env, napi_callback_info info) {
                   sym(L.gen_info_free, "ptx_gen_info_free") && sym(L.batch_download, "ptx_batch_download") && sym(L.host_batch_free, "ptx_host_batch_free") && sym(L.change, "ptx_change") &&
                   sym(L.comm_unique_id, "ptx_comm_unique_id") && sym(L.comm_init, "ptx_comm_init") && sym(L.comm_destroy, "ptx_comm_destroy") &&
                   sym(L.allgather_digests, "ptx_allgather_digests") && sym(L.count_converged_digests, "ptx_count_converged_digests") &&
-                  sym(L.result_download_logs, "ptx_result_download_logs") && sym(L.device_alloc, "ptx_device_alloc") && sym(L.device_free, "ptx_device_free") &&
+                  sym(L.result_download_logs, "ptx_result_download_logs") && sym(L.root_map, "ptx_root_map") && sym(L.root_maps_free, "ptx_root_maps_free") && sym(L.device_alloc, "ptx_device_alloc") && sym(L.device_free, "ptx_device_free") &&
                   sym(L.device_read, "ptx_device_read") && sym(L.resolve_cursors, "ptx_resolve_cursors");
         if (!ok) {
             dlclose(L.handle);
@@ -547,6 +550,47 @@ napi_value Change(napi_env env, napi_callback_info info) {
     return out;
 }
 
+/* rootMap(ctx, batch): Micromerge.getRoot() for every replica log of the batch (ptx_root_map): upload, resolve.  Returns
+ * {entryOff: BigUint64Array [n_logs + 1], logs: Uint32Array (status, n_entries, first_bad_row, 0 per log), entries: Uint32Array
+ * (obj lo, obj hi, key, row, kind, value per entry)}. */
+napi_value RootMap(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    if (argc < 2) return throw_msg(env, "rootMap(ctx, batch)");
+    ptx_ctx* ctx = ctx_of(env, argv[0]);
+    if (!ctx) return throw_msg(env, "rootMap: bad context");
+    ptx_batch pb;
+    if (!read_batch(env, argv[1], &pb)) return nullptr;
+    ptx_dbatch* db = nullptr;
+    ptx_root_maps rm;
+    memset(&rm, 0, sizeof(rm));
+    ptx_status st = L.batch_upload(ctx, &pb, &db);
+    if (st == PTX_OK) st = L.root_map(ctx, db, &rm);
+    if (db) L.batch_free(ctx, db);
+    if (st != PTX_OK) {
+        char msg[1024];
+        snprintf(msg, sizeof(msg), "ptx_root_map failed (status %d): %s", st, L.last_error(ctx));
+        return throw_msg(env, msg);
+    }
+    static_assert(sizeof(ptx_root_entry) == 24 && sizeof(ptx_root_log) == 16, "ptx_root_entry / ptx_root_log layout");
+    napi_value out, v, ab, ta;
+    NAPI_OK(napi_create_object(env, &out));
+    void* data = nullptr;
+    const size_t n_off = (size_t)rm.n_logs + 1;
+    if (napi_create_arraybuffer(env, n_off * 8, &data, &ab) == napi_ok && napi_create_typedarray(env, napi_biguint64_array, n_off, ab, 0, &ta) == napi_ok) {
+        memcpy(data, rm.entry_off, n_off * 8);
+        napi_set_named_property(env, out, "entryOff", ta);
+    }
+    v = make_u32(env, rm.logs, (size_t)rm.n_logs * 4);
+    if (v) napi_set_named_property(env, out, "logs", v);
+    v = make_u32(env, rm.entries, (size_t)rm.entry_off[rm.n_logs] * 6);
+    if (v) napi_set_named_property(env, out, "entries", v);
+    L.root_maps_free(&rm);
+    return out;
+}
+
 /* cursors(ctx, batch, {log: Uint32Array, kind: Uint8Array, arg: BigUint64Array}): Micromerge.getCursor / resolveCursor for many replicas
  * (ptx_resolve_cursors): upload, merge, resolve.  Returns {out: BigUint64Array, status: Uint32Array}, one entry per query. */
 napi_value Cursors(napi_env env, napi_callback_info info) {
@@ -705,7 +749,7 @@ napi_value KernelName(napi_env env, napi_callback_info) {
 
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
-        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"generate", Generate}, {"change", Change}, {"cursors", Cursors}, {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"mergeAndGather", MergeAndGather},
+        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"generate", Generate}, {"change", Change}, {"cursors", Cursors}, {"rootMap", RootMap}, {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"mergeAndGather", MergeAndGather},
         {"maxOpsPerLog", MaxOpsPerLog}, {"kernelName", KernelName},
     };
     for (auto& f : fns) {

@@ -49,6 +49,8 @@ export interface WireBatch {
     /** the same unpacked (filled by encodeDocs / unpackEnvelope; decodeChanges and decodePatches read these) */
     chgActor?: Uint32Array; chgSeq?: Uint32Array; chgNops?: Uint32Array; chgDeps?: Uint32Array
     values: string[]; urls: string[]; logDoc: number[]; docActors: string[][]; docComments: string[][]
+    /** keys of the map objects (ref_b of the PTX_ACT_MAPSET / MAPDEL / MAKELIST rows) and the JSON text of the values they set (payload) */
+    keys?: string[]; mapValues?: string[]
 }
 export interface WireResult {
     logs: Uint32Array; values: Uint32Array; spans: Uint32Array; cintervals: Uint32Array; elemRank?: Uint32Array
@@ -85,7 +87,15 @@ export interface ReplicaHandle {
     getPatches(): Patch[][]
     /** throws RangeError("List element not found" | …) exactly where the reference's applyChange would have thrown */
     getTextWithFormatting(path: ["text"]): FormatSpanWithText[]
+    /** Micromerge.getRoot() (micromerge.ts:443-449): the root map and the maps nested in it, resolved on the device (ptx_root_map: last
+     *  writer wins per key, :572-602); list objects appear as { $list: true }.  RangeError("Object does not exist") like :538-540 */
+    getRoot(): RootJson
 }
+/** a map object as JSON: nested maps, the values set, { $list: true } where a list object (the text) hangs */
+export type RootJson = { [key: string]: RootJson | JsonValue | { $list: true } }
+export type JsonValue = string | number | boolean | null | JsonValue[] | { [key: string]: JsonValue }
+/** ptx_root_map's raw answer (include/peritext_hip.h ptx_root_maps) */
+export interface WireRootMaps { entryOff: BigUint64Array; logs: Uint32Array; entries: Uint32Array }
 
 export class MergeEngine {
     constructor(opts?: { device?: number; libPath?: string; addonPath?: string })
@@ -95,6 +105,8 @@ export class MergeEngine {
     applyChanges(docs: Change[][][]): FormatSpanWithText[][][]
     /** spans as applyChanges + patches[doc][replica][change] = what applyChange(change) returns (micromerge.ts:499) */
     applyChangesWithPatches(docs: Change[][][]): { spans: FormatSpanWithText[][][]; patches: Patch[][][][] }
+    /** getRoot() of every replica: roots[doc][replica] (ptx_root_map) */
+    roots(docs: Change[][][]): RootJson[][]
     /** on-device change(): edit histories generated on the GPU (ptx_generate; the documents of oracle/ptxgen.js for the same seed) and merged there */
     generate(cfg: { replicas: number; opsPerLog: number; mix: [number, number, number, number]; markTypes: MarkType[]; seed: number; nDocs: number; firstDoc?: number; listCap?: number; initialText?: string }):
         { docs: Change[][][]; spans: FormatSpanWithText[][][]; kernelMs: number; batch: WireBatch }
@@ -117,6 +129,7 @@ export function unpackEnvelope(batch: WireBatch): WireBatch
 export function decodeSpans(batch: WireBatch, res: WireResult, log: number): FormatSpanWithText[]
 export function decodePatches(batch: WireBatch, res: WireResult, log: number): Patch[][]
 export function decodeChanges(batch: WireBatch, log: number, textObjOfLog?: OperationId | null): Change[]
+export function decodeRoot(batch: WireBatch, rm: WireRootMaps, log: number): RootJson
 /** bridge.ts:394-414 prosemirrorDocFromCRDT, as the Node.toJSON() form of the document (parity unpinned: no ProseMirror in the build image) */
 export function prosemirrorDocFromSpans(spans: FormatSpanWithText[]): { type: "doc"; content: Array<{ type: "paragraph"; content?: Array<{ type: "text"; text: string; marks?: Array<{ type: MarkType; attrs?: Record<string, string> }> }> }> }
 export function census(batch: WireBatch): Uint32Array

@@ -21,7 +21,8 @@
  */
 const path = require("path")
 
-const ACT = { MAKELIST: 0, INSERT: 1, DELETE: 2, ADDMARK: 3, REMOVEMARK: 4, NOP: 5 }
+const ACT = { MAKELIST: 0, INSERT: 1, DELETE: 2, ADDMARK: 3, REMOVEMARK: 4, NOP: 5, MAPSET: 6, MAPDEL: 7 }
+const MAPV = { SCALAR: 0, MAP: 1, LIST: 2, DELETED: 3 } /* what a map row writes / ptx_root_entry.kind */
 const MARK_NAMES = ["strong", "em", "comment", "link"] /* schema.ts:125 ALL_MARKS */
 const SIDE_NAMES = ["before", "after", "startOfText", "endOfText"] /* peritext.ts:17-21 */
 const ATTR = { STRONG: 0x10000000, EM: 0x20000000, LINK: 0x40000000, COMMENT: 0x80000000, ID_MASK: 0x0fffffff }
@@ -87,6 +88,16 @@ function encodeDocs(docs, opts) {
     const textObjs = (opts && opts.textObjs) || [] /* per document: opId of the text list when the logs do not hold its makeList */
     const values = [], valueIx = new Map()
     const urls = [], urlIx = new Map()
+    const keys = [], keyIx = new Map() /* keys of the map objects (ref_b of the map rows) */
+    const mapValues = [], mapValueIx = new Map() /* JSON text of the values the map rows set */
+    const intern = (table, index, v) => {
+        if (!index.has(v)) {
+            index.set(v, table.length)
+            table.push(v)
+        }
+        return index.get(v)
+    }
+    /* JSON with sorted keys: the same text wire.py makes (json.dumps(sort_keys=True) only differs in separators, which never reach the device) */
     const rows = { opId: [], refA: [], refB: [], payload: [], action: [], markType: [], sideA: [], sideB: [] }
     const logOff = [0]
     const chgOff = [0], chgActor = [], chgSeq = [], chgNops = [], chgDepsRows = []
@@ -103,6 +114,7 @@ function encodeDocs(docs, opts) {
                     const refs = [op.elemId, op.start && op.start.elemId, op.end && op.end.elemId]
                     for (const r of refs) if (typeof r === "string" && r !== HEAD && r !== ROOT) actors.add(splitOpId(r)[1])
                     if (op.markType === "comment") comments.add(op.attrs.id)
+                    if (typeof op.obj === "string" && op.obj !== HEAD && op.obj !== ROOT) actors.add(splitOpId(op.obj)[1])
                 }
             }
         for (const a of extraActors[d] || []) actors.add(a)
@@ -132,6 +144,7 @@ function encodeDocs(docs, opts) {
                     const onRoot = op.obj === undefined || op.obj === null || op.obj === ROOT || typeof op.obj === "symbol"
                     if (op.action === "makeList" && onRoot && op.key === "text" && textObj === null) {
                         row.action = ACT.MAKELIST
+                        row.refB = BigInt(intern(keys, keyIx, "text")) /* also a write of the root map's key */
                         textObj = op.opId
                     } else if (textObj !== null && op.obj === textObj) {
                         if (op.action === "set" && op.insert) {
@@ -163,6 +176,16 @@ function encodeDocs(docs, opts) {
                                 row.payload = urlIx.get(u)
                             } else if (op.markType === "comment") row.payload = crank.get(op.attrs.id)
                         }
+                    } else if (op.key !== undefined && op.elemId === undefined && ["set", "del", "makeMap", "makeList"].indexOf(op.action) >= 0) {
+                        /* an op on a MAP object (the root map or a nested one), micromerge.ts:572-602: last writer wins per (object, key) */
+                        row.refA = encId(op.obj)
+                        row.refB = BigInt(intern(keys, keyIx, op.key))
+                        if (op.action === "del") row.action = ACT.MAPDEL
+                        else {
+                            row.action = ACT.MAPSET
+                            row.markType = op.action === "makeMap" ? MAPV.MAP : op.action === "makeList" ? MAPV.LIST : MAPV.SCALAR
+                            if (op.action === "set") row.payload = intern(mapValues, mapValueIx, JSON.stringify(op.value === undefined ? null : op.value))
+                        }
                     }
                     for (const k of Object.keys(rows)) rows[k].push(row[k])
                     nrows++
@@ -192,7 +215,7 @@ function encodeDocs(docs, opts) {
         chgNops: Uint32Array.from(chgNops),
         chgDeps: new Uint32Array(chgActor.length * maxActors),
         maxActors,
-        values, urls, logDoc, docActors, docComments,
+        values, urls, logDoc, docActors, docComments, keys, mapValues,
     }
     chgDepsRows.forEach((row, i) => row.forEach(([a, v]) => { batch.chgDeps[i * maxActors + a] = v }))
     packEnvelope(batch)
@@ -373,6 +396,33 @@ function decodeChanges(batch, log, textObjOfLog) {
  * reference's own source decides is pinned by tests/golden/pm_docs.json (oracle/gen_pm_golden.js reads the reference's schema.ts);
  * prosemirror-model itself is not available in this image: its toJSON / joining rules are restated, PARITY UNPINNED for those.
  */
+/**
+ * getRoot() of the replica behind `log` (micromerge.ts:443-449) from ptx_root_map's entries: nested objects for the maps,
+ * { $list: true } where a list object hangs (the text: its content is getTextWithFormatting's business), the set values elsewhere.
+ */
+function decodeRoot(batch, rm, log) {
+    const b0 = Number(batch.logOff[log]), e0 = Number(rm.entryOff[log]), n = rm.logs[log * 4 + 1]
+    if (rm.logs[log * 4] !== 0) throw new RangeError("Object does not exist (row " + rm.logs[log * 4 + 2] + " of the log)")
+    const byObj = new Map()
+    for (let k = e0; k < e0 + n; k++) {
+        const obj = (BigInt(rm.entries[k * 6 + 1]) << 32n) | BigInt(rm.entries[k * 6])
+        if (!byObj.has(obj)) byObj.set(obj, [])
+        byObj.get(obj).push({ key: rm.entries[k * 6 + 2], row: rm.entries[k * 6 + 3], kind: rm.entries[k * 6 + 4], value: rm.entries[k * 6 + 5] })
+    }
+    const build = obj => {
+        const out = {}
+        for (const e of byObj.get(obj) || []) {
+            if (e.kind === MAPV.DELETED) continue
+            const k = batch.keys[e.key]
+            if (e.kind === MAPV.MAP) out[k] = build(batch.opId[b0 + e.row])
+            else if (e.kind === MAPV.LIST) out[k] = { $list: true }
+            else out[k] = JSON.parse(batch.mapValues[e.value])
+        }
+        return out
+    }
+    return build(0n)
+}
+
 function prosemirrorDocFromSpans(spans) {
     if (spans.length === 1 && spans[0].text === "") return { type: "doc", content: [{ type: "paragraph" }] } /* bridge.ts:399-401 */
     const text = []
@@ -480,6 +530,15 @@ class MergeEngine {
             spans: docs.map(logs => logs.map(() => decodeSpans(batch, res, log++))),
             patches: docs.map(logs => logs.map(() => decodePatches(batch, res, log2++))),
         }
+    }
+    /** docs: Change[][][] -> getRoot() of every replica (ptx_root_map: the root map and the maps nested in it, last writer wins per
+     *  key, micromerge.ts:572-602; list objects appear as { $list: true }).  A replica the reference would have thrown on
+     *  ("Object does not exist") throws a RangeError here too. */
+    roots(docs) {
+        const batch = encodeDocs(docs)
+        const rm = this.addon.rootMap(this.ctx, batch)
+        let log = 0
+        return docs.map(logs => logs.map(() => decodeRoot(batch, rm, log++)))
     }
     /**
      * On-device change(): whole edit histories made on the GPU (ptx_generate — Micromerge.change, micromerge.ts:308-441, under the
@@ -651,6 +710,11 @@ class MergeEngine {
                 }
                 return rep.patches
             },
+            /** Micromerge.getRoot() (micromerge.ts:443-449): the root map with the maps nested in it, resolved on the device (last
+             *  writer wins per key); list objects appear as { $list: true } — their content is getTextWithFormatting's. */
+            getRoot() {
+                return self.roots([[rep.changes]])[0][0]
+            },
             getTextWithFormatting(p) {
                 if (!Array.isArray(p) || p.length !== 1 || p[0] !== "text") throw new Error("Only the text list is supported: " + JSON.stringify(p))
                 if (rep.spans === null && rep.error === null) self.flush()
@@ -729,4 +793,4 @@ class MergeEngine {
     }
 }
 
-module.exports = { MergeEngine, encodeDocs, encodeInputOps, packEnvelope, unpackEnvelope, decodeSpans, decodePatches, decodeChanges, prosemirrorDocFromSpans, PATCH, census, ACT, IN, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }
+module.exports = { MergeEngine, encodeDocs, encodeInputOps, packEnvelope, unpackEnvelope, decodeSpans, decodePatches, decodeChanges, decodeRoot, MAPV, prosemirrorDocFromSpans, PATCH, census, ACT, IN, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }

@@ -15,6 +15,7 @@ Encoding rules the wrapper owns:
     batch-wide string table; link urls -> ids in one batch-wide table;
   * comment ids -> DOC-LOCAL dense ranks in code-unit order (peritext.ts:318 keeps arrays id-sorted).
 """
+import json
 import re
 from dataclasses import dataclass, field
 
@@ -65,6 +66,8 @@ class Batch:
     log_doc: list = field(default_factory=list)  # log index -> doc index
     doc_actors: list = field(default_factory=list)  # doc -> [actor strings in rank order]
     doc_comments: list = field(default_factory=list)  # doc -> [comment id strings in rank order]
+    keys: list = field(default_factory=list)  # key id -> string (keys of the map objects: PTX_ACT_MAPSET / MAPDEL / MAKELIST rows, ref_b)
+    map_values: list = field(default_factory=list)  # value id -> JSON text of the value a PTX_ACT_MAPSET row sets
 
     @property
     def n_logs(self):
@@ -173,6 +176,15 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
     """
     values, value_ix = [], {}
     urls, url_ix = [], {}
+    keys, key_ix = [], {}
+    mvals, mval_ix = [], {}
+
+    def intern(table, index, v):
+        if v not in index:
+            index[v] = len(table)
+            table.append(v)
+        return index[v]
+
     cols = {k: [] for k in ("op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b")}
     log_off = [0]
     chg_off = [0]
@@ -195,6 +207,8 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
                             actors.add(split_op_id(ref)[1])
                     if op.get("markType") == "comment":
                         comments.add(op["attrs"]["id"])
+                    if isinstance(op.get("obj"), str) and op["obj"] not in (HEAD, ROOT):
+                        actors.add(split_op_id(op["obj"])[1])
         actors.update((extra_actors or [[]] * len(docs))[d])
         comments.update((extra_comments or [[]] * len(docs))[d])
         actor_list = sorted(actors, key=_u16key)
@@ -225,7 +239,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
                     obj = op.get("obj")
                     on_root = obj is None or obj == ROOT
                     if act == "makeList" and on_root and op.get("key") == "text" and text_obj is None:
-                        row["action"] = abi.ACT_MAKELIST
+                        row.update(action=abi.ACT_MAKELIST, ref_b=intern(keys, key_ix, "text"))  # also a write of the root map's key
                         text_obj = op["opId"]
                     elif text_obj is not None and obj == text_obj:
                         if act == "set" and op.get("insert"):
@@ -257,6 +271,16 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
                                 row["payload"] = url_ix[u]
                             elif mt == abi.MARK_COMMENT:
                                 row["payload"] = crank[op["attrs"]["id"]]
+                    elif "key" in op and "elemId" not in op and act in ("set", "del", "makeMap", "makeList"):
+                        # an op on a MAP object (the root map or a nested one), micromerge.ts:572-602: last writer wins per (object, key)
+                        row.update(ref_a=enc_id(obj), ref_b=intern(keys, key_ix, op["key"]))
+                        if act == "del":
+                            row["action"] = abi.ACT_MAPDEL
+                        else:
+                            row["action"] = abi.ACT_MAPSET
+                            row["mark_type"] = abi.MAPV_MAP if act == "makeMap" else abi.MAPV_LIST if act == "makeList" else abi.MAPV_SCALAR
+                            if act == "set":
+                                row["payload"] = intern(mvals, mval_ix, json.dumps(op.get("value"), sort_keys=True, ensure_ascii=False, separators=(",", ":")))
                     for k, v in row.items():
                         cols[k].append(v)
                     nrows += 1
@@ -278,8 +302,46 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
         mark_type=np.asarray(cols["mark_type"], dtype=np.uint8), side_a=np.asarray(cols["side_a"], dtype=np.uint8),
         side_b=np.asarray(cols["side_b"], dtype=np.uint8), chg_off=u64(chg_off),
         chg_hdr=chg_hdr, chg_env=chg_env, max_actors=max_actors,
-        values=values, urls=urls, log_doc=log_doc, doc_actors=doc_actors, doc_comments=doc_comments,
+        values=values, urls=urls, log_doc=log_doc, doc_actors=doc_actors, doc_comments=doc_comments, keys=keys, map_values=mvals,
     )
+
+
+@dataclass
+class RootMaps:
+    """Host view of ptx_root_map: per log the winning row of every (map object, key) its ops write."""
+
+    entry_off: np.ndarray  # u64 [n_logs + 1]
+    logs: np.ndarray  # ROOT_LOG_DTYPE [n_logs]
+    entries: np.ndarray  # ROOT_ENTRY_DTYPE
+
+
+def decode_root(batch, rm, log):
+    """getRoot() of the replica behind `log` (micromerge.ts:443-449) as JSON: nested dicts for the maps, {"$list": True} where a
+    list object hangs (the text list: its content is getTextWithFormatting's business), the set values elsewhere.  Maps that no
+    key points at any more (their makeMap lost, or was overwritten) are not reachable, as in the reference."""
+    b0 = int(batch.log_off[log])
+    e0 = int(rm.entry_off[log])
+    ent = rm.entries[e0:e0 + int(rm.logs["n_entries"][log])]
+    by_obj = {}
+    for e in ent:
+        by_obj.setdefault(int(e["obj"]), []).append(e)
+
+    def build(obj):
+        out = {}
+        for e in by_obj.get(obj, []):
+            kind = int(e["kind"])
+            if kind == abi.MAPV_DELETED:
+                continue
+            k = batch.keys[int(e["key"])]
+            if kind == abi.MAPV_MAP:
+                out[k] = build(int(batch.op_id[b0 + int(e["row"])]))
+            elif kind == abi.MAPV_LIST:
+                out[k] = {"$list": True}
+            else:
+                out[k] = json.loads(batch.map_values[int(e["value"])])
+        return out
+
+    return build(0)
 
 
 @dataclass
@@ -663,7 +725,7 @@ def save_batch(path, batch):
     """Write a Batch as one .npz: the SoA columns as they go to the device + the decode tables as JSON."""
     import json
 
-    meta = {"format": "peritext-soa-oplog", "abi": abi.PTX_ABI_VERSION, "max_actors": batch.max_actors, "values": batch.values, "urls": batch.urls,
+    meta = {"format": "peritext-soa-oplog", "abi": abi.PTX_ABI_VERSION, "max_actors": batch.max_actors, "values": batch.values, "urls": batch.urls, "keys": batch.keys, "map_values": batch.map_values,
             "log_doc": batch.log_doc, "doc_actors": batch.doc_actors, "doc_comments": batch.doc_comments}
     arrays = {k: getattr(batch, k) for k in _COLUMNS}
     if batch.log_hdr is not None:
@@ -681,4 +743,4 @@ def load_batch(path):
         cols = {k: z[k] for k in _COLUMNS}
         hdr = z["log_hdr"] if "log_hdr" in z.files else None
     return Batch(log_hdr=hdr, max_actors=int(meta["max_actors"]), values=meta["values"], urls=meta["urls"], log_doc=meta["log_doc"],
-                 doc_actors=meta["doc_actors"], doc_comments=meta["doc_comments"], **cols)
+                 doc_actors=meta["doc_actors"], doc_comments=meta["doc_comments"], keys=meta.get("keys", []), map_values=meta.get("map_values", []), **cols)

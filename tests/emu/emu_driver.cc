@@ -28,6 +28,7 @@ static void ptx_emu_lds_fill(uint8_t* lds, size_t bytes) {
 #include "../../peritext_amd/csrc/gen_core.h"
 #include "../../peritext_amd/csrc/change_core.h"
 #include "../../peritext_amd/csrc/cursor_core.h"
+#include "../../peritext_amd/csrc/rootmap_core.h"
 
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
                           uint32_t lds_bytes, int reverse, int admission, uint32_t* refs);
@@ -273,5 +274,32 @@ extern "C" int ptx_emu_cursors(const ptx_batch* b, const ptx_log_result* res, co
     ptx_emu_lds_fill(lds, 0);
     free(lds);
     free(hdr);
+    return 0;
+}
+
+/* the map objects of a replica (rootmap_core.h): the caller sizes the entry rows (entry_off) by the map rows of every log */
+extern "C" int ptx_emu_root_map(const ptx_batch* b, const uint64_t* entry_off, ptx_root_entry* entries, ptx_root_log* rlogs, uint32_t lds_bytes, int reverse) {
+    PtxRootArgs A;
+    A.log_off = b->log_off;
+    A.op_id = b->op_id;
+    A.ref_a = b->ref_a;
+    A.ref_b = b->ref_b;
+    A.payload = b->payload;
+    A.action = b->action;
+    A.mark_type = b->mark_type;
+    A.entry_off = entry_off;
+    A.entries = entries;
+    A.rlogs = rlogs;
+    A.n_logs = b->n_logs;
+    A.lds_bytes = lds_bytes;
+    uint8_t* lds = (uint8_t*)aligned_alloc(64, (((size_t)lds_bytes + 63) & ~(size_t)63) + 64);
+    if (!lds) return 1;
+    ptx_emu_reverse = reverse;
+    for (uint32_t l = 0; l < b->n_logs; ++l) {
+        ptx_emu_lds_fill(lds, lds_bytes);
+        ptx_rootmap_log<0>(A, l, lds);
+    }
+    ptx_emu_lds_fill(lds, 0);
+    free(lds);
     return 0;
 }

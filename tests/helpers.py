@@ -50,13 +50,13 @@ def oracle_gen(config="mini", docs=4, seed=1, ops=None, replicas=None, first=0, 
             return json.load(f)
 
 
-def oracle_apply(docs_logs, impl="oracle", cursors=False, patches=False):
+def oracle_apply(docs_logs, impl="oracle", cursors=False, patches=False, roots=False):
     """Apply every log of every doc to a fresh oracle replica; returns [[{spans,text,error?}]]."""
     with tempfile.TemporaryDirectory() as td:
         inp, out = os.path.join(td, "in.json"), os.path.join(td, "out.json")
         with open(inp, "w") as f:
             json.dump({"docs": [{"logs": logs} for logs in docs_logs]}, f)
-        run_node(["oracle/cli.js", "apply", "--in", inp, "--impl", impl, "--out", out] + (["--cursors"] if cursors else []) + (["--patches"] if patches else []))
+        run_node(["oracle/cli.js", "apply", "--in", inp, "--impl", impl, "--out", out] + (["--cursors"] if cursors else []) + (["--patches"] if patches else []) + (["--roots"] if roots else []))
         with open(out) as f:
             return [d["expected"] for d in json.load(f)["docs"]]
 
@@ -623,7 +623,7 @@ def malformed_row_batches():
 
     is_mark = lambda r: int(base.action[r]) in (abi.ACT_ADDMARK, abi.ACT_REMOVEMARK)  # noqa: E731
     r, g = row_of(0, 17)
-    a.action[g] = 6
+    a.action[g] = 8  # the first code beyond the table (6 / 7 are the map ops)
     want[0] = r
     r, g = row_of(1, 40)
     a.action[g] = 200
@@ -633,7 +633,7 @@ def malformed_row_batches():
     want[2] = r
     r1, g1 = row_of(3, 60)
     r0, g0 = row_of(3, 11)
-    a.action[g1] = 7
+    a.action[g1] = 9
     a.action[g0] = 33
     want[3] = r0  # the FIRST of two
     out.append((a, want, [l for l in range(a.n_logs) if l not in want]))
@@ -674,3 +674,106 @@ def check_malformed_rows(merge_fn):
         for log in intact:
             assert int(res.logs["status"][log]) == 0
             assert (res.logs["digest"][log] == good.logs["digest"][log]).all()
+
+
+# ---- map objects (getRoot): hand-written logs shared by the emulation suite and its GPU twin ----
+def root_map_docs():
+    """Documents whose changes write the root map and nested maps concurrently (micromerge.ts:572-602: last writer wins per key),
+    every replica in another delivery order; plus logs the reference throws on (an op on a map that does not exist yet)."""
+    def text_change(actor="a", text="ABC"):
+        ops = [{"opId": "1@%s" % actor, "action": "makeList", "obj": "_root", "key": "text"}]
+        prev = "_head"
+        for i, ch in enumerate(text):
+            ops.append({"opId": "%d@%s" % (i + 2, actor), "action": "set", "obj": "1@%s" % actor, "elemId": prev, "insert": True, "value": ch})
+            prev = "%d@%s" % (i + 2, actor)
+        return {"actor": actor, "seq": 1, "deps": {}, "startOp": 1, "ops": ops}
+
+    a1 = text_change()
+    a2 = {"actor": "a", "seq": 2, "deps": {"a": 1}, "startOp": 5, "ops": [
+        {"opId": "5@a", "action": "set", "obj": "_root", "key": "title", "value": "A title"},
+        {"opId": "6@a", "action": "makeMap", "obj": "_root", "key": "meta"},
+        {"opId": "7@a", "action": "set", "obj": "6@a", "key": "lang", "value": "en"},
+        {"opId": "8@a", "action": "set", "obj": "_root", "key": "count", "value": 1},
+    ]}
+    b1 = {"actor": "b", "seq": 1, "deps": {"a": 1}, "startOp": 5, "ops": [
+        {"opId": "5@b", "action": "set", "obj": "_root", "key": "title", "value": "B title"},
+        {"opId": "6@b", "action": "del", "obj": "_root", "key": "count"},
+        {"opId": "7@b", "action": "makeMap", "obj": "_root", "key": "meta"},
+        {"opId": "8@b", "action": "set", "obj": "7@b", "key": "lang", "value": "fr"},
+        {"opId": "9@b", "action": "set", "obj": "_root", "key": "flag", "value": True},
+    ]}
+    c1 = {"actor": "c", "seq": 1, "deps": {"a": 2}, "startOp": 9, "ops": [
+        {"opId": "9@c", "action": "set", "obj": "_root", "key": "title", "value": "C title \u00e9"},
+        {"opId": "10@c", "action": "del", "obj": "_root", "key": "flag"},
+        {"opId": "11@c", "action": "set", "obj": "6@a", "key": "extra", "value": None},
+        {"opId": "12@c", "action": "makeList", "obj": "_root", "key": "notes"},
+        {"opId": "13@c", "action": "set", "obj": "1@a", "elemId": "4@a", "insert": True, "value": "!"},
+    ]}
+    doc1 = [[a1, a2, b1, c1], [a1, b1, a2, c1], [a1, a2, c1, b1]]
+    # nested maps three deep, a parent key deleted afterwards (its subtree is not reachable any more), keys re-set after a del
+    d2 = {"actor": "a", "seq": 2, "deps": {"a": 1}, "startOp": 5, "ops": [
+        {"opId": "5@a", "action": "makeMap", "obj": "_root", "key": "cfg"},
+        {"opId": "6@a", "action": "makeMap", "obj": "5@a", "key": "ui"},
+        {"opId": "7@a", "action": "makeMap", "obj": "6@a", "key": "theme"},
+        {"opId": "8@a", "action": "set", "obj": "7@a", "key": "dark", "value": False},
+        {"opId": "9@a", "action": "set", "obj": "5@a", "key": "version", "value": 3.5},
+        {"opId": "10@a", "action": "del", "obj": "_root", "key": "gone"},
+        {"opId": "11@a", "action": "set", "obj": "_root", "key": "gone", "value": "back"},
+        {"opId": "12@a", "action": "set", "obj": "_root", "key": "nil", "value": None},
+    ]}
+    e1 = {"actor": "e", "seq": 1, "deps": {"a": 2}, "startOp": 13, "ops": [
+        {"opId": "13@e", "action": "del", "obj": "5@a", "key": "ui"},
+        {"opId": "14@e", "action": "set", "obj": "7@a", "key": "dark", "value": True},
+        {"opId": "15@e", "action": "del", "obj": "_root", "key": "gone"},
+    ]}
+    doc2 = [[a1, d2, e1], [a1, d2]]
+    # the reference throws: an op on a map that is only created later in this replica's order (its deps do not name the creator)
+    early = {"actor": "z", "seq": 1, "deps": {"a": 1}, "startOp": 5, "ops": [
+        {"opId": "5@z", "action": "set", "obj": "_root", "key": "ok", "value": 1},
+        {"opId": "6@z", "action": "set", "obj": "6@a", "key": "lang", "value": "xx"},
+    ]}
+    ghost = {"actor": "g", "seq": 1, "deps": {"a": 1}, "startOp": 5, "ops": [{"opId": "5@g", "action": "del", "obj": "77@q", "key": "k"}]}
+    doc3 = [[a1, early, a2], [a1, ghost], [a1, a2, early]]
+    return [doc1, doc2, doc3]
+
+
+def check_root_maps(root_fn, merge_fn, expected):
+    """root_fn(batch) -> wire.RootMaps, merge_fn(batch) -> wire.Results; expected = oracle_apply(..., roots=True) of root_map_docs()."""
+    docs = root_map_docs()
+    batch = wire.encode_docs(docs)
+    rm = root_fn(batch)
+    res = merge_fn(batch)
+    log = 0
+    for d, exp in enumerate(expected):
+        for e in exp:
+            if e.get("error"):
+                assert "Object does not exist" in e["error"], e["error"]
+                assert int(rm.logs["status"][log]) == abi.ERR_ELEM_NOT_FOUND, (log, rm.logs[log])
+                bad = int(rm.logs["first_bad_row"][log])
+                b0 = int(batch.log_off[log])
+                assert int(batch.action[b0 + bad]) in (abi.ACT_MAPSET, abi.ACT_MAPDEL)
+            else:
+                assert int(rm.logs["status"][log]) == 0, (log, rm.logs[log])
+                assert wire.decode_root(batch, rm, log) == e["root"], (log, wire.decode_root(batch, rm, log), e["root"])
+                check_log(batch, res, log, e)  # the text path does not see the map ops
+            log += 1
+    assert log == batch.n_logs
+    return batch, rm
+
+
+def emu_root_map(b, lds_bytes=64 * 1024, reverse=0, lib_path=EMU_LIB):
+    """ptx_root_map on the host emulation (tests only)."""
+    is_map = (b.action == abi.ACT_MAPSET) | (b.action == abi.ACT_MAPDEL) | (b.action == abi.ACT_MAKELIST)
+    cum = np.concatenate([[0], np.cumsum(is_map.astype(np.int64))])
+    counts = cum[b.log_off[1:].astype(np.int64)] - cum[b.log_off[:-1].astype(np.int64)]
+    off = np.zeros(b.n_logs + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(counts)
+    ent = np.zeros(max(int(off[-1]), 1), dtype=abi.ROOT_ENTRY_DTYPE)
+    logs = np.zeros(max(b.n_logs, 1), dtype=abi.ROOT_LOG_DTYPE)
+    s = batch_struct(b)
+    lib = _emu(lib_path)
+    lib.ptx_emu_root_map.restype = C.c_int
+    lib.ptx_emu_root_map.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    rc = lib.ptx_emu_root_map(C.byref(s), off.ctypes.data, ent.ctypes.data, logs.ctypes.data, lds_bytes, reverse)
+    assert rc == 0
+    return wire.RootMaps(entry_off=off, logs=logs[: b.n_logs], entries=ent[: int(off[-1])])

@@ -25,6 +25,8 @@ if (cmd === "encode") {
     const out = { nLogs: b.nLogs, nOps: b.nOps, values: b.values, urls: b.urls, docComments: b.docComments }
     for (const k of ["logOff", "opId", "refA", "refB", "payload", "action", "markType", "sideA", "sideB", "logHdr", "chgOff", "chgActor", "chgSeq", "chgNops", "chgDeps", "chgHdr", "chgEnv"]) out[k] = sha(b[k])
     out.maxActors = b.maxActors
+    out.keys = b.keys
+    out.mapValues = b.mapValues.map(v => JSON.parse(v))
     console.log(JSON.stringify(out))
 } else if (cmd === "load") {
     const addon = require(path.join(__dirname, "..", "peritext_amd", "node", "peritext_node.node"))
@@ -63,6 +65,30 @@ if (cmd === "encode") {
     }
     engine.close()
     console.log(JSON.stringify({ ok: true, logs }))
+} else if (cmd === "roots") {
+    /* GPU: getRoot() of every replica (ptx_root_map through N-API) against the reference-made fixture */
+    const g = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    const engine = new host.MergeEngine()
+    let checked = 0, thrown = 0
+    g.docs.forEach((logs, d) => {
+        logs.forEach((log, r) => {
+            const want = g.expected[d][r]
+            if (want.error) {
+                assert.throws(() => engine.roots([[log]]), RangeError)
+                thrown++
+            } else {
+                assert.deepStrictEqual(engine.roots([[log]])[0][0], want.root)
+                const rep = engine.replica("doc" + d + "-" + r)
+                for (const ch of log) rep.applyChange(ch)
+                assert.deepStrictEqual(rep.getRoot(), want.root)
+                assert.deepStrictEqual(norm(rep.getTextWithFormatting(["text"])), norm(want.spans))
+                checked++
+            }
+        })
+    })
+    const ok = g.docs.map(logs => logs.filter((_, r) => true))
+    engine.close()
+    console.log(JSON.stringify({ checked, thrown }))
 } else if (cmd === "patches") {
     /* GPU: the Patch[] every applyChange returns (fixtures made by the reference itself, oracle/gen_patch_golden.js) */
     const engine = new host.MergeEngine()

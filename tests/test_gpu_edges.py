@@ -347,3 +347,24 @@ def test_malformed_rows_are_named(eng):
     """GPU twin: the row pass only flags malformed rows while it streams (and keeps every store inside the log's LDS window when a
     header understates the rows); the first failing row is named by a second pass."""
     H.check_malformed_rows(eng.apply_materialize)
+
+
+def test_root_maps_on_the_device(eng):
+    """getRoot() (micromerge.ts:443-449; last writer wins per key, :572-602) of replicas whose changes write the root map and nested
+    maps concurrently, against the reference's own answers (rootmap_ref.json: made by the type-erased reference)."""
+    g = _load("rootmap_ref.json")
+    assert g["impl"] == "ref" and g["docs"] == H.root_map_docs()
+
+    def root_fn(batch):
+        db = eng.upload(batch)
+        try:
+            return eng.root_map(db)
+        finally:
+            eng.free_batch(db)
+
+    batch, rm = H.check_root_maps(root_fn, eng.apply_materialize, g["expected"])
+    # a text-only batch: every replica's root holds just the text list
+    mini = _load("ptxgen_mini.json")
+    b2 = wire.encode_docs([d["logs"] for d in mini["docs"]])
+    rm2 = root_fn(b2)
+    assert (rm2.logs["status"] == 0).all() and all(wire.decode_root(b2, rm2, l) == {"text": {"$list": True}} for l in range(b2.n_logs))

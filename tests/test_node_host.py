@@ -36,7 +36,7 @@ def test_addon_loads_and_binds_the_c_abi():
     assert info["abi"] == abi.PTX_ABI_VERSION
     assert info["kernel"].startswith("ptx_merge_kernel")
     assert info["exports"] == ["applyMaterialize", "change", "commDestroy", "commInit", "commUniqueId", "create", "cursors", "destroy", "generate", "kernelName", "maxOpsPerLog",
-                               "mergeAndGather", "open"]
+                               "mergeAndGather", "open", "rootMap"]
 
 
 @needs_node
@@ -56,6 +56,30 @@ def test_js_encoder_matches_python_encoder(name):
     assert js["maxActors"] == b.max_actors
     for k, a in cols.items():
         assert js[k] == sha(a), k
+
+
+@needs_node
+def test_js_encoder_matches_python_encoder_on_map_ops(tmp_path):
+    """Ops on the root map and nested maps (PTX_ACT_MAPSET / MAPDEL rows, key and value tables): JS == Python."""
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    docs = H.root_map_docs()
+    p = tmp_path / "rootdocs.json"
+    p.write_text(json.dumps({"docs": [{"logs": logs} for logs in docs]}))
+    js = _node("encode", str(p))
+    b = wire.encode_docs(docs)
+    assert js["keys"] == b.keys and js["mapValues"] == [json.loads(v) for v in b.map_values]
+    for k, a in {"opId": b.op_id, "refA": b.ref_a, "refB": b.ref_b, "payload": b.payload, "action": b.action, "markType": b.mark_type, "logHdr": b.log_hdr, "chgEnv": b.chg_env}.items():
+        assert js[k] == sha(a), k
+    assert int((b.action == abi.ACT_MAPSET).sum()) > 10 and int((b.action == abi.ACT_MAPDEL).sum()) > 3
+
+
+@pytest.mark.gpu
+@needs_node
+@needs_addon
+def test_node_host_root_maps():
+    """engine.roots / replica().getRoot() (ptx_root_map through N-API) against the reference-made fixture."""
+    out = _node("roots", os.path.join(H.GOLDEN, "rootmap_ref.json"))
+    assert out["checked"] == 6 and out["thrown"] == 2
 
 
 @pytest.mark.gpu
