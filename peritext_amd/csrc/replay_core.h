@@ -65,12 +65,12 @@ struct PtxReplayHdr {
 
 PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) {
     const uint64_t nw = (ks + 31) / 32, nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
-    (void)K;
+    const uint64_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
     (void)nw;
     return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + 2 * ptx_a16(4 * nws) +
-           3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(8 * (nws + 2)) + 3 * ptx_a16(4 * nws) +
+           ptx_a16(4 * (nws + 1)) + 3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * segcap) + ptx_a16(8 * ((segcap >> 5) + 2)) + 3 * ptx_a16(4 * nws) +
            ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
-           4 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
+           5 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
 }
 PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
@@ -119,6 +119,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     const uint32_t Kid = Kc ? hd.n_comment_ids : 0u; /* id space of the document's comments as this log has seen it */
     const uint32_t K = hd.n_mark[0] + hd.n_mark[1] + hd.n_mark[2] + hd.n_mark[3];
     const uint32_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
+    const uint32_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
+
     PtxBump bp;
     bp.base = lds;
     bp.off = (uint32_t)ptx_a16(sizeof(PtxReplayHdr));
@@ -128,6 +130,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     PtxBitWord* present = ptx_alloc<PtxBitWord>(bp, nwe);
     uint32_t* defined = ptx_alloc<uint32_t>(bp, nws);
     uint32_t* anyc = ptx_alloc<uint32_t>(bp, nws);
+    uint32_t* wcnt = ptx_alloc<uint32_t>(bp, nws + 1); /* defined slots of the range per word -> prefix */
     uint16_t* win[3];
     win[0] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* strong */
     win[1] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* em */
@@ -142,11 +145,13 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint16_t* c_a = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* insert / delete: final rank; mark: start slot */
     uint16_t* c_b = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* mark: end slot */
     uint8_t* c_kind = ptx_alloc<uint8_t>(bp, PTX_RCHUNK);  /* PTX_RK_* | mark type << 4 | addMark << 6 */
-    PtxBitWord* cf = ptx_alloc<PtxBitWord>(bp, nws + 2); /* bit j: slot slot_a + j of the op's range opens a patch; prefix = its place */
+    uint16_t* seg = ptx_alloc<uint16_t>(bp, segcap);      /* defined slots of the op's range, ascending */
+    PtxBitWord* cf = ptx_alloc<PtxBitWord>(bp, (segcap >> 5) + 2); /* bit j: slot seg[j] opens a patch; prefix = its place */
     uint16_t* ca = ptx_alloc<uint16_t>(bp, Kc + 1);       /* comment op: first covered slot */
     uint16_t* cb = ptx_alloc<uint16_t>(bp, Kc + 1);       /*             first slot not covered (PTX_SLOT_NONE = to the end) */
     uint16_t* ccid = ptx_alloc<uint16_t>(bp, Kc + 1);
-    uint16_t* cprev = ptx_alloc<uint16_t>(bp, Kc + 1);    /* chain of the ops with the same id, from the last applied one back */
+    uint16_t* cprev = ptx_alloc<uint16_t>(bp, Kc + 1);    /* chain of the ops with the same id, application order */
+    uint16_t* cnext = ptx_alloc<uint16_t>(bp, Kc + 1);
     uint16_t* ctail = ptx_alloc<uint16_t>(bp, Kid + 1);   /* per id: last registered op */
     uint8_t* cadd = ptx_alloc<uint8_t>(bp, Kc + 1);
     if (bp.overflow || n > 32766u || N > 65534u || Kid > 65535u) {
@@ -280,7 +285,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 PTX_FOR(kc, nc) {
                     if (cadd[kc] && ca[kc] <= l && l < cb[kc]) {
                         bool last = true; /* no later-applied covering op of the same id */
-                        for (uint32_t y = ctail[ccid[kc]]; y != kc && y != PTX_SLOT_NONE; y = cprev[y]) /* the ops of this id applied after kc */
+                        for (uint32_t y = cnext[kc]; y != PTX_SLOT_NONE; y = cnext[y])
                             if (ca[y] <= l && l < cb[y]) {
                                 last = false;
                                 break;
@@ -329,31 +334,39 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             }
             PTX_DEFINE_SLOT(slot_a);
             if (slot_b != PTX_SLOT_NONE) PTX_DEFINE_SLOT(slot_b); /* inherits the state BEFORE this op from inside the range */
-            /* the op walks the DEFINED slots of [slot_a, lim) (peritext.ts:167-214): the loops below run over every slot of the range and
-             * skip the others; the defined slot that follows one is found by scanning the bitmap words (short once the document has
-             * marks; no compacted list of the range's slots is kept: it cost 4.4 KB of LDS per log, a sixth log per CU) */
+            /* the defined slots of [slot_a, lim), ascending */
             const uint32_t lim = slot_b != PTX_SLOT_NONE ? slot_b : 2u * n;
-            const uint32_t span = lim - slot_a;
-            /* first defined slot of (s_, lim), or PTX_SLOT_NONE */
-#define PTX_NEXT_DEFINED(s_, out_)                                                          \
-    {                                                                                       \
-        uint32_t w_ = (uint32_t)(s_) >> 5;                                                  \
-        uint32_t m_ = defined[w_] & ~((2u << ((uint32_t)(s_) & 31u)) - 1u);                 \
-        out_ = PTX_SLOT_NONE;                                                               \
-        for (;;) {                                                                          \
-            if ((w_ << 5) + 32u > lim) m_ &= (lim & 31u) && (w_ << 5) < lim ? (1u << (lim & 31u)) - 1u : ((w_ << 5) < lim ? 0xFFFFFFFFu : 0u); \
-            if (m_) {                                                                       \
-                out_ = (w_ << 5) + (uint32_t)__builtin_ctz(m_);                             \
-                break;                                                                      \
-            }                                                                               \
-            ++w_;                                                                           \
-            if ((w_ << 5) >= lim) break;                                                    \
-            m_ = defined[w_];                                                               \
-        }                                                                                   \
-    }
+            const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5;
+#define PTX_RANGE_BITS(w_, m_)                                                       \
+    uint32_t m_ = defined[w_];                                                       \
+    if ((w_) == wlo) m_ &= ~((1u << (slot_a & 31u)) - 1u);                           \
+    if (((w_) << 5) + 32u > lim) m_ &= (lim & 31u) ? (1u << (lim & 31u)) - 1u : 0u;
+            PTX_FOR(wi, whi - wlo + 1u) {
+                const uint32_t w = wlo + wi;
+                uint32_t c = 0;
+                if (w < whi) {
+                    PTX_RANGE_BITS(w, m)
+                    c = ptx_popc(m);
+                }
+                wcnt[wi] = c;
+            }
+            PTX_SYNC_T();
+            const uint32_t S = ptx_scan_excl<uint32_t, 1, kThreads>(wcnt, whi - wlo + 1u, H->scan_tmp);
+            PTX_FOR(wi, whi - wlo) {
+                const uint32_t w = wlo + wi;
+                PTX_RANGE_BITS(w, m)
+                uint32_t o = wcnt[wi];
+                while (m) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    if (o < segcap) seg[o] = (uint16_t)((w << 5) + b);
+                    ++o;
+                }
+            }
+#undef PTX_RANGE_BITS
             PTX_SYNC_T();
             const uint32_t nvis = H->nvis, nc = H->ncom;
-            const uint32_t cfw = (span >> 5) + 1u; /* words of the patch-opening bitmap over the range's slots (+1 for the total) */
+            const uint32_t cfw = (S >> 5) + 1u; /* words of the patch-opening bitmap (+1 for the total) */
             PTX_FOR(w, cfw + 1u) {
                 PtxBitWord z;
                 z.bits = 0;
@@ -368,9 +381,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             const uint32_t my_id = c_pay[ci];
             const uint64_t my_op = c_id[ci];
             /* per defined slot: did the effective marks change (peritext.ts:208), new state, visible index */
-            PTX_FOR(j, span) {
-                const uint32_t s = slot_a + j;
-                if (!ptx_bittest(defined, s)) continue;
+            PTX_FOR(j, S) {
+                const uint32_t s = seg[j];
                 bool changed = false;
                 if (ty != PTX_MARK_COMMENT) {
                     uint16_t* wt = win[ty == PTX_MARK_STRONG ? 0 : ty == PTX_MARK_EM ? 1 : 2];
@@ -400,38 +412,28 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     changed = act == PTX_ACT_ADDMARK ? state != 1 : (state == 1 || !any); /* remove on no comment key: undefined -> [] */
                 }
                 if (changed) {
-                    uint32_t nd;
-                    PTX_NEXT_DEFINED(s, nd)
-                    const uint32_t ve = nd != PTX_SLOT_NONE ? PTX_VIS_AT(nd) : v_end;
+                    const uint32_t ve = j + 1u < S ? PTX_VIS_AT(seg[j + 1u]) : v_end;
                     if (ve > PTX_VIS_AT(s)) ptx_atomic_or(&cf[j >> 5].bits, 1u << (j & 31));
                 }
             }
             PTX_SYNC_T();
-            if (ty == PTX_MARK_COMMENT) { /* every defined slot of the range now carries the comment key: a word at a time */
-                const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5;
-                PTX_FOR(wi, whi - wlo) {
-                    const uint32_t w = wlo + wi;
-                    uint32_t m = defined[w];
-                    if (w == wlo) m &= ~((1u << (slot_a & 31u)) - 1u);
-                    if ((w << 5) + 32u > lim) m &= (lim & 31u) ? (1u << (lim & 31u)) - 1u : 0u;
-                    if (m) anyc[w] |= m; /* one thread per word */
+            if (ty == PTX_MARK_COMMENT) {
+                PTX_FOR(j, S) {
+                    const uint32_t s = seg[j];
+                    ptx_atomic_or(&anyc[s >> 5], 1u << (s & 31));
                 }
             }
             PTX_FOR(w, cfw) cf[w].pre = ptx_popc(cf[w].bits);
             PTX_SYNC_T();
             const uint32_t P = ptx_scan_excl<uint32_t, 2, kThreads>(&cf[0].pre, cfw + 1u, H->scan_tmp);
             const uint32_t p0 = H->npatch;
-            PTX_FOR(j, span) {
+            PTX_FOR(j, S) {
                 if ((cf[j >> 5].bits >> (j & 31)) & 1u) {
-                    const uint32_t s = slot_a + j;
-                    uint32_t nd;
-                    PTX_NEXT_DEFINED(s, nd)
-                    const uint32_t ve = nd != PTX_SLOT_NONE ? PTX_VIS_AT(nd) : v_end;
-                    ptx_patch_put(A, pbase, pcap, p0 + ptx_bitrank(cf, j), t, act == PTX_ACT_ADDMARK ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT(s), ve);
+                    const uint32_t ve = j + 1u < S ? PTX_VIS_AT(seg[j + 1u]) : v_end;
+                    ptx_patch_put(A, pbase, pcap, p0 + ptx_bitrank(cf, j), t, act == PTX_ACT_ADDMARK ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT(seg[j]), ve);
                 }
             }
 #undef PTX_VIS_AT
-#undef PTX_NEXT_DEFINED
             PTX_SYNC_T();
             PTX_LEADER {
                 H->npatch = p0 + P;
@@ -440,8 +442,10 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     cb[nc] = (uint16_t)slot_b;
                     ccid[nc] = (uint16_t)my_id;
                     cadd[nc] = act == PTX_ACT_ADDMARK ? 1 : 0;
+                    cnext[nc] = PTX_SLOT_NONE;
                     const uint32_t prev = ctail[my_id];
                     cprev[nc] = (uint16_t)prev;
+                    if (prev != PTX_SLOT_NONE) cnext[prev] = (uint16_t)nc;
                     ctail[my_id] = (uint16_t)nc;
                     H->ncom = nc + 1u;
                 }
