@@ -32,7 +32,8 @@
  *                  (peritext.ts:318 keeps the array sorted by id)
  *     action  u8   PTX_ACT_*      mark_type u8  PTX_MARK_* (schema.ts:125 ALL_MARKS order)
  *     side_a  u8   PTX_SIDE_* of start        side_b u8  PTX_SIDE_* of end
- *   Ops on other objects than the text list (makeMap / set / del on the root map) are PTX_ACT_NOP.
+ *   Ops on the map objects (set / del / makeMap on the root map or a nested map) are PTX_ACT_MAPSET / PTX_ACT_MAPDEL rows: the text path
+ *   ignores them, ptx_root_map resolves them; anything else is PTX_ACT_NOP.
  *
  * Output (all per log, canonical — two replicas have deep-equal getTextWithFormatting output iff
  * their canonical outputs, and therefore their digests, are equal):

@@ -379,7 +379,15 @@ function decodeChanges(batch, log, textObjOfLog) {
                 Object.assign(op, { action: act === ACT.ADDMARK ? "addMark" : "removeMark", obj: textObj, start, end, markType: mt })
                 if (mt === "link" && act === ACT.ADDMARK) op.attrs = { url: batch.urls[batch.payload[i]] }
                 else if (mt === "comment") op.attrs = { id: comments[batch.payload[i]] }
-            } else throw new Error("row " + i + " is not an op of the text list")
+            } else if (act === ACT.MAPSET || act === ACT.MAPDEL) { /* an op on a map object (the root map or a nested one) */
+                Object.assign(op, { obj: batch.refA[i] ? oid(batch.refA[i]) : ROOT, key: batch.keys[Number(batch.refB[i])] })
+                if (act === ACT.MAPDEL) op.action = "del"
+                else {
+                    const kind = batch.markType[i]
+                    op.action = kind === MAPV.MAP ? "makeMap" : kind === MAPV.LIST ? "makeList" : "set"
+                    if (kind === MAPV.SCALAR) op.value = JSON.parse(batch.mapValues[batch.payload[i]])
+                }
+            } else throw new Error("row " + i + " is not an op this engine models")
             ops.push(op)
         }
         out.push({ actor: actors[batch.chgActor[c]], seq: batch.chgSeq[c], deps, startOp: nops ? Number(batch.opId[row] >> 32n) : 0, ops })

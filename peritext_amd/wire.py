@@ -96,9 +96,9 @@ class Batch:
         return int(self.log_off[-1])
 
     def counted_ops(self, log=None):
-        """Ops the metric counts: everything except makeList / NOP rows."""
+        """Ops the metric counts: the ops of the text list (insert / delete / addMark / removeMark)."""
         a = self.action if log is None else self.action[int(self.log_off[log]) : int(self.log_off[log + 1])]
-        return int(np.count_nonzero((a != abi.ACT_MAKELIST) & (a != abi.ACT_NOP)))
+        return int(np.count_nonzero((a >= abi.ACT_INSERT) & (a <= abi.ACT_REMOVEMARK)))
 
     def tile(self, copies):
         """`copies` back-to-back copies of this batch (same content, distinct rows)."""
@@ -499,7 +499,7 @@ def split_batch(batch, first_changes):
 def decode_changes(batch, log, text_obj=None):
     """Change[] of one log — the inverse of encode_docs for the ops of the text list (reference/src/micromerge.ts:60-71
     Change, :150-212 Operation, src/peritext.ts:25-65 mark ops), in the JSON-portable form of the traces
-    (ROOT / HEAD as "_root" / "_head").  Needs the Change envelope; ops on other objects (PTX_ACT_NOP) cannot be restored.
+    (ROOT / HEAD as "_root" / "_head"), ops on the map objects included.  Needs the Change envelope; PTX_ACT_NOP rows cannot be restored.
     text_obj: opId of the text list when the log does not hold its makeList (a batch of newly made Changes only)."""
     if batch.chg_off is None:
         raise ValueError("the batch carries no Change envelope")
@@ -548,8 +548,18 @@ def decode_changes(batch, log, text_obj=None):
                     op["attrs"] = {"url": batch.urls[int(batch.payload[i])]}
                 elif mt == abi.MARK_COMMENT:
                     op["attrs"] = {"id": comments[int(batch.payload[i])]}
+            elif act in (abi.ACT_MAPSET, abi.ACT_MAPDEL):  # an op on a map object (the root map or a nested one)
+                ref = int(batch.ref_a[i])
+                op.update(obj=oid(ref) if ref else ROOT, key=batch.keys[int(batch.ref_b[i])])
+                if act == abi.ACT_MAPDEL:
+                    op["action"] = "del"
+                else:
+                    kind = int(batch.mark_type[i])
+                    op["action"] = "makeMap" if kind == abi.MAPV_MAP else "makeList" if kind == abi.MAPV_LIST else "set"
+                    if kind == abi.MAPV_SCALAR:
+                        op["value"] = json.loads(batch.map_values[int(batch.payload[i])])
             else:
-                raise ValueError("row %d of log %d is not an op of the text list" % (i - b0, log))
+                raise ValueError("row %d of log %d is not an op this engine models" % (i - b0, log))
             ops.append(op)
         start_op = int(batch.op_id[row]) >> 32 if nops else 0
         out.append({"actor": actors[int(c_actor[c])], "seq": int(c_seq[c]), "deps": deps, "startOp": start_op, "ops": ops})

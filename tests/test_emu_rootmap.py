@@ -41,3 +41,14 @@ def test_more_map_ops_than_the_table_holds_is_a_capacity_status():
     batch = wire.encode_docs(docs[:1])
     rm = H.emu_root_map(batch, lds_bytes=16 + 3 * 40)
     assert (rm.logs["status"] == abi.ERR_CAPACITY).all() and (rm.logs["n_entries"] == 0).all()
+
+
+def test_decode_changes_restores_the_map_ops():
+    """wire.decode_changes is the inverse of encode_docs for the rows of the map objects too."""
+    docs = H.root_map_docs()
+    batch = wire.encode_docs(docs)
+    log = 0
+    for logs in docs:
+        for changes in logs:
+            assert wire.decode_changes(batch, log) == changes
+            log += 1

@@ -161,6 +161,14 @@ def test_js_decode_changes_inverts_the_encoder(name):
     assert out["ok"] and out["logs"] > 0
 
 
+@needs_node
+def test_js_decode_changes_restores_the_map_ops(tmp_path):
+    p = tmp_path / "rootdocs.json"
+    p.write_text(json.dumps({"docs": [{"logs": logs} for logs in H.root_map_docs()]}))
+    out = _node("decode", str(p))
+    assert out["ok"] and out["logs"] == 8
+
+
 @pytest.mark.gpu
 @needs_node
 @needs_addon
