@@ -421,7 +421,7 @@ function decodeRoot(batch, rm, log) {
         const out = {}
         for (const e of byObj.get(obj) || []) {
             if (e.kind === MAPV.DELETED) continue
-            const k = batch.keys[e.key]
+            const k = (batch.keys && batch.keys.length ? batch.keys : ["text"])[e.key] /* batches made on the device hold the text list's makeList only: key id 0 */
             if (e.kind === MAPV.MAP) out[k] = build(batch.opId[b0 + e.row])
             else if (e.kind === MAPV.LIST) out[k] = { $list: true }
             else out[k] = JSON.parse(batch.mapValues[e.value])

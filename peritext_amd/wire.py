@@ -325,6 +325,7 @@ def decode_root(batch, rm, log):
     by_obj = {}
     for e in ent:
         by_obj.setdefault(int(e["obj"]), []).append(e)
+    keys = batch.keys or ["text"]  # batches made on the device (ptx_generate) hold the text list's makeList only: key id 0
 
     def build(obj):
         out = {}
@@ -332,7 +333,7 @@ def decode_root(batch, rm, log):
             kind = int(e["kind"])
             if kind == abi.MAPV_DELETED:
                 continue
-            k = batch.keys[int(e["key"])]
+            k = keys[int(e["key"])]
             if kind == abi.MAPV_MAP:
                 out[k] = build(int(batch.op_id[b0 + int(e["row"])]))
             elif kind == abi.MAPV_LIST:
