@@ -450,7 +450,13 @@ ptx_status ptx_resolve_cursors(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dres
  *   mark_type   PTX_MARK_*
  * `actor[l]` = actorRank of the replica behind log l (ranks as in the op ids of `base`).  Ids follow the tables of `base`: a new
  * comment id must already have its rank (the caller encodes the document with the ids it is about to use). */
-enum { PTX_IN_INSERT = 0, PTX_IN_DELETE = 1, PTX_IN_ADDMARK = 2, PTX_IN_REMOVEMARK = 3, PTX_IN_MAKELIST = 4 };
+enum { PTX_IN_INSERT = 0, PTX_IN_DELETE = 1, PTX_IN_ADDMARK = 2, PTX_IN_REMOVEMARK = 3, PTX_IN_MAKELIST = 4,
+       /* on a MAP object (micromerge.ts:400-425): {action: "set", key, value} / makeMap / makeList -> one PTX_ACT_MAPSET row, {action: "del",
+        * key} -> one PTX_ACT_MAPDEL row.  index = the map object the host resolved the path to (getObjectIdForPath, :446-463): 0 = the
+        * root map, PTX_IN_OBJ_NEW | k = the object made by row k of THIS log's output (a makeMap earlier in the same call), else counter
+        * << 12 | actor rank of the makeMap that created it; count = key id, mark_type = PTX_MAPV_*, payload = value id */
+       PTX_IN_MAPSET = 5, PTX_IN_MAPDEL = 6 };
+#define PTX_IN_OBJ_NEW 0x80000000u
 typedef struct ptx_input_ops {
     uint32_t n_logs;            /* == logs of the base batch */
     uint32_t max_actors;        /* actors of a document = row stride of the deps the new Changes carry (must equal the base

@@ -212,7 +212,8 @@ class ptx_gen_info(C.Structure):
 
 
 # InputOperation.action of ptx_change (reference/src/micromerge.ts:133-148)
-IN_INSERT, IN_DELETE, IN_ADDMARK, IN_REMOVEMARK, IN_MAKELIST = range(5)
+IN_INSERT, IN_DELETE, IN_ADDMARK, IN_REMOVEMARK, IN_MAKELIST, IN_MAPSET, IN_MAPDEL = range(7)
+IN_OBJ_NEW = 0x80000000  # ptx_input_ops.index of a map op: the object made by row k of this log's output
 CURSOR_RESOLVE, CURSOR_GET = 0, 1
 
 

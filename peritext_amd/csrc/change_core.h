@@ -263,9 +263,21 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
             const uint32_t act = A.in_action[q], idx = A.in_index[q], cnt = A.in_count[q], pay = A.in_payload[q], mt = A.in_mark_type[q];
             if (act == PTX_IN_MAKELIST) {
                 if (H->has_list) PTX_CHANGE_FAIL(PTX_ERR_BAD_OP); /* one text list per document */
-                PTX_CE_EMIT(PTX_ACT_MAKELIST, 0, 0ull, 0ull, 0, 0, 0u);
+                PTX_CE_EMIT(PTX_ACT_MAKELIST, 0, 0ull, (uint64_t)cnt, 0, 0, 0u); /* ref_b: the key's id ("text" is key 0 of every batch) */
                 PTX_LEADER { H->has_list = 1; }
                 PTX_SYNC();
+                continue;
+            }
+            if (act == PTX_IN_MAPSET || act == PTX_IN_MAPDEL) {
+                /* an op on a map object (micromerge.ts:400-425): the host has resolved the path; nothing of the list state is involved */
+                uint64_t obj = 0;
+                if (idx & PTX_IN_OBJ_NEW) {
+                    const uint32_t k = idx & ~PTX_IN_OBJ_NEW;
+                    if (k >= H->rows) PTX_CHANGE_FAIL(PTX_ERR_BAD_OP);
+                    obj = A.o_op_id[out0 + k]; /* a map made earlier in this very call */
+                } else if (idx) obj = ((uint64_t)(idx >> 12) << 32) | (uint64_t)(idx & 4095u);
+                if (act == PTX_IN_MAPSET && mt > PTX_MAPV_LIST) PTX_CHANGE_FAIL(PTX_ERR_BAD_OP);
+                PTX_CE_EMIT(act == PTX_IN_MAPSET ? PTX_ACT_MAPSET : PTX_ACT_MAPDEL, act == PTX_IN_MAPSET ? mt : 0u, obj, (uint64_t)cnt, 0, 0, act == PTX_IN_MAPSET ? pay : 0u);
                 continue;
             }
             if (!H->has_list || act > PTX_IN_MAKELIST) PTX_CHANGE_FAIL(PTX_ERR_BAD_OP); /* "Child not found: text" / unknown action */

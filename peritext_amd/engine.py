@@ -294,7 +294,7 @@ class Engine:
         finally:
             self.lib.ptx_gen_info_free(C.byref(info))
 
-    def download_batch(self, dbatch, values=None, urls=None, log_doc=None, doc_actors=None, doc_comments=None):
+    def download_batch(self, dbatch, values=None, urls=None, log_doc=None, doc_actors=None, doc_comments=None, keys=None, map_values=None):
         """Copy a resident batch back as a wire.Batch (the decode tables are the caller's: a generated batch uses
         wire.GEN_VALUES / GEN_URLS / generated_tables)."""
         hb = abi.ptx_host_batch()
@@ -314,7 +314,7 @@ class Engine:
                 log_off, arr(b.op_id, np.uint64, T), arr(b.ref_a, np.uint64, T), arr(b.ref_b, np.uint64, T), arr(b.payload, np.uint32, T),
                 arr(b.action, np.uint8, T), arr(b.mark_type, np.uint8, T), arr(b.side_a, np.uint8, T), arr(b.side_b, np.uint8, T),
                 chg_off, arr(b.chg_hdr, np.uint32, NC) if has_env else None,
-                arr(b.chg_env, np.uint16, NC * abi.env_stride(b.max_actors)) if has_env else None, int(b.max_actors), arr(b.log_hdr, abi.LOG_HDR_DTYPE, L), values or [], urls or [], log_doc or [], doc_actors or [], doc_comments or [])
+                arr(b.chg_env, np.uint16, NC * abi.env_stride(b.max_actors)) if has_env else None, int(b.max_actors), arr(b.log_hdr, abi.LOG_HDR_DTYPE, L), values or [], urls or [], log_doc or [], doc_actors or [], doc_comments or [], keys or [], map_values or [])
         finally:
             self.lib.ptx_host_batch_free(C.byref(hb))
 

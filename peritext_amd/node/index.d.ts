@@ -24,6 +24,10 @@ export type Operation = InsertOperation | DeleteOperation | MakeListOperation | 
 /** micromerge.ts:133-148 — what Micromerge.change(ops) takes: index-based operations on the text list (the only path this host serves) */
 export type InputOperation =
     | { path: []; action: "makeList"; key: "text" }
+    /** on a map object — the root map (path []) or a map nested in it (path = the keys down from the root), micromerge.ts:109-131 */
+    | { path: string[]; action: "makeMap" | "makeList"; key: string }
+    | { path: string[]; action: "set"; key: string; value: JsonValue }
+    | { path: string[]; action: "del"; key: string }
     | { path: ["text"]; action: "insert"; index: number; values: string[] }
     | { path: ["text"]; action: "delete"; index: number; count: number }
     | { path: ["text"]; action: "addMark"; startIndex: number; endIndex: number; markType: MarkType; attrs?: { url?: string; id?: string } }

@@ -35,7 +35,8 @@ const STATUS_MESSAGES = {
     6: "malformed op row",
     7: "List index out of bounds" /* :804 */,
 }
-const IN = { INSERT: 0, DELETE: 1, ADDMARK: 2, REMOVEMARK: 3, MAKELIST: 4 } /* ptx_input_ops.action */
+const IN = { INSERT: 0, DELETE: 1, ADDMARK: 2, REMOVEMARK: 3, MAKELIST: 4, MAPSET: 5, MAPDEL: 6 }
+const IN_OBJ_NEW = 0x80000000 /* ptx_input_ops.index of a map op: the object made by row k of this log's output */ /* ptx_input_ops.action */
 const CHG_ACTOR_SHIFT = 20, CHG_NOPS = 0x000fffff, ENV_SATURATED = 65535
 const envStride = maxActors => (1 + maxActors + 3) & ~3 /* PTX_ENV_STRIDE */
 
@@ -88,7 +89,7 @@ function encodeDocs(docs, opts) {
     const textObjs = (opts && opts.textObjs) || [] /* per document: opId of the text list when the logs do not hold its makeList */
     const values = [], valueIx = new Map()
     const urls = [], urlIx = new Map()
-    const keys = [], keyIx = new Map() /* keys of the map objects (ref_b of the map rows) */
+    const keys = ["text"], keyIx = new Map([["text", 0]]) /* keys of the map objects (ref_b of the map rows); key 0 of every batch: the text list's */
     const mapValues = [], mapValueIx = new Map() /* JSON text of the values the map rows set */
     const intern = (table, index, v) => {
         if (!index.has(v)) {
@@ -228,8 +229,45 @@ function encodeDocs(docs, opts) {
  * of the replica behind log l (each an InputOperation[]), actors[l] = its actor id.  New strings / urls extend batch.values /
  * batch.urls; comment ids and actors must already have their rank in `batch` (encodeDocs opts).
  */
+/** an InputOperation on a map object (micromerge.ts:109-131: makeMap / set / del, makeList of another key than the text's) */
+function isMapInput(op) {
+    if (op.action === "makeMap" || op.action === "set" || op.action === "del") return true
+    return op.action === "makeList" && !((op.path || []).length === 0 && op.key === "text")
+}
+/**
+ * metadata[CHILDREN] of every map object of the replica behind `log` (micromerge.ts:585-596): "obj:keyId" -> [child object id packed
+ * counter << 12 | actor rank, kind].  A makeMap / makeList registers its child when it wins its key AT THE TIME it is applied; later
+ * winners of the key that are no makeMap leave the entry alone — so this is a replay of the log's map rows in order.
+ */
+function mapChildrenOfLog(batch, log) {
+    const last = new Map(), children = new Map()
+    const pack = v => Number(((v >> 32n) << 12n) | (v & 0xfffn))
+    for (let i = Number(batch.logOff[log]); i < Number(batch.logOff[log + 1]); i++) {
+        const a = batch.action[i]
+        if (a !== ACT.MAKELIST && a !== ACT.MAPSET && a !== ACT.MAPDEL) continue
+        const key = (a === ACT.MAKELIST ? 0 : pack(batch.refA[i])) + ":" + Number(batch.refB[i] & 0xffffffffn)
+        if (!last.has(key) || last.get(key) < batch.opId[i]) {
+            last.set(key, batch.opId[i])
+            const kind = a === ACT.MAKELIST ? MAPV.LIST : a === ACT.MAPSET ? batch.markType[i] : MAPV.DELETED
+            if (kind === MAPV.MAP || kind === MAPV.LIST) children.set(key, [pack(batch.opId[i]), kind])
+        }
+    }
+    return children
+}
+
 function encodeInputOps(batch, perLog, actors) {
     const valueIx = new Map(batch.values.map((v, i) => [v, i])), urlIx = new Map(batch.urls.map((u, i) => [u, i]))
+    if (!batch.keys) batch.keys = []
+    if (!batch.keys.length) batch.keys.push("text")
+    if (!batch.mapValues) batch.mapValues = []
+    const keyIx = new Map(batch.keys.map((k, i) => [k, i])), mapValueIx = new Map(batch.mapValues.map((v, i) => [v, i]))
+    const intern = (table, ix, v) => {
+        if (!ix.has(v)) {
+            ix.set(v, table.length)
+            table.push(v)
+        }
+        return ix.get(v)
+    }
     const chgOff = [0], opOff = [0], action = [], markType = [], index = [], count = [], payload = [], values = [], actor = []
     perLog.forEach((calls, l) => {
         const d = batch.logDoc[l]
@@ -237,12 +275,32 @@ function encodeInputOps(batch, perLog, actors) {
         if (me < 0) throw new Error("actor " + actors[l] + " has no rank in this batch (encodeDocs opts.extraActors)")
         actor.push(me)
         const crank = new Map(batch.docComments[d].map((c, i) => [c, i]))
+        const children = calls.some(ops => ops.some(isMapInput)) ? mapChildrenOfLog(batch, l) : new Map()
+        let made = 0 /* rows this log's calls have made so far */
         for (const ops of calls) {
             for (const op of ops) {
                 let row
-                if (op.action === "makeList") {
+                if (isMapInput(op)) {
+                    /* getObjectIdForPath (micromerge.ts:446-463): down the CHILDREN of the map objects, from the root */
+                    let obj = 0
+                    for (const elem of op.path || []) {
+                        const child = children.get(obj + ":" + (keyIx.has(elem) ? keyIx.get(elem) : -1))
+                        if (child === undefined) throw new Error("Child not found: " + elem + " in " + JSON.stringify(op.path))
+                        if (child[1] !== MAPV.MAP) throw new RangeError("Object " + elem + " in path " + JSON.stringify(op.path) + " is a list")
+                        obj = child[0]
+                    }
+                    const k = intern(batch.keys, keyIx, op.key)
+                    if (op.action === "del") row = [IN.MAPDEL, 0, obj, k, 0]
+                    else {
+                        const kind = op.action === "makeMap" ? MAPV.MAP : op.action === "makeList" ? MAPV.LIST : MAPV.SCALAR
+                        row = [IN.MAPSET, kind, obj, k, op.action === "set" ? intern(batch.mapValues, mapValueIx, JSON.stringify(op.value === undefined ? null : op.value)) : 0]
+                        if (kind !== MAPV.SCALAR) children.set(obj + ":" + k, [(IN_OBJ_NEW | made) >>> 0, kind]) /* the newest op of the replica: it wins its key */
+                    }
+                    made += 1
+                } else if (op.action === "makeList") {
                     if ((op.path || []).length !== 0 || op.key !== "text") throw new Error("only the text list of the root map is supported")
                     row = [IN.MAKELIST, 0, 0, 0, 0]
+                    made += 1
                 } else if (!Array.isArray(op.path) || op.path.length !== 1 || op.path[0] !== "text") {
                     throw new Error("Only the text list is supported: " + JSON.stringify(op.path))
                 } else if (op.action === "insert") {
@@ -256,7 +314,11 @@ function encodeInputOps(batch, perLog, actors) {
                         values.push(valueIx.get(v))
                     }
                     row = [IN.INSERT, 0, op.index, op.values.length, first]
-                } else if (op.action === "delete") row = [IN.DELETE, 0, op.index, op.count, 0]
+                    made += op.values.length
+                } else if (op.action === "delete") {
+                    row = [IN.DELETE, 0, op.index, op.count, 0]
+                    made += op.count
+                }
                 else if (op.action === "addMark" || op.action === "removeMark") {
                     const mt = MARK_NAMES.indexOf(op.markType)
                     if (mt < 0) throw new Error("unknown mark type " + op.markType)
@@ -272,6 +334,7 @@ function encodeInputOps(batch, perLog, actors) {
                         pl = crank.get(op.attrs.id)
                     }
                     row = [op.action === "addMark" ? IN.ADDMARK : IN.REMOVEMARK, mt, op.startIndex, op.endIndex, pl]
+                    made += 1
                 } else throw new Error("unsupported InputOperation action " + op.action)
                 if (!(row[2] >= 0) || !(row[3] >= 0)) throw new RangeError("List index out of bounds: " + Math.min(row[2], row[3]))
                 action.push(row[0]); markType.push(row[1]); index.push(row[2]); count.push(row[3]); payload.push(row[4])
@@ -636,7 +699,7 @@ class MergeEngine {
         }))
         const inputOps = encodeInputOps(batch, flatCalls, flatActors)
         const raw = this.addon.change(this.ctx, batch, inputOps)
-        const made = Object.assign(raw.batch, { values: batch.values, urls: batch.urls, logDoc: batch.logDoc, docActors: batch.docActors, docComments: batch.docComments })
+        const made = Object.assign(raw.batch, { values: batch.values, urls: batch.urls, logDoc: batch.logDoc, docActors: batch.docActors, docComments: batch.docComments, keys: batch.keys, mapValues: batch.mapValues })
         let log = 0
         const changes = [], status = []
         docs.forEach((logs, d) => {

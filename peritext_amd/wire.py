@@ -176,7 +176,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
     """
     values, value_ix = [], {}
     urls, url_ix = [], {}
-    keys, key_ix = [], {}
+    keys, key_ix = ["text"], {"text": 0}  # key 0 of every batch: the text list's (rows made on the device use it)
     mvals, mval_ix = [], {}
 
     def intern(table, index, v):
@@ -362,27 +362,93 @@ class InputOps:
     max_actors: int
 
 
+def _is_map_input(op):
+    """An InputOperation on a map object (micromerge.ts:109-131: makeMap / set / del, makeList of another key than the text's)."""
+    a = op.get("action")
+    if a in ("makeMap", "set", "del"):
+        return True
+    return a == "makeList" and not (list(op.get("path", [])) == [] and op.get("key") == "text")
+
+
+def map_children_of_log(batch, log):
+    """metadata[CHILDREN] of every map object of the replica behind `log` (micromerge.ts:585-596): (object, key id) -> (child object
+    id packed counter << 12 | actor rank, kind).  A makeMap / makeList registers its child when it wins its key AT THE TIME it is
+    applied; later winners of the key that are no makeMap leave the entry alone — so this is a replay of the log's map rows in order."""
+    b0, b1 = int(batch.log_off[log]), int(batch.log_off[log + 1])
+    last, children = {}, {}
+    for i in range(b0, b1):
+        a = int(batch.action[i])
+        if a not in (abi.ACT_MAKELIST, abi.ACT_MAPSET, abi.ACT_MAPDEL):
+            continue
+        obj = 0 if a == abi.ACT_MAKELIST else int(batch.ref_a[i])
+        obj = ((obj >> 32) << 12) | (obj & 0xFFF)
+        key = (obj, int(batch.ref_b[i]) & 0xFFFFFFFF)
+        oid = int(batch.op_id[i])
+        if key not in last or last[key] < oid:
+            last[key] = oid
+            kind = abi.MAPV_LIST if a == abi.ACT_MAKELIST else int(batch.mark_type[i]) if a == abi.ACT_MAPSET else abi.MAPV_DELETED
+            if kind in (abi.MAPV_MAP, abi.MAPV_LIST):
+                children[key] = (((oid >> 32) << 12) | (oid & 0xFFF), kind)
+    return children
+
+
 def encode_input_ops(batch, per_log, actors):
     """per_log[l] = list of change() calls of the replica behind log l, each a list of InputOperation dicts in the reference's
     shape ({path, action: "insert", index, values} / {action: "delete", index, count} / {action: "addMark" | "removeMark",
-    startIndex, endIndex, markType, attrs?} / {path: [], action: "makeList", key: "text"}); actors[l] = that replica's actor id.
+    startIndex, endIndex, markType, attrs?} / {path: [], action: "makeList", key: "text"} / on map objects {path, action: "makeMap" |
+    "makeList" | "del", key} and {path, action: "set", key, value}: their paths are resolved here, micromerge.ts:446-463); actors[l] =
+    that replica's actor id.
     New inserted strings / urls extend batch.values / batch.urls; comment ids and actors must already have their rank in
     `batch` (encode_docs(..., extra_actors=, extra_comments=))."""
     value_ix = {v: i for i, v in enumerate(batch.values)}
     url_ix = {u: i for i, u in enumerate(batch.urls)}
+    if not batch.keys:
+        batch.keys.append("text")
+    key_ix = {k: i for i, k in enumerate(batch.keys)}
+    mval_ix = {v: i for i, v in enumerate(batch.map_values)}
+
+    def intern(table, ix, v):
+        if v not in ix:
+            ix[v] = len(table)
+            table.append(v)
+        return ix[v]
+
     chg_off, op_off = [0], [0]
     action, mark_type, index, count, payload, values, actor = [], [], [], [], [], [], []
     for l, calls in enumerate(per_log):
         d = batch.log_doc[l]
         actor.append(batch.doc_actors[d].index(actors[l]))
         crank = {c: i for i, c in enumerate(batch.doc_comments[d])}
+        children = map_children_of_log(batch, l) if any(_is_map_input(op) for ops in calls for op in ops) else {}
+        made = 0  # rows this log's calls have made so far
         for ops in calls:
             for op in ops:
                 a = op["action"]
-                if a == "makeList":
+                if _is_map_input(op):
+                    # getObjectIdForPath (micromerge.ts:446-463): down the CHILDREN of the map objects, from the root
+                    obj = 0
+                    for elem in op.get("path", []):
+                        child = children.get((obj, key_ix.get(elem, -1)))
+                        if child is None:
+                            raise ValueError("Child not found: %s in %s" % (elem, op.get("path")))
+                        if child[1] != abi.MAPV_MAP:
+                            raise ValueError("Object %s in path %r is a list" % (elem, op.get("path")))
+                        obj = child[0]
+                    k = intern(batch.keys, key_ix, op["key"])
+                    if a == "del":
+                        row = (abi.IN_MAPDEL, 0, obj, k, 0)
+                    else:
+                        kind = abi.MAPV_MAP if a == "makeMap" else abi.MAPV_LIST if a == "makeList" else abi.MAPV_SCALAR
+                        pl = intern(batch.map_values, mval_ix, json.dumps(op.get("value"), sort_keys=True, ensure_ascii=False, separators=(",", ":"))) if a == "set" else 0
+                        row = (abi.IN_MAPSET, kind, obj, k, pl)
+                        if kind != abi.MAPV_SCALAR:
+                            children[(obj, k)] = (abi.IN_OBJ_NEW | made, kind)  # the newest op of the replica: it wins its key
+                    made += 1
+                elif a == "makeList":
                     if list(op.get("path", [])) != [] or op.get("key") != "text":
                         raise ValueError("only the text list of the root map is supported")
                     row = (abi.IN_MAKELIST, 0, 0, 0, 0)
+                    made += 1
                 elif list(op.get("path", [])) != ["text"]:
                     raise ValueError("Only the text list is supported: %r" % (op.get("path"),))
                 elif a == "insert":
@@ -395,8 +461,10 @@ def encode_input_ops(batch, per_log, actors):
                             batch.values.append(v)
                         values.append(value_ix[v])
                     row = (abi.IN_INSERT, 0, int(op["index"]), len(op["values"]), first)
+                    made += len(op["values"])
                 elif a == "delete":
                     row = (abi.IN_DELETE, 0, int(op["index"]), int(op["count"]), 0)
+                    made += int(op["count"])
                 elif a in ("addMark", "removeMark"):
                     mt = abi.MARK_NAMES.index(op["markType"])
                     pl = 0
@@ -409,6 +477,7 @@ def encode_input_ops(batch, per_log, actors):
                     elif mt == abi.MARK_COMMENT:
                         pl = crank[op["attrs"]["id"]]
                     row = (abi.IN_ADDMARK if a == "addMark" else abi.IN_REMOVEMARK, mt, int(op["startIndex"]), int(op["endIndex"]), pl)
+                    made += 1
                 else:
                     raise ValueError("unsupported InputOperation action %r" % (a,))
                 for lst, v in zip((action, mark_type, index, count, payload), row):

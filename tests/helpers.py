@@ -211,7 +211,7 @@ def made_batch(batch, ops, cols, env, rows_made, chgs_made, out_off):
     chg_off[1:] = np.cumsum(chgs_made[:n_logs].astype(np.uint64))
     return wire.Batch(log_off, cols["op_id"][keep], cols["ref_a"][keep], cols["ref_b"][keep], cols["payload"][keep], cols["action"][keep], cols["mark_type"][keep],
                       cols["side_a"][keep], cols["side_b"][keep], chg_off, env["chg_hdr"][ckeep], env["chg_env"].reshape(-1, abi.env_stride(na))[ckeep].reshape(-1),
-                      na, None, batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments)
+                      na, None, batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments, batch.keys, batch.map_values)
 
 
 def emu_change(batch, res, ops, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB):
@@ -303,7 +303,7 @@ def concat_batches(base, more):
     hdr, env = cat_env(chgs)
     return wire.Batch((base.log_off + more.log_off).astype(np.uint64), cat("op_id", rows), cat("ref_a", rows), cat("ref_b", rows), cat("payload", rows), cat("action", rows),
                       cat("mark_type", rows), cat("side_a", rows), cat("side_b", rows), (base.chg_off + more.chg_off).astype(np.uint64), hdr, env, na, None,
-                      base.values, base.urls, base.log_doc, base.doc_actors, base.doc_comments)
+                      base.values, base.urls, base.log_doc, base.doc_actors, base.doc_comments, base.keys, base.map_values)
 
 
 def mini_doc(ops_second_change, first_text="ABCDE"):
@@ -777,3 +777,67 @@ def emu_root_map(b, lds_bytes=64 * 1024, reverse=0, lib_path=EMU_LIB):
     rc = lib.ptx_emu_root_map(C.byref(s), off.ctypes.data, ent.ctypes.data, logs.ctypes.data, lds_bytes, reverse)
     assert rc == 0
     return wire.RootMaps(entry_off=off, logs=logs[: b.n_logs], entries=ent[: int(off[-1])])
+
+
+def root_map_change_calls():
+    """change() calls with InputOperations on map objects (micromerge.ts:400-425) for the replicas of root_map_docs()[0:2] and of a
+    document that shows the reference's order-dependent CHILDREN table (a makeMap registers its child only if it wins its key when it
+    is applied; a later scalar winner leaves the entry alone): (docs, calls per log, actor per log)."""
+    docs = root_map_docs()[:2]
+    a1 = docs[0][0][0]
+    mk = {"actor": "m", "seq": 1, "deps": {"a": 1}, "startOp": 5, "ops": [{"opId": "5@m", "action": "makeMap", "obj": "_root", "key": "cfgx"}]}
+    st = {"actor": "s", "seq": 1, "deps": {"a": 1}, "startOp": 6, "ops": [{"opId": "6@s", "action": "set", "obj": "_root", "key": "cfgx", "value": 1}]}
+    docs = docs + [[[a1, mk, st], [a1, st, mk]]]
+    T = ["text"]
+    mixed = [
+        {"path": [], "action": "set", "key": "title", "value": "new title"},
+        {"path": [], "action": "makeMap", "key": "fresh"},
+        {"path": ["fresh"], "action": "set", "key": "n", "value": 7},
+        {"path": ["meta"], "action": "set", "key": "lang", "value": "de"},
+        {"path": T, "action": "insert", "index": 1, "values": ["x", "y"]},
+        {"path": ["fresh"], "action": "makeMap", "key": "deep"},
+        {"path": ["fresh", "deep"], "action": "del", "key": "nothing"},
+        {"path": [], "action": "del", "key": "count"},
+        {"path": [], "action": "makeList", "key": "todo"},
+        {"path": T, "action": "addMark", "markType": "strong", "startIndex": 0, "endIndex": 2},
+    ]
+    nested = [
+        {"path": ["cfg"], "action": "set", "key": "version", "value": 4},
+        {"path": ["cfg", "ui"], "action": "set", "key": "zz", "value": True},  # doc 2, replica 0: `ui` was deleted, CHILDREN still knows it
+        {"path": ["cfg", "ui", "theme"], "action": "del", "key": "dark"},
+    ]
+    through = [{"path": ["cfgx"], "action": "set", "key": "k", "value": None}]
+    calls = [[mixed, [{"path": [], "action": "set", "key": "title", "value": "second call"}]], [mixed], [mixed], [nested], [nested], [through], [through]]
+    actors = ["a", "b", "c", "a", "e", "m", "s"]
+    return docs, calls, actors
+
+
+def check_map_change_calls(change_fn, golden_change):
+    """change_fn(batch, ops) -> (made wire.Batch, status per log); golden_change = rootmap_ref.json["change"] (made by the reference)."""
+    import change_script as CS
+
+    docs, calls, actors = root_map_change_calls()
+    assert golden_change["docs"] == docs and golden_change["calls"] == calls and golden_change["actors"] == actors
+    want = golden_change["made"]
+    batch = wire.encode_docs(docs)
+    ok = [("error" not in w) for w in want]
+    # the reference's getObjectIdForPath throws where a path does not resolve: so does the host-side resolution
+    for l, w in enumerate(want):
+        if "error" in w:
+            assert "Child not found" in w["error"]
+            try:
+                wire.encode_input_ops(batch, [calls[k] if k == l else [] for k in range(len(calls))], actors)
+                raise AssertionError("log %d: the path should not resolve" % l)
+            except ValueError as e:
+                assert "Child not found" in str(e)
+    ops = wire.encode_input_ops(batch, [calls[l] if ok[l] else [] for l in range(len(calls))], actors)
+    made, status = change_fn(batch, ops)
+    assert (status == 0).all(), status
+    log = 0
+    for logs in docs:
+        for changes in logs:
+            if ok[log]:
+                got = wire.decode_changes(made, log, text_obj=CS.text_obj_of(changes))
+                assert [CS.norm_change(c) for c in got] == [CS.norm_change(c) for c in want[log]["changes"]], (log, got, want[log]["changes"])
+            log += 1
+    return batch, made

@@ -89,6 +89,59 @@ if (cmd === "encode") {
     const ok = g.docs.map(logs => logs.filter((_, r) => true))
     engine.close()
     console.log(JSON.stringify({ checked, thrown }))
+} else if (cmd === "mapinputops") {
+    /* no GPU: the InputOperations on map objects of rootmap_ref.json's change() calls, encoded against every replica's log */
+    const g = JSON.parse(fs.readFileSync(process.argv[3], "utf8")).change
+    const out = []
+    let l = 0
+    g.docs.forEach(logs => {
+        logs.forEach((log, r) => {
+            const b = host.encodeDocs([[log]], { extraActors: [[g.actors[l]]] })
+            try {
+                const io = host.encodeInputOps(b, [g.calls[l]], [g.actors[l]])
+                const row = { keys: b.keys, mapValues: b.mapValues.map(v => JSON.parse(v)) }
+                for (const k of ["chgOff", "opOff", "action", "markType", "index", "count", "payload", "values", "actor"]) row[k] = sha(io[k])
+                out.push(row)
+            } catch (e) {
+                out.push({ error: e.message })
+            }
+            l++
+        })
+    })
+    console.log(JSON.stringify(out))
+} else if (cmd === "mapchange") {
+    /* GPU: replica().change(InputOperation[]) with ops on map objects (ptx_change through N-API) against the Changes the reference returned */
+    const g = JSON.parse(fs.readFileSync(process.argv[3], "utf8")).change
+    const engine = new host.MergeEngine()
+    const strip = c => JSON.parse(JSON.stringify(c, (k, v) => ((k === "obj" && v === "_root") || (k === "elemId" && v === "_head") ? undefined : v)))
+    let l = 0, made = 0, thrown = 0
+    g.docs.forEach((logs, d) => {
+        logs.forEach((log, r) => {
+            const want = g.made[l], calls = g.calls[l], actor = g.actors[l]
+            const rep = engine.replica("d" + d + "r" + r, actor)
+            for (const ch of log) rep.applyChange(ch)
+            if (want.error) {
+                assert.throws(() => rep.change(calls[0]), /Child not found/)
+                thrown++
+            } else {
+                calls.forEach((ops, k) => {
+                    const got = rep.change(ops).change
+                    const w = want.changes[k]
+                    assert.deepStrictEqual({ actor: got.actor, seq: got.seq, startOp: got.startOp, ops: strip(got.ops) }, { actor: w.actor, seq: w.seq, startOp: w.startOp, ops: strip(w.ops) })
+                    const deps = {}
+                    for (const a of Object.keys(w.deps)) if (w.deps[a]) deps[a] = w.deps[a]
+                    assert.deepStrictEqual(got.deps, deps)
+                    made++
+                })
+                /* the replica has applied its own changes: its root shows them */
+                const root = rep.getRoot()
+                if (calls[0].some(op => op.key === "title")) assert.strictEqual(root.title, calls.length > 1 ? "second call" : "new title")
+            }
+            l++
+        })
+    })
+    engine.close()
+    console.log(JSON.stringify({ made, thrown }))
 } else if (cmd === "patches") {
     /* GPU: the Patch[] every applyChange returns (fixtures made by the reference itself, oracle/gen_patch_golden.js) */
     const engine = new host.MergeEngine()

@@ -52,3 +52,18 @@ def test_decode_changes_restores_the_map_ops():
         for changes in logs:
             assert wire.decode_changes(batch, log) == changes
             log += 1
+
+
+@pytest.mark.parametrize("reverse", [0, 2])
+def test_change_calls_on_map_objects(reverse):
+    """Micromerge.change with InputOperations on map objects (makeMap / set / del / makeList with a path, micromerge.ts:400-425), mixed
+    with text ops, two calls in a row, maps made earlier in the same call, the order-dependent CHILDREN table of the reference: the
+    Changes the reference itself returned (rootmap_ref.json)."""
+    with open(os.path.join(H.GOLDEN, "rootmap_ref.json")) as f:
+        g = json.load(f)
+
+    def change_fn(batch, ops):
+        res = H.emu_merge(batch, admission=True, reverse=reverse)
+        return H.emu_change(batch, res, ops, reverse=reverse)
+
+    H.check_map_change_calls(change_fn, g["change"])

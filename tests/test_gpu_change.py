@@ -36,7 +36,7 @@ class GpuBackend:
             e.merge(db, dr)
             e.sync()
             made_h, status = e.change(db, dr, ops)
-            made = e.download_batch(made_h, batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments)
+            made = e.download_batch(made_h, batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments, batch.keys, batch.map_values)
         finally:
             if made_h is not None:
                 e.free_batch(made_h)
@@ -50,6 +50,17 @@ class GpuBackend:
 
 def test_reference_test_file_change_calls(eng):
     assert CS.run_scripts(CS.load_scripts(), GpuBackend(eng)) == 125
+
+
+def test_change_calls_on_map_objects(eng):
+    """Micromerge.change with InputOperations on map objects (micromerge.ts:400-425) through ptx_change on the device: the Changes the
+    reference itself returned (rootmap_ref.json); what was made, appended to the replicas, gives the reference's getRoot()."""
+    import json
+    import os
+
+    with open(os.path.join(H.GOLDEN, "rootmap_ref.json")) as f:
+        g = json.load(f)
+    batch, made = H.check_map_change_calls(GpuBackend(eng).change, g["change"])
 
 
 def test_statuses_and_device_append(eng):

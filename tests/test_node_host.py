@@ -82,6 +82,39 @@ def test_node_host_root_maps():
     assert out["checked"] == 6 and out["thrown"] == 2
 
 
+@needs_node
+def test_js_input_ops_on_map_objects_match_python():
+    """InputOperations on map objects (path resolution through the reference's order-dependent CHILDREN table included): JS == Python."""
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    js = _node("mapinputops", os.path.join(H.GOLDEN, "rootmap_ref.json"))
+    docs, calls, actors = H.root_map_change_calls()
+    l = 0
+    for logs in docs:
+        for log in logs:
+            b = wire.encode_docs([[log]], extra_actors=[[actors[l]]])
+            try:
+                io = wire.encode_input_ops(b, [calls[l]], [actors[l]])
+            except ValueError as e:
+                assert "Child not found" in str(e) and "Child not found" in js[l]["error"]
+                l += 1
+                continue
+            assert js[l]["keys"] == b.keys and js[l]["mapValues"] == [json.loads(v) for v in b.map_values]
+            for name, col in (("chgOff", io.chg_off), ("opOff", io.op_off), ("action", io.action), ("markType", io.mark_type), ("index", io.index),
+                              ("count", io.count), ("payload", io.payload), ("values", io.values), ("actor", io.actor)):
+                assert js[l][name] == sha(col), (l, name)
+            l += 1
+    assert l == 7
+
+
+@pytest.mark.gpu
+@needs_node
+@needs_addon
+def test_node_host_change_calls_on_map_objects():
+    """replica().change(InputOperation[]) with ops on map objects (micromerge.ts:400-425): the Changes the reference returned."""
+    out = _node("mapchange", os.path.join(H.GOLDEN, "rootmap_ref.json"))
+    assert out["made"] == 7 and out["thrown"] == 1
+
+
 @pytest.mark.gpu
 @needs_node
 @needs_addon
