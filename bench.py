@@ -152,8 +152,6 @@ def main():
     ap.add_argument("--no-admission", action="store_true", help="skip applyChange's causal admission (seq/deps) in the timed path")
     ap.add_argument("--sustain-s", type=float, default=5.0, help="extra leg: back-to-back steps for at least this many seconds (clocks / thermals)")
     ap.add_argument("--host-sync-step", action="store_true", help="the round-1 step: engine on its own stream, a host-side sync between merge and digest check")
-    ap.add_argument("--narrow-ids", type=int, default=0, help="1: the timed path reads the narrow mirror of the id / side columns (PTX_FLAG_NARROW_IDS); the other "
-                    "encoding is timed on the same resident batch as an extra leg (id_columns_ab) either way")
     ap.add_argument("--list-cap", type=int, default=2048, help="list elements per replica the generator holds on chip")
     args = ap.parse_args()
 
@@ -183,8 +181,7 @@ def main():
     else:
         first_doc, n_docs = shard.doc_range(args.docs, rank, world)
         total_docs = args.docs
-    eng = Engine(local, flags=abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0) | (abi.FLAG_NARROW_IDS if args.narrow_ids else 0))
-    narrow = bool(eng.flags() & abi.FLAG_NARROW_IDS)
+    eng = Engine(local, flags=abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0))
     gcfg = workloads.gen_config(args.config, ops=args.ops)
     gen_args = (gcfg["replicas"], gcfg["ops_per_log"], gcfg["mix"], gcfg["mark_types"])
     replicas = gcfg["replicas"]
@@ -295,37 +292,9 @@ def main():
     if stream is not None:
         eng.set_stream(0)
 
-    # ---- extra leg: the OTHER encoding of the id / side columns on the same resident batch (wire columns <-> narrow mirror), same-box A/B ----
-    id_ab = None
-    try:
-        log("id-column A/B leg")
-        eng.narrow_mirror(db, not narrow)
-        eng.merge(db, dr)
-        eng.sync()
-        it = max(2, args.steps // 2)
-        ms_other = eng.merge_timed(db, dr, it) / it
-        logs_other = eng.download_logs(dr, n_logs)
-        eng.narrow_mirror(db, narrow)
-        eng.merge(db, dr)  # the result rows checked below are the timed path's
-        eng.sync()
-        ms_same = eng.merge_timed(db, dr, it) / it
-        id_ab = {"timed_path": "narrow mirror" if narrow else "wire columns", "other": "wire columns" if narrow else "narrow mirror",
-                 "kernel_ms_timed_path": ms_same, "kernel_ms_other": ms_other, "launches_each": it, "_logs_other": logs_other}
-    except Exception as e:  # noqa: BLE001 - an extra leg must not cost the bench line
-        id_ab = {"error": str(e)[:300]}
-        try:
-            eng.narrow_mirror(db, narrow)
-            eng.merge(db, dr)
-            eng.sync()
-        except Exception:  # noqa: BLE001
-            pass
-
     log("checks")
     # ---- every log ok, every document converged ----
     logs = eng.download_logs(dr, n_logs)
-    if id_ab is not None and "_logs_other" in id_ab:
-        lo = id_ab.pop("_logs_other")
-        id_ab["identical_results"] = bool((lo["status"] == logs["status"]).all() and (lo["digest"] == logs["digest"]).all() and (lo["n_spans"] == logs["n_spans"]).all())
     assert int(logs["status"].max()) == 0, "a log failed"
     assert int(logs["n_ops"].sum()) == ops_per_step
     dg = logs["digest"].reshape(-1, replicas, 2)
@@ -376,7 +345,7 @@ def main():
             it = max(2, args.steps // 2)
             ms_noadm = eng2.merge_timed(db, dr, it) / it
             eng2.close()
-        traffic = None if narrow else load_traffic(n_logs, rows)  # the committed PMC passes are of the wire-column kernel
+        traffic = load_traffic(n_logs, rows)
         threads, lds = eng.launch_shape(db)
         out = {
             "metric": "CRDT ops applied+materialised per second (whole node)",
@@ -406,7 +375,6 @@ def main():
                 "parallelism": "doc-sharded x%d, digests-only all-gather (ptx_allgather_digests: RCCL inside the C ABI)" % world,
                 "causal_admission": not args.no_admission,
                 "step": "merge + device-side convergence count, one stream, no host sync" if stream is not None else "merge, host sync, digest check",
-                "id_columns": "narrow mirror (32-bit ids, PTX_FLAG_NARROW_IDS)" if narrow else "wire columns (64-bit ids)",
             },
             "docs_converged_per_s": converged_docs * args.steps / elapsed,
             "docs_converged": converged_docs,
@@ -431,7 +399,6 @@ def main():
             "without_admission": None if ms_noadm is None else {"kernel_ms": ms_noadm, "ops_per_s_1gpu": ops_per_step / (ms_noadm * 1e-3),
                                                                 "hbm_GBps": alg_bytes / (ms_noadm * 1e-3) / 1e9, "frac": alg_bytes / (ms_noadm * 1e-3) / HBM_PEAK},
             "sustained": sustained,
-            "id_columns_ab": id_ab,
             "parity": parity,
             "launch": {"threads_per_log": threads, "lds_bytes_per_log": lds},
             "host": {"cores": cores, "gen_s": t_gen},

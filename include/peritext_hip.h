@@ -251,11 +251,6 @@ typedef struct ptx_dresult ptx_dresult;  /* result buffers resident in HBM */
 /* ptx_create flags */
 #define PTX_FLAG_NO_ELEM_RANK 1u /* do not produce ptx_result.elem_rank (saves 4 B/op of HBM writes) */
 #define PTX_FLAG_NO_ADMISSION 2u /* ignore the Change envelope (chg_*) even when the batch carries it: no seq / deps checks */
-#define PTX_FLAG_NARROW_IDS 4u   /* every batch that becomes resident also gets a NARROW MIRROR of its id and side columns — op_id / ref_a / ref_b as
-                                    counter << 12 | actorRank in 32 bits, side_a / side_b in one byte: 13 bytes per row beside the 26 of the wire
-                                    columns — and ptx_merge reads the mirror (half the cache lines per id gather).  Results are bit-identical: a log
-                                    the merge accepts has counters below 2^19 and actor ranks below 4096, ids that do not fit are looked up in vain
-                                    or rejected exactly like the wide ids they stand for.  Costs 13 B/row of HBM and one streaming pass per batch */
 
 /* ---- lifecycle ---- */
 uint32_t ptx_abi_version(void);
@@ -272,10 +267,6 @@ void ptx_result_free(ptx_result* res);
 
 /* ---- staged form (what bench.py and the multi-GPU driver use: inputs resident in HBM) ---- */
 ptx_status ptx_batch_upload(ptx_ctx* ctx, const ptx_batch* host, ptx_dbatch** out);
-/* Give a resident batch the narrow mirror of its id / side columns (on != 0; see PTX_FLAG_NARROW_IDS — batches created under that flag
- * have it already) or drop it (on == 0): ptx_merge reads the mirror of a batch that has one.  Synchronises the context's stream. */
-ptx_status ptx_batch_narrow_mirror(ptx_ctx* ctx, ptx_dbatch* b, int on);
-int ptx_batch_has_narrow_mirror(const ptx_dbatch* b);
 /* Build a resident batch made of `copies` back-to-back copies of `host` (distinct HBM addresses,
  * used to scale a synthetic batch to BASELINE sizes without regenerating it). */
 ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* host, uint32_t copies, ptx_dbatch** out);
@@ -502,12 +493,8 @@ void ptx_host_batch_free(ptx_host_batch* hb);
 /* ---- introspection ---- */
 /* Largest number of ops one log may have in this build/device (on-chip working set limit). */
 uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx);
-/* Name of the kernel the merge launches (to find it in a rocprofv3 trace); contexts with PTX_FLAG_NARROW_IDS launch the build of the same
- * name with the suffix "_n". */
+/* Name of the kernel the merge launches (to find it in a rocprofv3 trace). */
 const char* ptx_kernel_name(void);
-/* The flags in effect for this context: ptx_create's, after the environment's tuning override (PTX_NARROW=1 / 0 sets / clears
- * PTX_FLAG_NARROW_IDS). */
-uint32_t ptx_context_flags(const ptx_ctx* ctx);
 
 #ifdef __cplusplus
 }

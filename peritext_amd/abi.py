@@ -29,7 +29,6 @@ RANK_MASK = 0x7FFFFFFF
 
 FLAG_NO_ELEM_RANK = 1
 FLAG_NO_ADMISSION = 2
-FLAG_NARROW_IDS = 4  # resident batches carry a narrow mirror of the id / side columns and ptx_merge reads it
 COMM_ID_BYTES = 128
 
 PTX_OK = 0
@@ -316,9 +315,6 @@ FUNCTIONS = {
     "ptx_host_batch_free": (None, [C.POINTER(ptx_host_batch)]),
     "ptx_max_ops_per_log": (C.c_uint32, [vp]),
     "ptx_kernel_name": (C.c_char_p, []),
-    "ptx_context_flags": (C.c_uint32, [vp]),
-    "ptx_batch_narrow_mirror": (C.c_int32, [vp, vp, C.c_int]),
-    "ptx_batch_has_narrow_mirror": (C.c_int, [vp]),
 }
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")

@@ -105,13 +105,6 @@ struct PtxMergeArgs {
     const uint8_t* mark_type;
     const uint8_t* side_a;
     const uint8_t* side_b;
-    /* narrow mirror of the id and side columns (library-private; built by ptx_narrow_pack_row when the batch becomes resident).  The kNarrow
-     * builds of the kernel read it INSTEAD of op_id / ref_a / ref_b / side_a / side_b on every hot path: 13 bytes per row where the wide
-     * columns have 26, i.e. half the cache lines per id gather.  The wide columns stay beside it (the rare error-naming passes read them). */
-    const uint32_t* id32;  /* op_id as counter << 12 | actorRank (PTX_NARROW_NONE when the id does not fit) */
-    const uint32_t* ra32;  /* ref_a likewise */
-    const uint32_t* rb32;  /* ref_b likewise */
-    const uint8_t* sides;  /* min(side_a, 3) | min(side_b, 3) << 2 */
     /* causal envelope (optional: chg_off == nullptr skips causal admission) */
     const uint64_t* chg_off;
     const uint32_t* chg_hdr;  /* actor << 20 | nops */
@@ -210,35 +203,14 @@ struct PtxElemIndex {
     PtxBitWord* ib; /* bitmap over the keys of the INSERT ops */
     uint32_t na1, max_ctr, max_actor; /* key = counter * na1 + actor, na1 = max_actor + 1: a dense id keyspace */
 };
-/* Two id encodings: the wire format's 64-bit ids (counter << 32 | actorRank) and the 32-bit ids of the narrow mirror
- * (counter << 12 | actorRank).  Both keep compareOpIds' order (counter, then actor) under plain integer comparison, and 0 is HEAD / "none"
- * in both.  A log whose header passes the capacity check has counters below 2^19 and actor ranks below 4096, so every id that can be FOUND
- * fits the narrow encoding; an id that does not fit becomes PTX_NARROW_NONE, whose counter (2^20 - 1) is beyond every admissible bound:
- * it is looked up in vain / flagged as malformed exactly like the wide id it stands for. */
-#define PTX_NARROW_ACTOR_BITS 12u
-#define PTX_NARROW_NONE 0xFFFFFFFFu
-PTX_HD uint32_t ptx_narrow_id(uint64_t id) {
-    const uint32_t ctr = (uint32_t)(id >> 32), act = (uint32_t)id;
-    return (ctr >> (32u - PTX_NARROW_ACTOR_BITS)) != 0u || (act >> PTX_NARROW_ACTOR_BITS) != 0u ? PTX_NARROW_NONE : (ctr << PTX_NARROW_ACTOR_BITS) | act;
-}
-PTX_HD uint8_t ptx_narrow_sides(uint8_t side_a, uint8_t side_b) { /* the kernel only tells BEFORE / AFTER from "anything else" */
-    return (uint8_t)((side_a < 3u ? side_a : 3u) | ((side_b < 3u ? side_b : 3u) << 2));
-}
-PTX_DEV uint32_t ptx_id_ctr(uint64_t id) { return (uint32_t)(id >> 32); }
-PTX_DEV uint32_t ptx_id_act(uint64_t id) { return (uint32_t)id; }
-PTX_DEV uint32_t ptx_id_ctr(uint32_t id) { return id >> PTX_NARROW_ACTOR_BITS; }
-PTX_DEV uint32_t ptx_id_act(uint32_t id) { return id & ((1u << PTX_NARROW_ACTOR_BITS) - 1u); }
-template <class IdT>
-PTX_DEV bool ptx_id_key(const PtxElemIndex& ix, IdT id, uint32_t& key) {
-    static_assert(std::is_same<IdT, uint64_t>::value || std::is_same<IdT, uint32_t>::value, "a wide or a narrow id");
-    const uint32_t ctr = ptx_id_ctr(id), actor = ptx_id_act(id);
+PTX_DEV bool ptx_id_key(const PtxElemIndex& ix, uint64_t id, uint32_t& key) {
+    const uint32_t ctr = (uint32_t)(id >> 32), actor = (uint32_t)id;
     if (ctr == 0 || ctr > ix.max_ctr || actor > ix.max_actor) return false;
     key = ctr * ix.na1 + actor;
     return true;
 }
 /* dense index (rank in compareOpIds order among the inserts) of the list element with this id, or -1 */
-template <class IdT>
-PTX_DEV int ptx_elem_lookup(const PtxElemIndex& ix, IdT id) {
+PTX_DEV int ptx_elem_lookup(const PtxElemIndex& ix, uint64_t id) {
     uint32_t key;
     if (!ptx_id_key(ix, id, key)) return -1;
     return ptx_bitrank_if_set(ix.ib, key);
@@ -561,7 +533,7 @@ PTX_DEV bool ptx_mark_of(const PtxMarkBlocks& M, uint32_t b, uint32_t t, uint32_
 /* ================================================================================================ */
 /* Applies log `log`; returns its status (PTX_OK or a per-log PTX_ERR_*) and the LDS high-water mark.  The caller
  * writes the result row (ptx_write_result) — ONE copy of that code instead of one per early exit. */
-template <bool kManyActors, uint32_t kThreads, bool kDiag, bool kNarrow>
+template <bool kManyActors, uint32_t kThreads, bool kDiag>
 PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t* lds, uint32_t& lds_high) {
     const uint64_t base = A.log_off[log];
     const uint64_t N64 = A.log_off[log + 1] - base;
@@ -589,12 +561,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         return PTX_ERR_CAPACITY;
     }
     const uint32_t N = (uint32_t)N64;
-    /* the id columns the hot paths read: the wire format's, or (kNarrow) the 32-bit mirror */
-    typedef typename std::conditional<kNarrow, uint32_t, uint64_t>::type IdT;
-    const IdT* op_id = kNarrow ? (const IdT*)(const void*)(A.id32 + base) : (const IdT*)(const void*)(A.op_id + base);
-    const IdT* ref_a = kNarrow ? (const IdT*)(const void*)(A.ra32 + base) : (const IdT*)(const void*)(A.ref_a + base);
-    const IdT* ref_b = kNarrow ? (const IdT*)(const void*)(A.rb32 + base) : (const IdT*)(const void*)(A.ref_b + base);
-    const uint64_t* op_id_wide = A.op_id + base; /* the passes that name the first malformed / repeated row (rare) */
+    const uint64_t* op_id = A.op_id + base;
+    const uint64_t* ref_a = A.ref_a + base;
+    const uint64_t* ref_b = A.ref_b + base;
     const uint32_t* payload = A.payload + base;
     const uint8_t* action = A.action + base;
     const uint8_t* mark_type = A.mark_type + base;
@@ -989,7 +958,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
      * behind the duplicate check and the prefix scan of the id bitmap) */
     const uint32_t d_fused = D < n + 1u ? D : n + 1u; /* deletes that ride along with the inserts in P3a */
     uint32_t p3_i[PTX_U], p3_di[PTX_U];
-    IdT p3_id[PTX_U], p3_ra[PTX_U], p3_dra[PTX_U];
+    uint64_t p3_id[PTX_U], p3_ra[PTX_U], p3_dra[PTX_U];
     /* rows of this thread's inserts and deletes of a step (list reads, then the column gathers) */
 #define PTX_P3A_LOAD(st_, i_, id_, ra_, di_, dra_)                          \
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
@@ -1011,10 +980,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         uint32_t err4 = 0, ctr_hi = 0, act_hi = 0; /* malformed class bytes; max counter - 1 and max actor met */
         const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_full = N / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
         static_assert(PTX_U1 == 3, "three class bytes per dword; the fourth byte read belongs to the next thread's first row");
-        IdT id[PTX_U1], id_n[PTX_U1];
+        uint64_t id[PTX_U1], id_n[PTX_U1];
         uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
 #if PTX_P1_AHEAD > 1
-        IdT id_m[PTX_U1]; /* the step in between */
+        uint64_t id_m[PTX_U1]; /* the step in between */
         uint32_t a4_m, mt4_m;
 #endif
         /* this thread's PTX_U1 consecutive rows of a step.  A wave whose rows all exist reads them from one address; the wave that
@@ -1096,7 +1065,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 const uint32_t i = r0 + (uint32_t)u;
                 const bool in = !kMasked || (uint32_t)u < nv;
                 const uint32_t c = (c4 >> (8u * (uint32_t)u)) & 255u;
-                const uint32_t ctr = ptx_id_ctr(id[u]), act = ptx_id_act(id[u]);
+                const uint32_t ctr = (uint32_t)(id[u] >> 32), act = (uint32_t)id[u];
                 if (in) {
                     ctr_hi = ctr - 1u > ctr_hi ? ctr - 1u : ctr_hi; /* a counter of 0 wraps to the top */
                     act_hi = act > act_hi ? act : act_hi;
@@ -1155,7 +1124,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
             PTX_SYNC();
             PTX_FOR(i, N) {
-                const uint32_t ctr = (uint32_t)(op_id_wide[i] >> 32), act = (uint32_t)op_id_wide[i], a = action[i], mt = mark_type[i];
+                const uint32_t ctr = (uint32_t)(op_id[i] >> 32), act = (uint32_t)op_id[i], a = action[i], mt = mark_type[i];
                 const bool mark = a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK;
                 if (a >= 8u || (mark && mt > 3u) || ctr - 1u >= ix.max_ctr || act > ix.max_actor) ptx_raise(H, i, 1, PTX_ERR_BAD_OP);
                 else if (a == PTX_ACT_INSERT) ptx_atomic_add(&cnt6[0], 1u);
@@ -1189,7 +1158,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_SYNC();
             PTX_FOR(i, N) {
                 uint32_t key = 0;
-                ptx_id_key(ix, op_id_wide[i], key);
+                ptx_id_key(ix, op_id[i], key);
                 const uint32_t bit = 1u << (key & 31);
                 if (ptx_atomic_or(&ix.ib[key >> 5].pre, bit) & bit) ptx_raise(H, i, 1, PTX_ERR_DUPLICATE_OP);
             }
@@ -1230,8 +1199,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             const uint32_t jmax = n > d_fused ? n : d_fused;
             const uint32_t steps = PTX_JSTEPS(jmax);
             uint32_t i[PTX_U], i_n[PTX_U], di[PTX_U], di_n[PTX_U];
-            IdT id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
-            IdT dra[PTX_U], dra_n[PTX_U];
+            uint64_t id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
+            uint64_t dra[PTX_U], dra_n[PTX_U];
 #ifdef PTX_NO_HOIST_P3A
             PTX_P3A_LOAD(0u, p3_i, p3_id, p3_ra, p3_di, p3_dra)
 #endif
@@ -1458,10 +1427,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     const uint32_t m_steps = PTX_JB_STEPS(MB.B, PTX_UM);
     uint32_t kq[PTX_UM], kq_n[PTX_UM]; /* the thread's mark ops of a step (0xFFFFFFFF: none) */
     uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
-    IdT ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
+    uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
 #if PTX_MARK_AHEAD > 1
     uint32_t kq_m[PTX_UM], i_m[PTX_UM], sa_m[PTX_UM], sb_m[PTX_UM], pl_m[PTX_UM]; /* the step in between */
-    IdT ra_m[PTX_UM], rb_m[PTX_UM];
+    uint64_t ra_m[PTX_UM], rb_m[PTX_UM];
 #endif
     /* rows of this thread's mark ops of a step (list read, then the column gathers; the payload only of the comment ops — their
      * id —, the others' is not needed before P5b, and then only the winners') */
@@ -1477,13 +1446,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
         rb_[u] = ref_b[i_[u]];                                              \
         ra_[u] = PTX_KO == 2 ? rb_[u] : ref_a[i_[u]];                       \
-        if (kNarrow) { /* both sides in one byte */                         \
-            sa_[u] = A.sides[base + i_[u]];                                 \
-            sb_[u] = 0u;                                                    \
-        } else {                                                            \
-            sa_[u] = A.side_a[base + i_[u]];                                \
-            sb_[u] = A.side_b[base + i_[u]];                                \
-        }                                                                   \
+        sa_[u] = A.side_a[base + i_[u]];                                    \
+        sb_[u] = A.side_b[base + i_[u]];                                    \
         if (pl_[u] && PTX_KO != 3) pl_[u] = payload[i_[u]];                 \
     }
 #if PTX_HOIST_MARK
@@ -1578,23 +1542,22 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #pragma unroll
         for (int u = 0; u < (int)PTX_UM; ++u)
             if (kq[u] != 0xFFFFFFFFu) {
-                const uint32_t sa_u = kNarrow ? sa[u] & 3u : sa[u], sb_u = kNarrow ? sa[u] >> 2 : sb[u]; /* narrow: both sides in the one byte loaded */
                 const uint32_t k = kq[u];
                 uint32_t lo = 0, hi = 0;
                 /* start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is
                    not in the list when the op is applied means the op never starts */
                 int js = -1;
-                if (sa_u == PTX_SIDE_BEFORE || sa_u == PTX_SIDE_AFTER) {
+                if (sa[u] == PTX_SIDE_BEFORE || sa[u] == PTX_SIDE_AFTER) {
                     js = ptx_elem_lookup(ix, ra[u]);
                     if (js >= 0 && row_of[js] >= i[u]) js = -1;
                 }
                 if (js >= 0) {
-                    const uint32_t slot_a = 2u * rnk[js] + (sa_u == PTX_SIDE_AFTER ? 1u : 0u);
+                    const uint32_t slot_a = 2u * rnk[js] + (sa[u] == PTX_SIDE_AFTER ? 1u : 0u);
                     uint32_t slot_b = 0xFFFFFFFFu; /* never reached: runs to the end of the text */
-                    if (sb_u == PTX_SIDE_BEFORE || sb_u == PTX_SIDE_AFTER) {
+                    if (sb[u] == PTX_SIDE_BEFORE || sb[u] == PTX_SIDE_AFTER) {
                         int je = ptx_elem_lookup(ix, rb[u]);
                         if (je >= 0 && row_of[je] >= i[u]) je = -1;
-                        if (je >= 0) slot_b = 2u * rnk[je] + (sb_u == PTX_SIDE_AFTER ? 1u : 0u);
+                        if (je >= 0) slot_b = 2u * rnk[je] + (sb[u] == PTX_SIDE_AFTER ? 1u : 0u);
                     }
                     /* same slot: the start test fires first and the end is never seen */
                     if (slot_b == slot_a) slot_b = 0xFFFFFFFFu;
@@ -1610,10 +1573,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 if (A.out_refs) {
                     /* both boundary slots, each on its own (the replay needs the end slot even where the op never starts) */
                     uint32_t va = 0xFFFFu, vb = 0xFFFFu;
-                    if (js >= 0) va = 2u * rnk[js] + (sa_u == PTX_SIDE_AFTER ? 1u : 0u);
-                    if (sb_u == PTX_SIDE_BEFORE || sb_u == PTX_SIDE_AFTER) {
+                    if (js >= 0) va = 2u * rnk[js] + (sa[u] == PTX_SIDE_AFTER ? 1u : 0u);
+                    if (sb[u] == PTX_SIDE_BEFORE || sb[u] == PTX_SIDE_AFTER) {
                         const int je = ptx_elem_lookup(ix, rb[u]);
-                        if (je >= 0 && row_of[je] < i[u]) vb = 2u * rnk[je] + (sb_u == PTX_SIDE_AFTER ? 1u : 0u);
+                        if (je >= 0 && row_of[je] < i[u]) vb = 2u * rnk[je] + (sb[u] == PTX_SIDE_AFTER ? 1u : 0u);
                     }
                     A.out_refs[base + i[u]] = va | (vb << 16);
                 }
@@ -1775,7 +1738,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #pragma nounroll
                 for (uint32_t st = 0; st < b_steps; ++st) {
                     uint32_t kq[PTX_UB], lo[PTX_UB], hi[PTX_UB];
-                    IdT idq[PTX_UB];
+                    uint64_t idq[PTX_UB];
 #pragma unroll
                     for (int u = 0; u < (int)PTX_UB; ++u) {
                         uint32_t k;
@@ -1796,7 +1759,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         idq[u] = 0;
                         if (l < h && PTX_TYPE_OF(k) != PTX_MARK_COMMENT) {
                             const uint32_t r = mlist[k];
-                            idq[u] = PTX_KO == 1 ? (IdT)((IdT)r << (kNarrow ? PTX_NARROW_ACTOR_BITS : 32u)) : op_id[r < N ? r : N - 1u];
+                            idq[u] = PTX_KO == 1 ? (uint64_t)r << 32 : op_id[r < N ? r : N - 1u];
                         }
                     }
 #pragma unroll
@@ -1876,10 +1839,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
 /* kManyActors: include the admission path for batches with more than four actors per document (it costs ~35
  * VGPRs, i.e. two waves per SIMD, so it lives in its own build of the kernel) */
-template <bool kManyActors, uint32_t kThreads, bool kDiag = false, bool kNarrow = false>
+template <bool kManyActors, uint32_t kThreads, bool kDiag = false>
 PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     uint32_t lds_high = 0;
-    const uint32_t status = ptx_merge_log_body<kManyActors, kThreads, kDiag, kNarrow>(A, log, lds, lds_high);
+    const uint32_t status = ptx_merge_log_body<kManyActors, kThreads, kDiag>(A, log, lds, lds_high);
     PTX_SYNC();
     ptx_write_result<kDiag>(A, log, (PtxHdr*)lds, status, lds_high);
 }

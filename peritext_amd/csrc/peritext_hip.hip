@@ -35,23 +35,18 @@
 /* One body, several register budgets: __launch_bounds__(T, W) = at most T threads per workgroup and at
  * least W waves per SIMD resident, i.e. the compiler must stay within 512/W VGPRs (MI355X_MICROARCH.md
  * "Register files"). */
-#define PTX_MERGE_KERNEL(name, T, W, MANY, KT, DIAG, NARROW)                             \
+#define PTX_MERGE_KERNEL(name, T, W, MANY, KT, DIAG)                                     \
     extern "C" __global__ void __launch_bounds__(T, W) name(PtxMergeArgs A) {          \
         extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];              \
         /* one workgroup per log (grid == n_logs): no grid-stride loop, so that nothing is hoisted \
            out of it and kept in registers for the whole kernel */                    \
-        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT, DIAG, NARROW>(A, A.log_index ? A.log_index[blockIdx.x] : blockIdx.x, ptx_lds); \
+        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT, DIAG>(A, A.log_index ? A.log_index[blockIdx.x] : blockIdx.x, ptx_lds); \
     }
-PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false, 0, false, false)     /* any launch shape (blockDim.x read at run time) */
-PTX_MERGE_KERNEL(ptx_merge_kernel_rest, 1024, 1, false, 0, false, false) /* the same kernel under another name: the second launch of a split batch (the few logs
+PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false, 0, false)     /* any launch shape (blockDim.x read at run time) */
+PTX_MERGE_KERNEL(ptx_merge_kernel_rest, 1024, 1, false, 0, false) /* the same kernel under another name: the second launch of a split batch (the few logs
                                                                     with a larger LDS window), so that per-kernel statistics of a trace keep the two apart */
-PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false, false) /* + causal admission for documents with more than three actors */
-PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, 1, true, 0, true, false)  /* + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
-/* the same four over the narrow mirror of the id / side columns (PTX_FLAG_NARROW_IDS: 32-bit ids, both sides in one byte) */
-PTX_MERGE_KERNEL(ptx_merge_kernel_n, 1024, 1, false, 0, false, true)
-PTX_MERGE_KERNEL(ptx_merge_kernel_rest_n, 1024, 1, false, 0, false, true)
-PTX_MERGE_KERNEL(ptx_merge_kernel_many_n, 1024, 1, true, 0, false, true)
-PTX_MERGE_KERNEL(ptx_merge_kernel_diag_n, 1024, 1, true, 0, true, true)
+PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false) /* + causal admission for documents with more than three actors */
+PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, 1, true, 0, true)  /* + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
 /* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
  * issue ~1 % fewer instructions but need twice the VGPRs unless PTX_U=1, so only the run-time-sized builds are shipped) */
 
@@ -169,17 +164,6 @@ __global__ void ptx_take_rows_kernel(PtxAppendCols S, const uint64_t* s_off, con
     const uint64_t sc0 = s_coff[l], dc0 = d_coff[l], nc = chgs[l];
     ptx_append_col(S.chg_hdr, sc0, nc, S.chg_hdr, 0, 0, D.chg_hdr, dc0, 1);
     ptx_append_col(S.chg_env, sc0, nc, S.chg_env, 0, 0, D.chg_env, dc0, (uint64_t)PTX_ENV_STRIDE(max_actors));
-}
-
-/* The narrow mirror of a resident batch (PTX_FLAG_NARROW_IDS): one streaming pass, 26 bytes read and 13 written per row, once per batch */
-__global__ void __launch_bounds__(256) ptx_narrow_pack_kernel(const uint64_t* op_id, const uint64_t* ref_a, const uint64_t* ref_b, const uint8_t* side_a, const uint8_t* side_b,
-                                                               uint32_t* id32, uint32_t* ra32, uint32_t* rb32, uint8_t* sides, uint64_t n_ops) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ops; i += (uint64_t)gridDim.x * blockDim.x) {
-        id32[i] = ptx_narrow_id(op_id[i]);
-        ra32[i] = ptx_narrow_id(ref_a[i]);
-        rb32[i] = ptx_narrow_id(ref_b[i]);
-        sides[i] = ptx_narrow_sides(side_a[i], side_b[i]);
-    }
 }
 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
@@ -349,7 +333,6 @@ struct ptx_ctx {
     int force_lds = 0;     /* PTX_LDS_BYTES env override (tuning) */
     int stop_after = 0;    /* PTX_STOP_AFTER env (diagnostic): truncate the kernel after a phase, for per-phase PMC deltas */
     uint32_t flags = 0;
-    bool narrow = false;   /* PTX_FLAG_NARROW_IDS (or PTX_NARROW=1/0 in the environment, tuning): resident batches carry the narrow mirror and ptx_merge reads it */
     unsigned long long* clocks = nullptr; /* device [PTX_NCLK], non-null only while ptx_merge_phase_cycles runs */
 };
 
@@ -361,9 +344,6 @@ struct ptx_dbatch {
     uint32_t* payload = nullptr;
     uint8_t *action = nullptr, *mark_type = nullptr, *side_a = nullptr, *side_b = nullptr;
     ptx_log_hdr* log_hdr = nullptr; /* always owned: provided headers are copied, missing ones computed */
-    /* narrow mirror of op_id / ref_a / ref_b / side_a / side_b (always owned; null unless the context asked for it) */
-    uint32_t *id32 = nullptr, *ra32 = nullptr, *rb32 = nullptr;
-    uint8_t* sides = nullptr;
     /* Change envelope for causal admission (owned copies; null when the batch came without it) */
     uint64_t* chg_off = nullptr;
     uint32_t* chg_hdr = nullptr;
@@ -424,35 +404,7 @@ static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t ma
 
 /* Census of a resident batch: headers (computed on the device unless the caller supplied them) and the
  * launch shape.  `have_hdr`: b->log_hdr already holds the caller's headers. */
-/* (Re)build the narrow mirror of a resident batch: every way a batch becomes resident ends in census_and_shape, which calls this */
-static ptx_status build_narrow_mirror(ptx_ctx* ctx, ptx_dbatch* b, bool on) {
-    (void)hipFree(b->id32);
-    (void)hipFree(b->ra32);
-    (void)hipFree(b->rb32);
-    (void)hipFree(b->sides);
-    b->id32 = b->ra32 = b->rb32 = nullptr;
-    b->sides = nullptr;
-    if (!on || b->n_ops == 0) return PTX_OK;
-    const uint64_t T = b->n_ops;
-    hipError_t e = hipMalloc((void**)&b->id32, T * 4 + PTX_NARROW_PAD); /* the row pass reads the ids 16 bytes at a time */
-    if (e == hipSuccess) e = hipMalloc((void**)&b->ra32, T * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->rb32, T * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->sides, T);
-    if (e == hipSuccess) {
-        const uint64_t blocks = std::min<uint64_t>((T + 255) / 256, (uint64_t)ctx->cu_count * 32);
-        hipLaunchKernelGGL(ptx_narrow_pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, b->op_id, b->ref_a, b->ref_b, b->side_a, b->side_b, b->id32, b->ra32,
-                           b->rb32, b->sides, T);
-        e = hipGetLastError();
-    }
-    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("narrow mirror: ") + hipGetErrorString(e));
-    return PTX_OK;
-}
-
 static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
-    {
-        const ptx_status st = build_narrow_mirror(ctx, b, ctx->narrow);
-        if (st) return st;
-    }
     uint32_t *shape = nullptr, *d_need = nullptr;
     uint32_t h[3] = {0, 0, 0};
     std::vector<uint32_t> need;
@@ -542,7 +494,6 @@ extern "C" {
 uint32_t ptx_abi_version(void) { return PTX_ABI_VERSION; }
 
 const char* ptx_kernel_name(void) { return "ptx_merge_kernel"; }
-uint32_t ptx_context_flags(const ptx_ctx* ctx) { return ctx ? ((ctx->flags & ~PTX_FLAG_NARROW_IDS) | (ctx->narrow ? PTX_FLAG_NARROW_IDS : 0u)) : 0u; }
 
 const char* ptx_last_error(const ptx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -563,8 +514,6 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     ctx->flags = flags;
     ctx->cu_count = prop.multiProcessorCount;
     ctx->max_lds = 160 * 1024;
-    ctx->narrow = (flags & PTX_FLAG_NARROW_IDS) != 0;
-    if (const char* s = getenv("PTX_NARROW")) ctx->narrow = atoi(s) != 0;
     if (const char* s = getenv("PTX_THREADS")) ctx->force_threads = atoi(s);
     if (const char* s = getenv("PTX_LDS_BYTES")) ctx->force_lds = atoi(s);
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -578,7 +527,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_n, (const void*)ptx_merge_kernel_rest_n, (const void*)ptx_merge_kernel_many_n, (const void*)ptx_merge_kernel_diag_n, (const void*)ptx_replay_kernel, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -636,10 +585,6 @@ void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
         (void)hipFree(b->side_b);
     }
     (void)hipFree(b->log_hdr);
-    (void)hipFree(b->id32);
-    (void)hipFree(b->ra32);
-    (void)hipFree(b->rb32);
-    (void)hipFree(b->sides);
     (void)hipFree(b->log_index);
     (void)hipFree(b->chg_off);
     (void)hipFree(b->chg_hdr);
@@ -653,15 +598,6 @@ void ptx_batch_launch_shape(const ptx_dbatch* b, uint32_t* threads, uint32_t* ld
     if (lds_bytes) *lds_bytes = b ? (b->n_main ? b->lds_main : b->lds_bytes) : 0;
 }
 uint64_t ptx_batch_n_ops(const ptx_dbatch* b) { return b ? b->n_ops : 0; }
-
-ptx_status ptx_batch_narrow_mirror(ptx_ctx* ctx, ptx_dbatch* b, int on) {
-    if (!ctx || !b) return PTX_ERR_INVALID_ARG;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); /* no launch that reads the mirror is left in flight */
-    if (ctx->side) PTX_HIP(ctx, hipStreamSynchronize(ctx->side));
-    return build_narrow_mirror(ctx, b, on != 0);
-}
-int ptx_batch_has_narrow_mirror(const ptx_dbatch* b) { return b && b->id32 ? 1 : 0; }
 uint64_t ptx_batch_n_changes(const ptx_dbatch* b) { return b && b->chg_off ? b->n_changes : 0; }
 
 ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t copies, ptx_dbatch** out) {
@@ -948,11 +884,6 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.mark_type = b->mark_type;
     A.side_a = b->side_a;
     A.side_b = b->side_b;
-    A.id32 = b->id32;
-    A.ra32 = b->ra32;
-    A.rb32 = b->rb32;
-    A.sides = b->sides;
-    const bool narrow = b->id32 != nullptr; /* the batch carries the mirror: the kernels that read it */
     A.log_hdr = b->log_hdr;
     const bool admit = b->chg_off && !(ctx->flags & PTX_FLAG_NO_ADMISSION);
     A.chg_off = admit ? b->chg_off : nullptr;
@@ -991,13 +922,13 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
         }
         hipStream_t st = part && fork ? ctx->side : ctx->stream;
         if (diag)
-            hipLaunchKernelGGL(narrow ? ptx_merge_kernel_diag_n : ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), lds, st, A);
+            hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), lds, st, A);
         else if (admit && b->max_actors > 3)
-            hipLaunchKernelGGL(narrow ? ptx_merge_kernel_many_n : ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);
+            hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);
         else if (part)
-            hipLaunchKernelGGL(narrow ? ptx_merge_kernel_rest_n : ptx_merge_kernel_rest, dim3(grid), dim3(b->threads), lds, st, A);
+            hipLaunchKernelGGL(ptx_merge_kernel_rest, dim3(grid), dim3(b->threads), lds, st, A);
         else
-            hipLaunchKernelGGL(narrow ? ptx_merge_kernel_n : ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, st, A);
+            hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, st, A);
     }
     if (fork) {
         (void)hipEventRecord(ctx->ev_join, ctx->side);

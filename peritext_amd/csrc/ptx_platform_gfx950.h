@@ -361,25 +361,15 @@ typedef uint32_t ptx_u32_a1 __attribute__((aligned(1)));
 /* the action / mark_type bytes of a thread's PTX_U1 consecutive rows from r0_ on, one byte each in dst_ (uses N): ONE unaligned
  * 4-byte load; the library pads its copies of the byte columns by PTX_BYTE_PAD */
 /* the ids of a thread's PTX_U1 consecutive rows, all of which exist: one address, loads of 16 + 8 bytes */
-PTX_DEV void ptx_p1_ids(uint64_t* dst, const uint64_t* p) {
-    static_assert(PTX_U1 == 3, "16 + 8 bytes");
-    const ptx_u64x2 q = PTX_STREAM_LOAD((const ptx_u64x2_a8*)p);
-    dst[0] = q.x;
-    dst[1] = q.y;
-    dst[2] = PTX_STREAM_LOAD(p + 2);
-}
-/* the narrow mirror's ids: 12 bytes per lane from one address.  Written as ONE 16-byte vector load (scalar loads get merged with the clamped
- * path's and come out as three instructions with three addresses); the compiler may narrow it to global_load_dwordx3.  The fourth dword
- * belongs to the next lane's first row: past the last row of the batch it is the PTX_NARROW_PAD bytes the library allocates behind the column. */
-#define PTX_NARROW_PAD 16u
-PTX_DEV void ptx_p1_ids(uint32_t* dst, const uint32_t* p) {
-    static_assert(PTX_U1 == 3, "12 of 16 bytes");
-    const ptx_u32x4 q = PTX_STREAM_LOAD((const ptx_u32x4_a4*)p);
-    dst[0] = q.x;
-    dst[1] = q.y;
-    dst[2] = q.z;
-}
-#define PTX_P1_IDS(dst_, ptr_) ptx_p1_ids(dst_, ptr_);
+#define PTX_P1_IDS(dst_, ptr_)                                                         \
+    {                                                                                  \
+        static_assert(PTX_U1 == 3, "16 + 8 bytes");                                    \
+        const uint64_t* p_ = (ptr_);                                                   \
+        const ptx_u64x2 q_ = PTX_STREAM_LOAD((const ptx_u64x2_a8*)p_);                 \
+        dst_[0] = q_.x;                                                                \
+        dst_[1] = q_.y;                                                                \
+        dst_[2] = PTX_STREAM_LOAD(p_ + 2);                                             \
+    }
 #define PTX_P1_BYTES(col_, r0_, dst_) dst_ = PTX_STREAM_LOAD((const ptx_u32_a1*)(col_ + ((r0_) < N ? (r0_) : N - 1u)));
 
 /* ---- gen_core.h / change_core.h: ONE wave per workgroup ---- */

@@ -341,19 +341,8 @@ class Engine:
         self.lib.ptx_batch_launch_shape(dbatch, C.byref(t), C.byref(l))
         return int(t.value), int(l.value)
 
-    def narrow_mirror(self, dbatch, on=True):
-        """Build (or drop) the narrow mirror of a resident batch's id / side columns; ptx_merge reads the mirror of a batch that has one."""
-        self._check(self.lib.ptx_batch_narrow_mirror(self.ctx, dbatch, 1 if on else 0))
-
-    def has_narrow_mirror(self, dbatch):
-        return bool(self.lib.ptx_batch_has_narrow_mirror(dbatch))
-
     def max_ops_per_log(self):
         return int(self.lib.ptx_max_ops_per_log(self.ctx))
 
     def kernel_name(self):
-        return self.lib.ptx_kernel_name().decode() + ("_n" if self.flags() & abi.FLAG_NARROW_IDS else "")
-
-    def flags(self):
-        """The flags in effect (ptx_create's, after the PTX_NARROW environment override)."""
-        return int(self.lib.ptx_context_flags(self.ctx))
+        return self.lib.ptx_kernel_name().decode()

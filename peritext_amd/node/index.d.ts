@@ -102,11 +102,7 @@ export type JsonValue = string | number | boolean | null | JsonValue[] | { [key:
 export interface WireRootMaps { entryOff: BigUint64Array; logs: Uint32Array; entries: Uint32Array }
 
 export class MergeEngine {
-    /** ptx_create flags (include/peritext_hip.h) */
-    static readonly FLAG_NO_ELEM_RANK: 1
-    static readonly FLAG_NO_ADMISSION: 2
-    static readonly FLAG_NARROW_IDS: 4
-    constructor(opts?: { device?: number; libPath?: string; addonPath?: string; flags?: number })
+    constructor(opts?: { device?: number; libPath?: string; addonPath?: string })
     close(): void
     applyMaterialize(batch: WireBatch, wantPatches?: boolean): WireResult
     /** docs -> replica logs -> changes in application order  =>  spans per replica log */

@@ -575,12 +575,12 @@ function decodePatches(batch, res, log) {
 }
 
 class MergeEngine {
-    /** opts: {device?: number, libPath?: string, addonPath?: string, flags?: number (PTX_FLAG_*, e.g. MergeEngine.FLAG_NARROW_IDS)} */
+    /** opts: {device?: number, libPath?: string, addonPath?: string} */
     constructor(opts) {
         const o = opts || {}
         this.addon = require(o.addonPath || path.join(__dirname, "peritext_node.node"))
         this.addon.open(o.libPath || path.join(__dirname, "..", "lib", "libperitext_hip.so"))
-        this.ctx = this.addon.create(o.device || 0, (o.flags || 0) >>> 0) /* throws without a gfx950 device: there is no CPU fallback */
+        this.ctx = this.addon.create(o.device || 0, 0) /* throws without a gfx950 device: there is no CPU fallback */
         this.pending = []
     }
     close() {
@@ -863,10 +863,5 @@ class MergeEngine {
             }
     }
 }
-
-/* ptx_create flags (include/peritext_hip.h) */
-MergeEngine.FLAG_NO_ELEM_RANK = 1
-MergeEngine.FLAG_NO_ADMISSION = 2
-MergeEngine.FLAG_NARROW_IDS = 4 /* resident batches carry a 32-bit mirror of the id columns and the merge reads it */
 
 module.exports = { MergeEngine, encodeDocs, encodeInputOps, packEnvelope, unpackEnvelope, decodeSpans, decodePatches, decodeChanges, decodeRoot, MAPV, prosemirrorDocFromSpans, PATCH, census, ACT, IN, MARK_NAMES, SIDE_NAMES, ATTR, STATUS_MESSAGES, ROOT, HEAD }

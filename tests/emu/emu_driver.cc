@@ -33,18 +33,6 @@ static void ptx_emu_lds_fill(uint8_t* lds, size_t bytes) {
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
                           uint32_t lds_bytes, int reverse, int admission, uint32_t* refs);
 
-/* 1: every ptx_emu_merge* call runs the kNarrow build of the kernel body over a narrow mirror made here the way the library's
- * ptx_narrow_pack_kernel makes it (PTX_FLAG_NARROW_IDS); PTX_EMU_NARROW=1 in the environment sets the initial value */
-static int ptx_emu_narrow = -1;
-extern "C" void ptx_emu_set_narrow(int on) { ptx_emu_narrow = on ? 1 : 0; }
-extern "C" int ptx_emu_get_narrow() {
-    if (ptx_emu_narrow < 0) {
-        const char* e = getenv("PTX_EMU_NARROW");
-        ptx_emu_narrow = e && atoi(e) ? 1 : 0;
-    }
-    return ptx_emu_narrow;
-}
-
 extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans,
                              ptx_cinterval* cints, uint32_t* rank, uint32_t lds_bytes, int reverse) {
     return emu_merge_impl(b, res, values, spans, cints, rank, lds_bytes, reverse, 0, nullptr);
@@ -73,27 +61,6 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     A.mark_type = b->mark_type;
     A.side_a = b->side_a;
     A.side_b = b->side_b;
-    A.id32 = A.ra32 = A.rb32 = nullptr;
-    A.sides = nullptr;
-    const bool narrow = ptx_emu_get_narrow() != 0;
-    uint32_t* mirror = nullptr;
-    uint8_t* msides = nullptr;
-    if (narrow) {
-        const uint64_t T = b->n_logs ? b->log_off[b->n_logs] : 0;
-        mirror = (uint32_t*)malloc((size_t)(3 * T + 1) * 4);
-        msides = (uint8_t*)malloc((size_t)T + 1);
-        if (!mirror || !msides) return 1;
-        for (uint64_t i = 0; i < T; ++i) {
-            mirror[i] = ptx_narrow_id(b->op_id[i]);
-            mirror[T + i] = ptx_narrow_id(b->ref_a[i]);
-            mirror[2 * T + i] = ptx_narrow_id(b->ref_b[i]);
-            msides[i] = ptx_narrow_sides(b->side_a[i], b->side_b[i]);
-        }
-        A.id32 = mirror;
-        A.ra32 = mirror + T;
-        A.rb32 = mirror + 2 * T;
-        A.sides = msides;
-    }
     A.chg_off = admission ? b->chg_off : nullptr;
     A.chg_hdr = b->chg_hdr;
     A.chg_env = b->chg_env;
@@ -126,14 +93,11 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     ptx_emu_reverse = reverse;
     for (uint32_t l = 0; l < b->n_logs; ++l) {
         ptx_emu_lds_fill(lds, lds_bytes); /* LDS is not zero-initialised on the GPU either */
-        if (narrow) ptx_merge_log<true, 0, false, true>(A, l, lds);
-        else ptx_merge_log<true, 0>(A, l, lds);
+        ptx_merge_log<true, 0>(A, l, lds);
     }
     ptx_emu_lds_fill(lds, 0);
     free(lds);
     free(hdr);
-    free(mirror);
-    free(msides);
     return 0;
 }
 
