@@ -389,6 +389,7 @@ def main():
                 "traffic": None if traffic is None else traffic["hbm_bytes_per_launch"],
                 "traffic_over_algorithmic": None if traffic is None else traffic["hbm_bytes_per_launch"] / alg_bytes,
                 "traffic_source": None if traffic is None else traffic.get("source"),
+                "traffic_note": None if traffic is None else traffic.get("note"),
                 "kernel": eng.kernel_name(),
                 "kernel_ms_avg": k_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,

@@ -69,6 +69,13 @@
 #ifndef PTX_HOIST_MARK
 #define PTX_HOIST_MARK 1 /* P5a's first gathers are issued ahead of P4 and the values pass (1 % faster; with the marks visited in row order it costs no extra read requests) */
 #endif
+#ifndef PTX_PARK_MLIST
+#define PTX_PARK_MLIST 1 /* 1: the mark list (2 bytes per mark op) is not kept in LDS from P1 to P5: it is built in P1's scratch, PARKED in the log's own span rows
+                            in HBM (unused until P6) while the causal tree is resolved, and read back when P5 starts — 3.1 KB less at the LDS high-water mark of a
+                            config-4 log (22.6 -> 19.7 KB for the largest log of the 64K-doc batch: EIGHT logs share a CU instead of seven) for one coalesced
+                            store + load of those bytes.  Measured same-call against the build without it: 9.45 against 9.86 ms per 64K-doc launch
+                            (profiles/r02_ab_*); 0 = the list stays in LDS */
+#endif
 #ifndef PTX_P1_WIDE
 #define PTX_P1_WIDE 1 /* P1 reads the ids of a thread's three rows from one address (16 + 8 bytes) where all of them exist */
 #endif
@@ -273,10 +280,11 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     (void)N;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
     const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P5a */
-    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(2 * (K + 1)) + ptx_a16(4 * (K / 32 + 1)) + elem;
+    const uint64_t mlist_b = ptx_a16(2 * (K + 1)), mpark = PTX_PARK_MLIST ? mlist_b : 0; /* parked: part of P1's and P5's scratch instead of the persistent state */
+    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + (mlist_b - mpark) + ptx_a16(4 * (K / 32 + 1)) + elem;
     const uint64_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
     const uint64_t lists = ptx_a16(2 * (n + 1)) + ptx_a16(2 * l_len);
-    const uint64_t p1 = lists + 16; /* + the dump of the unlisted rows */
+    const uint64_t p1 = lists + 16 + mpark; /* + the dump of the unlisted rows */
     const uint64_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
     const uint64_t p3 = lists + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
     const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0;
@@ -285,7 +293,7 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     const uint64_t trees1 = n > T4 ? ptx_overflow3(elem, 4 * 2 * T1, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
     uint64_t tail = comments > trees4 ? comments : trees4;
     if (trees1 > tail) tail = trees1;
-    const uint64_t p5 = ptx_a16(8 * (nwe + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (nwe + 1)) + tail;
+    const uint64_t p5 = mpark + ptx_a16(8 * (nwe + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (nwe + 1)) + tail;
     uint64_t m = p1 > p3 ? p1 : p3;
     if (p5 > m) m = p5;
     return persist + m;
@@ -931,7 +939,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
     const uint32_t nw = (keyspace + 31) / 32;
     const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
+#if PTX_PARK_MLIST
+    uint16_t* mlist = nullptr; /* allocated in P1's scratch, parked in HBM during P3 / P4, allocated again (and read back) when P5 starts */
+#else
     uint16_t* mlist = ptx_alloc<uint16_t>(bp, K + 1); /* rows of the mark ops, grouped by type; [K] = spare slot */
+#endif
     uint32_t* maddbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 1); /* mark op k is an addMark (the tail phases need no look back at `action`) */
     /* element-side state: dead once the mark intervals are known (P5a), then reused as scratch of the tail phases */
     const uint32_t elem_lds = bp.off;
@@ -1022,6 +1034,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * land in a four-entry dump. */
         uint16_t* const lds16 = (uint16_t*)lds;
         uint16_t* dump = ptx_alloc<uint16_t>(bp, 4);
+#if PTX_PARK_MLIST
+        mlist = ptx_alloc<uint16_t>(bp, K + 1);
+#endif
         PTX_BAIL_CAPACITY();
         const uint32_t i_at = (uint32_t)(ilist - lds16), d_at = (uint32_t)(dlist - lds16), m_at = (uint32_t)(mlist - lds16), dump_at = (uint32_t)(dump - lds16);
         const uint32_t k_delta = (uint32_t)(klist - ilist);   /* the key of an insert sits this far behind its list entry */
@@ -1111,6 +1126,17 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_P1_LOAD
         if (err4 != 0u || ctr_hi >= ix.max_ctr || act_hi > ix.max_actor) ptx_atomic_or(&H->cur[7], 1u);
         PTX_SYNC();
+#if PTX_PARK_MLIST
+        /* the mark list is complete: park it in the log's span rows (8 bytes per row of the log, written only by P6; K <= N).  Every thread reads back
+         * in P5 exactly the words it stores here (the same PTX_FOR partition), so nothing but its own program order is relied on.  A header that
+         * understates the mark rows parks junk: the census check below rejects that log before anything reads it. */
+        {
+            uint32_t* park = (uint32_t*)(A.out_spans + base);
+            const uint32_t* src = (const uint32_t*)mlist;
+            PTX_FOR(w, K >> 1) park[w] = src[w];
+            if (K & 1u) PTX_LEADER { ((uint16_t*)park)[K - 1u] = mlist[K - 1u]; }
+        }
+#endif
 #ifndef PTX_NO_HOIST_P3A
         PTX_P3A_LOAD(0u, p3_i, p3_id, p3_ra, p3_di, p3_dra) /* the lists are complete: P3a's first step is on its way */
 #endif
@@ -1420,6 +1446,17 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
     uint16_t* rnk = par;
     bp.off = mark_lds; /* release the tree scratch */
+#if PTX_PARK_MLIST
+    mlist = ptx_alloc<uint16_t>(bp, K + 1);
+    PTX_BAIL_CAPACITY();
+    {
+        const uint32_t* park = (const uint32_t*)(A.out_spans + base);
+        uint32_t* dst = (uint32_t*)mlist;
+        PTX_FOR(w, K >> 1) dst[w] = park[w];
+        if (K & 1u) PTX_LEADER { mlist[K - 1u] = ((const uint16_t*)park)[K - 1u]; }
+    }
+    PTX_SYNC();
+#endif
     PTX_STAMP(5);
 
     /* P5a's loads: the first step's gathers are issued here, ahead of P4 and the values pass (PTX_HOIST_MARK) */

@@ -465,7 +465,8 @@ def test_lds_bound_covers_the_high_water_mark(name):
         need = lib.ptx_emu_lds_need(int(batch.log_off[log + 1] - batch.log_off[log]), int(h["n_ins"]), int(h["n_del"]), int(h["n_mark"].sum()),
                                     int(h["n_mark"][2]), (int(h["max_counter"]) + 1) * (int(h["max_actor"]) + 1), int(h["n_comment_ids"]))
         used = int(res.logs["reserved"][log][0])
-        assert used <= need <= used + 6144, (log, used, need)  # slack = the LWW trees sized for V = n
+        parked = (2 * (int(h["n_mark"].sum()) + 1) + 15) & ~15  # the mark list, parked in HBM between P1 and P5, counts in both phases' scratch
+        assert used <= need <= used + 6144 + parked, (log, used, need)  # slack = the LWW trees sized for V = n
 
 
 @pytest.mark.parametrize("reverse", [0, 1, 2])
