@@ -123,6 +123,20 @@ def cpu_baseline(docs_logs, budget_s, procs):
     }
 
 
+def extra_legs(args, n_docs, first_doc, local, iters):
+    """Extra legs (N = 1 only; none of them is `value`), run by tools/bench_extras.py in a process of its own so that nothing an experimental
+    build does can cost the bench line: the patch-stream replay rate and the SAME workload under the experimental builds
+    peritext_amd/lib/exp_*.so (__graft_entry__.EXPERIMENTS) and other launch shapes of the product build, each compared log for log with the
+    product build's results in that process."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_extras.py"), "--config", args.config, "--docs", str(n_docs), "--first-doc", str(first_doc), "--seed", str(args.seed),
+           "--list-cap", str(args.list_cap), "--iters", str(iters), "--device", str(local)] + (["--ops", str(args.ops)] if args.ops else []) + (["--no-admission"] if args.no_admission else [])
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as ex:  # noqa: BLE001
+        return {"error": str(ex)[:300]}
+
+
 def load_traffic(n_logs, rows):
     """PMC-measured HBM bytes per launch of this command, if profiles/ holds them for this very workload."""
     p = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
@@ -152,6 +166,7 @@ def main():
     ap.add_argument("--no-admission", action="store_true", help="skip applyChange's causal admission (seq/deps) in the timed path")
     ap.add_argument("--sustain-s", type=float, default=5.0, help="extra leg: back-to-back steps for at least this many seconds (clocks / thermals)")
     ap.add_argument("--host-sync-step", action="store_true", help="the round-1 step: engine on its own stream, a host-side sync between merge and digest check")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (patch-stream replay rate, experimental builds / launch shapes on the same workload)")
     ap.add_argument("--list-cap", type=int, default=2048, help="list elements per replica the generator holds on chip")
     args = ap.parse_args()
 
@@ -346,6 +361,10 @@ def main():
             ms_noadm = eng2.merge_timed(db, dr, it) / it
             eng2.close()
         traffic = load_traffic(n_logs, rows)
+        extras = None
+        if world == 1 and not args.no_extras:
+            log("extra legs")
+            extras = extra_legs(args, n_docs, first_doc, local, max(2, args.steps // 2))
         threads, lds = eng.launch_shape(db)
         out = {
             "metric": "CRDT ops applied+materialised per second (whole node)",
@@ -400,6 +419,7 @@ def main():
             "without_admission": None if ms_noadm is None else {"kernel_ms": ms_noadm, "ops_per_s_1gpu": ops_per_step / (ms_noadm * 1e-3),
                                                                 "hbm_GBps": alg_bytes / (ms_noadm * 1e-3) / 1e9, "frac": alg_bytes / (ms_noadm * 1e-3) / HBM_PEAK},
             "sustained": sustained,
+            "extras": extras,  # tools/bench_extras.py: patch-stream replay rate; experimental builds / launch shapes on the same workload (not `value`)
             "parity": parity,
             "launch": {"threads_per_log": threads, "lds_bytes_per_log": lds},
             "host": {"cores": cores, "gen_s": t_gen},

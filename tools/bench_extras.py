@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""The extra legs of bench.py, in a process of their own (no torch; nothing here is the bench's `value`):
+  patch_replay  ptx_replay_patches on 2 048 documents of the bench's config: ops replayed per second (kernel time measured inside the library);
+  experiments   the bench's workload (same generator arguments, so the same documents) under the product build, then under every experimental build
+                peritext_amd/lib/exp_*.so (__graft_entry__.EXPERIMENTS) and under other launch shapes of the product build (PTX_THREADS): kernel ms per
+                launch (HIP events on the engine's stream), and whether statuses / digests / row counts of EVERY log equal the product build's.
+Every leg records its own failure instead of raising.  One JSON line on stdout.
+    python tools/bench_extras.py --config config4 --docs 65536 [--iters 10]"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from peritext_amd import abi, workloads  # noqa: E402
+from peritext_amd.engine import Engine  # noqa: E402
+
+T0 = time.time()
+
+
+def say(msg):
+    print("[extras %6.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="config4")
+    ap.add_argument("--docs", type=int, default=65536)
+    ap.add_argument("--first-doc", type=int, default=0)
+    ap.add_argument("--ops", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--list-cap", type=int, default=2048)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--no-admission", action="store_true")
+    ap.add_argument("--threads", default="128,256", help="launch shapes of the product build to time beside its own choice")
+    args = ap.parse_args()
+    g = workloads.gen_config(args.config, ops=args.ops)
+    gen_args = (g["replicas"], g["ops_per_log"], g["mix"], g["mark_types"])
+    out = {"patch_replay": None, "experiments": None}
+
+    try:
+        with Engine(args.device) as e:  # with elem_rank: the replay reads it
+            docs = min(2048, args.docs)
+            db, _ = e.generate(*gen_args, docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
+            dr = e.alloc_result(db)
+            e.merge(db, dr)
+            e.sync()
+            pat = e.replay_patches(db, dr)
+            ops = e.n_logs(db) * g["ops_per_log"]
+            n_pat = int(pat.logs["n_patches"].sum())
+            out["patch_replay"] = {"docs": docs, "ops": ops, "patches": n_pat, "kernel_ms": pat.kernel_ms, "launches": pat.launches,
+                                   "every_log_has_a_stream": bool(int(pat.logs["status"].max()) == 0),
+                                   "ops_per_s": ops / pat.kernel_ms * 1e3, "patches_per_s": n_pat / pat.kernel_ms * 1e3}
+            e.free_result(dr)
+            e.free_batch(db)
+    except Exception as ex:  # noqa: BLE001
+        out["patch_replay"] = {"error": str(ex)[:300]}
+    say("patch_replay %s" % json.dumps(out["patch_replay"]))
+
+    flags = abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0)
+    variants = [("product build", None, 0)]
+    variants += [(os.path.basename(p)[:-3], p, 0) for p in sorted(glob.glob(os.path.join(ROOT, "peritext_amd", "lib", "exp_*.so")))]
+    variants += [("product build, PTX_THREADS=%d" % int(t), None, int(t)) for t in args.threads.split(",") if t]
+    rows, ref = [], None
+    for name, lib, threads in variants:
+        row = {"name": name}
+        try:
+            if threads:
+                os.environ["PTX_THREADS"] = str(threads)
+            try:
+                e = Engine(args.device, flags=flags, lib_path=lib)
+            finally:
+                os.environ.pop("PTX_THREADS", None)
+            db, _ = e.generate(*gen_args, args.docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
+            dr = e.alloc_result(db)
+            e.merge(db, dr)
+            e.sync()
+            row["kernel_ms"] = e.merge_timed(db, dr, args.iters) / args.iters
+            row["launch"] = list(e.launch_shape(db))
+            lo = e.download_logs(dr, e.n_logs(db))
+            if ref is None:
+                ref = lo
+                row["every_log_ok"] = bool(int(lo["status"].max()) == 0)
+            else:
+                row["identical_results"] = bool((lo["status"] == ref["status"]).all() and (lo["digest"] == ref["digest"]).all() and (lo["n_spans"] == ref["n_spans"]).all()
+                                                and (lo["n_visible"] == ref["n_visible"]).all())
+            e.free_result(dr)
+            e.free_batch(db)
+            e.close()
+        except Exception as ex:  # noqa: BLE001
+            row["error"] = str(ex)[:300]
+        rows.append(row)
+        say(json.dumps(row))
+        if ref is None:
+            break  # nothing to compare the variants with
+    out["experiments"] = {"workload": "%s, %d docs (the bench's own documents)" % (args.config, args.docs), "launches_each": args.iters, "same_box_same_call": True, "variants": rows}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
