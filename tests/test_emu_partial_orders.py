@@ -1,0 +1,72 @@
+"""Differential fuzz over replica logs the generator never makes: for every PTXGEN document, the union of its replicas' changes is re-dealt into
+random CAUSALLY CLOSED SUBSETS in random linear extensions of the causal order (any change whose seq is next for its actor and whose deps are
+satisfied may come next) — replicas that have seen different parts of the history, in orders no replica of the generator applied them in.
+Every such log is a valid input of applyChange (micromerge.ts:499-511); the oracle replays it and the kernel logic (host emulation, causal
+admission on) must give the same document, raw rows and digest.  The reference's own fuzzer (test/fuzz.ts) only ever syncs whole queues."""
+import os
+import random
+
+import pytest
+
+import helpers as H
+from peritext_amd import wire
+
+pytestmark = [pytest.mark.skipif(not os.path.exists(H.EMU_LIB), reason="tests/emu/libperitext_emu.so not built (run __graft_entry__.build())"),
+              pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")]
+
+
+def _redeal(logs, rng, n_logs):
+    """n_logs random causally closed sub-logs of the document whose replicas' logs are `logs`."""
+    by_key = {}
+    for log in logs:
+        for ch in log:
+            by_key[(ch["actor"], ch["seq"])] = ch
+    changes = list(by_key.values())
+    out = []
+    for _ in range(n_logs):
+        want = rng.randint(1, len(changes))
+        clock, log, pool = {}, [], list(changes)
+        while len(log) < want:
+            ready = [c for c in pool if c["seq"] == clock.get(c["actor"], 0) + 1 and all(clock.get(a, 0) >= s for a, s in c["deps"].items())]
+            if not ready:
+                break
+            c = rng.choice(ready)
+            pool.remove(c)
+            clock[c["actor"]] = c["seq"]
+            log.append(c)
+        out.append(log)
+    return out
+
+
+@pytest.mark.parametrize("config,docs,ops,replicas,seed", [("mini", 6, None, None, 71), ("rich", 3, 160, None, 72), ("config4", 2, 220, None, 73), ("rich", 2, 120, 4, 74)])
+def test_random_causally_closed_sublogs_in_random_causal_orders(config, docs, ops, replicas, seed):
+    gen = H.oracle_gen(config, docs=docs, seed=seed, ops=ops, replicas=replicas)
+    rng = random.Random(seed)
+    dealt = [_redeal(d["logs"], rng, 8) for d in gen["docs"]]
+    # the makeList change must be in every log for the text path to exist: logs without it are documents without a text list, skipped here
+    dealt = [[log for log in logs if any(op["action"] == "makeList" for ch in log for op in ch["ops"])] for logs in dealt]
+    assert sum(len(logs) for logs in dealt) >= 4 * docs
+    expected = H.oracle_apply(dealt)
+    batch = wire.encode_docs(dealt)
+    res = H.emu_merge(batch, admission=True)
+    log = 0
+    for logs, exps in zip(dealt, expected):
+        for exp in exps:
+            assert "error" not in exp, exp.get("error")
+            H.check_log(batch, res, log, exp)
+            log += 1
+    assert H.emu_exact_walks() >= 0
+
+
+def test_patch_streams_and_cursors_of_redealt_logs():
+    """The same re-dealt logs through the patch-stream replay (every applyChange's Patch[]) and the cursor resolution, against the oracle."""
+    gen = H.oracle_gen("rich", docs=3, seed=81, ops=140)
+    rng = random.Random(81)
+    dealt = [[log for log in _redeal(d["logs"], rng, 6) if any(op["action"] == "makeList" for ch in log for op in ch["ops"])] for d in gen["docs"]]
+    expected = H.oracle_apply(dealt, patches=True, cursors=True)
+    batch = wire.encode_docs(dealt)
+    res = H.emu_merge(batch, admission=True)
+    assert H.check_patch_streams(batch, H.emu_replay(batch, res), expected) == batch.n_logs
+    q_log, q_kind, q_arg, want = H.cursor_queries(batch, expected)
+    out, status = H.emu_cursors(batch, res, q_log, q_kind, q_arg)
+    H.check_cursor_answers(q_kind, want, out, status)
