@@ -390,6 +390,31 @@ def unsynced_docs():
 
 
 
+def redeal_logs(logs, rng, n_logs):
+    """n_logs random causally closed sub-logs (random linear extensions of the causal order) of the document whose replicas' logs are `logs`;
+    logs that do not hold the makeList change (no text list yet) are left out."""
+    by_key = {}
+    for log in logs:
+        for ch in log:
+            by_key[(ch["actor"], ch["seq"])] = ch
+    changes = list(by_key.values())
+    out = []
+    for _ in range(n_logs):
+        want = rng.randint(1, len(changes))
+        clock, log, pool = {}, [], list(changes)
+        while len(log) < want:
+            ready = [c for c in pool if c["seq"] == clock.get(c["actor"], 0) + 1 and all(clock.get(a, 0) >= s for a, s in c["deps"].items())]
+            if not ready:
+                break
+            c = rng.choice(ready)
+            pool.remove(c)
+            clock[c["actor"]] = c["seq"]
+            log.append(c)
+        if any(op["action"] == "makeList" for ch in log for op in ch["ops"]):
+            out.append(log)
+    return out
+
+
 def more_deletes_than_inserts_docs():
     """Logs with more deletes than inserts + 1 (the same chars deleted again and again, which the reference allows,
     micromerge.ts:693): [all fine -> "!", a late delete whose target is only inserted by the NEXT op, a late delete of an unknown

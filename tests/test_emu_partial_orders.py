@@ -15,27 +15,7 @@ pytestmark = [pytest.mark.skipif(not os.path.exists(H.EMU_LIB), reason="tests/em
               pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")]
 
 
-def _redeal(logs, rng, n_logs):
-    """n_logs random causally closed sub-logs of the document whose replicas' logs are `logs`."""
-    by_key = {}
-    for log in logs:
-        for ch in log:
-            by_key[(ch["actor"], ch["seq"])] = ch
-    changes = list(by_key.values())
-    out = []
-    for _ in range(n_logs):
-        want = rng.randint(1, len(changes))
-        clock, log, pool = {}, [], list(changes)
-        while len(log) < want:
-            ready = [c for c in pool if c["seq"] == clock.get(c["actor"], 0) + 1 and all(clock.get(a, 0) >= s for a, s in c["deps"].items())]
-            if not ready:
-                break
-            c = rng.choice(ready)
-            pool.remove(c)
-            clock[c["actor"]] = c["seq"]
-            log.append(c)
-        out.append(log)
-    return out
+_redeal = H.redeal_logs
 
 
 @pytest.mark.parametrize("config,docs,ops,replicas,seed", [("mini", 6, None, None, 71), ("rich", 3, 160, None, 72), ("config4", 2, 220, None, 73), ("rich", 2, 120, 4, 74)])

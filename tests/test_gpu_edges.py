@@ -189,6 +189,41 @@ def test_cursors_resolved_on_the_device(eng, golden):
         eng.free_batch(db)
 
 
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+@pytest.mark.parametrize("config,docs,ops,replicas,seed", [("mini", 6, None, None, 71), ("rich", 3, 160, None, 72), ("config4", 2, 220, None, 73), ("rich", 2, 120, 4, 74)])
+def test_redealt_logs_against_the_oracle(eng, config, docs, ops, replicas, seed):
+    """GPU twin of test_emu_partial_orders.py: random causally closed subsets of a document's changes in random linear extensions of the
+    causal order — valid inputs of applyChange no replica of the generator ever applied — merged (causal admission on), replayed into patch
+    streams and queried for cursors on the device, all against a live oracle replay."""
+    import random
+
+    gen = H.oracle_gen(config, docs=docs, seed=seed, ops=ops, replicas=replicas)
+    rng = random.Random(seed)
+    dealt = [H.redeal_logs(d["logs"], rng, 8) for d in gen["docs"]]
+    expected = H.oracle_apply(dealt, patches=True, cursors=True)
+    batch = wire.encode_docs(dealt)
+    db = eng.upload(batch)
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        eng.sync()
+        res = eng.download(db, dr)
+        log = 0
+        for exps in expected:
+            for exp in exps:
+                assert "error" not in exp, exp.get("error")
+                H.check_log(batch, res, log, exp)
+                log += 1
+        assert log == batch.n_logs >= 4 * docs
+        assert H.check_patch_streams(batch, eng.replay_patches(db, dr), expected) == batch.n_logs
+        q_log, q_kind, q_arg, want = H.cursor_queries(batch, expected)
+        out, status = eng.resolve_cursors(db, dr, q_log, q_kind, q_arg)
+        H.check_cursor_answers(q_kind, want, out, status)
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
+
+
 def test_ten_actor_document_string_order(eng):
     """a1: "7@doc10" < "7@doc2" (compareOpIds compares actor STRINGS, micromerge.ts:826): a 10-replica fixture made by the
     reference; ranks follow the string order and the many-actor admission build runs."""
