@@ -81,6 +81,16 @@ def main():
             e.sync()
             row["kernel_ms"] = e.merge_timed(db, dr, args.iters) / args.iters
             row["launch"] = list(e.launch_shape(db))
+            if ref is None:  # the product build: where a log's residency goes (thread-0 cycle stamps of the diagnostic build of the same kernel body)
+                try:
+                    cyc = e.phase_cycles(db, dr)
+                    names = ["P0+P1 admission+rows", "P2", "P3a+P3b buckets", "P3c child order", "P3d tour+rank", "P4 tombstones", "P5a values+intervals", "P5c comments",
+                             "P5b+P6 LWW trees+spans", "P6 tail"]
+                    row["phase_cycles_per_log"] = {(names[k] if k < len(names) else str(k)): round(cyc[k] / e.n_logs(db)) for k in range(len(cyc)) if cyc[k]}
+                    e.merge(db, dr)  # the diagnostic launch wrote the same rows; run the product kernel once more before they are read
+                    e.sync()
+                except Exception as ex:  # noqa: BLE001
+                    row["phase_cycles_per_log"] = {"error": str(ex)[:200]}
             lo = e.download_logs(dr, e.n_logs(db))
             if ref is None:
                 ref = lo
