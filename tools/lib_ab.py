@@ -3,7 +3,10 @@
   1. parity of build B: every committed PTXGEN fixture against the oracle's output (tests/helpers.check_generated);
   2. the same generated batch resident under both builds, ptx_merge timed with HIP events on each engine's stream, alternating A / B;
      statuses, digests and row counts of every log compared between the builds.
-    python tools/lib_ab.py --b peritext_amd/lib/exp_park.so --docs 65536 > gpurun_out/lib_ab.json"""
+    python tools/lib_ab.py --b peritext_amd/lib/exp_x.so [peritext_amd/lib/exp_y.so ...] --docs 65536 > gpurun_out/lib_ab.json
+Experimental builds: hipcc with the product's flags (__graft_entry__.py) plus -D<macro>=<value> (the tuning macros at the top of merge_core.h), e.g.
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-atomic-optimizer-strategy=None -DPTX_S=8 -o peritext_amd/lib/exp_s8.so peritext_amd/csrc/peritext_hip.hip
+(16 s each on the build container; the .so files travel to the GPU box with the snapshot)."""
 import argparse
 import json
 import os
@@ -24,7 +27,7 @@ FIXTURES = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json"
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--a", default=None, help="build A (default: peritext_amd/lib/libperitext_hip.so)")
-    ap.add_argument("--b", required=True, help="build B")
+    ap.add_argument("--b", required=True, nargs="+", help="build(s) B: each is checked against the fixtures and timed against build A")
     ap.add_argument("--docs", type=int, default=8192)
     ap.add_argument("--config", default="config4")
     ap.add_argument("--iters", type=int, default=10)
@@ -32,7 +35,7 @@ def main():
     ap.add_argument("--flags", type=int, default=abi.FLAG_NO_ELEM_RANK)
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
-    libs = [args.a and os.path.join(ROOT, args.a), os.path.join(ROOT, args.b)]
+    libs = [args.a and os.path.join(ROOT, args.a)] + [os.path.join(ROOT, b) for b in args.b]
     names = [os.path.basename(p or "libperitext_hip.so") for p in libs]
     t0 = time.time()
     out = {"builds": names, "parity_b": {}, "timing": []}
@@ -40,17 +43,18 @@ def main():
     def say(msg):
         print("[%5.1fs] %s" % (time.time() - t0, msg), file=sys.stderr, flush=True)
 
-    if not args.no_parity:
-        with Engine(0, lib_path=libs[1]) as e:
+    for k in range(1, len(libs) if not args.no_parity else 0):
+        with Engine(0, lib_path=libs[k]) as e:
             for name in FIXTURES:
                 with open(os.path.join(H.GOLDEN, name)) as f:
                     gen = json.load(f)
                 try:
                     H.check_generated(gen, e.apply_materialize)
-                    out["parity_b"][name] = "ok"
+                    verdict = "ok"
                 except Exception as ex:  # noqa: BLE001
-                    out["parity_b"][name] = "FAIL: " + str(ex).splitlines()[0][:200]
-                say("parity of %s on %s: %s" % (names[1], name, out["parity_b"][name]))
+                    verdict = "FAIL: " + str(ex).splitlines()[0][:200]
+                out["parity_b"]["%s %s" % (names[k], name)] = verdict
+                say("parity of %s on %s: %s" % (names[k], name, verdict))
     g = workloads.gen_config(args.config)
     engs = [Engine(0, flags=args.flags, lib_path=p) for p in libs]
     state = []
@@ -61,11 +65,14 @@ def main():
         e.sync()
         state.append((db, dr, e.n_logs(db), e.launch_shape(db)))
     logs = [e.download_logs(dr, n) for e, (db, dr, n, _) in zip(engs, state)]
-    same = bool((logs[0]["status"] == logs[1]["status"]).all() and (logs[0]["digest"] == logs[1]["digest"]).all() and (logs[0]["n_spans"] == logs[1]["n_spans"]).all()
-                and (logs[0]["n_visible"] == logs[1]["n_visible"]).all() and int(logs[0]["status"].max()) == 0)
+    same = int(logs[0]["status"].max()) == 0
+    for k in range(1, len(libs)):
+        same_k = bool((logs[0]["status"] == logs[k]["status"]).all() and (logs[0]["digest"] == logs[k]["digest"]).all() and (logs[0]["n_spans"] == logs[k]["n_spans"]).all()
+                      and (logs[0]["n_visible"] == logs[k]["n_visible"]).all())
+        say("results of %s identical with build A's over %d logs: %s" % (names[k], state[0][2], same_k))
+        same = same and same_k
     out["identical_results"] = same
     out["logs_compared"] = int(state[0][2])
-    say("results of the two builds identical over %d logs: %s" % (state[0][2], same))
     for rnd in range(args.rounds):
         for k, e in enumerate(engs):
             db, dr, n_logs, shape = state[k]
