@@ -688,7 +688,7 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
     {
         uint64_t* tmp = nullptr;
         PTX_TRY(dalloc(&tmp, (uint64_t)h->n_logs + 1));
-        hipError_t e1 = hipMemcpyAsync(tmp, h->log_off, ((uint64_t)h->n_logs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e1 = h->n_logs ? hipMemcpyAsync(tmp, h->log_off, ((uint64_t)h->n_logs + 1) * 8, hipMemcpyHostToDevice, ctx->stream) : hipSuccess; /* an empty batch may come without log_off */
         if (e1 == hipSuccess && h->n_logs) {
             const uint64_t total = (uint64_t)b->n_logs + 1;
             hipLaunchKernelGGL(ptx_tile_offsets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, tmp, b->log_off,
