@@ -76,6 +76,11 @@
                             store + load of those bytes.  Measured same-call against the build without it: 9.45 against 9.86 ms per 64K-doc launch
                             (profiles/r02_ab_*); 0 = the list stays in LDS */
 #endif
+#ifndef PTX_UNPARK_EARLY
+#define PTX_UNPARK_EARLY 0 /* 1 (with PTX_PARK_MLIST): the first PTX_UPF words per thread of the parked mark list are loaded into registers when P3d starts, so that their
+                              round trip hides behind the Euler tour and the list ranking instead of standing between P3d and P5 (experimental build exp_unpark_early) */
+#endif
+#define PTX_UPF 6u
 #ifndef PTX_P1_WIDE
 #define PTX_P1_WIDE 1 /* P1 reads the ids of a thread's three rows from one address (16 + 8 bytes) where all of them exist */
 #endif
@@ -1199,6 +1204,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     bp.off = tree_lds;
     PTX_STAMP(2);
 
+#if PTX_PARK_MLIST && PTX_UNPARK_EARLY
+    uint32_t upf[PTX_UPF]; /* the thread's first words of the parked mark list, on their way while P3d runs */
+#endif
     /* ---- P3: causal tree of the inserts -> document position of every element ---- */
     {
         /* children per parent -> bucket starts -> bucket ends; 16-bit counters, two per atomically updated word */
@@ -1386,6 +1394,16 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_SYNC();
         PTX_STAMP(4);
+#if PTX_PARK_MLIST && PTX_UNPARK_EARLY
+        {
+            const uint32_t* park = (const uint32_t*)(A.out_spans + base);
+#pragma unroll
+            for (int u = 0; u < (int)PTX_UPF; ++u) {
+                const uint32_t j = PTX_J_OF_U(0u, u, PTX_UPF);
+                upf[u] = j < (K >> 1) ? park[j] : 0u;
+            }
+        }
+#endif
         /* P3d: Euler tour.  Nodes: 0 = enter(HEAD), x+1 = enter(x), n+1+x = exit(x) for x in [0,n), and the
          * terminal node 2n+1.  weight 1 on enter(x): the suffix sum at enter(x) counts the elements from x
          * to the end of the document, so position(x) = n - suffix(enter(x)). */
@@ -1452,7 +1470,25 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     {
         const uint32_t* park = (const uint32_t*)(A.out_spans + base);
         uint32_t* dst = (uint32_t*)mlist;
+#if PTX_UNPARK_EARLY
+        /* word j belongs to thread j mod T here as in the park loop: step 0 came in while P3d ran, the (rare) later steps are read now */
+        const uint32_t W = K >> 1, up_steps = PTX_JSTEPS_U(W, PTX_UPF);
+#pragma unroll
+        for (int u = 0; u < (int)PTX_UPF; ++u) {
+            const uint32_t j = PTX_J_OF_U(0u, u, PTX_UPF);
+            if (j < W) dst[j] = upf[u];
+        }
+#pragma nounroll
+        for (uint32_t st = 1; st < up_steps; ++st) {
+#pragma unroll
+            for (int u = 0; u < (int)PTX_UPF; ++u) {
+                const uint32_t j = PTX_J_OF_U(st, u, PTX_UPF);
+                if (j < W) dst[j] = park[j];
+            }
+        }
+#else
         PTX_FOR(w, K >> 1) dst[w] = park[w];
+#endif
         if (K & 1u) PTX_LEADER { mlist[K - 1u] = ((const uint16_t*)park)[K - 1u]; }
     }
     PTX_SYNC();
