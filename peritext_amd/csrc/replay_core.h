@@ -69,7 +69,7 @@ PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_
     (void)nw;
     return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + 2 * ptx_a16(4 * nws) +
            ptx_a16(4 * (nws + 1)) + 3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * segcap) + ptx_a16(8 * ((segcap >> 5) + 2)) + 3 * ptx_a16(4 * nws) +
-           ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
+           ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 3 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
            5 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
 }
 PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h) {
@@ -120,6 +120,11 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     const uint32_t K = hd.n_mark[0] + hd.n_mark[1] + hd.n_mark[2] + hd.n_mark[3];
     const uint32_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
     const uint32_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
+    /* LWW winners of strong / em per slot: where every op id of the log has a dense key (counter * (max actor + 1) + actor, the merge kernel's) below
+     * 65 535, the slot holds the winner's key + 1 — compareOpIds is then a compare of two LDS values — instead of its row (whose op id would have to
+     * be fetched from HBM for every slot of every mark op: a dependent round trip in a sequential replay).  Links keep the row: their url is read through it. */
+    const uint32_t na1 = hd.max_actor + 1u;
+    const bool key_mode = (uint64_t)(hd.max_counter + 1ull) * na1 <= 65535ull;
 
     PtxBump bp;
     bp.base = lds;
@@ -144,6 +149,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint32_t* c_pay = ptx_alloc<uint32_t>(bp, PTX_RCHUNK);
     uint16_t* c_a = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* insert / delete: final rank; mark: start slot */
     uint16_t* c_b = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* mark: end slot */
+    uint16_t* c_key = ptx_alloc<uint16_t>(bp, PTX_RCHUNK); /* (key_mode) the op id's dense key + 1 */
     uint8_t* c_kind = ptx_alloc<uint8_t>(bp, PTX_RCHUNK);  /* PTX_RK_* | mark type << 4 | addMark << 6 */
     uint16_t* seg = ptx_alloc<uint16_t>(bp, segcap);      /* defined slots of the op's range, ascending */
     PtxBitWord* cf = ptx_alloc<PtxBitWord>(bp, (segcap >> 5) + 2); /* bit j: slot seg[j] opens a patch; prefix = its place */
@@ -187,26 +193,29 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     }
     PTX_SYNC_T();
 
-    /* last defined slot strictly below `lim` -> H->tmp = slot + 1 (0 = none); every thread calls it */
-#define PTX_LAST_DEFINED_BELOW(lim_)                                                            \
-    do {                                                                                        \
-        PTX_LEADER { H->tmp = 0; }                                                              \
-        PTX_SYNC_T();                                                                             \
+    /* last defined slot strictly below `lim` -> out_ = slot + 1 (0 = none), the same in every lane; every thread calls it.  The workgroup is ONE
+     * wave: every lane keeps the best of its own words and a wave-wide maximum (register shuffles) makes it common — no LDS atomic, no read back */
+#ifndef PTX_EMU
+    static_assert(kThreads == 64u, "the replay's reductions are wave-wide");
+#endif
+#define PTX_LAST_DEFINED_BELOW(lim_, out_)                                                      \
+    uint32_t out_ = 0;                                                                          \
+    {                                                                                           \
         PTX_FOR(w_, ((lim_) + 31u) >> 5) {                                                      \
             uint32_t m_ = defined[w_];                                                          \
             if ((w_ << 5) + 32u > (lim_)) m_ &= (1u << ((lim_)&31u)) - 1u;                      \
-            if (m_) ptx_atomic_max(&H->tmp, (w_ << 5) + (31u - (uint32_t)__builtin_clz(m_)) + 1u); \
+            const uint32_t c_ = m_ ? (w_ << 5) + (31u - (uint32_t)__builtin_clz(m_)) + 1u : 0u; \
+            out_ = c_ > out_ ? c_ : out_;                                                       \
         }                                                                                       \
-        PTX_SYNC_T();                                                                             \
-    } while (0)
+        out_ = ptx_wave_max(out_);                                                              \
+    }
 
     /* make slot s_ a defined one: its state is that of the closest defined slot to the left (peritext.ts:176) */
 #define PTX_DEFINE_SLOT(s_)                                                                     \
     do {                                                                                        \
         if (!ptx_bittest(defined, (s_))) {                                                      \
-            PTX_LAST_DEFINED_BELOW(s_);                                                         \
+            PTX_LAST_DEFINED_BELOW(s_, l1_)                                                     \
             PTX_LEADER {                                                                        \
-                const uint32_t l1_ = H->tmp;                                                    \
                 win[0][s_] = l1_ ? win[0][l1_ - 1u] : (uint16_t)0;                              \
                 win[1][s_] = l1_ ? win[1][l1_ - 1u] : (uint16_t)0;                              \
                 win[2][s_] = l1_ ? win[2][l1_ - 1u] : (uint16_t)0;                              \
@@ -249,6 +258,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         c_b[i] = (uint16_t)vb;
         c_pay[i] = payload[tt];
         c_id[i] = op_id[tt];
+        c_key[i] = (uint16_t)(key_mode ? (uint32_t)(op_id[tt] >> 32) * na1 + (uint32_t)op_id[tt] + 1u : 0u);
     }
     PTX_SYNC_T();
 #pragma nounroll
@@ -263,8 +273,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             PTX_SYNC_T();
         } else if (kind == PTX_RK_INSERT) {
             const uint32_t r = c_a[ci];
-            PTX_LAST_DEFINED_BELOW(2u * r);
-            const uint32_t l1 = H->tmp; /* slot + 1 */
+            PTX_LAST_DEFINED_BELOW(2u * r, l1) /* slot + 1 */
             const uint32_t p0 = H->npatch;
             PTX_SYNC_T();
             PTX_LEADER {
@@ -380,6 +389,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             PTX_SYNC_T();
             const uint32_t my_id = c_pay[ci];
             const uint64_t my_op = c_id[ci];
+            const uint32_t my_key1 = c_key[ci];
+            const bool by_key = key_mode && ty != PTX_MARK_LINK;
             /* per defined slot: did the effective marks change (peritext.ts:208), new state, visible index */
             PTX_FOR(j, S) {
                 const uint32_t s = seg[j];
@@ -389,12 +400,13 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     uint32_t* wo = won[ty == PTX_MARK_STRONG ? 0 : ty == PTX_MARK_EM ? 1 : 2];
                     const uint32_t w = wt[s];
                     const bool old_on = ptx_bittest(wo, s);
-                    const bool wins = !w || my_op > op_id[w - 1u]; /* compareOpIds: counter, then actor (ranks keep the string order) */
+                    /* compareOpIds: counter, then actor (ranks keep the string order); the dense keys keep that order */
+                    const bool wins = !w || (by_key ? my_key1 > w : my_op > op_id[w - 1u]);
                     if (wins) {
                         const bool new_on = act == PTX_ACT_ADDMARK;
                         changed = new_on != old_on;
                         if (new_on && old_on && ty == PTX_MARK_LINK) changed = (my_id & PTX_ATTR_ID_MASK) != (payload[w - 1u] & PTX_ATTR_ID_MASK);
-                        wt[s] = (uint16_t)(t + 1u);
+                        wt[s] = (uint16_t)(by_key ? my_key1 : t + 1u);
                         if (new_on != old_on) {
                             if (new_on) ptx_atomic_or(&wo[s >> 5], 1u << (s & 31));
                             else ptx_atomic_and(&wo[s >> 5], ~(1u << (s & 31)));

@@ -178,3 +178,15 @@ def test_patch_streams_random_workloads():
             res = H.emu_merge(batch, lds_bytes=160 * 1024, reverse=reverse)
             pat = H.emu_replay(batch, res, reverse=reverse)
             _check_streams(batch, pat, expected)
+
+
+def test_patch_streams_with_op_counters_beyond_the_dense_key_range():
+    """The replay keeps the LWW winners of strong / em per slot as dense op-id keys where the log's id space fits 16 bits, and as rows (op ids read
+    back from the columns) where it does not: the same documents with every counter moved up by 70 000 take the second path and must give the very
+    same streams (a patch carries no op id)."""
+    g = _load("patches_rich_300.json")
+    docs = [d["logs"] for d in g["docs"]]
+    wide = wire.encode_docs(H.shift_counters(docs, 70000))
+    assert (int(wide.log_hdr["max_counter"].max()) + 1) * (int(wide.log_hdr["max_actor"].max()) + 1) > 65535
+    res = H.emu_merge(wide, lds_bytes=160 * 1024)
+    assert _check_streams(wide, H.emu_replay(wide, res), [d["expected"] for d in g["docs"]]) == wide.n_logs

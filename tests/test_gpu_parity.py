@@ -344,6 +344,16 @@ def test_golden_patch_streams(eng, name):
         assert pat.launches == 2  # more than two records per op: the library sized the second launch exactly
 
 
+def test_patch_streams_with_op_counters_beyond_the_dense_key_range(eng):
+    """The replay keeps the LWW winners of strong / em per slot as dense op-id keys where the log's id space fits 16 bits and as rows where it
+    does not: the reference-made fixture with every counter moved up by 70 000 takes the second path and must give the same streams."""
+    g = _load("patches_rich_300.json")
+    wide = wire.encode_docs(H.shift_counters([d["logs"] for d in g["docs"]], 70000))
+    res, pat = _streams(eng, wide)
+    assert (res.logs["status"] == 0).all()
+    assert H.check_patch_streams(wide, pat, [d["expected"] for d in g["docs"]]) == wide.n_logs
+
+
 def test_patch_streams_kat_traces_and_failed_logs(eng):
     if not H.have_node():
         pytest.skip("node not installed")
