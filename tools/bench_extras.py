@@ -42,24 +42,50 @@ def main():
     gen_args = (g["replicas"], g["ops_per_log"], g["mix"], g["mark_types"])
     out = {"patch_replay": None, "experiments": None}
 
-    try:
-        with Engine(args.device) as e:  # with elem_rank: the replay reads it
-            docs = min(2048, args.docs)
-            db, _ = e.generate(*gen_args, docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
-            dr = e.alloc_result(db)
-            e.merge(db, dr)
-            e.sync()
-            pat = e.replay_patches(db, dr)
-            ops = e.n_logs(db) * g["ops_per_log"]
-            n_pat = int(pat.logs["n_patches"].sum())
-            out["patch_replay"] = {"docs": docs, "ops": ops, "patches": n_pat, "kernel_ms": pat.kernel_ms, "launches": pat.launches,
-                                   "every_log_has_a_stream": bool(int(pat.logs["status"].max()) == 0),
-                                   "ops_per_s": ops / pat.kernel_ms * 1e3, "patches_per_s": n_pat / pat.kernel_ms * 1e3}
-            e.free_result(dr)
-            e.free_batch(db)
-    except Exception as ex:  # noqa: BLE001
-        out["patch_replay"] = {"error": str(ex)[:300]}
+    def stream_checksum(pat):
+        """Order-sensitive checksum over the records every log really produced (the rows past a log's count are capacity, not data)."""
+        import numpy as np
+
+        caps = np.diff(pat.patch_off.astype(np.int64))
+        n = pat.logs["n_patches"].astype(np.int64)
+        valid = (np.arange(int(caps.sum()), dtype=np.int64) - np.repeat(pat.patch_off[:-1].astype(np.int64), caps)) < np.repeat(n, caps)
+        rows = pat.patches[: len(valid)][valid]
+        w = np.arange(1, len(rows) + 1, dtype=np.uint64)
+        mix = (rows["row"].astype(np.uint64) * np.uint64(0x9E3779B1) + rows["kind"].astype(np.uint64) * np.uint64(0x85EBCA77) + rows["a"].astype(np.uint64) * np.uint64(0xC2B2AE3D)
+               + rows["b"].astype(np.uint64) * np.uint64(0x27D4EB2F))
+        return int(n.sum()), int((mix * w).sum() & np.uint64(0xFFFFFFFFFFFFFFFF))
+
+    def replay_rate(lib):
+        try:
+            with Engine(args.device, lib_path=lib) as e:  # with elem_rank: the replay reads it
+                docs = min(2048, args.docs)
+                db, _ = e.generate(*gen_args, docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
+                dr = e.alloc_result(db)
+                e.merge(db, dr)
+                e.sync()
+                pat = e.replay_patches(db, dr)
+                ops = e.n_logs(db) * g["ops_per_log"]
+                n_pat = int(pat.logs["n_patches"].sum())
+                r = {"build": os.path.basename(lib or "libperitext_hip.so"), "docs": docs, "ops": ops, "patches": n_pat, "kernel_ms": pat.kernel_ms, "launches": pat.launches,
+                     "every_log_has_a_stream": bool(int(pat.logs["status"].max()) == 0), "ops_per_s": ops / pat.kernel_ms * 1e3, "patches_per_s": n_pat / pat.kernel_ms * 1e3,
+                     "_sum": stream_checksum(pat)}
+                e.free_result(dr)
+                e.free_batch(db)
+                return r
+        except Exception as ex:  # noqa: BLE001
+            return {"build": os.path.basename(lib or "libperitext_hip.so"), "error": str(ex)[:300]}
+
+    out["patch_replay"] = replay_rate(None)
     say("patch_replay %s" % json.dumps(out["patch_replay"]))
+    prev = os.path.join(ROOT, "peritext_amd", "lib", "exp_nopark.so")  # made with PTX_REPLAY_V1: the replay as measured before this build's changes
+    if os.path.exists(prev):
+        other = replay_rate(prev)
+        if "_sum" in other and "_sum" in out["patch_replay"]:
+            other["same_streams_by_checksum"] = other["_sum"] == out["patch_replay"]["_sum"]
+        other.pop("_sum", None)
+        out["patch_replay"]["previous_replay_kernel"] = other
+        say("patch_replay (previous kernel) %s" % json.dumps(other))
+    out["patch_replay"].pop("_sum", None)
 
     flags = abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0)
     variants = [("product build", None, 0)]
