@@ -474,6 +474,27 @@ PTX_DEV void ptx_plane_shift_up(uint32_t* plane, uint32_t at, uint32_t n) {
         wh = wl;
     }
 }
+/* position + 1 of the highest set bit of `bits` strictly below `lim`, 0 when there is none — the same value in every lane (one-wave workgroups; every lane
+ * calls it).  Chunks of 64 words from the top down, one word per lane: a ballot finds the highest lane whose word has a bit, ONE readlane fetches that word. */
+PTX_DEV uint32_t ptx_last_set_below(const uint32_t* bits, uint32_t lim) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t words = (lim + 31u) >> 5;
+    for (uint32_t top = (words + 63u) & ~63u; top != 0u; top -= 64u) {
+        const uint32_t w = top - 64u + lane;
+        uint32_t m = 0;
+        if (w < words) {
+            m = bits[w];
+            if ((w << 5) + 32u > lim) m &= (1u << (lim & 31u)) - 1u;
+        }
+        const unsigned long long nz = __ballot(m != 0u);
+        if (nz) {
+            const uint32_t l = 63u - (uint32_t)__builtin_clzll(nz);
+            const uint32_t mm = (uint32_t)__shfl((int)m, (int)l, 64);
+            return ((top - 64u + l) << 5) + (31u - (uint32_t)__builtin_clz(mm)) + 1u;
+        }
+    }
+    return 0u;
+}
 /* position of the k-th (0-based) ZERO bit of plane among positions [0, n), or 0xFFFFFFFF */
 PTX_DEV uint32_t ptx_plane_select0(const uint32_t* plane, uint32_t n, uint32_t k) {
     const uint32_t lane = threadIdx.x & 63u;

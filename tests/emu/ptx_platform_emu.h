@@ -235,6 +235,11 @@ PTX_DEV void ptx_plane_shift_up(uint32_t* plane, uint32_t at, uint32_t n) {
     for (uint32_t i = n; i > at; --i) ptx_emu_setbit(plane, i, ptx_emu_bit(plane, i - 1u));
     ptx_emu_setbit(plane, at, false);
 }
+PTX_DEV uint32_t ptx_last_set_below(const uint32_t* bits, uint32_t lim) {
+    for (uint32_t s = lim; s-- > 0u;)
+        if (ptx_emu_bit(bits, s)) return s + 1u;
+    return 0u;
+}
 PTX_DEV uint32_t ptx_plane_select0(const uint32_t* plane, uint32_t n, uint32_t k) {
     for (uint32_t i = 0; i < n; ++i)
         if (!ptx_emu_bit(plane, i) && k-- == 0u) return i;

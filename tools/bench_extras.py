@@ -76,16 +76,18 @@ def main():
             return {"build": os.path.basename(lib or "libperitext_hip.so"), "error": str(ex)[:300]}
 
     out["patch_replay"] = replay_rate(None)
-    say("patch_replay %s" % json.dumps(out["patch_replay"]))
-    prev = os.path.join(ROOT, "peritext_amd", "lib", "exp_nopark.so")  # made with PTX_REPLAY_V1: the replay as measured before this build's changes
-    if os.path.exists(prev):
-        other = replay_rate(prev)
+    say("patch_replay %s" % json.dumps({k: v for k, v in out["patch_replay"].items() if k != "_sum"}))
+    # the same under every experimental build (exp_nopark carries the replay as it was measured before, PTX_REPLAY_V1; exp_replay_* other searches)
+    others = []
+    for lib in sorted(glob.glob(os.path.join(ROOT, "peritext_amd", "lib", "exp_*.so"))):
+        other = replay_rate(lib)
         if "_sum" in other and "_sum" in out["patch_replay"]:
             other["same_streams_by_checksum"] = other["_sum"] == out["patch_replay"]["_sum"]
         other.pop("_sum", None)
-        out["patch_replay"]["previous_replay_kernel"] = other
-        say("patch_replay (previous kernel) %s" % json.dumps(other))
+        others.append(other)
+        say("patch_replay %s" % json.dumps(other))
     out["patch_replay"].pop("_sum", None)
+    out["patch_replay"]["other_builds"] = others
 
     flags = abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0)
     variants = [("product build", None, 0)]
