@@ -135,6 +135,25 @@ def main():
         say(json.dumps(row))
         if ref is None:
             break  # nothing to compare the variants with
+    # how long ONE log takes when it has a CU to itself, and one full set of resident logs per CU (chain latency against contention)
+    probes = []
+    try:
+        with Engine(args.device, flags=flags) as e:
+            for docs in (85, 683, 5461):  # x 3 replicas = 255 / 2 049 / 16 383 logs: ~1, ~8, ~64 per CU
+                if docs > args.docs:
+                    continue
+                db, _ = e.generate(*gen_args, docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
+                dr = e.alloc_result(db)
+                e.merge(db, dr)
+                e.sync()
+                ms = e.merge_timed(db, dr, args.iters) / args.iters
+                probes.append({"logs": e.n_logs(db), "kernel_ms": ms, "us_per_log_per_cu": ms * 1e3 * 256 / e.n_logs(db)})
+                e.free_result(dr)
+                e.free_batch(db)
+    except Exception as ex:  # noqa: BLE001
+        probes.append({"error": str(ex)[:300]})
+    out["occupancy_probe"] = probes
+    say("occupancy_probe %s" % json.dumps(probes))
     out["experiments"] = {"workload": "%s, %d docs (the bench's own documents)" % (args.config, args.docs), "launches_each": args.iters, "same_box_same_call": True, "variants": rows}
     print(json.dumps(out), flush=True)
 
