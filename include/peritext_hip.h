@@ -251,6 +251,8 @@ typedef struct ptx_dresult ptx_dresult;  /* result buffers resident in HBM */
 /* ptx_create flags */
 #define PTX_FLAG_NO_ELEM_RANK 1u /* do not produce ptx_result.elem_rank (saves 4 B/op of HBM writes) */
 #define PTX_FLAG_NO_ADMISSION 2u /* ignore the Change envelope (chg_*) even when the batch carries it: no seq / deps checks */
+#define PTX_FLAG_PAD_GATHER 4u   /* ptx_allgather_digests always takes its padded path (pack, all-gather of max(counts) pairs per rank, compact on the
+                                    device) even when every rank holds the same number of logs: same result; lets a one-GPU host exercise that path */
 
 /* ---- lifecycle ---- */
 uint32_t ptx_abi_version(void);
@@ -258,6 +260,10 @@ uint32_t ptx_abi_version(void);
  * there is NO CPU fallback behind this ABI. */
 ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out);
 void ptx_destroy(ptx_ctx* ctx);
+/* Launch shape of the batches made resident AFTER this call (upload / append / generate / wrap): threads per replica log (a
+ * multiple of 64, <= 1024) and the LDS window per log in bytes; 0 = the library's own choice by log size (the default).  A tuning
+ * knob: results do not depend on it; a window too small for a log is that log's PTX_ERR_CAPACITY. */
+ptx_status ptx_set_launch_shape(ptx_ctx* ctx, uint32_t threads_per_log, uint32_t lds_bytes_per_log);
 const char* ptx_last_error(const ptx_ctx* ctx); /* ctx may be NULL: last ptx_create failure */
 
 /* ---- the drop-in call: replaces a loop of applyChange(...) + getTextWithFormatting(["text"]) ---- */
@@ -337,6 +343,8 @@ ptx_status ptx_comm_unique_id(ptx_ctx* ctx, uint8_t id[PTX_COMM_ID_BYTES]);
 /* Collective over all ranks (ncclCommInitRank) on the context's device. */
 ptx_status ptx_comm_init(ptx_ctx* ctx, const uint8_t id[PTX_COMM_ID_BYTES], uint32_t rank, uint32_t n_ranks, ptx_comm** out);
 void ptx_comm_destroy(ptx_ctx* ctx, ptx_comm* comm);
+uint32_t ptx_comm_n_ranks(const ptx_comm* comm); /* 0 for NULL: hosts check the length of `counts` against it */
+uint32_t ptx_comm_rank(const ptx_comm* comm);
 /* All-gather of the digests of every rank's result: counts[r] = replica logs of rank r (host array [n_ranks]; counts[rank] must be
  * the logs of `r`), out_device = [sum(counts)] x 2 u64 in DEVICE memory, rank-major.  Enqueued on the context's stream; ranks
  * whose blocks differ in size are gathered padded and compacted on the device. */

@@ -29,6 +29,7 @@ RANK_MASK = 0x7FFFFFFF
 
 FLAG_NO_ELEM_RANK = 1
 FLAG_NO_ADMISSION = 2
+FLAG_PAD_GATHER = 4
 COMM_ID_BYTES = 128
 
 PTX_OK = 0
@@ -282,6 +283,7 @@ FUNCTIONS = {
     "ptx_batch_launch_shape": (None, [vp, u32p, u32p]),
     "ptx_result_alloc": (C.c_int32, [vp, vp, C.POINTER(vp)]),
     "ptx_dresult_free": (None, [vp, vp]),
+    "ptx_set_launch_shape": (C.c_int32, [vp, C.c_uint32, C.c_uint32]),
     "ptx_merge": (C.c_int32, [vp, vp, vp]),
     "ptx_merge_timed": (C.c_int32, [vp, vp, vp, C.c_uint32, C.POINTER(C.c_float)]),
     "ptx_merge_phase_cycles": (C.c_int32, [vp, vp, vp, u64p, C.c_uint32]),
@@ -297,6 +299,8 @@ FUNCTIONS = {
     "ptx_comm_unique_id": (C.c_int32, [vp, u8p]),
     "ptx_comm_init": (C.c_int32, [vp, u8p, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
     "ptx_comm_destroy": (None, [vp, vp]),
+    "ptx_comm_n_ranks": (C.c_uint32, [vp]),
+    "ptx_comm_rank": (C.c_uint32, [vp]),
     "ptx_allgather_digests": (C.c_int32, [vp, vp, vp, u32p, vp]),
     "ptx_count_converged_digests": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
     "ptx_device_alloc": (C.c_int32, [vp, C.c_uint64, C.POINTER(vp)]),

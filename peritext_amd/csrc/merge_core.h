@@ -33,7 +33,7 @@
  * commutative atomics (or, in the pointer-jumping rounds, through single-word reads of a value whose
  * every intermediate state is valid).  That discipline lets the SAME source be compiled two ways:
  *   - by hipcc for gfx950 as the body of the kernel in peritext_hip.hip (the product), and
- *   - by g++ with -DPTX_EMU as a single-threaded emulation used ONLY by the CPU test-suite
+ *   - by g++ against the test-suite's own platform header as a single-threaded emulation used ONLY by the CPU test-suite
  *     (tests/emu) to check the kernel's logic where no GPU exists.  The emulation is not linked
  *     into libperitext_hip.so and is never a fallback for the product path.
  */
@@ -57,56 +57,24 @@
 #define PTX_UA 1 /* changes per thread in flight in the (rare) many-actor admission passes */
 #define PTX_INA(i0, u) PTX_IN(i0, u)
 #define PTX_IXA(i0, u) PTX_IX(i0, u)
-#ifndef PTX_AC
 #define PTX_AC 4u /* consecutive changes per lane and step in the admission pass (one 16-byte load of headers, two of envelope rows) */
-#endif
 #ifndef PTX_UM
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
-#endif
-#ifndef PTX_KO
-#define PTX_KO 0 /* diagnostic builds only (tools/pmc_variants.sh): knock ONE gather stream out to see its share of the read requests — wrong results */
-#endif
-#ifndef PTX_HOIST_MARK
-#define PTX_HOIST_MARK 1 /* P5a's first gathers are issued ahead of P4 and the values pass (1 % faster; with the marks visited in row order it costs no extra read requests) */
-#endif
-#ifndef PTX_PARK_MLIST
-#define PTX_PARK_MLIST 1 /* 1: the mark list (2 bytes per mark op) is not kept in LDS from P1 to P5: it is built in P1's scratch, PARKED in the log's own span rows
-                            in HBM (unused until P6) while the causal tree is resolved, and read back when P5 starts — 3.1 KB less at the LDS high-water mark of a
-                            config-4 log (22.6 -> 19.7 KB for the largest log of the 64K-doc batch: EIGHT logs share a CU instead of seven) for one coalesced
-                            store + load of those bytes.  Measured same-call against the build without it: 9.45 against 9.86 ms per 64K-doc launch
-                            (profiles/r02_ab_*); 0 = the list stays in LDS */
-#endif
-#ifndef PTX_UNPARK_EARLY
-#define PTX_UNPARK_EARLY 0 /* 1 (with PTX_PARK_MLIST): the first PTX_UPF words per thread of the parked mark list are loaded into registers when P3d starts, so that their
-                              round trip hides behind the Euler tour and the list ranking instead of standing between P3d and P5 (experimental build exp_unpark_early) */
-#endif
-#define PTX_UPF 6u
-#ifndef PTX_P1_WIDE
-#define PTX_P1_WIDE 1 /* P1 reads the ids of a thread's three rows from one address (16 + 8 bytes) where all of them exist */
 #endif
 #ifndef PTX_UB
 #define PTX_UB 2u /* mark ops per thread and step in the LWW pass P5b (one opId gather each, issued together) */
 #endif
-#ifndef PTX_P1_AHEAD
-#define PTX_P1_AHEAD 1 /* steps of row loads in flight ahead of the one in work in P1 (1 or 2; measured: 2 is 2 % slower — more requests in flight only queue) */
-#endif
-#ifndef PTX_ADM_AHEAD
-#define PTX_ADM_AHEAD 1 /* the same for the admission walk */
-#endif
-#ifndef PTX_MARK_AHEAD
-#define PTX_MARK_AHEAD 1 /* steps of mark gathers in flight ahead of the one in work in P5a (1 or 2; measured: 2 is 1 % slower) */
-#endif
 #define PTX_NCLK 16
 
-/* the machine: gfx950 for the product; the CPU test-suite plays the workgroup with one host thread (tests/emu) */
-#ifdef PTX_EMU
-#include "../../tests/emu/ptx_platform_emu.h"
-#else
-#include "ptx_platform_gfx950.h"
+/* the machine: gfx950.  (The CPU test-suite compiles these sources against a header of its own that plays the workgroup with one host
+ * thread: its driver names that header in PTX_PLATFORM_HEADER before it includes this file; nothing in csrc/ knows where it lives.) */
+#ifndef PTX_PLATFORM_HEADER
+#define PTX_PLATFORM_HEADER "ptx_platform_gfx950.h"
 #endif
+#include PTX_PLATFORM_HEADER
 
 
-/* kernel arguments: device pointers (host pointers under PTX_EMU) */
+/* kernel arguments: device pointers (host pointers in the test-suite's emulation) */
 struct PtxMergeArgs {
     const uint64_t* log_off;
     const uint64_t* op_id;
@@ -285,7 +253,7 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     (void)N;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
     const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P5a */
-    const uint64_t mlist_b = ptx_a16(2 * (K + 1)), mpark = PTX_PARK_MLIST ? mlist_b : 0; /* parked: part of P1's and P5's scratch instead of the persistent state */
+    const uint64_t mlist_b = ptx_a16(2 * (K + 1)), mpark = mlist_b; /* parked: part of P1's and P5's scratch instead of the persistent state */
     const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + (mlist_b - mpark) + ptx_a16(4 * (K / 32 + 1)) + elem;
     const uint64_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
     const uint64_t lists = ptx_a16(2 * (n + 1)) + ptx_a16(2 * l_len);
@@ -307,7 +275,7 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
 /* P0 scratch on top of the header: per-actor table starts + the (actor, seq) -> change table */
 PTX_HD uint64_t ptx_lds_need_admission(uint64_t n_changes, uint64_t max_actors) {
     if (max_actors <= 3) return ptx_a16(sizeof(PtxHdr)) + 2 * ptx_a16(4 * (1024 / 64 + 2)) + ptx_a16(4 * 12 * (1024 / 64 + 1)); /* per-wave clock totals and check records */
-    return ptx_a16(sizeof(PtxHdr)) + ptx_a16(4 * (max_actors + 2)) + ptx_a16(2 * (n_changes + 1));
+    return ptx_a16(sizeof(PtxHdr)) + ptx_a16(4 * (max_actors + 2)) + ptx_a16(4 * (n_changes + 1));
 }
 PTX_HD uint64_t ptx_lds_need_hdr(uint64_t N, const ptx_log_hdr& h) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
@@ -652,9 +620,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 S.bx = S.by = S.gx = S.gy = S.known = 0u;
                 uint32_t mx0 = 0, mx1 = 0, bad = 0, amax = 0, hsum = 0;
                 uint32_t h[PTX_AC], h_n[PTX_AC], e0[PTX_AC], e1[PTX_AC], e0_n[PTX_AC], e1_n[PTX_AC];
-#if PTX_ADM_AHEAD > 1
-                uint32_t h_m[PTX_AC], e0_m[PTX_AC], e1_m[PTX_AC]; /* the step in between */
-#endif
 #define PTX_ADM_LOAD(cb_, h_, e0_, e1_)                                     \
     {                                                                       \
         const uint32_t cl0_ = (cb_) + lane * PTX_AC;                        \
@@ -663,12 +628,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_ADM_ENVS32(e0_, e1_, cl_)                                       \
     }
                 PTX_ADM_LOAD(lo, h, e0, e1)
-#if PTX_ADM_AHEAD > 1
-                PTX_ADM_LOAD(lo + step, h_m, e0_m, e1_m)
-#endif
 #pragma nounroll
                 for (uint32_t cb = lo; cb < hi; cb += step) {
-                    PTX_ADM_LOAD(cb + (uint32_t)PTX_ADM_AHEAD * step, h_n, e0_n, e1_n)
+                    PTX_ADM_LOAD(cb + step, h_n, e0_n, e1_n)
                     if (cb + step <= hi) {
                         ptx_adm_step<false>(S, h, e0, e1, PTX_AC, mx0, mx1, bad, amax, hsum);
                     } else { /* the last, partial step of the segment: lanes past `hi` play changes of no actor */
@@ -677,18 +639,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < PTX_AC; ++u) {
-#if PTX_ADM_AHEAD > 1
-                        h[u] = h_m[u];
-                        e0[u] = e0_m[u];
-                        e1[u] = e1_m[u];
-                        h_m[u] = h_n[u];
-                        e0_m[u] = e0_n[u];
-                        e1_m[u] = e1_n[u];
-#else
                         h[u] = h_n[u];
                         e0[u] = e0_n[u];
                         e1[u] = e1_n[u];
-#endif
                     }
                 }
 #undef PTX_ADM_LOAD
@@ -848,10 +801,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * actor are 1, 2, ... in log order" and "dependency (b, d) sits earlier in the log" one LDS read each.  Kept
          * deliberately plain (one change per thread and step, serial prefix by the leader). */
         uint32_t* first = ptx_alloc<uint32_t>(bp, na + 2); /* changes per actor -> first table slot of the actor */
-        uint16_t* tbl = ptx_alloc<uint16_t>(bp, C + 1);     /* (actor, seq) -> change index */
+        uint32_t* tbl = ptx_alloc<uint32_t>(bp, C + 1);     /* (actor, seq) -> index of the EARLIEST change that claims it (atomic minimum: which change a duplicate
+                                                               fails at must not depend on the order the threads run in; the reference throws at the later one) */
         PTX_BAIL_CAPACITY();
         PTX_FOR(a, na + 2) first[a] = 0;
-        PTX_FOR(c, C + 1) tbl[c] = 0xFFFFu;
+        PTX_FOR(c, C + 1) tbl[c] = 0xFFFFFFFFu;
         PTX_LEADER { H->cur[7] = 0; }
         PTX_SYNC();
         PTX_FOR(c, C) {
@@ -880,7 +834,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_FOR(c, C) {
             const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT, sq = c_env[(uint64_t)c * estride];
             const uint32_t f = first[a], cnt_a = first[a + 1] - f;
-            if (sq - 1u < cnt_a) tbl[f + sq - 1u] = (uint16_t)c; /* a second claimant of the slot is caught below */
+            if (sq - 1u < cnt_a) ptx_atomic_min(&tbl[f + sq - 1u], c); /* a later claimant of the slot is caught below */
         }
         PTX_SYNC();
         PTX_FOR(c, C) {
@@ -944,11 +898,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
     const uint32_t nw = (keyspace + 31) / 32;
     const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
-#if PTX_PARK_MLIST
     uint16_t* mlist = nullptr; /* allocated in P1's scratch, parked in HBM during P3 / P4, allocated again (and read back) when P5 starts */
-#else
-    uint16_t* mlist = ptx_alloc<uint16_t>(bp, K + 1); /* rows of the mark ops, grouped by type; [K] = spare slot */
-#endif
     uint32_t* maddbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 1); /* mark op k is an addMark (the tail phases need no look back at `action`) */
     /* element-side state: dead once the mark intervals are known (P5a), then reused as scratch of the tail phases */
     const uint32_t elem_lds = bp.off;
@@ -990,7 +940,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
         if (!small_keys) id_[u] = op_id[i_[u]];                             \
         ra_[u] = ref_a[i_[u]];                                              \
-        dra_[u] = PTX_KO == 4 ? ra_[u] : ref_a[di_[u]];                     \
+        dra_[u] = ref_a[di_[u]];                  \
     }
     /* ---- P1: ONE pass over the rows: id bitmaps, row lists per class ---- */
     {
@@ -999,17 +949,13 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         static_assert(PTX_U1 == 3, "three class bytes per dword; the fourth byte read belongs to the next thread's first row");
         uint64_t id[PTX_U1], id_n[PTX_U1];
         uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
-#if PTX_P1_AHEAD > 1
-        uint64_t id_m[PTX_U1]; /* the step in between */
-        uint32_t a4_m, mt4_m;
-#endif
         /* this thread's PTX_U1 consecutive rows of a step.  A wave whose rows all exist reads them from one address; the wave that
          * holds the end of the log clamps every row index (effects of the rows past the end are masked).  The two byte columns are
          * read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
 #define PTX_P1_LOAD(g_, id_, a_, mt_)                                       \
     {                                                                       \
         const uint32_t r0_ = (g_) * PTX_U1;                                 \
-        if (PTX_P1_WIDE && PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) {        \
+        if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) { /* one address, 16 + 8 bytes */ \
             PTX_P1_IDS(id_, op_id + r0_)                                    \
         } else {                                                            \
             _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {            \
@@ -1021,9 +967,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_P1_BYTES(mark_type, r0_, mt_)                                   \
     }
         PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a4, mt4) /* the first rows are on their way while the bitmaps are cleared */
-#if PTX_P1_AHEAD > 1
-        PTX_P1_LOAD(PTX_G_OF(1u, p1_steps), id_m, a4_m, mt4_m)
-#endif
         /* during this pass ib[w] = {ids of the inserts, ids of ALL ops (duplicate detection)}: one 8-byte LDS atomic per row */
         PTX_FOR(w, nw + 1) {
             PtxBitWord z;
@@ -1039,9 +982,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * land in a four-entry dump. */
         uint16_t* const lds16 = (uint16_t*)lds;
         uint16_t* dump = ptx_alloc<uint16_t>(bp, 4);
-#if PTX_PARK_MLIST
         mlist = ptx_alloc<uint16_t>(bp, K + 1);
-#endif
         PTX_BAIL_CAPACITY();
         const uint32_t i_at = (uint32_t)(ilist - lds16), d_at = (uint32_t)(dlist - lds16), m_at = (uint32_t)(mlist - lds16), dump_at = (uint32_t)(dump - lds16);
         const uint32_t k_delta = (uint32_t)(klist - ilist);   /* the key of an insert sits this far behind its list entry */
@@ -1107,31 +1048,18 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         for (uint32_t st = 0; st < p1_steps; ++st) {
             const uint32_t g = PTX_G_OF(st, p1_steps);
             if (PTX_WAVE_FIRST(g) >= p1_groups) continue; /* this wave has no row left in this step (wave-uniform) */
-            const uint32_t gn = PTX_G_OF(st + (uint32_t)PTX_P1_AHEAD, p1_steps);
+            const uint32_t gn = PTX_G_OF(st + 1u, p1_steps);
             PTX_P1_LOAD(gn, id_n, a4_n, mt4_n) /* later steps' rows are in flight while this step is processed */
             if (PTX_WAVE_FIRST(g) + PTX_WS <= p1_full) p1_rows(std::false_type(), g, PTX_U1);
             else p1_rows(std::true_type(), g, g * PTX_U1 < N ? (N - g * PTX_U1 < PTX_U1 ? N - g * PTX_U1 : PTX_U1) : 0u);
-#if PTX_P1_AHEAD > 1
-#pragma unroll
-            for (int u = 0; u < PTX_U1; ++u) {
-                id[u] = id_m[u];
-                id_m[u] = id_n[u];
-            }
-            a4 = a4_m;
-            mt4 = mt4_m;
-            a4_m = a4_n;
-            mt4_m = mt4_n;
-#else
 #pragma unroll
             for (int u = 0; u < PTX_U1; ++u) id[u] = id_n[u];
             a4 = a4_n;
             mt4 = mt4_n;
-#endif
         }
 #undef PTX_P1_LOAD
         if (err4 != 0u || ctr_hi >= ix.max_ctr || act_hi > ix.max_actor) ptx_atomic_or(&H->cur[7], 1u);
         PTX_SYNC();
-#if PTX_PARK_MLIST
         /* the mark list is complete: park it in the log's span rows (8 bytes per row of the log, written only by P6; K <= N).  Every thread reads back
          * in P5 exactly the words it stores here (the same PTX_FOR partition), so nothing but its own program order is relied on.  A header that
          * understates the mark rows parks junk: the census check below rejects that log before anything reads it. */
@@ -1141,10 +1069,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_FOR(w, K >> 1) park[w] = src[w];
             if (K & 1u) PTX_LEADER { ((uint16_t*)park)[K - 1u] = mlist[K - 1u]; }
         }
-#endif
-#ifndef PTX_NO_HOIST_P3A
         PTX_P3A_LOAD(0u, p3_i, p3_id, p3_ra, p3_di, p3_dra) /* the lists are complete: P3a's first step is on its way */
-#endif
         if (H->cur[7] != 0u) {
             /* some row is malformed (unknown action or mark type, op id of counter 0 or beyond the header's bounds): the first one
              * in log order is the log's error — the rare path, one row per thread and step.  The malformed rows were listed under
@@ -1204,9 +1129,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     bp.off = tree_lds;
     PTX_STAMP(2);
 
-#if PTX_PARK_MLIST && PTX_UNPARK_EARLY
-    uint32_t upf[PTX_UPF]; /* the thread's first words of the parked mark list, on their way while P3d runs */
-#endif
     /* ---- P3: causal tree of the inserts -> document position of every element ---- */
     {
         /* children per parent -> bucket starts -> bucket ends; 16-bit counters, two per atomically updated word */
@@ -1235,9 +1157,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             uint32_t i[PTX_U], i_n[PTX_U], di[PTX_U], di_n[PTX_U];
             uint64_t id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
             uint64_t dra[PTX_U], dra_n[PTX_U];
-#ifdef PTX_NO_HOIST_P3A
-            PTX_P3A_LOAD(0u, p3_i, p3_id, p3_ra, p3_di, p3_dra)
-#endif
 #pragma unroll
             for (int u = 0; u < PTX_U; ++u) { /* step 0 was loaded at the end of P1 */
                 i[u] = p3_i[u];
@@ -1394,16 +1313,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_SYNC();
         PTX_STAMP(4);
-#if PTX_PARK_MLIST && PTX_UNPARK_EARLY
-        {
-            const uint32_t* park = (const uint32_t*)(A.out_spans + base);
-#pragma unroll
-            for (int u = 0; u < (int)PTX_UPF; ++u) {
-                const uint32_t j = PTX_J_OF_U(0u, u, PTX_UPF);
-                upf[u] = j < (K >> 1) ? park[j] : 0u;
-            }
-        }
-#endif
         /* P3d: Euler tour.  Nodes: 0 = enter(HEAD), x+1 = enter(x), n+1+x = exit(x) for x in [0,n), and the
          * terminal node 2n+1.  weight 1 on enter(x): the suffix sum at enter(x) counts the elements from x
          * to the end of the document, so position(x) = n - suffix(enter(x)). */
@@ -1464,47 +1373,23 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
     uint16_t* rnk = par;
     bp.off = mark_lds; /* release the tree scratch */
-#if PTX_PARK_MLIST
     mlist = ptx_alloc<uint16_t>(bp, K + 1);
     PTX_BAIL_CAPACITY();
     {
         const uint32_t* park = (const uint32_t*)(A.out_spans + base);
         uint32_t* dst = (uint32_t*)mlist;
-#if PTX_UNPARK_EARLY
-        /* word j belongs to thread j mod T here as in the park loop: step 0 came in while P3d ran, the (rare) later steps are read now */
-        const uint32_t W = K >> 1, up_steps = PTX_JSTEPS_U(W, PTX_UPF);
-#pragma unroll
-        for (int u = 0; u < (int)PTX_UPF; ++u) {
-            const uint32_t j = PTX_J_OF_U(0u, u, PTX_UPF);
-            if (j < W) dst[j] = upf[u];
-        }
-#pragma nounroll
-        for (uint32_t st = 1; st < up_steps; ++st) {
-#pragma unroll
-            for (int u = 0; u < (int)PTX_UPF; ++u) {
-                const uint32_t j = PTX_J_OF_U(st, u, PTX_UPF);
-                if (j < W) dst[j] = park[j];
-            }
-        }
-#else
         PTX_FOR(w, K >> 1) dst[w] = park[w];
-#endif
         if (K & 1u) PTX_LEADER { mlist[K - 1u] = ((const uint16_t*)park)[K - 1u]; }
     }
     PTX_SYNC();
-#endif
     PTX_STAMP(5);
 
-    /* P5a's loads: the first step's gathers are issued here, ahead of P4 and the values pass (PTX_HOIST_MARK) */
+    /* P5a's loads: the first step's gathers are issued here, ahead of P4 and the values pass */
     const PtxMarkBlocks MB = ptx_mark_blocks(moff1, moff2, moff3, K, PTX_JB_CAP);
     const uint32_t m_steps = PTX_JB_STEPS(MB.B, PTX_UM);
     uint32_t kq[PTX_UM], kq_n[PTX_UM]; /* the thread's mark ops of a step (0xFFFFFFFF: none) */
     uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
     uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
-#if PTX_MARK_AHEAD > 1
-    uint32_t kq_m[PTX_UM], i_m[PTX_UM], sa_m[PTX_UM], sb_m[PTX_UM], pl_m[PTX_UM]; /* the step in between */
-    uint64_t ra_m[PTX_UM], rb_m[PTX_UM];
-#endif
     /* rows of this thread's mark ops of a step (list read, then the column gathers; the payload only of the comment ops — their
      * id —, the others' is not needed before P5b, and then only the winners') */
 #define PTX_MARK_LOAD(st_, kq_, i_, ra_, rb_, sa_, sb_, pl_)                \
@@ -1518,17 +1403,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
         rb_[u] = ref_b[i_[u]];                                              \
-        ra_[u] = PTX_KO == 2 ? rb_[u] : ref_a[i_[u]];                       \
+        ra_[u] = ref_a[i_[u]];                    \
         sa_[u] = A.side_a[base + i_[u]];                                    \
         sb_[u] = A.side_b[base + i_[u]];                                    \
-        if (pl_[u] && PTX_KO != 3) pl_[u] = payload[i_[u]];                 \
+        if (pl_[u]) pl_[u] = payload[i_[u]];                 \
     }
-#if PTX_HOIST_MARK
     PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl)
-#if PTX_MARK_AHEAD > 1
-    PTX_MARK_LOAD(1u, kq_m, i_m, ra_m, rb_m, sa_m, sb_m, pl_m)
-#endif
-#endif
     /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = nwe; /* bit positions 0..n by document position */
     PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
@@ -1575,7 +1455,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
         w_[u] = alive[r_[u] >> 5];                                          \
         v_[u] = 0;                                                          \
-        if (PTX_KO != 5 && PTX_J_OF(st_, u) < n && ((w_[u].bits >> (r_[u] & 31)) & 1u)) v_[u] = payload[row_[u] < N ? row_[u] : N - 1u]; \
+        if (PTX_J_OF(st_, u) < n && ((w_[u].bits >> (r_[u] & 31)) & 1u)) v_[u] = payload[row_[u] < N ? row_[u] : N - 1u]; \
     }
         PTX_VAL_LOAD(0u, r, row, w, v)
 #pragma nounroll
@@ -1603,15 +1483,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         ptx_digest_flush(H, h1, h2);
     }
     {
-#if !PTX_HOIST_MARK
-    PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl)
-#if PTX_MARK_AHEAD > 1
-    PTX_MARK_LOAD(1u, kq_m, i_m, ra_m, rb_m, sa_m, sb_m, pl_m)
-#endif
-#endif
 #pragma nounroll
     for (uint32_t st = 0; st < m_steps; ++st) {
-        PTX_MARK_LOAD(st + (uint32_t)PTX_MARK_AHEAD, kq_n, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* later steps' gathers are in flight while this step is processed */
+        PTX_MARK_LOAD(st + 1u, kq_n, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* later steps' gathers are in flight while this step is processed */
 #pragma unroll
         for (int u = 0; u < (int)PTX_UM; ++u)
             if (kq[u] != 0xFFFFFFFFu) {
@@ -1660,22 +1534,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
 #pragma unroll
         for (int u = 0; u < (int)PTX_UM; ++u) {
-#if PTX_MARK_AHEAD > 1
-            kq[u] = kq_m[u];
-            kq_m[u] = kq_n[u];
-            i[u] = i_m[u];
-            ra[u] = ra_m[u];
-            rb[u] = rb_m[u];
-            sa[u] = sa_m[u];
-            sb[u] = sb_m[u];
-            pl[u] = pl_m[u];
-            i_m[u] = i_n[u];
-            ra_m[u] = ra_n[u];
-            rb_m[u] = rb_n[u];
-            sa_m[u] = sa_n[u];
-            sb_m[u] = sb_n[u];
-            pl_m[u] = pl_n[u];
-#else
             kq[u] = kq_n[u];
             i[u] = i_n[u];
             ra[u] = ra_n[u];
@@ -1683,7 +1541,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             sa[u] = sa_n[u];
             sb[u] = sb_n[u];
             pl[u] = pl_n[u];
-#endif
         }
     }
 #undef PTX_MARK_LOAD
@@ -1832,7 +1689,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         idq[u] = 0;
                         if (l < h && PTX_TYPE_OF(k) != PTX_MARK_COMMENT) {
                             const uint32_t r = mlist[k];
-                            idq[u] = PTX_KO == 1 ? (uint64_t)r << 32 : op_id[r < N ? r : N - 1u];
+                            idq[u] = op_id[r < N ? r : N - 1u];
                         }
                     }
 #pragma unroll

@@ -329,9 +329,9 @@ struct ptx_ctx {
     std::string err;
     int cu_count = 0;
     size_t max_lds = 0;
-    int force_threads = 0; /* PTX_THREADS env override (tuning) */
-    int force_lds = 0;     /* PTX_LDS_BYTES env override (tuning) */
-    int stop_after = 0;    /* PTX_STOP_AFTER env (diagnostic): truncate the kernel after a phase, for per-phase PMC deltas */
+    int force_threads = 0; /* ptx_set_launch_shape: threads per log (0 = the library's choice) */
+    int force_lds = 0;     /* ptx_set_launch_shape: LDS window per log (0 = the library's choice) */
+    int stop_after = 0;    /* -DPTX_DIAG builds only (ptx_diag_stop_after): truncate the diagnostic kernel after a phase, for per-phase PMC deltas */
     uint32_t flags = 0;
     unsigned long long* clocks = nullptr; /* device [PTX_NCLK], non-null only while ptx_merge_phase_cycles runs */
 };
@@ -514,8 +514,6 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     ctx->flags = flags;
     ctx->cu_count = prop.multiProcessorCount;
     ctx->max_lds = 160 * 1024;
-    if (const char* s = getenv("PTX_THREADS")) ctx->force_threads = atoi(s);
-    if (const char* s = getenv("PTX_LDS_BYTES")) ctx->force_lds = atoi(s);
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
@@ -525,9 +523,8 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     }
     ctx->own_stream = ctx->stream;
     /* one workgroup may use the CU's whole 160 KiB of LDS */
-    if (const char* sv = getenv("PTX_STOP_AFTER")) ctx->stop_after = atoi(sv);
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -556,6 +553,25 @@ void ptx_destroy(ptx_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
+
+ptx_status ptx_set_launch_shape(ptx_ctx* ctx, uint32_t threads_per_log, uint32_t lds_bytes_per_log) {
+    if (!ctx) return PTX_ERR_INVALID_ARG;
+    if (threads_per_log && (threads_per_log % 64u || threads_per_log > PTX_MAX_THREADS)) return fail(ctx, PTX_ERR_INVALID_ARG, "threads per log: a multiple of 64 up to 1024");
+    if (lds_bytes_per_log > ctx->max_lds) return fail(ctx, PTX_ERR_INVALID_ARG, "LDS window beyond the CU's 160 KiB");
+    ctx->force_threads = (int)threads_per_log;
+    ctx->force_lds = (int)lds_bytes_per_log;
+    return PTX_OK;
+}
+
+#ifdef PTX_DIAG
+/* diagnostic builds only (tools/pmc_phases.sh, tools/trunc_sweep.sh; never declared in include/peritext_hip.h, never in the product
+ * library): the diagnostic kernel leaves after the phase with stamp index k — its results are then WRONG by design */
+ptx_status ptx_diag_stop_after(ptx_ctx* ctx, uint32_t k) {
+    if (!ctx) return PTX_ERR_INVALID_ARG;
+    ctx->stop_after = (int)k;
+    return PTX_OK;
+}
+#endif
 
 uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx) {
     /* largest N with lds_need(N, worst split) <= LDS; conservative closed form: ~33 B per row */
@@ -1072,6 +1088,9 @@ struct ptx_comm {
     uint64_t *padded = nullptr, *mine = nullptr, *d_first = nullptr;
     uint32_t* d_counts = nullptr;
     uint32_t width = 0;
+    std::vector<uint32_t> counts_up; /* the counts d_first / d_counts were last uploaded for: a steady loop (the same shard sizes step after
+                                        step) uploads them once and has no host synchronisation inside the step */
+    std::vector<uint64_t> first_up;
 };
 
 ptx_status ptx_comm_unique_id(ptx_ctx* ctx, uint8_t id[PTX_COMM_ID_BYTES]) {
@@ -1119,6 +1138,9 @@ void ptx_comm_destroy(ptx_ctx* ctx, ptx_comm* c) {
     delete c;
 }
 
+uint32_t ptx_comm_n_ranks(const ptx_comm* c) { return c ? c->n_ranks : 0u; }
+uint32_t ptx_comm_rank(const ptx_comm* c) { return c ? c->rank : 0u; }
+
 ptx_status ptx_allgather_digests(ptx_ctx* ctx, ptx_comm* c, const ptx_dresult* r, const uint32_t* counts, uint64_t* out_device) {
     if (!ctx || !c || !r || !counts || !out_device) return PTX_ERR_INVALID_ARG;
     if (counts[c->rank] != r->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_allgather_digests: counts[rank] must be the logs of this rank's result");
@@ -1130,7 +1152,7 @@ ptx_status ptx_allgather_digests(ptx_ctx* ctx, ptx_comm* c, const ptx_dresult* r
         equal = equal && counts[k] == counts[0];
     }
     if (width == 0) return PTX_OK;
-    if (equal) {
+    if (equal && !(ctx->flags & PTX_FLAG_PAD_GATHER)) {
         /* the digests go out packed from a staging block of this rank's slice of the output itself */
         uint64_t* mine = out_device + (uint64_t)c->rank * width * 2;
         hipLaunchKernelGGL(ptx_pack_digests_kernel, dim3((width + 255) / 256), dim3(256), 0, ctx->stream, r->logs, 0u, width, mine);
@@ -1149,11 +1171,15 @@ ptx_status ptx_allgather_digests(ptx_ctx* ctx, ptx_comm* c, const ptx_dresult* r
         if (!c->d_counts) PTX_HIP(ctx, dalloc(&c->d_counts, (uint64_t)c->n_ranks));
         c->width = width;
     }
-    std::vector<uint64_t> first(c->n_ranks, 0);
-    for (uint32_t k = 1; k < c->n_ranks; ++k) first[k] = first[k - 1] + counts[k - 1];
-    PTX_HIP(ctx, hipMemcpyAsync(c->d_first, first.data(), (size_t)c->n_ranks * 8, hipMemcpyHostToDevice, ctx->stream));
-    PTX_HIP(ctx, hipMemcpyAsync(c->d_counts, counts, (size_t)c->n_ranks * 4, hipMemcpyHostToDevice, ctx->stream));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); /* `first` is a stack-local vector */
+    if (c->counts_up.size() != c->n_ranks || memcmp(c->counts_up.data(), counts, (size_t)c->n_ranks * 4) != 0) {
+        /* new shard sizes (the first call, normally): block starts and counts go to the device once; the host copies live in the communicator */
+        if (!c->counts_up.empty()) PTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); /* an earlier upload may still be reading them */
+        c->counts_up.assign(counts, counts + c->n_ranks);
+        c->first_up.assign(c->n_ranks, 0);
+        for (uint32_t k = 1; k < c->n_ranks; ++k) c->first_up[k] = c->first_up[k - 1] + counts[k - 1];
+        PTX_HIP(ctx, hipMemcpyAsync(c->d_first, c->first_up.data(), (size_t)c->n_ranks * 8, hipMemcpyHostToDevice, ctx->stream));
+        PTX_HIP(ctx, hipMemcpyAsync(c->d_counts, c->counts_up.data(), (size_t)c->n_ranks * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     PTX_HIP(ctx, hipMemsetAsync(c->mine, 0, (size_t)c->width * 16, ctx->stream));
     if (r->n_logs) {
         hipLaunchKernelGGL(ptx_pack_digests_kernel, dim3((r->n_logs + 255) / 256), dim3(256), 0, ctx->stream, r->logs, 0u, r->n_logs, c->mine);

@@ -30,16 +30,6 @@
 #pragma once
 #include "merge_core.h"
 
-#ifndef PTX_REPLAY_V1
-#define PTX_REPLAY_V1 0 /* 1: the replay as measured at 540 M ops/s (profiles/r02_v_*): winners as rows whatever the id space, last-defined-slot search through an LDS atomic
-                           (the experimental build exp_nopark, i.e. the round's previously measured build, is made with it for the bench's same-call comparison) */
-#endif
-#ifndef PTX_REPLAY_SEARCH
-#define PTX_REPLAY_SEARCH 0 /* how the closest defined slot to the left is found (one wave per log): 0 = every lane raises an LDS word with an atomic maximum, which is read
-                               back (the measured kernel); 1 = every lane keeps the best of its words, a wave-wide maximum by register shuffles (ptx_wave_max: six dependent
-                               bpermutes); 2 = a ballot over "my word has a bit" from the top chunk down and ONE readlane of the winning lane's word (ptx_last_set_below).
-                               1 and 2 are experimental builds (exp_replay_wavemax, exp_replay_ballot): the bench times them and compares their streams with the product's */
-#endif
 #define PTX_SLOT_NONE 0xFFFFu /* start never matches / end never reached */
 #define PTX_RCHUNK 64u
 enum { PTX_RK_SKIP = 0, PTX_RK_MAKELIST = 1, PTX_RK_INSERT = 2, PTX_RK_DELETE = 3, PTX_RK_MARK = 4 };
@@ -134,7 +124,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
      * 65 535, the slot holds the winner's key + 1 — compareOpIds is then a compare of two LDS values — instead of its row (whose op id would have to
      * be fetched from HBM for every slot of every mark op: a dependent round trip in a sequential replay).  Links keep the row: their url is read through it. */
     const uint32_t na1 = hd.max_actor + 1u;
-    const bool key_mode = !PTX_REPLAY_V1 && (uint64_t)(hd.max_counter + 1ull) * na1 <= 65535ull;
+    const bool key_mode = (uint64_t)(hd.max_counter + 1ull) * na1 <= 65535ull;
 
     PtxBump bp;
     bp.base = lds;
@@ -205,35 +195,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
 
     /* last defined slot strictly below `lim` -> out_ = slot + 1 (0 = none), the same in every lane; every thread calls it.  The workgroup is ONE
      * wave: every lane keeps the best of its own words and a wave-wide maximum (register shuffles) makes it common — no LDS atomic, no read back */
-#if !defined(PTX_EMU) && PTX_REPLAY_SEARCH != 0
-    static_assert(kThreads == 64u, "the replay's reductions are wave-wide");
-#endif
-#if PTX_REPLAY_SEARCH == 2
 #define PTX_LAST_DEFINED_BELOW(lim_, out_) const uint32_t out_ = ptx_last_set_below(defined, (lim_));
-#elif PTX_REPLAY_V1 || PTX_REPLAY_SEARCH == 0
-#define PTX_LAST_DEFINED_BELOW(lim_, out_)                                                      \
-    PTX_LEADER { H->tmp = 0; }                                                                  \
-    PTX_SYNC_T();                                                                               \
-    PTX_FOR(w_, ((lim_) + 31u) >> 5) {                                                          \
-        uint32_t m_ = defined[w_];                                                              \
-        if ((w_ << 5) + 32u > (lim_)) m_ &= (1u << ((lim_)&31u)) - 1u;                          \
-        if (m_) ptx_atomic_max(&H->tmp, (w_ << 5) + (31u - (uint32_t)__builtin_clz(m_)) + 1u);  \
-    }                                                                                           \
-    PTX_SYNC_T();                                                                               \
-    const uint32_t out_ = H->tmp;
-#else
-#define PTX_LAST_DEFINED_BELOW(lim_, out_)                                                      \
-    uint32_t out_ = 0;                                                                          \
-    {                                                                                           \
-        PTX_FOR(w_, ((lim_) + 31u) >> 5) {                                                      \
-            uint32_t m_ = defined[w_];                                                          \
-            if ((w_ << 5) + 32u > (lim_)) m_ &= (1u << ((lim_)&31u)) - 1u;                      \
-            const uint32_t c_ = m_ ? (w_ << 5) + (31u - (uint32_t)__builtin_clz(m_)) + 1u : 0u; \
-            out_ = c_ > out_ ? c_ : out_;                                                       \
-        }                                                                                       \
-        out_ = ptx_wave_max(out_);                                                              \
-    }
-#endif
 
     /* make slot s_ a defined one: its state is that of the closest defined slot to the left (peritext.ts:176) */
 #define PTX_DEFINE_SLOT(s_)                                                                     \

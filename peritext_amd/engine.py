@@ -72,6 +72,10 @@ class Engine:
         if st != 0:
             raise PtxError(st, (self.lib.ptx_last_error(self.ctx) or b"").decode())
 
+    def set_launch_shape(self, threads_per_log=0, lds_bytes_per_log=0):
+        """Threads per log / LDS window per log of the batches made resident after this call (0 = the library's choice)."""
+        self._check(self.lib.ptx_set_launch_shape(self.ctx, threads_per_log, lds_bytes_per_log))
+
     def close(self):
         if self.ctx:
             self.lib.ptx_destroy(self.ctx)
@@ -234,6 +238,8 @@ class Engine:
     def allgather_digests(self, comm, dresult, counts, out_device_ptr):
         """Digests of every rank's result -> [sum(counts), 2] u64 at `out_device_ptr` (rank-major), on the engine's stream."""
         c = np.ascontiguousarray(counts, dtype=np.uint32)
+        if len(c) != self.lib.ptx_comm_n_ranks(comm):
+            raise ValueError("allgather_digests: counts must hold one entry per rank of the communicator (%d)" % self.lib.ptx_comm_n_ranks(comm))
         self._check(self.lib.ptx_allgather_digests(self.ctx, comm, dresult, c.ctypes.data_as(abi.u32p), C.c_void_p(out_device_ptr)))
 
     def count_converged_digests(self, digests_device_ptr, n_logs, replicas, count_device_ptr):

@@ -59,6 +59,7 @@ struct Lib {
     ptx_status (*comm_unique_id)(ptx_ctx*, uint8_t*) = nullptr;
     ptx_status (*comm_init)(ptx_ctx*, const uint8_t*, uint32_t, uint32_t, ptx_comm**) = nullptr;
     void (*comm_destroy)(ptx_ctx*, ptx_comm*) = nullptr;
+    uint32_t (*comm_n_ranks)(const ptx_comm*) = nullptr;
     ptx_status (*allgather_digests)(ptx_ctx*, ptx_comm*, const ptx_dresult*, const uint32_t*, uint64_t*) = nullptr;
     ptx_status (*count_converged_digests)(ptx_ctx*, const uint64_t*, uint64_t, uint32_t, uint64_t*) = nullptr;
     ptx_status (*result_download_logs)(ptx_ctx*, const ptx_dresult*, ptx_log_result*, uint32_t) = nullptr;
@@ -111,7 +112,7 @@ napi_value Open(napi_env env, napi_callback_info info) {
                   sym(L.merge, "ptx_merge") && sym(L.sync, "ptx_sync") && sym(L.result_download, "ptx_result_download") &&
                   sym(L.replay_patches, "ptx_replay_patches") && sym(L.patches_free, "ptx_patches_free") && sym(L.generate, "ptx_generate") &&
                   sym(L.gen_info_free, "ptx_gen_info_free") && sym(L.batch_download, "ptx_batch_download") && sym(L.host_batch_free, "ptx_host_batch_free") && sym(L.change, "ptx_change") &&
-                  sym(L.comm_unique_id, "ptx_comm_unique_id") && sym(L.comm_init, "ptx_comm_init") && sym(L.comm_destroy, "ptx_comm_destroy") &&
+                  sym(L.comm_unique_id, "ptx_comm_unique_id") && sym(L.comm_init, "ptx_comm_init") && sym(L.comm_destroy, "ptx_comm_destroy") && sym(L.comm_n_ranks, "ptx_comm_n_ranks") &&
                   sym(L.allgather_digests, "ptx_allgather_digests") && sym(L.count_converged_digests, "ptx_count_converged_digests") &&
                   sym(L.result_download_logs, "ptx_result_download_logs") && sym(L.root_map, "ptx_root_map") && sym(L.root_maps_free, "ptx_root_maps_free") && sym(L.device_alloc, "ptx_device_alloc") && sym(L.device_free, "ptx_device_free") &&
                   sym(L.device_read, "ptx_device_read") && sym(L.resolve_cursors, "ptx_resolve_cursors");
@@ -694,6 +695,7 @@ napi_value MergeAndGather(napi_env env, napi_callback_info info) {
     napi_value ab;
     if (napi_get_typedarray_info(env, argv[3], &type, &n_ranks, &counts, &ab, &offset) != napi_ok || type != napi_uint32_array || n_ranks == 0)
         return throw_msg(env, "mergeAndGather: counts must be a Uint32Array with one entry per rank");
+    if (n_ranks != L.comm_n_ranks((const ptx_comm*)cp)) return throw_msg(env, "mergeAndGather: counts.length differs from the communicator's rank count");
     uint32_t replicas = 1;
     napi_get_value_uint32(env, argv[4], &replicas);
     uint64_t total = 0;

@@ -187,6 +187,11 @@ function encodeDocs(docs, opts) {
                             row.markType = op.action === "makeMap" ? MAPV.MAP : op.action === "makeList" ? MAPV.LIST : MAPV.SCALAR
                             if (op.action === "set") row.payload = intern(mapValues, mapValueIx, JSON.stringify(op.value === undefined ? null : op.value))
                         }
+                    } else if (op.action === "addMark" || op.action === "removeMark" || op.elemId !== undefined || op.insert) {
+                        /* a list op whose object is not the document's text list: the reference throws RangeError("Object does not exist")
+                         * (micromerge.ts:538) when there is no such object yet, or edits a second list object.  This engine holds ONE text list
+                         * per document (the first root makeList of key "text"; INTEGRATION.md): rejected here, never a silent no-op */
+                        throw new RangeError("list op " + String(op.opId) + " on an object that is not the document's text list (one text list per document is supported)")
                     }
                     for (const k of Object.keys(rows)) rows[k].push(row[k])
                     nrows++

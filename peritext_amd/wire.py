@@ -105,14 +105,18 @@ class Batch:
         n = self.n_ops
         offs = [self.log_off[:-1] + k * n for k in range(copies)]
         log_off = np.concatenate(offs + [np.array([copies * n], dtype=np.uint64)]).astype(np.uint64)
-        nc = int(self.chg_off[-1])
-        chg_off = np.concatenate([self.chg_off[:-1] + k * nc for k in range(copies)] + [np.array([copies * nc], dtype=np.uint64)]).astype(np.uint64)
         rep = lambda a: np.tile(a, copies)  # noqa: E731
+        if self.chg_off is None:  # a batch without the Change envelope (e.g. downloaded from a wrapped device batch)
+            chg_off = chg_hdr = chg_env = None
+        else:
+            nc = int(self.chg_off[-1])
+            chg_off = np.concatenate([self.chg_off[:-1] + k * nc for k in range(copies)] + [np.array([copies * nc], dtype=np.uint64)]).astype(np.uint64)
+            chg_hdr, chg_env = rep(self.chg_hdr), rep(self.chg_env)
         hdr = None if self.log_hdr is None else np.tile(self.log_hdr, copies)
         return Batch(
             log_off, rep(self.op_id), rep(self.ref_a), rep(self.ref_b), rep(self.payload), rep(self.action),
-            rep(self.mark_type), rep(self.side_a), rep(self.side_b), chg_off, rep(self.chg_hdr), rep(self.chg_env), self.max_actors, hdr, self.values, self.urls,
-            self.log_doc * copies, self.doc_actors, self.doc_comments,
+            rep(self.mark_type), rep(self.side_a), rep(self.side_b), chg_off, chg_hdr, chg_env, self.max_actors, hdr, self.values, self.urls,
+            self.log_doc * copies, self.doc_actors, self.doc_comments, keys=self.keys, map_values=self.map_values,
         )
 
 
@@ -281,6 +285,11 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
                             row["mark_type"] = abi.MAPV_MAP if act == "makeMap" else abi.MAPV_LIST if act == "makeList" else abi.MAPV_SCALAR
                             if act == "set":
                                 row["payload"] = intern(mvals, mval_ix, json.dumps(op.get("value"), sort_keys=True, ensure_ascii=False, separators=(",", ":")))
+                    elif act in ("addMark", "removeMark") or "elemId" in op or op.get("insert"):
+                        # A list op whose object is not the document's text list: the reference throws RangeError("Object does not exist")
+                        # (micromerge.ts:538) when no such object exists yet, or edits a second list object.  This engine holds ONE text
+                        # list per document (the first root makeList of key "text"): rejected here, never a silent no-op.
+                        raise ValueError("list op %s on object %r, which is not the document's text list (one text list per document is supported)" % (op.get("opId"), obj))
                     for k, v in row.items():
                         cols[k].append(v)
                     nrows += 1
@@ -807,7 +816,7 @@ def save_batch(path, batch):
 
     meta = {"format": "peritext-soa-oplog", "abi": abi.PTX_ABI_VERSION, "max_actors": batch.max_actors, "values": batch.values, "urls": batch.urls, "keys": batch.keys, "map_values": batch.map_values,
             "log_doc": batch.log_doc, "doc_actors": batch.doc_actors, "doc_comments": batch.doc_comments}
-    arrays = {k: getattr(batch, k) for k in _COLUMNS}
+    arrays = {k: getattr(batch, k) for k in _COLUMNS if getattr(batch, k) is not None}  # an envelope-less batch has no chg_* columns
     if batch.log_hdr is not None:
         arrays["log_hdr"] = batch.log_hdr
     np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta).encode("utf-8"), dtype=np.uint8), **arrays)
@@ -820,7 +829,7 @@ def load_batch(path):
         meta = json.loads(bytes(z["meta"]).decode("utf-8"))
         if meta.get("format") != "peritext-soa-oplog" or meta.get("abi") != abi.PTX_ABI_VERSION:
             raise ValueError("not a peritext SoA op-log file of ABI %d" % abi.PTX_ABI_VERSION)
-        cols = {k: z[k] for k in _COLUMNS}
+        cols = {k: (z[k] if k in z.files else None) for k in _COLUMNS}
         hdr = z["log_hdr"] if "log_hdr" in z.files else None
     return Batch(log_hdr=hdr, max_actors=int(meta["max_actors"]), values=meta["values"], urls=meta["urls"], log_doc=meta["log_doc"],
                  doc_actors=meta["doc_actors"], doc_comments=meta["doc_comments"], keys=meta.get("keys", []), map_values=meta.get("map_values", []), **cols)

@@ -8,6 +8,7 @@
  * libperitext_hip.so and exports nothing the product ABI declares.
  */
 #define PTX_EMU 1
+#define PTX_PLATFORM_HEADER "../../tests/emu/ptx_platform_emu.h" /* resolved from peritext_amd/csrc/, where the #include stands */
 #include <stdlib.h>
 #include <string.h>
 int ptx_emu_reverse = 0;

@@ -393,6 +393,34 @@ def test_many_actor_documents_admission_table_path():
 
 
 @pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+@pytest.mark.parametrize("reverse", [0, 1, 2])
+def test_many_actor_duplicate_seq_fails_at_the_later_change(reverse):
+    """two changes of one actor carrying the same seq in a document of more than three actors (the table path).  The
+    reference admits the first and throws at the second (micromerge.ts:501-504): status AND failing row must not depend on the
+    order the threads claim the (actor, seq) slot in."""
+    gen = H.oracle_gen("mini", 1, 5, None, 6)
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    assert batch.max_actors > 4
+    es = abi.env_stride(batch.max_actors)
+    env = batch.chg_env.copy().reshape(-1, es)
+    log = 1
+    c0, c1 = int(batch.chg_off[log]), int(batch.chg_off[log + 1])
+    actors = [int(a) for a in batch.chg_actor[c0:c1]]
+    a = max(set(actors), key=actors.count)
+    mine = [c0 + k for k, x in enumerate(actors) if x == a]
+    assert len(mine) >= 3
+    first, later = mine[0], mine[2]
+    env[later, 0] = env[first, 0]  # the third change of the actor claims seq 1 again
+    batch.chg_env = env.reshape(-1)
+    res = H.emu_merge(batch, admission=True, reverse=reverse)
+    assert int(res.logs["status"][log]) == abi.ERR_SEQ_GAP
+    nops = [int(x) for x in batch.chg_nops[c0:c1]]
+    want_row = sum(nops[: later - c0])
+    assert int(res.logs["reserved"][log, 1]) == want_row
+    assert all(int(res.logs["status"][l]) == 0 for l in range(batch.n_logs) if l != log)
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
 def test_cursors_from_elem_rank():
     """getCursor / resolveCursor (micromerge.ts:465-477) resolved on the host from the elem_rank column (document
     position + tombstone flag) — every visible index and every element ever inserted, against the oracle."""
@@ -446,6 +474,28 @@ def test_batch_file_round_trip(tmp_path):
     r1, r2 = H.emu_merge(batch, admission=True), H.emu_merge(back, admission=True)
     assert (r1.logs["digest"] == r2.logs["digest"]).all() and (r2.logs["status"] == 0).all()
     assert wire.decode_spans(back, r2, 0) == wire.decode_spans(batch, r1, 0)
+
+
+def test_batch_file_round_trip_without_envelope_and_tiled_tables(tmp_path):
+    """a batch without the Change envelope (what download_batch returns for a wrapped device batch) saves and loads; a
+    tiled batch keeps the key / map-value tables its map rows decode against."""
+    import dataclasses
+
+    gen = _load("ptxgen_mini.json")
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    bare = dataclasses.replace(batch, chg_off=None, chg_hdr=None, chg_env=None)
+    p = str(tmp_path / "bare.npz")
+    wire.save_batch(p, bare)
+    back = wire.load_batch(p)
+    assert back.chg_off is None and back.chg_hdr is None and back.chg_env is None
+    assert (back.op_id == batch.op_id).all() and (back.log_off == batch.log_off).all()
+    r = H.emu_merge(back)
+    assert (r.logs["status"] == 0).all() and (r.logs["digest"] == H.emu_merge(batch).logs["digest"]).all()
+    t2 = bare.tile(2)
+    assert t2.chg_off is None and t2.n_logs == 2 * batch.n_logs
+    with_maps = dataclasses.replace(batch, keys=["text", "title"], map_values=['"x"'])
+    t3 = with_maps.tile(3)
+    assert t3.keys == ["text", "title"] and t3.map_values == ['"x"']
 
 
 @pytest.mark.parametrize("name", GOLDEN_GEN)

@@ -239,16 +239,14 @@ SHAPE_FIXTURES = ["ptxgen_config4_600.json", "ptxgen_rich_2600.json", "ptxgen_co
 
 @pytest.mark.parametrize("lds", [0, 48 * 1024, 160 * 1024])
 @pytest.mark.parametrize("threads", [64, 128, 192, 256, 512])
-def test_every_launch_shape(threads, lds, monkeypatch):
+def test_every_launch_shape(threads, lds):
     """The merge kernel under every workgroup size the library ever picks (and the two LDS windows of config #5 / the CU
     maximum), with and without causal admission: reference-made fixtures incl. the full 8 192-op config-5 log, bit-exact."""
     from peritext_amd.engine import Engine
 
-    monkeypatch.setenv("PTX_THREADS", str(threads))
-    if lds:
-        monkeypatch.setenv("PTX_LDS_BYTES", str(lds))
     for flags in (0, abi.FLAG_NO_ADMISSION):
         with Engine(0, flags=flags) as e:
+            e.set_launch_shape(threads, lds)
             for name in SHAPE_FIXTURES:
                 g = _load(name)
                 batch = wire.encode_docs([d["logs"] for d in g["docs"]])
@@ -290,13 +288,13 @@ def test_default_shapes_cover_256_and_512_threads(eng):
         H.check_generated(g, eng.apply_materialize)
 
 
-def test_capacity_status_when_the_lds_window_is_too_small(monkeypatch):
+def test_capacity_status_when_the_lds_window_is_too_small():
     from peritext_amd.engine import Engine
 
-    monkeypatch.setenv("PTX_LDS_BYTES", "2048")
     g = _load("ptxgen_config4_600.json")
     batch = wire.encode_docs([g["docs"][0]["logs"]])
     with Engine(0) as e:
+        e.set_launch_shape(0, 2048)
         res = e.apply_materialize(batch)
     assert (res.logs["status"] == abi.ERR_CAPACITY).all()
 

@@ -73,6 +73,24 @@ def test_js_encoder_matches_python_encoder_on_map_ops(tmp_path):
     assert int((b.action == abi.ACT_MAPSET).sum()) > 10 and int((b.action == abi.ACT_MAPDEL).sum()) > 3
 
 
+@needs_node
+def test_encoders_reject_list_ops_on_objects_that_are_not_the_text_list(tmp_path):
+    """an insert / delete / mark whose `obj` is not the document's text list (an op before the makeList, an op on a second
+    list object) must not become a silent no-op row: the reference throws RangeError("Object does not exist") (micromerge.ts:538)
+    or edits the other list; both encoders reject it."""
+    mk = {"actor": "a", "seq": 1, "deps": {}, "startOp": 1, "ops": [{"opId": "1@a", "action": "makeList", "obj": None, "key": "text"}]}
+    stray = {"actor": "a", "seq": 2, "deps": {}, "startOp": 2, "ops": [{"opId": "2@a", "action": "set", "obj": "9@zz", "elemId": None, "insert": True, "value": "x"}]}
+    early = {"actor": "a", "seq": 1, "deps": {}, "startOp": 1,
+             "ops": [{"opId": "1@a", "action": "addMark", "obj": "7@a", "markType": "strong", "start": {"type": "before", "elemId": "2@a"}, "end": {"type": "before", "elemId": "3@a"}}]}
+    for log in ([mk, stray], [early]):
+        with pytest.raises(ValueError, match="not the document's text list"):
+            wire.encode_docs([[log]])
+        p = tmp_path / "bad.json"
+        p.write_text(json.dumps({"docs": [{"logs": [log]}]}))
+        r = subprocess.run([H.NODE, DRIVER, "encode", str(p)], cwd=H.ROOT, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "not the document's text list" in (r.stdout + r.stderr)
+
+
 @pytest.mark.gpu
 @needs_node
 @needs_addon

@@ -92,17 +92,14 @@ def main():
     flags = abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0)
     variants = [("product build", None, 0)]
     variants += [(os.path.basename(p)[:-3], p, 0) for p in sorted(glob.glob(os.path.join(ROOT, "peritext_amd", "lib", "exp_*.so")))]
-    variants += [("product build, PTX_THREADS=%d" % int(t), None, int(t)) for t in args.threads.split(",") if t]
+    variants += [("product build, %d threads per log" % int(t), None, int(t)) for t in args.threads.split(",") if t]
     rows, ref = [], None
     for name, lib, threads in variants:
         row = {"name": name}
         try:
+            e = Engine(args.device, flags=flags, lib_path=lib)
             if threads:
-                os.environ["PTX_THREADS"] = str(threads)
-            try:
-                e = Engine(args.device, flags=flags, lib_path=lib)
-            finally:
-                os.environ.pop("PTX_THREADS", None)
+                e.set_launch_shape(threads, 0)
             db, _ = e.generate(*gen_args, args.docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
             dr = e.alloc_result(db)
             e.merge(db, dr)

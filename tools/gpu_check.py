@@ -24,9 +24,8 @@ def main():
     names = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json", "ptxgen_config4_600.json", "ptxgen_rich_700.json", "ptxgen_rich_2600.json"]
     for var in args.variants.split(","):
         for t in args.threads.split(","):
-            os.environ["PTX_VARIANT"] = var
-            os.environ["PTX_THREADS"] = t
             eng = Engine(0, lib_path=lib)
+            eng.set_launch_shape(int(t), 0)
             for name in names:
                 gen = json.load(open(os.path.join(H.GOLDEN, name)))
                 try:

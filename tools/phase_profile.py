@@ -20,8 +20,9 @@ def main():
     ap.add_argument("--config", default="config4")
     ap.add_argument("--docs", type=int, default=8192)
     ap.add_argument("--ops", type=int, default=None)
-    ap.add_argument("--threads", default="0", help="PTX_THREADS values to sweep (0 = the library's own choice)")
+    ap.add_argument("--threads", default="0", help="threads per log to sweep (0 = the library's own choice)")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--stop-after", type=int, default=0, help="diagnostic builds (-DPTX_DIAG): truncate the kernel after the phase with this stamp index")
     ap.add_argument("--lib", default=None, help="experimental build of libperitext_hip.so")
     ap.add_argument("--no-phases", action="store_true")
     ap.add_argument("--no-check", action="store_true")
@@ -32,9 +33,13 @@ def main():
         args.lib = os.path.join(ROOT, args.lib)
     c = workloads.gen_config(args.config, ops=args.ops)
     for t in [int(x) for x in args.threads.split(",")]:
-        if t:
-            os.environ["PTX_THREADS"] = str(t)
         eng = Engine(0, flags=args.flags, lib_path=args.lib)
+        if t:
+            eng.set_launch_shape(t, 0)
+        if args.stop_after:  # -DPTX_DIAG builds only (the symbol is not part of the ABI): the diagnostic kernel leaves after a phase
+            import ctypes
+            eng.lib.ptx_diag_stop_after.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+            assert eng.lib.ptx_diag_stop_after(eng.ctx, args.stop_after) == 0
         db, info = eng.generate(c["replicas"], c["ops_per_log"], c["mix"], c["mark_types"], args.docs, 2024, list_cap=args.list_cap)
         n_logs = eng.n_logs(db)
         ops = n_logs * c["ops_per_log"]
@@ -54,7 +59,6 @@ def main():
         eng.free_result(dr)
         eng.free_batch(db)
         eng.close()
-    os.environ.pop("PTX_THREADS", None)
 
 
 if __name__ == "__main__":
