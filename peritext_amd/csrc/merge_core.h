@@ -106,6 +106,33 @@ struct PtxMergeArgs {
     const uint32_t* log_index; /* optional: workgroup i handles log log_index[i] (launches over a subset of the logs) */
 };
 
+/* sensitivity probe (experimental builds only, -DPTX_PROBE=k): 64 extra instructions of one kind per step of the row loop — which unit answers? */
+#ifndef PTX_PROBE
+#define PTX_PROBE_HERE
+#elif PTX_PROBE == 1
+#define PTX_PROBE_HERE { _Pragma("unroll") for (int q_ = 0; q_ < 64; ++q_) asm volatile("s_nop 0"); }
+#elif PTX_PROBE == 2
+#define PTX_PROBE_HERE { uint32_t d_ = 0; _Pragma("unroll") for (int q_ = 0; q_ < 64; ++q_) asm volatile("v_mov_b32 %0, %0" : "+v"(d_)); }
+#elif PTX_PROBE == 3
+#define PTX_PROBE_HERE { uint32_t d_ = 0; _Pragma("unroll") for (int q_ = 0; q_ < 64; ++q_) asm volatile("s_mov_b32 %0, %0" : "+s"(d_)); }
+#elif PTX_PROBE == 5 /* + one read of the ref_b column (8 bytes per row, ~256 more cache lines per 4K-op log) beside the row loop's own loads */
+#define PTX_PROBE_HERE { const uint32_t r_ = g * PTX_U1 + 2u < N ? g * PTX_U1 : 0u; const uint64_t x_ = ref_b[r_] | ref_b[r_ + 1u] | ref_b[r_ + 2u]; err4 |= (uint32_t)(x_ >> 63); }
+#elif PTX_PROBE == 4
+#define PTX_PROBE_HERE { uint32_t d_ = 0; _Pragma("unroll") for (int q_ = 0; q_ < 64; ++q_) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(d_)); }
+#else
+#define PTX_PROBE_HERE
+#endif
+/* knock-out probes (experimental builds only; WRONG results): what the gathers of P5a (PTX_PROBE 6) and of P3a too (7) cost in time */
+#if defined(PTX_PROBE) && PTX_PROBE >= 6
+#define PTX_KO_MARK_GATHERS(u, i_, ra_, rb_, sa_, sb_, pl_) { rb_[u] = i_[u]; ra_[u] = i_[u] + 1u; sa_[u] = 1u; sb_[u] = 1u; }
+#else
+#define PTX_KO_MARK_GATHERS(u, i_, ra_, rb_, sa_, sb_, pl_) { rb_[u] = ref_b[i_[u]]; ra_[u] = ref_a[i_[u]]; sa_[u] = A.side_a[base + i_[u]]; sb_[u] = A.side_b[base + i_[u]]; if (pl_[u]) pl_[u] = payload[i_[u]]; }
+#endif
+#if defined(PTX_PROBE) && PTX_PROBE >= 7
+#define PTX_KO_P3A_GATHERS(u, i_, ra_, di_, dra_) { ra_[u] = 0; dra_[u] = ((uint64_t)1u << 32); }
+#else
+#define PTX_KO_P3A_GATHERS(u, i_, ra_, di_, dra_) { ra_[u] = ref_a[i_[u]]; dra_[u] = ref_a[di_[u]]; }
+#endif
 #define PTX_END 0xFFFFu
 #ifndef PTX_S
 #define PTX_S 16u /* every PTX_S-th node of the Euler tour is a splitter of the list ranking (measured: 16 is 1 % faster than 8 and needs 0.6 KB less, 4 is 7 % slower) */
@@ -152,10 +179,13 @@ PTX_DEV void ptx_raise(PtxHdr* H, uint32_t row, uint32_t level, uint32_t code) {
     ptx_atomic_min(&H->err, ((row * 2u + level) << 4) | code);
 }
 
-/* one LDS atomic per wave and half of the digest (a wave-level butterfly first) */
+/* a thread's share of the digest: two 8-byte LDS atomics, issued by the threads that have one (a few dozen per log: the wave-wide butterfly this
+ * replaces cost every wave ~70 vector instructions per flush, three flushes per log) */
 PTX_DEV void ptx_digest_flush(PtxHdr* H, uint64_t h1, uint64_t h2) {
-    ptx_reduce_add64(&H->h1, (unsigned long long)h1);
-    ptx_reduce_add64(&H->h2, (unsigned long long)h2);
+    if ((h1 | h2) != 0) {
+        ptx_atomic_add64(&H->h1, (unsigned long long)h1);
+        ptx_atomic_add64(&H->h2, (unsigned long long)h2);
+    }
 }
 
 
@@ -229,6 +259,17 @@ PTX_DEV T* ptx_alloc2(PtxBump& bd, PtxBump& bp, uint32_t count) {
     return ptx_alloc<T>(bp, count);
 }
 
+/* from the recycled region only, and only if it has room (nullptr otherwise): for scratch the caller can do without */
+template <class T>
+PTX_DEV T* ptx_try_alloc(PtxBump& bd, uint32_t count) {
+    const uint32_t bytes = (uint32_t)(((uint64_t)count * sizeof(T) + 15u) & ~15ull);
+    if ((uint64_t)bd.off + bytes > bd.cap) return nullptr;
+    T* p = (T*)(bd.base + bd.off);
+    bd.off += bytes;
+    PTX_LDS_ALLOCATED(p, (uint64_t)count * sizeof(T), bytes);
+    return p;
+}
+
 PTX_DEV uint32_t ptx_ceil_log2(uint32_t x) { /* smallest k with (1<<k) >= x, x>=1 */
     uint32_t k = 0;
     while ((1u << k) < x) ++k;
@@ -240,15 +281,16 @@ PTX_DEV uint32_t ptx_ceil_log2(uint32_t x) { /* smallest k with (1<<k) >= x, x>=
  *      which Kc comment ops over Kid comment ids, id keyspace of ks bits. ---- */
 PTX_HD uint64_t ptx_a16(uint64_t x) { return (x + 15) & ~15ull; }
 /* bytes that do not fit the recycled region when arrays of the given sizes are placed first-fit in order */
-PTX_HD uint64_t ptx_overflow3(uint64_t free_bytes, uint64_t s0, uint64_t s1, uint64_t s2) {
+PTX_HD uint64_t ptx_overflow4(uint64_t free_bytes, uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3) {
     uint64_t over = 0;
-    const uint64_t sz[3] = {ptx_a16(s0), ptx_a16(s1), ptx_a16(s2)};
-    for (int i = 0; i < 3; ++i) {
+    const uint64_t sz[4] = {ptx_a16(s0), ptx_a16(s1), ptx_a16(s2), ptx_a16(s3)};
+    for (int i = 0; i < 4; ++i) {
         if (sz[i] <= free_bytes) free_bytes -= sz[i];
         else over += sz[i];
     }
     return over;
 }
+PTX_HD uint64_t ptx_overflow3(uint64_t free_bytes, uint64_t s0, uint64_t s1, uint64_t s2) { return ptx_overflow4(free_bytes, s0, s1, s2, 0); }
 PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) {
     (void)N;
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
@@ -260,7 +302,7 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     const uint64_t p1 = lists + 16 + mpark; /* + the dump of the unlisted rows */
     const uint64_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
     const uint64_t p3 = lists + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
-    const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0;
+    const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0; /* (the list of interval rows only takes what is left of the recycled region) */
     const uint64_t T4 = PTX_TILE_4, T1 = PTX_TILE_1;
     const uint64_t trees4 = ptx_overflow3(elem, 4 * 4 * 2 * T4, 4 * (T4 + 1), 8 * (T4 / 32 + 2));
     const uint64_t trees1 = n > T4 ? ptx_overflow3(elem, 4 * 2 * T1, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
@@ -471,21 +513,35 @@ PTX_DEV PtxMarkBlocks ptx_mark_blocks(uint32_t moff1, uint32_t moff2, uint32_t m
     for (int g = 0; g < 4; ++g) M.c[g] = M.B ? (M.sz[g] + M.B - 1u) / M.B : 0u;
     return M;
 }
-PTX_DEV bool ptx_mark_of(const PtxMarkBlocks& M, uint32_t b, uint32_t t, uint32_t& k) {
+/* lane t of EVERY block works on the same run: run g owns the lanes [c[0] + .. + c[g-1], .. + c[g]) (the counts per block are rounded up, so the four
+ * slices of a block need not be packed: a lane beyond the end of its run idles in the last block).  What a thread needs per step is then one multiply-add
+ * and one compare; the lane's share is loop-invariant (threadIdx.x on the GPU) and computed once. */
+struct PtxMarkLane {
+    uint32_t kbase, c, lim; /* the lane's mark op of block b: k = kbase + b * c, it exists iff b * c < lim */
+};
+PTX_DEV PtxMarkLane ptx_mark_lane(const PtxMarkBlocks& M, uint32_t t) {
+    PtxMarkLane L;
+    L.kbase = L.c = L.lim = 0;
     uint32_t o = 0;
     bool found = false;
-    k = 0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const uint32_t s0 = b * M.c[g], s = s0 < M.sz[g] ? s0 : M.sz[g];
-        const uint32_t e = s + M.c[g] < M.sz[g] ? s + M.c[g] : M.sz[g];
-        if (!found && t < o + (e - s)) {
-            k = M.off[g] + s + (t - o);
+        if (!found && t < o + M.c[g]) {
+            const uint32_t j = t - o;
+            L.kbase = M.off[g] + j;
+            L.c = M.c[g];
+            L.lim = j < M.sz[g] ? M.sz[g] - j : 0u;
             found = true;
         }
-        o += e - s;
+        o += M.c[g];
     }
-    return found;
+    return L;
+}
+PTX_DEV bool ptx_mark_of(const PtxMarkBlocks& M, uint32_t b, uint32_t t, uint32_t& k) {
+    const PtxMarkLane L = ptx_mark_lane(M, t);
+    const uint32_t s = ptx_mul24(b, L.c);
+    k = s < L.lim ? L.kbase + s : 0u;
+    return s < L.lim;
 }
 
 /* Uniform early exit on a per-log error.  The error word is sampled between two barriers so that a
@@ -627,23 +683,25 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_ADM_HDRS(h_, cl_)                                               \
         PTX_ADM_ENVS32(e0_, e1_, cl_)                                       \
     }
+                /* two register sets in turn (no copies from "next" to "current"): set A holds the even steps, set B the odd ones */
+#define PTX_ADM_STEP(cb_, h_, e0_, e1_)                                                                           \
+    if ((cb_) + step <= hi) {                                                                                     \
+        ptx_adm_step<false>(S, h_, e0_, e1_, PTX_AC, mx0, mx1, bad, amax, hsum);                                  \
+    } else { /* the last, partial step of the segment: lanes past `hi` play changes of no actor */                \
+        const uint32_t cl = (cb_) + lane * PTX_AC;                                                                \
+        ptx_adm_step<true>(S, h_, e0_, e1_, cl < hi ? hi - cl : 0u, mx0, mx1, bad, amax, hsum);                   \
+    }
                 PTX_ADM_LOAD(lo, h, e0, e1)
 #pragma nounroll
-                for (uint32_t cb = lo; cb < hi; cb += step) {
+                for (uint32_t cb = lo; cb < hi; cb += 2u * step) {
                     PTX_ADM_LOAD(cb + step, h_n, e0_n, e1_n)
-                    if (cb + step <= hi) {
-                        ptx_adm_step<false>(S, h, e0, e1, PTX_AC, mx0, mx1, bad, amax, hsum);
-                    } else { /* the last, partial step of the segment: lanes past `hi` play changes of no actor */
-                        const uint32_t cl = cb + lane * PTX_AC;
-                        ptx_adm_step<true>(S, h, e0, e1, cl < hi ? hi - cl : 0u, mx0, mx1, bad, amax, hsum);
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < PTX_AC; ++u) {
-                        h[u] = h_n[u];
-                        e0[u] = e0_n[u];
-                        e1[u] = e1_n[u];
+                    PTX_ADM_STEP(cb, h, e0, e1)
+                    if (cb + step < hi) { /* wave-uniform */
+                        PTX_ADM_LOAD(cb + 2u * step, h, e0, e1)
+                        PTX_ADM_STEP(cb + step, h_n, e0_n, e1_n)
                     }
                 }
+#undef PTX_ADM_STEP
 #undef PTX_ADM_LOAD
                 mx0 = ptx_wave_pk_max_u16(mx0);
                 mx1 = ptx_wave_pk_max_u16(mx1);
@@ -866,6 +924,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
 
 
+    PTX_STAMP(1); /* (diagnostic builds: end of the admission phase) */
     /* ---- the log header (census) sizes everything; the row pass below verifies it ---- */
     const ptx_log_hdr hd = A.log_hdr[log];
     const uint32_t n = hd.n_ins; /* list elements (inserts) */
@@ -939,8 +998,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
         if (!small_keys) id_[u] = op_id[i_[u]];                             \
-        ra_[u] = ref_a[i_[u]];                                              \
-        dra_[u] = ref_a[di_[u]];                  \
+        PTX_KO_P3A_GATHERS(u, i_, ra_, di_, dra_)                           \
     }
     /* ---- P1: ONE pass over the rows: id bitmaps, row lists per class ---- */
     {
@@ -1005,7 +1063,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * store is kept inside the log's window — and the census check after the pass rejects the log; a row with a malformed
          * action / mark type / op id only raises a flag here, and the (rare) pass below names the first such row. */
         /* the work on one thread's rows; kMasked: only the first `nv` of them exist */
-        auto p1_rows = [&](auto masked, uint32_t g, uint32_t nv) {
+        auto p1_rows = [&](auto masked, uint32_t g, uint32_t nv, const uint64_t (&id)[PTX_U1], uint32_t a4, uint32_t mt4) {
             constexpr bool kMasked = decltype(masked)::value;
             const uint32_t r0 = g * PTX_U1;
             const uint32_t live = kMasked ? (1u << (8u * nv)) - 1u : 0x00FFFFFFu; /* bytes of a4 / mt4 that are rows of this thread */
@@ -1019,6 +1077,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             err4 |= ((a4 & 0xF8F8F8F8u) | (mt4 & 0xFCFCFCFCu & mmask)) & live;
             if (kMasked) c4 = (c4 & live) | (0x07070707u & ~live);
             const uint32_t add4 = a4 & mk & live; /* bit 0 tells PTX_ACT_ADDMARK (3) from PTX_ACT_REMOVEMARK (4) */
+            PTX_PROBE_HERE
             uint32_t slot[PTX_U1];
             ptx_wave_slots4<PTX_U1>(H->cur, dump_at, c4, slot);
 #pragma unroll
@@ -1044,22 +1103,27 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 }
             }
         };
+        /* two register sets in turn (no copies from "next" to "current"): the even steps' rows arrive in id / a4 / mt4, the odd ones' in id_n / a4_n / mt4_n;
+         * a wave that has no row left in a step (wave-uniform) has none in the later ones either */
+#define PTX_P1_STEP(st_, id_, a_, mt_, idn_, an_, mtn_)                                                                      \
+    {                                                                                                                        \
+        const uint32_t g_ = PTX_G_OF(st_, p1_steps);                                                                          \
+        if (PTX_WAVE_FIRST(g_) >= p1_groups) break;                                                                           \
+        PTX_P1_LOAD(PTX_G_OF((st_) + 1u, p1_steps), idn_, an_, mtn_) /* the next step's rows are in flight while this one is processed */ \
+        if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) p1_rows(std::false_type(), g_, PTX_U1, id_, a_, mt_);                     \
+        else p1_rows(std::true_type(), g_, g_ * PTX_U1 < N ? (N - g_ * PTX_U1 < PTX_U1 ? N - g_ * PTX_U1 : PTX_U1) : 0u, id_, a_, mt_); \
+    }
 #pragma nounroll
-        for (uint32_t st = 0; st < p1_steps; ++st) {
-            const uint32_t g = PTX_G_OF(st, p1_steps);
-            if (PTX_WAVE_FIRST(g) >= p1_groups) continue; /* this wave has no row left in this step (wave-uniform) */
-            const uint32_t gn = PTX_G_OF(st + 1u, p1_steps);
-            PTX_P1_LOAD(gn, id_n, a4_n, mt4_n) /* later steps' rows are in flight while this step is processed */
-            if (PTX_WAVE_FIRST(g) + PTX_WS <= p1_full) p1_rows(std::false_type(), g, PTX_U1);
-            else p1_rows(std::true_type(), g, g * PTX_U1 < N ? (N - g * PTX_U1 < PTX_U1 ? N - g * PTX_U1 : PTX_U1) : 0u);
-#pragma unroll
-            for (int u = 0; u < PTX_U1; ++u) id[u] = id_n[u];
-            a4 = a4_n;
-            mt4 = mt4_n;
+        for (uint32_t st = 0; st < p1_steps; st += 2u) {
+            PTX_P1_STEP(st, id, a4, mt4, id_n, a4_n, mt4_n)
+            if (st + 1u >= p1_steps) break;
+            PTX_P1_STEP(st + 1u, id_n, a4_n, mt4_n, id, a4, mt4)
         }
+#undef PTX_P1_STEP
 #undef PTX_P1_LOAD
         if (err4 != 0u || ctr_hi >= ix.max_ctr || act_hi > ix.max_actor) ptx_atomic_or(&H->cur[7], 1u);
         PTX_SYNC();
+        PTX_STAMP(11); /* end of the row loop; census, duplicate check and the prefix scan of the id bitmap follow */
         /* the mark list is complete: park it in the log's span rows (8 bytes per row of the log, written only by P6; K <= N).  Every thread reads back
          * in P5 exactly the words it stores here (the same PTX_FOR partition), so nothing but its own program order is relied on.  A header that
          * understates the mark rows parks junk: the census check below rejects that log before anything reads it. */
@@ -1154,20 +1218,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         {
             const uint32_t jmax = n > d_fused ? n : d_fused;
             const uint32_t steps = PTX_JSTEPS(jmax);
-            uint32_t i[PTX_U], i_n[PTX_U], di[PTX_U], di_n[PTX_U];
-            uint64_t id[PTX_U], ra[PTX_U], id_n[PTX_U], ra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
-            uint64_t dra[PTX_U], dra_n[PTX_U];
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u) { /* step 0 was loaded at the end of P1 */
-                i[u] = p3_i[u];
-                id[u] = p3_id[u];
-                ra[u] = p3_ra[u];
-                di[u] = p3_di[u];
-                dra[u] = p3_dra[u];
-            }
-#pragma nounroll
-            for (uint32_t st = 0; st < steps; ++st) {
-                PTX_P3A_LOAD(st + 1u, i_n, id_n, ra_n, di_n, dra_n) /* in flight while this step is processed */
+            /* two register sets in turn (no copies from "next" to "current"): p3_* (step 0 was loaded at the end of P1) holds the even steps, *_n the odd ones */
+            uint32_t i_n[PTX_U], di_n[PTX_U];
+            uint64_t id_n[PTX_U], ra_n[PTX_U], dra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
+            auto p3a_step = [&](uint32_t st, const uint32_t (&i)[PTX_U], const uint64_t (&id)[PTX_U], const uint64_t (&ra)[PTX_U], const uint32_t (&di)[PTX_U],
+                                const uint64_t (&dra)[PTX_U]) {
 #pragma unroll
                 for (int u = 0; u < PTX_U; ++u) {
                     const uint32_t j = PTX_J_OF(st, u);
@@ -1193,18 +1248,19 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         ilist[j < n ? PTX_JX(j, n) : j] = (uint16_t)(t < 0 ? 0xFFFF : t); /* j <= n; slot n is P1's spare */
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < PTX_U; ++u) {
-                    i[u] = i_n[u];
-                    id[u] = id_n[u];
-                    ra[u] = ra_n[u];
-                    di[u] = di_n[u];
-                    dra[u] = dra_n[u];
-                }
+            };
+#pragma nounroll
+            for (uint32_t st = 0; st < steps; st += 2u) {
+                PTX_P3A_LOAD(st + 1u, i_n, id_n, ra_n, di_n, dra_n) /* in flight while this step is processed */
+                p3a_step(st, p3_i, p3_id, p3_ra, p3_di, p3_dra);
+                if (st + 1u >= steps) break;
+                PTX_P3A_LOAD(st + 2u, p3_i, p3_id, p3_ra, p3_di, p3_dra)
+                p3a_step(st + 1u, i_n, id_n, ra_n, di_n, dra_n);
             }
 #undef PTX_P3A_LOAD
         }
         PTX_BAIL_IF_ERROR();
+        PTX_STAMP(12); /* end of P3a */
         ptx_scan_excl<uint16_t, 1, kThreads>(cnt, n + 2, H->scan_tmp, A.div_magic); /* cnt[p] = first slot of p's children */
         /* P3b: scatter into the parent buckets; tombstone flags; application-order checks now that row_of is complete */
         PTX_FORU(e0, n) {
@@ -1331,6 +1387,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             L[xo] = (uint16_t)other; /* j == n writes the terminal node */
         }
         PTX_SYNC();
+        PTX_STAMP(14); /* the Euler tour stands; the list ranking follows */
         /* List ranking, work-efficient: every PTX_S-th node is a splitter.  A splitter walks to the next one (each tour
          * node is visited once), counts the enter nodes (weight 1: node ids 1..n) it passes and leaves on each of them
          * its splitter and the count before it (in `L` and `par`, both dead by then); the ~2n/PTX_S splitters are
@@ -1402,19 +1459,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         pl_[u] = has_ && k_ >= moff2 && k_ < moff3 ? 1u : 0u;               \
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
-        rb_[u] = ref_b[i_[u]];                                              \
-        ra_[u] = ref_a[i_[u]];                    \
-        sa_[u] = A.side_a[base + i_[u]];                                    \
-        sb_[u] = A.side_b[base + i_[u]];                                    \
-        if (pl_[u]) pl_[u] = payload[i_[u]];                 \
+        PTX_KO_MARK_GATHERS(u, i_, ra_, rb_, sa_, sb_, pl_)                 \
     }
     PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl)
     /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = nwe; /* bit positions 0..n by document position */
     PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
-    uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
-    uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
-    uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);    /* comment mark -> doc-local comment id */
     uint32_t* brkbits = ptx_alloc<uint32_t>(bp, nwe + 1); /* visible positions where a comment interval starts/ends */
     PTX_BAIL_CAPACITY();
     PTX_FOR(w, nwv + 1) {
@@ -1425,8 +1475,14 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         brkbits[w] = 0;
     }
     PTX_SYNC();
-    PTX_FOR(e, n) {
-        if (!ptx_bittest(delbits, e)) {
+    /* word by word over the tombstone bitmap, a lane per 32 elements: the work is per SURVIVING element (a document that has seen
+     * thousands of ops usually shows a few dozen characters), not per element ever inserted */
+#define PTX_LIVE_WORD(w_) ((~delbits[w_]) & ((w_) == (n >> 5) ? (1u << (n & 31u)) - 1u : 0xFFFFFFFFu))
+    PTX_FOR(w, nwe) {
+        uint32_t live = PTX_LIVE_WORD(w);
+        while (live) {
+            const uint32_t e = (w << 5) + (uint32_t)__builtin_ctz(live);
+            live &= live - 1u;
             const uint32_t r = rnk[e];
             ptx_atomic_or(&alive[r >> 5].bits, 1u << (r & 31));
         }
@@ -1435,57 +1491,68 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_FOR(w, nwv + 1) alive[w].pre = ptx_popc(alive[w].bits);
     PTX_SYNC();
     const uint32_t V = ptx_scan_excl<uint32_t, 2, kThreads>(&alive[0].pre, nwv + 1, H->scan_tmp, A.div_magic);
+    /* the visible interval of every mark op; until the marks are looked at, the space holds the rows of the visible elements (vrow) if they fit */
+    const uint32_t mrk_at = bp.off;
+    uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
+    uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
+    uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);    /* comment mark -> doc-local comment id */
+    PTX_BAIL_CAPACITY();
+    const uint32_t mrk_bytes = bp.off - mrk_at; /* the three arrays stand back to back; nothing is stored in them before the marks are looked at */
     PTX_STAMP(6);
 
     /* ---- P5a: visible values out; every mark op -> visible interval [lo, hi) ---- */
     {
         uint64_t h1 = 0, h2 = 0;
-        /* software-pipelined like the other gather loops: the next step's position / row / alive word (LDS) and value (HBM, visible
-         * elements only) are on their way while this step's values are written */
-        const uint32_t v_steps = PTX_JSTEPS(n);
-        uint32_t r[PTX_U], row[PTX_U], v[PTX_U], r_n[PTX_U], row_n[PTX_U], v_n[PTX_U];
-        PtxBitWord w[PTX_U], w_n[PTX_U];
-#define PTX_VAL_LOAD(st_, r_, row_, w_, v_)                                 \
-    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
-        const uint32_t j_ = PTX_J_OF(st_, u);                               \
-        const uint32_t e_ = j_ < n ? PTX_JX(j_, n) : 0u;                    \
-        r_[u] = rnk[e_];                                                    \
-        row_[u] = row_of[e_];                                               \
-    }                                                                       \
-    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
-        w_[u] = alive[r_[u] >> 5];                                          \
-        v_[u] = 0;                                                          \
-        if (PTX_J_OF(st_, u) < n && ((w_[u].bits >> (r_[u] & 31)) & 1u)) v_[u] = payload[row_[u] < N ? row_[u] : N - 1u]; \
-    }
-        PTX_VAL_LOAD(0u, r, row, w, v)
-#pragma nounroll
-        for (uint32_t st = 0; st < v_steps; ++st) {
-            PTX_VAL_LOAD(st + 1u, r_n, row_n, w_n, v_n)
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u)
-                if (PTX_J_OF(st, u) < n) {
-                    if ((w[u].bits >> (r[u] & 31)) & 1u) {
-                        const uint32_t q = w[u].pre + ptx_popc(w[u].bits & ((1u << (r[u] & 31)) - 1u));
-                        A.out_values[base + q] = v[u];
-                        ptx_digest_item(h1, h2, 1u, q, v[u], 0u);
-                    }
-                    if (A.out_rank) A.out_rank[base + row[u]] = r[u] | (((w[u].bits >> (r[u] & 31)) & 1u) ? 0u : PTX_RANK_TOMBSTONE);
+        /* the surviving elements again (a lane per word of the tombstone bitmap): their rows by visible index (= alive bits below the element's position) into
+         * a dense list — the digest is ~100 vector instructions per item and wave, so it runs over a packed list (one wave pass per 64 visible characters),
+         * never inside the sparse loop */
+        if (2u * (V + 1u) <= mrk_bytes) {
+            uint16_t* vrow = mrk_lo;
+            PTX_LDS_ALLOCATED(mrk_lo, mrk_bytes, mrk_bytes); /* (the list runs over the three arrays and the padding between them) */
+            PTX_FOR(w, nwe) {
+                uint32_t live = PTX_LIVE_WORD(w);
+                while (live) {
+                    const uint32_t e = (w << 5) + (uint32_t)__builtin_ctz(live);
+                    live &= live - 1u;
+                    vrow[ptx_bitrank(alive, rnk[e])] = row_of[e];
                 }
-#pragma unroll
-            for (int u = 0; u < PTX_U; ++u) {
-                r[u] = r_n[u];
-                row[u] = row_n[u];
-                w[u] = w_n[u];
-                v[u] = v_n[u];
+            }
+            PTX_SYNC();
+            PTX_FOR(q, V) {
+                const uint32_t row = vrow[q];
+                const uint32_t v = payload[row < N ? row : N - 1u];
+                A.out_values[base + q] = v;
+                ptx_digest_item(h1, h2, 1u, q, v, 0u);
+            }
+        } else { /* (a log with hardly any mark op and many visible characters: no room for the list) */
+            PTX_FOR(w, nwe) {
+                uint32_t live = PTX_LIVE_WORD(w);
+                while (live) {
+                    const uint32_t e = (w << 5) + (uint32_t)__builtin_ctz(live);
+                    live &= live - 1u;
+                    const uint32_t row = row_of[e], q = ptx_bitrank(alive, rnk[e]);
+                    const uint32_t v = payload[row < N ? row : N - 1u];
+                    A.out_values[base + q] = v;
+                    ptx_digest_item(h1, h2, 1u, q, v, 0u);
+                }
             }
         }
-#undef PTX_VAL_LOAD
+        /* elem_rank (optional output): document position + tombstone flag of EVERY element, by the row that inserted it */
+        if (A.out_rank) {
+            PTX_FOR(e, n) {
+                const uint32_t r = rnk[e];
+                A.out_rank[base + row_of[e]] = r | (ptx_bittest(delbits, e) ? PTX_RANK_TOMBSTONE : 0u);
+            }
+        }
         ptx_digest_flush(H, h1, h2);
+        PTX_SYNC(); /* vrow (= the head of mrk_lo) has been read by everyone before the first interval is stored */
     }
+#undef PTX_LIVE_WORD
+    PTX_STAMP(13); /* the values are out; the marks' intervals follow */
     {
-#pragma nounroll
-    for (uint32_t st = 0; st < m_steps; ++st) {
-        PTX_MARK_LOAD(st + 1u, kq_n, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* later steps' gathers are in flight while this step is processed */
+    /* two register sets in turn (no copies from "next" to "current"): kq / i / ra ... hold the even steps' mark ops, the *_n set the odd ones' */
+    auto mark_step = [&](const uint32_t (&kq)[PTX_UM], const uint32_t (&i)[PTX_UM], const uint64_t (&ra)[PTX_UM], const uint64_t (&rb)[PTX_UM], const uint32_t (&sa)[PTX_UM],
+                         const uint32_t (&sb)[PTX_UM], const uint32_t (&pl)[PTX_UM]) {
 #pragma unroll
         for (int u = 0; u < (int)PTX_UM; ++u)
             if (kq[u] != 0xFFFFFFFFu) {
@@ -1532,16 +1599,14 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     cid[k - moff2] = (uint16_t)(pl[u] < Kid ? pl[u] : 0u);
                 }
             }
-#pragma unroll
-        for (int u = 0; u < (int)PTX_UM; ++u) {
-            kq[u] = kq_n[u];
-            i[u] = i_n[u];
-            ra[u] = ra_n[u];
-            rb[u] = rb_n[u];
-            sa[u] = sa_n[u];
-            sb[u] = sb_n[u];
-            pl[u] = pl_n[u];
-        }
+    };
+#pragma nounroll
+    for (uint32_t st = 0; st < m_steps; st += 2u) {
+        PTX_MARK_LOAD(st + 1u, kq_n, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* the next step's gathers are in flight while this step is processed */
+        mark_step(kq, i, ra, rb, sa, sb, pl);
+        if (st + 1u >= m_steps) break;
+        PTX_MARK_LOAD(st + 2u, kq, i, ra, rb, sa, sb, pl)
+        mark_step(kq_n, i_n, ra_n, rb_n, sa_n, sb_n, pl_n);
     }
 #undef PTX_MARK_LOAD
     }
@@ -1599,23 +1664,43 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_SYNC();
         const uint32_t I = ptx_scan_excl<uint32_t, 1, kThreads>(cicnt, Kid + 1, H->scan_tmp, A.div_magic);
         PTX_LEADER { H->I = I; }
-        {
-            uint64_t h1 = 0, h2 = 0;
-            PTX_FOR(c, Kid) {
-                uint32_t row = cicnt[c];
-                ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [&](uint32_t s, uint32_t e) {
+        /* the interval rows: first into LDS by the per-id sweeps (a lane per id, ragged), then out — rows, break bits and digest — by a dense pass (the
+         * digest is ~100 vector instructions per item and wave: it must not sit inside the ragged loop) */
+        uint32_t* crow = ptx_try_alloc<uint32_t>(bd, 2 * I + 2); /* {id, start | end << 16}; from what is left of the recycled region, if it has room */
+        uint64_t h1 = 0, h2 = 0;
+        PTX_FOR(c, Kid) {
+            uint32_t row = cicnt[c];
+            ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [&](uint32_t s, uint32_t e) {
+                if (crow) {
+                    crow[2u * row] = c;
+                    crow[2u * row + 1u] = s | (e << 16);
+                } else { /* no room: the row goes out from here */
                     ptx_cinterval ci;
                     ci.id = c;
                     ci.start = s;
                     ci.end = e;
-                    A.out_cints[base + row++] = ci;
+                    A.out_cints[base + row] = ci;
                     ptx_atomic_or(&brkbits[s >> 5], 1u << (s & 31));
-                    ptx_atomic_or(&brkbits[e >> 5], 1u << (e & 31)); /* e <= V: bit V is never read */
+                    ptx_atomic_or(&brkbits[e >> 5], 1u << (e & 31));
                     ptx_digest_item(h1, h2, 3u, c, s, e);
-                });
-            }
-            ptx_digest_flush(H, h1, h2);
+                }
+                ++row;
+            });
         }
+        if (crow) {
+            PTX_SYNC();
+            PTX_FOR(r, I) {
+                ptx_cinterval ci;
+                ci.id = crow[2u * r];
+                ci.start = crow[2u * r + 1u] & 0xFFFFu;
+                ci.end = crow[2u * r + 1u] >> 16;
+                A.out_cints[base + r] = ci;
+                ptx_atomic_or(&brkbits[ci.start >> 5], 1u << (ci.start & 31));
+                ptx_atomic_or(&brkbits[ci.end >> 5], 1u << (ci.end & 31)); /* end <= V: bit V is never read */
+                ptx_digest_item(h1, h2, 3u, ci.id, ci.start, ci.end);
+            }
+        }
+        ptx_digest_flush(H, h1, h2);
         PTX_SYNC();
     }
     bp.off = mark2_lds; /* release the comment scratch */
@@ -1754,11 +1839,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_LEADER {
             H->V = V;
             H->S = span_base;
+        }
+        PTX_FOR(t, 2u) { /* the two count items of the digest, a lane each */
             uint64_t g1 = 0, g2 = 0;
-            ptx_digest_item(g1, g2, 4u, 0u, V, span_base);
-            ptx_digest_item(g1, g2, 4u, 1u, H->I, n);
-            H->h1 += g1;
-            H->h2 += g2;
+            ptx_digest_item(g1, g2, 4u, t, t ? H->I : V, t ? n : span_base);
+            ptx_digest_flush(H, g1, g2);
         }
     }
     PTX_SYNC();

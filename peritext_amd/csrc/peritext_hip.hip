@@ -35,6 +35,9 @@
 /* One body, several register budgets: __launch_bounds__(T, W) = at most T threads per workgroup and at
  * least W waves per SIMD resident, i.e. the compiler must stay within 512/W VGPRs (MI355X_MICROARCH.md
  * "Register files"). */
+#ifndef PTX_W
+#define PTX_W 1 /* minimum waves per SIMD the register allocation of ptx_merge_kernel must allow (8: ten 3-wave logs per CU need it; costs SGPR spills) */
+#endif
 #define PTX_MERGE_KERNEL(name, T, W, MANY, KT, DIAG)                                     \
     extern "C" __global__ void __launch_bounds__(T, W) name(PtxMergeArgs A) {          \
         extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];              \
@@ -42,7 +45,7 @@
            out of it and kept in registers for the whole kernel */                    \
         if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT, DIAG>(A, A.log_index ? A.log_index[blockIdx.x] : blockIdx.x, ptx_lds); \
     }
-PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, 1, false, 0, false)     /* any launch shape (blockDim.x read at run time) */
+PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, PTX_W, false, 0, false)     /* any launch shape (blockDim.x read at run time) */
 PTX_MERGE_KERNEL(ptx_merge_kernel_rest, 1024, 1, false, 0, false) /* the same kernel under another name: the second launch of a split batch (the few logs
                                                                     with a larger LDS window), so that per-kernel statistics of a trace keep the two apart */
 PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false) /* + causal admission for documents with more than three actors */

@@ -194,11 +194,13 @@ PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint3
 #define PTX_JSTEPS_U(n, U) ((PTX_DIV_T((n) + PTX_BLOCKDIM - 1u) + (U)-1u) / (U)) /* = ceil(n / (U * T)) */
 #define PTX_J_OF_U(st, u, U) (((st) * (U) + (uint32_t)(u)) * PTX_BLOCKDIM + threadIdx.x)
 #define PTX_JX(j, n) (j)
-/* loops over BLOCKS of items, U blocks per step: block b is handled by the whole workgroup, lane t of it by thread t */
-#define PTX_JB_CAP PTX_BLOCKDIM
-#define PTX_JB_STEPS(B, U) (((B) + (U)-1u) / (U))
-#define PTX_JB_BLOCK(st, u, U) ((st) * (U) + (uint32_t)(u))
-#define PTX_JB_LANE(st, u, U) (threadIdx.x)
+/* loops over BLOCKS of items: a block is ONE wave's work (64 lanes), every wave takes U blocks per step.  The marks' loops use them: a block holds the mark
+ * ops of one stretch of the log, so the cache lines a wave's gathers touch are touched by no other wave (with a block per workgroup the three waves of a
+ * step asked for the same lines one after the other, and the L1 had often dropped them in between: 1.6 x the lines the columns hold) */
+#define PTX_JB_CAP 64u
+#define PTX_JB_STEPS(B, U) (((B) + (U) * PTX_NWAVES - 1u) / ((U) * PTX_NWAVES))
+#define PTX_JB_BLOCK(st, u, U) (((st) * (U) + (uint32_t)(u)) * PTX_NWAVES + (threadIdx.x >> 6))
+#define PTX_JB_LANE(st, u, U) (threadIdx.x & 63u)
 
 /* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
  * emulation plays three one-lane waves in turn */

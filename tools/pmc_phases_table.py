@@ -17,8 +17,8 @@ launches = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 for d in rows.values():
     for c in d:
         d[c] /= launches
-order = [2, 3, 4, 5, 6, 7, 8, 0]
-names = {2: "P0+P1 admission+rows", 3: "P3a+b buckets", 4: "P3c child order", 5: "P3d tour+rank", 6: "P4 tombstones", 7: "P5a values+intervals", 8: "P5c comments", 0: "P5b trees+spans"}
+order = [1, 11, 2, 12, 3, 4, 14, 5, 6, 13, 7, 8, 0]
+names = {1: "P0 admission", 11: "P1 row loop", 2: "P1 tail: census, dup, scan", 12: "P3a index+parents", 3: "P3b scatter+checks", 14: "P3d tour", 5: "P3d ranking+unpark", 13: "P5a values", 7: "P5a mark intervals", 99: "", 4: "P3c child order", 6: "P4 tombstones", 8: "P5c comments", 0: "P5b trees+spans"}
 prev = {}
 print("per log: %-22s %8s %8s %8s %8s %8s | %10s %10s %10s" % ("phase", "VALU", "SALU", "LDS", "VMEM", "BRANCH", "wavecyc(q)", "wait(q)", "active(q)"))
 for k in order:
