@@ -548,10 +548,10 @@ PTX_DEV bool ptx_mark_of(const PtxMarkBlocks& M, uint32_t b, uint32_t t, uint32_
  * later phase's error write can never be seen by a thread that is still at this check point. */
 #define PTX_BAIL_IF_ERROR()                                        \
     do {                                                           \
-        PTX_SYNC();                                                \
+        PTX_SYNC_LDS();                                                \
         uint32_t _st = H->err;                                     \
         if (_st != PTX_NO_ERR && H->adm < _st) _st = H->adm; /* an earlier change failed admission first */ \
-        PTX_SYNC();                                                \
+        PTX_SYNC_LDS();                                                \
         if (_st != PTX_NO_ERR) {                                   \
             lds_high = bp.high;                                    \
             return _st & 15u;                                      \
@@ -591,7 +591,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     bp.cap = A.lds_bytes;
     bp.high = bp.off;
     bp.overflow = false;
-    PTX_SYNC();
+    PTX_SYNC_LDS();
     PTX_STAMP(0);
     if (N64 > 65534u) {
         lds_high = bp.high;
@@ -612,7 +612,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             H->h1 += g1;
             H->h2 += g2;
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         lds_high = bp.high;
         return PTX_OK;
     }
@@ -652,7 +652,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             uint32_t* wt23 = ptx_alloc<uint32_t>(bp, PTX_MAX_THREADS / 64 + 2);
             PTX_BAIL_CAPACITY();
             PTX_LEADER { H->cur[7] = 0; }
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             const uint32_t nwv_ = PTX_NWAVES;
             const uint32_t step = PTX_WS * PTX_AC; /* changes per wave and step */
             const uint32_t seg = ((C + nwv_ - 1u) / nwv_ + step - 1u) / step * step; /* changes per wave, whole steps */
@@ -723,7 +723,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     r[8] = amax;
                 }
             }
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             bool admitted = H->cur[7] == N; /* the same answer in every thread: wrec is complete.  The changes must tile the rows of the log exactly */
             {
                 uint32_t B[3] = {0u, 0u, 0u};
@@ -744,9 +744,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             if (!admitted) {
                 /* EXACT walk of a failing log: which change fails first, and how (the reference throws there) */
                 PTX_NOTE_EXACT_WALK(); /* test / diagnostic hook: valid logs must never come here */
-                PTX_SYNC();
+                PTX_SYNC_LDS();
                 PTX_LEADER { H->cur[7] = 0; }
-                PTX_SYNC();
+                PTX_SYNC_LDS();
             /* pass A: per-wave totals of changes per actor, rows per log, actor range */
                 PTX_FOR_WAVE(w, lane) {
                     const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
@@ -779,7 +779,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         ptx_atomic_min(&H->adm, ((row * 2u) << 4) | PTX_ERR_BAD_OP);
                     }
                 }
-                PTX_SYNC();
+                PTX_SYNC_LDS();
                 if (H->adm != PTX_NO_ERR || H->cur[7] != N) { /* malformed envelope; the changes must tile the rows of the log exactly */
                     lds_high = bp.high;
                     return PTX_ERR_BAD_OP;
@@ -848,7 +848,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_ADM_LOAD
                 }
             }
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
         } else if constexpr (!kManyActors) {
             /* this build of the kernel carries only the <= 3-actor admission; the host launches the other one */
@@ -865,7 +865,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_FOR(a, na + 2) first[a] = 0;
         PTX_FOR(c, C + 1) tbl[c] = 0xFFFFFFFFu;
         PTX_LEADER { H->cur[7] = 0; }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         PTX_FOR(c, C) {
             const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT;
             ptx_atomic_add(&H->cur[7], c_hdr[c] & PTX_CHG_NOPS);
@@ -875,7 +875,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 ptx_atomic_min(&H->adm, ((row * 2u) << 4) | PTX_ERR_BAD_OP);
             } else ptx_atomic_add(&first[a], 1u);
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         if (H->adm != PTX_NO_ERR || H->cur[7] != N) { /* malformed envelope; the changes must tile the rows of the log exactly */
             lds_high = bp.high;
             return PTX_ERR_BAD_OP;
@@ -888,13 +888,13 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 run += v;
             }
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         PTX_FOR(c, C) {
             const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT, sq = c_env[(uint64_t)c * estride];
             const uint32_t f = first[a], cnt_a = first[a + 1] - f;
             if (sq - 1u < cnt_a) ptx_atomic_min(&tbl[f + sq - 1u], c); /* a later claimant of the slot is caught below */
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         PTX_FOR(c, C) {
             const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT, sq = c_env[(uint64_t)c * estride];
             const uint32_t f = first[a], cnt_a = first[a + 1] - f;
@@ -917,7 +917,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         /* a failed admission stays pending in H->adm: an op-level error of an EARLIER row (found by the phases
          * below, which still run) wins over it, exactly as in a sequential replay */
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
         } /* na > 3 */
 #undef PTX_CHANGE_ROW
@@ -1034,7 +1034,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_FOR(w, nwe + 1) delbits[w] = 0;
         PTX_FOR(w, (K >> 5) + 1) maddbits[w] = 0;
-        if (A.out_rank) PTX_FOR(i, N) A.out_rank[base + i] = 0xFFFFFFFFu; /* the insert rows are overwritten in P5a */
+        if (A.out_rank) { /* the insert rows are overwritten in P5a, by other threads: these stores must have completed by then (the one full barrier) */
+            PTX_FOR(i, N) A.out_rank[base + i] = 0xFFFFFFFFu;
+            PTX_SYNC();
+        }
         /* The list cursors are ABSOLUTE: indices of 16-bit words from the start of the log's LDS window, so that a row's list slot
          * is one number whatever its class (no per-row choice of a list).  Rows that are listed nowhere (makeList, NOP, malformed)
          * land in a four-entry dump. */
@@ -1057,7 +1060,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             H->n_ins = n;
             H->n_applied = n + D + K;
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         /* Branch-free row loop, PTX_U1 consecutive rows per thread and step.  What the header promised is NOT re-checked per
          * row: a list that overflows (more rows of a class than the header says) overwrites scratch of this log only — every
          * store is kept inside the log's window — and the census check after the pass rejects the log; a row with a malformed
@@ -1122,7 +1125,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_P1_STEP
 #undef PTX_P1_LOAD
         if (err4 != 0u || ctr_hi >= ix.max_ctr || act_hi > ix.max_actor) ptx_atomic_or(&H->cur[7], 1u);
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         PTX_STAMP(11); /* end of the row loop; census, duplicate check and the prefix scan of the id bitmap follow */
         /* the mark list is complete: park it in the log's span rows (8 bytes per row of the log, written only by P6; K <= N).  Every thread reads back
          * in P5 exactly the words it stores here (the same PTX_FOR partition), so nothing but its own program order is relied on.  A header that
@@ -1142,7 +1145,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_LEADER {
                 for (int c = 0; c < 6; ++c) cnt6[c] = 0;
             }
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             PTX_FOR(i, N) {
                 const uint32_t ctr = (uint32_t)(op_id[i] >> 32), act = (uint32_t)op_id[i], a = action[i], mt = mark_type[i];
                 const bool mark = a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK;
@@ -1151,7 +1154,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 else if (a == PTX_ACT_DELETE) ptx_atomic_add(&cnt6[1], 1u);
                 else if (mark) ptx_atomic_add(&cnt6[2u + mt], 1u);
             }
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             PTX_LEADER {
                 if (cnt6[0] != n || cnt6[1] != D || cnt6[2] != moff1 || cnt6[3] != moff2 - moff1 || cnt6[4] != moff3 - moff2 || cnt6[5] != K - moff3)
                     ptx_raise(H, 0, 0, PTX_ERR_BAD_OP);
@@ -1169,13 +1172,13 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_FOR(w, nw + 1) distinct += ptx_popc(ix.ib[w].pre);
             ptx_atomic_add(&H->cur[6], distinct);
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         if (H->err == PTX_NO_ERR && H->cur[6] != N) {
             /* some opId occurs twice (every row had a well-formed id, so N distinct ids were expected): find the
              * first repeated row with a second, returning pass over a cleared bitmap — the rare path */
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             PTX_FOR(w, nw + 1) ix.ib[w].pre = 0;
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             PTX_FOR(i, N) {
                 uint32_t key = 0;
                 ptx_id_key(ix, op_id[i], key);
@@ -1184,9 +1187,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
             /* (which of two equal ids is "the repeat" depends on the race; the status is what is reported) */
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp, A.div_magic);
     }
     PTX_BAIL_IF_ERROR();
@@ -1209,7 +1212,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         uint16_t* big = seg + n + 1; /* positions in seg of the members of large buckets */
 
         PTX_FOR(p, (n + 2 + 1) / 2 + 1) cntw[p] = 0;
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         /* P3a: element index of every insert, its parent, children counts.  The deletes ride along: their gathers of ref_a hit
          * the lines the inserts of the same stretch of the log have just brought in (one trip to HBM instead of two), and their
          * round trips hide behind the inserts'.  What a delete cannot do yet is the application-order check (row_of is being
@@ -1321,7 +1324,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             /* the first member of a huge bucket announces its parent */
             if (m > PTX_HUGE_BUCKET && j == s) huge[ptx_atomic_add(&H->cur_huge, 1u)] = (uint16_t)p;
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         {
             const uint32_t nm = H->cur_med, nb = H->cur_big, nh = H->cur_huge;
             PTX_FOR(b, nm) {
@@ -1351,23 +1354,23 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     z.pre = 0;
                     hb[w] = z;
                 }
-                PTX_SYNC();
+                PTX_SYNC_LDS();
                 PTX_FOR(k, t - s) {
                     const uint32_t x = seg[s + k];
                     ptx_atomic_or(&hb[x >> 5].bits, 1u << (x & 31));
                 }
-                PTX_SYNC();
+                PTX_SYNC_LDS();
                 PTX_FOR(w, nwe + 1) hb[w].pre = ptx_popc(hb[w].bits);
-                PTX_SYNC();
+                PTX_SYNC_LDS();
                 ptx_scan_excl<uint32_t, 2, kThreads>(&hb[0].pre, nwe + 1, H->scan_tmp, A.div_magic);
                 PTX_FOR(k, t - s) {
                     const uint32_t x = seg[s + k];
                     srt[s + (t - s - 1u - ptx_bitrank(hb, x))] = (uint16_t)x; /* members with a larger index come first */
                 }
-                PTX_SYNC();
+                PTX_SYNC_LDS();
             }
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         PTX_STAMP(4);
         /* P3d: Euler tour.  Nodes: 0 = enter(HEAD), x+1 = enter(x), n+1+x = exit(x) for x in [0,n), and the
          * terminal node 2n+1.  weight 1 on enter(x): the suffix sum at enter(x) counts the elements from x
@@ -1386,7 +1389,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             L[j < n ? j + 1u : 0u] = (uint16_t)nx;
             L[xo] = (uint16_t)other; /* j == n writes the terminal node */
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         PTX_STAMP(14); /* the Euler tour stands; the list ranking follows */
         /* List ranking, work-efficient: every PTX_S-th node is a splitter.  A splitter walks to the next one (each tour
          * node is visited once), counts the enter nodes (weight 1: node ids 1..n) it passes and leaves on each of them
@@ -1409,7 +1412,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 R[sp] = ((v == term ? ns : v / PTX_S) << 16) | acc;
             }
             PTX_LEADER { R[ns] = ns << 16; } /* terminal: points at itself with weight 0 */
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             const uint32_t rounds = ptx_ceil_log2(ns + 1);
 #pragma nounroll
             for (uint32_t r = 0; r < rounds; ++r) {
@@ -1421,12 +1424,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     const uint32_t b = R[a >> 16];
                     R[sp] = (b & 0xFFFF0000u) | ((a + b) & 0xFFFFu);
                 }
-                PTX_SYNC();
+                PTX_SYNC_LDS();
             }
             /* elements from x to the end of the document = suffix of x's splitter - enter nodes before x in its segment */
             PTX_FOR(x, n) par[x] = (uint16_t)(n - ((R[L[x + 1u]] & 0xFFFFu) - (uint32_t)par[x])); /* document position incl. tombstones */
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
     }
     uint16_t* rnk = par;
     bp.off = mark_lds; /* release the tree scratch */
@@ -1438,7 +1441,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_FOR(w, K >> 1) dst[w] = park[w];
         if (K & 1u) PTX_LEADER { mlist[K - 1u] = ((const uint16_t*)park)[K - 1u]; }
     }
-    PTX_SYNC();
+    PTX_SYNC_LDS();
     PTX_STAMP(5);
 
     /* P5a's loads: the first step's gathers are issued here, ahead of P4 and the values pass */
@@ -1474,7 +1477,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         alive[w] = z;
         brkbits[w] = 0;
     }
-    PTX_SYNC();
+    PTX_SYNC_LDS();
     /* word by word over the tombstone bitmap, a lane per 32 elements: the work is per SURVIVING element (a document that has seen
      * thousands of ops usually shows a few dozen characters), not per element ever inserted */
 #define PTX_LIVE_WORD(w_) ((~delbits[w_]) & ((w_) == (n >> 5) ? (1u << (n & 31u)) - 1u : 0xFFFFFFFFu))
@@ -1487,9 +1490,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             ptx_atomic_or(&alive[r >> 5].bits, 1u << (r & 31));
         }
     }
-    PTX_SYNC();
+    PTX_SYNC_LDS();
     PTX_FOR(w, nwv + 1) alive[w].pre = ptx_popc(alive[w].bits);
-    PTX_SYNC();
+    PTX_SYNC_LDS();
     const uint32_t V = ptx_scan_excl<uint32_t, 2, kThreads>(&alive[0].pre, nwv + 1, H->scan_tmp, A.div_magic);
     /* the visible interval of every mark op; until the marks are looked at, the space holds the rows of the visible elements (vrow) if they fit */
     const uint32_t mrk_at = bp.off;
@@ -1517,7 +1520,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     vrow[ptx_bitrank(alive, rnk[e])] = row_of[e];
                 }
             }
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             PTX_FOR(q, V) {
                 const uint32_t row = vrow[q];
                 const uint32_t v = payload[row < N ? row : N - 1u];
@@ -1545,7 +1548,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
         }
         ptx_digest_flush(H, h1, h2);
-        PTX_SYNC(); /* vrow (= the head of mrk_lo) has been read by everyone before the first interval is stored */
+        PTX_SYNC_LDS(); /* vrow (= the head of mrk_lo) has been read by everyone before the first interval is stored */
     }
 #undef PTX_LIVE_WORD
     PTX_STAMP(13); /* the values are out; the marks' intervals follow */
@@ -1637,12 +1640,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             ccnt[c] = 0;
             ccur[c] = 0;
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         PTX_FOR(kc, Kc) {
             const uint32_t k = moff2 + kc;
             if (mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[cid[kc]], 1u);
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         ptx_scan_excl<uint32_t, 1, kThreads>(ccnt, Kid + 1, H->scan_tmp, A.div_magic); /* ccnt[c] = first entry of id c, ccnt[Kid] = total */
         PTX_FOR(kc, Kc) {
             const uint32_t k = moff2 + kc;
@@ -1657,11 +1660,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 cent[pos] = e;
             }
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         PTX_FOR(c, Kid + 1) {
             cicnt[c] = c < Kid ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         }
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         const uint32_t I = ptx_scan_excl<uint32_t, 1, kThreads>(cicnt, Kid + 1, H->scan_tmp, A.div_magic);
         PTX_LEADER { H->I = I; }
         /* the interval rows: first into LDS by the per-id sweeps (a lane per id, ragged), then out — rows, break bits and digest — by a dense pass (the
@@ -1688,7 +1691,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             });
         }
         if (crow) {
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             PTX_FOR(r, I) {
                 ptx_cinterval ci;
                 ci.id = crow[2u * r];
@@ -1701,7 +1704,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
         }
         ptx_digest_flush(H, h1, h2);
-        PTX_SYNC();
+        PTX_SYNC_LDS();
     }
     bp.off = mark2_lds; /* release the comment scratch */
     bd.off = elem_lds;
@@ -1744,7 +1747,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 const uint32_t k_hi = four ? K : (g == 0 ? moff1 : g == 1 ? moff2 : g == 2 ? moff3 : K);
                 if (k_hi == k_lo) continue;
                 PTX_FOR(p, ntree * 2 * TV) tree[p] = 0;
-                PTX_SYNC();
+                PTX_SYNC_LDS();
                 /* PTX_UB mark ops per thread and step: the opIds of those that still cover a visible char (LWW order = opId order;
                  * the comment tree only records "some comment op covers") are gathered together — one round trip to HBM per
                  * step instead of one per op */
@@ -1787,7 +1790,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                             ptx_tree_chmax(tree + (four ? ty : 0u) * 2 * TV, TV, lo[u], hi[u], ty == PTX_MARK_COMMENT ? 1u : ((key + 1u) << kbits) | k);
                         }
                 }
-                PTX_SYNC();
+                PTX_SYNC_LDS();
                 PTX_FOR(q, tv) {
                     uint32_t at = 0;
                     for (uint32_t ty = g; ty < g + ntree; ++ty) {
@@ -1805,19 +1808,19 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     }
                     if (at) attr[q + 1] |= at; /* attr[0] = last char of the previous tile */
                 }
-                PTX_SYNC();
+                PTX_SYNC_LDS();
             }
             PTX_LEADER { attr[0] = prev_attr; }
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             /* spans = maximal runs of equal marks over the visible chars (peritext.ts:438-455) */
             PTX_FOR(q, tv) {
                 const uint32_t gq = t0 + q;
                 const bool is_start = gq == 0 || attr[q + 1] != attr[q] || ptx_bittest(brkbits, gq);
                 if (is_start) ptx_atomic_or(&st[q >> 5].bits, 1u << (q & 31));
             }
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             PTX_FOR(w, TV / 32 + 2) st[w].pre = ptx_popc(st[w].bits);
-            PTX_SYNC();
+            PTX_SYNC_LDS();
             const uint32_t S_tile = ptx_scan_excl<uint32_t, 2, kThreads>(&st[0].pre, TV / 32 + 2, H->scan_tmp, A.div_magic);
             PTX_FOR(q, tv) {
                 const PtxBitWord w = st[q >> 5];
@@ -1832,10 +1835,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
             span_base += S_tile;
             prev_attr = attr[tv];
-            PTX_SYNC();
+            PTX_SYNC_LDS();
         }
         ptx_digest_flush(H, h1, h2);
-        PTX_SYNC();
+        PTX_SYNC_LDS();
         PTX_LEADER {
             H->V = V;
             H->S = span_base;
@@ -1846,7 +1849,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             ptx_digest_flush(H, g1, g2);
         }
     }
-    PTX_SYNC();
+    PTX_SYNC_LDS();
     PTX_STAMP(10);
     lds_high = bp.high;
     return PTX_OK;
@@ -1858,6 +1861,6 @@ template <bool kManyActors, uint32_t kThreads, bool kDiag = false>
 PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     uint32_t lds_high = 0;
     const uint32_t status = ptx_merge_log_body<kManyActors, kThreads, kDiag>(A, log, lds, lds_high);
-    PTX_SYNC();
+    PTX_SYNC_LDS();
     ptx_write_result<kDiag>(A, log, (PtxHdr*)lds, status, lds_high);
 }

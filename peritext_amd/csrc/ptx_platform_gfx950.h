@@ -13,6 +13,15 @@
 #define PTX_HD __host__ __device__ static inline
 #define PTX_DEV __device__ __forceinline__
 #define PTX_SYNC() __syncthreads()
+/* the barrier between two phases that talk through LDS only: the wave's LDS operations are complete (lgkmcnt), its loads from and stores to HBM stay in
+ * flight across it.  __syncthreads() also waits for every outstanding global access (vmcnt(0)): the software-pipelined gathers issued ahead of a barrier
+ * would be waited for at the barrier, and every output store would stand in the critical path of its phase. */
+#define PTX_SYNC_LDS()                                                      \
+    do {                                                                    \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     \
+        __builtin_amdgcn_s_barrier();                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");     \
+    } while (0)
 #define PTX_LDS_ALLOCATED(p, used_bytes, total_bytes) ((void)0) /* a hook of the bump allocator (the CPU test-suite's sanitizer build marks the padding) */
 /* P1's list stores: inside the log's LDS window, but — when a header understates the rows of a class — not necessarily inside the list
  * (the log is rejected afterwards); a hook for the CPU test-suite's sanitizer build, which poisons the padding between the arrays */
@@ -25,7 +34,7 @@
         __builtin_amdgcn_wave_barrier();                         \
     } while (0)
 /* the barrier of a phase in a kernel that may run as ONE wave (kThreads == 64 known at compile time) */
-#define PTX_SYNC_T() do { if (kThreads == 64u) PTX_WSYNC(); else __syncthreads(); } while (0)
+#define PTX_SYNC_T() do { if (kThreads == 64u) PTX_WSYNC(); else PTX_SYNC_LDS(); } while (0)
 /* threads per workgroup: a compile-time constant in the builds specialised for the usual launch shapes (kThreads != 0:
  * the per-phase loop bounds and strides then fold, which removes a quarter of the scalar instructions), else blockDim.x */
 #define PTX_BLOCKDIM (kThreads ? kThreads : blockDim.x)
@@ -282,16 +291,18 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
     return total;
 }
 
-/* diagnostic build only: phase k = time from stamp k to the next recorded stamp, summed over the logs */
+/* diagnostic build only: phase k = time from stamp k to the stamp recorded next IN TIME (the stamp indices are not in execution order), summed over the logs */
 PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* clk, int nclk) {
     if (!clocks) return;
     clk[nclk] = ptx_clock();
 #pragma nounroll
     for (int k = 0; k < nclk; ++k) {
         if (clk[k] == 0) continue;
-        int j = k + 1;
-        while (j < nclk && clk[j] == 0) ++j;
-        atomicAdd(&clocks[k], clk[j] - clk[k]);
+        unsigned long long next = clk[nclk];
+#pragma nounroll
+        for (int j = 0; j < nclk; ++j)
+            if (clk[j] > clk[k] && clk[j] < next) next = clk[j];
+        atomicAdd(&clocks[k], next - clk[k]);
     }
 }
 

@@ -11,8 +11,9 @@ sys.path.insert(0, ROOT)
 from peritext_amd import abi, workloads  # noqa: E402
 from peritext_amd.engine import Engine  # noqa: E402
 
-PHASES = ["P0+P1 admission+rows", "P2 index+lists", "P3a buckets", "P3b child order", "P3c tour+rank", "P4 tombstones", "P5a values+intervals",
-          "P5b LWW trees", "P5c comments", "P6 spans+digest"]
+PHASES = {0: "P0 admission", 1: "P1 row loop", 11: "P1 tail (census, dup, scan)", 2: "P3a index+parents", 12: "P3b scatter+checks", 3: "P3c child order", 4: "P3d tour",
+          14: "P3d ranking+unpark", 5: "P4 tombstones", 6: "P5a values", 13: "P5a mark intervals", 7: "P5c comments", 8: "P5b trees + P6 spans", 10: "end"}
+ORDER = [0, 1, 11, 2, 12, 3, 4, 14, 5, 6, 13, 7, 8]
 
 
 def main():
@@ -54,7 +55,7 @@ def main():
         row = {"lib": os.path.basename(args.lib or "default"), "config": args.config, "threads": t, "flags": args.flags, "ms": ms, "Gops_s": ops / ms / 1e6,
                "us_per_log_per_cu": ms * 1e3 * 256 / n_logs, "lds_high": int(logs["reserved"][:, 0].max()), "launch": eng.launch_shape(db),
                "cycles_per_log": tot / n_logs, "gen_ms": info["kernel_ms"],
-               "phases": {PHASES[k] if k < len(PHASES) else str(k): round(cyc[k] / n_logs) for k in range(len(cyc)) if cyc[k]}}
+               "phases": {PHASES.get(k, str(k)): round(cyc[k] / n_logs) for k in ORDER if k < len(cyc) and cyc[k]}}
         print(json.dumps(row), flush=True)
         eng.free_result(dr)
         eng.free_batch(db)
