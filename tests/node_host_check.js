@@ -298,6 +298,38 @@ if (cmd === "encode") {
     assert.ok(got.statuses.every(s => s === 0))
     engine.close()
     console.log(JSON.stringify({ ok: true, docs: docs.length, converged: got.converged }))
+} else if (cmd === "commrank") {
+    /* GPU: ONE RANK of a multi-process digest all-gather through N-API (tests/test_gpu_shard_ranks.py: the processes share GPU 0, RCCL is the
+     * test-suite's shared-memory stand-in): node tests/node_host_check.js commrank <rank> <nRanks> <idFile> <docs.json> */
+    const rank = Number(process.argv[3]), nRanks = Number(process.argv[4]), idFile = process.argv[5]
+    const docs = JSON.parse(fs.readFileSync(process.argv[6], "utf8")).docs
+    const R = docs[0].length
+    const range = r => { const base = Math.floor(docs.length / nRanks), extra = docs.length % nRanks; return [r * base + Math.min(r, extra), base + (r < extra ? 1 : 0)] }
+    const counts = []
+    for (let r = 0; r < nRanks; r++) counts.push(range(r)[1] * R)
+    const engine = new host.MergeEngine()
+    let id
+    if (rank === 0) {
+        id = engine.commUniqueId()
+        fs.writeFileSync(idFile + ".tmp", Buffer.from(id))
+        fs.renameSync(idFile + ".tmp", idFile)
+    } else {
+        const t0 = Date.now(), nap = new Int32Array(new SharedArrayBuffer(4))
+        while (!fs.existsSync(idFile)) {
+            if (Date.now() - t0 > 60000) throw new Error("rank 0 never published the communicator id")
+            Atomics.wait(nap, 0, 0, 10)
+        }
+        id = new Uint8Array(fs.readFileSync(idFile))
+    }
+    const comm = engine.commInit(id, rank, nRanks)
+    const [first, count] = range(rank)
+    const mine = docs.slice(first, first + count)
+    const got = engine.convergedDocs(mine, comm, counts, R)
+    assert.throws(() => engine.convergedDocs(mine, comm, counts.concat([3]), R), /rank count/) /* ADVICE r2: counts.length is checked against the communicator */
+    engine.commDestroy(comm)
+    engine.close()
+    console.log(JSON.stringify({ ok: true, rank, counts, converged: got.converged, total: got.total,
+        gathered: got.digests.map(d => d[0].toString(16).padStart(16, "0") + d[1].toString(16).padStart(16, "0")), statuses: got.statuses }))
 } else if (cmd === "pmdoc") {
     /* no GPU: ProseMirror doc JSON of every expected span list of a fixture */
     const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))

@@ -376,6 +376,37 @@ def test_digest_allgather_in_the_c_abi_single_rank(eng):
         eng.free_batch(db)
 
 
+def test_padded_gather_path_with_real_rccl_single_rank():
+    """PTX_FLAG_PAD_GATHER: pack -> all-gather of max(counts) pairs -> ptx_compact_digests_kernel, here with the REAL RCCL and a communicator of one rank
+    (the multi-process runs of the same path are in test_gpu_shard_ranks.py, over the test-suite's RCCL stand-in)."""
+    import torch
+    from peritext_amd.engine import Engine
+
+    g = _load("ptxgen_config4_600.json")
+    batch = wire.encode_docs([d["logs"] for d in g["docs"]])
+    with Engine(0, flags=abi.FLAG_PAD_GATHER) as e:
+        db = e.upload(batch, copies=3)
+        dr = e.alloc_result(db)
+        n_logs = e.n_logs(db)
+        comm = e.comm_init(e.comm_unique_id(), 0, 1)
+        gathered = torch.zeros((n_logs, 2), dtype=torch.int64, device="cuda")
+        count = torch.full((1,), -1, dtype=torch.int64, device="cuda")
+        try:
+            e.merge(db, dr)
+            for _ in range(2):  # the second call reuses the cached block table
+                e.allgather_digests(comm, dr, [n_logs], gathered.data_ptr())
+            e.count_converged_digests(gathered.data_ptr(), n_logs, 3, count.data_ptr())
+            e.sync()
+            logs = e.download_logs(dr, n_logs)
+            assert (gathered.cpu().numpy().view(np.uint64) == logs["digest"]).all() and int(count.item()) == n_logs // 3
+            with pytest.raises(ValueError):
+                e.allgather_digests(comm, dr, [n_logs, 3], gathered.data_ptr())  # ADVICE r2: one count per rank of the communicator
+        finally:
+            e.comm_destroy(comm)
+            e.free_result(dr)
+            e.free_batch(db)
+
+
 def test_malformed_rows_are_named(eng):
     """GPU twin: the row pass only flags malformed rows while it streams (and keeps every store inside the log's LDS window when a
     header understates the rows); the first failing row is named by a second pass."""
