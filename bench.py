@@ -131,7 +131,7 @@ def extra_legs(args, n_docs, first_doc, local, iters):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_extras.py"), "--config", args.config, "--docs", str(n_docs), "--first-doc", str(first_doc), "--seed", str(args.seed),
            "--list-cap", str(args.list_cap), "--iters", str(iters), "--device", str(local)] + (["--ops", str(args.ops)] if args.ops else []) + (["--no-admission"] if args.no_admission else [])
     try:
-        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
         return json.loads(p.stdout.strip().splitlines()[-1])
     except Exception as ex:  # noqa: BLE001
         return {"error": str(ex)[:300]}

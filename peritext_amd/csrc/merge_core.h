@@ -179,16 +179,19 @@ PTX_DEV void ptx_raise(PtxHdr* H, uint32_t row, uint32_t level, uint32_t code) {
     ptx_atomic_min(&H->err, ((row * 2u + level) << 4) | code);
 }
 
-/* a thread's share of the digest: two 8-byte LDS atomics, issued by the threads that have one (a few dozen per log: the wave-wide butterfly this
- * replaces cost every wave ~70 vector instructions per flush, three flushes per log) */
+/* a thread's share of the digest goes to the header as two 8-byte LDS atomics, issued by the threads that have one (in a sparse document a few dozen per
+ * log: the wave-wide butterfly cost every wave ~70 vector instructions per flush, three flushes per log).  ptx_digest_flush_dense is the butterfly: for
+ * the passes in which most lanes of a wave carry a share (same-address atomics are served one lane at a time). */
 PTX_DEV void ptx_digest_flush(PtxHdr* H, uint64_t h1, uint64_t h2) {
     if ((h1 | h2) != 0) {
         ptx_atomic_add64(&H->h1, (unsigned long long)h1);
         ptx_atomic_add64(&H->h2, (unsigned long long)h2);
     }
 }
-
-
+PTX_DEV void ptx_digest_flush_dense(PtxHdr* H, uint64_t h1, uint64_t h2) {
+    ptx_reduce_add64(&H->h1, (unsigned long long)h1);
+    ptx_reduce_add64(&H->h2, (unsigned long long)h2);
+}
 
 /* ---- bit-rank: one 8-byte LDS word per 32 positions = {bits, exclusive popcount prefix} ---- */
 struct PtxBitWord {
@@ -1478,18 +1481,30 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         brkbits[w] = 0;
     }
     PTX_SYNC_LDS();
-    /* word by word over the tombstone bitmap, a lane per 32 elements: the work is per SURVIVING element (a document that has seen
-     * thousands of ops usually shows a few dozen characters), not per element ever inserted */
+    /* Over the SURVIVING elements.  Sparse documents (a document that has seen thousands of ops usually shows a few dozen characters) go word by word over
+     * the tombstone bitmap, a lane per 32 elements, so that the work is per survivor and not per element ever inserted; documents that keep a good share of
+     * their elements go element by element (a lane would loop over up to 32 survivors one after the other). */
 #define PTX_LIVE_WORD(w_) ((~delbits[w_]) & ((w_) == (n >> 5) ? (1u << (n & 31u)) - 1u : 0xFFFFFFFFu))
-    PTX_FOR(w, nwe) {
-        uint32_t live = PTX_LIVE_WORD(w);
-        while (live) {
-            const uint32_t e = (w << 5) + (uint32_t)__builtin_ctz(live);
-            live &= live - 1u;
-            const uint32_t r = rnk[e];
-            ptx_atomic_or(&alive[r >> 5].bits, 1u << (r & 31));
+    auto for_live = [&](bool sparse, auto body) {
+        if (sparse) {
+            PTX_FOR(w, nwe) {
+                uint32_t live = PTX_LIVE_WORD(w);
+                while (live) {
+                    const uint32_t e = (w << 5) + (uint32_t)__builtin_ctz(live);
+                    live &= live - 1u;
+                    body(e);
+                }
+            }
+        } else {
+            PTX_FOR(e, n) {
+                if (!ptx_bittest(delbits, e)) body(e);
+            }
         }
-    }
+    };
+    for_live((n > D ? n - D : 0u) * 8u < n, [&](uint32_t e) { /* (n - D: the least number of survivors the header allows) */
+        const uint32_t r = rnk[e];
+        ptx_atomic_or(&alive[r >> 5].bits, 1u << (r & 31));
+    });
     PTX_SYNC_LDS();
     PTX_FOR(w, nwv + 1) alive[w].pre = ptx_popc(alive[w].bits);
     PTX_SYNC_LDS();
@@ -1509,17 +1524,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         /* the surviving elements again (a lane per word of the tombstone bitmap): their rows by visible index (= alive bits below the element's position) into
          * a dense list — the digest is ~100 vector instructions per item and wave, so it runs over a packed list (one wave pass per 64 visible characters),
          * never inside the sparse loop */
+        const bool sparse = V * 8u < n;
         if (2u * (V + 1u) <= mrk_bytes) {
             uint16_t* vrow = mrk_lo;
             PTX_LDS_ALLOCATED(mrk_lo, mrk_bytes, mrk_bytes); /* (the list runs over the three arrays and the padding between them) */
-            PTX_FOR(w, nwe) {
-                uint32_t live = PTX_LIVE_WORD(w);
-                while (live) {
-                    const uint32_t e = (w << 5) + (uint32_t)__builtin_ctz(live);
-                    live &= live - 1u;
-                    vrow[ptx_bitrank(alive, rnk[e])] = row_of[e];
-                }
-            }
+            for_live(sparse, [&](uint32_t e) { vrow[ptx_bitrank(alive, rnk[e])] = row_of[e]; });
             PTX_SYNC_LDS();
             PTX_FOR(q, V) {
                 const uint32_t row = vrow[q];
@@ -1528,17 +1537,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 ptx_digest_item(h1, h2, 1u, q, v, 0u);
             }
         } else { /* (a log with hardly any mark op and many visible characters: no room for the list) */
-            PTX_FOR(w, nwe) {
-                uint32_t live = PTX_LIVE_WORD(w);
-                while (live) {
-                    const uint32_t e = (w << 5) + (uint32_t)__builtin_ctz(live);
-                    live &= live - 1u;
-                    const uint32_t row = row_of[e], q = ptx_bitrank(alive, rnk[e]);
-                    const uint32_t v = payload[row < N ? row : N - 1u];
-                    A.out_values[base + q] = v;
-                    ptx_digest_item(h1, h2, 1u, q, v, 0u);
-                }
-            }
+            for_live(sparse, [&](uint32_t e) {
+                const uint32_t row = row_of[e], q = ptx_bitrank(alive, rnk[e]);
+                const uint32_t v = payload[row < N ? row : N - 1u];
+                A.out_values[base + q] = v;
+                ptx_digest_item(h1, h2, 1u, q, v, 0u);
+            });
         }
         /* elem_rank (optional output): document position + tombstone flag of EVERY element, by the row that inserted it */
         if (A.out_rank) {
@@ -1547,7 +1551,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 A.out_rank[base + row_of[e]] = r | (ptx_bittest(delbits, e) ? PTX_RANK_TOMBSTONE : 0u);
             }
         }
-        ptx_digest_flush(H, h1, h2);
+        if (V >= 48u) ptx_digest_flush_dense(H, h1, h2); /* uniform: most lanes of a wave carry a share */
+        else ptx_digest_flush(H, h1, h2);
         PTX_SYNC_LDS(); /* vrow (= the head of mrk_lo) has been read by everyone before the first interval is stored */
     }
 #undef PTX_LIVE_WORD
@@ -1837,7 +1842,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             prev_attr = attr[tv];
             PTX_SYNC_LDS();
         }
-        ptx_digest_flush(H, h1, h2);
+        if (V >= 48u) ptx_digest_flush_dense(H, h1, h2); /* uniform: most lanes of a wave carry a share */
+        else ptx_digest_flush(H, h1, h2);
         PTX_SYNC_LDS();
         PTX_LEADER {
             H->V = V;

@@ -1,28 +1,124 @@
 #!/usr/bin/env python3
 """The extra legs of bench.py, in a process of their own (no torch; nothing here is the bench's `value`):
-  patch_replay  ptx_replay_patches on 2 048 documents of the bench's config: ops replayed per second (kernel time measured inside the library);
-  experiments   the bench's workload (same generator arguments, so the same documents) under the product build, then under every experimental build
-                peritext_amd/lib/exp_*.so (__graft_entry__.EXPERIMENTS) and under other launch shapes of the product build (PTX_THREADS): kernel ms per
-                launch (HIP events on the engine's stream), and whether statuses / digests / row counts of EVERY log equal the product build's.
+  baseline_configs  EVERY other BASELINE.json configuration on this GPU — #2 (1 024 docs x 256 ops as specified, and a GPU-filling multiple), #3 (8 192 docs x
+                    1 024 ops, and a GPU-filling multiple), #5 (8 192-op logs with link / comment marks and 50 % deletes: the share of one of eight GPUs and
+                    twice that) — each with the kernel's launch duration (HIP events on the engine's stream), the SURVEY 8(d) roofline fraction of that launch
+                    (B_alg = sum of 32 N + 4 V + 8 S + 16 T + 16 over its logs), the launch shape, and --parity-docs documents of the resident batch
+                    checked against the oracle on the host (whole logs: decoded spans, raw rows, digests);
+  patch_replay      ptx_replay_patches on 2 048 documents of the bench's config: ops replayed per second (kernel time measured in the library);
+  phase_cycles      where a log's residency goes (thread-0 cycle stamps of the diagnostic build of the same kernel body), loaded and with a CU to itself;
+  candidate         when a candidate build peritext_amd/lib/exp_<name>.so stands beside the product (__graft_entry__.CANDIDATE): the bench's workload under
+                    it, same box, same call, every log's status / digest / row counts compared with the product's.
 Every leg records its own failure instead of raising.  One JSON line on stdout.
     python tools/bench_extras.py --config config4 --docs 65536 [--iters 10]"""
 import argparse
 import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from peritext_amd import abi, workloads  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from peritext_amd import abi, wire, workloads  # noqa: E402
 from peritext_amd.engine import Engine  # noqa: E402
 
 T0 = time.time()
+HBM_PEAK = 8.0e12
+PHASES = {0: "P0 admission", 1: "P1 row loop", 11: "P1 tail (census, dup, scan)", 2: "P3a index+parents", 12: "P3b scatter+checks", 3: "P3c child order", 4: "P3d tour",
+          14: "P3d ranking+unpark", 5: "P4 tombstones", 6: "P5a values", 13: "P5a mark intervals", 7: "P5c comments", 8: "P5b trees + P6 spans"}
+ORDER = [0, 1, 11, 2, 12, 3, 4, 14, 5, 6, 13, 7, 8]
+# (config, documents): the specified size first, then sizes that fill the GPU
+BASELINE_LEGS = [("config2", 1024), ("config2", 524288), ("config3", 8192), ("config3", 196608), ("config5", 32768), ("config5", 65536)]
 
 
 def say(msg):
     print("[extras %6.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
+
+
+def oracle_spans(docs_logs):
+    """Expected {spans, text} of every replica log through oracle/peritext_oracle.js (whole logs, Patch[] bookkeeping off), one node process per 4 logs."""
+    node = shutil.which("node")
+    if node is None:
+        raise RuntimeError("node (the oracle runtime) is not on this box")
+    flat = [(d, r) for d in range(len(docs_logs)) for r in range(len(docs_logs[d]))]
+    parts = [flat[p::8] for p in range(min(8, len(flat)))]
+    td = tempfile.mkdtemp(prefix="ptxextra_")
+    jobs = []
+    for p, mine in enumerate(parts):
+        inp, outp = os.path.join(td, "in%d.json" % p), os.path.join(td, "out%d.json" % p)
+        with open(inp, "w") as f:
+            json.dump({"docs": [{"logs": [docs_logs[d][r]]} for d, r in mine]}, f)
+        jobs.append((subprocess.Popen([node, os.path.join(ROOT, "oracle", "cli.js"), "apply", "--impl", "oracle", "--no-patches", "--in", inp, "--out", outp], cwd=ROOT), outp))
+    expected = [[None] * len(l) for l in docs_logs]
+    for (pr, outp), mine in zip(jobs, parts):
+        if pr.wait() != 0:
+            raise RuntimeError("oracle run failed")
+        with open(outp) as f:
+            o = json.load(f)
+        for (d, r), e in zip(mine, o["docs"]):
+            expected[d][r] = e["expected"][0]
+    shutil.rmtree(td, ignore_errors=True)
+    return expected
+
+
+def config_leg(args, name, docs, flags):
+    """One BASELINE configuration resident on the GPU: kernel ms, SURVEY 8(d) fraction, launch shape, oracle parity of a few of its documents."""
+    import helpers
+
+    g = workloads.gen_config(name)
+    gen_args = (g["replicas"], g["ops_per_log"], g["mix"], g["mark_types"])
+    row = {"config": name, "docs": docs, "replicas": g["replicas"], "ops_per_log": g["ops_per_log"], "mix_ins_del_add_rem": g["mix"], "causal_admission": not args.no_admission}
+    try:
+        with Engine(args.device, flags=flags) as e:
+            list_cap = max(args.list_cap, g["ops_per_log"] // 2 + 512)  # the longest element list a replica holds on chip while its document is generated
+            db, info = e.generate(*gen_args, docs, args.seed, list_cap=list_cap)
+            n_logs, rows = e.n_logs(db), e.n_ops(db)
+            dr = e.alloc_result(db)
+            e.merge(db, dr)
+            e.sync()
+            iters = max(args.iters, 3)
+            ms = min(e.merge_timed(db, dr, iters) / iters for _ in range(2))
+            logs = e.download_logs(dr, n_logs)
+            ok = bool(int(logs["status"].max()) == 0)
+            V, S, T = int(logs["n_visible"].sum()), int(logs["n_spans"].sum()), int(logs["n_cintervals"].sum())
+            alg = 32 * rows + 4 * V + 8 * S + 16 * T + 16 * n_logs
+            env = 0 if args.no_admission else abi.envelope_bytes(e.n_changes(db), g["replicas"])
+            threads, lds = e.launch_shape(db)
+            row.update({"replica_logs": n_logs, "ops": n_logs * g["ops_per_log"], "kernel_ms": ms, "ops_per_s": n_logs * g["ops_per_log"] / (ms * 1e-3), "every_log_ok": ok,
+                        "algorithmic_bytes": alg, "roofline_GBps": alg / (ms * 1e-3) / 1e9, "roofline_frac": alg / (ms * 1e-3) / HBM_PEAK,
+                        "with_envelope_frac": (alg + env) / (ms * 1e-3) / HBM_PEAK, "launch": {"threads_per_log": threads, "lds_bytes_per_log": lds,
+                                                                                                 "logs_per_cu_by_lds": int((160 * 1024) // max(512, (lds + 511) // 512 * 512))},
+                        "lds_high": int(logs["reserved"][:, 0].max()), "visible_chars_per_log": V / n_logs, "gen_kernel_ms": info["kernel_ms"]})
+            # parity: documents of the RESIDENT batch (regenerated one by one with the same generator arguments, so the same documents) against the oracle
+            if args.parity_docs > 0 and shutil.which("node"):
+                rng = np.random.default_rng(args.seed + docs)
+                pick = sorted(int(x) for x in rng.choice(docs, size=min(args.parity_docs, docs), replace=False))
+                ones, docs_logs = [], []
+                for d in pick:
+                    hb, hinfo = e.generate(*gen_args, 1, args.seed, first_doc=d, list_cap=list_cap)
+                    actors_t, comments_t, log_doc_t = wire.generated_tables(1, g["replicas"], hinfo["n_comments"])
+                    one = e.download_batch(hb, wire.GEN_VALUES, wire.GEN_URLS, log_doc_t, actors_t, comments_t)
+                    e.free_batch(hb)
+                    ones.append(one)
+                    docs_logs.append([wire.decode_changes(one, r) for r in range(g["replicas"])])
+                expected = oracle_spans(docs_logs)
+                for d, one, exp in zip(pick, ones, expected):
+                    sub = e.download_range(db, dr, d * g["replicas"], g["replicas"])
+                    for r in range(g["replicas"]):
+                        helpers.check_log(one, sub, r, exp[r])
+                row["parity"] = {"documents_checked": len(pick), "against": "oracle/peritext_oracle.js (whole logs): decoded spans, raw rows, digests of the resident batch's result rows"}
+            e.free_result(dr)
+            e.free_batch(db)
+    except Exception as ex:  # noqa: BLE001
+        row["error"] = str(ex)[:300]
+    return row
 
 
 def main():
@@ -36,28 +132,25 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--no-admission", action="store_true")
-    ap.add_argument("--threads", default="128,256", help="launch shapes of the product build to time beside its own choice")
+    ap.add_argument("--parity-docs", type=int, default=8)
+    ap.add_argument("--legs", default="configs,replay,phases,candidate,probe")
     args = ap.parse_args()
+    legs = set(args.legs.split(","))
     g = workloads.gen_config(args.config, ops=args.ops)
     gen_args = (g["replicas"], g["ops_per_log"], g["mix"], g["mark_types"])
-    out = {"patch_replay": None, "experiments": None}
+    flags = abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0)
+    out = {}
 
-    def stream_checksum(pat):
-        """Order-sensitive checksum over the records every log really produced (the rows past a log's count are capacity, not data)."""
-        import numpy as np
+    if "configs" in legs:
+        out["baseline_configs"] = []
+        for name, docs in BASELINE_LEGS:
+            row = config_leg(args, name, docs, flags)
+            out["baseline_configs"].append(row)
+            say("baseline_configs %s" % json.dumps(row))
 
-        caps = np.diff(pat.patch_off.astype(np.int64))
-        n = pat.logs["n_patches"].astype(np.int64)
-        valid = (np.arange(int(caps.sum()), dtype=np.int64) - np.repeat(pat.patch_off[:-1].astype(np.int64), caps)) < np.repeat(n, caps)
-        rows = pat.patches[: len(valid)][valid]
-        w = np.arange(1, len(rows) + 1, dtype=np.uint64)
-        mix = (rows["row"].astype(np.uint64) * np.uint64(0x9E3779B1) + rows["kind"].astype(np.uint64) * np.uint64(0x85EBCA77) + rows["a"].astype(np.uint64) * np.uint64(0xC2B2AE3D)
-               + rows["b"].astype(np.uint64) * np.uint64(0x27D4EB2F))
-        return int(n.sum()), int((mix * w).sum() & np.uint64(0xFFFFFFFFFFFFFFFF))
-
-    def replay_rate(lib):
+    if "replay" in legs:
         try:
-            with Engine(args.device, lib_path=lib) as e:  # with elem_rank: the replay reads it
+            with Engine(args.device) as e:  # with elem_rank: the replay reads it
                 docs = min(2048, args.docs)
                 db, _ = e.generate(*gen_args, docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
                 dr = e.alloc_result(db)
@@ -66,92 +159,75 @@ def main():
                 pat = e.replay_patches(db, dr)
                 ops = e.n_logs(db) * g["ops_per_log"]
                 n_pat = int(pat.logs["n_patches"].sum())
-                r = {"build": os.path.basename(lib or "libperitext_hip.so"), "docs": docs, "ops": ops, "patches": n_pat, "kernel_ms": pat.kernel_ms, "launches": pat.launches,
-                     "every_log_has_a_stream": bool(int(pat.logs["status"].max()) == 0), "ops_per_s": ops / pat.kernel_ms * 1e3, "patches_per_s": n_pat / pat.kernel_ms * 1e3,
-                     "_sum": stream_checksum(pat)}
+                out["patch_replay"] = {"docs": docs, "ops": ops, "patches": n_pat, "kernel_ms": pat.kernel_ms, "launches": pat.launches,
+                                       "every_log_has_a_stream": bool(int(pat.logs["status"].max()) == 0), "ops_per_s": ops / pat.kernel_ms * 1e3,
+                                       "patches_per_s": n_pat / pat.kernel_ms * 1e3}
                 e.free_result(dr)
                 e.free_batch(db)
-                return r
         except Exception as ex:  # noqa: BLE001
-            return {"build": os.path.basename(lib or "libperitext_hip.so"), "error": str(ex)[:300]}
+            out["patch_replay"] = {"error": str(ex)[:300]}
+        say("patch_replay %s" % json.dumps(out["patch_replay"]))
 
-    out["patch_replay"] = replay_rate(None)
-    say("patch_replay %s" % json.dumps({k: v for k, v in out["patch_replay"].items() if k != "_sum"}))
-    # the same under every experimental build (exp_nopark carries the replay as it was measured before, PTX_REPLAY_V1; exp_replay_* other searches)
-    others = []
-    for lib in sorted(glob.glob(os.path.join(ROOT, "peritext_amd", "lib", "exp_*.so"))):
-        other = replay_rate(lib)
-        if "_sum" in other and "_sum" in out["patch_replay"]:
-            other["same_streams_by_checksum"] = other["_sum"] == out["patch_replay"]["_sum"]
-        other.pop("_sum", None)
-        others.append(other)
-        say("patch_replay %s" % json.dumps(other))
-    out["patch_replay"].pop("_sum", None)
-    out["patch_replay"]["other_builds"] = others
-
-    flags = abi.FLAG_NO_ELEM_RANK | (abi.FLAG_NO_ADMISSION if args.no_admission else 0)
-    variants = [("product build", None, 0)]
-    variants += [(os.path.basename(p)[:-3], p, 0) for p in sorted(glob.glob(os.path.join(ROOT, "peritext_amd", "lib", "exp_*.so")))]
-    variants += [("product build, %d threads per log" % int(t), None, int(t)) for t in args.threads.split(",") if t]
-    rows, ref = [], None
-    for name, lib, threads in variants:
-        row = {"name": name}
-        try:
-            e = Engine(args.device, flags=flags, lib_path=lib)
-            if threads:
-                e.set_launch_shape(threads, 0)
-            db, _ = e.generate(*gen_args, args.docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
-            dr = e.alloc_result(db)
-            e.merge(db, dr)
-            e.sync()
-            row["kernel_ms"] = e.merge_timed(db, dr, args.iters) / args.iters
-            row["launch"] = list(e.launch_shape(db))
-            if ref is None:  # the product build: where a log's residency goes (thread-0 cycle stamps of the diagnostic build of the same kernel body)
-                try:
-                    cyc = e.phase_cycles(db, dr)
-                    names = ["P0+P1 admission+rows", "P2", "P3a+P3b buckets", "P3c child order", "P3d tour+rank", "P4 tombstones", "P5a values+intervals", "P5c comments",
-                             "P5b+P6 LWW trees+spans", "P6 tail"]
-                    row["phase_cycles_per_log"] = {(names[k] if k < len(names) else str(k)): round(cyc[k] / e.n_logs(db)) for k in range(len(cyc)) if cyc[k]}
-                    e.merge(db, dr)  # the diagnostic launch wrote the same rows; run the product kernel once more before they are read
+    ref = None
+    if "phases" in legs or "candidate" in legs:
+        variants = [("product build", None)]
+        if "candidate" in legs:
+            variants += [(os.path.basename(p)[:-3], p) for p in sorted(glob.glob(os.path.join(ROOT, "peritext_amd", "lib", "exp_*.so"))) if not p.endswith(("exp_diag.so", "exp_base.so"))]
+        rows = []
+        for name, lib in variants:
+            row = {"name": name}
+            try:
+                with Engine(args.device, flags=flags, lib_path=lib) as e:
+                    db, _ = e.generate(*gen_args, args.docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
+                    dr = e.alloc_result(db)
+                    e.merge(db, dr)
                     e.sync()
-                except Exception as ex:  # noqa: BLE001
-                    row["phase_cycles_per_log"] = {"error": str(ex)[:200]}
-            lo = e.download_logs(dr, e.n_logs(db))
-            if ref is None:
-                ref = lo
-                row["every_log_ok"] = bool(int(lo["status"].max()) == 0)
-            else:
-                row["identical_results"] = bool((lo["status"] == ref["status"]).all() and (lo["digest"] == ref["digest"]).all() and (lo["n_spans"] == ref["n_spans"]).all()
-                                                and (lo["n_visible"] == ref["n_visible"]).all())
-            e.free_result(dr)
-            e.free_batch(db)
-            e.close()
+                    row["kernel_ms"] = e.merge_timed(db, dr, args.iters) / args.iters
+                    row["launch"] = list(e.launch_shape(db))
+                    if ref is None and "phases" in legs:
+                        cyc = e.phase_cycles(db, dr)
+                        row["phase_cycles_per_log"] = {PHASES.get(k, str(k)): round(cyc[k] / e.n_logs(db)) for k in ORDER if k < len(cyc) and cyc[k]}
+                        e.merge(db, dr)  # the diagnostic launch wrote the same rows; run the product kernel once more before they are read
+                        e.sync()
+                    lo = e.download_logs(dr, e.n_logs(db))
+                    if ref is None:
+                        ref = lo
+                        row["every_log_ok"] = bool(int(lo["status"].max()) == 0)
+                    else:
+                        row["identical_results"] = bool((lo["status"] == ref["status"]).all() and (lo["digest"] == ref["digest"]).all() and (lo["n_spans"] == ref["n_spans"]).all()
+                                                        and (lo["n_visible"] == ref["n_visible"]).all())
+                    e.free_result(dr)
+                    e.free_batch(db)
+            except Exception as ex:  # noqa: BLE001
+                row["error"] = str(ex)[:300]
+            rows.append(row)
+            say(json.dumps(row))
+        out["same_workload"] = {"workload": "%s, %d docs (the bench's own documents)" % (args.config, args.docs), "launches_each": args.iters, "same_box_same_call": True, "builds": rows}
+
+    if "probe" in legs:
+        # how long ONE log takes when it has a CU to itself, and one full set of resident logs per CU (chain latency against contention)
+        probes = []
+        try:
+            with Engine(args.device, flags=flags) as e:
+                for docs in (85, 683, 5461):  # x 3 replicas = 255 / 2 049 / 16 383 logs: ~1, ~8, ~64 per CU
+                    if docs > args.docs:
+                        continue
+                    db, _ = e.generate(*gen_args, docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
+                    dr = e.alloc_result(db)
+                    e.merge(db, dr)
+                    e.sync()
+                    ms = e.merge_timed(db, dr, args.iters) / args.iters
+                    row = {"logs": e.n_logs(db), "kernel_ms": ms, "us_per_log_per_cu": ms * 1e3 * 256 / e.n_logs(db)}
+                    if docs == 85:
+                        cyc = e.phase_cycles(db, dr)
+                        row["phase_cycles_per_log_alone"] = {PHASES.get(k, str(k)): round(cyc[k] / e.n_logs(db)) for k in ORDER if k < len(cyc) and cyc[k]}
+                    probes.append(row)
+                    e.free_result(dr)
+                    e.free_batch(db)
         except Exception as ex:  # noqa: BLE001
-            row["error"] = str(ex)[:300]
-        rows.append(row)
-        say(json.dumps(row))
-        if ref is None:
-            break  # nothing to compare the variants with
-    # how long ONE log takes when it has a CU to itself, and one full set of resident logs per CU (chain latency against contention)
-    probes = []
-    try:
-        with Engine(args.device, flags=flags) as e:
-            for docs in (85, 683, 5461):  # x 3 replicas = 255 / 2 049 / 16 383 logs: ~1, ~8, ~64 per CU
-                if docs > args.docs:
-                    continue
-                db, _ = e.generate(*gen_args, docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
-                dr = e.alloc_result(db)
-                e.merge(db, dr)
-                e.sync()
-                ms = e.merge_timed(db, dr, args.iters) / args.iters
-                probes.append({"logs": e.n_logs(db), "kernel_ms": ms, "us_per_log_per_cu": ms * 1e3 * 256 / e.n_logs(db)})
-                e.free_result(dr)
-                e.free_batch(db)
-    except Exception as ex:  # noqa: BLE001
-        probes.append({"error": str(ex)[:300]})
-    out["occupancy_probe"] = probes
-    say("occupancy_probe %s" % json.dumps(probes))
-    out["experiments"] = {"workload": "%s, %d docs (the bench's own documents)" % (args.config, args.docs), "launches_each": args.iters, "same_box_same_call": True, "variants": rows}
+            probes.append({"error": str(ex)[:300]})
+        out["occupancy_probe"] = probes
+        say("occupancy_probe %s" % json.dumps(probes))
     print(json.dumps(out), flush=True)
 
 
