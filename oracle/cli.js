@@ -186,6 +186,7 @@ if (cmd === "gen") {
     const impl = flag("--impl", "oracle")
     const Impl = implClass(impl)
     const budgetMs = parseFloat(flag("--budget-ms", "10000"))
+    const whole = process.argv.includes("--whole") /* whole logs: the budget is only a deadline against a hang (a log it cuts is reported as cut) */
     const input = JSON.parse(fs.readFileSync(flag("--in"), "utf8"))
     let logs = 0
     let ops = 0

@@ -106,33 +106,6 @@ struct PtxMergeArgs {
     const uint32_t* log_index; /* optional: workgroup i handles log log_index[i] (launches over a subset of the logs) */
 };
 
-/* sensitivity probe (experimental builds only, -DPTX_PROBE=k): 64 extra instructions of one kind per step of the row loop — which unit answers? */
-#ifndef PTX_PROBE
-#define PTX_PROBE_HERE
-#elif PTX_PROBE == 1
-#define PTX_PROBE_HERE { _Pragma("unroll") for (int q_ = 0; q_ < 64; ++q_) asm volatile("s_nop 0"); }
-#elif PTX_PROBE == 2
-#define PTX_PROBE_HERE { uint32_t d_ = 0; _Pragma("unroll") for (int q_ = 0; q_ < 64; ++q_) asm volatile("v_mov_b32 %0, %0" : "+v"(d_)); }
-#elif PTX_PROBE == 3
-#define PTX_PROBE_HERE { uint32_t d_ = 0; _Pragma("unroll") for (int q_ = 0; q_ < 64; ++q_) asm volatile("s_mov_b32 %0, %0" : "+s"(d_)); }
-#elif PTX_PROBE == 5 /* + one read of the ref_b column (8 bytes per row, ~256 more cache lines per 4K-op log) beside the row loop's own loads */
-#define PTX_PROBE_HERE { const uint32_t r_ = g * PTX_U1 + 2u < N ? g * PTX_U1 : 0u; const uint64_t x_ = ref_b[r_] | ref_b[r_ + 1u] | ref_b[r_ + 2u]; err4 |= (uint32_t)(x_ >> 63); }
-#elif PTX_PROBE == 4
-#define PTX_PROBE_HERE { uint32_t d_ = 0; _Pragma("unroll") for (int q_ = 0; q_ < 64; ++q_) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(d_)); }
-#else
-#define PTX_PROBE_HERE
-#endif
-/* knock-out probes (experimental builds only; WRONG results): what the gathers of P5a (PTX_PROBE 6) and of P3a too (7) cost in time */
-#if defined(PTX_PROBE) && PTX_PROBE >= 6
-#define PTX_KO_MARK_GATHERS(u, i_, ra_, rb_, sa_, sb_, pl_) { rb_[u] = i_[u]; ra_[u] = i_[u] + 1u; sa_[u] = 1u; sb_[u] = 1u; }
-#else
-#define PTX_KO_MARK_GATHERS(u, i_, ra_, rb_, sa_, sb_, pl_) { rb_[u] = ref_b[i_[u]]; ra_[u] = ref_a[i_[u]]; sa_[u] = A.side_a[base + i_[u]]; sb_[u] = A.side_b[base + i_[u]]; if (pl_[u]) pl_[u] = payload[i_[u]]; }
-#endif
-#if defined(PTX_PROBE) && PTX_PROBE >= 7
-#define PTX_KO_P3A_GATHERS(u, i_, ra_, di_, dra_) { ra_[u] = 0; dra_[u] = ((uint64_t)1u << 32); }
-#else
-#define PTX_KO_P3A_GATHERS(u, i_, ra_, di_, dra_) { ra_[u] = ref_a[i_[u]]; dra_[u] = ref_a[di_[u]]; }
-#endif
 #define PTX_END 0xFFFFu
 #ifndef PTX_S
 #define PTX_S 16u /* every PTX_S-th node of the Euler tour is a splitter of the list ranking (measured: 16 is 1 % faster than 8 and needs 0.6 KB less, 4 is 7 % slower) */
@@ -1001,7 +974,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
         if (!small_keys) id_[u] = op_id[i_[u]];                             \
-        PTX_KO_P3A_GATHERS(u, i_, ra_, di_, dra_)                           \
+        ra_[u] = ref_a[i_[u]];                                              \
+        dra_[u] = ref_a[di_[u]];                                            \
     }
     /* ---- P1: ONE pass over the rows: id bitmaps, row lists per class ---- */
     {
@@ -1083,7 +1057,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             err4 |= ((a4 & 0xF8F8F8F8u) | (mt4 & 0xFCFCFCFCu & mmask)) & live;
             if (kMasked) c4 = (c4 & live) | (0x07070707u & ~live);
             const uint32_t add4 = a4 & mk & live; /* bit 0 tells PTX_ACT_ADDMARK (3) from PTX_ACT_REMOVEMARK (4) */
-            PTX_PROBE_HERE
             uint32_t slot[PTX_U1];
             ptx_wave_slots4<PTX_U1>(H->cur, dump_at, c4, slot);
 #pragma unroll
@@ -1465,7 +1438,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         pl_[u] = has_ && k_ >= moff2 && k_ < moff3 ? 1u : 0u;               \
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
-        PTX_KO_MARK_GATHERS(u, i_, ra_, rb_, sa_, sb_, pl_)                 \
+        rb_[u] = ref_b[i_[u]];                                              \
+        ra_[u] = ref_a[i_[u]];                                              \
+        sa_[u] = A.side_a[base + i_[u]];                                    \
+        sb_[u] = A.side_b[base + i_[u]];                                    \
+        if (pl_[u]) pl_[u] = payload[i_[u]];                                \
     }
     PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl)
     /* ---- P4: tombstones -> visible index ---- */
