@@ -109,7 +109,7 @@ enum {
     PTX_ERR_SEQ_GAP = 2,         /* RangeError "Expected sequence number"    micromerge.ts:503 */
     PTX_ERR_MISSING_DEP = 3,     /* RangeError "Missing dependency"          micromerge.ts:507 */
     PTX_ERR_DUPLICATE_OP = 4,    /* same opId twice in one log (the seq check makes this impossible upstream) */
-    PTX_ERR_CAPACITY = 5,        /* log too large for the on-chip working set of this build */
+    PTX_ERR_CAPACITY = 5,        /* log beyond what this build holds (ptx_merge: beyond the HBM-staged path's bounds or a forced LDS window; the on-chip-only entry points: beyond one CU's LDS) */
     PTX_ERR_BAD_OP = 6,          /* malformed row: unknown action / mark type / comment id beyond the header's n_comment_ids */
     PTX_ERR_INDEX_OOB = 7,       /* RangeError "List index out of bounds"    micromerge.ts:804 (ptx_change only) */
     /* call-level */
@@ -499,7 +499,10 @@ ptx_status ptx_batch_download(ptx_ctx* ctx, const ptx_dbatch* b, ptx_host_batch*
 void ptx_host_batch_free(ptx_host_batch* hb);
 
 /* ---- introspection ---- */
-/* Largest number of ops one log may have in this build/device (on-chip working set limit). */
+/* Largest number of ops a log may have and still be merged ENTIRELY ON CHIP (the LDS kernel: one CU's 160 KB, 16-bit indices).  A longer log — the
+ * reference has no bound, micromerge.ts:614-672 — is merged in the same ptx_merge call by the HBM-staged kernel (working set in device scratch the
+ * library sizes per log, 32-bit indices; an order of magnitude slower per op), up to 2^26 rows and an id keyspace (max counter + 1) x (actors) of 2^30;
+ * PTX_ERR_CAPACITY beyond that.  ptx_replay_patches / ptx_change / ptx_resolve_cursors still work on chip only: such a log reports PTX_ERR_CAPACITY there. */
 uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx);
 /* Name of the kernel the merge launches (to find it in a rocprofv3 trace). */
 const char* ptx_kernel_name(void);

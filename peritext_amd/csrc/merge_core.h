@@ -104,6 +104,9 @@ struct PtxMergeArgs {
     uint32_t stop_after; /* diagnostic: leave after the phase with this stamp index (0 = run everything) */
     uint32_t div_magic;  /* floor(2^32 / threads per workgroup) + 1, see PTX_DIV_T */
     const uint32_t* log_index; /* optional: workgroup i handles log log_index[i] (launches over a subset of the logs) */
+    /* the HBM-staged path for logs beyond one CU's LDS (biglog_core.h): workgroup i works in big_scratch[big_off[i] .. big_off[i + 1]) */
+    uint8_t* big_scratch;
+    const uint64_t* big_off;
 };
 
 #define PTX_END 0xFFFFu
@@ -368,8 +371,8 @@ struct PtxCEntry {
  * iterates the slot's ops in application order, so the last one decides).
  * Calls emit(start,end) for every maximal present interval in ascending order; returns their count.
  */
-template <class F>
-PTX_DEV uint32_t ptx_comment_sweep(const PtxCEntry* ent, uint32_t m, F emit) {
+template <class E, class F>
+PTX_DEV uint32_t ptx_comment_sweep(const E* ent, uint32_t m, F emit) {
     uint32_t count = 0;
     int64_t cur = -1;
     bool present = false;

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "merge_core.h"
+#include "biglog_core.h"
 #include "replay_core.h"
 #include "gen_core.h"
 #include "change_core.h"
@@ -53,8 +54,17 @@ PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, 1, true, 0, true)  /* + phase cycl
 /* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
  * issue ~1 % fewer instructions but need twice the VGPRs unless PTX_U=1, so only the run-time-sized builds are shipped) */
 
+/* Logs beyond one CU's LDS (biglog_core.h): one workgroup of PTX_BIG_THREADS per log, the working set in a slice of HBM scratch */
+#define PTX_BIG_THREADS 1024
+extern "C" __global__ void __launch_bounds__(PTX_BIG_THREADS) ptx_merge_big_kernel(PtxMergeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
+    if (blockIdx.x < A.n_logs) ptx_big_merge_log(A, A.log_index[blockIdx.x], A.big_scratch + A.big_off[blockIdx.x], A.big_off[blockIdx.x + 1] - A.big_off[blockIdx.x], ptx_lds);
+}
+
 /* Patch-stream replay (replay_core.h): one 64-thread workgroup (one wave) per log, sequential in application order */
+#ifndef PTX_REPLAY_THREADS
 #define PTX_REPLAY_THREADS 64
+#endif
 extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kernel(PtxReplayArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS>(A, blockIdx.x, ptx_lds);
@@ -173,7 +183,7 @@ __global__ void ptx_take_rows_kernel(PtxAppendCols S, const uint64_t* s_off, con
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
 __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off, const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type,
                                                           const uint32_t* payload, ptx_log_hdr* hdr, uint32_t* shape, int compute, const uint64_t* chg_off, uint32_t max_actors,
-                                                          uint32_t* need_per_log, uint64_t n_ops) {
+                                                          uint32_t* need_per_log, uint64_t n_ops, uint64_t* big_need_per_log, uint32_t max_lds) {
     __shared__ uint32_t sh[9];
     const uint32_t log = blockIdx.x;
     const uint64_t b0 = log_off[log], b1 = log_off[log + 1];
@@ -240,10 +250,22 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
     if (threadIdx.x == 0) {
         const ptx_log_hdr h = hdr[log];
         uint64_t need = ptx_lds_need_hdr(b1 - b0, h);
-        if (chg_off) need = max(need, ptx_lds_need_admission(chg_off[log + 1] - chg_off[log], max_actors));
-        atomicMax(&shape[0], (uint32_t)min(need, (uint64_t)0xFFFFFFFFu));
+        const uint64_t C = chg_off ? chg_off[log + 1] - chg_off[log] : 0;
+        if (chg_off) need = max(need, ptx_lds_need_admission(C, max_actors));
+        /* what the LDS kernel refuses whatever the window (16-bit indices, packed words): such a log takes the HBM-staged path (biglog_core.h) */
+        const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
+        const uint64_t ks = ((uint64_t)h.max_counter + 1) * ((uint64_t)h.max_actor + 1);
+        uint32_t kbits = 0;
+        while ((1ull << kbits) < K + 1) ++kbits;
+        const bool lds_ok = b1 - b0 <= 65534u && h.n_ins <= 32766u && h.max_counter < (1u << 19) && h.max_actor <= 4095u && (!h.n_mark[PTX_MARK_COMMENT] || h.n_comment_ids <= 65535u) &&
+                            ((ks + 1) << kbits) <= 0xFFFFFFFFull && C <= 65533u;
+        if (!lds_ok) need = 0xFFFFFFFFull;
         need_per_log[log] = (uint32_t)min(need, (uint64_t)0xFFFFFFFFu);
-        atomicMax(&shape[1], (uint32_t)min(b1 - b0, (uint64_t)0xFFFFFFFFu));
+        big_need_per_log[log] = ptx_big_need(b1 - b0, h, C, max_actors, PTX_BIG_THREADS);
+        if (need <= max_lds) { /* the launch shape of the LDS kernel is sized by the logs that take it */
+            atomicMax(&shape[0], (uint32_t)need);
+            atomicMax(&shape[1], (uint32_t)(b1 - b0));
+        }
     }
 }
 
@@ -363,6 +385,10 @@ struct ptx_dbatch {
     uint32_t* log_index = nullptr;
     uint32_t n_main = 0;     /* 0 = one launch over all logs */
     uint32_t lds_main = 0;
+    /* logs beyond one CU's LDS (biglog_core.h): the last n_big entries of log_index, each with its slice of `big_scratch` (one merge of this batch at a time) */
+    uint32_t n_big = 0;
+    uint64_t* big_off = nullptr;  /* device [n_big + 1] */
+    uint8_t* big_scratch = nullptr;
 };
 
 struct ptx_dresult {
@@ -409,53 +435,87 @@ static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t ma
  * launch shape.  `have_hdr`: b->log_hdr already holds the caller's headers. */
 static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
     uint32_t *shape = nullptr, *d_need = nullptr;
+    uint64_t* d_big = nullptr;
     uint32_t h[3] = {0, 0, 0};
     std::vector<uint32_t> need;
+    std::vector<uint64_t> big_need;
     if (b->n_logs) {
         PTX_HIP(ctx, hipMalloc((void**)&shape, 12));
         hipError_t e = hipMalloc((void**)&d_need, (size_t)b->n_logs * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_big, (size_t)b->n_logs * 8);
         if (e == hipSuccess) e = hipMemsetAsync(shape, 0, 12, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(ptx_census_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->log_off, b->op_id, b->action, b->mark_type, b->payload, b->log_hdr,
-                               shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors, d_need, b->n_ops);
+                               shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors, d_need, b->n_ops, d_big, (uint32_t)ctx->max_lds);
             e = hipGetLastError();
         }
         need.resize(b->n_logs);
+        big_need.resize(b->n_logs);
         if (e == hipSuccess) e = hipMemcpyAsync(h, shape, 12, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(need.data(), d_need, (size_t)b->n_logs * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(big_need.data(), d_big, (size_t)b->n_logs * 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         (void)hipFree(shape);
         (void)hipFree(d_need);
+        (void)hipFree(d_big);
         if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("census: ") + hipGetErrorString(e));
         if (h[2]) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off must run from 0 to n_ops without decreasing");
     }
     shape_launch(ctx, b, h[0], h[1]);
-    /* Would one more log fit a CU if the launch were sized for all but a few logs?  LDS is allocated in 512-byte
-     * granules; k logs share a CU when each needs at most floor(LDS / k) rounded down to a granule. */
     (void)hipFree(b->log_index);
+    (void)hipFree(b->big_off);
+    (void)hipFree(b->big_scratch);
     b->log_index = nullptr;
+    b->big_off = nullptr;
+    b->big_scratch = nullptr;
     b->n_main = 0;
-    if (b->n_logs >= 64 && !ctx->force_lds && b->lds_bytes >= 4096) {
+    b->n_big = 0;
+    /* Three groups of logs: (1) the many, merged by the LDS kernel at the launch's window; (2) a few that need a larger window — they would cost EVERY log
+     * a share of the CU (the dynamic LDS size is per launch), so they get a launch of their own when they are at most a tenth; (3) logs beyond one CU's LDS
+     * or the LDS kernel's 16-bit indices: the HBM-staged kernel (biglog_core.h), each with a slice of scratch.  A forced window (ptx_set_launch_shape) keeps
+     * (1) and (2) together; a log it does not hold is that log's PTX_ERR_CAPACITY, as documented there. */
+    std::vector<uint32_t> big, small;
+    for (uint32_t l = 0; l < b->n_logs; ++l) (need[l] > ctx->max_lds && !ctx->force_lds ? big : small).push_back(l);
+    uint32_t fit = 0, max_fit = 0;
+    bool split = false;
+    if (small.size() >= 64 && !ctx->force_lds && b->lds_bytes >= 4096) {
+        /* Would one more log fit a CU if the launch were sized for all but a few logs?  LDS is allocated in 512-byte granules; k logs share a CU when each
+         * needs at most floor(LDS / k) rounded down to a granule. */
         const uint64_t gran = 512, lds_now = (b->lds_bytes + gran - 1) / gran * gran;
         const uint64_t k_now = std::max<uint64_t>(ctx->max_lds / lds_now, 1);
         const uint64_t bound = ctx->max_lds / (k_now + 1) / gran * gran; /* per-log LDS at which k_now + 1 logs share a CU */
-        uint32_t fit = 0, max_fit = 0;
-        for (uint32_t l = 0; l < b->n_logs; ++l)
+        for (uint32_t l : small)
             if (need[l] <= bound) {
                 ++fit;
                 max_fit = std::max(max_fit, need[l]);
             }
-        if (fit < b->n_logs && (uint64_t)fit * 10 >= (uint64_t)b->n_logs * 9 && k_now < 16) {
-            std::vector<uint32_t> idx(b->n_logs);
-            uint32_t p = 0, q = fit;
-            for (uint32_t l = 0; l < b->n_logs; ++l) (need[l] <= bound ? idx[p++] : idx[q++]) = l;
-            hipError_t e = hipMalloc((void**)&b->log_index, (size_t)b->n_logs * 4);
-            if (e == hipSuccess) e = hipMemcpyAsync(b->log_index, idx.data(), (size_t)b->n_logs * 4, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("launch split: ") + hipGetErrorString(e));
-            b->n_main = fit;
+        split = fit < small.size() && (uint64_t)fit * 10 >= (uint64_t)small.size() * 9 && k_now < 16;
+        if (split) {
+            std::stable_partition(small.begin(), small.end(), [&](uint32_t l) { return need[l] <= bound; });
             b->lds_main = (uint32_t)std::max<uint64_t>(max_fit, 4096);
         }
+    }
+    if (split || !big.empty()) {
+        std::vector<uint32_t> idx(small);
+        idx.insert(idx.end(), big.begin(), big.end());
+        hipError_t e = hipMalloc((void**)&b->log_index, std::max<size_t>(idx.size(), 1) * 4);
+        if (e == hipSuccess && !idx.empty()) e = hipMemcpyAsync(b->log_index, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        b->n_main = split ? fit : (uint32_t)small.size();
+        b->n_big = (uint32_t)big.size();
+        if (!split) b->lds_main = b->lds_bytes;
+        if (e == hipSuccess && !big.empty()) {
+            std::vector<uint64_t> off(big.size() + 1, 0);
+            for (size_t k = 0; k < big.size(); ++k) off[k + 1] = off[k] + ((big_need[big[k]] + 255) & ~255ull);
+            e = hipMalloc((void**)&b->big_off, off.size() * 8);
+            if (e == hipSuccess) e = hipMemcpyAsync(b->big_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMalloc((void**)&b->big_scratch, std::max<uint64_t>(off.back(), 256));
+            if (e == hipErrorOutOfMemory) {
+                (void)hipStreamSynchronize(ctx->stream);
+                return fail(ctx, PTX_ERR_OOM, "no device memory for the working set of the logs beyond one CU's LDS");
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("launch groups: ") + hipGetErrorString(e));
     }
     return PTX_OK;
 }
@@ -604,6 +664,8 @@ void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
         (void)hipFree(b->side_b);
     }
     (void)hipFree(b->log_hdr);
+    (void)hipFree(b->big_off);
+    (void)hipFree(b->big_scratch);
     (void)hipFree(b->log_index);
     (void)hipFree(b->chg_off);
     (void)hipFree(b->chg_hdr);
@@ -614,7 +676,7 @@ void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
 uint32_t ptx_batch_n_logs(const ptx_dbatch* b) { return b ? b->n_logs : 0; }
 void ptx_batch_launch_shape(const ptx_dbatch* b, uint32_t* threads, uint32_t* lds_bytes) {
     if (threads) *threads = b ? b->threads : 0;
-    if (lds_bytes) *lds_bytes = b ? (b->n_main ? b->lds_main : b->lds_bytes) : 0;
+    if (lds_bytes) *lds_bytes = b ? (b->log_index ? b->lds_main : b->lds_bytes) : 0;
 }
 uint64_t ptx_batch_n_ops(const ptx_dbatch* b) { return b ? b->n_ops : 0; }
 uint64_t ptx_batch_n_changes(const ptx_dbatch* b) { return b && b->chg_off ? b->n_changes : 0; }
@@ -921,26 +983,30 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.lds_bytes = b->lds_bytes;
     A.div_magic = (uint32_t)(0x100000000ull / b->threads) + 1u;
     A.log_index = nullptr;
-    /* one workgroup per log; far more workgroups than the 256 CUs so the dispatcher load-balances.  Two launches when a
-     * few logs need more LDS than the rest (census_and_shape): the many at their size, the few at theirs — the few on a side
-     * stream forked from and joined to the caller's, so that they run beside the many instead of after them. */
+    A.big_scratch = b->big_scratch;
+    A.big_off = b->big_off;
+    /* one workgroup per log; far more workgroups than the 256 CUs so the dispatcher load-balances.  Up to three launches (census_and_shape): the many at
+     * their LDS window, the few that need a larger one, the logs beyond one CU's LDS through the HBM-staged kernel — the latter two on a side stream forked
+     * from and joined to the caller's, so that they run beside the many instead of after them. */
     const bool diag = ctx->clocks || ctx->stop_after;
-    const bool fork = b->n_main && !diag && ctx->side;
+    const uint32_t n_small = b->log_index ? b->n_logs - b->n_big : b->n_logs;
+    const uint32_t n_rest = b->log_index ? n_small - b->n_main : 0;
+    const bool fork = (n_rest || b->n_big) && !diag && ctx->side;
     if (fork) {
         (void)hipEventRecord(ctx->ev_fork, ctx->stream);
         (void)hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
     }
-    for (int part = 0; part < (b->n_main ? 2 : 1); ++part) {
-        uint32_t grid = b->n_logs, lds = b->lds_bytes;
-        if (b->n_main) {
-            A.log_index = b->log_index + (part ? b->n_main : 0);
-            grid = part ? b->n_logs - b->n_main : b->n_main;
-            lds = part ? b->lds_bytes : b->lds_main;
-            A.n_logs = grid;
-            A.lds_bytes = lds;
-        }
+    for (int part = 0; part < 3; ++part) {
+        uint32_t grid = part == 0 ? (b->log_index ? b->n_main : b->n_logs) : part == 1 ? n_rest : b->n_big;
+        if (grid == 0) continue;
+        uint32_t lds = part == 0 && b->log_index ? b->lds_main : b->lds_bytes;
+        A.log_index = b->log_index ? b->log_index + (part == 0 ? 0 : part == 1 ? b->n_main : n_small) : nullptr;
+        A.n_logs = grid;
+        A.lds_bytes = lds;
         hipStream_t st = part && fork ? ctx->side : ctx->stream;
-        if (diag)
+        if (part == 2)
+            hipLaunchKernelGGL(ptx_merge_big_kernel, dim3(grid), dim3(PTX_BIG_THREADS), (uint32_t)ptx_a16(sizeof(PtxHdr)), st, A);
+        else if (diag)
             hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), lds, st, A);
         else if (admit && b->max_actors > 3)
             hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);

@@ -47,6 +47,7 @@ PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v
 PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 PTX_DEV void ptx_atomic_or64(unsigned long long* p, unsigned long long v) { (void)atomicOr(p, v); }
+PTX_DEV void ptx_atomic_max64(unsigned long long* p, unsigned long long v) { (void)atomicMax(p, v); }
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__popc(x); }
 /* wave-aggregated append: ONE LDS atomic per wave, lanes get consecutive slots.  May be called in
  * divergent control flow (the ballot covers the active lanes only). */

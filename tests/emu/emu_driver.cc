@@ -15,6 +15,7 @@ int ptx_emu_reverse = 0;
 unsigned long long ptx_emu_exact_walks = 0;
 extern "C" unsigned long long ptx_emu_exact_walk_count() { return ptx_emu_exact_walks; }
 #include "../../peritext_amd/csrc/merge_core.h"
+#include "../../peritext_amd/csrc/biglog_core.h"
 
 /* LDS of the next log: not zero-initialised on the GPU either; a sanitizer build forgets the padding marks of the log before */
 static size_t ptx_emu_lds_size = 0;
@@ -97,6 +98,55 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
         ptx_merge_log<true, 0>(A, l, lds);
     }
     ptx_emu_lds_fill(lds, 0);
+    free(lds);
+    free(hdr);
+    return 0;
+}
+
+/* the HBM-staged path for logs beyond one CU's LDS (biglog_core.h): every log of the batch through ptx_big_merge_log, its working set in a host buffer
+ * sized by ptx_big_need (slack > 0 adds bytes the kernel must not need; < 0 takes some away: the log must then report PTX_ERR_CAPACITY) */
+extern "C" int ptx_emu_merge_big(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank, int reverse, int admission,
+                                 long long slack) {
+    PtxMergeArgs A;
+    memset(&A, 0, sizeof(A));
+    A.log_off = b->log_off;
+    A.op_id = b->op_id;
+    A.ref_a = b->ref_a;
+    A.ref_b = b->ref_b;
+    A.payload = b->payload;
+    A.action = b->action;
+    A.mark_type = b->mark_type;
+    A.side_a = b->side_a;
+    A.side_b = b->side_b;
+    A.chg_off = admission ? b->chg_off : nullptr;
+    A.chg_hdr = b->chg_hdr;
+    A.chg_env = b->chg_env;
+    A.max_actors = b->max_actors;
+    A.res = res;
+    A.out_values = values;
+    A.out_spans = spans;
+    A.out_cints = cints;
+    A.out_rank = rank;
+    A.n_logs = b->n_logs;
+    ptx_log_hdr* hdr = (ptx_log_hdr*)calloc(b->n_logs ? b->n_logs : 1, sizeof(ptx_log_hdr));
+    for (uint32_t l = 0; l < b->n_logs; ++l) {
+        const uint64_t b0 = b->log_off[l], b1 = b->log_off[l + 1];
+        if (b->log_hdr) hdr[l] = b->log_hdr[l];
+        else ptx_census_rows(b->op_id + b0, b->action + b0, b->mark_type + b0, b->payload + b0, b1 - b0, &hdr[l]);
+    }
+    A.log_hdr = hdr;
+    ptx_emu_reverse = reverse;
+    uint8_t* lds = (uint8_t*)aligned_alloc(64, 4096);
+    for (uint32_t l = 0; l < b->n_logs; ++l) {
+        const uint64_t C = A.chg_off ? A.chg_off[l + 1] - A.chg_off[l] : 0;
+        const long long need = (long long)ptx_big_need(b->log_off[l + 1] - b->log_off[l], hdr[l], C, b->max_actors, PTX_NTHREADS) + slack;
+        const uint64_t bytes = need > 64 ? (uint64_t)need : 64;
+        uint8_t* win = (uint8_t*)aligned_alloc(64, (bytes + 63) & ~63ull);
+        memset(win, 0xA5, bytes);
+        memset(lds, 0xA5, 4096);
+        ptx_big_merge_log(A, l, win, bytes, lds);
+        free(win);
+    }
     free(lds);
     free(hdr);
     return 0;

@@ -46,6 +46,7 @@ PTX_DEV uint32_t ptx_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (
 PTX_DEV uint32_t ptx_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 PTX_DEV void ptx_atomic_or64(unsigned long long* p, unsigned long long v) { *p |= v; }
+PTX_DEV void ptx_atomic_max64(unsigned long long* p, unsigned long long v) { if (v > *p) *p = v; }
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
 /* append to a list: index of this element (valid only where pred) */
 PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }

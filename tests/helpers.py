@@ -50,13 +50,13 @@ def oracle_gen(config="mini", docs=4, seed=1, ops=None, replicas=None, first=0, 
             return json.load(f)
 
 
-def oracle_apply(docs_logs, impl="oracle", cursors=False, patches=False, roots=False):
+def oracle_apply(docs_logs, impl="oracle", cursors=False, patches=False, roots=False, no_patches=False, timeout=600):
     """Apply every log of every doc to a fresh oracle replica; returns [[{spans,text,error?}]]."""
     with tempfile.TemporaryDirectory() as td:
         inp, out = os.path.join(td, "in.json"), os.path.join(td, "out.json")
         with open(inp, "w") as f:
             json.dump({"docs": [{"logs": logs} for logs in docs_logs]}, f)
-        run_node(["oracle/cli.js", "apply", "--in", inp, "--impl", impl, "--out", out] + (["--cursors"] if cursors else []) + (["--patches"] if patches else []) + (["--roots"] if roots else []))
+        run_node(["oracle/cli.js", "apply", "--in", inp, "--impl", impl, "--out", out] + (["--cursors"] if cursors else []) + (["--patches"] if patches else []) + (["--roots"] if roots else []) + (["--no-patches"] if no_patches else []), timeout=timeout)
         with open(out) as f:
             return [d["expected"] for d in json.load(f)["docs"]]
 
@@ -144,6 +144,63 @@ def emu_merge(b, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB, admission=Fal
         C.byref(s), res.logs.ctypes.data, res.values.ctypes.data, res.spans.ctypes.data, res.cintervals.ctypes.data,
         res.elem_rank.ctypes.data, res.ref_slots.ctypes.data, lds_bytes, reverse, 1 if admission else 0,
     )
+    assert rc == 0
+    return res
+
+
+def synthetic_marks_log(n_chars, n_marks, seed, n_deletes=0, max_span=40):
+    """ONE replica log (Change[]) built without the generator: a text of n_chars, n_deletes deletes, then n_marks random add / removeMark ops of the four mark
+    types over it (the boundary rule of peritext.ts:483-497: inclusive marks end `before` the next element or at endOfText, the others `after` the last).
+    For documents far beyond what the oracle's change() generates in reasonable time; the expected output comes from the oracle's applyChange."""
+    import random
+
+    rnd = random.Random(seed)
+    ids = ["%d@doc1" % (2 + i) for i in range(n_chars)]
+    ops = [{"opId": "1@doc1", "action": "makeList", "obj": "_root", "key": "text"}]
+    for i in range(n_chars):
+        ops.append({"opId": ids[i], "action": "set", "obj": "1@doc1", "elemId": "_head" if i == 0 else ids[i - 1], "insert": True, "value": "abcdefghij"[rnd.randrange(10)]})
+    changes = [{"actor": "doc1", "seq": 1, "deps": {}, "startOp": 1, "ops": ops}]
+    ctr = n_chars + 2
+    seq = 2
+    for _ in range(n_deletes):
+        changes.append({"actor": "doc1", "seq": seq, "deps": {}, "startOp": ctr, "ops": [{"opId": "%d@doc1" % ctr, "action": "del", "obj": "1@doc1", "elemId": ids[rnd.randrange(n_chars)]}]})
+        ctr += 1
+        seq += 1
+    for _ in range(n_marks):
+        mt = ("strong", "em", "link", "comment")[rnd.randrange(4)]
+        a = rnd.randrange(n_chars)
+        e = a + 1 + rnd.randrange(min(n_chars - a, max_span))  # (the reference copies the op set of every slot it passes: short spans keep it tractable)
+        op = {"opId": "%d@doc1" % ctr, "action": "addMark" if rnd.random() < 0.65 else "removeMark", "obj": "1@doc1", "start": {"type": "before", "elemId": ids[a]}, "markType": mt}
+        if mt in ("strong", "em"):
+            op["end"] = {"type": "endOfText"} if e >= n_chars else {"type": "before", "elemId": ids[e]}
+        else:
+            op["end"] = {"type": "after", "elemId": ids[e - 1]}
+        if mt == "link" and op["action"] == "addMark":
+            op["attrs"] = {"url": "%s.com" % "ABCDEFGHIJKLMNOPQRSTUVWXYZ"[rnd.randrange(26)]}
+        if mt == "comment":
+            op["attrs"] = {"id": "comment-%d" % rnd.randrange(max(1, n_marks // 40))}
+        changes.append({"actor": "doc1", "seq": seq, "deps": {}, "startOp": ctr, "ops": [op]})
+        ctr += 1
+        seq += 1
+    return changes
+
+
+def emu_merge_big(b, reverse=0, lib_path=EMU_LIB, admission=False, slack=0):
+    """The HBM-staged path for logs beyond one CU's LDS (biglog_core.h) through the host emulation: every log of the batch, whatever its size."""
+    n = max(b.n_ops, 1)
+    res = wire.Results(
+        logs=np.zeros(b.n_logs, dtype=abi.LOG_RESULT_DTYPE),
+        values=np.full(n, 0xDEADBEEF, dtype=np.uint32),
+        spans=np.zeros(n, dtype=abi.SPAN_DTYPE),
+        cintervals=np.zeros(n, dtype=abi.CINTERVAL_DTYPE),
+        elem_rank=np.zeros(n, dtype=np.uint32),
+        ref_slots=np.full(n, 0xFFFFFFFF, dtype=np.uint32),
+    )
+    s = batch_struct(b)
+    f = _emu(lib_path).ptx_emu_merge_big
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong]
+    rc = f(C.byref(s), res.logs.ctypes.data, res.values.ctypes.data, res.spans.ctypes.data, res.cintervals.ctypes.data, res.elem_rank.ctypes.data, reverse,
+           1 if admission else 0, slack)
     assert rc == 0
     return res
 

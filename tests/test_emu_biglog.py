@@ -1,0 +1,150 @@
+"""Logs beyond one CU's LDS (VERDICT r2 "missing" #3): peritext_amd/csrc/biglog_core.h — the HBM-staged merge — on the CPU emulation.
+The path is taken by size on the GPU; here EVERY log is forced through it, so the committed fixtures (made by the oracle / the type-erased
+reference) check its logic in all three loop orders, the error cases check that it names the reference's error and the failing row exactly
+like the LDS kernel, and two large documents (one insert/delete-heavy, one all-marks) that the LDS kernel refuses are compared with the
+oracle.  Matches the unbounded arrays of reference/src/micromerge.ts:614-672."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from peritext_amd import abi, wire
+
+GOLDEN_GEN = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json", "ptxgen_config4_600.json", "ptxgen_rich_700.json", "ptxgen_rich_2600.json",
+              "ptxgen_mini_10actors.json"]
+
+
+def _load(name):
+    with open(os.path.join(H.GOLDEN, name)) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("reverse", [0, 1, 2])
+@pytest.mark.parametrize("name", GOLDEN_GEN)
+def test_fixtures_through_the_hbm_staged_path(name, reverse):
+    gen = _load(name)
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    for admission in (False, True):
+        res = H.emu_merge_big(batch, reverse=reverse, admission=admission)
+        log = 0
+        for d in gen["docs"]:
+            for exp in d["expected"]:
+                H.check_log(batch, res, log, exp)
+                log += 1
+    small = H.emu_merge(batch, admission=True)
+    for k in ("status", "n_ops", "n_elems", "n_visible", "n_spans", "n_cintervals", "digest"):
+        assert (res.logs[k] == small.logs[k]).all(), k  # the two paths agree row for row, digest for digest
+
+
+def test_reference_tests_traces_and_edge_cases_through_the_hbm_staged_path():
+    """The reference's 46 test cases, its 9 traces and the SURVEY A.6 quirk documents: the HBM-staged path gives the rows the LDS kernel gives."""
+    kat = _load("kat_reference_tests.json")
+    docs = [[r["log"] for r in c["replicas"]] for c in kat["cases"]]
+    docs += [t["logs"] for t in _load("reference_traces.json")]
+    docs += H.edge_case_docs()
+    batch = wire.encode_docs(docs)
+    for reverse in (0, 2):
+        big, small = H.emu_merge_big(batch, reverse=reverse), H.emu_merge(batch, reverse=reverse)
+        for k in ("status", "n_visible", "n_spans", "n_cintervals", "digest"):
+            assert (big.logs[k] == small.logs[k]).all(), k
+        for log in range(batch.n_logs):
+            assert wire.decode_spans(batch, big, log) == wire.decode_spans(batch, small, log)
+    assert batch.n_logs > 100
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_errors_are_named_like_the_lds_kernel_and_the_reference():
+    """Mutated logs (dropped / swapped / duplicated change, skipped seq, inflated dep, unknown element, double fault): status AND failing row equal the LDS
+    kernel's, which the other suites pin against live oracle replays."""
+    gen = _load("ptxgen_mini.json")
+    base = gen["docs"][0]["logs"][1]
+
+    def mutate(kind):
+        log = copy.deepcopy(base)
+        if kind == "drop":
+            del log[3]
+        elif kind == "swap":
+            idx = [i for i, c in enumerate(log) if c["actor"] == log[-1]["actor"]]
+            log[idx[-2]], log[idx[-1]] = log[idx[-1]], log[idx[-2]]
+        elif kind == "seq_skip":
+            log[5]["seq"] += 1
+        elif kind == "dep_future":
+            other = [a for a in {c["actor"] for c in log} if a != log[2]["actor"]][0]
+            log[2]["deps"][other] = 10 ** 6
+        elif kind == "unknown_elem":
+            ins = [op for c in log for op in c["ops"] if op.get("insert")]
+            ins[len(ins) // 2]["elemId"] = "999@zz"
+        elif kind == "unknown_delete":
+            dl = [op for c in log for op in c["ops"] if op["action"] == "del"]
+            if dl:
+                dl[0]["elemId"] = "998@zz"
+        elif kind == "double_fault":
+            del log[6]
+            ins = [op for op in log[2]["ops"] if op.get("insert")]
+            if ins:
+                ins[0]["elemId"] = "999@zz"
+        return log
+
+    kinds = ["drop", "swap", "seq_skip", "dep_future", "unknown_elem", "unknown_delete", "double_fault", "intact"]
+    logs = [mutate(k) for k in kinds]
+    batch = wire.encode_docs([[l] for l in logs], extra_actors=[["zz"]] * len(logs))
+    for admission in (False, True):
+        for reverse in (0, 1):
+            big, small = H.emu_merge_big(batch, reverse=reverse, admission=admission), H.emu_merge(batch, reverse=reverse, admission=admission)
+            assert [int(x) for x in big.logs["status"]] == [int(x) for x in small.logs["status"]], (admission, reverse)
+            assert [int(x) for x in big.logs["reserved"][:, 1]] == [int(x) for x in small.logs["reserved"][:, 1]], (admission, reverse)
+    assert int(small.logs["status"][-1]) == 0 and int((small.logs["status"] != 0).sum()) >= 5
+    exp = H.oracle_apply([[l] for l in logs])
+    for k, e, st in zip(kinds, exp, big.logs["status"]):
+        assert (int(st) != 0) == ("error" in e[0]), k
+
+
+def test_capacity_and_lying_headers():
+    gen = _load("ptxgen_config4_600.json")
+    batch = wire.encode_docs([gen["docs"][0]["logs"]])
+    res = H.emu_merge_big(batch, slack=-4096)  # a slice too small for the working set: the log reports it, nothing is written past the slice
+    assert (res.logs["status"] == abi.ERR_CAPACITY).all()
+    bad = wire.encode_docs([gen["docs"][0]["logs"]])
+    bad.log_hdr = bad.log_hdr.copy()
+    bad.log_hdr["n_ins"][0] -= 1  # the header understates the inserts: BAD_OP at row 0, never a wrong result
+    r = H.emu_merge_big(bad, slack=1 << 16)
+    assert int(r.logs["status"][0]) == abi.ERR_BAD_OP and (r.logs["status"][1:] == 0).all()
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_large_documents_against_the_oracle():
+    """A 40 000-op insert/delete document (25 000 list elements: the LDS kernel, given a whole CU, reports PTX_ERR_CAPACITY) and a
+    mark-heavy one, through the HBM-staged path against the oracle.  (The GPU suite repeats it at 100 000 / 20 000 ops: tests/test_gpu_biglog.py;
+    the oracle needs a minute to GENERATE each of those, too long for this suite.)"""
+    essay = H.oracle_gen("config2", 1, 77, 40000, 1)
+    marks = H.oracle_gen("config3", 1, 78, 5000, 1, mix=(8, 2, 60, 30), marks=("strong", "em", "link", "comment"))
+    b1 = wire.encode_docs([d["logs"] for d in essay["docs"]])
+    assert int(b1.log_hdr["n_ins"][0]) > 20000  # 12 bytes of LDS per element and more: far beyond the 160 KB of a CU
+    assert int(H.emu_merge(b1, lds_bytes=160 * 1024).logs["status"][0]) == abi.ERR_CAPACITY
+    r1 = H.emu_merge_big(b1, admission=True)
+    H.check_log(b1, r1, 0, essay["docs"][0]["expected"][0])
+    b2 = wire.encode_docs([d["logs"] for d in marks["docs"]])
+    for reverse in (0, 2):
+        r2 = H.emu_merge_big(b2, reverse=reverse, admission=True)
+        H.check_log(b2, r2, 0, marks["docs"][0]["expected"][0])
+    assert (H.emu_merge(b2, lds_bytes=160 * 1024, admission=True).logs["digest"] == r2.logs["digest"]).all()
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_all_marks_document_of_20000_ops():
+    """a 20 000-op all-marks document (4 000 characters, 16 000 add / removeMark ops of the four types, 400 comment ids): built without
+    the generator (helpers.synthetic_marks_log), expected output from the oracle's applyChange; """
+    log = H.synthetic_marks_log(4000, 16000, 5)
+    exp = H.oracle_apply([[log]], no_patches=True)[0][0]
+    batch = wire.encode_docs([[log]])
+    assert batch.n_ops == 20001
+    res = H.emu_merge_big(batch, admission=True)
+    H.check_log(batch, res, 0, exp)
+    small = H.emu_merge(batch, lds_bytes=160 * 1024, admission=True)  # (a whole CU's LDS just holds this one: 140 KB; the library's launch would give it a CU to itself)
+    assert int(small.logs["status"][0]) in (0, abi.ERR_CAPACITY)
+    if int(small.logs["status"][0]) == 0:
+        assert (small.logs["digest"] == res.logs["digest"]).all()
+    assert int(res.logs["n_cintervals"][0]) > 50 and int(res.logs["n_spans"][0]) > 200

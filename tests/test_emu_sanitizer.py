@@ -8,7 +8,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUITES = ["tests/test_emu_parity.py", "tests/test_emu_partial_orders.py", "tests/test_emu_generate.py", "tests/test_emu_change.py", "tests/test_emu_patches.py", "tests/test_emu_rootmap.py"]
+SUITES = ["tests/test_emu_parity.py", "tests/test_emu_partial_orders.py", "tests/test_emu_generate.py", "tests/test_emu_change.py", "tests/test_emu_patches.py", "tests/test_emu_rootmap.py", "tests/test_emu_biglog.py"]
 
 
 def _lib(name):

@@ -1,0 +1,77 @@
+"""Logs beyond one CU's LDS on the GPU (VERDICT r2 "missing" #3 / next #7): the library routes them to ptx_merge_big_kernel (biglog_core.h: working set in HBM
+scratch, 32-bit indices, one 1 024-thread workgroup per log) inside the SAME ptx_merge call that merges the ordinary logs of the batch through the LDS kernel.
+A 100 000-op insert/delete document (the reference's arrays have no bound: reference/src/micromerge.ts:614-672) and all-marks documents of 20 000 and 40 000 ops,
+against the oracle; a failing large log names the reference's error and the failing row."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from peritext_amd import abi, wire
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from peritext_amd.engine import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _load(name):
+    with open(os.path.join(H.GOLDEN, name)) as f:
+        return json.load(f)
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_large_logs_beside_ordinary_ones(eng):
+    small = _load("ptxgen_config4_600.json")
+    essay = H.oracle_gen("config2", 1, 77, 100000, 1)          # 100 000 ops: ~64 000 list elements, beyond the LDS kernel's 16-bit element index
+    marks40 = H.synthetic_marks_log(6000, 34000, 9)            # 40 001 rows of which 34 000 mark ops: mark lists alone beyond one CU's LDS
+    marks20 = H.synthetic_marks_log(4000, 16000, 5)            # 20 001 rows: the LDS kernel holds it with a CU to itself
+    exp_marks = H.oracle_apply([[marks40], [marks20]], no_patches=True, timeout=1200)
+    docs = [d["logs"] for d in small["docs"]] + [essay["docs"][0]["logs"], [marks40], [marks20]]
+    expected = [e for d in small["docs"] for e in d["expected"]] + [essay["docs"][0]["expected"][0], exp_marks[0][0], exp_marks[1][0]]
+    batch = wire.encode_docs(docs)
+    db = eng.upload(batch)
+    dr = eng.alloc_result(db)
+    try:
+        for _ in range(2):  # the scratch of the large logs is reused from merge to merge
+            eng.merge(db, dr)
+        res = eng.download(db, dr)
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
+    assert (res.logs["status"] == 0).all()
+    for log, exp in enumerate(expected):
+        H.check_log(batch, res, log, exp)
+    n_small = sum(len(d["logs"]) for d in small["docs"])
+    lds = res.logs["reserved"][:, 0]
+    assert (lds[:n_small] > 0).all() and lds[n_small] == 0 and lds[n_small + 1] == 0  # the two largest took the HBM-staged kernel (it reports no LDS figure)
+    assert int(res.logs["n_elems"][n_small]) > 32766 and int(res.logs["n_ops"][n_small + 1]) == 40000
+    # every replica of the ordinary documents still converges, and the launch shape of the LDS kernel is the ordinary logs' own (not the CU maximum)
+    dg = res.logs["digest"][:n_small].reshape(-1, 3, 2)
+    assert (dg == dg[:, :1, :]).all()
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_a_failing_large_log_names_the_error_and_the_row(eng):
+    essay = H.oracle_gen("config2", 1, 77, 100000, 1)["docs"][0]["logs"][0]
+    bad = copy.deepcopy(essay)
+    c = len(bad) * 2 // 3
+    op = next(o for o in bad[c]["ops"] if o["action"] == "del" or o.get("insert"))
+    op["elemId"] = "999999@zz"  # an element nobody inserted: RangeError("List element not found"), micromerge.ts:752
+    row = sum(len(ch["ops"]) for ch in bad[:c]) + bad[c]["ops"].index(op)
+    dropped = copy.deepcopy(essay)
+    del dropped[len(dropped) // 2]  # a change is missing: the next change of that actor fails the seq check (single actor: micromerge.ts:501-504)
+    row2 = sum(len(ch["ops"]) for ch in dropped[: len(dropped) // 2])
+    batch = wire.encode_docs([[bad], [dropped], [essay]], extra_actors=[["zz"], [], []])
+    res = eng.apply_materialize(batch)
+    assert [int(x) for x in res.logs["status"]] == [abi.ERR_ELEM_NOT_FOUND, abi.ERR_SEQ_GAP, 0]
+    assert int(res.logs["reserved"][0, 1]) == row and int(res.logs["reserved"][1, 1]) == row2
