@@ -1738,10 +1738,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                  * step instead of one per op */
                 /* all four types at once: the ops in row order (blocks, as in P5a); one type at a time: its run is in row order */
                 const uint32_t kn = k_hi - k_lo, b_steps = four ? PTX_JB_STEPS(MB.B, PTX_UB) : PTX_JSTEPS_U(kn, PTX_UB);
-#pragma nounroll
-                for (uint32_t st = 0; st < b_steps; ++st) {
-                    uint32_t kq[PTX_UB], lo[PTX_UB], hi[PTX_UB];
-                    uint64_t idq[PTX_UB];
+                /* two register sets in turn: the opId gathers of the next step are in flight while this step's ranges go into the trees */
+                uint32_t kq_a[PTX_UB], lo_a[PTX_UB], hi_a[PTX_UB], kq_b[PTX_UB], lo_b[PTX_UB], hi_b[PTX_UB];
+                uint64_t idq_a[PTX_UB], idq_b[PTX_UB];
+                auto lww_load = [&](uint32_t st, uint32_t (&kq)[PTX_UB], uint32_t (&lo)[PTX_UB], uint32_t (&hi)[PTX_UB], uint64_t (&idq)[PTX_UB]) {
 #pragma unroll
                     for (int u = 0; u < (int)PTX_UB; ++u) {
                         uint32_t k;
@@ -1755,7 +1755,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         uint32_t l = mrk_lo[k], h = mrk_hi[k];
                         l = l > t0 ? l - t0 : 0u;
                         h = h > t0 ? (h - t0 < tv ? h - t0 : tv) : 0u;
-                        if (!has) l = h = 0u;
+                        if (!has || st >= b_steps) l = h = 0u;
                         kq[u] = k;
                         lo[u] = l;
                         hi[u] = h;
@@ -1765,6 +1765,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                             idq[u] = op_id[r < N ? r : N - 1u];
                         }
                     }
+                };
+                auto lww_put = [&](const uint32_t (&kq)[PTX_UB], const uint32_t (&lo)[PTX_UB], const uint32_t (&hi)[PTX_UB], const uint64_t (&idq)[PTX_UB]) {
 #pragma unroll
                     for (int u = 0; u < (int)PTX_UB; ++u)
                         if (lo[u] < hi[u]) {
@@ -1774,6 +1776,15 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                             /* the low bits say who won */
                             ptx_tree_chmax(tree + (four ? ty : 0u) * 2 * TV, TV, lo[u], hi[u], ty == PTX_MARK_COMMENT ? 1u : ((key + 1u) << kbits) | k);
                         }
+                };
+                lww_load(0u, kq_a, lo_a, hi_a, idq_a);
+#pragma nounroll
+                for (uint32_t st = 0; st < b_steps; st += 2u) {
+                    lww_load(st + 1u, kq_b, lo_b, hi_b, idq_b);
+                    lww_put(kq_a, lo_a, hi_a, idq_a);
+                    if (st + 1u >= b_steps) break;
+                    lww_load(st + 2u, kq_a, lo_a, hi_a, idq_a);
+                    lww_put(kq_b, lo_b, hi_b, idq_b);
                 }
                 PTX_SYNC_LDS();
                 PTX_FOR(q, tv) {
