@@ -18,7 +18,7 @@ One JSON line on stdout (rank 0):
       mark-state table — and the 128-bit digest), divided by the kernel's average launch duration measured with HIP events on
       the stream the kernel runs on.  The Change envelope that causal admission reads on top is NOT in B_alg; the figure
       that includes it is reported separately (roofline.with_envelope).
-  roofline.traffic  = HBM bytes per launch from the PMC counters of the same command (profiles/r02_hbm_traffic.json, made by
+  roofline.traffic  = HBM bytes per launch from the PMC counters of the same command (profiles/r03_hbm_traffic.json, made by
       tools/pmc_traffic.sh on the GPU box: separate --pmc passes; reads = the L2's read requests by size, cross-checked against
       FETCH_SIZE calibrated as MI355X_MICROARCH.md prescribes; writes = WRITE_SIZE); null when that file does not describe this workload.
   parity            = --check-docs random documents of the RESIDENT batch checked against the oracle run on the host cores on
@@ -174,14 +174,27 @@ def extra_legs(args, n_docs, first_doc, local, iters):
         return {"error": str(ex)[:300]}
 
 
-def load_traffic(n_logs, rows):
-    """PMC-measured HBM bytes per launch of this command, if profiles/ holds them for this very workload."""
-    p = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+def kernel_source_sha16():
+    """sha256 over the kernel sources and the ABI header (tools/traffic_json.py records the same for the build its counters were taken on)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "peritext_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/peritext_hip.h"]:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(n_logs, rows, launch):
+    """PMC-measured HBM bytes per launch of this command, if profiles/ holds them for this very workload, launch shape AND build of the kernel sources
+    (a traffic file of another build is refused: roofline.traffic is null then, never a stale number)."""
+    p = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
     if not os.path.exists(p):
         return None
     with open(p) as f:
         t = json.load(f)
-    if t.get("n_logs") != n_logs or t.get("rows") != rows:
+    if t.get("n_logs") != n_logs or t.get("rows") != rows or t.get("kernel_source_sha16") != kernel_source_sha16() or list(t.get("launch") or []) != list(launch):
         return None
     return t
 
@@ -403,7 +416,7 @@ def main():
             it = max(2, args.steps // 2)
             ms_noadm = eng2.merge_timed(db, dr, it) / it
             eng2.close()
-        traffic = load_traffic(n_logs, rows)
+        traffic = load_traffic(n_logs, rows, eng.launch_shape(db))
         extras = None
         if world == 1 and not args.no_extras:
             log("extra legs")

@@ -17,6 +17,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def eng():
+    import torch  # (first, like the other GPU suites: torch brings its own HIP runtime, which must be the one the process initialises)
+
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
     from peritext_amd.engine import Engine
 
     e = Engine(0)

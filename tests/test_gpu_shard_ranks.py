@@ -55,6 +55,9 @@ def _run_ranks(tmp_path, docs, n_ranks, flags=0, rounds=1):
 def _expected(docs, n_ranks):
     """Digests of every replica log, rank-major, each rank's block encoded on its own as the rank does (value / url ids are tables of the batch, so a
     digest is comparable inside one rank's batch only — which is all the convergence check needs: the replicas of a document share a rank)."""
+    import torch  # (first, like the other GPU suites: this process may run them too)
+
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
     from peritext_amd.engine import Engine
 
     dgs = []

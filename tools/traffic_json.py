@@ -1,11 +1,25 @@
 #!/usr/bin/env python3
-"""Turn the two PMC passes of tools/pmc_traffic.sh into profiles/r02_hbm_traffic.json (what bench.py reports as roofline.traffic).
+"""Turn the two PMC passes of tools/pmc_traffic.sh into profiles/r03_hbm_traffic.json (what bench.py reports as roofline.traffic).
 FETCH_SIZE / WRITE_SIZE are in KB; the read side is calibrated on ptx_calib_stream_kernel, whose byte count is known."""
+import hashlib
 import json
+import os
 import re
 import sys
 
 out = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha16():
+    """Identity of the build the counters were taken on: sha256 over the kernel sources and the ABI header (bench.py recomputes it and refuses a traffic
+    file of another build)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "peritext_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/peritext_hip.h"]:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def per_launch(path, kernel, counter, launches):
@@ -38,6 +52,7 @@ try:
 except (OSError, TypeError):
     sizes, fetch, calib_exact = None, fetch_calibrated, None
 print(json.dumps({
+    "kernel_source_sha16": kernel_source_sha16(), "launch": run.get("launch"),
     "n_logs": run["n_logs"], "rows": run["rows"], "n_changes": run["n_changes"],
     "fetch_size_kb_per_launch": f_merge, "write_size_kb_per_launch": w_merge,
     "calibration": {"kernel": "ptx_calib_stream_kernel", "known_bytes": run["calib_known_bytes"], "fetch_size_kb": f_calib, "true_bytes_per_counted_byte": factor},

@@ -29,7 +29,7 @@ def main():
     logs = eng.download_logs(dr, eng.n_logs(db))
     assert int(logs["status"].max()) == 0
     print("TRAFFIC_RUN " + json.dumps({"n_logs": eng.n_logs(db), "rows": eng.n_ops(db), "n_changes": eng.n_changes(db), "calib_known_bytes": known,
-                                       "V": int(logs["n_visible"].sum()), "S": int(logs["n_spans"].sum()), "T": int(logs["n_cintervals"].sum())}), flush=True)
+                                       "launch": list(eng.launch_shape(db)), "V": int(logs["n_visible"].sum()), "S": int(logs["n_spans"].sum()), "T": int(logs["n_cintervals"].sum())}), flush=True)
     eng.free_result(dr)
     eng.free_batch(db)
     eng.close()
