@@ -2,7 +2,11 @@
 on one rank, no data-path collective; the only exchange is an all-gather of the per-replica 128-bit digests so that
 every rank can state global convergence (the reference's `assert.deepStrictEqual(leftText, rightText)`,
 test/fuzz.ts:277-278, for the whole batch).  `torch.distributed` backend "nccl" is RCCL over xGMI on the GPU box;
-the same code runs over gloo on CPU tensors in the tests.  Plumbing only — merges happen in engine.py."""
+the same code runs over gloo on CPU tensors in the tests.  Plumbing only — merges happen in engine.py.
+
+`doc_range` is what every host uses for the partition.  `allgather_digests` / `global_convergence` are the torch.distributed TWIN of the C ABI's
+ptx_allgather_digests / ptx_count_converged_digests: the default bench step and the hosts use the C functions (RCCL bound inside the library; executed
+between processes in tests/test_gpu_shard_ranks.py); the twin serves the world-size-2 gloo CPU test (tests/test_shard_gloo.py) and `bench.py --host-sync-step`."""
 
 
 def doc_range(n_docs, rank, world):
