@@ -30,6 +30,7 @@ RANK_MASK = 0x7FFFFFFF
 FLAG_NO_ELEM_RANK = 1
 FLAG_NO_ADMISSION = 2
 FLAG_PAD_GATHER = 4
+FLAG_REPLAY_LDS_ONLY = 8
 COMM_ID_BYTES = 128
 
 PTX_OK = 0

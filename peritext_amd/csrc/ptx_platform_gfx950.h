@@ -49,6 +49,11 @@ PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long
 PTX_DEV void ptx_atomic_or64(unsigned long long* p, unsigned long long v) { (void)atomicOr(p, v); }
 PTX_DEV void ptx_atomic_max64(unsigned long long* p, unsigned long long v) { (void)atomicMax(p, v); }
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__popc(x); }
+/* global memory that lanes of ONE workgroup hand to each other: workgroup-scope accesses (the waves of a workgroup share their CU's L1, which stores
+ * write through and update) and the wait for the wave's outstanding stores that must stand between a store and another lane's load of it */
+PTX_DEV uint16_t ptx_coherent_load16(const uint16_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PTX_DEV void ptx_coherent_store16(uint16_t* p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PTX_DEV void ptx_global_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 /* wave-aggregated append: ONE LDS atomic per wave, lanes get consecutive slots.  May be called in
  * divergent control flow (the ballot covers the active lanes only). */
 PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) {
@@ -273,14 +278,18 @@ PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in L
     uint32_t sum = 0;
     for (uint32_t j = lo; j < hi; ++j) sum += a[j * STRIDE];
     const uint32_t incl = ptx_wave_incl_scan(sum); /* DPP prefix sum: no LDS traffic */
-    if (lane == 63) tmp[wave] = incl;
-    PTX_SYNC_T();
     uint32_t wbase = 0, total = 0;
+    if (kThreads == 64) { /* one wave: the total is lane 63's prefix, no trip through the LDS */
+        total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    } else {
+        if (lane == 63) tmp[wave] = incl;
+        PTX_SYNC_T();
 #pragma nounroll
-    for (uint32_t w = 0; w < nwaves; ++w) { /* a workgroup has at most 16 waves: every thread sums the few wave totals itself */
-        const uint32_t t = tmp[w];
-        wbase += w < wave ? t : 0u;
-        total += t;
+        for (uint32_t w = 0; w < nwaves; ++w) { /* a workgroup has at most 16 waves: every thread sums the few wave totals itself */
+            const uint32_t t = tmp[w];
+            wbase += w < wave ? t : 0u;
+            total += t;
+        }
     }
     uint32_t run = wbase + incl - sum;
     for (uint32_t j = lo; j < hi; ++j) {

@@ -53,6 +53,7 @@ struct PtxReplayArgs {
     ptx_patch_log* plogs;
     uint32_t n_logs;
     uint32_t lds_bytes;
+    uint16_t* win_scratch; /* optional: the per-slot winner arrays of every log live HERE (16 bytes per row of the batch + 128 per log; the list of a mark op's defined slots too) instead of in LDS */
 };
 
 struct PtxReplayHdr {
@@ -63,20 +64,27 @@ struct PtxReplayHdr {
     uint32_t scan_tmp[36];
 };
 
-PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) {
+#ifndef PTX_SEG_LDS
+#define PTX_SEG_LDS 1024u /* slot-list entries of a mark op's range kept in the LDS when the winner arrays are global */
+#endif
+PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid, bool gwin = false) {
     const uint64_t nw = (ks + 31) / 32, nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
     const uint64_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
     (void)nw;
     return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + 2 * ptx_a16(4 * nws) +
-           ptx_a16(4 * (nws + 1)) + 3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * segcap) + ptx_a16(8 * ((segcap >> 5) + 2)) + 3 * ptx_a16(4 * nws) +
+           ptx_a16(4 * (nws + 1)) + (gwin ? ptx_a16(2 * (segcap < PTX_SEG_LDS ? segcap : PTX_SEG_LDS)) : 3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * segcap)) + ptx_a16(8 * ((segcap >> 5) + 2)) + 3 * ptx_a16(4 * nws) +
            ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 3 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
-           5 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
+           4 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
 }
-PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h) {
+PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gwin = false) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
     const uint64_t ks = ((uint64_t)h.max_counter + 1) * ((uint64_t)(h.max_actor > 4095u ? 4095u : h.max_actor) + 1);
-    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], ks, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u);
+    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], ks, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u, gwin);
 }
+/* bytes of win_scratch a batch takes, and where the arrays of a log start (in u16 units): three winner arrays and the slot list of a mark op's range, each of at
+ * most 2 N + 3 entries, 16-byte aligned */
+PTX_HD uint64_t ptx_replay_win_bytes(uint64_t n_ops, uint64_t n_logs) { return 16 * n_ops + 128 * n_logs + 64; }
+PTX_HD uint64_t ptx_replay_win_at(uint64_t base_row, uint64_t log) { return 8 * base_row + 64 * log; }
 
 /* one patch record; rows past the capacity are counted, not written */
 PTX_DEV void ptx_patch_put(const PtxReplayArgs& A, uint64_t pbase, uint32_t pcap, uint32_t idx, uint32_t row, uint32_t kind, uint32_t a, uint32_t b) {
@@ -90,7 +98,9 @@ PTX_DEV void ptx_patch_put(const PtxReplayArgs& A, uint64_t pbase, uint32_t pcap
     }
 }
 
-template <uint32_t kThreads>
+/* kGWin: the winner arrays live in global memory (A.win_scratch), read and written past the L1 (device-scope relaxed atomics) with the wave's outstanding
+ * stores waited for wherever one lane reads what another has written */
+template <uint32_t kThreads, bool kGWin = false>
 PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) {
     PtxReplayHdr* H = (PtxReplayHdr*)lds;
     const uint64_t base = A.log_off[log];
@@ -137,9 +147,20 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint32_t* anyc = ptx_alloc<uint32_t>(bp, nws);
     uint32_t* wcnt = ptx_alloc<uint32_t>(bp, nws + 1); /* defined slots of the range per word -> prefix */
     uint16_t* win[3];
-    win[0] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* strong */
-    win[1] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* em */
-    win[2] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* link */
+    if (kGWin) {
+        const uint32_t stride = (2u * n + 2u + 7u) & ~7u;
+        uint16_t* g = A.win_scratch + ptx_replay_win_at(base, log);
+        win[0] = g;
+        win[1] = g + stride;
+        win[2] = g + 2u * stride;
+    } else {
+        win[0] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* strong */
+        win[1] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* em */
+        win[2] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* link */
+    }
+#define PTX_WIN_LD(p_) (kGWin ? ptx_coherent_load16(p_) : *(p_))
+#define PTX_WIN_ST(p_, v_) do { if (kGWin) ptx_coherent_store16((p_), (uint16_t)(v_)); else *(p_) = (uint16_t)(v_); } while (0)
+#define PTX_WIN_FENCE() do { if (kGWin) ptx_global_stores_done(); } while (0)
     uint32_t* won[3]; /* per slot: the winner of the type is an addMark (saves re-reading its action from HBM) */
     won[0] = ptx_alloc<uint32_t>(bp, nws);
     won[1] = ptx_alloc<uint32_t>(bp, nws);
@@ -151,13 +172,17 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint16_t* c_b = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* mark: end slot */
     uint16_t* c_key = ptx_alloc<uint16_t>(bp, PTX_RCHUNK); /* (key_mode) the op id's dense key + 1 */
     uint8_t* c_kind = ptx_alloc<uint8_t>(bp, PTX_RCHUNK);  /* PTX_RK_* | mark type << 4 | addMark << 6 */
-    uint16_t* seg = ptx_alloc<uint16_t>(bp, segcap);      /* defined slots of the op's range, ascending */
+    /* defined slots of the op's range, ascending.  (global winners) the first PTX_SEG_LDS of them stay in the LDS — most ranges end there, and the list is
+     * read right after it is filled: a global one costs the op two more round trips — the rest goes to global memory behind the winner arrays */
+    const uint32_t segl = kGWin ? (segcap < PTX_SEG_LDS ? segcap : (uint32_t)PTX_SEG_LDS) : segcap;
+    uint16_t* seg_l = ptx_alloc<uint16_t>(bp, segl);
+    uint16_t* seg = kGWin ? A.win_scratch + ptx_replay_win_at(base, log) + 3u * ((2u * n + 2u + 7u) & ~7u) : seg_l;
+#define PTX_SEG_LD(j_) ((j_) < segl ? seg_l[j_] : ptx_coherent_load16(&seg[j_]))
     PtxBitWord* cf = ptx_alloc<PtxBitWord>(bp, (segcap >> 5) + 2); /* bit j: slot seg[j] opens a patch; prefix = its place */
     uint16_t* ca = ptx_alloc<uint16_t>(bp, Kc + 1);       /* comment op: first covered slot */
     uint16_t* cb = ptx_alloc<uint16_t>(bp, Kc + 1);       /*             first slot not covered (PTX_SLOT_NONE = to the end) */
     uint16_t* ccid = ptx_alloc<uint16_t>(bp, Kc + 1);
-    uint16_t* cprev = ptx_alloc<uint16_t>(bp, Kc + 1);    /* chain of the ops with the same id, application order */
-    uint16_t* cnext = ptx_alloc<uint16_t>(bp, Kc + 1);
+    uint16_t* cprev = ptx_alloc<uint16_t>(bp, Kc + 1);    /* chain of the ops with the same id, latest first from ctail[id] */
     uint16_t* ctail = ptx_alloc<uint16_t>(bp, Kid + 1);   /* per id: last registered op */
     uint8_t* cadd = ptx_alloc<uint8_t>(bp, Kc + 1);
     if (bp.overflow || n > 32766u || N > 65534u || Kid > 65535u) {
@@ -197,24 +222,32 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
      * wave: every lane keeps the best of its own words and a wave-wide maximum (register shuffles) makes it common — no LDS atomic, no read back */
 #define PTX_LAST_DEFINED_BELOW(lim_, out_) const uint32_t out_ = ptx_last_set_below(defined, (lim_));
 
-    /* make slot s_ a defined one: its state is that of the closest defined slot to the left (peritext.ts:176) */
+    /* make slot s_ a defined one: its state is that of the closest defined slot to the left (peritext.ts:176).  The leader reads the three winners before it
+     * stores any (one round trip when they are global). */
+#define PTX_COPY_SLOT_STATE(s_, l1_, v0_, v1_, v2_)                                               \
+    do {                                                                                        \
+        PTX_WIN_ST(&win[0][s_], v0_);                                                           \
+        PTX_WIN_ST(&win[1][s_], v1_);                                                           \
+        PTX_WIN_ST(&win[2][s_], v2_);                                                           \
+        if ((l1_) && ptx_bittest(anyc, (l1_)-1u)) anyc[(s_) >> 5] |= 1u << ((s_)&31u);          \
+        for (int ty_ = 0; ty_ < 3; ++ty_)                                                       \
+            if ((l1_) && ptx_bittest(won[ty_], (l1_)-1u)) won[ty_][(s_) >> 5] |= 1u << ((s_)&31u); \
+        defined[(s_) >> 5] |= 1u << ((s_)&31u);                                                 \
+    } while (0)
 #define PTX_DEFINE_SLOT(s_)                                                                     \
     do {                                                                                        \
         if (!ptx_bittest(defined, (s_))) {                                                      \
             PTX_LAST_DEFINED_BELOW(s_, l1_)                                                     \
+            PTX_WIN_FENCE(); /* (global winners) the stores of the ops before have landed: the wait stands at the reader, where it is usually over */ \
             PTX_LEADER {                                                                        \
-                win[0][s_] = l1_ ? win[0][l1_ - 1u] : (uint16_t)0;                              \
-                win[1][s_] = l1_ ? win[1][l1_ - 1u] : (uint16_t)0;                              \
-                win[2][s_] = l1_ ? win[2][l1_ - 1u] : (uint16_t)0;                              \
-                if (l1_ && ptx_bittest(anyc, l1_ - 1u)) anyc[(s_) >> 5] |= 1u << ((s_)&31u);    \
-                for (int ty_ = 0; ty_ < 3; ++ty_)                                               \
-                    if (l1_ && ptx_bittest(won[ty_], l1_ - 1u)) won[ty_][(s_) >> 5] |= 1u << ((s_)&31u); \
-                defined[(s_) >> 5] |= 1u << ((s_)&31u);                                         \
+                const uint16_t v0_ = l1_ ? PTX_WIN_LD(&win[0][l1_ - 1u]) : (uint16_t)0;         \
+                const uint16_t v1_ = l1_ ? PTX_WIN_LD(&win[1][l1_ - 1u]) : (uint16_t)0;         \
+                const uint16_t v2_ = l1_ ? PTX_WIN_LD(&win[2][l1_ - 1u]) : (uint16_t)0;         \
+                PTX_COPY_SLOT_STATE(s_, l1_, v0_, v1_, v2_);                                    \
             }                                                                                   \
-            PTX_SYNC_T();                                                                         \
+            PTX_SYNC_T();                                                                       \
         }                                                                                       \
     } while (0)
-
     /* ---- the replay: PTX_RCHUNK rows are resolved in parallel, then applied one at a time ---- */
 #pragma nounroll
     for (uint32_t t0 = 0; t0 < N; t0 += PTX_RCHUNK) {
@@ -262,6 +295,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             const uint32_t r = c_a[ci];
             PTX_LAST_DEFINED_BELOW(2u * r, l1) /* slot + 1 */
             const uint32_t p0 = H->npatch;
+            PTX_WIN_FENCE();
             PTX_SYNC_T();
             PTX_LEADER {
                 uint32_t attr = 0;
@@ -269,7 +303,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     const uint32_t l = l1 - 1u;
                     if (ptx_bittest(won[0], l)) attr |= PTX_ATTR_STRONG;
                     if (ptx_bittest(won[1], l)) attr |= PTX_ATTR_EM;
-                    if (ptx_bittest(won[2], l)) attr |= PTX_ATTR_LINK | (payload[win[2][l] - 1u] & PTX_ATTR_ID_MASK);
+                    if (ptx_bittest(won[2], l)) attr |= PTX_ATTR_LINK | (payload[PTX_WIN_LD(&win[2][l]) - 1u] & PTX_ATTR_ID_MASK);
                     if (ptx_bittest(anyc, l)) attr |= PTX_ATTR_COMMENT;
                 }
                 ptx_patch_put(A, pbase, pcap, p0, t, PTX_PATCH_INSERT, ptx_bitrank(present, r), attr);
@@ -280,8 +314,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 const uint32_t l = l1 - 1u, nc = H->ncom;
                 PTX_FOR(kc, nc) {
                     if (cadd[kc] && ca[kc] <= l && l < cb[kc]) {
-                        bool last = true; /* no later-applied covering op of the same id */
-                        for (uint32_t y = cnext[kc]; y != PTX_SLOT_NONE; y = cnext[y])
+                        bool last = true; /* no later-applied covering op of the same id: the chain of the id, latest first, down to this op */
+                        for (uint32_t y = ctail[ccid[kc]]; y != kc && y != PTX_SLOT_NONE; y = cprev[y])
                             if (ca[y] <= l && l < cb[y]) {
                                 last = false;
                                 break;
@@ -329,7 +363,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 continue;
             }
             PTX_DEFINE_SLOT(slot_a);
-            if (slot_b != PTX_SLOT_NONE) PTX_DEFINE_SLOT(slot_b); /* inherits the state BEFORE this op from inside the range */
+            if (slot_b != PTX_SLOT_NONE) PTX_DEFINE_SLOT(slot_b); /* inherits the state BEFORE this op from inside the range (reading both ends' sources in one
+                                                                   * round trip was measured: 4 % slower) */
             /* the defined slots of [slot_a, lim), ascending */
             const uint32_t lim = slot_b != PTX_SLOT_NONE ? slot_b : 2u * n;
             const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5;
@@ -355,11 +390,13 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 while (m) {
                     const uint32_t b = (uint32_t)__builtin_ctz(m);
                     m &= m - 1u;
-                    if (o < segcap) seg[o] = (uint16_t)((w << 5) + b);
+                    if (o < segl) seg_l[o] = (uint16_t)((w << 5) + b);
+                    else if (o < segcap) PTX_WIN_ST(&seg[o], (w << 5) + b);
                     ++o;
                 }
             }
 #undef PTX_RANGE_BITS
+            if (S > segl) PTX_WIN_FENCE(); /* the slot list is read by other lanes than the ones that filled it */
             PTX_SYNC_T();
             const uint32_t nvis = H->nvis, nc = H->ncom;
             const uint32_t cfw = (S >> 5) + 1u; /* words of the patch-opening bitmap (+1 for the total) */
@@ -380,12 +417,12 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             const bool by_key = key_mode && ty != PTX_MARK_LINK;
             /* per defined slot: did the effective marks change (peritext.ts:208), new state, visible index */
             PTX_FOR(j, S) {
-                const uint32_t s = seg[j];
+                const uint32_t s = PTX_SEG_LD(j);
                 bool changed = false;
                 if (ty != PTX_MARK_COMMENT) {
                     uint16_t* wt = win[ty == PTX_MARK_STRONG ? 0 : ty == PTX_MARK_EM ? 1 : 2];
                     uint32_t* wo = won[ty == PTX_MARK_STRONG ? 0 : ty == PTX_MARK_EM ? 1 : 2];
-                    const uint32_t w = wt[s];
+                    const uint32_t w = PTX_WIN_LD(&wt[s]);
                     const bool old_on = ptx_bittest(wo, s);
                     /* compareOpIds: counter, then actor (ranks keep the string order); the dense keys keep that order */
                     const bool wins = !w || (by_key ? my_key1 > w : my_op > op_id[w - 1u]);
@@ -393,7 +430,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                         const bool new_on = act == PTX_ACT_ADDMARK;
                         changed = new_on != old_on;
                         if (new_on && old_on && ty == PTX_MARK_LINK) changed = (my_id & PTX_ATTR_ID_MASK) != (payload[w - 1u] & PTX_ATTR_ID_MASK);
-                        wt[s] = (uint16_t)(by_key ? my_key1 : t + 1u);
+                        PTX_WIN_ST(&wt[s], by_key ? my_key1 : t + 1u);
                         if (new_on != old_on) {
                             if (new_on) ptx_atomic_or(&wo[s >> 5], 1u << (s & 31));
                             else ptx_atomic_and(&wo[s >> 5], ~(1u << (s & 31)));
@@ -411,14 +448,14 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     changed = act == PTX_ACT_ADDMARK ? state != 1 : (state == 1 || !any); /* remove on no comment key: undefined -> [] */
                 }
                 if (changed) {
-                    const uint32_t ve = j + 1u < S ? PTX_VIS_AT(seg[j + 1u]) : v_end;
+                    const uint32_t ve = j + 1u < S ? PTX_VIS_AT(PTX_SEG_LD(j + 1u)) : v_end;
                     if (ve > PTX_VIS_AT(s)) ptx_atomic_or(&cf[j >> 5].bits, 1u << (j & 31));
                 }
             }
-            PTX_SYNC_T();
+            PTX_SYNC_T(); /* (global winners: the ops that read what was stored here wait for it themselves) */
             if (ty == PTX_MARK_COMMENT) {
                 PTX_FOR(j, S) {
-                    const uint32_t s = seg[j];
+                    const uint32_t s = PTX_SEG_LD(j);
                     ptx_atomic_or(&anyc[s >> 5], 1u << (s & 31));
                 }
             }
@@ -428,8 +465,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             const uint32_t p0 = H->npatch;
             PTX_FOR(j, S) {
                 if ((cf[j >> 5].bits >> (j & 31)) & 1u) {
-                    const uint32_t ve = j + 1u < S ? PTX_VIS_AT(seg[j + 1u]) : v_end;
-                    ptx_patch_put(A, pbase, pcap, p0 + ptx_bitrank(cf, j), t, act == PTX_ACT_ADDMARK ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT(seg[j]), ve);
+                    const uint32_t ve = j + 1u < S ? PTX_VIS_AT(PTX_SEG_LD(j + 1u)) : v_end;
+                    ptx_patch_put(A, pbase, pcap, p0 + ptx_bitrank(cf, j), t, act == PTX_ACT_ADDMARK ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT(PTX_SEG_LD(j)), ve);
                 }
             }
 #undef PTX_VIS_AT
@@ -441,10 +478,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     cb[nc] = (uint16_t)slot_b;
                     ccid[nc] = (uint16_t)my_id;
                     cadd[nc] = act == PTX_ACT_ADDMARK ? 1 : 0;
-                    cnext[nc] = PTX_SLOT_NONE;
-                    const uint32_t prev = ctail[my_id];
-                    cprev[nc] = (uint16_t)prev;
-                    if (prev != PTX_SLOT_NONE) cnext[prev] = (uint16_t)nc;
+                    cprev[nc] = ctail[my_id];
                     ctail[my_id] = (uint16_t)nc;
                     H->ncom = nc + 1u;
                 }
@@ -456,6 +490,11 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     }
 #undef PTX_LAST_DEFINED_BELOW
 #undef PTX_DEFINE_SLOT
+#undef PTX_COPY_SLOT_STATE
+#undef PTX_WIN_LD
+#undef PTX_WIN_ST
+#undef PTX_WIN_FENCE
+#undef PTX_SEG_LD
     PTX_SYNC_T();
     PTX_LEADER {
         ptx_patch_log pl;

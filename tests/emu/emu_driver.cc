@@ -190,16 +190,25 @@ extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, con
         }
         A.log_hdr = hdr;
     }
+    /* bit 8 of `reverse`: the per-slot winner arrays in "global" memory, as the library does for working sets above 5.5 KB (this build
+     * keeps only PTX_SEG_LDS = 24 slot-list entries in the LDS, so that the tests cross into the global tail of the list) */
+    const bool gwin = (reverse & 256) != 0;
+    reverse &= 255;
+    const uint64_t n_ops = b->n_logs ? b->log_off[b->n_logs] : 0;
+    A.win_scratch = gwin ? (uint16_t*)malloc(ptx_replay_win_bytes(n_ops, b->n_logs)) : nullptr;
+    if (gwin) memset(A.win_scratch, 0xA5, ptx_replay_win_bytes(n_ops, b->n_logs));
     uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)lds_bytes + 64);
     if (!lds) return 1;
     ptx_emu_reverse = reverse;
     for (uint32_t l = 0; l < b->n_logs; ++l) {
         ptx_emu_lds_fill(lds, lds_bytes);
-        ptx_replay_log<0>(A, l, lds);
+        if (gwin) ptx_replay_log<0, true>(A, l, lds);
+        else ptx_replay_log<0, false>(A, l, lds);
     }
     ptx_emu_lds_fill(lds, 0);
     free(lds);
     free(hdr);
+    free(A.win_scratch);
     return 0;
 }
 extern "C" uint64_t ptx_emu_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) { return ptx_replay_lds_need(n, K, Kc, ks, Kid); }

@@ -48,6 +48,9 @@ PTX_DEV unsigned long long ptx_atomic_add64(unsigned long long* p, unsigned long
 PTX_DEV void ptx_atomic_or64(unsigned long long* p, unsigned long long v) { *p |= v; }
 PTX_DEV void ptx_atomic_max64(unsigned long long* p, unsigned long long v) { if (v > *p) *p = v; }
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+PTX_DEV uint16_t ptx_coherent_load16(const uint16_t* p) { return *p; }
+PTX_DEV void ptx_coherent_store16(uint16_t* p, uint16_t v) { *p = v; }
+PTX_DEV void ptx_global_stores_done() {}
 /* append to a list: index of this element (valid only where pred) */
 PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }
 PTX_DEV uint64_t ptx_clock() { return 0; }

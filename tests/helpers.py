@@ -212,8 +212,9 @@ def emu_exact_walks(lib_path=EMU_LIB):
     return int(f())
 
 
-def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=None):
-    """Patch streams from the host emulation of replay_core.h (tests only): wire.Patches."""
+def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=None, gwin=False):
+    """Patch streams from the host emulation of replay_core.h (tests only): wire.Patches.  gwin: the form with the per-slot winner arrays in global memory."""
+    reverse |= 256 if gwin else 0
     n_logs = b.n_logs
     sizes = np.diff(b.log_off.astype(np.int64))
     caps = (2 * sizes + 16) if cap is None else np.full(n_logs, cap, dtype=np.int64)

@@ -28,13 +28,14 @@ accumulate = H.accumulate_patches
 
 @pytest.mark.parametrize("name", PATCH_GOLDEN)
 @pytest.mark.parametrize("reverse", [0, 1, 2])
-def test_golden_patch_streams(name, reverse):
+@pytest.mark.parametrize("gwin", [False, True])
+def test_golden_patch_streams(name, reverse, gwin):
     """Fixtures produced by the reference itself: every patch of every replica log, in order, deep-equal."""
     g = _load(name)
     assert g["impl"] == "ref"
     batch = wire.encode_docs([d["logs"] for d in g["docs"]])
     res = H.emu_merge(batch, lds_bytes=160 * 1024, reverse=reverse)
-    pat = H.emu_replay(batch, res, reverse=reverse)
+    pat = H.emu_replay(batch, res, reverse=reverse, gwin=gwin)
     n = _check_streams(batch, pat, [d["expected"] for d in g["docs"]])
     assert n == batch.n_logs
 
@@ -50,10 +51,10 @@ def test_kat_and_trace_patch_streams():
     expected = H.oracle_apply(docs, patches=True)
     for reverse in (0, 1):
         res = H.emu_merge(batch, reverse=reverse)
-        pat = H.emu_replay(batch, res, reverse=reverse)
         ok = [[e for e in exp if "error" not in e] for exp in expected]
         assert all(len(a) == len(b) for a, b in zip(ok, expected)), "no KAT / trace log fails"
-        _check_streams(batch, pat, expected)
+        for gwin in (False, True):
+            _check_streams(batch, H.emu_replay(batch, res, reverse=reverse, gwin=gwin), expected)
 
 
 def _mini_doc(ops, first_text="ABCDE"):
@@ -121,6 +122,8 @@ def test_live_oracle_patch_streams_and_accumulate(config, docs, ops):
     res = H.emu_merge(batch, lds_bytes=160 * 1024)
     pat = H.emu_replay(batch, res)
     _check_streams(batch, pat, expected)
+    pat_g = H.emu_replay(batch, res, gwin=True)  # winner arrays + the tail of the slot list in global memory: the same records
+    assert np.array_equal(pat_g.patch_off, pat.patch_off) and np.array_equal(pat_g.patches, pat.patches) and np.array_equal(pat_g.logs, pat.logs)
     for log in range(batch.n_logs):
         got = accumulate(wire.decode_patches(batch, pat, log, with_rows=True))
         want = wire.decode_spans(batch, res, log)

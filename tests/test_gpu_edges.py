@@ -309,6 +309,43 @@ def test_config5_patch_stream_golden(eng):
     H.check_patch_streams(batch, pat, [d["expected"] for d in p["docs"]])
 
 
+def _canonical_patches(pat):
+    """Records with the comment ids of one insert patch (kind INSERT_COMMENT, emitted through an atomic counter) in id order."""
+    off = pat.patch_off.astype(np.int64)
+    valid = np.concatenate([np.arange(off[l], off[l] + n) for l, n in enumerate(pat.logs["n_patches"].astype(np.int64))] or [np.zeros(0, np.int64)])
+    rec = pat.patches[valid]  # (the gaps between the logs' capacities are not written)
+    is_c = rec["kind"] == abi.PATCH_INSERT_COMMENT
+    start = np.arange(len(rec))
+    start[is_c] = 0
+    start = np.maximum.accumulate(start)  # a comment record sorts with the run that follows its insert record
+    order = np.lexsort((np.where(is_c, rec["a"], 0), is_c, start))
+    return rec[order]
+
+
+def test_replay_with_global_winner_arrays_equals_the_lds_only_form():
+    """Logs whose replay working set exceeds 5.5 KB replay with the per-slot winner arrays (and the tail of the slot list) in global memory:
+    same records as the all-LDS form (PTX_FLAG_REPLAY_LDS_ONLY) on 2 048-op config-4 logs, whose slot lists run past the LDS-resident part."""
+    from peritext_amd import workloads
+    from peritext_amd.engine import Engine
+
+    c = workloads.gen_config("config4", ops=2048)
+    out = []
+    for flags in (0, abi.FLAG_REPLAY_LDS_ONLY):
+        with Engine(0, flags=flags) as e:
+            db, _ = e.generate(c["replicas"], c["ops_per_log"], c["mix"], c["mark_types"], 24, 99, list_cap=2048)
+            dr = e.alloc_result(db)
+            e.merge(db, dr)
+            e.sync()
+            pat = e.replay_patches(db, dr)
+            assert (pat.logs["status"] == 0).all() and int(pat.logs["n_patches"].sum()) > 24 * 3 * 2048
+            out.append(pat)
+            e.free_result(dr)
+            e.free_batch(db)
+    a, b = out
+    assert np.array_equal(a.logs, b.logs)
+    assert np.array_equal(_canonical_patches(a), _canonical_patches(b))
+
+
 def test_set_stream_and_count_converged(eng):
     """ptx_set_stream + ptx_count_converged: the engine runs on the caller's HIP stream (here a torch stream) and counts the
     converged documents on the device, no host synchronisation in between."""

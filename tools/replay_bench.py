@@ -23,10 +23,11 @@ def main():
     ap.add_argument("--docs", type=int, default=2048)
     ap.add_argument("--ops", type=int, default=None)
     ap.add_argument("--lib", default=None, help="a candidate build of the library")
+    ap.add_argument("--flags", type=int, default=0, help="ptx_create flags (8 = PTX_FLAG_REPLAY_LDS_ONLY)")
     ap.add_argument("--check", type=int, default=0, help="compare the streams of the first CHECK documents with the oracle's (needs node)")
     args = ap.parse_args()
     c = workloads.gen_config(args.config, ops=args.ops)
-    eng = Engine(0, lib_path=args.lib if (args.lib is None or os.path.isabs(args.lib)) else os.path.join(ROOT, args.lib))
+    eng = Engine(0, flags=args.flags, lib_path=args.lib if (args.lib is None or os.path.isabs(args.lib)) else os.path.join(ROOT, args.lib))
     db, info = eng.generate(c["replicas"], c["ops_per_log"], c["mix"], c["mark_types"], args.docs, 4242, list_cap=2048)
     dr = eng.alloc_result(db)
     eng.merge(db, dr)
@@ -39,7 +40,7 @@ def main():
     n_pat = int(pat.logs["n_patches"].sum())
     bad = np.flatnonzero(pat.logs["status"] != 0)
     assert len(bad) == 0, "logs without a stream: %s status %s n_patches %s launches %d" % (bad[:8], pat.logs["status"][bad[:8]], pat.logs["n_patches"][bad[:8]], pat.launches)
-    out = {"lib": os.path.basename(args.lib or "product"), "config": args.config, "logs": n_logs, "ops": ops, "patches": n_pat, "launches": pat.launches, "kernel_ms": pat.kernel_ms,
+    out = {"lib": os.path.basename(args.lib or "product"), "flags": args.flags, "config": args.config, "logs": n_logs, "ops": ops, "patches": n_pat, "launches": pat.launches, "kernel_ms": pat.kernel_ms,
            "ops_per_s": ops / pat.kernel_ms * 1e3, "patches_per_s": n_pat / pat.kernel_ms * 1e3, "us_per_log": pat.kernel_ms * 1e3 / n_logs,
            "wall_s_incl_download": wall}
     if args.check:
