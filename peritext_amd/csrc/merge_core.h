@@ -282,9 +282,14 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     const uint64_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
     const uint64_t p3 = lists + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
     const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0; /* (the list of interval rows only takes what is left of the recycled region) */
-    const uint64_t T4 = PTX_TILE_4, T1 = PTX_TILE_1;
-    const uint64_t trees4 = ptx_overflow3(elem, 4 * 4 * 2 * T4, 4 * (T4 + 1), 8 * (T4 / 32 + 2));
-    const uint64_t trees1 = n > T4 ? ptx_overflow3(elem, 4 * 2 * T1, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
+    uint64_t T4 = PTX_TILE_4; /* the short-document tile is the visible length rounded up to a power of two: at most that of the inserts */
+    if (n < T4) {
+        T4 = 1;
+        while (T4 < n) T4 <<= 1;
+    }
+    const uint64_t T1 = PTX_TILE_1;
+    const uint64_t trees4 = ptx_overflow3(elem, K ? 4 * 4 * 2 * T4 : 0, 4 * (T4 + 1), 8 * (T4 / 32 + 2)); /* no mark ops: no trees */
+    const uint64_t trees1 = n > PTX_TILE_4 ? ptx_overflow3(elem, K ? 4 * 2 * T1 : 0, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
     uint64_t tail = comments > trees4 ? comments : trees4;
     if (trees1 > tail) tail = trees1;
     const uint64_t p5 = mpark + ptx_a16(8 * (nwe + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (nwe + 1)) + tail;
@@ -1707,7 +1712,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             TV = PTX_TILE_1;
         }
         const uint32_t ntree = four ? 4u : 1u;
-        uint32_t* tree = ptx_alloc2<uint32_t>(bd, bp, ntree * 2 * TV);
+        uint32_t* tree = ptx_alloc2<uint32_t>(bd, bp, K ? ntree * 2 * TV : 0u); /* a log without mark ops has one span per break: no trees */
         uint32_t* attr = ptx_alloc2<uint32_t>(bd, bp, TV + 1);
         PtxBitWord* st = ptx_alloc2<PtxBitWord>(bd, bp, TV / 32 + 2);
         PTX_BAIL_CAPACITY();
