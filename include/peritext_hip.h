@@ -367,6 +367,11 @@ ptx_status ptx_device_read(ptx_ctx* ctx, const void* device, void* host, uint64_
  * complete (the call synchronises).  Capacity is guessed (2 records per op) and the launch repeated once with exact
  * sizes when a log produced more. */
 ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_patches* out);
+/* The same for the TAIL of every log: first_row[l] (host array [n_logs]; NULL = 0 everywhere) is the first row of log l whose records are wanted —
+ * what the applyChange calls of the Changes appended since the last call return (a host that keeps its replicas resident: ptx_batch_append, ptx_merge,
+ * this).  The rows before are replayed for their state only: no record of theirs is written, counted or downloaded; `row` in the records stays the row
+ * in the log.  first_row[l] >= the log's rows: an empty stream. */
+ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, const uint32_t* first_row, ptx_patches* out);
 void ptx_patches_free(ptx_patches* p);
 
 /* ---- the map objects of a replica: getRoot() (micromerge.ts:443-449) ----

@@ -308,6 +308,7 @@ FUNCTIONS = {
     "ptx_device_free": (None, [vp, vp]),
     "ptx_device_read": (C.c_int32, [vp, vp, vp, C.c_uint64]),
     "ptx_replay_patches": (C.c_int32, [vp, vp, vp, C.POINTER(ptx_patches)]),
+    "ptx_replay_patches_from": (C.c_int32, [vp, vp, vp, vp, C.POINTER(ptx_patches)]),
     "ptx_patches_free": (None, [C.POINTER(ptx_patches)]),
     "ptx_root_map": (C.c_int32, [vp, vp, C.POINTER(ptx_root_maps)]),
     "ptx_root_maps_free": (None, [C.POINTER(ptx_root_maps)]),

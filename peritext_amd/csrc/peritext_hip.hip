@@ -1414,7 +1414,9 @@ void ptx_patches_free(ptx_patches* p) {
     memset(p, 0, sizeof(*p));
 }
 
-ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_patches* out) {
+ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, ptx_patches* out) { return ptx_replay_patches_from(ctx, b, r, nullptr, out); }
+
+ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, const uint32_t* first_row, ptx_patches* out) {
     if (!ctx || !b || !r || !out) return PTX_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
     if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
@@ -1455,8 +1457,22 @@ ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresu
     if (gwin) need = need_g;
     const uint32_t lds_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, ctx->max_lds); /* larger logs report PTX_ERR_CAPACITY */
     uint16_t* d_win = nullptr;
+    uint32_t* d_first = nullptr;
     if (gwin) PTX_HIP(ctx, hipMalloc((void**)&d_win, ptx_replay_win_bytes(b->n_ops, L)));
-    for (uint32_t l = 0; l < L; ++l) h->off[l + 1] = h->off[l] + 2 * (log_off[l + 1] - log_off[l]) + 16;
+    if (first_row) {
+        e = hipMalloc((void**)&d_first, (size_t)L * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_first, first_row, (size_t)L * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(d_win);
+            (void)hipFree(d_first);
+            ptx_patches_free(out);
+            return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("replay set-up: ") + hipGetErrorString(e));
+        }
+    }
+    for (uint32_t l = 0; l < L; ++l) {
+        const uint64_t n = log_off[l + 1] - log_off[l], skip = first_row ? std::min<uint64_t>(first_row[l], n) : 0;
+        h->off[l + 1] = h->off[l] + 2 * (n - skip) + 16; /* the guess: two records per row asked for */
+    }
 
     uint64_t* d_off = nullptr;
     ptx_patch_log* d_logs = nullptr;
@@ -1497,6 +1513,7 @@ ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresu
             A.n_logs = L;
             A.lds_bytes = lds_bytes;
             A.win_scratch = d_win;
+            A.first_row = d_first;
             (void)hipEventRecord(ctx->ev0, ctx->stream);
             if (gwin) hipLaunchKernelGGL(ptx_replay_kernel_gwin, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);
             else hipLaunchKernelGGL(ptx_replay_kernel, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);
@@ -1526,6 +1543,7 @@ ptx_status ptx_replay_patches(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresu
     }
     release();
     (void)hipFree(d_win);
+    (void)hipFree(d_first);
     if (st != PTX_OK) {
         ptx_patches_free(out);
         return st;

@@ -53,6 +53,7 @@ struct PtxReplayArgs {
     ptx_patch_log* plogs;
     uint32_t n_logs;
     uint32_t lds_bytes;
+    const uint32_t* first_row; /* optional [n_logs]: only the records of the rows from here on are produced (the rows before are replayed for their state alone) */
     uint16_t* win_scratch; /* optional: the per-slot winner arrays of every log live HERE (16 bytes per row of the batch + 128 per log; the list of a mark op's defined slots too) instead of in LDS */
 };
 
@@ -106,7 +107,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     const uint64_t base = A.log_off[log];
     const uint32_t N = (uint32_t)(A.log_off[log + 1] - base);
     const uint64_t pbase = A.patch_off[log];
-    const uint32_t pcap = (uint32_t)(A.patch_off[log + 1] - pbase);
+    const uint32_t pcap_all = (uint32_t)(A.patch_off[log + 1] - pbase);
+    const uint32_t first = A.first_row ? A.first_row[log] : 0u; /* the stream starts with this row's records */
     const uint64_t* op_id = A.op_id + base;
     const uint32_t* payload = A.payload + base;
     const uint8_t* action = A.action + base;
@@ -284,6 +286,11 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
 #pragma nounroll
     for (uint32_t ci = 0; ci < chunk_n; ++ci) {
         const uint32_t t = t0 + ci;
+        const uint32_t pcap = t >= first ? pcap_all : 0u; /* the rows before `first` count records (npatch) but write none ... */
+        if (t == first && first != 0u) {                  /* ... and the count starts again at the first row asked for */
+            PTX_LEADER { H->npatch = 0; }
+            PTX_SYNC_T();
+        }
         const uint32_t kind = c_kind[ci] & 15u;
         if (kind == PTX_RK_MAKELIST) {
             PTX_LEADER {
@@ -498,8 +505,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     PTX_SYNC_T();
     PTX_LEADER {
         ptx_patch_log pl;
-        pl.status = H->npatch > pcap ? (uint32_t)PTX_ERR_CAPACITY : (uint32_t)PTX_OK;
-        pl.n_patches = H->npatch;
+        const uint32_t produced = first < N ? H->npatch : 0u; /* (first >= N: nothing was asked for) */
+        pl.status = produced > pcap_all ? (uint32_t)PTX_ERR_CAPACITY : (uint32_t)PTX_OK;
+        pl.n_patches = produced;
         A.plogs[log] = pl;
     }
 }

@@ -265,11 +265,18 @@ class Engine:
         finally:
             self.lib.ptx_result_free(C.byref(res))
 
-    def replay_patches(self, dbatch, dresult):
+    def replay_patches(self, dbatch, dresult, first_row=None):
         """The Patch[] stream every applyChange of every log would have returned (reference/src/micromerge.ts:499),
-        as wire.Patches; `dresult` = the merge of the same batch (engine created without FLAG_NO_ELEM_RANK)."""
+        as wire.Patches; `dresult` = the merge of the same batch (engine created without FLAG_NO_ELEM_RANK).
+        first_row[l]: only the records of log l's rows from there on (ptx_replay_patches_from: the Changes appended to a resident replica)."""
         p = abi.ptx_patches()
-        self._check(self.lib.ptx_replay_patches(self.ctx, dbatch, dresult, C.byref(p)))
+        if first_row is None:
+            self._check(self.lib.ptx_replay_patches(self.ctx, dbatch, dresult, C.byref(p)))
+        else:
+            first = np.ascontiguousarray(first_row, dtype=np.uint32)
+            if len(first) != self.n_logs(dbatch):
+                raise ValueError("first_row needs one entry per replica log")
+            self._check(self.lib.ptx_replay_patches_from(self.ctx, dbatch, dresult, first.ctypes.data_as(C.c_void_p), C.byref(p)))
         try:
             n = int(p.n_logs)
             off = np.ctypeslib.as_array(p.patch_off, shape=(n + 1,)).copy() if n else np.zeros(1, dtype=np.uint64)

@@ -47,6 +47,10 @@ struct Lib {
     ptx_status (*sync)(ptx_ctx*) = nullptr;
     ptx_status (*result_download)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, ptx_result*) = nullptr;
     ptx_status (*replay_patches)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, ptx_patches*) = nullptr;
+    /* resident replicas: the logs stay in HBM between calls, new Changes are appended, only their Patch[] records come back */
+    ptx_status (*batch_append)(ptx_ctx*, const ptx_dbatch*, const ptx_batch*, ptx_dbatch**) = nullptr;
+    ptx_status (*replay_patches_from)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, const uint32_t*, ptx_patches*) = nullptr;
+    uint32_t (*batch_n_logs)(const ptx_dbatch*) = nullptr;
     void (*patches_free)(ptx_patches*) = nullptr;
     /* on-device change(): op logs generated in HBM */
     ptx_status (*generate)(ptx_ctx*, const ptx_gen_config*, ptx_dbatch**, ptx_gen_info*) = nullptr;
@@ -110,7 +114,8 @@ napi_value Open(napi_env env, napi_callback_info info) {
                   sym(L.max_ops_per_log, "ptx_max_ops_per_log") && sym(L.kernel_name, "ptx_kernel_name") && sym(L.batch_upload, "ptx_batch_upload") &&
                   sym(L.batch_free, "ptx_batch_free") && sym(L.result_alloc, "ptx_result_alloc") && sym(L.dresult_free, "ptx_dresult_free") &&
                   sym(L.merge, "ptx_merge") && sym(L.sync, "ptx_sync") && sym(L.result_download, "ptx_result_download") &&
-                  sym(L.replay_patches, "ptx_replay_patches") && sym(L.patches_free, "ptx_patches_free") && sym(L.generate, "ptx_generate") &&
+                  sym(L.replay_patches, "ptx_replay_patches") && sym(L.batch_append, "ptx_batch_append") && sym(L.replay_patches_from, "ptx_replay_patches_from") &&
+                  sym(L.batch_n_logs, "ptx_batch_n_logs") && sym(L.patches_free, "ptx_patches_free") && sym(L.generate, "ptx_generate") &&
                   sym(L.gen_info_free, "ptx_gen_info_free") && sym(L.batch_download, "ptx_batch_download") && sym(L.host_batch_free, "ptx_host_batch_free") && sym(L.change, "ptx_change") &&
                   sym(L.comm_unique_id, "ptx_comm_unique_id") && sym(L.comm_init, "ptx_comm_init") && sym(L.comm_destroy, "ptx_comm_destroy") && sym(L.comm_n_ranks, "ptx_comm_n_ranks") &&
                   sym(L.allgather_digests, "ptx_allgather_digests") && sym(L.count_converged_digests, "ptx_count_converged_digests") &&
@@ -295,6 +300,44 @@ napi_value batch_to_js(napi_env env, const ptx_batch& b) {
     return batch;
 }
 
+/* ptx_result (+ the patch streams) -> the JS result object; both are freed here */
+napi_value result_to_js(napi_env env, ptx_result& res, ptx_patches* patp) {
+    napi_value out;
+    NAPI_OK(napi_create_object(env, &out));
+    napi_value v;
+    static_assert(sizeof(ptx_log_result) == 48, "ptx_log_result layout");
+    v = make_u32(env, res.logs, (size_t)res.n_logs * 12);
+    if (v) napi_set_named_property(env, out, "logs", v);
+    v = make_u32(env, res.values, (size_t)res.n_rows);
+    if (v) napi_set_named_property(env, out, "values", v);
+    v = make_u32(env, res.spans, (size_t)res.n_rows * 2);
+    if (v) napi_set_named_property(env, out, "spans", v);
+    v = make_u32(env, res.cintervals, (size_t)res.n_rows * 3);
+    if (v) napi_set_named_property(env, out, "cintervals", v);
+    if (res.elem_rank) {
+        v = make_u32(env, res.elem_rank, (size_t)res.n_rows);
+        if (v) napi_set_named_property(env, out, "elemRank", v);
+    }
+    L.result_free(&res);
+    if (patp) {
+        ptx_patches& pat = *patp;
+        static_assert(sizeof(ptx_patch) == 16 && sizeof(ptx_patch_log) == 8, "ptx_patch layout");
+        napi_value ab, ta;
+        void* data = nullptr;
+        const size_t n_off = (size_t)pat.n_logs + 1;
+        if (napi_create_arraybuffer(env, n_off * 8, &data, &ab) == napi_ok && napi_create_typedarray(env, napi_biguint64_array, n_off, ab, 0, &ta) == napi_ok) {
+            memcpy(data, pat.patch_off, n_off * 8);
+            napi_set_named_property(env, out, "patchOff", ta);
+        }
+        v = make_u32(env, pat.logs, (size_t)pat.n_logs * 2);
+        if (v) napi_set_named_property(env, out, "patchLogs", v);
+        v = make_u32(env, pat.patches, (size_t)pat.patch_off[pat.n_logs] * 4);
+        if (v) napi_set_named_property(env, out, "patches", v);
+        L.patches_free(&pat);
+    }
+    return out;
+}
+
 napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
     if (!L.handle) return throw_msg(env, "call open(libPath) first");
     size_t argc = 3;
@@ -334,39 +377,105 @@ napi_value ApplyMaterialize(napi_env env, napi_callback_info info) {
         snprintf(msg, sizeof(msg), "ptx_apply_materialize failed (status %d): %s", st, L.last_error(ctx));
         return throw_msg(env, msg);
     }
-    napi_value out;
-    NAPI_OK(napi_create_object(env, &out));
-    napi_value v;
-    static_assert(sizeof(ptx_log_result) == 48, "ptx_log_result layout");
-    v = make_u32(env, res.logs, (size_t)res.n_logs * 12);
-    if (v) napi_set_named_property(env, out, "logs", v);
-    v = make_u32(env, res.values, (size_t)res.n_rows);
-    if (v) napi_set_named_property(env, out, "values", v);
-    v = make_u32(env, res.spans, (size_t)res.n_rows * 2);
-    if (v) napi_set_named_property(env, out, "spans", v);
-    v = make_u32(env, res.cintervals, (size_t)res.n_rows * 3);
-    if (v) napi_set_named_property(env, out, "cintervals", v);
-    if (res.elem_rank) {
-        v = make_u32(env, res.elem_rank, (size_t)res.n_rows);
-        if (v) napi_set_named_property(env, out, "elemRank", v);
-    }
-    L.result_free(&res);
-    if (want_patches) {
-        static_assert(sizeof(ptx_patch) == 16 && sizeof(ptx_patch_log) == 8, "ptx_patch layout");
-        napi_value ab, ta;
-        void* data = nullptr;
-        const size_t n_off = (size_t)pat.n_logs + 1;
-        if (napi_create_arraybuffer(env, n_off * 8, &data, &ab) == napi_ok && napi_create_typedarray(env, napi_biguint64_array, n_off, ab, 0, &ta) == napi_ok) {
-            memcpy(data, pat.patch_off, n_off * 8);
-            napi_set_named_property(env, out, "patchOff", ta);
+    return result_to_js(env, res, want_patches ? &pat : nullptr);
+}
+
+
+/* ---- resident replicas (INTEGRATION.md "Resident replicas"): residentUpload(ctx, batch) -> handle; residentAppend(ctx, handle, more) -> new handle (the
+ *      old one is released); residentApply(ctx, handle, wantPatches[, firstRow: Uint32Array]) -> the result object of applyMaterialize, the patch streams
+ *      from firstRow[l] on; residentFree(ctx, handle) ---- */
+ptx_dbatch* dbatch_of(napi_env env, napi_value v) {
+    void* p = nullptr;
+    if (napi_get_value_external(env, v, &p) != napi_ok) return nullptr;
+    return (ptx_dbatch*)p;
+}
+napi_value lib_error(napi_env env, ptx_ctx* ctx, const char* what, ptx_status st) {
+    char msg[1024];
+    snprintf(msg, sizeof(msg), "%s failed (status %d): %s", what, st, L.last_error(ctx));
+    return throw_msg(env, msg);
+}
+napi_value ResidentUpload(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc > 1 ? ctx_of(env, argv[0]) : nullptr;
+    if (!ctx) return throw_msg(env, "residentUpload(ctx, batch)");
+    ptx_batch pb;
+    if (!read_batch(env, argv[1], &pb)) return nullptr;
+    ptx_dbatch* db = nullptr;
+    const ptx_status st = L.batch_upload(ctx, &pb, &db);
+    if (st != PTX_OK) return lib_error(env, ctx, "ptx_batch_upload", st);
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, db, nullptr, nullptr, &ext));
+    return ext;
+}
+napi_value ResidentAppend(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc > 2 ? ctx_of(env, argv[0]) : nullptr;
+    ptx_dbatch* base = ctx ? dbatch_of(env, argv[1]) : nullptr;
+    if (!base) return throw_msg(env, "residentAppend(ctx, handle, moreBatch)");
+    ptx_batch pb;
+    if (!read_batch(env, argv[2], &pb)) return nullptr;
+    ptx_dbatch* db = nullptr;
+    const ptx_status st = L.batch_append(ctx, base, &pb, &db);
+    if (st != PTX_OK) return lib_error(env, ctx, "ptx_batch_append", st);
+    L.batch_free(ctx, base);
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, db, nullptr, nullptr, &ext));
+    return ext;
+}
+napi_value ResidentApply(napi_env env, napi_callback_info info) {
+    if (!L.handle) return throw_msg(env, "call open(libPath) first");
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc > 1 ? ctx_of(env, argv[0]) : nullptr;
+    ptx_dbatch* db = ctx ? dbatch_of(env, argv[1]) : nullptr;
+    if (!db) return throw_msg(env, "residentApply(ctx, handle[, wantPatches[, firstRow]])");
+    bool want_patches = false;
+    if (argc > 2) napi_get_value_bool(env, argv[2], &want_patches);
+    const uint32_t* first = nullptr;
+    if (argc > 3) {
+        bool is_ta = false;
+        napi_is_typedarray(env, argv[3], &is_ta);
+        if (is_ta) {
+            napi_typedarray_type type;
+            size_t length = 0, offset = 0;
+            void* data = nullptr;
+            napi_value ab;
+            if (napi_get_typedarray_info(env, argv[3], &type, &length, &data, &ab, &offset) != napi_ok || type != napi_uint32_array || length != L.batch_n_logs(db))
+                return throw_msg(env, "residentApply: firstRow must be a Uint32Array with one entry per replica log");
+            first = (const uint32_t*)data;
         }
-        v = make_u32(env, pat.logs, (size_t)pat.n_logs * 2);
-        if (v) napi_set_named_property(env, out, "patchLogs", v);
-        v = make_u32(env, pat.patches, (size_t)pat.patch_off[pat.n_logs] * 4);
-        if (v) napi_set_named_property(env, out, "patches", v);
-        L.patches_free(&pat);
     }
-    return out;
+    ptx_dresult* dr = nullptr;
+    ptx_result res;
+    ptx_patches pat;
+    memset(&pat, 0, sizeof(pat));
+    ptx_status st = L.result_alloc(ctx, db, &dr);
+    if (st == PTX_OK) st = L.merge(ctx, db, dr);
+    if (st == PTX_OK) st = L.sync(ctx);
+    if (st == PTX_OK) st = L.result_download(ctx, db, dr, &res);
+    if (st == PTX_OK && want_patches) {
+        st = L.replay_patches_from(ctx, db, dr, first, &pat);
+        if (st != PTX_OK) L.result_free(&res);
+    }
+    if (dr) L.dresult_free(ctx, dr);
+    if (st != PTX_OK) return lib_error(env, ctx, "residentApply (ptx_merge / ptx_replay_patches_from)", st);
+    return result_to_js(env, res, want_patches ? &pat : nullptr);
+}
+napi_value ResidentFree(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ptx_ctx* ctx = argc > 1 ? ctx_of(env, argv[0]) : nullptr;
+    ptx_dbatch* db = ctx ? dbatch_of(env, argv[1]) : nullptr;
+    if (db && L.handle) L.batch_free(ctx, db);
+    return nullptr;
 }
 
 uint32_t u32_prop(napi_env env, napi_value obj, const char* name, uint32_t dflt) {
@@ -751,7 +860,7 @@ napi_value KernelName(napi_env env, napi_callback_info) {
 
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
-        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"generate", Generate}, {"change", Change}, {"cursors", Cursors}, {"rootMap", RootMap}, {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"mergeAndGather", MergeAndGather},
+        {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"applyMaterialize", ApplyMaterialize}, {"residentUpload", ResidentUpload}, {"residentAppend", ResidentAppend}, {"residentApply", ResidentApply}, {"residentFree", ResidentFree}, {"generate", Generate}, {"change", Change}, {"cursors", Cursors}, {"rootMap", RootMap}, {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"mergeAndGather", MergeAndGather},
         {"maxOpsPerLog", MaxOpsPerLog}, {"kernelName", KernelName},
     };
     for (auto& f : fns) {

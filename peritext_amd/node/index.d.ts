@@ -102,7 +102,12 @@ export type JsonValue = string | number | boolean | null | JsonValue[] | { [key:
 export interface WireRootMaps { entryOff: BigUint64Array; logs: Uint32Array; entries: Uint32Array }
 
 export class MergeEngine {
-    constructor(opts?: { device?: number; libPath?: string; addonPath?: string })
+    /** resident (default true): the logs of a document's replica() handles stay in HBM between calls — a read encodes and uploads only the Changes that
+     *  arrived since (ptx_batch_append), merges the resident logs and fetches the Patch[] records of the new rows only (ptx_replay_patches_from).
+     *  false: every read encodes, uploads and replays the whole log of every handle. */
+    constructor(opts?: { device?: number; libPath?: string; addonPath?: string; resident?: boolean })
+    /** what the resident replicas cost so far: documents uploaded whole (first read, or a new actor re-ranked its op ids), appends, rows sent to the device */
+    readonly stats: { residentUploads: number; residentAppends: number; rowsUploaded: number }
     close(): void
     applyMaterialize(batch: WireBatch, wantPatches?: boolean): WireResult
     /** docs -> replica logs -> changes in application order  =>  spans per replica log */

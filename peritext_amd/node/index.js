@@ -86,11 +86,13 @@ function splitOpId(id) {
  *  of the text list when the logs of this batch do not hold its makeList (a batch of newly arrived changes only). */
 function encodeDocs(docs, opts) {
     const extraActors = (opts && opts.extraActors) || [], extraComments = (opts && opts.extraComments) || []
-    const textObjs = (opts && opts.textObjs) || [] /* per document: opId of the text list when the logs do not hold its makeList */
-    const values = [], valueIx = new Map()
-    const urls = [], urlIx = new Map()
-    const keys = ["text"], keyIx = new Map([["text", 0]]) /* keys of the map objects (ref_b of the map rows); key 0 of every batch: the text list's */
-    const mapValues = [], mapValueIx = new Map() /* JSON text of the values the map rows set */
+    const textObjs = (opts && opts.textObjs) || [] /* per document: opId of the text list when the logs do not hold its makeList (or one entry per log) */
+    /* opts.seed: the tables of an earlier batch of the same documents — ids already given stay (the rows of Changes appended to a resident batch) */
+    const seed = (opts && opts.seed) || {}
+    const values = (seed.values || []).slice(), valueIx = new Map(values.map((v, i) => [v, i]))
+    const urls = (seed.urls || []).slice(), urlIx = new Map(urls.map((v, i) => [v, i]))
+    const keys = (seed.keys || ["text"]).slice(), keyIx = new Map(keys.map((v, i) => [v, i])) /* keys of the map objects (ref_b of the map rows); key 0 of every batch: the text list's */
+    const mapValues = (seed.mapValues || []).slice(), mapValueIx = new Map(mapValues.map((v, i) => [v, i])) /* JSON text of the values the map rows set */
     const intern = (table, index, v) => {
         if (!index.has(v)) {
             index.set(v, table.length)
@@ -121,7 +123,11 @@ function encodeDocs(docs, opts) {
         for (const a of extraActors[d] || []) actors.add(a)
         for (const c of extraComments[d] || []) comments.add(c)
         const actorList = Array.from(actors).sort() /* default sort = UTF-16 code-unit order = JS `<` (micromerge.ts:826) */
-        const commentList = Array.from(comments).sort()
+        /* comment ids: ranks in string order — or, for Changes appended to a resident batch (opts.commentOrder), the ids that batch knows keep theirs and the
+         * new ones follow (the device only ever compares comment ids for equality; the decoders order them by their strings) */
+        const known = (opts && opts.commentOrder && opts.commentOrder[d]) || []
+        for (const c of known) comments.delete(c)
+        const commentList = known.concat(Array.from(comments).sort())
         const arank = new Map(actorList.map((a, i) => [a, i]))
         const crank = new Map(commentList.map((c, i) => [c, i]))
         docActors.push(actorList)
@@ -132,8 +138,9 @@ function encodeDocs(docs, opts) {
             const [ctr, actor] = splitOpId(s)
             return (BigInt(ctr) << 32n) | BigInt(arank.get(actor))
         }
-        for (const log of logs) {
-            let textObj = textObjs[d] === undefined ? null : textObjs[d], nrows = 0
+        logs.forEach((log, r) => {
+            const t0 = Array.isArray(textObjs[d]) ? textObjs[d][r] : textObjs[d]
+            let textObj = t0 === undefined ? null : t0, nrows = 0
             for (const ch of log) {
                 /* the Change envelope (micromerge.ts:60-71): what applyChange's admission checks (:499-511) */
                 chgActor.push(arank.get(ch.actor))
@@ -200,7 +207,7 @@ function encodeDocs(docs, opts) {
             logOff.push(logOff[logOff.length - 1] + nrows)
             chgOff.push(chgActor.length)
             logDoc.push(d)
-        }
+        })
     })
     const nLogs = logOff.length - 1
     const batch = {
@@ -399,7 +406,7 @@ function decodeSpans(batch, res, log) {
                 const id = res.cintervals[3 * (b + c)], s = res.cintervals[3 * (b + c) + 1], e = res.cintervals[3 * (b + c) + 2]
                 if (s <= start && start < e) ids.push(id)
             }
-            marks.comment = ids.sort((x, y) => x - y).map(i => ({ id: comments[i] }))
+            marks.comment = ids.map(i => comments[i]).sort().map(id => ({ id })) /* by id string (= by rank, unless the table grew in arrival order) */
         }
         if (attr & ATTR.LINK) marks.link = { url: batch.urls[attr & ATTR.ID_MASK] }
         let text = ""
@@ -563,7 +570,7 @@ function decodePatches(batch, res, log) {
             if ((v & ATTR.COMMENT) !== 0) {
                 const ids = []
                 while (k + 1 < n && res.patches[4 * (p0 + k + 1) + 1] === PATCH.INSERT_COMMENT) ids.push(res.patches[4 * (p0 + ++k) + 2])
-                marks.comment = ids.sort((x, y) => x - y).map(i => ({ id: comments[i] }))
+                marks.comment = ids.map(i => comments[i]).sort().map(id => ({ id })) /* by id string (= by rank, unless the table grew in arrival order) */
             }
             if (v & ATTR.LINK) marks.link = { url: batch.urls[v & ATTR.ID_MASK] }
             patch = { path: ["text"], action: "insert", index: a, values: [batch.values[batch.payload[b + r]]], marks }
@@ -580,16 +587,26 @@ function decodePatches(batch, res, log) {
 }
 
 class MergeEngine {
-    /** opts: {device?: number, libPath?: string, addonPath?: string} */
+    /** opts: {device?: number, libPath?: string, addonPath?: string, resident?: boolean} */
     constructor(opts) {
         const o = opts || {}
-        this.addon = require(o.addonPath || path.join(__dirname, "peritext_node.node"))
+        this.addon = o.addon || require(o.addonPath || path.join(__dirname, "peritext_node.node")) /* (o.addon: the tests' stand-in that records what would be uploaded) */
         this.addon.open(o.libPath || path.join(__dirname, "..", "lib", "libperitext_hip.so"))
         this.ctx = this.addon.create(o.device || 0, 0) /* throws without a gfx950 device: there is no CPU fallback */
         this.pending = []
+        /* resident replicas (default): the logs of a document's replica() handles stay in HBM between calls; a flush encodes and uploads only the Changes
+         * that arrived since (ptx_batch_append), merges the resident logs and fetches the Patch[] records of the new rows only (ptx_replay_patches_from).
+         * {resident: false}: every flush encodes, uploads and replays every handle's whole log in one launch (the round-2 behaviour). */
+        this.resident = o.resident !== false
+        this.sessions = new Map() /* docId -> resident state of the document's handles */
+        this.stats = { residentUploads: 0, residentAppends: 0, rowsUploaded: 0 }
     }
     close() {
-        if (this.ctx) this.addon.destroy(this.ctx)
+        if (this.ctx) {
+            for (const st of this.sessions.values()) if (st.handle) this.addon.residentFree(this.ctx, st.handle)
+            this.sessions.clear()
+            this.addon.destroy(this.ctx)
+        }
         this.ctx = null
     }
     /** Raw call: SoA batch -> result typed arrays (ptx_apply_materialize). */
@@ -827,11 +844,112 @@ class MergeEngine {
         for (const k of missing) r.status[k] = 1
         return { out: r.out, status: r.status, textObj, oid: v => String(v >> 32n) + "@" + actors[Number(v & 0xffffffffn)] }
     }
+    /**
+     * One document's handles against their resident logs: what is in HBM is a prefix of every handle's Changes (checked by identity) and the Changes
+     * since need no new actor / comment rank -> only they are encoded (against the tables of the resident batch) and appended; otherwise the document
+     * is encoded and uploaded afresh.  Returns {batch: what decodeSpans / decodePatches read, res, firstChange: per handle, the first Change whose patches
+     * `res` holds}.
+     */
+    residentApply(docId, group, wantPatches) {
+        let st = this.sessions.get(docId)
+        const textObjOf = changes => {
+            for (const ch of changes) for (const op of ch.ops) if (op.action === "makeList" && op.key === "text" && (op.obj === undefined || op.obj === null || op.obj === ROOT || typeof op.obj === "symbol")) return op.opId
+            return undefined
+        }
+        let ok = !!st && st.reps.length === group.length && group.every((r, i) => r === st.reps[i] && r.changes.length >= st.seen[i].length && st.seen[i].every((c, k) => c === r.changes[k]))
+        let delta = null
+        if (ok) {
+            delta = encodeDocs([group.map((r, i) => r.changes.slice(st.seen[i].length))], { extraActors: [st.actorList], commentOrder: [st.commentList], textObjs: [st.textObjs], seed: st.tables })
+            /* a new actor re-ranks the ids of the old rows (actor ranks follow the string order, compareOpIds): then everything is encoded again.  New comment
+             * ids just take the next ranks. */
+            ok = delta.docActors[0].length === st.actorList.length
+            if (ok) st.commentList = delta.docComments[0]
+        }
+        if (!ok) {
+            if (st && st.handle) this.addon.residentFree(this.ctx, st.handle)
+            this.sessions.delete(docId)
+            const full = encodeDocs([group.map(r => r.changes)])
+            st = { reps: group.slice(), seen: group.map(() => []), patched: group.map(() => 0), actorList: full.docActors[0], commentList: full.docComments[0], handle: null,
+                   rows: group.map(() => 0), chgNops: group.map(() => []), payload: group.map(() => new Uint32Array(0)), markType: group.map(() => new Uint8Array(0)) }
+            delta = full
+            st.handle = this.addon.residentUpload(this.ctx, full)
+            this.sessions.set(docId, st)
+            this.stats.residentUploads++
+        } else if (delta.chgActor.length > 0) {
+            st.handle = this.addon.residentAppend(this.ctx, st.handle, delta) /* (the old handle is released by the addon) */
+            this.stats.residentAppends++
+        }
+        this.stats.rowsUploaded += delta.nOps
+        st.tables = { values: delta.values, urls: delta.urls, keys: delta.keys, mapValues: delta.mapValues }
+        /* the host's view of the resident logs: what the decoders read (rows of a log are contiguous, as in HBM) */
+        const firstRow = new Uint32Array(group.length), firstChange = []
+        group.forEach((r, i) => {
+            const b = Number(delta.logOff[i]), e = Number(delta.logOff[i + 1]), c0 = Number(delta.chgOff[i]), c1 = Number(delta.chgOff[i + 1])
+            const grow = (old, add) => {
+                const out = new old.constructor(old.length + add.length)
+                out.set(old)
+                out.set(add, old.length)
+                return out
+            }
+            st.payload[i] = grow(st.payload[i], delta.payload.subarray(b, e))
+            st.markType[i] = grow(st.markType[i], delta.markType.subarray(b, e))
+            for (let c = c0; c < c1; c++) st.chgNops[i].push(delta.chgNops[c])
+            st.seen[i] = r.changes.slice()
+            /* patches are wanted from the first Change that has none yet */
+            let row = 0
+            for (let c = 0; c < st.patched[i]; c++) row += st.chgNops[i][c]
+            firstRow[i] = row
+            firstChange.push(st.patched[i])
+            st.rows[i] += e - b
+        })
+        st.textObjs = group.map(r => textObjOf(r.changes))
+        const logOff = new BigUint64Array(group.length + 1), chgOff = new BigUint64Array(group.length + 1)
+        group.forEach((r, i) => {
+            logOff[i + 1] = logOff[i] + BigInt(st.rows[i])
+            chgOff[i + 1] = chgOff[i] + BigInt(st.chgNops[i].length)
+        })
+        const cat = (parts, T) => {
+            const out = new T(parts.reduce((n, p) => n + p.length, 0))
+            let at = 0
+            for (const p of parts) {
+                out.set(p, at)
+                at += p.length
+            }
+            return out
+        }
+        const batch = { nLogs: group.length, logOff, chgOff, chgNops: cat(st.chgNops, Uint32Array), payload: cat(st.payload, Uint32Array), markType: cat(st.markType, Uint8Array),
+                        values: st.tables.values, urls: st.tables.urls, logDoc: group.map(() => 0), docActors: [st.actorList], docComments: [st.commentList] }
+        const res = this.addon.residentApply(this.ctx, st.handle, !!wantPatches, firstRow)
+        return { batch, res, firstChange, st }
+    }
     flush(wantPatches) {
         const byDoc = new Map()
         for (const r of this.pending) {
             if (!byDoc.has(r.docId)) byDoc.set(r.docId, [])
             byDoc.get(r.docId).push(r)
+        }
+        if (this.resident) {
+            for (const [docId, g] of byDoc) {
+                if (!g.some(r => r.error === null && (r.spans === null || (wantPatches && r.patches === null)))) continue /* nothing new for this document */
+                const { batch, res, firstChange, st } = this.residentApply(docId, g, wantPatches)
+                g.forEach((r, log) => {
+                    try {
+                        r.spans = decodeSpans(batch, res, log)
+                        if (wantPatches) {
+                            const tail = decodePatches(batch, res, log) /* entries before firstChange are empty: those Changes were patched by an earlier flush */
+                            r.patches = (r.patchCache || []).slice(0, firstChange[log]).concat(tail.slice(firstChange[log]))
+                            r.patchCache = r.patches
+                            st.patched[log] = r.patches.length
+                        }
+                        r.error = null
+                    } catch (e) {
+                        this.dropFailedChange(r, res, log, e)
+                        st.patched[log] = 0 /* the log changes under the resident copy: the next flush uploads the document again */
+                        r.patchCache = null
+                    }
+                })
+            }
+            return
         }
         const groups = Array.from(byDoc.values())
         const batch = encodeDocs(groups.map(g => g.map(r => r.changes)))
@@ -844,28 +962,31 @@ class MergeEngine {
                     if (wantPatches) r.patches = decodePatches(batch, res, log)
                     r.error = null
                 } catch (e) {
-                    /* an op of some change failed on the device (e.g. "List element not found", micromerge.ts:752): the reference
-                     * would have thrown out of that applyChange call.  The change is dropped from the log (ptx_log_result names the
-                     * row) so that later changes are not held hostage; the error surfaces once, at the next read. */
-                    r.error = e
-                    r.spans = null
-                    r.patches = null
-                    const failRow = res.logs[12 * log + 7]
-                    if (failRow !== 0xffffffff) {
-                        let row = 0
-                        for (let c = 0; c < r.changes.length; c++) {
-                            const n = r.changes[c].ops.length
-                            if (failRow < row + n || (n === 0 && failRow === row)) {
-                                const gone = r.changes.splice(c, 1)[0]
-                                if (r.clock[gone.actor] === gone.seq) r.clock[gone.actor] = gone.seq - 1
-                                break
-                            }
-                            row += n
-                        }
-                    }
+                    this.dropFailedChange(r, res, log, e)
                 }
                 log++
             }
+    }
+    /* an op of some change failed on the device (e.g. "List element not found", micromerge.ts:752): the reference would have thrown out of that
+     * applyChange call.  The change is dropped from the log (ptx_log_result names the row) so that later changes are not held hostage; the error
+     * surfaces once, at the next read. */
+    dropFailedChange(r, res, log, e) {
+        r.error = e
+        r.spans = null
+        r.patches = null
+        const failRow = res.logs[12 * log + 7]
+        if (failRow !== 0xffffffff) {
+            let row = 0
+            for (let c = 0; c < r.changes.length; c++) {
+                const n = r.changes[c].ops.length
+                if (failRow < row + n || (n === 0 && failRow === row)) {
+                    const gone = r.changes.splice(c, 1)[0]
+                    if (r.clock[gone.actor] === gone.seq) r.clock[gone.actor] = gone.seq - 1
+                    break
+                }
+                row += n
+            }
+        }
     }
 }
 

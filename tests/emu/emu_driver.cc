@@ -159,9 +159,10 @@ extern "C" uint64_t ptx_emu_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_
 
 /* patch-stream replay (replay_core.h) over the merge results `res` / `rank` of the same batch; patch_off = capacity
  * offsets [n_logs + 1] */
-extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint32_t* refs, const uint64_t* patch_off, ptx_patch* patches,
-                              ptx_patch_log* plogs, uint32_t lds_bytes, int reverse) {
+extern "C" int ptx_emu_replay_from(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint32_t* refs, const uint64_t* patch_off, ptx_patch* patches,
+                                   ptx_patch_log* plogs, uint32_t lds_bytes, int reverse, const uint32_t* first_row /* NULL: whole streams */) {
     PtxReplayArgs A;
+    A.first_row = first_row;
     A.log_off = b->log_off;
     A.op_id = b->op_id;
     A.ref_a = b->ref_a;
@@ -210,6 +211,10 @@ extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, con
     free(hdr);
     free(A.win_scratch);
     return 0;
+}
+extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint32_t* refs, const uint64_t* patch_off, ptx_patch* patches,
+                              ptx_patch_log* plogs, uint32_t lds_bytes, int reverse) {
+    return ptx_emu_replay_from(b, res, rank, refs, patch_off, patches, plogs, lds_bytes, reverse, nullptr);
 }
 extern "C" uint64_t ptx_emu_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) { return ptx_replay_lds_need(n, K, Kc, ks, Kid); }
 

@@ -123,6 +123,8 @@ def _emu(path):
         fn.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
     lib.ptx_emu_replay.restype = C.c_int
     lib.ptx_emu_replay.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    lib.ptx_emu_replay_from.restype = C.c_int
+    lib.ptx_emu_replay_from.argtypes = lib.ptx_emu_replay.argtypes + [C.c_void_p]
     lib.ptx_emu_merge_refs.restype = C.c_int
     lib.ptx_emu_merge_refs.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
     return lib
@@ -212,11 +214,15 @@ def emu_exact_walks(lib_path=EMU_LIB):
     return int(f())
 
 
-def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=None, gwin=False):
-    """Patch streams from the host emulation of replay_core.h (tests only): wire.Patches.  gwin: the form with the per-slot winner arrays in global memory."""
+def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=None, gwin=False, first_row=None):
+    """Patch streams from the host emulation of replay_core.h (tests only): wire.Patches.  gwin: the form with the per-slot winner arrays in global memory;
+    first_row[l]: only the records of the rows from there on (ptx_replay_patches_from)."""
     reverse |= 256 if gwin else 0
     n_logs = b.n_logs
     sizes = np.diff(b.log_off.astype(np.int64))
+    first = None if first_row is None else np.ascontiguousarray(first_row, dtype=np.uint32)
+    if first is not None:
+        sizes = sizes - np.minimum(first.astype(np.int64), sizes)
     caps = (2 * sizes + 16) if cap is None else np.full(n_logs, cap, dtype=np.int64)
     off = np.zeros(n_logs + 1, dtype=np.uint64)
     off[1:] = np.cumsum(caps)
@@ -226,7 +232,8 @@ def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=No
     lib = _emu(lib_path)
     launches = 0
     while True:
-        rc = lib.ptx_emu_replay(C.byref(s), res.logs.ctypes.data, res.elem_rank.ctypes.data, res.ref_slots.ctypes.data, off.ctypes.data, rows.ctypes.data, logs.ctypes.data, lds_bytes, reverse)
+        rc = lib.ptx_emu_replay_from(C.byref(s), res.logs.ctypes.data, res.elem_rank.ctypes.data, res.ref_slots.ctypes.data, off.ctypes.data, rows.ctypes.data, logs.ctypes.data, lds_bytes, reverse,
+                                     None if first is None else first.ctypes.data)
         assert rc == 0
         launches += 1
         produced = logs["n_patches"].astype(np.int64)

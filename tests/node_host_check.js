@@ -343,6 +343,138 @@ if (cmd === "encode") {
     let log = 0
     docs.forEach(logs => logs.forEach(l => assert.deepStrictEqual(host.decodeChanges(b, log++), l)))
     console.log(JSON.stringify({ ok: true, logs: log }))
+} else if (cmd === "resident-mock") {
+    /* no GPU: the resident-replica bookkeeping of MergeEngine.flush against a stand-in addon that keeps the "resident" batch on the host.  After every
+     * flush the stand-in's batch — uploads and appends put together the way ptx_batch_append does — decodes (decodeChanges, the encoder's inverse) to
+     * exactly the Changes every handle holds, every row was uploaded once unless a new actor / comment id forced the document to be encoded again, and the
+     * first rows asked of the replay are those of the Changes not patched yet. */
+    const ES = ma => (1 + ma + 3) & ~3 /* PTX_ENV_STRIDE: u16 per envelope row */
+    const COLS = [["opId", BigUint64Array], ["refA", BigUint64Array], ["refB", BigUint64Array], ["payload", Uint32Array], ["action", Uint8Array], ["markType", Uint8Array], ["sideA", Uint8Array], ["sideB", Uint8Array]]
+    const pick = b => {
+        const o = { nLogs: b.nLogs, maxActors: b.maxActors, logOff: b.logOff.slice(), chgOff: b.chgOff.slice(), chgHdr: b.chgHdr.slice(), chgEnv: b.chgEnv.slice() }
+        for (const [c] of COLS) o[c] = b[c].slice()
+        return o
+    }
+    const appendHost = (base, more) => {
+        assert.strictEqual(base.nLogs, more.nLogs)
+        assert.strictEqual(base.maxActors, more.maxActors, "ptx_batch_append wants the same envelope stride")
+        const es = base.chgEnv.length / Math.max(base.chgHdr.length, 1) || more.chgEnv.length / Math.max(more.chgHdr.length, 1) || ES(base.maxActors)
+        const out = { nLogs: base.nLogs, maxActors: base.maxActors, logOff: new BigUint64Array(base.nLogs + 1), chgOff: new BigUint64Array(base.nLogs + 1) }
+        const rows = [], chgs = []
+        for (let l = 0; l < base.nLogs; l++) {
+            rows.push([[base, Number(base.logOff[l]), Number(base.logOff[l + 1])], [more, Number(more.logOff[l]), Number(more.logOff[l + 1])]])
+            chgs.push([[base, Number(base.chgOff[l]), Number(base.chgOff[l + 1])], [more, Number(more.chgOff[l]), Number(more.chgOff[l + 1])]])
+            out.logOff[l + 1] = out.logOff[l] + BigInt(rows[l].reduce((n, [, a, b]) => n + b - a, 0))
+            out.chgOff[l + 1] = out.chgOff[l] + BigInt(chgs[l].reduce((n, [, a, b]) => n + b - a, 0))
+        }
+        const gather = (name, T, parts, stride) => {
+            const outArr = new T(parts.reduce((n, ps) => n + ps.reduce((m, [, a, b]) => m + (b - a) * stride, 0), 0))
+            let at = 0
+            for (const ps of parts)
+                for (const [src, a, b] of ps) {
+                    outArr.set(src[name].subarray(a * stride, b * stride), at)
+                    at += (b - a) * stride
+                }
+            return outArr
+        }
+        for (const [c, T] of COLS) out[c] = gather(c, T, rows, 1)
+        out.chgHdr = gather("chgHdr", Uint32Array, chgs, 1)
+        out.chgEnv = gather("chgEnv", Uint16Array, chgs, es)
+        return out
+    }
+    const calls = { uploads: 0, appends: 0, rows: 0, applies: [] }
+    const mock = {
+        open() {}, create() { return {} }, destroy() {},
+        residentUpload(ctx, b) { calls.uploads++; calls.rows += b.nOps; return { batch: pick(b) } },
+        residentAppend(ctx, h, more) { calls.appends++; calls.rows += more.nOps; return { batch: appendHost(h.batch, pick(more)) } },
+        residentFree() {},
+        residentApply(ctx, h, wantPatches, firstRow) {
+            calls.applies.push({ handle: h, wantPatches, firstRow: Array.from(firstRow) })
+            const n = h.batch.nLogs, rowsN = Number(h.batch.logOff[n])
+            const logs = new Uint32Array(12 * n)
+            for (let l = 0; l < n; l++) logs[12 * l + 7] = 0xffffffff
+            return { logs, values: new Uint32Array(rowsN), spans: new Uint32Array(2 * rowsN), cintervals: new Uint32Array(3 * rowsN), patchOff: new BigUint64Array(n + 1), patchLogs: new Uint32Array(2 * n), patches: new Uint32Array(0) }
+        },
+    }
+    const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    let flushes = 0, totalRows = 0
+    let seed = 12345
+    const rnd = n => (seed = (seed * 1103515245 + 12345) >>> 0) % n
+    gen.docs.forEach((d, di) => {
+        const engine = new host.MergeEngine({ addon: mock })
+        const reps = d.logs.map(() => engine.replica(di))
+        const at = d.logs.map(() => 0)
+        const before = { uploads: calls.uploads, rows: calls.rows }
+        let reencodes = 0
+        while (at.some((a, r) => a < d.logs[r].length)) {
+            /* a few more Changes to some of the handles, then one read (with or without patches) */
+            d.logs.forEach((log, r) => {
+                const k = Math.min(log.length - at[r], rnd(6))
+                for (let c = 0; c < k; c++) reps[r].applyChange(log[at[r]++])
+            })
+            const wantPatches = rnd(2) === 1
+            const actorsBefore = engine.sessions.get(di) ? engine.sessions.get(di).actorList.length + engine.sessions.get(di).commentList.length : -1
+            const appliesBefore = calls.applies.length
+            if (wantPatches) reps[rnd(reps.length)].getPatches()
+            else reps[rnd(reps.length)].getTextWithFormatting(["text"])
+            if (calls.applies.length === appliesBefore) continue /* the handle that was read had nothing new: no flush */
+            flushes++
+            const st = engine.sessions.get(di)
+            if (actorsBefore >= 0 && st.actorList.length + st.commentList.length !== actorsBefore) reencodes++
+            const last = calls.applies[calls.applies.length - 1]
+            const b = Object.assign({}, last.handle.batch, { logDoc: reps.map(() => 0), docActors: [st.actorList], docComments: [st.commentList], values: st.tables.values, urls: st.tables.urls, keys: st.tables.keys, mapValues: st.tables.mapValues })
+            reps.forEach((_, r) => assert.deepStrictEqual(host.decodeChanges(b, r), d.logs[r].slice(0, at[r]), "doc " + di + " replica " + r + " after flush " + flushes))
+            /* the replay is asked for the rows of the Changes that have no patches yet */
+            reps.forEach((_, r) => {
+                let row = 0
+                for (let c = 0; c < (last.wantPatches ? 0 : st.patched[r]); c++) row += d.logs[r][c].ops.length
+                if (!last.wantPatches) assert.strictEqual(last.firstRow[r], row)
+            })
+        }
+        reps[0].applyChange === undefined || reps.forEach(r => r.getTextWithFormatting(["text"])) /* whatever is still queued */
+        const rowsOfDoc = d.logs.reduce((n, l) => n + l.reduce((m, c) => m + c.ops.length, 0), 0)
+        totalRows += rowsOfDoc
+        if (calls.uploads - before.uploads === 1) assert.strictEqual(calls.rows - before.rows, rowsOfDoc, "every row uploaded exactly once")
+        assert.ok(calls.uploads - before.uploads <= 1 + reencodes, "a document is encoded again only when its actor / comment tables grow")
+        engine.close()
+    })
+    console.log(JSON.stringify({ ok: true, docs: gen.docs.length, flushes, uploads: calls.uploads, appends: calls.appends, rowsUploaded: calls.rows, rows: totalRows }))
+} else if (cmd === "resident") {
+    /* GPU: replica() handles fed a few Changes at a time — spans and patches after every step equal those of an engine that re-encodes, re-uploads and
+     * replays everything every time ({resident: false}), and equal the reference's at the end */
+    const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    let steps = 0, appends = 0, uploads = 0, rowsUploaded = 0, rows = 0
+    let seed = 777
+    const rnd = n => (seed = (seed * 1103515245 + 12345) >>> 0) % n
+    gen.docs.slice(0, parseInt(process.argv[4] || "4", 10)).forEach((d, di) => {
+        const a = new host.MergeEngine(), b = new host.MergeEngine({ resident: false })
+        const ra = d.logs.map(() => a.replica(di)), rb = d.logs.map(() => b.replica(di))
+        const at = d.logs.map(() => 0)
+        while (at.some((x, r) => x < d.logs[r].length)) {
+            d.logs.forEach((log, r) => {
+                const k = Math.min(log.length - at[r], 1 + rnd(12))
+                for (let c = 0; c < k; c++) {
+                    ra[r].applyChange(log[at[r]])
+                    rb[r].applyChange(log[at[r]++])
+                }
+            })
+            const r = rnd(ra.length)
+            if (rnd(3) > 0) assert.deepStrictEqual(ra[r].getPatches(), rb[r].getPatches(), "doc " + di + " replica " + r + " step " + steps)
+            assert.deepStrictEqual(norm(ra[r].getTextWithFormatting(["text"])), norm(rb[r].getTextWithFormatting(["text"])))
+            steps++
+        }
+        ra.forEach((r, ri) => {
+            assert.deepStrictEqual(norm(r.getTextWithFormatting(["text"])), norm(d.expected[ri].spans))
+            assert.deepStrictEqual([].concat(...r.getPatches()), d.expected[ri].patches)
+        })
+        appends += a.stats.residentAppends
+        uploads += a.stats.residentUploads
+        rowsUploaded += a.stats.rowsUploaded
+        rows += d.logs.reduce((n, l) => n + l.reduce((m, c) => m + c.ops.length, 0), 0)
+        a.close()
+        b.close()
+    })
+    console.log(JSON.stringify({ ok: true, steps, appends, uploads, rowsUploaded, rows }))
 } else if (cmd === "generate") {
     /* GPU: on-device change() reproduces the committed PTXGEN fixtures (config + seed in the file) and merges them to their spans */
     const engine = new host.MergeEngine()
@@ -362,6 +494,6 @@ if (cmd === "encode") {
     engine.close()
     console.log(JSON.stringify({ ok: true, logs }))
 } else {
-    console.error("usage: encode|load|run|patches|decode|generate|inputops|change")
+    console.error("usage: encode|load|run|patches|decode|generate|inputops|change|resident-mock|resident")
     process.exit(2)
 }

@@ -193,3 +193,24 @@ def test_patch_streams_with_op_counters_beyond_the_dense_key_range():
     assert (int(wide.log_hdr["max_counter"].max()) + 1) * (int(wide.log_hdr["max_actor"].max()) + 1) > 65535
     res = H.emu_merge(wide, lds_bytes=160 * 1024)
     assert _check_streams(wide, H.emu_replay(wide, res), [d["expected"] for d in g["docs"]]) == wide.n_logs
+
+
+@pytest.mark.parametrize("gwin", [False, True])
+def test_tail_streams_are_the_suffix_of_the_whole_stream(gwin):
+    """ptx_replay_patches_from: the records of the rows from first_row[l] on are exactly the tail of the log's whole stream (same records, same order),
+    whatever the cut — row 0, inside a change, the last row, past the end."""
+    g = _load("patches_rich_300.json")
+    batch = wire.encode_docs([d["logs"] for d in g["docs"]])
+    res = H.emu_merge(batch, lds_bytes=160 * 1024)
+    whole = H.emu_replay(batch, res, gwin=gwin)
+    sizes = np.diff(batch.log_off.astype(np.int64))
+    rng = np.random.default_rng(5)
+    for cut in ("zero", "random", "last", "past"):
+        first = {"zero": np.zeros_like(sizes), "random": rng.integers(0, np.maximum(sizes, 1)), "last": np.maximum(sizes - 1, 0), "past": sizes + 3}[cut]
+        tail = H.emu_replay(batch, res, gwin=gwin, first_row=first)
+        for log in range(batch.n_logs):
+            a = whole.patches[int(whole.patch_off[log]):int(whole.patch_off[log]) + int(whole.logs["n_patches"][log])]
+            b = tail.patches[int(tail.patch_off[log]):int(tail.patch_off[log]) + int(tail.logs["n_patches"][log])]
+            want = a[a["row"] >= first[log]]
+            assert tail.logs["status"][log] == whole.logs["status"][log]
+            assert np.array_equal(b, want), (cut, log, int(first[log]))

@@ -387,6 +387,33 @@ def test_patch_streams_live_oracle_and_accumulate(eng, config, docs, ops, seed):
         assert H.norm_spans(got) == H.norm_spans(wire.decode_spans(batch, res, log)), "log %d" % log
 
 
+def test_tail_patch_streams_are_the_suffix_of_the_whole_stream(eng):
+    """ptx_replay_patches_from (what a host with resident replicas asks for after appending Changes): the records from first_row[l] on = the tail of the
+    log's whole stream, for cuts at row 0, inside the log, at the last row and past the end."""
+    g = _load("patches_rich_300.json")
+    batch = wire.encode_docs([d["logs"] for d in g["docs"]])
+    db = eng.upload(batch)
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        eng.sync()
+        whole = eng.replay_patches(db, dr)
+        sizes = np.diff(batch.log_off.astype(np.int64))
+        rng = np.random.default_rng(11)
+        for first in (np.zeros_like(sizes), rng.integers(0, np.maximum(sizes, 1)), np.maximum(sizes - 1, 0), sizes + 5):
+            tail = eng.replay_patches(db, dr, first_row=first)
+            assert np.array_equal(tail.logs["status"], whole.logs["status"])
+            for log in range(batch.n_logs):
+                a = whole.patches[int(whole.patch_off[log]):int(whole.patch_off[log]) + int(whole.logs["n_patches"][log])]
+                b = tail.patches[int(tail.patch_off[log]):int(tail.patch_off[log]) + int(tail.logs["n_patches"][log])]
+                assert np.array_equal(b, a[a["row"] >= first[log]]), (log, int(first[log]))
+        with pytest.raises(ValueError):
+            eng.replay_patches(db, dr, first_row=[0])
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
+
+
 def test_patch_streams_need_elem_rank_and_handle_empty(eng):
     from peritext_amd.engine import Engine, PtxError
 

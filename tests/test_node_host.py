@@ -36,7 +36,7 @@ def test_addon_loads_and_binds_the_c_abi():
     assert info["abi"] == abi.PTX_ABI_VERSION
     assert info["kernel"].startswith("ptx_merge_kernel")
     assert info["exports"] == ["applyMaterialize", "change", "commDestroy", "commInit", "commUniqueId", "create", "cursors", "destroy", "generate", "kernelName", "maxOpsPerLog",
-                               "mergeAndGather", "open", "rootMap"]
+                               "mergeAndGather", "open", "residentAppend", "residentApply", "residentFree", "residentUpload", "rootMap"]
 
 
 @needs_node
@@ -151,6 +151,29 @@ def test_node_host_patch_streams():
     out = _node("patches", *[os.path.join(H.GOLDEN, n) for n in names], timeout=600)
     want = [e for n in names for d in json.load(open(os.path.join(H.GOLDEN, n)))["docs"] for e in d["expected"]]
     assert out["ok"] and out["logs"] == len(want) and out["patches"] == sum(len(e["patches"]) for e in want)
+
+
+@needs_node
+def test_resident_replica_bookkeeping_of_the_js_host():
+    """replica() handles keep their logs resident: against a stand-in addon (no GPU) every flush appends only the Changes that arrived since, what is
+    "resident" decodes back to exactly the Changes the handles hold, and every row is uploaded once (new comment ids take the next ranks; only a new actor
+    makes the document be encoded again)."""
+    out = _node("resident-mock", os.path.join(H.GOLDEN, "patches_rich_300.json"))
+    assert out["ok"] and out["uploads"] == out["docs"] and out["appends"] > 100 and out["rowsUploaded"] == out["rows"]
+    out = _node("resident-mock", os.path.join(H.GOLDEN, "patches_mini.json"))  # (here some actors show up late: those documents are encoded a second time)
+    assert out["ok"] and out["uploads"] <= 2 * out["docs"] and out["rowsUploaded"] < 1.2 * out["rows"]
+
+
+@pytest.mark.gpu
+@needs_node
+@needs_addon
+def test_node_host_resident_replicas():
+    """The same on the GPU (ptx_batch_append + ptx_merge + ptx_replay_patches_from behind N-API): after every step spans and Patch[][] equal those of an
+    engine that re-encodes, re-uploads and replays everything each time, and the reference's at the end; every row went up once."""
+    out = _node("resident", os.path.join(H.GOLDEN, "patches_rich_300.json"), "2", timeout=900)
+    assert out["ok"] and out["appends"] > 20 and out["uploads"] == 2 and out["rowsUploaded"] == out["rows"]
+    out = _node("resident", os.path.join(H.GOLDEN, "patches_mini.json"), "6", timeout=900)
+    assert out["ok"] and out["rowsUploaded"] < 1.5 * out["rows"]
 
 
 @pytest.mark.gpu

@@ -7,6 +7,8 @@
                     checked against the oracle on the host (whole logs: decoded spans, raw rows, digests);
   patch_replay      ptx_replay_patches (SURVEY 8 f1) on 2 048 documents of the bench's config: ops replayed per second (kernel time measured in the library);
   phase_cycles      where a log's residency goes (thread-0 cycle stamps of the diagnostic build of the same kernel body), loaded and with a CU to itself;
+  pipeline          change() -> merge -> convergence as a two-stage pipeline: ptx_generate of batch k + 1 (one engine, its stream) runs while ptx_merge of batch k and
+                    the digest comparison run on a second engine's stream — against the same batches one after the other on one engine;
   candidate         when a candidate build peritext_amd/lib/exp_<name>.so stands beside the product (__graft_entry__.CANDIDATE): the bench's workload under
                     it, same box, same call, every log's status / digest / row counts compared with the product's.
 Every leg records its own failure instead of raising.  One JSON line on stdout.
@@ -121,6 +123,72 @@ def config_leg(args, name, docs, flags):
     return row
 
 
+def pipeline_leg(args, gen_args, flags, batches=6, docs=8192):
+    """generate -> merge -> converged count over `batches` batches of `docs` documents: serial on one engine, then generator and merger on two engines (two HIP
+    streams of one device) in two host threads (the ctypes calls release the GIL).  Handles made by one engine are merged by the other: a resident batch is plain
+    device memory.  The count is taken on the host from the 16-byte digests of the result rows (no torch in this process)."""
+    import queue
+    import threading
+
+    replicas = gen_args[0]
+
+    def converged(e, db, dr):
+        dg = e.download_logs(dr, e.n_logs(db))["digest"].reshape(-1, replicas, 2)
+        return int((dg == dg[:, :1, :]).all(axis=(1, 2)).sum())
+
+    def consume(e, db):
+        dr = e.alloc_result(db)
+        e.merge(db, dr)
+        e.sync()
+        c = converged(e, db, dr)
+        e.free_result(dr)
+        return c
+
+    ops = batches * docs * replicas * gen_args[1]
+    with Engine(args.device, flags=flags) as g, Engine(args.device, flags=flags) as m:
+        db, _ = g.generate(*gen_args, 256, args.seed, list_cap=args.list_cap)  # warm both engines
+        consume(m, db)
+        g.free_batch(db)
+        t0 = time.time()
+        conv_serial = 0
+        for k in range(batches):
+            db, _ = g.generate(*gen_args, docs, args.seed, first_doc=args.first_doc + k * docs, list_cap=args.list_cap)
+            conv_serial += consume(g, db)
+            g.free_batch(db)
+        serial_s = time.time() - t0
+        ready, done, errs = queue.Queue(maxsize=2), queue.Queue(), []
+
+        def produce():
+            try:
+                for k in range(batches):
+                    while not done.empty():
+                        g.free_batch(done.get())
+                    db, _ = g.generate(*gen_args, docs, args.seed, first_doc=args.first_doc + k * docs, list_cap=args.list_cap)
+                    ready.put(db)
+            except Exception as ex:  # noqa: BLE001
+                errs.append(str(ex)[:300])
+            ready.put(None)
+
+        t0 = time.time()
+        th = threading.Thread(target=produce)
+        th.start()
+        conv_pipe = 0
+        while True:
+            db = ready.get()
+            if db is None:
+                break
+            conv_pipe += consume(m, db)
+            done.put(db)
+        th.join()
+        pipe_s = time.time() - t0
+        while not done.empty():
+            g.free_batch(done.get())
+    if errs:
+        raise RuntimeError(errs[0])
+    return {"batches": batches, "docs_per_batch": docs, "ops": ops, "serial_s": serial_s, "pipelined_s": pipe_s, "serial_ops_per_s": ops / serial_s, "pipelined_ops_per_s": ops / pipe_s,
+            "docs_converged": conv_pipe, "same_count_serial": conv_pipe == conv_serial, "stages": "ptx_generate (engine A) || ptx_merge + digest comparison (engine B)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="config4")
@@ -133,7 +201,7 @@ def main():
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--no-admission", action="store_true")
     ap.add_argument("--parity-docs", type=int, default=8)
-    ap.add_argument("--legs", default="configs,replay,phases,candidate,probe")
+    ap.add_argument("--legs", default="configs,replay,pipeline,phases,candidate,probe")
     args = ap.parse_args()
     legs = set(args.legs.split(","))
     g = workloads.gen_config(args.config, ops=args.ops)
@@ -167,6 +235,13 @@ def main():
         except Exception as ex:  # noqa: BLE001
             out["patch_replay"] = {"error": str(ex)[:300]}
         say("patch_replay %s" % json.dumps(out["patch_replay"]))
+
+    if "pipeline" in legs:
+        try:
+            out["generate_merge_pipeline"] = pipeline_leg(args, gen_args, flags)
+        except Exception as ex:  # noqa: BLE001
+            out["generate_merge_pipeline"] = {"error": str(ex)[:300]}
+        say("generate_merge_pipeline %s" % json.dumps(out["generate_merge_pipeline"]))
 
     ref = None
     if "phases" in legs or "candidate" in legs:
