@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 4u
+#define PTX_ABI_VERSION 5u
 
 /* Operation.action (micromerge.ts:150-212, peritext.ts:25-65) */
 enum {
