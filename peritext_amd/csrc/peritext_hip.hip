@@ -1448,7 +1448,18 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
     uint64_t need = 0, need_g = 0;
     for (uint32_t l = 0; l < L; ++l) {
         need = std::max<uint64_t>(need, ptx_replay_lds_need_hdr(hdr[l]));
-        need_g = std::max<uint64_t>(need_g, ptx_replay_lds_need_hdr(hdr[l], true));
+        need_g = std::max<uint64_t>(need_g, ptx_replay_lds_need_hdr(hdr[l], true, 0));
+    }
+    /* (global winners) how much of a mark op's slot list stays in the LDS — it saves the op two global round trips, and costs resident logs.  Measured on
+     * one MI355X: 4 096-op logs (19 per CU without it) are fastest at 1 024 entries = 15 per CU, 2 048-op logs (more than the CU's 28 wave
+     * slots would take) lose a quarter at 1 024.  So: what fits while the wave slots stay full, else what costs no more than a fifth of the resident logs. */
+    uint32_t seg_lds = 0;
+    {
+        const uint64_t lds0 = std::max<uint64_t>((need_g + 255) & ~255ull, 256), logs0 = std::min<uint64_t>(ctx->max_lds / lds0, 28);
+        const uint64_t keep = logs0 >= 28 ? 28 : (logs0 * 4 + 4) / 5;
+        const uint64_t room = keep ? ctx->max_lds / keep : 0;
+        if (room > need_g + 256) seg_lds = (uint32_t)std::min<uint64_t>(((room - need_g - 256) / 2) & ~63ull, 1536);
+        for (uint32_t l = 0; l < L && seg_lds; ++l) need_g = std::max<uint64_t>(need_g, ptx_replay_lds_need_hdr(hdr[l], true, seg_lds));
     }
     /* The replay is one wave per log and lives on occupancy (the op chain is dependent round trips).  Above PTX_REPLAY_GWIN_ABOVE bytes of working set the LDS,
      * not the wave slots, bounds the resident logs: the three per-slot winner arrays (more than half of it) and the tail of a mark op's slot list move to global
@@ -1513,6 +1524,7 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
             A.n_logs = L;
             A.lds_bytes = lds_bytes;
             A.win_scratch = d_win;
+            A.seg_lds = seg_lds;
             A.first_row = d_first;
             (void)hipEventRecord(ctx->ev0, ctx->stream);
             if (gwin) hipLaunchKernelGGL(ptx_replay_kernel_gwin, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);

@@ -54,6 +54,7 @@ struct PtxReplayArgs {
     uint32_t n_logs;
     uint32_t lds_bytes;
     const uint32_t* first_row; /* optional [n_logs]: only the records of the rows from here on are produced (the rows before are replayed for their state alone) */
+    uint32_t seg_lds;      /* (win_scratch) entries of a mark op's slot list kept in the LDS; the rest of the list lives behind the winner arrays */
     uint16_t* win_scratch; /* optional: the per-slot winner arrays of every log live HERE (16 bytes per row of the batch + 128 per log; the list of a mark op's defined slots too) instead of in LDS */
 };
 
@@ -65,22 +66,20 @@ struct PtxReplayHdr {
     uint32_t scan_tmp[36];
 };
 
-#ifndef PTX_SEG_LDS
-#define PTX_SEG_LDS 1024u /* slot-list entries of a mark op's range kept in the LDS when the winner arrays are global */
-#endif
-PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid, bool gwin = false) {
+/* gwin: the per-slot winner arrays live in global memory and only the first seg_lds entries of a mark op's slot list in the LDS (PtxReplayArgs.seg_lds) */
+PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid, bool gwin = false, uint64_t seg_lds = 0) {
     const uint64_t nw = (ks + 31) / 32, nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
     const uint64_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
     (void)nw;
     return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + 2 * ptx_a16(4 * nws) +
-           ptx_a16(4 * (nws + 1)) + (gwin ? ptx_a16(2 * (segcap < PTX_SEG_LDS ? segcap : PTX_SEG_LDS)) : 3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * segcap)) + ptx_a16(8 * ((segcap >> 5) + 2)) + 3 * ptx_a16(4 * nws) +
+           ptx_a16(4 * (nws + 1)) + (gwin ? ptx_a16(2 * (segcap < seg_lds ? segcap : seg_lds)) : 3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * segcap)) + ptx_a16(8 * ((segcap >> 5) + 2)) + 3 * ptx_a16(4 * nws) +
            ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 3 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
            4 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
 }
-PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gwin = false) {
+PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gwin = false, uint64_t seg_lds = 0) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
     const uint64_t ks = ((uint64_t)h.max_counter + 1) * ((uint64_t)(h.max_actor > 4095u ? 4095u : h.max_actor) + 1);
-    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], ks, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u, gwin);
+    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], ks, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u, gwin, seg_lds);
 }
 /* bytes of win_scratch a batch takes, and where the arrays of a log start (in u16 units): three winner arrays and the slot list of a mark op's range, each of at
  * most 2 N + 3 entries, 16-byte aligned */
@@ -174,9 +173,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint16_t* c_b = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* mark: end slot */
     uint16_t* c_key = ptx_alloc<uint16_t>(bp, PTX_RCHUNK); /* (key_mode) the op id's dense key + 1 */
     uint8_t* c_kind = ptx_alloc<uint8_t>(bp, PTX_RCHUNK);  /* PTX_RK_* | mark type << 4 | addMark << 6 */
-    /* defined slots of the op's range, ascending.  (global winners) the first PTX_SEG_LDS of them stay in the LDS — most ranges end there, and the list is
+    /* defined slots of the op's range, ascending.  (global winners) the first A.seg_lds of them stay in the LDS — most ranges end there, and the list is
      * read right after it is filled: a global one costs the op two more round trips — the rest goes to global memory behind the winner arrays */
-    const uint32_t segl = kGWin ? (segcap < PTX_SEG_LDS ? segcap : (uint32_t)PTX_SEG_LDS) : segcap;
+    const uint32_t segl = kGWin ? (segcap < A.seg_lds ? segcap : A.seg_lds) : segcap;
     uint16_t* seg_l = ptx_alloc<uint16_t>(bp, segl);
     uint16_t* seg = kGWin ? A.win_scratch + ptx_replay_win_at(base, log) + 3u * ((2u * n + 2u + 7u) & ~7u) : seg_l;
 #define PTX_SEG_LD(j_) ((j_) < segl ? seg_l[j_] : ptx_coherent_load16(&seg[j_]))

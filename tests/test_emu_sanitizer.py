@@ -24,7 +24,7 @@ def test_emulation_suites_under_asan_and_ubsan(tmp_path):
     if not asan or not ubsan:
         pytest.skip("no libasan / libubsan in this image")
     lib = str(tmp_path / "libperitext_emu_asan.so")
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-DPTX_SEG_LDS=24u",
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined",
                     "-o", lib, os.path.join(ROOT, "tests", "emu", "emu_driver.cc")], check=True, timeout=600)
     env = dict(os.environ, PTX_EMU_LIB=lib, LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", "-p", "no:cacheprovider"] + SUITES, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
