@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Logs per CU against throughput on the SAME logs: one generated batch merged under several LDS windows per log (ptx_set_launch_shape), i.e. 10 / 9 / 8 / 7 ... logs
-resident per CU, for one or more builds of the library.  GPU box; no torch.
-    python tools/occ_probe.py --ops 3200 --docs 16384 --lds 16384,18176,20480,23040 [--lib peritext_amd/lib/exp_w8.so ...]"""
+resident per CU (the CU hands out LDS in 1 280-byte granules: tools/micro/occupancy_query.hip), for one or more builds of the library.  GPU box; no torch.
+    python tools/occ_probe.py --ops 3200 --docs 16384 --lds 16640,19200,23040   (granules of 1 280 B: 9 / 8 / 7 logs per CU) [--lib peritext_amd/lib/exp_w8.so ...]"""
 import argparse
 import json
 import os
@@ -40,7 +40,7 @@ def main():
                     n_logs = e.n_logs(db)
                     shape = e.launch_shape(db)
                     row = {"lib": os.path.basename(lib or "product"), "config": args.config, "ops": c["ops_per_log"], "docs": args.docs, "launch": shape,
-                           "logs_per_cu_by_lds": (160 * 1024) // max(512, (shape[1] + 511) // 512 * 512), "ms": ms, "Gops_s": n_logs * c["ops_per_log"] / ms / 1e6,
+                           "logs_per_cu_by_lds": (160 * 1024) // max(1280, (shape[1] + 1279) // 1280 * 1280), "ms": ms, "Gops_s": n_logs * c["ops_per_log"] / ms / 1e6,
                            "us_per_log_per_cu": ms * 1e3 * 256 / n_logs, "lds_high": int(logs["reserved"][:, 0].max()), "ok": bool(int(logs["status"].max()) == 0),
                            "digest_xor": "%016x" % int(abs(int(logs["digest"].astype("uint64").sum())) & 0xFFFFFFFFFFFFFFFF)}
                     print(json.dumps(row), flush=True)
