@@ -39,8 +39,14 @@
 #ifndef PTX_W
 #define PTX_W 1 /* minimum waves per SIMD the register allocation of ptx_merge_kernel must allow (8: ten 3-wave logs per CU need it; costs SGPR spills) */
 #endif
-#define PTX_MERGE_KERNEL(name, T, W, MANY, KT, DIAG)                                     \
-    extern "C" __global__ void __launch_bounds__(T, W) name(PtxMergeArgs A) {          \
+/* Scalar registers decide the wave slots too, and not as the compiler's occupancy figure says: measured on MI355X (tools/micro/reg_occupancy.hip,
+ * profiles/r03_p_*) a kernel of up to 96 SGPRs (vcc etc. included) holds 7 waves per SIMD, one of 98 or more holds 6 — 24 waves per CU, i.e. exactly the
+ * eight 3-wave logs that the LDS window of a 4 096-op log allows anyway.  Where the LDS would allow more waves than 24 (short logs), the host launches
+ * the "_w7" builds: the same body held to 90 SGPRs (+ vcc ...; costs ~70 more SGPR spills into VGPR lanes, 1-2 % at equal occupancy). */
+#define PTX_SGPRS_W7 __attribute__((amdgpu_num_sgpr(90)))
+#define PTX_MERGE_KERNEL(name, T, W, MANY, KT, DIAG) PTX_MERGE_KERNEL_A(name, T, W, MANY, KT, DIAG, )
+#define PTX_MERGE_KERNEL_A(name, T, W, MANY, KT, DIAG, PTX_SGPR_CAP)                                     \
+    extern "C" __global__ void __launch_bounds__(T, W) PTX_SGPR_CAP name(PtxMergeArgs A) { \
         extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];              \
         /* one workgroup per log (grid == n_logs): no grid-stride loop, so that nothing is hoisted \
            out of it and kept in registers for the whole kernel */                    \
@@ -49,6 +55,8 @@
 PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, PTX_W, false, 0, false)     /* any launch shape (blockDim.x read at run time) */
 PTX_MERGE_KERNEL(ptx_merge_kernel_rest, 1024, 1, false, 0, false) /* the same kernel under another name: the second launch of a split batch (the few logs
                                                                     with a larger LDS window), so that per-kernel statistics of a trace keep the two apart */
+PTX_MERGE_KERNEL_A(ptx_merge_kernel_w7, 1024, PTX_W, false, 0, false, PTX_SGPRS_W7)      /* the same two at 7 waves per SIMD (see above) */
+PTX_MERGE_KERNEL_A(ptx_merge_kernel_rest_w7, 1024, 1, false, 0, false, PTX_SGPRS_W7)
 PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false) /* + causal admission for documents with more than three actors */
 PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, 1, true, 0, true)  /* + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
 /* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
@@ -63,11 +71,13 @@ extern "C" __global__ void __launch_bounds__(PTX_BIG_THREADS) ptx_merge_big_kern
 
 /* Patch-stream replay (replay_core.h): one 64-thread workgroup (one wave) per log, sequential in application order */
 #ifndef PTX_REPLAY_GWIN_ABOVE
-#define PTX_REPLAY_GWIN_ABOVE 5632u /* LDS bytes per log beyond which the replay's winner arrays and the tail of its slot list move to global memory (below it the 28 wave slots of a CU, not its LDS, bound the resident logs) */
+#define PTX_REPLAY_GWIN_ABOVE 5632u /* LDS bytes per log beyond which the replay's winner arrays and the tail of its slot list move to global memory (below it the wave slots of a CU — 24 at this kernel's 106 SGPRs, see PTX_SGPRS_W7 —, not its LDS, bound the resident logs) */
 #endif
 #ifndef PTX_REPLAY_THREADS
 #define PTX_REPLAY_THREADS 64
 #endif
+/* (held to 90 SGPRs for 28 instead of 24 wave slots per CU — see PTX_SGPRS_W7 — the replay is SLOWER: 0.98 against 1.05 G ops/s on 4 096-op logs, its spills sit
+ * on the sequential chain) */
 extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kernel(PtxReplayArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS, false>(A, blockIdx.x, ptx_lds);
@@ -595,7 +605,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     ctx->own_stream = ctx->stream;
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -1018,10 +1028,13 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
             hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), lds, st, A);
         else if (admit && b->max_actors > 3)
             hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);
-        else if (part)
-            hipLaunchKernelGGL(ptx_merge_kernel_rest, dim3(grid), dim3(b->threads), lds, st, A);
-        else
-            hipLaunchKernelGGL(ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, st, A);
+        else {
+            /* would the LDS window let more than 24 waves share a CU (LDS comes in granules of 1 280 bytes)?  Then the build that fits 7 waves per SIMD */
+            const uint32_t waves = (b->threads + 63u) / 64u, by_lds = (uint32_t)(ctx->max_lds / ((((uint64_t)lds + 1279u) / 1280u) * 1280u));
+            const bool w7 = by_lds * waves > 24u;
+            if (part) hipLaunchKernelGGL(w7 ? ptx_merge_kernel_rest_w7 : ptx_merge_kernel_rest, dim3(grid), dim3(b->threads), lds, st, A);
+            else hipLaunchKernelGGL(w7 ? ptx_merge_kernel_w7 : ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, st, A);
+        }
     }
     if (fork) {
         (void)hipEventRecord(ctx->ev_join, ctx->side);
