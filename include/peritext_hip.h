@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 5u
+#define PTX_ABI_VERSION 6u
 
 /* Operation.action (micromerge.ts:150-212, peritext.ts:25-65) */
 enum {
@@ -160,11 +160,19 @@ typedef struct ptx_batch {
     const uint64_t* chg_off;   /* [n_logs + 1] or NULL */
     const uint32_t* chg_hdr;   /* [n_changes] actorRank << PTX_CHG_ACTOR_SHIFT | ops in the change (consecutive rows of the log) */
     const uint16_t* chg_env;   /* [n_changes * PTX_ENV_STRIDE(max_actors)] one row per change: seq, deps[0 .. max_actors) (0 = none),
-                                  zero padding.  16-bit: a log holds at most 65 533 changes; larger values saturate at 65 535, which
-                                  can never be admitted — the same RangeError as the true value */
+                                  zero padding.  The LOW 16 bits of every value when the batch carries chg_env_hi; without it the
+                                  values themselves, saturated at 65 535 (PTX_ENV_SATURATED) — a log of up to 65 533 changes can
+                                  never admit such a change: the reference's RangeError either way (micromerge.ts:501-509) */
     uint32_t max_actors;       /* actors of a document (deps entries per change) */
     uint32_t reserved2;
     const ptx_log_hdr* log_hdr; /* [n_logs] or NULL (the library computes it) */
+    /* optional wide envelope (ABI 6): the HIGH 16 bits of every chg_env value, same shape; NULL = every seq / dep of the batch fits 16
+     * bits.  seq / deps are plain numbers in the reference (micromerge.ts:499-511): a replica that typed one change per keystroke
+     * (bridge.ts:535) passes 65 535 changes of one actor.  Encoders emit the column whenever some value of the batch exceeds 65 534;
+     * values are then EXACT (lo | hi << 16, no saturation).  A log whose rows of it are not all zero, or that holds more than 65 533
+     * changes, is merged by the HBM-staged kernel (32-bit admission table); a log of more than 65 533 changes in a batch WITHOUT the
+     * column cannot be represented and reports PTX_ERR_CAPACITY — never a spurious PTX_ERR_SEQ_GAP. */
+    const uint16_t* chg_env_hi; /* [n_changes * PTX_ENV_STRIDE(max_actors)] or NULL */
 } ptx_batch;
 
 typedef struct ptx_span {

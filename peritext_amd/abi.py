@@ -7,7 +7,7 @@ the shared object is missing, and `ptx_create` fails when no gfx950 device is vi
 import ctypes as C
 import os
 
-PTX_ABI_VERSION = 5
+PTX_ABI_VERSION = 6
 
 # Operation.action (reference/src/micromerge.ts:150-212, src/peritext.ts:25-65)
 ACT_MAKELIST, ACT_INSERT, ACT_DELETE, ACT_ADDMARK, ACT_REMOVEMARK, ACT_NOP, ACT_MAPSET, ACT_MAPDEL = range(8)
@@ -112,6 +112,7 @@ class ptx_batch(C.Structure):
         ("max_actors", C.c_uint32),
         ("reserved2", C.c_uint32),
         ("log_hdr", C.POINTER(ptx_log_hdr)),
+        ("chg_env_hi", u16p),
     ]
 
 

@@ -174,8 +174,10 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     uint32_t C = 0, na = 0;
     uint32_t *first = nullptr, *tbl = nullptr, *crow = nullptr;
     const uint32_t* c_hdr = nullptr;
-    const uint16_t* c_env = nullptr;
+    const uint16_t *c_env = nullptr, *c_env_hi = nullptr;
     uint32_t estride = 0;
+    /* value k of the envelope of this log: exact (lo | hi << 16) when the batch carries the wide column */
+    auto env_at = [&](uint64_t k) -> uint32_t { return (uint32_t)c_env[k] | (c_env_hi ? (uint32_t)c_env_hi[k] << 16 : 0u); };
     if (A.chg_off) {
         const uint64_t c0 = A.chg_off[log], C64 = A.chg_off[log + 1] - c0;
         na = A.max_actors;
@@ -185,6 +187,10 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         estride = PTX_ENV_STRIDE(na);
         c_hdr = A.chg_hdr + c0;
         c_env = A.chg_env + c0 * estride;
+        c_env_hi = A.chg_env_hi ? A.chg_env_hi + c0 * estride : nullptr;
+        /* seq / deps beyond 16 bits need the wide column; without it a log of more than 65533 changes cannot be represented (its values
+         * saturate at 65535): a capacity report, never a spurious sequence gap */
+        if (C > 65533u && !c_env_hi) return PTX_ERR_CAPACITY;
         first = (uint32_t*)take(4ull * (na + 2));
         tbl = (uint32_t*)take(4ull * (C + 1));
         crow = (uint32_t*)take(4ull * (C + 1));
@@ -246,18 +252,18 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_SYNC();
         PTX_FOR(c, C) {
-            const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT, sq = c_env[(uint64_t)c * estride];
+            const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT, sq = env_at((uint64_t)c * estride);
             const uint32_t f = first[a], cnt_a = first[a + 1] - f;
             if (sq - 1u < cnt_a) ptx_atomic_min(&tbl[f + sq - 1u], c);
         }
         PTX_SYNC();
         PTX_FOR(c, C) {
-            const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT, sq = c_env[(uint64_t)c * estride];
+            const uint32_t a = c_hdr[c] >> PTX_CHG_ACTOR_SHIFT, sq = env_at((uint64_t)c * estride);
             const uint32_t f = first[a], cnt_a = first[a + 1] - f;
             const bool bad_seq = !(sq - 1u < cnt_a) || tbl[f + sq - 1u] != c || (sq > 1u && tbl[f + sq - 2u] >= c); /* seq == clock[a] + 1 */
             bool bad_dep = false;
             for (uint32_t b = 0; b < na && !bad_seq; ++b) { /* clock[b] >= deps[b] for every actor */
-                const uint32_t d = c_env[(uint64_t)c * estride + 1u + b];
+                const uint32_t d = env_at((uint64_t)c * estride + 1u + b);
                 if (d != 0u) {
                     const uint32_t fb = first[b], cnt_b = first[b + 1] - fb;
                     if (!(d <= cnt_b) || tbl[fb + d - 1u] >= c) bad_dep = true;

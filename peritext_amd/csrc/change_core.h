@@ -64,7 +64,9 @@ struct PtxChangeArgs {
     uint8_t* o_side_a;
     uint8_t* o_side_b;
     uint32_t* o_chg_hdr;
-    uint16_t* o_chg_env;       /* rows of PTX_ENV_STRIDE(max_actors) */
+    uint16_t* o_chg_env;       /* rows of PTX_ENV_STRIDE(max_actors): the low halves of seq / deps */
+    uint16_t* o_chg_env_hi;    /* the high halves (the wide column of include/peritext_hip.h), same shape */
+    uint32_t* any_wide;        /* set to 1 when some high half is not zero (the host then keeps the wide column) */
     uint32_t* status;          /* [n_logs] PTX_OK / PTX_ERR_* */
     uint32_t* rows_made;       /* [n_logs] rows written (0 on error) */
     uint32_t* chgs_made;       /* [n_logs] */
@@ -254,7 +256,12 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
         const uint32_t seq = clock[me] + 1u;
         PTX_SYNC();
         const uint32_t es = PTX_ENV_STRIDE(na);
-        PTX_FOR(b, es - 1u) A.o_chg_env[c * es + 1u + b] = (uint16_t)(b < na ? (clock[b] < PTX_ENV_SATURATED ? clock[b] : PTX_ENV_SATURATED) : 0u);
+        PTX_FOR(b, es - 1u) { /* exact values: low halves here, high halves in the wide column */
+            const uint32_t v = b < na ? clock[b] : 0u;
+            A.o_chg_env[c * es + 1u + b] = (uint16_t)v;
+            A.o_chg_env_hi[c * es + 1u + b] = (uint16_t)(v >> 16);
+            if (v >= PTX_ENV_SATURATED) *A.any_wide = 1u; /* 65535 itself would read as "saturated" without the column */
+        }
         PTX_SYNC();
         PTX_LEADER { clock[me] = seq; }
         PTX_SYNC();
@@ -351,7 +358,9 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
         }
         PTX_LEADER {
             A.o_chg_hdr[c] = (me << PTX_CHG_ACTOR_SHIFT) | nops;
-            A.o_chg_env[c * es] = (uint16_t)(seq < PTX_ENV_SATURATED ? seq : PTX_ENV_SATURATED);
+            A.o_chg_env[c * es] = (uint16_t)seq;
+            A.o_chg_env_hi[c * es] = (uint16_t)(seq >> 16);
+            if (seq >= PTX_ENV_SATURATED) *A.any_wide = 1u; /* 65535 itself would read as "saturated" without the column */
         }
         ++made;
     }

@@ -89,6 +89,7 @@ struct PtxMergeArgs {
     const uint64_t* chg_off;
     const uint32_t* chg_hdr;  /* actor << 20 | nops */
     const uint16_t* chg_env;  /* rows of PTX_ENV_STRIDE(max_actors) u16: seq, deps[...] */
+    const uint16_t* chg_env_hi; /* optional: the high halves of the same values (only the HBM-staged kernel reads them: the host routes every log that needs them there) */
     const ptx_log_hdr* log_hdr; /* [n_logs] per-log census (always present: the host computes it when the caller did not) */
     ptx_log_result* res;
     uint32_t* out_values;
@@ -604,8 +605,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     /* ---- P0: causal admission (micromerge.ts:499-511), when the batch carries the Change envelope ----
      * Sequential rule: change c of actor a is admitted iff seq == clock[a] + 1 and clock[b] >= deps[b] for all b,
      * where clock[b] counts the changes of b applied before c.  Envelope per change: chg_hdr = actor << 20 | nops and one
-     * chg_env row of u16 {seq, deps[0 .. max_actors)} (values saturate at 65535: a log holds at most 65533 changes, so a
-     * saturated value can never be admitted — the same error as the true one). */
+     * chg_env row of u16 {seq, deps[0 .. max_actors)}.  This kernel takes logs of at most 65533 changes whose values fit 16 bits
+     * (the census sends the others to biglog_core.h): a value saturated at 65535 can never be admitted here — the same error as
+     * the true one. */
     if (A.chg_off) {
         const uint64_t c0 = A.chg_off[log];
         const uint64_t C64 = A.chg_off[log + 1] - c0;

@@ -152,6 +152,7 @@ struct PtxAppendCols {
     const uint8_t *action, *mark_type, *side_a, *side_b;
     const uint32_t* chg_hdr;
     const uint16_t* chg_env;
+    const uint16_t* chg_env_hi; /* may be NULL: zeros */
 };
 struct PtxAppendDst {
     uint64_t *op_id, *ref_a, *ref_b;
@@ -159,7 +160,13 @@ struct PtxAppendDst {
     uint8_t *action, *mark_type, *side_a, *side_b;
     uint32_t* chg_hdr;
     uint16_t* chg_env;
+    uint16_t* chg_env_hi; /* NULL: the destination has no wide column */
 };
+/* the wide envelope column of an appended batch: a side that has none contributes zeros */
+__device__ void ptx_append_hi(const uint16_t* a, uint64_t a0, uint64_t na, const uint16_t* b, uint64_t b0, uint64_t nb, uint16_t* dst, uint64_t d0, uint64_t width) {
+    for (uint64_t i = threadIdx.x; i < na * width; i += blockDim.x) dst[d0 * width + i] = a ? a[a0 * width + i] : (uint16_t)0;
+    for (uint64_t i = threadIdx.x; i < nb * width; i += blockDim.x) dst[(d0 + na) * width + i] = b ? b[b0 * width + i] : (uint16_t)0;
+}
 __global__ void ptx_append_rows_kernel(PtxAppendCols A, const uint64_t* a_off, const uint64_t* a_coff, PtxAppendCols B, const uint64_t* b_off, const uint64_t* b_coff,
                                        PtxAppendDst D, const uint64_t* d_off, const uint64_t* d_coff, uint32_t max_actors) {
     const uint32_t l = blockIdx.x;
@@ -176,6 +183,7 @@ __global__ void ptx_append_rows_kernel(PtxAppendCols A, const uint64_t* a_off, c
         const uint64_t ac0 = a_coff[l], nac = a_coff[l + 1] - ac0, bc0 = b_coff[l], nbc = b_coff[l + 1] - bc0, dc0 = d_coff[l];
         ptx_append_col(A.chg_hdr, ac0, nac, B.chg_hdr, bc0, nbc, D.chg_hdr, dc0, 1);
         ptx_append_col(A.chg_env, ac0, nac, B.chg_env, bc0, nbc, D.chg_env, dc0, (uint64_t)PTX_ENV_STRIDE(max_actors));
+        if (D.chg_env_hi) ptx_append_hi(A.chg_env_hi, ac0, nac, B.chg_env_hi, bc0, nbc, D.chg_env_hi, dc0, (uint64_t)PTX_ENV_STRIDE(max_actors));
     }
 }
 
@@ -195,14 +203,16 @@ __global__ void ptx_take_rows_kernel(PtxAppendCols S, const uint64_t* s_off, con
     const uint64_t sc0 = s_coff[l], dc0 = d_coff[l], nc = chgs[l];
     ptx_append_col(S.chg_hdr, sc0, nc, S.chg_hdr, 0, 0, D.chg_hdr, dc0, 1);
     ptx_append_col(S.chg_env, sc0, nc, S.chg_env, 0, 0, D.chg_env, dc0, (uint64_t)PTX_ENV_STRIDE(max_actors));
+    if (D.chg_env_hi) ptx_append_hi(S.chg_env_hi, sc0, nc, nullptr, 0, 0, D.chg_env_hi, dc0, (uint64_t)PTX_ENV_STRIDE(max_actors));
 }
 
 /* Census pre-pass: one workgroup per log.  compute != 0: derive the log header from the rows (batches
  * that came without one); always: fold the log's LDS requirement and row count into shape[0..1]. */
 __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off, const uint64_t* op_id, const uint8_t* action, const uint8_t* mark_type,
                                                           const uint32_t* payload, ptx_log_hdr* hdr, uint32_t* shape, int compute, const uint64_t* chg_off, uint32_t max_actors,
-                                                          uint32_t* need_per_log, uint64_t n_ops, uint64_t* big_need_per_log, uint32_t max_lds) {
+                                                          uint32_t* need_per_log, uint64_t n_ops, uint64_t* big_need_per_log, uint32_t max_lds, const uint16_t* chg_env_hi) {
     __shared__ uint32_t sh[9];
+    __shared__ uint32_t wide;
     const uint32_t log = blockIdx.x;
     const uint64_t b0 = log_off[log], b1 = log_off[log + 1];
     if (b1 < b0 || b1 > n_ops || (log == 0 && b0 != 0) || (log + 1 == gridDim.x && b1 != n_ops)) {
@@ -265,6 +275,16 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
             hdr[log] = h;
         }
     }
+    /* does the log use the wide envelope column (some seq / dep beyond 16 bits)?  Then only the HBM-staged kernel can admit it */
+    if (threadIdx.x == 0) wide = 0;
+    __syncthreads();
+    if (chg_off && chg_env_hi) {
+        const uint64_t es = PTX_ENV_STRIDE(max_actors), e0 = chg_off[log] * es, e1 = chg_off[log + 1] * es;
+        uint32_t any = 0;
+        for (uint64_t i = e0 + threadIdx.x; i < e1; i += blockDim.x) any |= chg_env_hi[i];
+        if (any) atomicOr(&wide, 1u);
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         const ptx_log_hdr h = hdr[log];
         uint64_t need = ptx_lds_need_hdr(b1 - b0, h);
@@ -276,7 +296,7 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
         uint32_t kbits = 0;
         while ((1ull << kbits) < K + 1) ++kbits;
         const bool lds_ok = b1 - b0 <= 65534u && h.n_ins <= 32766u && h.max_counter < (1u << 19) && h.max_actor <= 4095u && (!h.n_mark[PTX_MARK_COMMENT] || h.n_comment_ids <= 65535u) &&
-                            ((ks + 1) << kbits) <= 0xFFFFFFFFull && C <= 65533u;
+                            ((ks + 1) << kbits) <= 0xFFFFFFFFull && C <= 65533u && !wide;
         if (!lds_ok) need = 0xFFFFFFFFull;
         need_per_log[log] = (uint32_t)min(need, (uint64_t)0xFFFFFFFFu);
         big_need_per_log[log] = ptx_big_need(b1 - b0, h, C, max_actors, PTX_BIG_THREADS);
@@ -391,6 +411,7 @@ struct ptx_dbatch {
     uint64_t* chg_off = nullptr;
     uint32_t* chg_hdr = nullptr;
     uint16_t* chg_env = nullptr;
+    uint16_t* chg_env_hi = nullptr; /* the wide column (high halves of chg_env's values), only when some value of the batch needs it */
     uint32_t max_actors = 0;
     uint64_t n_changes = 0;
     /* launch shape derived from the largest log */
@@ -464,7 +485,7 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
         if (e == hipSuccess) e = hipMemsetAsync(shape, 0, 12, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(ptx_census_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->log_off, b->op_id, b->action, b->mark_type, b->payload, b->log_hdr,
-                               shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors, d_need, b->n_ops, d_big, (uint32_t)ctx->max_lds);
+                               shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors, d_need, b->n_ops, d_big, (uint32_t)ctx->max_lds, b->chg_env_hi);
             e = hipGetLastError();
         }
         need.resize(b->n_logs);
@@ -688,6 +709,7 @@ void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
     (void)hipFree(b->chg_off);
     (void)hipFree(b->chg_hdr);
     (void)hipFree(b->chg_env);
+    (void)hipFree(b->chg_env_hi);
     delete b;
 }
 
@@ -746,10 +768,13 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
         const uint64_t ES = PTX_ENV_STRIDE(h->max_actors);
         PTX_TRY(dalloc(&b->chg_hdr, NC * copies + PTX_ENV_PAD)); /* padding: the admission pass reads headers and rows with 16-byte loads */
         PTX_TRY(dalloc(&b->chg_env, (NC * copies + PTX_ENV_PAD) * ES));
+        if (h->chg_env_hi) PTX_TRY(dalloc(&b->chg_env_hi, (NC * copies + PTX_ENV_PAD) * ES));
         for (uint32_t k = 0; k < copies && NC; ++k) {
             const hipMemcpyKind kd = k ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
             PTX_TRY(hipMemcpyAsync(b->chg_hdr + k * NC, k ? (const void*)b->chg_hdr : (const void*)h->chg_hdr, NC * 4, kd, ctx->stream));
             PTX_TRY(hipMemcpyAsync(b->chg_env + k * NC * ES, k ? (const void*)b->chg_env : (const void*)h->chg_env, NC * ES * 2, kd, ctx->stream));
+            if (h->chg_env_hi)
+                PTX_TRY(hipMemcpyAsync(b->chg_env_hi + k * NC * ES, k ? (const void*)b->chg_env_hi : (const void*)h->chg_env_hi, NC * ES * 2, kd, ctx->stream));
         }
         uint64_t* tmpc = nullptr;
         PTX_TRY(dalloc(&tmpc, (uint64_t)h->n_logs + 1));
@@ -854,6 +879,7 @@ ptx_status ptx_batch_append_device(ptx_ctx* ctx, const ptx_dbatch* base, const p
         PTX_TRYA(dalloc(&b->chg_off, L + 1));
         PTX_TRYA(dalloc(&b->chg_hdr, NC + PTX_ENV_PAD));
         PTX_TRYA(dalloc(&b->chg_env, (NC + PTX_ENV_PAD) * PTX_ENV_STRIDE(b->max_actors)));
+        if ((base_env && base->chg_env_hi) || m->chg_env_hi) PTX_TRYA(dalloc(&b->chg_env_hi, (NC + PTX_ENV_PAD) * PTX_ENV_STRIDE(b->max_actors)));
         if (!base_env) {
             PTX_TRYA(dalloc(&zero_off, L + 1));
             PTX_TRYA(hipMemsetAsync(zero_off, 0, (L + 1) * 8, ctx->stream));
@@ -865,9 +891,9 @@ ptx_status ptx_batch_append_device(ptx_ctx* ctx, const ptx_dbatch* base, const p
         hipLaunchKernelGGL(ptx_append_offsets_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base->log_off, m->log_off, b->log_off, (uint32_t)L);
         if (env) hipLaunchKernelGGL(ptx_append_offsets_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base_coff, m->chg_off, b->chg_off, (uint32_t)L);
         PtxAppendCols A = {base->op_id, base->ref_a, base->ref_b, base->payload, base->action, base->mark_type, base->side_a, base->side_b,
-                           base->chg_hdr, base->chg_env};
-        PtxAppendCols B = {m->op_id, m->ref_a, m->ref_b, m->payload, m->action, m->mark_type, m->side_a, m->side_b, m->chg_hdr, m->chg_env};
-        PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_hdr, b->chg_env};
+                           base->chg_hdr, base->chg_env, base_env ? base->chg_env_hi : nullptr};
+        PtxAppendCols B = {m->op_id, m->ref_a, m->ref_b, m->payload, m->action, m->mark_type, m->side_a, m->side_b, m->chg_hdr, m->chg_env, m->chg_env_hi};
+        PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_hdr, b->chg_env, b->chg_env_hi};
         hipLaunchKernelGGL(ptx_append_rows_kernel, dim3((unsigned)L), dim3(256), 0, ctx->stream, A, base->log_off, env ? base_coff : nullptr, B, m->log_off,
                            env ? m->chg_off : nullptr, D, b->log_off, env ? b->chg_off : nullptr, b->max_actors);
         PTX_TRYA(hipGetLastError());
@@ -988,6 +1014,7 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.chg_off = admit ? b->chg_off : nullptr;
     A.chg_hdr = b->chg_hdr;
     A.chg_env = b->chg_env;
+    A.chg_env_hi = b->chg_env_hi;
     A.max_actors = b->max_actors;
     A.clocks = ctx->clocks;
     A.stop_after = (uint32_t)ctx->stop_after;
@@ -1482,7 +1509,13 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
     const uint32_t lds_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, ctx->max_lds); /* larger logs report PTX_ERR_CAPACITY */
     uint16_t* d_win = nullptr;
     uint32_t* d_first = nullptr;
-    if (gwin) PTX_HIP(ctx, hipMalloc((void**)&d_win, ptx_replay_win_bytes(b->n_ops, L)));
+    if (gwin) {
+        e = hipMalloc((void**)&d_win, ptx_replay_win_bytes(b->n_ops, L));
+        if (e != hipSuccess) { /* (an early return here leaked the offsets already held by `out`, and named an out-of-memory PTX_ERR_HIP) */
+            ptx_patches_free(out);
+            return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("replay set-up (winner arrays): ") + hipGetErrorString(e));
+        }
+    }
     if (first_row) {
         e = hipMalloc((void**)&d_first, (size_t)L * 4);
         if (e == hipSuccess) e = hipMemcpyAsync(d_first, first_row, (size_t)L * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -2042,6 +2075,10 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
     PTX_TRYC(dalloc(&cap->side_b, T));
     PTX_TRYC(dalloc(&cap->chg_hdr, NC));
     PTX_TRYC(dalloc(&cap->chg_env, NC * PTX_ENV_STRIDE(na)));
+    PTX_TRYC(dalloc(&cap->chg_env_hi, NC * PTX_ENV_STRIDE(na) + 2)); /* + the "some high half is set" word behind the column */
+    uint32_t* d_wide = (uint32_t*)(cap->chg_env_hi + ((NC * PTX_ENV_STRIDE(na) + 1) & ~1ull));
+    uint32_t any_wide = 0;
+    PTX_TRYC(hipMemsetAsync(d_wide, 0, 4, ctx->stream));
     std::vector<uint32_t> rows_made(std::max<uint32_t>(L, 1)), chgs_made(std::max<uint32_t>(L, 1));
     if (L) {
         PtxChangeArgs A;
@@ -2080,6 +2117,8 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
         A.o_side_b = cap->side_b;
         A.o_chg_hdr = cap->chg_hdr;
         A.o_chg_env = cap->chg_env;
+        A.o_chg_env_hi = cap->chg_env_hi;
+        A.any_wide = d_wide;
         A.status = d_status;
         A.rows_made = d_rows;
         A.chgs_made = d_chgs;
@@ -2090,6 +2129,7 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
         PTX_TRYC(hipMemcpyAsync(status_out, d_status, (size_t)L * 4, hipMemcpyDeviceToHost, ctx->stream));
         PTX_TRYC(hipMemcpyAsync(rows_made.data(), d_rows, (size_t)L * 4, hipMemcpyDeviceToHost, ctx->stream));
         PTX_TRYC(hipMemcpyAsync(chgs_made.data(), d_chgs, (size_t)L * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PTX_TRYC(hipMemcpyAsync(&any_wide, d_wide, 4, hipMemcpyDeviceToHost, ctx->stream));
         PTX_TRYC(hipStreamSynchronize(ctx->stream));
     }
     /* the batch of what was made: failed logs contribute nothing */
@@ -2116,10 +2156,11 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
     PTX_TRYC(dalloc(&b->log_hdr, (uint64_t)L));
     PTX_TRYC(dalloc(&b->chg_hdr, b->n_changes + PTX_ENV_PAD));
     PTX_TRYC(dalloc(&b->chg_env, (b->n_changes + PTX_ENV_PAD) * PTX_ENV_STRIDE(na)));
+    if (any_wide) PTX_TRYC(dalloc(&b->chg_env_hi, (b->n_changes + PTX_ENV_PAD) * PTX_ENV_STRIDE(na))); /* some new seq / dep is beyond 16 bits */
     if (L) {
         PtxAppendCols S = {cap->op_id, cap->ref_a, cap->ref_b, cap->payload, cap->action, cap->mark_type, cap->side_a, cap->side_b,
-                           cap->chg_hdr, cap->chg_env};
-        PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_hdr, b->chg_env};
+                           cap->chg_hdr, cap->chg_env, cap->chg_env_hi};
+        PtxAppendDst D = {b->op_id, b->ref_a, b->ref_b, b->payload, b->action, b->mark_type, b->side_a, b->side_b, b->chg_hdr, b->chg_env, b->chg_env_hi};
         hipLaunchKernelGGL(ptx_take_rows_kernel, dim3(L), dim3(64), 0, ctx->stream, S, d_out_off, d_in_chg, d_rows, d_chgs, D, b->log_off, b->chg_off, na);
         PTX_TRYC(hipGetLastError());
         PTX_TRYC(hipStreamSynchronize(ctx->stream));
@@ -2138,7 +2179,7 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
 struct ptx_host_batch_store {
     std::vector<uint64_t> log_off, op_id, ref_a, ref_b, chg_off;
     std::vector<uint32_t> payload, chg_hdr;
-    std::vector<uint16_t> chg_env;
+    std::vector<uint16_t> chg_env, chg_env_hi;
     std::vector<uint8_t> action, mark_type, side_a, side_b;
     std::vector<ptx_log_hdr> hdr;
 };
@@ -2184,6 +2225,10 @@ ptx_status ptx_batch_download(ptx_ctx* ctx, const ptx_dbatch* b, ptx_host_batch*
         dl(s->chg_off.data(), b->chg_off, (L + 1) * 8);
         dl(s->chg_hdr.data(), b->chg_hdr, NC * 4);
         dl(s->chg_env.data(), b->chg_env, NC * ES * 2);
+        if (b->chg_env_hi) {
+            s->chg_env_hi.resize(std::max<uint64_t>(NC * ES, 1));
+            dl(s->chg_env_hi.data(), b->chg_env_hi, NC * ES * 2);
+        }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -2207,6 +2252,7 @@ ptx_status ptx_batch_download(ptx_ctx* ctx, const ptx_dbatch* b, ptx_host_batch*
         h.chg_off = s->chg_off.data();
         h.chg_hdr = s->chg_hdr.data();
         h.chg_env = s->chg_env.data();
+        h.chg_env_hi = b->chg_env_hi ? s->chg_env_hi.data() : nullptr;
         h.max_actors = b->max_actors;
     }
     out->owner = s;

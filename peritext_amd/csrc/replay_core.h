@@ -402,7 +402,10 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 }
             }
 #undef PTX_RANGE_BITS
-            if (S > segl) PTX_WIN_FENCE(); /* the slot list is read by other lanes than the ones that filled it */
+            /* (global winners) the slot list's tail is read by other lanes than the ones that filled it, and the per-slot loop below loads winners that an
+             * EARLIER op's other lanes stored: one wait for the wave's outstanding stores orders both (without it the second relied on same-wave
+             * store -> load ordering through the L1 alone) */
+            PTX_WIN_FENCE();
             PTX_SYNC_T();
             const uint32_t nvis = H->nvis, nc = H->ncom;
             const uint32_t cfw = (S >> 5) + 1u; /* words of the patch-opening bitmap (+1 for the total) */

@@ -31,6 +31,8 @@ def _batch_struct(b):
         s.chg_off = p(b.chg_off, abi.u64p)
         s.chg_hdr = p(b.chg_hdr, abi.u32p)
         s.chg_env = p(b.chg_env, abi.u16p)
+        if b.chg_env_hi is not None:
+            s.chg_env_hi = p(b.chg_env_hi, abi.u16p)
         s.max_actors = b.max_actors
     if b.log_hdr is not None and len(b.log_hdr):
         s.log_hdr = b.log_hdr.ctypes.data_as(C.POINTER(abi.ptx_log_hdr))
@@ -327,7 +329,8 @@ class Engine:
                 log_off, arr(b.op_id, np.uint64, T), arr(b.ref_a, np.uint64, T), arr(b.ref_b, np.uint64, T), arr(b.payload, np.uint32, T),
                 arr(b.action, np.uint8, T), arr(b.mark_type, np.uint8, T), arr(b.side_a, np.uint8, T), arr(b.side_b, np.uint8, T),
                 chg_off, arr(b.chg_hdr, np.uint32, NC) if has_env else None,
-                arr(b.chg_env, np.uint16, NC * abi.env_stride(b.max_actors)) if has_env else None, int(b.max_actors), arr(b.log_hdr, abi.LOG_HDR_DTYPE, L), values or [], urls or [], log_doc or [], doc_actors or [], doc_comments or [], keys or [], map_values or [])
+                arr(b.chg_env, np.uint16, NC * abi.env_stride(b.max_actors)) if has_env else None, int(b.max_actors), arr(b.log_hdr, abi.LOG_HDR_DTYPE, L), values or [], urls or [], log_doc or [], doc_actors or [], doc_comments or [], keys or [], map_values or [],
+                chg_env_hi=arr(b.chg_env_hi, np.uint16, NC * abi.env_stride(b.max_actors)) if has_env and bool(b.chg_env_hi) else None)
         finally:
             self.lib.ptx_host_batch_free(C.byref(hb))
 

@@ -259,6 +259,13 @@ bool read_batch(napi_env env, napi_value b, ptx_batch* out) {
             pb.chg_hdr = (const uint32_t*)ch;
             pb.chg_env = (const uint16_t*)ce;
             pb.max_actors = max_actors;
+            /* optional wide column (ptx_batch.chg_env_hi): the high halves of chgEnv's values, same shape */
+            size_t n_hi = 0;
+            const void* hi = nullptr;
+            if (column(env, b, "chgEnvHi", 2, &hi, &n_hi, true) && hi) {
+                if (n_hi != n_e) return throw_msg(env, "batch.chgEnvHi: Uint16Array of the shape of chgEnv expected"), false;
+                pb.chg_env_hi = (const uint16_t*)hi;
+            }
         }
     }
     return true;
@@ -285,6 +292,7 @@ napi_value batch_to_js(napi_env env, const ptx_batch& b) {
         {"markType", napi_uint8_array, 1, b.mark_type, T}, {"sideA", napi_uint8_array, 1, b.side_a, T}, {"sideB", napi_uint8_array, 1, b.side_b, T},
         {"logHdr", napi_uint32_array, 4, b.log_hdr, Lg * (sizeof(ptx_log_hdr) / 4)}, {"chgOff", napi_biguint64_array, 8, b.chg_off, Lg + 1},
         {"chgHdr", napi_uint32_array, 4, b.chg_hdr, NC}, {"chgEnv", napi_uint16_array, 2, b.chg_env, NC * PTX_ENV_STRIDE(b.max_actors)},
+        {"chgEnvHi", napi_uint16_array, 2, b.chg_env_hi, b.chg_env_hi ? NC * PTX_ENV_STRIDE(b.max_actors) : 0},
     };
     for (auto& col : cols) {
         if (!col.src && col.count) continue;

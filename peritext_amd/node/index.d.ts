@@ -50,6 +50,8 @@ export interface WireBatch {
     chgOff?: BigUint64Array; maxActors?: number
     /** what the device reads: chgHdr = actorRank << 20 | nops, chgEnv rows of ((1 + maxActors + 3) & ~3) u16 = seq, deps[...] */
     chgHdr?: Uint32Array; chgEnv?: Uint16Array
+    /** the wide envelope column (ptx_batch.chg_env_hi): high halves of chgEnv's values, present once some seq / dep exceeds 65534 */
+    chgEnvHi?: Uint16Array
     /** the same unpacked (filled by encodeDocs / unpackEnvelope; decodeChanges and decodePatches read these) */
     chgActor?: Uint32Array; chgSeq?: Uint32Array; chgNops?: Uint32Array; chgDeps?: Uint32Array
     values: string[]; urls: string[]; logDoc: number[]; docActors: string[][]; docComments: string[][]

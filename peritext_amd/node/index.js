@@ -41,16 +41,27 @@ const CHG_ACTOR_SHIFT = 20, CHG_NOPS = 0x000fffff, ENV_SATURATED = 65535
 const envStride = maxActors => (1 + maxActors + 3) & ~3 /* PTX_ENV_STRIDE */
 
 /** chgActor / chgSeq / chgNops / chgDeps -> the packed envelope the device reads: chgHdr = actor << 20 | nops, chgEnv rows of
- *  envStride(maxActors) u16 = seq, deps[...] (values saturate at 65535: such a change can never be admitted). */
+ *  envStride(maxActors) u16 = seq, deps[...].  While every value is at most 65534 that is all; once some seq / dep is larger (seq and deps are
+ *  plain numbers in the reference, micromerge.ts:499-511: one change per keystroke passes 65535) the values are split exactly into chgEnv
+ *  (low halves) and chgEnvHi (high halves) — ptx_batch.chg_env_hi of include/peritext_hip.h. */
 function packEnvelope(batch) {
     const n = batch.chgActor.length, es = envStride(batch.maxActors)
     batch.chgHdr = new Uint32Array(n)
     batch.chgEnv = new Uint16Array(n * es)
+    delete batch.chgEnvHi
+    let top = 0
+    for (let c = 0; c < n; c++) top = Math.max(top, batch.chgSeq[c])
+    for (let i = 0; i < batch.chgDeps.length; i++) top = Math.max(top, batch.chgDeps[i])
+    const wide = top >= ENV_SATURATED
+    if (wide) batch.chgEnvHi = new Uint16Array(n * es)
     for (let c = 0; c < n; c++) {
         if (batch.chgActor[c] > 4095 || batch.chgNops[c] > CHG_NOPS) throw new RangeError("a document has at most 4096 actors and a change at most " + CHG_NOPS + " ops")
         batch.chgHdr[c] = ((batch.chgActor[c] << CHG_ACTOR_SHIFT) | batch.chgNops[c]) >>> 0
-        batch.chgEnv[c * es] = Math.min(batch.chgSeq[c], ENV_SATURATED)
-        for (let a = 0; a < batch.maxActors; a++) batch.chgEnv[c * es + 1 + a] = Math.min(batch.chgDeps[c * batch.maxActors + a], ENV_SATURATED)
+        for (let k = 0; k <= batch.maxActors; k++) {
+            const v = k === 0 ? batch.chgSeq[c] : batch.chgDeps[c * batch.maxActors + k - 1]
+            batch.chgEnv[c * es + k] = v & 0xffff
+            if (wide) batch.chgEnvHi[c * es + k] = v >>> 16
+        }
     }
     return batch
 }
@@ -64,8 +75,9 @@ function unpackEnvelope(batch) {
     for (let c = 0; c < n; c++) {
         batch.chgActor[c] = batch.chgHdr[c] >>> CHG_ACTOR_SHIFT
         batch.chgNops[c] = batch.chgHdr[c] & CHG_NOPS
-        batch.chgSeq[c] = batch.chgEnv[c * es]
-        for (let a = 0; a < batch.maxActors; a++) batch.chgDeps[c * batch.maxActors + a] = batch.chgEnv[c * es + 1 + a]
+        const hi = batch.chgEnvHi && batch.chgEnvHi.length ? batch.chgEnvHi : null
+        batch.chgSeq[c] = (batch.chgEnv[c * es] | (hi ? hi[c * es] << 16 : 0)) >>> 0
+        for (let a = 0; a < batch.maxActors; a++) batch.chgDeps[c * batch.maxActors + a] = (batch.chgEnv[c * es + 1 + a] | (hi ? hi[c * es + 1 + a] << 16 : 0)) >>> 0
     }
     return batch
 }
@@ -752,6 +764,20 @@ class MergeEngine {
             if (change.seq !== last + 1) throw new RangeError("Expected sequence number " + (last + 1) + ", got " + change.seq)
             for (const a of Object.keys(change.deps || {}))
                 if (!rep.clock[a] || rep.clock[a] < change.deps[a]) throw new RangeError("Missing dependency: change " + change.deps[a] + " by actor " + a)
+            /* a list op must name the document's text list (the encoder's rule, encodeDocs): checked HERE, before the replica changes, so that a bad
+             * Change is refused once — like the reference's RangeError("Object does not exist") out of applyChange (micromerge.ts:538) — and the replica
+             * stays readable (ADVICE r3: thrown later, by every re-encode of the queued Change, it made the replica unreadable for good) */
+            let textObj = rep.textObj === undefined ? null : rep.textObj
+            for (const op of change.ops || []) {
+                const onRoot = op.obj === undefined || op.obj === null || op.obj === ROOT || typeof op.obj === "symbol"
+                if (op.action === "makeList" && onRoot && op.key === "text" && textObj === null) textObj = op.opId
+                else if (textObj !== null && op.obj === textObj) {
+                    if (op.action === "set" && op.insert && typeof op.value !== "string") throw new Error("Expected value inserted into text to be a string")
+                } else if (op.key !== undefined && op.elemId === undefined && ["set", "del", "makeMap", "makeList"].indexOf(op.action) >= 0) continue
+                else if (op.action === "addMark" || op.action === "removeMark" || op.elemId !== undefined || op.insert)
+                    throw new RangeError("Object does not exist: list op " + String(op.opId) + " on an object that is not the document's text list (one text list per document is supported)")
+            }
+            rep.textObj = textObj
             rep.clock[change.actor] = change.seq
             rep.changes.push(change)
             rep.spans = null

@@ -68,6 +68,8 @@ class Batch:
     doc_comments: list = field(default_factory=list)  # doc -> [comment id strings in rank order]
     keys: list = field(default_factory=list)  # key id -> string (keys of the map objects: PTX_ACT_MAPSET / MAPDEL / MAKELIST rows, ref_b)
     map_values: list = field(default_factory=list)  # value id -> JSON text of the value a PTX_ACT_MAPSET row sets
+    # the wide envelope column (ptx_batch.chg_env_hi): high halves of chg_env's values, None while every seq / dep fits 16 bits
+    chg_env_hi: np.ndarray = None
 
     @property
     def n_logs(self):
@@ -84,12 +86,17 @@ class Batch:
 
     @property
     def chg_seq(self):
-        return self.chg_env.reshape(-1, abi.env_stride(self.max_actors))[:, 0].astype(np.uint32)
+        return self._env32().reshape(-1, abi.env_stride(self.max_actors))[:, 0]
 
     @property
     def chg_deps(self):
         """[n_changes, max_actors]"""
-        return self.chg_env.reshape(-1, abi.env_stride(self.max_actors))[:, 1:1 + self.max_actors].astype(np.uint32)
+        return self._env32().reshape(-1, abi.env_stride(self.max_actors))[:, 1:1 + self.max_actors]
+
+    def _env32(self):
+        """The envelope's values as u32: exact with the wide column, else the 16-bit column (saturated at 65 535)."""
+        v = self.chg_env.astype(np.uint32)
+        return v if self.chg_env_hi is None else v | (self.chg_env_hi.astype(np.uint32) << np.uint32(16))
 
     @property
     def n_ops(self):
@@ -108,15 +115,17 @@ class Batch:
         rep = lambda a: np.tile(a, copies)  # noqa: E731
         if self.chg_off is None:  # a batch without the Change envelope (e.g. downloaded from a wrapped device batch)
             chg_off = chg_hdr = chg_env = None
+            chg_env_hi = None
         else:
             nc = int(self.chg_off[-1])
             chg_off = np.concatenate([self.chg_off[:-1] + k * nc for k in range(copies)] + [np.array([copies * nc], dtype=np.uint64)]).astype(np.uint64)
             chg_hdr, chg_env = rep(self.chg_hdr), rep(self.chg_env)
+            chg_env_hi = None if self.chg_env_hi is None else rep(self.chg_env_hi)
         hdr = None if self.log_hdr is None else np.tile(self.log_hdr, copies)
         return Batch(
             log_off, rep(self.op_id), rep(self.ref_a), rep(self.ref_b), rep(self.payload), rep(self.action),
             rep(self.mark_type), rep(self.side_a), rep(self.side_b), chg_off, chg_hdr, chg_env, self.max_actors, hdr, self.values, self.urls,
-            self.log_doc * copies, self.doc_actors, self.doc_comments, keys=self.keys, map_values=self.map_values,
+            self.log_doc * copies, self.doc_actors, self.doc_comments, keys=self.keys, map_values=self.map_values, chg_env_hi=chg_env_hi,
         )
 
 
@@ -162,6 +171,26 @@ def pack_envelope(actor, seq, nops, deps, max_actors):
         env[:, 0] = np.minimum(np.asarray(seq, dtype=np.uint64), abi.ENV_SATURATED).astype(np.uint16)
         env[:, 1:1 + max_actors] = np.minimum(np.asarray(deps, dtype=np.uint64).reshape(len(actor), max_actors), abi.ENV_SATURATED).astype(np.uint16)
     return hdr, env.reshape(-1)
+
+
+def pack_envelope_wide(actor, seq, nops, deps, max_actors):
+    """(chg_hdr, chg_env, chg_env_hi): as pack_envelope while every seq / dep is at most 65 534 (chg_env_hi = None); otherwise the
+    values are split EXACTLY into low and high halves (include/peritext_hip.h ptx_batch.chg_env_hi) — seq / deps are plain numbers in
+    the reference (micromerge.ts:499-511), a replica that made one change per keystroke passes 65 535."""
+    seq = np.asarray(seq, dtype=np.uint64)
+    deps = np.asarray(deps, dtype=np.uint64).reshape(len(seq), max_actors)
+    top = max(int(seq.max()) if len(seq) else 0, int(deps.max()) if deps.size else 0)
+    if top < abi.ENV_SATURATED:
+        hdr, env = pack_envelope(actor, seq, nops, deps, max_actors)
+        return hdr, env, None
+    if top > 0xFFFFFFFF:
+        raise ValueError("seq / deps beyond 32 bits")
+    hdr, _ = pack_envelope(actor, np.zeros(len(seq), np.uint64), nops, np.zeros_like(deps), max_actors)
+    es = abi.env_stride(max_actors)
+    v = np.zeros((len(seq), es), dtype=np.uint32)
+    v[:, 0] = seq
+    v[:, 1:1 + max_actors] = deps
+    return hdr, (v & np.uint32(0xFFFF)).astype(np.uint16).reshape(-1), (v >> np.uint32(16)).astype(np.uint16).reshape(-1)
 
 
 def _pack(ctr, rank):
@@ -301,7 +330,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
         for a, v in row.items():
             deps[i, a] = v
     u64 = lambda x: np.asarray(x, dtype=np.uint64)  # noqa: E731
-    chg_hdr, chg_env = pack_envelope(chg_actor, chg_seq, chg_nops, deps, max_actors)
+    chg_hdr, chg_env, chg_env_hi = pack_envelope_wide(chg_actor, chg_seq, chg_nops, deps, max_actors)
     hdr = census(u64(log_off), u64(cols["op_id"]), np.asarray(cols["action"], dtype=np.uint8), np.asarray(cols["mark_type"], dtype=np.uint8),
                  np.asarray(cols["payload"], dtype=np.uint32))
     return Batch(
@@ -311,7 +340,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
         mark_type=np.asarray(cols["mark_type"], dtype=np.uint8), side_a=np.asarray(cols["side_a"], dtype=np.uint8),
         side_b=np.asarray(cols["side_b"], dtype=np.uint8), chg_off=u64(chg_off),
         chg_hdr=chg_hdr, chg_env=chg_env, max_actors=max_actors,
-        values=values, urls=urls, log_doc=log_doc, doc_actors=doc_actors, doc_comments=doc_comments, keys=keys, map_values=mvals,
+        values=values, urls=urls, log_doc=log_doc, doc_actors=doc_actors, doc_comments=doc_comments, keys=keys, map_values=mvals, chg_env_hi=chg_env_hi,
     )
 
 
@@ -571,7 +600,8 @@ def split_batch(batch, first_changes):
             np.asarray(rows[part], dtype=np.uint64), batch.op_id[ridx], batch.ref_a[ridx], batch.ref_b[ridx], batch.payload[ridx], batch.action[ridx],
             batch.mark_type[ridx], batch.side_a[ridx], batch.side_b[ridx], np.asarray(chgs[part], dtype=np.uint64), batch.chg_hdr[cidx],
             batch.chg_env.reshape(-1, abi.env_stride(batch.max_actors))[cidx].reshape(-1), batch.max_actors, None,
-            batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments))
+            batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments,
+            chg_env_hi=None if batch.chg_env_hi is None else batch.chg_env_hi.reshape(-1, abi.env_stride(batch.max_actors))[cidx].reshape(-1)))
     return out[0], out[1]
 
 
@@ -807,7 +837,7 @@ def get_cursor(batch, res, log, index):
 
 # ---- on-disk form of a batch (SURVEY.md §5 "checkpoint / resume": the reference only has JSON.stringify dumps of
 # Change objects, test/fuzz.ts:16-20; replaying a saved op log = re-running the merge) ----
-_COLUMNS = ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_hdr", "chg_env")
+_COLUMNS = ("log_off", "op_id", "ref_a", "ref_b", "payload", "action", "mark_type", "side_a", "side_b", "chg_off", "chg_hdr", "chg_env", "chg_env_hi")
 
 
 def save_batch(path, batch):

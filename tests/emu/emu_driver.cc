@@ -66,6 +66,7 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     A.chg_off = admission ? b->chg_off : nullptr;
     A.chg_hdr = b->chg_hdr;
     A.chg_env = b->chg_env;
+    A.chg_env_hi = b->chg_env_hi;
     A.max_actors = b->max_actors;
     A.clocks = nullptr;
     A.stop_after = 0;
@@ -121,6 +122,7 @@ extern "C" int ptx_emu_merge_big(const ptx_batch* b, ptx_log_result* res, uint32
     A.chg_off = admission ? b->chg_off : nullptr;
     A.chg_hdr = b->chg_hdr;
     A.chg_env = b->chg_env;
+    A.chg_env_hi = b->chg_env_hi;
     A.max_actors = b->max_actors;
     A.res = res;
     A.out_values = values;
@@ -245,7 +247,8 @@ extern "C" int ptx_emu_generate(PtxGenArgs* A, int reverse) {
  * the caller allocates the capacity-layout output (out_off = rows per log, known from the InputOperations) */
 extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const ptx_input_ops* in, const uint64_t* out_off, uint64_t* o_op_id,
                               uint64_t* o_ref_a, uint64_t* o_ref_b, uint32_t* o_payload, uint8_t* o_action, uint8_t* o_mark_type, uint8_t* o_side_a, uint8_t* o_side_b,
-                              uint32_t* o_chg_hdr, uint16_t* o_chg_env, uint32_t* status, uint32_t* rows_made, uint32_t* chgs_made, uint32_t lds_bytes, int reverse) {
+                              uint32_t* o_chg_hdr, uint16_t* o_chg_env, uint16_t* o_chg_env_hi, uint32_t* any_wide, uint32_t* status, uint32_t* rows_made, uint32_t* chgs_made,
+                              uint32_t lds_bytes, int reverse) {
     PtxChangeArgs A;
     memset(&A, 0, sizeof(A));
     A.log_off = b->log_off;
@@ -281,6 +284,8 @@ extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, con
     A.o_side_b = o_side_b;
     A.o_chg_hdr = o_chg_hdr;
     A.o_chg_env = o_chg_env;
+    A.o_chg_env_hi = o_chg_env_hi;
+    A.any_wide = any_wide;
     A.status = status;
     A.rows_made = rows_made;
     A.chgs_made = chgs_made;

@@ -109,6 +109,8 @@ def batch_struct(b):
         s.chg_off = ptr(b.chg_off, abi.u64p)
         s.chg_hdr = ptr(b.chg_hdr, abi.u32p)
         s.chg_env = ptr(b.chg_env, abi.u16p)
+        if b.chg_env_hi is not None:
+            s.chg_env_hi = ptr(b.chg_env_hi, abi.u16p)
         s.max_actors = b.max_actors
     if b.log_hdr is not None and len(b.log_hdr):
         s.log_hdr = b.log_hdr.ctypes.data_as(C.POINTER(abi.ptx_log_hdr))
@@ -276,7 +278,8 @@ def made_batch(batch, ops, cols, env, rows_made, chgs_made, out_off):
     chg_off[1:] = np.cumsum(chgs_made[:n_logs].astype(np.uint64))
     return wire.Batch(log_off, cols["op_id"][keep], cols["ref_a"][keep], cols["ref_b"][keep], cols["payload"][keep], cols["action"][keep], cols["mark_type"][keep],
                       cols["side_a"][keep], cols["side_b"][keep], chg_off, env["chg_hdr"][ckeep], env["chg_env"].reshape(-1, abi.env_stride(na))[ckeep].reshape(-1),
-                      na, None, batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments, batch.keys, batch.map_values)
+                      na, None, batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments, batch.keys, batch.map_values,
+                      chg_env_hi=env["chg_env_hi"].reshape(-1, abi.env_stride(na))[ckeep].reshape(-1) if env.get("any_wide") is not None and int(env["any_wide"][0]) else None)
 
 
 def emu_change(batch, res, ops, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB):
@@ -287,14 +290,15 @@ def emu_change(batch, res, ops, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB
     T, NC, na = max(int(out_off[-1]), 1), max(int(ops.chg_off[-1]), 1), ops.max_actors
     cols = {"op_id": np.zeros(T, np.uint64), "ref_a": np.zeros(T, np.uint64), "ref_b": np.zeros(T, np.uint64), "payload": np.zeros(T, np.uint32),
             "action": np.zeros(T, np.uint8), "mark_type": np.zeros(T, np.uint8), "side_a": np.zeros(T, np.uint8), "side_b": np.zeros(T, np.uint8)}
-    env = {"chg_hdr": np.zeros(NC, np.uint32), "chg_env": np.zeros(NC * abi.env_stride(na), np.uint16)}
+    env = {"chg_hdr": np.zeros(NC, np.uint32), "chg_env": np.zeros(NC * abi.env_stride(na), np.uint16), "chg_env_hi": np.zeros(NC * abi.env_stride(na), np.uint16),
+           "any_wide": np.zeros(1, np.uint32)}
     status, rows_made, chgs_made = (np.zeros(max(n_logs, 1), np.uint32) for _ in range(3))
     lib = C.CDLL(lib_path)
     lib.ptx_emu_change.restype = C.c_int
     s, si = batch_struct(batch), input_ops_struct(ops)
     vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
     rc = lib.ptx_emu_change(C.byref(s), vp(res.logs), vp(res.elem_rank), C.byref(si), vp(out_off), vp(cols["op_id"]), vp(cols["ref_a"]), vp(cols["ref_b"]), vp(cols["payload"]),
-                            vp(cols["action"]), vp(cols["mark_type"]), vp(cols["side_a"]), vp(cols["side_b"]), vp(env["chg_hdr"]), vp(env["chg_env"]), vp(status), vp(rows_made), vp(chgs_made), C.c_uint32(lds_bytes), C.c_int(reverse))
+                            vp(cols["action"]), vp(cols["mark_type"]), vp(cols["side_a"]), vp(cols["side_b"]), vp(env["chg_hdr"]), vp(env["chg_env"]), vp(env["chg_env_hi"]), vp(env["any_wide"]), vp(status), vp(rows_made), vp(chgs_made), C.c_uint32(lds_bytes), C.c_int(reverse))
     assert rc == 0
     return made_batch(batch, ops, cols, env, rows_made, chgs_made, out_off), status[:n_logs]
 
@@ -361,14 +365,13 @@ def concat_batches(base, more):
         out = []
         for src, a, b in parts:
             x = base if src == "b" else more
-            out.append(wire.pack_envelope(x.chg_actor[a:b], x.chg_seq[a:b], x.chg_nops[a:b],
-                                          np.pad(x.chg_deps[a:b], ((0, 0), (0, na - x.max_actors))) if b > a else np.zeros((0, na), np.uint32), na))
-        return np.concatenate([h for h, _ in out]).astype(np.uint32), np.concatenate([e for _, e in out]).astype(np.uint16)
+            out.append((x.chg_actor[a:b], x.chg_seq[a:b], x.chg_nops[a:b], np.pad(x.chg_deps[a:b], ((0, 0), (0, na - x.max_actors))) if b > a else np.zeros((0, na), np.uint32)))
+        return wire.pack_envelope_wide(*(np.concatenate([o[k] for o in out]) for k in range(4)), na)
 
-    hdr, env = cat_env(chgs)
+    hdr, env, env_hi = cat_env(chgs)
     return wire.Batch((base.log_off + more.log_off).astype(np.uint64), cat("op_id", rows), cat("ref_a", rows), cat("ref_b", rows), cat("payload", rows), cat("action", rows),
                       cat("mark_type", rows), cat("side_a", rows), cat("side_b", rows), (base.chg_off + more.chg_off).astype(np.uint64), hdr, env, na, None,
-                      base.values, base.urls, base.log_doc, base.doc_actors, base.doc_comments, base.keys, base.map_values)
+                      base.values, base.urls, base.log_doc, base.doc_actors, base.doc_comments, base.keys, base.map_values, chg_env_hi=env_hi)
 
 
 def mini_doc(ops_second_change, first_text="ABCDE"):

@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(abi.ptx_span) == 8 and abi.SPAN_DTYPE.itemsize == 8
     assert C.sizeof(abi.ptx_cinterval) == 12 and abi.CINTERVAL_DTYPE.itemsize == 12
     assert C.sizeof(abi.ptx_log_result) == 48 and abi.LOG_RESULT_DTYPE.itemsize == 48
-    assert C.sizeof(abi.ptx_batch) == 8 + 8 + 12 * 8 + 8 + 8
+    assert C.sizeof(abi.ptx_batch) == 8 + 8 + 12 * 8 + 8 + 8 + 8  # + chg_env_hi (ABI 6)
     assert C.sizeof(abi.ptx_log_hdr) == 40 and abi.LOG_HDR_DTYPE.itemsize == 40
     assert C.sizeof(abi.ptx_result) == 8 + 8 + 6 * 8
 

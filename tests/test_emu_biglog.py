@@ -4,6 +4,7 @@ reference) check its logic in all three loop orders, the error cases check that 
 like the LDS kernel, and two large documents (one insert/delete-heavy, one all-marks) that the LDS kernel refuses are compared with the
 oracle.  Matches the unbounded arrays of reference/src/micromerge.ts:614-672."""
 import copy
+import dataclasses
 import json
 import os
 
@@ -148,3 +149,81 @@ def test_all_marks_document_of_20000_ops():
     if int(small.logs["status"][0]) == 0:
         assert (small.logs["digest"] == res.logs["digest"]).all()
     assert int(res.logs["n_cintervals"][0]) > 50 and int(res.logs["n_spans"][0]) > 200
+
+
+# ---- seq / deps beyond 16 bits: the wide envelope column ----
+def _typed_log(n_changes, actor="a", first_ctr=1, make_list=True, deps_of=None, seq0=1):
+    """One change per keystroke (what bridge.ts:535 produces): change 1 makes the list, every further one inserts one character at the head
+    (cheap for the reference: no element search).  deps_of(k) -> deps of the k-th change."""
+    log, ctr = [], first_ctr
+    for k in range(n_changes):
+        if k == 0 and make_list:
+            ops = [{"opId": "%d@%s" % (ctr, actor), "action": "makeList", "obj": "_root", "key": "text"}]
+        else:
+            ops = [{"opId": "%d@%s" % (ctr, actor), "action": "set", "obj": "1@a", "elemId": "_head", "insert": True, "value": chr(97 + k % 26)}]
+        log.append({"actor": actor, "seq": seq0 + k, "deps": deps_of(k) if deps_of else {}, "startOp": ctr, "ops": ops})
+        ctr += 1
+    return log
+
+
+def wide_envelope_docs(only=None):
+    """(i) 70 001 one-op changes of one actor; (ii) two actors, the second one's deps cross 65 535 — valid, and with a dependency one too far;
+    (iii) a genuine sequence gap past change 65 535; (iv) the same sequence number twice past 65 535.  `only`: just these documents."""
+    want = lambda k: only is None or k in only  # noqa: E731
+    out = {}
+    single = _typed_log(70001) if any(want(k) for k in ("single", "seq_gap", "seq_twice")) else None
+    if want("single"):
+        out["single"] = [single]
+    if want("deps_cross") or want("dep_missing"):
+        a_part = _typed_log(66000)
+        b_ok = _typed_log(3, actor="b", first_ctr=66001, make_list=False, deps_of=lambda k: {"a": 66000})
+        if want("deps_cross"):
+            out["deps_cross"] = [a_part + b_ok]
+        if want("dep_missing"):
+            b_far = copy.deepcopy(b_ok)
+            b_far[1]["deps"] = {"a": 66001}
+            out["dep_missing"] = [a_part + b_far]
+    if want("seq_gap"):
+        gap = [dict(ch) for ch in single[:66010]]
+        for ch in gap[66000:]:
+            ch["seq"] += 1
+        out["seq_gap"] = [gap]
+    if want("seq_twice"):
+        twice = [dict(ch) for ch in single[:66010]]
+        twice[66005]["seq"] = twice[66004]["seq"]
+        out["seq_twice"] = [twice]
+    return out
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_logs_with_more_than_65535_changes_against_the_reference():
+    """A valid log typed as one change per keystroke passes 65 535 changes of one actor (reference/src/micromerge.ts:499-511 takes plain numbers).
+    The encoders then emit the wide envelope column and the HBM-staged kernel admits every change; failing logs past 65 535 still name the
+    reference's error and the row it throws at; without the column such a log is PTX_ERR_CAPACITY, never a spurious sequence gap."""
+    docs = wide_envelope_docs()
+    names = list(docs)
+    batch = wire.encode_docs([docs[k] for k in names])
+    assert batch.chg_env_hi is not None and int(batch.chg_seq.max()) == 70001
+    exp = H.oracle_apply([docs[k] for k in names], impl="ref", no_patches=True, timeout=900)
+    for reverse in (0, 1):
+        res = H.emu_merge_big(batch, reverse=reverse, admission=True)
+        for log, k in enumerate(names):
+            e = exp[log][0]
+            st, row = int(res.logs["status"][log]), int(res.logs["reserved"][log, 1])
+            if k in ("single", "deps_cross"):
+                assert "error" not in e and st == 0, (k, st, row)
+                H.check_log(batch, res, log, e)
+            elif k == "dep_missing":
+                assert "Missing dependency" in e["error"] and st == abi.ERR_MISSING_DEP and row == 66001, (k, st, row, e["error"])
+            else:
+                assert "Expected sequence number" in e["error"] and st == abi.ERR_SEQ_GAP and row == (66000 if k == "seq_gap" else 66005), (k, st, row, e["error"])
+    assert int(res.logs["n_visible"][0]) == 70000
+    # the same batch without the wide column (what an ABI-5 encoder would have sent: values saturated at 65 535): not representable
+    es = abi.env_stride(batch.max_actors)
+    sat = np.minimum(batch.chg_seq.astype(np.uint64), 65535)
+    narrow = dataclasses.replace(batch, chg_env=batch.chg_env.copy(), chg_env_hi=None)
+    narrow.chg_env.reshape(-1, es)[:, 0] = sat.astype(np.uint16)
+    r = H.emu_merge_big(narrow, admission=True)
+    assert (r.logs["status"] == abi.ERR_CAPACITY).all()
+    # without admission nothing reads the envelope
+    assert (H.emu_merge_big(narrow, admission=False).logs["status"] == 0).all()

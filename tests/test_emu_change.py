@@ -119,3 +119,25 @@ def test_change_on_generated_replicas_matches_the_oracle():
             got = wire.decode_changes(made, log, text_obj=CS.text_obj_of(logs[r]))
             assert CS.norm_change(got[0]) == CS.norm_change(want[log]), (d, r)
             log += 1
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_change_on_a_replica_past_65535_changes():
+    """seq = clock + 1 and deps = the clock are plain numbers (micromerge.ts:314-327): a replica that has made 65 600 changes (most of them empty:
+    change() with no ops still bumps seq) makes change 65 601 with the exact values — the made batch then carries the wide column.
+    Expected: the type-erased reference's own change()."""
+    log = [H.mini_doc([])[0]] + [{"actor": "a", "seq": k, "deps": {}, "startOp": 7, "ops": []} for k in range(2, 65601)]
+    batch = wire.encode_docs([[log]])
+    assert batch.chg_env_hi is not None
+    calls = [[[{"path": ["text"], "action": "insert", "index": 2, "values": ["x", "y"]}], [{"path": ["text"], "action": "addMark", "markType": "strong", "startIndex": 1, "endIndex": 4}]]]
+    want = H.oracle_change([[log]], calls, ["a"], impl="ref")
+    ops = wire.encode_input_ops(batch, calls, ["a"])
+    res = H.emu_merge(batch, admission=False)  # (admission of such a log is the HBM-staged kernel's: tests/test_emu_biglog.py)
+    made, status = H.emu_change(batch, res, ops)
+    assert int(status[0]) == 0 and made.chg_env_hi is not None
+    got = wire.decode_changes(made, 0, text_obj="1@a")
+    assert [c["seq"] for c in got] == [65601, 65602] and got == want
+    # ... and the replica after the two changes is admitted by the HBM-staged kernel
+    after = H.concat_batches(batch, made)
+    r = H.emu_merge_big(after, admission=True)
+    assert int(r.logs["status"][0]) == 0 and int(r.logs["n_visible"][0]) == 7

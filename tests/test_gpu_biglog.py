@@ -78,3 +78,54 @@ def test_a_failing_large_log_names_the_error_and_the_row(eng):
     res = eng.apply_materialize(batch)
     assert [int(x) for x in res.logs["status"]] == [abi.ERR_ELEM_NOT_FOUND, abi.ERR_SEQ_GAP, 0]
     assert int(res.logs["reserved"][0, 1]) == row and int(res.logs["reserved"][1, 1]) == row2
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_logs_with_more_than_65535_changes(eng):
+    """seq / deps are plain numbers in the reference (micromerge.ts:499-511); a replica typed as one change per keystroke passes 65 535
+    changes of one actor.  Through the C ABI: the wide envelope column goes up with the batch, the census sends these logs to the HBM-staged kernel, every
+    change is admitted; failing logs past 65 535 name the reference's error and the row; an ordinary document in the same batch keeps the LDS kernel; a
+    resident log that CROSSES 65 535 changes by ptx_batch_append stays valid.  Expected values: the type-erased reference itself."""
+    from test_emu_biglog import wide_envelope_docs
+
+    docs = wide_envelope_docs()
+    names = list(docs)
+    small = _load("ptxgen_mini.json")
+    all_docs = [docs[k] for k in names] + [d["logs"] for d in small["docs"]]
+    exp = H.oracle_apply([docs[k] for k in names], impl="ref", no_patches=True, timeout=900) + [d["expected"] for d in small["docs"]]
+    batch = wire.encode_docs(all_docs)
+    assert batch.chg_env_hi is not None
+    res = eng.apply_materialize(batch)
+    want = {"single": (0, None), "deps_cross": (0, None), "dep_missing": (abi.ERR_MISSING_DEP, 66001), "seq_gap": (abi.ERR_SEQ_GAP, 66000), "seq_twice": (abi.ERR_SEQ_GAP, 66005)}
+    for log, k in enumerate(names):
+        st, row = want[k]
+        assert int(res.logs["status"][log]) == st, (k, int(res.logs["status"][log]), int(res.logs["reserved"][log, 1]))
+        assert ("error" in exp[log][0]) == (st != 0)
+        if st == 0:
+            H.check_log(batch, res, log, exp[log][0])
+        else:
+            assert int(res.logs["reserved"][log, 1]) == row
+    log = len(names)
+    for d in exp[len(names):]:
+        for e in d:
+            H.check_log(batch, res, log, e)
+            assert int(res.logs["reserved"][log, 0]) > 0  # the ordinary logs took the LDS kernel
+            log += 1
+    # streaming append across the 16-bit line: 65 000 changes resident, 5 001 more arrive (their seqs need the wide column, the base had none)
+    single = docs["single"][0]
+    head, tail = wire.encode_docs([[single[:65000]]]), wire.encode_docs([[single[65000:]]], text_objs=["1@a"])
+    assert head.chg_env_hi is None and tail.chg_env_hi is not None
+    db = eng.upload(head)
+    db2 = eng.append(db, tail)
+    dr = eng.alloc_result(db2)
+    try:
+        eng.merge(db2, dr)
+        logs = eng.download_logs(dr, 1)
+        back = eng.download_batch(db2)
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db2)
+        eng.free_batch(db)
+    assert int(logs["status"][0]) == 0 and int(logs["n_visible"][0]) == 70000
+    assert (logs["digest"][0] == res.logs["digest"][0]).all()
+    assert back.chg_env_hi is not None and (back.chg_seq == np.arange(1, 70002)).all()

@@ -59,6 +59,25 @@ def test_js_encoder_matches_python_encoder(name):
 
 
 @needs_node
+def test_js_encoder_matches_python_encoder_past_65535_changes(tmp_path):
+    """The wide envelope column (ptx_batch.chg_env_hi): a log of 66 003 one-op changes of two actors, the second one's deps beyond 16 bits — both encoders
+    split seq / deps into the same low and high halves; a batch whose values all fit 16 bits carries no such column from either."""
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    from test_emu_biglog import wide_envelope_docs
+
+    docs = [wide_envelope_docs(only=("deps_cross",))["deps_cross"], [H.mini_doc([])]]
+    p = tmp_path / "wide.json"
+    p.write_text(json.dumps({"docs": [{"logs": logs} for logs in docs]}))
+    js = _node("encode", str(p))
+    b = wire.encode_docs(docs)
+    assert b.chg_env_hi is not None and int(b.chg_deps.max()) == 66000
+    for k, a in {"chgSeq": b.chg_seq, "chgDeps": b.chg_deps, "chgHdr": b.chg_hdr, "chgEnv": b.chg_env, "chgEnvHi": b.chg_env_hi}.items():
+        assert js[k] == sha(a), k
+    p.write_text(json.dumps({"docs": [{"logs": docs[1]}]}))
+    assert _node("encode", str(p))["chgEnvHi"] is None and wire.encode_docs([docs[1]]).chg_env_hi is None
+
+
+@needs_node
 def test_js_encoder_matches_python_encoder_on_map_ops(tmp_path):
     """Ops on the root map and nested maps (PTX_ACT_MAPSET / MAPDEL rows, key and value tables): JS == Python."""
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
@@ -162,6 +181,14 @@ def test_resident_replica_bookkeeping_of_the_js_host():
     assert out["ok"] and out["uploads"] == out["docs"] and out["appends"] > 100 and out["rowsUploaded"] == out["rows"]
     out = _node("resident-mock", os.path.join(H.GOLDEN, "patches_mini.json"))  # (here some actors show up late: those documents are encoded a second time)
     assert out["ok"] and out["uploads"] <= 2 * out["docs"] and out["rowsUploaded"] < 1.2 * out["rows"]
+
+
+@needs_node
+def test_a_list_op_outside_the_text_list_is_refused_by_apply_change_and_leaves_the_replica_usable():
+    """the one-text-list check runs inside applyChange's admission, before the replica is touched — the reference throws out of
+    applyChange (micromerge.ts:538) and leaves the replica usable; queued and thrown by every later encode it made the replica unreadable."""
+    out = _node("admit-mock")
+    assert out["ok"] and out["thrown"] == 4
 
 
 @pytest.mark.gpu
@@ -290,3 +317,12 @@ def test_prosemirror_doc_against_the_fixture_derived_from_the_reference_schema()
     assert _node("pmdoc", name) == want
     joined = [c for c in g["cases"] if c["spans"] and c["spans"][0]["marks"] == {"comment": []}][0]["doc"]
     assert [n["text"] for n in joined["content"][0]["content"]] == ["abcd", "e"]
+
+
+@needs_node
+def test_index_d_ts_matches_index_js():
+    """no tsc in the image, index.d.ts is hand-written — every export, MergeEngine method and ReplicaHandle member it declares exists in
+    index.js and the declared parameter counts fit the implementation's arity."""
+    out = _node("dts")
+    assert out["ok"], out["problems"]
+    assert out["checked"] >= 45
