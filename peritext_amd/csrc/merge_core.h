@@ -64,7 +64,11 @@
 #ifndef PTX_UB
 #define PTX_UB 2u /* mark ops per thread and step in the LWW pass P5b (one opId gather each, issued together) */
 #endif
-#define PTX_NCLK 16
+#define PTX_NCLK 32 /* phase stamps of the diagnostic build (slot PTX_CLK_EXACT_WALKS counts the logs whose admission was walked twice) */
+#define PTX_CLK_EXACT_WALKS 15
+#ifndef PTX_UV
+#define PTX_UV 8 /* items per thread and step in the loops that are chains of dependent LDS reads per item (tree order, list ranking, unpark): the chains of a step run side by side */
+#endif
 
 /* the machine: gfx950.  (The CPU test-suite compiles these sources against a header of its own that plays the workgroup with one host
  * thread: its driver names that header in PTX_PLATFORM_HEADER before it includes this file; nothing in csrc/ knows where it lives.) */
@@ -273,15 +277,12 @@ PTX_HD uint64_t ptx_overflow4(uint64_t free_bytes, uint64_t s0, uint64_t s1, uin
 PTX_HD uint64_t ptx_overflow3(uint64_t free_bytes, uint64_t s0, uint64_t s1, uint64_t s2) { return ptx_overflow4(free_bytes, s0, s1, s2, 0); }
 PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) {
     (void)N;
+    (void)D; /* the row list of the deletes lives in HBM (the park), like the mark ops' between P1 and P5 */
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
     const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P5a */
-    const uint64_t mlist_b = ptx_a16(2 * (K + 1)), mpark = mlist_b; /* parked: part of P1's and P5's scratch instead of the persistent state */
-    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + (mlist_b - mpark) + ptx_a16(4 * (K / 32 + 1)) + elem;
-    const uint64_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
-    const uint64_t lists = ptx_a16(2 * (n + 1)) + ptx_a16(2 * l_len);
-    const uint64_t p1 = lists + 16 + mpark; /* + the dump of the unlisted rows */
-    const uint64_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
-    const uint64_t p3 = lists + ptx_a16(4 * ((n + 2 + 1) / 2 + 1)) + ptx_a16(4 * r_words) + ptx_a16(2 * (n / PTX_HUGE_BUCKET + 2));
+    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(4 * (K / 32 + 1)) + elem;
+    /* P1 .. P3: insert rows / sorted children + child counters (later the ranking words), keys / bucket members / successors, the parents with many children, the bitmap of a huge bucket */
+    const uint64_t p3 = ptx_a16(4 * (n + 3)) + ptx_a16(2 * (n + 2)) + ptx_a16(2 * (n / (PTX_SMALL_BUCKET + 1) + 2)) + ptx_a16(8 * (nwe + 1));
     const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0; /* (the list of interval rows only takes what is left of the recycled region) */
     uint64_t T4 = PTX_TILE_4; /* the short-document tile is the visible length rounded up to a power of two: at most that of the inserts */
     if (n < T4) {
@@ -293,10 +294,9 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     const uint64_t trees1 = n > PTX_TILE_4 ? ptx_overflow3(elem, K ? 4 * 2 * T1 : 0, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
     uint64_t tail = comments > trees4 ? comments : trees4;
     if (trees1 > tail) tail = trees1;
-    const uint64_t p5 = mpark + ptx_a16(8 * (nwe + 1)) + 2 * ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * (nwe + 1)) + tail;
-    uint64_t m = p1 > p3 ? p1 : p3;
-    if (p5 > m) m = p5;
-    return persist + m;
+    /* P5: mark rows / interval starts, alive bits, comment breaks, interval ends, comment ids + the tail phases' overflow */
+    const uint64_t p5 = ptx_a16(2 * (K + 1)) + ptx_a16(8 * (nwe + 1)) + ptx_a16(4 * (nwe + 1)) + ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + tail;
+    return persist + (p3 > p5 ? p3 : p5);
 }
 /* the same from a log header */
 /* P0 scratch on top of the header: per-actor table starts + the (actor, seq) -> change table */
@@ -943,7 +943,15 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
     const uint32_t nw = (keyspace + 31) / 32;
     const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
-    uint16_t* mlist = nullptr; /* allocated in P1's scratch, parked in HBM during P3 / P4, allocated again (and read back) when P5 starts */
+    /* The row lists of the deletes and of the mark ops never live in LDS during P1 .. P4: the row pass writes them straight to their PARK in HBM — the log's own
+     * span rows (8 bytes per row of the log = 2 N entries of 4 bytes, written by nobody before P6): entry = row | id key << 16, the deletes at [0, D), the mark ops
+     * at the TOP, [mp0, 2 N) with mp0 = 2 N - K, type t from mp0 + moff_t.  P3a reads the deletes back (coalesced), P5 the marks (into LDS: `mlist`); rows and keys
+     * of the marks that still cover a visible character are read from the park by P5c / P5b — also AFTER the first span rows are out (long documents go tile by
+     * tile): a log has at most n spans and N > n + D + K rows, so span row s (entries 2 s, 2 s + 1 < 2 n) never reaches entry mp0 > 2 n. */
+    uint32_t* const park = (uint32_t*)(A.out_spans + base);
+    const uint32_t park_top = 2u * N - 1u; /* last 4-byte entry of the park (a lying header's stores are kept inside it) */
+    const uint32_t mp0 = 2u * N - K;       /* (K <= N was checked above) */
+    uint16_t* mlist = nullptr; /* rows of the mark ops, read back from the park when P5 starts (then overwritten in place by the ops' interval starts) */
     uint32_t* maddbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 1); /* mark op k is an addMark (the tail phases need no look back at `action`) */
     /* element-side state: dead once the mark intervals are known (P5a), then reused as scratch of the tail phases */
     const uint32_t elem_lds = bp.off;
@@ -953,33 +961,43 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     uint32_t* delbits = ptx_alloc<uint32_t>(bp, nwe + 1);      /* element -> tombstone */
     PTX_BAIL_CAPACITY();
     const uint32_t mark_lds = bp.off; /* everything above this mark is phase scratch */
-    /* scratch of P1..P3: rows of the inserts (later `srt`), then ONE array that is first the row list of the deletes
-     * (its tail), then the bucket work lists `seg` | `big`, then the Euler tour `L` */
-    uint16_t* ilist = ptx_alloc<uint16_t>(bp, n + 1);
-    const uint32_t l_len = 2 * n + 2 > n + D + 2 ? 2 * n + 2 : n + D + 2;
-    uint16_t* L = ptx_alloc<uint16_t>(bp, l_len);
+    /* scratch of P1..P3, three n-sized arrays:
+     *   RW  one block of n + 3 words = `ilist` (rows of the inserts in row order; P3a leaves the deletes' target elements there; P3c: `srt`) followed by `cntw`
+     *       (children per parent -> bucket ends); once the successor list stands both are dead and the block is `R`, the {next, weight} words of the list ranking
+     *   L   `klist` (id keys of the inserts; P3a leaves the deletes' rows there), then `seg` (bucket members in arrival order), then `nx` (successors)
+     *   aux the list of the parents with many children and the bitmap that ranks a huge bucket */
+    uint32_t* RW = ptx_alloc<uint32_t>(bp, n + 3);
+    uint16_t* ilist = (uint16_t*)RW;
+    uint32_t* cntw = RW + (n + 2) / 2; /* behind the n + 1 entries of ilist */
+    uint16_t* L = ptx_alloc<uint16_t>(bp, n + 2);
     /* when every id key fits 16 bits (the usual case): key of the insert in slot s, written beside ilist[s] by P1, so that P3a
-     * needs no second look at the op_id column.  Lives in the head of L, which is free until P3b fills it as `seg`. */
+     * needs no second look at the op_id column (the marks' keys go to the park beside their rows, for P5b) */
     const bool small_keys = keyspace <= 65536u;
     uint16_t* klist = L;
-    uint16_t* dlist = L + n + 1; /* read until P3b; `seg` = L[0 .. n] is written meanwhile, `big` (same place as dlist) only after */
+    uint16_t* bigp = ptx_alloc<uint16_t>(bp, n / (PTX_SMALL_BUCKET + 1u) + 2); /* parents with more than PTX_SMALL_BUCKET children */
+    PtxBitWord* hb = ptx_alloc<PtxBitWord>(bp, nwe + 1);
     PTX_BAIL_CAPACITY();
-    const uint32_t tree_lds = bp.off;
 
     /* P3a's loads, declared here because its first step is issued as soon as P1 has completed the lists (its latency then hides
      * behind the duplicate check and the prefix scan of the id bitmap) */
     const uint32_t d_fused = D < n + 1u ? D : n + 1u; /* deletes that ride along with the inserts in P3a */
-    uint32_t p3_i[PTX_U], p3_di[PTX_U];
+    uint32_t p3_i[PTX_U], p3_di[PTX_U], p3_dq[PTX_U];
     uint64_t p3_id[PTX_U], p3_ra[PTX_U], p3_dra[PTX_U];
+    /* the park entries of this thread's deletes of a step (coalesced; issued TWO steps ahead: the gathers through them are a second trip) */
+#define PTX_P3A_DQ(st_, dq_)                                                \
+    _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
+        const uint32_t j_ = PTX_J_OF(st_, u);                               \
+        dq_[u] = ptx_coherent_load32(&park[j_ < d_fused ? PTX_JX(j_, D) : 0u]); \
+    }
     /* rows of this thread's inserts and deletes of a step (list reads, then the column gathers) */
-#define PTX_P3A_LOAD(st_, i_, id_, ra_, di_, dra_)                          \
+#define PTX_P3A_LOAD(st_, i_, id_, ra_, di_, dra_, dq_)                     \
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
         const uint32_t j_ = PTX_J_OF(st_, u);                               \
         const uint32_t s_ = j_ < n ? PTX_JX(j_, n) : 0u;                    \
         const uint32_t r_ = ilist[s_];                                      \
         i_[u] = r_ < N ? r_ : N - 1u;                                       \
         if (small_keys) id_[u] = klist[s_];                                 \
-        const uint32_t dr_ = dlist[j_ < d_fused ? PTX_JX(j_, D) : 0u];      \
+        const uint32_t dr_ = dq_[u] & 0xFFFFu;                              \
         di_[u] = dr_ < N ? dr_ : N - 1u;                                    \
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < PTX_U; ++u) {                     \
@@ -1025,24 +1043,21 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_FOR(i, N) A.out_rank[base + i] = 0xFFFFFFFFu;
             PTX_SYNC();
         }
-        /* The list cursors are ABSOLUTE: indices of 16-bit words from the start of the log's LDS window, so that a row's list slot
-         * is one number whatever its class (no per-row choice of a list).  Rows that are listed nowhere (makeList, NOP, malformed)
-         * land in a four-entry dump. */
+        /* The insert list's cursor is ABSOLUTE: an index of 16-bit words from the start of the log's LDS window; the cursors of the deletes and of the four
+         * mark types are entries of the park (deletes from 0, mark type t from D + moff_t).  A row's slot is one number whatever its class; rows that are
+         * listed nowhere (makeList, NOP, map ops, malformed) store nothing. */
         uint16_t* const lds16 = (uint16_t*)lds;
-        uint16_t* dump = ptx_alloc<uint16_t>(bp, 4);
-        mlist = ptx_alloc<uint16_t>(bp, K + 1);
-        PTX_BAIL_CAPACITY();
-        const uint32_t i_at = (uint32_t)(ilist - lds16), d_at = (uint32_t)(dlist - lds16), m_at = (uint32_t)(mlist - lds16), dump_at = (uint32_t)(dump - lds16);
+        const uint32_t i_at = (uint32_t)(ilist - lds16);
         const uint32_t k_delta = (uint32_t)(klist - ilist);   /* the key of an insert sits this far behind its list entry */
         const uint32_t top16 = A.lds_bytes / 2u - 1u;          /* last 16-bit word of the window */
         PTX_LEADER {
-            /* class 0 insert -> ilist, 1 delete -> dlist, 2..5 mark type 0..3 -> its range of mlist */
+            /* class 0 insert -> ilist (LDS), 1 delete -> park[0 ..), 2..5 mark type 0..3 -> its range of park[mp0 ..) */
             H->cur[0] = i_at;
-            H->cur[1] = d_at;
-            H->cur[2] = m_at;
-            H->cur[3] = m_at + moff1;
-            H->cur[4] = m_at + moff2;
-            H->cur[5] = m_at + moff3;
+            H->cur[1] = 0u;
+            H->cur[2] = mp0;
+            H->cur[3] = mp0 + moff1;
+            H->cur[4] = mp0 + moff2;
+            H->cur[5] = mp0 + moff3;
             H->cur[6] = H->cur[7] = 0; /* cur[7]: some row is malformed */
             H->n_ins = n;
             H->n_applied = n + D + K;
@@ -1068,7 +1083,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             if (kMasked) c4 = (c4 & live) | (0x07070707u & ~live);
             const uint32_t add4 = a4 & mk & live; /* bit 0 tells PTX_ACT_ADDMARK (3) from PTX_ACT_REMOVEMARK (4) */
             uint32_t slot[PTX_U1];
-            ptx_wave_slots4<PTX_U1>(H->cur, dump_at, c4, slot);
+            ptx_wave_slots4<PTX_U1>(H->cur, 0u, c4, slot);
 #pragma unroll
             for (int u = 0; u < PTX_U1; ++u) {
                 const uint32_t i = r0 + (uint32_t)u;
@@ -1083,11 +1098,15 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 const uint32_t key = ptx_min(ptx_mad24_su(ctr, ix.na1, act), keyspace - 1u);
                 const uint32_t bit = 1u << (key & 31u);
                 if (in) ptx_atomic_or64((unsigned long long*)&ix.ib[key >> 5], (unsigned long long)(c == 0u ? bit : 0u) | ((unsigned long long)bit << 32));
-                const uint32_t sl = ptx_min(slot[u], top16);
-                PTX_LDS_WILD_STORE16(&lds16[sl], i); /* anywhere inside the window when the header understates the rows */
-                if (small_keys && c == 0u) PTX_LDS_WILD_STORE16(&lds16[ptx_min(sl + k_delta, top16)], key);
+                if (c == 0u) { /* an insert: row and key into the LDS lists (anywhere inside the window when the header understates the rows) */
+                    const uint32_t sl = ptx_min(slot[u], top16);
+                    PTX_LDS_WILD_STORE16(&lds16[sl], i);
+                    if (small_keys) PTX_LDS_WILD_STORE16(&lds16[ptx_min(sl + k_delta, top16)], key);
+                } else if (c <= 5u) { /* a delete or a mark op: row | key << 16 into the park (anywhere inside the log's own span rows ...) */
+                    park[ptx_min(slot[u], park_top)] = i | (small_keys ? key << 16 : 0u);
+                }
                 if ((add4 >> (8u * (uint32_t)u)) & 1u) {
-                    const uint32_t k = ptx_min(sl - m_at, K); /* K: the spare bit */
+                    const uint32_t k = ptx_min(slot[u] - mp0, K); /* K: the spare bit */
                     ptx_atomic_or(&maddbits[k >> 5], 1u << (k & 31u));
                 }
             }
@@ -1111,18 +1130,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #undef PTX_P1_STEP
 #undef PTX_P1_LOAD
         if (err4 != 0u || ctr_hi >= ix.max_ctr || act_hi > ix.max_actor) ptx_atomic_or(&H->cur[7], 1u);
-        PTX_SYNC_LDS();
+        /* the ONE full barrier of the list phase: the park entries were stored by whichever thread met the row and are read by others (P3a: the deletes,
+         * P5: the marks), so the stores to HBM must have completed.  A header that understates the rows of a class parks junk: the census check below
+         * rejects that log before anything is made of it. */
+        PTX_SYNC();
         PTX_STAMP(11); /* end of the row loop; census, duplicate check and the prefix scan of the id bitmap follow */
-        /* the mark list is complete: park it in the log's span rows (8 bytes per row of the log, written only by P6; K <= N).  Every thread reads back
-         * in P5 exactly the words it stores here (the same PTX_FOR partition), so nothing but its own program order is relied on.  A header that
-         * understates the mark rows parks junk: the census check below rejects that log before anything reads it. */
-        {
-            uint32_t* park = (uint32_t*)(A.out_spans + base);
-            const uint32_t* src = (const uint32_t*)mlist;
-            PTX_FOR(w, K >> 1) park[w] = src[w];
-            if (K & 1u) PTX_LEADER { ((uint16_t*)park)[K - 1u] = mlist[K - 1u]; }
-        }
-        PTX_P3A_LOAD(0u, p3_i, p3_id, p3_ra, p3_di, p3_dra) /* the lists are complete: P3a's first step is on its way */
+        PTX_P3A_DQ(0u, p3_dq) /* the lists are complete: the deletes of P3a's first step are on their way */
         if (H->cur[7] != 0u) {
             /* some row is malformed (unknown action or mark type, op id of counter 0 or beyond the header's bounds): the first one
              * in log order is the log's error — the rare path, one row per thread and step.  The malformed rows were listed under
@@ -1148,11 +1161,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         } else {
             PTX_LEADER {
                 /* the header must be the exact census of the rows */
-                if (H->cur[0] != i_at + n || H->cur[1] != d_at + D || H->cur[2] != m_at + moff1 || H->cur[3] != m_at + moff2 || H->cur[4] != m_at + moff3 ||
-                    H->cur[5] != m_at + K)
+                if (H->cur[0] != i_at + n || H->cur[1] != D || H->cur[2] != mp0 + moff1 || H->cur[3] != mp0 + moff2 || H->cur[4] != mp0 + moff3 || H->cur[5] != mp0 + K)
                     ptx_raise(H, 0, 0, PTX_ERR_BAD_OP);
             }
         }
+        PTX_P3A_LOAD(0u, p3_i, p3_id, p3_ra, p3_di, p3_dra, p3_dq) /* P3a's first step: the gathers go out behind the duplicate check and the prefix scan */
+        PTX_P3A_DQ(1u, p3_dq)
         {
             uint32_t distinct = 0;
             PTX_FOR(w, nw + 1) distinct += ptx_popc(ix.ib[w].pre);
@@ -1179,35 +1193,28 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp, A.div_magic);
     }
     PTX_BAIL_IF_ERROR();
-    bp.off = tree_lds;
     PTX_STAMP(2);
 
     /* ---- P3: causal tree of the inserts -> document position of every element ---- */
     {
         /* children per parent -> bucket starts -> bucket ends; 16-bit counters, two per atomically updated word */
-        uint32_t* cntw = ptx_alloc<uint32_t>(bp, (n + 2 + 1) / 2 + 1);
         uint16_t* cnt = (uint16_t*)cntw;
-        /* the splitters' list of the list ranking (next splitter << 16 | weight); before that the bitmap of one huge bucket */
-        const uint32_t r_words = (2 * n) / PTX_S + 2 > 2 * (nwe + 2) ? (2 * n) / PTX_S + 2 : 2 * (nwe + 2);
-        uint32_t* R = ptx_alloc<uint32_t>(bp, r_words);
-        PtxBitWord* hb = (PtxBitWord*)R;
-        uint16_t* huge = ptx_alloc<uint16_t>(bp, n / PTX_HUGE_BUCKET + 2); /* parents with more than PTX_HUGE_BUCKET children */
-        PTX_BAIL_CAPACITY();
-        uint16_t* srt = ilist;       /* children of every parent, descending opId, parents ascending (ilist is dead after P3a) */
-        uint16_t* seg = L;           /* bucket members in arrival order (dead before L is built) */
-        uint16_t* big = seg + n + 1; /* positions in seg of the members of large buckets */
+        uint16_t* srt = ilist;       /* children of every parent, descending opId, parents ascending (ilist is dead after P3b) */
+        uint16_t* seg = L;           /* bucket members in arrival order (klist is dead after P3b's checks) */
 
         PTX_FOR(p, (n + 2 + 1) / 2 + 1) cntw[p] = 0;
         PTX_SYNC_LDS();
         /* P3a: element index of every insert, its parent, children counts.  The deletes ride along: their gathers of ref_a hit
          * the lines the inserts of the same stretch of the log have just brought in (one trip to HBM instead of two), and their
          * round trips hide behind the inserts'.  What a delete cannot do yet is the application-order check (row_of is being
-         * written): the thread leaves the target element in the slot of `ilist` it has just consumed — same thread, same index,
-         * no hazard — and the check runs below, from LDS alone.  Deletes beyond slot n (more deletes than inserts) go the old way. */
+         * written): the thread leaves the target element in the slot of `ilist` and the delete's row in the slot of `klist` it has
+         * just consumed — same thread, same index, no hazard — and the check runs below, from LDS alone.  Deletes beyond slot n
+         * (more deletes than inserts) go the old way. */
         {
             const uint32_t jmax = n > d_fused ? n : d_fused;
             const uint32_t steps = PTX_JSTEPS(jmax);
-            /* two register sets in turn (no copies from "next" to "current"): p3_* (step 0 was loaded at the end of P1) holds the even steps, *_n the odd ones */
+            /* two register sets in turn (no copies from "next" to "current"): p3_* (step 0 was loaded at the end of P1) holds the even steps, *_n the odd ones;
+             * p3_dq: the park entries of the deletes of the step whose gathers go out next */
             uint32_t i_n[PTX_U], di_n[PTX_U];
             uint64_t id_n[PTX_U], ra_n[PTX_U], dra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
             auto p3a_step = [&](uint32_t st, const uint32_t (&i)[PTX_U], const uint64_t (&id)[PTX_U], const uint64_t (&ra)[PTX_U], const uint32_t (&di)[PTX_U],
@@ -1234,24 +1241,60 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         const int t = ptx_elem_lookup(ix, dra[u]);
                         if (t < 0) ptx_raise(H, di[u], 1, PTX_ERR_ELEM_NOT_FOUND);
                         else ptx_atomic_or(&delbits[(uint32_t)t >> 5], 1u << ((uint32_t)t & 31u));
-                        ilist[j < n ? PTX_JX(j, n) : j] = (uint16_t)(t < 0 ? 0xFFFF : t); /* j <= n; slot n is P1's spare */
+                        const uint32_t sl = j < n ? PTX_JX(j, n) : j; /* j <= n; slot n is P1's spare */
+                        ilist[sl] = (uint16_t)(t < 0 ? 0xFFFF : t);
+                        klist[sl] = (uint16_t)di[u];
                     }
                 }
             };
 #pragma nounroll
             for (uint32_t st = 0; st < steps; st += 2u) {
-                PTX_P3A_LOAD(st + 1u, i_n, id_n, ra_n, di_n, dra_n) /* in flight while this step is processed */
+                PTX_P3A_LOAD(st + 1u, i_n, id_n, ra_n, di_n, dra_n, p3_dq) /* in flight while this step is processed */
+                PTX_P3A_DQ(st + 2u, p3_dq)
                 p3a_step(st, p3_i, p3_id, p3_ra, p3_di, p3_dra);
                 if (st + 1u >= steps) break;
-                PTX_P3A_LOAD(st + 2u, p3_i, p3_id, p3_ra, p3_di, p3_dra)
+                PTX_P3A_LOAD(st + 2u, p3_i, p3_id, p3_ra, p3_di, p3_dra, p3_dq)
+                PTX_P3A_DQ(st + 3u, p3_dq)
                 p3a_step(st + 1u, i_n, id_n, ra_n, di_n, dra_n);
             }
 #undef PTX_P3A_LOAD
+#undef PTX_P3A_DQ
         }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(12); /* end of P3a */
-        ptx_scan_excl<uint16_t, 1, kThreads>(cnt, n + 2, H->scan_tmp, A.div_magic); /* cnt[p] = first slot of p's children */
-        /* P3b: scatter into the parent buckets; tombstone flags; application-order checks now that row_of is complete */
+        /* the deletes' application-order check, now that row_of is complete: target element and row left in ilist / klist by P3a */
+        PTX_FORV(j0, d_fused, PTX_UV) {
+            uint32_t t[PTX_UV], i[PTX_UV], rt[PTX_UV];
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u) {
+                const uint32_t j = PTX_IN(j0, u) ? PTX_IX(j0, u) : 0u;
+                const uint32_t sl = j < n ? PTX_JX(j, n) : j;
+                t[u] = PTX_IN(j0, u) ? ilist[sl] : 0xFFFFu;
+                i[u] = klist[sl];
+            }
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u) rt[u] = row_of[t[u] != 0xFFFFu ? t[u] : 0u];
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u)
+                if (t[u] != 0xFFFFu) {
+                    if (rt[u] >= i[u]) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);
+                    if (A.out_refs && i[u] < N) A.out_refs[base + i[u]] = rt[u];
+                }
+        }
+        if (D > d_fused) { /* more deletes than inserts + 1: the rest, two trips each (park, then the column) */
+            PTX_FOR(jj, D - d_fused) {
+                const uint32_t j = d_fused + jj;
+                const uint32_t r = ptx_coherent_load32(&park[PTX_JX(j, D)]) & 0xFFFFu, i = r < N ? r : N - 1u;
+                const int t = ptx_elem_lookup(ix, ref_a[i]);
+                if (t < 0 || row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND);
+                else {
+                    ptx_atomic_or(&delbits[(uint32_t)t >> 5], 1u << ((uint32_t)t & 31u));
+                    if (A.out_refs) A.out_refs[base + i] = row_of[t];
+                }
+            }
+        }
+        ptx_scan_excl<uint16_t, 1, kThreads>(cnt, n + 2, H->scan_tmp, A.div_magic); /* cnt[p] = first slot of p's children (its barriers stand between the checks above, which read klist, and the scatter below, which writes the same words as seg) */
+        /* P3b: scatter into the parent buckets; application-order checks of the inserts now that row_of is complete */
         PTX_FORU(e0, n) {
             uint32_t pe[PTX_U], re[PTX_U], rp[PTX_U];
 #pragma unroll
@@ -1272,68 +1315,54 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     seg[(ptx_atomic_add(&cntw[pe[u] >> 1], 1u << (16u * (pe[u] & 1u))) >> (16u * (pe[u] & 1u))) & 0xFFFFu] = (uint16_t)PTX_IX(e0, u);
                 }
         }
-        /* the deletes' application-order check, now that row_of is complete: target element left in ilist by P3a */
-        PTX_FOR(j, d_fused) {
-            const uint32_t t = ilist[j < n ? PTX_JX(j, n) : j], i = dlist[PTX_JX(j, D)];
-            if (t != 0xFFFFu && row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND);
-            if (A.out_refs && t != 0xFFFFu && i < N) A.out_refs[base + i] = row_of[t];
-        }
-        if (D > d_fused) { /* more deletes than inserts + 1: the rest, one gather each */
-            PTX_FOR(jj, D - d_fused) {
-                const uint32_t j = d_fused + jj;
-                const uint32_t r = dlist[PTX_JX(j, D)], i = r < N ? r : N - 1u;
-                const int t = ptx_elem_lookup(ix, ref_a[i]);
-                if (t < 0 || row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND);
-                else {
-                    ptx_atomic_or(&delbits[(uint32_t)t >> 5], 1u << ((uint32_t)t & 31u));
-                    if (A.out_refs) A.out_refs[base + i] = row_of[t];
-                }
-            }
-        }
+        PTX_LEADER { H->cur_big = 0; }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(3);
-        /* P3c: rank inside the bucket: descending element index == descending opId.  Most elements are an only
-         * child (placed at once); buckets of 2..PTX_SMALL_BUCKET members are ranked by one lane per member scanning
-         * the bucket; up to PTX_HUGE_BUCKET members by PTX_G lanes per member; larger ones (typically the children
-         * of HEAD) through a bitmap over the element indices: rank = members with a larger index. */
-        PTX_FOR(j, n) {
-            const uint32_t x = seg[j];
-            const uint32_t p = par[x];
+        /* P3c: the children of every parent in descending element index == descending opId (the skip loop of micromerge.ts:630-635), one PARENT per lane:
+         * a bucket of up to PTX_SMALL_BUCKET members (all but a handful: most elements are an only child) is sorted in registers by a 19-exchange network;
+         * the parents with more go to a list: up to PTX_HUGE_BUCKET members by PTX_G lanes per member, larger ones (the children of HEAD in a document
+         * everybody types at the start of) through a bitmap over the element indices: rank = members with a larger index. */
+        PTX_FOR(p, n + 1) {
             const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
             const uint32_t m = t - s;
-            if (m == 1u) srt[s] = (uint16_t)x;
-            const bool is_med = m > 1u && m <= PTX_SMALL_BUCKET, is_big = m > PTX_SMALL_BUCKET && m <= PTX_HUGE_BUCKET;
-            const uint32_t jm = ptx_append(&H->cur_med, is_med);
-            const uint32_t jb = ptx_append(&H->cur_big, is_big);
-            if (is_med) big[jm] = (uint16_t)j;              /* medium members from the front of the work list */
-            else if (is_big) big[n - 1u - jb] = (uint16_t)j; /* large members from its back */
-            /* the first member of a huge bucket announces its parent */
-            if (m > PTX_HUGE_BUCKET && j == s) huge[ptx_atomic_add(&H->cur_huge, 1u)] = (uint16_t)p;
+            static_assert(PTX_SMALL_BUCKET == 8u, "the exchange network below sorts eight");
+            if (m >= 1u && m <= PTX_SMALL_BUCKET) {
+                uint32_t v[8]; /* element index + 1 (0 = no member: sorts to the end) */
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k) v[k] = k < m ? (uint32_t)seg[s + k] + 1u : 0u;
+#define PTX_CE(a_, b_)                                    \
+    {                                                     \
+        const uint32_t hi_ = v[a_] > v[b_] ? v[a_] : v[b_]; \
+        v[b_] = v[a_] > v[b_] ? v[b_] : v[a_];            \
+        v[a_] = hi_;                                      \
+    }
+                PTX_CE(0, 1) PTX_CE(2, 3) PTX_CE(4, 5) PTX_CE(6, 7) PTX_CE(0, 2) PTX_CE(1, 3) PTX_CE(4, 6) PTX_CE(5, 7) PTX_CE(1, 2) PTX_CE(5, 6)
+                PTX_CE(0, 4) PTX_CE(1, 5) PTX_CE(2, 6) PTX_CE(3, 7) PTX_CE(2, 4) PTX_CE(3, 5) PTX_CE(1, 2) PTX_CE(3, 4) PTX_CE(5, 6)
+#undef PTX_CE
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k)
+                    if (k < m) srt[s + k] = (uint16_t)(v[k] - 1u);
+            }
+            const uint32_t jb = ptx_append(&H->cur_big, m > PTX_SMALL_BUCKET);
+            if (m > PTX_SMALL_BUCKET) bigp[jb] = (uint16_t)p;
         }
         PTX_SYNC_LDS();
         {
-            const uint32_t nm = H->cur_med, nb = H->cur_big, nh = H->cur_huge;
-            PTX_FOR(b, nm) {
-                const uint32_t x = seg[big[b]];
-                const uint32_t p = par[x];
+            const uint32_t nb = H->cur_big;
+            for (uint32_t h = 0; h < nb; ++h) { /* uniform: nb and the bucket bounds come from LDS after the barrier */
+                const uint32_t p = bigp[h];
                 const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
-                uint32_t c = 0;
-                for (uint32_t k = s; k < t; ++k) c += seg[k] > x ? 1u : 0u;
-                srt[s + c] = (uint16_t)x;
-            }
-            PTX_FOR(w, nb * PTX_G) {
-                const uint32_t b = w / PTX_G, g = w % PTX_G;
-                const uint32_t x = seg[big[n - 1u - b]];
-                const uint32_t p = par[x];
-                const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
-                uint32_t c = 0;
-                for (uint32_t k = s + g; k < t; k += PTX_G) c += seg[k] > x ? 1u : 0u;
-                c = ptx_group_sum(c);
-                if (g == 0) srt[s + c] = (uint16_t)x;
-            }
-            for (uint32_t h = 0; h < nh; ++h) { /* uniform: nh comes from LDS after the barrier */
-                const uint32_t p = huge[h];
-                const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
+                if (t - s <= PTX_HUGE_BUCKET) {
+                    PTX_FOR(w, (t - s) * PTX_G) {
+                        const uint32_t k = w / PTX_G, g = w % PTX_G;
+                        const uint32_t x = seg[s + k];
+                        uint32_t c = 0;
+                        for (uint32_t q = s + g; q < t; q += PTX_G) c += seg[q] > x ? 1u : 0u;
+                        c = ptx_group_sum(c);
+                        if (g == 0) srt[s + c] = (uint16_t)x;
+                    }
+                    continue;
+                }
                 PTX_FOR(w, nwe + 1) {
                     PtxBitWord z;
                     z.bits = 0;
@@ -1358,53 +1387,112 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_SYNC_LDS();
         PTX_STAMP(4);
-        /* P3d: Euler tour.  Nodes: 0 = enter(HEAD), x+1 = enter(x), n+1+x = exit(x) for x in [0,n), and the
-         * terminal node 2n+1.  weight 1 on enter(x): the suffix sum at enter(x) counts the elements from x
-         * to the end of the document, so position(x) = n - suffix(enter(x)). */
-        const uint32_t term = 2 * n + 1;
-        PTX_FOR(j, n + 1) {
-            const uint32_t s = j ? cnt[j - 1] : 0u, t = cnt[j];
-            const uint32_t nx = t > s ? (uint32_t)srt[s] + 1u : (j == n ? term : n + 1u + j);
-            uint32_t xo = term, other = term;
-            if (j < n) {
-                const uint32_t x = srt[j];
-                const uint32_t p = par[x];
-                other = j + 1u < cnt[p] ? (uint32_t)srt[j + 1] + 1u : (p == n ? term : n + 1u + p);
-                xo = n + 1u + x;
+        /* P3d: document order = pre-order of the tree.  Successor of an element x: its first child; a leaf's: `after(x)` = the next sibling, or — x being the
+         * last child — after(parent).  after() of the last children is resolved by pointer jumping up the tree (a few rounds: the chains of last children are
+         * short; the rounds stop when a pass finds nothing open); then the successor list of the n + 1 nodes (elements, HEAD = n; the terminal node n + 1)
+         * is ranked by in-place pointer jumping over {next << 16 | elements in [node, next)} words. */
+        const uint32_t term = n + 1u;
+        uint16_t* nx = seg; /* (seg is dead: srt holds the sorted buckets) */
+        PTX_FORV(j0, n, PTX_UV) {
+            uint32_t x[PTX_UV], sib[PTX_UV], p[PTX_UV], e[PTX_UV];
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u) {
+                const uint32_t j = PTX_IN(j0, u) ? PTX_IX(j0, u) : 0u;
+                x[u] = srt[j];
+                sib[u] = srt[j + 1u < n ? j + 1u : j];
             }
-            L[j < n ? j + 1u : 0u] = (uint16_t)nx;
-            L[xo] = (uint16_t)other; /* j == n writes the terminal node */
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u) p[u] = par[x[u]];
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u) e[u] = cnt[p[u]];
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u)
+                if (PTX_IN(j0, u)) nx[x[u]] = (uint16_t)(PTX_IX(j0, u) + 1u < e[u] ? sib[u] : (p[u] == n ? term : 0x8000u | p[u])); /* 0x8000 | p: open, ask p */
+        }
+        uint32_t* open3 = &H->cur_big; /* cur_big, cur_med, cur_huge: "some node is still open" of round r in word r % 3.  The leader of round r clears the word of
+                                          round r + 1; a thread that is slow to read round r's word cannot find it cleared: that is the leader of round r + 2's
+                                          doing, who has passed the barrier of round r + 1 — behind the slow thread's read */
+        PTX_LEADER {
+            nx[n] = (uint16_t)term;
+            open3[0] = 0;
         }
         PTX_SYNC_LDS();
-        PTX_STAMP(14); /* the Euler tour stands; the list ranking follows */
-        /* List ranking, work-efficient: every PTX_S-th node is a splitter.  A splitter walks to the next one (each tour
-         * node is visited once), counts the enter nodes (weight 1: node ids 1..n) it passes and leaves on each of them
-         * its splitter and the count before it (in `L` and `par`, both dead by then); the ~2n/PTX_S splitters are
-         * ranked by in-place pointer jumping; one flat pass turns (splitter suffix, local count) into positions. */
+#pragma nounroll
+        for (uint32_t r = 0;; ++r) {
+            uint32_t open = 0;
+            /* branch-free: an item past the end plays HEAD (resolved from the start); a resolved node writes back what it read */
+            PTX_FORV(x0, n, PTX_UV) {
+                uint32_t ix_[PTX_UV], v[PTX_UV], w[PTX_UV];
+#pragma unroll
+                for (int u = 0; u < PTX_UV; ++u) {
+                    ix_[u] = PTX_IN(x0, u) ? PTX_IX(x0, u) : n;
+                    v[u] = nx[ix_[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < PTX_UV; ++u) w[u] = nx[v[u] & 0x7FFFu]; /* (of an open node) resolved, or a node further up: either way a valid state of x */
+#pragma unroll
+                for (int u = 0; u < PTX_UV; ++u) {
+                    const uint32_t nv = (v[u] & 0x8000u) ? w[u] : v[u];
+                    nx[ix_[u]] = (uint16_t)nv;
+                    open |= nv & 0x8000u;
+                }
+            }
+            if (open) ptx_atomic_or(&open3[r % 3u], 1u);
+            PTX_LEADER { open3[(r + 1u) % 3u] = 0; }
+            PTX_SYNC_LDS();
+            if (!open3[r % 3u]) break;
+        }
+        PTX_STAMP(14); /* after() stands; the successor list and its ranking follow */
+        PTX_FORV(x0, n + 1, PTX_UV) { /* the successor, in place: the first child where there is one */
+            uint32_t s[PTX_UV], t[PTX_UV], f[PTX_UV];
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u) {
+                const uint32_t x = PTX_IN(x0, u) ? PTX_IX(x0, u) : 0u;
+                s[u] = x ? cnt[x - 1] : 0u;
+                t[u] = cnt[x];
+            }
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u) f[u] = srt[s[u] < n ? s[u] : 0u];
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u)
+                if (PTX_IN(x0, u) && t[u] > s[u]) nx[PTX_IX(x0, u)] = (uint16_t)f[u];
+        }
+        PTX_SYNC_LDS();
+        PTX_STAMP(16); /* the successor list stands */
+        /* List ranking, work-efficient (every pass touches a node once; Wyllie's doubling over all n nodes was measured: 4 x the instructions, no faster alone):
+         * every S-th element, and HEAD, is a splitter.  A splitter walks to the next one, counts the elements it passes and leaves on each of them its own
+         * index (in nx: only this walker ever reads nx[v], and it just did) and the count before it (in par, dead by now); the splitters are ranked by in-place
+         * pointer jumping over {next splitter << 16 | elements of the segment}; one flat pass turns (splitter suffix, local count) into positions.
+         * S: 8 while the splitters fit one pass of the workgroup (segments are geometric: mean S, the longest of them bounds the pass). */
+        uint32_t* R = RW; /* srt and cnt are dead */
         {
-            const uint32_t ns = (2 * n) / PTX_S + 1; /* splitters 0, S, 2S, ... <= 2n */
+            uint32_t lgS = 3u;
+            while ((n >> lgS) + 3u > PTX_NTHREADS && lgS < 15u) ++lgS;
+            const uint32_t smask = (1u << lgS) - 1u;
+            const uint32_t nsE = n ? ((n - 1u) >> lgS) + 1u : 0u; /* splitters 0 .. nsE - 1: the elements sp << lgS; nsE: HEAD; ns = nsE + 1: the terminal node */
+            const uint32_t ns = nsE + 1u;
             PTX_FOR(sp, ns) {
-                uint32_t v = sp * PTX_S, acc = 0;
+                uint32_t v = sp < nsE ? sp << lgS : n, acc = 0;
                 for (;;) {
-                    const uint32_t nx = L[v];
-                    if (v - 1u < n) {
-                        par[v - 1u] = (uint16_t)acc; /* enter nodes of this segment strictly before v */
-                        L[v] = (uint16_t)sp;         /* only this walker ever reads L[v], and it just did */
+                    const uint32_t nxt = nx[v];
+                    if (v < n) {
+                        par[v] = (uint16_t)acc; /* elements of this segment strictly before v */
+                        nx[v] = (uint16_t)sp;
                         ++acc;
                     }
-                    v = nx;
-                    if (v == term || (v & (PTX_S - 1u)) == 0u) break;
+                    v = nxt;
+                    if (v >= n || (v & smask) == 0u) break; /* the terminal node (n + 1; HEAD is nobody's successor) or the next splitter */
                 }
-                R[sp] = ((v == term ? ns : v / PTX_S) << 16) | acc;
+                R[sp] = ((v < n ? v >> lgS : ns) << 16) | acc;
             }
             PTX_LEADER { R[ns] = ns << 16; } /* terminal: points at itself with weight 0 */
             PTX_SYNC_LDS();
+            PTX_STAMP(17); /* the walks are over */
             const uint32_t rounds = ptx_ceil_log2(ns + 1);
 #pragma nounroll
             for (uint32_t r = 0; r < rounds; ++r) {
-                /* in-place pointer jumping: every intermediate {next, weight} word is a valid state
-                 * (weight = sum over [node, next)), so reading a word another thread already advanced
-                 * this round only makes the jump longer */
+                /* in-place pointer jumping: every intermediate {next, weight} word is a valid state (weight = elements in [node, next)), so reading a word
+                 * another thread already advanced this round only makes the jump longer */
                 PTX_FOR(sp, ns) {
                     const uint32_t a = R[sp];
                     const uint32_t b = R[a >> 16];
@@ -1412,20 +1500,37 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 }
                 PTX_SYNC_LDS();
             }
-            /* elements from x to the end of the document = suffix of x's splitter - enter nodes before x in its segment */
-            PTX_FOR(x, n) par[x] = (uint16_t)(n - ((R[L[x + 1u]] & 0xFFFFu) - (uint32_t)par[x])); /* document position incl. tombstones */
+            /* elements from x to the end of the document = suffix of x's splitter - elements before x in its segment */
+            PTX_FORV(x0, n, PTX_UV) { /* document position incl. tombstones */
+                uint32_t sp[PTX_UV], lc[PTX_UV], a[PTX_UV];
+#pragma unroll
+                for (int u = 0; u < PTX_UV; ++u) {
+                    const uint32_t x = PTX_IN(x0, u) ? PTX_IX(x0, u) : 0u;
+                    sp[u] = nx[x];
+                    lc[u] = par[x];
+                }
+#pragma unroll
+                for (int u = 0; u < PTX_UV; ++u) a[u] = R[sp[u] <= ns ? sp[u] : ns];
+#pragma unroll
+                for (int u = 0; u < PTX_UV; ++u)
+                    if (PTX_IN(x0, u)) par[PTX_IX(x0, u)] = (uint16_t)(n - ((a[u] & 0xFFFFu) - lc[u]));
+            }
         }
         PTX_SYNC_LDS();
     }
+    PTX_STAMP(18); /* document positions stand; the mark list comes back from its park */
     uint16_t* rnk = par;
     bp.off = mark_lds; /* release the tree scratch */
+    /* the rows of the mark ops come back from the park (the low halves of its entries from mp0 on) */
     mlist = ptx_alloc<uint16_t>(bp, K + 1);
     PTX_BAIL_CAPACITY();
-    {
-        const uint32_t* park = (const uint32_t*)(A.out_spans + base);
-        uint32_t* dst = (uint32_t*)mlist;
-        PTX_FOR(w, K >> 1) dst[w] = park[w];
-        if (K & 1u) PTX_LEADER { mlist[K - 1u] = ((const uint16_t*)park)[K - 1u]; }
+    PTX_FORV(k0, K, PTX_UV) { /* (the loads of a step are in flight together: a loop of one load per turn is one round trip to the L2 per turn) */
+        uint32_t v[PTX_UV];
+#pragma unroll
+        for (int u = 0; u < PTX_UV; ++u) v[u] = ptx_coherent_load32(&park[mp0 + (PTX_IN(k0, u) ? PTX_IX(k0, u) : 0u)]);
+#pragma unroll
+        for (int u = 0; u < PTX_UV; ++u)
+            if (PTX_IN(k0, u)) mlist[PTX_IX(k0, u)] = (uint16_t)v[u];
     }
     PTX_SYNC_LDS();
     PTX_STAMP(5);
@@ -1496,13 +1601,15 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_FOR(w, nwv + 1) alive[w].pre = ptx_popc(alive[w].bits);
     PTX_SYNC_LDS();
     const uint32_t V = ptx_scan_excl<uint32_t, 2, kThreads>(&alive[0].pre, nwv + 1, H->scan_tmp, A.div_magic);
-    /* the visible interval of every mark op; until the marks are looked at, the space holds the rows of the visible elements (vrow) if they fit */
+    /* the visible interval [lo, hi) of every mark op.  `lo` takes the place of the op's row in `mlist`: P5a's thread has consumed the row when it stores the
+     * interval (same thread, same index), and the few later uses of a row — the ops that still cover a visible character — read it from the park.  Until the
+     * marks are looked at, the space of `hi` and of the comment ids holds the rows of the visible elements (vrow) if they fit */
+    uint16_t* mrk_lo = mlist;
     const uint32_t mrk_at = bp.off;
-    uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
     uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
     uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);    /* comment mark -> doc-local comment id */
     PTX_BAIL_CAPACITY();
-    const uint32_t mrk_bytes = bp.off - mrk_at; /* the three arrays stand back to back; nothing is stored in them before the marks are looked at */
+    const uint32_t mrk_bytes = bp.off - mrk_at; /* the two arrays stand back to back; nothing is stored in them before the marks are looked at */
     PTX_STAMP(6);
 
     /* ---- P5a: visible values out; every mark op -> visible interval [lo, hi) ---- */
@@ -1513,8 +1620,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * never inside the sparse loop */
         const bool sparse = V * 8u < n;
         if (2u * (V + 1u) <= mrk_bytes) {
-            uint16_t* vrow = mrk_lo;
-            PTX_LDS_ALLOCATED(mrk_lo, mrk_bytes, mrk_bytes); /* (the list runs over the three arrays and the padding between them) */
+            uint16_t* vrow = mrk_hi;
+            PTX_LDS_ALLOCATED(mrk_hi, mrk_bytes, mrk_bytes); /* (the list runs over the two arrays and the padding between them) */
             for_live(sparse, [&](uint32_t e) { vrow[ptx_bitrank(alive, rnk[e])] = row_of[e]; });
             PTX_SYNC_LDS();
             PTX_FOR(q, V) {
@@ -1540,7 +1647,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         if (V >= 48u) ptx_digest_flush_dense(H, h1, h2); /* uniform: most lanes of a wave carry a share */
         else ptx_digest_flush(H, h1, h2);
-        PTX_SYNC_LDS(); /* vrow (= the head of mrk_lo) has been read by everyone before the first interval is stored */
+        PTX_SYNC_LDS(); /* vrow (= the head of mrk_hi) has been read by everyone before the first interval is stored */
     }
 #undef PTX_LIVE_WORD
     PTX_STAMP(13); /* the values are out; the marks' intervals follow */
@@ -1647,7 +1754,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 PtxCEntry e;
                 e.lo = mrk_lo[k];
                 e.hi = mrk_hi[k];
-                e.t = mlist[k]; /* application index = row in the log */
+                e.t = (uint16_t)ptx_coherent_load32(&park[mp0 + k]); /* application index = row in the log (from the park: the LDS copy has become mrk_lo) */
                 e.add = ptx_bittest(maddbits, k) ? 1 : 0;
                 cent[pos] = e;
             }
@@ -1747,8 +1854,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 const uint32_t kn = k_hi - k_lo, b_steps = four ? PTX_JB_STEPS(MB.B, PTX_UB) : PTX_JSTEPS_U(kn, PTX_UB);
                 /* two register sets in turn: the opId gathers of the next step are in flight while this step's ranges go into the trees */
                 uint32_t kq_a[PTX_UB], lo_a[PTX_UB], hi_a[PTX_UB], kq_b[PTX_UB], lo_b[PTX_UB], hi_b[PTX_UB];
-                uint64_t idq_a[PTX_UB], idq_b[PTX_UB];
-                auto lww_load = [&](uint32_t st, uint32_t (&kq)[PTX_UB], uint32_t (&lo)[PTX_UB], uint32_t (&hi)[PTX_UB], uint64_t (&idq)[PTX_UB]) {
+                uint32_t idq_a[PTX_UB], idq_b[PTX_UB]; /* the park entry of the op: row | id key << 16 */
+                auto lww_load = [&](uint32_t st, uint32_t (&kq)[PTX_UB], uint32_t (&lo)[PTX_UB], uint32_t (&hi)[PTX_UB], uint32_t (&idq)[PTX_UB]) {
 #pragma unroll
                     for (int u = 0; u < (int)PTX_UB; ++u) {
                         uint32_t k;
@@ -1767,19 +1874,19 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         lo[u] = l;
                         hi[u] = h;
                         idq[u] = 0;
-                        if (l < h && PTX_TYPE_OF(k) != PTX_MARK_COMMENT) {
-                            const uint32_t r = mlist[k];
-                            idq[u] = op_id[r < N ? r : N - 1u];
-                        }
+                        if (l < h && PTX_TYPE_OF(k) != PTX_MARK_COMMENT) idq[u] = ptx_coherent_load32(&park[mp0 + k]);
                     }
                 };
-                auto lww_put = [&](const uint32_t (&kq)[PTX_UB], const uint32_t (&lo)[PTX_UB], const uint32_t (&hi)[PTX_UB], const uint64_t (&idq)[PTX_UB]) {
+                auto lww_put = [&](const uint32_t (&kq)[PTX_UB], const uint32_t (&lo)[PTX_UB], const uint32_t (&hi)[PTX_UB], const uint32_t (&idq)[PTX_UB]) {
 #pragma unroll
                     for (int u = 0; u < (int)PTX_UB; ++u)
                         if (lo[u] < hi[u]) {
                             const uint32_t k = kq[u], ty = PTX_TYPE_OF(k);
-                            uint32_t key = 0;
-                            ptx_id_key(ix, idq[u], key);
+                            uint32_t key = idq[u] >> 16; /* LWW order = opId order = order of the dense id keys */
+                            if (!small_keys && ty != PTX_MARK_COMMENT) { /* (keys beyond 16 bits are not parked: a second trip, through the row) */
+                                const uint32_t r = idq[u] & 0xFFFFu;
+                                ptx_id_key(ix, op_id[r < N ? r : N - 1u], key);
+                            }
                             /* the low bits say who won */
                             ptx_tree_chmax(tree + (four ? ty : 0u) * 2 * TV, TV, lo[u], hi[u], ty == PTX_MARK_COMMENT ? 1u : ((key + 1u) << kbits) | k);
                         }
@@ -1805,7 +1912,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                             if (ptx_bittest(maddbits, k)) {
                                 if (ty == PTX_MARK_STRONG) at |= PTX_ATTR_STRONG;
                                 else if (ty == PTX_MARK_EM) at |= PTX_ATTR_EM;
-                                else at |= PTX_ATTR_LINK | (payload[mlist[k]] & PTX_ATTR_ID_MASK);
+                                else at |= PTX_ATTR_LINK | (payload[ptx_coherent_load32(&park[mp0 + k]) & 0xFFFFu] & PTX_ATTR_ID_MASK);
                             }
                         }
                     }

@@ -58,7 +58,7 @@ PTX_MERGE_KERNEL(ptx_merge_kernel_rest, 1024, 1, false, 0, false) /* the same ke
 PTX_MERGE_KERNEL_A(ptx_merge_kernel_w7, 1024, PTX_W, false, 0, false, PTX_SGPRS_W7)      /* the same two at 7 waves per SIMD (see above) */
 PTX_MERGE_KERNEL_A(ptx_merge_kernel_rest_w7, 1024, 1, false, 0, false, PTX_SGPRS_W7)
 PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false) /* + causal admission for documents with more than three actors */
-PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, 1, true, 0, true)  /* + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
+PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, PTX_W, false, 0, true)  /* (the admission of the product kernel — with the table path of the many-actor build it needs 105 VGPRs and its phase stamps would be taken at 4 waves per SIMD —) + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
 /* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
  * issue ~1 % fewer instructions but need twice the VGPRs unless PTX_U=1, so only the run-time-sized builds are shipped) */
 
@@ -381,6 +381,7 @@ __global__ void ptx_tile_offsets_kernel(const uint64_t* src, uint64_t* dst, uint
 /* rows by which the library over-allocates its copies of the envelope columns: the admission pass reads PTX_AC headers /
  * envelope rows of a lane with one wide load each, also at the last change of the batch */
 #define PTX_ENV_PAD 8u
+#define PTX_LDS_GRANULE 1280u /* bytes: the CU's 160 KB in 128 granules */
 
 struct ptx_ctx {
     int device = 0;
@@ -518,9 +519,9 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
     uint32_t fit = 0, max_fit = 0;
     bool split = false;
     if (small.size() >= 64 && !ctx->force_lds && b->lds_bytes >= 4096) {
-        /* Would one more log fit a CU if the launch were sized for all but a few logs?  LDS is allocated in 512-byte granules; k logs share a CU when each
-         * needs at most floor(LDS / k) rounded down to a granule. */
-        const uint64_t gran = 512, lds_now = (b->lds_bytes + gran - 1) / gran * gran;
+        /* Would one more log fit a CU if the launch were sized for all but a few logs?  The CU hands out LDS in granules of PTX_LDS_GRANULE bytes (measured:
+         * tools/micro/occupancy_query.hip, profiles/r03_n_*); k logs share a CU when each needs at most floor(LDS / k) rounded down to a granule. */
+        const uint64_t gran = PTX_LDS_GRANULE, lds_now = (b->lds_bytes + gran - 1) / gran * gran;
         const uint64_t k_now = std::max<uint64_t>(ctx->max_lds / lds_now, 1);
         const uint64_t bound = ctx->max_lds / (k_now + 1) / gran * gran; /* per-log LDS at which k_now + 1 logs share a CU */
         for (uint32_t l : small)
@@ -1056,8 +1057,8 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
         else if (admit && b->max_actors > 3)
             hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);
         else {
-            /* would the LDS window let more than 24 waves share a CU (LDS comes in granules of 1 280 bytes)?  Then the build that fits 7 waves per SIMD */
-            const uint32_t waves = (b->threads + 63u) / 64u, by_lds = (uint32_t)(ctx->max_lds / ((((uint64_t)lds + 1279u) / 1280u) * 1280u));
+            /* would the LDS window let more than 24 waves share a CU?  Then the build that fits 7 waves per SIMD */
+            const uint32_t waves = (b->threads + 63u) / 64u, by_lds = (uint32_t)(ctx->max_lds / ((((uint64_t)lds + PTX_LDS_GRANULE - 1u) / PTX_LDS_GRANULE) * PTX_LDS_GRANULE));
             const bool w7 = by_lds * waves > 24u;
             if (part) hipLaunchKernelGGL(w7 ? ptx_merge_kernel_rest_w7 : ptx_merge_kernel_rest, dim3(grid), dim3(b->threads), lds, st, A);
             else hipLaunchKernelGGL(w7 ? ptx_merge_kernel_w7 : ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, st, A);
@@ -1495,8 +1496,9 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
      * slots would take) lose a quarter at 1 024.  So: what fits while the wave slots stay full, else what costs no more than a fifth of the resident logs. */
     uint32_t seg_lds = 0;
     {
-        const uint64_t lds0 = std::max<uint64_t>((need_g + 255) & ~255ull, 256), logs0 = std::min<uint64_t>(ctx->max_lds / lds0, 28);
-        const uint64_t keep = logs0 >= 28 ? 28 : (logs0 * 4 + 4) / 5;
+        /* (the replay kernel's 106 SGPRs hold it to 6 waves per SIMD = 24 one-wave logs per CU, profiles/r03_p_*; the LDS comes in granules) */
+        const uint64_t lds0 = std::max<uint64_t>((need_g + PTX_LDS_GRANULE - 1) / PTX_LDS_GRANULE * PTX_LDS_GRANULE, PTX_LDS_GRANULE), logs0 = std::min<uint64_t>(ctx->max_lds / lds0, 24);
+        const uint64_t keep = logs0 >= 24 ? 24 : (logs0 * 4 + 4) / 5;
         const uint64_t room = keep ? ctx->max_lds / keep : 0;
         if (room > need_g + 256) seg_lds = (uint32_t)std::min<uint64_t>(((room - need_g - 256) / 2) & ~63ull, 1536);
         for (uint32_t l = 0; l < L && seg_lds; ++l) need_g = std::max<uint64_t>(need_g, ptx_replay_lds_need_hdr(hdr[l], true, seg_lds));

@@ -53,6 +53,7 @@ PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__popc(x); }
  * write through and update) and the wait for the wave's outstanding stores that must stand between a store and another lane's load of it */
 PTX_DEV uint16_t ptx_coherent_load16(const uint16_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PTX_DEV void ptx_coherent_store16(uint16_t* p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PTX_DEV uint32_t ptx_coherent_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PTX_DEV void ptx_global_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 /* wave-aggregated append: ONE LDS atomic per wave, lanes get consecutive slots.  May be called in
  * divergent control flow (the ballot covers the active lanes only). */
@@ -75,6 +76,9 @@ PTX_DEV uint32_t ptx_group_sum(uint32_t c) {
     return c;
 }
 #define PTX_FORU(i0, n) for (uint32_t i0 = threadIdx.x, _n = (n), _T = PTX_BLOCKDIM; i0 < _n; i0 += PTX_U * _T)
+/* the same with U items per thread and step (item u of a step: PTX_IX(i0, u), it exists iff PTX_IN(i0, u)): the loops whose iterations are chains of dependent
+ * LDS reads run U chains at once instead of one after the other (PTX_FOR is deliberately not unrolled) */
+#define PTX_FORV(i0, n, U) _Pragma("nounroll") for (uint32_t i0 = threadIdx.x, _n = (n), _T = PTX_BLOCKDIM; i0 < _n; i0 += (U) * _T)
 #define PTX_IX(i0, u) ((i0) + (uint32_t)(u) * _T)
 
 /* ---- list slots for a batch of rows: rows of class c < 6 get consecutive slots from cursor[c], in ROW order
@@ -316,11 +320,11 @@ PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* cl
     }
 }
 
-/* logs whose one-pass admission check failed and were walked again: counted by the diagnostic build only (slot PTX_NCLK - 1 of the
+/* logs whose one-pass admission check failed and were walked again: counted by the diagnostic build only (slot PTX_CLK_EXACT_WALKS of the
  * phase clocks; tools/phase_profile.py prints it) */
 #define PTX_NOTE_EXACT_WALK()                                                                              \
     do {                                                                                                   \
-        if (kDiag && A.clocks && threadIdx.x == 0) atomicAdd(&A.clocks[PTX_NCLK - 1], 1ull);               \
+        if (kDiag && A.clocks && threadIdx.x == 0) atomicAdd(&A.clocks[PTX_CLK_EXACT_WALKS], 1ull);               \
     } while (0)
 
 /* only in the diagnostic build of the kernel (kDiag): phase cycle stamps and the early exit of the per-phase PMC runs */

@@ -201,7 +201,7 @@ class Engine:
         finally:
             self.lib.ptx_root_maps_free(C.byref(m))
 
-    def phase_cycles(self, dbatch, dresult, n=16):
+    def phase_cycles(self, dbatch, dresult, n=32):
         """Diagnostic: shader-clock cycles per phase of merge_core.h, summed over all workgroups."""
         out = (C.c_uint64 * n)()
         self._check(self.lib.ptx_merge_phase_cycles(self.ctx, dbatch, dresult, out, n))

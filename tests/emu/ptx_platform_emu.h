@@ -50,6 +50,7 @@ PTX_DEV void ptx_atomic_max64(unsigned long long* p, unsigned long long v) { if 
 PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
 PTX_DEV uint16_t ptx_coherent_load16(const uint16_t* p) { return *p; }
 PTX_DEV void ptx_coherent_store16(uint16_t* p, uint16_t v) { *p = v; }
+PTX_DEV uint32_t ptx_coherent_load32(const uint32_t* p) { return *p; }
 PTX_DEV void ptx_global_stores_done() {}
 /* append to a list: index of this element (valid only where pred) */
 PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }
@@ -58,6 +59,7 @@ PTX_DEV uint64_t ptx_clock() { return 0; }
 PTX_DEV uint32_t ptx_group_sum(uint32_t c) { return c; }
 /* batched parallel loop: PTX_U iterations per step so that their loads are all in flight together */
 #define PTX_FORU(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_U)
+#define PTX_FORV(i0, n, U) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += (U))
 #define PTX_IX(i0, u) ((i0) + (uint32_t)(u) < _n ? ptx_emu_ix((i0) + (uint32_t)(u), _n) : (i0) + (uint32_t)(u))
 
 /* ---- list slots for a batch of rows: rows of class c < 6 get consecutive slots from cursor[c], in ROW order

@@ -11,9 +11,10 @@ sys.path.insert(0, ROOT)
 from peritext_amd import abi, workloads  # noqa: E402
 from peritext_amd.engine import Engine  # noqa: E402
 
-PHASES = {0: "P0 admission", 1: "P1 row loop", 11: "P1 tail (census, dup, scan)", 2: "P3a index+parents", 12: "P3b scatter+checks", 3: "P3c child order", 4: "P3d tour",
-          14: "P3d ranking+unpark", 5: "P4 tombstones", 6: "P5a values", 13: "P5a mark intervals", 7: "P5c comments", 8: "P5b trees + P6 spans", 10: "end"}
-ORDER = [0, 1, 11, 2, 12, 3, 4, 14, 5, 6, 13, 7, 8]
+PHASES = {0: "P0 admission", 1: "P1 row loop", 11: "P1 tail (census, dup, scan)", 2: "P3a index+parents", 12: "P3b checks+scatter", 3: "P3c child order", 4: "P3d after()",
+          14: "P3d successor words", 16: "P3d jumping rounds", 17: "P3d positions", 18: "unpark marks", 5: "P4 tombstones", 6: "P5a values", 13: "P5a mark intervals",
+          7: "P5c comments", 8: "P5b trees + P6 spans", 10: "end"}
+ORDER = [0, 1, 11, 2, 12, 3, 4, 14, 16, 17, 18, 5, 6, 13, 7, 8]
 
 
 def main():
