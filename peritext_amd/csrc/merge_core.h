@@ -38,6 +38,7 @@
  *     into libperitext_hip.so and is never a fallback for the product path.
  */
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include <type_traits>
 #include "../../include/peritext_hip.h"
@@ -153,6 +154,10 @@ struct PtxHdr {
     unsigned long long clk[PTX_NCLK + 1];
 };
 
+/* LDS bytes of the header: the phase stamps are the diagnostic kernel's alone (its launch adds PTX_HDR_DIAG_EXTRA to the window) */
+#define PTX_HDR_BYTES ((uint32_t)((offsetof(PtxHdr, clk) + 15u) & ~15u))
+#define PTX_HDR_BYTES_DIAG ((uint32_t)((sizeof(PtxHdr) + 15u) & ~15u))
+#define PTX_HDR_DIAG_EXTRA (PTX_HDR_BYTES_DIAG - PTX_HDR_BYTES)
 #define PTX_NO_ERR 0xFFFFFFFFu
 /* the reference throws at the FIRST failing op in application order: keep the minimum position.
  * level 0 = change-level check (seq / deps, micromerge.ts:501-509), 1 = op-level (:752) */
@@ -280,9 +285,11 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
     (void)D; /* the row list of the deletes lives in HBM (the park), like the mark ops' between P1 and P5 */
     const uint64_t nw = (ks + 31) / 32, nwe = n / 32 + 1;
     const uint64_t elem = ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(4 * (nwe + 1)); /* recycled after P5a */
-    const uint64_t persist = ptx_a16(sizeof(PtxHdr)) + ptx_a16(4 * (K / 32 + 1)) + elem;
-    /* P1 .. P3: insert rows / sorted children + child counters (later the ranking words), keys / bucket members / successors, the parents with many children, the bitmap of a huge bucket */
-    const uint64_t p3 = ptx_a16(4 * (n + 3)) + ptx_a16(2 * (n + 2)) + ptx_a16(2 * (n / (PTX_SMALL_BUCKET + 1) + 2)) + ptx_a16(8 * (nwe + 1));
+    const uint64_t persist = PTX_HDR_BYTES + ptx_a16(4 * (K / 32 + 1)) + elem;
+    /* P1 .. P3: insert rows / sorted children + child counters (later the ranking words), keys / bucket members / successors, the parents with many children,
+     * the parents with two or more (later the bitmap of a huge bucket) */
+    const uint64_t aux_words = n / 4 + 1 > 2 * (nwe + 1) ? n / 4 + 1 : 2 * (nwe + 1);
+    const uint64_t p3 = ptx_a16(4 * (n + 3)) + ptx_a16(2 * (n + 2)) + ptx_a16(2 * (n / (PTX_SMALL_BUCKET + 1) + 2)) + ptx_a16(4 * aux_words);
     const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0; /* (the list of interval rows only takes what is left of the recycled region) */
     uint64_t T4 = PTX_TILE_4; /* the short-document tile is the visible length rounded up to a power of two: at most that of the inserts */
     if (n < T4) {
@@ -301,8 +308,8 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
 /* the same from a log header */
 /* P0 scratch on top of the header: per-actor table starts + the (actor, seq) -> change table */
 PTX_HD uint64_t ptx_lds_need_admission(uint64_t n_changes, uint64_t max_actors) {
-    if (max_actors <= 3) return ptx_a16(sizeof(PtxHdr)) + 2 * ptx_a16(4 * (1024 / 64 + 2)) + ptx_a16(4 * 12 * (1024 / 64 + 1)); /* per-wave clock totals and check records */
-    return ptx_a16(sizeof(PtxHdr)) + ptx_a16(4 * (max_actors + 2)) + ptx_a16(4 * (n_changes + 1));
+    if (max_actors <= 3) return PTX_HDR_BYTES + 2 * ptx_a16(4 * (1024 / 64 + 2)) + ptx_a16(4 * 12 * (1024 / 64 + 1)); /* per-wave clock totals and check records */
+    return PTX_HDR_BYTES + ptx_a16(4 * (max_actors + 2)) + ptx_a16(4 * (n_changes + 1));
 }
 PTX_HD uint64_t ptx_lds_need_hdr(uint64_t N, const ptx_log_hdr& h) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
@@ -568,11 +575,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         H->n_ins = H->n_applied = 0;
         H->V = H->S = H->I = 0;
         H->h1 = H->h2 = 0;
-        for (int k = 0; k <= PTX_NCLK; ++k) H->clk[k] = 0;
+        if (kDiag)
+            for (int k = 0; k <= PTX_NCLK; ++k) H->clk[k] = 0;
     }
     PtxBump bp;
     bp.base = lds;
-    bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
+    bp.off = (kDiag ? PTX_HDR_BYTES_DIAG : PTX_HDR_BYTES);
     bp.cap = A.lds_bytes;
     bp.high = bp.off;
     bp.overflow = false;
@@ -835,7 +843,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 }
             }
             PTX_SYNC_LDS();
-            bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
+            bp.off = (kDiag ? PTX_HDR_BYTES_DIAG : PTX_HDR_BYTES);
         } else if constexpr (!kManyActors) {
             /* this build of the kernel carries only the <= 3-actor admission; the host launches the other one */
             lds_high = bp.high;
@@ -904,7 +912,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         /* a failed admission stays pending in H->adm: an op-level error of an EARLIER row (found by the phases
          * below, which still run) wins over it, exactly as in a sequential replay */
         PTX_SYNC_LDS();
-        bp.off = (uint32_t)((sizeof(PtxHdr) + 15u) & ~15u);
+        bp.off = (kDiag ? PTX_HDR_BYTES_DIAG : PTX_HDR_BYTES);
         } /* na > 3 */
 #undef PTX_CHANGE_ROW
     }
@@ -975,7 +983,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     const bool small_keys = keyspace <= 65536u;
     uint16_t* klist = L;
     uint16_t* bigp = ptx_alloc<uint16_t>(bp, n / (PTX_SMALL_BUCKET + 1u) + 2); /* parents with more than PTX_SMALL_BUCKET children */
-    PtxBitWord* hb = ptx_alloc<PtxBitWord>(bp, nwe + 1);
+    /* parents with two or more children (at most half of the elements' parents); once they are sorted the same words hold the bitmap that ranks a huge bucket */
+    const uint32_t aux_words = n / 4u + 1u > 2u * (nwe + 1u) ? n / 4u + 1u : 2u * (nwe + 1u);
+    uint32_t* auxw = ptx_alloc<uint32_t>(bp, aux_words);
+    uint16_t* plist = (uint16_t*)auxw;
+    PtxBitWord* hb = (PtxBitWord*)auxw;
     PTX_BAIL_CAPACITY();
 
     /* P3a's loads, declared here because its first step is issued as soon as P1 has completed the lists (its latency then hides
@@ -1315,18 +1327,47 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     seg[(ptx_atomic_add(&cntw[pe[u] >> 1], 1u << (16u * (pe[u] & 1u))) >> (16u * (pe[u] & 1u))) & 0xFFFFu] = (uint16_t)PTX_IX(e0, u);
                 }
         }
-        PTX_LEADER { H->cur_big = 0; }
+        PTX_LEADER { H->cur_big = H->cur_med = 0; }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(3);
-        /* P3c: the children of every parent in descending element index == descending opId (the skip loop of micromerge.ts:630-635), one PARENT per lane:
-         * a bucket of up to PTX_SMALL_BUCKET members (all but a handful: most elements are an only child) is sorted in registers by a 19-exchange network;
-         * the parents with more go to a list: up to PTX_HUGE_BUCKET members by PTX_G lanes per member, larger ones (the children of HEAD in a document
-         * everybody types at the start of) through a bitmap over the element indices: rank = members with a larger index. */
-        PTX_FOR(p, n + 1) {
+        /* P3c: the children of every parent in descending element index == descending opId (the skip loop of micromerge.ts:630-635), one PARENT per lane.
+         * Pass 1, all parents: an only child (most elements are one) is placed at once, a parent with more goes to a list.  Pass 2, the listed parents: a
+         * bucket of up to PTX_SMALL_BUCKET members is sorted in registers by a 19-exchange network; up to PTX_HUGE_BUCKET members by PTX_G lanes per member,
+         * larger ones (the children of HEAD in a document everybody types at the start of) through a bitmap over the element indices: rank = members with a
+         * larger index.  (The network over ALL parents was measured: 2.6 k vector instructions per log, 10 % of the kernel's, for the fifth that need it.) */
+        {
+            const uint32_t steps1 = PTX_JSTEPS_U(n + 1u, PTX_UV);
+#pragma nounroll
+            for (uint32_t st = 0; st < steps1; ++st) { /* every thread runs every step: the list slots come from a wave-wide prefix sum */
+                uint32_t pp[PTX_UV], s1[PTX_UV], t1[PTX_UV], x1[PTX_UV], many = 0;
+#pragma unroll
+                for (int u = 0; u < PTX_UV; ++u) {
+                    const uint32_t j = PTX_J_OF_U(st, u, PTX_UV);
+                    const bool in = j < n + 1u;
+                    pp[u] = in ? PTX_JX(j, n + 1u) : 0u;
+                    s1[u] = in && pp[u] ? (uint32_t)cnt[pp[u] - 1u] : 0u;
+                    t1[u] = in ? (uint32_t)cnt[pp[u]] : 0u; /* (an item past the end: an empty bucket) */
+                }
+#pragma unroll
+                for (int u = 0; u < PTX_UV; ++u) x1[u] = seg[s1[u] < n ? s1[u] : 0u];
+#pragma unroll
+                for (int u = 0; u < PTX_UV; ++u) {
+                    if (t1[u] - s1[u] == 1u) srt[s1[u]] = (uint16_t)x1[u];
+                    many += t1[u] - s1[u] >= 2u ? 1u : 0u;
+                }
+                uint32_t at = ptx_append_n(&H->cur_med, many);
+#pragma unroll
+                for (int u = 0; u < PTX_UV; ++u)
+                    if (t1[u] - s1[u] >= 2u) plist[at++] = (uint16_t)pp[u];
+            }
+        }
+        PTX_SYNC_LDS();
+        PTX_FOR(h, H->cur_med) {
+            const uint32_t p = plist[h];
             const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
             const uint32_t m = t - s;
             static_assert(PTX_SMALL_BUCKET == 8u, "the exchange network below sorts eight");
-            if (m >= 1u && m <= PTX_SMALL_BUCKET) {
+            if (m <= PTX_SMALL_BUCKET) {
                 uint32_t v[8]; /* element index + 1 (0 = no member: sorts to the end) */
 #pragma unroll
                 for (uint32_t k = 0; k < 8u; ++k) v[k] = k < m ? (uint32_t)seg[s + k] + 1u : 0u;
@@ -1342,9 +1383,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #pragma unroll
                 for (uint32_t k = 0; k < 8u; ++k)
                     if (k < m) srt[s + k] = (uint16_t)(v[k] - 1u);
+            } else {
+                const uint32_t jb = ptx_append(&H->cur_big, true);
+                bigp[jb] = (uint16_t)p;
             }
-            const uint32_t jb = ptx_append(&H->cur_big, m > PTX_SMALL_BUCKET);
-            if (m > PTX_SMALL_BUCKET) bigp[jb] = (uint16_t)p;
         }
         PTX_SYNC_LDS();
         {

@@ -1052,8 +1052,10 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
         hipStream_t st = part && fork ? ctx->side : ctx->stream;
         if (part == 2)
             hipLaunchKernelGGL(ptx_merge_big_kernel, dim3(grid), dim3(PTX_BIG_THREADS), (uint32_t)ptx_a16(sizeof(PtxHdr)), st, A);
-        else if (diag)
-            hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), lds, st, A);
+        else if (diag) { /* + room for its phase stamps in the header */
+            A.lds_bytes = std::min<uint32_t>(lds + PTX_HDR_DIAG_EXTRA, (uint32_t)ctx->max_lds);
+            hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), A.lds_bytes, st, A);
+        }
         else if (admit && b->max_actors > 3)
             hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);
         else {

@@ -67,6 +67,17 @@ PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) {
     b = (uint32_t)__shfl((int)b, (int)leader, 64);
     return b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
+/* the same for a COUNT per lane (0 .. ): the lane's first slot; one DPP prefix sum and one LDS atomic per wave.  Every lane of the wave must call it
+ * (uniform control flow). */
+PTX_DEV uint32_t ptx_wave_incl_scan(uint32_t v);
+PTX_DEV uint32_t ptx_append_n(uint32_t* cursor, uint32_t count) {
+    const uint32_t incl = ptx_wave_incl_scan(count);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t b = 0;
+    if ((threadIdx.x & 63u) == 0u && total) b = atomicAdd(cursor, total);
+    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    return b + incl - count;
+}
 PTX_DEV uint64_t ptx_clock() { return (uint64_t)__builtin_readcyclecounter(); }
 #define PTX_G 8u /* lanes that share one member of a large child bucket */
 PTX_DEV uint32_t ptx_group_sum(uint32_t c) {
@@ -328,14 +339,20 @@ PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* cl
     } while (0)
 
 /* only in the diagnostic build of the kernel (kDiag): phase cycle stamps and the early exit of the per-phase PMC runs */
+#ifdef PTX_DIAG /* the early exits cost the diagnostic kernel 35 VGPRs (its stamps would then be taken at 4 waves per SIMD): only in the builds that ask for them */
+#define PTX_STOP_AFTER(k)                                              \
+    if ((k) != 0 && A.stop_after == (k)) {                             \
+        lds_high = bp.high;                                            \
+        return PTX_OK;                                                 \
+    }
+#else
+#define PTX_STOP_AFTER(k)
+#endif
 #define PTX_STAMP(k)                                                   \
     do {                                                               \
         if (kDiag) {                                                   \
             if (A.clocks && threadIdx.x == 0) H->clk[k] = ptx_clock(); \
-            if ((k) != 0 && A.stop_after == (k)) {                     \
-                lds_high = bp.high;                                    \
-                return PTX_OK;                                         \
-            }                                                          \
+            PTX_STOP_AFTER(k)                                          \
         }                                                              \
     } while (0)
 

@@ -54,6 +54,7 @@ PTX_DEV uint32_t ptx_coherent_load32(const uint32_t* p) { return *p; }
 PTX_DEV void ptx_global_stores_done() {}
 /* append to a list: index of this element (valid only where pred) */
 PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }
+PTX_DEV uint32_t ptx_append_n(uint32_t* cursor, uint32_t count) { const uint32_t b = *cursor; *cursor += count; return b; }
 PTX_DEV uint64_t ptx_clock() { return 0; }
 #define PTX_G 1u
 PTX_DEV uint32_t ptx_group_sum(uint32_t c) { return c; }
