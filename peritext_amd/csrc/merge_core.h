@@ -122,7 +122,7 @@ struct PtxMergeArgs {
 #define PTX_TILE_4 128u  /* visible chars up to which the four LWW trees are resident at once */
 #define PTX_TILE_1 512u  /* tile of the visible axis for longer documents (one tree, reused per mark type) */
 #define PTX_SMALL_BUCKET 8u  /* child buckets up to this size: one lane per member */
-#define PTX_HUGE_BUCKET 32u  /* beyond this size: bitmap ranking, one bucket at a time */
+#define PTX_HUGE_BUCKET 256u /* beyond this size: bitmap ranking, one bucket at a time */
 
 /* ---- digest: 128-bit multiset hash of the canonical output (restated in peritext_amd/canon.py) ---- */
 PTX_DEV uint64_t ptx_fmix64(uint64_t x) {
@@ -290,17 +290,20 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
      * the parents with two or more (later the bitmap of a huge bucket) */
     const uint64_t aux_words = n / 4 + 1 > 2 * (nwe + 1) ? n / 4 + 1 : 2 * (nwe + 1);
     const uint64_t p3 = ptx_a16(4 * (n + 3)) + ptx_a16(2 * (n + 2)) + ptx_a16(2 * (n / (PTX_SMALL_BUCKET + 1) + 2)) + ptx_a16(4 * aux_words);
-    const uint64_t comments = Kc ? ptx_overflow3(elem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0; /* (the list of interval rows only takes what is left of the recycled region) */
+    /* the tail phases take the recycled element region first (the list of the live mark ops only what their worst case leaves of it) */
+    const uint64_t rem = elem;
+    const uint64_t comments = Kc ? ptx_overflow3(rem, 4 * (Kid + 1), 4 * (Kid + 1), 8 * (Kc + 1)) : 0; /* (the list of interval rows only takes what is left of the recycled region) */
     uint64_t T4 = PTX_TILE_4; /* the short-document tile is the visible length rounded up to a power of two: at most that of the inserts */
     if (n < T4) {
         T4 = 1;
         while (T4 < n) T4 <<= 1;
     }
     const uint64_t T1 = PTX_TILE_1;
-    const uint64_t trees4 = ptx_overflow3(elem, K ? 4 * 4 * 2 * T4 : 0, 4 * (T4 + 1), 8 * (T4 / 32 + 2)); /* no mark ops: no trees */
-    const uint64_t trees1 = n > PTX_TILE_4 ? ptx_overflow3(elem, K ? 4 * 2 * T1 : 0, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
+    const uint64_t trees4 = ptx_overflow3(rem, K ? 4 * 4 * 2 * T4 : 0, 4 * (T4 + 1), 8 * (T4 / 32 + 2)); /* no mark ops: no trees */
+    const uint64_t trees1 = n > PTX_TILE_4 ? ptx_overflow3(rem, K ? 4 * 2 * T1 : 0, 4 * (T1 + 1), 8 * (T1 / 32 + 2)) : 0;
     uint64_t tail = comments > trees4 ? comments : trees4;
     if (trees1 > tail) tail = trees1;
+
     /* P5: mark rows / interval starts, alive bits, comment breaks, interval ends, comment ids + the tail phases' overflow */
     const uint64_t p5 = ptx_a16(2 * (K + 1)) + ptx_a16(8 * (nwe + 1)) + ptx_a16(4 * (nwe + 1)) + ptx_a16(2 * (K + 1)) + ptx_a16(2 * (Kc + 1)) + tail;
     return persist + (p3 > p5 ? p3 : p5);
@@ -1394,14 +1397,20 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             for (uint32_t h = 0; h < nb; ++h) { /* uniform: nb and the bucket bounds come from LDS after the barrier */
                 const uint32_t p = bigp[h];
                 const uint32_t s = p ? cnt[p - 1] : 0u, t = cnt[p];
-                if (t - s <= PTX_HUGE_BUCKET) {
-                    PTX_FOR(w, (t - s) * PTX_G) {
-                        const uint32_t k = w / PTX_G, g = w % PTX_G;
+                if (t - s <= PTX_HUGE_BUCKET) { /* a lane per member; the members it is compared with are the same words in every lane, eight reads in flight */
+                    PTX_FOR(k, t - s) {
                         const uint32_t x = seg[s + k];
-                        uint32_t c = 0;
-                        for (uint32_t q = s + g; q < t; q += PTX_G) c += seg[q] > x ? 1u : 0u;
-                        c = ptx_group_sum(c);
-                        if (g == 0) srt[s + c] = (uint16_t)x;
+                        uint32_t c = 0, q = s;
+#pragma nounroll
+                        for (; q + 8u <= t; q += 8u) {
+                            uint32_t y[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) y[u] = seg[q + (uint32_t)u];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) c += y[u] > x ? 1u : 0u;
+                        }
+                        for (; q < t; ++q) c += seg[q] > x ? 1u : 0u;
+                        srt[s + c] = (uint16_t)x;
                     }
                     continue;
                 }
@@ -1754,6 +1763,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
 #undef PTX_MARK_LOAD
     }
+    PTX_LEADER { H->cur_med = 0; } /* (the cursor of the list of live mark ops, below; the barriers of the error check stand in between) */
     PTX_BAIL_IF_ERROR();
     if (H->adm != PTX_NO_ERR) { /* no op-level error anywhere: the failed admission is the log's error */
         lds_high = bp.high;
@@ -1769,6 +1779,51 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     bd.high = 0;
     bd.overflow = false;
     PTX_STAMP(7);
+    /* the mark ops that still cover a visible character (a tenth of them in a document that has seen thousands of ops and shows a few dozen characters):
+     * the comment rule and the LWW trees of a short document walk this list instead of every mark op */
+    /* The list takes what the recycled element region has left once the worst case of the tail phases (the comments' tables, the trees) is set aside — so
+     * that it never costs a byte of the log's LDS window; a log with more live mark ops than that (rare) walks all its mark ops as before. */
+    uint32_t live_cap = 0;
+    {
+        const uint32_t t4 = n < PTX_TILE_4 ? (n ? 1u << ptx_ceil_log2(n) : 1u) : PTX_TILE_4;
+        const uint32_t need_c = Kc ? 2u * (uint32_t)ptx_a16(4u * (Kid + 1u)) + (uint32_t)ptx_a16(8u * (Kc + 1u)) : 0u;
+        const uint32_t need_4 = (uint32_t)(ptx_a16(K ? 4u * 4u * 2u * t4 : 0u) + ptx_a16(4u * (t4 + 1u)) + ptx_a16(8u * (t4 / 32u + 2u)));
+        const uint32_t need_1 = n > PTX_TILE_4 ? (uint32_t)(ptx_a16(K ? 4u * 2u * PTX_TILE_1 : 0u) + ptx_a16(4u * (PTX_TILE_1 + 1u)) + ptx_a16(8u * (PTX_TILE_1 / 32u + 2u))) : 0u;
+        uint32_t reserve = need_c > need_4 ? need_c : need_4;
+        if (need_1 > reserve) reserve = need_1;
+        const uint32_t room = mark_lds - elem_lds;
+        live_cap = room > reserve + 32u ? (room - reserve - 32u) / 2u : 0u;
+        if (live_cap > K) live_cap = K;
+    }
+    uint16_t* live = ptx_alloc2<uint16_t>(bd, bp, live_cap + 1);
+    PTX_BAIL_CAPACITY();
+    {
+        const uint32_t steps = PTX_JSTEPS_U(K, PTX_UV);
+#pragma nounroll
+        for (uint32_t st = 0; st < steps; ++st) { /* every thread runs every step: the list slots come from a wave-wide prefix sum */
+            uint32_t kk[PTX_UV], lo_[PTX_UV], hi_[PTX_UV], cnt_ = 0;
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u) {
+                const uint32_t j = PTX_J_OF_U(st, u, PTX_UV);
+                kk[u] = j < K ? PTX_JX(j, K) : K; /* (entry K of the interval arrays is spare) */
+                lo_[u] = mrk_lo[kk[u]];
+                hi_[u] = mrk_hi[kk[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u) cnt_ += kk[u] < K && lo_[u] < hi_[u] ? 1u : 0u;
+            uint32_t at = ptx_append_n(&H->cur_med, cnt_);
+#pragma unroll
+            for (int u = 0; u < PTX_UV; ++u)
+                if (kk[u] < K && lo_[u] < hi_[u]) {
+                    if (at < live_cap) live[at] = (uint16_t)kk[u];
+                    ++at;
+                }
+        }
+    }
+    PTX_SYNC_LDS();
+    const bool use_live = H->cur_med <= live_cap; /* else: the list is incomplete, every mark op is looked at */
+    const uint32_t nlive = use_live ? H->cur_med : 0u;
+    const uint32_t live_lds = bd.off, live_top = bp.off; /* (the list stays until the end: the scratch of the tail phases is released down to here) */
 
     /* ---- P5c: comments: per id, presence intervals decided by the last-applied covering op ---- */
     if (Kc > 0) {
@@ -1782,16 +1837,17 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             ccur[c] = 0;
         }
         PTX_SYNC_LDS();
-        PTX_FOR(kc, Kc) {
-            const uint32_t k = moff2 + kc;
-            if (mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[cid[kc]], 1u);
+        const uint32_t c_items = use_live ? nlive : Kc; /* the live mark ops, or (no list) every comment op */
+        PTX_FOR(j, c_items) {
+            const uint32_t k = use_live ? (uint32_t)live[j] : moff2 + j;
+            if (k >= moff2 && k < moff3 && mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[cid[k - moff2]], 1u);
         }
         PTX_SYNC_LDS();
         ptx_scan_excl<uint32_t, 1, kThreads>(ccnt, Kid + 1, H->scan_tmp, A.div_magic); /* ccnt[c] = first entry of id c, ccnt[Kid] = total */
-        PTX_FOR(kc, Kc) {
-            const uint32_t k = moff2 + kc;
-            if (mrk_lo[k] < mrk_hi[k]) {
-                const uint32_t c = cid[kc];
+        PTX_FOR(j, c_items) {
+            const uint32_t k = use_live ? (uint32_t)live[j] : moff2 + j;
+            if (k >= moff2 && k < moff3 && mrk_lo[k] < mrk_hi[k]) {
+                const uint32_t c = cid[k - moff2];
                 const uint32_t pos = ccnt[c] + ptx_atomic_add(&ccur[c], 1u);
                 PtxCEntry e;
                 e.lo = mrk_lo[k];
@@ -1847,8 +1903,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         ptx_digest_flush(H, h1, h2);
         PTX_SYNC_LDS();
     }
-    bp.off = mark2_lds; /* release the comment scratch */
-    bd.off = elem_lds;
+    bp.off = live_top; /* release the comment scratch */
+    bd.off = live_lds;
     PTX_STAMP(8);
 
     /* ---- P5b + P6: LWW winners per visible char, spans, digest — in tiles of the visible axis ----
@@ -1892,8 +1948,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 /* PTX_UB mark ops per thread and step: the opIds of those that still cover a visible char (LWW order = opId order;
                  * the comment tree only records "some comment op covers") are gathered together — one round trip to HBM per
                  * step instead of one per op */
-                /* all four types at once: the ops in row order (blocks, as in P5a); one type at a time: its run is in row order */
-                const uint32_t kn = k_hi - k_lo, b_steps = four ? PTX_JB_STEPS(MB.B, PTX_UB) : PTX_JSTEPS_U(kn, PTX_UB);
+                /* all four types at once: the live ops; one type at a time: its run, in row order */
+                const bool by_list = four && use_live;
+                const uint32_t kn = k_hi - k_lo, b_steps = by_list ? PTX_JSTEPS_U(nlive, PTX_UB) : PTX_JSTEPS_U(kn, PTX_UB);
                 /* two register sets in turn: the opId gathers of the next step are in flight while this step's ranges go into the trees */
                 uint32_t kq_a[PTX_UB], lo_a[PTX_UB], hi_a[PTX_UB], kq_b[PTX_UB], lo_b[PTX_UB], hi_b[PTX_UB];
                 uint32_t idq_a[PTX_UB], idq_b[PTX_UB]; /* the park entry of the op: row | id key << 16 */
@@ -1902,8 +1959,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     for (int u = 0; u < (int)PTX_UB; ++u) {
                         uint32_t k;
                         bool has;
-                        if (four) has = ptx_mark_of(MB, PTX_JB_BLOCK(st, u, PTX_UB), PTX_JB_LANE(st, u, PTX_UB), k);
-                        else {
+                        if (by_list) { /* a short document: the live mark ops, all four types at once */
+                            const uint32_t j = PTX_J_OF_U(st, u, PTX_UB);
+                            has = j < nlive;
+                            k = live[has ? PTX_JX(j, nlive) : 0u];
+                        } else {
                             const uint32_t j = PTX_J_OF_U(st, u, PTX_UB);
                             has = j < kn;
                             k = k_lo + (has ? PTX_JX(j, kn) : 0u);

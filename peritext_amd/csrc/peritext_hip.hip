@@ -43,7 +43,10 @@
  * profiles/r03_p_*) a kernel of up to 96 SGPRs (vcc etc. included) holds 7 waves per SIMD, one of 98 or more holds 6 — 24 waves per CU, i.e. exactly the
  * eight 3-wave logs that the LDS window of a 4 096-op log allows anyway.  Where the LDS would allow more waves than 24 (short logs), the host launches
  * the "_w7" builds: the same body held to 90 SGPRs (+ vcc ...; costs ~70 more SGPR spills into VGPR lanes, 1-2 % at equal occupancy). */
-#define PTX_SGPRS_W7 __attribute__((amdgpu_num_sgpr(90)))
+#ifndef PTX_W7_SGPRS
+#define PTX_W7_SGPRS 96 /* (granted: 94 with vcc etc. — the last count that still holds 7 waves per SIMD; 90 cost 50 more spills) */
+#endif
+#define PTX_SGPRS_W7 __attribute__((amdgpu_num_sgpr(PTX_W7_SGPRS)))
 #define PTX_MERGE_KERNEL(name, T, W, MANY, KT, DIAG) PTX_MERGE_KERNEL_A(name, T, W, MANY, KT, DIAG, )
 #define PTX_MERGE_KERNEL_A(name, T, W, MANY, KT, DIAG, PTX_SGPR_CAP)                                     \
     extern "C" __global__ void __launch_bounds__(T, W) PTX_SGPR_CAP name(PtxMergeArgs A) { \

@@ -415,11 +415,11 @@ def edge_case_docs():
     ]
 
 
-def huge_bucket_log():
-    """70 inserts at index 0 (all children of HEAD: the bitmap-ranked bucket path) interleaved with children of other elements,
-    deletes and a mark."""
+def huge_bucket_log(n_head=70):
+    """n_head inserts at index 0 (all children of HEAD: 70 take the lane-per-member ranking of a large bucket, more than 256 the bitmap-ranked path)
+    interleaved with children of other elements, deletes and a mark."""
     ops = []
-    for k in range(70):
+    for k in range(n_head):
         ops.append({"action": "set", "insert": True, "elemId": "_head", "value": "abcdefghij"[k % 10]})
         if k % 7 == 0:
             ops.append({"action": "set", "insert": True, "elemId": "3@a", "value": "X"})  # siblings under 'B': a medium bucket

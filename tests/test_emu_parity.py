@@ -236,6 +236,9 @@ def test_huge_sibling_bucket_prepends(reverse):
     exp = H.oracle_apply([[log]])[0][0]
     H.check_log(batch, res, 0, exp)
     assert len(exp["text"]) == 5 + 70 + 10 + 8 + 11 - 1
+    big = H.huge_bucket_log(n_head=300)  # beyond PTX_HUGE_BUCKET members: ranked through the bitmap over the element indices
+    b2 = wire.encode_docs([[big]])
+    H.check_log(b2, H.emu_merge(b2, reverse=reverse), 0, H.oracle_apply([[big]])[0][0])
 
 
 def _expected_status(exp):

@@ -68,6 +68,10 @@ def test_huge_sibling_bucket(eng, golden):
     batch = wire.encode_docs([[log]])
     res = eng.apply_materialize(batch)
     H.check_log(batch, res, 0, golden["huge_bucket"][0][0])
+    if H.have_node():  # beyond PTX_HUGE_BUCKET (256) children of HEAD: the bitmap-ranked path, against a live run of the oracle
+        big = H.huge_bucket_log(n_head=300)
+        b2 = wire.encode_docs([[big]])
+        H.check_log(b2, eng.apply_materialize(b2), 0, H.oracle_apply([[big]])[0][0])
 
 
 def test_duplicate_op_id(eng):
