@@ -196,6 +196,43 @@ PTX_DEV int ptx_bitrank_if_set(const PtxBitWord* b, uint32_t pos) {
     return (int)(w.pre + ptx_popc(w.bits & ((1u << s) - 1u)));
 }
 PTX_DEV bool ptx_bittest(const uint32_t* bits, uint32_t pos) { return (bits[pos >> 5] >> (pos & 31)) & 1u; }
+/* pre = exclusive popcount prefix over m bit words, by ONE wave (64 words per step: a DPP prefix sum, no barrier inside); every thread calls it, it ends
+ * with the barrier that publishes the words and returns the total.  tmp: one LDS word of the CALL SITE's own (a thread that is slow to read the total must
+ * not find the next prefix's there; H->scan_tmp[16 ..], the block-wide scan uses the words below) */
+PTX_DEV uint32_t ptx_bitwords_prefix(PtxBitWord* b, uint32_t m, uint32_t* tmp) {
+    PTX_ONE_WAVE {
+        uint32_t run = 0;
+#pragma nounroll
+        for (uint32_t w0 = 0; w0 < m; w0 += PTX_WS) {
+            const uint32_t w = w0 + PTX_LANE_ID;
+            const uint32_t c = w < m ? ptx_popc(b[w].bits) : 0u;
+            const uint32_t incl = ptx_wave_incl_scan(c);
+            if (w < m) b[w].pre = run + incl - c;
+            run += ptx_wave_last(incl);
+        }
+        if (PTX_LANE_ID == 0u) *tmp = run;
+    }
+    PTX_SYNC_LDS();
+    return *tmp;
+}
+/* the same for a plain array of counts: in place, exclusive; returns the total */
+template <class T>
+PTX_DEV uint32_t ptx_counts_prefix(T* a, uint32_t m, uint32_t* tmp) {
+    PTX_ONE_WAVE {
+        uint32_t run = 0;
+#pragma nounroll
+        for (uint32_t w0 = 0; w0 < m; w0 += PTX_WS) {
+            const uint32_t w = w0 + PTX_LANE_ID;
+            const uint32_t c = w < m ? (uint32_t)a[w] : 0u;
+            const uint32_t incl = ptx_wave_incl_scan(c);
+            if (w < m) a[w] = (T)(run + incl - c);
+            run += ptx_wave_last(incl);
+        }
+        if (PTX_LANE_ID == 0u) *tmp = run;
+    }
+    PTX_SYNC_LDS();
+    return *tmp;
+}
 
 /* ---- elemId -> element index ---- */
 struct PtxElemIndex {
@@ -1203,9 +1240,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             /* (which of two equal ids is "the repeat" depends on the race; the status is what is reported) */
         }
         PTX_SYNC_LDS();
-        PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
-        PTX_SYNC_LDS();
-        ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp, A.div_magic);
+        ptx_bitwords_prefix(ix.ib, nw + 1, &H->scan_tmp[16]);
     }
     PTX_BAIL_IF_ERROR();
     PTX_STAMP(2);
@@ -1426,9 +1461,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     ptx_atomic_or(&hb[x >> 5].bits, 1u << (x & 31));
                 }
                 PTX_SYNC_LDS();
-                PTX_FOR(w, nwe + 1) hb[w].pre = ptx_popc(hb[w].bits);
-                PTX_SYNC_LDS();
-                ptx_scan_excl<uint32_t, 2, kThreads>(&hb[0].pre, nwe + 1, H->scan_tmp, A.div_magic);
+                ptx_bitwords_prefix(hb, nwe + 1, &H->scan_tmp[17]);
                 PTX_FOR(k, t - s) {
                     const uint32_t x = seg[s + k];
                     srt[s + (t - s - 1u - ptx_bitrank(hb, x))] = (uint16_t)x; /* members with a larger index come first */
@@ -1540,17 +1573,21 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_SYNC_LDS();
             PTX_STAMP(17); /* the walks are over */
             const uint32_t rounds = ptx_ceil_log2(ns + 1);
+            /* in-place pointer jumping: every intermediate {next, weight} word is a valid state (weight = elements in [node, next)), so reading a word
+             * another lane already advanced this round only makes the jump longer.  The few splitters are ONE wave's work: its lanes talk through the LDS
+             * in program order, so the rounds need no barrier (the other waves wait at the one below) */
+            PTX_ONE_WAVE {
 #pragma nounroll
-            for (uint32_t r = 0; r < rounds; ++r) {
-                /* in-place pointer jumping: every intermediate {next, weight} word is a valid state (weight = elements in [node, next)), so reading a word
-                 * another thread already advanced this round only makes the jump longer */
-                PTX_FOR(sp, ns) {
-                    const uint32_t a = R[sp];
-                    const uint32_t b = R[a >> 16];
-                    R[sp] = (b & 0xFFFF0000u) | ((a + b) & 0xFFFFu);
+                for (uint32_t r = 0; r < rounds; ++r) {
+                    PTX_FOR_LANES(sp, ns) {
+                        const uint32_t a = R[sp];
+                        const uint32_t b = R[a >> 16];
+                        R[sp] = (b & 0xFFFF0000u) | ((a + b) & 0xFFFFu);
+                    }
+                    PTX_WSYNC();
                 }
-                PTX_SYNC_LDS();
             }
+            PTX_SYNC_LDS();
             /* elements from x to the end of the document = suffix of x's splitter - elements before x in its segment */
             PTX_FORV(x0, n, PTX_UV) { /* document position incl. tombstones */
                 uint32_t sp[PTX_UV], lc[PTX_UV], a[PTX_UV];
@@ -1649,9 +1686,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         ptx_atomic_or(&alive[r >> 5].bits, 1u << (r & 31));
     });
     PTX_SYNC_LDS();
-    PTX_FOR(w, nwv + 1) alive[w].pre = ptx_popc(alive[w].bits);
-    PTX_SYNC_LDS();
-    const uint32_t V = ptx_scan_excl<uint32_t, 2, kThreads>(&alive[0].pre, nwv + 1, H->scan_tmp, A.div_magic);
+    const uint32_t V = ptx_bitwords_prefix(alive, nwv + 1, &H->scan_tmp[18]);
     /* the visible interval [lo, hi) of every mark op.  `lo` takes the place of the op's row in `mlist`: P5a's thread has consumed the row when it stores the
      * interval (same thread, same index), and the few later uses of a row — the ops that still cover a visible character — read it from the park.  Until the
      * marks are looked at, the space of `hi` and of the comment ids holds the rows of the visible elements (vrow) if they fit */
@@ -1843,7 +1878,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             if (k >= moff2 && k < moff3 && mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[cid[k - moff2]], 1u);
         }
         PTX_SYNC_LDS();
-        ptx_scan_excl<uint32_t, 1, kThreads>(ccnt, Kid + 1, H->scan_tmp, A.div_magic); /* ccnt[c] = first entry of id c, ccnt[Kid] = total */
+        ptx_counts_prefix(ccnt, Kid + 1, &H->scan_tmp[20]); /* ccnt[c] = first entry of id c, ccnt[Kid] = total */
         PTX_FOR(j, c_items) {
             const uint32_t k = use_live ? (uint32_t)live[j] : moff2 + j;
             if (k >= moff2 && k < moff3 && mrk_lo[k] < mrk_hi[k]) {
@@ -1862,7 +1897,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             cicnt[c] = c < Kid ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         }
         PTX_SYNC_LDS();
-        const uint32_t I = ptx_scan_excl<uint32_t, 1, kThreads>(cicnt, Kid + 1, H->scan_tmp, A.div_magic);
+        const uint32_t I = ptx_counts_prefix(cicnt, Kid + 1, &H->scan_tmp[21]);
         PTX_LEADER { H->I = I; }
         /* the interval rows: first into LDS by the per-id sweeps (a lane per id, ragged), then out — rows, break bits and digest — by a dense pass (the
          * digest is ~100 vector instructions per item and wave: it must not sit inside the ragged loop) */
@@ -2031,9 +2066,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 if (is_start) ptx_atomic_or(&st[q >> 5].bits, 1u << (q & 31));
             }
             PTX_SYNC_LDS();
-            PTX_FOR(w, TV / 32 + 2) st[w].pre = ptx_popc(st[w].bits);
-            PTX_SYNC_LDS();
-            const uint32_t S_tile = ptx_scan_excl<uint32_t, 2, kThreads>(&st[0].pre, TV / 32 + 2, H->scan_tmp, A.div_magic);
+            const uint32_t S_tile = ptx_bitwords_prefix(st, TV / 32 + 2, &H->scan_tmp[19]);
             PTX_FOR(q, tv) {
                 const PtxBitWord w = st[q >> 5];
                 if ((w.bits >> (q & 31)) & 1u) {

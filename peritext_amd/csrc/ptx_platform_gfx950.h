@@ -40,6 +40,11 @@
 #define PTX_BLOCKDIM (kThreads ? kThreads : blockDim.x)
 #define PTX_FOR(i, n) _Pragma("nounroll") for (uint32_t i = threadIdx.x, _n = (n); i < _n; i += PTX_BLOCKDIM)
 #define PTX_LEADER if (threadIdx.x == 0)
+/* a section that ONE wave of the workgroup runs (the others go on to the next barrier), and its loop over items, a lane each: for the phases of a few dozen
+ * items, whose steps then need no s_barrier — PTX_WSYNC() orders the wave's own LDS accesses */
+#define PTX_ONE_WAVE if (threadIdx.x < 64u)
+#define PTX_LANE_ID (threadIdx.x & 63u)
+#define PTX_FOR_LANES(i, n) _Pragma("nounroll") for (uint32_t i = threadIdx.x, _n = (n); i < _n; i += 64u)
 PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
 PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }

@@ -39,6 +39,9 @@ static inline uint32_t ptx_emu_ix(uint32_t k, uint32_t n) { /* k-th iteration ru
     for (uint32_t _n = (n), _k = 0, i = (_n ? ptx_emu_ix(0, _n) : 0); _k < _n;                    \
          ++_k, i = (_k < _n ? ptx_emu_ix(_k, _n) : 0))
 #define PTX_LEADER if (true)
+#define PTX_ONE_WAVE if (true)
+#define PTX_LANE_ID 0u
+#define PTX_FOR_LANES(i, n) PTX_FOR(i, n)
 PTX_DEV uint32_t ptx_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 PTX_DEV uint32_t ptx_atomic_and(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o & v; return o; }
 PTX_DEV uint32_t ptx_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
