@@ -1830,7 +1830,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         live_cap = room > reserve + 32u ? (room - reserve - 32u) / 2u : 0u;
         if (live_cap > K) live_cap = K;
     }
-    uint16_t* live = ptx_alloc2<uint16_t>(bd, bp, live_cap + 1);
+    uint16_t* live = live_cap ? ptx_alloc2<uint16_t>(bd, bp, live_cap + 1) : (uint16_t*)lds; /* (no room: no list, not a byte taken — and nothing read through it) */
     PTX_BAIL_CAPACITY();
     {
         const uint32_t steps = PTX_JSTEPS_U(K, PTX_UV);

@@ -522,6 +522,24 @@ def test_lds_bound_covers_the_high_water_mark(name):
         assert used <= need <= used + 6144 + parked, (log, used, need)  # slack = the LWW trees sized for V = n
 
 
+def test_lds_bound_covers_small_and_lopsided_logs():
+    """The same for hand-written logs whose element region is too small for the scratch of the tail phases (a handful of inserts, trees larger than everything
+    else), for a log of 300 children of HEAD, and for the edge-case documents: the GPU suite runs them in the window the bound gives."""
+    import ctypes as C
+
+    lib = H._emu(H.EMU_LIB)
+    lib.ptx_emu_lds_need.restype = C.c_uint64
+    lib.ptx_emu_lds_need.argtypes = [C.c_uint64] * 7
+    docs = [[H.huge_bucket_log()], [H.huge_bucket_log(300)]] + H.edge_case_docs() + H.unsynced_docs() + H.more_deletes_than_inserts_docs()
+    batch = wire.encode_docs(docs)
+    res = H.emu_merge(batch)
+    for log in range(batch.n_logs):
+        h = batch.log_hdr[log]
+        need = lib.ptx_emu_lds_need(int(batch.log_off[log + 1] - batch.log_off[log]), int(h["n_ins"]), int(h["n_del"]), int(h["n_mark"].sum()),
+                                    int(h["n_mark"][2]), (int(h["max_counter"]) + 1) * (int(h["max_actor"]) + 1), int(h["n_comment_ids"]))
+        assert int(res.logs["reserved"][log][0]) <= need, (log, int(res.logs["reserved"][log][0]), need)
+
+
 @pytest.mark.parametrize("reverse", [0, 1, 2])
 def test_malformed_rows_are_named(reverse):
     """Unknown action / mark type, op ids of counter 0 or beyond the header's bounds, a header that promises fewer rows than the
