@@ -230,12 +230,22 @@ def main():
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    # Fewer GPUs than ranks (a one-GPU box running the N > 1 path as a test: tests/test_gpu_bench_ranks.py): the ranks share the GPUs, and torch's side channel
+    # — the 128-byte communicator id, the barriers, the max over ranks of the timings — goes over gloo on the host (torch's NCCL refuses two ranks on one
+    # device).  The data-path collective is the library's either way (ptx_allgather_digests); with PTX_RCCL_LIB the library binds it from that path.
+    n_dev = torch.cuda.device_count()
+    shared_gpus = world > n_dev
+    local = local % n_dev
     torch.cuda.set_device(local)
+    side = "cpu" if shared_gpus else "cuda"  # where the side channel's small tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+        if shared_gpus:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
 
     from peritext_amd import abi, shard, wire, workloads
     from peritext_amd.engine import Engine
@@ -272,7 +282,9 @@ def main():
     if world > 1 and not args.host_sync_step:
         # the digest all-gather lives in the C ABI (ptx_allgather_digests: RCCL bound inside libperitext_hip.so); torch.distributed
         # only carries the 128-byte communicator id from rank 0 to the others
-        uid = torch.tensor(list(eng.comm_unique_id()) if rank == 0 else [0] * abi.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if os.environ.get("PTX_RCCL_LIB"):
+            eng.comm_use_library(os.environ["PTX_RCCL_LIB"])
+        uid = torch.tensor(list(eng.comm_unique_id()) if rank == 0 else [0] * abi.COMM_ID_BYTES, dtype=torch.uint8, device=side)
         dist.broadcast(uid, 0)
         comm = eng.comm_init(bytes(uid.cpu().tolist()), rank, world)
 
@@ -327,7 +339,7 @@ def main():
     if stream is not None:
         kernel_ms = [a.elapsed_time(b) for a, b in events]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=side)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     converged_docs = int(conv.item())
@@ -338,7 +350,7 @@ def main():
     if args.sustain_s > 0:
         n_sus = max(args.steps, int(args.sustain_s / max(elapsed / args.steps, 1e-6)) + 1)
         if world > 1:
-            t = torch.tensor([n_sus], dtype=torch.int64, device="cuda")
+            t = torch.tensor([n_sus], dtype=torch.int64, device=side)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             n_sus = int(t.item())
         events.clear()
@@ -350,7 +362,7 @@ def main():
         if stream is not None:
             sus_ms = [a.elapsed_time(b) for a, b in events]
         if world > 1:
-            t = torch.tensor([sus_elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([sus_elapsed], dtype=torch.float64, device=side)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sus_elapsed = float(t.item())
         third = max(1, n_sus // 3)
@@ -447,7 +459,8 @@ def main():
                 "ops_this_gpu_per_step": ops_per_step,
                 "op_log_bytes_this_gpu": 32 * rows,
                 "changes_this_gpu": n_changes,
-                "parallelism": "doc-sharded x%d, digests-only all-gather (ptx_allgather_digests: RCCL inside the C ABI)" % world,
+                "parallelism": "doc-sharded x%d, digests-only all-gather (ptx_allgather_digests: RCCL inside the C ABI)%s" % (
+                    world, "; the ranks SHARE %d GPU(s): torch side channel over gloo, a test set-up, not a scaling figure" % n_dev if shared_gpus else ""),
                 "causal_admission": not args.no_admission,
                 "step": "merge + device-side convergence count, one stream, no host sync" if stream is not None else "merge, host sync, digest check",
             },

@@ -347,6 +347,10 @@ ptx_status ptx_pack_digests(ptx_ctx* ctx, const ptx_dresult* r, uint32_t first, 
  * RCCL is loaded at run time (librccl.so.1) by the first of these calls: a single-GPU host never needs it. */
 #define PTX_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
 typedef struct ptx_comm ptx_comm;
+/* Optional, before the first ptx_comm_* call of the process: bind the collective library (the five RCCL entry points this ABI uses) from `path`
+ * instead of the process's librccl.so.1 — a host that ships its own RCCL build; the test-suite's shared-memory stand-in, which lets several ranks
+ * share one GPU.  PTX_ERR_INVALID_ARG once a library is bound. */
+ptx_status ptx_comm_use_library(ptx_ctx* ctx, const char* path);
 /* Rank 0 makes the id (ncclGetUniqueId) and hands it to the other ranks over the host's own channel. */
 ptx_status ptx_comm_unique_id(ptx_ctx* ctx, uint8_t id[PTX_COMM_ID_BYTES]);
 /* Collective over all ranks (ncclCommInitRank) on the context's device. */

@@ -298,6 +298,7 @@ FUNCTIONS = {
     "ptx_result_download_logs": (C.c_int32, [vp, vp, C.POINTER(ptx_log_result), C.c_uint32]),
     "ptx_dresult_logs_device": (vp, [vp]),
     "ptx_pack_digests": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "ptx_comm_use_library": (C.c_int32, [vp, C.c_char_p]),
     "ptx_comm_unique_id": (C.c_int32, [vp, u8p]),
     "ptx_comm_init": (C.c_int32, [vp, u8p, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
     "ptx_comm_destroy": (None, [vp, vp]),

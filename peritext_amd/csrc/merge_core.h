@@ -993,13 +993,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
     /* The row lists of the deletes and of the mark ops never live in LDS during P1 .. P4: the row pass writes them straight to their PARK in HBM — the log's own
      * span rows (8 bytes per row of the log = 2 N entries of 4 bytes, written by nobody before P6): entry = row | id key << 16, the deletes at [0, D), the mark ops
-     * at the TOP, [mp0, 2 N) with mp0 = 2 N - K, type t from mp0 + moff_t.  P3a reads the deletes back (coalesced), P5 the marks (into LDS: `mlist`); rows and keys
+     * at the TOP, [mp0, 2 N) with mp0 = 2 N - K, type t from mp0 + moff_t.  P3a reads the deletes back, P5a the marks (both coalesced, each two steps ahead of the gathers that go through them); rows and keys
      * of the marks that still cover a visible character are read from the park by P5c / P5b — also AFTER the first span rows are out (long documents go tile by
      * tile): a log has at most n spans and N > n + D + K rows, so span row s (entries 2 s, 2 s + 1 < 2 n) never reaches entry mp0 > 2 n. */
     uint32_t* const park = (uint32_t*)(A.out_spans + base);
     const uint32_t park_top = 2u * N - 1u; /* last 4-byte entry of the park (a lying header's stores are kept inside it) */
     const uint32_t mp0 = 2u * N - K;       /* (K <= N was checked above) */
-    uint16_t* mlist = nullptr; /* rows of the mark ops, read back from the park when P5 starts (then overwritten in place by the ops' interval starts) */
     uint32_t* maddbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 1); /* mark op k is an addMark (the tail phases need no look back at `action`) */
     /* element-side state: dead once the mark intervals are known (P5a), then reused as scratch of the tail phases */
     const uint32_t elem_lds = bp.off;
@@ -1609,34 +1608,32 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_STAMP(18); /* document positions stand; the mark list comes back from its park */
     uint16_t* rnk = par;
     bp.off = mark_lds; /* release the tree scratch */
-    /* the rows of the mark ops come back from the park (the low halves of its entries from mp0 on) */
-    mlist = ptx_alloc<uint16_t>(bp, K + 1);
-    PTX_BAIL_CAPACITY();
-    PTX_FORV(k0, K, PTX_UV) { /* (the loads of a step are in flight together: a loop of one load per turn is one round trip to the L2 per turn) */
-        uint32_t v[PTX_UV];
-#pragma unroll
-        for (int u = 0; u < PTX_UV; ++u) v[u] = ptx_coherent_load32(&park[mp0 + (PTX_IN(k0, u) ? PTX_IX(k0, u) : 0u)]);
-#pragma unroll
-        for (int u = 0; u < PTX_UV; ++u)
-            if (PTX_IN(k0, u)) mlist[PTX_IX(k0, u)] = (uint16_t)v[u];
-    }
-    PTX_SYNC_LDS();
     PTX_STAMP(5);
 
-    /* P5a's loads: the first step's gathers are issued here, ahead of P4 and the values pass */
+    /* P5a's loads.  The rows of the mark ops come straight from their park (the low halves of its entries from mp0 on; a lane's entries of a block are
+     * consecutive words): the park entries of the first step go out here, ahead of P4, its gathers once P4's bitmap stands, ahead of the values pass; in the loop
+     * the park entries run two steps ahead of the step in work, the gathers one.  (Round 4: copying the list back into LDS first was ONE exposed trip to HBM per
+     * log — 2 k cycles with a CU to itself, 28 k under load.) */
     const PtxMarkBlocks MB = ptx_mark_blocks(moff1, moff2, moff3, K, PTX_JB_CAP);
     const uint32_t m_steps = PTX_JB_STEPS(MB.B, PTX_UM);
     uint32_t kq[PTX_UM], kq_n[PTX_UM]; /* the thread's mark ops of a step (0xFFFFFFFF: none) */
+    uint32_t mq[PTX_UM];               /* the park entries of the step whose gathers go out next */
+#define PTX_MARK_PQ(st_, mq_)                                               \
+    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
+        uint32_t k_;                                                        \
+        (void)ptx_mark_of(MB, PTX_JB_BLOCK(st_, u, PTX_UM), PTX_JB_LANE(st_, u, PTX_UM), k_); \
+        mq_[u] = ptx_coherent_load32(&park[K ? mp0 + k_ : 0u]);             \
+    }
     uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
     uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
     /* rows of this thread's mark ops of a step (list read, then the column gathers; the payload only of the comment ops — their
      * id —, the others' is not needed before P5b, and then only the winners') */
-#define PTX_MARK_LOAD(st_, kq_, i_, ra_, rb_, sa_, sb_, pl_)                \
+#define PTX_MARK_LOAD(st_, kq_, i_, ra_, rb_, sa_, sb_, pl_, mq_)           \
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
         uint32_t k_;                                                        \
         const bool has_ = ptx_mark_of(MB, PTX_JB_BLOCK(st_, u, PTX_UM), PTX_JB_LANE(st_, u, PTX_UM), k_); \
         kq_[u] = has_ ? k_ : 0xFFFFFFFFu;                                   \
-        const uint32_t r_ = mlist[k_];                                      \
+        const uint32_t r_ = mq_[u] & 0xFFFFu;                               \
         i_[u] = r_ < N ? r_ : N - 1u;                                       \
         pl_[u] = has_ && k_ >= moff2 && k_ < moff3 ? 1u : 0u;               \
     }                                                                       \
@@ -1647,7 +1644,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         sb_[u] = A.side_b[base + i_[u]];                                    \
         if (pl_[u]) pl_[u] = payload[i_[u]];                                \
     }
-    PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl)
+    PTX_MARK_PQ(0u, mq)
     /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = nwe; /* bit positions 0..n by document position */
     PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
@@ -1687,10 +1684,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     });
     PTX_SYNC_LDS();
     const uint32_t V = ptx_bitwords_prefix(alive, nwv + 1, &H->scan_tmp[18]);
-    /* the visible interval [lo, hi) of every mark op.  `lo` takes the place of the op's row in `mlist`: P5a's thread has consumed the row when it stores the
-     * interval (same thread, same index), and the few later uses of a row — the ops that still cover a visible character — read it from the park.  Until the
-     * marks are looked at, the space of `hi` and of the comment ids holds the rows of the visible elements (vrow) if they fit */
-    uint16_t* mrk_lo = mlist;
+    PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl, mq) /* the first step's gathers: in flight during the values pass */
+    PTX_MARK_PQ(1u, mq)
+    /* the visible interval [lo, hi) of every mark op (the few later uses of an op's row — the ops that still cover a visible character — read it from the
+     * park).  Until the marks are looked at, the space of `hi` and of the comment ids holds the rows of the visible elements (vrow) if they fit */
+    uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
     const uint32_t mrk_at = bp.off;
     uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
     uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);    /* comment mark -> doc-local comment id */
@@ -1790,13 +1788,16 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     };
 #pragma nounroll
     for (uint32_t st = 0; st < m_steps; st += 2u) {
-        PTX_MARK_LOAD(st + 1u, kq_n, i_n, ra_n, rb_n, sa_n, sb_n, pl_n) /* the next step's gathers are in flight while this step is processed */
+        PTX_MARK_LOAD(st + 1u, kq_n, i_n, ra_n, rb_n, sa_n, sb_n, pl_n, mq) /* the next step's gathers are in flight while this step is processed */
+        PTX_MARK_PQ(st + 2u, mq)
         mark_step(kq, i, ra, rb, sa, sb, pl);
         if (st + 1u >= m_steps) break;
-        PTX_MARK_LOAD(st + 2u, kq, i, ra, rb, sa, sb, pl)
+        PTX_MARK_LOAD(st + 2u, kq, i, ra, rb, sa, sb, pl, mq)
+        PTX_MARK_PQ(st + 3u, mq)
         mark_step(kq_n, i_n, ra_n, rb_n, sa_n, sb_n, pl_n);
     }
 #undef PTX_MARK_LOAD
+#undef PTX_MARK_PQ
     }
     PTX_LEADER { H->cur_med = 0; } /* (the cursor of the list of live mark ops, below; the barriers of the error check stand in between) */
     PTX_BAIL_IF_ERROR();

@@ -1180,12 +1180,12 @@ struct PtxRccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static PtxRccl g_rccl;
-static ptx_status rccl_load(ptx_ctx* ctx) {
-    if (g_rccl.handle) return PTX_OK;
+static ptx_status rccl_load(ptx_ctx* ctx, const char* path = nullptr) {
+    if (g_rccl.handle) return path ? fail(ctx, PTX_ERR_INVALID_ARG, "ptx_comm_use_library: a collective library is already bound in this process") : PTX_OK;
     /* the process may already hold RCCL (e.g. torch.distributed): the soname resolves to that copy */
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    void* h = path ? dlopen(path, RTLD_NOW | RTLD_LOCAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h && !path) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h && !path) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return fail(ctx, PTX_ERR_HIP, std::string("RCCL is not available: ") + dlerror());
     PtxRccl r;
     r.handle = h;
@@ -1215,6 +1215,11 @@ struct ptx_comm {
                                         step) uploads them once and has no host synchronisation inside the step */
     std::vector<uint64_t> first_up;
 };
+
+ptx_status ptx_comm_use_library(ptx_ctx* ctx, const char* path) {
+    if (!ctx || !path || !*path) return PTX_ERR_INVALID_ARG;
+    return rccl_load(ctx, path);
+}
 
 ptx_status ptx_comm_unique_id(ptx_ctx* ctx, uint8_t id[PTX_COMM_ID_BYTES]) {
     if (!ctx || !id) return PTX_ERR_INVALID_ARG;

@@ -1,6 +1,7 @@
 """Thin ctypes driver over the C ABI (include/peritext_hip.h).  Plumbing only: every merge goes
 through libperitext_hip.so on a gfx950 device; nothing here computes a result on the CPU."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -222,6 +223,10 @@ class Engine:
         return int(n.value)
 
     # ---- multi-GPU: the digest all-gather over RCCL, inside the library ----
+    def comm_use_library(self, path):
+        """Bind the collective library from `path` (before the first comm_* call of the process) instead of the process's librccl.so.1."""
+        self._check(self.lib.ptx_comm_use_library(self.ctx, os.fsencode(path)))
+
     def comm_unique_id(self):
         """128 bytes (ncclUniqueId) rank 0 makes and hands to the other ranks."""
         buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
