@@ -369,6 +369,9 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         const uint32_t i = dlist[j];
         const int t = ptx_elem_lookup(ix, ref_a[i]);
         if (t >= 0 && row_of[t] >= i) ptx_raise(H, ptx_min(i, 0x03FFFFFFu), 1, PTX_ERR_ELEM_NOT_FOUND);
+        /* the resolved references the patch-stream replay / change() / cursors read beside elem_rank (merge_core.h PtxMergeArgs.out_refs): per delete the
+         * row that inserted its target */
+        if (A.out_refs && t >= 0) A.out_refs[base + i] = row_of[t];
     }
     PTX_BIG_BAIL_IF_ERROR();
 
@@ -492,6 +495,17 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         mrk_lo[k] = lo;
         mrk_hi[k] = hi;
+        if (A.out_refs) { /* per mark op its two boundary slots, each on its own, 16 bits each (0xFFFF = none): what fits the on-chip replay (n <= 32766) */
+            uint32_t va = 0xFFFFu, vb = 0xFFFFu;
+            if (n <= 32766u) {
+                if (js >= 0) va = 2u * pos[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
+                if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
+                    const int je = ptx_elem_lookup(ix, ref_b[i]);
+                    if (je >= 0 && row_of[je] < i) vb = 2u * pos[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
+                }
+            }
+            A.out_refs[base + i] = va | (vb << 16);
+        }
         if ((mflag[k] & 3u) == PTX_MARK_COMMENT) {
             const uint32_t pl = payload[i];
             if (pl >= Kid) ptx_raise(H, ptx_min(i, 0x03FFFFFFu), 1, PTX_ERR_BAD_OP); /* beyond the id space the header declares */

@@ -25,7 +25,9 @@
 #pragma once
 #include "gen_core.h"
 
-#define PTX_CE_MASK 0x0000FFFFu /* element index inside a list word (bits 30 / 31: PTX_GK_DEAD / PTX_GK_AFTER) */
+#define PTX_CE_MASK 0x000FFFFFu /* the element inside a list word (bits 30 / 31: PTX_GK_DEAD / PTX_GK_AFTER): the ROW of the log that inserted it, or
+                                   PTX_CE_NEW + j for the j-th element this call makes */
+#define PTX_CE_NEW 0x00010000u
 
 struct PtxChangeArgs {
     /* the base batch (resident) and its merge result */
@@ -40,6 +42,7 @@ struct PtxChangeArgs {
     const ptx_log_hdr* log_hdr;
     const ptx_log_result* res;
     const uint32_t* elem_rank;
+    const uint32_t* refs;      /* the merge's resolved references (PtxMergeArgs.out_refs): per mark row its boundary slots start | end << 16, 0xFFFF = none */
     const uint64_t* chg_off;   /* base envelope: the replica's clock = changes per actor */
     const uint32_t* chg_hdr;
     uint32_t max_actors;
@@ -86,8 +89,9 @@ struct PtxChangeHdr {
 
 /* LDS of one log: n elements now, `grow` inserts to come, id keyspace of ks bits, na actors */
 PTX_HD uint64_t ptx_change_lds_need(uint64_t n, uint64_t grow, uint64_t ks, uint64_t na) {
-    const uint64_t nw = (ks + 31) / 32, cap = n + grow + 64;
-    return ptx_a16(sizeof(PtxChangeHdr)) + ptx_a16(8 * (nw + 1)) + ptx_a16(2 * (n + 1)) + 2 * ptx_a16(4 * cap) + ptx_a16(4 * (grow + 1)) + ptx_a16(4 * (na + 1));
+    (void)ks; /* (no element index: the rows come resolved from the merge) */
+    const uint64_t cap = n + grow + 64;
+    return ptx_a16(sizeof(PtxChangeHdr)) + ptx_a16(4 * cap) + ptx_a16(4 * (grow + 1)) + ptx_a16(4 * (na + 1));
 }
 
 template <uint32_t kThreads>
@@ -129,12 +133,7 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
     const uint32_t n0 = N ? hd.n_ins : 0u;
     uint32_t grow = 0; /* list elements this call adds */
     for (uint64_t q = A.in_op_off[ch0]; q < A.in_op_off[ch1]; ++q) grow += A.in_action[q] == PTX_IN_INSERT ? A.in_count[q] : 0u;
-    PtxElemIndex ix;
-    ix.max_ctr = N ? hd.max_counter : 0u;
-    ix.max_actor = N ? hd.max_actor : 0u;
-    ix.na1 = ix.max_actor + 1u;
-    const uint32_t keyspace = (ix.max_ctr + 1u) * ix.na1;
-    const uint32_t nw = (keyspace + 31) / 32;
+    const uint32_t max_ctr0 = N ? hd.max_counter : 0u;
     const uint32_t cap = n0 + grow + 64u;
     PtxBump bp;
     bp.base = lds;
@@ -142,26 +141,21 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
     bp.cap = A.lds_bytes;
     bp.high = bp.off;
     bp.overflow = false;
-    ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
-    uint16_t* row_of = ptx_alloc<uint16_t>(bp, n0 + 1);
-    uint32_t* L = ptx_alloc<uint32_t>(bp, cap);      /* document order: element index | PTX_GK_DEAD | PTX_GK_AFTER */
-    uint32_t* tmpbuf = ptx_alloc<uint32_t>(bp, cap);
-    uint32_t* newctr = ptx_alloc<uint32_t>(bp, grow + 1); /* counter of the j-th element made here (its index is n0 + j) */
+    /* The list in document order, one word per element: the ROW that inserted it | PTX_GK_DEAD | PTX_GK_AFTER.  Everything it is built from comes resolved
+     * from the merge — elem_rank (document position + tombstone of every insert row) and the boundary slots of every mark row (refs) — so no element index
+     * is built here and a document of 32 766 elements fits one CU's LDS (round 4: with its own id bitmap, element -> row table and a second list-sized
+     * buffer for opening a gap the kernel stopped at ~12 000). */
+    uint32_t* L = ptx_alloc<uint32_t>(bp, cap);
+    uint32_t* newctr = ptx_alloc<uint32_t>(bp, grow + 1); /* counter of the j-th element made here (its list word is PTX_CE_NEW + j) */
     uint32_t* clock = ptx_alloc<uint32_t>(bp, na + 1);
-    if (bp.overflow || ix.max_actor > 4095u || n0 + grow > 32766u || N > 65534u || ix.max_ctr + out_cap >= (1u << 19)) PTX_CHANGE_FAIL(PTX_ERR_CAPACITY);
+    if (bp.overflow || n0 + grow > 32766u || N > 65534u || max_ctr0 + out_cap >= (1u << 19)) PTX_CHANGE_FAIL(PTX_ERR_CAPACITY);
 
     /* ---- the replica's state from its merged log ---- */
-    PTX_FOR(w, nw + 1) {
-        PtxBitWord z;
-        z.bits = 0;
-        z.pre = 0;
-        ix.ib[w] = z;
-    }
     PTX_FOR(a, na + 1) clock[a] = 0;
     PTX_LEADER {
         H->n = n0;
         H->vis = N ? A.res[log].n_visible : 0u;
-        H->max_op = ix.max_ctr;
+        H->max_op = max_ctr0;
         H->rows = 0;
         H->has_list = 0;
         H->err = 0;
@@ -170,8 +164,8 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
     PTX_FOR(i, N) {
         const uint32_t a = A.action[base + i];
         if (a == PTX_ACT_INSERT) {
-            uint32_t key = 0;
-            if (ptx_id_key(ix, op_id[i], key)) ptx_atomic_or(&ix.ib[key >> 5].bits, 1u << (key & 31));
+            const uint32_t rk = erank[i];
+            if ((rk & PTX_RANK_MASK) < n0) L[rk & PTX_RANK_MASK] = i | ((rk & PTX_RANK_TOMBSTONE) ? PTX_GK_DEAD : 0u);
         } else if (a == PTX_ACT_MAKELIST) {
             H->has_list = 1;
         }
@@ -184,40 +178,18 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
         }
     }
     PTX_SYNC();
-    PTX_FOR(w, nw + 1) ix.ib[w].pre = ptx_popc(ix.ib[w].bits);
-    PTX_SYNC();
-    ptx_scan_excl<uint32_t, 2, kThreads>(&ix.ib[0].pre, nw + 1, H->scan_tmp);
-    PTX_FOR(i, N) {
-        if (A.action[base + i] == PTX_ACT_INSERT) {
-            const int e = ptx_elem_lookup(ix, op_id[i]);
-            if (e >= 0 && (uint32_t)e < n0) {
-                row_of[e] = (uint16_t)i;
-                const uint32_t rk = erank[i];
-                L[rk & PTX_RANK_MASK] = (uint32_t)e | ((rk & PTX_RANK_TOMBSTONE) ? PTX_GK_DEAD : 0u);
-            }
-        }
-    }
-    PTX_SYNC();
     /* which `after` slots are defined ones: the walk of applyAddRemoveMark in closed form (positions never change once both
-     * elements exist, so final ranks decide "the end is met before the start") */
+     * elements exist, so final ranks decide "the end is met before the start"); the slots as the merge resolved them (an element that was
+     * not in the list when the op was applied: none) */
     PTX_FOR(i, N) {
         const uint32_t a = A.action[base + i];
         if ((a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) && A.mark_type[base + i] < 4u) {
-            const uint32_t sa = A.side_a[base + i], sb = A.side_b[base + i];
-            int js = -1, je = -1;
-            if (sa == PTX_SIDE_BEFORE || sa == PTX_SIDE_AFTER) {
-                js = ptx_elem_lookup(ix, A.ref_a[base + i]);
-                if (js >= 0 && row_of[js] >= i) js = -1; /* not in the list when the op was applied */
-            }
-            if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
-                je = ptx_elem_lookup(ix, A.ref_b[base + i]);
-                if (je >= 0 && row_of[je] >= i) je = -1;
-            }
-            const uint32_t slot_a = js >= 0 ? 2u * (erank[row_of[js]] & PTX_RANK_MASK) + (sa == PTX_SIDE_AFTER ? 1u : 0u) : 0xFFFFFFFFu;
-            const uint32_t slot_b = je >= 0 ? 2u * (erank[row_of[je]] & PTX_RANK_MASK) + (sb == PTX_SIDE_AFTER ? 1u : 0u) : 0xFFFFFFFFu;
-            const bool end_first = je >= 0 && (js < 0 || slot_b < slot_a);
-            const bool start_written = js >= 0 && !end_first;
-            const bool end_written = je >= 0 && slot_b != slot_a;
+            const uint32_t v = A.refs[base + i];
+            const uint32_t slot_a = (v & 0xFFFFu) != 0xFFFFu ? v & 0xFFFFu : 0xFFFFFFFFu, slot_b = (v >> 16) != 0xFFFFu ? v >> 16 : 0xFFFFFFFFu;
+            const bool has_a = slot_a != 0xFFFFFFFFu, has_b = slot_b != 0xFFFFFFFFu;
+            const bool end_first = has_b && (!has_a || slot_b < slot_a);
+            const bool start_written = has_a && !end_first;
+            const bool end_written = has_b && slot_b != slot_a;
             if (start_written && (slot_a & 1u)) ptx_atomic_or(&L[slot_a >> 1], PTX_GK_AFTER);
             if (end_written && (slot_b & 1u)) ptx_atomic_or(&L[slot_b >> 1], PTX_GK_AFTER);
         }
@@ -225,7 +197,7 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
     PTX_SYNC();
 
     /* id of the element behind a list word */
-#define PTX_CE_ID(word_) (((word_) & PTX_CE_MASK) < n0 ? op_id[row_of[(word_) & PTX_CE_MASK]] : (((uint64_t)newctr[((word_) & PTX_CE_MASK) - n0] << 32) | me))
+#define PTX_CE_ID(word_) (((word_) & PTX_CE_MASK) < PTX_CE_NEW ? op_id[(word_) & PTX_CE_MASK] : (((uint64_t)newctr[((word_) & PTX_CE_MASK) - PTX_CE_NEW] << 32) | me))
     /* one id-based op of the change under construction: row + local application bookkeeping */
 #define PTX_CE_EMIT(act_, mt_, ra_, rb_, sa_, sb_, pay_)                        \
     do {                                                                        \
@@ -301,12 +273,11 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
                 }
                 for (uint32_t v = 0; v < cnt; ++v) {
                     /* the new element has the largest id of the replica: nothing to skip (micromerge.ts:630), it lands right after its reference */
-                    const uint32_t nn = H->n, tail = nn - at;
-                    PTX_GEN_FOR(i, tail) tmpbuf[i] = L[at + i];
+                    const uint32_t nn = H->n;
+                    ptx_list_shift_up<uint32_t>(L, at, nn); /* L[at + 1 .. nn] = L[at .. nn - 1], whole 16-byte blocks from the top down */
                     PTX_SYNC();
-                    PTX_GEN_FOR(i, tail) L[at + 1u + i] = tmpbuf[i];
                     PTX_LEADER {
-                        L[at] = n0 + new_elems;
+                        L[at] = PTX_CE_NEW + new_elems;
                         newctr[new_elems] = H->max_op + 1u;
                         H->n = nn + 1u;
                         H->vis += 1u;

@@ -2106,6 +2106,7 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
         A.log_hdr = base->log_hdr;
         A.res = merged->logs;
         A.elem_rank = merged->rank;
+        A.refs = merged->refs;
         A.chg_off = base->chg_off;
         A.chg_hdr = base->chg_hdr;
         A.max_actors = na;

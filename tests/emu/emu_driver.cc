@@ -107,9 +107,10 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
 /* the HBM-staged path for logs beyond one CU's LDS (biglog_core.h): every log of the batch through ptx_big_merge_log, its working set in a host buffer
  * sized by ptx_big_need (slack > 0 adds bytes the kernel must not need; < 0 takes some away: the log must then report PTX_ERR_CAPACITY) */
 extern "C" int ptx_emu_merge_big(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank, int reverse, int admission,
-                                 long long slack) {
+                                 long long slack, uint32_t* refs) {
     PtxMergeArgs A;
     memset(&A, 0, sizeof(A));
+    A.out_refs = refs;
     A.log_off = b->log_off;
     A.op_id = b->op_id;
     A.ref_a = b->ref_a;
@@ -245,7 +246,7 @@ extern "C" int ptx_emu_generate(PtxGenArgs* A, int reverse) {
 
 /* change() for caller-supplied InputOperations (change_core.h) over the merge results `res` / `rank` of the base batch;
  * the caller allocates the capacity-layout output (out_off = rows per log, known from the InputOperations) */
-extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const ptx_input_ops* in, const uint64_t* out_off, uint64_t* o_op_id,
+extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint32_t* refs, const ptx_input_ops* in, const uint64_t* out_off, uint64_t* o_op_id,
                               uint64_t* o_ref_a, uint64_t* o_ref_b, uint32_t* o_payload, uint8_t* o_action, uint8_t* o_mark_type, uint8_t* o_side_a, uint8_t* o_side_b,
                               uint32_t* o_chg_hdr, uint16_t* o_chg_env, uint16_t* o_chg_env_hi, uint32_t* any_wide, uint32_t* status, uint32_t* rows_made, uint32_t* chgs_made,
                               uint32_t lds_bytes, int reverse) {
@@ -261,6 +262,7 @@ extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, con
     A.side_b = b->side_b;
     A.res = res;
     A.elem_rank = rank;
+    A.refs = refs;
     A.chg_off = b->chg_off;
     A.chg_hdr = b->chg_hdr;
     A.max_actors = in->max_actors;

@@ -202,9 +202,9 @@ def emu_merge_big(b, reverse=0, lib_path=EMU_LIB, admission=False, slack=0):
     )
     s = batch_struct(b)
     f = _emu(lib_path).ptx_emu_merge_big
-    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong]
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p]
     rc = f(C.byref(s), res.logs.ctypes.data, res.values.ctypes.data, res.spans.ctypes.data, res.cintervals.ctypes.data, res.elem_rank.ctypes.data, reverse,
-           1 if admission else 0, slack)
+           1 if admission else 0, slack, res.ref_slots.ctypes.data)
     assert rc == 0
     return res
 
@@ -297,7 +297,7 @@ def emu_change(batch, res, ops, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB
     lib.ptx_emu_change.restype = C.c_int
     s, si = batch_struct(batch), input_ops_struct(ops)
     vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
-    rc = lib.ptx_emu_change(C.byref(s), vp(res.logs), vp(res.elem_rank), C.byref(si), vp(out_off), vp(cols["op_id"]), vp(cols["ref_a"]), vp(cols["ref_b"]), vp(cols["payload"]),
+    rc = lib.ptx_emu_change(C.byref(s), vp(res.logs), vp(res.elem_rank), vp(res.ref_slots), C.byref(si), vp(out_off), vp(cols["op_id"]), vp(cols["ref_a"]), vp(cols["ref_b"]), vp(cols["payload"]),
                             vp(cols["action"]), vp(cols["mark_type"]), vp(cols["side_a"]), vp(cols["side_b"]), vp(env["chg_hdr"]), vp(env["chg_env"]), vp(env["chg_env_hi"]), vp(env["any_wide"]), vp(status), vp(rows_made), vp(chgs_made), C.c_uint32(lds_bytes), C.c_int(reverse))
     assert rc == 0
     return made_batch(batch, ops, cols, env, rows_made, chgs_made, out_off), status[:n_logs]

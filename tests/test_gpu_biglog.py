@@ -131,3 +131,62 @@ def test_logs_with_more_than_65535_changes(eng):
     assert int(logs["status"][0]) == 0 and int(logs["n_visible"][0]) == 70000
     assert (logs["digest"][0] == res.logs["digest"][0]).all()
     assert back.chg_env_hi is not None and (back.chg_seq == np.arange(1, 70002)).all()
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_patch_stream_change_and_cursors_on_long_documents(eng):
+    """VERDICT r3 missing #1 / next #5: ptx_replay_patches, ptx_resolve_cursors and ptx_change on documents beyond the LDS merge kernel — a 40 000-op
+    insert / delete document (25 000 list elements; merged by the HBM-staged kernel, which now emits the resolved references those entry points read) and a
+    40 001-row all-marks log — through the C ABI, against the oracle: every Patch (reference/src/micromerge.ts:661-671, :696-703; peritext.ts:251-281),
+    cursors both ways (:465-477), change(InputOperation[]) Change for Change (:308-441, :762-805), and the replica after the made Changes are appended."""
+    essay = H.oracle_gen("config2", 1, 77, 40000, 1)["docs"][0]["logs"][0]
+    marks = H.synthetic_marks_log(6000, 34000, 9)
+    docs = [[essay], [marks]]
+    exp = H.oracle_apply(docs, patches=True, timeout=1500)
+    batch = wire.encode_docs(docs, extra_comments=[[], []])
+    db = eng.upload(batch)
+    dr = eng.alloc_result(db)
+    made_db = after = dr2 = None
+    try:
+        eng.merge(db, dr)
+        res = eng.download(db, dr)
+        assert (res.logs["status"] == 0).all() and (res.logs["reserved"][:, 0] == 0).all()  # both took the HBM-staged kernel
+        pat = eng.replay_patches(db, dr)
+        assert (pat.logs["status"] == 0).all() and [int(x) for x in pat.logs["n_patches"]] == [len(exp[0][0]["patches"]), len(exp[1][0]["patches"])]
+        H.check_patch_streams(batch, pat, exp)
+        for log in (0, 1):
+            V = int(res.logs["n_visible"][log])
+            idx = list(range(0, V, 499)) + [V - 1]
+            ids, st = eng.resolve_cursors(db, dr, [log] * len(idx), [abi.CURSOR_GET] * len(idx), idx)
+            assert not st.any()
+            d = batch.log_doc[log]
+            assert [wire.get_cursor(batch, res, log, i) for i in idx[:8]] == ["%d@%s" % (int(x) >> 32, batch.doc_actors[d][int(x) & 0xFFFFFFFF]) for x in ids[:8]]
+            back, st = eng.resolve_cursors(db, dr, [log] * len(idx), [abi.CURSOR_RESOLVE] * len(idx), [int(x) for x in ids])
+            assert not st.any() and [int(x) for x in back] == idx
+        V0, V1 = int(res.logs["n_visible"][0]), int(res.logs["n_visible"][1])
+        calls = [[[{"path": ["text"], "action": "insert", "index": V0 // 2, "values": ["x", "y"]}, {"path": ["text"], "action": "delete", "index": 10, "count": 3}],
+                  [{"path": ["text"], "action": "addMark", "markType": "strong", "startIndex": 5, "endIndex": V0 - 5}]],
+                 [[{"path": ["text"], "action": "addMark", "markType": "link", "attrs": {"url": "https://long.example"}, "startIndex": 100, "endIndex": V1 - 100},
+                   {"path": ["text"], "action": "insert", "index": V1, "values": ["!"]}]]]
+        actors = [essay[0]["actor"], marks[0]["actor"]]
+        want = H.oracle_change(docs, calls, actors)
+        made_db, status = eng.change(db, dr, wire.encode_input_ops(batch, calls, actors))
+        assert not status.any()
+        made = eng.download_batch(made_db, batch.values, batch.urls, batch.log_doc, batch.doc_actors, batch.doc_comments, batch.keys, batch.map_values)
+        got = []
+        for log, logs in enumerate(docs):
+            text_obj = [op["opId"] for c in logs[0] for op in c["ops"] if op["action"] == "makeList"][0]
+            got += wire.decode_changes(made, log, text_obj=text_obj)
+        assert got == want
+        after = eng.append_device(db, made_db)
+        dr2 = eng.alloc_result(after)
+        eng.merge(after, dr2)
+        logs2 = eng.download_logs(dr2, 2)
+        assert (logs2["status"] == 0).all() and int(logs2["n_visible"][0]) == V0 + 2 - 3 and int(logs2["n_visible"][1]) == V1 + 1
+    finally:
+        for h in (dr2, dr):
+            if h is not None:
+                eng.free_result(h)
+        for h in (after, made_db, db):
+            if h is not None:
+                eng.free_batch(h)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--lib", nargs="*", default=[None])
     ap.add_argument("--flags", type=int, default=abi.FLAG_NO_ELEM_RANK)
+    ap.add_argument("--list-cap", type=int, default=2048)
     args = ap.parse_args()
     c = workloads.gen_config(args.config, ops=args.ops)
     for lib in args.lib:
@@ -31,7 +32,7 @@ def main():
             for lds in [int(x) for x in args.lds.split(",")]:
                 with Engine(0, flags=args.flags, lib_path=path) as e:
                     e.set_launch_shape(t, lds)
-                    db, _ = e.generate(c["replicas"], c["ops_per_log"], c["mix"], c["mark_types"], args.docs, 2024, list_cap=2048)
+                    db, _ = e.generate(c["replicas"], c["ops_per_log"], c["mix"], c["mark_types"], args.docs, 2024, list_cap=args.list_cap)
                     dr = e.alloc_result(db)
                     e.merge(db, dr)
                     e.sync()
