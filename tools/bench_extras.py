@@ -102,7 +102,13 @@ def config_leg(args, name, docs, flags):
             # parity: documents of the RESIDENT batch (regenerated one by one with the same generator arguments, so the same documents) against the oracle
             if args.parity_docs > 0 and shutil.which("node"):
                 rng = np.random.default_rng(args.seed + docs)
-                pick = sorted(int(x) for x in rng.choice(docs, size=min(args.parity_docs, docs), replace=False))
+                # half drawn at random, half the documents that show the most text (a 50 %-deletes configuration leaves most documents nearly empty: random
+                # draws alone would hardly exercise span and comment-interval rows)
+                half = min(args.parity_docs, docs) // 2
+                vis_doc = logs["n_visible"].reshape(-1, g["replicas"])[:, 0]
+                rich = [int(x) for x in np.argsort(-vis_doc.astype(np.int64), kind="stable")[:half]]
+                rest = [int(x) for x in rng.permutation(docs) if int(x) not in set(rich)][: min(args.parity_docs, docs) - len(rich)]
+                pick = sorted(rich + rest)
                 ones, docs_logs = [], []
                 for d in pick:
                     hb, hinfo = e.generate(*gen_args, 1, args.seed, first_doc=d, list_cap=list_cap)
@@ -116,12 +122,69 @@ def config_leg(args, name, docs, flags):
                     sub = e.download_range(db, dr, d * g["replicas"], g["replicas"])
                     for r in range(g["replicas"]):
                         helpers.check_log(one, sub, r, exp[r])
-                row["parity"] = {"documents_checked": len(pick), "against": "oracle/peritext_oracle.js (whole logs): decoded spans, raw rows, digests of the resident batch's result rows"}
+                row["parity"] = {"documents_checked": len(pick), "visible_chars_checked": int(sum(int(vis_doc[d]) for d in pick)), "against": "oracle/peritext_oracle.js (whole logs): decoded spans, raw rows, digests of the resident batch's result rows"}
             e.free_result(dr)
             e.free_batch(db)
     except Exception as ex:  # noqa: BLE001
         row["error"] = str(ex)[:300]
     return row
+
+
+def typed_essay(n_ops, seed, actor="essay"):
+    """A long single-author document made on the host: mostly typing at the cursor, some jumps, a fifth deletes — Changes of 1..12 ops (no oracle here:
+    the parity of such logs is the test-suite's, tests/test_gpu_biglog.py; this leg only times them)."""
+    import random
+
+    rng = random.Random(seed)
+    ctr, seq = 1, 1
+    log = [{"actor": actor, "seq": seq, "deps": {}, "startOp": 1, "ops": [{"opId": "1@%s" % actor, "action": "makeList", "obj": "_root", "key": "text"}]}]
+    alive, cursor, made = [], "_head", 1
+    while made < n_ops:
+        ops = []
+        for _ in range(min(rng.randint(1, 12), n_ops - made)):
+            ctr += 1
+            oid = "%d@%s" % (ctr, actor)
+            if alive and rng.random() < 0.2:
+                k = rng.randrange(len(alive))
+                alive[k], alive[-1] = alive[-1], alive[k]
+                ops.append({"opId": oid, "action": "del", "obj": "1@%s" % actor, "elemId": alive.pop()})
+            else:
+                if alive and rng.random() < 0.1:
+                    cursor = alive[rng.randrange(len(alive))]
+                ops.append({"opId": oid, "action": "set", "obj": "1@%s" % actor, "elemId": cursor, "insert": True, "value": chr(97 + ctr % 26)})
+                alive.append(oid)
+                cursor = oid
+            made += 1
+        seq += 1
+        log.append({"actor": actor, "seq": seq, "deps": {}, "startOp": ctr - len(ops) + 1, "ops": ops})
+    return log
+
+
+def biglog_leg(args):
+    """Documents beyond one CU's LDS (biglog_core.h, the HBM-staged kernel inside the same ptx_merge): a 100 000-op essay and a 40 001-row all-marks log,
+    each alone in a batch and both together — ms per merge (HIP events around ptx_merge), ops/s."""
+    import helpers
+
+    from peritext_amd import wire
+
+    rows = []
+    essay = typed_essay(100000, 7)
+    marks = helpers.synthetic_marks_log(6000, 34000, 9)
+    for name, docs in (("essay_100k", [[essay]]), ("marks_40k", [[marks]]), ("both", [[essay], [marks]])):
+        batch = wire.encode_docs(docs)
+        with Engine(args.device, flags=abi.FLAG_NO_ELEM_RANK) as e:
+            db = e.upload(batch)
+            dr = e.alloc_result(db)
+            e.merge(db, dr)
+            e.sync()
+            ms = min(e.merge_timed(db, dr, 3) / 3 for _ in range(2))
+            logs = e.download_logs(dr, batch.n_logs)
+            rows.append({"batch": name, "rows": int(batch.n_ops), "elements": [int(x) for x in logs["n_elems"]], "visible": [int(x) for x in logs["n_visible"]],
+                         "every_log_ok": bool(int(logs["status"].max()) == 0), "hbm_staged": bool((logs["reserved"][:, 0] == 0).all()), "ms": ms,
+                         "ops_per_s": batch.n_ops / ms * 1e3})
+            e.free_result(dr)
+            e.free_batch(db)
+    return {"kernel": "ptx_merge_big_kernel (one 1 024-thread workgroup per log, working set in HBM scratch)", "legs": rows}
 
 
 def pipeline_leg(args, gen_args, flags, batches=6, docs=8192):
@@ -201,8 +264,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--no-admission", action="store_true")
-    ap.add_argument("--parity-docs", type=int, default=8)
-    ap.add_argument("--legs", default="configs,replay,pipeline,phases,candidate,probe")
+    ap.add_argument("--parity-docs", type=int, default=32)
+    ap.add_argument("--legs", default="configs,replay,biglog,pipeline,phases,candidate,probe")
     args = ap.parse_args()
     legs = set(args.legs.split(","))
     g = workloads.gen_config(args.config, ops=args.ops)
@@ -236,6 +299,13 @@ def main():
         except Exception as ex:  # noqa: BLE001
             out["patch_replay"] = {"error": str(ex)[:300]}
         say("patch_replay %s" % json.dumps(out["patch_replay"]))
+
+    if "biglog" in legs:
+        try:
+            out["biglog"] = biglog_leg(args)
+        except Exception as ex:  # noqa: BLE001
+            out["biglog"] = {"error": str(ex)[:300]}
+        say("biglog %s" % json.dumps(out["biglog"]))
 
     if "pipeline" in legs:
         try:
