@@ -59,6 +59,7 @@ struct Lib {
     void (*host_batch_free)(ptx_host_batch*) = nullptr;
     /* change(): caller-supplied InputOperations */
     ptx_status (*change)(ptx_ctx*, const ptx_dbatch*, const ptx_dresult*, const ptx_input_ops*, ptx_dbatch**, uint32_t*) = nullptr;
+    ptx_status (*batch_append_device)(ptx_ctx*, const ptx_dbatch*, const ptx_dbatch*, ptx_dbatch**) = nullptr;
     /* multi-GPU: the digest all-gather (RCCL inside the library) */
     ptx_status (*comm_unique_id)(ptx_ctx*, uint8_t*) = nullptr;
     ptx_status (*comm_init)(ptx_ctx*, const uint8_t*, uint32_t, uint32_t, ptx_comm**) = nullptr;
@@ -120,7 +121,7 @@ napi_value Open(napi_env env, napi_callback_info info) {
                   sym(L.comm_unique_id, "ptx_comm_unique_id") && sym(L.comm_init, "ptx_comm_init") && sym(L.comm_destroy, "ptx_comm_destroy") && sym(L.comm_n_ranks, "ptx_comm_n_ranks") &&
                   sym(L.allgather_digests, "ptx_allgather_digests") && sym(L.count_converged_digests, "ptx_count_converged_digests") &&
                   sym(L.result_download_logs, "ptx_result_download_logs") && sym(L.root_map, "ptx_root_map") && sym(L.root_maps_free, "ptx_root_maps_free") && sym(L.device_alloc, "ptx_device_alloc") && sym(L.device_free, "ptx_device_free") &&
-                  sym(L.device_read, "ptx_device_read") && sym(L.resolve_cursors, "ptx_resolve_cursors");
+                  sym(L.device_read, "ptx_device_read") && sym(L.resolve_cursors, "ptx_resolve_cursors") && sym(L.batch_append_device, "ptx_batch_append_device");
         if (!ok) {
             dlclose(L.handle);
             L.handle = nullptr;
@@ -607,9 +608,19 @@ napi_value Change(napi_env env, napi_callback_info info) {
     napi_value argv[3];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     ptx_ctx* ctx = argc > 2 ? ctx_of(env, argv[0]) : nullptr;
-    if (!ctx) return throw_msg(env, "change(ctx, batch, inputOps)");
+    if (!ctx) return throw_msg(env, "change(ctx, batch | resident handle, inputOps)");
+    /* the replicas: a host batch (encoded, uploaded and merged here), or the handle of a RESIDENT batch (residentUpload / residentAppend): then nothing of the
+     * document goes up — the InputOperations are resolved against the logs in HBM, the Changes made are appended to them on the device and the new handle
+     * comes back beside the made rows (the old one is released) */
+    napi_valuetype vt;
+    const bool resident = napi_typeof(env, argv[1], &vt) == napi_ok && vt == napi_external;
     ptx_batch pb;
-    if (!read_batch(env, argv[1], &pb)) return nullptr;
+    memset(&pb, 0, sizeof(pb));
+    ptx_dbatch* rdb = resident ? dbatch_of(env, argv[1]) : nullptr;
+    if (resident) {
+        if (!rdb) return throw_msg(env, "change: bad resident handle");
+        pb.n_logs = L.batch_n_logs(rdb);
+    } else if (!read_batch(env, argv[1], &pb)) return nullptr;
     napi_value io = argv[2];
     ptx_input_ops in;
     memset(&in, 0, sizeof(in));
@@ -633,6 +644,7 @@ napi_value Change(napi_env env, napi_callback_info info) {
     in.actor = (const uint32_t*)p;
     in.n_logs = pb.n_logs;
     in.max_actors = u32_prop(env, io, "maxActors", pb.max_actors);
+    if (resident && in.max_actors == 0) return throw_msg(env, "change on a resident handle: inputOps.maxActors is needed");
     ptx_dbatch *db = nullptr, *made = nullptr;
     ptx_dresult* dr = nullptr;
     ptx_host_batch hb;
@@ -645,14 +657,17 @@ napi_value Change(napi_env env, napi_callback_info info) {
             napi_create_typedarray(env, napi_uint32_array, pb.n_logs, ab, 0, &status_arr) != napi_ok)
             return throw_msg(env, "change: cannot allocate the status array");
     }
-    ptx_status st = L.batch_upload(ctx, &pb, &db);
+    ptx_dbatch* after = nullptr;
+    ptx_status st = resident ? PTX_OK : L.batch_upload(ctx, &pb, &db);
+    if (resident) db = rdb;
     if (st == PTX_OK) st = L.result_alloc(ctx, db, &dr);
     if (st == PTX_OK) st = L.merge(ctx, db, dr);
     if (st == PTX_OK) st = L.sync(ctx);
     if (st == PTX_OK) st = L.change(ctx, db, dr, &in, &made, (uint32_t*)status_data);
     if (st == PTX_OK) st = L.batch_download(ctx, made, &hb);
+    if (st == PTX_OK && resident) st = L.batch_append_device(ctx, db, made, &after); /* the replicas after the edit: still resident, nothing re-uploaded */
     if (dr) L.dresult_free(ctx, dr);
-    if (db) L.batch_free(ctx, db);
+    if (db && !resident) L.batch_free(ctx, db);
     if (made) L.batch_free(ctx, made);
     if (st != PTX_OK) {
         char msg[1024];
@@ -665,6 +680,12 @@ napi_value Change(napi_env env, napi_callback_info info) {
     if (!batch || napi_create_object(env, &out) != napi_ok) return throw_msg(env, "change: cannot build the result object");
     napi_set_named_property(env, out, "batch", batch);
     napi_set_named_property(env, out, "status", status_arr);
+    if (resident) {
+        L.batch_free(ctx, rdb); /* superseded by `after` */
+        napi_value ext;
+        NAPI_OK(napi_create_external(env, after, nullptr, nullptr, &ext));
+        napi_set_named_property(env, out, "handle", ext);
+    }
     return out;
 }
 
@@ -717,9 +738,14 @@ napi_value Cursors(napi_env env, napi_callback_info info) {
     napi_value argv[3];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     ptx_ctx* ctx = argc > 2 ? ctx_of(env, argv[0]) : nullptr;
-    if (!ctx) return throw_msg(env, "cursors(ctx, batch, queries)");
+    if (!ctx) return throw_msg(env, "cursors(ctx, batch | resident handle, queries)");
+    napi_valuetype vt;
+    const bool resident = napi_typeof(env, argv[1], &vt) == napi_ok && vt == napi_external; /* the logs already in HBM: nothing is encoded or uploaded */
     ptx_batch pb;
-    if (!read_batch(env, argv[1], &pb)) return nullptr;
+    memset(&pb, 0, sizeof(pb));
+    ptx_dbatch* rdb = resident ? dbatch_of(env, argv[1]) : nullptr;
+    if (resident && !rdb) return throw_msg(env, "cursors: bad resident handle");
+    if (!resident && !read_batch(env, argv[1], &pb)) return nullptr;
     const void *ql = nullptr, *qk = nullptr, *qa = nullptr;
     size_t n = 0, n2 = 0, n3 = 0;
     if (!column(env, argv[2], "log", 4, &ql, &n) || !column(env, argv[2], "kind", 1, &qk, &n2) || !column(env, argv[2], "arg", 8, &qa, &n3) || n != n2 || n != n3)
@@ -728,14 +754,15 @@ napi_value Cursors(napi_env env, napi_callback_info info) {
     std::vector<uint32_t> status(n ? n : 1);
     ptx_dbatch* db = nullptr;
     ptx_dresult* dr = nullptr;
-    ptx_status st = L.batch_upload(ctx, &pb, &db);
+    ptx_status st = resident ? PTX_OK : L.batch_upload(ctx, &pb, &db);
+    if (resident) db = rdb;
     if (st == PTX_OK) st = L.result_alloc(ctx, db, &dr);
     if (st == PTX_OK) st = L.merge(ctx, db, dr);
     if (st == PTX_OK) st = L.sync(ctx);
     if (st == PTX_OK) st = L.resolve_cursors(ctx, db, dr, (uint32_t)n, (const uint32_t*)ql, (const uint8_t*)qk, (const uint64_t*)qa, out.data(), status.data());
     std::string err = st != PTX_OK ? L.last_error(ctx) : "";
     if (dr) L.dresult_free(ctx, dr);
-    if (db) L.batch_free(ctx, db);
+    if (db && !resident) L.batch_free(ctx, db);
     if (st != PTX_OK) return throw_msg(env, ("ptx_resolve_cursors failed: " + err).c_str());
     napi_value o, v;
     NAPI_OK(napi_create_object(env, &o));

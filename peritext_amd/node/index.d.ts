@@ -109,7 +109,7 @@ export class MergeEngine {
      *  false: every read encodes, uploads and replays the whole log of every handle. */
     constructor(opts?: { device?: number; libPath?: string; addonPath?: string; resident?: boolean })
     /** what the resident replicas cost so far: documents uploaded whole (first read, or a new actor re-ranked its op ids), appends, rows sent to the device */
-    readonly stats: { residentUploads: number; residentAppends: number; rowsUploaded: number }
+    readonly stats: { residentUploads: number; residentAppends: number; rowsUploaded: number; residentChanges: number; residentChangeMs: number; residentCursorCalls: number }
     close(): void
     applyMaterialize(batch: WireBatch, wantPatches?: boolean): WireResult
     /** docs -> replica logs -> changes in application order  =>  spans per replica log */

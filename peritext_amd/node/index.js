@@ -611,7 +611,7 @@ class MergeEngine {
          * {resident: false}: every flush encodes, uploads and replays every handle's whole log in one launch (the round-2 behaviour). */
         this.resident = o.resident !== false
         this.sessions = new Map() /* docId -> resident state of the document's handles */
-        this.stats = { residentUploads: 0, residentAppends: 0, rowsUploaded: 0 }
+        this.stats = { residentUploads: 0, residentAppends: 0, rowsUploaded: 0, residentChanges: 0, residentChangeMs: 0, residentCursorCalls: 0 }
     }
     close() {
         if (this.ctx) {
@@ -792,6 +792,11 @@ class MergeEngine {
              *  returns {change, patches} like the reference (patches = what applying the change returned). */
             change(ops) {
                 if (rep.actorId === undefined) throw new Error("engine.replica(docId, actorId): an actor id is needed to make changes")
+                const onDevice = self.residentChange(rep, ops, admit) /* the resident write path: nothing of the document is encoded or uploaded */
+                if (onDevice) {
+                    const patches = this.getPatches()
+                    return { change: onDevice, patches: patches[patches.length - 1] }
+                }
                 const mates = self.pending.filter(r => r.docId === rep.docId)
                 const docs = [mates.map(r => r.changes)]
                 const comments = []
@@ -847,9 +852,52 @@ class MergeEngine {
         }
     }
     /** queries: [kind (0 resolve, 1 get), elemId string | BigInt index] of one replica -> device answers (ptx_resolve_cursors) */
+    /** Micromerge.change on the RESIDENT logs (bridge.ts:535 makes one per keystroke): the replica's new Changes are in HBM already (or go up now, alone), the
+     *  InputOperations are resolved there (ptx_change on the resident batch), the Change made is appended there (ptx_batch_append_device) and comes back as a
+     *  few rows for the host's own bookkeeping.  null: not applicable (no resident sessions, ops on map objects, an actor or a comment id the session has no
+     *  rank for yet) — the caller takes the path that encodes the document. */
+    residentChange(rep, ops, admit) {
+        if (!this.resident || ops.some(isMapInput)) return null
+        const mates = this.pending.filter(r => r.docId === rep.docId)
+        if (mates.some(r => r.error !== null)) return null
+        const { batch, st } = this.residentApply(rep.docId, mates, false, true)
+        if (st.actorList.indexOf(rep.actorId) < 0 || mates.some(m => m.actorId !== undefined && st.actorList.indexOf(m.actorId) < 0)) return null
+        for (const op of ops) if (op.markType === "comment" && op.attrs && op.attrs.id !== undefined && st.commentList.indexOf(op.attrs.id) < 0) st.commentList.push(op.attrs.id) /* takes the next rank */
+        const me = mates.indexOf(rep)
+        const view = { values: st.tables.values, urls: st.tables.urls, keys: st.tables.keys, mapValues: st.tables.mapValues, logDoc: mates.map(() => 0), docActors: [st.actorList],
+                       docComments: [st.commentList], maxActors: st.maxActors || st.actorList.length }
+        const io = encodeInputOps(view, mates.map(m => (m === rep ? [ops] : [])), mates.map(m => (m.actorId === undefined ? rep.actorId : m.actorId)))
+        io.maxActors = view.maxActors
+        const t0 = process.hrtime.bigint()
+        const raw = this.addon.change(this.ctx, st.handle, io)
+        this.stats.residentChangeMs += Number(process.hrtime.bigint() - t0) / 1e6 /* merge of the resident logs + ptx_change + append on the device + the made rows back */
+        st.handle = raw.handle
+        this.stats.residentChanges++
+        if (raw.status[me] !== 0) throw new RangeError(STATUS_MESSAGES[raw.status[me]] || "change error " + raw.status[me])
+        const made = Object.assign(raw.batch, view)
+        const change = decodeChanges(made, me, st.textObjs[me] === undefined ? null : st.textObjs[me])[0]
+        admit(change)
+        /* the host's view of the resident logs follows: the made rows of this replica, its Change is "seen" (it is in HBM, no upload pending) */
+        const b = Number(made.logOff[me]), e = Number(made.logOff[me + 1])
+        const grow = (old, add) => {
+            const out = new old.constructor(old.length + add.length)
+            out.set(old)
+            out.set(add, old.length)
+            return out
+        }
+        st.payload[me] = grow(st.payload[me], made.payload.subarray(b, e))
+        st.markType[me] = grow(st.markType[me], made.markType.subarray(b, e))
+        st.chgNops[me].push(e - b)
+        st.rows[me] += e - b
+        st.seen[me] = rep.changes.slice()
+        if (st.textObjs[me] === undefined) for (const op of change.ops) if (op.action === "makeList" && op.key === "text") st.textObjs[me] = op.opId
+        return change
+    }
     cursorQueries(rep, queries) {
         const mates = this.pending.filter(r => r.docId === rep.docId)
-        const batch = encodeDocs([mates.map(r => r.changes)])
+        const useResident = this.resident && !mates.some(r => r.error !== null)
+        const synced = useResident ? this.residentApply(rep.docId, mates, false, true) : null
+        const batch = synced ? { docActors: [synced.st.actorList] } : encodeDocs([mates.map(r => r.changes)])
         const log = mates.indexOf(rep)
         const actors = batch.docActors[0]
         let textObj = null
@@ -866,7 +914,8 @@ class MergeEngine {
                 q.arg[k] = rank < 0 ? 0n : (BigInt(ctr) << 32n) | BigInt(rank)
             }
         })
-        const r = this.addon.cursors(this.ctx, batch, q)
+        if (synced) this.stats.residentCursorCalls++
+        const r = this.addon.cursors(this.ctx, synced ? synced.st.handle : batch, q) /* the resident logs: nothing is encoded or uploaded */
         for (const k of missing) r.status[k] = 1
         return { out: r.out, status: r.status, textObj, oid: v => String(v >> 32n) + "@" + actors[Number(v & 0xffffffffn)] }
     }
@@ -876,7 +925,7 @@ class MergeEngine {
      * is encoded and uploaded afresh.  Returns {batch: what decodeSpans / decodePatches read, res, firstChange: per handle, the first Change whose patches
      * `res` holds}.
      */
-    residentApply(docId, group, wantPatches) {
+    residentApply(docId, group, wantPatches, syncOnly) {
         let st = this.sessions.get(docId)
         const textObjOf = changes => {
             for (const ch of changes) for (const op of ch.ops) if (op.action === "makeList" && op.key === "text" && (op.obj === undefined || op.obj === null || op.obj === ROOT || typeof op.obj === "symbol")) return op.opId
@@ -945,7 +994,9 @@ class MergeEngine {
         }
         const batch = { nLogs: group.length, logOff, chgOff, chgNops: cat(st.chgNops, Uint32Array), payload: cat(st.payload, Uint32Array), markType: cat(st.markType, Uint8Array),
                         values: st.tables.values, urls: st.tables.urls, logDoc: group.map(() => 0), docActors: [st.actorList], docComments: [st.commentList] }
-        const res = this.addon.residentApply(this.ctx, st.handle, !!wantPatches, firstRow)
+        st.maxActors = delta.maxActors !== undefined && delta.chgActor.length ? delta.maxActors : st.maxActors /* the row stride of the resident envelope */
+        /* syncOnly: the resident logs are current (only the new Changes went up) — the caller works on them in HBM (change(), cursors) */
+        const res = syncOnly ? null : this.addon.residentApply(this.ctx, st.handle, !!wantPatches, firstRow)
         return { batch, res, firstChange, st }
     }
     flush(wantPatches) {

@@ -575,6 +575,71 @@ if (cmd === "encode") {
         b.close()
     })
     console.log(JSON.stringify({ ok: true, steps, appends, uploads, rowsUploaded, rows }))
+} else if (cmd === "resident-edit") {
+    /* GPU (VERDICT r3 next #7): an editing session on RESIDENT replicas — every transaction is one replica().change(ops) (what bridge.ts:535 does per keystroke) plus,
+     * now and then, a sync (applyChange of the Change on the other replica, bridge.ts:253) and cursor calls.  Engine A keeps the logs in HBM: change() and the
+     * cursor calls work on them there (ptx_change / ptx_resolve_cursors on the resident batch, ptx_batch_append_device) — after the first upload of the
+     * document NOTHING of it is uploaded whole again.  Engine B ({resident: false}) encodes and uploads the document for every call.  Both must return the same
+     * Changes, patches, cursors and spans at every step. */
+    const edits = parseInt(process.argv[3] || "200", 10)
+    const a = new host.MergeEngine(), b = new host.MergeEngine({ resident: false })
+    const A = [a.replica("d", "alice"), a.replica("d", "bob")], B = [b.replica("d", "alice"), b.replica("d", "bob")]
+    let seed = 4242
+    const rnd = n => (seed = (seed * 1103515245 + 12345) >>> 0) % n
+    /* both actors are known from the start: alice makes the list, bob receives it and types once (a new actor re-ranks the op ids: that is a re-encode by design) */
+    const first = A[0].change([{ path: [], action: "makeList", key: "text" }, { path: ["text"], action: "insert", index: 0, values: "Hello".split("") }])
+    assert.deepStrictEqual(B[0].change([{ path: [], action: "makeList", key: "text" }, { path: ["text"], action: "insert", index: 0, values: "Hello".split("") }]).change, first.change)
+    A[1].applyChange(first.change); B[1].applyChange(first.change)
+    const c2 = A[1].change([{ path: ["text"], action: "insert", index: 5, values: ["!"] }])
+    assert.deepStrictEqual(B[1].change([{ path: ["text"], action: "insert", index: 5, values: ["!"] }]).change, c2.change)
+    A[0].applyChange(c2.change); B[0].applyChange(c2.change)
+    A[0].getTextWithFormatting(["text"]); A[1].getTextWithFormatting(["text"])
+    const uploadsAfterSetup = a.stats.residentUploads, rowsAfterSetup = a.stats.rowsUploaded
+    const pending = [[], []] /* Changes made by replica r that the other has not seen yet */
+    let len = [6, 6], made = 0, cursorCalls = 0
+    for (let e = 0; e < edits; e++) {
+        const r = rnd(2)
+        const k = rnd(10)
+        let ops
+        if (k < 6 || len[r] < 4) ops = [{ path: ["text"], action: "insert", index: rnd(len[r] + 1), values: [String.fromCharCode(97 + rnd(26))] }]
+        else if (k < 8) ops = [{ path: ["text"], action: "delete", index: rnd(len[r] - 1), count: 1 }]
+        else {
+            const s0 = rnd(len[r] - 1), e0 = s0 + 1 + rnd(len[r] - s0 - 1)
+            const mt = ["strong", "em", "link", "comment"][rnd(4)]
+            ops = [{ path: ["text"], action: rnd(4) ? "addMark" : "removeMark", markType: mt, startIndex: s0, endIndex: e0 }]
+            if (mt === "link" && ops[0].action === "addMark") ops[0].attrs = { url: "https://" + "abc"[rnd(3)] + ".example" }
+            if (mt === "comment") ops[0].attrs = { id: "c" + rnd(6) }
+        }
+        const ga = A[r].change(ops), gb = B[r].change(ops)
+        assert.deepStrictEqual(ga.change, gb.change, "edit " + e)
+        assert.deepStrictEqual(ga.patches, gb.patches, "patches of edit " + e)
+        made++
+        if (ops[0].action === "insert") len[r]++
+        if (ops[0].action === "delete") len[r]--
+        pending[r].push(ga.change)
+        if (rnd(5) === 0) { /* sync both ways */
+            for (const from of [0, 1]) {
+                for (const ch of pending[from]) { A[1 - from].applyChange(ch); B[1 - from].applyChange(ch) }
+                pending[from] = []
+            }
+            const sa = norm(A[0].getTextWithFormatting(["text"]))
+            assert.deepStrictEqual(sa, norm(B[0].getTextWithFormatting(["text"])))
+            assert.deepStrictEqual(sa, norm(A[1].getTextWithFormatting(["text"])), "synced replicas converge")
+            len = [0, 1].map(q => A[q].getTextWithFormatting(["text"]).reduce((n, s) => n + s.text.length, 0))
+        }
+        if (rnd(7) === 0 && len[r] > 0) {
+            const i = rnd(len[r])
+            const cur = A[r].getCursor(["text"], i)
+            assert.deepStrictEqual(cur, B[r].getCursor(["text"], i))
+            assert.strictEqual(A[r].resolveCursor(cur), i)
+            cursorCalls++
+        }
+    }
+    const out = { ok: true, edits: made, cursorCalls, wholeDocumentUploadsAfterSetup: a.stats.residentUploads - uploadsAfterSetup, rowsUploadedAfterSetup: a.stats.rowsUploaded - rowsAfterSetup,
+                  residentChanges: a.stats.residentChanges, residentCursorCalls: a.stats.residentCursorCalls, msPerResidentChange: a.stats.residentChangeMs / Math.max(a.stats.residentChanges, 1),
+                  appends: a.stats.residentAppends }
+    a.close(); b.close()
+    console.log(JSON.stringify(out))
 } else if (cmd === "generate") {
     /* GPU: on-device change() reproduces the committed PTXGEN fixtures (config + seed in the file) and merges them to their spans */
     const engine = new host.MergeEngine()
@@ -594,6 +659,6 @@ if (cmd === "encode") {
     engine.close()
     console.log(JSON.stringify({ ok: true, logs }))
 } else {
-    console.error("usage: encode|load|run|patches|decode|generate|inputops|change|resident-mock|resident")
+    console.error("usage: encode|load|run|patches|decode|generate|inputops|change|resident-mock|resident|resident-edit|admit-mock|dts")
     process.exit(2)
 }

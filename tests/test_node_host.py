@@ -206,6 +206,20 @@ def test_node_host_resident_replicas():
 @pytest.mark.gpu
 @needs_node
 @needs_addon
+def test_node_host_resident_write_path():
+    """a 200-edit session of replica().change() / applyChange / getCursor / resolveCursor on resident replicas: after the set-up the document
+    is never uploaded whole again — change() and the cursor calls run on the logs in HBM (ptx_change / ptx_resolve_cursors on the resident batch,
+    ptx_batch_append_device) — and every Change, patch, cursor and span equals those of an engine that encodes and uploads the document for every call
+    (reference/src/bridge.ts:253, :535)."""
+    out = _node("resident-edit", "200", timeout=900)
+    assert out["ok"] and out["edits"] == 200 and out["wholeDocumentUploadsAfterSetup"] == 0
+    assert out["residentChanges"] >= 200 and out["residentCursorCalls"] >= out["cursorCalls"] > 0
+    assert out["rowsUploadedAfterSetup"] < out["edits"]  # only the Changes received from the other replica go up, each once
+
+
+@pytest.mark.gpu
+@needs_node
+@needs_addon
 def test_node_host_cursors():
     """replica().getCursor / resolveCursor through N-API on the GPU against the reference's answers."""
     out = _node("cursors", os.path.join(H.GOLDEN, "ptxgen_mini.json"), os.path.join(H.GOLDEN, "edge_cases_ref.json"), timeout=600)
