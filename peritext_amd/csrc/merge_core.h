@@ -650,6 +650,30 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         return PTX_OK;
     }
 
+    /* ---- the loads of P1's first step (declared here: with the usual three-actor admission they go out as soon as its walk has let go of its registers, and
+     *      are in flight during the validation of the walk and the clearing of the bitmaps: most of one trip to HBM, of the handful a 256-op log is) ---- */
+    bool p1_loaded = false;
+    const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_full = N / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
+    static_assert(PTX_U1 == 3, "three class bytes per dword; the fourth byte read belongs to the next thread's first row");
+    uint64_t id[PTX_U1], id_n[PTX_U1];
+    uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
+    /* this thread's PTX_U1 consecutive rows of a step.  A wave whose rows all exist reads them from one address; the wave that
+     * holds the end of the log clamps every row index (effects of the rows past the end are masked).  The two byte columns are
+     * read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
+#define PTX_P1_LOAD(g_, id_, a_, mt_)                                       \
+{                                                                       \
+    const uint32_t r0_ = (g_) * PTX_U1;                                 \
+    if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) { /* one address, 16 + 8 bytes */ \
+        PTX_P1_IDS(id_, op_id + r0_)                                    \
+    } else {                                                            \
+        _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {            \
+            const uint32_t r_ = r0_ + (uint32_t)u;                      \
+            id_[u] = op_id[r_ < N ? r_ : N - 1u];                       \
+        }                                                               \
+    }                                                                   \
+    PTX_P1_BYTES(action, r0_, a_)                                       \
+    PTX_P1_BYTES(mark_type, r0_, mt_)                                   \
+}
     /* ---- P0: causal admission (micromerge.ts:499-511), when the batch carries the Change envelope ----
      * Sequential rule: change c of actor a is admitted iff seq == clock[a] + 1 and clock[b] >= deps[b] for all b,
      * where clock[b] counts the changes of b applied before c.  Envelope per change: chg_hdr = actor << 20 | nops and one
@@ -737,6 +761,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 }
 #undef PTX_ADM_STEP
 #undef PTX_ADM_LOAD
+                PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a4, mt4)
+                p1_loaded = true;
                 mx0 = ptx_wave_pk_max_u16(mx0);
                 mx1 = ptx_wave_pk_max_u16(mx1);
                 bad = ptx_wave_max(bad);
@@ -1059,28 +1085,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     /* ---- P1: ONE pass over the rows: id bitmaps, row lists per class ---- */
     {
         uint32_t err4 = 0, ctr_hi = 0, act_hi = 0; /* malformed class bytes; max counter - 1 and max actor met */
-        const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_full = N / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
-        static_assert(PTX_U1 == 3, "three class bytes per dword; the fourth byte read belongs to the next thread's first row");
-        uint64_t id[PTX_U1], id_n[PTX_U1];
-        uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
-        /* this thread's PTX_U1 consecutive rows of a step.  A wave whose rows all exist reads them from one address; the wave that
-         * holds the end of the log clamps every row index (effects of the rows past the end are masked).  The two byte columns are
-         * read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
-#define PTX_P1_LOAD(g_, id_, a_, mt_)                                       \
-    {                                                                       \
-        const uint32_t r0_ = (g_) * PTX_U1;                                 \
-        if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) { /* one address, 16 + 8 bytes */ \
-            PTX_P1_IDS(id_, op_id + r0_)                                    \
-        } else {                                                            \
-            _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {            \
-                const uint32_t r_ = r0_ + (uint32_t)u;                      \
-                id_[u] = op_id[r_ < N ? r_ : N - 1u];                       \
-            }                                                               \
-        }                                                                   \
-        PTX_P1_BYTES(action, r0_, a_)                                       \
-        PTX_P1_BYTES(mark_type, r0_, mt_)                                   \
-    }
-        PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a4, mt4) /* the first rows are on their way while the bitmaps are cleared */
+        if (!p1_loaded) { PTX_P1_LOAD(PTX_G_OF(0u, p1_steps), id, a4, mt4) } /* (no admission phase ahead: the first rows go out here, while the bitmaps are cleared) */
         /* during this pass ib[w] = {ids of the inserts, ids of ALL ops (duplicate detection)}: one 8-byte LDS atomic per row */
         PTX_FOR(w, nw + 1) {
             PtxBitWord z;
