@@ -522,8 +522,12 @@ void ptx_host_batch_free(ptx_host_batch* hb);
  * library sizes per log, 32-bit indices; an order of magnitude slower per op), up to 2^26 rows and an id keyspace (max counter + 1) x (actors) of 2^30;
  * PTX_ERR_CAPACITY beyond that.  ptx_replay_patches / ptx_change / ptx_resolve_cursors still work on chip only: such a log reports PTX_ERR_CAPACITY there. */
 uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx);
-/* Name of the kernel the merge launches (to find it in a rocprofv3 trace). */
+/* Name of the kernel the merge launches (to find it in a rocprofv3 trace): the family's ... */
 const char* ptx_kernel_name(void);
+/* ... and the build of it ptx_merge launches for THIS resident batch under this context: "ptx_merge_kernel", "ptx_merge_kernel_w7" (the same body held to the
+ * scalar registers of seven waves per SIMD: launched when the batch's LDS window lets more than 24 waves share a CU) or "ptx_merge_kernel_many" (admission of
+ * documents with more than three actors); a split batch's few large logs run as "..._rest*" / "ptx_merge_big_kernel" beside it. */
+const char* ptx_batch_kernel_name(const ptx_ctx* ctx, const ptx_dbatch* b);
 
 #ifdef __cplusplus
 }

@@ -323,6 +323,7 @@ FUNCTIONS = {
     "ptx_host_batch_free": (None, [C.POINTER(ptx_host_batch)]),
     "ptx_max_ops_per_log": (C.c_uint32, [vp]),
     "ptx_kernel_name": (C.c_char_p, []),
+    "ptx_batch_kernel_name": (C.c_char_p, [vp, vp]),
 }
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")

@@ -563,6 +563,12 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
     return PTX_OK;
 }
 
+/* would the LDS window let more than 24 waves share a CU?  Then the build of the merge kernel that fits 7 waves per SIMD (PTX_SGPRS_W7) */
+static bool wants_w7(const ptx_ctx* ctx, const ptx_dbatch* b, uint32_t lds) {
+    const uint32_t waves = (b->threads + 63u) / 64u, by_lds = (uint32_t)(ctx->max_lds / ((((uint64_t)lds + PTX_LDS_GRANULE - 1u) / PTX_LDS_GRANULE) * PTX_LDS_GRANULE));
+    return by_lds * waves > 24u;
+}
+
 static ptx_status check_batch(ptx_ctx* ctx, const ptx_batch* h) {
     if (!h) return fail(ctx, PTX_ERR_INVALID_ARG, "batch is NULL");
     if (h->n_logs && !h->log_off) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off is NULL");
@@ -600,6 +606,13 @@ extern "C" {
 uint32_t ptx_abi_version(void) { return PTX_ABI_VERSION; }
 
 const char* ptx_kernel_name(void) { return "ptx_merge_kernel"; }
+
+const char* ptx_batch_kernel_name(const ptx_ctx* ctx, const ptx_dbatch* b) {
+    if (!ctx || !b) return "ptx_merge_kernel";
+    const bool admit = b->chg_off && !(ctx->flags & PTX_FLAG_NO_ADMISSION);
+    if (admit && b->max_actors > 3) return "ptx_merge_kernel_many";
+    return wants_w7(ctx, b, b->log_index ? b->lds_main : b->lds_bytes) ? "ptx_merge_kernel_w7" : "ptx_merge_kernel";
+}
 
 const char* ptx_last_error(const ptx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -1062,9 +1075,7 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
         else if (admit && b->max_actors > 3)
             hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);
         else {
-            /* would the LDS window let more than 24 waves share a CU?  Then the build that fits 7 waves per SIMD */
-            const uint32_t waves = (b->threads + 63u) / 64u, by_lds = (uint32_t)(ctx->max_lds / ((((uint64_t)lds + PTX_LDS_GRANULE - 1u) / PTX_LDS_GRANULE) * PTX_LDS_GRANULE));
-            const bool w7 = by_lds * waves > 24u;
+            const bool w7 = wants_w7(ctx, b, lds);
             if (part) hipLaunchKernelGGL(w7 ? ptx_merge_kernel_rest_w7 : ptx_merge_kernel_rest, dim3(grid), dim3(b->threads), lds, st, A);
             else hipLaunchKernelGGL(w7 ? ptx_merge_kernel_w7 : ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, st, A);
         }

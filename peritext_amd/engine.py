@@ -367,3 +367,7 @@ class Engine:
 
     def kernel_name(self):
         return self.lib.ptx_kernel_name().decode()
+
+    def batch_kernel_name(self, dbatch):
+        """The build of the merge kernel ptx_merge launches for this resident batch (its name in a rocprofv3 trace)."""
+        return self.lib.ptx_batch_kernel_name(self.ctx, dbatch).decode()
