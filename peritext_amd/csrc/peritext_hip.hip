@@ -1510,23 +1510,10 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
     uint64_t need = 0, need_g = 0;
     for (uint32_t l = 0; l < L; ++l) {
         need = std::max<uint64_t>(need, ptx_replay_lds_need_hdr(hdr[l]));
-        need_g = std::max<uint64_t>(need_g, ptx_replay_lds_need_hdr(hdr[l], true, 0));
+        need_g = std::max<uint64_t>(need_g, ptx_replay_lds_need_hdr(hdr[l], true));
     }
-    /* (global winners) how much of a mark op's slot list stays in the LDS — it saves the op two global round trips, and costs resident logs.  Measured on
-     * one MI355X: 4 096-op logs (19 per CU without it) are fastest at 1 024 entries = 15 per CU, 2 048-op logs (more than the CU's 28 wave
-     * slots would take) lose a quarter at 1 024.  So: what fits while the wave slots stay full, else what costs no more than a fifth of the resident logs. */
-    uint32_t seg_lds = 0;
-    {
-        /* (the replay kernel's 106 SGPRs hold it to 6 waves per SIMD = 24 one-wave logs per CU, profiles/r03_p_*; the LDS comes in granules) */
-        const uint64_t lds0 = std::max<uint64_t>((need_g + PTX_LDS_GRANULE - 1) / PTX_LDS_GRANULE * PTX_LDS_GRANULE, PTX_LDS_GRANULE), logs0 = std::min<uint64_t>(ctx->max_lds / lds0, 24);
-        const uint64_t keep = logs0 >= 24 ? 24 : (logs0 * 4 + 4) / 5;
-        const uint64_t room = keep ? ctx->max_lds / keep : 0;
-        if (room > need_g + 256) seg_lds = (uint32_t)std::min<uint64_t>(((room - need_g - 256) / 2) & ~63ull, 1536);
-        for (uint32_t l = 0; l < L && seg_lds; ++l) need_g = std::max<uint64_t>(need_g, ptx_replay_lds_need_hdr(hdr[l], true, seg_lds));
-    }
-    /* The replay is one wave per log and lives on occupancy (the op chain is dependent round trips).  Above PTX_REPLAY_GWIN_ABOVE bytes of working set the LDS,
-     * not the wave slots, bounds the resident logs: the three per-slot winner arrays (more than half of it) and the tail of a mark op's slot list move to global
-     * memory — 3 x the resident logs for a global round trip or two per mark op (0.55 -> 1.04 G ops/s on 4 096-op logs). */
+    /* The replay is one wave per log and lives on occupancy.  Above PTX_REPLAY_GWIN_ABOVE bytes of working set the LDS, not the wave slots, bounds the resident
+     * logs: the per-slot link urls and the tables of applied mark ops (half of it; read only by the few ops that need them) move to global memory. */
     const bool gwin = need > PTX_REPLAY_GWIN_ABOVE && !(ctx->flags & PTX_FLAG_REPLAY_LDS_ONLY);
     if (gwin) need = need_g;
     const uint32_t lds_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, ctx->max_lds); /* larger logs report PTX_ERR_CAPACITY */
@@ -1593,7 +1580,6 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
             A.n_logs = L;
             A.lds_bytes = lds_bytes;
             A.win_scratch = d_win;
-            A.seg_lds = seg_lds;
             A.first_row = d_first;
             (void)hipEventRecord(ctx->ev0, ctx->stream);
             if (gwin) hipLaunchKernelGGL(ptx_replay_kernel_gwin, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);

@@ -59,6 +59,8 @@ PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__popc(x); }
 PTX_DEV uint16_t ptx_coherent_load16(const uint16_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PTX_DEV void ptx_coherent_store16(uint16_t* p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PTX_DEV uint32_t ptx_coherent_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PTX_DEV void ptx_coherent_store32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PTX_DEV uint32_t ptx_brev(uint32_t x) { return __builtin_bitreverse32(x); } /* v_bfrev_b32 */
 PTX_DEV void ptx_global_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 /* wave-aggregated append: ONE LDS atomic per wave, lanes get consecutive slots.  May be called in
  * divergent control flow (the ballot covers the active lanes only). */

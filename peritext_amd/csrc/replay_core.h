@@ -13,17 +13,30 @@
  * How: ptx_merge_kernel has already produced the FINAL document position (rank incl. tombstones) of every element
  * (`elem_rank`).  Because the RGA order of any two elements never changes once both exist, the state of the
  * replica at application time t is the final order restricted to the elements inserted before t.  The log is therefore
- * replayed in time order over arrays indexed by final rank / final boundary slot (slot = 2*rank + side):
+ * replayed in time order over BITMAPS indexed by final rank / final boundary slot (slot = 2*rank + side); a mark op is a
+ * handful of passes with one 32-slot word per lane (round 4; before, one defined slot per lane out of a compacted list,
+ * with per-slot winner arrays):
  *   present   bit per rank  {bits, running popcount prefix}: inserted and not deleted -> visible index = popcount below
  *   defined   bit per slot : the reference's `markOpsBefore/After !== undefined` (peritext.ts:167-214): set at the start
  *             and end slot of every applied mark op; patches break at every defined slot inside the op's range
- *   win[3]    per defined slot: row of the max-opId covering op per non-multi mark type (opsToMarks, :304-313)
+ *   on[3]     bit per defined slot and LWW type (strong, em, link): the max-opId op that covers the slot is an addMark
+ *             (opsToMarks, :304-313).  A slot defined later copies the closest defined slot to its left (:176) — which is
+ *             the same as saying that an op covers the slots of its interval [start, end) for good.  So "does this op win
+ *             at slot s" (compareOpIds against the slot's winner) needs no per-slot winner: it LOSES exactly at the slots
+ *             covered by an earlier-applied op of its type with a larger opId.  Those are rare (an op that arrives after
+ *             a concurrent one with a larger id): the op whose id exceeds every applied id of its type (kept in a
+ *             register) wins everywhere; the others scan the table of applied ops of the type (row, start, end) once
+ *             and OR the intervals of the larger ones into a mask.
+ *   url       per slot, links only: the url of the winner where the link is on (an addMark of a link over a linked
+ *             slot changes it iff the urls differ, :208; the marks of an inserted char name it)
  *   anyc      bit per slot : some comment op covers (the `comment: []` state)
  *   comment ops: [start, end) slots + per-id chains in application order (the LAST-applied covering op of an id
- *             decides its presence, :314-321)
- * One 64-thread workgroup (one wave) per log: the replay is sequential in t, every step is a handful of wave-wide
- * passes over bitmap words / the defined slots of the range.  As ONE wave the phases need no s_barrier and no wait for the patches
- * just stored to HBM (nothing this kernel writes there is read back): PTX_SYNC_T is a compiler fence then.
+ *             decides its presence, :314-321): per word, the chain of the op's id is walked latest first over masks
+ * A changed slot opens a patch that the next defined slot closes; zero-width ones are dropped (:269-281): per word, the
+ * visible chars are spread to their "before" slots and one reversed addition hands every one of them to the defined slot
+ * that governs it, so only the records that will be written are counted, ranked (one scan) and written.
+ * One 64-thread workgroup (one wave) per log: the replay is sequential in t.  As ONE wave the phases need no s_barrier and
+ * no wait for the patches just stored to HBM (nothing this kernel writes there is read back): PTX_SYNC_T is a compiler fence then.
  *
  * Compiled two ways like merge_core.h (hipcc: the product kernel; g++ -DPTX_EMU: CPU test tooling only).
  */
@@ -54,35 +67,30 @@ struct PtxReplayArgs {
     uint32_t n_logs;
     uint32_t lds_bytes;
     const uint32_t* first_row; /* optional [n_logs]: only the records of the rows from here on are produced (the rows before are replayed for their state alone) */
-    uint32_t seg_lds;      /* (win_scratch) entries of a mark op's slot list kept in the LDS; the rest of the list lives behind the winner arrays */
-    uint16_t* win_scratch; /* optional: the per-slot winner arrays of every log live HERE (16 bytes per row of the batch + 128 per log; the list of a mark op's defined slots too) instead of in LDS */
+    uint16_t* win_scratch; /* optional: the per-slot link urls and the tables of applied mark ops of every log live HERE (16 bytes per row of the batch + 128 per log) instead of in LDS */
 };
 
 struct PtxReplayHdr {
-    uint32_t npatch;   /* patches produced so far (may run past the capacity: only the count is kept then) */
-    uint32_t ncom;     /* comment ops registered */
-    uint32_t tmp;      /* per-step scratch: max / counter */
-    uint32_t nvis;     /* visible length */
+    uint32_t tmp;      /* per-step scratch: counter */
+    uint32_t pad[3];
     uint32_t scan_tmp[36];
 };
 
-/* gwin: the per-slot winner arrays live in global memory and only the first seg_lds entries of a mark op's slot list in the LDS (PtxReplayArgs.seg_lds) */
-PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid, bool gwin = false, uint64_t seg_lds = 0) {
-    const uint64_t nw = (ks + 31) / 32, nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
-    const uint64_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
-    (void)nw;
-    return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + 2 * ptx_a16(4 * nws) +
-           ptx_a16(4 * (nws + 1)) + (gwin ? ptx_a16(2 * (segcap < seg_lds ? segcap : seg_lds)) : 3 * ptx_a16(2 * (2 * n + 2)) + ptx_a16(2 * segcap)) + ptx_a16(8 * ((segcap >> 5) + 2)) + 3 * ptx_a16(4 * nws) +
-           ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 3 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
+/* gscratch: the per-slot link urls and the op tables live in global memory (PtxReplayArgs.win_scratch) */
+PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid, bool gscratch = false) {
+    const uint64_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2, Kl = K - Kc;
+    (void)ks;
+    return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + 5 * ptx_a16(4 * nws) + 3 * ptx_a16(4 * (nws + 1)) +
+           (gscratch ? 0 : ptx_a16(4 * (2 * n + 2)) + 3 * ptx_a16(2 * (Kl + 1))) +
+           ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
            4 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
 }
-PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gwin = false, uint64_t seg_lds = 0) {
+PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gscratch = false) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
-    const uint64_t ks = ((uint64_t)h.max_counter + 1) * ((uint64_t)(h.max_actor > 4095u ? 4095u : h.max_actor) + 1);
-    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], ks, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u, gwin, seg_lds);
+    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], 0, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u, gscratch);
 }
-/* bytes of win_scratch a batch takes, and where the arrays of a log start (in u16 units): three winner arrays and the slot list of a mark op's range, each of at
- * most 2 N + 3 entries, 16-byte aligned */
+/* bytes of win_scratch a batch takes, and where the arrays of a log start (in u16 units): per-slot urls (4 bytes x (2 n + 2)) and three u16 columns of at most
+ * K + 1 entries, each 16-byte aligned: 4 n + 3 K + 40 units <= 8 N + 64 */
 PTX_HD uint64_t ptx_replay_win_bytes(uint64_t n_ops, uint64_t n_logs) { return 16 * n_ops + 128 * n_logs + 64; }
 PTX_HD uint64_t ptx_replay_win_at(uint64_t base_row, uint64_t log) { return 8 * base_row + 64 * log; }
 
@@ -98,8 +106,26 @@ PTX_DEV void ptx_patch_put(const PtxReplayArgs& A, uint64_t pbase, uint32_t pcap
     }
 }
 
-/* kGWin: the winner arrays live in global memory (A.win_scratch), read and written past the L1 (device-scope relaxed atomics) with the wave's outstanding
- * stores waited for wherever one lane reads what another has written */
+PTX_DEV uint32_t ptx_bits_from(uint32_t b) { return b >= 32u ? 0u : ~0u << b; }        /* bits [b, 32) */
+PTX_DEV uint32_t ptx_bits_below(uint32_t b) { return b >= 32u ? ~0u : (1u << b) - 1u; } /* bits [0, b) */
+/* the slots of [a, b) that fall into word w */
+PTX_DEV uint32_t ptx_span_mask(uint32_t a, uint32_t b, uint32_t w) {
+    const uint32_t lo = w << 5;
+    if (b <= lo || a >= lo + 32u || a >= b) return 0u;
+    return ptx_bits_from(a > lo ? a - lo : 0u) & ptx_bits_below(b - lo);
+}
+/* bit i of the low half -> bit 2 i */
+PTX_DEV uint32_t ptx_spread16(uint32_t x) {
+    x &= 0xFFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+/* kGWin: the per-slot urls and the op tables live in global memory (A.win_scratch), read and written past the L1 (workgroup-scope relaxed atomics) with the
+ * wave's outstanding stores waited for wherever one lane reads what another has written */
 template <uint32_t kThreads, bool kGWin = false>
 PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) {
     PtxReplayHdr* H = (PtxReplayHdr*)lds;
@@ -130,12 +156,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     const uint32_t Kid = Kc ? hd.n_comment_ids : 0u; /* id space of the document's comments as this log has seen it */
     const uint32_t K = hd.n_mark[0] + hd.n_mark[1] + hd.n_mark[2] + hd.n_mark[3];
     const uint32_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2;
-    const uint32_t segcap = (2 * n + 2 < 2 * K + 2 ? 2 * n + 2 : 2 * K + 2) + 1;
-    /* LWW winners of strong / em per slot: where every op id of the log has a dense key (counter * (max actor + 1) + actor, the merge kernel's) below
-     * 65 535, the slot holds the winner's key + 1 — compareOpIds is then a compare of two LDS values — instead of its row (whose op id would have to
-     * be fetched from HBM for every slot of every mark op: a dependent round trip in a sequential replay).  Links keep the row: their url is read through it. */
-    const uint32_t na1 = hd.max_actor + 1u;
-    const bool key_mode = (uint64_t)(hd.max_counter + 1ull) * na1 <= 65535ull;
+    /* tables of the applied LWW mark ops per type (0 strong, 1 em, 2 link), in application order */
+    const uint32_t Kl = K - Kc;
+    const uint32_t toff[3] = {0u, hd.n_mark[PTX_MARK_STRONG], hd.n_mark[PTX_MARK_STRONG] + hd.n_mark[PTX_MARK_EM]};
 
     PtxBump bp;
     bp.base = lds;
@@ -146,40 +169,40 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     PtxBitWord* present = ptx_alloc<PtxBitWord>(bp, nwe);
     uint32_t* defined = ptx_alloc<uint32_t>(bp, nws);
     uint32_t* anyc = ptx_alloc<uint32_t>(bp, nws);
-    uint32_t* wcnt = ptx_alloc<uint32_t>(bp, nws + 1); /* defined slots of the range per word -> prefix */
-    uint16_t* win[3];
+    uint32_t* on[3]; /* per defined slot: the winner of the type is an addMark */
+    on[0] = ptx_alloc<uint32_t>(bp, nws);
+    on[1] = ptx_alloc<uint32_t>(bp, nws);
+    on[2] = ptx_alloc<uint32_t>(bp, nws);
+    /* per word of a mark op's range: the changed slots -> the slots that open a record; their count -> its prefix; the slots the op wins (links) */
+    uint32_t* cw = ptx_alloc<uint32_t>(bp, nws + 1);
+    uint32_t* cnt = ptx_alloc<uint32_t>(bp, nws + 1);
+    uint32_t* uw = ptx_alloc<uint32_t>(bp, nws + 1);
+    uint32_t* lurl;
+    uint16_t *trow, *ta, *tl;
     if (kGWin) {
-        const uint32_t stride = (2u * n + 2u + 7u) & ~7u;
         uint16_t* g = A.win_scratch + ptx_replay_win_at(base, log);
-        win[0] = g;
-        win[1] = g + stride;
-        win[2] = g + 2u * stride;
+        const uint32_t ucols = (2u * (2u * n + 2u) + 7u) & ~7u, tcols = (Kl + 1u + 7u) & ~7u;
+        lurl = (uint32_t*)g;
+        trow = g + ucols;
+        ta = trow + tcols;
+        tl = ta + tcols;
     } else {
-        win[0] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* strong */
-        win[1] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* em */
-        win[2] = ptx_alloc<uint16_t>(bp, 2 * n + 2); /* link */
+        lurl = ptx_alloc<uint32_t>(bp, 2 * n + 2);
+        trow = ptx_alloc<uint16_t>(bp, Kl + 1);
+        ta = ptx_alloc<uint16_t>(bp, Kl + 1);
+        tl = ptx_alloc<uint16_t>(bp, Kl + 1);
     }
-#define PTX_WIN_LD(p_) (kGWin ? ptx_coherent_load16(p_) : *(p_))
-#define PTX_WIN_ST(p_, v_) do { if (kGWin) ptx_coherent_store16((p_), (uint16_t)(v_)); else *(p_) = (uint16_t)(v_); } while (0)
-#define PTX_WIN_FENCE() do { if (kGWin) ptx_global_stores_done(); } while (0)
-    uint32_t* won[3]; /* per slot: the winner of the type is an addMark (saves re-reading its action from HBM) */
-    won[0] = ptx_alloc<uint32_t>(bp, nws);
-    won[1] = ptx_alloc<uint32_t>(bp, nws);
-    won[2] = ptx_alloc<uint32_t>(bp, nws);
+#define PTX_G_LD16(p_) (kGWin ? ptx_coherent_load16(p_) : *(p_))
+#define PTX_G_ST16(p_, v_) do { if (kGWin) ptx_coherent_store16((p_), (uint16_t)(v_)); else *(p_) = (uint16_t)(v_); } while (0)
+#define PTX_G_LD32(p_) (kGWin ? ptx_coherent_load32(p_) : *(p_))
+#define PTX_G_ST32(p_, v_) do { if (kGWin) ptx_coherent_store32((p_), (uint32_t)(v_)); else *(p_) = (uint32_t)(v_); } while (0)
+#define PTX_G_FENCE() do { if (kGWin) ptx_global_stores_done(); } while (0)
     /* the next PTX_RCHUNK rows, resolved in parallel (element lookups, boundary slots) before they are replayed in order */
     uint64_t* c_id = ptx_alloc<uint64_t>(bp, PTX_RCHUNK);
     uint32_t* c_pay = ptx_alloc<uint32_t>(bp, PTX_RCHUNK);
     uint16_t* c_a = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* insert / delete: final rank; mark: start slot */
     uint16_t* c_b = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* mark: end slot */
-    uint16_t* c_key = ptx_alloc<uint16_t>(bp, PTX_RCHUNK); /* (key_mode) the op id's dense key + 1 */
     uint8_t* c_kind = ptx_alloc<uint8_t>(bp, PTX_RCHUNK);  /* PTX_RK_* | mark type << 4 | addMark << 6 */
-    /* defined slots of the op's range, ascending.  (global winners) the first A.seg_lds of them stay in the LDS — most ranges end there, and the list is
-     * read right after it is filled: a global one costs the op two more round trips — the rest goes to global memory behind the winner arrays */
-    const uint32_t segl = kGWin ? (segcap < A.seg_lds ? segcap : A.seg_lds) : segcap;
-    uint16_t* seg_l = ptx_alloc<uint16_t>(bp, segl);
-    uint16_t* seg = kGWin ? A.win_scratch + ptx_replay_win_at(base, log) + 3u * ((2u * n + 2u + 7u) & ~7u) : seg_l;
-#define PTX_SEG_LD(j_) ((j_) < segl ? seg_l[j_] : ptx_coherent_load16(&seg[j_]))
-    PtxBitWord* cf = ptx_alloc<PtxBitWord>(bp, (segcap >> 5) + 2); /* bit j: slot seg[j] opens a patch; prefix = its place */
     uint16_t* ca = ptx_alloc<uint16_t>(bp, Kc + 1);       /* comment op: first covered slot */
     uint16_t* cb = ptx_alloc<uint16_t>(bp, Kc + 1);       /*             first slot not covered (PTX_SLOT_NONE = to the end) */
     uint16_t* ccid = ptx_alloc<uint16_t>(bp, Kc + 1);
@@ -206,45 +229,38 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     PTX_FOR(w, nws) {
         defined[w] = 0;
         anyc[w] = 0;
-        won[0][w] = 0;
-        won[1][w] = 0;
-        won[2][w] = 0;
+        on[0][w] = 0;
+        on[1][w] = 0;
+        on[2][w] = 0;
     }
     PTX_FOR(c, Kid + 1) ctail[c] = PTX_SLOT_NONE;
-    PTX_LEADER {
-        H->npatch = 0;
-        H->ncom = 0;
-        H->tmp = 0;
-        H->nvis = 0;
-    }
+    PTX_LEADER { H->tmp = 0; }
     PTX_SYNC_T();
+    /* the wave's own counters: the same value in every lane */
+    uint32_t npatch = 0, ncom = 0, nvis = 0;
+    uint32_t ntab[3] = {0u, 0u, 0u};
+    uint64_t maxop[3] = {0ull, 0ull, 0ull}; /* largest opId applied so far per LWW type */
 
-    /* last defined slot strictly below `lim` -> out_ = slot + 1 (0 = none), the same in every lane; every thread calls it.  The workgroup is ONE
-     * wave: every lane keeps the best of its own words and a wave-wide maximum (register shuffles) makes it common — no LDS atomic, no read back */
-#define PTX_LAST_DEFINED_BELOW(lim_, out_) const uint32_t out_ = ptx_last_set_below(defined, (lim_));
-
-    /* make slot s_ a defined one: its state is that of the closest defined slot to the left (peritext.ts:176).  The leader reads the three winners before it
-     * stores any (one round trip when they are global). */
-#define PTX_COPY_SLOT_STATE(s_, l1_, v0_, v1_, v2_)                                               \
-    do {                                                                                        \
-        PTX_WIN_ST(&win[0][s_], v0_);                                                           \
-        PTX_WIN_ST(&win[1][s_], v1_);                                                           \
-        PTX_WIN_ST(&win[2][s_], v2_);                                                           \
-        if ((l1_) && ptx_bittest(anyc, (l1_)-1u)) anyc[(s_) >> 5] |= 1u << ((s_)&31u);          \
-        for (int ty_ = 0; ty_ < 3; ++ty_)                                                       \
-            if ((l1_) && ptx_bittest(won[ty_], (l1_)-1u)) won[ty_][(s_) >> 5] |= 1u << ((s_)&31u); \
-        defined[(s_) >> 5] |= 1u << ((s_)&31u);                                                 \
-    } while (0)
+#define PTX_VIS_AT(s_) ptx_bitrank(present, ((uint32_t)(s_) + 1u) >> 1) /* visible index at a boundary slot */
+    /* make slot s_ a defined one: its state is that of the closest defined slot to the left (peritext.ts:176) */
 #define PTX_DEFINE_SLOT(s_)                                                                     \
     do {                                                                                        \
         if (!ptx_bittest(defined, (s_))) {                                                      \
-            PTX_LAST_DEFINED_BELOW(s_, l1_)                                                     \
-            PTX_WIN_FENCE(); /* (global winners) the stores of the ops before have landed: the wait stands at the reader, where it is usually over */ \
+            const uint32_t l1_ = ptx_last_set_below(defined, (s_)); /* slot + 1, the same in every lane */ \
             PTX_LEADER {                                                                        \
-                const uint16_t v0_ = l1_ ? PTX_WIN_LD(&win[0][l1_ - 1u]) : (uint16_t)0;         \
-                const uint16_t v1_ = l1_ ? PTX_WIN_LD(&win[1][l1_ - 1u]) : (uint16_t)0;         \
-                const uint16_t v2_ = l1_ ? PTX_WIN_LD(&win[2][l1_ - 1u]) : (uint16_t)0;         \
-                PTX_COPY_SLOT_STATE(s_, l1_, v0_, v1_, v2_);                                    \
+                const uint32_t bit_ = 1u << ((s_)&31u), ws_ = (s_) >> 5;                        \
+                if (l1_) {                                                                      \
+                    const uint32_t l_ = l1_ - 1u;                                               \
+                    if (ptx_bittest(anyc, l_)) anyc[ws_] |= bit_;                               \
+                    if (ptx_bittest(on[0], l_)) on[0][ws_] |= bit_;                             \
+                    if (ptx_bittest(on[1], l_)) on[1][ws_] |= bit_;                             \
+                    if (ptx_bittest(on[2], l_)) {                                               \
+                        on[2][ws_] |= bit_;                                                     \
+                        PTX_G_FENCE(); /* (global urls) the stores of the ops before have landed */ \
+                        PTX_G_ST32(&lurl[s_], PTX_G_LD32(&lurl[l_]));                           \
+                    }                                                                           \
+                }                                                                               \
+                defined[ws_] |= bit_;                                                           \
             }                                                                                   \
             PTX_SYNC_T();                                                                       \
         }                                                                                       \
@@ -279,46 +295,39 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         c_b[i] = (uint16_t)vb;
         c_pay[i] = payload[tt];
         c_id[i] = op_id[tt];
-        c_key[i] = (uint16_t)(key_mode ? (uint32_t)(op_id[tt] >> 32) * na1 + (uint32_t)op_id[tt] + 1u : 0u);
     }
     PTX_SYNC_T();
 #pragma nounroll
     for (uint32_t ci = 0; ci < chunk_n; ++ci) {
         const uint32_t t = t0 + ci;
         const uint32_t pcap = t >= first ? pcap_all : 0u; /* the rows before `first` count records (npatch) but write none ... */
-        if (t == first && first != 0u) {                  /* ... and the count starts again at the first row asked for */
-            PTX_LEADER { H->npatch = 0; }
-            PTX_SYNC_T();
-        }
+        if (t == first) npatch = 0u;                      /* ... and the count starts again at the first row asked for */
         const uint32_t kind = c_kind[ci] & 15u;
         if (kind == PTX_RK_MAKELIST) {
-            PTX_LEADER {
-                ptx_patch_put(A, pbase, pcap, H->npatch, t, PTX_PATCH_MAKELIST, 0u, 0u);
-                H->npatch += 1;
-            }
-            PTX_SYNC_T();
+            PTX_LEADER { ptx_patch_put(A, pbase, pcap, npatch, t, PTX_PATCH_MAKELIST, 0u, 0u); }
+            npatch += 1u;
         } else if (kind == PTX_RK_INSERT) {
             const uint32_t r = c_a[ci];
-            PTX_LAST_DEFINED_BELOW(2u * r, l1) /* slot + 1 */
-            const uint32_t p0 = H->npatch;
-            PTX_WIN_FENCE();
-            PTX_SYNC_T();
-            PTX_LEADER {
-                uint32_t attr = 0;
-                if (l1) {
-                    const uint32_t l = l1 - 1u;
-                    if (ptx_bittest(won[0], l)) attr |= PTX_ATTR_STRONG;
-                    if (ptx_bittest(won[1], l)) attr |= PTX_ATTR_EM;
-                    if (ptx_bittest(won[2], l)) attr |= PTX_ATTR_LINK | (payload[PTX_WIN_LD(&win[2][l]) - 1u] & PTX_ATTR_ID_MASK);
-                    if (ptx_bittest(anyc, l)) attr |= PTX_ATTR_COMMENT;
+            const uint32_t l1 = ptx_last_set_below(defined, 2u * r); /* slot + 1 */
+            const uint32_t p0 = npatch;
+            uint32_t attr = 0;
+            bool coms = false;
+            if (l1) { /* the marks of the closest defined slot to the left (every lane computes them: LDS broadcasts, one url load) */
+                const uint32_t l = l1 - 1u;
+                if (ptx_bittest(on[0], l)) attr |= PTX_ATTR_STRONG;
+                if (ptx_bittest(on[1], l)) attr |= PTX_ATTR_EM;
+                if (ptx_bittest(on[2], l)) {
+                    PTX_G_FENCE();
+                    attr |= PTX_ATTR_LINK | (PTX_G_LD32(&lurl[l]) & PTX_ATTR_ID_MASK);
                 }
-                ptx_patch_put(A, pbase, pcap, p0, t, PTX_PATCH_INSERT, ptx_bitrank(present, r), attr);
-                H->tmp = 0; /* comment ids of this patch */
+                coms = ptx_bittest(anyc, l);
+                if (coms) attr |= PTX_ATTR_COMMENT;
             }
-            PTX_SYNC_T();
-            if (l1 && ptx_bittest(anyc, l1 - 1u)) {
-                const uint32_t l = l1 - 1u, nc = H->ncom;
-                PTX_FOR(kc, nc) {
+            PTX_LEADER { ptx_patch_put(A, pbase, pcap, p0, t, PTX_PATCH_INSERT, ptx_bitrank(present, r), attr); }
+            uint32_t extra = 0;
+            if (coms) {
+                const uint32_t l = l1 - 1u;
+                PTX_FOR(kc, ncom) {
                     if (cadd[kc] && ca[kc] <= l && l < cb[kc]) {
                         bool last = true; /* no later-applied covering op of the same id: the chain of the id, latest first, down to this op */
                         for (uint32_t y = ctail[ccid[kc]]; y != kc && y != PTX_SLOT_NONE; y = cprev[y])
@@ -330,27 +339,25 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     }
                 }
                 PTX_SYNC_T();
+                extra = H->tmp;
+                PTX_SYNC_T();
+                PTX_LEADER { H->tmp = 0; }
             }
             /* the element is visible from now on */
             PTX_FOR(w, nwe) {
                 if (w == (r >> 5)) present[w].bits |= 1u << (r & 31);
                 else if (w > (r >> 5)) present[w].pre += 1;
             }
-            PTX_LEADER {
-                H->npatch = p0 + 1u + H->tmp;
-                H->nvis += 1;
-            }
+            npatch = p0 + 1u + extra;
+            nvis += 1u;
             PTX_SYNC_T();
         } else if (kind == PTX_RK_DELETE) {
             const uint32_t r = c_a[ci];
             const bool was = (present[r >> 5].bits >> (r & 31)) & 1u;
-            PTX_SYNC_T();
             if (was) {
-                PTX_LEADER {
-                    ptx_patch_put(A, pbase, pcap, H->npatch, t, PTX_PATCH_DELETE, ptx_bitrank(present, r), 1u);
-                    H->npatch += 1;
-                    H->nvis -= 1;
-                }
+                PTX_LEADER { ptx_patch_put(A, pbase, pcap, npatch, t, PTX_PATCH_DELETE, ptx_bitrank(present, r), 1u); }
+                npatch += 1u;
+                nvis -= 1u;
                 PTX_SYNC_T();
                 PTX_FOR(w, nwe) {
                     if (w == (r >> 5)) present[w].bits &= ~(1u << (r & 31));
@@ -359,7 +366,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 PTX_SYNC_T();
             }
         } else if (kind == PTX_RK_MARK) {
-            const uint32_t ty = (c_kind[ci] >> 4) & 3u, act = (c_kind[ci] & 64u) ? (uint32_t)PTX_ACT_ADDMARK : (uint32_t)PTX_ACT_REMOVEMARK;
+            const uint32_t ty = (c_kind[ci] >> 4) & 3u;
+            const bool add = (c_kind[ci] & 64u) != 0u;
             uint32_t slot_a = c_a[ci], slot_b = c_b[ci];
             if (slot_a != PTX_SLOT_NONE && slot_b == slot_a) slot_b = PTX_SLOT_NONE; /* the start test fires first (A.6-3) */
             if (slot_a == PTX_SLOT_NONE || slot_b < slot_a) {
@@ -369,145 +377,187 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 continue;
             }
             PTX_DEFINE_SLOT(slot_a);
-            if (slot_b != PTX_SLOT_NONE) PTX_DEFINE_SLOT(slot_b); /* inherits the state BEFORE this op from inside the range (reading both ends' sources in one
-                                                                   * round trip was measured: 4 % slower) */
-            /* the defined slots of [slot_a, lim), ascending */
+            if (slot_b != PTX_SLOT_NONE) PTX_DEFINE_SLOT(slot_b); /* inherits the state BEFORE this op from inside the range */
+            /* the words of [slot_a, lim) */
             const uint32_t lim = slot_b != PTX_SLOT_NONE ? slot_b : 2u * n;
-            const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5;
-#define PTX_RANGE_BITS(w_, m_)                                                       \
-    uint32_t m_ = defined[w_];                                                       \
-    if ((w_) == wlo) m_ &= ~((1u << (slot_a & 31u)) - 1u);                           \
-    if (((w_) << 5) + 32u > lim) m_ &= (lim & 31u) ? (1u << (lim & 31u)) - 1u : 0u;
-            PTX_FOR(wi, whi - wlo + 1u) {
-                const uint32_t w = wlo + wi;
-                uint32_t c = 0;
-                if (w < whi) {
-                    PTX_RANGE_BITS(w, m)
-                    c = ptx_popc(m);
-                }
-                wcnt[wi] = c;
-            }
-            PTX_SYNC_T();
-            const uint32_t S = ptx_scan_excl<uint32_t, 1, kThreads>(wcnt, whi - wlo + 1u, H->scan_tmp);
-            PTX_FOR(wi, whi - wlo) {
-                const uint32_t w = wlo + wi;
-                PTX_RANGE_BITS(w, m)
-                uint32_t o = wcnt[wi];
-                while (m) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(m);
-                    m &= m - 1u;
-                    if (o < segl) seg_l[o] = (uint16_t)((w << 5) + b);
-                    else if (o < segcap) PTX_WIN_ST(&seg[o], (w << 5) + b);
-                    ++o;
-                }
-            }
-#undef PTX_RANGE_BITS
-            /* (global winners) the slot list's tail is read by other lanes than the ones that filled it, and the per-slot loop below loads winners that an
-             * EARLIER op's other lanes stored: one wait for the wave's outstanding stores orders both (without it the second relied on same-wave
-             * store -> load ordering through the L1 alone) */
-            PTX_WIN_FENCE();
-            PTX_SYNC_T();
-            const uint32_t nvis = H->nvis, nc = H->ncom;
-            const uint32_t cfw = (S >> 5) + 1u; /* words of the patch-opening bitmap (+1 for the total) */
-            PTX_FOR(w, cfw + 1u) {
-                PtxBitWord z;
-                z.bits = 0;
-                z.pre = 0;
-                cf[w] = z;
-            }
-            /* a changed slot opens a patch that the next defined slot (or the end of the range / text) closes;
-             * zero-width ones are dropped (peritext.ts:269-281) */
-            const uint32_t v_end = slot_b != PTX_SLOT_NONE ? ptx_bitrank(present, (slot_b + 1u) >> 1) : nvis;
-#define PTX_VIS_AT(s_) ptx_bitrank(present, ((uint32_t)(s_) + 1u) >> 1) /* visible index at a boundary slot */
-            PTX_SYNC_T();
+            const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5, nw = whi > wlo && lim > slot_a ? whi - wlo : 0u;
             const uint32_t my_id = c_pay[ci];
             const uint64_t my_op = c_id[ci];
-            const uint32_t my_key1 = c_key[ci];
-            const bool by_key = key_mode && ty != PTX_MARK_LINK;
-            /* per defined slot: did the effective marks change (peritext.ts:208), new state, visible index */
-            PTX_FOR(j, S) {
-                const uint32_t s = PTX_SEG_LD(j);
-                bool changed = false;
-                if (ty != PTX_MARK_COMMENT) {
-                    uint16_t* wt = win[ty == PTX_MARK_STRONG ? 0 : ty == PTX_MARK_EM ? 1 : 2];
-                    uint32_t* wo = won[ty == PTX_MARK_STRONG ? 0 : ty == PTX_MARK_EM ? 1 : 2];
-                    const uint32_t w = PTX_WIN_LD(&wt[s]);
-                    const bool old_on = ptx_bittest(wo, s);
-                    /* compareOpIds: counter, then actor (ranks keep the string order); the dense keys keep that order */
-                    const bool wins = !w || (by_key ? my_key1 > w : my_op > op_id[w - 1u]);
-                    if (wins) {
-                        const bool new_on = act == PTX_ACT_ADDMARK;
-                        changed = new_on != old_on;
-                        if (new_on && old_on && ty == PTX_MARK_LINK) changed = (my_id & PTX_ATTR_ID_MASK) != (payload[w - 1u] & PTX_ATTR_ID_MASK);
-                        PTX_WIN_ST(&wt[s], by_key ? my_key1 : t + 1u);
-                        if (new_on != old_on) {
-                            if (new_on) ptx_atomic_or(&wo[s >> 5], 1u << (s & 31));
-                            else ptx_atomic_and(&wo[s >> 5], ~(1u << (s & 31)));
+            /* the defined slots of the range in word w_ */
+#define PTX_RANGE_MASK(w_) (ptx_span_mask(slot_a, lim, (w_)))
+            /* first defined slot of the range in the words after w_, else the end of the range */
+#define PTX_NEXT_AFTER_WORD(w_, out_)                                  \
+    uint32_t out_ = lim;                                               \
+    for (uint32_t v_ = (w_) + 1u; v_ < whi; ++v_) {                    \
+        const uint32_t mm_ = defined[v_] & PTX_RANGE_MASK(v_);         \
+        if (mm_) {                                                     \
+            out_ = (v_ << 5) + (uint32_t)__builtin_ctz(mm_);           \
+            break;                                                     \
+        }                                                              \
+    }
+            /* word wi_ = w_: of the changed slots ch_ (defined slots m_ of the range) keep those whose patch — up to the next defined slot, or the end of the
+             * range — holds a visible char (peritext.ts:269-281): a char of rank r sits between slots 2 r and 2 r + 1, so it belongs to the patch of the last
+             * defined slot at or below 2 r.  Chars spread to their even slots; a reversed addition carries every one of them down to the defined slot that
+             * governs it; what follows the word belongs to its highest defined slot. */
+#define PTX_FINISH_WORD(wi_, w_, m_, ch_)                                                                               \
+    do {                                                                                                                \
+        uint32_t R_ = 0;                                                                                                \
+        if (ch_) {                                                                                                      \
+            const uint32_t pw_ = present[(w_) >> 1].bits;                                                               \
+            const uint32_t P2_ = ptx_spread16(((w_)&1u) ? pw_ >> 16 : pw_) & PTX_RANGE_MASK(w_);                        \
+            uint32_t G_ = P2_ & (m_);                                                                                   \
+            const uint32_t Q_ = P2_ & ~(m_);                                                                            \
+            if (Q_) {                                                                                                   \
+                const uint32_t Dr_ = ptx_brev(m_);                                                                      \
+                G_ |= ptx_brev((~Dr_ + ptx_brev(Q_)) & Dr_);                                                            \
+            }                                                                                                           \
+            const uint32_t top_ = 31u - (uint32_t)__builtin_clz(m_);                                                    \
+            if ((((ch_) & ~G_) >> top_) & 1u) {                                                                         \
+                PTX_NEXT_AFTER_WORD(w_, nx_)                                                                            \
+                if (nx_ > (((w_) + 1u) << 5) && PTX_VIS_AT(nx_) > ptx_bitrank(present, ((w_) + 1u) << 4)) G_ |= 1u << top_; \
+            }                                                                                                           \
+            R_ = (ch_) & G_;                                                                                            \
+        }                                                                                                               \
+        cw[wi_] = R_;                                                                                                   \
+        cnt[wi_] = ptx_popc(R_);                                                                                        \
+    } while (0)
+            if (ty != PTX_MARK_COMMENT) {
+                const uint32_t li = ty == PTX_MARK_STRONG ? 0u : ty == PTX_MARK_EM ? 1u : 2u;
+                uint32_t* wo = on[li];
+                /* compareOpIds (counter, then actor: the op ids keep that order): this op loses at the slots an applied op of its type with a larger id covers */
+                const bool fast = my_op > maxop[li];
+                if (!fast) {
+                    PTX_FOR(wi, nw) cw[wi] = 0u;
+                    PTX_G_FENCE();
+                    PTX_SYNC_T();
+                    PTX_FOR(e, ntab[li]) {
+                        const uint32_t row = PTX_G_LD16(&trow[toff[li] + e]);
+                        if (op_id[row] > my_op) {
+                            const uint32_t ya = PTX_G_LD16(&ta[toff[li] + e]), yl = PTX_G_LD16(&tl[toff[li] + e]);
+                            const uint32_t v0 = (ya >> 5) > wlo ? ya >> 5 : wlo, v1 = ((yl + 31u) >> 5) < whi ? (yl + 31u) >> 5 : whi;
+                            for (uint32_t v = v0; v < v1; ++v) ptx_atomic_or(&cw[v - wlo], ptx_span_mask(ya, yl, v));
                         }
                     }
-                } else {
-                    /* the last-applied covering op with this id (this op is not registered yet) */
-                    int state = -1; /* -1 none, 0 removed, 1 present */
-                    for (uint32_t y = my_id < Kid ? ctail[my_id] : PTX_SLOT_NONE; y != PTX_SLOT_NONE; y = cprev[y])
-                        if (ca[y] <= s && s < cb[y]) {
-                            state = cadd[y] ? 1 : 0;
-                            break;
+                    PTX_SYNC_T();
+                }
+                const bool per_slot = li == 2u && add; /* the url of every slot the op wins is stored; where the link was on, it decides "changed" */
+                PTX_FOR(wi, nw) {
+                    const uint32_t w = wlo + wi;
+                    const uint32_t m = defined[w] & PTX_RANGE_MASK(w);
+                    const uint32_t upd = fast ? m : m & ~cw[wi];
+                    const uint32_t old = wo[w];
+                    if (upd) wo[w] = add ? old | upd : old & ~upd;
+                    if (per_slot) {
+                        cw[wi] = upd & ~old;
+                        cnt[wi] = upd & old;
+                        uw[wi] = upd;
+                    } else {
+                        const uint32_t ch = upd & (add ? ~old : old);
+                        PTX_FINISH_WORD(wi, w, m, ch);
+                    }
+                }
+                if (per_slot) {
+                    PTX_G_FENCE();
+                    PTX_SYNC_T();
+                    const uint32_t my_url = my_id & PTX_ATTR_ID_MASK;
+                    PTX_FOR(j, nw << 5) {
+                        const uint32_t wi = j >> 5, bit = j & 31u;
+                        if ((uw[wi] >> bit) & 1u) {
+                            const uint32_t s = ((wlo + wi) << 5) + bit;
+                            if (((cnt[wi] >> bit) & 1u) && (PTX_G_LD32(&lurl[s]) & PTX_ATTR_ID_MASK) != my_url) ptx_atomic_or(&cw[wi], 1u << bit);
+                            PTX_G_ST32(&lurl[s], my_id);
                         }
-                    const bool any = ptx_bittest(anyc, s);
-                    changed = act == PTX_ACT_ADDMARK ? state != 1 : (state == 1 || !any); /* remove on no comment key: undefined -> [] */
+                    }
+                    PTX_SYNC_T();
+                    PTX_FOR(wi, nw) {
+                        const uint32_t w = wlo + wi;
+                        const uint32_t m = defined[w] & PTX_RANGE_MASK(w);
+                        const uint32_t ch = cw[wi];
+                        PTX_FINISH_WORD(wi, w, m, ch);
+                    }
                 }
-                if (changed) {
-                    const uint32_t ve = j + 1u < S ? PTX_VIS_AT(PTX_SEG_LD(j + 1u)) : v_end;
-                    if (ve > PTX_VIS_AT(s)) ptx_atomic_or(&cf[j >> 5].bits, 1u << (j & 31));
+                /* the op joins the table of its type */
+                PTX_LEADER {
+                    const uint32_t e = toff[li] + ntab[li];
+                    PTX_G_ST16(&trow[e], t);
+                    PTX_G_ST16(&ta[e], slot_a);
+                    PTX_G_ST16(&tl[e], lim);
                 }
-            }
-            PTX_SYNC_T(); /* (global winners: the ops that read what was stored here wait for it themselves) */
-            if (ty == PTX_MARK_COMMENT) {
-                PTX_FOR(j, S) {
-                    const uint32_t s = PTX_SEG_LD(j);
-                    ptx_atomic_or(&anyc[s >> 5], 1u << (s & 31));
-                }
-            }
-            PTX_FOR(w, cfw) cf[w].pre = ptx_popc(cf[w].bits);
-            PTX_SYNC_T();
-            const uint32_t P = ptx_scan_excl<uint32_t, 2, kThreads>(&cf[0].pre, cfw + 1u, H->scan_tmp);
-            const uint32_t p0 = H->npatch;
-            PTX_FOR(j, S) {
-                if ((cf[j >> 5].bits >> (j & 31)) & 1u) {
-                    const uint32_t ve = j + 1u < S ? PTX_VIS_AT(PTX_SEG_LD(j + 1u)) : v_end;
-                    ptx_patch_put(A, pbase, pcap, p0 + ptx_bitrank(cf, j), t, act == PTX_ACT_ADDMARK ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT(PTX_SEG_LD(j)), ve);
-                }
-            }
-#undef PTX_VIS_AT
-            PTX_SYNC_T();
-            PTX_LEADER {
-                H->npatch = p0 + P;
-                if (ty == PTX_MARK_COMMENT && my_id < Kid && nc < Kc) {
-                    ca[nc] = (uint16_t)slot_a;
-                    cb[nc] = (uint16_t)slot_b;
-                    ccid[nc] = (uint16_t)my_id;
-                    cadd[nc] = act == PTX_ACT_ADDMARK ? 1 : 0;
-                    cprev[nc] = ctail[my_id];
-                    ctail[my_id] = (uint16_t)nc;
-                    H->ncom = nc + 1u;
+                ntab[li] += 1u;
+                if (fast) maxop[li] = my_op;
+            } else {
+                /* comments: the last-applied covering op with this id decides (this op is not registered yet): per word, the id's chain latest first */
+                PTX_FOR(wi, nw) {
+                    const uint32_t w = wlo + wi;
+                    const uint32_t m = defined[w] & PTX_RANGE_MASK(w);
+                    uint32_t und = m, onm = 0;
+                    for (uint32_t y = my_id < Kid ? ctail[my_id] : PTX_SLOT_NONE; y != PTX_SLOT_NONE && und; y = cprev[y]) {
+                        const uint32_t c = ptx_span_mask(ca[y], cb[y], w) & und;
+                        if (cadd[y]) onm |= c;
+                        und &= ~c;
+                    }
+                    const uint32_t any = anyc[w];
+                    const uint32_t ch = add ? m & ~onm : m & (onm | ~any); /* remove on no comment key: undefined -> [] */
+                    if (m) anyc[w] = any | m;
+                    PTX_FINISH_WORD(wi, w, m, ch);
                 }
             }
             PTX_SYNC_T();
+            const uint32_t P = ptx_scan_excl<uint32_t, 1, kThreads>(cnt, nw, H->scan_tmp);
+            const uint32_t p0 = npatch;
+            if (P) {
+                PTX_FOR(wi, nw) {
+                    uint32_t R = cw[wi];
+                    if (R) {
+                        const uint32_t w = wlo + wi;
+                        const uint32_t m = defined[w] & PTX_RANGE_MASK(w);
+                        uint32_t o = p0 + cnt[wi];
+                        while (R) {
+                            const uint32_t b = (uint32_t)__builtin_ctz(R);
+                            R &= R - 1u;
+                            const uint32_t above = m & ptx_bits_from(b + 1u);
+                            uint32_t nxt;
+                            if (above) {
+                                nxt = (w << 5) + (uint32_t)__builtin_ctz(above);
+                            } else {
+                                PTX_NEXT_AFTER_WORD(w, nx)
+                                nxt = nx;
+                            }
+                            ptx_patch_put(A, pbase, pcap, o++, t, add ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT((w << 5) + b), PTX_VIS_AT(nxt));
+                        }
+                    }
+                }
+            }
+            npatch = p0 + P;
+            if (ty == PTX_MARK_COMMENT && my_id < Kid && ncom < Kc) {
+                PTX_LEADER {
+                    ca[ncom] = (uint16_t)slot_a;
+                    cb[ncom] = (uint16_t)slot_b;
+                    ccid[ncom] = (uint16_t)my_id;
+                    cadd[ncom] = add ? 1 : 0;
+                    cprev[ncom] = ctail[my_id];
+                    ctail[my_id] = (uint16_t)ncom;
+                }
+                ncom += 1u;
+            }
+            PTX_SYNC_T();
+#undef PTX_FINISH_WORD
+#undef PTX_NEXT_AFTER_WORD
+#undef PTX_RANGE_MASK
         }
     }
     PTX_SYNC_T(); /* the chunk buffers are rewritten next */
     }
-#undef PTX_LAST_DEFINED_BELOW
 #undef PTX_DEFINE_SLOT
-#undef PTX_COPY_SLOT_STATE
-#undef PTX_WIN_LD
-#undef PTX_WIN_ST
-#undef PTX_WIN_FENCE
-#undef PTX_SEG_LD
-    PTX_SYNC_T();
+#undef PTX_VIS_AT
+#undef PTX_G_LD16
+#undef PTX_G_ST16
+#undef PTX_G_LD32
+#undef PTX_G_ST32
+#undef PTX_G_FENCE
     PTX_LEADER {
         ptx_patch_log pl;
-        const uint32_t produced = first < N ? H->npatch : 0u; /* (first >= N: nothing was asked for) */
+        const uint32_t produced = first < N ? npatch : 0u; /* (first >= N: nothing was asked for) */
         pl.status = produced > pcap_all ? (uint32_t)PTX_ERR_CAPACITY : (uint32_t)PTX_OK;
         pl.n_patches = produced;
         A.plogs[log] = pl;

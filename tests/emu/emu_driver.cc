@@ -194,12 +194,10 @@ extern "C" int ptx_emu_replay_from(const ptx_batch* b, const ptx_log_result* res
         }
         A.log_hdr = hdr;
     }
-    /* bit 8 of `reverse`: the per-slot winner arrays in "global" memory, as the library does for working sets above 5.5 KB (with only
-     * 24 slot-list entries in the LDS, so that the tests cross into the global tail of the list) */
+    /* bit 8 of `reverse`: the per-slot link urls and the op tables in "global" memory, as the library does for working sets above 5.5 KB */
     const bool gwin = (reverse & 256) != 0;
     reverse &= 255;
     const uint64_t n_ops = b->n_logs ? b->log_off[b->n_logs] : 0;
-    A.seg_lds = 24;
     A.win_scratch = gwin ? (uint16_t*)malloc(ptx_replay_win_bytes(n_ops, b->n_logs)) : nullptr;
     if (gwin) memset(A.win_scratch, 0xA5, ptx_replay_win_bytes(n_ops, b->n_logs));
     uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)lds_bytes + 64);

@@ -54,6 +54,12 @@ PTX_DEV uint32_t ptx_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); 
 PTX_DEV uint16_t ptx_coherent_load16(const uint16_t* p) { return *p; }
 PTX_DEV void ptx_coherent_store16(uint16_t* p, uint16_t v) { *p = v; }
 PTX_DEV uint32_t ptx_coherent_load32(const uint32_t* p) { return *p; }
+PTX_DEV void ptx_coherent_store32(uint32_t* p, uint32_t v) { *p = v; }
+PTX_DEV uint32_t ptx_brev(uint32_t x) {
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);
+    return r;
+}
 PTX_DEV void ptx_global_stores_done() {}
 /* append to a list: index of this element (valid only where pred) */
 PTX_DEV uint32_t ptx_append(uint32_t* cursor, bool pred) { return pred ? (*cursor)++ : 0u; }
