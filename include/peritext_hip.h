@@ -243,7 +243,8 @@ typedef struct ptx_patch_log {
  * Owned by the library until ptx_patches_free. */
 typedef struct ptx_patches {
     uint32_t n_logs;
-    uint32_t launches;          /* kernel launches it took (2 when the first capacity guess was too small) */
+    uint32_t launches;          /* launches of the replay kernel it took: 1 (a log that outgrows the guessed capacity continues in an overflow extent; the records are
+                                   packed to exact offsets on the device); 2 only when the overflow arena itself ran out */
     float kernel_ms;            /* duration of the last launch (HIP events) */
     uint32_t reserved;
     const uint64_t* patch_off;  /* [n_logs + 1] */

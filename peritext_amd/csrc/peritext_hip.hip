@@ -91,6 +91,14 @@ extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kern
     if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS, true>(A, blockIdx.x, ptx_lds);
 }
 
+/* the records of every log — first its own capacity [cap_off[l], cap_off[l + 1]), then its overflow extent from ext_off[l] — packed to out_off[l] */
+extern "C" __global__ void __launch_bounds__(256) ptx_patch_pack_kernel(const ptx_patch* src, const uint64_t* cap_off, const uint64_t* ext_off, const uint64_t* out_off, ptx_patch* dst) {
+    const uint32_t l = blockIdx.x;
+    const uint64_t c0 = cap_off[l], cap = cap_off[l + 1] - c0, o0 = out_off[l], n = out_off[l + 1] - o0;
+    const uint64_t x0 = ext_off[3 * (uint64_t)l], x1 = ext_off[3 * (uint64_t)l + 1], xcap = ext_off[3 * (uint64_t)l + 2];
+    for (uint64_t i = threadIdx.x; i < n; i += 256) dst[o0 + i] = i < cap ? src[c0 + i] : i - cap < xcap ? src[x0 + (i - cap)] : src[x1 + (i - cap - xcap)];
+}
+
 /* On-device change() / PTXGEN (gen_core.h): one 64-thread workgroup (one wave) per document */
 extern "C" __global__ void __launch_bounds__(64) ptx_gen_kernel(PtxGenArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
@@ -1541,24 +1549,38 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
         h->off[l + 1] = h->off[l] + 2 * (n - skip) + 16; /* the guess: two records per row asked for */
     }
 
-    uint64_t* d_off = nullptr;
+    uint64_t *d_off = nullptr, *d_ext = nullptr, *d_xoff = nullptr;
+    unsigned long long* d_next = nullptr;
     ptx_patch_log* d_logs = nullptr;
-    ptx_patch* d_patches = nullptr;
+    ptx_patch *d_patches = nullptr, *d_packed = nullptr;
     ptx_status st = PTX_OK;
     auto release = [&]() {
         (void)hipFree(d_off);
+        (void)hipFree(d_ext);
+        (void)hipFree(d_xoff);
+        (void)hipFree(d_next);
         (void)hipFree(d_logs);
         (void)hipFree(d_patches);
-        d_off = nullptr;
+        (void)hipFree(d_packed);
+        d_off = d_ext = d_xoff = nullptr;
+        d_next = nullptr;
         d_logs = nullptr;
-        d_patches = nullptr;
+        d_patches = d_packed = nullptr;
     };
+    /* ONE launch: every log writes into its guessed capacity; a log that outgrows it takes one overflow extent from an arena behind the capacities (an atomic
+     * bump inside the kernel) and goes on there; a small kernel then packs the records of every log to exact offsets, and only those are downloaded.  Only when
+     * the arena itself runs out (or a log outgrows its second extent) is the replay launched again, with exact capacities. */
+    std::vector<uint64_t> xoff((size_t)L + 1, 0);
     for (uint32_t attempt = 0; attempt < 2 && st == PTX_OK; ++attempt) {
-        const uint64_t total = h->off[L];
+        const uint64_t total = h->off[L], arena_cap = attempt == 0 ? total + 65536 : 0;
         e = hipMalloc((void**)&d_off, ((size_t)L + 1) * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_ext, (size_t)L * 24);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_xoff, ((size_t)L + 1) * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_next, 8);
         if (e == hipSuccess) e = hipMalloc((void**)&d_logs, (size_t)L * sizeof(ptx_patch_log));
-        if (e == hipSuccess) e = hipMalloc((void**)&d_patches, std::max<uint64_t>(total, 1) * sizeof(ptx_patch));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_patches, std::max<uint64_t>(total + arena_cap, 1) * sizeof(ptx_patch));
         if (e == hipSuccess) e = hipMemcpyAsync(d_off, h->off.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_next, 0, 8, ctx->stream);
         if (e == hipSuccess) {
             PtxReplayArgs A;
             A.log_off = b->log_off;
@@ -1581,6 +1603,10 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
             A.lds_bytes = lds_bytes;
             A.win_scratch = d_win;
             A.first_row = d_first;
+            A.arena_next = arena_cap ? d_next : nullptr;
+            A.arena_base = total;
+            A.arena_cap = arena_cap;
+            A.ext_off = d_ext;
             (void)hipEventRecord(ctx->ev0, ctx->stream);
             if (gwin) hipLaunchKernelGGL(ptx_replay_kernel_gwin, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);
             else hipLaunchKernelGGL(ptx_replay_kernel, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);
@@ -1595,16 +1621,25 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
             break;
         }
         out->launches = attempt + 1;
-        bool over = false;
-        for (uint32_t l = 0; l < L; ++l) over = over || h->logs[l].n_patches > h->off[l + 1] - h->off[l];
+        bool over = false; /* a log that produced records and reports PTX_ERR_CAPACITY ran out of room for them (one whose working set exceeds the LDS produces none) */
+        for (uint32_t l = 0; l < L; ++l) over = over || (h->logs[l].status == PTX_ERR_CAPACITY && h->logs[l].n_patches != 0);
         if (!over || attempt == 1) {
-            h->patches.resize(std::max<uint64_t>(total, 1));
-            if (total) e = hipMemcpyAsync(h->patches.data(), d_patches, total * sizeof(ptx_patch), hipMemcpyDeviceToHost, ctx->stream);
+            for (uint32_t l = 0; l < L; ++l) xoff[l + 1] = xoff[l] + (h->logs[l].status == PTX_OK ? h->logs[l].n_patches : 0u);
+            const uint64_t xtotal = xoff[L];
+            e = hipMalloc((void**)&d_packed, std::max<uint64_t>(xtotal, 1) * sizeof(ptx_patch));
+            if (e == hipSuccess) e = hipMemcpyAsync(d_xoff, xoff.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(ptx_patch_pack_kernel, dim3(L), dim3(256), 0, ctx->stream, d_patches, d_off, d_ext, d_xoff, d_packed);
+                e = hipGetLastError();
+            }
+            h->patches.resize(std::max<uint64_t>(xtotal, 1));
+            if (e == hipSuccess && xtotal) e = hipMemcpyAsync(h->patches.data(), d_packed, xtotal * sizeof(ptx_patch), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) st = fail(ctx, PTX_ERR_HIP, std::string("patch download: ") + hipGetErrorString(e));
+            if (e != hipSuccess) st = fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("patch download: ") + hipGetErrorString(e));
+            h->off = xoff;
             break;
         }
-        /* some log produced more records than guessed: exact sizes, once more */
+        /* the arena ran out, or a log outgrew its extent: exact capacities, once more */
         for (uint32_t l = 0; l < L; ++l) h->off[l + 1] = h->off[l] + std::max<uint64_t>(h->logs[l].n_patches, 1);
         release();
     }

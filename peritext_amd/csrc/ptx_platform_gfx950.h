@@ -61,6 +61,8 @@ PTX_DEV void ptx_coherent_store16(uint16_t* p, uint16_t v) { __hip_atomic_store(
 PTX_DEV uint32_t ptx_coherent_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PTX_DEV void ptx_coherent_store32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PTX_DEV uint32_t ptx_brev(uint32_t x) { return __builtin_bitreverse32(x); } /* v_bfrev_b32 */
+/* a value that is the same in every lane of the wave (read from one LDS address, say): tell the compiler, so that what depends on it is scalar code and scalar branches */
+#define PTX_U32(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 PTX_DEV void ptx_global_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 /* wave-aggregated append: ONE LDS atomic per wave, lanes get consecutive slots.  May be called in
  * divergent control flow (the ballot covers the active lanes only). */
@@ -294,6 +296,13 @@ PTX_DEV void ptx_reduce_max32(uint32_t* dst, uint32_t v) {
 template <class T, int STRIDE, uint32_t kThreads>
 PTX_DEV uint32_t ptx_scan_excl(T* a, uint32_t m, uint32_t* tmp /* >= 36 u32 in LDS */, uint32_t div_magic = 0 /* as PTX_DIV_T; needed when kThreads == 0 */) {
     const uint32_t T_ = PTX_BLOCKDIM, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (T_ + 63) >> 6;
+    if (kThreads == 64 && m <= 64u) { /* one wave, one element per lane: a DPP prefix sum and nothing else */
+        const uint32_t v = lane < m ? (uint32_t)a[lane * STRIDE] : 0u;
+        const uint32_t in = ptx_wave_incl_scan(v);
+        if (lane < m) a[lane * STRIDE] = (T)(in - v);
+        PTX_SYNC_T();
+        return (uint32_t)__builtin_amdgcn_readlane((int)in, 63);
+    }
     const uint32_t chunk = kThreads ? (m + T_ - 1) / (kThreads ? kThreads : 1u) : (uint32_t)__umulhi(m + T_ - 1, div_magic);
     const uint32_t lo = tid * chunk < m ? tid * chunk : m;
     const uint32_t hi = lo + chunk < m ? lo + chunk : m;
@@ -529,7 +538,16 @@ PTX_DEV void ptx_plane_shift_up(uint32_t* plane, uint32_t at, uint32_t n) {
  * calls it).  Chunks of 64 words from the top down, one word per lane: a ballot finds the highest lane whose word has a bit, ONE readlane fetches that word. */
 PTX_DEV uint32_t ptx_last_set_below(const uint32_t* bits, uint32_t lim) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t words = (lim + 31u) >> 5;
+    if (lim == 0u) return 0u;
+    { /* usually the word that holds slot lim - 1 has it (one LDS address for the wave: a broadcast, then scalar code) */
+        const uint32_t w = (lim - 1u) >> 5;
+        uint32_t m = bits[w];
+        if (lim & 31u) m &= (1u << (lim & 31u)) - 1u;
+        m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+        if (m) return (w << 5) + 32u - (uint32_t)__builtin_clz(m);
+        lim = w << 5; /* the words below it */
+    }
+    const uint32_t words = lim >> 5;
     for (uint32_t top = (words + 63u) & ~63u; top != 0u; top -= 64u) {
         const uint32_t w = top - 64u + lane;
         uint32_t m = 0;

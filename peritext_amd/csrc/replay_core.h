@@ -68,11 +68,19 @@ struct PtxReplayArgs {
     uint32_t lds_bytes;
     const uint32_t* first_row; /* optional [n_logs]: only the records of the rows from here on are produced (the rows before are replayed for their state alone) */
     uint16_t* win_scratch; /* optional: the per-slot link urls and the tables of applied mark ops of every log live HERE (16 bytes per row of the batch + 128 per log) instead of in LDS */
+    /* optional: overflow extents.  A log whose records outgrow its capacity [patch_off[l], patch_off[l + 1]) takes an extent of `patches` from the arena
+     * [arena_base, arena_base + arena_cap) (an atomic bump of *arena_next) and goes on writing there — sized from its own record rate so far; should that run
+     * out too, a second, much larger one.  ext_off[3 l ..] = {first extent, second extent (~0: none), records the first holds}.  The host packs the parts. */
+    unsigned long long* arena_next;
+    uint64_t arena_base, arena_cap;
+    uint64_t* ext_off; /* [3 * n_logs] */
 };
 
 struct PtxReplayHdr {
     uint32_t tmp;      /* per-step scratch: counter */
-    uint32_t pad[3];
+    uint32_t ext_ok;   /* the extent asked for was granted */
+    uint32_t ext_cap[2]; /* the log's overflow extents: records each holds (0: none) ... */
+    uint32_t ext_lo[2], ext_hi[2]; /* ... and where they start in `patches` */
     uint32_t scan_tmp[36];
 };
 
@@ -80,7 +88,7 @@ struct PtxReplayHdr {
 PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid, bool gscratch = false) {
     const uint64_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2, Kl = K - Kc;
     (void)ks;
-    return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + 5 * ptx_a16(4 * nws) + 3 * ptx_a16(4 * (nws + 1)) +
+    return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + 5 * ptx_a16(4 * nws) + 2 * ptx_a16(4 * (nws + 1)) +
            (gscratch ? 0 : ptx_a16(4 * (2 * n + 2)) + 3 * ptx_a16(2 * (Kl + 1))) +
            ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
            4 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
@@ -94,15 +102,36 @@ PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gscratch = fa
 PTX_HD uint64_t ptx_replay_win_bytes(uint64_t n_ops, uint64_t n_logs) { return 16 * n_ops + 128 * n_logs + 64; }
 PTX_HD uint64_t ptx_replay_win_at(uint64_t base_row, uint64_t log) { return 8 * base_row + 64 * log; }
 
-/* one patch record; rows past the capacity are counted, not written */
-PTX_DEV void ptx_patch_put(const PtxReplayArgs& A, uint64_t pbase, uint32_t pcap, uint32_t idx, uint32_t row, uint32_t kind, uint32_t a, uint32_t b) {
-    if (idx < pcap) {
-        ptx_patch p;
-        p.row = row;
-        p.kind = kind;
-        p.a = a;
-        p.b = b;
-        A.patches[pbase + idx] = p;
+/* where a log's records go: its own capacity first, then its overflow extent */
+struct PtxPatchDst {
+    ptx_patch* out;            /* the log's own capacity ... */
+    uint32_t pcap;             /* ... in records */
+    const PtxReplayHdr* H;     /* the overflow extents (the rare path reads them from the LDS) */
+    ptx_patch* patches;
+};
+/* one patch record; rows past the capacity (and the extents) are counted, not written.  `open`: the row is one of those asked for (first_row) */
+PTX_DEV void ptx_patch_put(const PtxPatchDst& d, bool open, uint32_t idx, uint32_t row, uint32_t kind, uint32_t a, uint32_t b) {
+    if (!open) return;
+#if defined(PTX_REPLAY_EXP) && (PTX_REPLAY_EXP & 2) /* timing experiment only: what the record stores cost */
+    if (idx != 0xFFFFFFFFu) return;
+#endif
+    ptx_patch p;
+    p.row = row;
+    p.kind = kind;
+    p.a = a;
+    p.b = b;
+    if (idx < d.pcap) {
+        d.out[idx] = p;
+    } else {
+        uint32_t x = idx - d.pcap;
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t c = d.H->ext_cap[k];
+            if (x < c) {
+                d.patches[(((uint64_t)d.H->ext_hi[k] << 32) | d.H->ext_lo[k]) + x] = p;
+                break;
+            }
+            x -= c;
+        }
     }
 }
 
@@ -113,6 +142,12 @@ PTX_DEV uint32_t ptx_span_mask(uint32_t a, uint32_t b, uint32_t w) {
     const uint32_t lo = w << 5;
     if (b <= lo || a >= lo + 32u || a >= b) return 0u;
     return ptx_bits_from(a > lo ? a - lo : 0u) & ptx_bits_below(b - lo);
+}
+/* the same for a word w that the non-empty interval reaches: a >> 5 <= w < (b + 31) >> 5 (no range checks left) */
+PTX_DEV uint32_t ptx_span_mask_in(uint32_t a, uint32_t b, uint32_t w) {
+    const uint32_t lo = w << 5;
+    const uint32_t from = a > lo ? a - lo : 0u, to = b - lo < 32u ? b - lo : 32u; /* 0 .. 31, 1 .. 32 */
+    return (~0u << from) & (~0u >> (32u - to));
 }
 /* bit i of the low half -> bit 2 i */
 PTX_DEV uint32_t ptx_spread16(uint32_t x) {
@@ -131,8 +166,13 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     PtxReplayHdr* H = (PtxReplayHdr*)lds;
     const uint64_t base = A.log_off[log];
     const uint32_t N = (uint32_t)(A.log_off[log + 1] - base);
-    const uint64_t pbase = A.patch_off[log];
-    const uint32_t pcap_all = (uint32_t)(A.patch_off[log + 1] - pbase);
+    PtxPatchDst dst;
+    dst.out = A.patches + A.patch_off[log];
+    dst.pcap = (uint32_t)(A.patch_off[log + 1] - A.patch_off[log]);
+    dst.H = H;
+    dst.patches = A.patches;
+    uint32_t room = dst.pcap;                   /* records the log can hold: its capacity + its extents */
+    uint32_t ext_left = A.arena_next ? 2u : 0u; /* extents it may still ask for */
     const uint32_t first = A.first_row ? A.first_row[log] : 0u; /* the stream starts with this row's records */
     const uint64_t* op_id = A.op_id + base;
     const uint32_t* payload = A.payload + base;
@@ -148,6 +188,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             pl.status = merge_status;
             pl.n_patches = 0;
             A.plogs[log] = pl;
+            if (A.ext_off) A.ext_off[3 * (uint64_t)log] = A.ext_off[3 * (uint64_t)log + 1] = ~0ull;
         }
         return;
     }
@@ -173,10 +214,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     on[0] = ptx_alloc<uint32_t>(bp, nws);
     on[1] = ptx_alloc<uint32_t>(bp, nws);
     on[2] = ptx_alloc<uint32_t>(bp, nws);
-    /* per word of a mark op's range: the changed slots -> the slots that open a record; their count -> its prefix; the slots the op wins (links) */
+    /* per word of a mark op's range: the changed slots -> the slots that open a record; their count -> its prefix */
     uint32_t* cw = ptx_alloc<uint32_t>(bp, nws + 1);
     uint32_t* cnt = ptx_alloc<uint32_t>(bp, nws + 1);
-    uint32_t* uw = ptx_alloc<uint32_t>(bp, nws + 1);
     uint32_t* lurl;
     uint16_t *trow, *ta, *tl;
     if (kGWin) {
@@ -196,7 +236,11 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
 #define PTX_G_ST16(p_, v_) do { if (kGWin) ptx_coherent_store16((p_), (uint16_t)(v_)); else *(p_) = (uint16_t)(v_); } while (0)
 #define PTX_G_LD32(p_) (kGWin ? ptx_coherent_load32(p_) : *(p_))
 #define PTX_G_ST32(p_, v_) do { if (kGWin) ptx_coherent_store32((p_), (uint32_t)(v_)); else *(p_) = (uint32_t)(v_); } while (0)
+#if defined(PTX_REPLAY_EXP) && (PTX_REPLAY_EXP & 1) /* timing experiment only (wrong results possible): what the waits for the wave's outstanding stores cost */
+#define PTX_G_FENCE() do { } while (0)
+#else
 #define PTX_G_FENCE() do { if (kGWin) ptx_global_stores_done(); } while (0)
+#endif
     /* the next PTX_RCHUNK rows, resolved in parallel (element lookups, boundary slots) before they are replayed in order */
     uint64_t* c_id = ptx_alloc<uint64_t>(bp, PTX_RCHUNK);
     uint32_t* c_pay = ptx_alloc<uint32_t>(bp, PTX_RCHUNK);
@@ -215,6 +259,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             pl.status = PTX_ERR_CAPACITY;
             pl.n_patches = 0;
             A.plogs[log] = pl;
+            if (A.ext_off) A.ext_off[3 * (uint64_t)log] = A.ext_off[3 * (uint64_t)log + 1] = ~0ull;
         }
         return;
     }
@@ -234,7 +279,10 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         on[2][w] = 0;
     }
     PTX_FOR(c, Kid + 1) ctail[c] = PTX_SLOT_NONE;
-    PTX_LEADER { H->tmp = 0; }
+    PTX_LEADER {
+        H->tmp = 0;
+        H->ext_cap[0] = H->ext_cap[1] = 0;
+    }
     PTX_SYNC_T();
     /* the wave's own counters: the same value in every lane */
     uint32_t npatch = 0, ncom = 0, nvis = 0;
@@ -242,11 +290,43 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint64_t maxop[3] = {0ull, 0ull, 0ull}; /* largest opId applied so far per LWW type */
 
 #define PTX_VIS_AT(s_) ptx_bitrank(present, ((uint32_t)(s_) + 1u) >> 1) /* visible index at a boundary slot */
+    /* Room for the records, looked after once per chunk of rows (not per record): a log that may outgrow its room within the chunk — three times its record
+     * rate so far, at least eight per row — asks for an extent that holds that rate for all the rows still to come; should that run out too, one sixteen times
+     * as generous.  (A chunk that beats even that loses records: PTX_ERR_CAPACITY with the exact count, and the host launches again with exact capacities.) */
+#define PTX_RESERVE(t_)                                                                                        \
+    do {                                                                                                       \
+        uint32_t rate_ = 3u * (npatch / ((t_) > first ? (t_) - first + 1u : 1u) + 1u);                         \
+        rate_ = rate_ < 8u ? 8u : rate_;                                                                       \
+        if (ext_left && (t_) + PTX_RCHUNK > first && npatch + rate_ * PTX_RCHUNK > room) {                     \
+            rate_ *= ext_left == 2u ? 1u : 16u;                                                                \
+            const uint64_t want64_ = (uint64_t)rate_ * (N - (t_)) + 1024u;                                     \
+            const uint32_t want_ = want64_ < 0x7FFFFFFFull - room ? (uint32_t)want64_ : 0x7FFFFFFFu - room;    \
+            PTX_LEADER {                                                                                       \
+                const unsigned long long at_ = ptx_atomic_add64(A.arena_next, (unsigned long long)want_);      \
+                const bool ok_ = at_ + want_ <= A.arena_cap;                                                   \
+                H->ext_ok = ok_ ? 1u : 0u;                                                                     \
+                if (ok_) {                                                                                     \
+                    const uint32_t k_ = 2u - ext_left;                                                         \
+                    H->ext_cap[k_] = want_;                                                                    \
+                    H->ext_lo[k_] = (uint32_t)(A.arena_base + at_);                                            \
+                    H->ext_hi[k_] = (uint32_t)((A.arena_base + at_) >> 32);                                    \
+                }                                                                                              \
+            }                                                                                                  \
+            PTX_SYNC_T();                                                                                      \
+            if (PTX_U32(H->ext_ok)) {                                                                          \
+                room += want_;                                                                                 \
+                ext_left -= 1u;                                                                                \
+            } else {                                                                                           \
+                ext_left = 0u; /* the arena is exhausted */                                                    \
+            }                                                                                                  \
+            PTX_SYNC_T();                                                                                      \
+        }                                                                                                      \
+    } while (0)
     /* make slot s_ a defined one: its state is that of the closest defined slot to the left (peritext.ts:176) */
 #define PTX_DEFINE_SLOT(s_)                                                                     \
     do {                                                                                        \
-        if (!ptx_bittest(defined, (s_))) {                                                      \
-            const uint32_t l1_ = ptx_last_set_below(defined, (s_)); /* slot + 1, the same in every lane */ \
+        if (!((PTX_U32(defined[(s_) >> 5]) >> ((s_)&31u)) & 1u)) {                              \
+            const uint32_t l1_ = PTX_U32(ptx_last_set_below(defined, (s_))); /* slot + 1, the same in every lane */ \
             PTX_LEADER {                                                                        \
                 const uint32_t bit_ = 1u << ((s_)&31u), ws_ = (s_) >> 5;                        \
                 if (l1_) {                                                                      \
@@ -269,6 +349,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
 #pragma nounroll
     for (uint32_t t0 = 0; t0 < N; t0 += PTX_RCHUNK) {
     const uint32_t chunk_n = N - t0 < PTX_RCHUNK ? N - t0 : PTX_RCHUNK;
+    PTX_RESERVE(t0);
     PTX_FOR(i, chunk_n) {
         const uint32_t tt = t0 + i, a_ = action[tt];
         uint32_t kind = PTX_RK_SKIP, va = PTX_SLOT_NONE, vb = PTX_SLOT_NONE;
@@ -300,30 +381,32 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
 #pragma nounroll
     for (uint32_t ci = 0; ci < chunk_n; ++ci) {
         const uint32_t t = t0 + ci;
-        const uint32_t pcap = t >= first ? pcap_all : 0u; /* the rows before `first` count records (npatch) but write none ... */
-        if (t == first) npatch = 0u;                      /* ... and the count starts again at the first row asked for */
-        const uint32_t kind = c_kind[ci] & 15u;
+        const bool open = t >= first;  /* the rows before `first` count records (npatch) but write none ... */
+        if (t == first) npatch = 0u;   /* ... and the count starts again at the first row asked for */
+        const uint32_t kindb = PTX_U32(c_kind[ci]); /* (one LDS address: the same in every lane) */
+        const uint32_t kind = kindb & 15u;
         if (kind == PTX_RK_MAKELIST) {
-            PTX_LEADER { ptx_patch_put(A, pbase, pcap, npatch, t, PTX_PATCH_MAKELIST, 0u, 0u); }
+            PTX_LEADER { ptx_patch_put(dst, open, npatch, t, PTX_PATCH_MAKELIST, 0u, 0u); }
             npatch += 1u;
         } else if (kind == PTX_RK_INSERT) {
-            const uint32_t r = c_a[ci];
-            const uint32_t l1 = ptx_last_set_below(defined, 2u * r); /* slot + 1 */
+            const uint32_t r = PTX_U32(c_a[ci]);
+            const uint32_t l1 = PTX_U32(ptx_last_set_below(defined, 2u * r)); /* slot + 1 */
             const uint32_t p0 = npatch;
             uint32_t attr = 0;
             bool coms = false;
             if (l1) { /* the marks of the closest defined slot to the left (every lane computes them: LDS broadcasts, one url load) */
                 const uint32_t l = l1 - 1u;
-                if (ptx_bittest(on[0], l)) attr |= PTX_ATTR_STRONG;
-                if (ptx_bittest(on[1], l)) attr |= PTX_ATTR_EM;
-                if (ptx_bittest(on[2], l)) {
+                const uint32_t lw = l >> 5, lb = l & 31u;
+                if ((PTX_U32(on[0][lw]) >> lb) & 1u) attr |= PTX_ATTR_STRONG;
+                if ((PTX_U32(on[1][lw]) >> lb) & 1u) attr |= PTX_ATTR_EM;
+                if ((PTX_U32(on[2][lw]) >> lb) & 1u) {
                     PTX_G_FENCE();
-                    attr |= PTX_ATTR_LINK | (PTX_G_LD32(&lurl[l]) & PTX_ATTR_ID_MASK);
+                    attr |= PTX_ATTR_LINK | (PTX_U32(PTX_G_LD32(&lurl[l])) & PTX_ATTR_ID_MASK);
                 }
-                coms = ptx_bittest(anyc, l);
+                coms = (PTX_U32(anyc[lw]) >> lb) & 1u;
                 if (coms) attr |= PTX_ATTR_COMMENT;
             }
-            PTX_LEADER { ptx_patch_put(A, pbase, pcap, p0, t, PTX_PATCH_INSERT, ptx_bitrank(present, r), attr); }
+            PTX_LEADER { ptx_patch_put(dst, open, p0, t, PTX_PATCH_INSERT, ptx_bitrank(present, r), attr); }
             uint32_t extra = 0;
             if (coms) {
                 const uint32_t l = l1 - 1u;
@@ -335,11 +418,11 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                                 last = false;
                                 break;
                             }
-                        if (last) ptx_patch_put(A, pbase, pcap, p0 + 1u + ptx_atomic_add(&H->tmp, 1u), t, PTX_PATCH_INSERT_COMMENT, ccid[kc], 0u);
+                        if (last) ptx_patch_put(dst, open, p0 + 1u + ptx_atomic_add(&H->tmp, 1u), t, PTX_PATCH_INSERT_COMMENT, ccid[kc], 0u);
                     }
                 }
                 PTX_SYNC_T();
-                extra = H->tmp;
+                extra = PTX_U32(H->tmp);
                 PTX_SYNC_T();
                 PTX_LEADER { H->tmp = 0; }
             }
@@ -352,10 +435,10 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             nvis += 1u;
             PTX_SYNC_T();
         } else if (kind == PTX_RK_DELETE) {
-            const uint32_t r = c_a[ci];
-            const bool was = (present[r >> 5].bits >> (r & 31)) & 1u;
+            const uint32_t r = PTX_U32(c_a[ci]);
+            const bool was = (PTX_U32(present[r >> 5].bits) >> (r & 31)) & 1u;
             if (was) {
-                PTX_LEADER { ptx_patch_put(A, pbase, pcap, npatch, t, PTX_PATCH_DELETE, ptx_bitrank(present, r), 1u); }
+                    PTX_LEADER { ptx_patch_put(dst, open, npatch, t, PTX_PATCH_DELETE, ptx_bitrank(present, r), 1u); }
                 npatch += 1u;
                 nvis -= 1u;
                 PTX_SYNC_T();
@@ -366,9 +449,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 PTX_SYNC_T();
             }
         } else if (kind == PTX_RK_MARK) {
-            const uint32_t ty = (c_kind[ci] >> 4) & 3u;
-            const bool add = (c_kind[ci] & 64u) != 0u;
-            uint32_t slot_a = c_a[ci], slot_b = c_b[ci];
+            const uint32_t ty = (kindb >> 4) & 3u;
+            const bool add = (kindb & 64u) != 0u;
+            uint32_t slot_a = PTX_U32(c_a[ci]), slot_b = PTX_U32(c_b[ci]);
             if (slot_a != PTX_SLOT_NONE && slot_b == slot_a) slot_b = PTX_SLOT_NONE; /* the start test fires first (A.6-3) */
             if (slot_a == PTX_SLOT_NONE || slot_b < slot_a) {
                 /* the end is met while the op has not started: its slot becomes a defined one (a copy of the state to
@@ -381,10 +464,10 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             /* the words of [slot_a, lim) */
             const uint32_t lim = slot_b != PTX_SLOT_NONE ? slot_b : 2u * n;
             const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5, nw = whi > wlo && lim > slot_a ? whi - wlo : 0u;
-            const uint32_t my_id = c_pay[ci];
-            const uint64_t my_op = c_id[ci];
+            const uint32_t my_id = PTX_U32(c_pay[ci]);
+            const uint64_t my_op = ((uint64_t)PTX_U32((uint32_t)(c_id[ci] >> 32)) << 32) | PTX_U32((uint32_t)c_id[ci]);
             /* the defined slots of the range in word w_ */
-#define PTX_RANGE_MASK(w_) (ptx_span_mask(slot_a, lim, (w_)))
+#define PTX_RANGE_MASK(w_) (ptx_span_mask_in(slot_a, lim, (w_))) /* wlo <= w_ < whi */
             /* first defined slot of the range in the words after w_, else the end of the range */
 #define PTX_NEXT_AFTER_WORD(w_, out_)                                  \
     uint32_t out_ = lim;                                               \
@@ -448,9 +531,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     const uint32_t old = wo[w];
                     if (upd) wo[w] = add ? old | upd : old & ~upd;
                     if (per_slot) {
-                        cw[wi] = upd & ~old;
+                        cw[wi] = upd & ~old; /* (the two together: the slots the op wins) */
                         cnt[wi] = upd & old;
-                        uw[wi] = upd;
                     } else {
                         const uint32_t ch = upd & (add ? ~old : old);
                         PTX_FINISH_WORD(wi, w, m, ch);
@@ -462,9 +544,10 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     const uint32_t my_url = my_id & PTX_ATTR_ID_MASK;
                     PTX_FOR(j, nw << 5) {
                         const uint32_t wi = j >> 5, bit = j & 31u;
-                        if ((uw[wi] >> bit) & 1u) {
+                        const bool both = (cnt[wi] >> bit) & 1u; /* the link was on: changed iff the urls differ */
+                        if (both || ((cw[wi] >> bit) & 1u)) { /* (a lane only ever sets ITS bit of cw, and only where `both`: the test reads what the pass before wrote) */
                             const uint32_t s = ((wlo + wi) << 5) + bit;
-                            if (((cnt[wi] >> bit) & 1u) && (PTX_G_LD32(&lurl[s]) & PTX_ATTR_ID_MASK) != my_url) ptx_atomic_or(&cw[wi], 1u << bit);
+                            if (both && (PTX_G_LD32(&lurl[s]) & PTX_ATTR_ID_MASK) != my_url) ptx_atomic_or(&cw[wi], 1u << bit);
                             PTX_G_ST32(&lurl[s], my_id);
                         }
                     }
@@ -523,7 +606,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                                 PTX_NEXT_AFTER_WORD(w, nx)
                                 nxt = nx;
                             }
-                            ptx_patch_put(A, pbase, pcap, o++, t, add ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT((w << 5) + b), PTX_VIS_AT(nxt));
+                            ptx_patch_put(dst, open, o++, t, add ? PTX_PATCH_ADDMARK : PTX_PATCH_REMOVEMARK, PTX_VIS_AT((w << 5) + b), PTX_VIS_AT(nxt));
                         }
                     }
                 }
@@ -549,6 +632,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     PTX_SYNC_T(); /* the chunk buffers are rewritten next */
     }
 #undef PTX_DEFINE_SLOT
+#undef PTX_RESERVE
 #undef PTX_VIS_AT
 #undef PTX_G_LD16
 #undef PTX_G_ST16
@@ -558,8 +642,13 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     PTX_LEADER {
         ptx_patch_log pl;
         const uint32_t produced = first < N ? npatch : 0u; /* (first >= N: nothing was asked for) */
-        pl.status = produced > pcap_all ? (uint32_t)PTX_ERR_CAPACITY : (uint32_t)PTX_OK;
+        pl.status = produced > room ? (uint32_t)PTX_ERR_CAPACITY : (uint32_t)PTX_OK;
         pl.n_patches = produced;
         A.plogs[log] = pl;
+        if (A.ext_off) {
+            A.ext_off[3 * (uint64_t)log] = H->ext_cap[0] ? ((uint64_t)H->ext_hi[0] << 32) | H->ext_lo[0] : ~0ull;
+            A.ext_off[3 * (uint64_t)log + 1] = H->ext_cap[1] ? ((uint64_t)H->ext_hi[1] << 32) | H->ext_lo[1] : ~0ull;
+            A.ext_off[3 * (uint64_t)log + 2] = H->ext_cap[0];
+        }
     }
 }

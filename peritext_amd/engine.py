@@ -289,7 +289,10 @@ class Engine:
             off = np.ctypeslib.as_array(p.patch_off, shape=(n + 1,)).copy() if n else np.zeros(1, dtype=np.uint64)
             logs = np.frombuffer(C.string_at(p.logs, n * C.sizeof(abi.ptx_patch_log)), dtype=abi.PATCH_LOG_DTYPE).copy() if n else np.zeros(0, dtype=abi.PATCH_LOG_DTYPE)
             total = int(off[n]) if n else 0
-            rows = np.frombuffer(C.string_at(p.patches, total * C.sizeof(abi.ptx_patch)), dtype=abi.PATCH_DTYPE).copy() if total else np.zeros(0, dtype=abi.PATCH_DTYPE)
+            if total:  # (not C.string_at: its size is a C int, and the streams of a large batch exceed 2 GiB)
+                rows = np.ctypeslib.as_array(C.cast(p.patches, C.POINTER(C.c_uint8)), shape=(total * C.sizeof(abi.ptx_patch),)).view(abi.PATCH_DTYPE).copy()
+            else:
+                rows = np.zeros(0, dtype=abi.PATCH_DTYPE)
             return wire.Patches(patch_off=off, logs=logs, patches=rows, kernel_ms=float(p.kernel_ms), launches=int(p.launches))
         finally:
             self.lib.ptx_patches_free(C.byref(p))

@@ -162,10 +162,16 @@ extern "C" uint64_t ptx_emu_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_
 
 /* patch-stream replay (replay_core.h) over the merge results `res` / `rank` of the same batch; patch_off = capacity
  * offsets [n_logs + 1] */
-extern "C" int ptx_emu_replay_from(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint32_t* refs, const uint64_t* patch_off, ptx_patch* patches,
-                                   ptx_patch_log* plogs, uint32_t lds_bytes, int reverse, const uint32_t* first_row /* NULL: whole streams */) {
+/* arena_cap > 0: `patches` holds arena_cap more records behind patch_off[n_logs] for the overflow extents; ext_off[n_logs] says where a log's extent starts (~0: none) */
+extern "C" int ptx_emu_replay_arena(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint32_t* refs, const uint64_t* patch_off, ptx_patch* patches,
+                                    ptx_patch_log* plogs, uint32_t lds_bytes, int reverse, const uint32_t* first_row /* NULL: whole streams */, uint64_t arena_cap, uint64_t* ext_off) {
     PtxReplayArgs A;
+    unsigned long long arena_next = 0;
     A.first_row = first_row;
+    A.arena_next = arena_cap ? &arena_next : nullptr;
+    A.arena_base = b->n_logs ? patch_off[b->n_logs] : 0;
+    A.arena_cap = arena_cap;
+    A.ext_off = arena_cap ? ext_off : nullptr;
     A.log_off = b->log_off;
     A.op_id = b->op_id;
     A.ref_a = b->ref_a;
@@ -213,6 +219,10 @@ extern "C" int ptx_emu_replay_from(const ptx_batch* b, const ptx_log_result* res
     free(hdr);
     free(A.win_scratch);
     return 0;
+}
+extern "C" int ptx_emu_replay_from(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint32_t* refs, const uint64_t* patch_off, ptx_patch* patches,
+                                   ptx_patch_log* plogs, uint32_t lds_bytes, int reverse, const uint32_t* first_row /* NULL: whole streams */) {
+    return ptx_emu_replay_arena(b, res, rank, refs, patch_off, patches, plogs, lds_bytes, reverse, first_row, 0, nullptr);
 }
 extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint32_t* refs, const uint64_t* patch_off, ptx_patch* patches,
                               ptx_patch_log* plogs, uint32_t lds_bytes, int reverse) {

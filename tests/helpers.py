@@ -247,6 +247,40 @@ def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=No
     return wire.Patches(patch_off=off, logs=logs, patches=rows, launches=launches)
 
 
+def emu_replay_with_arena(b, res, cap, arena, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, gwin=False):
+    """The replay with `cap` records of capacity per log and an overflow arena of `arena` records behind the capacities (what ptx_replay_patches does in its one
+    launch), packed to exact offsets here as the library's pack kernel does: wire.Patches."""
+    reverse |= 256 if gwin else 0
+    n_logs = b.n_logs
+    off = (np.arange(n_logs + 1, dtype=np.uint64) * np.uint64(cap)).astype(np.uint64)
+    logs = np.zeros(n_logs, dtype=abi.PATCH_LOG_DTYPE)
+    rows = np.zeros(int(off[-1]) + arena + 1, dtype=abi.PATCH_DTYPE)
+    ext = np.zeros(3 * max(n_logs, 1), dtype=np.uint64)
+    s = batch_struct(b)
+    lib = _emu(lib_path)
+    lib.ptx_emu_replay_arena.restype = C.c_int
+    lib.ptx_emu_replay_arena.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
+    rc = lib.ptx_emu_replay_arena(C.cast(C.byref(s), C.c_void_p), res.logs.ctypes.data, res.elem_rank.ctypes.data, res.ref_slots.ctypes.data, off.ctypes.data, rows.ctypes.data, logs.ctypes.data,
+                                  lds_bytes, reverse, None, arena, ext.ctypes.data)
+    assert rc == 0
+    xoff = np.zeros(n_logs + 1, dtype=np.uint64)
+    xoff[1:] = np.cumsum(np.where(logs["status"] == 0, logs["n_patches"], 0).astype(np.uint64))
+    packed = np.zeros(max(int(xoff[-1]), 1), dtype=abi.PATCH_DTYPE)
+    for l in range(n_logs):
+        n = int(xoff[l + 1] - xoff[l])
+        a = min(n, cap)
+        packed[int(xoff[l]):int(xoff[l]) + a] = rows[int(off[l]):int(off[l]) + a]
+        if n > a:
+            x0, x1, xcap = int(ext[3 * l]), int(ext[3 * l + 1]), int(ext[3 * l + 2])
+            assert x0 != 0xFFFFFFFFFFFFFFFF
+            k = min(n - a, xcap)
+            packed[int(xoff[l]) + a:int(xoff[l]) + a + k] = rows[x0:x0 + k]
+            if n - a > k:
+                assert x1 != 0xFFFFFFFFFFFFFFFF
+                packed[int(xoff[l]) + a + k:int(xoff[l]) + n] = rows[x1:x1 + n - a - k]
+    return wire.Patches(patch_off=xoff, logs=logs, patches=packed, launches=1), ext.reshape(-1, 3)
+
+
 def input_ops_struct(ops):
     s = abi.ptx_input_ops()
     s.n_logs, s.max_actors = len(ops.chg_off) - 1, ops.max_actors

@@ -214,3 +214,34 @@ def test_tail_streams_are_the_suffix_of_the_whole_stream(gwin):
             want = a[a["row"] >= first[log]]
             assert tail.logs["status"][log] == whole.logs["status"][log]
             assert np.array_equal(b, want), (cut, log, int(first[log]))
+
+
+@pytest.mark.parametrize("gwin", [False, True])
+def test_overflow_extents_give_the_same_streams(gwin):
+    """ptx_replay_patches launches the replay ONCE: a log that outgrows the capacity guessed for it takes one overflow extent from an arena (an atomic bump)
+    and goes on writing there; the two parts are packed afterwards.  With 40 records of capacity every log of the fixture overflows: the packed streams
+    equal the ones replayed into ample room; with an arena too small for all of them, the logs that got no extent report PTX_ERR_CAPACITY with exact counts."""
+    g = _load("patches_rich_300.json")
+    batch = wire.encode_docs([d["logs"] for d in g["docs"]])
+    res = H.emu_merge(batch)
+    ref = H.emu_replay(batch, res, gwin=gwin)
+    pat, ext = H.emu_replay_with_arena(batch, res, cap=40, arena=200000, gwin=gwin)
+    assert np.all(ext[:batch.n_logs, 0] != np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(pat.logs["status"] == 0)
+    assert np.array_equal(pat.logs["n_patches"], ref.logs["n_patches"])
+    for log in range(batch.n_logs):
+        assert np.array_equal(pat.patches[int(pat.patch_off[log]):int(pat.patch_off[log + 1])], ref.patches[int(ref.patch_off[log]):int(ref.patch_off[log]) + int(ref.logs[log]["n_patches"])])
+    assert H.check_patch_streams(batch, pat, [d["expected"] for d in g["docs"]]) == batch.n_logs
+    starved, ext2 = H.emu_replay_with_arena(batch, res, cap=40, arena=9000, gwin=gwin)
+    got = ext2[:batch.n_logs, 0] != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert got.any() and not got.all()
+    assert np.array_equal(starved.logs["n_patches"][~got], ref.logs["n_patches"][~got]) and np.all(starved.logs["status"][~got] == abi.ERR_CAPACITY)
+    assert np.all(starved.logs["status"][got] == 0)
+    # a log that starts quietly (one record per row) and then produces many per row outgrows the first extent (sized from the rate so far) and takes a second
+    late = wire.encode_docs([[H.synthetic_marks_log(400, 300, 5, max_span=400)]])
+    lres = H.emu_merge(late, lds_bytes=160 * 1024)
+    lref = H.emu_replay(late, lres, cap=200000, gwin=gwin)
+    lpat, lext = H.emu_replay_with_arena(late, lres, cap=40, arena=400000, gwin=gwin)
+    assert int(lext[0, 1]) != 0xFFFFFFFFFFFFFFFF and int(lpat.logs[0]["status"]) == 0, (lext, lref.logs)
+    n = int(lref.logs[0]["n_patches"])
+    assert int(lpat.logs[0]["n_patches"]) == n and n > 40 + int(lext[0, 2])
+    assert np.array_equal(lpat.patches[:n], lref.patches[:n])

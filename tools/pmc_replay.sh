@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 k=0
 for CTRS in "$@"; do
   k=$((k+1))
-  timeout 240 rocprofv3 --pmc $CTRS --kernel-trace -d "$OUT/raw$k" -- python "$ROOT/tools/replay_bench.py" > "$OUT/run$k.log" 2>&1
+  timeout 240 rocprofv3 --pmc $CTRS --kernel-trace -d "$OUT/raw$k" -- python "$ROOT/tools/replay_bench.py" ${REPLAY_ARGS:-} > "$OUT/run$k.log" 2>&1
   db=$(find "$OUT/raw$k" -name '*.db' | head -1)
   [ -n "$db" ] && python "$ROOT/tools/prof_summary.py" "$db" --pmc --all | grep -E 'ptx_replay.*(per_dispatch|grid=)' | tee -a "$OUT/summary.txt"
   rm -rf "$OUT/raw$k"
