@@ -289,6 +289,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint32_t ntab[3] = {0u, 0u, 0u};
     uint64_t maxop[3] = {0ull, 0ull, 0ull}; /* largest opId applied so far per LWW type */
 
+#ifndef PTX_REPLAY_EXP
+#define PTX_REPLAY_EXP 0 /* timing experiments only (wrong results): bits switch parts of the step off */
+#endif
 #define PTX_VIS_AT(s_) ptx_bitrank(present, ((uint32_t)(s_) + 1u) >> 1) /* visible index at a boundary slot */
     /* Room for the records, looked after once per chunk of rows (not per record): a log that may outgrow its room within the chunk — three times its record
      * rate so far, at least eight per row — asks for an extent that holds that rate for all the rows still to come; should that run out too, one sixteen times
@@ -326,7 +329,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
 #define PTX_DEFINE_SLOT(s_)                                                                     \
     do {                                                                                        \
         if (!((PTX_U32(defined[(s_) >> 5]) >> ((s_)&31u)) & 1u)) {                              \
-            const uint32_t l1_ = PTX_U32(ptx_last_set_below(defined, (s_))); /* slot + 1, the same in every lane */ \
+            const uint32_t l1_ = (PTX_REPLAY_EXP & 8) ? 0u : PTX_U32(ptx_last_set_below(defined, (s_))); /* slot + 1, the same in every lane */ \
             PTX_LEADER {                                                                        \
                 const uint32_t bit_ = 1u << ((s_)&31u), ws_ = (s_) >> 5;                        \
                 if (l1_) {                                                                      \
@@ -384,13 +387,15 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         const bool open = t >= first;  /* the rows before `first` count records (npatch) but write none ... */
         if (t == first) npatch = 0u;   /* ... and the count starts again at the first row asked for */
         const uint32_t kindb = PTX_U32(c_kind[ci]); /* (one LDS address: the same in every lane) */
-        const uint32_t kind = kindb & 15u;
+        uint32_t kind = kindb & 15u;
+        if ((PTX_REPLAY_EXP & 256) && kind == PTX_RK_MARK) kind = PTX_RK_SKIP;
+        if ((PTX_REPLAY_EXP & 512) && (kind == PTX_RK_INSERT || kind == PTX_RK_DELETE)) kind = PTX_RK_SKIP;
         if (kind == PTX_RK_MAKELIST) {
             PTX_LEADER { ptx_patch_put(dst, open, npatch, t, PTX_PATCH_MAKELIST, 0u, 0u); }
             npatch += 1u;
         } else if (kind == PTX_RK_INSERT) {
             const uint32_t r = PTX_U32(c_a[ci]);
-            const uint32_t l1 = PTX_U32(ptx_last_set_below(defined, 2u * r)); /* slot + 1 */
+            const uint32_t l1 = (PTX_REPLAY_EXP & 32) ? 0u : PTX_U32(ptx_last_set_below(defined, 2u * r)); /* slot + 1 */
             const uint32_t p0 = npatch;
             uint32_t attr = 0;
             bool coms = false;
@@ -427,7 +432,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 PTX_LEADER { H->tmp = 0; }
             }
             /* the element is visible from now on */
-            PTX_FOR(w, nwe) {
+            if (!(PTX_REPLAY_EXP & 64)) PTX_FOR(w, nwe) {
                 if (w == (r >> 5)) present[w].bits |= 1u << (r & 31);
                 else if (w > (r >> 5)) present[w].pre += 1;
             }
@@ -442,7 +447,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 npatch += 1u;
                 nvis -= 1u;
                 PTX_SYNC_T();
-                PTX_FOR(w, nwe) {
+                if (!(PTX_REPLAY_EXP & 64)) PTX_FOR(w, nwe) {
                     if (w == (r >> 5)) present[w].bits &= ~(1u << (r & 31));
                     else if (w > (r >> 5)) present[w].pre -= 1;
                 }
@@ -463,7 +468,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             if (slot_b != PTX_SLOT_NONE) PTX_DEFINE_SLOT(slot_b); /* inherits the state BEFORE this op from inside the range */
             /* the words of [slot_a, lim) */
             const uint32_t lim = slot_b != PTX_SLOT_NONE ? slot_b : 2u * n;
-            const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5, nw = whi > wlo && lim > slot_a ? whi - wlo : 0u;
+            const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5, nw = whi > wlo && lim > slot_a && !(PTX_REPLAY_EXP & 128) ? whi - wlo : 0u;
             const uint32_t my_id = PTX_U32(c_pay[ci]);
             const uint64_t my_op = ((uint64_t)PTX_U32((uint32_t)(c_id[ci] >> 32)) << 32) | PTX_U32((uint32_t)c_id[ci]);
             /* the defined slots of the range in word w_ */
@@ -485,7 +490,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
 #define PTX_FINISH_WORD(wi_, w_, m_, ch_)                                                                               \
     do {                                                                                                                \
         uint32_t R_ = 0;                                                                                                \
-        if (ch_) {                                                                                                      \
+        if ((ch_) && !(PTX_REPLAY_EXP & 16)) {                                                                          \
             const uint32_t pw_ = present[(w_) >> 1].bits;                                                               \
             const uint32_t P2_ = ptx_spread16(((w_)&1u) ? pw_ >> 16 : pw_) & PTX_RANGE_MASK(w_);                        \
             uint32_t G_ = P2_ & (m_);                                                                                   \
