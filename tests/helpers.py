@@ -517,6 +517,47 @@ def redeal_logs(logs, rng, n_logs):
     return out
 
 
+def concurrent_marks_doc(n_chars, per_actor, seed):
+    """One document: actor `a` types n_chars, then actors a, b, c — each knowing only that text — make per_actor random mark ops of all four types.  Returned:
+    the three replicas' logs [a's order: own ops first, then b's, then c's], [c's ops, then b's, then a's: every later op has a SMALLER opId than many applied
+    before it], and random causally closed interleavings."""
+    import random
+
+    rnd = random.Random(seed)
+    ids = ["%d@a" % (2 + i) for i in range(n_chars)]
+    ops = [{"opId": "1@a", "action": "makeList", "obj": "_root", "key": "text"}]
+    for i in range(n_chars):
+        ops.append({"opId": ids[i], "action": "set", "obj": "1@a", "elemId": "_head" if i == 0 else ids[i - 1], "insert": True, "value": "abcdefghij"[rnd.randrange(10)]})
+    base = {"actor": "a", "seq": 1, "deps": {}, "startOp": 1, "ops": ops}
+    chains = {}
+    for actor in "abc":
+        ctr, seq, chain = n_chars + 2, (2 if actor == "a" else 1), []
+        for _ in range(per_actor):
+            mt = ("strong", "em", "link", "comment")[rnd.randrange(4)]
+            a = rnd.randrange(n_chars)
+            e = a + 1 + rnd.randrange(n_chars - a)
+            op = {"opId": "%d@%s" % (ctr, actor), "action": "addMark" if rnd.random() < 0.6 else "removeMark", "obj": "1@a", "start": {"type": "before", "elemId": ids[a]}, "markType": mt}
+            if mt in ("strong", "em"):
+                op["end"] = {"type": "endOfText"} if e >= n_chars else {"type": "before", "elemId": ids[e]}
+            else:
+                op["end"] = {"type": "after", "elemId": ids[e - 1]}
+            if mt == "link" and op["action"] == "addMark":
+                op["attrs"] = {"url": "%s.com" % "ABC"[rnd.randrange(3)]}
+            if mt == "comment":
+                op["attrs"] = {"id": "comment-%d" % rnd.randrange(6)}
+            chain.append({"actor": actor, "seq": seq, "deps": {} if actor == "a" else {"a": 1}, "startOp": ctr, "ops": [op]})
+            ctr += 1
+            seq += 1
+        chains[actor] = chain
+    fwd = [base] + chains["a"] + chains["b"] + chains["c"]
+    back = [base] + chains["c"] + chains["b"] + chains["a"]
+    return [fwd, back] + redeal_logs([fwd], rnd, 4)
+
+
+def concurrent_marks_docs():
+    return [concurrent_marks_doc(40, 60, 1), concurrent_marks_doc(25, 120, 2)]
+
+
 def more_deletes_than_inserts_docs():
     """Logs with more deletes than inserts + 1 (the same chars deleted again and again, which the reference allows,
     micromerge.ts:693): [all fine -> "!", a late delete whose target is only inserted by the NEXT op, a late delete of an unknown

@@ -245,3 +245,20 @@ def test_overflow_extents_give_the_same_streams(gwin):
     n = int(lref.logs[0]["n_patches"])
     assert int(lpat.logs[0]["n_patches"]) == n and n > 40 + int(lext[0, 2])
     assert np.array_equal(lpat.patches[:n], lref.patches[:n])
+
+
+@pytest.mark.parametrize("gwin", [False, True])
+def test_marks_that_arrive_after_larger_op_ids(gwin):
+    """The replay decides compareOpIds per slot without a per-slot winner: an op loses where an earlier-APPLIED op of its type with a larger opId covers.  In the
+    fuzzer's logs few ops meet a larger id; here three actors mark the same text concurrently and a replica applies them in descending id order, so that almost
+    every op has many larger ones applied before it (and every link / comment state is met): streams against the oracle, op for op."""
+    if not H.have_node():
+        pytest.skip("node not installed")
+    docs = H.concurrent_marks_docs()
+    expected = H.oracle_apply(docs, patches=True)
+    batch = wire.encode_docs(docs)
+    for reverse in (0, 1, 2):
+        res = H.emu_merge(batch, reverse=reverse, lds_bytes=160 * 1024)
+        assert np.all(res.logs["status"] == 0)
+        pat = H.emu_replay(batch, res, reverse=reverse, gwin=gwin)
+        _check_streams(batch, pat, expected)

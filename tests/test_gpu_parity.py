@@ -348,6 +348,18 @@ def test_golden_patch_streams(eng, name):
         assert np.any(pat.logs["n_patches"].astype(np.int64) > 2 * rows + 16)
 
 
+def test_marks_that_arrive_after_larger_op_ids(eng):
+    """GPU twin of test_emu_patches.py's: three actors mark one text concurrently and a replica applies them in descending id order — almost every op meets
+    larger ids applied before it (the replay's table scan instead of per-slot winners), every link / comment state is met."""
+    if not H.have_node():
+        pytest.skip("node not installed")
+    docs = H.concurrent_marks_docs()
+    expected = H.oracle_apply(docs, patches=True)
+    batch = wire.encode_docs(docs)
+    res, pat = _streams(eng, batch)
+    assert H.check_patch_streams(batch, pat, expected) == batch.n_logs
+
+
 def test_patch_streams_with_op_counters_beyond_the_dense_key_range(eng):
     """The replay keeps the LWW winners of strong / em per slot as dense op-id keys where the log's id space fits 16 bits and as rows where it
     does not: the reference-made fixture with every counter moved up by 70 000 takes the second path and must give the same streams."""
