@@ -76,6 +76,11 @@ struct PtxReplayArgs {
     uint64_t* ext_off; /* [3 * n_logs] */
 };
 
+/* the mark state of 32 slots, one 16-byte LDS access: "some comment op covers" and, per LWW type (strong, em, link), "the winner is an addMark" */
+struct PtxMarkBits {
+    uint32_t ac, on[3];
+};
+
 struct PtxReplayHdr {
     uint32_t tmp;      /* per-step scratch: counter */
     uint32_t ext_ok;   /* the extent asked for was granted */
@@ -88,7 +93,7 @@ struct PtxReplayHdr {
 PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid, bool gscratch = false) {
     const uint64_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2, Kl = K - Kc;
     (void)ks;
-    return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + 5 * ptx_a16(4 * nws) + 2 * ptx_a16(4 * (nws + 1)) +
+    return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + ptx_a16(4 * nws) + ptx_a16(16 * nws) + 2 * ptx_a16(4 * (nws + 1)) +
            (gscratch ? 0 : ptx_a16(4 * (2 * n + 2)) + 3 * ptx_a16(2 * (Kl + 1))) +
            ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
            4 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
@@ -209,11 +214,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     bp.overflow = false;
     PtxBitWord* present = ptx_alloc<PtxBitWord>(bp, nwe);
     uint32_t* defined = ptx_alloc<uint32_t>(bp, nws);
-    uint32_t* anyc = ptx_alloc<uint32_t>(bp, nws);
-    uint32_t* on[3]; /* per defined slot: the winner of the type is an addMark */
-    on[0] = ptx_alloc<uint32_t>(bp, nws);
-    on[1] = ptx_alloc<uint32_t>(bp, nws);
-    on[2] = ptx_alloc<uint32_t>(bp, nws);
+    PtxMarkBits* mb = ptx_alloc<PtxMarkBits>(bp, nws); /* per defined slot: covered by a comment op; the winner of the LWW type is an addMark */
     /* per word of a mark op's range: the changed slots -> the slots that open a record; their count -> its prefix */
     uint32_t* cw = ptx_alloc<uint32_t>(bp, nws + 1);
     uint32_t* cnt = ptx_alloc<uint32_t>(bp, nws + 1);
@@ -273,10 +274,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     }
     PTX_FOR(w, nws) {
         defined[w] = 0;
-        anyc[w] = 0;
-        on[0][w] = 0;
-        on[1][w] = 0;
-        on[2][w] = 0;
+        PtxMarkBits z;
+        z.ac = z.on[0] = z.on[1] = z.on[2] = 0;
+        mb[w] = z;
     }
     PTX_FOR(c, Kid + 1) ctail[c] = PTX_SLOT_NONE;
     PTX_LEADER {
@@ -332,13 +332,16 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             const uint32_t l1_ = (PTX_REPLAY_EXP & 8) ? 0u : PTX_U32(ptx_last_set_below(defined, (s_))); /* slot + 1, the same in every lane */ \
             PTX_LEADER {                                                                        \
                 const uint32_t bit_ = 1u << ((s_)&31u), ws_ = (s_) >> 5;                        \
-                if (l1_) {                                                                      \
-                    const uint32_t l_ = l1_ - 1u;                                               \
-                    if (ptx_bittest(anyc, l_)) anyc[ws_] |= bit_;                               \
-                    if (ptx_bittest(on[0], l_)) on[0][ws_] |= bit_;                             \
-                    if (ptx_bittest(on[1], l_)) on[1][ws_] |= bit_;                             \
-                    if (ptx_bittest(on[2], l_)) {                                               \
-                        on[2][ws_] |= bit_;                                                     \
+                if (l1_) { /* (one 16-byte read of the neighbour's word, one of the slot's own, one write) */ \
+                    const uint32_t l_ = l1_ - 1u, lb_ = l_ & 31u;                               \
+                    const PtxMarkBits src_ = mb[l_ >> 5];                                       \
+                    PtxMarkBits own_ = (l_ >> 5) == ws_ ? src_ : mb[ws_];                       \
+                    if ((src_.ac >> lb_) & 1u) own_.ac |= bit_;                                 \
+                    if ((src_.on[0] >> lb_) & 1u) own_.on[0] |= bit_;                           \
+                    if ((src_.on[1] >> lb_) & 1u) own_.on[1] |= bit_;                           \
+                    if ((src_.on[2] >> lb_) & 1u) own_.on[2] |= bit_;                           \
+                    mb[ws_] = own_;                                                             \
+                    if ((src_.on[2] >> lb_) & 1u) {                                             \
                         PTX_G_FENCE(); /* (global urls) the stores of the ops before have landed */ \
                         PTX_G_ST32(&lurl[s_], PTX_G_LD32(&lurl[l_]));                           \
                     }                                                                           \
@@ -402,13 +405,14 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             if (l1) { /* the marks of the closest defined slot to the left (every lane computes them: LDS broadcasts, one url load) */
                 const uint32_t l = l1 - 1u;
                 const uint32_t lw = l >> 5, lb = l & 31u;
-                if ((PTX_U32(on[0][lw]) >> lb) & 1u) attr |= PTX_ATTR_STRONG;
-                if ((PTX_U32(on[1][lw]) >> lb) & 1u) attr |= PTX_ATTR_EM;
-                if ((PTX_U32(on[2][lw]) >> lb) & 1u) {
+                const PtxMarkBits st = mb[lw]; /* (one 16-byte read) */
+                if ((PTX_U32(st.on[0]) >> lb) & 1u) attr |= PTX_ATTR_STRONG;
+                if ((PTX_U32(st.on[1]) >> lb) & 1u) attr |= PTX_ATTR_EM;
+                if ((PTX_U32(st.on[2]) >> lb) & 1u) {
                     PTX_G_FENCE();
                     attr |= PTX_ATTR_LINK | (PTX_U32(PTX_G_LD32(&lurl[l])) & PTX_ATTR_ID_MASK);
                 }
-                coms = (PTX_U32(anyc[lw]) >> lb) & 1u;
+                coms = (PTX_U32(st.ac) >> lb) & 1u;
                 if (coms) attr |= PTX_ATTR_COMMENT;
             }
             PTX_LEADER { ptx_patch_put(dst, open, p0, t, PTX_PATCH_INSERT, ptx_bitrank(present, r), attr); }
@@ -511,7 +515,6 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     } while (0)
             if (ty != PTX_MARK_COMMENT) {
                 const uint32_t li = ty == PTX_MARK_STRONG ? 0u : ty == PTX_MARK_EM ? 1u : 2u;
-                uint32_t* wo = on[li];
                 /* compareOpIds (counter, then actor: the op ids keep that order): this op loses at the slots an applied op of its type with a larger id covers */
                 const bool fast = my_op > maxop[li];
                 if (!fast) {
@@ -533,8 +536,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     const uint32_t w = wlo + wi;
                     const uint32_t m = defined[w] & PTX_RANGE_MASK(w);
                     const uint32_t upd = fast ? m : m & ~cw[wi];
-                    const uint32_t old = wo[w];
-                    if (upd) wo[w] = add ? old | upd : old & ~upd;
+                    const uint32_t old = mb[w].on[li];
+                    if (upd) mb[w].on[li] = add ? old | upd : old & ~upd;
                     if (per_slot) {
                         cw[wi] = upd & ~old; /* (the two together: the slots the op wins) */
                         cnt[wi] = upd & old;
@@ -584,9 +587,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                         if (cadd[y]) onm |= c;
                         und &= ~c;
                     }
-                    const uint32_t any = anyc[w];
+                    const uint32_t any = mb[w].ac;
                     const uint32_t ch = add ? m & ~onm : m & (onm | ~any); /* remove on no comment key: undefined -> [] */
-                    if (m) anyc[w] = any | m;
+                    if (m) mb[w].ac = any | m;
                     PTX_FINISH_WORD(wi, w, m, ch);
                 }
             }
