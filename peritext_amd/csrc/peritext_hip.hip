@@ -1526,12 +1526,20 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
     if (gwin) need = need_g;
     const uint32_t lds_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, ctx->max_lds); /* larger logs report PTX_ERR_CAPACITY */
     uint16_t* d_win = nullptr;
+    uint64_t* d_winoff = nullptr;
     uint32_t* d_first = nullptr;
-    if (gwin) {
-        e = hipMalloc((void**)&d_win, ptx_replay_win_bytes(b->n_ops, L));
+    if (gwin) { /* every log's slice of the scratch: what its header says it needs */
+        std::vector<uint64_t> woff((size_t)L + 1, 0);
+        for (uint32_t l = 0; l < L; ++l) woff[l + 1] = woff[l] + ptx_replay_win_units_hdr(hdr[l]);
+        e = hipMalloc((void**)&d_win, 2 * woff[L] + 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_winoff, ((size_t)L + 1) * 8);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_winoff, woff.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); /* (woff leaves scope) */
         if (e != hipSuccess) { /* (an early return here leaked the offsets already held by `out`, and named an out-of-memory PTX_ERR_HIP) */
+            (void)hipFree(d_win);
+            (void)hipFree(d_winoff);
             ptx_patches_free(out);
-            return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("replay set-up (winner arrays): ") + hipGetErrorString(e));
+            return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("replay set-up (scratch): ") + hipGetErrorString(e));
         }
     }
     if (first_row) {
@@ -1539,6 +1547,7 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
         if (e == hipSuccess) e = hipMemcpyAsync(d_first, first_row, (size_t)L * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) {
             (void)hipFree(d_win);
+            (void)hipFree(d_winoff);
             (void)hipFree(d_first);
             ptx_patches_free(out);
             return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("replay set-up: ") + hipGetErrorString(e));
@@ -1602,6 +1611,7 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
             A.n_logs = L;
             A.lds_bytes = lds_bytes;
             A.win_scratch = d_win;
+            A.win_off = d_winoff;
             A.first_row = d_first;
             A.arena_next = arena_cap ? d_next : nullptr;
             A.arena_base = total;
@@ -1645,6 +1655,7 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
     }
     release();
     (void)hipFree(d_win);
+    (void)hipFree(d_winoff);
     (void)hipFree(d_first);
     if (st != PTX_OK) {
         ptx_patches_free(out);

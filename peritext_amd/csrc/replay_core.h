@@ -44,7 +44,7 @@
 #include "merge_core.h"
 
 #define PTX_SLOT_NONE 0xFFFFu /* start never matches / end never reached */
-#define PTX_RCHUNK 64u
+#define PTX_RCHUNK 32u /* rows resolved together (their LDS buffers: 17 bytes per row) */
 enum { PTX_RK_SKIP = 0, PTX_RK_MAKELIST = 1, PTX_RK_INSERT = 2, PTX_RK_DELETE = 3, PTX_RK_MARK = 4 };
 
 struct PtxReplayArgs {
@@ -67,7 +67,8 @@ struct PtxReplayArgs {
     uint32_t n_logs;
     uint32_t lds_bytes;
     const uint32_t* first_row; /* optional [n_logs]: only the records of the rows from here on are produced (the rows before are replayed for their state alone) */
-    uint16_t* win_scratch; /* optional: the per-slot link urls and the tables of applied mark ops of every log live HERE (16 bytes per row of the batch + 128 per log) instead of in LDS */
+    uint16_t* win_scratch; /* optional: the per-slot link urls, the tables of applied mark ops and the comment ops' id tables of every log live HERE instead of in LDS ... */
+    const uint64_t* win_off; /* ... [n_logs + 1], in u16 units: the slice of log l (ptx_replay_win_units of its header) */
     /* optional: overflow extents.  A log whose records outgrow its capacity [patch_off[l], patch_off[l + 1]) takes an extent of `patches` from the arena
      * [arena_base, arena_base + arena_cap) (an atomic bump of *arena_next) and goes on writing there — sized from its own record rate so far; should that run
      * out too, a second, much larger one.  ext_off[3 l ..] = {first extent, second extent (~0: none), records the first holds}.  The host packs the parts. */
@@ -94,18 +95,24 @@ PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_
     const uint64_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2, Kl = K - Kc;
     (void)ks;
     return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + ptx_a16(4 * nws) + ptx_a16(16 * nws) + 2 * ptx_a16(4 * (nws + 1)) +
-           (gscratch ? 0 : ptx_a16(4 * (2 * n + 2)) + 3 * ptx_a16(2 * (Kl + 1))) +
+           (gscratch ? 0 : ptx_a16(4 * (2 * n + 2)) + 3 * ptx_a16(2 * (Kl + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1))) +
            ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
-           4 * ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1)) + ptx_a16(Kc + 1);
+           3 * ptx_a16(2 * (Kc + 1)) + ptx_a16(Kc + 1);
 }
 PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gscratch = false) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
     return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], 0, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u, gscratch);
 }
-/* bytes of win_scratch a batch takes, and where the arrays of a log start (in u16 units): per-slot urls (4 bytes x (2 n + 2)) and three u16 columns of at most
- * K + 1 entries, each 16-byte aligned: 4 n + 3 K + 40 units <= 8 N + 64 */
-PTX_HD uint64_t ptx_replay_win_bytes(uint64_t n_ops, uint64_t n_logs) { return 16 * n_ops + 128 * n_logs + 64; }
-PTX_HD uint64_t ptx_replay_win_at(uint64_t base_row, uint64_t log) { return 8 * base_row + 64 * log; }
+/* u16 units of win_scratch a log takes: per-slot urls (4 bytes x (2 n + 2)), three u16 columns of the LWW op tables, the comment ops' ids and the last op per
+ * comment id; every array 16-byte aligned */
+PTX_HD uint64_t ptx_replay_win_units(uint64_t n, uint64_t K, uint64_t Kc, uint64_t Kid) {
+    const uint64_t Kl = K - Kc;
+    return ((2 * (2 * n + 2) + 7) & ~7ull) + 3 * ((Kl + 1 + 7) & ~7ull) + ((Kc + 1 + 7) & ~7ull) + ((Kid + 1 + 7) & ~7ull);
+}
+PTX_HD uint64_t ptx_replay_win_units_hdr(const ptx_log_hdr& h) {
+    const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
+    return ptx_replay_win_units(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u);
+}
 
 /* where a log's records go: its own capacity first, then its overflow extent */
 struct PtxPatchDst {
@@ -220,18 +227,24 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint32_t* cnt = ptx_alloc<uint32_t>(bp, nws + 1);
     uint32_t* lurl;
     uint16_t *trow, *ta, *tl;
+    uint16_t* ccid;  /* comment op: its id */
+    uint16_t* ctail; /* per comment id: the last registered op (the chain of the ops with one id starts here, latest first) */
     if (kGWin) {
-        uint16_t* g = A.win_scratch + ptx_replay_win_at(base, log);
+        uint16_t* g = A.win_scratch + A.win_off[log];
         const uint32_t ucols = (2u * (2u * n + 2u) + 7u) & ~7u, tcols = (Kl + 1u + 7u) & ~7u;
         lurl = (uint32_t*)g;
         trow = g + ucols;
         ta = trow + tcols;
         tl = ta + tcols;
+        ccid = tl + tcols;
+        ctail = ccid + ((Kc + 1u + 7u) & ~7u);
     } else {
         lurl = ptx_alloc<uint32_t>(bp, 2 * n + 2);
         trow = ptx_alloc<uint16_t>(bp, Kl + 1);
         ta = ptx_alloc<uint16_t>(bp, Kl + 1);
         tl = ptx_alloc<uint16_t>(bp, Kl + 1);
+        ccid = ptx_alloc<uint16_t>(bp, Kc + 1);
+        ctail = ptx_alloc<uint16_t>(bp, Kid + 1);
     }
 #define PTX_G_LD16(p_) (kGWin ? ptx_coherent_load16(p_) : *(p_))
 #define PTX_G_ST16(p_, v_) do { if (kGWin) ptx_coherent_store16((p_), (uint16_t)(v_)); else *(p_) = (uint16_t)(v_); } while (0)
@@ -250,9 +263,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint8_t* c_kind = ptx_alloc<uint8_t>(bp, PTX_RCHUNK);  /* PTX_RK_* | mark type << 4 | addMark << 6 */
     uint16_t* ca = ptx_alloc<uint16_t>(bp, Kc + 1);       /* comment op: first covered slot */
     uint16_t* cb = ptx_alloc<uint16_t>(bp, Kc + 1);       /*             first slot not covered (PTX_SLOT_NONE = to the end) */
-    uint16_t* ccid = ptx_alloc<uint16_t>(bp, Kc + 1);
     uint16_t* cprev = ptx_alloc<uint16_t>(bp, Kc + 1);    /* chain of the ops with the same id, latest first from ctail[id] */
-    uint16_t* ctail = ptx_alloc<uint16_t>(bp, Kid + 1);   /* per id: last registered op */
     uint8_t* cadd = ptx_alloc<uint8_t>(bp, Kc + 1);
     if (bp.overflow || n > 32766u || N > 65534u || Kid > 65535u) {
         PTX_LEADER {
@@ -278,7 +289,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         z.ac = z.on[0] = z.on[1] = z.on[2] = 0;
         mb[w] = z;
     }
-    PTX_FOR(c, Kid + 1) ctail[c] = PTX_SLOT_NONE;
+    PTX_FOR(c, Kid + 1) PTX_G_ST16(&ctail[c], PTX_SLOT_NONE);
     PTX_LEADER {
         H->tmp = 0;
         H->ext_cap[0] = H->ext_cap[1] = 0;
@@ -419,15 +430,17 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             uint32_t extra = 0;
             if (coms) {
                 const uint32_t l = l1 - 1u;
+                PTX_G_FENCE();
                 PTX_FOR(kc, ncom) {
                     if (cadd[kc] && ca[kc] <= l && l < cb[kc]) {
                         bool last = true; /* no later-applied covering op of the same id: the chain of the id, latest first, down to this op */
-                        for (uint32_t y = ctail[ccid[kc]]; y != kc && y != PTX_SLOT_NONE; y = cprev[y])
+                        const uint32_t id = PTX_G_LD16(&ccid[kc]);
+                        for (uint32_t y = PTX_G_LD16(&ctail[id]); y != kc && y != PTX_SLOT_NONE; y = cprev[y])
                             if (ca[y] <= l && l < cb[y]) {
                                 last = false;
                                 break;
                             }
-                        if (last) ptx_patch_put(dst, open, p0 + 1u + ptx_atomic_add(&H->tmp, 1u), t, PTX_PATCH_INSERT_COMMENT, ccid[kc], 0u);
+                        if (last) ptx_patch_put(dst, open, p0 + 1u + ptx_atomic_add(&H->tmp, 1u), t, PTX_PATCH_INSERT_COMMENT, id, 0u);
                     }
                 }
                 PTX_SYNC_T();
@@ -513,6 +526,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         cw[wi_] = R_;                                                                                                   \
         cnt[wi_] = ptx_popc(R_);                                                                                        \
     } while (0)
+            uint32_t y0 = PTX_SLOT_NONE; /* (comments) the last registered op of this op's id */
             if (ty != PTX_MARK_COMMENT) {
                 const uint32_t li = ty == PTX_MARK_STRONG ? 0u : ty == PTX_MARK_EM ? 1u : 2u;
                 /* compareOpIds (counter, then actor: the op ids keep that order): this op loses at the slots an applied op of its type with a larger id covers */
@@ -578,11 +592,13 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 if (fast) maxop[li] = my_op;
             } else {
                 /* comments: the last-applied covering op with this id decides (this op is not registered yet): per word, the id's chain latest first */
+                PTX_G_FENCE();
+                y0 = my_id < Kid ? PTX_U32(PTX_G_LD16(&ctail[my_id])) : (uint32_t)PTX_SLOT_NONE;
                 PTX_FOR(wi, nw) {
                     const uint32_t w = wlo + wi;
                     const uint32_t m = defined[w] & PTX_RANGE_MASK(w);
                     uint32_t und = m, onm = 0;
-                    for (uint32_t y = my_id < Kid ? ctail[my_id] : PTX_SLOT_NONE; y != PTX_SLOT_NONE && und; y = cprev[y]) {
+                    for (uint32_t y = y0; y != PTX_SLOT_NONE && und; y = cprev[y]) {
                         const uint32_t c = ptx_span_mask(ca[y], cb[y], w) & und;
                         if (cadd[y]) onm |= c;
                         und &= ~c;
@@ -624,10 +640,10 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 PTX_LEADER {
                     ca[ncom] = (uint16_t)slot_a;
                     cb[ncom] = (uint16_t)slot_b;
-                    ccid[ncom] = (uint16_t)my_id;
+                    PTX_G_ST16(&ccid[ncom], my_id);
                     cadd[ncom] = add ? 1 : 0;
-                    cprev[ncom] = ctail[my_id];
-                    ctail[my_id] = (uint16_t)ncom;
+                    cprev[ncom] = (uint16_t)y0;
+                    PTX_G_ST16(&ctail[my_id], ncom);
                 }
                 ncom += 1u;
             }

@@ -204,8 +204,12 @@ extern "C" int ptx_emu_replay_arena(const ptx_batch* b, const ptx_log_result* re
     const bool gwin = (reverse & 256) != 0;
     reverse &= 255;
     const uint64_t n_ops = b->n_logs ? b->log_off[b->n_logs] : 0;
-    A.win_scratch = gwin ? (uint16_t*)malloc(ptx_replay_win_bytes(n_ops, b->n_logs)) : nullptr;
-    if (gwin) memset(A.win_scratch, 0xA5, ptx_replay_win_bytes(n_ops, b->n_logs));
+    (void)n_ops;
+    uint64_t* win_off = (uint64_t*)calloc((size_t)b->n_logs + 1, 8);
+    for (uint32_t l = 0; l < b->n_logs; ++l) win_off[l + 1] = win_off[l] + ptx_replay_win_units_hdr(A.log_hdr[l]);
+    A.win_off = win_off;
+    A.win_scratch = gwin ? (uint16_t*)malloc(2 * win_off[b->n_logs] + 16) : nullptr;
+    if (gwin) memset(A.win_scratch, 0xA5, 2 * win_off[b->n_logs] + 16);
     uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)lds_bytes + 64);
     if (!lds) return 1;
     ptx_emu_reverse = reverse;
@@ -218,6 +222,7 @@ extern "C" int ptx_emu_replay_arena(const ptx_batch* b, const ptx_log_result* re
     free(lds);
     free(hdr);
     free(A.win_scratch);
+    free(win_off);
     return 0;
 }
 extern "C" int ptx_emu_replay_from(const ptx_batch* b, const ptx_log_result* res, const uint32_t* rank, const uint32_t* refs, const uint64_t* patch_off, ptx_patch* patches,

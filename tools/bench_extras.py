@@ -283,7 +283,7 @@ def main():
     if "replay" in legs:
         try:
             with Engine(args.device) as e:  # with elem_rank: the replay reads it
-                docs = min(2048, args.docs)
+                docs = min(4096, args.docs)  # (12 288 logs: three full rounds of workgroups at 16 resident logs per CU)
                 db, _ = e.generate(*gen_args, docs, args.seed, first_doc=args.first_doc, list_cap=args.list_cap)
                 dr = e.alloc_result(db)
                 e.merge(db, dr)

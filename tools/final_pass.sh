@@ -17,5 +17,6 @@ find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \
 rm -rf "$OUT/prof"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 for i in 1 2; do python tools/replay_bench.py 2>&1 | tail -1 >> "$OUT/replay.jsonl"; done
+python tools/replay_bench.py --docs 4096 2>&1 | tail -1 >> "$OUT/replay.jsonl"
 python tools/replay_bench.py --ops 2048 2>&1 | tail -1 >> "$OUT/replay.jsonl"
 tail -3 "$OUT/gpu_tests.txt"; tail -c 1500 "$OUT/bench.json"; cat "$OUT/replay.jsonl" | cut -c1-300
