@@ -1249,6 +1249,41 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_BAIL_IF_ERROR();
     PTX_STAMP(2);
 
+    /* P5a's loads.  The rows of the mark ops come straight from their park (the low halves of its entries from mp0 on; a lane's entries of a block are
+     * consecutive words): the park entries of the first step go out at the start of P3c (two LDS-only phases ahead of their use: with nine logs per CU a trip to HBM takes 10-20 k cycles, and
+     * P4 — 5 k cycles of LDS work — used to stand waiting for them), its gathers ahead of P4; in the loop
+     * the park entries run two steps ahead of the step in work, the gathers one.  (Round 4: copying the list back into LDS first was ONE exposed trip to HBM per
+     * log — 2 k cycles with a CU to itself, 28 k under load.) */
+    const PtxMarkBlocks MB = ptx_mark_blocks(moff1, moff2, moff3, K, PTX_JB_CAP);
+    const uint32_t m_steps = PTX_JB_STEPS(MB.B, PTX_UM);
+    uint32_t kq[PTX_UM], kq_n[PTX_UM]; /* the thread's mark ops of a step (0xFFFFFFFF: none) */
+    uint32_t mq[PTX_UM];               /* the park entries of the step whose gathers go out next */
+#define PTX_MARK_PQ(st_, mq_)                                               \
+    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
+        uint32_t k_;                                                        \
+        (void)ptx_mark_of(MB, PTX_JB_BLOCK(st_, u, PTX_UM), PTX_JB_LANE(st_, u, PTX_UM), k_); \
+        mq_[u] = ptx_coherent_load32(&park[K ? mp0 + k_ : 0u]);             \
+    }
+    uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
+    uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
+    /* rows of this thread's mark ops of a step (list read, then the column gathers; the payload only of the comment ops — their
+     * id —, the others' is not needed before P5b, and then only the winners') */
+#define PTX_MARK_LOAD(st_, kq_, i_, ra_, rb_, sa_, sb_, pl_, mq_)           \
+    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
+        uint32_t k_;                                                        \
+        const bool has_ = ptx_mark_of(MB, PTX_JB_BLOCK(st_, u, PTX_UM), PTX_JB_LANE(st_, u, PTX_UM), k_); \
+        kq_[u] = has_ ? k_ : 0xFFFFFFFFu;                                   \
+        const uint32_t r_ = mq_[u] & 0xFFFFu;                               \
+        i_[u] = r_ < N ? r_ : N - 1u;                                       \
+        pl_[u] = has_ && k_ >= moff2 && k_ < moff3 ? 1u : 0u;               \
+    }                                                                       \
+    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
+        rb_[u] = ref_b[i_[u]];                                              \
+        ra_[u] = ref_a[i_[u]];                                              \
+        sa_[u] = A.side_a[base + i_[u]];                                    \
+        sb_[u] = A.side_b[base + i_[u]];                                    \
+        if (pl_[u]) pl_[u] = payload[i_[u]];                                \
+    }
     /* ---- P3: causal tree of the inserts -> document position of every element ---- */
     {
         /* children per parent -> bucket starts -> bucket ends; 16-bit counters, two per atomically updated word */
@@ -1372,6 +1407,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_LEADER { H->cur_big = H->cur_med = 0; }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(3);
+        PTX_MARK_PQ(0u, mq) /* P5a's first park entries: on their way while the tree is ordered and ranked (LDS only) */
         /* P3c: the children of every parent in descending element index == descending opId (the skip loop of micromerge.ts:630-635), one PARENT per lane.
          * Pass 1, all parents: an only child (most elements are one) is placed at once, a parent with more goes to a list.  Pass 2, the listed parents: a
          * bucket of up to PTX_SMALL_BUCKET members is sorted in registers by a 19-exchange network; up to PTX_HUGE_BUCKET members by PTX_G lanes per member,
@@ -1615,41 +1651,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     bp.off = mark_lds; /* release the tree scratch */
     PTX_STAMP(5);
 
-    /* P5a's loads.  The rows of the mark ops come straight from their park (the low halves of its entries from mp0 on; a lane's entries of a block are
-     * consecutive words): the park entries of the first step go out here, ahead of P4, its gathers once P4's bitmap stands, ahead of the values pass; in the loop
-     * the park entries run two steps ahead of the step in work, the gathers one.  (Round 4: copying the list back into LDS first was ONE exposed trip to HBM per
-     * log — 2 k cycles with a CU to itself, 28 k under load.) */
-    const PtxMarkBlocks MB = ptx_mark_blocks(moff1, moff2, moff3, K, PTX_JB_CAP);
-    const uint32_t m_steps = PTX_JB_STEPS(MB.B, PTX_UM);
-    uint32_t kq[PTX_UM], kq_n[PTX_UM]; /* the thread's mark ops of a step (0xFFFFFFFF: none) */
-    uint32_t mq[PTX_UM];               /* the park entries of the step whose gathers go out next */
-#define PTX_MARK_PQ(st_, mq_)                                               \
-    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
-        uint32_t k_;                                                        \
-        (void)ptx_mark_of(MB, PTX_JB_BLOCK(st_, u, PTX_UM), PTX_JB_LANE(st_, u, PTX_UM), k_); \
-        mq_[u] = ptx_coherent_load32(&park[K ? mp0 + k_ : 0u]);             \
-    }
-    uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
-    uint64_t ra[PTX_UM], rb[PTX_UM], ra_n[PTX_UM], rb_n[PTX_UM];
-    /* rows of this thread's mark ops of a step (list read, then the column gathers; the payload only of the comment ops — their
-     * id —, the others' is not needed before P5b, and then only the winners') */
-#define PTX_MARK_LOAD(st_, kq_, i_, ra_, rb_, sa_, sb_, pl_, mq_)           \
-    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
-        uint32_t k_;                                                        \
-        const bool has_ = ptx_mark_of(MB, PTX_JB_BLOCK(st_, u, PTX_UM), PTX_JB_LANE(st_, u, PTX_UM), k_); \
-        kq_[u] = has_ ? k_ : 0xFFFFFFFFu;                                   \
-        const uint32_t r_ = mq_[u] & 0xFFFFu;                               \
-        i_[u] = r_ < N ? r_ : N - 1u;                                       \
-        pl_[u] = has_ && k_ >= moff2 && k_ < moff3 ? 1u : 0u;               \
-    }                                                                       \
-    _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
-        rb_[u] = ref_b[i_[u]];                                              \
-        ra_[u] = ref_a[i_[u]];                                              \
-        sa_[u] = A.side_a[base + i_[u]];                                    \
-        sb_[u] = A.side_b[base + i_[u]];                                    \
-        if (pl_[u]) pl_[u] = payload[i_[u]];                                \
-    }
-    PTX_MARK_PQ(0u, mq)
+    /* (P5a's loads: the park entries of its first step went out at the start of P3c) their gathers go out here, ahead of P4, and the second step's park entries */
+    PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl, mq)
+    PTX_MARK_PQ(1u, mq)
     /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = nwe; /* bit positions 0..n by document position */
     PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
@@ -1689,8 +1693,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     });
     PTX_SYNC_LDS();
     const uint32_t V = ptx_bitwords_prefix(alive, nwv + 1, &H->scan_tmp[18]);
-    PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl, mq) /* the first step's gathers: in flight during the values pass */
-    PTX_MARK_PQ(1u, mq)
     /* the visible interval [lo, hi) of every mark op (the few later uses of an op's row — the ops that still cover a visible character — read it from the
      * park).  Until the marks are looked at, the space of `hi` and of the comment ids holds the rows of the visible elements (vrow) if they fit */
     uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
