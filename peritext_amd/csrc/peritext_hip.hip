@@ -81,6 +81,7 @@ extern "C" __global__ void __launch_bounds__(PTX_BIG_THREADS) ptx_merge_big_kern
 #endif
 /* (held to 90 SGPRs for 28 instead of 24 wave slots per CU — see PTX_SGPRS_W7 — the replay is SLOWER: 0.98 against 1.05 G ops/s on 4 096-op logs, its spills sit
  * on the sequential chain) */
+static_assert(PTX_REPLAY_THREADS == 64, "replay_core.h is written for ONE wave per log: wave-wide searches, register counters, a one-wave scan without LDS scratch");
 extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kernel(PtxReplayArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS, false>(A, blockIdx.x, ptx_lds);

@@ -87,7 +87,7 @@ struct PtxReplayHdr {
     uint32_t ext_ok;   /* the extent asked for was granted */
     uint32_t ext_cap[2]; /* the log's overflow extents: records each holds (0: none) ... */
     uint32_t ext_lo[2], ext_hi[2]; /* ... and where they start in `patches` */
-    uint32_t scan_tmp[36];
+    uint32_t scan_tmp[4]; /* (ptx_scan_excl's scratch: a one-wave workgroup takes the total from a lane, no trip through the LDS — the kernel is only built for 64 threads) */
 };
 
 /* gscratch: the per-slot link urls and the op tables live in global memory (PtxReplayArgs.win_scratch) */
@@ -97,7 +97,7 @@ PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_
     return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + ptx_a16(4 * nws) + ptx_a16(16 * nws) + 2 * ptx_a16(4 * (nws + 1)) +
            (gscratch ? 0 : ptx_a16(4 * (2 * n + 2)) + 3 * ptx_a16(2 * (Kl + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1))) +
            ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
-           3 * ptx_a16(2 * (Kc + 1)) + ptx_a16(Kc + 1);
+           3 * ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * ((Kc >> 5) + 1));
 }
 PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gscratch = false) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
@@ -264,7 +264,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint16_t* ca = ptx_alloc<uint16_t>(bp, Kc + 1);       /* comment op: first covered slot */
     uint16_t* cb = ptx_alloc<uint16_t>(bp, Kc + 1);       /*             first slot not covered (PTX_SLOT_NONE = to the end) */
     uint16_t* cprev = ptx_alloc<uint16_t>(bp, Kc + 1);    /* chain of the ops with the same id, latest first from ctail[id] */
-    uint8_t* cadd = ptx_alloc<uint8_t>(bp, Kc + 1);
+    uint32_t* cadd = ptx_alloc<uint32_t>(bp, (Kc >> 5) + 1); /* bit per comment op: it is an addMark */
     if (bp.overflow || n > 32766u || N > 65534u || Kid > 65535u) {
         PTX_LEADER {
             ptx_patch_log pl;
@@ -290,6 +290,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         mb[w] = z;
     }
     PTX_FOR(c, Kid + 1) PTX_G_ST16(&ctail[c], PTX_SLOT_NONE);
+    PTX_FOR(c, (Kc >> 5) + 1) cadd[c] = 0;
     PTX_LEADER {
         H->tmp = 0;
         H->ext_cap[0] = H->ext_cap[1] = 0;
@@ -432,7 +433,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 const uint32_t l = l1 - 1u;
                 PTX_G_FENCE();
                 PTX_FOR(kc, ncom) {
-                    if (cadd[kc] && ca[kc] <= l && l < cb[kc]) {
+                    if (ptx_bittest(cadd, kc) && ca[kc] <= l && l < cb[kc]) {
                         bool last = true; /* no later-applied covering op of the same id: the chain of the id, latest first, down to this op */
                         const uint32_t id = PTX_G_LD16(&ccid[kc]);
                         for (uint32_t y = PTX_G_LD16(&ctail[id]); y != kc && y != PTX_SLOT_NONE; y = cprev[y])
@@ -600,7 +601,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     uint32_t und = m, onm = 0;
                     for (uint32_t y = y0; y != PTX_SLOT_NONE && und; y = cprev[y]) {
                         const uint32_t c = ptx_span_mask(ca[y], cb[y], w) & und;
-                        if (cadd[y]) onm |= c;
+                        if (ptx_bittest(cadd, y)) onm |= c;
                         und &= ~c;
                     }
                     const uint32_t any = mb[w].ac;
@@ -641,7 +642,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     ca[ncom] = (uint16_t)slot_a;
                     cb[ncom] = (uint16_t)slot_b;
                     PTX_G_ST16(&ccid[ncom], my_id);
-                    cadd[ncom] = add ? 1 : 0;
+                    if (add) cadd[ncom >> 5] |= 1u << (ncom & 31u);
                     cprev[ncom] = (uint16_t)y0;
                     PTX_G_ST16(&ctail[my_id], ncom);
                 }
