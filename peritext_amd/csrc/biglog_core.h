@@ -19,6 +19,9 @@
 #pragma once
 #include "merge_core.h"
 
+#ifndef PTX_BIG_COMMENT_OPS_PER_ID
+#define PTX_BIG_COMMENT_OPS_PER_ID 1024u /* comment ops with a visible interval one comment id may have in a log beyond one CU's LDS (their sweep is quadratic, one lane per id) */
+#endif
 struct PtxBigEntry { /* one comment op that covers something: visible interval, application index (row), add / remove */
     uint32_t lo, hi, t, add;
 };
@@ -543,6 +546,13 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
         }
         PTX_SYNC();
+        /* the sweep of one id is ONE lane's work and quadratic in the id's ops (with a visible interval), read from HBM here: bounded, so that a log with tens of
+         * thousands of comment ops on one id is a capacity report and not minutes in one lane */
+        PTX_LEADER { H->cur[7] = 0; }
+        PTX_SYNC();
+        PTX_FOR(c, Kid) ptx_atomic_max(&H->cur[7], ccnt[c + 1] - ccnt[c]);
+        PTX_SYNC();
+        if (H->cur[7] > PTX_BIG_COMMENT_OPS_PER_ID) return PTX_ERR_CAPACITY;
         PTX_FOR(c, Kid + 1) ccur[c] = c < Kid ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         PTX_SYNC();
         const uint32_t I = ptx_big_scan<uint32_t, 1>(ccur, Kid + 1, part);

@@ -263,3 +263,39 @@ def test_patch_stream_change_and_cursors_on_a_40000_op_document():
     assert int(status[0]) == 0
     text_obj = [op["opId"] for c in log for op in c["ops"] if op["action"] == "makeList"][0]
     assert wire.decode_changes(made, 0, text_obj=text_obj) == H.oracle_change([[log]], calls, [actor])
+
+
+def _one_comment_id_log(n_chars, n_ops, seed):
+    """A replica log whose n_ops comment ops all carry ONE id (the HBM-staged path sweeps an id's ops in one lane, quadratic in their number)."""
+    import random
+
+    rnd = random.Random(seed)
+    ids = ["%d@doc1" % (2 + i) for i in range(n_chars)]
+    ops = [{"opId": "1@doc1", "action": "makeList", "obj": "_root", "key": "text"}]
+    for i in range(n_chars):
+        ops.append({"opId": ids[i], "action": "set", "obj": "1@doc1", "elemId": "_head" if i == 0 else ids[i - 1], "insert": True, "value": "x"})
+    changes = [{"actor": "doc1", "seq": 1, "deps": {}, "startOp": 1, "ops": ops}]
+    ctr = n_chars + 2
+    for k in range(n_ops):
+        a = rnd.randrange(n_chars)
+        e = a + 1 + rnd.randrange(n_chars - a)
+        op = {"opId": "%d@doc1" % ctr, "action": "addMark" if rnd.random() < 0.6 else "removeMark", "obj": "1@doc1", "markType": "comment", "attrs": {"id": "the-one"},
+              "start": {"type": "before", "elemId": ids[a]}, "end": {"type": "after", "elemId": ids[e - 1]}}
+        changes.append({"actor": "doc1", "seq": 2 + k, "deps": {}, "startOp": ctr, "ops": [op]})
+        ctr += 1
+    return changes
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_comment_ops_on_one_id_are_bounded_in_the_hbm_staged_path():
+    """the per-id comment sweep is quadratic and runs in one lane; the HBM-staged kernel takes up to PTX_BIG_COMMENT_OPS_PER_ID (1 024) ops with a
+    visible interval per id — 900 of them equal the oracle's intervals, 1 300 are a capacity report, not minutes in one lane."""
+    ok = [[_one_comment_id_log(60, 900, 3)]]
+    expected = H.oracle_apply(ok)
+    batch = wire.encode_docs(ok)
+    res = H.emu_merge_big(batch)
+    assert int(res.logs["status"][0]) == 0
+    H.check_log(batch, res, 0, expected[0][0])
+    too_many = wire.encode_docs([[_one_comment_id_log(60, 1300, 4)]])
+    assert int(H.emu_merge_big(too_many).logs["status"][0]) == abi.ERR_CAPACITY
+    assert int(H.emu_merge(too_many, lds_bytes=160 * 1024).logs["status"][0]) == 0  # (the LDS kernel, whose LDS bounds the ops of a log, takes it)
