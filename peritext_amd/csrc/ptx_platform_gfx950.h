@@ -60,6 +60,8 @@ PTX_DEV uint16_t ptx_coherent_load16(const uint16_t* p) { return __hip_atomic_lo
 PTX_DEV void ptx_coherent_store16(uint16_t* p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PTX_DEV uint32_t ptx_coherent_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PTX_DEV void ptx_coherent_store32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PTX_DEV uint64_t ptx_coherent_load64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PTX_DEV void ptx_coherent_store64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PTX_DEV uint32_t ptx_brev(uint32_t x) { return __builtin_bitreverse32(x); } /* v_bfrev_b32 */
 /* a value that is the same in every lane of the wave (read from one LDS address, say): tell the compiler, so that what depends on it is scalar code and scalar branches */
 #define PTX_U32(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))

@@ -82,6 +82,13 @@ struct PtxMarkBits {
     uint32_t ac, on[3];
 };
 
+/* one of the next PTX_RCHUNK rows, resolved (one 16-byte LDS access when its turn comes) */
+struct PtxChunkRow {
+    uint64_t id;   /* the op id (mark ops: compareOpIds) */
+    uint32_t pay;  /* payload: url / comment id */
+    uint16_t a, b; /* insert / delete: final rank; mark: start slot, end slot */
+};
+
 struct PtxReplayHdr {
     uint32_t tmp;      /* per-step scratch: counter */
     uint32_t ext_ok;   /* the extent asked for was granted */
@@ -95,19 +102,19 @@ PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_
     const uint64_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2, Kl = K - Kc;
     (void)ks;
     return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + ptx_a16(4 * nws) + ptx_a16(16 * nws) + 2 * ptx_a16(4 * (nws + 1)) +
-           (gscratch ? 0 : ptx_a16(4 * (2 * n + 2)) + 3 * ptx_a16(2 * (Kl + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1))) +
-           ptx_a16(8 * PTX_RCHUNK) + ptx_a16(4 * PTX_RCHUNK) + 2 * ptx_a16(2 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
+           (gscratch ? 0 : ptx_a16(4 * (2 * n + 2)) + ptx_a16(8 * (Kl + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1))) +
+           ptx_a16(16 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
            3 * ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * ((Kc >> 5) + 1));
 }
 PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gscratch = false) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
     return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], 0, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u, gscratch);
 }
-/* u16 units of win_scratch a log takes: per-slot urls (4 bytes x (2 n + 2)), three u16 columns of the LWW op tables, the comment ops' ids and the last op per
- * comment id; every array 16-byte aligned */
+/* u16 units of win_scratch a log takes: per-slot urls (4 bytes x (2 n + 2)), the table of the applied LWW mark ops (8 bytes each), the comment ops' ids and the
+ * last op per comment id; every array 16-byte aligned */
 PTX_HD uint64_t ptx_replay_win_units(uint64_t n, uint64_t K, uint64_t Kc, uint64_t Kid) {
     const uint64_t Kl = K - Kc;
-    return ((2 * (2 * n + 2) + 7) & ~7ull) + 3 * ((Kl + 1 + 7) & ~7ull) + ((Kc + 1 + 7) & ~7ull) + ((Kid + 1 + 7) & ~7ull);
+    return ((2 * (2 * n + 2) + 7) & ~7ull) + 4 * ((Kl + 1 + 7) & ~7ull) + ((Kc + 1 + 7) & ~7ull) + ((Kid + 1 + 7) & ~7ull);
 }
 PTX_HD uint64_t ptx_replay_win_units_hdr(const ptx_log_hdr& h) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
@@ -226,29 +233,27 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint32_t* cw = ptx_alloc<uint32_t>(bp, nws + 1);
     uint32_t* cnt = ptx_alloc<uint32_t>(bp, nws + 1);
     uint32_t* lurl;
-    uint16_t *trow, *ta, *tl;
+    uint64_t* tab;   /* applied LWW mark op: row | start slot << 16 | end of its interval << 32 */
     uint16_t* ccid;  /* comment op: its id */
     uint16_t* ctail; /* per comment id: the last registered op (the chain of the ops with one id starts here, latest first) */
     if (kGWin) {
         uint16_t* g = A.win_scratch + A.win_off[log];
         const uint32_t ucols = (2u * (2u * n + 2u) + 7u) & ~7u, tcols = (Kl + 1u + 7u) & ~7u;
         lurl = (uint32_t*)g;
-        trow = g + ucols;
-        ta = trow + tcols;
-        tl = ta + tcols;
-        ccid = tl + tcols;
+        tab = (uint64_t*)(g + ucols);
+        ccid = g + ucols + 4u * tcols;
         ctail = ccid + ((Kc + 1u + 7u) & ~7u);
     } else {
         lurl = ptx_alloc<uint32_t>(bp, 2 * n + 2);
-        trow = ptx_alloc<uint16_t>(bp, Kl + 1);
-        ta = ptx_alloc<uint16_t>(bp, Kl + 1);
-        tl = ptx_alloc<uint16_t>(bp, Kl + 1);
+        tab = ptx_alloc<uint64_t>(bp, Kl + 1);
         ccid = ptx_alloc<uint16_t>(bp, Kc + 1);
         ctail = ptx_alloc<uint16_t>(bp, Kid + 1);
     }
 #define PTX_G_LD16(p_) (kGWin ? ptx_coherent_load16(p_) : *(p_))
 #define PTX_G_ST16(p_, v_) do { if (kGWin) ptx_coherent_store16((p_), (uint16_t)(v_)); else *(p_) = (uint16_t)(v_); } while (0)
 #define PTX_G_LD32(p_) (kGWin ? ptx_coherent_load32(p_) : *(p_))
+#define PTX_G_LD64(p_) (kGWin ? ptx_coherent_load64(p_) : *(p_))
+#define PTX_G_ST64(p_, v_) do { if (kGWin) ptx_coherent_store64((p_), (uint64_t)(v_)); else *(p_) = (uint64_t)(v_); } while (0)
 #define PTX_G_ST32(p_, v_) do { if (kGWin) ptx_coherent_store32((p_), (uint32_t)(v_)); else *(p_) = (uint32_t)(v_); } while (0)
 #if defined(PTX_REPLAY_EXP) && (PTX_REPLAY_EXP & 1) /* timing experiment only (wrong results possible): what the waits for the wave's outstanding stores cost */
 #define PTX_G_FENCE() do { } while (0)
@@ -256,10 +261,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
 #define PTX_G_FENCE() do { if (kGWin) ptx_global_stores_done(); } while (0)
 #endif
     /* the next PTX_RCHUNK rows, resolved in parallel (element lookups, boundary slots) before they are replayed in order */
-    uint64_t* c_id = ptx_alloc<uint64_t>(bp, PTX_RCHUNK);
-    uint32_t* c_pay = ptx_alloc<uint32_t>(bp, PTX_RCHUNK);
-    uint16_t* c_a = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* insert / delete: final rank; mark: start slot */
-    uint16_t* c_b = ptx_alloc<uint16_t>(bp, PTX_RCHUNK);   /* mark: end slot */
+    PtxChunkRow* c_row = ptx_alloc<PtxChunkRow>(bp, PTX_RCHUNK);
     uint8_t* c_kind = ptx_alloc<uint8_t>(bp, PTX_RCHUNK);  /* PTX_RK_* | mark type << 4 | addMark << 6 */
     uint16_t* ca = ptx_alloc<uint16_t>(bp, Kc + 1);       /* comment op: first covered slot */
     uint16_t* cb = ptx_alloc<uint16_t>(bp, Kc + 1);       /*             first slot not covered (PTX_SLOT_NONE = to the end) */
@@ -390,10 +392,12 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             kind = PTX_RK_MARK | ((uint32_t)mark_type[tt] << 4) | (a_ == PTX_ACT_ADDMARK ? 64u : 0u);
         }
         c_kind[i] = (uint8_t)kind;
-        c_a[i] = (uint16_t)va;
-        c_b[i] = (uint16_t)vb;
-        c_pay[i] = payload[tt];
-        c_id[i] = op_id[tt];
+        PtxChunkRow cr;
+        cr.id = op_id[tt];
+        cr.pay = payload[tt];
+        cr.a = (uint16_t)va;
+        cr.b = (uint16_t)vb;
+        c_row[i] = cr;
     }
     PTX_SYNC_T();
 #pragma nounroll
@@ -409,7 +413,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             PTX_LEADER { ptx_patch_put(dst, open, npatch, t, PTX_PATCH_MAKELIST, 0u, 0u); }
             npatch += 1u;
         } else if (kind == PTX_RK_INSERT) {
-            const uint32_t r = PTX_U32(c_a[ci]);
+            const uint32_t r = PTX_U32(c_row[ci].a);
             const uint32_t l1 = (PTX_REPLAY_EXP & 32) ? 0u : PTX_U32(ptx_last_set_below(defined, 2u * r)); /* slot + 1 */
             const uint32_t p0 = npatch;
             uint32_t attr = 0;
@@ -458,7 +462,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             nvis += 1u;
             PTX_SYNC_T();
         } else if (kind == PTX_RK_DELETE) {
-            const uint32_t r = PTX_U32(c_a[ci]);
+            const uint32_t r = PTX_U32(c_row[ci].a);
             const bool was = (PTX_U32(present[r >> 5].bits) >> (r & 31)) & 1u;
             if (was) {
                     PTX_LEADER { ptx_patch_put(dst, open, npatch, t, PTX_PATCH_DELETE, ptx_bitrank(present, r), 1u); }
@@ -474,7 +478,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         } else if (kind == PTX_RK_MARK) {
             const uint32_t ty = (kindb >> 4) & 3u;
             const bool add = (kindb & 64u) != 0u;
-            uint32_t slot_a = PTX_U32(c_a[ci]), slot_b = PTX_U32(c_b[ci]);
+            const PtxChunkRow cr = c_row[ci];
+            uint32_t slot_a = PTX_U32(cr.a), slot_b = PTX_U32(cr.b);
             if (slot_a != PTX_SLOT_NONE && slot_b == slot_a) slot_b = PTX_SLOT_NONE; /* the start test fires first (A.6-3) */
             if (slot_a == PTX_SLOT_NONE || slot_b < slot_a) {
                 /* the end is met while the op has not started: its slot becomes a defined one (a copy of the state to
@@ -487,8 +492,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             /* the words of [slot_a, lim) */
             const uint32_t lim = slot_b != PTX_SLOT_NONE ? slot_b : 2u * n;
             const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5, nw = whi > wlo && lim > slot_a && !(PTX_REPLAY_EXP & 128) ? whi - wlo : 0u;
-            const uint32_t my_id = PTX_U32(c_pay[ci]);
-            const uint64_t my_op = ((uint64_t)PTX_U32((uint32_t)(c_id[ci] >> 32)) << 32) | PTX_U32((uint32_t)c_id[ci]);
+            const uint32_t my_id = PTX_U32(cr.pay);
+            const uint64_t my_op = ((uint64_t)PTX_U32((uint32_t)(cr.id >> 32)) << 32) | PTX_U32((uint32_t)cr.id);
             /* the defined slots of the range in word w_ */
 #define PTX_RANGE_MASK(w_) (ptx_span_mask_in(slot_a, lim, (w_))) /* wlo <= w_ < whi */
             /* first defined slot of the range in the words after w_, else the end of the range */
@@ -537,9 +542,9 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     PTX_G_FENCE();
                     PTX_SYNC_T();
                     PTX_FOR(e, ntab[li]) {
-                        const uint32_t row = PTX_G_LD16(&trow[toff[li] + e]);
-                        if (op_id[row] > my_op) {
-                            const uint32_t ya = PTX_G_LD16(&ta[toff[li] + e]), yl = PTX_G_LD16(&tl[toff[li] + e]);
+                        const uint64_t ent = PTX_G_LD64(&tab[toff[li] + e]);
+                        if (op_id[(uint32_t)ent & 0xFFFFu] > my_op) {
+                            const uint32_t ya = (uint32_t)(ent >> 16) & 0xFFFFu, yl = (uint32_t)(ent >> 32);
                             const uint32_t v0 = (ya >> 5) > wlo ? ya >> 5 : wlo, v1 = ((yl + 31u) >> 5) < whi ? (yl + 31u) >> 5 : whi;
                             for (uint32_t v = v0; v < v1; ++v) ptx_atomic_or(&cw[v - wlo], ptx_span_mask(ya, yl, v));
                         }
@@ -583,12 +588,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     }
                 }
                 /* the op joins the table of its type */
-                PTX_LEADER {
-                    const uint32_t e = toff[li] + ntab[li];
-                    PTX_G_ST16(&trow[e], t);
-                    PTX_G_ST16(&ta[e], slot_a);
-                    PTX_G_ST16(&tl[e], lim);
-                }
+                PTX_LEADER { PTX_G_ST64(&tab[toff[li] + ntab[li]], (uint64_t)t | ((uint64_t)slot_a << 16) | ((uint64_t)lim << 32)); }
                 ntab[li] += 1u;
                 if (fast) maxop[li] = my_op;
             } else {
@@ -662,6 +662,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
 #undef PTX_G_LD16
 #undef PTX_G_ST16
 #undef PTX_G_LD32
+#undef PTX_G_LD64
+#undef PTX_G_ST64
 #undef PTX_G_ST32
 #undef PTX_G_FENCE
     PTX_LEADER {

@@ -55,6 +55,8 @@ PTX_DEV uint16_t ptx_coherent_load16(const uint16_t* p) { return *p; }
 PTX_DEV void ptx_coherent_store16(uint16_t* p, uint16_t v) { *p = v; }
 PTX_DEV uint32_t ptx_coherent_load32(const uint32_t* p) { return *p; }
 PTX_DEV void ptx_coherent_store32(uint32_t* p, uint32_t v) { *p = v; }
+PTX_DEV uint64_t ptx_coherent_load64(const uint64_t* p) { return *p; }
+PTX_DEV void ptx_coherent_store64(uint64_t* p, uint64_t v) { *p = v; }
 #define PTX_U32(x) ((uint32_t)(x))
 PTX_DEV uint32_t ptx_brev(uint32_t x) {
     uint32_t r = 0;
