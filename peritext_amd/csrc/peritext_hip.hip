@@ -477,8 +477,9 @@ static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t ma
     if (ctx->force_lds) lds = (uint64_t)ctx->force_lds;
     b->lds_bytes = (uint32_t)lds;
     /* threads per log, measured on MI355X (profiles/): fewer waves per log = fewer per-wave fixed costs, more logs per CU;
-     * 256-op logs peak at 64 threads, 1K at 128, 4K at 192 (3 waves x 7 logs per CU: 60.3 vs 58.7 G ops/s at 256), 8K at 512 */
-    uint32_t t = max_log_ops <= 512 ? 64u : max_log_ops <= 2048 ? 128u : max_log_ops <= 4608 ? 192u : max_log_ops <= 6144 ? 256u : 512u;
+     * 256-op logs peak at 64 threads, 1K and 2K at 128, 4K at 192, 6K and 8K at 256 (round 4, profiles/r04_i_*: config #5's 8 192-op logs, four per CU by
+     * their LDS, run 8 % faster as four waves each than as eight — 74.2 against 68.4 G ops/s; five waves are always the worst choice) */
+    uint32_t t = max_log_ops <= 512 ? 64u : max_log_ops <= 2048 ? 128u : max_log_ops <= 4608 ? 192u : max_log_ops <= 12288 ? 256u : 512u;
     if (ctx->force_threads) t = (uint32_t)ctx->force_threads;
     b->threads = t;
 }
