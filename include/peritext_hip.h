@@ -260,7 +260,8 @@ typedef struct ptx_dresult ptx_dresult;  /* result buffers resident in HBM */
 /* ptx_create flags */
 #define PTX_FLAG_NO_ELEM_RANK 1u /* do not produce ptx_result.elem_rank (saves 4 B/op of HBM writes) */
 #define PTX_FLAG_NO_ADMISSION 2u /* ignore the Change envelope (chg_*) even when the batch carries it: no seq / deps checks */
-#define PTX_FLAG_REPLAY_LDS_ONLY 8u /* ptx_replay_patches keeps its whole working set in LDS even where the per-slot winner arrays exceeds 5.5 KB of working set per log (tuning / A-B) */
+#define PTX_FLAG_REPLAY_LDS_ONLY 8u /* ptx_replay_patches keeps its whole working set in LDS even where it exceeds 5.5 KB per log (by default the per-slot link urls and the
+                                      tables of applied ops then live in global memory: four times the logs per CU); tuning / A-B */
 #define PTX_FLAG_PAD_GATHER 4u   /* ptx_allgather_digests always takes its padded path (pack, all-gather of max(counts) pairs per rank, compact on the
                                     device) even when every rank holds the same number of logs: same result; lets a one-GPU host exercise that path */
 

@@ -74,19 +74,19 @@ extern "C" __global__ void __launch_bounds__(PTX_BIG_THREADS) ptx_merge_big_kern
 
 /* Patch-stream replay (replay_core.h): one 64-thread workgroup (one wave) per log, sequential in application order */
 #ifndef PTX_REPLAY_GWIN_ABOVE
-#define PTX_REPLAY_GWIN_ABOVE 5632u /* LDS bytes per log beyond which the replay's winner arrays and the tail of its slot list move to global memory (below it the wave slots of a CU — 24 at this kernel's 106 SGPRs, see PTX_SGPRS_W7 —, not its LDS, bound the resident logs) */
+#define PTX_REPLAY_GWIN_ABOVE 5632u /* LDS bytes per log beyond which the replay's per-slot link urls, its tables of applied mark ops and the comment ops' id tables move to global memory (below it the wave slots of a CU — 24 at this kernel's 106 SGPRs, see PTX_SGPRS_W7 —, not its LDS, bound the resident logs) */
 #endif
 #ifndef PTX_REPLAY_THREADS
 #define PTX_REPLAY_THREADS 64
 #endif
-/* (held to 90 SGPRs for 28 instead of 24 wave slots per CU — see PTX_SGPRS_W7 — the replay is SLOWER: 0.98 against 1.05 G ops/s on 4 096-op logs, its spills sit
- * on the sequential chain) */
+/* (round 3's kernel held to 90 SGPRs for 28 instead of 24 wave slots per CU — see PTX_SGPRS_W7 — was SLOWER, its spills sit on the sequential chain; round 4's
+ * 6.2 KB of LDS per 4K-op log allow 24 logs per CU, exactly what its 106 SGPRs do) */
 static_assert(PTX_REPLAY_THREADS == 64, "replay_core.h is written for ONE wave per log: wave-wide searches, register counters, a one-wave scan without LDS scratch");
 extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kernel(PtxReplayArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS, false>(A, blockIdx.x, ptx_lds);
 }
-/* the same with the per-slot winner arrays in global memory (A.win_scratch): 15 of a 4K-op log's 28 KB of LDS, i.e. twelve logs per CU instead of five */
+/* the same with the per-slot link urls, the op tables and the comment ops' id tables in global memory (A.win_scratch): 20 of a 4K-op log's 26 KB of LDS, i.e. 24 logs per CU instead of six */
 extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kernel_gwin(PtxReplayArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS, true>(A, blockIdx.x, ptx_lds);

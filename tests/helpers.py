@@ -217,7 +217,7 @@ def emu_exact_walks(lib_path=EMU_LIB):
 
 
 def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=None, gwin=False, first_row=None):
-    """Patch streams from the host emulation of replay_core.h (tests only): wire.Patches.  gwin: the form with the per-slot winner arrays in global memory;
+    """Patch streams from the host emulation of replay_core.h (tests only): wire.Patches.  gwin: the form with the per-slot link urls, the op tables and the comment ops' id tables in global memory;
     first_row[l]: only the records of the rows from there on (ptx_replay_patches_from)."""
     reverse |= 256 if gwin else 0
     n_logs = b.n_logs

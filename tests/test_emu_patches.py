@@ -122,7 +122,7 @@ def test_live_oracle_patch_streams_and_accumulate(config, docs, ops):
     res = H.emu_merge(batch, lds_bytes=160 * 1024)
     pat = H.emu_replay(batch, res)
     _check_streams(batch, pat, expected)
-    pat_g = H.emu_replay(batch, res, gwin=True)  # winner arrays + the tail of the slot list in global memory: the same records
+    pat_g = H.emu_replay(batch, res, gwin=True)  # per-slot urls, op tables and comment id tables in global memory: the same records
     assert np.array_equal(pat_g.patch_off, pat.patch_off) and np.array_equal(pat_g.patches, pat.patches) and np.array_equal(pat_g.logs, pat.logs)
     for log in range(batch.n_logs):
         got = accumulate(wire.decode_patches(batch, pat, log, with_rows=True))

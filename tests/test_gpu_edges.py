@@ -350,8 +350,8 @@ def _canonical_patches(pat):
 
 
 def test_replay_with_global_winner_arrays_equals_the_lds_only_form():
-    """Logs whose replay working set exceeds 5.5 KB replay with the per-slot winner arrays (and the tail of the slot list) in global memory:
-    same records as the all-LDS form (PTX_FLAG_REPLAY_LDS_ONLY) on 2 048-op config-4 logs, whose slot lists run past the LDS-resident part."""
+    """Logs whose replay working set exceeds 5.5 KB replay with the per-slot link urls, the op tables and the comment ops' id tables in global memory:
+    same records as the all-LDS form (PTX_FLAG_REPLAY_LDS_ONLY) on 2 048-op config-4 logs."""
     from peritext_amd import workloads
     from peritext_amd.engine import Engine
 
