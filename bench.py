@@ -219,7 +219,7 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=5.0, help="extra leg: back-to-back steps for at least this many seconds (clocks / thermals)")
     ap.add_argument("--host-sync-step", action="store_true", help="the round-1 step: engine on its own stream, a host-side sync between merge and digest check")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (patch-stream replay rate, experimental builds / launch shapes on the same workload)")
-    ap.add_argument("--list-cap", type=int, default=2048, help="list elements per replica the generator holds on chip")
+    ap.add_argument("--list-cap", type=int, default=1536, help="list elements per replica the generator holds on chip (the longest list of the 65 536 documents of this seed has 1 334: profiles/r04_j_*; the LDS per document decides how many are generated side by side)")
     args = ap.parse_args()
 
     import torch
