@@ -175,6 +175,7 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     };
     uint32_t* part = (uint32_t*)take(4ull * (TT + 2));
     uint32_t C = 0, na = 0;
+    bool narrow_long = false;
     uint32_t *first = nullptr, *tbl = nullptr, *crow = nullptr;
     const uint32_t* c_hdr = nullptr;
     const uint16_t *c_env = nullptr, *c_env_hi = nullptr;
@@ -191,9 +192,10 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         c_hdr = A.chg_hdr + c0;
         c_env = A.chg_env + c0 * estride;
         c_env_hi = A.chg_env_hi ? A.chg_env_hi + c0 * estride : nullptr;
-        /* seq / deps beyond 16 bits need the wide column; without it a log of more than 65533 changes cannot be represented (its values
-         * saturate at 65535): a capacity report, never a spurious sequence gap */
-        if (C > 65533u && !c_env_hi) return PTX_ERR_CAPACITY;
+        /* seq / deps beyond 16 bits need the wide column; without it the values of a long log saturate at 65535.  A log of more than 65533 changes whose
+         * narrow values all stay below that sentinel (several actors, each with fewer than 65535 changes) is exact as it stands and is admitted; one that
+         * holds a saturated value cannot be represented: a capacity report, never a spurious sequence gap (checked below, once the header words are free) */
+        narrow_long = C > 65533u && !c_env_hi;
         first = (uint32_t*)take(4ull * (na + 2));
         tbl = (uint32_t*)take(4ull * (C + 1));
         crow = (uint32_t*)take(4ull * (C + 1));
@@ -228,6 +230,17 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     if (over) return PTX_ERR_CAPACITY;
     ix.ib = ib;
 
+    if (narrow_long) { /* (uniform) a long log without the wide column: exact iff no seq / dep sits at the 16-bit sentinel */
+        uint32_t sat = 0;
+        PTX_FOR(c, C) {
+            for (uint32_t b = 0; b <= na; ++b) sat |= c_env[(uint64_t)c * estride + b] == 0xFFFFu ? 1u : 0u;
+        }
+        if (sat) ptx_atomic_or(&H->cur[6], 1u);
+        PTX_SYNC();
+        const bool saturated = H->cur[6] != 0u;
+        PTX_SYNC();
+        if (saturated) return PTX_ERR_CAPACITY;
+    }
     /* ---- P0: causal admission (micromerge.ts:499-511): the (actor, seq) -> change table of merge_core.h's many-actor path, 32-bit ---- */
     if (A.chg_off) {
         PTX_FOR(a, na + 2) first[a] = 0;

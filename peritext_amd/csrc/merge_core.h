@@ -58,7 +58,9 @@
 #define PTX_UA 1 /* changes per thread in flight in the (rare) many-actor admission passes */
 #define PTX_INA(i0, u) PTX_IN(i0, u)
 #define PTX_IXA(i0, u) PTX_IX(i0, u)
-#define PTX_AC 4u /* consecutive changes per lane and step in the admission pass (one 16-byte load of headers, two of envelope rows) */
+#ifndef PTX_AC
+#define PTX_AC 4u /* consecutive changes per lane and step in the admission pass (16-byte loads: one of headers and two of envelope rows per four changes) */
+#endif
 #ifndef PTX_UM
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
 #endif
@@ -67,6 +69,9 @@
 #endif
 #define PTX_NCLK 32 /* phase stamps of the diagnostic build (slot PTX_CLK_EXACT_WALKS counts the logs whose admission was walked twice) */
 #define PTX_CLK_EXACT_WALKS 15
+#ifndef PTX_KO_P5A_RA
+#define PTX_KO_P5A_RA 0 /* knock-out (WRONG results, timing experiments only): the mark ops do not read ref_a a second time */
+#endif
 #ifndef PTX_UV
 #define PTX_UV 8 /* items per thread and step in the loops that are chains of dependent LDS reads per item (tree order, list ranking, unpark): the chains of a step run side by side */
 #endif
@@ -199,6 +204,7 @@ PTX_DEV bool ptx_bittest(const uint32_t* bits, uint32_t pos) { return (bits[pos 
 /* pre = exclusive popcount prefix over m bit words, by ONE wave (64 words per step: a DPP prefix sum, no barrier inside); every thread calls it, it ends
  * with the barrier that publishes the words and returns the total.  tmp: one LDS word of the CALL SITE's own (a thread that is slow to read the total must
  * not find the next prefix's there; H->scan_tmp[16 ..], the block-wide scan uses the words below) */
+template <uint32_t kThreads>
 PTX_DEV uint32_t ptx_bitwords_prefix(PtxBitWord* b, uint32_t m, uint32_t* tmp) {
     PTX_ONE_WAVE {
         uint32_t run = 0;
@@ -216,7 +222,7 @@ PTX_DEV uint32_t ptx_bitwords_prefix(PtxBitWord* b, uint32_t m, uint32_t* tmp) {
     return *tmp;
 }
 /* the same for a plain array of counts: in place, exclusive; returns the total */
-template <class T>
+template <uint32_t kThreads, class T>
 PTX_DEV uint32_t ptx_counts_prefix(T* a, uint32_t m, uint32_t* tmp) {
     PTX_ONE_WAVE {
         uint32_t run = 0;
@@ -602,7 +608,7 @@ PTX_DEV bool ptx_mark_of(const PtxMarkBlocks& M, uint32_t b, uint32_t t, uint32_
 /* ================================================================================================ */
 /* Applies log `log`; returns its status (PTX_OK or a per-log PTX_ERR_*) and the LDS high-water mark.  The caller
  * writes the result row (ptx_write_result) — ONE copy of that code instead of one per early exit. */
-template <bool kManyActors, uint32_t kThreads, bool kDiag>
+template <bool kManyActors, uint32_t kThreads, bool kDiag, bool kLean>
 PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t* lds, uint32_t& lds_high) {
     const uint64_t base = A.log_off[log];
     const uint64_t N64 = A.log_off[log + 1] - base;
@@ -1045,7 +1051,15 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     uint16_t* L = ptx_alloc<uint16_t>(bp, n + 2);
     /* when every id key fits 16 bits (the usual case): key of the insert in slot s, written beside ilist[s] by P1, so that P3a
      * needs no second look at the op_id column (the marks' keys go to the park beside their rows, for P5b) */
-    const bool small_keys = keyspace <= 65536u;
+    /* kLean: the build for batches whose every log has 16-bit id keys and whose caller wants neither elem_rank nor the resolved references (the host checks both:
+     * census + PTX_FLAG_NO_ELEM_RANK) — the code of the wide-key paths and of the two optional outputs is not in it (fewer scalar registers spilled) */
+    const bool small_keys = kLean || keyspace <= 65536u;
+    if (kLean && keyspace > 65536u) { /* (never launched for such a log) */
+        lds_high = bp.high;
+        return PTX_ERR_CAPACITY;
+    }
+    uint32_t* const out_rank = kLean ? nullptr : A.out_rank;
+    uint32_t* const out_refs = kLean ? nullptr : A.out_refs;
     uint16_t* klist = L;
     uint16_t* bigp = ptx_alloc<uint16_t>(bp, n / (PTX_SMALL_BUCKET + 1u) + 2); /* parents with more than PTX_SMALL_BUCKET children */
     /* parents with two or more children (at most half of the elements' parents); once they are sorted the same words hold the bitmap that ranks a huge bucket */
@@ -1095,9 +1109,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_FOR(w, nwe + 1) delbits[w] = 0;
         PTX_FOR(w, (K >> 5) + 1) maddbits[w] = 0;
-        if (A.out_rank) { /* the insert rows are overwritten in P5a, by other threads: these stores must have completed by then (the one full barrier) */
-            PTX_FOR(i, N) A.out_rank[base + i] = 0xFFFFFFFFu;
-            PTX_SYNC();
+        if (out_rank) { /* the insert rows are overwritten in P5a, by other threads: these stores must have completed by then (the one full barrier) */
+            PTX_FOR(i, N) out_rank[base + i] = 0xFFFFFFFFu;
+            PTX_SYNC_FULL();
         }
         /* The insert list's cursor is ABSOLUTE: an index of 16-bit words from the start of the log's LDS window; the cursors of the deletes and of the four
          * mark types are entries of the park (deletes from 0, mark type t from D + moff_t).  A row's slot is one number whatever its class; rows that are
@@ -1189,7 +1203,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         /* the ONE full barrier of the list phase: the park entries were stored by whichever thread met the row and are read by others (P3a: the deletes,
          * P5: the marks), so the stores to HBM must have completed.  A header that understates the rows of a class parks junk: the census check below
          * rejects that log before anything is made of it. */
-        PTX_SYNC();
+        PTX_SYNC_FULL();
         PTX_STAMP(11); /* end of the row loop; census, duplicate check and the prefix scan of the id bitmap follow */
         PTX_P3A_DQ(0u, p3_dq) /* the lists are complete: the deletes of P3a's first step are on their way */
         if (H->cur[7] != 0u) {
@@ -1244,7 +1258,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             /* (which of two equal ids is "the repeat" depends on the race; the status is what is reported) */
         }
         PTX_SYNC_LDS();
-        ptx_bitwords_prefix(ix.ib, nw + 1, &H->scan_tmp[16]);
+        ptx_bitwords_prefix<kThreads>(ix.ib, nw + 1, &H->scan_tmp[16]);
     }
     PTX_BAIL_IF_ERROR();
     PTX_STAMP(2);
@@ -1279,7 +1293,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }                                                                       \
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
         rb_[u] = ref_b[i_[u]];                                              \
-        ra_[u] = ref_a[i_[u]];                                              \
+        ra_[u] = PTX_KO_P5A_RA ? rb_[u] : ref_a[i_[u]];                     \
         sa_[u] = A.side_a[base + i_[u]];                                    \
         sb_[u] = A.side_b[base + i_[u]];                                    \
         if (pl_[u]) pl_[u] = payload[i_[u]];                                \
@@ -1367,7 +1381,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             for (int u = 0; u < PTX_UV; ++u)
                 if (t[u] != 0xFFFFu) {
                     if (rt[u] >= i[u]) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND);
-                    if (A.out_refs && i[u] < N) A.out_refs[base + i[u]] = rt[u];
+                    if (out_refs && i[u] < N) out_refs[base + i[u]] = rt[u];
                 }
         }
         if (D > d_fused) { /* more deletes than inserts + 1: the rest, two trips each (park, then the column) */
@@ -1378,7 +1392,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 if (t < 0 || row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND);
                 else {
                     ptx_atomic_or(&delbits[(uint32_t)t >> 5], 1u << ((uint32_t)t & 31u));
-                    if (A.out_refs) A.out_refs[base + i] = row_of[t];
+                    if (out_refs) out_refs[base + i] = row_of[t];
                 }
             }
         }
@@ -1501,7 +1515,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     ptx_atomic_or(&hb[x >> 5].bits, 1u << (x & 31));
                 }
                 PTX_SYNC_LDS();
-                ptx_bitwords_prefix(hb, nwe + 1, &H->scan_tmp[17]);
+                ptx_bitwords_prefix<kThreads>(hb, nwe + 1, &H->scan_tmp[17]);
                 PTX_FOR(k, t - s) {
                     const uint32_t x = seg[s + k];
                     srt[s + (t - s - 1u - ptx_bitrank(hb, x))] = (uint16_t)x; /* members with a larger index come first */
@@ -1692,7 +1706,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         ptx_atomic_or(&alive[r >> 5].bits, 1u << (r & 31));
     });
     PTX_SYNC_LDS();
-    const uint32_t V = ptx_bitwords_prefix(alive, nwv + 1, &H->scan_tmp[18]);
+    const uint32_t V = ptx_bitwords_prefix<kThreads>(alive, nwv + 1, &H->scan_tmp[18]);
     /* the visible interval [lo, hi) of every mark op (the few later uses of an op's row — the ops that still cover a visible character — read it from the
      * park).  Until the marks are looked at, the space of `hi` and of the comment ids holds the rows of the visible elements (vrow) if they fit */
     uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
@@ -1730,10 +1744,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             });
         }
         /* elem_rank (optional output): document position + tombstone flag of EVERY element, by the row that inserted it */
-        if (A.out_rank) {
+        if (out_rank) {
             PTX_FOR(e, n) {
                 const uint32_t r = rnk[e];
-                A.out_rank[base + row_of[e]] = r | (ptx_bittest(delbits, e) ? PTX_RANK_TOMBSTONE : 0u);
+                out_rank[base + row_of[e]] = r | (ptx_bittest(delbits, e) ? PTX_RANK_TOMBSTONE : 0u);
             }
         }
         if (V >= 48u) ptx_digest_flush_dense(H, h1, h2); /* uniform: most lanes of a wave carry a share */
@@ -1777,7 +1791,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 }
                 mrk_lo[k] = (uint16_t)lo;
                 mrk_hi[k] = (uint16_t)hi;
-                if (A.out_refs) {
+                if (out_refs) {
                     /* both boundary slots, each on its own (the replay needs the end slot even where the op never starts) */
                     uint32_t va = 0xFFFFu, vb = 0xFFFFu;
                     if (js >= 0) va = 2u * rnk[js] + (sa[u] == PTX_SIDE_AFTER ? 1u : 0u);
@@ -1785,7 +1799,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         const int je = ptx_elem_lookup(ix, rb[u]);
                         if (je >= 0 && row_of[je] < i[u]) vb = 2u * rnk[je] + (sb[u] == PTX_SIDE_AFTER ? 1u : 0u);
                     }
-                    A.out_refs[base + i[u]] = va | (vb << 16);
+                    out_refs[base + i[u]] = va | (vb << 16);
                 }
                 if (k >= moff2 && k < moff3) {
                     if (pl[u] >= Kid) ptx_raise(H, i[u], 1, PTX_ERR_BAD_OP); /* beyond the id space the header declares */
@@ -1886,7 +1900,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             if (k >= moff2 && k < moff3 && mrk_lo[k] < mrk_hi[k]) ptx_atomic_add(&ccnt[cid[k - moff2]], 1u);
         }
         PTX_SYNC_LDS();
-        ptx_counts_prefix(ccnt, Kid + 1, &H->scan_tmp[20]); /* ccnt[c] = first entry of id c, ccnt[Kid] = total */
+        ptx_counts_prefix<kThreads>(ccnt, Kid + 1, &H->scan_tmp[20]); /* ccnt[c] = first entry of id c, ccnt[Kid] = total */
         PTX_FOR(j, c_items) {
             const uint32_t k = use_live ? (uint32_t)live[j] : moff2 + j;
             if (k >= moff2 && k < moff3 && mrk_lo[k] < mrk_hi[k]) {
@@ -1905,7 +1919,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             cicnt[c] = c < Kid ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         }
         PTX_SYNC_LDS();
-        const uint32_t I = ptx_counts_prefix(cicnt, Kid + 1, &H->scan_tmp[21]);
+        const uint32_t I = ptx_counts_prefix<kThreads>(cicnt, Kid + 1, &H->scan_tmp[21]);
         PTX_LEADER { H->I = I; }
         /* the interval rows: first into LDS by the per-id sweeps (a lane per id, ragged), then out — rows, break bits and digest — by a dense pass (the
          * digest is ~100 vector instructions per item and wave: it must not sit inside the ragged loop) */
@@ -2074,7 +2088,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 if (is_start) ptx_atomic_or(&st[q >> 5].bits, 1u << (q & 31));
             }
             PTX_SYNC_LDS();
-            const uint32_t S_tile = ptx_bitwords_prefix(st, TV / 32 + 2, &H->scan_tmp[19]);
+            const uint32_t S_tile = ptx_bitwords_prefix<kThreads>(st, TV / 32 + 2, &H->scan_tmp[19]);
             PTX_FOR(q, tv) {
                 const PtxBitWord w = st[q >> 5];
                 if ((w.bits >> (q & 31)) & 1u) {
@@ -2111,10 +2125,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
 /* kManyActors: include the admission path for batches with more than four actors per document (it costs ~35
  * VGPRs, i.e. two waves per SIMD, so it lives in its own build of the kernel) */
-template <bool kManyActors, uint32_t kThreads, bool kDiag = false>
+template <bool kManyActors, uint32_t kThreads, bool kDiag = false, bool kLean = false>
 PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     uint32_t lds_high = 0;
-    const uint32_t status = ptx_merge_log_body<kManyActors, kThreads, kDiag>(A, log, lds, lds_high);
+    const uint32_t status = ptx_merge_log_body<kManyActors, kThreads, kDiag, kLean>(A, log, lds, lds_high);
     PTX_SYNC_LDS();
     ptx_write_result<kDiag>(A, log, (PtxHdr*)lds, status, lds_high);
 }

@@ -48,18 +48,26 @@
 #endif
 #define PTX_SGPRS_W7 __attribute__((amdgpu_num_sgpr(PTX_W7_SGPRS)))
 #define PTX_MERGE_KERNEL(name, T, W, MANY, KT, DIAG) PTX_MERGE_KERNEL_A(name, T, W, MANY, KT, DIAG, )
-#define PTX_MERGE_KERNEL_A(name, T, W, MANY, KT, DIAG, PTX_SGPR_CAP)                                     \
+#define PTX_MERGE_KERNEL_A(name, T, W, MANY, KT, DIAG, PTX_SGPR_CAP) PTX_MERGE_KERNEL_L(name, T, W, MANY, KT, DIAG, false, PTX_SGPR_CAP)
+#define PTX_MERGE_KERNEL_L(name, T, W, MANY, KT, DIAG, LEAN, PTX_SGPR_CAP)                                     \
     extern "C" __global__ void __launch_bounds__(T, W) PTX_SGPR_CAP name(PtxMergeArgs A) { \
         extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];              \
         /* one workgroup per log (grid == n_logs): no grid-stride loop, so that nothing is hoisted \
            out of it and kept in registers for the whole kernel */                    \
-        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT, DIAG>(A, A.log_index ? A.log_index[blockIdx.x] : blockIdx.x, ptx_lds); \
+        if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT, DIAG, LEAN>(A, A.log_index ? A.log_index[blockIdx.x] : blockIdx.x, ptx_lds); \
     }
 PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, PTX_W, false, 0, false)     /* any launch shape (blockDim.x read at run time) */
 PTX_MERGE_KERNEL(ptx_merge_kernel_rest, 1024, 1, false, 0, false) /* the same kernel under another name: the second launch of a split batch (the few logs
                                                                     with a larger LDS window), so that per-kernel statistics of a trace keep the two apart */
 PTX_MERGE_KERNEL_A(ptx_merge_kernel_w7, 1024, PTX_W, false, 0, false, PTX_SGPRS_W7)      /* the same two at 7 waves per SIMD (see above) */
 PTX_MERGE_KERNEL_A(ptx_merge_kernel_rest_w7, 1024, 1, false, 0, false, PTX_SGPRS_W7)
+/* Round 5: the LEAN builds, one per usual launch shape (threads per log known at compile time: the loop strides fold; a one-wave log has no s_barrier at all).
+ * For batches whose every log has 16-bit id keys (census) merged without elem_rank / resolved references (PTX_FLAG_NO_ELEM_RANK): neither the wide-key paths nor
+ * the two optional outputs are in the code — 84 instead of 113 scalar registers spilled at the 96 that 7 waves per SIMD allow.  Measured same box against the
+ * general build (profiles/r05_b_*): config #4 -1.2 %, #3 (two waves per log) -4.2 %, #2 (one wave) -4.9 %. */
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean64, 64, PTX_W, false, 64, false, true, PTX_SGPRS_W7)
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean128, 128, PTX_W, false, 128, false, true, PTX_SGPRS_W7)
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean192, 192, PTX_W, false, 192, false, true, PTX_SGPRS_W7)
 PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false) /* + causal admission for documents with more than three actors */
 PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, PTX_W, false, 0, true)  /* (the admission of the product kernel — with the table path of the many-actor build it needs 105 VGPRs and its phase stamps would be taken at 4 waves per SIMD —) + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
 /* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
@@ -315,6 +323,7 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
         if (need <= max_lds) { /* the launch shape of the LDS kernel is sized by the logs that take it */
             atomicMax(&shape[0], (uint32_t)need);
             atomicMax(&shape[1], (uint32_t)(b1 - b0));
+            atomicMax(&shape[3], (uint32_t)min(ks, (uint64_t)0xFFFFFFFFu)); /* their largest id keyspace: 16-bit keys everywhere allow the lean builds */
         }
     }
 }
@@ -431,6 +440,7 @@ struct ptx_dbatch {
     uint32_t max_log_ops = 0;
     uint32_t lds_bytes = 0;
     uint32_t threads = 0;
+    bool small_keys = false; /* every log the LDS kernel takes has an id keyspace of at most 2^16 (census): the lean builds apply */
     /* split launch: when a few logs need more LDS than the rest, they would cost EVERY log a share of the CU (the
      * dynamic LDS size is per launch): the logs are then merged in two launches, `log_index` = the logs of the main
      * group followed by the rest */
@@ -489,14 +499,14 @@ static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t ma
 static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
     uint32_t *shape = nullptr, *d_need = nullptr;
     uint64_t* d_big = nullptr;
-    uint32_t h[3] = {0, 0, 0};
+    uint32_t h[4] = {0, 0, 0, 0};
     std::vector<uint32_t> need;
     std::vector<uint64_t> big_need;
     if (b->n_logs) {
-        PTX_HIP(ctx, hipMalloc((void**)&shape, 12));
+        PTX_HIP(ctx, hipMalloc((void**)&shape, 16));
         hipError_t e = hipMalloc((void**)&d_need, (size_t)b->n_logs * 4);
         if (e == hipSuccess) e = hipMalloc((void**)&d_big, (size_t)b->n_logs * 8);
-        if (e == hipSuccess) e = hipMemsetAsync(shape, 0, 12, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(shape, 0, 16, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(ptx_census_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->log_off, b->op_id, b->action, b->mark_type, b->payload, b->log_hdr,
                                shape, have_hdr ? 0 : 1, b->chg_off, b->max_actors, d_need, b->n_ops, d_big, (uint32_t)ctx->max_lds, b->chg_env_hi);
@@ -504,7 +514,7 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
         }
         need.resize(b->n_logs);
         big_need.resize(b->n_logs);
-        if (e == hipSuccess) e = hipMemcpyAsync(h, shape, 12, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h, shape, 16, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(need.data(), d_need, (size_t)b->n_logs * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(big_need.data(), d_big, (size_t)b->n_logs * 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -515,6 +525,7 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
         if (h[2]) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off must run from 0 to n_ops without decreasing");
     }
     shape_launch(ctx, b, h[0], h[1]);
+    b->small_keys = h[3] <= 65536u;
     (void)hipFree(b->log_index);
     (void)hipFree(b->big_off);
     (void)hipFree(b->big_scratch);
@@ -579,6 +590,13 @@ static bool wants_w7(const ptx_ctx* ctx, const ptx_dbatch* b, uint32_t lds) {
     return by_lds * waves > 24u;
 }
 
+/* the main launch of a batch through a lean build (see PTX_MERGE_KERNEL_L above)?  0, or its threads per log */
+static uint32_t wants_lean(const ptx_ctx* ctx, const ptx_dbatch* b, bool with_rank, uint32_t lds) {
+    const bool admit = b->chg_off && !(ctx->flags & PTX_FLAG_NO_ADMISSION);
+    if (with_rank || !b->small_keys || ctx->clocks || ctx->stop_after || (admit && b->max_actors > 3) || !wants_w7(ctx, b, lds)) return 0u;
+    return b->threads == 64u || b->threads == 128u || b->threads == 192u ? b->threads : 0u;
+}
+
 static ptx_status check_batch(ptx_ctx* ctx, const ptx_batch* h) {
     if (!h) return fail(ctx, PTX_ERR_INVALID_ARG, "batch is NULL");
     if (h->n_logs && !h->log_off) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off is NULL");
@@ -621,7 +639,10 @@ const char* ptx_batch_kernel_name(const ptx_ctx* ctx, const ptx_dbatch* b) {
     if (!ctx || !b) return "ptx_merge_kernel";
     const bool admit = b->chg_off && !(ctx->flags & PTX_FLAG_NO_ADMISSION);
     if (admit && b->max_actors > 3) return "ptx_merge_kernel_many";
-    return wants_w7(ctx, b, b->log_index ? b->lds_main : b->lds_bytes) ? "ptx_merge_kernel_w7" : "ptx_merge_kernel";
+    const uint32_t lds = b->log_index ? b->lds_main : b->lds_bytes;
+    const uint32_t lean = wants_lean(ctx, b, !(ctx->flags & PTX_FLAG_NO_ELEM_RANK), lds);
+    if (lean) return lean == 64u ? "ptx_merge_kernel_lean64" : lean == 128u ? "ptx_merge_kernel_lean128" : "ptx_merge_kernel_lean192";
+    return wants_w7(ctx, b, lds) ? "ptx_merge_kernel_w7" : "ptx_merge_kernel";
 }
 
 const char* ptx_last_error(const ptx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -653,7 +674,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     ctx->own_stream = ctx->stream;
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_merge_kernel_lean64, (const void*)ptx_merge_kernel_lean128, (const void*)ptx_merge_kernel_lean192, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -1086,7 +1107,11 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
             hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);
         else {
             const bool w7 = wants_w7(ctx, b, lds);
+            const uint32_t lean = part ? 0u : wants_lean(ctx, b, r->rank || r->refs, lds);
             if (part) hipLaunchKernelGGL(w7 ? ptx_merge_kernel_rest_w7 : ptx_merge_kernel_rest, dim3(grid), dim3(b->threads), lds, st, A);
+            else if (lean == 64u) hipLaunchKernelGGL(ptx_merge_kernel_lean64, dim3(grid), dim3(64), lds, st, A);
+            else if (lean == 128u) hipLaunchKernelGGL(ptx_merge_kernel_lean128, dim3(grid), dim3(128), lds, st, A);
+            else if (lean == 192u) hipLaunchKernelGGL(ptx_merge_kernel_lean192, dim3(grid), dim3(192), lds, st, A);
             else hipLaunchKernelGGL(w7 ? ptx_merge_kernel_w7 : ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, st, A);
         }
     }

@@ -13,15 +13,19 @@
 #define PTX_HD __host__ __device__ static inline
 #define PTX_DEV __device__ __forceinline__
 #define PTX_SYNC() __syncthreads()
+/* the full barrier of merge_core.h (global stores of one phase are read by other lanes in the next): a one-wave build waits for its own outstanding accesses only */
+#define PTX_SYNC_FULL() do { if (kThreads == 64u) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); PTX_WSYNC(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } else __syncthreads(); } while (0)
 /* the barrier between two phases that talk through LDS only: the wave's LDS operations are complete (lgkmcnt), its loads from and stores to HBM stay in
  * flight across it.  __syncthreads() also waits for every outstanding global access (vmcnt(0)): the software-pipelined gathers issued ahead of a barrier
  * would be waited for at the barrier, and every output store would stand in the critical path of its phase. */
-#define PTX_SYNC_LDS()                                                      \
+#define PTX_SYNC_LDS_WG()                                                   \
     do {                                                                    \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     \
         __builtin_amdgcn_s_barrier();                                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");     \
     } while (0)
+/* (in a build whose workgroup is known to be ONE wave — kThreads == 64 — the phases are separated by the wave's own program order: no s_barrier at all) */
+#define PTX_SYNC_LDS() do { if (kThreads == 64u) PTX_WSYNC(); else PTX_SYNC_LDS_WG(); } while (0)
 #define PTX_LDS_ALLOCATED(p, used_bytes, total_bytes) ((void)0) /* a hook of the bump allocator (the CPU test-suite's sanitizer build marks the padding) */
 /* P1's list stores: inside the log's LDS window, but — when a header understates the rows of a class — not necessarily inside the list
  * (the log is rejected afterwards); a hook for the CPU test-suite's sanitizer build, which poisons the padding between the arrays */
@@ -34,7 +38,7 @@
         __builtin_amdgcn_wave_barrier();                         \
     } while (0)
 /* the barrier of a phase in a kernel that may run as ONE wave (kThreads == 64 known at compile time) */
-#define PTX_SYNC_T() do { if (kThreads == 64u) PTX_WSYNC(); else PTX_SYNC_LDS(); } while (0)
+#define PTX_SYNC_T() PTX_SYNC_LDS()
 /* threads per workgroup: a compile-time constant in the builds specialised for the usual launch shapes (kThreads != 0:
  * the per-phase loop bounds and strides then fold, which removes a quarter of the scalar instructions), else blockDim.x */
 #define PTX_BLOCKDIM (kThreads ? kThreads : blockDim.x)

@@ -33,7 +33,7 @@ static void ptx_emu_lds_fill(uint8_t* lds, size_t bytes) {
 #include "../../peritext_amd/csrc/rootmap_core.h"
 
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
-                          uint32_t lds_bytes, int reverse, int admission, uint32_t* refs);
+                          uint32_t lds_bytes, int reverse, int admission, uint32_t* refs, int lean = 0);
 
 extern "C" int ptx_emu_merge(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans,
                              ptx_cinterval* cints, uint32_t* rank, uint32_t lds_bytes, int reverse) {
@@ -51,8 +51,14 @@ extern "C" int ptx_emu_merge_refs(const ptx_batch* b, ptx_log_result* res, uint3
     return emu_merge_impl(b, res, values, spans, cints, rank, lds_bytes, reverse, admission, refs);
 }
 
+/* the LEAN build of the body (16-bit id keys, no elem_rank / resolved references: what ptx_merge_kernel_lean* are made of) for every log that qualifies */
+extern "C" int ptx_emu_merge_lean(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t lds_bytes, int reverse,
+                                  int admission) {
+    return emu_merge_impl(b, res, values, spans, cints, nullptr, lds_bytes, reverse, admission, nullptr, 1);
+}
+
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
-                          uint32_t lds_bytes, int reverse, int admission, uint32_t* refs) {
+                          uint32_t lds_bytes, int reverse, int admission, uint32_t* refs, int lean) {
     PtxMergeArgs A;
     A.log_off = b->log_off;
     A.op_id = b->op_id;
@@ -96,7 +102,9 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     ptx_emu_reverse = reverse;
     for (uint32_t l = 0; l < b->n_logs; ++l) {
         ptx_emu_lds_fill(lds, lds_bytes); /* LDS is not zero-initialised on the GPU either */
-        ptx_merge_log<true, 0>(A, l, lds);
+        const uint64_t ks = ((uint64_t)A.log_hdr[l].max_counter + 1) * ((uint64_t)A.log_hdr[l].max_actor + 1);
+        if (lean && !rank && !refs && ks <= 65536u && !(admission && b->max_actors > 3)) ptx_merge_log<false, 0, false, true>(A, l, lds); /* (the host's own rule: wants_lean) */
+        else ptx_merge_log<true, 0>(A, l, lds);
     }
     ptx_emu_lds_fill(lds, 0);
     free(lds);

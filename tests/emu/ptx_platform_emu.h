@@ -10,6 +10,7 @@
 #define PTX_DEV static inline
 #define PTX_SYNC() ((void)0)
 #define PTX_SYNC_LDS() ((void)0)
+#define PTX_SYNC_FULL() ((void)0)
 /* sanitizer build of the emulation (g++ -fsanitize=address): the padding behind every array of the LDS bump allocator is poisoned,
  * so that an off-by-one of the kernel logic is reported instead of landing silently in the next array's slack */
 #if defined(__SANITIZE_ADDRESS__)

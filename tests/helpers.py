@@ -132,9 +132,25 @@ def _emu(path):
     return lib
 
 
-def emu_merge(b, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB, admission=False):
-    """Run the host emulation of the kernel logic (tests only) over a wire.Batch."""
+def emu_merge(b, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB, admission=False, lean=False):
+    """Run the host emulation of the kernel logic (tests only) over a wire.Batch.  lean: the body the ptx_merge_kernel_lean* builds are made of (no elem_rank,
+    no resolved references, 16-bit id keys) for every log that qualifies."""
     n = max(b.n_ops, 1)
+    if lean:
+        res = wire.Results(
+            logs=np.zeros(b.n_logs, dtype=abi.LOG_RESULT_DTYPE),
+            values=np.full(n, 0xDEADBEEF, dtype=np.uint32),
+            spans=np.zeros(n, dtype=abi.SPAN_DTYPE),
+            cintervals=np.zeros(n, dtype=abi.CINTERVAL_DTYPE),
+            elem_rank=None,
+        )
+        s = batch_struct(b)
+        f = _emu(lib_path).ptx_emu_merge_lean
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(abi.ptx_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
+        rc = f(C.byref(s), res.logs.ctypes.data, res.values.ctypes.data, res.spans.ctypes.data, res.cintervals.ctypes.data, lds_bytes, reverse, 1 if admission else 0)
+        assert rc == 0
+        return res
     res = wire.Results(
         logs=np.zeros(b.n_logs, dtype=abi.LOG_RESULT_DTYPE),
         values=np.full(n, 0xDEADBEEF, dtype=np.uint32),

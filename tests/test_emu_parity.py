@@ -44,6 +44,44 @@ def test_golden_ptxgen(name, reverse):
     H.check_generated(_load(name), lambda b: H.emu_merge(b, reverse=reverse))
 
 
+@pytest.mark.parametrize("name", GOLDEN_GEN)
+@pytest.mark.parametrize("reverse", [0, 2])
+def test_lean_body_gives_the_same_documents(name, reverse):
+    """The LEAN build of the body (what ptx_merge_kernel_lean64 / 128 / 192 are made of: 16-bit id keys taken for granted, no elem_rank, no resolved
+    references) against the oracle, with and without causal admission; the logs it does not take (more than three actors under admission) go the general way."""
+    gen = _load(name)
+    H.check_generated(gen, lambda b: H.emu_merge(b, reverse=reverse, lean=True))
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    a, b = H.emu_merge(batch, reverse=reverse, admission=True), H.emu_merge(batch, reverse=reverse, admission=True, lean=True)
+    for f in ("status", "n_visible", "n_spans", "n_cintervals", "digest"):
+        assert (a.logs[f] == b.logs[f]).all(), f
+
+
+def test_lean_body_reports_the_same_errors():
+    """Mutated logs (a dropped change, a reference to an unknown element, a repeated op id): the lean build names the same status and the same row."""
+    gen = _load("ptxgen_config4_600.json")
+    logs = [d["logs"][0] for d in gen["docs"][:4]]
+    import copy
+
+    bad = [copy.deepcopy(x) for x in logs]
+    del bad[0][len(bad[0]) // 2]  # a dropped change: a sequence gap or a missing dependency
+    for ch in bad[1]:
+        for op in ch["ops"]:
+            if op.get("action") == "del":
+                op["elemId"] = "9999@zzz"  # an element nobody inserted
+                break
+        else:
+            continue
+        break
+    bad[2][-1]["ops"][-1]["opId"] = bad[2][-2]["ops"][-1]["opId"] if bad[2][-2]["ops"] else bad[2][-1]["ops"][-1]["opId"]
+    batch = wire.encode_docs([[x] for x in bad])
+    for adm in (False, True):
+        a, b = H.emu_merge(batch, admission=adm), H.emu_merge(batch, admission=adm, lean=True)
+        assert (a.logs["status"] == b.logs["status"]).all() and (a.logs["reserved"] [:, 1] == b.logs["reserved"][:, 1]).all()
+        assert (a.logs["digest"] == b.logs["digest"]).all()
+    assert int(H.emu_merge(batch, admission=True, lean=True).logs["status"][0]) != 0
+
+
 def test_reference_traces():
     traces = _load("reference_traces.json")
     batch = wire.encode_docs([t["logs"] for t in traces])

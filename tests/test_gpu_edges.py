@@ -271,6 +271,64 @@ def test_every_launch_shape(threads, lds):
                         log += 1
 
 
+LEAN_FIXTURES = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json", "ptxgen_config4_600.json", "ptxgen_rich_700.json", "ptxgen_rich_2600.json"]
+
+
+@pytest.mark.parametrize("threads", [64, 128, 192])
+def test_lean_builds_of_the_merge_kernel(threads):
+    """Round 5: ptx_merge_kernel_lean64 / 128 / 192 — the builds for batches of 16-bit id keys merged without elem_rank (PTX_FLAG_NO_ELEM_RANK; the
+    workgroup size a compile-time constant, a one-wave log without s_barrier).  The library must CHOOSE them for such batches (the kernel's name is
+    asserted) and they must reproduce the reference-made fixtures bit for bit, with and without causal admission; a batch with wide id keys, or a
+    context that wants elem_rank, keeps the general build."""
+    from peritext_amd.engine import Engine
+
+    for flags in (abi.FLAG_NO_ELEM_RANK, abi.FLAG_NO_ELEM_RANK | abi.FLAG_NO_ADMISSION):
+        with Engine(0, flags=flags) as e:
+            e.set_launch_shape(threads, 0)
+            seen = set()
+            for name in LEAN_FIXTURES:
+                g = _load(name)
+                batch = wire.encode_docs([d["logs"] for d in g["docs"]])
+                db = e.upload(batch)
+                dr = e.alloc_result(db)
+                try:
+                    # (the lean builds are held to 96 scalar registers like ptx_merge_kernel_w7: chosen where the LDS window lets more than 24 waves share a CU)
+                    t, l = e.launch_shape(db)
+                    waves_per_cu = (160 * 1024 // (-(-l // 1280) * 1280)) * (t // 64)
+                    want = "ptx_merge_kernel_lean%d" % threads if waves_per_cu > 24 else "ptx_merge_kernel"
+                    assert e.batch_kernel_name(db) == want, name
+                    seen.add(want)
+                    e.merge(db, dr)
+                    res = e.download(db, dr)
+                finally:
+                    e.free_result(dr)
+                    e.free_batch(db)
+                log = 0
+                for d in g["docs"]:
+                    for exp in d["expected"]:
+                        H.check_log(batch, res, log, exp)
+                        log += 1
+            assert "ptx_merge_kernel_lean%d" % threads in seen
+            # wide id keys (counters moved up by 70 000): not a lean batch, same documents
+            gen = _load("ptxgen_mini.json")
+            docs = [d["logs"] for d in gen["docs"][:4]]
+            base, wide = wire.encode_docs(docs), wire.encode_docs(H.shift_counters(docs, 70000))
+            db = e.upload(wide)
+            try:
+                assert "lean" not in e.batch_kernel_name(db)
+            finally:
+                e.free_batch(db)
+            r0, r1 = e.apply_materialize(base), e.apply_materialize(wide)
+            assert (r0.logs["status"] == 0).all() and (r0.logs["digest"] == r1.logs["digest"]).all()
+    with Engine(0) as e:  # elem_rank wanted: the general build
+        e.set_launch_shape(threads, 0)
+        db = e.upload(wire.encode_docs([d["logs"] for d in _load("ptxgen_config4_600.json")["docs"]]))
+        try:
+            assert "lean" not in e.batch_kernel_name(db)
+        finally:
+            e.free_batch(db)
+
+
 def test_default_shapes_cover_256_and_512_threads(eng):
     """What the library picks on its own: 192 threads up to 4 608 ops, 256 up to 12 288 (config #5's 8 192-op logs run 8 % faster as four waves than as eight,
     profiles/r04_i_*), 512 beyond."""
