@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 6u
+#define PTX_ABI_VERSION 7u
 
 /* Operation.action (micromerge.ts:150-212, peritext.ts:25-65) */
 enum {
@@ -199,21 +199,30 @@ typedef struct ptx_log_result {
     uint64_t digest[2];
 } ptx_log_result;
 
-/* Host-side view of a result set (returned by ptx_result_download / ptx_apply_materialize).
- * Row r of log l lives at index log_off[l] + r.  Owned by the library until ptx_result_free. */
+/* Host-side view of a result set (returned by ptx_result_download[_range] / ptx_apply_materialize).  ABI 7: the rows are COMPACT — only the rows that
+ * exist come down (a 4 096-op fuzz log shows a few dozen characters; round 4 downloaded one row per op: 2.4 GB for 100 M ops whose output is ~1 MB) —
+ * gathered on the device into dense arrays and copied into pinned host memory:
+ *     values[value_off[l] .. value_off[l + 1])          the n_visible value ids of log l, in document order
+ *     spans[span_off[l] .. span_off[l + 1])             its n_spans span rows
+ *     cintervals[cint_off[l] .. cint_off[l + 1])        its n_cintervals comment-interval rows
+ * (a failed log has none).  elem_rank, where the context produces it, keeps one entry per op ROW of the downloaded logs (row r of log l at
+ * log_off[l] - log_off[first log] + r).  Owned by the library until ptx_result_free. */
 typedef struct ptx_result {
     uint32_t n_logs;
     uint32_t reserved;
-    uint64_t n_rows;                  /* == batch n_ops (row capacity of the three arrays) */
+    uint64_t n_rows;                  /* op rows of the downloaded logs (entries of elem_rank) */
     const ptx_log_result* logs;       /* [n_logs] */
-    const uint32_t* values;           /* [n_rows] */
-    const ptx_span* spans;            /* [n_rows] */
-    const ptx_cinterval* cintervals;  /* [n_rows] */
-    const uint32_t* elem_rank;        /* [n_rows] per op row: document position (incl. tombstones) of the
+    const uint32_t* values;           /* [value_off[n_logs]] */
+    const ptx_span* spans;            /* [span_off[n_logs]] */
+    const ptx_cinterval* cintervals;  /* [cint_off[n_logs]] */
+    const uint32_t* elem_rank;        /* [n_rows] or NULL (PTX_FLAG_NO_ELEM_RANK).  Per op row: document position (incl. tombstones) of the
                                          element an INSERT row created (what findListElement(...).index
                                          would return, micromerge.ts:731), | PTX_RANK_TOMBSTONE when the
                                          element is deleted; 0xffffffff for other rows.  Enough to resolve
                                          cursors (getCursor / resolveCursor, micromerge.ts:465-477) on the host */
+    const uint64_t* value_off;        /* [n_logs + 1] exclusive prefix sum of logs[].n_visible */
+    const uint64_t* span_off;         /* [n_logs + 1] ... of logs[].n_spans */
+    const uint64_t* cint_off;         /* [n_logs + 1] ... of logs[].n_cintervals */
     void* owner;
 } ptx_result;
 

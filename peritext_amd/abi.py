@@ -7,7 +7,7 @@ the shared object is missing, and `ptx_create` fails when no gfx950 device is vi
 import ctypes as C
 import os
 
-PTX_ABI_VERSION = 6
+PTX_ABI_VERSION = 7
 
 # Operation.action (reference/src/micromerge.ts:150-212, src/peritext.ts:25-65)
 ACT_MAKELIST, ACT_INSERT, ACT_DELETE, ACT_ADDMARK, ACT_REMOVEMARK, ACT_NOP, ACT_MAPSET, ACT_MAPDEL = range(8)
@@ -147,6 +147,9 @@ class ptx_result(C.Structure):
         ("spans", C.POINTER(ptx_span)),
         ("cintervals", C.POINTER(ptx_cinterval)),
         ("elem_rank", u32p),
+        ("value_off", C.POINTER(C.c_uint64)),  # ABI 7: the rows are compact, log l's at [off[l], off[l + 1])
+        ("span_off", C.POINTER(C.c_uint64)),
+        ("cint_off", C.POINTER(C.c_uint64)),
         ("owner", C.c_void_p),
     ]
 

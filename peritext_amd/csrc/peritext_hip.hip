@@ -387,6 +387,65 @@ __global__ void ptx_pack_digests_kernel(const ptx_log_result* res, uint32_t firs
     }
 }
 
+/* ---- compact result rows (ABI 7): the merge writes a log's rows at the log's own row offset (capacity = one row per op: no allocation on the device); a
+ *      host wants the rows that EXIST — a few dozen per 4K-op log.  (1) offsets: exclusive prefix sums of n_visible / n_spans / n_cintervals over the logs of the
+ *      range, by ONE workgroup (a chunk of 1 024 logs per step; a failed log's counts are 0); (2) gather: a wave per log copies its rows to the dense arrays. ---- */
+__global__ void __launch_bounds__(1024) ptx_result_offsets_kernel(const ptx_log_result* logs, uint32_t first, uint32_t n_logs, uint64_t* off /* [3][n_logs + 1] */) {
+    __shared__ uint64_t wsum[3][16];
+    __shared__ uint64_t run[3];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 3) run[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n_logs; c0 += 1024u) {
+        const uint32_t l = c0 + threadIdx.x;
+        uint64_t v[3] = {0, 0, 0};
+        if (l < n_logs) {
+            const ptx_log_result r = logs[first + l];
+            v[0] = r.n_visible;
+            v[1] = r.n_spans;
+            v[2] = r.n_cintervals;
+        }
+        uint64_t incl[3];
+        for (int k = 0; k < 3; ++k) {
+            uint64_t x = v[k];
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint64_t y = __shfl_up(x, d, 64);
+                if ((int)lane >= d) x += y;
+            }
+            incl[k] = x;
+            if (lane == 63u) wsum[k][wave] = x;
+        }
+        __syncthreads();
+        for (int k = 0; k < 3; ++k) {
+            uint64_t base = run[k];
+            for (uint32_t w = 0; w < wave; ++w) base += wsum[k][w];
+            if (l < n_logs) off[(uint64_t)k * (n_logs + 1) + l] = base + incl[k] - v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            uint64_t t = 0;
+            for (uint32_t w = 0; w < 16u; ++w) t += wsum[threadIdx.x][w];
+            run[threadIdx.x] += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) off[(uint64_t)threadIdx.x * (n_logs + 1) + n_logs] = run[threadIdx.x];
+}
+__global__ void __launch_bounds__(64) ptx_result_compact_kernel(const uint64_t* log_off, const ptx_log_result* logs, uint32_t first, uint32_t n_logs, const uint64_t* off,
+                                                                const uint32_t* values, const ptx_span* spans, const ptx_cinterval* cints, uint32_t* dvalues, ptx_span* dspans,
+                                                                ptx_cinterval* dcints) {
+    const uint32_t l = blockIdx.x;
+    if (l >= n_logs) return;
+    const ptx_log_result r = logs[first + l];
+    const uint64_t b = log_off[first + l];
+    const uint64_t ov = off[l], os = off[(uint64_t)(n_logs + 1) + l], oc = off[2ull * (n_logs + 1) + l];
+    for (uint32_t i = threadIdx.x; i < r.n_visible; i += 64u) dvalues[ov + i] = values[b + i];
+    for (uint32_t i = threadIdx.x; i < r.n_spans; i += 64u) dspans[os + i] = spans[b + i];
+    const uint32_t* cs = (const uint32_t*)(cints + b);
+    uint32_t* cd = (uint32_t*)(dcints + oc);
+    for (uint32_t i = threadIdx.x; i < 3u * r.n_cintervals; i += 64u) cd[i] = cs[i];
+}
+
 /* log_off of a tiled batch: copy k of log l starts at k * n_ops + log_off[l] */
 __global__ void ptx_tile_offsets_kernel(const uint64_t* src, uint64_t* dst, uint32_t n_logs, uint32_t copies, uint64_t n_ops) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1399,12 +1458,16 @@ ptx_status ptx_device_read(ptx_ctx* ctx, const void* device, void* host, uint64_
     return PTX_OK;
 }
 
+/* What a ptx_result owns (ABI 7: COMPACT rows).  The arrays a log's few rows go to are pinned host memory (the device writes them by DMA, nothing is
+ * zero-filled, nothing is copied again); elem_rank — one entry per op row, hundreds of MB for a large batch, wanted by few callers — is plain memory. */
 struct ptx_host_result {
-    std::vector<ptx_log_result> logs;
-    std::vector<uint32_t> values;
-    std::vector<ptx_span> spans;
-    std::vector<ptx_cinterval> cints;
-    std::vector<uint32_t> rank;
+    void* pinned[2] = {nullptr, nullptr}; /* [0] logs + the three offset arrays, [1] values + spans + cintervals */
+    uint32_t* rank = nullptr;
+    ~ptx_host_result() {
+        for (void* p : pinned)
+            if (p) (void)hipHostFree(p);
+        free(rank);
+    }
 };
 
 void ptx_result_free(ptx_result* res) {
@@ -1413,6 +1476,7 @@ void ptx_result_free(ptx_result* res) {
     memset(res, 0, sizeof(*res));
 }
 
+#define PTX_SMALL_DOWNLOAD_ROWS 65536ull /* ranges of up to this many op rows (a replica of an editor session): dense arrays sized by the rows, one allocation, one wait */
 ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dresult* r, uint32_t first_log, uint32_t n_logs, ptx_result* out) {
     if (!ctx || !b || !r || !out) return PTX_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
@@ -1428,31 +1492,84 @@ ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const pt
     if (lo[1] < lo[0] || lo[1] > r->n_rows) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off is not monotonic");
     const uint64_t r0 = lo[0], nr = lo[1] - lo[0];
     ptx_host_result* h = new ptx_host_result();
-    h->logs.resize(std::max<uint64_t>(n_logs, 1));
-    h->values.resize(std::max<uint64_t>(nr, 1));
-    h->spans.resize(std::max<uint64_t>(nr, 1));
-    h->cints.resize(std::max<uint64_t>(nr, 1));
-    h->rank.resize(std::max<uint64_t>(nr, 1));
-    hipError_t e = hipSuccess;
-    if (n_logs) e = hipMemcpyAsync(h->logs.data(), r->logs + first_log, (size_t)n_logs * sizeof(ptx_log_result), hipMemcpyDeviceToHost, ctx->stream);
-    if (nr) {
-        if (e == hipSuccess) e = hipMemcpyAsync(h->values.data(), r->values + r0, nr * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->spans.data(), r->spans + r0, nr * sizeof(ptx_span), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->cints.data(), r->cints + r0, nr * sizeof(ptx_cinterval), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && r->rank) e = hipMemcpyAsync(h->rank.data(), r->rank + r0, nr * 4, hipMemcpyDeviceToHost, ctx->stream);
+    const uint64_t no = (uint64_t)n_logs + 1;
+    const bool small = nr <= PTX_SMALL_DOWNLOAD_ROWS;
+    auto a16 = [](uint64_t x) { return (x + 15) & ~15ull; };
+    /* block 0: the per-log result rows and the offsets of the logs in the dense arrays (three exclusive prefix sums of their row counts, made on the device) */
+    const uint64_t logs_bytes = a16((uint64_t)n_logs * sizeof(ptx_log_result)), off_bytes = a16(3 * no * 8);
+    /* block 1: the dense rows.  A small range takes its row capacity as their size (known now: everything goes out in one batch of copies and one wait); a large
+     * one waits for the totals first and allocates exactly those */
+    uint64_t cv = nr, cs = nr, cc = nr;
+    uint8_t *hp0 = nullptr, *hp1 = nullptr, *dblk = nullptr, *dblk1 = nullptr;
+    hipError_t e = hipHostMalloc((void**)&hp0, logs_bytes + off_bytes + (small ? a16(cv * 4) + a16(cs * sizeof(ptx_span)) + a16(cc * sizeof(ptx_cinterval)) : 0) + 16, hipHostMallocDefault);
+    h->pinned[0] = hp0;
+    if (e == hipSuccess) e = hipMalloc((void**)&dblk, off_bytes + (small ? a16(cv * 4) + a16(cs * sizeof(ptx_span)) + a16(cc * sizeof(ptx_cinterval)) : 0) + 16);
+    uint64_t* offs = (uint64_t*)(hp0 + logs_bytes);
+    uint64_t* d_off = (uint64_t*)dblk;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ptx_result_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, r->logs, first_log, n_logs, d_off);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(offs, d_off, 3 * no * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && n_logs) e = hipMemcpyAsync(hp0, r->logs + first_log, (size_t)n_logs * sizeof(ptx_log_result), hipMemcpyDeviceToHost, ctx->stream);
+    uint8_t* dense_h = nullptr;
+    uint8_t* dense_d = nullptr;
+    if (small) {
+        dense_h = hp0 + logs_bytes + off_bytes;
+        dense_d = dblk + off_bytes;
+    } else {
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) {
+            cv = offs[n_logs];
+            cs = offs[no + n_logs];
+            cc = offs[2 * no + n_logs];
+            if (cv > nr || cs > nr || cc > nr) e = hipErrorInvalidValue; /* (a log never produces more rows than it has ops) */
+        }
+        const uint64_t dense_bytes = a16(cv * 4) + a16(cs * sizeof(ptx_span)) + a16(cc * sizeof(ptx_cinterval)) + 16;
+        if (e == hipSuccess) e = hipHostMalloc((void**)&hp1, dense_bytes, hipHostMallocDefault);
+        h->pinned[1] = hp1;
+        if (e == hipSuccess) e = hipMalloc((void**)&dblk1, dense_bytes);
+        dense_h = hp1;
+        dense_d = dblk1;
+    }
+    uint32_t* hv = (uint32_t*)dense_h;
+    ptx_span* hs = (ptx_span*)(dense_h + a16(cv * 4));
+    ptx_cinterval* hc = (ptx_cinterval*)(dense_h + a16(cv * 4) + a16(cs * sizeof(ptx_span)));
+    if (e == hipSuccess && n_logs) {
+        uint32_t* dv = (uint32_t*)dense_d;
+        ptx_span* ds = (ptx_span*)(dense_d + a16(cv * 4));
+        ptx_cinterval* dc = (ptx_cinterval*)(dense_d + a16(cv * 4) + a16(cs * sizeof(ptx_span)));
+        hipLaunchKernelGGL(ptx_result_compact_kernel, dim3(n_logs), dim3(64), 0, ctx->stream, b->log_off, r->logs, first_log, n_logs, d_off, r->values, r->spans, r->cints, dv, ds, dc);
+        e = hipGetLastError();
+        /* (a small range copies its capacity: the totals are not known on the host yet, and a few hundred KB cost less than a second wait) */
+        if (e == hipSuccess && cv) e = hipMemcpyAsync(hv, dv, cv * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && cs) e = hipMemcpyAsync(hs, ds, cs * sizeof(ptx_span), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && cc) e = hipMemcpyAsync(hc, dc, cc * sizeof(ptx_cinterval), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    /* elem_rank (where the context produces it): one entry per op row of the range, as the merge wrote it */
+    if (e == hipSuccess && r->rank) {
+        h->rank = (uint32_t*)malloc(std::max<uint64_t>(nr, 1) * 4);
+        if (!h->rank) e = hipErrorOutOfMemory;
+        else if (nr) e = hipMemcpyAsync(h->rank, r->rank + r0, nr * 4, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    else (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dblk);
+    (void)hipFree(dblk1);
     if (e != hipSuccess) {
         delete h;
-        return fail(ctx, PTX_ERR_HIP, std::string("result download: ") + hipGetErrorString(e));
+        return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("result download: ") + hipGetErrorString(e));
     }
     out->n_logs = n_logs;
     out->n_rows = nr;
-    out->logs = h->logs.data();
-    out->values = h->values.data();
-    out->spans = h->spans.data();
-    out->cintervals = h->cints.data();
-    out->elem_rank = r->rank ? h->rank.data() : nullptr;
+    out->logs = (const ptx_log_result*)hp0;
+    out->value_off = offs;
+    out->span_off = offs + no;
+    out->cint_off = offs + 2 * no;
+    out->values = hv;
+    out->spans = hs;
+    out->cintervals = hc;
+    out->elem_rank = r->rank ? h->rank : nullptr;
     out->owner = h;
     return PTX_OK;
 }

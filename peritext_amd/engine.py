@@ -41,7 +41,7 @@ def _batch_struct(b):
 
 
 def _copy_result(res):
-    """ptx_result (library-owned host memory) -> wire.Results (numpy copies)."""
+    """ptx_result (library-owned host memory, COMPACT rows since ABI 7) -> wire.Results (numpy copies)."""
     nl, nr = int(res.n_logs), int(res.n_rows)
 
     def arr(ptr, dtype, n):
@@ -50,12 +50,16 @@ def _copy_result(res):
         buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(C.addressof(ptr.contents))
         return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
+    voff, soff, coff = (arr(p, np.uint64, nl + 1) if nl else np.zeros(1, dtype=np.uint64) for p in (res.value_off, res.span_off, res.cint_off))
     return wire.Results(
         logs=arr(res.logs, abi.LOG_RESULT_DTYPE, nl),
-        values=arr(res.values, np.uint32, nr),
-        spans=arr(res.spans, abi.SPAN_DTYPE, nr),
-        cintervals=arr(res.cintervals, abi.CINTERVAL_DTYPE, nr),
+        values=arr(res.values, np.uint32, int(voff[nl])),
+        spans=arr(res.spans, abi.SPAN_DTYPE, int(soff[nl])),
+        cintervals=arr(res.cintervals, abi.CINTERVAL_DTYPE, int(coff[nl])),
         elem_rank=arr(res.elem_rank, np.uint32, nr) if res.elem_rank else np.zeros(0, dtype=np.uint32),
+        value_off=voff,
+        span_off=soff,
+        cint_off=coff,
     )
 
 

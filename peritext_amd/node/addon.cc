@@ -10,7 +10,8 @@
  *
  * Exports:  open(libPath) -> abiVersion      create(device, flags) -> ctx (external)      destroy(ctx)
  *           applyMaterialize(ctx, batch) -> {logs:Uint32Array(12/log), values:Uint32Array, spans:Uint32Array(2/row),
- *                                            cintervals:Uint32Array(3/row), elemRank:Uint32Array|null}
+ *                                            cintervals:Uint32Array(3/row), valueOff / spanOff / cintOff: BigUint64Array(nLogs + 1) (the rows are compact: ABI 7),
+ *                                            elemRank:Uint32Array|null}
  *           generate(ctx, cfg)  change(ctx, batch, inputOps) -> {batch, status}  maxOpsPerLog(ctx)  kernelName()
  * Errors of the library surface as JS exceptions (Error with the library's message); per-LOG failures stay in
  * logs[12*l] (status) and are turned into RangeError by index.js, mirroring micromerge.ts:503,:507,:752.
@@ -309,24 +310,41 @@ napi_value batch_to_js(napi_env env, const ptx_batch& b) {
     return batch;
 }
 
+/* the rows of a ptx_result (compact since ABI 7: log l's values at [valueOff[l], valueOff[l + 1]) ...) as typed arrays on `obj` */
+static void result_rows_to_js(napi_env env, const ptx_result& res, napi_value obj) {
+    napi_value v;
+    static_assert(sizeof(ptx_log_result) == 48, "ptx_log_result layout");
+    const size_t nl = (size_t)res.n_logs, n_off = nl + 1;
+    v = make_u32(env, res.logs, nl * 12);
+    if (v) napi_set_named_property(env, obj, "logs", v);
+    v = make_u32(env, res.values, (size_t)res.value_off[nl]);
+    if (v) napi_set_named_property(env, obj, "values", v);
+    v = make_u32(env, res.spans, (size_t)res.span_off[nl] * 2);
+    if (v) napi_set_named_property(env, obj, "spans", v);
+    v = make_u32(env, res.cintervals, (size_t)res.cint_off[nl] * 3);
+    if (v) napi_set_named_property(env, obj, "cintervals", v);
+    const char* names[3] = {"valueOff", "spanOff", "cintOff"};
+    const uint64_t* offs[3] = {res.value_off, res.span_off, res.cint_off};
+    for (int k = 0; k < 3; ++k) {
+        napi_value ab, ta;
+        void* data = nullptr;
+        if (napi_create_arraybuffer(env, n_off * 8, &data, &ab) == napi_ok && napi_create_typedarray(env, napi_biguint64_array, n_off, ab, 0, &ta) == napi_ok) {
+            memcpy(data, offs[k], n_off * 8);
+            napi_set_named_property(env, obj, names[k], ta);
+        }
+    }
+    if (res.elem_rank) {
+        v = make_u32(env, res.elem_rank, (size_t)res.n_rows);
+        if (v) napi_set_named_property(env, obj, "elemRank", v);
+    }
+}
+
 /* ptx_result (+ the patch streams) -> the JS result object; both are freed here */
 napi_value result_to_js(napi_env env, ptx_result& res, ptx_patches* patp) {
     napi_value out;
     NAPI_OK(napi_create_object(env, &out));
     napi_value v;
-    static_assert(sizeof(ptx_log_result) == 48, "ptx_log_result layout");
-    v = make_u32(env, res.logs, (size_t)res.n_logs * 12);
-    if (v) napi_set_named_property(env, out, "logs", v);
-    v = make_u32(env, res.values, (size_t)res.n_rows);
-    if (v) napi_set_named_property(env, out, "values", v);
-    v = make_u32(env, res.spans, (size_t)res.n_rows * 2);
-    if (v) napi_set_named_property(env, out, "spans", v);
-    v = make_u32(env, res.cintervals, (size_t)res.n_rows * 3);
-    if (v) napi_set_named_property(env, out, "cintervals", v);
-    if (res.elem_rank) {
-        v = make_u32(env, res.elem_rank, (size_t)res.n_rows);
-        if (v) napi_set_named_property(env, out, "elemRank", v);
-    }
+    result_rows_to_js(env, res, out);
     L.result_free(&res);
     if (patp) {
         ptx_patches& pat = *patp;
@@ -578,18 +596,7 @@ napi_value Generate(napi_env env, napi_callback_info info) {
     napi_create_double(env, (double)gi.kernel_ms, &v);
     napi_set_named_property(env, out, "kernelMs", v);
     if (have_res) {
-        v = make_u32(env, res.logs, (size_t)res.n_logs * 12);
-        if (v) napi_set_named_property(env, result, "logs", v);
-        v = make_u32(env, res.values, (size_t)res.n_rows);
-        if (v) napi_set_named_property(env, result, "values", v);
-        v = make_u32(env, res.spans, (size_t)res.n_rows * 2);
-        if (v) napi_set_named_property(env, result, "spans", v);
-        v = make_u32(env, res.cintervals, (size_t)res.n_rows * 3);
-        if (v) napi_set_named_property(env, result, "cintervals", v);
-        if (res.elem_rank) {
-            v = make_u32(env, res.elem_rank, (size_t)res.n_rows);
-            if (v) napi_set_named_property(env, result, "elemRank", v);
-        }
+        result_rows_to_js(env, res, result);
         L.result_free(&res);
         napi_set_named_property(env, out, "result", result);
     }

@@ -60,6 +60,8 @@ export interface WireBatch {
 }
 export interface WireResult {
     logs: Uint32Array; values: Uint32Array; spans: Uint32Array; cintervals: Uint32Array; elemRank?: Uint32Array
+    /** ABI 7: the rows are compact — log l's values at values[valueOff[l] .. valueOff[l + 1]), span rows (2 u32 each) from spanOff[l], comment intervals (3 u32 each) from cintOff[l] */
+    valueOff: BigUint64Array; spanOff: BigUint64Array; cintOff: BigUint64Array
     /** with applyMaterialize(batch, true): ptx_patches (patch_off, {status, n_patches} per log, 4 u32 per record) */
     patchOff?: BigUint64Array; patchLogs?: Uint32Array; patches?: Uint32Array
 }

@@ -537,15 +537,23 @@ class Results:
     cintervals: np.ndarray  # CINTERVAL_DTYPE [n_rows]
     elem_rank: np.ndarray  # u32 [n_rows]
     ref_slots: np.ndarray = None  # u32 [n_rows], emulation only: the merge's resolved references of the delete / mark rows (the library keeps them on the device)
+    # ABI 7: the library's rows are COMPACT — log l's values at values[value_off[l] : value_off[l + 1]] etc.; None = the capacity layout (a log's rows at its
+    # own row offset batch.log_off[l]: what the kernels write on the device, and what the test-suite's emulation returns)
+    value_off: np.ndarray = None
+    span_off: np.ndarray = None
+    cint_off: np.ndarray = None
 
 
 def canonical_of_log(batch, res, log):
     """(values u32[], spans [(start, attr)], cintervals [(id, s, e)]) of one log, as plain arrays."""
-    b = int(batch.log_off[log])
     r = res.logs[log]
-    v = res.values[b : b + int(r["n_visible"])]
-    s = res.spans[b : b + int(r["n_spans"])]
-    c = res.cintervals[b : b + int(r["n_cintervals"])]
+    if res.value_off is None:
+        bv = bs = bc = int(batch.log_off[log])
+    else:
+        bv, bs, bc = int(res.value_off[log]), int(res.span_off[log]), int(res.cint_off[log])
+    v = res.values[bv : bv + int(r["n_visible"])]
+    s = res.spans[bs : bs + int(r["n_spans"])]
+    c = res.cintervals[bc : bc + int(r["n_cintervals"])]
     return v, s, c
 
 
@@ -857,7 +865,7 @@ def load_batch(path):
 
     with np.load(path) as z:
         meta = json.loads(bytes(z["meta"]).decode("utf-8"))
-        if meta.get("format") != "peritext-soa-oplog" or meta.get("abi") != abi.PTX_ABI_VERSION:
+        if meta.get("format") != "peritext-soa-oplog" or meta.get("abi") not in (5, 6, abi.PTX_ABI_VERSION):  # (the file format has not changed since ABI 5: v6 added the optional chg_env_hi column, v7 changed ptx_result only)
             raise ValueError("not a peritext SoA op-log file of ABI %d" % abi.PTX_ABI_VERSION)
         cols = {k: (z[k] if k in z.files else None) for k in _COLUMNS}
         hdr = z["log_hdr"] if "log_hdr" in z.files else None

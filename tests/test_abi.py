@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(abi.ptx_log_result) == 48 and abi.LOG_RESULT_DTYPE.itemsize == 48
     assert C.sizeof(abi.ptx_batch) == 8 + 8 + 12 * 8 + 8 + 8 + 8  # + chg_env_hi (ABI 6)
     assert C.sizeof(abi.ptx_log_hdr) == 40 and abi.LOG_HDR_DTYPE.itemsize == 40
-    assert C.sizeof(abi.ptx_result) == 8 + 8 + 6 * 8
+    assert C.sizeof(abi.ptx_result) == 8 + 8 + 9 * 8  # + value_off, span_off, cint_off (ABI 7: compact rows)
 
 
 @needs_lib

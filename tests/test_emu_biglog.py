@@ -234,6 +234,28 @@ def test_logs_with_more_than_65535_changes_against_the_reference():
 
 
 @pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_long_log_of_several_actors_whose_values_stay_narrow():
+    """two actors x 33 000 one-op changes = 66 000 changes whose every seq / dep is below 65 535.  The encoders emit NO wide column
+    for it (no value needs one) and the census sends it to the HBM-staged kernel (more than 65 533 changes): narrow values that never touch the
+    sentinel are exact, so the log is admitted like the reference admits it — round 4 answered PTX_ERR_CAPACITY.  The same log with one dependency too
+    far still names the reference's error and row."""
+    a = _typed_log(33000)
+    b = _typed_log(33000, actor="b", first_ctr=33001, make_list=False, deps_of=lambda k: {"a": 33000})
+    far = copy.deepcopy(b)
+    far[10]["deps"] = {"a": 33001}
+    docs = [[a + b], [a + far]]
+    batch = wire.encode_docs(docs)
+    assert batch.chg_env_hi is None and int(batch.chg_seq.max()) == 33000 and int(batch.chg_off[1]) == 66000
+    exp = H.oracle_apply(docs, no_patches=True, timeout=900)
+    for reverse in (0, 2):
+        res = H.emu_merge_big(batch, reverse=reverse, admission=True)
+        assert "error" not in exp[0][0] and int(res.logs["status"][0]) == 0
+        H.check_log(batch, res, 0, exp[0][0])
+        assert "Missing dependency" in exp[1][0]["error"] and int(res.logs["status"][1]) == abi.ERR_MISSING_DEP and int(res.logs["reserved"][1, 1]) == 33010
+    assert int(res.logs["n_visible"][0]) == 65999
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
 def test_patch_stream_change_and_cursors_on_a_40000_op_document():
     """VERDICT r3 missing #1: the editor-facing half on a long document.  The HBM-staged merge now also emits the resolved references the replay / change() /
     cursors read (row of a delete's target, boundary slots of a mark op), so a 40 000-op document (25 000 list elements, a fifth of them visible) gets its

@@ -82,6 +82,42 @@ def test_a_failing_large_log_names_the_error_and_the_row(eng):
 
 
 @pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_long_log_of_several_actors_whose_values_stay_narrow(eng):
+    """ADVICE r4 (medium), GPU twin: 2 actors x 33 000 one-op changes — more than 65 533 changes, no value near 65 535, hence no wide column: admitted by the
+    HBM-staged kernel (round 4: PTX_ERR_CAPACITY); so is a resident log that two narrow parts make this long (ptx_batch_append_device)."""
+    import copy
+
+    from test_emu_biglog import _typed_log
+
+    a = _typed_log(33000)
+    b = _typed_log(33000, actor="b", first_ctr=33001, make_list=False, deps_of=lambda k: {"a": 33000})
+    far = copy.deepcopy(b)
+    far[10]["deps"] = {"a": 33001}
+    docs = [[a + b], [a + far]]
+    batch = wire.encode_docs(docs)
+    assert batch.chg_env_hi is None
+    exp = H.oracle_apply(docs, no_patches=True, timeout=900)
+    res = eng.apply_materialize(batch)
+    assert int(res.logs["status"][0]) == 0 and int(res.logs["n_visible"][0]) == 65999
+    H.check_log(batch, res, 0, exp[0][0])
+    assert int(res.logs["status"][1]) == abi.ERR_MISSING_DEP and int(res.logs["reserved"][1, 1]) == 33010
+    # two narrow parts (40 000 + 26 000 changes) appended on the device cross the 65 533-change line of the LDS kernel's admission
+    one = wire.encode_docs([docs[0]])
+    head, tail = wire.split_batch(one, [40000])
+    head, tail = dataclasses.replace(head, chg_env_hi=None), dataclasses.replace(tail, chg_env_hi=None)
+    db, dm = eng.upload(head), eng.upload(tail)
+    db2 = eng.append_device(db, dm)
+    dr = eng.alloc_result(db2)
+    try:
+        eng.merge(db2, dr)
+        logs = eng.download_logs(dr, 1)
+    finally:
+        eng.free_result(dr)
+        for x in (db2, dm, db):
+            eng.free_batch(x)
+    assert int(logs["status"][0]) == 0 and (logs["digest"][0] == res.logs["digest"][0]).all()
+
+
 def test_logs_with_more_than_65535_changes(eng):
     """seq / deps are plain numbers in the reference (micromerge.ts:499-511); a replica typed as one change per keystroke passes 65 535
     changes of one actor.  Through the C ABI: the wide envelope column goes up with the batch, the census sends these logs to the HBM-staged kernel, every

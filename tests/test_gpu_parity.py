@@ -95,11 +95,47 @@ def test_staged_api_equals_one_shot_and_tiling(eng):
         sl = slice(k * batch.n_logs, (k + 1) * batch.n_logs)
         assert (got.logs[sl] == one.logs).all() and (logs_only[sl] == one.logs).all()
         for log in range(batch.n_logs):
-            a, b = wire.canonical_of_log(batch, one, log)[0], got.values[k * n + int(batch.log_off[log]) :][: int(one.logs[log]["n_visible"])]
+            a, b = wire.canonical_of_log(batch, one, log)[0], wire.canonical_of_log(batch, got, k * batch.n_logs + log)[0]  # (compact rows since ABI 7: by value_off)
             assert (a == b).all()
     tiled = batch.tile(3)
     for log in (0, batch.n_logs + 1, 3 * batch.n_logs - 1):
         assert wire.decode_spans(tiled, got, log) == wire.decode_spans(batch, one, log % batch.n_logs)
+
+
+def test_compact_result_rows_of_large_and_small_ranges(eng):
+    """ABI 7: ptx_result rows are compact (gathered on the device by the per-log offsets, copied into pinned memory).  A download of more than 65 536 op rows
+    (offsets first, dense arrays of exactly the totals) and the downloads of single logs (one allocation sized by the rows, one wait) must return the same
+    rows, and both the reference-made fixture's documents; the offsets are the exclusive prefix sums of the per-log counts."""
+    gen = _load("ptxgen_rich_2600.json")
+    batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    copies = 70000 // batch.n_ops + 1
+    db = eng.upload(batch, copies=copies)
+    dr = eng.alloc_result(db)
+    try:
+        assert eng.n_ops(db) > 65536
+        eng.merge(db, dr)
+        whole = eng.download(db, dr)
+        n = eng.n_logs(db)
+        for name, cnt in (("value_off", "n_visible"), ("span_off", "n_spans"), ("cint_off", "n_cintervals")):
+            off = getattr(whole, name)
+            assert int(off[0]) == 0 and (np.diff(off.astype(np.int64)) == whole.logs[cnt].astype(np.int64)).all(), name
+        assert len(whole.values) == int(whole.value_off[n]) and len(whole.spans) == int(whole.span_off[n]) and len(whole.cintervals) == int(whole.cint_off[n])
+        tiled = batch.tile(copies)
+        exp = [e for d in gen["docs"] for e in d["expected"]]
+        for log in (0, 1, batch.n_logs, n // 2, n - 1):
+            one = eng.download_range(db, dr, log, 1)
+            assert (one.logs[0] == whole.logs[log]).all()
+            for a, b in zip(wire.canonical_of_log(tiled, whole, log), wire.canonical_of_log(tiled, one, 0)):
+                assert a.tobytes() == b.tobytes()
+            H.check_log(tiled, whole, log, exp[log % batch.n_logs])
+        some = eng.download_range(db, dr, 3, 4)  # a range in the middle: offsets rebased to its first log
+        for k in range(4):
+            for a, b in zip(wire.canonical_of_log(tiled, whole, 3 + k), wire.canonical_of_log(tiled, some, k)):
+                assert a.tobytes() == b.tobytes()
+        assert int(eng.download_range(db, dr, 2, 0).value_off[0]) == 0  # an empty range
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
 
 
 def test_wrap_device_columns(eng):

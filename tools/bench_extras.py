@@ -9,6 +9,8 @@
   phase_cycles      where a log's residency goes (thread-0 cycle stamps of the diagnostic build of the same kernel body), loaded and with a CU to itself;
   pipeline          change() -> merge -> convergence as a two-stage pipeline: ptx_generate of batch k + 1 (one engine, its stream) runs while ptx_merge of batch k and
                     the digest comparison run on a second engine's stream — against the same batches one after the other on one engine;
+  host_to_host      the boundary's one-shot call with HOST buffers: upload, merge, download of the compact result rows (tools/pcie_rate.py);
+  many              documents of 5 and 8 actors under causal admission (ptx_merge_kernel_many) beside 3-actor documents prepared the same way;
   candidate         when a candidate build peritext_amd/lib/exp_<name>.so stands beside the product (__graft_entry__.CANDIDATE): the bench's workload under
                     it, same box, same call, every log's status / digest / row counts compared with the product's.
 Every leg records its own failure instead of raising.  One JSON line on stdout.
@@ -187,6 +189,62 @@ def biglog_leg(args):
     return {"kernel": "ptx_merge_big_kernel (one 1 024-thread workgroup per log, working set in HBM scratch)", "legs": rows}
 
 
+def many_actor_leg(args, n_docs=6, target_logs=24480):
+    """Documents with MORE than three actors under causal admission (ptx_merge_kernel_many: the (actor, seq) -> change table instead of the DPP-carried clock),
+    VERDICT r4 weak #7: config-4-shaped documents of 5 and 8 replicas, made on the host by the oracle's PTXGEN (the device generator holds at most 4 replicas),
+    tiled to fill the GPU, beside 3-replica documents prepared the same way (the <= 3-actor build).  Kernel ms, SURVEY 8(d) fraction, every document against the
+    oracle's expected output."""
+    import helpers
+
+    node = shutil.which("node")
+    if node is None:
+        raise RuntimeError("node (the oracle runtime) is not on this box")
+    g = workloads.gen_config(args.config)
+    rows = []
+    td = tempfile.mkdtemp(prefix="ptxmany_")
+    for R in (3, 5, 8):
+        outp = os.path.join(td, "g%d.json" % R)
+        subprocess.run([node, os.path.join(ROOT, "oracle", "cli.js"), "gen", "--config", args.config, "--replicas", str(R), "--docs", str(n_docs), "--seed", str(args.seed + R), "--out", outp],
+                       cwd=ROOT, check=True)
+        with open(outp) as f:
+            gen = json.load(f)
+        batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
+        copies = max(1, target_logs // batch.n_logs)
+        with Engine(args.device, flags=abi.FLAG_NO_ELEM_RANK) as e:
+            db = e.upload(batch, copies=copies)
+            dr = e.alloc_result(db)
+            e.merge(db, dr)
+            e.sync()
+            iters = max(args.iters, 3)
+            ms = min(e.merge_timed(db, dr, iters) / iters for _ in range(2))
+            n_logs, n_rows = e.n_logs(db), e.n_ops(db)
+            logs = e.download_logs(dr, n_logs)
+            one = e.download_range(db, dr, 0, batch.n_logs)
+            V, S, T = int(logs["n_visible"].sum()), int(logs["n_spans"].sum()), int(logs["n_cintervals"].sum())
+            alg = 32 * n_rows + 4 * V + 8 * S + 16 * T + 16 * n_logs
+            env = abi.envelope_bytes(e.n_changes(db), batch.max_actors)
+            row = {"replicas": R, "documents": n_docs, "copies": copies, "replica_logs": n_logs, "ops": n_logs * g["ops_per_log"], "kernel": e.batch_kernel_name(db),
+                   "launch": list(e.launch_shape(db)), "kernel_ms": ms, "ops_per_s": n_logs * g["ops_per_log"] / (ms * 1e-3), "us_per_log_per_cu": ms * 1e3 * 256 / n_logs,
+                   "roofline_frac": alg / (ms * 1e-3) / HBM_PEAK, "with_envelope_frac": (alg + env) / (ms * 1e-3) / HBM_PEAK,
+                   "every_log_ok": bool(int(logs["status"].max()) == 0),
+                   "copies_agree": bool((logs["digest"].reshape(copies, batch.n_logs, 2) == logs["digest"][: batch.n_logs]).all())}
+            log = 0
+            for d in gen["docs"]:
+                for exp in d["expected"]:
+                    helpers.check_log(batch, one, log, exp)
+                    log += 1
+            row["parity"] = "%d replica logs of %d documents against the oracle's expected output (decoded spans, raw rows, digests)" % (log, n_docs)
+            e.free_result(dr)
+            e.free_batch(db)
+        rows.append(row)
+        say("many_actor %s" % json.dumps(row))
+    shutil.rmtree(td, ignore_errors=True)
+    base = rows[0]["us_per_log_per_cu"]
+    for r in rows:
+        r["per_log_cost_vs_3_replicas"] = r["us_per_log_per_cu"] / base
+    return {"workload": "%s documents made by the oracle's PTXGEN on the host, %d distinct documents per leg, tiled" % (args.config, n_docs), "legs": rows}
+
+
 def pipeline_leg(args, gen_args, flags, batches=6, docs=8192):
     """generate -> merge -> converged count over `batches` batches of `docs` documents: serial on one engine, then generator and merger on two engines (two HIP
     streams of one device) in two host threads (the ctypes calls release the GIL).  Handles made by one engine are merged by the other: a resident batch is plain
@@ -265,7 +323,7 @@ def main():
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--no-admission", action="store_true")
     ap.add_argument("--parity-docs", type=int, default=32)
-    ap.add_argument("--legs", default="configs,replay,biglog,pipeline,phases,candidate,probe")
+    ap.add_argument("--legs", default="configs,replay,biglog,pipeline,host,many,phases,candidate,probe")
     args = ap.parse_args()
     legs = set(args.legs.split(","))
     g = workloads.gen_config(args.config, ops=args.ops)
@@ -313,6 +371,24 @@ def main():
         except Exception as ex:  # noqa: BLE001
             out["generate_merge_pipeline"] = {"error": str(ex)[:300]}
         say("generate_merge_pipeline %s" % json.dumps(out["generate_merge_pipeline"]))
+
+    if "host" in legs:
+        # the boundary's one-shot call with HOST buffers (ptx_batch_upload -> ptx_merge -> ptx_result_download: ptx_apply_materialize), 8 192 documents: never `value`
+        try:
+            import pcie_rate
+
+            m = pcie_rate.measure(min(8192, args.docs), args.config, reps=3)
+            out["host_to_host"] = {k: m[k] for k in ("config", "docs", "replica_logs", "ops", "host_input_bytes", "abi", "best")}
+        except Exception as ex:  # noqa: BLE001
+            out["host_to_host"] = {"error": str(ex)[:300]}
+        say("host_to_host %s" % json.dumps(out["host_to_host"]))
+
+    if "many" in legs:
+        try:
+            out["many_actor_documents"] = many_actor_leg(args)
+        except Exception as ex:  # noqa: BLE001
+            out["many_actor_documents"] = {"error": str(ex)[:300]}
+        say("many_actor_documents %s" % json.dumps(out["many_actor_documents"]))
 
     ref = None
     if "phases" in legs or "candidate" in legs:
