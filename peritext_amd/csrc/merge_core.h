@@ -355,7 +355,9 @@ PTX_HD uint64_t ptx_lds_need(uint64_t N, uint64_t n, uint64_t D, uint64_t K, uin
 /* P0 scratch on top of the header: per-actor table starts + the (actor, seq) -> change table */
 PTX_HD uint64_t ptx_lds_need_admission(uint64_t n_changes, uint64_t max_actors) {
     if (max_actors <= 3) return PTX_HDR_BYTES + 2 * ptx_a16(4 * (1024 / 64 + 2)) + ptx_a16(4 * 12 * (1024 / 64 + 1)); /* per-wave clock totals and check records */
-    return PTX_HDR_BYTES + ptx_a16(4 * (max_actors + 2)) + ptx_a16(4 * (n_changes + 1));
+    const uint64_t table = PTX_HDR_BYTES + ptx_a16(4 * (max_actors + 2)) + ptx_a16(4 * (n_changes + 1));
+    const uint64_t walk = PTX_HDR_BYTES + ptx_a16(4 * 28 * (1024 / 64 + 1)); /* (four to fifteen actors: the per-wave records of the one-pass check, before the table) */
+    return max_actors <= 15 && walk > table ? walk : table;
 }
 PTX_HD uint64_t ptx_lds_need_hdr(uint64_t N, const ptx_log_hdr& h) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
@@ -528,6 +530,160 @@ PTX_DEV void ptx_adm_step(PtxAdmWave& S, const uint32_t* h, const uint32_t* e0, 
     S.by += ptx_wave_last(iy);
 }
 
+/* ---- P0, documents of four to fifteen actors (envelope rows of kW dwords: seq, deps[0 .. 2 kW - 1); kW = 4 up to seven actors, 6 up to eleven, 8 up to
+ *      fifteen): the same one-pass walk with the relative vector clock in kW words, packed like the row it is compared with — half k of the row holds
+ *      deps[k - 1], half k of the clock words the changes of actor k - 1 so far (half 0, beside seq, stays 0).  h = Change headers, e[u][j] = word j of the row of
+ *      the lane's change u.  Round 5: such documents took the (actor, seq) -> change table for every log — three passes of one change per thread and step,
+ *      1.85 x the per-log cost of a three-actor document at five actors (profiles/r05_d_*); the table is now what names the error of a log that fails this check. ---- */
+template <uint32_t kW>
+struct PtxAdmWaveN { /* the same in every lane of the wave */
+    uint32_t b[kW]; /* changes per actor before this step, relative to the segment */
+    uint32_t g[kW]; /* G per actor (seq - relative clock of its changes), same packing */
+    uint32_t known; /* bit a: G of actor a has been learned */
+};
+/* the 16-bit half k of kW packed words, through a byte permute of the word PAIR that holds it (k >> 2) */
+template <uint32_t kW>
+PTX_DEV uint32_t ptx_adm_half(const uint32_t (&w)[kW], uint32_t k, uint32_t sel) {
+    if constexpr (kW == 4) return ((k >> 2) & 1u) ? ptx_perm(w[3], w[2], sel) : ptx_perm(w[1], w[0], sel);
+    uint32_t v = ptx_perm(w[1], w[0], sel);
+#pragma unroll
+    for (uint32_t p = 1; p < kW / 2u; ++p) v = (k >> 2) == p ? ptx_perm(w[2u * p + 1u], w[2u * p], sel) : v;
+    return v;
+}
+template <uint32_t kW, uint32_t kAC, bool kTail>
+PTX_DEV void ptx_adm_step_n(PtxAdmWaveN<kW>& S, uint32_t na, const uint32_t* h, const uint32_t (*e)[kW], uint32_t nvalid, uint32_t (&mx)[kW], uint32_t& bad, uint32_t& amax,
+                            uint32_t& rows) {
+    uint32_t t[kW];
+#pragma unroll
+    for (uint32_t j = 0; j < kW; ++j) t[j] = 0u;
+#pragma unroll
+    for (uint32_t u = 0; u < kAC; ++u) {
+        const bool in = !kTail || u < nvalid;
+        const uint32_t hu = in ? h[u] : 0u;
+        amax = hu > amax ? hu : amax; /* the actor sits in the top bits */
+        rows += hu & PTX_CHG_NOPS;
+        const uint32_t k = (hu >> PTX_CHG_ACTOR_SHIFT) + 1u; /* the actor's half of the packing (an actor the document does not have: the log fails through amax) */
+        const uint32_t one = in ? 1u << (16u * (k & 1u)) : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < kW; ++j) t[j] += (k >> 1) == j ? one : 0u;
+    }
+    uint32_t c[kW], incl[kW];
+#pragma unroll
+    for (uint32_t j = 0; j < kW; ++j) {
+        incl[j] = ptx_wave_incl_scan(t[j]);
+        c[j] = S.b[j] + incl[j] - t[j]; /* relative clock before this lane's first change */
+    }
+    /* (nothing per change is kept between the two loops below: a lane holds its changes' headers and rows as it is) */
+#define PTX_ADMN_K(u_, in_) ((((in_) ? h[u_] : 0u) >> PTX_CHG_ACTOR_SHIFT) + 1u)
+#define PTX_ADMN_SEL(k_, in_) ((in_) ? 0x0c0c0100u + ((k_) & 3u) * 0x0202u : 0x0c0c0c0cu) /* the two bytes of half k & 3 of a word pair */
+    const uint32_t all = (1u << na) - 1u;
+    if ((S.known & all) != all) { /* wave-uniform; normally only in the first step of a segment: G of an actor = seq (-) clock of one of its changes */
+        uint32_t c2[kW];
+#pragma unroll
+        for (uint32_t j = 0; j < kW; ++j) c2[j] = c[j];
+        for (uint32_t u = 0; u < kAC; ++u) {
+            const bool in = !kTail || u < nvalid;
+            const uint32_t k = PTX_ADMN_K(u, in);
+            const uint32_t su = ptx_pk_subsat_u16(in ? e[u][0] : 0u, ptx_adm_half<kW>(c2, k, PTX_ADMN_SEL(k, in))) & 0xFFFFu;
+            for (uint32_t b = 0; b < na; ++b) {
+                uint32_t v = 0;
+                if (!((S.known >> b) & 1u) && ptx_wave_pick(in && k == b + 1u, su, v)) {
+                    const uint32_t sh = 16u * ((b + 1u) & 1u);
+                    S.g[(b + 1u) >> 1] = (S.g[(b + 1u) >> 1] & ~(0xFFFFu << sh)) | (v << sh); /* (an indexed register array: the compiler keeps these few words in scratch for this rare block — measured against the unrolled forms, which cost the whole kernel 16 VGPRs) */
+                    S.known |= 1u << b;
+                }
+            }
+            const uint32_t one = in ? 1u << (16u * (k & 1u)) : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < kW; ++j) c2[j] += (k >> 1) == j ? one : 0u;
+        }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kAC; ++u) {
+        const bool in = !kTail || u < nvalid;
+        const uint32_t k = PTX_ADMN_K(u, in), sel = PTX_ADMN_SEL(k, in);
+        const uint32_t su = ptx_pk_subsat_u16(in ? e[u][0] : 0u, ptx_adm_half<kW>(c, k, sel)); /* low half: seq (-) clock[actor] */
+        bad |= (su ^ ptx_adm_half<kW>(S.g, k, sel)) & 0xFFFFu;                              /* every seq (-) clock of an actor is its G */
+#pragma unroll
+        for (uint32_t j = 0; j < kW; ++j) mx[j] = ptx_pk_max_u16(mx[j], ptx_pk_subsat_u16(in ? e[u][j] : 0u, c[j])); /* deps (-) clock, per half (half 0: ignored) */
+        const uint32_t one = in ? 1u << (16u * (k & 1u)) : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < kW; ++j) c[j] += (k >> 1) == j ? one : 0u;
+    }
+#undef PTX_ADMN_K
+#undef PTX_ADMN_SEL
+#pragma unroll
+    for (uint32_t j = 0; j < kW; ++j) S.b[j] += ptx_wave_last(incl[j]);
+}
+#define PTX_ADMN_WREC 28u /* words a wave leaves for the validation: b[kW], g[kW], mx[kW] (kW <= 8), known, bad, amax */
+#define PTX_ADMN_HALF(w_, k_) (((w_)[(k_) >> 1] >> (16u * ((k_) & 1u))) & 0xFFFFu)
+
+/* the walk of one log: true = every change is admitted (the same answer in every thread; ends with the barrier after which wrec may be reused) */
+template <uint32_t kW, uint32_t kAC, uint32_t kThreads, class HdrT>
+PTX_DEV bool ptx_adm_walk_n(const PtxMergeArgs& A, HdrT* H, uint32_t* wrec, const uint32_t* c_hdr, const uint16_t* c_env, uint32_t C, uint32_t N, uint32_t na) {
+    (void)A;
+    PTX_LEADER { H->cur[7] = 0; }
+    PTX_SYNC_LDS();
+    const uint32_t nwv_ = PTX_NWAVES;
+    const uint32_t step = PTX_WS * kAC; /* changes per wave and step: kAC consecutive changes per lane (four of 16-byte rows; two of the longer ones: their words are what a lane holds in registers) */
+    const uint32_t seg = ((C + nwv_ - 1u) / nwv_ + step - 1u) / step * step; /* changes per wave, whole steps */
+    PTX_FOR_WAVE(w, lane) {
+        const uint32_t lo = w * seg < C ? w * seg : C, hi = lo + seg < C ? lo + seg : C;
+        PtxAdmWaveN<kW> S;
+        uint32_t mx[kW], bad = 0, amax = 0, rows = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kW; ++j) S.b[j] = S.g[j] = mx[j] = 0u;
+        S.known = 0u;
+#pragma nounroll
+        for (uint32_t cb = lo; cb < hi; cb += step) {
+            uint32_t h[kAC], e[kAC][kW];
+            const uint32_t cl0 = cb + lane * kAC;
+            const uint32_t cl = cl0 < hi ? cl0 : (hi ? hi - 1u : 0u);
+            PTX_ADM_HDRSN(h, cl, kAC)
+            PTX_ADM_ROWSN(e, cl, kW, kAC)
+            if (cb + step <= hi) ptx_adm_step_n<kW, kAC, false>(S, na, h, e, kAC, mx, bad, amax, rows);
+            else ptx_adm_step_n<kW, kAC, true>(S, na, h, e, cl0 < hi ? hi - cl0 : 0u, mx, bad, amax, rows); /* the last, partial step: lanes past `hi` play changes of no actor */
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kW; ++j) mx[j] = ptx_wave_pk_max_u16(mx[j]);
+        bad = ptx_wave_max(bad);
+        amax = ptx_wave_max(amax);
+        ptx_reduce_add32(&H->cur[7], rows);
+        if (lane == 0u) {
+            uint32_t* r = wrec + w * PTX_ADMN_WREC;
+#pragma unroll
+            for (uint32_t j = 0; j < kW; ++j) {
+                r[j] = S.b[j];
+                r[8u + j] = S.g[j];
+                r[16u + j] = mx[j];
+            }
+            r[24] = S.known;
+            r[25] = bad;
+            r[26] = amax;
+        }
+    }
+    PTX_SYNC_LDS();
+    bool admitted = H->cur[7] == N; /* the same answer in every thread; the changes must tile the rows of the log exactly */
+    {
+        uint32_t B[2u * kW - 1u];
+#pragma unroll
+        for (uint32_t b = 0; b < 2u * kW - 1u; ++b) B[b] = 0u;
+        for (uint32_t w = 0; w < nwv_; ++w) {
+            const uint32_t* r = wrec + w * PTX_ADMN_WREC;
+            if ((r[26] >> PTX_CHG_ACTOR_SHIFT) >= na || r[25] != 0u) admitted = false; /* an actor beyond the document's; two changes of an actor disagree on seq - clock */
+#pragma unroll
+            for (uint32_t b = 0; b < 2u * kW - 1u; ++b) {
+                const uint32_t k = b + 1u;
+                if (b < na && ((r[24] >> b) & 1u) && PTX_ADMN_HALF(r + 8, k) != B[b] + 1u) admitted = false; /* some seq != clock + 1 */
+                if (b < na && PTX_ADMN_HALF(r + 16, k) > B[b]) admitted = false;                              /* some dep > clock */
+                B[b] += PTX_ADMN_HALF(r, k);
+            }
+        }
+    }
+    PTX_SYNC_LDS(); /* (wrec has been read by everyone) */
+    return admitted;
+}
+
 /* ---- the mark ops of a log in ROW order although their list is grouped by mark type (four runs, each in row order): block b takes
  *      the b-th slice of every run, so that the ops of a block come from one stretch of the log and their gathers of ref_a / ref_b /
  *      sides / payload share cache lines (visiting run after run fetched every line of those columns once per run).  A block holds at
@@ -608,7 +764,7 @@ PTX_DEV bool ptx_mark_of(const PtxMarkBlocks& M, uint32_t b, uint32_t t, uint32_
 /* ================================================================================================ */
 /* Applies log `log`; returns its status (PTX_OK or a per-log PTX_ERR_*) and the LDS high-water mark.  The caller
  * writes the result row (ptx_write_result) — ONE copy of that code instead of one per early exit. */
-template <bool kManyActors, uint32_t kThreads, bool kDiag, bool kLean>
+template <int kManyActors, uint32_t kThreads, bool kDiag, bool kLean>
 PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t* lds, uint32_t& lds_high) {
     const uint64_t base = A.log_off[log];
     const uint64_t N64 = A.log_off[log + 1] - base;
@@ -921,7 +1077,24 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             lds_high = bp.high;
             return PTX_ERR_CAPACITY;
         } else {
-        /* More than three actors (rare): tbl[first[a] + seq - 1] = index of the change (a, seq) makes "the seqs of an
+        bool fast_admitted = false;
+        if (kManyActors == 2 ? na >= 8u && na <= 15u : na <= 7u) {
+            /* Four to fifteen actors (envelope rows of 16 / 24 / 32 bytes): the one-pass check of the three-actor path with the clock in as many words as a row has
+             * (ptx_adm_step_n).  A log that passes is admitted; one that fails (rare) goes through the table below, which names the first failing change.
+             * Two builds (kManyActors 1: up to seven actors, the walk over 16-byte rows; 2: eight to fifteen — its wider words would cost the first build
+             * two waves per SIMD); documents of more than fifteen actors take the table of the first. */
+            uint32_t* wrec = ptx_alloc<uint32_t>(bp, (PTX_MAX_THREADS / 64 + 1) * PTX_ADMN_WREC);
+            PTX_BAIL_CAPACITY();
+            if constexpr (kManyActors == 2) {
+                fast_admitted = na <= 11u ? ptx_adm_walk_n<6, 2, kThreads>(A, H, wrec, c_hdr, c_env, C, N, na) : ptx_adm_walk_n<8, 2, kThreads>(A, H, wrec, c_hdr, c_env, C, N, na);
+            } else {
+                fast_admitted = ptx_adm_walk_n<4, 4, kThreads>(A, H, wrec, c_hdr, c_env, C, N, na);
+            }
+            bp.off = (kDiag ? PTX_HDR_BYTES_DIAG : PTX_HDR_BYTES);
+            if (!fast_admitted) PTX_NOTE_EXACT_WALK();
+        }
+        if (!fast_admitted) {
+        /* More than fifteen actors, or a log that failed the check above (rare): tbl[first[a] + seq - 1] = index of the change (a, seq) makes "the seqs of an
          * actor are 1, 2, ... in log order" and "dependency (b, d) sits earlier in the log" one LDS read each.  Kept
          * deliberately plain (one change per thread and step, serial prefix by the leader). */
         uint32_t* first = ptx_alloc<uint32_t>(bp, na + 2); /* changes per actor -> first table slot of the actor */
@@ -985,6 +1158,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * below, which still run) wins over it, exactly as in a sequential replay */
         PTX_SYNC_LDS();
         bp.off = (kDiag ? PTX_HDR_BYTES_DIAG : PTX_HDR_BYTES);
+        } /* the table */
         } /* na > 3 */
 #undef PTX_CHANGE_ROW
     }
@@ -2123,9 +2297,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     return PTX_OK;
 }
 
-/* kManyActors: include the admission path for batches with more than four actors per document (it costs ~35
+/* kManyActors (0 / 1 / 2): include the admission paths for batches with more than three actors per document (1: the walk for up to seven + the table; 2: the walks for eight to fifteen + the table; they cost ~35
  * VGPRs, i.e. two waves per SIMD, so it lives in its own build of the kernel) */
-template <bool kManyActors, uint32_t kThreads, bool kDiag = false, bool kLean = false>
+template <int kManyActors, uint32_t kThreads, bool kDiag = false, bool kLean = false>
 PTX_DEV void ptx_merge_log(const PtxMergeArgs& A, uint32_t log, uint8_t* lds) {
     uint32_t lds_high = 0;
     const uint32_t status = ptx_merge_log_body<kManyActors, kThreads, kDiag, kLean>(A, log, lds, lds_high);

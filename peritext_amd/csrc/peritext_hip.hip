@@ -56,20 +56,21 @@
            out of it and kept in registers for the whole kernel */                    \
         if (blockIdx.x < A.n_logs) ptx_merge_log<MANY, KT, DIAG, LEAN>(A, A.log_index ? A.log_index[blockIdx.x] : blockIdx.x, ptx_lds); \
     }
-PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, PTX_W, false, 0, false)     /* any launch shape (blockDim.x read at run time) */
-PTX_MERGE_KERNEL(ptx_merge_kernel_rest, 1024, 1, false, 0, false) /* the same kernel under another name: the second launch of a split batch (the few logs
+PTX_MERGE_KERNEL(ptx_merge_kernel, 1024, PTX_W, 0, 0, false)     /* any launch shape (blockDim.x read at run time) */
+PTX_MERGE_KERNEL(ptx_merge_kernel_rest, 1024, 1, 0, 0, false) /* the same kernel under another name: the second launch of a split batch (the few logs
                                                                     with a larger LDS window), so that per-kernel statistics of a trace keep the two apart */
-PTX_MERGE_KERNEL_A(ptx_merge_kernel_w7, 1024, PTX_W, false, 0, false, PTX_SGPRS_W7)      /* the same two at 7 waves per SIMD (see above) */
-PTX_MERGE_KERNEL_A(ptx_merge_kernel_rest_w7, 1024, 1, false, 0, false, PTX_SGPRS_W7)
+PTX_MERGE_KERNEL_A(ptx_merge_kernel_w7, 1024, PTX_W, 0, 0, false, PTX_SGPRS_W7)      /* the same two at 7 waves per SIMD (see above) */
+PTX_MERGE_KERNEL_A(ptx_merge_kernel_rest_w7, 1024, 1, 0, 0, false, PTX_SGPRS_W7)
 /* Round 5: the LEAN builds, one per usual launch shape (threads per log known at compile time: the loop strides fold; a one-wave log has no s_barrier at all).
  * For batches whose every log has 16-bit id keys (census) merged without elem_rank / resolved references (PTX_FLAG_NO_ELEM_RANK): neither the wide-key paths nor
  * the two optional outputs are in the code — 84 instead of 113 scalar registers spilled at the 96 that 7 waves per SIMD allow.  Measured same box against the
  * general build (profiles/r05_b_*): config #4 -1.2 %, #3 (two waves per log) -4.2 %, #2 (one wave) -4.9 %. */
-PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean64, 64, PTX_W, false, 64, false, true, PTX_SGPRS_W7)
-PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean128, 128, PTX_W, false, 128, false, true, PTX_SGPRS_W7)
-PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean192, 192, PTX_W, false, 192, false, true, PTX_SGPRS_W7)
-PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, true, 0, false) /* + causal admission for documents with more than three actors */
-PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, PTX_W, false, 0, true)  /* (the admission of the product kernel — with the table path of the many-actor build it needs 105 VGPRs and its phase stamps would be taken at 4 waves per SIMD —) + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean64, 64, PTX_W, 0, 64, false, true, PTX_SGPRS_W7)
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean128, 128, PTX_W, 0, 128, false, true, PTX_SGPRS_W7)
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean192, 192, PTX_W, 0, 192, false, true, PTX_SGPRS_W7)
+PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, 1, 0, false) /* + causal admission for documents with more than three actors: a one-pass walk up to seven, the (actor, seq) table beyond fifteen */
+PTX_MERGE_KERNEL(ptx_merge_kernel_many_wide, 1024, 1, 2, 0, false) /* the same for documents of eight to fifteen actors (walks over 24- and 32-byte envelope rows) */
+PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, PTX_W, 0, 0, true)  /* (the admission of the product kernel — with the table path of the many-actor build it needs 105 VGPRs and its phase stamps would be taken at 4 waves per SIMD —) + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
 /* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
  * issue ~1 % fewer instructions but need twice the VGPRs unless PTX_U=1, so only the run-time-sized builds are shipped) */
 
@@ -697,7 +698,7 @@ const char* ptx_kernel_name(void) { return "ptx_merge_kernel"; }
 const char* ptx_batch_kernel_name(const ptx_ctx* ctx, const ptx_dbatch* b) {
     if (!ctx || !b) return "ptx_merge_kernel";
     const bool admit = b->chg_off && !(ctx->flags & PTX_FLAG_NO_ADMISSION);
-    if (admit && b->max_actors > 3) return "ptx_merge_kernel_many";
+    if (admit && b->max_actors > 3) return b->max_actors >= 8u && b->max_actors <= 15u ? "ptx_merge_kernel_many_wide" : "ptx_merge_kernel_many";
     const uint32_t lds = b->log_index ? b->lds_main : b->lds_bytes;
     const uint32_t lean = wants_lean(ctx, b, !(ctx->flags & PTX_FLAG_NO_ELEM_RANK), lds);
     if (lean) return lean == 64u ? "ptx_merge_kernel_lean64" : lean == 128u ? "ptx_merge_kernel_lean128" : "ptx_merge_kernel_lean192";
@@ -733,7 +734,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     ctx->own_stream = ctx->stream;
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_merge_kernel_lean64, (const void*)ptx_merge_kernel_lean128, (const void*)ptx_merge_kernel_lean192, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_many_wide, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_merge_kernel_lean64, (const void*)ptx_merge_kernel_lean128, (const void*)ptx_merge_kernel_lean192, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -1162,8 +1163,10 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
             A.lds_bytes = std::min<uint32_t>(lds + PTX_HDR_DIAG_EXTRA, (uint32_t)ctx->max_lds);
             hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), A.lds_bytes, st, A);
         }
-        else if (admit && b->max_actors > 3)
-            hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);
+        else if (admit && b->max_actors > 3) {
+            if (b->max_actors >= 8u && b->max_actors <= 15u) hipLaunchKernelGGL(ptx_merge_kernel_many_wide, dim3(grid), dim3(b->threads), lds, st, A);
+            else hipLaunchKernelGGL(ptx_merge_kernel_many, dim3(grid), dim3(b->threads), lds, st, A);
+        }
         else {
             const bool w7 = wants_w7(ctx, b, lds);
             const uint32_t lean = part ? 0u : wants_lean(ctx, b, r->rank || r->refs, lds);

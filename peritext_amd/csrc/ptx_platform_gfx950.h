@@ -385,6 +385,8 @@ PTX_DEV void ptx_flush_clocks(unsigned long long* clocks, unsigned long long* cl
 #endif
 typedef uint32_t ptx_u32x4 __attribute__((ext_vector_type(4)));
 typedef ptx_u32x4 ptx_u32x4_a4 __attribute__((aligned(4)));
+typedef uint32_t ptx_u32x2 __attribute__((ext_vector_type(2)));
+typedef ptx_u32x2 ptx_u32x2_a4 __attribute__((aligned(4)));
 typedef uint64_t ptx_u64x2 __attribute__((ext_vector_type(2)));
 typedef ptx_u64x2 ptx_u64x2_a8 __attribute__((aligned(8)));
 typedef uint32_t ptx_u32_a1 __attribute__((aligned(1)));
@@ -415,6 +417,40 @@ typedef uint32_t ptx_u32_a1 __attribute__((aligned(1)));
         e1_[2] = qb_.y;                                                                      \
         e0_[3] = qb_.z;                                                                      \
         e1_[3] = qb_.w;                                                                      \
+    }
+/* AC_ consecutive headers (AC_ = 4: one 16-byte load, 2: one of 8 bytes) */
+#define PTX_ADM_HDRSN(dst_, cl_, AC_)                                                        \
+    {                                                                                        \
+        if ((AC_) == 4u) {                                                                   \
+            const ptx_u32x4 q_ = PTX_STREAM_LOAD((const ptx_u32x4_a4*)(c_hdr + (cl_)));      \
+            dst_[0] = q_.x;                                                                  \
+            dst_[1] = q_.y;                                                                  \
+            dst_[(AC_) - 2u] = q_.z;                                                         \
+            dst_[(AC_) - 1u] = q_.w;                                                         \
+        } else {                                                                             \
+            const ptx_u32x2 q_ = PTX_STREAM_LOAD((const ptx_u32x2_a4*)(c_hdr + (cl_)));      \
+            dst_[0] = q_.x;                                                                  \
+            dst_[1] = q_.y;                                                                  \
+        }                                                                                    \
+    }
+/* AC_ consecutive envelope rows of W_ dwords (W_ = 4, 6, 8: four to fifteen actors) : e_[u][j] = halves 2 j, 2 j + 1 of the row of change cl_ + u; loads of 16 (+ 8) bytes */
+#define PTX_ADM_ROWSN(e_, cl_, W_, AC_)                                                           \
+    {                                                                                        \
+        const uint32_t* p_ = (const uint32_t*)(c_env + (uint64_t)(cl_) * (2u * (W_)));       \
+        _Pragma("unroll") for (uint32_t u_ = 0; u_ < (AC_); ++u_) {                         \
+            _Pragma("unroll") for (uint32_t j_ = 0; j_ + 4u <= (W_); j_ += 4u) {             \
+                const ptx_u32x4 q_ = PTX_STREAM_LOAD((const ptx_u32x4_a4*)(p_ + u_ * (W_) + j_)); \
+                e_[u_][j_] = q_.x;                                                           \
+                e_[u_][j_ + 1u] = q_.y;                                                      \
+                e_[u_][j_ + 2u] = q_.z;                                                      \
+                e_[u_][j_ + 3u] = q_.w;                                                      \
+            }                                                                                \
+            if ((W_) % 4u == 2u) {                                                           \
+                const ptx_u32x2 q_ = PTX_STREAM_LOAD((const ptx_u32x2_a4*)(p_ + u_ * (W_) + ((W_) - 2u))); \
+                e_[u_][(W_) - 2u] = q_.x;                                                    \
+                e_[u_][(W_) - 1u] = q_.y;                                                    \
+            }                                                                                \
+        }                                                                                    \
     }
 #define PTX_ADM_ENVS(dst_, cl_)                                                              \
     {                                                                                        \

@@ -684,14 +684,20 @@ napi_value Change(napi_env env, napi_callback_info info) {
     }
     napi_value out, batch = batch_to_js(env, hb.b);
     L.host_batch_free(&hb);
-    if (!batch || napi_create_object(env, &out) != napi_ok) return throw_msg(env, "change: cannot build the result object");
+    if (!batch || napi_create_object(env, &out) != napi_ok) {
+        if (after) L.batch_free(ctx, after); /* the session keeps its old handle (rdb): still valid */
+        return throw_msg(env, "change: cannot build the result object");
+    }
     napi_set_named_property(env, out, "batch", batch);
     napi_set_named_property(env, out, "status", status_arr);
     if (resident) {
-        L.batch_free(ctx, rdb); /* superseded by `after` */
+        /* the new handle first, the old batch only once the result object holds it: a failure here must leave the session with a live handle */
         napi_value ext;
-        NAPI_OK(napi_create_external(env, after, nullptr, nullptr, &ext));
-        napi_set_named_property(env, out, "handle", ext);
+        if (napi_create_external(env, after, nullptr, nullptr, &ext) != napi_ok || napi_set_named_property(env, out, "handle", ext) != napi_ok) {
+            L.batch_free(ctx, after);
+            return throw_msg(env, "change: cannot hand out the resident batch");
+        }
+        L.batch_free(ctx, rdb); /* superseded by `after` */
     }
     return out;
 }

@@ -103,8 +103,9 @@ static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* val
     for (uint32_t l = 0; l < b->n_logs; ++l) {
         ptx_emu_lds_fill(lds, lds_bytes); /* LDS is not zero-initialised on the GPU either */
         const uint64_t ks = ((uint64_t)A.log_hdr[l].max_counter + 1) * ((uint64_t)A.log_hdr[l].max_actor + 1);
-        if (lean && !rank && !refs && ks <= 65536u && !(admission && b->max_actors > 3)) ptx_merge_log<false, 0, false, true>(A, l, lds); /* (the host's own rule: wants_lean) */
-        else ptx_merge_log<true, 0>(A, l, lds);
+        if (lean && !rank && !refs && ks <= 65536u && !(admission && b->max_actors > 3)) ptx_merge_log<0, 0, false, true>(A, l, lds); /* (the host's own rule: wants_lean) */
+        else if (admission && b->max_actors >= 8u && b->max_actors <= 15u) ptx_merge_log<2, 0>(A, l, lds); /* (the host's own rule: launch_merge) */
+        else ptx_merge_log<1, 0>(A, l, lds);
     }
     ptx_emu_lds_fill(lds, 0);
     free(lds);

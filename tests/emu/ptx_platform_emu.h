@@ -211,6 +211,13 @@ extern unsigned long long ptx_emu_exact_walks;
         e0_[u_] = (uint32_t)row_[0] | ((uint32_t)row_[1] << 16);                                              \
         e1_[u_] = (uint32_t)row_[2] | ((uint32_t)row_[3] << 16);                                              \
     }
+#define PTX_ADM_HDRSN(dst_, cl_, AC_) \
+    for (uint32_t u_ = 0; u_ < (AC_); ++u_) dst_[u_] = c_hdr[(cl_) + u_ < C ? (cl_) + u_ : C - 1u];
+#define PTX_ADM_ROWSN(e_, cl_, W_, AC_)                                                                          \
+    for (uint32_t u_ = 0; u_ < (AC_); ++u_) {                                                                \
+        const uint16_t* row_ = c_env + (uint64_t)((cl_) + u_ < C ? (cl_) + u_ : C - 1u) * (2u * (W_));        \
+        for (uint32_t j_ = 0; j_ < (W_); ++j_) e_[u_][j_] = (uint32_t)row_[2u * j_] | ((uint32_t)row_[2u * j_ + 1u] << 16); \
+    }
 #define PTX_ADM_ENVS(dst_, cl_)                                                              \
     for (uint32_t u_ = 0; u_ < PTX_AC; ++u_)                                                 \
         for (uint32_t b_ = 0; b_ < 4u; ++b_) dst_[u_][b_] = c_env[(uint64_t)((cl_) + u_ < C ? (cl_) + u_ : C - 1u) * 4u + b_];

@@ -398,6 +398,48 @@ def test_admission_fast_check_agrees_with_a_sequential_replay(reverse):
     assert want.count(0) > copies and want.count(abi.ERR_SEQ_GAP) > 10 and want.count(abi.ERR_MISSING_DEP) > 10
 
 
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+@pytest.mark.parametrize("replicas", [4, 5, 7, 8, 11, 12, 15, 16])
+def test_admission_walk_of_four_to_fifteen_actors_agrees_with_a_sequential_replay(replicas):
+    """Round 5: documents of four to fifteen actors take a one-pass admission walk too (the relative vector clock in as many packed words as an envelope row has:
+    4 up to seven actors, 6 up to eleven, 8 up to fifteen — ptx_adm_step_n; sixteen and more: the table as before); the (actor, seq) -> change table only names
+    the error of a log that fails it.  Pass / fail must be exactly a sequential replay's: logs with one envelope word
+    perturbed at random (seq or a dependency, up or down, anywhere), plus untouched ones — which must never reach the table — in three loop orders."""
+    gen = H.oracle_gen("mini", 3, 40 + replicas, 300, replicas)
+    base = wire.encode_docs([d["logs"] for d in gen["docs"]])
+    es = abi.env_stride(replicas)
+    assert base.max_actors == replicas and es == {4: 8, 5: 8, 7: 8, 8: 12, 11: 12, 12: 16, 15: 16, 16: 20}[replicas]
+    for reverse in (0, 1, 2):
+        rng = np.random.default_rng(100 * replicas + reverse)
+        batch = base.tile(8)
+        env = batch.chg_env.copy().reshape(-1, es)
+        touched = {}
+        for log in range(batch.n_logs):
+            if log % 5 == 0:
+                continue  # left intact
+            c = int(rng.integers(int(batch.chg_off[log]), int(batch.chg_off[log + 1])))
+            col = int(rng.integers(0, 1 + replicas))
+            delta = int(rng.choice([-2, -1, 1, 2, 40000]))
+            env[c, col] = np.uint16(max(0, min(65535, int(env[c, col]) + delta)))
+            touched[log] = (c, col, delta)
+        batch.chg_env = env.reshape(-1)
+        walks = H.emu_exact_walks()
+        res = H.emu_merge(batch, admission=True, reverse=reverse)
+        want = [_sequential_admission(batch, log) for log in range(batch.n_logs)]
+        got = [int(x) for x in res.logs["status"]]
+        assert got == want, [(l, touched.get(l), g, w) for l, (g, w) in enumerate(zip(got, want)) if g != w][:5]
+        if replicas <= 15:
+            assert H.emu_exact_walks() - walks == len(want) - want.count(0), "the table is built for the failing logs and only for them"
+        assert want.count(0) >= batch.n_logs // 5 and want.count(abi.ERR_SEQ_GAP) > 3 and want.count(abi.ERR_MISSING_DEP) > 3
+    # the documents themselves, admitted, against the oracle
+    res = H.emu_merge(base, admission=True)
+    log = 0
+    for d in gen["docs"]:
+        for exp in d["expected"]:
+            H.check_log(base, res, log, exp)
+            log += 1
+
+
 @pytest.mark.parametrize("reverse", [0, 1, 2])
 def test_duplicate_op_id_is_reported(reverse):
     """Two rows with one opId: the count of distinct ids falls short of the row count and the (rare-path) second

@@ -647,3 +647,37 @@ def test_admission_fast_check_agrees_with_a_sequential_replay(eng):
     want = [_sequential_admission(batch, log) for log in range(batch.n_logs)]
     assert [int(x) for x in res.logs["status"]] == want
     assert want.count(0) >= 18 and want.count(abi.ERR_SEQ_GAP) > 5 and want.count(abi.ERR_MISSING_DEP) > 5
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+@pytest.mark.parametrize("replicas", [4, 5, 7, 8, 11, 12, 15])
+def test_admission_walk_of_four_to_fifteen_actors(eng, replicas):
+    """Round 5, GPU twin of the emulation test: documents of four to fifteen actors are admitted by a one-pass walk (64-lane waves, the vector clock in 4 / 6 / 8
+    packed words: DPP prefix sums, v_perm selects, packed 16-bit arithmetic) — pass / fail exactly like a sequential replay on 2 000-op logs with one envelope
+    word perturbed at random; the documents themselves against the oracle; the failing row of a dropped change comes from the table, as before."""
+    from test_emu_parity import _sequential_admission
+
+    gen = H.oracle_gen("mini", 3, 60 + replicas, 2000, replicas)
+    base, res0 = H.check_generated(gen, eng.apply_materialize)
+    assert base.max_actors == replicas
+    batch = base.tile(6)
+    env = batch.chg_env.copy().reshape(-1, abi.env_stride(replicas))
+    rng = np.random.default_rng(replicas)
+    for log in range(batch.n_logs):
+        if log % 5 == 0:
+            continue
+        c = int(rng.integers(int(batch.chg_off[log]), int(batch.chg_off[log + 1])))
+        col = int(rng.integers(0, 1 + replicas))
+        env[c, col] = np.uint16(max(0, min(65535, int(env[c, col]) + int(rng.choice([-2, -1, 1, 2, 40000])))))
+    batch.chg_env = env.reshape(-1)
+    db = eng.upload(batch)
+    try:
+        assert eng.batch_kernel_name(db) == ("ptx_merge_kernel_many" if replicas <= 7 else "ptx_merge_kernel_many_wide")
+    finally:
+        eng.free_batch(db)
+    res = eng.apply_materialize(batch)
+    want = [_sequential_admission(batch, log) for log in range(batch.n_logs)]
+    assert [int(x) for x in res.logs["status"]] == want
+    assert want.count(0) >= batch.n_logs // 5 and want.count(abi.ERR_SEQ_GAP) > 3 and want.count(abi.ERR_MISSING_DEP) > 3
+    ok = [l for l, w in enumerate(want) if w == 0]
+    assert all((res.logs["digest"][l] == res0.logs["digest"][l % base.n_logs]).all() for l in ok)
