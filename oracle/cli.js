@@ -19,7 +19,7 @@
  *       applyChange (its own changes included; `seq` is then set to its clock entry — a replica is never rebuilt like that
  *       upstream), then every entry of `calls` is one doc.change(ops) (micromerge.ts:308).
  *       FILE out = {replicas:[{changes: Change[], error?}]}
- *   node oracle/cli.js time  --in FILE [--impl oracle|ref] [--budget-ms T]
+ *   node oracle/cli.js time  --in FILE [--impl oracle|ref] [--budget-ms T] [--whole] [--spans-out FILE]
  *       CPU baseline: time applyChange over every change of every log + getTextWithFormatting, one log
  *       after another on this core until the budget is spent; prints one JSON line
  *       {impl, logs, ops, seconds, ops_per_s}.
@@ -187,6 +187,8 @@ if (cmd === "gen") {
     const Impl = implClass(impl)
     const budgetMs = parseFloat(flag("--budget-ms", "10000"))
     const whole = process.argv.includes("--whole") /* whole logs: the budget is only a deadline against a hang (a log it cuts is reported as cut) */
+    const spansOut = flag("--spans-out", null)
+    const outDocs = []
     const input = JSON.parse(fs.readFileSync(flag("--in"), "utf8"))
     let logs = 0
     let ops = 0
@@ -216,9 +218,13 @@ if (cmd === "gen") {
             ops += done - 1 /* the makeList */
             if (cut) truncated++
             else logs++
+            /* --spans-out: what the replica shows at the end of a WHOLE log (outside the timed section): bench.py compares it with the device's rows, so the
+               logs this leg times through the reference's own code are parity checks against the reference as well */
+            if (spansOut) outDocs.push({ expected: [cut ? null : expectedOf(doc)] })
             if (spent() > budgetMs) break outer
         }
     }
+    if (spansOut) fs.writeFileSync(spansOut, JSON.stringify({ impl, docs: outDocs }))
     console.log(JSON.stringify({ impl, logs, truncated_logs: truncated, ops, seconds: elapsed / 1e3, ops_per_s: ops / (elapsed / 1e3) }))
 } else {
     console.error("usage: cli.js gen|apply|change|time ... (see header)")

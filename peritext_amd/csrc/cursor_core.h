@@ -13,6 +13,7 @@
  * workgroup per replica log that has queries builds, in LDS, the id index of the inserts (bitmap + popcount prefix, as
  * merge_core.h), element -> row, document position -> row and the alive bitmap by document position with its popcount prefix;
  * every query is then O(1) (resolve: two lookups + one popcount) or O(log n) (get: a binary search over the prefix words).
+ * Documents beyond that form's 16-bit row indices or the CU's LDS take the long-document form below (one pass over the rows per query).
  * Compiled two ways like merge_core.h (hipcc: the product; g++ -DPTX_EMU: CPU tests).
  */
 #pragma once
@@ -46,6 +47,14 @@ PTX_HD uint64_t ptx_cursor_lds_need(uint64_t n, uint64_t ks) {
     const uint64_t nw = (ks + 31) / 32, nwe = (n >> 5) + 2;
     return ptx_a16(sizeof(PtxCursorHdr)) + ptx_a16(8 * (nw + 1)) + 2 * ptx_a16(2 * (n + 1)) + ptx_a16(8 * nwe);
 }
+/* Documents beyond the indexed form's 16-bit row indices (32 766 elements / 65 534 rows) or one CU's LDS (round 5; the reference has no bound,
+ * micromerge.ts:465-477): only the alive bitmap by document position lives in LDS (a quarter byte per element: ~600 000 elements in a CU's 160 KB); a query is
+ * then one pass of the workgroup over the log's rows (resolve: the row that inserted the id; get: the row whose element sits at the wanted position) + one
+ * popcount lookup.  O(rows) per query instead of O(1) — cursors are a handful per replica. */
+PTX_HD uint64_t ptx_cursor_lds_need_long(uint64_t n) { return ptx_a16(sizeof(PtxCursorHdr)) + ptx_a16(8 * ((n >> 5) + 2)); }
+PTX_HD bool ptx_cursor_indexed(uint64_t N, uint64_t n, uint64_t max_actor, uint64_t ks, uint64_t lds_bytes) {
+    return n <= 32766u && N <= 65534u && max_actor <= 4095u && ks < (1ull << 31) && ptx_cursor_lds_need(n, ks) <= lds_bytes;
+}
 
 template <uint32_t kThreads>
 PTX_DEV void ptx_cursor_group(const PtxCursorArgs& A, uint32_t g, uint8_t* lds) {
@@ -63,7 +72,74 @@ PTX_DEV void ptx_cursor_group(const PtxCursorArgs& A, uint32_t g, uint8_t* lds) 
     ix.max_ctr = N ? hd.max_counter : 0u;
     ix.max_actor = N ? hd.max_actor : 0u;
     ix.na1 = ix.max_actor + 1u;
-    const uint32_t keyspace = (ix.max_ctr + 1u) * ix.na1;
+    const uint64_t ks64 = ((uint64_t)ix.max_ctr + 1u) * ix.na1;
+    if (merge_status == PTX_OK && !ptx_cursor_indexed(N, n, ix.max_actor, ks64, A.lds_bytes)) {
+        /* ---- the long-document form: alive bitmap by document position + one pass over the rows per query ---- */
+        const uint32_t nwl = (n >> 5) + 2;
+        PtxBitWord* al = (PtxBitWord*)(lds + ptx_a16(sizeof(PtxCursorHdr)));
+        if (ptx_cursor_lds_need_long(n) > A.lds_bytes) {
+            PTX_FOR(k, (uint32_t)(q1 - q0)) {
+                const uint32_t q = A.q_perm[q0 + k];
+                A.status[q] = PTX_ERR_CAPACITY;
+                A.out[q] = 0;
+            }
+            return;
+        }
+        PTX_FOR(w, nwl) {
+            PtxBitWord z;
+            z.bits = 0;
+            z.pre = 0;
+            al[w] = z;
+        }
+        PTX_SYNC();
+        PTX_FOR(i, N) {
+            if (A.action[base + i] == PTX_ACT_INSERT) {
+                const uint32_t rk = erank[i], r = rk & PTX_RANK_MASK;
+                if (r < n && !(rk & PTX_RANK_TOMBSTONE)) ptx_atomic_or(&al[r >> 5].bits, 1u << (r & 31));
+            }
+        }
+        PTX_SYNC();
+        PTX_FOR(w, nwl) al[w].pre = ptx_popc(al[w].bits);
+        PTX_SYNC();
+        const uint32_t Vl = ptx_scan_excl<uint32_t, 2, kThreads>(&al[0].pre, nwl, H->scan_tmp);
+        for (uint64_t k = 0; k < q1 - q0; ++k) { /* (uniform: every thread works on the same query) */
+            const uint32_t q = A.q_perm[q0 + k];
+            const uint64_t arg = A.q_arg[q];
+            const bool resolve = A.q_kind[q] == PTX_CURSOR_RESOLVE;
+            uint32_t want_rank = 0xFFFFFFFFu;
+            if (!resolve && arg < Vl) { /* the position of the arg-th visible element: the word whose prefix range holds the index, then the bit */
+                const uint32_t want = (uint32_t)arg;
+                uint32_t lo = 0, hi = nwl - 1u;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1u) >> 1;
+                    if (al[mid].pre <= want) lo = mid;
+                    else hi = mid - 1u;
+                }
+                uint32_t m = al[lo].bits;
+                for (uint32_t s2 = al[lo].pre; s2 < want; ++s2) m &= m - 1u;
+                want_rank = (lo << 5) + (uint32_t)__builtin_ctz(m);
+            }
+            PTX_LEADER {
+                A.status[q] = resolve ? PTX_ERR_ELEM_NOT_FOUND : PTX_ERR_INDEX_OOB; /* micromerge.ts:752 / :804, unless a row answers below */
+                A.out[q] = 0;
+            }
+            PTX_SYNC(); /* (the leader's defaults stand before a finder overwrites them) */
+            if (resolve || want_rank != 0xFFFFFFFFu) {
+                PTX_FOR(i, N) {
+                    if (A.action[base + i] == PTX_ACT_INSERT) {
+                        const uint32_t r = erank[i] & PTX_RANK_MASK;
+                        if (resolve ? op_id[i] == arg : r == want_rank) { /* ids and positions are unique: at most one row answers */
+                            A.out[q] = resolve ? (uint64_t)ptx_bitrank(al, r) : op_id[i];
+                            A.status[q] = PTX_OK;
+                        }
+                    }
+                }
+            }
+            PTX_SYNC();
+        }
+        return;
+    }
+    const uint32_t keyspace = (uint32_t)ks64;
     const uint32_t nw = (keyspace + 31) / 32, nwe = (n >> 5) + 2;
     PtxBump bp;
     bp.base = lds;

@@ -118,6 +118,7 @@ struct PtxMergeArgs {
     /* the HBM-staged path for logs beyond one CU's LDS (biglog_core.h): workgroup i works in big_scratch[big_off[i] .. big_off[i + 1]) */
     uint8_t* big_scratch;
     const uint64_t* big_off;
+    uint32_t* grid_bar; /* a large log merged by the workgroups of ONE cooperative launch: the two words (arrivals, generation) of its grid barrier, zeroed by the host */
 };
 
 #define PTX_END 0xFFFFu

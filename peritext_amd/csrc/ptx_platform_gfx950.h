@@ -94,6 +94,38 @@ PTX_DEV uint32_t ptx_append_n(uint32_t* cursor, uint32_t count) {
     return b + incl - count;
 }
 PTX_DEV uint64_t ptx_clock() { return (uint64_t)__builtin_readcyclecounter(); }
+/* ---- biglog_core.h: the team that merges ONE large log is a workgroup or — kGrid, a compile-time constant in scope — all the workgroups of a cooperative launch ---- */
+/* grid barrier (MI355X_MICROARCH.md "barrier-counter"): ONE monotonic arrival counter — arrival a belongs to barrier a / workgroups, which is over once the
+ * counter reaches the next multiple; no reset, no generation word.  One lane per workgroup talks to memory: release fence at agent scope (writes back the XCD's
+ * dirty L2 lines: the L2 slices are not coherent with each other) + an explicit wait for it (the compiler may drop the fence's own when it believes the wave's
+ * vector-memory scoreboard empty), a relaxed arrival, a RELAXED poll (acquire polls cost 2-3 x), then ONE acquire fence (a CU's L1 is never refreshed by another
+ * CU's stores).  Every workgroup must be resident: the host launches such a kernel with hipLaunchCooperativeKernel. */
+__device__ __forceinline__ void ptx_grid_sync(uint32_t* bar) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t mine = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t target = (mine / gridDim.x + 1u) * gridDim.x;
+        while ((int32_t)(__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+#define PTX_BTID (kGrid ? blockIdx.x * blockDim.x + threadIdx.x : threadIdx.x)
+#define PTX_BNT (kGrid ? gridDim.x * blockDim.x : blockDim.x)
+#define PTX_BFOR(i, n) _Pragma("nounroll") for (uint32_t i = PTX_BTID, _n = (n), _bs = PTX_BNT; i < _n; i += _bs)
+#define PTX_BLEADER if (PTX_BTID == 0u)
+#define PTX_BSYNC() do { if (kGrid) ptx_grid_sync(_gbar); else __syncthreads(); } while (0)
+#define PTX_BFIRST_WAVE if (PTX_BTID < 64u)
+/* inside the team: the workgroup's own loop and barrier (its waves talk through global memory: the CU's L1 serves them all), its index and the team's workgroups */
+#define PTX_WFOR(i, n) _Pragma("nounroll") for (uint32_t i = threadIdx.x, _wn = (n); i < _wn; i += blockDim.x)
+#define PTX_WG_SYNC() __syncthreads()
+#define PTX_BWG_ID (kGrid ? blockIdx.x : 0u)
+#define PTX_BWG_COUNT (kGrid ? gridDim.x : 1u)
+#define PTX_BLANE (threadIdx.x & 63u)
+#define PTX_BIG_KEEP(t, s, incl)   /* (every thread runs exactly one iteration of the scan's loops over the team's threads: its registers keep what it found) */
+#define PTX_BIG_RECALL(t, s, incl)
 #define PTX_G 8u /* lanes that share one member of a large child bucket */
 PTX_DEV uint32_t ptx_group_sum(uint32_t c) {
     c += (uint32_t)__shfl_xor((int)c, 1, 64);

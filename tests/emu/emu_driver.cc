@@ -156,7 +156,9 @@ extern "C" int ptx_emu_merge_big(const ptx_batch* b, ptx_log_result* res, uint32
         uint8_t* win = (uint8_t*)aligned_alloc(64, (bytes + 63) & ~63ull);
         memset(win, 0xA5, bytes);
         memset(lds, 0xA5, 4096);
-        ptx_big_merge_log(A, l, win, bytes, lds);
+        /* (the same text either way: with the permuted loop order the header lives in the scratch slice, as in the cooperative multi-workgroup launch) */
+        if (reverse == 2) ptx_big_merge_log<true>(A, l, win, bytes, nullptr);
+        else ptx_big_merge_log<false>(A, l, win, bytes, lds);
         free(win);
     }
     free(lds);

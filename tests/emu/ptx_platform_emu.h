@@ -157,6 +157,20 @@ PTX_DEV uint32_t ptx_wave_min(uint32_t v) { return v; }
 PTX_DEV uint32_t ptx_wave_max(uint32_t v) { return v; }
 
 #define PTX_NTHREADS 5u /* the emulation splits per-thread runs five ways so that the run/prefix logic is exercised */
+/* biglog_core.h's team vocabulary: one host thread plays the whole team (a workgroup, or the workgroups of a cooperative launch) */
+#define PTX_BFOR(i, n) PTX_FOR(i, n)
+#define PTX_BSYNC() ((void)0)
+#define PTX_BLEADER if (true)
+#define PTX_BNT PTX_NTHREADS
+#define PTX_BFIRST_WAVE if (true)
+#define PTX_WFOR(i, n) PTX_FOR(i, n)
+#define PTX_WG_SYNC() ((void)0)
+#define PTX_BWG_ID 0u
+#define PTX_BWG_COUNT 1u
+#define PTX_BLANE 0u
+static uint32_t ptx_emu_keep[2][PTX_NTHREADS];
+#define PTX_BIG_KEEP(t, s, incl) ptx_emu_keep[0][t] = (s), ptx_emu_keep[1][t] = (incl);
+#define PTX_BIG_RECALL(t, s, incl) (s) = ptx_emu_keep[0][t], (incl) = ptx_emu_keep[1][t];
 
 #define PTX_FORA(i0, n) for (uint32_t i0 = 0, _n = (n), _T = 1; i0 < _n; i0 += PTX_UA)
 

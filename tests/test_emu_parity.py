@@ -524,6 +524,24 @@ def test_cursors_from_elem_rank():
 
 
 @pytest.mark.parametrize("reverse", [0, 1, 2])
+def test_long_document_form_of_the_cursor_kernel_against_the_reference_fixture(reverse):
+    """Round 5: documents beyond the indexed form's 16-bit row indices (or one CU's LDS) answer their cursor queries from the alive bitmap + one pass over the
+    rows per query.  Forced here by an LDS window the indexed form does not fit: every getCursor / resolveCursor answer the reference gave (edge_cases_ref.json),
+    and both RangeErrors."""
+    g = _load("edge_cases_ref.json")
+    gen = _load("ptxgen_mini.json")
+    docs = [d["logs"] for d in gen["docs"][:3]]
+    batch = wire.encode_docs(docs)
+    res = H.emu_merge(batch)
+    q_log, q_kind, q_arg, want = H.cursor_queries(batch, g["cursors"])
+    out, status = H.emu_cursors(batch, res, q_log, q_kind, q_arg, reverse=reverse, lds_bytes=384)
+    H.check_cursor_answers(q_kind, want, out, status)
+    o2, s2 = H.emu_cursors(batch, res, [0, 0], [abi.CURSOR_GET, abi.CURSOR_RESOLVE], [10 ** 6, (999 << 32) | 1], reverse=reverse, lds_bytes=384)
+    assert [int(x) for x in s2] == [abi.ERR_INDEX_OOB, abi.ERR_ELEM_NOT_FOUND]
+    assert len(want) > 300
+
+
+@pytest.mark.parametrize("reverse", [0, 1, 2])
 def test_cursor_kernel_against_the_reference_fixture(reverse):
     """cursor_core.h (ptx_resolve_cursors): every getCursor(index) and resolveCursor(elemId) of three documents against the
     answers the reference itself gave (edge_cases_ref.json), plus the two RangeErrors (past the end, unknown element)."""

