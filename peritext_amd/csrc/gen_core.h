@@ -9,12 +9,16 @@
  * op-log columns + Change envelope of include/peritext_hip.h, written straight into HBM: a generated batch goes to
  * ptx_merge without ever visiting the host.
  *
- * State per replica, in LDS: the element list in document order,
+ * State per DOCUMENT, in LDS (round 5: ONE element list for all its replicas — the RGA order of two elements does not depend on the replica, SURVEY A.3, so a
+ * replica's list is the document's list restricted to the elements that replica has applied; rounds 1-4 kept a list per replica: three times the LDS, and every
+ * delivered insert opened a gap again):
+ *   the list of ALL elements made so far, in document order (every insert enters it when it is made, by the reference's own skip rule, micromerge.ts:630-635),
  *   key = counter << 2 | actor   (integer order == compareOpIds order, micromerge.ts:812-827; actors "doc1".."doc4"), u16 while
  *         the counters of the document stay below 2^14 (ptx_gen_small_keys), else u32: 16 bytes = 8 or 4 keys per lane and read
- *   two bit planes by list position: `dead` = tombstone, `after` = the element's `after` slot is a defined one
- *         (markOpsAfter !== undefined: set when a non-inclusive mark op ends on it, peritext.ts:240) — what `lookAfterTombstones`
- *         looks at.  The k-th visible element is one popcount scan over the `dead` plane.
+ * and per replica two bit planes by list position: `dead` = the element is NOT VISIBLE in this replica (not applied yet, or deleted), `after` = the element's
+ *         `after` slot is a defined one (markOpsAfter !== undefined: set when a non-inclusive mark op ends on it, peritext.ts:240) — what `lookAfterTombstones`
+ *         looks at (an element the replica has not applied has no such slot and is walked over like a tombstone without one).  The k-th visible element is
+ *         one popcount scan over the `dead` plane; applying a REMOTE insert is one look-up and one bit.
  * plus clock / maxOp / visible length.  Marks need no other state to GENERATE ops.
  * Everything is uniform control flow over ONE wave: lanes talk through LDS with PTX_WSYNC (a compiler fence: the LDS serves a wave's
  * accesses in order); the full barrier, which also waits for the wave's outstanding stores to HBM, only stands where rows, change
@@ -70,7 +74,7 @@ struct PtxGenArgs {
 };
 
 struct PtxGenHdr {
-    uint32_t n[PTX_GEN_MAX_R];      /* list length incl. tombstones */
+    uint32_t n[PTX_GEN_MAX_R];      /* n[0]: length of the document's list (every element made so far) */
     uint32_t vis[PTX_GEN_MAX_R];    /* visible length */
     uint32_t clock[PTX_GEN_MAX_R][PTX_GEN_MAX_R];
     uint32_t max_op[PTX_GEN_MAX_R];
@@ -89,7 +93,7 @@ PTX_HD uint64_t ptx_gen_list_stride(uint64_t list_cap) { return (list_cap + 64 +
 PTX_HD uint64_t ptx_gen_plane_words(uint64_t list_cap) { return (ptx_gen_list_stride(list_cap) >> 5) + 2; }
 PTX_HD uint64_t ptx_gen_lds_need(uint64_t R, uint64_t list_cap, uint64_t rows_per_log) {
     const uint64_t kb = ptx_gen_small_keys(R, rows_per_log) ? 2 : 4;
-    return ptx_a16(sizeof(PtxGenHdr)) + ptx_a16(kb * R * ptx_gen_list_stride(list_cap)) + 2 * ptx_a16(4 * R * ptx_gen_plane_words(list_cap)) +
+    return ptx_a16(sizeof(PtxGenHdr)) + ptx_a16(kb * ptx_gen_list_stride(list_cap)) + 2 * ptx_a16(4 * R * ptx_gen_plane_words(list_cap)) +
            ptx_a16(4 * ((rows_per_log >> 5) + 2));
 }
 
@@ -181,8 +185,8 @@ template <uint32_t kThreads, class KeyT>
 struct PtxGenDoc {
     const PtxGenArgs& A;
     PtxGenHdr* H;
-    KeyT* key0;          /* replica r's keys = key0 + r * lst_stride (no pointer table: nothing of this kernel lives in scratch) */
-    uint32_t* dead0;     /* its planes = dead0 / after0 + r * plane_words */
+    KeyT* key0;          /* the document's list */
+    uint32_t* dead0;     /* replica r's planes = dead0 / after0 + r * plane_words (no pointer table: nothing of this kernel lives in scratch) */
     uint32_t* after0;
     uint32_t lst_stride, plane_words;
     uint32_t* done;   /* pending-change bitmap of a delivery */
@@ -193,21 +197,32 @@ struct PtxGenDoc {
     uint32_t cap;
 
     PTX_MEM uint64_t log_base(uint32_t r) const { return row0 + (uint64_t)r * A.rows_per_log; }
-    PTX_MEM KeyT* keys(uint32_t r) const { return key0 + (uint64_t)r * lst_stride; }
+    PTX_MEM KeyT* keys(uint32_t) const { return key0; }
     PTX_MEM uint32_t* dead(uint32_t r) const { return dead0 + (uint64_t)r * plane_words; }
     PTX_MEM uint32_t* after(uint32_t r) const { return after0 + (uint64_t)r * plane_words; }
     /* id of the element at position p of replica r's list */
     PTX_MEM uint64_t id_at(uint32_t r, uint32_t p) const { return ptx_gen_id_of(keys(r)[p]); }
 
-    /* applyOp on replica r's list (micromerge.ts:614-640 insert, :677-695 delete; for marks only the `after` flag) */
+    /* applyOp for replica r (micromerge.ts:614-640 insert, :677-695 delete; for marks only the `after` flag).  An insert r MAKES (it carries r as its actor
+     * and is applied by r first) enters the document's list; one that arrives from another replica is already there: r only starts to see it. */
     PTX_MEM void apply(uint32_t r, const PtxGenRow& o) {
-        KeyT* L = keys(r);
-        const uint32_t n = H->n[r];
+        KeyT* L = key0;
+        const uint32_t n = H->n[0];
         if (o.action == PTX_ACT_INSERT) {
             const uint32_t key = ptx_gen_key_of(o.op_id);
+            if (((uint32_t)o.op_id & 3u) != r) { /* a delivered insert: its element is in the list since its author made it (causal delivery) */
+                const uint32_t p = ptx_list_find<KeyT>(L, n, key);
+                if (PTX_LANE0 && p != 0xFFFFFFFFu && ((dead(r)[p >> 5] >> (p & 31u)) & 1u)) {
+                    dead(r)[p >> 5] &= ~(1u << (p & 31u));
+                    H->vis[r] += 1u;
+                }
+                PTX_WSYNC();
+                return;
+            }
             uint32_t at = 0;
             if (o.ref_a != 0) at = ptx_list_find<KeyT>(L, n, ptx_gen_key_of(o.ref_a)) + 1u; /* the reference element exists (causal delivery) */
-            /* skip the elements with a greater id (concurrent inserts at the same spot, :630-635) */
+            /* skip the elements with a greater id (concurrent inserts at the same spot, :630-635): over the document's list, which already holds what the
+             * other replicas made concurrently — the position every replica will agree on */
             for (;;) {
                 PTX_BALLOT64(stop, l, at + l >= n || (uint32_t)L[at + l] < key)
                 if (stop) {
@@ -221,13 +236,17 @@ struct PtxGenDoc {
                 PTX_WSYNC();
                 return;
             }
-            /* open the gap in the keys and in both planes (the new element is alive, its `after` slot undefined) */
+            /* open the gap in the keys and in every replica's planes: the new element is visible to its author, not yet to the others; its `after` slot undefined */
             ptx_list_shift_up<KeyT>(L, at, n);
-            ptx_plane_shift_up(dead(r), at, n);
-            ptx_plane_shift_up(after(r), at, n);
+            for (uint32_t q = 0; q < A.R; ++q) {
+                ptx_plane_shift_up(dead(q), at, n);
+                ptx_plane_shift_up(after(q), at, n);
+            }
             if (PTX_LANE0) {
                 L[at] = (KeyT)key;
-                H->n[r] = n + 1u;
+                for (uint32_t q = 0; q < A.R; ++q)
+                    if (q != r) dead(q)[at >> 5] |= 1u << (at & 31u);
+                H->n[0] = n + 1u;
                 H->vis[r] += 1u;
             }
             PTX_WSYNC();
@@ -380,7 +399,7 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
     PtxGenDoc<kThreads, KeyT> G{A, H, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, A.list_cap};
     G.lst_stride = (uint32_t)ptx_gen_list_stride(A.list_cap);
     G.plane_words = (uint32_t)ptx_gen_plane_words(A.list_cap);
-    G.key0 = ptx_alloc<KeyT>(bp, G.lst_stride * R);
+    G.key0 = ptx_alloc<KeyT>(bp, G.lst_stride);
     G.dead0 = ptx_alloc<uint32_t>(bp, G.plane_words * R);
     G.after0 = ptx_alloc<uint32_t>(bp, G.plane_words * R);
     G.done = ptx_alloc<uint32_t>(bp, (N >> 5) + 2);
@@ -477,8 +496,8 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
             if (nvals > budget) nvals = budget;
             uint64_t ref = 0;
             if (index != 0u) {
-                const uint32_t p = ptx_plane_select0(G.dead(k), H->n[k], index - 1u);
-                ref = G.id_at(k, ptx_plane_after_tombstones(G.dead(k), G.after(k), H->n[k], p));
+                const uint32_t p = ptx_plane_select0(G.dead(k), H->n[0], index - 1u);
+                ref = G.id_at(k, ptx_plane_after_tombstones(G.dead(k), G.after(k), H->n[0], p));
             }
             for (uint32_t v = 0; v < nvals; ++v) {
                 const uint32_t h = ptx_gen_rand(rng, 16u);
@@ -495,7 +514,7 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
             uint32_t count = 1u + ptx_gen_rand(rng, room < 3u ? room : 3u);
             if (count > budget) count = budget;
             for (uint32_t q = 0; q < count; ++q) {
-                const uint32_t p = ptx_plane_select0(G.dead(k), H->n[k], index);
+                const uint32_t p = ptx_plane_select0(G.dead(k), H->n[0], index);
                 o.action = PTX_ACT_DELETE;
                 o.ref_a = G.id_at(k, p);
                 G.emit(k, o, nops_);
@@ -523,16 +542,16 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
             o.mark_type = (uint8_t)mt;
             o.payload = pay;
             o.side_a = PTX_SIDE_BEFORE;
-            o.ref_a = G.id_at(k, ptx_plane_select0(G.dead(k), H->n[k], start_index));
+            o.ref_a = G.id_at(k, ptx_plane_select0(G.dead(k), H->n[0], start_index));
             if (inclusive && end_index >= len) {
                 o.side_b = PTX_SIDE_END_OF_TEXT;
                 o.ref_b = 0;
             } else if (inclusive) {
                 o.side_b = PTX_SIDE_BEFORE;
-                o.ref_b = G.id_at(k, ptx_plane_select0(G.dead(k), H->n[k], end_index));
+                o.ref_b = G.id_at(k, ptx_plane_select0(G.dead(k), H->n[0], end_index));
             } else {
                 o.side_b = PTX_SIDE_AFTER;
-                o.ref_b = G.id_at(k, ptx_plane_select0(G.dead(k), H->n[k], end_index - 1u));
+                o.ref_b = G.id_at(k, ptx_plane_select0(G.dead(k), H->n[0], end_index - 1u));
             }
             G.emit(k, o, nops_);
         }

@@ -120,7 +120,10 @@ extern "C" __global__ void __launch_bounds__(256) ptx_patch_pack_kernel(const pt
 }
 
 /* On-device change() / PTXGEN (gen_core.h): one 64-thread workgroup (one wave) per document */
-extern "C" __global__ void __launch_bounds__(64) ptx_gen_kernel(PtxGenArgs A) {
+#ifndef PTX_GEN_SGPR_CAP
+#define PTX_GEN_SGPR_CAP
+#endif
+extern "C" __global__ void __launch_bounds__(64) PTX_GEN_SGPR_CAP ptx_gen_kernel(PtxGenArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_docs) ptx_gen_doc<64>(A, blockIdx.x, ptx_lds);
 }

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--flags", type=int, default=abi.FLAG_NO_ELEM_RANK)
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--threads", type=int, default=0, help="force the threads per log of every build (0 = the library's choice)")
     args = ap.parse_args()
     libs = [args.a and os.path.join(ROOT, args.a)] + [os.path.join(ROOT, b) for b in args.b]
     names = [os.path.basename(p or "libperitext_hip.so") for p in libs]
@@ -57,6 +58,9 @@ def main():
                 say("parity of %s on %s: %s" % (names[k], name, verdict))
     g = workloads.gen_config(args.config)
     engs = [Engine(0, flags=args.flags, lib_path=p) for p in libs]
+    for e in engs:
+        if args.threads:
+            e.set_launch_shape(args.threads, 0)
     state = []
     for e in engs:
         db, _ = e.generate(g["replicas"], g["ops_per_log"], g["mix"], g["mark_types"], args.docs, 2024, list_cap=2048)
