@@ -9,7 +9,7 @@
  *                            [--impl oracle|ref] --out FILE
  *       PTXGEN traces + expected output.  FILE = {config, seed, docs:[{docIndex, seed, actors,
  *       logs:[Change[] per replica], expected:[{spans, text} per replica]}]}
- *   node oracle/cli.js apply --in FILE [--impl oracle|ref] [--cursors] [--patches] [--timing] [--no-patches] --out FILE
+ *   node oracle/cli.js apply --in FILE [--impl oracle|ref] [--cursors] [--patches] [--timing] [--no-patches] [--list-key K] --out FILE
  *       FILE in  = {docs:[{logs:[Change[]...]}]} (e.g. a reference trace or a KAT);  every log is applied
  *       to a FRESH replica with applyChange (micromerge.ts:499) and flattened (peritext.ts:337).
  *       FILE out = {docs:[{expected:[{spans, text, error?}]}]}; --timing adds timing: {seconds, ops, logs} = the time spent in
@@ -72,16 +72,18 @@ function rootOf(v) {
     return v
 }
 
+/* --list-key K: the list object under root key K instead of "text" (a document may hold several: micromerge.ts:589) */
+const LIST_KEY = flag("--list-key", "text")
 function expectedOf(doc) {
     let text = []
     try {
-        text = (doc.root.text || []).slice()
+        text = (doc.root[LIST_KEY] || []).slice()
     } catch (e) {
         text = []
     }
     let spans
     try {
-        spans = doc.getTextWithFormatting(["text"])
+        spans = doc.getTextWithFormatting([LIST_KEY])
     } catch (e) {
         return { spans: null, text, error: String(e.message) }
     }

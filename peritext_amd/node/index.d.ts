@@ -57,6 +57,8 @@ export interface WireBatch {
     values: string[]; urls: string[]; logDoc: number[]; docActors: string[][]; docComments: string[][]
     /** keys of the map objects (ref_b of the PTX_ACT_MAPSET / MAPDEL / MAKELIST rows) and the JSON text of the values they set (payload) */
     keys?: string[]; mapValues?: string[]
+    /** encodeDocs(listKeys): device log l merges the list under root key logList[l] of replica logReplica[l] of its document */
+    logList?: string[]; logReplica?: number[]
 }
 export interface WireResult {
     logs: Uint32Array; values: Uint32Array; spans: Uint32Array; cintervals: Uint32Array; elemRank?: Uint32Array
@@ -115,7 +117,9 @@ export class MergeEngine {
     close(): void
     applyMaterialize(batch: WireBatch, wantPatches?: boolean): WireResult
     /** docs -> replica logs -> changes in application order  =>  spans per replica log */
-    applyChanges(docs: Change[][][]): FormatSpanWithText[][][]
+    /** without opts: the spans of the list under "text" per replica; with opts.listKeys (several list objects per document, round 5): every replica's entry is
+     *  {key: getTextWithFormatting([key])} for the root keys named */
+    applyChanges(docs: Change[][][], opts?: { listKeys: string[] }): FormatSpanWithText[][][] | Array<Array<{ [key: string]: FormatSpanWithText[] }>>
     /** spans as applyChanges + patches[doc][replica][change] = what applyChange(change) returns (micromerge.ts:499) */
     applyChangesWithPatches(docs: Change[][][]): { spans: FormatSpanWithText[][][]; patches: Patch[][][][] }
     /** getRoot() of every replica: roots[doc][replica] (ptx_root_map) */
@@ -135,7 +139,7 @@ export class MergeEngine {
     replica(docId?: number | string, actorId?: ActorId): ReplicaHandle
     flush(wantPatches?: boolean): void
 }
-export function encodeDocs(docs: Change[][][], opts?: { extraActors?: ActorId[][]; extraComments?: string[][]; textObjs?: Array<OperationId | null> }): WireBatch
+export function encodeDocs(docs: Change[][][], opts?: { extraActors?: ActorId[][]; extraComments?: string[][]; textObjs?: Array<OperationId | null>; listKeys?: string[] }): WireBatch
 export function encodeInputOps(batch: WireBatch, perLog: InputOperation[][][], actors: ActorId[]): WireInputOps
 export function packEnvelope(batch: WireBatch): WireBatch
 export function unpackEnvelope(batch: WireBatch): WireBatch

@@ -95,8 +95,13 @@ function splitOpId(id) {
  *  opts.extraActors / opts.extraComments: per document, actor names / comment ids that get a rank although no change uses them
  *  yet (a replica about to make its first change, comment ids a later InputOperation introduces: ranks are positions in the
  *  document's sorted id list, so they are reserved before the rows that use them exist).  opts.textObjs: per document the opId
- *  of the text list when the logs of this batch do not hold its makeList (a batch of newly arrived changes only). */
+ *  of the text list when the logs of this batch do not hold its makeList (a batch of newly arrived changes only).
+ *  opts.listKeys (round 5; default ["text"]): the LIST objects of the root map to merge, by key.  The engine merges one list object per device log; a document that
+ *  holds several (micromerge.ts:589: makeList under any key; :534-571: applyOp takes any list object) becomes one device log per (replica, key), in that order — each
+ *  with the replica's whole Change envelope and, of the list ops, those of ITS list (the ops on the replica's other list objects are rows without effect there);
+ *  batch.logList[l] names the key of device log l, batch.logReplica[l] its replica within the document. */
 function encodeDocs(docs, opts) {
+    const listKeys = (opts && opts.listKeys) || ["text"]
     const extraActors = (opts && opts.extraActors) || [], extraComments = (opts && opts.extraComments) || []
     const textObjs = (opts && opts.textObjs) || [] /* per document: opId of the text list when the logs do not hold its makeList (or one entry per log) */
     /* opts.seed: the tables of an earlier batch of the same documents — ids already given stay (the rows of Changes appended to a resident batch) */
@@ -117,7 +122,7 @@ function encodeDocs(docs, opts) {
     const logOff = [0]
     const chgOff = [0], chgActor = [], chgSeq = [], chgNops = [], chgDepsRows = []
     let maxActors = 1
-    const logDoc = [], docActors = [], docComments = []
+    const logDoc = [], docActors = [], docComments = [], logList = [], logReplica = []
     docs.forEach((logs, d) => {
         const actors = new Set(), comments = new Set()
         for (const log of logs)
@@ -150,9 +155,10 @@ function encodeDocs(docs, opts) {
             const [ctr, actor] = splitOpId(s)
             return (BigInt(ctr) << 32n) | BigInt(arank.get(actor))
         }
-        logs.forEach((log, r) => {
+        logs.forEach((log, r) => listKeys.forEach(lkey => {
             const t0 = Array.isArray(textObjs[d]) ? textObjs[d][r] : textObjs[d]
             let textObj = t0 === undefined ? null : t0, nrows = 0
+            const otherLists = new Set() /* the replica's list objects that are not this device log's: their ops are rows without effect here */
             for (const ch of log) {
                 /* the Change envelope (micromerge.ts:60-71): what applyChange's admission checks (:499-511) */
                 chgActor.push(arank.get(ch.actor))
@@ -162,9 +168,9 @@ function encodeDocs(docs, opts) {
                 for (const op of ch.ops) {
                     const row = { opId: encId(op.opId), refA: 0n, refB: 0n, payload: 0, action: ACT.NOP, markType: 0, sideA: 0, sideB: 0 }
                     const onRoot = op.obj === undefined || op.obj === null || op.obj === ROOT || typeof op.obj === "symbol"
-                    if (op.action === "makeList" && onRoot && op.key === "text" && textObj === null) {
+                    if (op.action === "makeList" && onRoot && op.key === lkey && textObj === null) {
                         row.action = ACT.MAKELIST
-                        row.refB = BigInt(intern(keys, keyIx, "text")) /* also a write of the root map's key */
+                        row.refB = BigInt(intern(keys, keyIx, lkey)) /* also a write of the root map's key */
                         textObj = op.opId
                     } else if (textObj !== null && op.obj === textObj) {
                         if (op.action === "set" && op.insert) {
@@ -205,12 +211,14 @@ function encodeDocs(docs, opts) {
                             row.action = ACT.MAPSET
                             row.markType = op.action === "makeMap" ? MAPV.MAP : op.action === "makeList" ? MAPV.LIST : MAPV.SCALAR
                             if (op.action === "set") row.payload = intern(mapValues, mapValueIx, JSON.stringify(op.value === undefined ? null : op.value))
+                            if (op.action === "makeList") otherLists.add(op.opId)
                         }
+                    } else if (otherLists.has(op.obj) && (op.action === "addMark" || op.action === "removeMark" || op.elemId !== undefined || op.insert)) {
+                        /* an op on ANOTHER list object of this replica (merged by its own device log when its key is in listKeys): PTX_ACT_NOP here */
                     } else if (op.action === "addMark" || op.action === "removeMark" || op.elemId !== undefined || op.insert) {
-                        /* a list op whose object is not the document's text list: the reference throws RangeError("Object does not exist")
-                         * (micromerge.ts:538) when there is no such object yet, or edits a second list object.  This engine holds ONE text list
-                         * per document (the first root makeList of key "text"; INTEGRATION.md): rejected here, never a silent no-op */
-                        throw new RangeError("list op " + String(op.opId) + " on an object that is not the document's text list (one text list per document is supported)")
+                        /* a list op whose object no earlier makeList of this log created: the reference throws RangeError("Object does not exist")
+                         * (micromerge.ts:538): rejected here, never a silent no-op */
+                        throw new RangeError("list op " + String(op.opId) + " on an object that no earlier makeList of this log created")
                     }
                     for (const k of Object.keys(rows)) rows[k].push(row[k])
                     nrows++
@@ -219,7 +227,9 @@ function encodeDocs(docs, opts) {
             logOff.push(logOff[logOff.length - 1] + nrows)
             chgOff.push(chgActor.length)
             logDoc.push(d)
-        })
+            logList.push(lkey)
+            logReplica.push(r)
+        }))
     })
     const nLogs = logOff.length - 1
     const batch = {
@@ -241,6 +251,10 @@ function encodeDocs(docs, opts) {
         chgDeps: new Uint32Array(chgActor.length * maxActors),
         maxActors,
         values, urls, logDoc, docActors, docComments, keys, mapValues,
+    }
+    if (listKeys.length !== 1 || listKeys[0] !== "text") {
+        batch.logList = logList
+        batch.logReplica = logReplica
     }
     chgDepsRows.forEach((row, i) => row.forEach(([a, v]) => { batch.chgDeps[i * maxActors + a] = v }))
     packEnvelope(batch)
@@ -675,12 +689,20 @@ class MergeEngine {
         }
         return { docs, spans, kernelMs: raw.kernelMs, batch }
     }
-    /** docs: Change[][][]  ->  FormatSpanWithText[][][] (doc -> replica -> spans).  A failed log throws RangeError like the reference. */
-    applyChanges(docs) {
-        const batch = encodeDocs(docs)
+    /** docs: Change[][][]  ->  FormatSpanWithText[][][] (doc -> replica -> spans).  A failed log throws RangeError like the reference.
+     *  opts.listKeys (round 5): the list objects of the root map to materialise, by key — then every replica's entry is an object {key: spans}
+     *  (getTextWithFormatting([key]) of that replica, micromerge.ts:516) instead of the spans of "text" alone. */
+    applyChanges(docs, opts) {
+        const listKeys = opts && opts.listKeys
+        const batch = encodeDocs(docs, listKeys ? { listKeys } : undefined)
         const res = this.applyMaterialize(batch)
         let log = 0
-        return docs.map(logs => logs.map(() => decodeSpans(batch, res, log++)))
+        if (!listKeys) return docs.map(logs => logs.map(() => decodeSpans(batch, res, log++)))
+        return docs.map(logs => logs.map(() => {
+            const out = {}
+            for (const k of listKeys) out[k] = decodeSpans(batch, res, log++)
+            return out
+        }))
     }
     /** Per-document digests (2 x u64 as BigInt pairs) of every log: equal digests <=> deep-equal spans. */
     digests(docs) {
@@ -770,16 +792,20 @@ class MergeEngine {
              * Change is refused once — like the reference's RangeError("Object does not exist") out of applyChange (micromerge.ts:538) — and the replica
              * stays readable (ADVICE r3: thrown later, by every re-encode of the queued Change, it made the replica unreadable for good) */
             let textObj = rep.textObj === undefined ? null : rep.textObj
+            const lists = new Set(rep.otherLists || []) /* the replica's other list objects (round 5: their ops are accepted — rows without effect on the text list; the batch API, applyChanges(docs, {listKeys}), materialises them) */
             for (const op of change.ops || []) {
                 const onRoot = op.obj === undefined || op.obj === null || op.obj === ROOT || typeof op.obj === "symbol"
                 if (op.action === "makeList" && onRoot && op.key === "text" && textObj === null) textObj = op.opId
                 else if (textObj !== null && op.obj === textObj) {
                     if (op.action === "set" && op.insert && typeof op.value !== "string") throw new Error("Expected value inserted into text to be a string")
-                } else if (op.key !== undefined && op.elemId === undefined && ["set", "del", "makeMap", "makeList"].indexOf(op.action) >= 0) continue
+                } else if (op.key !== undefined && op.elemId === undefined && ["set", "del", "makeMap", "makeList"].indexOf(op.action) >= 0) {
+                    if (op.action === "makeList") lists.add(op.opId)
+                } else if (lists.has(op.obj) && (op.action === "addMark" || op.action === "removeMark" || op.elemId !== undefined || op.insert)) continue
                 else if (op.action === "addMark" || op.action === "removeMark" || op.elemId !== undefined || op.insert)
-                    throw new RangeError("Object does not exist: list op " + String(op.opId) + " on an object that is not the document's text list (one text list per document is supported)")
+                    throw new RangeError("Object does not exist: list op " + String(op.opId) + " on an object that no earlier makeList of this replica created")
             }
             rep.textObj = textObj
+            rep.otherLists = lists
             rep.clock[change.actor] = change.seq
             rep.changes.push(change)
             rep.spans = null

@@ -70,6 +70,9 @@ class Batch:
     map_values: list = field(default_factory=list)  # value id -> JSON text of the value a PTX_ACT_MAPSET row sets
     # the wide envelope column (ptx_batch.chg_env_hi): high halves of chg_env's values, None while every seq / dep fits 16 bits
     chg_env_hi: np.ndarray = None
+    # a document with several list objects (encode_docs(list_keys=...)): device log l merges the list under root key log_list[l] of replica log_replica[l]
+    log_list: list = None
+    log_replica: list = None
 
     @property
     def n_logs(self):
@@ -197,8 +200,14 @@ def _pack(ctr, rank):
     return (int(ctr) << 32) | int(rank)
 
 
-def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
+def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None, list_keys=("text",)):
     """docs: list of docs; a doc is a list of replica logs; a replica log is a list of Change dicts.
+
+    list_keys (round 5): the LIST objects of the root map to merge, by key.  The engine merges one list object per device log; a document that holds several
+    (micromerge.ts:589: makeList under any key; :534-571: applyOp takes any list object) becomes one device log per (replica, key), in that order — each with the
+    replica's whole Change envelope (causal admission is the replica's, not the list's) and, of the list ops, those of ITS list: the ops on the replica's other
+    list objects are rows without effect there.  `Batch.log_list[l]` names the key of device log l, `Batch.log_replica[l]` its replica within the document.
+    The default merges the list under "text" alone, as the reference's editor does (bridge.ts).
 
     All replicas of a doc share actor ranks and comment-id ranks, so their digests are comparable.
     extra_actors / extra_comments: per doc, actor names / comment ids that get a rank although no change of the batch uses them
@@ -223,6 +232,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
     chg_off = [0]
     chg_actor, chg_seq, chg_nops, chg_deps_rows = [], [], [], []
     log_doc, doc_actors, doc_comments = [], [], []
+    log_list, log_replica = [], []
     max_actors = 1
     for d, logs in enumerate(docs):
         actors, comments = set(), set()
@@ -258,8 +268,10 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
             ctr, actor = split_op_id(s)
             return _pack(ctr, arank[actor])
 
-        for log in logs:
+        for rep_ix, lkey in ((r_, k_) for r_ in range(len(logs)) for k_ in list_keys):
+            log = logs[rep_ix]
             text_obj = text_objs[d] if text_objs else None
+            other_lists = set()  # the replica's list objects that are not this device log's: their ops are rows without effect here
             nrows = 0
             for ch in log:
                 chg_actor.append(arank[ch["actor"]])
@@ -271,8 +283,8 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
                     row = dict(op_id=enc_id(op["opId"]), ref_a=0, ref_b=0, payload=0, action=abi.ACT_NOP, mark_type=0, side_a=0, side_b=0)
                     obj = op.get("obj")
                     on_root = obj is None or obj == ROOT
-                    if act == "makeList" and on_root and op.get("key") == "text" and text_obj is None:
-                        row.update(action=abi.ACT_MAKELIST, ref_b=intern(keys, key_ix, "text"))  # also a write of the root map's key
+                    if act == "makeList" and on_root and op.get("key") == lkey and text_obj is None:
+                        row.update(action=abi.ACT_MAKELIST, ref_b=intern(keys, key_ix, lkey))  # also a write of the root map's key
                         text_obj = op["opId"]
                     elif text_obj is not None and obj == text_obj:
                         if act == "set" and op.get("insert"):
@@ -314,17 +326,23 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
                             row["mark_type"] = abi.MAPV_MAP if act == "makeMap" else abi.MAPV_LIST if act == "makeList" else abi.MAPV_SCALAR
                             if act == "set":
                                 row["payload"] = intern(mvals, mval_ix, json.dumps(op.get("value"), sort_keys=True, ensure_ascii=False, separators=(",", ":")))
+                            if act == "makeList":
+                                other_lists.add(op["opId"])
+                    elif obj in other_lists and (act in ("addMark", "removeMark") or "elemId" in op or op.get("insert")):
+                        pass  # an op on ANOTHER list object of this replica (merged by its own device log when its key is in list_keys): PTX_ACT_NOP here
                     elif act in ("addMark", "removeMark") or "elemId" in op or op.get("insert"):
                         # A list op whose object is not the document's text list: the reference throws RangeError("Object does not exist")
                         # (micromerge.ts:538) when no such object exists yet, or edits a second list object.  This engine holds ONE text
                         # list per document (the first root makeList of key "text"): rejected here, never a silent no-op.
-                        raise ValueError("list op %s on object %r, which is not the document's text list (one text list per document is supported)" % (op.get("opId"), obj))
+                        raise ValueError("list op %s on object %r, which no earlier makeList of this log created" % (op.get("opId"), obj))
                     for k, v in row.items():
                         cols[k].append(v)
                     nrows += 1
             log_off.append(log_off[-1] + nrows)
             chg_off.append(len(chg_actor))
             log_doc.append(d)
+            log_list.append(lkey)
+            log_replica.append(rep_ix)
     deps = np.zeros((len(chg_actor), max_actors), dtype=np.uint32)
     for i, row in enumerate(chg_deps_rows):
         for a, v in row.items():
@@ -341,6 +359,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None):
         side_b=np.asarray(cols["side_b"], dtype=np.uint8), chg_off=u64(chg_off),
         chg_hdr=chg_hdr, chg_env=chg_env, max_actors=max_actors,
         values=values, urls=urls, log_doc=log_doc, doc_actors=doc_actors, doc_comments=doc_comments, keys=keys, map_values=mvals, chg_env_hi=chg_env_hi,
+        log_list=log_list if tuple(list_keys) != ("text",) else None, log_replica=log_replica if tuple(list_keys) != ("text",) else None,
     )
 
 

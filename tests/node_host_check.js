@@ -21,14 +21,29 @@ const norm = spans => spans.map(s => ({ text: s.text, marks: JSON.parse(JSON.str
 
 if (cmd === "encode") {
     const gen = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
-    const b = host.encodeDocs(gen.docs.map(d => d.logs))
-    const out = { nLogs: b.nLogs, nOps: b.nOps, values: b.values, urls: b.urls, docComments: b.docComments }
+    const b = host.encodeDocs(gen.docs.map(d => d.logs), process.argv[4] ? { listKeys: process.argv[4].split(",") } : undefined) /* argv[4]: list keys (several list objects per document) */
+    const out = { nLogs: b.nLogs, nOps: b.nOps, values: b.values, urls: b.urls, docComments: b.docComments, logList: b.logList || null, logReplica: b.logReplica || null }
     for (const k of ["logOff", "opId", "refA", "refB", "payload", "action", "markType", "sideA", "sideB", "logHdr", "chgOff", "chgActor", "chgSeq", "chgNops", "chgDeps", "chgHdr", "chgEnv"]) out[k] = sha(b[k])
     out.chgEnvHi = b.chgEnvHi ? sha(b.chgEnvHi) : null
     out.maxActors = b.maxActors
     out.keys = b.keys
     out.mapValues = b.mapValues.map(v => JSON.parse(v))
     console.log(JSON.stringify(out))
+} else if (cmd === "multilist") {
+    /* GPU: a document with two list objects through MergeEngine.applyChanges(docs, {listKeys}) against what the oracle's replicas show (argv[3]: {logs, expected: {key: [{spans}]}}) */
+    const t = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+    const engine = new host.MergeEngine()
+    const keys = Object.keys(t.expected)
+    const got = engine.applyChanges([t.logs], { listKeys: keys })
+    let checked = 0
+    for (let r = 0; r < t.logs.length; r++)
+        for (const k of keys) {
+            assert.deepStrictEqual(norm(got[0][r][k]), norm(t.expected[k][r].spans), "replica " + r + " list " + k)
+            checked++
+        }
+    assert.deepStrictEqual(norm(engine.applyChanges([t.logs])[0][0]), norm(t.expected.text[0].spans)) /* the default: "text" alone */
+    engine.close()
+    console.log(JSON.stringify({ ok: true, checked }))
 } else if (cmd === "load") {
     const addon = require(path.join(__dirname, "..", "peritext_amd", "node", "peritext_node.node"))
     const v = addon.open(path.join(__dirname, "..", "peritext_amd", "lib", "libperitext_hip.so"))

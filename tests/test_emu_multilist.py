@@ -1,0 +1,84 @@
+"""Documents with more than one list object (VERDICT r4 missing #5; reference/src/micromerge.ts:534-571: applyOp takes any list object, :589: makeList under any
+key).  The engine merges one list object per device log: wire.encode_docs(list_keys=...) gives one device log per (replica, key).  Expected values: the oracle
+and the type-erased reference (getTextWithFormatting([key]) of replicas that applied the same logs)."""
+import os
+
+import pytest
+
+import helpers as H
+from peritext_amd import abi, wire
+
+pytestmark = [pytest.mark.skipif(not os.path.exists(H.EMU_LIB), reason="tests/emu/libperitext_emu.so not built (run __graft_entry__.build())"),
+              pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")]
+
+
+def two_list_document():
+    """Two replicas, two lists ("text" and "notes") and a nested map, edited concurrently; every Change made by the oracle's change()."""
+    a1 = H.oracle_change([[[]]], [[
+        [{"path": [], "action": "makeList", "key": "text"}],
+        [{"path": [], "action": "makeList", "key": "notes"}, {"path": [], "action": "makeMap", "key": "meta"}],
+        [{"path": ["text"], "action": "insert", "index": 0, "values": list("The quick fox")}],
+        [{"path": ["notes"], "action": "insert", "index": 0, "values": list("todo: jump")}, {"path": ["meta"], "action": "set", "key": "title", "value": "draft"}],
+        [{"path": ["notes"], "action": "addMark", "markType": "strong", "startIndex": 0, "endIndex": 4}],
+        [{"path": ["text"], "action": "addMark", "markType": "comment", "attrs": {"id": "c-1"}, "startIndex": 4, "endIndex": 9}],
+    ]], ["alice"])
+    b1 = H.oracle_change([[a1]], [[
+        [{"path": ["notes"], "action": "insert", "index": 5, "values": list(" (bob)")}],
+        [{"path": ["text"], "action": "delete", "index": 0, "count": 4}],
+        [{"path": ["text"], "action": "addMark", "markType": "em", "startIndex": 0, "endIndex": 5}, {"path": ["notes"], "action": "delete", "index": 0, "count": 2}],
+        [{"path": ["notes"], "action": "addMark", "markType": "link", "attrs": {"url": "https://n.example"}, "startIndex": 1, "endIndex": 6}],
+    ]], ["bob"])
+    a2 = H.oracle_change([[a1]], [[
+        [{"path": ["notes"], "action": "insert", "index": 5, "values": list("!!")}, {"path": ["text"], "action": "insert", "index": 13, "values": list(" jumps")}],
+        [{"path": ["notes"], "action": "removeMark", "markType": "strong", "startIndex": 2, "endIndex": 8}],
+        [{"path": ["text"], "action": "delete", "index": 2, "count": 2}],
+    ]], ["alice"])
+    return [a1 + a2 + b1, a1 + b1 + a2]
+
+
+def _expected(logs, key, impl):
+    with H.tempfile.TemporaryDirectory() as td:
+        inp, out = os.path.join(td, "in.json"), os.path.join(td, "out.json")
+        with open(inp, "w") as f:
+            H.json.dump({"docs": [{"logs": logs}]}, f)
+        H.run_node(["oracle/cli.js", "apply", "--in", inp, "--impl", impl, "--list-key", key, "--out", out])
+        with open(out) as f:
+            return H.json.load(f)["docs"][0]["expected"]
+
+
+@pytest.mark.parametrize("impl", ["oracle", "ref"])
+def test_two_lists_of_one_document(impl):
+    if impl == "ref" and not os.path.exists(os.path.join(H.ROOT, "oracle", "_ref", "micromerge.js")):
+        pytest.skip("oracle/_ref not built")
+    logs = two_list_document()
+    batch = wire.encode_docs([logs], list_keys=("text", "notes"))
+    assert batch.n_logs == 4 and batch.log_list == ["text", "notes", "text", "notes"] and batch.log_replica == [0, 0, 1, 1]
+    want = {k: _expected(logs, k, impl) for k in ("text", "notes")}
+    assert want["notes"][0]["spans"] != want["text"][0]["spans"] and len(want["notes"][0]["spans"]) > 1
+    for reverse in (0, 1, 2):
+        for adm in (False, True):
+            res = H.emu_merge(batch, reverse=reverse, admission=adm)
+            assert (res.logs["status"] == 0).all()
+            for log in range(4):
+                e = want[batch.log_list[log]][batch.log_replica[log]]
+                assert H.norm_spans(wire.decode_spans(batch, res, log)) == H.norm_spans(e["spans"]), (log, reverse, adm)
+            # replicas converge, list by list; the two lists are different documents
+            assert (res.logs["digest"][0] == res.logs["digest"][2]).all() and (res.logs["digest"][1] == res.logs["digest"][3]).all()
+            assert not (res.logs["digest"][0] == res.logs["digest"][1]).all()
+    # the default still merges "text" alone, the other list's ops rows without effect
+    one = wire.encode_docs([logs])
+    r1 = H.emu_merge(one)
+    assert one.n_logs == 2 and one.log_list is None
+    assert H.norm_spans(wire.decode_spans(one, r1, 0)) == H.norm_spans(want["text"][0]["spans"])
+    # the root map names both lists and the nested map
+    roots = wire.decode_root(batch, H.emu_root_map(batch), 0) if hasattr(H, "emu_root_map") else None
+    if roots is not None:
+        assert roots["text"] == {"$list": True} and roots["notes"] == {"$list": True} and roots["meta"] == {"title": "draft"}
+
+
+def test_a_list_op_on_an_object_nobody_made_is_still_refused():
+    logs = two_list_document()
+    bad = [dict(c) for c in logs[0]]
+    bad[3] = dict(bad[3], ops=[dict(bad[3]["ops"][0], obj="999@zed")] + bad[3]["ops"][1:])
+    with pytest.raises(ValueError):
+        wire.encode_docs([[bad]], list_keys=("text", "notes"))
