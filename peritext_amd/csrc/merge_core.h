@@ -69,9 +69,6 @@
 #endif
 #define PTX_NCLK 32 /* phase stamps of the diagnostic build (slot PTX_CLK_EXACT_WALKS counts the logs whose admission was walked twice) */
 #define PTX_CLK_EXACT_WALKS 15
-#ifndef PTX_PROBE_P1_RA
-#define PTX_PROBE_P1_RA 0 /* probe (timing experiments only): the row pass also streams ref_a, coalesced, and does nothing with it */
-#endif
 #ifndef PTX_KO_P5A_RA
 #define PTX_KO_P5A_RA 0 /* knock-out (WRONG results, timing experiments only): the mark ops do not read ref_a a second time */
 #endif
@@ -822,21 +819,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_full = N / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
     static_assert(PTX_U1 == 3, "three class bytes per dword; the fourth byte read belongs to the next thread's first row");
     uint64_t id[PTX_U1], id_n[PTX_U1];
-#if PTX_PROBE_P1_RA
-    uint64_t pra[PTX_U1], pra_n[PTX_U1]; /* probe: what one more coalesced column costs the row pass */
-#endif
     uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
     /* this thread's PTX_U1 consecutive rows of a step.  A wave whose rows all exist reads them from one address; the wave that
      * holds the end of the log clamps every row index (effects of the rows past the end are masked).  The two byte columns are
      * read with ONE (unaligned) 4-byte load each: the library pads its copies of them by PTX_BYTE_PAD bytes. */
-#if PTX_PROBE_P1_RA
-#define PTX_P1_PROBE_LOAD(id_, r0_)                                         \
-    if (PTX_WAVE_FIRST((r0_) / PTX_U1) + PTX_WS <= p1_full) {               \
-        if (&id_[0] == &id[0]) { PTX_P1_IDS(pra, ref_a + (r0_)) } else { PTX_P1_IDS(pra_n, ref_a + (r0_)) } \
-    }
-#else
-#define PTX_P1_PROBE_LOAD(id_, r0_)
-#endif
 #define PTX_P1_LOAD(g_, id_, a_, mt_)                                       \
 {                                                                       \
     const uint32_t r0_ = (g_) * PTX_U1;                                 \
@@ -850,7 +836,6 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }                                                                   \
     PTX_P1_BYTES(action, r0_, a_)                                       \
     PTX_P1_BYTES(mark_type, r0_, mt_)                                   \
-    PTX_P1_PROBE_LOAD(id_, r0_)                                         \
 }
     /* ---- P0: causal admission (micromerge.ts:499-511), when the batch carries the Change envelope ----
      * Sequential rule: change c of actor a is admitted iff seq == clock[a] + 1 and clock[b] >= deps[b] for all b,
@@ -1373,21 +1358,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         };
         /* two register sets in turn (no copies from "next" to "current"): the even steps' rows arrive in id / a4 / mt4, the odd ones' in id_n / a4_n / mt4_n;
          * a wave that has no row left in a step (wave-uniform) has none in the later ones either */
-#if PTX_PROBE_P1_RA
-#define PTX_P1_PROBE_USE(id_)                                                                                                     \
-    if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) {                                                                              \
-        const uint64_t* q_ = &id_[0] == &id[0] ? pra : pra_n;                                                                  \
-        _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) err4 |= q_[u] == 0xDEADBEEFCAFEF00Dull ? 0x80u : 0u;               \
-    }
-#else
-#define PTX_P1_PROBE_USE(id_)
-#endif
 #define PTX_P1_STEP(st_, id_, a_, mt_, idn_, an_, mtn_)                                                                      \
     {                                                                                                                        \
         const uint32_t g_ = PTX_G_OF(st_, p1_steps);                                                                          \
         if (PTX_WAVE_FIRST(g_) >= p1_groups) break;                                                                           \
         PTX_P1_LOAD(PTX_G_OF((st_) + 1u, p1_steps), idn_, an_, mtn_) /* the next step's rows are in flight while this one is processed */ \
-        PTX_P1_PROBE_USE(id_)                                                                                                 \
         if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) p1_rows(std::false_type(), g_, PTX_U1, id_, a_, mt_);                     \
         else p1_rows(std::true_type(), g_, g_ * PTX_U1 < N ? (N - g_ * PTX_U1 < PTX_U1 ? N - g_ * PTX_U1 : PTX_U1) : 0u, id_, a_, mt_); \
     }
