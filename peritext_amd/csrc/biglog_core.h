@@ -23,7 +23,7 @@
 #define PTX_BIG_SORT_TILE 4096u /* keys (a power of two) a workgroup sorts between two team barriers */
 #endif
 #ifndef PTX_BIG_COMMENT_OPS_PER_ID
-#define PTX_BIG_COMMENT_OPS_PER_ID 1024u /* comment ops with a visible interval one comment id may have in a log beyond one CU's LDS (their sweep is quadratic, one lane per id) */
+#define PTX_BIG_COMMENT_OPS_PER_ID 1024u /* comment ops with a visible interval up to which ONE lane sweeps a comment id (quadratic); an id with more is swept by the whole team through a range-chmax tree (round 5) */
 #endif
 struct PtxBigEntry { /* one comment op that covers something: visible interval, application index (row), add / remove */
     uint32_t lo, hi, t, add;
@@ -53,7 +53,7 @@ PTX_HD uint64_t ptx_big_need(uint64_t N, const ptx_log_hdr& h, uint64_t C, uint6
     b += ptx_a64(8 * P2) + ptx_a64(4 * (n + 3));                       /* sort keys, bucket starts */
     b += ptx_a64(8 * (2 * n + 3));                                     /* Euler tour */
     b += ptx_a64(8 * (nwe + 1));                                       /* alive {bits, prefix} */
-    b += 2 * ptx_a64(4 * (Kid + 2)) + ptx_a64(16 * (Kc + 1)) + ptx_a64(4 * (Kc + 1)); /* comments: per-id counters, entries, ids */
+    b += 2 * ptx_a64(4 * (Kid + 2)) + ptx_a64(16 * (Kc + 1)) + ptx_a64(4 * (Kc + 1)) + ptx_a64(4 * (Kc / PTX_BIG_COMMENT_OPS_PER_ID + 2)); /* comments: per-id counters, entries, ids, the heavy ids */
     b += 4 * ptx_a64(8 * 2 * PV);                                      /* four LWW trees */
     b += ptx_a64(4 * (n + 2)) + ptx_a64(8 * (nwe + 1)) + ptx_a64(4 * (nwe + 1)); /* attr, span starts, comment breaks */
     return b + 256;
@@ -239,6 +239,8 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     uint32_t* ccur = (uint32_t*)take(4ull * (Kid + 2));
     PtxBigEntry* cent = (PtxBigEntry*)take(16ull * (Kc + 1));
     uint32_t* cidx = (uint32_t*)take(4ull * (Kc + 1)); /* comment-mark ordinal -> mark index */
+    const uint32_t hvy_cap = Kc / PTX_BIG_COMMENT_OPS_PER_ID + 2u;
+    uint32_t* hvy = (uint32_t*)take(4ull * hvy_cap); /* the comment ids with more ops than one lane sweeps */
     const uint32_t PV = (uint32_t)ptx_pow2_ge((uint64_t)n + 1);
     unsigned long long* tree[4];
     for (int ty = 0; ty < 4; ++ty) tree[ty] = (unsigned long long*)take(8ull * 2 * PV);
@@ -611,21 +613,104 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             }
         }
         PTX_BSYNC();
-        /* the sweep of one id is ONE lane's work and quadratic in the id's ops (with a visible interval), read from HBM here: bounded, so that a log with tens of
-         * thousands of comment ops on one id is a capacity report and not minutes in one lane */
+        /* The sweep of one id is ONE lane's work and quadratic in the id's ops (with a visible interval), read from HBM here.  An id with more than
+         * PTX_BIG_COMMENT_OPS_PER_ID of them (round 5: no longer a capacity report) is swept by the whole TEAM instead, one such id at a time: its presence function
+         * — "add" of the LAST-applied covering op per visible position — is a range-chmax tree over the positions of (application index + 1) << 1 | add (the first
+         * LWW tree's storage: those are built after this phase), queried once per position into a bitmap whose runs of ones are the id's intervals. */
         PTX_BLEADER { H->cur[7] = 0; }
         PTX_BSYNC();
-        PTX_BFOR(c, Kid) ptx_atomic_max(&H->cur[7], ccnt[c + 1] - ccnt[c]);
+        PTX_BFOR(c, Kid) {
+            if (ccnt[c + 1] - ccnt[c] > PTX_BIG_COMMENT_OPS_PER_ID) {
+                const uint32_t s2 = ptx_append(&H->cur[7], true);
+                if (s2 < hvy_cap) hvy[s2] = c;
+            }
+        }
         PTX_BSYNC();
-        if (H->cur[7] > PTX_BIG_COMMENT_OPS_PER_ID) return PTX_ERR_CAPACITY;
-        PTX_BFOR(c, Kid + 1) ccur[c] = c < Kid ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
+        const uint32_t nheavy = H->cur[7] < hvy_cap ? H->cur[7] : hvy_cap; /* (at most Kc / PTX_BIG_COMMENT_OPS_PER_ID ids can be that heavy: the list holds them all) */
         PTX_BSYNC();
+        uint32_t TVc = 1;
+        while (TVc < V) TVc <<= 1;
+        const uint32_t vwords = (V + 31u) >> 5;
+        /* intervals of heavy id c: counted (emit = false) or written as rows row0 .. (emit = true); the same answer in every thread */
+        auto heavy_sweep = [&](uint32_t c, uint32_t row0, bool emit, uint64_t& h1, uint64_t& h2) -> uint32_t {
+            const uint32_t e0 = ccnt[c], m = ccnt[c + 1] - e0;
+            PTX_BFOR(p, 2u * TVc) tree[0][p] = 0;
+            PTX_BFOR(w, nwe + 1) {
+                PtxBitWord z;
+                z.bits = 0;
+                z.pre = 0;
+                st[w] = z;
+            }
+            PTX_BSYNC();
+            PTX_BFOR(j, m) {
+                const PtxBigEntry e = cent[e0 + j];
+                ptx_big_chmax(tree[0], TVc, e.lo, e.hi, (((unsigned long long)e.t + 1ull) << 1) | (unsigned long long)(e.add & 1u));
+            }
+            PTX_BSYNC();
+            PTX_BFOR(w, vwords) {
+                uint32_t bits = 0;
+                for (uint32_t bq = 0; bq < 32u; ++bq) {
+                    const uint32_t q = (w << 5) + bq;
+                    if (q < V && (ptx_big_query(tree[0], TVc, q) & 1ull)) bits |= 1u << bq;
+                }
+                st[w].bits = bits;
+            }
+            PTX_BSYNC();
+            PTX_BFOR(w, nwe + 1) { /* the starts of the runs of ones: a one whose lower neighbour is a zero */
+                const uint32_t bw = st[w].bits, prev = w ? st[w - 1].bits >> 31 : 0u;
+                st[w].pre = ptx_popc(bw & ~((bw << 1) | prev));
+            }
+            PTX_BSYNC();
+            const uint32_t total = ptx_big_scan<kGrid, uint32_t, 2>(&st[0].pre, nwe + 1, part, _gbar);
+            if (emit) {
+                PTX_BFOR(w, vwords) {
+                    const uint32_t bw = st[w].bits, prev = w ? st[w - 1].bits >> 31 : 0u;
+                    uint32_t starts = bw & ~((bw << 1) | prev), row = row0 + st[w].pre;
+                    while (starts) {
+                        const uint32_t sq = (w << 5) + (uint32_t)__builtin_ctz(starts);
+                        starts &= starts - 1u;
+                        uint32_t eq = sq; /* the first zero behind the start (bits from V on are zero; the bitmap has a spare word) */
+                        for (;;) {
+                            const uint32_t ww = eq >> 5, zz = ~st[ww].bits & (0xFFFFFFFFu << (eq & 31u));
+                            if (zz) {
+                                eq = (ww << 5) + (uint32_t)__builtin_ctz(zz);
+                                break;
+                            }
+                            eq = (ww + 1u) << 5;
+                        }
+                        ptx_cinterval ci;
+                        ci.id = c;
+                        ci.start = sq;
+                        ci.end = eq;
+                        A.out_cints[base + row++] = ci;
+                        ptx_atomic_or(&brkbits[sq >> 5], 1u << (sq & 31u));
+                        ptx_atomic_or(&brkbits[eq >> 5], 1u << (eq & 31u));
+                        ptx_digest_item(h1, h2, 3u, c, sq, eq);
+                    }
+                }
+            }
+            PTX_BSYNC();
+            return total;
+        };
+        uint64_t h1 = 0, h2 = 0;
+        PTX_BFOR(c, Kid + 1) {
+            const uint32_t m = c < Kid ? ccnt[c + 1] - ccnt[c] : 0u;
+            ccur[c] = m && m <= PTX_BIG_COMMENT_OPS_PER_ID ? ptx_comment_sweep(cent + ccnt[c], m, [](uint32_t, uint32_t) {}) : 0u;
+        }
+        PTX_BSYNC();
+        for (uint32_t hq = 0; hq < nheavy; ++hq) { /* (uniform) */
+            const uint32_t c = hvy[hq];
+            const uint32_t cntc = heavy_sweep(c, 0u, false, h1, h2);
+            PTX_BLEADER { ccur[c] = cntc; }
+            PTX_BSYNC();
+        }
         const uint32_t I = ptx_big_scan<kGrid, uint32_t, 1>(ccur, Kid + 1, part, _gbar);
         PTX_BLEADER { H->I = I; }
-        uint64_t h1 = 0, h2 = 0;
         PTX_BFOR(c, Kid) {
+            const uint32_t m = ccnt[c + 1] - ccnt[c];
+            if (m == 0u || m > PTX_BIG_COMMENT_OPS_PER_ID) continue;
             uint32_t row = ccur[c];
-            ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [&](uint32_t s, uint32_t e) {
+            ptx_comment_sweep(cent + ccnt[c], m, [&](uint32_t s, uint32_t e) {
                 ptx_cinterval ci;
                 ci.id = c;
                 ci.start = s;
@@ -635,6 +720,18 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 ptx_atomic_or(&brkbits[e >> 5], 1u << (e & 31u));
                 ptx_digest_item(h1, h2, 3u, c, s, e);
             });
+        }
+        for (uint32_t hq = 0; hq < nheavy; ++hq) {
+            const uint32_t c = hvy[hq];
+            (void)heavy_sweep(c, ccur[c], true, h1, h2);
+        }
+        if (nheavy) { /* the span-start bitmap of P6 lent its words to the sweeps */
+            PTX_BFOR(w, nwe + 1) {
+                PtxBitWord z;
+                z.bits = 0;
+                z.pre = 0;
+                st[w] = z;
+            }
         }
         ptx_digest_flush_dense(H, h1, h2); /* (a butterfly per wave, then one atomic: the header may live in global memory) */
         PTX_BSYNC();

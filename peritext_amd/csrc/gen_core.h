@@ -29,7 +29,7 @@
 #pragma once
 #include "merge_core.h"
 
-#define PTX_GEN_MAX_R 4u
+#define PTX_GEN_MAX_R 8u /* replicas per document (round 5: 8; "doc1" .. "doc8": their string order is their number's) */
 #define PTX_GK_DEAD 0x40000000u
 #define PTX_GK_AFTER 0x80000000u
 #define PTX_GK_KEY 0x3FFFFFFFu
@@ -38,8 +38,7 @@
 struct PtxGenChange {
     uint32_t rowoff;
     uint32_t nops_start; /* nops << 24 | startOp */
-    uint32_t deps01;     /* deps[0] | deps[1] << 16 */
-    uint32_t deps23;
+    uint32_t deps[PTX_GEN_MAX_R / 2]; /* deps[2 j] | deps[2 j + 1] << 16 */
 };
 
 struct PtxGenArgs {
@@ -87,8 +86,10 @@ struct PtxGenHdr {
     uint32_t scan_tmp[36];
 };
 
-/* u16 keys while every counter of the document fits 14 bits (a document makes R * ops_per_log + 1 ops) */
-PTX_HD bool ptx_gen_small_keys(uint64_t R, uint64_t rows_per_log) { return R * rows_per_log + 8 < (1u << 14); }
+/* actor bits of a key: 2 up to four replicas, 3 up to eight */
+PTX_HD uint32_t ptx_gen_actor_bits(uint64_t R) { return R <= 4 ? 2u : 3u; }
+/* u16 keys while every counter of the document fits 14 (13) bits (a document makes R * ops_per_log + 1 ops) */
+PTX_HD bool ptx_gen_small_keys(uint64_t R, uint64_t rows_per_log) { return R * rows_per_log + 8 < (1ull << (16 - ptx_gen_actor_bits(R))); }
 PTX_HD uint64_t ptx_gen_list_stride(uint64_t list_cap) { return (list_cap + 64 + 15) & ~15ull; } /* keys per replica: whole 16-byte blocks + slack */
 PTX_HD uint64_t ptx_gen_plane_words(uint64_t list_cap) { return (ptx_gen_list_stride(list_cap) >> 5) + 2; }
 PTX_HD uint64_t ptx_gen_lds_need(uint64_t R, uint64_t list_cap, uint64_t rows_per_log) {
@@ -155,10 +156,16 @@ struct PtxGenRow {
     uint32_t payload;
     uint8_t action, mark_type, side_a, side_b;
 };
-PTX_DEV uint32_t ptx_gen_key_of(uint64_t id) { return ((uint32_t)(id >> 32) << 2) | ((uint32_t)id & 3u); } /* 0 for HEAD (id 0) */
-PTX_DEV uint64_t ptx_gen_id_of(uint32_t key) { return ((uint64_t)(key >> 2) << 32) | (uint64_t)(key & 3u); }
+/* key = counter << kb | actor, kb = 2 bits of actor up to four replicas, 3 up to eight (ptx_gen_actor_bits): integer order == compareOpIds order */
+PTX_DEV uint32_t ptx_gen_key_of(uint64_t id, uint32_t kb) { return ((uint32_t)(id >> 32) << kb) | ((uint32_t)id & ((1u << kb) - 1u)); } /* 0 for HEAD (id 0) */
+PTX_DEV uint64_t ptx_gen_id_of(uint32_t key, uint32_t kb) { return ((uint64_t)(key >> kb) << 32) | (uint64_t)(key & ((1u << kb) - 1u)); }
 
-PTX_DEV uint32_t ptx_gen_dep(const PtxGenChange& c, uint32_t b) { return ((b < 2u ? c.deps01 : c.deps23) >> (16u * (b & 1u))) & 0xFFFFu; }
+PTX_DEV uint32_t ptx_gen_dep(const PtxGenChange& c, uint32_t b) {
+    uint32_t w = c.deps[0];
+#pragma unroll
+    for (uint32_t j = 1; j < PTX_GEN_MAX_R / 2u; ++j) w = (b >> 1) == j ? c.deps[j] : w;
+    return (w >> (16u * (b & 1u))) & 0xFFFFu;
+}
 /* is the decimal string of j smaller than that of k (string order, j != k) */
 PTX_DEV uint32_t ptx_gen_digits(uint32_t v) {
     uint32_t n = 1;
@@ -195,13 +202,14 @@ struct PtxGenDoc {
     PtxGenChange* ctab;
     uint16_t* known;
     uint32_t cap;
+    uint32_t kb; /* actor bits of a key */
 
     PTX_MEM uint64_t log_base(uint32_t r) const { return row0 + (uint64_t)r * A.rows_per_log; }
     PTX_MEM KeyT* keys(uint32_t) const { return key0; }
     PTX_MEM uint32_t* dead(uint32_t r) const { return dead0 + (uint64_t)r * plane_words; }
     PTX_MEM uint32_t* after(uint32_t r) const { return after0 + (uint64_t)r * plane_words; }
     /* id of the element at position p of replica r's list */
-    PTX_MEM uint64_t id_at(uint32_t r, uint32_t p) const { return ptx_gen_id_of(keys(r)[p]); }
+    PTX_MEM uint64_t id_at(uint32_t r, uint32_t p) const { return ptx_gen_id_of(keys(r)[p], kb); }
 
     /* applyOp for replica r (micromerge.ts:614-640 insert, :677-695 delete; for marks only the `after` flag).  An insert r MAKES (it carries r as its actor
      * and is applied by r first) enters the document's list; one that arrives from another replica is already there: r only starts to see it. */
@@ -209,8 +217,8 @@ struct PtxGenDoc {
         KeyT* L = key0;
         const uint32_t n = H->n[0];
         if (o.action == PTX_ACT_INSERT) {
-            const uint32_t key = ptx_gen_key_of(o.op_id);
-            if (((uint32_t)o.op_id & 3u) != r) { /* a delivered insert: its element is in the list since its author made it (causal delivery) */
+            const uint32_t key = ptx_gen_key_of(o.op_id, kb);
+            if ((uint32_t)o.op_id != r) { /* a delivered insert: its element is in the list since its author made it (causal delivery) */
                 const uint32_t p = ptx_list_find<KeyT>(L, n, key);
                 if (PTX_LANE0 && p != 0xFFFFFFFFu && ((dead(r)[p >> 5] >> (p & 31u)) & 1u)) {
                     dead(r)[p >> 5] &= ~(1u << (p & 31u));
@@ -220,7 +228,7 @@ struct PtxGenDoc {
                 return;
             }
             uint32_t at = 0;
-            if (o.ref_a != 0) at = ptx_list_find<KeyT>(L, n, ptx_gen_key_of(o.ref_a)) + 1u; /* the reference element exists (causal delivery) */
+            if (o.ref_a != 0) at = ptx_list_find<KeyT>(L, n, ptx_gen_key_of(o.ref_a, kb)) + 1u; /* the reference element exists (causal delivery) */
             /* skip the elements with a greater id (concurrent inserts at the same spot, :630-635): over the document's list, which already holds what the
              * other replicas made concurrently — the position every replica will agree on */
             for (;;) {
@@ -251,14 +259,14 @@ struct PtxGenDoc {
             }
             PTX_WSYNC();
         } else if (o.action == PTX_ACT_DELETE) {
-            const uint32_t p = ptx_list_find<KeyT>(L, n, ptx_gen_key_of(o.ref_a));
+            const uint32_t p = ptx_list_find<KeyT>(L, n, ptx_gen_key_of(o.ref_a, kb));
             if (PTX_LANE0 && p != 0xFFFFFFFFu && !((dead(r)[p >> 5] >> (p & 31u)) & 1u)) {
                 dead(r)[p >> 5] |= 1u << (p & 31u);
                 H->vis[r] -= 1u;
             }
             PTX_WSYNC();
         } else if ((o.action == PTX_ACT_ADDMARK || o.action == PTX_ACT_REMOVEMARK) && o.side_b == PTX_SIDE_AFTER) {
-            const uint32_t p = ptx_list_find<KeyT>(L, n, ptx_gen_key_of(o.ref_b));
+            const uint32_t p = ptx_list_find<KeyT>(L, n, ptx_gen_key_of(o.ref_b, kb));
             if (PTX_LANE0 && p != 0xFFFFFFFFu) after(r)[p >> 5] |= 1u << (p & 31u);
             PTX_WSYNC();
         }
@@ -396,7 +404,7 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
     bp.cap = A.lds_bytes;
     bp.high = bp.off;
     bp.overflow = false;
-    PtxGenDoc<kThreads, KeyT> G{A, H, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, A.list_cap};
+    PtxGenDoc<kThreads, KeyT> G{A, H, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, A.list_cap, ptx_gen_actor_bits(A.R)};
     G.lst_stride = (uint32_t)ptx_gen_list_stride(A.list_cap);
     G.plane_words = (uint32_t)ptx_gen_plane_words(A.list_cap);
     G.key0 = ptx_alloc<KeyT>(bp, G.lst_stride);
@@ -438,8 +446,8 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
     const uint32_t ck_ = (k_);                                                                   \
     uint32_t nops_ = 0;                                                                          \
     PtxGenChange c_;                                                                             \
-    c_.deps01 = H->clock[ck_][0] | (H->clock[ck_][1] << 16);                                     \
-    c_.deps23 = H->clock[ck_][2] | (H->clock[ck_][3] << 16);                                     \
+    _Pragma("unroll") for (uint32_t j_ = 0; j_ < PTX_GEN_MAX_R / 2u; ++j_)                       \
+        c_.deps[j_] = H->clock[ck_][2u * j_] | (H->clock[ck_][2u * j_ + 1u] << 16);              \
     c_.rowoff = H->rows[ck_];                                                                    \
     const uint32_t seq_ = H->clock[ck_][ck_] + 1u, start_ = H->max_op[ck_] + 1u;                 \
     PTX_WSYNC();                                                                                 \

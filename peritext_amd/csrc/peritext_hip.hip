@@ -1885,7 +1885,7 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     if (info) memset(info, 0, sizeof(*info));
     if (cfg->replicas < 1 || cfg->replicas > PTX_GEN_MAX_R || cfg->n_mark_types > 4 || cfg->ops_per_log < 1 || cfg->ops_per_log > 65533u ||
         cfg->mix[0] > 100u || cfg->mix[1] > 100u || cfg->mix[2] > 100u || cfg->mix[3] > 100u || cfg->mix[0] + cfg->mix[1] + cfg->mix[2] + cfg->mix[3] != 100u)
-        return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_generate: 1..4 replicas, at most 65533 ops per log, mix percentages summing to 100");
+        return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_generate: 1..8 replicas, at most 65533 ops per log, mix percentages summing to 100");
     for (uint32_t i = 0; i < cfg->n_mark_types; ++i)
         if (cfg->mark_types[i] > PTX_MARK_LINK) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_generate: mark_types must be PTX_MARK_* values");
     const size_t tl = strnlen(cfg->initial_text, sizeof(cfg->initial_text));

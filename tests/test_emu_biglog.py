@@ -312,8 +312,8 @@ def test_cursors_on_a_document_beyond_16_bit_row_indices():
     assert [int(x) for x in st] == [abi.ERR_INDEX_OOB, abi.ERR_ELEM_NOT_FOUND]
 
 
-def _one_comment_id_log(n_chars, n_ops, seed):
-    """A replica log whose n_ops comment ops all carry ONE id (the HBM-staged path sweeps an id's ops in one lane, quadratic in their number)."""
+def _one_comment_id_log(n_chars, n_ops, seed, ids_of_ops=("the-one",), weights=None):
+    """A replica log whose n_ops comment ops carry few ids (the HBM-staged path sweeps an id's ops in one lane, quadratic in their number, or — beyond 1 024 — as a team)."""
     import random
 
     rnd = random.Random(seed)
@@ -325,8 +325,9 @@ def _one_comment_id_log(n_chars, n_ops, seed):
     ctr = n_chars + 2
     for k in range(n_ops):
         a = rnd.randrange(n_chars)
-        e = a + 1 + rnd.randrange(n_chars - a)
-        op = {"opId": "%d@doc1" % ctr, "action": "addMark" if rnd.random() < 0.6 else "removeMark", "obj": "1@doc1", "markType": "comment", "attrs": {"id": "the-one"},
+        e = a + 1 + rnd.randrange(min(n_chars - a, 1 + n_chars // 6))
+        cid = rnd.choices(ids_of_ops, weights)[0]
+        op = {"opId": "%d@doc1" % ctr, "action": "addMark" if rnd.random() < 0.6 else "removeMark", "obj": "1@doc1", "markType": "comment", "attrs": {"id": cid},
               "start": {"type": "before", "elemId": ids[a]}, "end": {"type": "after", "elemId": ids[e - 1]}}
         changes.append({"actor": "doc1", "seq": 2 + k, "deps": {}, "startOp": ctr, "ops": [op]})
         ctr += 1
@@ -334,15 +335,17 @@ def _one_comment_id_log(n_chars, n_ops, seed):
 
 
 @pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
-def test_comment_ops_on_one_id_are_bounded_in_the_hbm_staged_path():
-    """the per-id comment sweep is quadratic and runs in one lane; the HBM-staged kernel takes up to PTX_BIG_COMMENT_OPS_PER_ID (1 024) ops with a
-    visible interval per id — 900 of them equal the oracle's intervals, 1 300 are a capacity report, not minutes in one lane."""
-    ok = [[_one_comment_id_log(60, 900, 3)]]
-    expected = H.oracle_apply(ok)
-    batch = wire.encode_docs(ok)
-    res = H.emu_merge_big(batch)
-    assert int(res.logs["status"][0]) == 0
-    H.check_log(batch, res, 0, expected[0][0])
-    too_many = wire.encode_docs([[_one_comment_id_log(60, 1300, 4)]])
-    assert int(H.emu_merge_big(too_many).logs["status"][0]) == abi.ERR_CAPACITY
-    assert int(H.emu_merge(too_many, lds_bytes=160 * 1024).logs["status"][0]) == 0  # (the LDS kernel, whose LDS bounds the ops of a log, takes it)
+def test_comment_ops_on_one_id_beyond_one_lanes_sweep_in_the_hbm_staged_path():
+    """ADVICE r3 bounded the per-id comment sweep (quadratic, one lane) at PTX_BIG_COMMENT_OPS_PER_ID = 1 024 ops with a visible interval per id; round 5 sweeps an id
+    with more as a team (range-chmax tree of the application index over the visible positions, presence bitmap, runs of ones): 900, 1 300 and 3 000 ops on one id
+    and a log with two heavy and three light ids all equal the oracle's intervals, in each of the emulation's loop orders."""
+    docs = [[_one_comment_id_log(60, 900, 3)], [_one_comment_id_log(60, 1300, 4)], [_one_comment_id_log(200, 3000, 5)],
+            [_one_comment_id_log(333, 4200, 6, ("a", "b", "c", "d", "e"), (8, 1, 10, 1, 1))]]
+    expected = H.oracle_apply(docs)
+    batch = wire.encode_docs(docs)
+    for kw in ({}, {"reverse": 1}, {"reverse": 2}):
+        res = H.emu_merge_big(batch, **kw)
+        assert not res.logs["status"].any(), res.logs["status"]
+        for d in range(len(docs)):
+            H.check_log(batch, res, d, expected[d][0])
+    assert int(H.emu_merge(batch, lds_bytes=160 * 1024).logs["status"][1]) == 0  # (the LDS kernel, whose LDS bounds the ops of a log, sweeps every id in a lane)

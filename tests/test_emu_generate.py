@@ -81,9 +81,11 @@ def test_generator_capacity_and_single_replica():
         check_generated_logs(batch, [d["logs"] for d in g["docs"]])
 
 
-@pytest.mark.parametrize("cfg,replicas,ops,docs,seed", [("mini", 2, None, 8, 91), ("mini", 4, 160, 6, 92), ("rich", 4, 400, 2, 93), ("config3", 2, 300, 3, 94)])
+@pytest.mark.parametrize("cfg,replicas,ops,docs,seed", [("mini", 2, None, 8, 91), ("mini", 4, 160, 6, 92), ("rich", 4, 400, 2, 93), ("config3", 2, 300, 3, 94),
+                                                         ("mini", 5, 200, 4, 95), ("rich", 8, 500, 2, 96), ("mini", 7, 150, 3, 97), ("config4", 6, 900, 1, 98)])
 def test_generator_other_replica_counts(cfg, replicas, ops, docs, seed):
-    """2 and 4 replicas (the sync pairs, the pending-queue order and the deps rows change with R)."""
+    """2 to 8 replicas (the sync pairs, the pending-queue order and the deps rows change with R; round 5: five to eight replicas — three actor bits per key, four
+    words of dependencies per change, documents that ptx_merge_kernel_many / _many_wide admit)."""
     if not H.have_node():
         pytest.skip("node not installed")
     g = H.oracle_gen(cfg, seed=seed, docs=docs, ops=ops, replicas=replicas)

@@ -259,3 +259,17 @@ def test_cursors_on_a_document_beyond_16_bit_row_indices(eng):
     finally:
         eng.free_result(dr)
         eng.free_batch(db)
+
+
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_comment_ids_with_thousands_of_ops_in_the_hbm_staged_kernels(eng):
+    """Round 5: a comment id with more than PTX_BIG_COMMENT_OPS_PER_ID (1 024) ops that cover something is swept by the whole team (rounds 3-4: PTX_ERR_CAPACITY):
+    a 16 501-row log (team of workgroups) whose 15 000 comment ops fall on five ids, two of them with ~6 600 ops each, against the oracle's intervals."""
+    from test_emu_biglog import _one_comment_id_log
+
+    docs = [[_one_comment_id_log(1500, 15000, 11, ("a", "b", "c", "d", "e"), (15, 1, 15, 1, 2))]]
+    exp = H.oracle_apply(docs, no_patches=True, timeout=600)
+    batch = wire.encode_docs(docs)
+    res = eng.apply_materialize(batch)
+    assert int(res.logs["status"][0]) == 0 and int(res.logs["reserved"][0, 0]) == 0  # (the HBM-staged kernel reports no LDS figure)
+    H.check_log(batch, res, 0, exp[0][0])

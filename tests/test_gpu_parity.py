@@ -547,6 +547,32 @@ def test_generate_full_config4_document_against_live_oracle(eng):
         eng.free_batch(h)
 
 
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+@pytest.mark.parametrize("cfg,replicas,ops,docs,seed", [("mini", 5, 200, 4, 95), ("rich", 8, 500, 2, 96), ("config4", 6, 900, 1, 98)])
+def test_generate_documents_of_five_to_eight_replicas(eng, cfg, replicas, ops, docs, seed):
+    """Round 5: the generator holds up to 8 replicas per document (three actor bits per key, four words of dependencies per change).  Change for Change the
+    oracle's PTXGEN; the resident batch is then admitted by the many-actor builds and merges to the oracle's spans; every replica of a document converges."""
+    g = H.oracle_gen(cfg, seed=seed, docs=docs, ops=ops, replicas=replicas)
+    h, batch, info = _generate(eng, H.gen_config(cfg, ops=ops, replicas=replicas), docs, seed, list_cap=4096)
+    try:
+        _check_changes(batch, [d["logs"] for d in g["docs"]])
+        assert eng.batch_kernel_name(h) == ("ptx_merge_kernel_many" if replicas <= 7 else "ptx_merge_kernel_many_wide")
+        dr = eng.alloc_result(h)
+        eng.merge(h, dr)
+        eng.sync()
+        res = eng.download(h, dr)
+        eng.free_result(dr)
+        log = 0
+        for d in g["docs"]:
+            for exp in d["expected"]:
+                H.check_log(batch, res, log, exp)
+                log += 1
+        dg = res.logs["digest"].reshape(docs, replicas, 2)
+        assert (dg == dg[:, :1, :]).all()
+    finally:
+        eng.free_batch(h)
+
+
 def test_generate_capacity_and_arguments(eng):
     from peritext_amd.engine import PtxError
 
@@ -554,7 +580,7 @@ def test_generate_capacity_and_arguments(eng):
     with pytest.raises(PtxError, match="list_cap"):
         _generate(eng, c, 4, 5, list_cap=8)
     with pytest.raises(PtxError, match="replicas"):
-        eng.generate(5, 16, [25, 25, 25, 25], [0], 1, 1)
+        eng.generate(9, 16, [25, 25, 25, 25], [0], 1, 1)
     h, batch, info = _generate(eng, c, 0, 1)
     assert batch.n_logs == 0
     eng.free_batch(h)

@@ -73,16 +73,16 @@ def oracle_spans(docs_logs):
     return expected
 
 
-def config_leg(args, name, docs, flags):
+def config_leg(args, name, docs, flags, replicas=None):
     """One BASELINE configuration resident on the GPU: kernel ms, SURVEY 8(d) fraction, launch shape, oracle parity of a few of its documents."""
     import helpers
 
-    g = workloads.gen_config(name)
+    g = workloads.gen_config(name, replicas=replicas)
     gen_args = (g["replicas"], g["ops_per_log"], g["mix"], g["mark_types"])
     row = {"config": name, "docs": docs, "replicas": g["replicas"], "ops_per_log": g["ops_per_log"], "mix_ins_del_add_rem": g["mix"], "causal_admission": not args.no_admission}
     try:
         with Engine(args.device, flags=flags) as e:
-            list_cap = max(args.list_cap, g["ops_per_log"] // 2 + 512)  # the longest element list a replica holds on chip while its document is generated
+            list_cap = max(args.list_cap, g["ops_per_log"] // 2 + 512, g["replicas"] * 640 if g["replicas"] > 4 else 0)  # the element list of a document, held on chip while it is generated (it grows with the replicas: every one of them makes ops_per_log ops)
             db, info = e.generate(*gen_args, docs, args.seed, list_cap=list_cap)
             n_logs, rows = e.n_logs(db), e.n_ops(db)
             dr = e.alloc_result(db)
@@ -96,7 +96,7 @@ def config_leg(args, name, docs, flags):
             alg = 32 * rows + 4 * V + 8 * S + 16 * T + 16 * n_logs
             env = 0 if args.no_admission else abi.envelope_bytes(e.n_changes(db), g["replicas"])
             threads, lds = e.launch_shape(db)
-            row.update({"replica_logs": n_logs, "ops": n_logs * g["ops_per_log"], "kernel_ms": ms, "ops_per_s": n_logs * g["ops_per_log"] / (ms * 1e-3), "every_log_ok": ok,
+            row.update({"replica_logs": n_logs, "ops": n_logs * g["ops_per_log"], "kernel": e.batch_kernel_name(db), "kernel_ms": ms, "ops_per_s": n_logs * g["ops_per_log"] / (ms * 1e-3), "every_log_ok": ok,
                         "algorithmic_bytes": alg, "roofline_GBps": alg / (ms * 1e-3) / 1e9, "roofline_frac": alg / (ms * 1e-3) / HBM_PEAK,
                         "with_envelope_frac": (alg + env) / (ms * 1e-3) / HBM_PEAK, "launch": {"threads_per_log": threads, "lds_bytes_per_log": lds,
                                                                                                  "logs_per_cu_by_lds": int((160 * 1024) // max(512, (lds + 511) // 512 * 512))},
@@ -189,60 +189,23 @@ def biglog_leg(args):
     return {"kernel": "ptx_merge_big_grid_kernel: a cooperative launch of up to 64 workgroups per log of 16 384 rows or more (working set in HBM scratch; smaller ones: ptx_merge_big_kernel, one 1 024-thread workgroup each)", "legs": rows}
 
 
-def many_actor_leg(args, n_docs=6, target_logs=24480):
-    """Documents with MORE than three actors under causal admission (ptx_merge_kernel_many: the (actor, seq) -> change table instead of the DPP-carried clock),
-    VERDICT r4 weak #7: config-4-shaped documents of 5 and 8 replicas, made on the host by the oracle's PTXGEN (the device generator holds at most 4 replicas),
-    tiled to fill the GPU, beside 3-replica documents prepared the same way (the <= 3-actor build).  Kernel ms, SURVEY 8(d) fraction, every document against the
-    oracle's expected output."""
-    import helpers
-
-    node = shutil.which("node")
-    if node is None:
-        raise RuntimeError("node (the oracle runtime) is not on this box")
-    g = workloads.gen_config(args.config)
+def many_actor_leg(args, target_logs=48960):
+    """Documents with MORE than three actors under causal admission: config-4-shaped documents of 5 and 8 replicas beside 3-replica ones,
+    all made on the device (round 5: the generator holds up to 8 replicas) — the same number of replica logs per leg, every document distinct.  Per leg: the
+    kernel build the library chose (ptx_merge_kernel_many: the one-pass admission walk up to seven actors; _many_wide: eight to fifteen), its ms, the SURVEY 8(d)
+    fraction, the per-log cost against three replicas, and --parity-docs documents of the resident batch against the oracle."""
     rows = []
-    td = tempfile.mkdtemp(prefix="ptxmany_")
     for R in (3, 5, 8):
-        outp = os.path.join(td, "g%d.json" % R)
-        subprocess.run([node, os.path.join(ROOT, "oracle", "cli.js"), "gen", "--config", args.config, "--replicas", str(R), "--docs", str(n_docs), "--seed", str(args.seed + R), "--out", outp],
-                       cwd=ROOT, check=True)
-        with open(outp) as f:
-            gen = json.load(f)
-        batch = wire.encode_docs([d["logs"] for d in gen["docs"]])
-        copies = max(1, target_logs // batch.n_logs)
-        with Engine(args.device, flags=abi.FLAG_NO_ELEM_RANK) as e:
-            db = e.upload(batch, copies=copies)
-            dr = e.alloc_result(db)
-            e.merge(db, dr)
-            e.sync()
-            iters = max(args.iters, 3)
-            ms = min(e.merge_timed(db, dr, iters) / iters for _ in range(2))
-            n_logs, n_rows = e.n_logs(db), e.n_ops(db)
-            logs = e.download_logs(dr, n_logs)
-            one = e.download_range(db, dr, 0, batch.n_logs)
-            V, S, T = int(logs["n_visible"].sum()), int(logs["n_spans"].sum()), int(logs["n_cintervals"].sum())
-            alg = 32 * n_rows + 4 * V + 8 * S + 16 * T + 16 * n_logs
-            env = abi.envelope_bytes(e.n_changes(db), batch.max_actors)
-            row = {"replicas": R, "documents": n_docs, "copies": copies, "replica_logs": n_logs, "ops": n_logs * g["ops_per_log"], "kernel": e.batch_kernel_name(db),
-                   "launch": list(e.launch_shape(db)), "kernel_ms": ms, "ops_per_s": n_logs * g["ops_per_log"] / (ms * 1e-3), "us_per_log_per_cu": ms * 1e3 * 256 / n_logs,
-                   "roofline_frac": alg / (ms * 1e-3) / HBM_PEAK, "with_envelope_frac": (alg + env) / (ms * 1e-3) / HBM_PEAK,
-                   "every_log_ok": bool(int(logs["status"].max()) == 0),
-                   "copies_agree": bool((logs["digest"].reshape(copies, batch.n_logs, 2) == logs["digest"][: batch.n_logs]).all())}
-            log = 0
-            for d in gen["docs"]:
-                for exp in d["expected"]:
-                    helpers.check_log(batch, one, log, exp)
-                    log += 1
-            row["parity"] = "%d replica logs of %d documents against the oracle's expected output (decoded spans, raw rows, digests)" % (log, n_docs)
-            e.free_result(dr)
-            e.free_batch(db)
+        row = config_leg(args, args.config, target_logs // R, abi.FLAG_NO_ELEM_RANK, replicas=R)
+        if "kernel_ms" in row:
+            row["us_per_log_per_cu"] = row["kernel_ms"] * 1e3 * 256 / row["replica_logs"]
         rows.append(row)
         say("many_actor %s" % json.dumps(row))
-    shutil.rmtree(td, ignore_errors=True)
-    base = rows[0]["us_per_log_per_cu"]
+    base = rows[0].get("us_per_log_per_cu")
     for r in rows:
-        r["per_log_cost_vs_3_replicas"] = r["us_per_log_per_cu"] / base
-    return {"workload": "%s documents made by the oracle's PTXGEN on the host, %d distinct documents per leg, tiled" % (args.config, n_docs), "legs": rows}
+        if base and "us_per_log_per_cu" in r:
+            r["per_log_cost_vs_3_replicas"] = r["us_per_log_per_cu"] / base
+    return {"workload": "%s documents generated on the device, %d replica logs per leg" % (args.config, target_logs), "legs": rows}
 
 
 def pipeline_leg(args, gen_args, flags, batches=6, docs=8192):
