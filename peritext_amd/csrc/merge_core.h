@@ -738,6 +738,27 @@ PTX_DEV bool ptx_mark_of(const PtxMarkBlocks& M, uint32_t b, uint32_t t, uint32_
     k = s < L.lim ? L.kbase + s : 0u;
     return s < L.lim;
 }
+/* The lane's share where it does not change from step to step (the GPU: lane = threadIdx.x & 63), worked out ONCE per log and packed into two registers that the
+ * compiler is told to keep (left to itself it works the four-way choice out again at each of the three uses of a step — a dozen vector and as many scalar
+ * instructions each, round 5's instruction counts): kbase | end << 16 (both at most K < 65 536; op k = kbase + b * c exists iff it is below `end` of its run) and c. */
+struct PtxMarkLaneKept {
+    uint32_t kb_end, c;
+};
+PTX_DEV PtxMarkLaneKept ptx_mark_lane_kept(const PtxMarkBlocks& M, uint32_t t) {
+    const PtxMarkLane L = ptx_mark_lane(M, t);
+    PtxMarkLaneKept P;
+    P.kb_end = L.kbase | ((L.kbase + L.lim) << 16);
+    P.c = L.c;
+    PTX_KEEP_VGPR(P.kb_end);
+    PTX_KEEP_VGPR(P.c);
+    return P;
+}
+PTX_DEV bool ptx_mark_of_kept(const PtxMarkLaneKept& P, uint32_t b, uint32_t& k) {
+    const uint32_t kk = ptx_mad24(b, P.c, P.kb_end & 0xFFFFu);
+    const bool has = kk < (P.kb_end >> 16);
+    k = has ? kk : 0u;
+    return has;
+}
 
 /* Uniform early exit on a per-log error.  The error word is sampled between two barriers so that a
  * later phase's error write can never be seen by a thread that is still at this check point. */
@@ -1445,12 +1466,18 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
      * log — 2 k cycles with a CU to itself, 28 k under load.) */
     const PtxMarkBlocks MB = ptx_mark_blocks(moff1, moff2, moff3, K, PTX_JB_CAP);
     const uint32_t m_steps = PTX_JB_STEPS(MB.B, PTX_UM);
+#ifdef PTX_JB_LANE_IS_FIXED
+    const PtxMarkLaneKept MLK = ptx_mark_lane_kept(MB, PTX_JB_LANE(0u, 0, PTX_UM));
+#define PTX_MARK_OF(st_, u_, k_) ptx_mark_of_kept(MLK, PTX_JB_BLOCK(st_, u_, PTX_UM), k_)
+#else
+#define PTX_MARK_OF(st_, u_, k_) ptx_mark_of(MB, PTX_JB_BLOCK(st_, u_, PTX_UM), PTX_JB_LANE(st_, u_, PTX_UM), k_)
+#endif
     uint32_t kq[PTX_UM], kq_n[PTX_UM]; /* the thread's mark ops of a step (0xFFFFFFFF: none) */
     uint32_t mq[PTX_UM];               /* the park entries of the step whose gathers go out next */
 #define PTX_MARK_PQ(st_, mq_)                                               \
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
         uint32_t k_;                                                        \
-        (void)ptx_mark_of(MB, PTX_JB_BLOCK(st_, u, PTX_UM), PTX_JB_LANE(st_, u, PTX_UM), k_); \
+        (void)PTX_MARK_OF(st_, u, k_);                                       \
         mq_[u] = ptx_coherent_load32(&park[K ? mp0 + k_ : 0u]);             \
     }
     uint32_t i[PTX_UM], sa[PTX_UM], sb[PTX_UM], pl[PTX_UM], i_n[PTX_UM], sa_n[PTX_UM], sb_n[PTX_UM], pl_n[PTX_UM];
@@ -1460,7 +1487,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #define PTX_MARK_LOAD(st_, kq_, i_, ra_, rb_, sa_, sb_, pl_, mq_)           \
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
         uint32_t k_;                                                        \
-        const bool has_ = ptx_mark_of(MB, PTX_JB_BLOCK(st_, u, PTX_UM), PTX_JB_LANE(st_, u, PTX_UM), k_); \
+        const bool has_ = PTX_MARK_OF(st_, u, k_);                         \
         kq_[u] = has_ ? k_ : 0xFFFFFFFFu;                                   \
         const uint32_t r_ = mq_[u] & 0xFFFFu;                               \
         i_[u] = r_ < N ? r_ : N - 1u;                                       \
@@ -1994,6 +2021,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
 #undef PTX_MARK_LOAD
 #undef PTX_MARK_PQ
+#undef PTX_MARK_OF
     }
     PTX_LEADER { H->cur_med = 0; } /* (the cursor of the list of live mark ops, below; the barriers of the error check stand in between) */
     PTX_BAIL_IF_ERROR();

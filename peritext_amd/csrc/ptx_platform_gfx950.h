@@ -278,6 +278,8 @@ PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint3
 #define PTX_JB_STEPS(B, U) (((B) + (U) * PTX_NWAVES - 1u) / ((U) * PTX_NWAVES))
 #define PTX_JB_BLOCK(st, u, U) (((st) * (U) + (uint32_t)(u)) * PTX_NWAVES + (threadIdx.x >> 6))
 #define PTX_JB_LANE(st, u, U) (threadIdx.x & 63u)
+#define PTX_JB_LANE_IS_FIXED 1 /* a thread's lane of a block is the same in every step: its share of the runs is worked out once per log */
+#define PTX_KEEP_VGPR(x) asm volatile("" : "+v"(x)) /* the value stays in its register: the compiler neither works it out again at each use nor treats it as a constant */
 
 /* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the
  * emulation plays three one-lane waves in turn */
