@@ -439,7 +439,7 @@ void ptx_root_maps_free(ptx_root_maps* m);
  * "<A-Z>.com", comment payload = rank of "comment-<k>" in string order among the document's n_comments ids,
  * actors "doc1".."doc<replicas>". */
 typedef struct ptx_gen_config {
-    uint32_t replicas;      /* 1..4 */
+    uint32_t replicas;      /* 1..8 */
     uint32_t ops_per_log;   /* ops of every replica log (the makeList row comes on top) */
     uint32_t mix[4];        /* percent of insert, delete, addMark, removeMark steps */
     uint32_t n_mark_types;  /* 0..4 */
