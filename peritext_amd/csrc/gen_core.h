@@ -29,17 +29,21 @@
 #pragma once
 #include "merge_core.h"
 
-#define PTX_GEN_MAX_R 8u /* replicas per document (round 5: 8; "doc1" .. "doc8": their string order is their number's) */
+#define PTX_GEN_MAX_R 8u /* replicas per document (round 5: 8; "doc1" .. "doc8": their string order is their number's).  The document code is compiled for 4 and for 8
+                           * (kMaxR): the per-replica state of a document of up to four replicas — the usual case — keeps round 4's size and registers */
 #define PTX_GK_DEAD 0x40000000u
 #define PTX_GK_AFTER 0x80000000u
 #define PTX_GK_KEY 0x3FFFFFFFu
 
 /* one made change: where its rows sit in its author's log + what applyChange checks */
-struct PtxGenChange {
+template <uint32_t kMaxR>
+struct PtxGenChangeT {
     uint32_t rowoff;
     uint32_t nops_start; /* nops << 24 | startOp */
-    uint32_t deps[PTX_GEN_MAX_R / 2]; /* deps[2 j] | deps[2 j + 1] << 16 */
+    uint32_t deps[kMaxR / 2]; /* deps[2 j] | deps[2 j + 1] << 16 */
 };
+PTX_HD uint32_t ptx_gen_max_r(uint64_t R) { return R <= 4 ? 4u : PTX_GEN_MAX_R; } /* the build (kMaxR) that generates documents of R replicas */
+PTX_HD uint64_t ptx_gen_change_bytes(uint64_t R) { return R <= 4 ? sizeof(PtxGenChangeT<4>) : sizeof(PtxGenChangeT<PTX_GEN_MAX_R>); }
 
 struct PtxGenArgs {
     uint32_t n_docs, first_doc, seed;
@@ -68,19 +72,20 @@ struct PtxGenArgs {
     uint32_t* n_comments; /* [n_docs] comment ids "comment-0" .. "comment-(C-1)" the document uses */
     uint32_t* status;     /* [n_docs] PTX_OK / PTX_ERR_CAPACITY */
     /* scratch in HBM, per document: change table [R][rows_per_log] and known-comment lists [R][rows_per_log] */
-    PtxGenChange* ctab;
+    void* ctab;           /* PtxGenChangeT<ptx_gen_max_r(R)> [n_docs][R][rows_per_log] */
     uint16_t* known;
 };
 
-struct PtxGenHdr {
-    uint32_t n[PTX_GEN_MAX_R];      /* n[0]: length of the document's list (every element made so far) */
-    uint32_t vis[PTX_GEN_MAX_R];    /* visible length */
-    uint32_t clock[PTX_GEN_MAX_R][PTX_GEN_MAX_R];
-    uint32_t max_op[PTX_GEN_MAX_R];
-    uint32_t rows[PTX_GEN_MAX_R];   /* rows written to the replica's log */
-    uint32_t chgs[PTX_GEN_MAX_R];   /* changes written to its envelope */
-    uint32_t nknown[PTX_GEN_MAX_R];
-    uint32_t plo[PTX_GEN_MAX_R], phi[PTX_GEN_MAX_R]; /* pending changes of a delivery, per actor */
+template <uint32_t kMaxR>
+struct PtxGenHdrT {
+    uint32_t n[kMaxR];      /* n[0]: length of the document's list (every element made so far) */
+    uint32_t vis[kMaxR];    /* visible length */
+    uint32_t clock[kMaxR][kMaxR];
+    uint32_t max_op[kMaxR];
+    uint32_t rows[kMaxR];   /* rows written to the replica's log */
+    uint32_t chgs[kMaxR];   /* changes written to its envelope */
+    uint32_t nknown[kMaxR];
+    uint32_t plo[kMaxR], phi[kMaxR]; /* pending changes of a delivery, per actor */
     uint32_t tmp;
     uint32_t overflow;
     uint32_t scan_tmp[36];
@@ -94,7 +99,7 @@ PTX_HD uint64_t ptx_gen_list_stride(uint64_t list_cap) { return (list_cap + 64 +
 PTX_HD uint64_t ptx_gen_plane_words(uint64_t list_cap) { return (ptx_gen_list_stride(list_cap) >> 5) + 2; }
 PTX_HD uint64_t ptx_gen_lds_need(uint64_t R, uint64_t list_cap, uint64_t rows_per_log) {
     const uint64_t kb = ptx_gen_small_keys(R, rows_per_log) ? 2 : 4;
-    return ptx_a16(sizeof(PtxGenHdr)) + ptx_a16(kb * ptx_gen_list_stride(list_cap)) + 2 * ptx_a16(4 * R * ptx_gen_plane_words(list_cap)) +
+    return ptx_a16(R <= 4 ? sizeof(PtxGenHdrT<4>) : sizeof(PtxGenHdrT<PTX_GEN_MAX_R>)) + ptx_a16(kb * ptx_gen_list_stride(list_cap)) + 2 * ptx_a16(4 * R * ptx_gen_plane_words(list_cap)) +
            ptx_a16(4 * ((rows_per_log >> 5) + 2));
 }
 
@@ -160,10 +165,12 @@ struct PtxGenRow {
 PTX_DEV uint32_t ptx_gen_key_of(uint64_t id, uint32_t kb) { return ((uint32_t)(id >> 32) << kb) | ((uint32_t)id & ((1u << kb) - 1u)); } /* 0 for HEAD (id 0) */
 PTX_DEV uint64_t ptx_gen_id_of(uint32_t key, uint32_t kb) { return ((uint64_t)(key >> kb) << 32) | (uint64_t)(key & ((1u << kb) - 1u)); }
 
-PTX_DEV uint32_t ptx_gen_dep(const PtxGenChange& c, uint32_t b) {
+template <uint32_t kMaxR>
+PTX_DEV uint32_t ptx_gen_dep(const PtxGenChangeT<kMaxR>& c, uint32_t b) {
+    if (kMaxR == 4u) return ((b < 2u ? c.deps[0] : c.deps[1]) >> (16u * (b & 1u))) & 0xFFFFu;
     uint32_t w = c.deps[0];
 #pragma unroll
-    for (uint32_t j = 1; j < PTX_GEN_MAX_R / 2u; ++j) w = (b >> 1) == j ? c.deps[j] : w;
+    for (uint32_t j = 1; j < kMaxR / 2u; ++j) w = (b >> 1) == j ? c.deps[j] : w;
     return (w >> (16u * (b & 1u))) & 0xFFFFu;
 }
 /* is the decimal string of j smaller than that of k (string order, j != k) */
@@ -188,10 +195,11 @@ PTX_DEV bool ptx_gen_str_less(uint32_t j, uint32_t k) {
     return jp != k ? jp < k : false;
 }
 
-template <uint32_t kThreads, class KeyT>
+template <uint32_t kThreads, class KeyT, uint32_t kMaxR>
 struct PtxGenDoc {
+    typedef PtxGenChangeT<kMaxR> PtxGenChange;
     const PtxGenArgs& A;
-    PtxGenHdr* H;
+    PtxGenHdrT<kMaxR>* H;
     KeyT* key0;          /* the document's list */
     uint32_t* dead0;     /* replica r's planes = dead0 / after0 + r * plane_words (no pointer table: nothing of this kernel lives in scratch) */
     uint32_t* after0;
@@ -202,7 +210,7 @@ struct PtxGenDoc {
     PtxGenChange* ctab;
     uint16_t* known;
     uint32_t cap;
-    uint32_t kb; /* actor bits of a key */
+    static constexpr uint32_t kb = kMaxR <= 4u ? 2u : 3u; /* actor bits of a key (= ptx_gen_actor_bits of the replica counts this build generates) */
 
     PTX_MEM uint64_t log_base(uint32_t r) const { return row0 + (uint64_t)r * A.rows_per_log; }
     PTX_MEM KeyT* keys(uint32_t) const { return key0; }
@@ -218,7 +226,7 @@ struct PtxGenDoc {
         const uint32_t n = H->n[0];
         if (o.action == PTX_ACT_INSERT) {
             const uint32_t key = ptx_gen_key_of(o.op_id, kb);
-            if ((uint32_t)o.op_id != r) { /* a delivered insert: its element is in the list since its author made it (causal delivery) */
+            if (((uint32_t)o.op_id & (kMaxR - 1u)) != r) { /* a delivered insert: its element is in the list since its author made it (causal delivery) */
                 const uint32_t p = ptx_list_find<KeyT>(L, n, key);
                 if (PTX_LANE0 && p != 0xFFFFFFFFu && ((dead(r)[p >> 5] >> (p & 31u)) & 1u)) {
                     dead(r)[p >> 5] &= ~(1u << (p & 31u));
@@ -394,8 +402,10 @@ struct PtxGenDoc {
     }
 };
 
-template <uint32_t kThreads, class KeyT>
+template <uint32_t kThreads, class KeyT, uint32_t kMaxR>
 PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) {
+    typedef PtxGenChangeT<kMaxR> PtxGenChange;
+    typedef PtxGenHdrT<kMaxR> PtxGenHdr;
     PtxGenHdr* H = (PtxGenHdr*)lds;
     const uint32_t R = A.R, N = A.rows_per_log;
     PtxBump bp;
@@ -404,7 +414,7 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
     bp.cap = A.lds_bytes;
     bp.high = bp.off;
     bp.overflow = false;
-    PtxGenDoc<kThreads, KeyT> G{A, H, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, A.list_cap, ptx_gen_actor_bits(A.R)};
+    PtxGenDoc<kThreads, KeyT, kMaxR> G{A, H, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, A.list_cap};
     G.lst_stride = (uint32_t)ptx_gen_list_stride(A.list_cap);
     G.plane_words = (uint32_t)ptx_gen_plane_words(A.list_cap);
     G.key0 = ptx_alloc<KeyT>(bp, G.lst_stride);
@@ -413,20 +423,20 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
     G.done = ptx_alloc<uint32_t>(bp, (N >> 5) + 2);
     G.crank = (uint16_t*)G.key0; /* needed once the documents are finished and the lists (keys + planes, contiguous) dead: see the end */
     G.row0 = (uint64_t)doc_local * R * N;
-    G.ctab = A.ctab + (uint64_t)doc_local * R * N;
+    G.ctab = (PtxGenChange*)A.ctab + (uint64_t)doc_local * R * N;
     G.known = A.known + (uint64_t)doc_local * R * N;
-    if (bp.overflow || R == 0 || R > PTX_GEN_MAX_R || N > 0xFFFFFFu) {
+    if (bp.overflow || R == 0 || R > kMaxR || N > 0xFFFFFFu) {
         if (PTX_LANE0) {
             A.status[doc_local] = PTX_ERR_CAPACITY;
             A.n_comments[doc_local] = 0;
-            for (uint32_t r = 0; r < R && r < PTX_GEN_MAX_R; ++r) A.n_changes[doc_local * R + r] = 0;
+            for (uint32_t r = 0; r < R && r < kMaxR; ++r) A.n_changes[doc_local * R + r] = 0;
         }
         return;
     }
     if (PTX_LANE0) {
-        for (uint32_t r = 0; r < PTX_GEN_MAX_R; ++r) {
+        for (uint32_t r = 0; r < kMaxR; ++r) {
             H->n[r] = H->vis[r] = H->max_op[r] = H->rows[r] = H->chgs[r] = H->nknown[r] = 0;
-            for (uint32_t a = 0; a < PTX_GEN_MAX_R; ++a) H->clock[r][a] = 0;
+            for (uint32_t a = 0; a < kMaxR; ++a) H->clock[r][a] = 0;
         }
         H->overflow = 0;
         H->tmp = 0;
@@ -446,7 +456,9 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
     const uint32_t ck_ = (k_);                                                                   \
     uint32_t nops_ = 0;                                                                          \
     PtxGenChange c_;                                                                             \
-    _Pragma("unroll") for (uint32_t j_ = 0; j_ < PTX_GEN_MAX_R / 2u; ++j_)                       \
+    c_.deps[0] = H->clock[ck_][0] | (H->clock[ck_][1] << 16);                                    \
+    c_.deps[1] = H->clock[ck_][2] | (H->clock[ck_][3] << 16);                                    \
+    _Pragma("unroll") for (uint32_t j_ = 2; j_ < kMaxR / 2u; ++j_)                               \
         c_.deps[j_] = H->clock[ck_][2u * j_] | (H->clock[ck_][2u * j_ + 1u] << 16);              \
     c_.rowoff = H->rows[ck_];                                                                    \
     const uint32_t seq_ = H->clock[ck_][ck_] + 1u, start_ = H->max_op[ck_] + 1u;                 \
@@ -616,8 +628,8 @@ PTX_DEV void ptx_gen_doc_keyed(const PtxGenArgs& A, uint32_t doc_local, uint8_t*
 }
 
 /* one document: the key width follows from the size of the document */
-template <uint32_t kThreads>
+template <uint32_t kThreads, uint32_t kMaxR>
 PTX_DEV void ptx_gen_doc(const PtxGenArgs& A, uint32_t doc_local, uint8_t* lds) {
-    if (ptx_gen_small_keys(A.R, A.rows_per_log)) ptx_gen_doc_keyed<kThreads, uint16_t>(A, doc_local, lds);
-    else ptx_gen_doc_keyed<kThreads, uint32_t>(A, doc_local, lds);
+    if (ptx_gen_small_keys(A.R, A.rows_per_log)) ptx_gen_doc_keyed<kThreads, uint16_t, kMaxR>(A, doc_local, lds);
+    else ptx_gen_doc_keyed<kThreads, uint32_t, kMaxR>(A, doc_local, lds);
 }

@@ -123,9 +123,13 @@ extern "C" __global__ void __launch_bounds__(256) ptx_patch_pack_kernel(const pt
 #ifndef PTX_GEN_SGPR_CAP
 #define PTX_GEN_SGPR_CAP
 #endif
-extern "C" __global__ void __launch_bounds__(64) PTX_GEN_SGPR_CAP ptx_gen_kernel(PtxGenArgs A) {
+extern "C" __global__ void __launch_bounds__(64) PTX_GEN_SGPR_CAP ptx_gen_kernel(PtxGenArgs A) { /* documents of up to four replicas */
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
-    if (blockIdx.x < A.n_docs) ptx_gen_doc<64>(A, blockIdx.x, ptx_lds);
+    if (blockIdx.x < A.n_docs) ptx_gen_doc<64, 4>(A, blockIdx.x, ptx_lds);
+}
+extern "C" __global__ void __launch_bounds__(64) ptx_gen_kernel_r8(PtxGenArgs A) { /* five to eight replicas: the per-replica state twice as wide */
+    extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
+    if (blockIdx.x < A.n_docs) ptx_gen_doc<64, PTX_GEN_MAX_R>(A, blockIdx.x, ptx_lds);
 }
 /* change() for caller-supplied InputOperations (change_core.h): one 64-thread workgroup (one wave) per replica log */
 extern "C" __global__ void __launch_bounds__(64) ptx_change_kernel(PtxChangeArgs A) {
@@ -774,7 +778,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     ctx->own_stream = ctx->stream;
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_many_wide, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_merge_kernel_lean64, (const void*)ptx_merge_kernel_lean128, (const void*)ptx_merge_kernel_lean192, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_gen_kernel, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_many_wide, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_merge_kernel_lean64, (const void*)ptx_merge_kernel_lean128, (const void*)ptx_merge_kernel_lean192, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_gen_kernel, (const void*)ptx_gen_kernel_r8, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -1902,7 +1906,7 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     const uint64_t T = b->n_ops;
     uint32_t *cap_hdr = nullptr, *d_nchg = nullptr, *d_ncom = nullptr, *d_status = nullptr;
     uint16_t* cap_env = nullptr;
-    PtxGenChange* d_ctab = nullptr;
+    uint8_t* d_ctab = nullptr; /* PtxGenChangeT<ptx_gen_max_r(R)> per op */
     uint16_t* d_known = nullptr;
     auto drop = [&]() { /* idempotent: a later failure path may call it again */
         (void)hipFree(cap_hdr);
@@ -1943,7 +1947,7 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     PTX_TRYG(dalloc(&d_nchg, (uint64_t)b->n_logs));
     PTX_TRYG(dalloc(&d_ncom, (uint64_t)D));
     PTX_TRYG(dalloc(&d_status, (uint64_t)D));
-    PTX_TRYG(dalloc(&d_ctab, T));
+    PTX_TRYG(dalloc(&d_ctab, T * ptx_gen_change_bytes(R)));
     PTX_TRYG(dalloc(&d_known, T));
     if (D == 0) {
         drop();
@@ -1994,7 +1998,8 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     A.known = d_known;
     hipLaunchKernelGGL(ptx_regular_offsets_kernel, dim3((b->n_logs + 256) / 256), dim3(256), 0, ctx->stream, b->log_off, b->n_logs, (uint64_t)N);
     (void)hipEventRecord(ctx->ev0, ctx->stream);
-    hipLaunchKernelGGL(ptx_gen_kernel, dim3(D), dim3(64), A.lds_bytes, ctx->stream, A);
+    if (R <= 4) hipLaunchKernelGGL(ptx_gen_kernel, dim3(D), dim3(64), A.lds_bytes, ctx->stream, A);
+    else hipLaunchKernelGGL(ptx_gen_kernel_r8, dim3(D), dim3(64), A.lds_bytes, ctx->stream, A);
     PTX_TRYG(hipGetLastError());
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     std::vector<uint32_t> nchg(b->n_logs), status(D);

@@ -250,14 +250,15 @@ extern "C" uint64_t ptx_emu_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc,
  * (rows_per_log rows per log, R logs per doc); the envelope is left at capacity stride, n_changes says how much is used */
 extern "C" int ptx_emu_generate(PtxGenArgs* A, int reverse) {
     A->lds_bytes = 160 * 1024;
-    A->ctab = (PtxGenChange*)calloc((size_t)A->n_docs * A->R * A->rows_per_log + 1, sizeof(PtxGenChange));
+    A->ctab = calloc((size_t)A->n_docs * A->R * A->rows_per_log + 1, ptx_gen_change_bytes(A->R));
     A->known = (uint16_t*)calloc((size_t)A->n_docs * A->R * A->rows_per_log + 1, sizeof(uint16_t));
     uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)A->lds_bytes + 64);
     if (!lds || !A->ctab || !A->known) return 1;
     ptx_emu_reverse = reverse;
     for (uint32_t d = 0; d < A->n_docs; ++d) {
         ptx_emu_lds_fill(lds, A->lds_bytes);
-        ptx_gen_doc<0>(*A, d, lds);
+        if (A->R <= 4) ptx_gen_doc<0, 4>(*A, d, lds);
+        else ptx_gen_doc<0, PTX_GEN_MAX_R>(*A, d, lds);
     }
     ptx_emu_lds_fill(lds, 0);
     free(lds);
