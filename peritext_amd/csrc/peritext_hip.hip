@@ -111,10 +111,12 @@ extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kern
     if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS, true>(A, blockIdx.x, ptx_lds);
 }
 
-/* the records of every log — first its own capacity [cap_off[l], cap_off[l + 1]), then its overflow extent from ext_off[l] — packed to out_off[l] */
-extern "C" __global__ void __launch_bounds__(256) ptx_patch_pack_kernel(const ptx_patch* src, const uint64_t* cap_off, const uint64_t* ext_off, const uint64_t* out_off, ptx_patch* dst) {
-    const uint32_t l = blockIdx.x;
-    const uint64_t c0 = cap_off[l], cap = cap_off[l + 1] - c0, o0 = out_off[l], n = out_off[l + 1] - o0;
+/* the records of every log — first its own capacity [cap_off[l], cap_off[l + 1]), then its overflow extent from ext_off[l] — packed to out_off[l]; the logs from
+ * first_log on, into a buffer that starts at record out_base of the packed stream (the whole stream in one go unless device memory is short) */
+extern "C" __global__ void __launch_bounds__(256) ptx_patch_pack_kernel(const ptx_patch* src, const uint64_t* cap_off, const uint64_t* ext_off, const uint64_t* out_off, ptx_patch* dst,
+                                                                        uint32_t first_log, uint64_t out_base) {
+    const uint32_t l = first_log + blockIdx.x;
+    const uint64_t c0 = cap_off[l], cap = cap_off[l + 1] - c0, o0 = out_off[l] - out_base, n = out_off[l + 1] - out_off[l];
     const uint64_t x0 = ext_off[3 * (uint64_t)l], x1 = ext_off[3 * (uint64_t)l + 1], xcap = ext_off[3 * (uint64_t)l + 2];
     for (uint64_t i = threadIdx.x; i < n; i += 256) dst[o0 + i] = i < cap ? src[c0 + i] : i - cap < xcap ? src[x0 + (i - cap)] : src[x1 + (i - cap - xcap)];
 }
@@ -1786,14 +1788,25 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
      * bump inside the kernel) and goes on there; a small kernel then packs the records of every log to exact offsets, and only those are downloaded.  Only when
      * the arena itself runs out (or a log outgrows its second extent) is the replay launched again, with exact capacities. */
     std::vector<uint64_t> xoff((size_t)L + 1, 0);
+    /* (tests: PTX_REPLAY_NO_ARENA=1 plays a device too full for the arena, PTX_REPLAY_PACK_RECORDS=<n> one too full for the packed copy) */
+    const bool no_arena_env = getenv("PTX_REPLAY_NO_ARENA") != nullptr;
+    const uint64_t pack_env = getenv("PTX_REPLAY_PACK_RECORDS") ? (uint64_t)std::max<long long>(atoll(getenv("PTX_REPLAY_PACK_RECORDS")), 1) : 0;
     for (uint32_t attempt = 0; attempt < 2 && st == PTX_OK; ++attempt) {
-        const uint64_t total = h->off[L], arena_cap = attempt == 0 ? total + 65536 : 0;
+        const uint64_t total = h->off[L];
+        uint64_t arena_cap = attempt == 0 && !no_arena_env ? total + 65536 : 0;
         e = hipMalloc((void**)&d_off, ((size_t)L + 1) * 8);
         if (e == hipSuccess) e = hipMalloc((void**)&d_ext, (size_t)L * 24);
         if (e == hipSuccess) e = hipMalloc((void**)&d_xoff, ((size_t)L + 1) * 8);
         if (e == hipSuccess) e = hipMalloc((void**)&d_next, 8);
         if (e == hipSuccess) e = hipMalloc((void**)&d_logs, (size_t)L * sizeof(ptx_patch_log));
-        if (e == hipSuccess) e = hipMalloc((void**)&d_patches, std::max<uint64_t>(total + arena_cap, 1) * sizeof(ptx_patch));
+        if (e == hipSuccess) {
+            e = hipMalloc((void**)&d_patches, std::max<uint64_t>(total + arena_cap, 1) * sizeof(ptx_patch));
+            if (e == hipErrorOutOfMemory && arena_cap) { /* no room for the arena: the capacities alone (a log that outgrows its own is then replayed again with exact sizes) */
+                (void)hipGetLastError();
+                arena_cap = 0;
+                e = hipMalloc((void**)&d_patches, std::max<uint64_t>(total, 1) * sizeof(ptx_patch));
+            }
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(d_off, h->off.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_next, 0, 8, ctx->stream);
         if (e == hipSuccess) {
@@ -1842,14 +1855,31 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
         if (!over || attempt == 1) {
             for (uint32_t l = 0; l < L; ++l) xoff[l + 1] = xoff[l] + (h->logs[l].status == PTX_OK ? h->logs[l].n_patches : 0u);
             const uint64_t xtotal = xoff[L];
-            e = hipMalloc((void**)&d_packed, std::max<uint64_t>(xtotal, 1) * sizeof(ptx_patch));
-            if (e == hipSuccess) e = hipMemcpyAsync(d_xoff, xoff.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(ptx_patch_pack_kernel, dim3(L), dim3(256), 0, ctx->stream, d_patches, d_off, d_ext, d_xoff, d_packed);
-                e = hipGetLastError();
+            /* the packed copy: the whole stream at once — or, where device memory is short, as large a buffer as there is (never smaller than the longest log's
+             * stream), filled and downloaded a range of logs at a time */
+            uint64_t longest = 1, pack_cap = std::max<uint64_t>(xtotal, 1);
+            for (uint32_t l = 0; l < L; ++l) longest = std::max<uint64_t>(longest, xoff[l + 1] - xoff[l]);
+            if (pack_env) pack_cap = std::max<uint64_t>(std::min<uint64_t>(pack_cap, pack_env), longest);
+            for (;;) {
+                e = hipMalloc((void**)&d_packed, pack_cap * sizeof(ptx_patch));
+                if (e != hipErrorOutOfMemory || pack_cap == longest) break;
+                (void)hipGetLastError();
+                pack_cap = std::max<uint64_t>(pack_cap / 2, longest);
             }
+            if (e == hipSuccess) e = hipMemcpyAsync(d_xoff, xoff.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
             h->patches.resize(std::max<uint64_t>(xtotal, 1));
-            if (e == hipSuccess && xtotal) e = hipMemcpyAsync(h->patches.data(), d_packed, xtotal * sizeof(ptx_patch), hipMemcpyDeviceToHost, ctx->stream);
+            for (uint32_t l0 = 0; e == hipSuccess && l0 < L;) {
+                uint32_t l1 = l0 + 1;
+                while (l1 < L && xoff[l1 + 1] - xoff[l0] <= pack_cap) ++l1;
+                const uint64_t cnt = xoff[l1] - xoff[l0];
+                if (cnt) {
+                    hipLaunchKernelGGL(ptx_patch_pack_kernel, dim3(l1 - l0), dim3(256), 0, ctx->stream, d_patches, d_off, d_ext, d_xoff, d_packed, l0, xoff[l0]);
+                    e = hipGetLastError();
+                    if (e == hipSuccess) e = hipMemcpyAsync(h->patches.data() + xoff[l0], d_packed, cnt * sizeof(ptx_patch), hipMemcpyDeviceToHost, ctx->stream);
+                    if (e == hipSuccess && l1 < L) e = hipStreamSynchronize(ctx->stream); /* the buffer is filled again */
+                }
+                l0 = l1;
+            }
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) st = fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("patch download: ") + hipGetErrorString(e));
             h->off = xoff;

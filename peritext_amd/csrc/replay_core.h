@@ -322,6 +322,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                 const unsigned long long at_ = ptx_atomic_add64(A.arena_next, (unsigned long long)want_);      \
                 const bool ok_ = at_ + want_ <= A.arena_cap;                                                   \
                 H->ext_ok = ok_ ? 1u : 0u;                                                                     \
+                if (!ok_) (void)ptx_atomic_add64(A.arena_next, 0ull - (unsigned long long)want_); /* hand it back: a smaller request of another log may still fit */ \
                 if (ok_) {                                                                                     \
                     const uint32_t k_ = 2u - ext_left;                                                         \
                     H->ext_cap[k_] = want_;                                                                    \

@@ -384,6 +384,28 @@ def test_golden_patch_streams(eng, name):
         assert np.any(pat.logs["n_patches"].astype(np.int64) > 2 * rows + 16)
 
 
+def test_patch_streams_when_device_memory_is_short(eng, monkeypatch):
+    """the one-launch replay asks for its guessed capacities, an arena of the same size and a packed copy; where the device has no room for the
+    arena the capacities alone must do (a log that outgrows its own is replayed again with exact sizes: two launches), and where it has none for the whole packed
+    copy the streams are packed and downloaded a range of logs at a time.  Both are played through the library's test switches on the reference-made fixture whose
+    logs overflow the guess; the streams must equal the reference's, patch for patch."""
+    g = _load("patches_rich_300.json")
+    batch = wire.encode_docs([d["logs"] for d in g["docs"]])
+    expected = [d["expected"] for d in g["docs"]]
+    _, whole = _streams(eng, batch)
+    monkeypatch.setenv("PTX_REPLAY_NO_ARENA", "1")
+    _, pat = _streams(eng, batch)
+    assert pat.launches == 2 and H.check_patch_streams(batch, pat, expected) == batch.n_logs
+    monkeypatch.delenv("PTX_REPLAY_NO_ARENA")
+    monkeypatch.setenv("PTX_REPLAY_PACK_RECORDS", "1")  # (never smaller than the longest log's stream: a log at a time)
+    _, pat = _streams(eng, batch)
+    assert pat.launches == 1 and H.check_patch_streams(batch, pat, expected) == batch.n_logs
+    assert np.array_equal(pat.patch_off, whole.patch_off) and np.array_equal(pat.patches, whole.patches)
+    monkeypatch.setenv("PTX_REPLAY_PACK_RECORDS", str(int(whole.patch_off[-1]) // 3))
+    _, pat = _streams(eng, batch)
+    assert np.array_equal(pat.patch_off, whole.patch_off) and np.array_equal(pat.patches, whole.patches)
+
+
 def test_marks_that_arrive_after_larger_op_ids(eng):
     """GPU twin of test_emu_patches.py's: three actors mark one text concurrently and a replica applies them in descending id order — almost every op meets
     larger ids applied before it (the replay's table scan instead of per-slot winners), every link / comment state is met."""
