@@ -349,3 +349,33 @@ def test_comment_ops_on_one_id_beyond_one_lanes_sweep_in_the_hbm_staged_path():
         for d in range(len(docs)):
             H.check_log(batch, res, d, expected[d][0])
     assert int(H.emu_merge(batch, lds_bytes=160 * 1024).logs["status"][1]) == 0  # (the LDS kernel, whose LDS bounds the ops of a log, sweeps every id in a lane)
+
+
+def test_team_sweep_of_heavy_comment_ids_equals_the_lds_kernels_lane_sweep_on_random_logs():
+    """The HBM-staged kernel's team sweep (ids with more than 1 024 covering ops: range-chmax tree + presence bitmap) against the LDS kernel's per-lane sweep of the
+    same log — two implementations of peritext.ts:314-321 over one set of inputs: rows, counts and digests equal on ten random logs of one to four ids, 1 100 to
+    2 600 comment ops, short and long ranges (no oracle needed: the LDS kernel's sweep is the one every other comment test pins against it)."""
+    import random
+
+    heavy_logs = 0
+    for seed in range(10):
+        rnd = random.Random(1000 + seed)
+        n_chars = rnd.choice([40, 97, 160, 333])
+        n_ops = rnd.randrange(1100, 2600)
+        ids = tuple("c%d" % i for i in range(rnd.randrange(1, 5)))
+        weights = tuple(rnd.choice([1, 2, 9]) for _ in ids)
+        log = _one_comment_id_log(n_chars, n_ops, seed, ids, weights)
+        per_id = {}
+        for ch in log[1:]:
+            per_id[ch["ops"][0]["attrs"]["id"]] = per_id.get(ch["ops"][0]["attrs"]["id"], 0) + 1
+        heavy_logs += max(per_id.values()) > 1024
+        batch = wire.encode_docs([[log]])
+        small = H.emu_merge(batch, lds_bytes=160 * 1024)
+        big = H.emu_merge_big(batch, reverse=seed % 3)
+        assert int(small.logs["status"][0]) == 0 and int(big.logs["status"][0]) == 0
+        for f in ("n_visible", "n_spans", "n_cintervals"):
+            assert int(small.logs[f][0]) == int(big.logs[f][0]), (seed, f)
+        assert (small.logs["digest"][0] == big.logs["digest"][0]).all(), seed
+        k = int(big.logs["n_cintervals"][0])
+        assert np.array_equal(small.cintervals[:k], big.cintervals[:k]) and np.array_equal(small.spans[:int(big.logs["n_spans"][0])], big.spans[:int(big.logs["n_spans"][0])])
+    assert heavy_logs >= 5, heavy_logs
