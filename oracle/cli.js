@@ -72,18 +72,22 @@ function rootOf(v) {
     return v
 }
 
-/* --list-key K: the list object under root key K instead of "text" (a document may hold several: micromerge.ts:589) */
+/* --list-key K: the list object under root key K instead of "text" (a document may hold several: micromerge.ts:589); "a.b": the list under key b of the map
+ * under root key a (an OperationPath, micromerge.ts:178-196) */
 const LIST_KEY = flag("--list-key", "text")
+const LIST_PATH = LIST_KEY.split(".")
 function expectedOf(doc) {
     let text = []
     try {
-        text = (doc.root[LIST_KEY] || []).slice()
+        let at = doc.root
+        for (const k of LIST_PATH) at = at[k]
+        text = (at || []).slice()
     } catch (e) {
         text = []
     }
     let spans
     try {
-        spans = doc.getTextWithFormatting([LIST_KEY])
+        spans = doc.getTextWithFormatting(LIST_PATH)
     } catch (e) {
         return { spans: null, text, error: String(e.message) }
     }

@@ -57,7 +57,7 @@ export interface WireBatch {
     values: string[]; urls: string[]; logDoc: number[]; docActors: string[][]; docComments: string[][]
     /** keys of the map objects (ref_b of the PTX_ACT_MAPSET / MAPDEL / MAKELIST rows) and the JSON text of the values they set (payload) */
     keys?: string[]; mapValues?: string[]
-    /** encodeDocs(listKeys): device log l merges the list under root key logList[l] of replica logReplica[l] of its document */
+    /** encodeDocs(listKeys): device log l merges the list under root key logList[l] ("a.b": the list under key b of the map under root key a — an OperationPath) of replica logReplica[l] of its document */
     logList?: string[]; logReplica?: number[]
 }
 export interface WireResult {

@@ -159,6 +159,8 @@ function encodeDocs(docs, opts) {
             const t0 = Array.isArray(textObjs[d]) ? textObjs[d][r] : textObjs[d]
             let textObj = t0 === undefined ? null : t0, nrows = 0
             const otherLists = new Set() /* the replica's list objects that are not this device log's: their ops are rows without effect here */
+            const wantPath = String(lkey).split(".") /* "meta.notes": a list nested in map objects, by its path (micromerge.ts:178-196); one key: a list of the root map */
+            const pathOf = new Map() /* map / list object -> the keys that lead to it from the root map, as the ops of this log made them */
             for (const ch of log) {
                 /* the Change envelope (micromerge.ts:60-71): what applyChange's admission checks (:499-511) */
                 chgActor.push(arank.get(ch.actor))
@@ -168,6 +170,8 @@ function encodeDocs(docs, opts) {
                 for (const op of ch.ops) {
                     const row = { opId: encId(op.opId), refA: 0n, refB: 0n, payload: 0, action: ACT.NOP, markType: 0, sideA: 0, sideB: 0 }
                     const onRoot = op.obj === undefined || op.obj === null || op.obj === ROOT || typeof op.obj === "symbol"
+                    if ((op.action === "makeMap" || op.action === "makeList") && op.key !== undefined && (onRoot || pathOf.has(op.obj)) && !pathOf.has(op.opId))
+                        pathOf.set(op.opId, (onRoot ? [] : pathOf.get(op.obj)).concat([op.key]))
                     if (op.action === "makeList" && onRoot && op.key === lkey && textObj === null) {
                         row.action = ACT.MAKELIST
                         row.refB = BigInt(intern(keys, keyIx, lkey)) /* also a write of the root map's key */
@@ -211,7 +215,12 @@ function encodeDocs(docs, opts) {
                             row.action = ACT.MAPSET
                             row.markType = op.action === "makeMap" ? MAPV.MAP : op.action === "makeList" ? MAPV.LIST : MAPV.SCALAR
                             if (op.action === "set") row.payload = intern(mapValues, mapValueIx, JSON.stringify(op.value === undefined ? null : op.value))
-                            if (op.action === "makeList") otherLists.add(op.opId)
+                            if (op.action === "makeList") {
+                                const p = pathOf.get(op.opId)
+                                /* the nested list this device log merges: its makeList stays a write of its map's key */
+                                if (textObj === null && wantPath.length > 1 && p && p.length === wantPath.length && p.every((k, i) => k === wantPath[i])) textObj = op.opId
+                                else otherLists.add(op.opId)
+                            }
                         }
                     } else if (otherLists.has(op.obj) && (op.action === "addMark" || op.action === "removeMark" || op.elemId !== undefined || op.insert)) {
                         /* an op on ANOTHER list object of this replica (merged by its own device log when its key is in listKeys): PTX_ACT_NOP here */

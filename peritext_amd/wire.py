@@ -207,7 +207,9 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None, li
     (micromerge.ts:589: makeList under any key; :534-571: applyOp takes any list object) becomes one device log per (replica, key), in that order — each with the
     replica's whole Change envelope (causal admission is the replica's, not the list's) and, of the list ops, those of ITS list: the ops on the replica's other
     list objects are rows without effect there.  `Batch.log_list[l]` names the key of device log l, `Batch.log_replica[l]` its replica within the document.
-    The default merges the list under "text" alone, as the reference's editor does (bridge.ts).
+    The default merges the list under "text" alone, as the reference's editor does (bridge.ts).  A key with dots — "meta.notes" — names a list NESTED in map
+    objects by its path (the reference's OperationPath ["meta", "notes"], micromerge.ts:178-196): the list the first makeList of key "notes" made in the map
+    the first makeMap of key "meta" made in the root map.
 
     All replicas of a doc share actor ranks and comment-id ranks, so their digests are comparable.
     extra_actors / extra_comments: per doc, actor names / comment ids that get a rank although no change of the batch uses them
@@ -272,6 +274,8 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None, li
             log = logs[rep_ix]
             text_obj = text_objs[d] if text_objs else None
             other_lists = set()  # the replica's list objects that are not this device log's: their ops are rows without effect here
+            want_path = tuple(lkey.split("."))  # the list's path through the map objects (one key: a list of the root map)
+            path_of = {}  # map / list object -> the keys that lead to it from the root map, as the ops of this log made them
             nrows = 0
             for ch in log:
                 chg_actor.append(arank[ch["actor"]])
@@ -283,6 +287,8 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None, li
                     row = dict(op_id=enc_id(op["opId"]), ref_a=0, ref_b=0, payload=0, action=abi.ACT_NOP, mark_type=0, side_a=0, side_b=0)
                     obj = op.get("obj")
                     on_root = obj is None or obj == ROOT
+                    if act in ("makeMap", "makeList") and "key" in op and (on_root or obj in path_of):
+                        path_of.setdefault(op["opId"], (() if on_root else path_of[obj]) + (op["key"],))
                     if act == "makeList" and on_root and op.get("key") == lkey and text_obj is None:
                         row.update(action=abi.ACT_MAKELIST, ref_b=intern(keys, key_ix, lkey))  # also a write of the root map's key
                         text_obj = op["opId"]
@@ -327,7 +333,10 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None, li
                             if act == "set":
                                 row["payload"] = intern(mvals, mval_ix, json.dumps(op.get("value"), sort_keys=True, ensure_ascii=False, separators=(",", ":")))
                             if act == "makeList":
-                                other_lists.add(op["opId"])
+                                if text_obj is None and len(want_path) > 1 and path_of.get(op["opId"]) == want_path:
+                                    text_obj = op["opId"]  # the nested list this device log merges: its makeList stays a write of its map's key
+                                else:
+                                    other_lists.add(op["opId"])
                     elif obj in other_lists and (act in ("addMark", "removeMark") or "elemId" in op or op.get("insert")):
                         pass  # an op on ANOTHER list object of this replica (merged by its own device log when its key is in list_keys): PTX_ACT_NOP here
                     elif act in ("addMark", "removeMark") or "elemId" in op or op.get("insert"):

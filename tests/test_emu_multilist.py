@@ -76,6 +76,50 @@ def test_two_lists_of_one_document(impl):
         assert roots["text"] == {"$list": True} and roots["notes"] == {"$list": True} and roots["meta"] == {"title": "draft"}
 
 
+def nested_list_document():
+    """Two replicas; a list under key "notes" of the map under root key "meta" (OperationPath ["meta", "notes"]) beside the root list "text"; concurrent edits."""
+    a1 = H.oracle_change([[[]]], [[
+        [{"path": [], "action": "makeList", "key": "text"}, {"path": [], "action": "makeMap", "key": "meta"}],
+        [{"path": ["meta"], "action": "makeList", "key": "notes"}, {"path": ["meta"], "action": "set", "key": "title", "value": "draft"}],
+        [{"path": ["meta", "notes"], "action": "insert", "index": 0, "values": list("remember the milk")}],
+        [{"path": ["text"], "action": "insert", "index": 0, "values": list("Hello")}],
+        [{"path": ["meta", "notes"], "action": "addMark", "markType": "strong", "startIndex": 0, "endIndex": 8}],
+    ]], ["alice"])
+    b1 = H.oracle_change([[a1]], [[
+        [{"path": ["meta", "notes"], "action": "insert", "index": 8, "values": list(" (bob)")}],
+        [{"path": ["meta", "notes"], "action": "delete", "index": 0, "count": 3}, {"path": ["text"], "action": "insert", "index": 5, "values": list(" world")}],
+        [{"path": ["meta", "notes"], "action": "addMark", "markType": "comment", "attrs": {"id": "n-1"}, "startIndex": 2, "endIndex": 9}],
+    ]], ["bob"])
+    a2 = H.oracle_change([[a1]], [[
+        [{"path": ["meta", "notes"], "action": "insert", "index": 17, "values": list("!")}],
+        [{"path": ["meta", "notes"], "action": "removeMark", "markType": "strong", "startIndex": 4, "endIndex": 12}],
+    ]], ["alice"])
+    return [a1 + a2 + b1, a1 + b1 + a2]
+
+
+@pytest.mark.parametrize("impl", ["oracle", "ref"])
+def test_a_list_nested_in_a_map_by_its_path(impl):
+    """Round 5: encode_docs(list_keys=("text", "meta.notes")) — the nested list is a device log of its own, named by the reference's OperationPath; expected values:
+    getTextWithFormatting(["meta", "notes"]) of the oracle's / the type-erased reference's replicas."""
+    if impl == "ref" and not os.path.exists(os.path.join(H.ROOT, "oracle", "_ref", "micromerge.js")):
+        pytest.skip("oracle/_ref not built")
+    logs = nested_list_document()
+    batch = wire.encode_docs([logs], list_keys=("text", "meta.notes"))
+    assert batch.n_logs == 4 and batch.log_list == ["text", "meta.notes", "text", "meta.notes"]
+    want = {k: _expected(logs, k, impl) for k in ("text", "meta.notes")}
+    assert len(want["meta.notes"][0]["spans"]) > 2 and "".join(s["text"] for s in want["meta.notes"][0]["spans"]).startswith("ember")
+    for reverse in (0, 1, 2):
+        res = H.emu_merge(batch, reverse=reverse, admission=True)
+        assert (res.logs["status"] == 0).all()
+        for log in range(4):
+            e = want[batch.log_list[log]][batch.log_replica[log]]
+            assert H.norm_spans(wire.decode_spans(batch, res, log)) == H.norm_spans(e["spans"]), (log, reverse)
+        assert (res.logs["digest"][1] == res.logs["digest"][3]).all() and not (res.logs["digest"][0] == res.logs["digest"][1]).all()
+    # without its path in list_keys the nested list's ops are rows without effect (as every other list's)
+    one = wire.encode_docs([logs])
+    assert H.norm_spans(wire.decode_spans(one, H.emu_merge(one), 0)) == H.norm_spans(want["text"][0]["spans"])
+
+
 def test_a_list_op_on_an_object_nobody_made_is_still_refused():
     logs = two_list_document()
     bad = [dict(c) for c in logs[0]]

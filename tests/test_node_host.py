@@ -108,6 +108,18 @@ def test_js_encoder_matches_python_encoder_on_documents_with_several_lists(tmp_p
                  "sideB": b.side_b, "logHdr": b.log_hdr, "chgOff": b.chg_off, "chgHdr": b.chg_hdr, "chgEnv": b.chg_env}.items():
         assert js[k] == sha(a), k
     assert _node("encode", str(p))["nLogs"] == 2  # the default: the list under "text" alone
+    # a list nested in a map, named by its path
+    from test_emu_multilist import nested_list_document
+
+    nlogs = nested_list_document()
+    p2 = tmp_path / "nested.json"
+    p2.write_text(json.dumps({"docs": [{"logs": nlogs}]}))
+    js = _node("encode", str(p2), "text,meta.notes")
+    b = wire.encode_docs([nlogs], list_keys=("text", "meta.notes"))
+    assert js["nLogs"] == b.n_logs == 4 and js["logList"] == b.log_list and js["keys"] == b.keys
+    for k, a in {"logOff": b.log_off, "opId": b.op_id, "refA": b.ref_a, "refB": b.ref_b, "payload": b.payload, "action": b.action, "markType": b.mark_type, "logHdr": b.log_hdr,
+                 "chgHdr": b.chg_hdr, "chgEnv": b.chg_env}.items():
+        assert js[k] == sha(a), k
 
 
 @pytest.mark.gpu
