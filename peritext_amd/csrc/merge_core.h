@@ -43,8 +43,14 @@
 #include <type_traits>
 #include "../../include/peritext_hip.h"
 
+#ifndef PTX_U64
+#define PTX_U64 1
+#endif
+#ifndef PTX_U128
+#define PTX_U128 2
+#endif
 #ifndef PTX_U
-#define PTX_U 2 /* rows in flight per thread in the batched loops */
+#define PTX_U (kThreads == 64u ? PTX_U64 : kThreads == 128u ? PTX_U128 : 2) /* rows in flight per thread in the batched loops (per build, like PTX_UV below) */
 #endif
 
 #define PTX_IN(i0, u) ((i0) + (uint32_t)(u) * _T < _n)
@@ -64,16 +70,32 @@
 #ifndef PTX_UM
 #define PTX_UM 1u /* mark ops per thread and step in P5a: five gathers per op, so one op in flight + one in work */
 #endif
-#ifndef PTX_UB
-#define PTX_UB 2u /* mark ops per thread and step in the LWW pass P5b (one opId gather each, issued together) */
+#ifndef PTX_UB64
+#define PTX_UB64 1u
 #endif
+#ifndef PTX_UB128
+#define PTX_UB128 2u
+#endif
+#ifndef PTX_UB
+#define PTX_UB (kThreads == 64u ? PTX_UB64 : kThreads == 128u ? PTX_UB128 : 2u)
+#endif
+/* (PTX_UB: mark ops per thread and step in the LWW pass P5b — one opId gather each, issued together) */
 #define PTX_NCLK 32 /* phase stamps of the diagnostic build (slot PTX_CLK_EXACT_WALKS counts the logs whose admission was walked twice) */
 #define PTX_CLK_EXACT_WALKS 15
 #ifndef PTX_KO_P5A_RA
 #define PTX_KO_P5A_RA 0 /* knock-out (WRONG results, timing experiments only): the mark ops do not read ref_a a second time */
 #endif
+#ifndef PTX_UV64
+#define PTX_UV64 1
+#endif
+#ifndef PTX_UV128
+#define PTX_UV128 4
+#endif
 #ifndef PTX_UV
-#define PTX_UV 8 /* items per thread and step in the loops that are chains of dependent LDS reads per item (tree order, list ranking, unpark): the chains of a step run side by side */
+/* items per thread and step in the loops that are chains of dependent LDS reads per item (tree order, list ranking, unpark): the chains of a step run side by side.
+ * Eight where a log is three waves or more; the one- and two-wave builds (logs of a few hundred rows, some eighty to three hundred elements) take fewer — an item
+ * slot past the end of a short list still executes its instructions (round 6, same box: 4 instead of 8 is -8.2 % on BASELINE config #2, -6.5 % on #3, -0.2 % on #4) */
+#define PTX_UV (kThreads == 64u ? PTX_UV64 : kThreads == 128u ? PTX_UV128 : 8)
 #endif
 
 /* the machine: gfx950.  (The CPU test-suite compiles these sources against a header of its own that plays the workgroup with one host
@@ -139,7 +161,15 @@ PTX_DEV uint64_t ptx_fmix64(uint64_t x) {
     x ^= x >> 31;
     return x;
 }
+#ifndef PTX_KO_DIGEST
+#define PTX_KO_DIGEST 0 /* knock-out (WRONG digests, timing experiments only): what the digest arithmetic costs */
+#endif
 PTX_DEV void ptx_digest_item(uint64_t& h1, uint64_t& h2, uint32_t tag, uint32_t a, uint32_t b, uint32_t c) {
+    if (PTX_KO_DIGEST) {
+        h1 += tag + a;
+        h2 += b + c;
+        return;
+    }
     const uint64_t x = ((uint64_t)tag << 60) ^ ((uint64_t)a << 32) ^ (uint64_t)b;
     const uint64_t y = ptx_fmix64(x) ^ ((uint64_t)c * 0x9E3779B97F4A7C15ull);
     h1 += ptx_fmix64(y);
@@ -259,6 +289,20 @@ PTX_DEV int ptx_elem_lookup(const PtxElemIndex& ix, uint64_t id) {
     return ptx_bitrank_if_set(ix.ib, key);
 }
 
+/* The same for the logs this file's kernel takes (max_counter < 2^19 and max_actor < 4096 were checked against the header: every factor fits 24 bits): the key
+ * by ONE full-rate v_mad_u32_u24 — the compiler's own choice for `ctr * na1 + actor` is the quarter-rate 64-bit multiply-add —, an id outside the header's bounds
+ * looks up key 0 (a counter of 0: no insert of an accepted log has it), and no branch: one 8-byte LDS read, a select at the end. */
+PTX_DEV int ptx_elem_lookup24(const PtxElemIndex& ix, uint64_t id) {
+    const uint32_t ctr = (uint32_t)(id >> 32), actor = (uint32_t)id;
+    const bool ok = (ctr - 1u < ix.max_ctr) & (actor <= ix.max_actor);
+    const uint32_t key0 = ptx_mul24(ctr, ix.na1) + actor; /* (not the inline-asm form: the compiler branches around an asm it cannot speculate) */
+    const uint32_t key = ok ? key0 : 0u;
+    const PtxBitWord w = ix.ib[key >> 5];
+    const uint32_t s = key & 31u;
+    const uint32_t r = w.pre + ptx_popc(w.bits & ((1u << s) - 1u));
+    return ((w.bits >> s) & 1u) ? (int)r : -1;
+}
+
 /* ---- LDS bump allocator ---- */
 struct PtxBump {
     uint8_t* base;
@@ -304,9 +348,7 @@ PTX_DEV T* ptx_try_alloc(PtxBump& bd, uint32_t count) {
 }
 
 PTX_DEV uint32_t ptx_ceil_log2(uint32_t x) { /* smallest k with (1<<k) >= x, x>=1 */
-    uint32_t k = 0;
-    while ((1u << k) < x) ++k;
-    return k;
+    return x <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(x - 1u);
 }
 
 /* ---- LDS working set of ptx_merge_log (mirrors its ptx_alloc calls; used by the host to size the
@@ -383,6 +425,23 @@ static inline void ptx_census_rows(const uint64_t* op_id, const uint8_t* action,
         }
     }
     *out = h;
+}
+
+/* a log's header by the scalar unit, word by word (a 40-byte struct copy through the constant address space came out as vector loads) */
+PTX_DEV ptx_log_hdr ptx_load_log_hdr(const ptx_log_hdr* p) {
+    const uint32_t* w = (const uint32_t*)p;
+    ptx_log_hdr h;
+    h.n_ins = PTX_CONST_LOAD(w + 0);
+    h.n_del = PTX_CONST_LOAD(w + 1);
+    h.n_mark[0] = PTX_CONST_LOAD(w + 2);
+    h.n_mark[1] = PTX_CONST_LOAD(w + 3);
+    h.n_mark[2] = PTX_CONST_LOAD(w + 4);
+    h.n_mark[3] = PTX_CONST_LOAD(w + 5);
+    h.max_counter = PTX_CONST_LOAD(w + 6);
+    h.max_actor = PTX_CONST_LOAD(w + 7);
+    h.n_comment_ids = PTX_CONST_LOAD(w + 8);
+    h.reserved = 0;
+    return h;
 }
 
 template <bool kDiag>
@@ -788,7 +847,11 @@ PTX_DEV bool ptx_mark_of_kept(const PtxMarkLaneKept& P, uint32_t b, uint32_t& k)
  * writes the result row (ptx_write_result) — ONE copy of that code instead of one per early exit. */
 template <int kManyActors, uint32_t kThreads, bool kDiag, bool kLean>
 PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t* lds, uint32_t& lds_high) {
-    const uint64_t base = A.log_off[log];
+    /* What the phases take from the kernel arguments and the log's header is derived AGAIN at the head of every phase (PTX_REMAT below): scalar loads and scalar
+     * arithmetic, which the vector units do not see.  Carried from the top of the kernel these ~70 values outlive every loop, the 96 scalar registers that seven
+     * waves per SIMD allow cannot hold them, and each trip through a VGPR lane is a v_readlane — 6 % of the kernel's vector instructions in round 5, on the unit
+     * that bounds it ("What bounds the kernel"). */
+    uint64_t base = A.log_off[log];
     const uint64_t N64 = A.log_off[log + 1] - base;
     PtxHdr* H = (PtxHdr*)lds;
     PTX_LEADER {
@@ -814,13 +877,40 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         lds_high = bp.high;
         return PTX_ERR_CAPACITY;
     }
-    const uint32_t N = (uint32_t)N64;
+    uint32_t N = (uint32_t)N64;
     const uint64_t* op_id = A.op_id + base;
     const uint64_t* ref_a = A.ref_a + base;
     const uint64_t* ref_b = A.ref_b + base;
     const uint32_t* payload = A.payload + base;
     const uint8_t* action = A.action + base;
     const uint8_t* mark_type = A.mark_type + base;
+    const uint8_t* side_a = A.side_a + base;
+    const uint8_t* side_b = A.side_b + base;
+    uint32_t* out_values = A.out_values + base;
+    ptx_span* out_spans = A.out_spans + base;
+    ptx_cinterval* out_cints = A.out_cints + base;
+    /* the row-side values again, from the kernel arguments as they stand in the kernarg segment */
+#define PTX_REMAT_ROWS()                                                    \
+    do {                                                                    \
+        const PtxMergeArgs& F_ = PTX_FRESH_ARGS(A);                         \
+        PTX_REMAT_ROWS_FROM(F_);                                            \
+    } while (0)
+#define PTX_REMAT_ROWS_FROM(F_)                                             \
+    do {                                                                    \
+        base = PTX_CONST_LOAD(&F_.log_off[log]);                            \
+        N = (uint32_t)(PTX_CONST_LOAD(&F_.log_off[log + 1]) - base);        \
+        op_id = F_.op_id + base;                                            \
+        ref_a = F_.ref_a + base;                                            \
+        ref_b = F_.ref_b + base;                                            \
+        payload = F_.payload + base;                                        \
+        action = F_.action + base;                                          \
+        mark_type = F_.mark_type + base;                                    \
+        side_a = F_.side_a + base;                                          \
+        side_b = F_.side_b + base;                                          \
+        out_values = F_.out_values + base;                                  \
+        out_spans = F_.out_spans + base;                                    \
+        out_cints = F_.out_cints + base;                                    \
+    } while (0)
     if (N == 0) { /* a log with no rows: an empty document */
         PTX_LEADER {
             uint64_t g1 = 0, g2 = 0;
@@ -1188,54 +1278,65 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
     PTX_STAMP(1); /* (diagnostic builds: end of the admission phase) */
     /* ---- the log header (census) sizes everything; the row pass below verifies it ---- */
-    const ptx_log_hdr hd = A.log_hdr[log];
-    const uint32_t n = hd.n_ins; /* list elements (inserts) */
-    const uint32_t D = hd.n_del; /* deletes */
-    const uint32_t moff1 = hd.n_mark[0], moff2 = moff1 + hd.n_mark[1], moff3 = moff2 + hd.n_mark[2];
-    const uint32_t Kc = hd.n_mark[PTX_MARK_COMMENT];
+    PTX_REMAT_ROWS();
+    ptx_log_hdr hd = ptx_load_log_hdr(&PTX_FRESH_ARGS(A).log_hdr[log]);
+    uint32_t n, D, moff1, moff2, moff3, Kc, Kid, K; /* list elements (inserts); deletes; mark ops, listed grouped by type: type t owns [moff_t, moff_{t+1}) */
+    PtxElemIndex ix;
+    uint32_t kbits, keyspace, nw, nwe;
     /* comment ids are doc-local ranks over ALL replicas of the document: a log that has seen only some of the comments
      * still carries the document's ranks, so the per-id tables are sized by the id space, not by the log's comment ops */
-    const uint32_t Kid = Kc ? hd.n_comment_ids : 0u;
-    const uint32_t K = moff3 + hd.n_mark[3]; /* mark ops; listed grouped by type: type t owns [moff_t, moff_{t+1}) */
+#define PTX_HDR_SCALARS()                                                   \
+    do {                                                                    \
+        n = hd.n_ins;                                                       \
+        D = hd.n_del;                                                       \
+        moff1 = hd.n_mark[0];                                               \
+        moff2 = moff1 + hd.n_mark[1];                                       \
+        moff3 = moff2 + hd.n_mark[2];                                       \
+        Kc = hd.n_mark[PTX_MARK_COMMENT];                                   \
+        Kid = Kc ? hd.n_comment_ids : 0u;                                   \
+        K = moff3 + hd.n_mark[3];                                           \
+        ix.max_ctr = hd.max_counter;                                        \
+        ix.max_actor = hd.max_actor;                                        \
+        ix.na1 = ix.max_actor + 1u;                                         \
+        kbits = ptx_ceil_log2(K + 1);                                       \
+        keyspace = (ix.max_ctr + 1u) * ix.na1;                              \
+        nw = (keyspace + 31) / 32;                                          \
+        nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */ \
+    } while (0)
+    PTX_HDR_SCALARS();
 #define PTX_TYPE_OF(k) (((k) >= moff1 ? 1u : 0u) + ((k) >= moff2 ? 1u : 0u) + ((k) >= moff3 ? 1u : 0u))
     if ((uint64_t)n + D + K > N) {
         lds_high = bp.high;
         return PTX_ERR_BAD_OP;
     }
-
-    PtxElemIndex ix;
-    ix.max_ctr = hd.max_counter;
-    ix.max_actor = hd.max_actor;
-    ix.na1 = ix.max_actor + 1u;
-    const uint32_t kbits = ptx_ceil_log2(K + 1);
     if (ix.max_actor > 4095u || ix.max_ctr >= (1u << 19) || n > 32766u || Kid > 65535u) { /* keyspace far below 2^31 bits; 2n+1 tour nodes in 16 bits */
         lds_high = bp.high;
         return PTX_ERR_CAPACITY;
     }
-    const uint32_t keyspace = (ix.max_ctr + 1u) * ix.na1;
     if (((uint64_t)(keyspace + 1u) << kbits) > 0xFFFFFFFFull) { /* (key+1) << kbits | mark index in one u32 */
         lds_high = bp.high;
         return PTX_ERR_CAPACITY;
     }
-    const uint32_t nw = (keyspace + 31) / 32;
-    const uint32_t nwe = (n >> 5) + 1; /* words of an element-indexed bitmap (bit positions 0..n) */
     /* The row lists of the deletes and of the mark ops never live in LDS during P1 .. P4: the row pass writes them straight to their PARK in HBM — the log's own
      * span rows (8 bytes per row of the log = 2 N entries of 4 bytes, written by nobody before P6): entry = row | id key << 16, the deletes at [0, D), the mark ops
      * at the TOP, [mp0, 2 N) with mp0 = 2 N - K, type t from mp0 + moff_t.  P3a reads the deletes back, P5a the marks (both coalesced, each two steps ahead of the gathers that go through them); rows and keys
      * of the marks that still cover a visible character are read from the park by P5c / P5b — also AFTER the first span rows are out (long documents go tile by
      * tile): a log has at most n spans and N > n + D + K rows, so span row s (entries 2 s, 2 s + 1 < 2 n) never reaches entry mp0 > 2 n. */
-    uint32_t* const park = (uint32_t*)(A.out_spans + base);
-    const uint32_t park_top = 2u * N - 1u; /* last 4-byte entry of the park (a lying header's stores are kept inside it) */
-    const uint32_t mp0 = 2u * N - K;       /* (K <= N was checked above) */
-    uint32_t* maddbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 1); /* mark op k is an addMark (the tail phases need no look back at `action`) */
-    /* element-side state: dead once the mark intervals are known (P5a), then reused as scratch of the tail phases */
-    const uint32_t elem_lds = bp.off;
+    uint32_t* park = (uint32_t*)out_spans;
+    uint32_t park_top = 2u * N - 1u; /* last 4-byte entry of the park (a lying header's stores are kept inside it) */
+    uint32_t mp0 = 2u * N - K;       /* (K <= N was checked above) */
+    /* element-side state: dead once the mark intervals are known (P5a), then reused as scratch of the tail phases.  The id bitmap comes first: its LDS address is a
+     * compile-time constant, so the word address of a look-up is its instruction's offset field (one vector instruction less per id look-up and per row of P1) */
+    const uint32_t elem_lds = (kDiag ? PTX_HDR_BYTES_DIAG : PTX_HDR_BYTES);
+    bp.off = elem_lds;
     ix.ib = ptx_alloc<PtxBitWord>(bp, nw + 1);
     uint16_t* row_of = ptx_alloc<uint16_t>(bp, n + 1);         /* element -> op row */
     uint16_t* par = ptx_alloc<uint16_t>(bp, n + 1);            /* element -> parent element (n = HEAD); later: document position */
     uint32_t* delbits = ptx_alloc<uint32_t>(bp, nwe + 1);      /* element -> tombstone */
+    uint32_t elem_end = bp.off;
+    uint32_t* maddbits = ptx_alloc<uint32_t>(bp, (K >> 5) + 1); /* mark op k is an addMark (the tail phases need no look back at `action`); lives to the end */
     PTX_BAIL_CAPACITY();
-    const uint32_t mark_lds = bp.off; /* everything above this mark is phase scratch */
+    uint32_t mark_lds = bp.off; /* everything above this mark is phase scratch */
     /* scratch of P1..P3, three n-sized arrays:
      *   RW  one block of n + 3 words = `ilist` (rows of the inserts in row order; P3a leaves the deletes' target elements there; P3c: `srt`) followed by `cntw`
      *       (children per parent -> bucket ends); once the successor list stands both are dead and the block is `R`, the {next, weight} words of the list ranking
@@ -1264,10 +1365,69 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     uint16_t* plist = (uint16_t*)auxw;
     PtxBitWord* hb = (PtxBitWord*)auxw;
     PTX_BAIL_CAPACITY();
+    uint32_t d_fused = D < n + 1u ? D : n + 1u; /* deletes that ride along with the inserts in P3a */
+    /* the arrays of P4 .. P6 that stand where the tree scratch stood (allocated after P3) */
+    PtxBitWord* alive = nullptr;
+    uint32_t* brkbits = nullptr;
+    uint16_t *mrk_lo = nullptr, *mrk_hi = nullptr, *cid = nullptr;
+    uint16_t* rnk = par; /* (document positions: the parents' array, from the end of P3 on) */
+    /* PTX_REMAT(): every scalar above again — the rows' side from the kernel arguments, the header from HBM (scalar loads), the LDS addresses by the
+     * allocator's own arithmetic (ptx_a16 sizes in its order).  Called at the head of a phase, after the barrier that ends the one before. */
+#ifndef PTX_REMAT_MASK
+#define PTX_REMAT_MASK 0x82u /* which of the numbered call sites below derive the scalars again (bit k: site k).  Two are enough for a build without a single spilled scalar register — the head of P3 and its end —; all thirteen cost +1 % (their scalar loads and arithmetic), round 6 */
+#endif
+#define PTX_REMAT_AT(k_, call_)                         \
+    do {                                                \
+        if ((PTX_REMAT_MASK >> (k_)) & 1u) { call_; }   \
+    } while (0)
+#define PTX_LDS_AT(T_, off_) ((T_*)(lds + (off_)))
+#define PTX_REMAT()                                                                          \
+    do {                                                                                     \
+        const PtxMergeArgs& F_ = PTX_FRESH_ARGS(A);                                          \
+        PTX_REMAT_ROWS_FROM(F_);                                                             \
+        hd = ptx_load_log_hdr(&F_.log_hdr[log]);                                             \
+        PTX_HDR_SCALARS();                                                                   \
+        park = (uint32_t*)out_spans;                                                         \
+        park_top = 2u * N - 1u;                                                              \
+        mp0 = 2u * N - K;                                                                    \
+        d_fused = D < n + 1u ? D : n + 1u;                                                   \
+        uint32_t o_ = elem_lds;                                                              \
+        ix.ib = PTX_LDS_AT(PtxBitWord, o_);                                                  \
+        o_ += (uint32_t)ptx_a16(8u * (nw + 1u));                                             \
+        row_of = PTX_LDS_AT(uint16_t, o_);                                                   \
+        o_ += (uint32_t)ptx_a16(2u * (n + 1u));                                              \
+        par = PTX_LDS_AT(uint16_t, o_);                                                      \
+        rnk = par;                                                                           \
+        o_ += (uint32_t)ptx_a16(2u * (n + 1u));                                              \
+        delbits = PTX_LDS_AT(uint32_t, o_);                                                  \
+        o_ += (uint32_t)ptx_a16(4u * (nwe + 1u));                                            \
+        elem_end = o_;                                                                       \
+        maddbits = PTX_LDS_AT(uint32_t, o_);                                                 \
+        o_ += (uint32_t)ptx_a16(4u * ((K >> 5) + 1u));                                       \
+        mark_lds = o_; /* the tree scratch ... */                                            \
+        RW = PTX_LDS_AT(uint32_t, o_);                                                       \
+        ilist = (uint16_t*)RW;                                                               \
+        cntw = RW + (n + 2) / 2;                                                             \
+        L = PTX_LDS_AT(uint16_t, o_ + (uint32_t)ptx_a16(4u * (n + 3u)));                     \
+        klist = L;                                                                           \
+        bigp = PTX_LDS_AT(uint16_t, o_ + (uint32_t)ptx_a16(4u * (n + 3u)) + (uint32_t)ptx_a16(2u * (n + 2u))); \
+        auxw = PTX_LDS_AT(uint32_t, o_ + (uint32_t)ptx_a16(4u * (n + 3u)) + (uint32_t)ptx_a16(2u * (n + 2u)) + (uint32_t)ptx_a16(2u * (n / (PTX_SMALL_BUCKET + 1u) + 2u))); \
+        plist = (uint16_t*)auxw;                                                             \
+        hb = (PtxBitWord*)auxw;                                                              \
+        /* ... and what P4 .. P6 keep in its place */                                        \
+        alive = PTX_LDS_AT(PtxBitWord, o_);                                                  \
+        o_ += (uint32_t)ptx_a16(8u * (nwe + 1u));                                            \
+        brkbits = PTX_LDS_AT(uint32_t, o_);                                                  \
+        o_ += (uint32_t)ptx_a16(4u * (nwe + 1u));                                            \
+        mrk_lo = PTX_LDS_AT(uint16_t, o_);                                                   \
+        o_ += (uint32_t)ptx_a16(2u * (K + 1u));                                              \
+        mrk_hi = PTX_LDS_AT(uint16_t, o_);                                                   \
+        o_ += (uint32_t)ptx_a16(2u * (K + 1u));                                              \
+        cid = PTX_LDS_AT(uint16_t, o_);                                                      \
+    } while (0)
 
     /* P3a's loads, declared here because its first step is issued as soon as P1 has completed the lists (its latency then hides
      * behind the duplicate check and the prefix scan of the id bitmap) */
-    const uint32_t d_fused = D < n + 1u ? D : n + 1u; /* deletes that ride along with the inserts in P3a */
     uint32_t p3_i[PTX_U], p3_di[PTX_U], p3_dq[PTX_U];
     uint64_t p3_id[PTX_U], p3_ra[PTX_U], p3_dra[PTX_U];
     /* the park entries of this thread's deletes of a step (coalesced; issued TWO steps ahead: the gathers through them are a second trip) */
@@ -1401,6 +1561,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * rejects that log before anything is made of it. */
         PTX_SYNC_FULL();
         PTX_STAMP(11); /* end of the row loop; census, duplicate check and the prefix scan of the id bitmap follow */
+        PTX_REMAT_AT(0, PTX_REMAT());
         PTX_P3A_DQ(0u, p3_dq) /* the lists are complete: the deletes of P3a's first step are on their way */
         if (H->cur[7] != 0u) {
             /* some row is malformed (unknown action or mark type, op id of counter 0 or beyond the header's bounds): the first one
@@ -1458,6 +1619,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
     PTX_BAIL_IF_ERROR();
     PTX_STAMP(2);
+    PTX_REMAT_AT(1, PTX_REMAT());
 
     /* P5a's loads.  The rows of the mark ops come straight from their park (the low halves of its entries from mp0 on; a lane's entries of a block are
      * consecutive words): the park entries of the first step go out at the start of P3c (two LDS-only phases ahead of their use: with nine logs per CU a trip to HBM takes 10-20 k cycles, and
@@ -1496,8 +1658,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     _Pragma("unroll") for (int u = 0; u < (int)PTX_UM; ++u) {               \
         rb_[u] = ref_b[i_[u]];                                              \
         ra_[u] = PTX_KO_P5A_RA ? rb_[u] : ref_a[i_[u]];                     \
-        sa_[u] = A.side_a[base + i_[u]];                                    \
-        sb_[u] = A.side_b[base + i_[u]];                                    \
+        sa_[u] = side_a[i_[u]];                                             \
+        sb_[u] = side_b[i_[u]];                                             \
         if (pl_[u]) pl_[u] = payload[i_[u]];                                \
     }
     /* ---- P3: causal tree of the inserts -> document position of every element ---- */
@@ -1506,6 +1668,17 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         uint16_t* cnt = (uint16_t*)cntw;
         uint16_t* srt = ilist;       /* children of every parent, descending opId, parents ascending (ilist is dead after P3b) */
         uint16_t* seg = L;           /* bucket members in arrival order (klist is dead after P3b's checks) */
+        uint16_t* nx = seg;          /* P3d: the successors (seg is dead by then: srt holds the sorted buckets) */
+        uint32_t* R = RW;            /* the list ranking's {next, weight} words (srt and cnt are dead by then) */
+#define PTX_REMAT_P3()           \
+    do {                         \
+        PTX_REMAT();             \
+        cnt = (uint16_t*)cntw;   \
+        srt = ilist;             \
+        seg = L;                 \
+        nx = seg;                \
+        R = RW;                  \
+    } while (0)
 
         PTX_FOR(p, (n + 2 + 1) / 2 + 1) cntw[p] = 0;
         PTX_SYNC_LDS();
@@ -1524,17 +1697,27 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             uint64_t id_n[PTX_U], ra_n[PTX_U], dra_n[PTX_U]; /* id: the op id, or (small_keys) just its key from klist */
             auto p3a_step = [&](uint32_t st, const uint32_t (&i)[PTX_U], const uint64_t (&id)[PTX_U], const uint64_t (&ra)[PTX_U], const uint32_t (&di)[PTX_U],
                                 const uint64_t (&dra)[PTX_U]) {
+                /* the three id look-ups of an item (own key, parent, the delete's target) and those of the step's other items first, side by side: one LDS round
+                 * trip for all of them, then the stores that depend on them (nested ifs ran them one after the other) */
+                uint32_t e_[PTX_U];
+                int p_[PTX_U], t_[PTX_U];
+#pragma unroll
+                for (int u = 0; u < PTX_U; ++u) {
+                    uint32_t key = (uint32_t)id[u];
+                    if (!small_keys) ptx_id_key(ix, id[u], key);
+                    e_[u] = ptx_bitrank(ix.ib, key < keyspace ? key : 0u);
+                    p_[u] = ptx_elem_lookup24(ix, ra[u]);
+                    t_[u] = ptx_elem_lookup24(ix, dra[u]);
+                }
 #pragma unroll
                 for (int u = 0; u < PTX_U; ++u) {
                     const uint32_t j = PTX_J_OF(st, u);
                     if (j < n) {
-                        uint32_t key = (uint32_t)id[u];
-                        if (!small_keys) ptx_id_key(ix, id[u], key);
-                        const uint32_t e = ptx_bitrank(ix.ib, key);
+                        const uint32_t e = e_[u];
                         row_of[e] = (uint16_t)i[u];
                         uint32_t pe = n;
                         if (ra[u] != 0) {
-                            const int p = ptx_elem_lookup(ix, ra[u]);
+                            const int p = p_[u];
                             if (p < 0) ptx_raise(H, i[u], 1, PTX_ERR_ELEM_NOT_FOUND); /* micromerge.ts:752 */
                             else pe = (uint32_t)p;
                         }
@@ -1543,7 +1726,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     }
                     if (j < d_fused) {
                         /* the element must exist when the delete is applied (micromerge.ts:752); deleting twice is fine (:693) */
-                        const int t = ptx_elem_lookup(ix, dra[u]);
+                        const int t = t_[u];
                         if (t < 0) ptx_raise(H, di[u], 1, PTX_ERR_ELEM_NOT_FOUND);
                         else ptx_atomic_or(&delbits[(uint32_t)t >> 5], 1u << ((uint32_t)t & 31u));
                         const uint32_t sl = j < n ? PTX_JX(j, n) : j; /* j <= n; slot n is P1's spare */
@@ -1567,6 +1750,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(12); /* end of P3a */
+        PTX_REMAT_AT(2, PTX_REMAT_P3());
         /* the deletes' application-order check, now that row_of is complete: target element and row left in ilist / klist by P3a */
         PTX_FORV(j0, d_fused, PTX_UV) {
             uint32_t t[PTX_UV], i[PTX_UV], rt[PTX_UV];
@@ -1590,7 +1774,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_FOR(jj, D - d_fused) {
                 const uint32_t j = d_fused + jj;
                 const uint32_t r = ptx_coherent_load32(&park[PTX_JX(j, D)]) & 0xFFFFu, i = r < N ? r : N - 1u;
-                const int t = ptx_elem_lookup(ix, ref_a[i]);
+                const int t = ptx_elem_lookup24(ix, ref_a[i]);
                 if (t < 0 || row_of[t] >= i) ptx_raise(H, i, 1, PTX_ERR_ELEM_NOT_FOUND);
                 else {
                     ptx_atomic_or(&delbits[(uint32_t)t >> 5], 1u << ((uint32_t)t & 31u));
@@ -1623,6 +1807,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_LEADER { H->cur_big = H->cur_med = 0; }
         PTX_BAIL_IF_ERROR();
         PTX_STAMP(3);
+        PTX_REMAT_AT(3, PTX_REMAT_P3());
         PTX_MARK_PQ(0u, mq) /* P5a's first park entries: on their way while the tree is ordered and ranked (LDS only) */
         /* P3c: the children of every parent in descending element index == descending opId (the skip loop of micromerge.ts:630-635), one PARENT per lane.
          * Pass 1, all parents: an only child (most elements are one) is placed at once, a parent with more goes to a list.  Pass 2, the listed parents: a
@@ -1727,12 +1912,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_SYNC_LDS();
         PTX_STAMP(4);
+        PTX_REMAT_AT(4, PTX_REMAT_P3());
         /* P3d: document order = pre-order of the tree.  Successor of an element x: its first child; a leaf's: `after(x)` = the next sibling, or — x being the
          * last child — after(parent).  after() of the last children is resolved by pointer jumping up the tree (a few rounds: the chains of last children are
          * short; the rounds stop when a pass finds nothing open); then the successor list of the n + 1 nodes (elements, HEAD = n; the terminal node n + 1)
          * is ranked by in-place pointer jumping over {next << 16 | elements in [node, next)} words. */
         const uint32_t term = n + 1u;
-        uint16_t* nx = seg; /* (seg is dead: srt holds the sorted buckets) */
         PTX_FORV(j0, n, PTX_UV) {
             uint32_t x[PTX_UV], sib[PTX_UV], p[PTX_UV], e[PTX_UV];
 #pragma unroll
@@ -1783,6 +1968,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             if (!open3[r % 3u]) break;
         }
         PTX_STAMP(14); /* after() stands; the successor list and its ranking follow */
+        PTX_REMAT_AT(5, PTX_REMAT_P3());
         PTX_FORV(x0, n + 1, PTX_UV) { /* the successor, in place: the first child where there is one */
             uint32_t s[PTX_UV], t[PTX_UV], f[PTX_UV];
 #pragma unroll
@@ -1799,12 +1985,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_SYNC_LDS();
         PTX_STAMP(16); /* the successor list stands */
+        PTX_REMAT_AT(6, PTX_REMAT_P3());
         /* List ranking, work-efficient (every pass touches a node once; Wyllie's doubling over all n nodes was measured: 4 x the instructions, no faster alone):
          * every S-th element, and HEAD, is a splitter.  A splitter walks to the next one, counts the elements it passes and leaves on each of them its own
          * index (in nx: only this walker ever reads nx[v], and it just did) and the count before it (in par, dead by now); the splitters are ranked by in-place
          * pointer jumping over {next splitter << 16 | elements of the segment}; one flat pass turns (splitter suffix, local count) into positions.
          * S: 8 while the splitters fit one pass of the workgroup (segments are geometric: mean S, the longest of them bounds the pass). */
-        uint32_t* R = RW; /* srt and cnt are dead */
         {
             uint32_t lgS = 3u;
             while ((n >> lgS) + 3u > PTX_NTHREADS && lgS < 15u) ++lgS;
@@ -1863,7 +2049,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PTX_SYNC_LDS();
     }
     PTX_STAMP(18); /* document positions stand; the mark list comes back from its park */
-    uint16_t* rnk = par;
+    PTX_REMAT_AT(7, PTX_REMAT());
     bp.off = mark_lds; /* release the tree scratch */
     PTX_STAMP(5);
 
@@ -1872,8 +2058,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_MARK_PQ(1u, mq)
     /* ---- P4: tombstones -> visible index ---- */
     const uint32_t nwv = nwe; /* bit positions 0..n by document position */
-    PtxBitWord* alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
-    uint32_t* brkbits = ptx_alloc<uint32_t>(bp, nwe + 1); /* visible positions where a comment interval starts/ends */
+    alive = ptx_alloc<PtxBitWord>(bp, nwv + 1);
+    brkbits = ptx_alloc<uint32_t>(bp, nwe + 1); /* visible positions where a comment interval starts/ends */
     PTX_BAIL_CAPACITY();
     PTX_FOR(w, nwv + 1) {
         PtxBitWord z;
@@ -1911,13 +2097,14 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     const uint32_t V = ptx_bitwords_prefix<kThreads>(alive, nwv + 1, &H->scan_tmp[18]);
     /* the visible interval [lo, hi) of every mark op (the few later uses of an op's row — the ops that still cover a visible character — read it from the
      * park).  Until the marks are looked at, the space of `hi` and of the comment ids holds the rows of the visible elements (vrow) if they fit */
-    uint16_t* mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
+    mrk_lo = ptx_alloc<uint16_t>(bp, K + 1);
     const uint32_t mrk_at = bp.off;
-    uint16_t* mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
-    uint16_t* cid = ptx_alloc<uint16_t>(bp, Kc + 1);    /* comment mark -> doc-local comment id */
+    mrk_hi = ptx_alloc<uint16_t>(bp, K + 1);
+    cid = ptx_alloc<uint16_t>(bp, Kc + 1);    /* comment mark -> doc-local comment id */
     PTX_BAIL_CAPACITY();
     const uint32_t mrk_bytes = bp.off - mrk_at; /* the two arrays stand back to back; nothing is stored in them before the marks are looked at */
     PTX_STAMP(6);
+    PTX_REMAT_AT(8, PTX_REMAT());
 
     /* ---- P5a: visible values out; every mark op -> visible interval [lo, hi) ---- */
     {
@@ -1934,14 +2121,14 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             PTX_FOR(q, V) {
                 const uint32_t row = vrow[q];
                 const uint32_t v = payload[row < N ? row : N - 1u];
-                A.out_values[base + q] = v;
+                out_values[q] = v;
                 ptx_digest_item(h1, h2, 1u, q, v, 0u);
             }
         } else { /* (a log with hardly any mark op and many visible characters: no room for the list) */
             for_live(sparse, [&](uint32_t e) {
                 const uint32_t row = row_of[e], q = ptx_bitrank(alive, rnk[e]);
                 const uint32_t v = payload[row < N ? row : N - 1u];
-                A.out_values[base + q] = v;
+                out_values[q] = v;
                 ptx_digest_item(h1, h2, 1u, q, v, 0u);
             });
         }
@@ -1958,6 +2145,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     }
 #undef PTX_LIVE_WORD
     PTX_STAMP(13); /* the values are out; the marks' intervals follow */
+    PTX_REMAT_AT(9, PTX_REMAT());
     {
     /* two register sets in turn (no copies from "next" to "current"): kq / i / ra ... hold the even steps' mark ops, the *_n set the odd ones' */
     auto mark_step = [&](const uint32_t (&kq)[PTX_UM], const uint32_t (&i)[PTX_UM], const uint64_t (&ra)[PTX_UM], const uint64_t (&rb)[PTX_UM], const uint32_t (&sa)[PTX_UM],
@@ -1966,31 +2154,28 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         for (int u = 0; u < (int)PTX_UM; ++u)
             if (kq[u] != 0xFFFFFFFFu) {
                 const uint32_t k = kq[u];
-                uint32_t lo = 0, hi = 0;
-                /* start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is
-                   not in the list when the op is applied means the op never starts */
-                int js = -1;
-                if (sa[u] == PTX_SIDE_BEFORE || sa[u] == PTX_SIDE_AFTER) {
-                    js = ptx_elem_lookup(ix, ra[u]);
-                    if (js >= 0 && row_of[js] >= i[u]) js = -1;
-                }
-                if (js >= 0) {
-                    const uint32_t slot_a = 2u * rnk[js] + (sa[u] == PTX_SIDE_AFTER ? 1u : 0u);
-                    uint32_t slot_b = 0xFFFFFFFFu; /* never reached: runs to the end of the text */
-                    if (sb[u] == PTX_SIDE_BEFORE || sb[u] == PTX_SIDE_AFTER) {
-                        int je = ptx_elem_lookup(ix, rb[u]);
-                        if (je >= 0 && row_of[je] >= i[u]) je = -1;
-                        if (je >= 0) slot_b = 2u * rnk[je] + (sb[u] == PTX_SIDE_AFTER ? 1u : 0u);
-                    }
-                    /* same slot: the start test fires first and the end is never seen */
-                    if (slot_b == slot_a) slot_b = 0xFFFFFFFFu;
-                    if (slot_b > slot_a) {
-                        const uint32_t lo_rank = (slot_a + 1u) >> 1;
-                        const uint32_t hi_rank = slot_b == 0xFFFFFFFFu ? n : (slot_b + 1u) >> 1;
-                        lo = ptx_bitrank(alive, lo_rank);
-                        hi = ptx_bitrank(alive, hi_rank);
-                    }
-                }
+                /* Both boundaries side by side, no branch: the two chains id -> element -> (row, position) -> visible rank are three dependent LDS round trips
+                 * together (written as nested ifs they were eight, one after the other: round 6 found the kernel bound by its chain of fixed latencies, not by
+                 * instruction issue).  start: only before/after(elem) can ever match a slot (peritext.ts:236); an element that is not in the list when the op
+                 * is applied means the op never starts; an end that is not found is never reached: the mark runs to the end of the text. */
+                const int js0 = ptx_elem_lookup24(ix, ra[u]), je0 = ptx_elem_lookup24(ix, rb[u]);
+                const uint32_t ea = js0 < 0 ? 0u : (uint32_t)js0, eb = je0 < 0 ? 0u : (uint32_t)je0;
+                const uint32_t row_a = row_of[ea], row_b = row_of[eb], rk_a = rnk[ea];
+                uint32_t rk_b = rnk[eb];
+                PTX_KEEP_VGPR(rk_b); /* (read now, with the other three: left alone the compiler sinks this read behind the test of the end's row) */
+                const bool has_a = (sa[u] <= PTX_SIDE_AFTER) & (js0 >= 0) & (row_a < i[u]); /* (& not &&: a short-circuit puts the LDS reads back into branches) */
+                const bool has_b = (sb[u] <= PTX_SIDE_AFTER) & (je0 >= 0) & (row_b < i[u]);
+                const uint32_t slot_a = 2u * rk_a + (sa[u] == PTX_SIDE_AFTER ? 1u : 0u);
+                uint32_t slot_b = has_b ? 2u * rk_b + (sb[u] == PTX_SIDE_AFTER ? 1u : 0u) : 0xFFFFFFFFu;
+                /* same slot: the start test fires first and the end is never seen */
+                if (slot_b == slot_a) slot_b = 0xFFFFFFFFu;
+                const bool covers = has_a & (slot_b > slot_a);
+                const uint32_t lo_rank = (slot_a + 1u) >> 1;
+                const uint32_t hi_rank = slot_b == 0xFFFFFFFFu ? n : (slot_b + 1u) >> 1;
+                const uint32_t lo_v = ptx_bitrank(alive, lo_rank), hi_v = ptx_bitrank(alive, hi_rank); /* (both ranks <= n whatever the lanes without a start hold) */
+                const uint32_t lo = covers ? lo_v : 0u, hi = covers ? hi_v : 0u;
+                const int js = has_a ? js0 : -1;
+                (void)js;
                 mrk_lo[k] = (uint16_t)lo;
                 mrk_hi[k] = (uint16_t)hi;
                 if (out_refs) {
@@ -1998,7 +2183,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     uint32_t va = 0xFFFFu, vb = 0xFFFFu;
                     if (js >= 0) va = 2u * rnk[js] + (sa[u] == PTX_SIDE_AFTER ? 1u : 0u);
                     if (sb[u] == PTX_SIDE_BEFORE || sb[u] == PTX_SIDE_AFTER) {
-                        const int je = ptx_elem_lookup(ix, rb[u]);
+                        const int je = ptx_elem_lookup24(ix, rb[u]);
                         if (je >= 0 && row_of[je] < i[u]) vb = 2u * rnk[je] + (sb[u] == PTX_SIDE_AFTER ? 1u : 0u);
                     }
                     out_refs[base + i[u]] = va | (vb << 16);
@@ -2029,13 +2214,14 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         lds_high = bp.high;
         return H->adm & 15u;
     }
+    PTX_REMAT_AT(10, PTX_REMAT());
     const uint32_t mark2_lds = bp.off;
     /* the element-side arrays (id bitmap, row_of, positions, tombstones) are dead now: their storage is the first
      * choice for the scratch of the tail phases */
     PtxBump bd;
     bd.base = lds;
     bd.off = elem_lds;
-    bd.cap = mark_lds;
+    bd.cap = elem_end; /* (the add / remove bitmap of the mark ops stands between the element arrays and the phase scratch: it lives to the end) */
     bd.high = 0;
     bd.overflow = false;
     PTX_STAMP(7);
@@ -2051,7 +2237,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         const uint32_t need_1 = n > PTX_TILE_4 ? (uint32_t)(ptx_a16(K ? 4u * 2u * PTX_TILE_1 : 0u) + ptx_a16(4u * (PTX_TILE_1 + 1u)) + ptx_a16(8u * (PTX_TILE_1 / 32u + 2u))) : 0u;
         uint32_t reserve = need_c > need_4 ? need_c : need_4;
         if (need_1 > reserve) reserve = need_1;
-        const uint32_t room = mark_lds - elem_lds;
+        const uint32_t room = elem_end - elem_lds;
         live_cap = room > reserve + 32u ? (room - reserve - 32u) / 2u : 0u;
         if (live_cap > K) live_cap = K;
     }
@@ -2081,6 +2267,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
     }
     PTX_SYNC_LDS();
+    PTX_REMAT_AT(11, PTX_REMAT());
     const bool use_live = H->cur_med <= live_cap; /* else: the list is incomplete, every mark op is looked at */
     const uint32_t nlive = use_live ? H->cur_med : 0u;
     const uint32_t live_lds = bd.off, live_top = bp.off; /* (the list stays until the end: the scratch of the tail phases is released down to here) */
@@ -2139,7 +2326,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     ci.id = c;
                     ci.start = s;
                     ci.end = e;
-                    A.out_cints[base + row] = ci;
+                    out_cints[row] = ci;
                     ptx_atomic_or(&brkbits[s >> 5], 1u << (s & 31));
                     ptx_atomic_or(&brkbits[e >> 5], 1u << (e & 31));
                     ptx_digest_item(h1, h2, 3u, c, s, e);
@@ -2154,7 +2341,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 ci.id = crow[2u * r];
                 ci.start = crow[2u * r + 1u] & 0xFFFFu;
                 ci.end = crow[2u * r + 1u] >> 16;
-                A.out_cints[base + r] = ci;
+                out_cints[r] = ci;
                 ptx_atomic_or(&brkbits[ci.start >> 5], 1u << (ci.start & 31));
                 ptx_atomic_or(&brkbits[ci.end >> 5], 1u << (ci.end & 31)); /* end <= V: bit V is never read */
                 ptx_digest_item(h1, h2, 3u, ci.id, ci.start, ci.end);
@@ -2166,6 +2353,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     bp.off = live_top; /* release the comment scratch */
     bd.off = live_lds;
     PTX_STAMP(8);
+    PTX_REMAT_AT(12, PTX_REMAT());
 
     /* ---- P5b + P6: LWW winners per visible char, spans, digest — in tiles of the visible axis ----
      * Short documents: one tile, four trees (one per mark type) updated and queried in one pass.
@@ -2299,7 +2487,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     ptx_span sp;
                     sp.start = t0 + q;
                     sp.attr = attr[q + 1];
-                    A.out_spans[base + s] = sp;
+                    out_spans[s] = sp;
                     ptx_digest_item(h1, h2, 2u, s, sp.start, sp.attr);
                 }
             }

@@ -279,6 +279,20 @@ PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint3
 #define PTX_JB_BLOCK(st, u, U) (((st) * (U) + (uint32_t)(u)) * PTX_NWAVES + (threadIdx.x >> 6))
 #define PTX_JB_LANE(st, u, U) (threadIdx.x & 63u)
 #define PTX_JB_LANE_IS_FIXED 1 /* a thread's lane of a block is the same in every step: its share of the runs is worked out once per log */
+/* the kernel arguments read AGAIN from the kernarg segment (scalar loads): what a phase derives from them is a new value to the compiler, so the
+ * values an earlier phase derived need not stay in scalar registers (or in the VGPR lanes they are spilled to) across the phases in between */
+template <class ArgsT>
+PTX_DEV const ArgsT& ptx_fresh_args(const ArgsT&) {
+    const __attribute__((address_space(4))) ArgsT* p = (const __attribute__((address_space(4))) ArgsT*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const ArgsT*)p;
+}
+#define PTX_FRESH_ARGS(A) ptx_fresh_args(A)
+/* a word of the batch that no kernel of the call writes (offsets, headers), at an address that is the same in every lane: read through the constant address space,
+ * i.e. by the scalar unit (left to itself the compiler only does so where it can prove that no store of the kernel so far may alias the word) */
+template <class T>
+PTX_DEV T ptx_const_load(const T* p) { return *(const __attribute__((address_space(4))) T*)p; }
+#define PTX_CONST_LOAD(p) ptx_const_load(p)
 #define PTX_KEEP_VGPR(x) asm volatile("" : "+v"(x)) /* the value stays in its register: the compiler neither works it out again at each use nor treats it as a constant */
 
 /* wave-explicit loops: every wave runs the body once with its wave index `w` and lane index `lane`; the

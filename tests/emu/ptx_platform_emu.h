@@ -141,6 +141,8 @@ PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint3
 /* loops over BLOCKS of items: the emulation plays blocks of 8 lanes, one lane per step, in the selected order */
 #define PTX_JB_CAP 8u
 #define PTX_KEEP_VGPR(x) ((void)(x))
+#define PTX_CONST_LOAD(p) (*(p))
+#define PTX_FRESH_ARGS(A) (A) /* (the GPU reads its kernel arguments again, scalar loads; here they are where they were) */
 #define PTX_JB_STEPS(B, U) (((B) * PTX_JB_CAP + (U)-1u) / (U))
 #define PTX_JB_BLOCK(st, u, U) (((st) * (U) + (uint32_t)(u)) / PTX_JB_CAP)
 #define PTX_JB_LANE(st, u, U) (ptx_emu_ix(((st) * (U) + (uint32_t)(u)) % PTX_JB_CAP, PTX_JB_CAP))
