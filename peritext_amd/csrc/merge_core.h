@@ -57,7 +57,7 @@
 #define PTX_JSTEPS(n) PTX_JSTEPS_U(n, PTX_U)
 #define PTX_J_OF(st, u) PTX_J_OF_U(st, u, PTX_U)
 #ifndef PTX_U1
-#define PTX_U1 3 /* consecutive rows per thread and step in the row pass P1 (measured: 2 -> 14.6, 3 -> 14.2, 4 -> 17 us per 4K-op log) */
+#define PTX_U1 4 /* consecutive rows per thread and step in the row pass P1: 3 or 4.  Round 6: four (the ids as two 16-byte loads, the class bytes of the four rows one dword each) is six steps instead of eight for a 4 097-row log of three waves — a step of this pass is a trip to HBM however many rows it carries: -1 % on BASELINE config #4, -1.5 % on #3, same box (rounds 1-2 measured 4 slower: the scalar registers it spilled then are gone) */
 #endif
 #define PTX_MAX_THREADS 1024u
 #define PTX_BYTE_PAD 4u /* bytes the library allocates past the end of the action / mark_type columns (the row pass reads them a dword at a time) */
@@ -928,7 +928,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
      *      are in flight during the validation of the walk and the clearing of the bitmaps: most of one trip to HBM, of the handful a 256-op log is) ---- */
     bool p1_loaded = false;
     const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_full = N / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
-    static_assert(PTX_U1 == 3, "three class bytes per dword; the fourth byte read belongs to the next thread's first row");
+    static_assert(PTX_U1 == 3 || PTX_U1 == 4, "the class bytes of a thread's rows come from ONE dword (with three rows its fourth byte belongs to the next thread's first row)");
     uint64_t id[PTX_U1], id_n[PTX_U1];
     uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
     /* this thread's PTX_U1 consecutive rows of a step.  A wave whose rows all exist reads them from one address; the wave that
@@ -1497,12 +1497,14 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         auto p1_rows = [&](auto masked, uint32_t g, uint32_t nv, const uint64_t (&id)[PTX_U1], uint32_t a4, uint32_t mt4) {
             constexpr bool kMasked = decltype(masked)::value;
             const uint32_t r0 = g * PTX_U1;
-            const uint32_t live = kMasked ? (1u << (8u * nv)) - 1u : 0x00FFFFFFu; /* bytes of a4 / mt4 that are rows of this thread */
+            constexpr uint32_t kAllRows = PTX_U1 == 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;
+            const uint32_t live = kMasked ? (nv >= 4u ? 0xFFFFFFFFu : (1u << (8u * nv)) - 1u) : kAllRows; /* bytes of a4 / mt4 that are rows of this thread */
             /* class of the rows, four bytes at a time (byte permutes as table look-ups):
              * action 0 makeList -> 6, 1 insert -> 0, 2 delete -> 1, 3 / 4 add / removeMark -> 2 + mark type, 5 nop / 6, 7 map ops -> 6 */
             const uint32_t k4 = ptx_perm(0x06060680u, 0x80010006u, a4 & 0x07070707u); /* 0x80: a mark op; 6: listed nowhere (makeList, NOP, map ops) */
             const uint32_t mk = (k4 >> 7) & 0x01010101u;     /* 1 in the bytes of the mark ops */
-            const uint32_t mmask = ptx_mul24(mk, 255u);        /* 0xFF there (the three bytes that are this thread's rows) */
+            /* 0xFF there: three rows' bytes fit the 24-bit multiply; with four, byte by byte (0x80 - 0x01 = 0x7F, or-ed with the 0x80: no borrow crosses a byte) */
+            const uint32_t mmask = PTX_U1 == 3 ? ptx_mul24(mk, 255u) : ((k4 & 0x80808080u) | ((k4 & 0x80808080u) - mk));
             uint32_t c4 = ((k4 & ~mmask) | (((mt4 & 0x03030303u) + 0x02020202u) & mmask)) & 0x07070707u;
             /* unknown action (beyond the table), mark type beyond 3: flagged; the row runs on under some class */
             err4 |= ((a4 & 0xF8F8F8F8u) | (mt4 & 0xFCFCFCFCu & mmask)) & live;

@@ -513,12 +513,18 @@ typedef uint32_t ptx_u32_a1 __attribute__((aligned(1)));
 /* the ids of a thread's PTX_U1 consecutive rows, all of which exist: one address, loads of 16 + 8 bytes */
 #define PTX_P1_IDS(dst_, ptr_)                                                         \
     {                                                                                  \
-        static_assert(PTX_U1 == 3, "16 + 8 bytes");                                    \
+        static_assert(PTX_U1 == 3 || PTX_U1 == 4, "16 + 8 or 16 + 16 bytes");          \
         const uint64_t* p_ = (ptr_);                                                   \
         const ptx_u64x2 q_ = PTX_STREAM_LOAD((const ptx_u64x2_a8*)p_);                 \
         dst_[0] = q_.x;                                                                \
         dst_[1] = q_.y;                                                                \
-        dst_[2] = PTX_STREAM_LOAD(p_ + 2);                                             \
+        if (PTX_U1 == 4) {                                                             \
+            const ptx_u64x2 r_ = PTX_STREAM_LOAD((const ptx_u64x2_a8*)(p_ + 2));       \
+            dst_[2] = r_.x;                                                            \
+            dst_[PTX_U1 - 1] = r_.y;                                                   \
+        } else {                                                                       \
+            dst_[2] = PTX_STREAM_LOAD(p_ + 2);                                         \
+        }                                                                              \
     }
 #define PTX_P1_BYTES(col_, r0_, dst_) dst_ = PTX_STREAM_LOAD((const ptx_u32_a1*)(col_ + ((r0_) < N ? (r0_) : N - 1u)));
 
