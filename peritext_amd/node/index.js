@@ -208,7 +208,10 @@ function encodeDocs(docs, opts) {
             const t0 = Array.isArray(textObjs[d]) ? textObjs[d][r] : textObjs[d]
             let textObj = t0 === undefined ? null : t0
             const firstRow = nRow
-            const otherLists = new Set() /* the replica's list objects that are not this device log's: their ops are rows without effect here */
+            /* the replica's list objects that are not this device log's: their ops are rows without effect here.  opts.otherLists[d][r]: the ones an EARLIER part of the
+             * log created (a resident session encodes only the Changes that arrived since: ADVICE r5) */
+            const seedLists = opts && opts.otherLists && opts.otherLists[d] && opts.otherLists[d][r]
+            const otherLists = new Set(seedLists || [])
             const wantPath = String(lkey).split(".") /* "meta.notes": a list nested in map objects, by its path (micromerge.ts:178-196); one key: a list of the root map */
             const pathOf = new Map() /* map / list object -> the keys that lead to it from the root map, as the ops of this log made them */
             for (const ch of log) {
@@ -288,7 +291,7 @@ function encodeDocs(docs, opts) {
                         /* an op on ANOTHER list object of this replica (merged by its own device log when its key is in listKeys): PTX_ACT_NOP here */
                     } else if (act === "addMark" || act === "removeMark" || op.elemId !== undefined || op.insert) {
                         /* a list op whose object no earlier makeList of this log created: the reference throws RangeError("Object does not exist")
-                         * (micromerge.ts:538): rejected here, never a silent no-op */
+                         * (micromerge.ts:538): rejected here.  (Ops on a list the log created under a key outside listKeys are rows without effect: that list's own checks, micromerge.ts:752, run only when the caller names its key) */
                         throw new RangeError("list op " + String(op.opId) + " on an object that no earlier makeList of this log created")
                     }
                 }
@@ -1036,10 +1039,18 @@ class MergeEngine {
         let ok = !!st && st.reps.length === group.length && group.every((r, i) => r === st.reps[i] && r.changes.length >= st.seen[i].length && st.seen[i].every((c, k) => c === r.changes[k]))
         let delta = null
         if (ok) {
-            delta = encodeDocs([group.map((r, i) => r.changes.slice(st.seen[i].length))], { extraActors: [st.actorList], commentOrder: [st.commentList], textObjs: [st.textObjs], seed: st.tables })
+            /* (the handles' admission remembers the list objects of the Changes already uploaded — rep.otherLists —: the delta's ops on them are rows without effect,
+             * not "a list no makeList of this log created"; whatever else the delta cannot be encoded for on its own sends the document through the full path) */
+            try {
+                delta = encodeDocs([group.map((r, i) => r.changes.slice(st.seen[i].length))],
+                                   { extraActors: [st.actorList], commentOrder: [st.commentList], textObjs: [st.textObjs], seed: st.tables, otherLists: [group.map(r => Array.from(r.otherLists || []))] })
+            } catch (e) {
+                if (!(e instanceof RangeError)) throw e
+                delta = null
+            }
             /* a new actor re-ranks the ids of the old rows (actor ranks follow the string order, compareOpIds): then everything is encoded again.  New comment
              * ids just take the next ranks. */
-            ok = delta.docActors[0].length === st.actorList.length
+            ok = delta !== null && delta.docActors[0].length === st.actorList.length
             if (ok) st.commentList = delta.docComments[0]
         }
         if (!ok) {

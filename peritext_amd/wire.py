@@ -340,9 +340,10 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None, li
                     elif obj in other_lists and (act in ("addMark", "removeMark") or "elemId" in op or op.get("insert")):
                         pass  # an op on ANOTHER list object of this replica (merged by its own device log when its key is in list_keys): PTX_ACT_NOP here
                     elif act in ("addMark", "removeMark") or "elemId" in op or op.get("insert"):
-                        # A list op whose object is not the document's text list: the reference throws RangeError("Object does not exist")
-                        # (micromerge.ts:538) when no such object exists yet, or edits a second list object.  This engine holds ONE text
-                        # list per document (the first root makeList of key "text"): rejected here, never a silent no-op.
+                        # A list op on an object that NO makeList of this log created: the reference throws RangeError("Object does not exist")
+                        # (micromerge.ts:538) — rejected here.  (An op on a list object the log did create under a key that is not in list_keys is a row
+                        # without effect, the branch above: the reference's checks on THAT list — an unknown element, micromerge.ts:752 — are made only
+                        # when the caller names the key in list_keys and so has the list merged; INTEGRATION.md "Several list objects per document".)
                         raise ValueError("list op %s on object %r, which no earlier makeList of this log created" % (op.get("opId"), obj))
                     for k, v in row.items():
                         cols[k].append(v)

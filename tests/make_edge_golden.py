@@ -22,6 +22,7 @@ def main():
         "impl": "ref",
         "edge": H.oracle_apply(H.edge_case_docs(), impl="ref"),
         "huge_bucket": H.oracle_apply([[H.huge_bucket_log()]], impl="ref"),
+        "boundary": H.oracle_apply(H.boundary_docs(), impl="ref", patches=True),
         "unsynced": H.oracle_apply(H.unsynced_docs(), impl="ref", patches=True),
         "cursors": [[{"text": e["text"], "cursorAt": e["cursorAt"], "cursorResolve": e["cursorResolve"]} for e in d]
                     for d in H.oracle_apply(cursor_docs, impl="ref", cursors=True)],

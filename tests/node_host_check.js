@@ -454,7 +454,36 @@ if (cmd === "encode") {
         assert.ok(calls.uploads - before.uploads <= 1 + reencodes, "a document is encoded again only when its actor / comment tables grow")
         engine.close()
     })
-    console.log(JSON.stringify({ ok: true, docs: gen.docs.length, flushes, uploads: calls.uploads, appends: calls.appends, rowsUploaded: calls.rows, rows: totalRows }))
+    /* ADVICE r5: a handle edits a SECOND list object whose makeList sits in a Change that is already resident — the delta encode must know the list (rows
+     * without effect on ["text"]), not throw "a list no makeList of this log created" for good */
+    let otherListAppends = 0
+    {
+        const engine = new host.MergeEngine({ addon: mock })
+        const rep = engine.replica("two-lists")
+        const c1 = { actor: "a", seq: 1, deps: {}, startOp: 1, ops: [
+            { opId: "1@a", action: "makeList", obj: "_root", key: "text" }, { opId: "2@a", action: "makeList", obj: "_root", key: "notes" },
+            { opId: "3@a", action: "set", obj: "1@a", elemId: "_head", insert: true, value: "A" }, { opId: "4@a", action: "set", obj: "2@a", elemId: "_head", insert: true, value: "n" }] }
+        const c2 = { actor: "a", seq: 2, deps: { a: 1 }, startOp: 5, ops: [
+            { opId: "5@a", action: "set", obj: "2@a", elemId: "4@a", insert: true, value: "o" }, { opId: "6@a", action: "del", obj: "2@a", elemId: "4@a" },
+            { opId: "7@a", action: "set", obj: "1@a", elemId: "3@a", insert: true, value: "B" }] }
+        const c3 = { actor: "a", seq: 3, deps: { a: 2 }, startOp: 8, ops: [{ opId: "8@a", action: "addMark", obj: "2@a", markType: "strong", start: { type: "before", elemId: "5@a" }, end: { type: "endOfText" } }] }
+        const u0 = calls.uploads, a0 = calls.appends
+        rep.applyChange(c1)
+        rep.getTextWithFormatting(["text"])
+        rep.applyChange(c2)
+        rep.getTextWithFormatting(["text"]) /* (threw RangeError before the fix — and every read after it) */
+        rep.applyChange(c3)
+        rep.getPatches()
+        assert.strictEqual(calls.uploads - u0, 1, "the document is uploaded once")
+        otherListAppends = calls.appends - a0
+        assert.strictEqual(otherListAppends, 2, "the two later Changes are appended to the resident log")
+        const st = engine.sessions.get("two-lists")
+        const last = calls.applies[calls.applies.length - 1]
+        const b = Object.assign({}, last.handle.batch, { logDoc: [0], docActors: [st.actorList], docComments: [st.commentList], values: st.tables.values, urls: st.tables.urls, keys: st.tables.keys, mapValues: st.tables.mapValues })
+        assert.strictEqual(Number(b.logOff[1]), 8, "all eight ops are rows of the resident log")
+        engine.close()
+    }
+    console.log(JSON.stringify({ ok: true, docs: gen.docs.length, flushes, uploads: calls.uploads - 1, appends: calls.appends - otherListAppends, rowsUploaded: calls.rows - 8, rows: totalRows, otherListAppends }))
 } else if (cmd === "dts") {
     /* no tsc in the image: index.d.ts is hand-written.  Every function / class method / const it exports must exist in index.js, and a declared
      * signature must fit the implementation's arity (required parameters <= Function.length <= all parameters), every ReplicaHandle member must be

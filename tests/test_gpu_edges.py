@@ -63,6 +63,27 @@ def test_edge_cases(eng, golden):
     assert golden["edge"][0][0]["spans"][1]["marks"] == {"comment": []}
 
 
+def test_boundaries_changemark_never_generates(eng, golden):
+    """helpers.boundary_docs on the device: startOfText as a start and as an end, endOfText as a start, `after` start on an inclusive mark, `before` end on a
+    link — spans and the patch streams of ptx_replay_patches against what the type-erased reference gave (edge_cases_ref.json)."""
+    docs = H.boundary_docs()
+    batch = wire.encode_docs(docs)
+    assert int((batch.side_a == 2).sum()) >= 3 and int((batch.side_b == 2).sum()) >= 2
+    db = eng.upload(batch)
+    dr = eng.alloc_result(db)
+    try:
+        eng.merge(db, dr)
+        eng.sync()
+        res = eng.download(db, dr)
+        pat = eng.replay_patches(db, dr)
+    finally:
+        eng.free_result(dr)
+        eng.free_batch(db)
+    for log, exp in enumerate(golden["boundary"]):
+        H.check_log(batch, res, log, exp[0])
+    assert H.check_patch_streams(batch, pat, golden["boundary"]) == len(docs)
+
+
 def test_huge_sibling_bucket(eng, golden):
     log = H.huge_bucket_log()
     batch = wire.encode_docs([[log]])
