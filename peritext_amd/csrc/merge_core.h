@@ -56,8 +56,11 @@
 #define PTX_IN(i0, u) ((i0) + (uint32_t)(u) * _T < _n)
 #define PTX_JSTEPS(n) PTX_JSTEPS_U(n, PTX_U)
 #define PTX_J_OF(st, u) PTX_J_OF_U(st, u, PTX_U)
+#ifndef PTX_U1_128
+#define PTX_U1_128 4
+#endif
 #ifndef PTX_U1
-#define PTX_U1 4 /* consecutive rows per thread and step in the row pass P1: 3 or 4.  Round 6: four (the ids as two 16-byte loads, the class bytes of the four rows one dword each) is six steps instead of eight for a 4 097-row log of three waves — a step of this pass is a trip to HBM however many rows it carries: -1 % on BASELINE config #4, -1.5 % on #3, same box (rounds 1-2 measured 4 slower: the scalar registers it spilled then are gone) */
+#define PTX_U1 (kThreads == 128u ? PTX_U1_128 : 4) /* consecutive rows per thread and step in the row pass P1: 3 or 4.  Round 6: four (the ids as two 16-byte loads, the class bytes of the four rows one dword each) is six steps instead of eight for a 4 097-row log of three waves — a step of this pass is a trip to HBM however many rows it carries: -1 % on BASELINE config #4, -1.5 % on #3, same box (rounds 1-2 measured 4 slower: the scalar registers it spilled then are gone) */
 #endif
 #define PTX_MAX_THREADS 1024u
 #define PTX_BYTE_PAD 4u /* bytes the library allocates past the end of the action / mark_type columns (the row pass reads them a dword at a time) */
@@ -1376,9 +1379,15 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 #ifndef PTX_REMAT_MASK
 #define PTX_REMAT_MASK 0x82u /* which of the numbered call sites below derive the scalars again (bit k: site k).  Two are enough for a build without a single spilled scalar register — the head of P3 and its end —; all thirteen cost +1 % (their scalar loads and arithmetic), round 6 */
 #endif
-#define PTX_REMAT_AT(k_, call_)                         \
-    do {                                                \
-        if ((PTX_REMAT_MASK >> (k_)) & 1u) { call_; }   \
+#ifndef PTX_REMAT_MASK64
+#define PTX_REMAT_MASK64 PTX_REMAT_MASK /* the one-wave build's own choice (it is held to 80 scalar registers: eight waves per SIMD) */
+#endif
+#ifndef PTX_REMAT_MASK128
+#define PTX_REMAT_MASK128 PTX_REMAT_MASK
+#endif
+#define PTX_REMAT_AT(k_, call_)                                                             \
+    do {                                                                                    \
+        if (((kThreads == 64u ? PTX_REMAT_MASK64 : kThreads == 128u ? PTX_REMAT_MASK128 : PTX_REMAT_MASK) >> (k_)) & 1u) { call_; } \
     } while (0)
 #define PTX_LDS_AT(T_, off_) ((T_*)(lds + (off_)))
 #define PTX_REMAT()                                                                          \
@@ -1628,10 +1637,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
      * P4 — 5 k cycles of LDS work — used to stand waiting for them), its gathers ahead of P4; in the loop
      * the park entries run two steps ahead of the step in work, the gathers one.  (Round 4: copying the list back into LDS first was ONE exposed trip to HBM per
      * log — 2 k cycles with a CU to itself, 28 k under load.) */
-    const PtxMarkBlocks MB = ptx_mark_blocks(moff1, moff2, moff3, K, PTX_JB_CAP);
-    const uint32_t m_steps = PTX_JB_STEPS(MB.B, PTX_UM);
+    PtxMarkBlocks MB = ptx_mark_blocks(moff1, moff2, moff3, K, PTX_JB_CAP);
+    uint32_t m_steps = PTX_JB_STEPS(MB.B, PTX_UM);
 #ifdef PTX_JB_LANE_IS_FIXED
-    const PtxMarkLaneKept MLK = ptx_mark_lane_kept(MB, PTX_JB_LANE(0u, 0, PTX_UM));
+    PtxMarkLaneKept MLK = ptx_mark_lane_kept(MB, PTX_JB_LANE(0u, 0, PTX_UM));
 #define PTX_MARK_OF(st_, u_, k_) ptx_mark_of_kept(MLK, PTX_JB_BLOCK(st_, u_, PTX_UM), k_)
 #else
 #define PTX_MARK_OF(st_, u_, k_) ptx_mark_of(MB, PTX_JB_BLOCK(st_, u_, PTX_UM), PTX_JB_LANE(st_, u_, PTX_UM), k_)
@@ -2054,6 +2063,13 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_REMAT_AT(7, PTX_REMAT());
     bp.off = mark_lds; /* release the tree scratch */
     PTX_STAMP(5);
+    /* the lane's share of the mark runs, worked out again from the header as it has just been read again: two vector registers that need not be kept — in a build of
+     * 64 of them, spilled to scratch memory — through the tree phases for the sake of the one early load above (round 6) */
+    MB = ptx_mark_blocks(moff1, moff2, moff3, K, PTX_JB_CAP);
+    m_steps = PTX_JB_STEPS(MB.B, PTX_UM);
+#ifdef PTX_JB_LANE_IS_FIXED
+    MLK = ptx_mark_lane_kept(MB, PTX_JB_LANE(0u, 0, PTX_UM));
+#endif
 
     /* (P5a's loads: the park entries of its first step went out at the start of P3c) their gathers go out here, ahead of P4, and the second step's park entries */
     PTX_MARK_LOAD(0u, kq, i, ra, rb, sa, sb, pl, mq)

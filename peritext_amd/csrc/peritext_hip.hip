@@ -65,8 +65,26 @@ PTX_MERGE_KERNEL_A(ptx_merge_kernel_rest_w7, 1024, 1, 0, 0, false, PTX_SGPRS_W7)
  * For batches whose every log has 16-bit id keys (census) merged without elem_rank / resolved references (PTX_FLAG_NO_ELEM_RANK): neither the wide-key paths nor
  * the two optional outputs are in the code — 84 instead of 113 scalar registers spilled at the 96 that 7 waves per SIMD allow.  Measured same box against the
  * general build (profiles/r05_b_*): config #4 -1.2 %, #3 (two waves per log) -4.2 %, #2 (one wave) -4.9 %. */
-PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean64, 64, PTX_W, 0, 64, false, true, PTX_SGPRS_W7)
-PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean128, 128, PTX_W, 0, 128, false, true, PTX_SGPRS_W7)
+/* Round 6: the one-wave build at EIGHT waves per SIMD (64 VGPRs, 80 SGPRs: 78 granted).  A one-wave log is a chain of fixed latencies on a SIMD it
+ * shares with the other resident logs, and its LDS window (4 KB for a 256-op log, 10 KB for a 1K-op one) allows 32 waves per CU: 32 instead of 28 one-wave logs,
+ * 16 instead of 14 two-wave ones.  Same box: config #2 -4.9 % (the ~70 scalar registers it spills cost less than the four more logs bring; the
+ * three-wave build stays at seven: nine logs per CU are 27 waves). */
+#ifndef PTX_LEAN64_W
+#define PTX_LEAN64_W 8
+#endif
+#ifndef PTX_LEAN64_SGPRS
+#define PTX_LEAN64_SGPRS 80
+#endif
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean64, 64, PTX_LEAN64_W, 0, 64, false, true, __attribute__((amdgpu_num_sgpr(PTX_LEAN64_SGPRS))))
+/* (the two-wave build at eight waves per SIMD measured -3.9 % on config #3 — 16 instead of 14 logs per CU — but at 64 VGPRs it spills two of them to scratch
+ * memory, which this repo's build guard refuses for every launched merge kernel: it stays at seven until its admission walk fits) */
+#ifndef PTX_LEAN128_W
+#define PTX_LEAN128_W PTX_W
+#endif
+#ifndef PTX_LEAN128_SGPRS
+#define PTX_LEAN128_SGPRS PTX_W7_SGPRS
+#endif
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean128, 128, PTX_LEAN128_W, 0, 128, false, true, __attribute__((amdgpu_num_sgpr(PTX_LEAN128_SGPRS))))
 PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean192, 192, PTX_W, 0, 192, false, true, PTX_SGPRS_W7)
 PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, 1, 0, false) /* + causal admission for documents with more than three actors: a one-pass walk up to seven, the (actor, seq) table beyond fifteen */
 PTX_MERGE_KERNEL(ptx_merge_kernel_many_wide, 1024, 1, 2, 0, false) /* the same for documents of eight to fifteen actors (walks over 24- and 32-byte envelope rows) */

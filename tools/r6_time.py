@@ -30,7 +30,7 @@ def main():
     g = workloads.gen_config(args.config)
     with Engine(0, flags=args.flags, lib_path=lib) as e:
       for _regen in range(args.regen):
-        db, _ = e.generate(g["replicas"], g["ops_per_log"], g["mix"], g["mark_types"], args.docs, 2024, list_cap=args.list_cap)
+        db, ginfo = e.generate(g["replicas"], g["ops_per_log"], g["mix"], g["mark_types"], args.docs, 2024, list_cap=args.list_cap)
         dr = e.alloc_result(db)
         e.merge(db, dr)
         e.sync()
@@ -40,7 +40,7 @@ def main():
         for k in ("status", "digest", "n_spans", "n_visible"):
             h.update(logs[k].tobytes())
         ms = [e.merge_timed(db, dr, args.iters) / args.iters for _ in range(args.rounds)]
-        print(json.dumps({"build": os.path.basename(lib or "libperitext_hip.so"), "config": args.config, "docs": args.docs, "kernel_ms": [round(x, 4) for x in ms], "min_ms": round(min(ms), 4),
+        print(json.dumps({"build": os.path.basename(lib or "libperitext_hip.so"), "config": args.config, "docs": args.docs, "kernel_ms": [round(x, 4) for x in ms], "gen_ms": round(ginfo["kernel_ms"], 3), "min_ms": round(min(ms), 4),
                           "kernel": e.batch_kernel_name(db), "launch": e.launch_shape(db), "max_status": int(logs["status"].max()), "results_sha1": h.hexdigest()[:16]}))
 
 
