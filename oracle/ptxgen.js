@@ -48,6 +48,8 @@ const CONFIGS = {
     /* insert-heavy, all mark types: documents GROW (hundreds of visible chars, many overlapping marks
        and comments) — stresses the mark sweep, which the tombstone-heavy BASELINE mixes barely touch */
     rich: { replicas: 3, opsPerLog: 1024, mix: [55, 10, 20, 15], markTypes: ["strong", "em", "link", "comment"] },
+    /* the same at the headline's log length (bench.py extras: a batch-scale leg on documents that hold text) */
+    rich4k: { replicas: 3, opsPerLog: 4096, mix: [55, 10, 20, 15], markTypes: ["strong", "em", "link", "comment"] },
     /* small all-features case used by unit tests and differential fuzzing */
     mini: { replicas: 3, opsPerLog: 96, mix: [25, 25, 25, 25], markTypes: ["strong", "em", "link", "comment"] },
 }

@@ -483,6 +483,18 @@ PTX_DEV uint32_t ptx_tree_query(const uint32_t* tree, uint32_t P, uint32_t q) {
     for (uint32_t p = q + P; p >= 1; p >>= 1) w = tree[p] > w ? tree[p] : w;
     return w;
 }
+/* the same for the tiles of a long document (P = PTX_TILE_1 = 512: ten nodes from the leaf to the root), all read at once — as a loop they are ten LDS round
+ * trips one after the other */
+PTX_DEV uint32_t ptx_tree_query_tile(const uint32_t* tree, uint32_t q) {
+    static_assert(PTX_TILE_1 == 512u, "ten levels");
+    uint32_t v[10];
+#pragma unroll
+    for (uint32_t i = 0; i < 10u; ++i) v[i] = tree[(q + PTX_TILE_1) >> i];
+    uint32_t w = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 10u; ++i) w = v[i] > w ? v[i] : w;
+    return w;
+}
 
 struct PtxCEntry {
     uint16_t lo, hi, t, add;
@@ -495,8 +507,56 @@ struct PtxCEntry {
  * iterates the slot's ops in application order, so the last one decides).
  * Calls emit(start,end) for every maximal present interval in ascending order; returns their count.
  */
-template <class E, class F>
+/* The same for an id with at most eight ops (nearly every id: a comment is added once and removed or re-added a few times), out of REGISTERS: the entries are read
+ * once (eight 8-byte LDS reads in flight), every step of the sweep is then a few dozen vector instructions.  The loops of the general form below read an entry from
+ * LDS at every turn — 8 m^2 dependent round trips for the two sweeps of an id, a lane per id, the wave as slow as its busiest id: 110 k of the 430 k cycles of a
+ * 4 096-op log that keeps its text (round 6, `rich4k`). */
+template <class F>
+PTX_DEV uint32_t ptx_comment_sweep8(const PtxCEntry* ent, uint32_t m, F emit) {
+    uint32_t lo_[8], hi_[8], ta_[8]; /* t << 1 | add (an entry past m: an empty interval that covers nothing) */
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; ++j) {
+        const PtxCEntry e = ent[j < m ? j : 0u];
+        lo_[j] = j < m ? (uint32_t)e.lo : 0xFFFFFFFFu;
+        hi_[j] = j < m ? (uint32_t)e.hi : 0xFFFFFFFFu;
+        ta_[j] = ((uint32_t)e.t << 1) | (e.add ? 1u : 0u);
+    }
+    uint32_t count = 0, start = 0;
+    int64_t cur = -1;
+    bool present = false;
+    for (;;) {
+        uint32_t p = 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+            if ((int64_t)lo_[j] > cur && lo_[j] < p) p = lo_[j];
+            if ((int64_t)hi_[j] > cur && hi_[j] < p) p = hi_[j];
+        }
+        if (p == 0xFFFFFFFFu) break;
+        int best = -1;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j)
+            if (lo_[j] <= p && p < hi_[j] && (int)ta_[j] > best) best = (int)ta_[j]; /* (t decides: the low bit rides along) */
+        const bool now = best >= 0 && (best & 1);
+        if (now != present) {
+            if (now) start = p;
+            else {
+                emit(start, p);
+                ++count;
+            }
+            present = now;
+        }
+        cur = (int64_t)p;
+    }
+    return count;
+}
+#ifndef PTX_SWEEP8
+#define PTX_SWEEP8 1
+#endif
+template <bool kRegs = true, class E, class F>
 PTX_DEV uint32_t ptx_comment_sweep(const E* ent, uint32_t m, F emit) {
+    if constexpr (PTX_SWEEP8 && kRegs && std::is_same<E, PtxCEntry>::value) { /* (kRegs false: the one-wave build, held to 64 VGPRs, keeps the plain form) */
+        if (m <= 8u) return ptx_comment_sweep8(ent, m, emit);
+    }
     uint32_t count = 0;
     int64_t cur = -1;
     bool present = false;
@@ -2324,7 +2384,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_SYNC_LDS();
         PTX_FOR(c, Kid + 1) {
-            cicnt[c] = c < Kid ? ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
+            cicnt[c] = c < Kid ? ptx_comment_sweep<kThreads != 64u>(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         }
         PTX_SYNC_LDS();
         const uint32_t I = ptx_counts_prefix<kThreads>(cicnt, Kid + 1, &H->scan_tmp[21]);
@@ -2335,7 +2395,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         uint64_t h1 = 0, h2 = 0;
         PTX_FOR(c, Kid) {
             uint32_t row = cicnt[c];
-            ptx_comment_sweep(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [&](uint32_t s, uint32_t e) {
+            ptx_comment_sweep<kThreads != 64u>(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [&](uint32_t s, uint32_t e) {
                 if (crow) {
                     crow[2u * row] = c;
                     crow[2u * row + 1u] = s | (e << 16);
@@ -2393,6 +2453,19 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         uint64_t h1 = 0, h2 = 0;
         uint32_t span_base = 0;
         uint32_t prev_attr = 0; /* marks of the last char of the previous tile */
+        /* Long documents (several tiles, a pass per tile and mark type): the park words — row | id key — of the ops a thread takes in step 0 of every type's run are
+         * read ONCE, here.  Read inside the pass they were a trip to HBM per tile and type — 16 of them, one after the other, for a document of 2 000 characters:
+         * a third of the 160 k cycles this phase takes of such a log (round 6, `rich4k`; a run of up to PTX_UB ops per thread is one step, i.e. all of it). */
+        uint32_t pk0[PTX_UB], pk1[PTX_UB], pk3[PTX_UB];
+        const bool pk_cached = kThreads != 64u && !four && K != 0u; /* (not in the one-wave build: a log of up to 512 rows has one tile, and the build is held to 64 VGPRs) */
+#pragma unroll
+        for (int u = 0; u < (int)PTX_UB; ++u) {
+            const uint32_t j = PTX_J_OF_U(0u, u, PTX_UB);
+            const uint32_t kn0 = moff1, kn1 = moff2 - moff1, kn3 = K - moff3;
+            pk0[u] = pk_cached && j < kn0 ? ptx_coherent_load32(&park[mp0 + PTX_JX(j, kn0)]) : 0u;
+            pk1[u] = pk_cached && j < kn1 ? ptx_coherent_load32(&park[mp0 + moff1 + PTX_JX(j, kn1)]) : 0u;
+            pk3[u] = pk_cached && j < kn3 ? ptx_coherent_load32(&park[mp0 + moff3 + PTX_JX(j, kn3)]) : 0u;
+        }
 #pragma nounroll
         for (uint32_t t0 = 0; t0 < V; t0 += TV) {
             const uint32_t tv = V - t0 < TV ? V - t0 : TV; /* chars in this tile */
@@ -2442,7 +2515,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         lo[u] = l;
                         hi[u] = h;
                         idq[u] = 0;
-                        if (l < h && PTX_TYPE_OF(k) != PTX_MARK_COMMENT) idq[u] = ptx_coherent_load32(&park[mp0 + k]);
+                        if (l < h && PTX_TYPE_OF(k) != PTX_MARK_COMMENT)
+                            idq[u] = pk_cached && st == 0u ? (g == 0u ? pk0[u] : g == 1u ? pk1[u] : pk3[u]) : ptx_coherent_load32(&park[mp0 + k]);
                     }
                 };
                 auto lww_put = [&](const uint32_t (&kq)[PTX_UB], const uint32_t (&lo)[PTX_UB], const uint32_t (&hi)[PTX_UB], const uint32_t (&idq)[PTX_UB]) {
@@ -2469,10 +2543,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     lww_put(kq_b, lo_b, hi_b, idq_b);
                 }
                 PTX_SYNC_LDS();
+                if (four) { /* a short document: one pass, four trees of a few levels, a char per lane */
                 PTX_FOR(q, tv) {
                     uint32_t at = 0;
                     for (uint32_t ty = g; ty < g + ntree; ++ty) {
-                        const uint32_t w = ptx_tree_query(tree + (four ? ty : 0u) * 2 * TV, TV, q);
+                        const uint32_t w = ptx_tree_query(tree + ty * 2 * TV, TV, q);
                         if (w == 0) continue;
                         if (ty == PTX_MARK_COMMENT) at |= PTX_ATTR_COMMENT;
                         else {
@@ -2485,6 +2560,44 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         }
                     }
                     if (at) attr[q + 1] |= at; /* attr[0] = last char of the previous tile */
+                }
+                } else {
+                /* three chars per thread and step: their tree look-ups first, then the park words of the link winners, then the urls — two trips to HBM per step
+                 * whatever the chars (a char at a time they were two trips EACH, one after the other: the larger part of this phase's time in a document of
+                 * thousands of characters, round 6) */
+                PTX_FORV(q0, tv, 3) {
+                    uint32_t at[3], lk[3], pw[3], url[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        at[u] = 0;
+                        lk[u] = 0xFFFFFFFFu; /* the link op that wins at this char, if one does */
+                        if (PTX_IN(q0, u)) {
+                            const uint32_t q = PTX_IX(q0, u);
+                            const uint32_t ty = g, w = ptx_tree_query_tile(tree, q); /* (one type per pass) */
+                            if (w != 0) {
+                                if (ty == PTX_MARK_COMMENT) at[u] |= PTX_ATTR_COMMENT;
+                                else {
+                                    const uint32_t k = w & kmask;
+                                    if (ptx_bittest(maddbits, k)) {
+                                        if (ty == PTX_MARK_STRONG) at[u] |= PTX_ATTR_STRONG;
+                                        else if (ty == PTX_MARK_EM) at[u] |= PTX_ATTR_EM;
+                                        else lk[u] = k;
+                                    }
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) pw[u] = lk[u] != 0xFFFFFFFFu ? ptx_coherent_load32(&park[mp0 + lk[u]]) & 0xFFFFu : 0u;
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) url[u] = lk[u] != 0xFFFFFFFFu ? payload[pw[u] < N ? pw[u] : N - 1u] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+                        if (PTX_IN(q0, u)) {
+                            if (lk[u] != 0xFFFFFFFFu) at[u] |= PTX_ATTR_LINK | (url[u] & PTX_ATTR_ID_MASK);
+                            if (at[u]) attr[PTX_IX(q0, u) + 1] |= at[u]; /* attr[0] = last char of the previous tile */
+                        }
+                }
                 }
                 PTX_SYNC_LDS();
             }

@@ -591,6 +591,10 @@ static void shape_launch(ptx_ctx* ctx, ptx_dbatch* b, uint64_t need, uint32_t ma
      * 256-op logs peak at 64 threads, 1K and 2K at 128, 4K at 192, 6K and 8K at 256 (round 4, profiles/r04_i_*: config #5's 8 192-op logs, four per CU by
      * their LDS, run 8 % faster as four waves each than as eight — 74.2 against 68.4 G ops/s; five waves are always the worst choice) */
     uint32_t t = max_log_ops <= 512 ? 64u : max_log_ops <= 2048 ? 128u : max_log_ops <= 4608 ? 192u : max_log_ops <= 12288 ? 256u : 512u;
+    /* (round 6) logs of up to 4 608 rows whose window leaves room for six of them or fewer per CU — documents that KEEP their text: thousands of elements — run as
+     * four waves each: the wave slots are there, and the tail phases of such a log (LWW trees tile by tile, spans) are work per visible character
+     * (`rich4k`, 3 x 4 096 ops at 55 % inserts, five logs per CU: 6.85 against 7.58 ms; 320 threads and more are slower again) */
+    if (t == 192u && lds > (160u * 1024u) / 7u) t = 256u;
     if (ctx->force_threads) t = (uint32_t)ctx->force_threads;
     b->threads = t;
 }

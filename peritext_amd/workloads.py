@@ -10,6 +10,8 @@ CONFIGS = {
     "config4": (3, 4096, [25, 25, 25, 25], ["strong", "em", "link", "comment"]),
     "config5": (1, 8192, [20, 50, 20, 10], ["link", "comment"]),
     "rich": (3, 1024, [55, 10, 20, 15], ["strong", "em", "link", "comment"]),
+    # the same mix at the headline's log length: documents that HOLD text (about two thousand visible characters, hundreds of spans) — bench.py's extras leg `rich4k`
+    "rich4k": (3, 4096, [55, 10, 20, 15], ["strong", "em", "link", "comment"]),
     "mini": (3, 96, [25, 25, 25, 25], ["strong", "em", "link", "comment"]),
 }
 

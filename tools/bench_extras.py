@@ -40,7 +40,8 @@ PHASES = {0: "P0 admission", 1: "P1 row loop", 11: "P1 tail (census, dup, scan)"
           7: "P5c comments", 8: "P5b trees + P6 spans", 10: "end"}
 ORDER = [0, 1, 11, 2, 12, 3, 4, 14, 16, 17, 18, 5, 6, 13, 7, 8]
 # (config, documents): the specified size first, then sizes that fill the GPU
-BASELINE_LEGS = [("config2", 1024), ("config2", 524288), ("config3", 8192), ("config3", 196608), ("config5", 32768), ("config5", 65536)]
+BASELINE_LEGS = [("config2", 1024), ("config2", 524288), ("config3", 8192), ("config3", 196608), ("config5", 32768), ("config5", 65536),
+                 ("rich4k", 16384)]  # (round 6: not a BASELINE configuration — the `rich` mix, 55 / 10 / 20 / 15 with all four mark types, at 3 x 4 096 ops: documents that hold ~2 000 characters)
 
 
 def say(msg):
@@ -73,7 +74,7 @@ def oracle_spans(docs_logs):
     return expected
 
 
-def config_leg(args, name, docs, flags, replicas=None):
+def config_leg(args, name, docs, flags, replicas=None, parity_docs=None):
     """One BASELINE configuration resident on the GPU: kernel ms, SURVEY 8(d) fraction, launch shape, oracle parity of a few of its documents."""
     import helpers
 
@@ -102,14 +103,15 @@ def config_leg(args, name, docs, flags, replicas=None):
                                                                                                  "logs_per_cu_by_lds": int((160 * 1024) // max(512, (lds + 511) // 512 * 512))},
                         "lds_high": int(logs["reserved"][:, 0].max()), "visible_chars_per_log": V / n_logs, "gen_kernel_ms": info["kernel_ms"]})
             # parity: documents of the RESIDENT batch (regenerated one by one with the same generator arguments, so the same documents) against the oracle
-            if args.parity_docs > 0 and shutil.which("node"):
+            n_parity = args.parity_docs if parity_docs is None else min(parity_docs, args.parity_docs)
+            if n_parity > 0 and shutil.which("node"):
                 rng = np.random.default_rng(args.seed + docs)
                 # half drawn at random, half the documents that show the most text (a 50 %-deletes configuration leaves most documents nearly empty: random
                 # draws alone would hardly exercise span and comment-interval rows)
-                half = min(args.parity_docs, docs) // 2
+                half = min(n_parity, docs) // 2
                 vis_doc = logs["n_visible"].reshape(-1, g["replicas"])[:, 0]
                 rich = [int(x) for x in np.argsort(-vis_doc.astype(np.int64), kind="stable")[:half]]
-                rest = [int(x) for x in rng.permutation(docs) if int(x) not in set(rich)][: min(args.parity_docs, docs) - len(rich)]
+                rest = [int(x) for x in rng.permutation(docs) if int(x) not in set(rich)][: min(n_parity, docs) - len(rich)]
                 pick = sorted(rich + rest)
                 ones, docs_logs = [], []
                 for d in pick:
@@ -297,7 +299,7 @@ def main():
     if "configs" in legs:
         out["baseline_configs"] = []
         for name, docs in BASELINE_LEGS:
-            row = config_leg(args, name, docs, flags)
+            row = config_leg(args, name, docs, flags, parity_docs=8 if name == "rich4k" else None)  # (a 4 096-op log that keeps its text is minutes of oracle time)
             out["baseline_configs"].append(row)
             say("baseline_configs %s" % json.dumps(row))
 
