@@ -18,7 +18,7 @@ One JSON line on stdout (rank 0):
       mark-state table — and the 128-bit digest), divided by the kernel's average launch duration measured with HIP events on
       the stream the kernel runs on.  The Change envelope that causal admission reads on top is NOT in B_alg; the figure
       that includes it is reported separately (roofline.with_envelope).
-  roofline.traffic  = HBM bytes per launch from the PMC counters of the same command (profiles/r05_hbm_traffic.json, made by
+  roofline.traffic  = HBM bytes per launch from the PMC counters of the same command (profiles/r06_hbm_traffic.json, made by
       tools/pmc_traffic.sh on the GPU box: separate --pmc passes; reads = the L2's read requests by size, cross-checked against
       FETCH_SIZE calibrated as MI355X_MICROARCH.md prescribes; writes = WRITE_SIZE); null when that file does not describe this workload.
   parity            = --check-docs random documents of the RESIDENT batch checked against the oracle run on the host cores on
@@ -196,7 +196,7 @@ def kernel_source_sha16():
 def load_traffic(n_logs, rows, launch):
     """PMC-measured HBM bytes per launch of this command, if profiles/ holds them for this very workload, launch shape AND build of the kernel sources
     (a traffic file of another build is refused: roofline.traffic is null then, never a stale number)."""
-    p = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
+    p = os.path.join(ROOT, "profiles", "r06_hbm_traffic.json")
     if not os.path.exists(p):
         return None
     with open(p) as f:

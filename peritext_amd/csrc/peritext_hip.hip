@@ -516,6 +516,11 @@ struct ptx_ctx {
     int stop_after = 0;    /* -DPTX_DIAG builds only (ptx_diag_stop_after): truncate the diagnostic kernel after a phase, for per-phase PMC deltas */
     uint32_t flags = 0;
     unsigned long long* clocks = nullptr; /* device [PTX_NCLK], non-null only while ptx_merge_phase_cycles runs */
+    /* staging of the SMALL result downloads (an editor session reads one replica per flush): a device block and a pinned host block that the context keeps and
+     * grows on demand — a hipMalloc / hipFree (a device-wide wait) / hipHostMalloc / hipHostFree per read cost more than the read */
+    uint8_t* stage_d = nullptr;
+    uint8_t* stage_h = nullptr;
+    size_t stage_d_cap = 0, stage_h_cap = 0;
 };
 
 struct ptx_dbatch {
@@ -829,6 +834,8 @@ void ptx_destroy(ptx_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->stage_d) (void)hipFree(ctx->stage_d);
+    if (ctx->stage_h) (void)hipHostFree(ctx->stage_h);
     delete ctx;
 }
 
@@ -1548,10 +1555,12 @@ ptx_status ptx_device_read(ptx_ctx* ctx, const void* device, void* host, uint64_
  * zero-filled, nothing is copied again); elem_rank — one entry per op row, hundreds of MB for a large batch, wanted by few callers — is plain memory. */
 struct ptx_host_result {
     void* pinned[2] = {nullptr, nullptr}; /* [0] logs + the three offset arrays, [1] values + spans + cintervals */
+    void* heap = nullptr;                 /* a SMALL range: one plain block for all of them, copied out of the context's pinned staging block */
     uint32_t* rank = nullptr;
     ~ptx_host_result() {
         for (void* p : pinned)
             if (p) (void)hipHostFree(p);
+        free(heap);
         free(rank);
     }
 };
@@ -1587,9 +1596,31 @@ ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const pt
      * one waits for the totals first and allocates exactly those */
     uint64_t cv = nr, cs = nr, cc = nr;
     uint8_t *hp0 = nullptr, *hp1 = nullptr, *dblk = nullptr, *dblk1 = nullptr;
-    hipError_t e = hipHostMalloc((void**)&hp0, logs_bytes + off_bytes + (small ? a16(cv * 4) + a16(cs * sizeof(ptx_span)) + a16(cc * sizeof(ptx_cinterval)) : 0) + 16, hipHostMallocDefault);
-    h->pinned[0] = hp0;
-    if (e == hipSuccess) e = hipMalloc((void**)&dblk, off_bytes + (small ? a16(cv * 4) + a16(cs * sizeof(ptx_span)) + a16(cc * sizeof(ptx_cinterval)) : 0) + 16);
+    hipError_t e = hipSuccess;
+    const uint64_t h0_bytes = logs_bytes + off_bytes + (small ? a16(cv * 4) + a16(cs * sizeof(ptx_span)) + a16(cc * sizeof(ptx_cinterval)) : 0) + 16;
+    const uint64_t d0_bytes = off_bytes + (small ? a16(cv * 4) + a16(cs * sizeof(ptx_span)) + a16(cc * sizeof(ptx_cinterval)) : 0) + 16;
+    if (small) { /* the context's own staging blocks (grown on demand, kept): no allocation, no hipFree — a device-wide wait — per read */
+        if (ctx->stage_h_cap < h0_bytes) {
+            if (ctx->stage_h) (void)hipHostFree(ctx->stage_h);
+            ctx->stage_h = nullptr;
+            ctx->stage_h_cap = 0;
+            e = hipHostMalloc((void**)&ctx->stage_h, h0_bytes * 2, hipHostMallocDefault);
+            if (e == hipSuccess) ctx->stage_h_cap = h0_bytes * 2;
+        }
+        if (e == hipSuccess && ctx->stage_d_cap < d0_bytes) {
+            if (ctx->stage_d) (void)hipFree(ctx->stage_d);
+            ctx->stage_d = nullptr;
+            ctx->stage_d_cap = 0;
+            e = hipMalloc((void**)&ctx->stage_d, d0_bytes * 2);
+            if (e == hipSuccess) ctx->stage_d_cap = d0_bytes * 2;
+        }
+        hp0 = ctx->stage_h;
+        dblk = ctx->stage_d;
+    } else {
+        e = hipHostMalloc((void**)&hp0, h0_bytes, hipHostMallocDefault);
+        h->pinned[0] = hp0;
+        if (e == hipSuccess) e = hipMalloc((void**)&dblk, d0_bytes);
+    }
     uint64_t* offs = (uint64_t*)(hp0 + logs_bytes);
     uint64_t* d_off = (uint64_t*)dblk;
     if (e == hipSuccess) {
@@ -1640,8 +1671,31 @@ ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const pt
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     else (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dblk);
-    (void)hipFree(dblk1);
+    if (!small) {
+        (void)hipFree(dblk);
+        (void)hipFree(dblk1);
+    } else if (e == hipSuccess) { /* out of the staging block into memory the result owns (the rows that exist: a few KB for a replica of an editor session) */
+        const uint64_t tv = offs[n_logs], ts = offs[no + n_logs], tc = offs[2 * no + n_logs];
+        if (tv > nr || ts > nr || tc > nr) e = hipErrorInvalidValue;
+        else {
+            const uint64_t own_bytes = logs_bytes + off_bytes + a16(tv * 4) + a16(ts * sizeof(ptx_span)) + a16(tc * sizeof(ptx_cinterval)) + 16;
+            uint8_t* own = (uint8_t*)malloc(own_bytes);
+            if (!own) e = hipErrorOutOfMemory;
+            else {
+                memcpy(own, hp0, logs_bytes + off_bytes);
+                uint8_t* dv2 = own + logs_bytes + off_bytes;
+                memcpy(dv2, hv, tv * 4);
+                memcpy(dv2 + a16(tv * 4), hs, ts * sizeof(ptx_span));
+                memcpy(dv2 + a16(tv * 4) + a16(ts * sizeof(ptx_span)), hc, tc * sizeof(ptx_cinterval));
+                h->heap = own;
+                hp0 = own;
+                offs = (uint64_t*)(own + logs_bytes);
+                hv = (uint32_t*)dv2;
+                hs = (ptx_span*)(dv2 + a16(tv * 4));
+                hc = (ptx_cinterval*)(dv2 + a16(tv * 4) + a16(ts * sizeof(ptx_span)));
+            }
+        }
+    }
     if (e != hipSuccess) {
         delete h;
         return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("result download: ") + hipGetErrorString(e));

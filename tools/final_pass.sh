@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd "$ROOT"
 python -m pytest tests -m gpu -q 2>&1 | tail -6 > "$OUT/gpu_tests.txt"
 bash tools/pmc_traffic.sh "$TAG" > "$OUT/traffic.log" 2>&1
-cp "gpurun_out/traffic_$TAG/hbm_traffic.json" profiles/r05_hbm_traffic.json
+cp "gpurun_out/traffic_$TAG/hbm_traffic.json" profiles/r06_hbm_traffic.json
 (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -- python "$ROOT/bench.py" --no-extras > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err")
 db=$(find "$OUT/prof" -name '*.db' | head -1)
 [ -n "$db" ] && python tools/prof_summary.py "$db" > "$OUT/kernel_stats.txt" 2>&1

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the two PMC passes of tools/pmc_traffic.sh into profiles/r05_hbm_traffic.json (what bench.py reports as roofline.traffic).
+"""Turn the two PMC passes of tools/pmc_traffic.sh into profiles/r06_hbm_traffic.json (what bench.py reports as roofline.traffic).
 FETCH_SIZE / WRITE_SIZE are in KB; the read side is calibrated on ptx_calib_stream_kernel, whose byte count is known."""
 import hashlib
 import json
