@@ -88,6 +88,11 @@ PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean128, 128, PTX_LEAN128_W, 0, 128, false, 
 PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean192, 192, PTX_W, 0, 192, false, true, PTX_SGPRS_W7)
 PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, 1, 0, false) /* + causal admission for documents with more than three actors: a one-pass walk up to seven, the (actor, seq) table beyond fifteen */
 PTX_MERGE_KERNEL(ptx_merge_kernel_many_wide, 1024, 1, 2, 0, false) /* the same for documents of eight to fifteen actors (walks over 24- and 32-byte envelope rows) */
+#ifdef PTX_DIAG /* (diagnostic builds only) the stamps of the LEAN builds: the same bodies as ptx_merge_kernel_lean64 / 128 / 192 with the phase stamps on */
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_diag64, 64, PTX_W, 0, 64, true, true, PTX_SGPRS_W7)
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_diag128, 128, PTX_W, 0, 128, true, true, PTX_SGPRS_W7)
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_diag192, 192, PTX_W, 0, 192, true, true, PTX_SGPRS_W7)
+#endif
 PTX_MERGE_KERNEL(ptx_merge_kernel_diag, 1024, PTX_W, 0, 0, true)  /* (the admission of the product kernel — with the table path of the many-actor build it needs 105 VGPRs and its phase stamps would be taken at 4 waves per SIMD —) + phase cycle stamps / early exit (ptx_merge_phase_cycles, PTX_STOP_AFTER) */
 /* (ptx_merge_log<MANY, T> can fold the workgroup size T in at compile time; measured on MI355X the specialised builds
  * issue ~1 % fewer instructions but need twice the VGPRs unless PTX_U=1, so only the run-time-sized builds are shipped) */
@@ -1251,6 +1256,14 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
         }
         else if (diag) { /* + room for its phase stamps in the header */
             A.lds_bytes = std::min<uint32_t>(lds + PTX_HDR_DIAG_EXTRA, (uint32_t)ctx->max_lds);
+#ifdef PTX_DIAG
+            const bool dl_ok = !part && !(r->rank || r->refs) && b->small_keys && !(admit && b->max_actors > 3) && wants_w7(ctx, b, lds);
+            const uint32_t dl = dl_ok && (b->threads == 64u || b->threads == 128u || b->threads == 192u) ? b->threads : 0u;
+            if (dl == 64u) hipLaunchKernelGGL(ptx_merge_kernel_diag64, dim3(grid), dim3(64), A.lds_bytes, st, A);
+            else if (dl == 128u) hipLaunchKernelGGL(ptx_merge_kernel_diag128, dim3(grid), dim3(128), A.lds_bytes, st, A);
+            else if (dl == 192u) hipLaunchKernelGGL(ptx_merge_kernel_diag192, dim3(grid), dim3(192), A.lds_bytes, st, A);
+            else
+#endif
             hipLaunchKernelGGL(ptx_merge_kernel_diag, dim3(grid), dim3(b->threads), A.lds_bytes, st, A);
         }
         else if (admit && b->max_actors > 3) {

@@ -203,7 +203,22 @@ PTX_DEV bool ptx_wave_pick(bool pred, uint32_t value, uint32_t& out) {
     out = (uint32_t)__builtin_amdgcn_readlane((int)value, (int)(__ffsll((long long)m) - 1));
     return true;
 }
-PTX_DEV uint32_t ptx_wave_pk_max_u16(uint32_t v) { /* per 16-bit half, the same value in every lane */
+/* Wave-wide reductions as DPP prefix steps (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31: lane 63 ends up with the reduction of all 64, read back by v_readlane) — a
+ * dozen vector instructions and no LDS.  As butterflies of __shfl_xor they were six ds_bpermute round trips EACH, one after the other: the five reductions that end
+ * a wave's admission walk were 30 dependent LDS trips, more than the walk of a one-step log itself (round 6: the kernel is bound by its chain of fixed latencies). */
+#define PTX_DPP_STEPS(OP_)                                                                                         \
+    v = OP_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */           \
+    v = OP_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */           \
+    v = OP_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */           \
+    v = OP_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false)); /* row_shr:8 */           \
+    v = OP_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 -> rows 1,3 */ \
+    v = OP_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 -> rows 2,3 */
+PTX_DEV uint32_t ptx_max_u32_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+PTX_DEV uint32_t ptx_wave_pk_max_u16_dpp(uint32_t v) { /* per 16-bit half, the same value in every lane (a lane without a source reads 0: the identity of an unsigned maximum) */
+    PTX_DPP_STEPS(ptx_pk_max_u16)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+PTX_DEV uint32_t ptx_wave_pk_max_u16(uint32_t v) { /* (the butterfly: what the builds of three and more waves per log keep — measured 0.9 % faster there, their LDS trips hide behind the other waves) */
     for (int d = 32; d >= 1; d >>= 1) v = ptx_pk_max_u16(v, (uint32_t)__shfl_xor((int)v, d, 64));
     return v;
 }
@@ -311,6 +326,10 @@ PTX_DEV uint32_t ptx_wave_min(uint32_t v) { /* the same value in every lane */
     }
     return v;
 }
+PTX_DEV uint32_t ptx_wave_max_dpp(uint32_t v) { /* the same value in every lane */
+    PTX_DPP_STEPS(ptx_max_u32_)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 PTX_DEV uint32_t ptx_wave_max(uint32_t v) {
     for (int d = 32; d >= 1; d >>= 1) {
         const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
@@ -331,17 +350,27 @@ PTX_DEV void ptx_reduce_add64(unsigned long long* dst, unsigned long long v) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(dst, v);
 }
+PTX_DEV void ptx_reduce_add64_dpp(unsigned long long* dst, unsigned long long v) {
+    /* the 64-bit sum of the wave from four 16-bit limbs, each a 32-bit DPP prefix sum (64 x 65 535 fits 22 bits), put together again: no LDS round trip
+     * (the butterfly of 64-bit shuffles was twelve ds_bpermute trips one after the other) */
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    const unsigned long long l0 = ptx_wave_last(ptx_wave_incl_scan(lo & 0xFFFFu)), l1 = ptx_wave_last(ptx_wave_incl_scan(lo >> 16));
+    const unsigned long long l2 = ptx_wave_last(ptx_wave_incl_scan(hi & 0xFFFFu)), l3 = ptx_wave_last(ptx_wave_incl_scan(hi >> 16));
+    const unsigned long long t = l0 + (l1 << 16) + (l2 << 32) + (l3 << 48);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, t);
+}
 
+PTX_DEV void ptx_reduce_add32_dpp(uint32_t* dst, uint32_t v) { /* every lane of the wave calls it: one LDS atomic per wave */
+    v = ptx_wave_last(ptx_wave_incl_scan(v)); /* (a DPP prefix sum, its last lane: the total) */
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
 PTX_DEV void ptx_reduce_add32(uint32_t* dst, uint32_t v) { /* every lane of the wave calls it: one LDS atomic per wave */
     for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
 }
 
 PTX_DEV void ptx_reduce_max32(uint32_t* dst, uint32_t v) {
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o > v ? o : v;
-    }
+    v = ptx_wave_max(v);
     if ((threadIdx.x & 63) == 0) atomicMax(dst, v);
 }
 

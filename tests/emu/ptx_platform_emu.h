@@ -141,6 +141,12 @@ PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint3
 /* loops over BLOCKS of items: the emulation plays blocks of 8 lanes, one lane per step, in the selected order */
 #define PTX_JB_CAP 8u
 #define PTX_KEEP_VGPR(x) ((void)(x))
+
+/* (the gfx950 header has DPP forms of the wave reductions beside the butterflies; here they are the same functions) */
+#define ptx_wave_pk_max_u16_dpp ptx_wave_pk_max_u16
+#define ptx_wave_max_dpp ptx_wave_max
+#define ptx_reduce_add32_dpp ptx_reduce_add32
+#define ptx_reduce_add64_dpp ptx_reduce_add64
 #define PTX_CONST_LOAD(p) (*(p))
 #define PTX_FRESH_ARGS(A) (A) /* (the GPU reads its kernel arguments again, scalar loads; here they are where they were) */
 #define PTX_JB_STEPS(B, U) (((B) * PTX_JB_CAP + (U)-1u) / (U))
