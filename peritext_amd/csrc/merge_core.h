@@ -920,6 +920,19 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
      * that bounds it ("What bounds the kernel"). */
     uint64_t base = A.log_off[log];
     const uint64_t N64 = A.log_off[log + 1] - base;
+    /* The builds of one and two waves per log (a few hundred rows: a dozen dependent trips to memory in all) read the log's Change offsets and its header HERE, with
+     * its row offsets — three scalar loads that depend on nothing but the kernel arguments, one wait — and do not read the row offsets a second time after the
+     * admission: read where they are used they were four more round trips in a row before the row pass could start (round 6). */
+    constexpr bool kShort = kThreads == 64u || kThreads == 128u;
+    uint64_t chg0_early = 0, chg1_early = 0;
+    ptx_log_hdr hd_early = ptx_log_hdr();
+    if (kShort) {
+        if (A.chg_off) {
+            chg0_early = A.chg_off[log];
+            chg1_early = A.chg_off[log + 1];
+        }
+        hd_early = A.log_hdr[log];
+    }
     PtxHdr* H = (PtxHdr*)lds;
     PTX_LEADER {
         H->err = PTX_NO_ERR;
@@ -1022,8 +1035,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
      * (the census sends the others to biglog_core.h): a value saturated at 65535 can never be admitted here — the same error as
      * the true one. */
     if (A.chg_off) {
-        const uint64_t c0 = A.chg_off[log];
-        const uint64_t C64 = A.chg_off[log + 1] - c0;
+        const uint64_t c0 = kShort ? chg0_early : A.chg_off[log];
+        const uint64_t C64 = (kShort ? chg1_early : A.chg_off[log + 1]) - c0;
         const uint32_t na = A.max_actors;
         if (C64 > 65533u || na == 0u || na > 4096u) {
             lds_high = bp.high;
@@ -1072,7 +1085,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                  * is checked against the value G of the FIRST change of that actor the wave meets (learned once per wave, scalar
                  * code); G itself is validated against the true clock before the segment after the pass. */
                 PtxAdmWave S;
-                S.bx = S.by = S.gx = S.gy = S.known = 0u;
+                S.bx = S.by = S.gx = S.gy = 0u;
+                S.known = (7u << na) & 7u; /* (an actor the document does not have has no G to learn: with one or two actors the search for it ran in EVERY step, round 6) */
                 uint32_t mx0 = 0, mx1 = 0, bad = 0, amax = 0, hsum = 0;
                 uint32_t h[PTX_AC], h_n[PTX_AC], e0[PTX_AC], e1[PTX_AC], e0_n[PTX_AC], e1_n[PTX_AC];
 #define PTX_ADM_LOAD(cb_, h_, e0_, e1_)                                     \
@@ -1136,7 +1150,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     if ((r[8] >> PTX_CHG_ACTOR_SHIFT) >= na || r[5] != 0u) admitted = false; /* an actor beyond the document's; two changes of an actor disagree on seq - clock */
 #pragma unroll
                     for (uint32_t b = 0; b < 3; ++b) {
-                        if (((r[4] >> b) & 1u) && G[b] != B[b] + 1u) admitted = false; /* some seq != clock + 1 */
+                        if (b < na && ((r[4] >> b) & 1u) && G[b] != B[b] + 1u) admitted = false; /* some seq != clock + 1 */
                         if (b < na && M[b] > B[b]) admitted = false;                     /* some dep > clock */
                     }
                     B[0] += r[0] >> 16;
@@ -1347,8 +1361,12 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 
     PTX_STAMP(1); /* (diagnostic builds: end of the admission phase) */
     /* ---- the log header (census) sizes everything; the row pass below verifies it ---- */
-    PTX_REMAT_ROWS();
-    ptx_log_hdr hd = ptx_load_log_hdr(&PTX_FRESH_ARGS(A).log_hdr[log]);
+    ptx_log_hdr hd;
+    if (kShort) hd = hd_early;
+    else {
+        PTX_REMAT_ROWS();
+        hd = ptx_load_log_hdr(&PTX_FRESH_ARGS(A).log_hdr[log]);
+    }
     uint32_t n, D, moff1, moff2, moff3, Kc, Kid, K; /* list elements (inserts); deletes; mark ops, listed grouped by type: type t owns [moff_t, moff_{t+1}) */
     PtxElemIndex ix;
     uint32_t kbits, keyspace, nw, nwe;
