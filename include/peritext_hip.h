@@ -44,7 +44,8 @@
  *                [start,end) on which that comment is present, sorted by (id, start).  A span's
  *                `comment` array is the set of ids whose interval covers it (present iff
  *                PTX_ATTR_COMMENT is set — `comment: []` is a real state).
- *     digest     2 x u64 multiset hash of the above (peritext_amd/canon.py, oracle/canon.js restate it)
+ *     digest     2 x u64 multiset hash of the above (peritext_amd/canon.py restates it).  Compared only with digests of the SAME build of the library
+ *                (replicas of a document, ranks of a job): the per-item mixing function is not part of the ABI (round 6 replaced it, csrc/merge_core.h)
  *   Output rows of log l start at row log_off[l] of each output array (a log never produces more
  *   rows than it has ops), so no cross-log compaction or device-side allocation is needed.
  */

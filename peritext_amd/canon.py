@@ -10,31 +10,43 @@ import numpy as np
 
 from . import abi
 
-_M1 = np.uint64(0xBF58476D1CE4E5B9)
-_M2 = np.uint64(0x94D049BB133111EB)
-_GOLD = np.uint64(0x9E3779B97F4A7C15)
-_SALT2 = np.uint64(0xD6E8FEB86659FD93)
+_U32 = np.uint32
 
 
-def _fmix64(x):
-    x = x.astype(np.uint64)
-    x = x ^ (x >> np.uint64(30))
-    x = x * _M1
-    x = x ^ (x >> np.uint64(27))
-    x = x * _M2
-    x = x ^ (x >> np.uint64(31))
-    return x
+def _rotl(x, r):
+    return (x << _U32(r)) | (x >> _U32(32 - r))
+
+
+def _qr(a, b, c, d):
+    """The ChaCha quarter round over four uint32 arrays (merge_core.h PTX_DIGEST_QR)."""
+    a = a + b
+    d = _rotl(d ^ a, 16)
+    c = c + d
+    b = _rotl(b ^ c, 12)
+    a = a + b
+    d = _rotl(d ^ a, 8)
+    c = c + d
+    b = _rotl(b ^ c, 7)
+    return a, b, c, d
 
 
 def _items(tag, a, b, c):
-    a = np.asarray(a, dtype=np.uint64)
-    b = np.asarray(b, dtype=np.uint64)
-    c = np.asarray(c, dtype=np.uint64)
+    """Sum over the items (tag, a[i], b[i], c[i]) of their 128-bit hashes, as two 64-bit halves (merge_core.h ptx_digest_item: four quarter rounds, the
+    words' roles rotated from round to round; 32-bit arithmetic that wraps)."""
+    a = np.asarray(a, dtype=np.uint64).astype(_U32)
+    b = np.asarray(b, dtype=np.uint64).astype(_U32)
+    c = np.asarray(c, dtype=np.uint64).astype(_U32)
     with np.errstate(over="ignore"):
-        x = (np.uint64(tag) << np.uint64(60)) ^ (a << np.uint64(32)) ^ b
-        y = _fmix64(x) ^ (c * _GOLD)
-        h1 = _fmix64(y).sum(dtype=np.uint64)
-        h2 = _fmix64(y ^ _SALT2).sum(dtype=np.uint64)
+        x0 = a ^ _U32(0x9E3779B9)
+        x1 = b ^ _U32(0x85EBCA6B)
+        x2 = c ^ _U32(0xC2B2AE35)
+        x3 = np.full(a.shape, (int(tag) | (int(tag) << 16)) ^ 0x165667B1, dtype=_U32)
+        x0, x1, x2, x3 = _qr(x0, x1, x2, x3)
+        x1, x2, x3, x0 = _qr(x1, x2, x3, x0)
+        x2, x3, x0, x1 = _qr(x2, x3, x0, x1)
+        x3, x0, x1, x2 = _qr(x3, x0, x1, x2)
+        h1 = (x0.astype(np.uint64) | (x1.astype(np.uint64) << np.uint64(32))).sum(dtype=np.uint64)
+        h2 = (x2.astype(np.uint64) | (x3.astype(np.uint64) << np.uint64(32))).sum(dtype=np.uint64)
     return int(h1), int(h2)
 
 

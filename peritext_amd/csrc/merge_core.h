@@ -155,28 +155,31 @@ struct PtxMergeArgs {
 #define PTX_SMALL_BUCKET 8u  /* child buckets up to this size: one lane per member */
 #define PTX_HUGE_BUCKET 256u /* beyond this size: bitmap ranking, one bucket at a time */
 
-/* ---- digest: 128-bit multiset hash of the canonical output (restated in peritext_amd/canon.py) ---- */
-PTX_DEV uint64_t ptx_fmix64(uint64_t x) {
-    x ^= x >> 30;
-    x *= 0xbf58476d1ce4e5b9ull;
-    x ^= x >> 27;
-    x *= 0x94d049bb133111ebull;
-    x ^= x >> 31;
-    return x;
-}
+/* ---- digest: 128-bit multiset hash of the canonical output (restated in peritext_amd/canon.py) ----
+ * Per item (tag, a, b, c) four 32-bit words, mixed by four add-rotate-xor quarter rounds (the ChaCha quarter round over the four words, the words' roles rotated
+ * from round to round), summed modulo 2^64 as two 64-bit halves over the items of a log.  Round 6: ONLY full-rate 32-bit instructions — the digest of rounds
+ * 1-5 (seven 64-bit multiplies per item, each four quarter-rate v_mul_lo/hi_u32) was 7 % of the time of a 256-op log and 3 % of a 1K-op one, whose builds the
+ * counters show bound by vector-instruction issue (knock-out timing, `-DPTX_KO_DIGEST=1`).  The values of two builds with different digest functions are not
+ * comparable: a digest is only ever compared with another digest of the same library (replicas of a document, ranks of a job). */
 #ifndef PTX_KO_DIGEST
 #define PTX_KO_DIGEST 0 /* knock-out (WRONG digests, timing experiments only): what the digest arithmetic costs */
 #endif
+PTX_DEV uint32_t ptx_rotl32(uint32_t x, uint32_t r) { return (x << r) | (x >> (32u - r)); } /* (v_alignbit_b32) */
+#define PTX_DIGEST_QR(a_, b_, c_, d_) \
+    a_ += b_; d_ ^= a_; d_ = ptx_rotl32(d_, 16u); c_ += d_; b_ ^= c_; b_ = ptx_rotl32(b_, 12u); a_ += b_; d_ ^= a_; d_ = ptx_rotl32(d_, 8u); c_ += d_; b_ ^= c_; b_ = ptx_rotl32(b_, 7u);
 PTX_DEV void ptx_digest_item(uint64_t& h1, uint64_t& h2, uint32_t tag, uint32_t a, uint32_t b, uint32_t c) {
     if (PTX_KO_DIGEST) {
         h1 += tag + a;
         h2 += b + c;
         return;
     }
-    const uint64_t x = ((uint64_t)tag << 60) ^ ((uint64_t)a << 32) ^ (uint64_t)b;
-    const uint64_t y = ptx_fmix64(x) ^ ((uint64_t)c * 0x9E3779B97F4A7C15ull);
-    h1 += ptx_fmix64(y);
-    h2 += ptx_fmix64(y ^ 0xD6E8FEB86659FD93ull);
+    uint32_t x0 = a ^ 0x9E3779B9u, x1 = b ^ 0x85EBCA6Bu, x2 = c ^ 0xC2B2AE35u, x3 = (tag | (tag << 16)) ^ 0x165667B1u;
+    PTX_DIGEST_QR(x0, x1, x2, x3)
+    PTX_DIGEST_QR(x1, x2, x3, x0)
+    PTX_DIGEST_QR(x2, x3, x0, x1)
+    PTX_DIGEST_QR(x3, x0, x1, x2)
+    h1 += (uint64_t)x0 | ((uint64_t)x1 << 32);
+    h2 += (uint64_t)x2 | ((uint64_t)x3 << 32);
 }
 
 /* ---- LDS header ---- */
