@@ -561,7 +561,7 @@ PTX_DEV uint32_t ptx_comment_sweep8(const PtxCEntry* ent, uint32_t m, F emit) {
 #endif
 template <bool kRegs = true, class E, class F>
 PTX_DEV uint32_t ptx_comment_sweep(const E* ent, uint32_t m, F emit) {
-    if constexpr (PTX_SWEEP8 && kRegs && std::is_same<E, PtxCEntry>::value) { /* (kRegs false: the one-wave build, held to 64 VGPRs, keeps the plain form) */
+    if constexpr (PTX_SWEEP8 && kRegs && std::is_same<E, PtxCEntry>::value) { /* (kRegs: the builds for any launch shape, which take the documents that keep their text; the lean builds of the three usual shapes — logs that show a few dozen characters, an op or two per comment id — keep the plain form: the unrolled one cost BASELINE config #4 1.2 %) */
         if (m <= 8u) return ptx_comment_sweep8(ent, m, emit);
     }
     uint32_t count = 0;
@@ -2414,7 +2414,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_SYNC_LDS();
         PTX_FOR(c, Kid + 1) {
-            cicnt[c] = c < Kid ? ptx_comment_sweep<kThreads != 64u>(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
+            cicnt[c] = c < Kid ? ptx_comment_sweep<kThreads == 0u>(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         }
         PTX_SYNC_LDS();
         const uint32_t I = ptx_counts_prefix<kThreads>(cicnt, Kid + 1, &H->scan_tmp[21]);
@@ -2425,7 +2425,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         uint64_t h1 = 0, h2 = 0;
         PTX_FOR(c, Kid) {
             uint32_t row = cicnt[c];
-            ptx_comment_sweep<kThreads != 64u>(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [&](uint32_t s, uint32_t e) {
+            ptx_comment_sweep<kThreads == 0u>(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [&](uint32_t s, uint32_t e) {
                 if (crow) {
                     crow[2u * row] = c;
                     crow[2u * row + 1u] = s | (e << 16);
