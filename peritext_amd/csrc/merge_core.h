@@ -2487,7 +2487,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
          * read ONCE, here.  Read inside the pass they were a trip to HBM per tile and type — 16 of them, one after the other, for a document of 2 000 characters:
          * a third of the 160 k cycles this phase takes of such a log (round 6, `rich4k`; a run of up to PTX_UB ops per thread is one step, i.e. all of it). */
         uint32_t pk0[PTX_UB], pk1[PTX_UB], pk3[PTX_UB];
-        const bool pk_cached = kThreads != 64u && !four && K != 0u; /* (not in the one-wave build: a log of up to 512 rows has one tile, and the build is held to 64 VGPRs) */
+        /* (both long-document forms — this and the three-chars-per-step query below — only in the builds for any launch shape, which take the documents that keep
+         * their text: in the lean builds of the three usual shapes they cost scalar registers and bought nothing, config #4 +0.7 %, #3 +0.5 %) */
+        constexpr bool kLongDocs = kThreads == 0u || kThreads == 128u; /* (the two-wave build too: a 1K-op log of BASELINE config #3 shows 158 characters, -0.9 %) */
+        const bool pk_cached = kLongDocs && !four && K != 0u;
 #pragma unroll
         for (int u = 0; u < (int)PTX_UB; ++u) {
             const uint32_t j = PTX_J_OF_U(0u, u, PTX_UB);
@@ -2573,11 +2576,11 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     lww_put(kq_b, lo_b, hi_b, idq_b);
                 }
                 PTX_SYNC_LDS();
-                if (four) { /* a short document: one pass, four trees of a few levels, a char per lane */
+                if (four || !kLongDocs) { /* a short document: one pass, four trees of a few levels, a char per lane (the lean builds: every document) */
                 PTX_FOR(q, tv) {
                     uint32_t at = 0;
                     for (uint32_t ty = g; ty < g + ntree; ++ty) {
-                        const uint32_t w = ptx_tree_query(tree + ty * 2 * TV, TV, q);
+                        const uint32_t w = ptx_tree_query(tree + (four ? ty : 0u) * 2 * TV, TV, q);
                         if (w == 0) continue;
                         if (ty == PTX_MARK_COMMENT) at |= PTX_ATTR_COMMENT;
                         else {
