@@ -83,7 +83,7 @@ def config_leg(args, name, docs, flags, replicas=None, parity_docs=None):
     row = {"config": name, "docs": docs, "replicas": g["replicas"], "ops_per_log": g["ops_per_log"], "mix_ins_del_add_rem": g["mix"], "causal_admission": not args.no_admission}
     try:
         with Engine(args.device, flags=flags) as e:
-            list_cap = max(args.list_cap, g["ops_per_log"] // 2 + 512, g["replicas"] * 640 if g["replicas"] > 4 else 0)  # the element list of a document, held on chip while it is generated (it grows with the replicas: every one of them makes ops_per_log ops)
+            list_cap = max(args.list_cap, g["ops_per_log"] // 2 + 512, g["replicas"] * 640 if g["replicas"] > 4 else 0, g["ops_per_log"] * 3 // 4 if g["mix"][0] > 50 else 0)  # the element list of a document, held on chip while it is generated (it grows with the replicas: every one of them makes ops_per_log ops)
             db, info = e.generate(*gen_args, docs, args.seed, list_cap=list_cap)
             n_logs, rows = e.n_logs(db), e.n_ops(db)
             dr = e.alloc_result(db)
