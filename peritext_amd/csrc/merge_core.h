@@ -2499,8 +2499,21 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             pk1[u] = pk_cached && j < kn1 ? ptx_coherent_load32(&park[mp0 + moff1 + PTX_JX(j, kn1)]) : 0u;
             pk3[u] = pk_cached && j < kn3 ? ptx_coherent_load32(&park[mp0 + moff3 + PTX_JX(j, kn3)]) : 0u;
         }
+        /* a log without a mark op (BASELINE config #2: inserts and deletes only): one span over the whole text, no attribute, no break — nothing to sweep
+         * (round 6: the tile pass of such a log was 313 of the 2 825 vector instructions of a 256-op log, whose build is bound by their issue) */
+        const uint32_t V_swept = K != 0u ? V : 0u;
+        if (K == 0u && V != 0u) {
+            PTX_LEADER {
+                ptx_span sp;
+                sp.start = 0;
+                sp.attr = 0;
+                out_spans[0] = sp;
+                ptx_digest_item(h1, h2, 2u, 0u, 0u, 0u);
+            }
+            span_base = 1u;
+        }
 #pragma nounroll
-        for (uint32_t t0 = 0; t0 < V; t0 += TV) {
+        for (uint32_t t0 = 0; t0 < V_swept; t0 += TV) {
             const uint32_t tv = V - t0 < TV ? V - t0 : TV; /* chars in this tile */
             PTX_FOR(q, tv + 1) attr[q] = 0;
             PTX_FOR(w, TV / 32 + 2) {
