@@ -2212,6 +2212,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     PTX_REMAT_AT(8, PTX_REMAT());
 
     /* ---- P5a: visible values out; every mark op -> visible interval [lo, hi) ---- */
+    /* (the one-wave build — bound by vector issue — carries a thread's digest share of the values on to the spans and flushes ONCE: a wave-wide 64-bit sum is ~70
+     * vector instructions, three of them were 7 % of a 256-op log's; the builds of more waves keep their flush per pass: four more live VGPRs through P5a cost them more) */
+    constexpr bool kOneFlush = kThreads == 64u;
+    uint64_t carry_h1 = 0, carry_h2 = 0;
     {
         uint64_t h1 = 0, h2 = 0;
         /* the surviving elements again (a lane per word of the tombstone bitmap): their rows by visible index (= alive bits below the element's position) into
@@ -2244,7 +2248,10 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 out_rank[base + row_of[e]] = r | (ptx_bittest(delbits, e) ? PTX_RANK_TOMBSTONE : 0u);
             }
         }
-        if (V >= 48u) { /* uniform: most lanes of a wave carry a share */
+        if (kOneFlush) {
+            carry_h1 = h1;
+            carry_h2 = h2;
+        } else if (V >= 48u) { /* uniform: most lanes of a wave carry a share */
             if (kThreads == 64u || kThreads == 128u) ptx_digest_flush_dense_dpp(H, h1, h2);
             else ptx_digest_flush_dense(H, h1, h2);
         }
@@ -2480,7 +2487,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         PtxBitWord* st = ptx_alloc2<PtxBitWord>(bd, bp, TV / 32 + 2);
         PTX_BAIL_CAPACITY();
         const uint32_t kmask = (1u << kbits) - 1u;
-        uint64_t h1 = 0, h2 = 0;
+        uint64_t h1 = kOneFlush ? carry_h1 : 0, h2 = kOneFlush ? carry_h2 : 0;
         uint32_t span_base = 0;
         uint32_t prev_attr = 0; /* marks of the last char of the previous tile */
         /* Long documents (several tiles, a pass per tile and mark type): the park words — row | id key — of the ops a thread takes in step 0 of every type's run are
