@@ -490,16 +490,19 @@ PTX_DEV uint32_t ptx_tree_query(const uint32_t* tree, uint32_t P, uint32_t q) {
     for (uint32_t p = q + P; p >= 1; p >>= 1) w = tree[p] > w ? tree[p] : w;
     return w;
 }
-/* the same for the tiles of a long document (P = PTX_TILE_1 = 512: ten nodes from the leaf to the root), all read at once — as a loop they are ten LDS round
+/* the same for the tiles of a long document (ten or eleven nodes from the leaf to the root), all read at once — as a loop they are ten LDS round
  * trips one after the other */
-PTX_DEV uint32_t ptx_tree_query_tile(const uint32_t* tree, uint32_t q) {
-    static_assert(PTX_TILE_1 == 512u, "ten levels");
-    uint32_t v[10];
+PTX_DEV uint32_t ptx_tree_query_tile(const uint32_t* tree, uint32_t P, uint32_t q) { /* P = 512 or 1 024 leaves */
+    static_assert(PTX_TILE_1 == 512u, "ten levels, eleven for the double tile");
+    uint32_t v[11];
 #pragma unroll
-    for (uint32_t i = 0; i < 10u; ++i) v[i] = tree[(q + PTX_TILE_1) >> i];
+    for (uint32_t i = 0; i < 11u; ++i) {
+        const uint32_t p = (q + P) >> i;
+        v[i] = tree[p ? p : 1u]; /* (level 11 of a 512-leaf tree: the root again) */
+    }
     uint32_t w = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 10u; ++i) w = v[i] > w ? v[i] : w;
+    for (uint32_t i = 0; i < 11u; ++i) w = v[i] > w ? v[i] : w;
     return w;
 }
 
@@ -2480,6 +2483,13 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             while (TV < V) TV <<= 1;
         } else {
             TV = PTX_TILE_1;
+            /* (round 6) a document of more than one tile takes tiles of twice the size where the recycled element region and the free phase scratch hold
+             * them: half the passes — each a handful of barriers and, for the links, two trips to HBM */
+            if (kThreads == 0u && V > PTX_TILE_1) {
+                const uint32_t T2 = 2u * PTX_TILE_1;
+                const uint64_t over = ptx_overflow3((uint64_t)bd.cap - bd.off, K ? 4u * 2u * T2 : 0u, 4u * (T2 + 1u), 8u * (T2 / 32u + 2u));
+                if ((uint64_t)bp.off + over <= bp.cap) TV = T2;
+            }
         }
         const uint32_t ntree = four ? 4u : 1u;
         uint32_t* tree = ptx_alloc2<uint32_t>(bd, bp, K ? ntree * 2 * TV : 0u); /* a log without mark ops has one span per break: no trees */
@@ -2626,7 +2636,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                         lk[u] = 0xFFFFFFFFu; /* the link op that wins at this char, if one does */
                         if (PTX_IN(q0, u)) {
                             const uint32_t q = PTX_IX(q0, u);
-                            const uint32_t ty = g, w = ptx_tree_query_tile(tree, q); /* (one type per pass) */
+                            const uint32_t ty = g, w = ptx_tree_query_tile(tree, TV, q); /* (one type per pass) */
                             if (w != 0) {
                                 if (ty == PTX_MARK_COMMENT) at[u] |= PTX_ATTR_COMMENT;
                                 else {

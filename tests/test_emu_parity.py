@@ -640,7 +640,10 @@ def test_lds_bound_covers_the_high_water_mark(name):
                                     int(h["n_mark"][2]), (int(h["max_counter"]) + 1) * (int(h["max_actor"]) + 1), int(h["n_comment_ids"]))
         used = int(res.logs["reserved"][log][0])
         parked = (2 * (int(h["n_mark"].sum()) + 1) + 15) & ~15  # the mark list, parked in HBM between P1 and P5, counts in both phases' scratch
-        assert used <= need <= used + 6144 + parked, (log, used, need)  # slack = the LWW trees sized for V = n
+        # (round 6) a document of more than one 512-char tile takes tiles of twice the size WHERE THE LAUNCH'S WINDOW HAS THE ROOM (the emulation's window is the
+        # CU's whole LDS): that opportunistic use is not part of the bound the host sizes the launch with
+        double_tile = (4 * 2 * 512 + 4 * 512 + 8 * 16 + 48) if int(h["n_ins"]) > 512 else 0
+        assert used <= need + double_tile and need <= used + 6144 + parked, (log, used, need)  # slack = the LWW trees sized for V = n
 
 
 def test_lds_bound_covers_small_and_lopsided_logs():
