@@ -76,16 +76,22 @@ PTX_MERGE_KERNEL_A(ptx_merge_kernel_rest_w7, 1024, 1, 0, 0, false, PTX_SGPRS_W7)
 #define PTX_LEAN64_SGPRS 80
 #endif
 PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean64, 64, PTX_LEAN64_W, 0, 64, false, true, __attribute__((amdgpu_num_sgpr(PTX_LEAN64_SGPRS))))
-/* (the two-wave build at eight waves per SIMD measured -3.9 % on config #3 — 16 instead of 14 logs per CU — but at 64 VGPRs it spills two of them to scratch
- * memory, which this repo's build guard refuses for every launched merge kernel: it stays at seven until its admission walk fits) */
+/* The two-wave build likewise since the last session of round 6 (64 VGPRs, 78 SGPRs granted, nothing in scratch — its admission walk fits now): 16 instead of 14 logs
+ * per CU where the LDS window allows; same box config #3 -4.6 % (2.912 -> 2.779 ms, same results). */
 #ifndef PTX_LEAN128_W
-#define PTX_LEAN128_W PTX_W
+#define PTX_LEAN128_W 8
 #endif
 #ifndef PTX_LEAN128_SGPRS
-#define PTX_LEAN128_SGPRS PTX_W7_SGPRS
+#define PTX_LEAN128_SGPRS 80
 #endif
 PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean128, 128, PTX_LEAN128_W, 0, 128, false, true, __attribute__((amdgpu_num_sgpr(PTX_LEAN128_SGPRS))))
-PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean192, 192, PTX_W, 0, 192, false, true, PTX_SGPRS_W7)
+#ifndef PTX_LEAN192_W
+#define PTX_LEAN192_W PTX_W
+#endif
+#ifndef PTX_LEAN192_SGPRS
+#define PTX_LEAN192_SGPRS PTX_W7_SGPRS
+#endif
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean192, 192, PTX_LEAN192_W, 0, 192, false, true, __attribute__((amdgpu_num_sgpr(PTX_LEAN192_SGPRS))))
 PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, 1, 0, false) /* + causal admission for documents with more than three actors: a one-pass walk up to seven, the (actor, seq) table beyond fifteen */
 PTX_MERGE_KERNEL(ptx_merge_kernel_many_wide, 1024, 1, 2, 0, false) /* the same for documents of eight to fifteen actors (walks over 24- and 32-byte envelope rows) */
 #ifdef PTX_DIAG /* (diagnostic builds only) the stamps of the LEAN builds: the same bodies as ptx_merge_kernel_lean64 / 128 / 192 with the phase stamps on */
