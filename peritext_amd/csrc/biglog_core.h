@@ -565,16 +565,18 @@ PTX_DEV uint32_t ptx_big_merge_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         mrk_lo[k] = lo;
         mrk_hi[k] = hi;
-        if (A.out_refs) { /* per mark op its two boundary slots, each on its own, 16 bits each (0xFFFF = none): what fits the on-chip replay (n <= 32766) */
-            uint32_t va = 0xFFFFu, vb = 0xFFFFu;
-            if (n <= 32766u) {
+        if (A.out_refs) { /* per mark op its two boundary slots, each on its own (none: all ones): 16 bits each in out_refs; a log of more than 32 766 elements has
+                             slots beyond 16 bits — their high halves go to out_refs_hi where the host provides it (round 6), else the log reports no slots */
+            uint32_t va = 0xFFFFFFFFu, vb = 0xFFFFFFFFu;
+            if (n <= 32766u || A.out_refs_hi) {
                 if (js >= 0) va = 2u * pos[js] + (sa == PTX_SIDE_AFTER ? 1u : 0u);
                 if (sb == PTX_SIDE_BEFORE || sb == PTX_SIDE_AFTER) {
                     const int je = ptx_elem_lookup(ix, ref_b[i]);
                     if (je >= 0 && row_of[je] < i) vb = 2u * pos[je] + (sb == PTX_SIDE_AFTER ? 1u : 0u);
                 }
             }
-            A.out_refs[base + i] = va | (vb << 16);
+            A.out_refs[base + i] = (va & 0xFFFFu) | (vb << 16);
+            if (A.out_refs_hi) A.out_refs_hi[base + i] = (va >> 16) | (vb & 0xFFFF0000u);
         }
         if ((mflag[k] & 3u) == PTX_MARK_COMMENT) {
             const uint32_t pl = payload[i];

@@ -25,9 +25,9 @@
 #pragma once
 #include "gen_core.h"
 
-#define PTX_CE_MASK 0x000FFFFFu /* the element inside a list word (bits 30 / 31: PTX_GK_DEAD / PTX_GK_AFTER): the ROW of the log that inserted it, or
-                                   PTX_CE_NEW + j for the j-th element this call makes */
-#define PTX_CE_NEW 0x00010000u
+#define PTX_CE_MASK 0x3FFFFFFFu /* the element inside a list word (bits 30 / 31: PTX_GK_DEAD / PTX_GK_AFTER): the ROW of the log that inserted it, or
+                                   PTX_CE_NEW + j for the j-th element this call makes (round 6: rows up to 2^29 — the word was 16 + 4 bits before) */
+#define PTX_CE_NEW 0x20000000u
 
 struct PtxChangeArgs {
     /* the base batch (resident) and its merge result */
@@ -43,6 +43,9 @@ struct PtxChangeArgs {
     const ptx_log_result* res;
     const uint32_t* elem_rank;
     const uint32_t* refs;      /* the merge's resolved references (PtxMergeArgs.out_refs): per mark row its boundary slots start | end << 16, 0xFFFF = none */
+    const uint32_t* refs_hi;   /* (a log of more than 32 766 list elements) the slots' high halves, PtxMergeArgs.out_refs_hi */
+    uint32_t* list_scratch;    /* optional: the element list of a log that does not fit one CU's LDS lives HERE (round 6) ... */
+    const uint64_t* list_off;  /* ... [n_logs + 1], in words: the slice of log l (empty: the list fits the LDS) */
     const uint64_t* chg_off;   /* base envelope: the replica's clock = changes per actor */
     const uint32_t* chg_hdr;
     uint32_t max_actors;
@@ -88,11 +91,12 @@ struct PtxChangeHdr {
 };
 
 /* LDS of one log: n elements now, `grow` inserts to come, id keyspace of ks bits, na actors */
-PTX_HD uint64_t ptx_change_lds_need(uint64_t n, uint64_t grow, uint64_t ks, uint64_t na) {
+PTX_HD uint64_t ptx_change_lds_need(uint64_t n, uint64_t grow, uint64_t ks, uint64_t na, bool list_in_hbm = false) {
     (void)ks; /* (no element index: the rows come resolved from the merge) */
     const uint64_t cap = n + grow + 64;
-    return ptx_a16(sizeof(PtxChangeHdr)) + ptx_a16(4 * cap) + ptx_a16(4 * (grow + 1)) + ptx_a16(4 * (na + 1));
+    return ptx_a16(sizeof(PtxChangeHdr)) + (list_in_hbm ? 0 : ptx_a16(4 * cap)) + ptx_a16(4 * (grow + 1)) + ptx_a16(4 * (na + 1));
 }
+PTX_HD uint64_t ptx_change_list_words(uint64_t n, uint64_t grow) { return (n + grow + 64 + 3) & ~3ull; } /* of list_scratch (16-byte blocks: ptx_list_shift_up) */
 
 template <uint32_t kThreads>
 PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) {
@@ -145,10 +149,14 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
      * from the merge — elem_rank (document position + tombstone of every insert row) and the boundary slots of every mark row (refs) — so no element index
      * is built here and a document of 32 766 elements fits one CU's LDS (round 4: with its own id bitmap, element -> row table and a second list-sized
      * buffer for opening a gap the kernel stopped at ~12 000). */
-    uint32_t* L = ptx_alloc<uint32_t>(bp, cap);
+    /* Round 6: a list that does not fit the LDS (more than ~40 000 elements) lives in the log's slice of A.list_scratch — the same primitives over flat
+     * addresses; the one wave's stores are complete and visible at every PTX_SYNC (a workgroup-scope barrier: the CU's own L1 is coherent for it). */
+    const bool list_in_hbm = A.list_scratch && A.list_off[log + 1] - A.list_off[log] >= cap;
+    uint32_t* L = list_in_hbm ? A.list_scratch + A.list_off[log] : ptx_alloc<uint32_t>(bp, cap);
     uint32_t* newctr = ptx_alloc<uint32_t>(bp, grow + 1); /* counter of the j-th element made here (its list word is PTX_CE_NEW + j) */
     uint32_t* clock = ptx_alloc<uint32_t>(bp, na + 1);
-    if (bp.overflow || n0 + grow > 32766u || N > 65534u || max_ctr0 + out_cap >= (1u << 19)) PTX_CHANGE_FAIL(PTX_ERR_CAPACITY);
+    if (bp.overflow || n0 + grow > 0x03FFFFFFu || N >= PTX_CE_NEW || grow >= PTX_CE_NEW || max_ctr0 + out_cap >= (1u << 19)) PTX_CHANGE_FAIL(PTX_ERR_CAPACITY);
+    if (n0 > 32766u && !A.refs_hi) PTX_CHANGE_FAIL(PTX_ERR_CAPACITY); /* (a result without the slots' high halves) */
 
     /* ---- the replica's state from its merged log ---- */
     PTX_FOR(a, na + 1) clock[a] = 0;
@@ -185,7 +193,12 @@ PTX_DEV void ptx_change_log(const PtxChangeArgs& A, uint32_t log, uint8_t* lds) 
         const uint32_t a = A.action[base + i];
         if ((a == PTX_ACT_ADDMARK || a == PTX_ACT_REMOVEMARK) && A.mark_type[base + i] < 4u) {
             const uint32_t v = A.refs[base + i];
-            const uint32_t slot_a = (v & 0xFFFFu) != 0xFFFFu ? v & 0xFFFFu : 0xFFFFFFFFu, slot_b = (v >> 16) != 0xFFFFu ? v >> 16 : 0xFFFFFFFFu;
+            uint32_t slot_a = (v & 0xFFFFu) != 0xFFFFu ? v & 0xFFFFu : 0xFFFFFFFFu, slot_b = (v >> 16) != 0xFFFFu ? v >> 16 : 0xFFFFFFFFu;
+            if (n0 > 32766u) { /* 32-bit slots: low halves | high halves, none = all ones in both */
+                const uint32_t vh = A.refs_hi[base + i];
+                slot_a = (v & 0xFFFFu) | (vh << 16);
+                slot_b = (v >> 16) | (vh & 0xFFFF0000u);
+            }
             const bool has_a = slot_a != 0xFFFFFFFFu, has_b = slot_b != 0xFFFFFFFFu;
             const bool end_first = has_b && (!has_a || slot_b < slot_a);
             const bool start_written = has_a && !end_first;

@@ -144,6 +144,9 @@ struct PtxMergeArgs {
     uint8_t* big_scratch;
     const uint64_t* big_off;
     uint32_t* grid_bar; /* a large log merged by the workgroups of ONE cooperative launch: the two words (arrivals, generation) of its grid barrier, zeroed by the host */
+    uint32_t* out_refs_hi; /* optional, beside out_refs: the HIGH halves of the boundary slots of the mark rows (start >> 16 | end >> 16 << 16; 0xFFFF beside a low half of
+                              0xFFFF = none) — written by the HBM-staged kernel alone, for logs of more than 32 766 list elements, whose slots 2 rank + side pass 16 bits
+                              (round 6: the replay and change() on such logs) */
 };
 
 #define PTX_END 0xFFFFu

@@ -139,6 +139,12 @@ extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kern
     extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
     if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS, true>(A, blockIdx.x, ptx_lds);
 }
+/* round 6: the wide build — ranks and boundary slots 32 bits wide — for batches with a log of more than 32 766 list elements or 65 534 rows (merged by the HBM-staged
+ * kernel, which hands the slots' high halves over in ptx_dresult.refs_hi); urls and op tables always in global memory */
+extern "C" __global__ void __launch_bounds__(PTX_REPLAY_THREADS) ptx_replay_kernel_wide(PtxReplayArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ptx_lds[];
+    if (blockIdx.x < A.n_logs) ptx_replay_log<PTX_REPLAY_THREADS, true, true>(A, blockIdx.x, ptx_lds);
+}
 
 /* the records of every log — first its own capacity [cap_off[l], cap_off[l + 1]), then its overflow extent from ext_off[l] — packed to out_off[l]; the logs from
  * first_log on, into a buffer that starts at record out_base of the packed stream (the whole stream in one go unless device memory is short) */
@@ -287,7 +293,7 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
     if (b1 < b0 || b1 > n_ops || (log == 0 && b0 != 0) || (log + 1 == gridDim.x && b1 != n_ops)) {
         /* offsets that decrease or leave the columns (a wrapped device batch is not checked on the host): no row is touched */
         if (threadIdx.x == 0) {
-            atomicMax(&shape[2], 1u);
+            atomicOr(&shape[2], 1u);
             need_per_log[log] = 0;
         }
         return;
@@ -367,6 +373,7 @@ __global__ void __launch_bounds__(256) ptx_census_kernel(const uint64_t* log_off
         const bool lds_ok = b1 - b0 <= 65534u && h.n_ins <= 32766u && h.max_counter < (1u << 19) && h.max_actor <= 4095u && (!h.n_mark[PTX_MARK_COMMENT] || h.n_comment_ids <= 65535u) &&
                             ((ks + 1) << kbits) <= 0xFFFFFFFFull && C <= 65533u && !wide;
         if (!lds_ok) need = 0xFFFFFFFFull;
+        if (h.n_ins > 32766u) atomicOr(&shape[2], 2u); /* boundary slots 2 rank + side beyond 16 bits: the result carries their high halves (ptx_dresult.refs_hi) */
         need_per_log[log] = (uint32_t)min(need, (uint64_t)0xFFFFFFFFu);
         big_need_per_log[log] = ptx_big_need(b1 - b0, h, C, max_actors, PTX_BIG_TEAM_MAX);
         if (need <= max_lds) { /* the launch shape of the LDS kernel is sized by the logs that take it */
@@ -554,6 +561,7 @@ struct ptx_dbatch {
     uint32_t lds_bytes = 0;
     uint32_t threads = 0;
     bool small_keys = false; /* every log the LDS kernel takes has an id keyspace of at most 2^16 (census): the lean builds apply */
+    bool wide_slots = false; /* some log has more than 32 766 list elements (census): boundary slots beyond 16 bits — results of this batch carry refs_hi */
     /* split launch: when a few logs need more LDS than the rest, they would cost EVERY log a share of the CU (the
      * dynamic LDS size is per launch): the logs are then merged in two launches, `log_index` = the logs of the main
      * group followed by the rest */
@@ -579,6 +587,7 @@ struct ptx_dresult {
     ptx_cinterval* cints = nullptr;
     uint32_t* rank = nullptr;
     uint32_t* refs = nullptr; /* with rank: resolved references of the delete / mark rows (PtxMergeArgs.out_refs), for ptx_replay_patches */
+    uint32_t* refs_hi = nullptr; /* with refs, for a batch that holds a log of more than 32 766 list elements: the high halves of its mark rows' boundary slots */
 };
 
 static thread_local std::string g_create_err;
@@ -643,10 +652,11 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
         (void)hipFree(d_need);
         (void)hipFree(d_big);
         if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("census: ") + hipGetErrorString(e));
-        if (h[2]) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off must run from 0 to n_ops without decreasing");
+        if (h[2] & 1u) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off must run from 0 to n_ops without decreasing");
     }
     shape_launch(ctx, b, h[0], h[1]);
     b->small_keys = h[3] <= 65536u;
+    b->wide_slots = (h[2] & 2u) != 0u;
     (void)hipFree(b->log_index);
     (void)hipFree(b->big_off);
     (void)hipFree(b->big_scratch);
@@ -818,7 +828,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     ctx->own_stream = ctx->stream;
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_many_wide, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_merge_kernel_lean64, (const void*)ptx_merge_kernel_lean128, (const void*)ptx_merge_kernel_lean192, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_gen_kernel, (const void*)ptx_gen_kernel_r8, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_many_wide, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_merge_kernel_lean64, (const void*)ptx_merge_kernel_lean128, (const void*)ptx_merge_kernel_lean192, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_replay_kernel_wide, (const void*)ptx_gen_kernel, (const void*)ptx_gen_kernel_r8, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -1167,6 +1177,7 @@ void ptx_dresult_free(ptx_ctx* ctx, ptx_dresult* r) {
     (void)hipFree(r->cints);
     (void)hipFree(r->rank);
     (void)hipFree(r->refs);
+    (void)hipFree(r->refs_hi);
     delete r;
 }
 
@@ -1183,6 +1194,7 @@ ptx_status ptx_result_alloc(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult** out
     if (e == hipSuccess) e = dalloc(&r->cints, r->n_rows);
     if (e == hipSuccess && !(ctx->flags & PTX_FLAG_NO_ELEM_RANK)) e = dalloc(&r->rank, r->n_rows);
     if (e == hipSuccess && !(ctx->flags & PTX_FLAG_NO_ELEM_RANK)) e = dalloc(&r->refs, r->n_rows);
+    if (e == hipSuccess && !(ctx->flags & PTX_FLAG_NO_ELEM_RANK) && b->wide_slots) e = dalloc(&r->refs_hi, r->n_rows);
     if (e != hipSuccess) {
         std::string m = std::string("result allocation: ") + hipGetErrorString(e);
         ptx_dresult_free(ctx, r);
@@ -1219,6 +1231,7 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
     A.out_cints = r->cints;
     A.out_rank = r->rank;
     A.out_refs = r->refs;
+    A.out_refs_hi = r->refs_hi;
     A.n_logs = b->n_logs;
     A.lds_bytes = b->lds_bytes;
     A.div_magic = (uint32_t)(0x100000000ull / b->threads) + 1u;
@@ -1819,13 +1832,18 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
         return fail(ctx, PTX_ERR_HIP, std::string("replay set-up: ") + hipGetErrorString(e));
     }
     uint64_t need = 0, need_g = 0;
+    /* round 6: a batch with a log of more than 32 766 list elements or 65 534 rows takes the wide build (32-bit ranks and slots; the slots' high halves come
+     * from the merge: r->refs_hi, there whenever the census found such a log) */
+    bool wide = false;
+    for (uint32_t l = 0; l < L; ++l) wide = wide || ptx_replay_wants_wide(log_off[l + 1] - log_off[l], hdr[l]);
+    if (wide && b->wide_slots && !r->refs_hi) wide = false; /* (results allocated for another batch: such logs report PTX_ERR_CAPACITY as before) */
     for (uint32_t l = 0; l < L; ++l) {
-        need = std::max<uint64_t>(need, ptx_replay_lds_need_hdr(hdr[l]));
-        need_g = std::max<uint64_t>(need_g, ptx_replay_lds_need_hdr(hdr[l], true));
+        need = std::max<uint64_t>(need, ptx_replay_lds_need_hdr(hdr[l], false, wide));
+        need_g = std::max<uint64_t>(need_g, ptx_replay_lds_need_hdr(hdr[l], true, wide));
     }
     /* The replay is one wave per log and lives on occupancy.  Above PTX_REPLAY_GWIN_ABOVE bytes of working set the LDS, not the wave slots, bounds the resident
      * logs: the per-slot link urls and the tables of applied mark ops (half of it; read only by the few ops that need them) move to global memory. */
-    const bool gwin = need > PTX_REPLAY_GWIN_ABOVE && !(ctx->flags & PTX_FLAG_REPLAY_LDS_ONLY);
+    const bool gwin = wide || (need > PTX_REPLAY_GWIN_ABOVE && !(ctx->flags & PTX_FLAG_REPLAY_LDS_ONLY));
     if (gwin) need = need_g;
     const uint32_t lds_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, ctx->max_lds); /* larger logs report PTX_ERR_CAPACITY */
     uint16_t* d_win = nullptr;
@@ -1833,7 +1851,7 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
     uint32_t* d_first = nullptr;
     if (gwin) { /* every log's slice of the scratch: what its header says it needs */
         std::vector<uint64_t> woff((size_t)L + 1, 0);
-        for (uint32_t l = 0; l < L; ++l) woff[l + 1] = woff[l] + ptx_replay_win_units_hdr(hdr[l]);
+        for (uint32_t l = 0; l < L; ++l) woff[l + 1] = woff[l] + ptx_replay_win_units_hdr(hdr[l], wide);
         e = hipMalloc((void**)&d_win, 2 * woff[L] + 16);
         if (e == hipSuccess) e = hipMalloc((void**)&d_winoff, ((size_t)L + 1) * 8);
         if (e == hipSuccess) e = hipMemcpyAsync(d_winoff, woff.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -1919,6 +1937,7 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
             A.res = r->logs;
             A.elem_rank = r->rank;
             A.refs = r->refs;
+            A.refs_hi = r->refs_hi;
             A.patch_off = d_off;
             A.patches = d_patches;
             A.plogs = d_logs;
@@ -1932,7 +1951,8 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
             A.arena_cap = arena_cap;
             A.ext_off = d_ext;
             (void)hipEventRecord(ctx->ev0, ctx->stream);
-            if (gwin) hipLaunchKernelGGL(ptx_replay_kernel_gwin, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);
+            if (wide) hipLaunchKernelGGL(ptx_replay_kernel_wide, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);
+            else if (gwin) hipLaunchKernelGGL(ptx_replay_kernel_gwin, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);
             else hipLaunchKernelGGL(ptx_replay_kernel, dim3(L), dim3(PTX_REPLAY_THREADS), lds_bytes, ctx->stream, A);
             e = hipGetLastError();
             (void)hipEventRecord(ctx->ev1, ctx->stream);
@@ -2406,12 +2426,19 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     uint64_t need = 4096;
-    for (uint32_t l = 0; l < L; ++l)
+    /* round 6: the element list of a log that does not fit one CU's LDS (more than ~40 000 elements) lives in a slice of global scratch */
+    std::vector<uint64_t> list_off((size_t)L + 1, 0);
+    for (uint32_t l = 0; l < L; ++l) {
+        list_off[l + 1] = list_off[l];
         if (in->chg_off[l + 1] > in->chg_off[l]) {
             const bool rows = log_off[l + 1] > log_off[l];
             const uint64_t ks = rows ? ((uint64_t)hdr[l].max_counter + 1) * ((uint64_t)std::min<uint32_t>(hdr[l].max_actor, 4095u) + 1) : 1;
-            need = std::max<uint64_t>(need, ptx_change_lds_need(rows ? hdr[l].n_ins : 0, grow[l], ks, na));
+            const uint64_t n_l = rows ? hdr[l].n_ins : 0;
+            const bool in_hbm = ptx_change_lds_need(n_l, grow[l], ks, na) > ctx->max_lds;
+            if (in_hbm) list_off[l + 1] += ptx_change_list_words(n_l, grow[l]);
+            need = std::max<uint64_t>(need, ptx_change_lds_need(n_l, grow[l], ks, na, in_hbm));
         }
+    }
     const uint32_t lds_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, ctx->max_lds); /* larger logs report PTX_ERR_CAPACITY */
 
     ptx_dbatch* cap = new ptx_dbatch(); /* the kernel's capacity-layout output, owned here */
@@ -2419,9 +2446,15 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
     uint64_t *d_in_chg = nullptr, *d_in_op = nullptr, *d_out_off = nullptr, *d_doff = nullptr, *d_dcoff = nullptr;
     uint8_t *d_in_action = nullptr, *d_in_mt = nullptr;
     uint32_t *d_in_index = nullptr, *d_in_count = nullptr, *d_in_payload = nullptr, *d_in_values = nullptr, *d_actor = nullptr, *d_status = nullptr, *d_rows = nullptr, *d_chgs = nullptr;
+    uint32_t* d_list = nullptr;
+    uint64_t* d_list_off = nullptr;
     auto drop = [&]() {
         ptx_batch_free(ctx, cap);
         cap = nullptr;
+        (void)hipFree(d_list);
+        (void)hipFree(d_list_off);
+        d_list = nullptr;
+        d_list_off = nullptr;
         for (void* p : {(void*)d_in_chg, (void*)d_in_op, (void*)d_out_off, (void*)d_doff, (void*)d_dcoff, (void*)d_in_action, (void*)d_in_mt, (void*)d_in_index, (void*)d_in_count,
                         (void*)d_in_payload, (void*)d_in_values, (void*)d_actor, (void*)d_status, (void*)d_rows, (void*)d_chgs})
             (void)hipFree(p);
@@ -2454,6 +2487,10 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
     PTX_TRYC(up(&d_in_payload, in->payload, NI));
     PTX_TRYC(up(&d_in_values, in->values, in->n_values));
     PTX_TRYC(up(&d_actor, in->actor, L));
+    if (list_off[L]) {
+        PTX_TRYC(dalloc(&d_list, list_off[L]));
+        PTX_TRYC(up(&d_list_off, list_off.data(), (uint64_t)L + 1));
+    }
     PTX_TRYC(dalloc(&d_status, L));
     PTX_TRYC(dalloc(&d_rows, L));
     PTX_TRYC(dalloc(&d_chgs, L));
@@ -2487,6 +2524,9 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
         A.res = merged->logs;
         A.elem_rank = merged->rank;
         A.refs = merged->refs;
+        A.refs_hi = merged->refs_hi;
+        A.list_scratch = d_list;
+        A.list_off = d_list_off;
         A.chg_off = base->chg_off;
         A.chg_hdr = base->chg_hdr;
         A.max_actors = na;

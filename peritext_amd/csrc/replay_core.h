@@ -43,7 +43,8 @@
 #pragma once
 #include "merge_core.h"
 
-#define PTX_SLOT_NONE 0xFFFFu /* start never matches / end never reached */
+#define PTX_SLOT_NONE 0xFFFFu /* start never matches / end never reached (the 16-bit form: logs of up to 32 766 list elements; the wide build: 0xFFFFFFFF) */
+#define PTX_CHAIN_NONE 0xFFFFu /* end of a chain of comment ops (indices of comment ops stay 16 bits wide in both builds) */
 #define PTX_RCHUNK 32u /* rows resolved together (their LDS buffers: 17 bytes per row) */
 enum { PTX_RK_SKIP = 0, PTX_RK_MAKELIST = 1, PTX_RK_INSERT = 2, PTX_RK_DELETE = 3, PTX_RK_MARK = 4 };
 
@@ -61,6 +62,7 @@ struct PtxReplayArgs {
     const ptx_log_result* res;  /* of ptx_merge on the same batch */
     const uint32_t* elem_rank;  /* of ptx_merge on the same batch */
     const uint32_t* refs;       /* of the same ptx_merge (PtxMergeArgs.out_refs): target row of every delete, boundary slots of every mark op */
+    const uint32_t* refs_hi;    /* (the wide build) PtxMergeArgs.out_refs_hi: the high halves of the boundary slots of a log of more than 32 766 list elements */
     const uint64_t* patch_off;  /* [n_logs + 1] capacity offsets into `patches` */
     ptx_patch* patches;
     ptx_patch_log* plogs;
@@ -82,11 +84,16 @@ struct PtxMarkBits {
     uint32_t ac, on[3];
 };
 
-/* one of the next PTX_RCHUNK rows, resolved (one 16-byte LDS access when its turn comes) */
-struct PtxChunkRow {
+/* Round 6: the WIDE build (kWide) for logs of more than 32 766 list elements or 65 534 rows (merged by the HBM-staged kernel): ranks and boundary slots are 32 bits
+ * wide (a chunk row is 24 bytes, an entry of the tables of applied LWW ops two 8-byte words, the comment ops' intervals 32-bit pairs); everything else is the same
+ * text.  What bounds such a log is the LDS its bitmaps take — 8 bytes per 32 elements + 28 per 32 slots: about 70 000 elements. */
+template <bool kWide> struct PtxSlotT { typedef uint16_t type; };
+template <> struct PtxSlotT<true> { typedef uint32_t type; };
+/* one of the next PTX_RCHUNK rows, resolved (one 16-byte LDS access when its turn comes; 24 bytes in the wide build) */
+template <bool kWide> struct PtxChunkRowT {
     uint64_t id;   /* the op id (mark ops: compareOpIds) */
     uint32_t pay;  /* payload: url / comment id */
-    uint16_t a, b; /* insert / delete: final rank; mark: start slot, end slot */
+    typename PtxSlotT<kWide>::type a, b; /* insert / delete: final rank; mark: start slot, end slot */
 };
 
 struct PtxReplayHdr {
@@ -98,28 +105,30 @@ struct PtxReplayHdr {
 };
 
 /* gscratch: the per-slot link urls and the op tables live in global memory (PtxReplayArgs.win_scratch) */
-PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid, bool gscratch = false) {
-    const uint64_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2, Kl = K - Kc;
+PTX_HD uint64_t ptx_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid, bool gscratch = false, bool wide = false) {
+    const uint64_t nwe = (n >> 5) + 2, nws = ((2 * n + 2) >> 5) + 2, Kl = K - Kc, sw = wide ? 4 : 2;
     (void)ks;
     return ptx_a16(sizeof(PtxReplayHdr)) + ptx_a16(8 * nwe) + ptx_a16(4 * nws) + ptx_a16(16 * nws) + 2 * ptx_a16(4 * (nws + 1)) +
-           (gscratch ? 0 : ptx_a16(4 * (2 * n + 2)) + ptx_a16(8 * (Kl + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1))) +
-           ptx_a16(16 * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
-           3 * ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * ((Kc >> 5) + 1));
+           (gscratch ? 0 : ptx_a16(4 * (2 * n + 2)) + ptx_a16((wide ? 16 : 8) * (Kl + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(2 * (Kid + 1))) +
+           ptx_a16((wide ? 24 : 16) * PTX_RCHUNK) + ptx_a16(PTX_RCHUNK) +
+           2 * ptx_a16(sw * (Kc + 1)) + ptx_a16(2 * (Kc + 1)) + ptx_a16(4 * ((Kc >> 5) + 1));
 }
-PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gscratch = false) {
+PTX_HD uint64_t ptx_replay_lds_need_hdr(const ptx_log_hdr& h, bool gscratch = false, bool wide = false) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
-    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], 0, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u, gscratch);
+    return ptx_replay_lds_need(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], 0, h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u, gscratch, wide);
 }
 /* u16 units of win_scratch a log takes: per-slot urls (4 bytes x (2 n + 2)), the table of the applied LWW mark ops (8 bytes each), the comment ops' ids and the
  * last op per comment id; every array 16-byte aligned */
-PTX_HD uint64_t ptx_replay_win_units(uint64_t n, uint64_t K, uint64_t Kc, uint64_t Kid) {
+PTX_HD uint64_t ptx_replay_win_units(uint64_t n, uint64_t K, uint64_t Kc, uint64_t Kid, bool wide = false) {
     const uint64_t Kl = K - Kc;
-    return ((2 * (2 * n + 2) + 7) & ~7ull) + 4 * ((Kl + 1 + 7) & ~7ull) + ((Kc + 1 + 7) & ~7ull) + ((Kid + 1 + 7) & ~7ull);
+    return ((2 * (2 * n + 2) + 7) & ~7ull) + (wide ? 8 : 4) * ((Kl + 1 + 7) & ~7ull) + ((Kc + 1 + 7) & ~7ull) + ((Kid + 1 + 7) & ~7ull);
 }
-PTX_HD uint64_t ptx_replay_win_units_hdr(const ptx_log_hdr& h) {
+PTX_HD uint64_t ptx_replay_win_units_hdr(const ptx_log_hdr& h, bool wide = false) {
     const uint64_t K = (uint64_t)h.n_mark[0] + h.n_mark[1] + h.n_mark[2] + h.n_mark[3];
-    return ptx_replay_win_units(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u);
+    return ptx_replay_win_units(h.n_ins, K, h.n_mark[PTX_MARK_COMMENT], h.n_mark[PTX_MARK_COMMENT] ? h.n_comment_ids : 0u, wide);
 }
+/* does the log need the wide build?  (ranks and slots 2 rank + side beyond 16 bits, or row numbers beyond them) */
+PTX_HD bool ptx_replay_wants_wide(uint64_t N, const ptx_log_hdr& h) { return h.n_ins > 32766u || N > 65534u; }
 
 /* where a log's records go: its own capacity first, then its overflow extent */
 struct PtxPatchDst {
@@ -180,8 +189,11 @@ PTX_DEV uint32_t ptx_spread16(uint32_t x) {
 
 /* kGWin: the per-slot urls and the op tables live in global memory (A.win_scratch), read and written past the L1 (workgroup-scope relaxed atomics) with the
  * wave's outstanding stores waited for wherever one lane reads what another has written */
-template <uint32_t kThreads, bool kGWin = false>
+template <uint32_t kThreads, bool kGWin = false, bool kWide = false>
 PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) {
+    typedef typename PtxSlotT<kWide>::type slot_t;
+    typedef PtxChunkRowT<kWide> PtxChunkRow;
+    const uint32_t SLOT_NONE = kWide ? 0xFFFFFFFFu : (uint32_t)PTX_SLOT_NONE;
     PtxReplayHdr* H = (PtxReplayHdr*)lds;
     const uint64_t base = A.log_off[log];
     const uint32_t N = (uint32_t)(A.log_off[log + 1] - base);
@@ -233,7 +245,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     uint32_t* cw = ptx_alloc<uint32_t>(bp, nws + 1);
     uint32_t* cnt = ptx_alloc<uint32_t>(bp, nws + 1);
     uint32_t* lurl;
-    uint64_t* tab;   /* applied LWW mark op: row | start slot << 16 | end of its interval << 32 */
+    uint64_t* tab;   /* applied LWW mark op: row | start slot << 16 | end of its interval << 32 (the wide build: two words, row | start slot << 32 and the end) */
     uint16_t* ccid;  /* comment op: its id */
     uint16_t* ctail; /* per comment id: the last registered op (the chain of the ops with one id starts here, latest first) */
     if (kGWin) {
@@ -241,11 +253,11 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         const uint32_t ucols = (2u * (2u * n + 2u) + 7u) & ~7u, tcols = (Kl + 1u + 7u) & ~7u;
         lurl = (uint32_t*)g;
         tab = (uint64_t*)(g + ucols);
-        ccid = g + ucols + 4u * tcols;
+        ccid = g + ucols + (kWide ? 8u : 4u) * tcols;
         ctail = ccid + ((Kc + 1u + 7u) & ~7u);
     } else {
         lurl = ptx_alloc<uint32_t>(bp, 2 * n + 2);
-        tab = ptx_alloc<uint64_t>(bp, Kl + 1);
+        tab = ptx_alloc<uint64_t>(bp, (kWide ? 2u : 1u) * (Kl + 1));
         ccid = ptx_alloc<uint16_t>(bp, Kc + 1);
         ctail = ptx_alloc<uint16_t>(bp, Kid + 1);
     }
@@ -263,11 +275,11 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     /* the next PTX_RCHUNK rows, resolved in parallel (element lookups, boundary slots) before they are replayed in order */
     PtxChunkRow* c_row = ptx_alloc<PtxChunkRow>(bp, PTX_RCHUNK);
     uint8_t* c_kind = ptx_alloc<uint8_t>(bp, PTX_RCHUNK);  /* PTX_RK_* | mark type << 4 | addMark << 6 */
-    uint16_t* ca = ptx_alloc<uint16_t>(bp, Kc + 1);       /* comment op: first covered slot */
-    uint16_t* cb = ptx_alloc<uint16_t>(bp, Kc + 1);       /*             first slot not covered (PTX_SLOT_NONE = to the end) */
+    slot_t* ca = ptx_alloc<slot_t>(bp, Kc + 1);           /* comment op: first covered slot */
+    slot_t* cb = ptx_alloc<slot_t>(bp, Kc + 1);           /*             first slot not covered (SLOT_NONE = to the end) */
     uint16_t* cprev = ptx_alloc<uint16_t>(bp, Kc + 1);    /* chain of the ops with the same id, latest first from ctail[id] */
     uint32_t* cadd = ptx_alloc<uint32_t>(bp, (Kc >> 5) + 1); /* bit per comment op: it is an addMark */
-    if (bp.overflow || n > 32766u || N > 65534u || Kid > 65535u) {
+    if (bp.overflow || (!kWide && (n > 32766u || N > 65534u)) || n > 0x03FFFFFFu || Kc > 65534u || Kid > 65535u) {
         PTX_LEADER {
             ptx_patch_log pl;
             pl.status = PTX_ERR_CAPACITY;
@@ -291,7 +303,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         z.ac = z.on[0] = z.on[1] = z.on[2] = 0;
         mb[w] = z;
     }
-    PTX_FOR(c, Kid + 1) PTX_G_ST16(&ctail[c], PTX_SLOT_NONE);
+    PTX_FOR(c, Kid + 1) PTX_G_ST16(&ctail[c], PTX_CHAIN_NONE);
     PTX_FOR(c, (Kc >> 5) + 1) cadd[c] = 0;
     PTX_LEADER {
         H->tmp = 0;
@@ -373,7 +385,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
     PTX_RESERVE(t0);
     PTX_FOR(i, chunk_n) {
         const uint32_t tt = t0 + i, a_ = action[tt];
-        uint32_t kind = PTX_RK_SKIP, va = PTX_SLOT_NONE, vb = PTX_SLOT_NONE;
+        uint32_t kind = PTX_RK_SKIP, va = SLOT_NONE, vb = SLOT_NONE;
         if (a_ == PTX_ACT_MAKELIST) {
             kind = PTX_RK_MAKELIST;
         } else if (a_ == PTX_ACT_INSERT) {
@@ -390,14 +402,24 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             const uint32_t v = refs[tt];
             va = v & 0xFFFFu;
             vb = v >> 16;
+            if (kWide) { /* a log of more than 32 766 elements carries the high halves beside (none: all ones in both); a shorter one of the same batch has none */
+                if (n > 32766u) {
+                    const uint32_t vh = A.refs_hi[base + tt];
+                    va |= vh << 16;
+                    vb |= vh & 0xFFFF0000u;
+                } else {
+                    va = va == 0xFFFFu ? SLOT_NONE : va;
+                    vb = vb == 0xFFFFu ? SLOT_NONE : vb;
+                }
+            }
             kind = PTX_RK_MARK | ((uint32_t)mark_type[tt] << 4) | (a_ == PTX_ACT_ADDMARK ? 64u : 0u);
         }
         c_kind[i] = (uint8_t)kind;
         PtxChunkRow cr;
         cr.id = op_id[tt];
         cr.pay = payload[tt];
-        cr.a = (uint16_t)va;
-        cr.b = (uint16_t)vb;
+        cr.a = (slot_t)va;
+        cr.b = (slot_t)vb;
         c_row[i] = cr;
     }
     PTX_SYNC_T();
@@ -441,7 +463,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     if (ptx_bittest(cadd, kc) && ca[kc] <= l && l < cb[kc]) {
                         bool last = true; /* no later-applied covering op of the same id: the chain of the id, latest first, down to this op */
                         const uint32_t id = PTX_G_LD16(&ccid[kc]);
-                        for (uint32_t y = PTX_G_LD16(&ctail[id]); y != kc && y != PTX_SLOT_NONE; y = cprev[y])
+                        for (uint32_t y = PTX_G_LD16(&ctail[id]); y != kc && y != PTX_CHAIN_NONE; y = cprev[y])
                             if (ca[y] <= l && l < cb[y]) {
                                 last = false;
                                 break;
@@ -481,17 +503,17 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             const bool add = (kindb & 64u) != 0u;
             const PtxChunkRow cr = c_row[ci];
             uint32_t slot_a = PTX_U32(cr.a), slot_b = PTX_U32(cr.b);
-            if (slot_a != PTX_SLOT_NONE && slot_b == slot_a) slot_b = PTX_SLOT_NONE; /* the start test fires first (A.6-3) */
-            if (slot_a == PTX_SLOT_NONE || slot_b < slot_a) {
+            if (slot_a != SLOT_NONE && slot_b == slot_a) slot_b = SLOT_NONE; /* the start test fires first (A.6-3) */
+            if (slot_a == SLOT_NONE || slot_b < slot_a) {
                 /* the end is met while the op has not started: its slot becomes a defined one (a copy of the state to
                  * its left), the op covers nothing and the walk stops (peritext.ts:240-243) */
-                if (slot_b != PTX_SLOT_NONE) PTX_DEFINE_SLOT(slot_b);
+                if (slot_b != SLOT_NONE) PTX_DEFINE_SLOT(slot_b);
                 continue;
             }
             PTX_DEFINE_SLOT(slot_a);
-            if (slot_b != PTX_SLOT_NONE) PTX_DEFINE_SLOT(slot_b); /* inherits the state BEFORE this op from inside the range */
+            if (slot_b != SLOT_NONE) PTX_DEFINE_SLOT(slot_b); /* inherits the state BEFORE this op from inside the range */
             /* the words of [slot_a, lim) */
-            const uint32_t lim = slot_b != PTX_SLOT_NONE ? slot_b : 2u * n;
+            const uint32_t lim = slot_b != SLOT_NONE ? slot_b : 2u * n;
             const uint32_t wlo = slot_a >> 5, whi = (lim + 31u) >> 5, nw = whi > wlo && lim > slot_a && !(PTX_REPLAY_EXP & 128) ? whi - wlo : 0u;
             const uint32_t my_id = PTX_U32(cr.pay);
             const uint64_t my_op = ((uint64_t)PTX_U32((uint32_t)(cr.id >> 32)) << 32) | PTX_U32((uint32_t)cr.id);
@@ -533,7 +555,7 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
         cw[wi_] = R_;                                                                                                   \
         cnt[wi_] = ptx_popc(R_);                                                                                        \
     } while (0)
-            uint32_t y0 = PTX_SLOT_NONE; /* (comments) the last registered op of this op's id */
+            uint32_t y0 = PTX_CHAIN_NONE; /* (comments) the last registered op of this op's id */
             if (ty != PTX_MARK_COMMENT) {
                 const uint32_t li = ty == PTX_MARK_STRONG ? 0u : ty == PTX_MARK_EM ? 1u : 2u;
                 /* compareOpIds (counter, then actor: the op ids keep that order): this op loses at the slots an applied op of its type with a larger id covers */
@@ -543,9 +565,10 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     PTX_G_FENCE();
                     PTX_SYNC_T();
                     PTX_FOR(e, ntab[li]) {
-                        const uint64_t ent = PTX_G_LD64(&tab[toff[li] + e]);
-                        if (op_id[(uint32_t)ent & 0xFFFFu] > my_op) {
-                            const uint32_t ya = (uint32_t)(ent >> 16) & 0xFFFFu, yl = (uint32_t)(ent >> 32);
+                        const uint64_t ent = PTX_G_LD64(&tab[(kWide ? 2u : 1u) * (toff[li] + e)]);
+                        if (op_id[kWide ? (uint32_t)ent : (uint32_t)ent & 0xFFFFu] > my_op) {
+                            const uint32_t ya = kWide ? (uint32_t)(ent >> 32) : (uint32_t)(ent >> 16) & 0xFFFFu;
+                            const uint32_t yl = kWide ? (uint32_t)PTX_G_LD64(&tab[2u * (toff[li] + e) + 1u]) : (uint32_t)(ent >> 32);
                             const uint32_t v0 = (ya >> 5) > wlo ? ya >> 5 : wlo, v1 = ((yl + 31u) >> 5) < whi ? (yl + 31u) >> 5 : whi;
                             for (uint32_t v = v0; v < v1; ++v) ptx_atomic_or(&cw[v - wlo], ptx_span_mask(ya, yl, v));
                         }
@@ -589,18 +612,25 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
                     }
                 }
                 /* the op joins the table of its type */
-                PTX_LEADER { PTX_G_ST64(&tab[toff[li] + ntab[li]], (uint64_t)t | ((uint64_t)slot_a << 16) | ((uint64_t)lim << 32)); }
+                PTX_LEADER {
+                    if (kWide) {
+                        PTX_G_ST64(&tab[2u * (toff[li] + ntab[li])], (uint64_t)t | ((uint64_t)slot_a << 32));
+                        PTX_G_ST64(&tab[2u * (toff[li] + ntab[li]) + 1u], (uint64_t)lim);
+                    } else {
+                        PTX_G_ST64(&tab[toff[li] + ntab[li]], (uint64_t)t | ((uint64_t)slot_a << 16) | ((uint64_t)lim << 32));
+                    }
+                }
                 ntab[li] += 1u;
                 if (fast) maxop[li] = my_op;
             } else {
                 /* comments: the last-applied covering op with this id decides (this op is not registered yet): per word, the id's chain latest first */
                 PTX_G_FENCE();
-                y0 = my_id < Kid ? PTX_U32(PTX_G_LD16(&ctail[my_id])) : (uint32_t)PTX_SLOT_NONE;
+                y0 = my_id < Kid ? PTX_U32(PTX_G_LD16(&ctail[my_id])) : (uint32_t)PTX_CHAIN_NONE;
                 PTX_FOR(wi, nw) {
                     const uint32_t w = wlo + wi;
                     const uint32_t m = defined[w] & PTX_RANGE_MASK(w);
                     uint32_t und = m, onm = 0;
-                    for (uint32_t y = y0; y != PTX_SLOT_NONE && und; y = cprev[y]) {
+                    for (uint32_t y = y0; y != PTX_CHAIN_NONE && und; y = cprev[y]) {
                         const uint32_t c = ptx_span_mask(ca[y], cb[y], w) & und;
                         if (ptx_bittest(cadd, y)) onm |= c;
                         und &= ~c;
@@ -640,8 +670,8 @@ PTX_DEV void ptx_replay_log(const PtxReplayArgs& A, uint32_t log, uint8_t* lds) 
             npatch = p0 + P;
             if (ty == PTX_MARK_COMMENT && my_id < Kid && ncom < Kc) {
                 PTX_LEADER {
-                    ca[ncom] = (uint16_t)slot_a;
-                    cb[ncom] = (uint16_t)slot_b;
+                    ca[ncom] = (slot_t)slot_a;
+                    cb[ncom] = (slot_t)slot_b;
                     PTX_G_ST16(&ccid[ncom], my_id);
                     if (add) cadd[ncom >> 5] |= 1u << (ncom & 31u);
                     cprev[ncom] = (uint16_t)y0;

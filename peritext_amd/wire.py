@@ -566,6 +566,7 @@ class Results:
     cintervals: np.ndarray  # CINTERVAL_DTYPE [n_rows]
     elem_rank: np.ndarray  # u32 [n_rows]
     ref_slots: np.ndarray = None  # u32 [n_rows], emulation only: the merge's resolved references of the delete / mark rows (the library keeps them on the device)
+    ref_slots_hi: np.ndarray = None  # u32 [n_rows], emulation only: the high halves of the mark rows' boundary slots (logs of more than 32 766 list elements; ptx_dresult.refs_hi)
     # ABI 7: the library's rows are COMPACT — log l's values at values[value_off[l] : value_off[l + 1]] etc.; None = the capacity layout (a log's rows at its
     # own row offset batch.log_off[l]: what the kernels write on the device, and what the test-suite's emulation returns)
     value_off: np.ndarray = None

@@ -57,9 +57,15 @@ extern "C" int ptx_emu_merge_lean(const ptx_batch* b, ptx_log_result* res, uint3
     return emu_merge_impl(b, res, values, spans, cints, nullptr, lds_bytes, reverse, admission, nullptr, 1);
 }
 
+/* (round 6) the high halves of the mark rows' boundary slots (PtxMergeArgs.out_refs_hi / ptx_dresult.refs_hi): a buffer the test sets before a merge through the
+ * HBM-staged path and leaves set for the replay / change() calls that read it; NULL = the library's behaviour for a result without the column */
+static uint32_t* ptx_emu_refs_hi = nullptr;
+extern "C" void ptx_emu_set_refs_hi(uint32_t* p) { ptx_emu_refs_hi = p; }
+
 static int emu_merge_impl(const ptx_batch* b, ptx_log_result* res, uint32_t* values, ptx_span* spans, ptx_cinterval* cints, uint32_t* rank,
                           uint32_t lds_bytes, int reverse, int admission, uint32_t* refs, int lean) {
     PtxMergeArgs A;
+    memset(&A, 0, sizeof(A));
     A.log_off = b->log_off;
     A.op_id = b->op_id;
     A.ref_a = b->ref_a;
@@ -120,6 +126,7 @@ extern "C" int ptx_emu_merge_big(const ptx_batch* b, ptx_log_result* res, uint32
     PtxMergeArgs A;
     memset(&A, 0, sizeof(A));
     A.out_refs = refs;
+    A.out_refs_hi = refs ? ptx_emu_refs_hi : nullptr;
     A.log_off = b->log_off;
     A.op_id = b->op_id;
     A.ref_a = b->ref_a;
@@ -195,6 +202,7 @@ extern "C" int ptx_emu_replay_arena(const ptx_batch* b, const ptx_log_result* re
     A.res = res;
     A.elem_rank = rank;
     A.refs = refs;
+    A.refs_hi = ptx_emu_refs_hi;
     A.patch_off = patch_off;
     A.patches = patches;
     A.plogs = plogs;
@@ -212,12 +220,20 @@ extern "C" int ptx_emu_replay_arena(const ptx_batch* b, const ptx_log_result* re
         A.log_hdr = hdr;
     }
     /* bit 8 of `reverse`: the per-slot link urls and the op tables in "global" memory, as the library does for working sets above 5.5 KB */
-    const bool gwin = (reverse & 256) != 0;
+    bool gwin = (reverse & 256) != 0;
     reverse &= 255;
+    /* the library's rule: a batch with a log beyond 16-bit ranks / slots / rows takes the wide build (its tables in global memory) — when the slots' high halves are there */
+    bool wide = false, wide_slots = false;
+    for (uint32_t l = 0; l < b->n_logs; ++l) {
+        wide = wide || ptx_replay_wants_wide(b->log_off[l + 1] - b->log_off[l], A.log_hdr[l]);
+        wide_slots = wide_slots || A.log_hdr[l].n_ins > 32766u;
+    }
+    if (wide && wide_slots && !ptx_emu_refs_hi) wide = false;
+    gwin = gwin || wide;
     const uint64_t n_ops = b->n_logs ? b->log_off[b->n_logs] : 0;
     (void)n_ops;
     uint64_t* win_off = (uint64_t*)calloc((size_t)b->n_logs + 1, 8);
-    for (uint32_t l = 0; l < b->n_logs; ++l) win_off[l + 1] = win_off[l] + ptx_replay_win_units_hdr(A.log_hdr[l]);
+    for (uint32_t l = 0; l < b->n_logs; ++l) win_off[l + 1] = win_off[l] + ptx_replay_win_units_hdr(A.log_hdr[l], wide);
     A.win_off = win_off;
     A.win_scratch = gwin ? (uint16_t*)malloc(2 * win_off[b->n_logs] + 16) : nullptr;
     if (gwin) memset(A.win_scratch, 0xA5, 2 * win_off[b->n_logs] + 16);
@@ -226,7 +242,8 @@ extern "C" int ptx_emu_replay_arena(const ptx_batch* b, const ptx_log_result* re
     ptx_emu_reverse = reverse;
     for (uint32_t l = 0; l < b->n_logs; ++l) {
         ptx_emu_lds_fill(lds, lds_bytes);
-        if (gwin) ptx_replay_log<0, true>(A, l, lds);
+        if (wide) ptx_replay_log<0, true, true>(A, l, lds);
+        else if (gwin) ptx_replay_log<0, true>(A, l, lds);
         else ptx_replay_log<0, false>(A, l, lds);
     }
     ptx_emu_lds_fill(lds, 0);
@@ -245,6 +262,7 @@ extern "C" int ptx_emu_replay(const ptx_batch* b, const ptx_log_result* res, con
     return ptx_emu_replay_from(b, res, rank, refs, patch_off, patches, plogs, lds_bytes, reverse, nullptr);
 }
 extern "C" uint64_t ptx_emu_replay_lds_need(uint64_t n, uint64_t K, uint64_t Kc, uint64_t ks, uint64_t Kid) { return ptx_replay_lds_need(n, K, Kc, ks, Kid); }
+extern "C" uint64_t ptx_emu_replay_lds_need_wide(uint64_t n, uint64_t K, uint64_t Kc, uint64_t Kid) { return ptx_replay_lds_need(n, K, Kc, 0, Kid, true, true); }
 
 /* on-device change() / PTXGEN (gen_core.h): generate n_docs documents into caller-allocated capacity-layout columns
  * (rows_per_log rows per log, R logs per doc); the envelope is left at capacity stride, n_changes says how much is used */
@@ -288,6 +306,7 @@ extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, con
     A.res = res;
     A.elem_rank = rank;
     A.refs = refs;
+    A.refs_hi = ptx_emu_refs_hi;
     A.chg_off = b->chg_off;
     A.chg_hdr = b->chg_hdr;
     A.max_actors = in->max_actors;
@@ -324,6 +343,19 @@ extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, con
         ptx_census_rows(b->op_id + b0, b->action + b0, b->mark_type + b0, b->payload + b0, b1 - b0, &hdr[l]);
     }
     A.log_hdr = hdr;
+    /* the library's rule (ptx_change): the element list of a log that does not fit the LDS lives in a slice of global scratch */
+    uint64_t* list_off = (uint64_t*)calloc((size_t)b->n_logs + 1, 8);
+    for (uint32_t l = 0; l < b->n_logs; ++l) {
+        list_off[l + 1] = list_off[l];
+        uint64_t grow = 0;
+        for (uint64_t q = in->op_off[in->chg_off[l]]; q < in->op_off[in->chg_off[l + 1]]; ++q) grow += in->action[q] == PTX_IN_INSERT ? in->count[q] : 0u;
+        const uint64_t n_l = b->log_off[l + 1] > b->log_off[l] ? hdr[l].n_ins : 0;
+        if (in->chg_off[l + 1] > in->chg_off[l] && ptx_change_lds_need(n_l, grow, 0, in->max_actors) > lds_bytes) list_off[l + 1] += ptx_change_list_words(n_l, grow);
+    }
+    uint32_t* list = list_off[b->n_logs] ? (uint32_t*)aligned_alloc(64, (4 * list_off[b->n_logs] + 63) & ~63ull) : nullptr;
+    if (list) memset(list, 0xA5, 4 * list_off[b->n_logs]);
+    A.list_scratch = list;
+    A.list_off = list_off;
     uint8_t* lds = (uint8_t*)aligned_alloc(64, (size_t)lds_bytes + 64);
     if (!lds) return 1;
     ptx_emu_reverse = reverse;
@@ -334,6 +366,8 @@ extern "C" int ptx_emu_change(const ptx_batch* b, const ptx_log_result* res, con
     ptx_emu_lds_fill(lds, 0);
     free(lds);
     free(hdr);
+    free(list);
+    free(list_off);
     return 0;
 }
 

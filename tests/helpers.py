@@ -205,8 +205,16 @@ def synthetic_marks_log(n_chars, n_marks, seed, n_deletes=0, max_span=40):
     return changes
 
 
-def emu_merge_big(b, reverse=0, lib_path=EMU_LIB, admission=False, slack=0):
-    """The HBM-staged path for logs beyond one CU's LDS (biglog_core.h) through the host emulation: every log of the batch, whatever its size."""
+def _emu_set_refs_hi(lib, arr):
+    """(round 6) the emulation's stand-in for ptx_dresult.refs_hi: the buffer the next merge writes / the next replay or change() reads (None: a result without it)"""
+    lib.ptx_emu_set_refs_hi.argtypes = [C.c_void_p]
+    lib.ptx_emu_set_refs_hi.restype = None
+    lib.ptx_emu_set_refs_hi(None if arr is None else arr.ctypes.data)
+
+
+def emu_merge_big(b, reverse=0, lib_path=EMU_LIB, admission=False, slack=0, refs_hi=True):
+    """The HBM-staged path for logs beyond one CU's LDS (biglog_core.h) through the host emulation: every log of the batch, whatever its size.
+    refs_hi: the result carries the high halves of the boundary slots (what ptx_result_alloc provides when the census finds a log of more than 32 766 elements)."""
     n = max(b.n_ops, 1)
     res = wire.Results(
         logs=np.zeros(b.n_logs, dtype=abi.LOG_RESULT_DTYPE),
@@ -215,12 +223,15 @@ def emu_merge_big(b, reverse=0, lib_path=EMU_LIB, admission=False, slack=0):
         cintervals=np.zeros(n, dtype=abi.CINTERVAL_DTYPE),
         elem_rank=np.zeros(n, dtype=np.uint32),
         ref_slots=np.full(n, 0xFFFFFFFF, dtype=np.uint32),
+        ref_slots_hi=np.full(n, 0xFFFFFFFF, dtype=np.uint32) if refs_hi else None,
     )
     s = batch_struct(b)
+    _emu_set_refs_hi(_emu(lib_path), res.ref_slots_hi)
     f = _emu(lib_path).ptx_emu_merge_big
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p]
     rc = f(C.byref(s), res.logs.ctypes.data, res.values.ctypes.data, res.spans.ctypes.data, res.cintervals.ctypes.data, res.elem_rank.ctypes.data, reverse,
            1 if admission else 0, slack, res.ref_slots.ctypes.data)
+    _emu_set_refs_hi(_emu(lib_path), None)
     assert rc == 0
     return res
 
@@ -248,6 +259,7 @@ def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=No
     rows = np.zeros(max(int(off[-1]), 1), dtype=abi.PATCH_DTYPE)
     s = batch_struct(b)
     lib = _emu(lib_path)
+    _emu_set_refs_hi(lib, getattr(res, "ref_slots_hi", None))
     launches = 0
     while True:
         rc = lib.ptx_emu_replay_from(C.byref(s), res.logs.ctypes.data, res.elem_rank.ctypes.data, res.ref_slots.ctypes.data, off.ctypes.data, rows.ctypes.data, logs.ctypes.data, lds_bytes, reverse,
@@ -260,6 +272,7 @@ def emu_replay(b, res, lds_bytes=160 * 1024, reverse=0, lib_path=EMU_LIB, cap=No
         caps = np.maximum(produced, 1)  # what ptx_replay_patches does: once more with exact sizes
         off[1:] = np.cumsum(caps)
         rows = np.zeros(max(int(off[-1]), 1), dtype=abi.PATCH_DTYPE)
+    _emu_set_refs_hi(lib, None)
     return wire.Patches(patch_off=off, logs=logs, patches=rows, launches=launches)
 
 
@@ -345,10 +358,12 @@ def emu_change(batch, res, ops, lds_bytes=LDS_BYTES, reverse=0, lib_path=EMU_LIB
     status, rows_made, chgs_made = (np.zeros(max(n_logs, 1), np.uint32) for _ in range(3))
     lib = C.CDLL(lib_path)
     lib.ptx_emu_change.restype = C.c_int
+    _emu_set_refs_hi(lib, getattr(res, "ref_slots_hi", None))
     s, si = batch_struct(batch), input_ops_struct(ops)
     vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
     rc = lib.ptx_emu_change(C.byref(s), vp(res.logs), vp(res.elem_rank), vp(res.ref_slots), C.byref(si), vp(out_off), vp(cols["op_id"]), vp(cols["ref_a"]), vp(cols["ref_b"]), vp(cols["payload"]),
                             vp(cols["action"]), vp(cols["mark_type"]), vp(cols["side_a"]), vp(cols["side_b"]), vp(env["chg_hdr"]), vp(env["chg_env"]), vp(env["chg_env_hi"]), vp(env["any_wide"]), vp(status), vp(rows_made), vp(chgs_made), C.c_uint32(lds_bytes), C.c_int(reverse))
+    _emu_set_refs_hi(lib, None)
     assert rc == 0
     return made_batch(batch, ops, cols, env, rows_made, chgs_made, out_off), status[:n_logs]
 

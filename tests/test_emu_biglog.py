@@ -312,6 +312,51 @@ def test_cursors_on_a_document_beyond_16_bit_row_indices():
     assert [int(x) for x in st] == [abi.ERR_INDEX_OOB, abi.ERR_ELEM_NOT_FOUND]
 
 
+@pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
+def test_patch_stream_and_change_beyond_16_bit_ranks_slots_and_rows():
+    """VERDICT r5 missing #2 / next #6: `applyChange`'s patches (reference/src/micromerge.ts:499-514, :661-671, :696-703; peritext.ts:154-220, :251-281) and
+    `change()` (:308-441, :762-805; peritext.ts:458-501) have no size limit; round 5's replay and change kernels stopped at 32 766 list elements / 65 534 rows
+    (16-bit ranks and boundary slots).  Round 6: the HBM-staged merge hands the slots' high halves over (out_refs_hi), the replay has a wide build
+    (ptx_replay_log<.., kWide>) and change()'s list words hold 29-bit rows, its list in global scratch where the LDS cannot hold it.  Two documents against the
+    oracle: a 36 000-character text with 1 500 deletes and 2 500 mark ops of all four types (slots beyond 16 bits on every path), and a 70 000-op insert / delete
+    essay (more than 65 534 rows AND 32 766 elements; its 50 000-element list does not fit one CU's LDS in change())."""
+    marks = H.synthetic_marks_log(36000, 2500, 19, n_deletes=1500)
+    essay = H.oracle_gen("config2", 1, 91, 70000, 1, mix=(80, 20, 0, 0))["docs"][0]["logs"][0]
+    docs = [[marks], [essay]]
+    batch = wire.encode_docs(docs, extra_comments=[[], ["c-wide"]])  # (the comment id a later change() introduces takes part in the document's id ranks)
+    assert int(batch.log_hdr["n_ins"][0]) > 32766 and int(batch.log_off[2] - batch.log_off[1]) > 65534
+    res = H.emu_merge_big(batch, admission=True)
+    assert (res.logs["status"] == 0).all()
+    exp = H.oracle_apply(docs, patches=True, timeout=2400)
+    pat = H.emu_replay(batch, res)
+    assert (pat.logs["status"] == 0).all() and [int(x) for x in pat.logs["n_patches"]] == [len(exp[0][0]["patches"]), len(exp[1][0]["patches"])]
+    H.check_patch_streams(batch, pat, exp)
+    pat2 = H.emu_replay(batch, res, reverse=1)  # (the other lane order)
+    assert pat2.patches[: int(pat2.patch_off[-1])].tobytes() == pat.patches[: int(pat.patch_off[-1])].tobytes()
+    # change(): marks whose boundaries lie beyond slot 65 535, inserts after tombstones, deletes — Change for Change
+    V0, V1 = int(res.logs["n_visible"][0]), int(res.logs["n_visible"][1])
+    calls = [[[{"path": ["text"], "action": "addMark", "markType": "link", "attrs": {"url": "https://wide.example"}, "startIndex": V0 - 900, "endIndex": V0 - 3},
+               {"path": ["text"], "action": "insert", "index": V0 - 100, "values": ["w", "i", "d", "e"]}, {"path": ["text"], "action": "delete", "index": V0 - 50, "count": 4}],
+              [{"path": ["text"], "action": "addMark", "markType": "strong", "startIndex": 7, "endIndex": V0 - 1}, {"path": ["text"], "action": "insert", "index": V0, "values": ["!"]}]],
+             [[{"path": ["text"], "action": "insert", "index": V1 - 10, "values": ["x", "y"]}, {"path": ["text"], "action": "delete", "index": V1 // 2, "count": 3},
+               {"path": ["text"], "action": "addMark", "markType": "comment", "attrs": {"id": "c-wide"}, "startIndex": V1 - 2000, "endIndex": V1 - 1}]]]
+    actors = [marks[0]["actor"], essay[0]["actor"]]
+    want = H.oracle_change(docs, calls, actors)
+    made, status = H.emu_change(batch, res, wire.encode_input_ops(batch, calls, actors), lds_bytes=160 * 1024)
+    assert not status.any()
+    got = []
+    for log, logs in enumerate(docs):
+        text_obj = [op["opId"] for c in logs[0] for op in c["ops"] if op["action"] == "makeList"][0]
+        got += wire.decode_changes(made, log, text_obj=text_obj)
+    assert got == want
+    # a result WITHOUT the high halves (allocated for another batch): such a log reports capacity, as before the round — never a wrong stream
+    res.ref_slots_hi = None
+    pat3 = H.emu_replay(batch, res)
+    assert [int(x) for x in pat3.logs["status"]] == [abi.ERR_CAPACITY, abi.ERR_CAPACITY]
+    _, status = H.emu_change(batch, res, wire.encode_input_ops(batch, calls, actors), lds_bytes=160 * 1024)
+    assert int(status[0]) == abi.ERR_CAPACITY
+
+
 def _one_comment_id_log(n_chars, n_ops, seed, ids_of_ops=("the-one",), weights=None):
     """A replica log whose n_ops comment ops carry few ids (the HBM-staged path sweeps an id's ops in one lane, quadratic in their number, or — beyond 1 024 — as a team)."""
     import random
