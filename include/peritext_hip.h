@@ -532,7 +532,9 @@ void ptx_host_batch_free(ptx_host_batch* hb);
 /* Largest number of ops a log may have and still be merged ENTIRELY ON CHIP (the LDS kernel: one CU's 160 KB, 16-bit indices).  A longer log — the
  * reference has no bound, micromerge.ts:614-672 — is merged in the same ptx_merge call by the HBM-staged kernel (working set in device scratch the
  * library sizes per log, 32-bit indices; an order of magnitude slower per op), up to 2^26 rows and an id keyspace (max counter + 1) x (actors) of 2^30;
- * PTX_ERR_CAPACITY beyond that.  ptx_replay_patches / ptx_change / ptx_resolve_cursors still work on chip only: such a log reports PTX_ERR_CAPACITY there. */
+ * PTX_ERR_CAPACITY beyond that.  The editor-facing entry points follow (rounds 5-6): ptx_resolve_cursors on a log of any length; ptx_change too (its element list in
+ * global scratch where one CU's LDS cannot hold it); ptx_replay_patches while the replay's bitmaps fit one CU's LDS (about 70 000 list elements, any number of
+ * rows: a wide build with 32-bit ranks and boundary slots) — PTX_ERR_CAPACITY for a log beyond that. */
 uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx);
 /* Name of the kernel the merge launches (to find it in a rocprofv3 trace): the family's ... */
 const char* ptx_kernel_name(void);

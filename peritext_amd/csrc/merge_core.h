@@ -1016,7 +1016,23 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
     /* ---- the loads of P1's first step (declared here: with the usual three-actor admission they go out as soon as its walk has let go of its registers, and
      *      are in flight during the validation of the walk and the clearing of the bitmaps: most of one trip to HBM, of the handful a 256-op log is) ---- */
     bool p1_loaded = false;
-    const uint32_t p1_groups = (N + PTX_U1 - 1u) / PTX_U1, p1_full = N / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
+    /* Round 6 (last session): a log of k full steps of the row pass PLUS ONE ROW whose first row is the document's makeList — the 257 rows of a 256-op log
+     * (one wave: 256 rows per step), the 1 025 of a 1 024-op one (two waves: 512) — would spend a whole step, i.e. a trip to HBM and the pass's few hundred
+     * vector instructions per wave, on its last row.  A makeList is listed nowhere: all the row pass does with it is its bit in the duplicate-id bitmap and its id
+     * in the bounds check.  The leader does that by hand and the pass runs over the rows FROM THE SECOND ON (every load one row further: the columns are read
+     * with 8- / 1-byte aligned loads anyway, a log's first row stands wherever the batch puts it).  Not in the three-wave lean build (4 097 rows are five steps
+     * and a third either way). */
+    constexpr bool kHeadRow = kThreads != 192u;
+    uint32_t p1_head = 0u;
+    if (kHeadRow && N > 1u && ((N - 1u) % PTX_U1) == 0u) {
+        const uint32_t g1_ = (N - 1u) / PTX_U1;
+        if (PTX_WHOLE_STEPS(g1_) && PTX_U32(PTX_CONST_LOAD(&action[0])) == PTX_ACT_MAKELIST) p1_head = 1u;
+    }
+    const uint32_t p1_N = N - p1_head;
+    const uint64_t* const p1_op_id = op_id + p1_head;
+    const uint8_t* const p1_action = action + p1_head;
+    const uint8_t* const p1_mark_type = mark_type + p1_head;
+    const uint32_t p1_groups = (p1_N + PTX_U1 - 1u) / PTX_U1, p1_full = p1_N / PTX_U1, p1_steps = PTX_STEPS(p1_groups);
     static_assert(PTX_U1 == 3 || PTX_U1 == 4, "the class bytes of a thread's rows come from ONE dword (with three rows its fourth byte belongs to the next thread's first row)");
     uint64_t id[PTX_U1], id_n[PTX_U1];
     uint32_t a4, mt4, a4_n, mt4_n; /* action / mark type of the thread's PTX_U1 rows, one byte each */
@@ -1027,15 +1043,15 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
 {                                                                       \
     const uint32_t r0_ = (g_) * PTX_U1;                                 \
     if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) { /* one address, 16 + 8 bytes */ \
-        PTX_P1_IDS(id_, op_id + r0_)                                    \
+        PTX_P1_IDS(id_, p1_op_id + r0_)                                 \
     } else {                                                            \
         _Pragma("unroll") for (int u = 0; u < PTX_U1; ++u) {            \
             const uint32_t r_ = r0_ + (uint32_t)u;                      \
-            id_[u] = op_id[r_ < N ? r_ : N - 1u];                       \
+            id_[u] = p1_op_id[r_ < p1_N ? r_ : p1_N - 1u];              \
         }                                                               \
     }                                                                   \
-    PTX_P1_BYTES(action, r0_, a_)                                       \
-    PTX_P1_BYTES(mark_type, r0_, mt_)                                   \
+    PTX_P1_BYTES(p1_action, r0_, a_, p1_N)                              \
+    PTX_P1_BYTES(p1_mark_type, r0_, mt_, p1_N)                          \
 }
     /* ---- P0: causal admission (micromerge.ts:499-511), when the batch carries the Change envelope ----
      * Sequential rule: change c of actor a is admitted iff seq == clock[a] + 1 and clock[b] >= deps[b] for all b,
@@ -1591,6 +1607,16 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             H->n_applied = n + D + K;
         }
         PTX_SYNC_LDS();
+        if (kHeadRow && p1_head) { /* the makeList the pass leaves out: its id's bit in the duplicate bitmap, its id in the bounds check (the leader's registers) */
+            PTX_LEADER {
+                const uint64_t id0 = op_id[0];
+                const uint32_t ctr = (uint32_t)(id0 >> 32), act = (uint32_t)id0;
+                ctr_hi = ctr - 1u;
+                act_hi = act;
+                const uint32_t key = ptx_min(ptx_mad24_su(ctr, ix.na1, act), keyspace - 1u);
+                ptx_atomic_or64((unsigned long long*)&ix.ib[key >> 5], (unsigned long long)(1u << (key & 31u)) << 32);
+            }
+        }
         /* Branch-free row loop, PTX_U1 consecutive rows per thread and step.  What the header promised is NOT re-checked per
          * row: a list that overflows (more rows of a class than the header says) overwrites scratch of this log only — every
          * store is kept inside the log's window — and the census check after the pass rejects the log; a row with a malformed
@@ -1598,7 +1624,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         /* the work on one thread's rows; kMasked: only the first `nv` of them exist */
         auto p1_rows = [&](auto masked, uint32_t g, uint32_t nv, const uint64_t (&id)[PTX_U1], uint32_t a4, uint32_t mt4) {
             constexpr bool kMasked = decltype(masked)::value;
-            const uint32_t r0 = g * PTX_U1;
+            const uint32_t r0 = g * PTX_U1 + (kHeadRow ? p1_head : 0u); /* the thread's first row, as the log numbers it */
             constexpr uint32_t kAllRows = PTX_U1 == 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;
             const uint32_t live = kMasked ? (nv >= 4u ? 0xFFFFFFFFu : (1u << (8u * nv)) - 1u) : kAllRows; /* bytes of a4 / mt4 that are rows of this thread */
             /* class of the rows, four bytes at a time (byte permutes as table look-ups):
@@ -1649,7 +1675,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         if (PTX_WAVE_FIRST(g_) >= p1_groups) break;                                                                           \
         PTX_P1_LOAD(PTX_G_OF((st_) + 1u, p1_steps), idn_, an_, mtn_) /* the next step's rows are in flight while this one is processed */ \
         if (PTX_WAVE_FIRST(g_) + PTX_WS <= p1_full) p1_rows(std::false_type(), g_, PTX_U1, id_, a_, mt_);                     \
-        else p1_rows(std::true_type(), g_, g_ * PTX_U1 < N ? (N - g_ * PTX_U1 < PTX_U1 ? N - g_ * PTX_U1 : PTX_U1) : 0u, id_, a_, mt_); \
+        else p1_rows(std::true_type(), g_, g_ * PTX_U1 < p1_N ? (p1_N - g_ * PTX_U1 < PTX_U1 ? p1_N - g_ * PTX_U1 : PTX_U1) : 0u, id_, a_, mt_); \
     }
 #pragma nounroll
         for (uint32_t st = 0; st < p1_steps; st += 2u) {

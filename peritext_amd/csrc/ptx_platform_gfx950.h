@@ -279,6 +279,7 @@ PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint3
 #define PTX_DIV_T(x) (kThreads ? (uint32_t)(x) / (kThreads ? kThreads : 1u) : (uint32_t)__umulhi((uint32_t)(x), A.div_magic))
 #define PTX_STEPS(groups) PTX_DIV_T((groups) + PTX_BLOCKDIM - 1u)
 #define PTX_G_OF(st, steps) (threadIdx.x + (st) * PTX_BLOCKDIM)
+#define PTX_WHOLE_STEPS(groups) (PTX_DIV_T(groups) * PTX_BLOCKDIM == (uint32_t)(groups)) /* the groups fill whole steps of the workgroup: no thread idles in the last one */
 
 /* the same for loops over list items, PTX_U items per thread and step, lanes on consecutive items:
  * step st, slot u handles item PTX_J_OF(st, u) (past the end = no work); PTX_JX maps it for the emulation's
@@ -555,7 +556,7 @@ typedef uint32_t ptx_u32_a1 __attribute__((aligned(1)));
             dst_[2] = PTX_STREAM_LOAD(p_ + 2);                                         \
         }                                                                              \
     }
-#define PTX_P1_BYTES(col_, r0_, dst_) dst_ = PTX_STREAM_LOAD((const ptx_u32_a1*)(col_ + ((r0_) < N ? (r0_) : N - 1u)));
+#define PTX_P1_BYTES(col_, r0_, dst_, n_) dst_ = PTX_STREAM_LOAD((const ptx_u32_a1*)(col_ + ((r0_) < (n_) ? (r0_) : (n_) - 1u)));
 
 /* ---- gen_core.h / change_core.h: ONE wave per workgroup ---- */
 /* 64-wide ballot over lanes: `expr` may use `lane_` */

@@ -130,6 +130,7 @@ PTX_DEV void ptx_wave_slots4(uint32_t* cursor, uint32_t dump, uint32_t c4, uint3
  * issued before step st is processed (the caller keeps two register sets).  Every thread runs every step; a
  * group index past the end means "no work" (its loads are clamped to valid addresses, its effects masked). */
 #define PTX_STEPS(groups) (groups)
+#define PTX_WHOLE_STEPS(groups) true /* (one group per step here) */
 #define PTX_G_OF(st, steps) ((st) < (steps) ? ptx_emu_ix((st), (steps)) : (steps) + ((st) - (steps)))
 
 /* the same for loops over list items, PTX_U items per thread and step, lanes on consecutive items:
@@ -247,9 +248,9 @@ extern unsigned long long ptx_emu_exact_walks;
 
 /* the action / mark_type bytes of a thread's PTX_U1 consecutive rows from r0_ on, one byte each in dst_ (uses N) */
 #define PTX_P1_IDS(dst_, ptr_) for (uint32_t u_ = 0; u_ < PTX_U1; ++u_) dst_[u_] = (ptr_)[u_];
-#define PTX_P1_BYTES(col_, r0_, dst_)                                    \
+#define PTX_P1_BYTES(col_, r0_, dst_, n_)                                \
     dst_ = 0;                                                            \
-    for (uint32_t u_ = 0; u_ < PTX_U1; ++u_) dst_ |= (uint32_t)col_[(r0_) + u_ < N ? (r0_) + u_ : N - 1u] << (8u * u_);
+    for (uint32_t u_ = 0; u_ < PTX_U1; ++u_) dst_ |= (uint32_t)col_[(r0_) + u_ < (n_) ? (r0_) + u_ : (n_) - 1u] << (8u * u_);
 
 /* ---- gen_core.h / change_core.h: ONE wave per workgroup; the ballots are built lane by lane ---- */
 #define PTX_BALLOT64(mask_, lane_, expr)                 \
