@@ -18,6 +18,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <set>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -539,7 +543,98 @@ struct ptx_ctx {
     uint8_t* stage_d = nullptr;
     uint8_t* stage_h = nullptr;
     size_t stage_d_cap = 0, stage_h_cap = 0;
+    /* freed device blocks of up to PTX_POOL_MAX_BLOCK bytes, by size class (ptx_dev_malloc / ptx_dev_free below) */
+    std::map<size_t, std::vector<void*>> pool_free;
+    size_t pool_cached = 0;
 };
+
+/* ---- small device blocks are KEPT by the context that freed them (round 6, last session) ----
+ * An editor session's change() / read is a dozen kernels over a few kilobytes — and was ~80 hipMalloc / hipFree pairs (result buffers, the InputOperation columns, the
+ * made batch, the appended batch, offsets, statuses), each a driver call of several microseconds, hipFree a device-wide wait on top: most of the 0.6 ms an edit took.
+ * Blocks of up to PTX_POOL_MAX_BLOCK bytes are now handed out in size classes and, when freed, go to a free list of the context whose call frees them (up to
+ * PTX_POOL_CAP bytes; the rest, and every larger block — a batch's columns — is hipMalloc / hipFree as before).  A block is only ever reused by calls on the same
+ * context, i.e. behind everything that context has put on its stream (the side stream of a split launch is joined before launch_merge returns); ptx_destroy
+ * releases them.  Which context a call belongs to: the one its entry point named (ptx_enter), per thread. */
+#define PTX_POOL_MAX_BLOCK (4ull << 20)
+#define PTX_POOL_CAP (256ull << 20)
+struct PtxPoolEntry {
+    size_t cls;
+    ptx_ctx* owner;
+};
+static std::mutex g_pool_mu;
+static std::unordered_map<void*, PtxPoolEntry> g_pool_live; /* pooled blocks in use */
+static std::set<ptx_ctx*> g_pool_ctxs;                      /* contexts alive */
+static thread_local ptx_ctx* g_tl_ctx = nullptr;
+static size_t ptx_pool_class(size_t bytes) {
+    if (bytes <= 4096) return (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    size_t c = 8192;
+    while (c < bytes) c <<= 1;
+    return c;
+}
+static hipError_t ptx_dev_malloc(void** p, size_t bytes) {
+    if (bytes <= PTX_POOL_MAX_BLOCK && g_tl_ctx) {
+        const size_t cls = ptx_pool_class(bytes);
+        ptx_ctx* c = nullptr;
+        {
+            std::lock_guard<std::mutex> g(g_pool_mu);
+            if (g_pool_ctxs.count(g_tl_ctx)) {
+                c = g_tl_ctx;
+                auto it = c->pool_free.find(cls);
+                if (it != c->pool_free.end() && !it->second.empty()) {
+                    *p = it->second.back();
+                    it->second.pop_back();
+                    c->pool_cached -= cls;
+                    g_pool_live[*p] = PtxPoolEntry{cls, c};
+                    return hipSuccess;
+                }
+            }
+        }
+        if (c) {
+            hipError_t e = hipMalloc(p, cls);
+            if (e == hipErrorOutOfMemory) { /* the device is full: what this context keeps goes back first */
+                (void)hipGetLastError();
+                std::vector<void*> drop;
+                {
+                    std::lock_guard<std::mutex> g(g_pool_mu);
+                    for (auto& kv : c->pool_free) drop.insert(drop.end(), kv.second.begin(), kv.second.end());
+                    c->pool_free.clear();
+                    c->pool_cached = 0;
+                }
+                for (void* q : drop) (void)hipFree(q);
+                e = hipMalloc(p, cls);
+            }
+            if (e == hipSuccess) {
+                std::lock_guard<std::mutex> g(g_pool_mu);
+                g_pool_live[*p] = PtxPoolEntry{cls, c};
+            }
+            return e;
+        }
+    }
+    return hipMalloc(p, bytes);
+}
+static hipError_t ptx_dev_free(void* p) {
+    if (!p) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        auto it = g_pool_live.find(p);
+        if (it != g_pool_live.end()) {
+            const PtxPoolEntry en = it->second;
+            g_pool_live.erase(it);
+            ptx_ctx* c = g_tl_ctx;
+            /* kept only by the context that handed it out and in whose call it is freed: its next user then runs behind this context's stream */
+            if (c && c == en.owner && g_pool_ctxs.count(c) && c->pool_cached + en.cls <= PTX_POOL_CAP) {
+                c->pool_free[en.cls].push_back(p);
+                c->pool_cached += en.cls;
+                return hipSuccess;
+            }
+        }
+    }
+    return hipFree(p);
+}
+static hipError_t ptx_enter(ptx_ctx* ctx) { /* every entry point that names a context: its device, and the context whose blocks this thread's calls take and return */
+    g_tl_ctx = ctx;
+    return hipSetDevice(ctx->device);
+}
 
 struct ptx_dbatch {
     uint32_t n_logs = 0;
@@ -633,9 +728,9 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
     std::vector<uint32_t> need;
     std::vector<uint64_t> big_need;
     if (b->n_logs) {
-        PTX_HIP(ctx, hipMalloc((void**)&shape, 16));
-        hipError_t e = hipMalloc((void**)&d_need, (size_t)b->n_logs * 4);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_big, (size_t)b->n_logs * 8);
+        PTX_HIP(ctx, ptx_dev_malloc((void**)&shape, 16));
+        hipError_t e = ptx_dev_malloc((void**)&d_need, (size_t)b->n_logs * 4);
+        if (e == hipSuccess) e = ptx_dev_malloc((void**)&d_big, (size_t)b->n_logs * 8);
         if (e == hipSuccess) e = hipMemsetAsync(shape, 0, 16, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(ptx_census_kernel, dim3(b->n_logs), dim3(256), 0, ctx->stream, b->log_off, b->op_id, b->action, b->mark_type, b->payload, b->log_hdr,
@@ -648,18 +743,18 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
         if (e == hipSuccess) e = hipMemcpyAsync(need.data(), d_need, (size_t)b->n_logs * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(big_need.data(), d_big, (size_t)b->n_logs * 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(shape);
-        (void)hipFree(d_need);
-        (void)hipFree(d_big);
+        (void)ptx_dev_free(shape);
+        (void)ptx_dev_free(d_need);
+        (void)ptx_dev_free(d_big);
         if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("census: ") + hipGetErrorString(e));
         if (h[2] & 1u) return fail(ctx, PTX_ERR_INVALID_ARG, "log_off must run from 0 to n_ops without decreasing");
     }
     shape_launch(ctx, b, h[0], h[1]);
     b->small_keys = h[3] <= 65536u;
     b->wide_slots = (h[2] & 2u) != 0u;
-    (void)hipFree(b->log_index);
-    (void)hipFree(b->big_off);
-    (void)hipFree(b->big_scratch);
+    (void)ptx_dev_free(b->log_index);
+    (void)ptx_dev_free(b->big_off);
+    (void)ptx_dev_free(b->big_scratch);
     b->log_index = nullptr;
     b->big_off = nullptr;
     b->big_scratch = nullptr;
@@ -671,7 +766,7 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
      * (1) and (2) together; a log it does not hold is that log's PTX_ERR_CAPACITY, as documented there. */
     std::vector<uint32_t> big, small;
     for (uint32_t l = 0; l < b->n_logs; ++l) (need[l] > ctx->max_lds && !ctx->force_lds ? big : small).push_back(l);
-    (void)hipFree(b->grid_bars);
+    (void)ptx_dev_free(b->grid_bars);
     b->grid_bars = nullptr;
     b->n_big_grid = 0;
     b->big_grid_wgs.clear();
@@ -690,7 +785,7 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
             }
         b->n_big_grid = (uint32_t)b->big_grid_wgs.size();
         if (b->n_big_grid) {
-            e = hipMalloc((void**)&b->grid_bars, (size_t)b->n_big_grid * 8);
+            e = ptx_dev_malloc((void**)&b->grid_bars, (size_t)b->n_big_grid * 8);
             if (e != hipSuccess) return fail(ctx, PTX_ERR_OOM, "no device memory for the grid barriers");
         }
     }
@@ -716,7 +811,7 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
     if (split || !big.empty()) {
         std::vector<uint32_t> idx(small);
         idx.insert(idx.end(), big.begin(), big.end());
-        hipError_t e = hipMalloc((void**)&b->log_index, std::max<size_t>(idx.size(), 1) * 4);
+        hipError_t e = ptx_dev_malloc((void**)&b->log_index, std::max<size_t>(idx.size(), 1) * 4);
         if (e == hipSuccess && !idx.empty()) e = hipMemcpyAsync(b->log_index, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream);
         b->n_main = split ? fit : (uint32_t)small.size();
         b->n_big = (uint32_t)big.size();
@@ -724,9 +819,9 @@ static ptx_status census_and_shape(ptx_ctx* ctx, ptx_dbatch* b, bool have_hdr) {
         if (e == hipSuccess && !big.empty()) {
             std::vector<uint64_t> off(big.size() + 1, 0);
             for (size_t k = 0; k < big.size(); ++k) off[k + 1] = off[k] + ((big_need[big[k]] + 255) & ~255ull);
-            e = hipMalloc((void**)&b->big_off, off.size() * 8);
+            e = ptx_dev_malloc((void**)&b->big_off, off.size() * 8);
             if (e == hipSuccess) e = hipMemcpyAsync(b->big_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMalloc((void**)&b->big_scratch, std::max<uint64_t>(off.back(), 256));
+            if (e == hipSuccess) e = ptx_dev_malloc((void**)&b->big_scratch, std::max<uint64_t>(off.back(), 256));
             if (e == hipErrorOutOfMemory) {
                 (void)hipStreamSynchronize(ctx->stream);
                 return fail(ctx, PTX_ERR_OOM, "no device memory for the working set of the logs beyond one CU's LDS");
@@ -776,7 +871,7 @@ static ptx_status check_host_offsets(ptx_ctx* ctx, const ptx_batch* h) {
 
 template <class T>
 static hipError_t dalloc(T** p, uint64_t count) {
-    return hipMalloc((void**)p, std::max<uint64_t>(count, 1) * sizeof(T));
+    return ptx_dev_malloc((void**)p, std::max<uint64_t>(count, 1) * sizeof(T));
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -838,13 +933,17 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
         delete ctx;
         return fail(nullptr, PTX_ERR_HIP, m);
     }
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        g_pool_ctxs.insert(ctx);
+    }
     *out = ctx;
     return PTX_OK;
 }
 
 void ptx_destroy(ptx_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    (void)ptx_enter(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -855,8 +954,18 @@ void ptx_destroy(ptx_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-    if (ctx->stage_d) (void)hipFree(ctx->stage_d);
+    g_tl_ctx = ctx;
+    if (ctx->stage_d) (void)ptx_dev_free(ctx->stage_d);
     if (ctx->stage_h) (void)hipHostFree(ctx->stage_h);
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        g_pool_ctxs.erase(ctx);
+        for (auto& kv : ctx->pool_free)
+            for (void* q : kv.second) (void)hipFree(q);
+        ctx->pool_free.clear();
+        ctx->pool_cached = 0;
+    }
+    g_tl_ctx = nullptr;
     delete ctx;
 }
 
@@ -894,27 +1003,27 @@ uint32_t ptx_max_ops_per_log(const ptx_ctx* ctx) {
 
 void ptx_batch_free(ptx_ctx* ctx, ptx_dbatch* b) {
     if (!b) return;
-    if (ctx) (void)hipSetDevice(ctx->device);
+    if (ctx) (void)ptx_enter(ctx);
     if (b->owns) {
-        (void)hipFree(b->log_off);
-        (void)hipFree(b->op_id);
-        (void)hipFree(b->ref_a);
-        (void)hipFree(b->ref_b);
-        (void)hipFree(b->payload);
-        (void)hipFree(b->action);
-        (void)hipFree(b->mark_type);
-        (void)hipFree(b->side_a);
-        (void)hipFree(b->side_b);
+        (void)ptx_dev_free(b->log_off);
+        (void)ptx_dev_free(b->op_id);
+        (void)ptx_dev_free(b->ref_a);
+        (void)ptx_dev_free(b->ref_b);
+        (void)ptx_dev_free(b->payload);
+        (void)ptx_dev_free(b->action);
+        (void)ptx_dev_free(b->mark_type);
+        (void)ptx_dev_free(b->side_a);
+        (void)ptx_dev_free(b->side_b);
     }
-    (void)hipFree(b->log_hdr);
-    (void)hipFree(b->big_off);
-    (void)hipFree(b->big_scratch);
-    (void)hipFree(b->grid_bars);
-    (void)hipFree(b->log_index);
-    (void)hipFree(b->chg_off);
-    (void)hipFree(b->chg_hdr);
-    (void)hipFree(b->chg_env);
-    (void)hipFree(b->chg_env_hi);
+    (void)ptx_dev_free(b->log_hdr);
+    (void)ptx_dev_free(b->big_off);
+    (void)ptx_dev_free(b->big_scratch);
+    (void)ptx_dev_free(b->grid_bars);
+    (void)ptx_dev_free(b->log_index);
+    (void)ptx_dev_free(b->chg_off);
+    (void)ptx_dev_free(b->chg_hdr);
+    (void)ptx_dev_free(b->chg_env);
+    (void)ptx_dev_free(b->chg_env_hi);
     delete b;
 }
 
@@ -935,7 +1044,7 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
     st = check_host_offsets(ctx, h);
     if (st) return st;
     if ((uint64_t)h->n_logs * copies > 0xFFFFFFFFull) return fail(ctx, PTX_ERR_INVALID_ARG, "too many logs");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     ptx_dbatch* b = new ptx_dbatch();
     b->n_logs = h->n_logs * copies;
     b->n_ops = h->n_ops * copies;
@@ -990,7 +1099,7 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
             ec = hipGetLastError();
         }
         hipError_t ec2 = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(tmpc);
+        (void)ptx_dev_free(tmpc);
         PTX_TRY(ec);
         PTX_TRY(ec2);
     }
@@ -1027,7 +1136,7 @@ ptx_status ptx_batch_upload_tiled(ptx_ctx* ctx, const ptx_batch* h, uint32_t cop
             e1 = hipMemsetAsync(b->log_off, 0, 8, ctx->stream);
         }
         hipError_t e2 = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(tmp);
+        (void)ptx_dev_free(tmp);
         PTX_TRY(e1);
         PTX_TRY(e2);
     }
@@ -1052,7 +1161,7 @@ ptx_status ptx_batch_append_device(ptx_ctx* ctx, const ptx_dbatch* base, const p
     const bool env = more_env && (base_env || base->n_ops == 0);
     if ((base_env && base->n_ops && !more_env) || (more_env && !env) || (env && base_env && base->n_changes && m->max_actors != base->max_actors))
         return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_batch_append: both batches carry the Change envelope with the same max_actors, or neither does");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     ptx_dbatch* b = new ptx_dbatch();
     b->n_logs = base->n_logs;
     b->n_ops = base->n_ops + m->n_ops;
@@ -1065,7 +1174,7 @@ ptx_status ptx_batch_append_device(ptx_ctx* ctx, const ptx_dbatch* base, const p
         hipError_t _e = (call);                         \
         if (_e != hipSuccess) {                         \
             std::string msg = std::string(#call) + ": " + hipGetErrorString(_e); \
-            (void)hipFree(zero_off);                    \
+            (void)ptx_dev_free(zero_off);                    \
             ptx_batch_free(ctx, b);                     \
             return fail(ctx, _e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, msg); \
         }                                               \
@@ -1109,7 +1218,7 @@ ptx_status ptx_batch_append_device(ptx_ctx* ctx, const ptx_dbatch* base, const p
         PTX_TRYA(hipStreamSynchronize(ctx->stream));
     }
 #undef PTX_TRYA
-    (void)hipFree(zero_off);
+    (void)ptx_dev_free(zero_off);
     const ptx_status st = census_and_shape(ctx, b, false);
     if (st != PTX_OK) {
         ptx_batch_free(ctx, b);
@@ -1151,7 +1260,7 @@ ptx_status ptx_batch_wrap_device(ptx_ctx* ctx, const ptx_batch* d, ptx_dbatch** 
     b->mark_type = (uint8_t*)d->mark_type;
     b->side_a = (uint8_t*)d->side_a;
     b->side_b = (uint8_t*)d->side_b;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     hipError_t e = dalloc(&b->log_hdr, (uint64_t)b->n_logs);
     if (e == hipSuccess && d->log_hdr && b->n_logs)
         e = hipMemcpyAsync(b->log_hdr, d->log_hdr, (size_t)b->n_logs * sizeof(ptx_log_hdr), hipMemcpyDeviceToDevice, ctx->stream);
@@ -1170,21 +1279,21 @@ ptx_status ptx_batch_wrap_device(ptx_ctx* ctx, const ptx_batch* d, ptx_dbatch** 
 
 void ptx_dresult_free(ptx_ctx* ctx, ptx_dresult* r) {
     if (!r) return;
-    if (ctx) (void)hipSetDevice(ctx->device);
-    (void)hipFree(r->logs);
-    (void)hipFree(r->values);
-    (void)hipFree(r->spans);
-    (void)hipFree(r->cints);
-    (void)hipFree(r->rank);
-    (void)hipFree(r->refs);
-    (void)hipFree(r->refs_hi);
+    if (ctx) (void)ptx_enter(ctx);
+    (void)ptx_dev_free(r->logs);
+    (void)ptx_dev_free(r->values);
+    (void)ptx_dev_free(r->spans);
+    (void)ptx_dev_free(r->cints);
+    (void)ptx_dev_free(r->rank);
+    (void)ptx_dev_free(r->refs);
+    (void)ptx_dev_free(r->refs_hi);
     delete r;
 }
 
 ptx_status ptx_result_alloc(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult** out) {
     if (!ctx || !b || !out) return PTX_ERR_INVALID_ARG;
     *out = nullptr;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     ptx_dresult* r = new ptx_dresult();
     r->n_logs = b->n_logs;
     r->n_rows = b->n_ops;
@@ -1311,14 +1420,14 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
 ptx_status ptx_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r) {
     if (!ctx || !b || !r) return PTX_ERR_INVALID_ARG;
     if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     return launch_merge(ctx, b, r);
 }
 
 ptx_status ptx_merge_timed(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, uint32_t iters, float* ms_total) {
     if (!ctx || !b || !r || !ms_total) return PTX_ERR_INVALID_ARG;
     if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     PTX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (uint32_t i = 0; i < iters; ++i) {
         ptx_status st = launch_merge(ctx, b, r);
@@ -1333,9 +1442,9 @@ ptx_status ptx_merge_timed(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, ui
 ptx_status ptx_merge_phase_cycles(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r, uint64_t* cycles, uint32_t n) {
     if (!ctx || !b || !r || !cycles) return PTX_ERR_INVALID_ARG;
     if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     unsigned long long* d = nullptr;
-    PTX_HIP(ctx, hipMalloc((void**)&d, PTX_NCLK * sizeof(unsigned long long)));
+    PTX_HIP(ctx, ptx_dev_malloc((void**)&d, PTX_NCLK * sizeof(unsigned long long)));
     hipError_t e = hipMemsetAsync(d, 0, PTX_NCLK * sizeof(unsigned long long), ctx->stream);
     ptx_status st = PTX_OK;
     if (e == hipSuccess) {
@@ -1346,7 +1455,7 @@ ptx_status ptx_merge_phase_cycles(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult
     unsigned long long h[PTX_NCLK];
     if (e == hipSuccess && st == PTX_OK) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
+    (void)ptx_dev_free(d);
     if (st) return st;
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("phase cycles: ") + hipGetErrorString(e));
     for (uint32_t k = 0; k < n; ++k) cycles[k] = k < PTX_NCLK ? (uint64_t)h[k] : 0;
@@ -1355,7 +1464,7 @@ ptx_status ptx_merge_phase_cycles(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult
 
 ptx_status ptx_set_stream(ptx_ctx* ctx, void* hip_stream) {
     if (!ctx) return PTX_ERR_INVALID_ARG;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); /* nothing of this context is left in flight on the stream it leaves */
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return PTX_OK;
@@ -1364,7 +1473,7 @@ ptx_status ptx_set_stream(ptx_ctx* ctx, void* hip_stream) {
 ptx_status ptx_count_converged(ptx_ctx* ctx, const ptx_dresult* r, uint32_t replicas, uint64_t* count_device) {
     if (!ctx || !r || !count_device || replicas == 0) return PTX_ERR_INVALID_ARG;
     if (r->n_logs % replicas) return fail(ctx, PTX_ERR_INVALID_ARG, "n_logs is not a multiple of replicas");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     PTX_HIP(ctx, hipMemsetAsync(count_device, 0, 8, ctx->stream));
     const uint32_t n_docs = r->n_logs / replicas;
     if (n_docs) {
@@ -1376,9 +1485,9 @@ ptx_status ptx_count_converged(ptx_ctx* ctx, const ptx_dresult* r, uint32_t repl
 
 ptx_status ptx_calib_stream(ptx_ctx* ctx, const ptx_dbatch* b, uint64_t* bytes_read) {
     if (!ctx || !b || !bytes_read) return PTX_ERR_INVALID_ARG;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     unsigned long long* d = nullptr;
-    PTX_HIP(ctx, hipMalloc((void**)&d, 8));
+    PTX_HIP(ctx, ptx_dev_malloc((void**)&d, 8));
     hipError_t e = hipMemsetAsync(d, 0, 8, ctx->stream);
     const bool env = b->chg_off != nullptr;
     if (e == hipSuccess) {
@@ -1387,7 +1496,7 @@ ptx_status ptx_calib_stream(ptx_ctx* ctx, const ptx_dbatch* b, uint64_t* bytes_r
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
+    (void)ptx_dev_free(d);
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("calibration stream: ") + hipGetErrorString(e));
     *bytes_read = 32 * b->n_ops + (env ? b->n_changes * (4 + 2ull * PTX_ENV_STRIDE(b->max_actors)) : 0);
     return PTX_OK;
@@ -1395,7 +1504,7 @@ ptx_status ptx_calib_stream(ptx_ctx* ctx, const ptx_dbatch* b, uint64_t* bytes_r
 
 ptx_status ptx_sync(ptx_ctx* ctx) {
     if (!ctx) return PTX_ERR_INVALID_ARG;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PTX_OK;
 }
@@ -1467,7 +1576,7 @@ ptx_status ptx_comm_init(ptx_ctx* ctx, const uint8_t id[PTX_COMM_ID_BYTES], uint
     *out = nullptr;
     ptx_status st = rccl_load(ctx);
     if (st) return st;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
     ptx_comm* c = new ptx_comm();
@@ -1485,14 +1594,14 @@ ptx_status ptx_comm_init(ptx_ctx* ctx, const uint8_t id[PTX_COMM_ID_BYTES], uint
 void ptx_comm_destroy(ptx_ctx* ctx, ptx_comm* c) {
     if (!c) return;
     if (ctx) {
-        (void)hipSetDevice(ctx->device);
+        (void)ptx_enter(ctx);
         (void)hipStreamSynchronize(ctx->stream);
     }
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
-    (void)hipFree(c->padded);
-    (void)hipFree(c->mine);
-    (void)hipFree(c->d_first);
-    (void)hipFree(c->d_counts);
+    (void)ptx_dev_free(c->padded);
+    (void)ptx_dev_free(c->mine);
+    (void)ptx_dev_free(c->d_first);
+    (void)ptx_dev_free(c->d_counts);
     delete c;
 }
 
@@ -1502,7 +1611,7 @@ uint32_t ptx_comm_rank(const ptx_comm* c) { return c ? c->rank : 0u; }
 ptx_status ptx_allgather_digests(ptx_ctx* ctx, ptx_comm* c, const ptx_dresult* r, const uint32_t* counts, uint64_t* out_device) {
     if (!ctx || !c || !r || !counts || !out_device) return PTX_ERR_INVALID_ARG;
     if (counts[c->rank] != r->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_allgather_digests: counts[rank] must be the logs of this rank's result");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     uint32_t width = 0;
     bool equal = true;
     for (uint32_t k = 0; k < c->n_ranks; ++k) {
@@ -1519,8 +1628,8 @@ ptx_status ptx_allgather_digests(ptx_ctx* ctx, ptx_comm* c, const ptx_dresult* r
         return PTX_OK;
     }
     if (c->width < width) { /* (re)size the scratch of the padded path */
-        (void)hipFree(c->padded);
-        (void)hipFree(c->mine);
+        (void)ptx_dev_free(c->padded);
+        (void)ptx_dev_free(c->mine);
         c->padded = c->mine = nullptr;
         c->width = 0;
         PTX_HIP(ctx, dalloc(&c->padded, (uint64_t)c->n_ranks * width * 2));
@@ -1553,7 +1662,7 @@ ptx_status ptx_allgather_digests(ptx_ctx* ctx, ptx_comm* c, const ptx_dresult* r
 ptx_status ptx_count_converged_digests(ptx_ctx* ctx, const uint64_t* digests_device, uint64_t n_logs, uint32_t replicas, uint64_t* count_device) {
     if (!ctx || !count_device || replicas == 0 || (!digests_device && n_logs)) return PTX_ERR_INVALID_ARG;
     if (n_logs % replicas) return fail(ctx, PTX_ERR_INVALID_ARG, "n_logs is not a multiple of replicas");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     PTX_HIP(ctx, hipMemsetAsync(count_device, 0, 8, ctx->stream));
     const uint64_t n_docs = n_logs / replicas;
     if (n_docs) {
@@ -1567,17 +1676,17 @@ ptx_status ptx_count_converged_digests(ptx_ctx* ctx, const uint64_t* digests_dev
 ptx_status ptx_device_alloc(ptx_ctx* ctx, uint64_t bytes, void** out_device) {
     if (!ctx || !out_device) return PTX_ERR_INVALID_ARG;
     *out_device = nullptr;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
-    PTX_HIP(ctx, hipMalloc(out_device, std::max<uint64_t>(bytes, 1)));
+    PTX_HIP(ctx, ptx_enter(ctx));
+    PTX_HIP(ctx, ptx_dev_malloc(out_device, std::max<uint64_t>(bytes, 1)));
     return PTX_OK;
 }
 void ptx_device_free(ptx_ctx* ctx, void* device) {
-    if (ctx) (void)hipSetDevice(ctx->device);
-    (void)hipFree(device);
+    if (ctx) (void)ptx_enter(ctx);
+    (void)ptx_dev_free(device);
 }
 ptx_status ptx_device_read(ptx_ctx* ctx, const void* device, void* host, uint64_t bytes) {
     if (!ctx || (bytes && (!device || !host))) return PTX_ERR_INVALID_ARG;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     if (bytes) PTX_HIP(ctx, hipMemcpyAsync(host, device, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PTX_OK;
@@ -1609,7 +1718,7 @@ ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const pt
     memset(out, 0, sizeof(*out));
     if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
     if ((uint64_t)first_log + n_logs > r->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "log range exceeds the result");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     uint64_t lo[2] = {0, 0};
     if (r->n_logs) {
         PTX_HIP(ctx, hipMemcpyAsync(&lo[0], b->log_off + first_log, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1640,10 +1749,10 @@ ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const pt
             if (e == hipSuccess) ctx->stage_h_cap = h0_bytes * 2;
         }
         if (e == hipSuccess && ctx->stage_d_cap < d0_bytes) {
-            if (ctx->stage_d) (void)hipFree(ctx->stage_d);
+            if (ctx->stage_d) (void)ptx_dev_free(ctx->stage_d);
             ctx->stage_d = nullptr;
             ctx->stage_d_cap = 0;
-            e = hipMalloc((void**)&ctx->stage_d, d0_bytes * 2);
+            e = ptx_dev_malloc((void**)&ctx->stage_d, d0_bytes * 2);
             if (e == hipSuccess) ctx->stage_d_cap = d0_bytes * 2;
         }
         hp0 = ctx->stage_h;
@@ -1651,7 +1760,7 @@ ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const pt
     } else {
         e = hipHostMalloc((void**)&hp0, h0_bytes, hipHostMallocDefault);
         h->pinned[0] = hp0;
-        if (e == hipSuccess) e = hipMalloc((void**)&dblk, d0_bytes);
+        if (e == hipSuccess) e = ptx_dev_malloc((void**)&dblk, d0_bytes);
     }
     uint64_t* offs = (uint64_t*)(hp0 + logs_bytes);
     uint64_t* d_off = (uint64_t*)dblk;
@@ -1677,7 +1786,7 @@ ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const pt
         const uint64_t dense_bytes = a16(cv * 4) + a16(cs * sizeof(ptx_span)) + a16(cc * sizeof(ptx_cinterval)) + 16;
         if (e == hipSuccess) e = hipHostMalloc((void**)&hp1, dense_bytes, hipHostMallocDefault);
         h->pinned[1] = hp1;
-        if (e == hipSuccess) e = hipMalloc((void**)&dblk1, dense_bytes);
+        if (e == hipSuccess) e = ptx_dev_malloc((void**)&dblk1, dense_bytes);
         dense_h = hp1;
         dense_d = dblk1;
     }
@@ -1704,8 +1813,8 @@ ptx_status ptx_result_download_range(ptx_ctx* ctx, const ptx_dbatch* b, const pt
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     else (void)hipStreamSynchronize(ctx->stream);
     if (!small) {
-        (void)hipFree(dblk);
-        (void)hipFree(dblk1);
+        (void)ptx_dev_free(dblk);
+        (void)ptx_dev_free(dblk1);
     } else if (e == hipSuccess) { /* out of the staging block into memory the result owns (the rows that exist: a few KB for a replica of an editor session) */
         const uint64_t tv = offs[n_logs], ts = offs[no + n_logs], tc = offs[2 * no + n_logs];
         if (tv > nr || ts > nr || tc > nr) e = hipErrorInvalidValue;
@@ -1754,7 +1863,7 @@ ptx_status ptx_result_download(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dres
 ptx_status ptx_result_download_logs(ptx_ctx* ctx, const ptx_dresult* r, ptx_log_result* out, uint32_t n_logs) {
     if (!ctx || !r || (!out && n_logs)) return PTX_ERR_INVALID_ARG;
     if (n_logs > r->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "n_logs exceeds the result");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     if (n_logs) PTX_HIP(ctx, hipMemcpyAsync(out, r->logs, (size_t)n_logs * sizeof(ptx_log_result), hipMemcpyDeviceToHost, ctx->stream));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PTX_OK;
@@ -1765,7 +1874,7 @@ const ptx_log_result* ptx_dresult_logs_device(const ptx_dresult* r) { return r ?
 ptx_status ptx_pack_digests(ptx_ctx* ctx, const ptx_dresult* r, uint32_t first, uint32_t count, uint64_t* dst_device) {
     if (!ctx || !r || (!dst_device && count)) return PTX_ERR_INVALID_ARG;
     if ((uint64_t)first + count > r->n_logs) return fail(ctx, PTX_ERR_INVALID_ARG, "digest range exceeds the result");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     if (count) {
         hipLaunchKernelGGL(ptx_pack_digests_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, r->logs, first, count, dst_device);
         PTX_HIP(ctx, hipGetLastError());
@@ -1807,7 +1916,7 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
     memset(out, 0, sizeof(*out));
     if (r->n_logs != b->n_logs || r->n_rows != b->n_ops) return fail(ctx, PTX_ERR_INVALID_ARG, "result buffers do not match the batch");
     if (!r->rank) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_replay_patches needs the elem_rank column (context created with PTX_FLAG_NO_ELEM_RANK)");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     ptx_host_patches* h = new ptx_host_patches();
     const uint32_t L = b->n_logs;
     h->off.assign((size_t)L + 1, 0);
@@ -1852,24 +1961,24 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
     if (gwin) { /* every log's slice of the scratch: what its header says it needs */
         std::vector<uint64_t> woff((size_t)L + 1, 0);
         for (uint32_t l = 0; l < L; ++l) woff[l + 1] = woff[l] + ptx_replay_win_units_hdr(hdr[l], wide);
-        e = hipMalloc((void**)&d_win, 2 * woff[L] + 16);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_winoff, ((size_t)L + 1) * 8);
+        e = ptx_dev_malloc((void**)&d_win, 2 * woff[L] + 16);
+        if (e == hipSuccess) e = ptx_dev_malloc((void**)&d_winoff, ((size_t)L + 1) * 8);
         if (e == hipSuccess) e = hipMemcpyAsync(d_winoff, woff.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); /* (woff leaves scope) */
         if (e != hipSuccess) { /* (an early return here leaked the offsets already held by `out`, and named an out-of-memory PTX_ERR_HIP) */
-            (void)hipFree(d_win);
-            (void)hipFree(d_winoff);
+            (void)ptx_dev_free(d_win);
+            (void)ptx_dev_free(d_winoff);
             ptx_patches_free(out);
             return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("replay set-up (scratch): ") + hipGetErrorString(e));
         }
     }
     if (first_row) {
-        e = hipMalloc((void**)&d_first, (size_t)L * 4);
+        e = ptx_dev_malloc((void**)&d_first, (size_t)L * 4);
         if (e == hipSuccess) e = hipMemcpyAsync(d_first, first_row, (size_t)L * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) {
-            (void)hipFree(d_win);
-            (void)hipFree(d_winoff);
-            (void)hipFree(d_first);
+            (void)ptx_dev_free(d_win);
+            (void)ptx_dev_free(d_winoff);
+            (void)ptx_dev_free(d_first);
             ptx_patches_free(out);
             return fail(ctx, e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_HIP, std::string("replay set-up: ") + hipGetErrorString(e));
         }
@@ -1885,13 +1994,13 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
     ptx_patch *d_patches = nullptr, *d_packed = nullptr;
     ptx_status st = PTX_OK;
     auto release = [&]() {
-        (void)hipFree(d_off);
-        (void)hipFree(d_ext);
-        (void)hipFree(d_xoff);
-        (void)hipFree(d_next);
-        (void)hipFree(d_logs);
-        (void)hipFree(d_patches);
-        (void)hipFree(d_packed);
+        (void)ptx_dev_free(d_off);
+        (void)ptx_dev_free(d_ext);
+        (void)ptx_dev_free(d_xoff);
+        (void)ptx_dev_free(d_next);
+        (void)ptx_dev_free(d_logs);
+        (void)ptx_dev_free(d_patches);
+        (void)ptx_dev_free(d_packed);
         d_off = d_ext = d_xoff = nullptr;
         d_next = nullptr;
         d_logs = nullptr;
@@ -1907,17 +2016,17 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
     for (uint32_t attempt = 0; attempt < 2 && st == PTX_OK; ++attempt) {
         const uint64_t total = h->off[L];
         uint64_t arena_cap = attempt == 0 && !no_arena_env ? total + 65536 : 0;
-        e = hipMalloc((void**)&d_off, ((size_t)L + 1) * 8);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_ext, (size_t)L * 24);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_xoff, ((size_t)L + 1) * 8);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_next, 8);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_logs, (size_t)L * sizeof(ptx_patch_log));
+        e = ptx_dev_malloc((void**)&d_off, ((size_t)L + 1) * 8);
+        if (e == hipSuccess) e = ptx_dev_malloc((void**)&d_ext, (size_t)L * 24);
+        if (e == hipSuccess) e = ptx_dev_malloc((void**)&d_xoff, ((size_t)L + 1) * 8);
+        if (e == hipSuccess) e = ptx_dev_malloc((void**)&d_next, 8);
+        if (e == hipSuccess) e = ptx_dev_malloc((void**)&d_logs, (size_t)L * sizeof(ptx_patch_log));
         if (e == hipSuccess) {
-            e = hipMalloc((void**)&d_patches, std::max<uint64_t>(total + arena_cap, 1) * sizeof(ptx_patch));
+            e = ptx_dev_malloc((void**)&d_patches, std::max<uint64_t>(total + arena_cap, 1) * sizeof(ptx_patch));
             if (e == hipErrorOutOfMemory && arena_cap) { /* no room for the arena: the capacities alone (a log that outgrows its own is then replayed again with exact sizes) */
                 (void)hipGetLastError();
                 arena_cap = 0;
-                e = hipMalloc((void**)&d_patches, std::max<uint64_t>(total, 1) * sizeof(ptx_patch));
+                e = ptx_dev_malloc((void**)&d_patches, std::max<uint64_t>(total, 1) * sizeof(ptx_patch));
             }
         }
         if (e == hipSuccess) e = hipMemcpyAsync(d_off, h->off.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -1976,7 +2085,7 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
             for (uint32_t l = 0; l < L; ++l) longest = std::max<uint64_t>(longest, xoff[l + 1] - xoff[l]);
             if (pack_env) pack_cap = std::max<uint64_t>(std::min<uint64_t>(pack_cap, pack_env), longest);
             for (;;) {
-                e = hipMalloc((void**)&d_packed, pack_cap * sizeof(ptx_patch));
+                e = ptx_dev_malloc((void**)&d_packed, pack_cap * sizeof(ptx_patch));
                 if (e != hipErrorOutOfMemory || pack_cap == longest) break;
                 (void)hipGetLastError();
                 pack_cap = std::max<uint64_t>(pack_cap / 2, longest);
@@ -2005,9 +2114,9 @@ ptx_status ptx_replay_patches_from(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_
         release();
     }
     release();
-    (void)hipFree(d_win);
-    (void)hipFree(d_winoff);
-    (void)hipFree(d_first);
+    (void)ptx_dev_free(d_win);
+    (void)ptx_dev_free(d_winoff);
+    (void)ptx_dev_free(d_first);
     if (st != PTX_OK) {
         ptx_patches_free(out);
         return st;
@@ -2041,7 +2150,7 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     const char* text = tl ? cfg->initial_text : "ABCDE";
     const uint32_t init_len = (uint32_t)(tl ? tl : 5);
     if (init_len > cfg->ops_per_log || tl >= sizeof(cfg->initial_text)) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_generate: initial text too long");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     const uint32_t R = cfg->replicas, N = cfg->ops_per_log + 1u, D = cfg->n_docs;
     if ((uint64_t)D * R > 0xFFFFFFFFull) return fail(ctx, PTX_ERR_INVALID_ARG, "too many logs");
     ptx_dbatch* b = new ptx_dbatch();
@@ -2054,13 +2163,13 @@ ptx_status ptx_generate(ptx_ctx* ctx, const ptx_gen_config* cfg, ptx_dbatch** ou
     uint8_t* d_ctab = nullptr; /* PtxGenChangeT<ptx_gen_max_r(R)> per op */
     uint16_t* d_known = nullptr;
     auto drop = [&]() { /* idempotent: a later failure path may call it again */
-        (void)hipFree(cap_hdr);
-        (void)hipFree(cap_env);
-        (void)hipFree(d_nchg);
-        (void)hipFree(d_ncom);
-        (void)hipFree(d_status);
-        (void)hipFree(d_ctab);
-        (void)hipFree(d_known);
+        (void)ptx_dev_free(cap_hdr);
+        (void)ptx_dev_free(cap_env);
+        (void)ptx_dev_free(d_nchg);
+        (void)ptx_dev_free(d_ncom);
+        (void)ptx_dev_free(d_status);
+        (void)ptx_dev_free(d_ctab);
+        (void)ptx_dev_free(d_known);
         cap_hdr = d_nchg = d_ncom = d_status = nullptr;
         cap_env = nullptr;
         d_ctab = nullptr;
@@ -2218,7 +2327,7 @@ void ptx_root_maps_free(ptx_root_maps* m) {
 ptx_status ptx_root_map(ptx_ctx* ctx, const ptx_dbatch* b, ptx_root_maps* out) {
     if (!ctx || !b || !out) return PTX_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     ptx_host_root_maps* h = new ptx_host_root_maps();
     const uint32_t L = b->n_logs;
     h->off.assign((size_t)L + 1, 0);
@@ -2235,10 +2344,10 @@ ptx_status ptx_root_map(ptx_ctx* ctx, const ptx_dbatch* b, ptx_root_maps* out) {
     ptx_root_log* d_logs = nullptr;
     ptx_root_entry* d_ent = nullptr;
     auto release = [&]() {
-        (void)hipFree(d_cnt);
-        (void)hipFree(d_off);
-        (void)hipFree(d_logs);
-        (void)hipFree(d_ent);
+        (void)ptx_dev_free(d_cnt);
+        (void)ptx_dev_free(d_off);
+        (void)ptx_dev_free(d_logs);
+        (void)ptx_dev_free(d_ent);
     };
     std::vector<uint32_t> cnt(L);
     hipError_t e = dalloc(&d_cnt, L);
@@ -2300,7 +2409,7 @@ ptx_status ptx_resolve_cursors(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dres
     if (n_queries == 0) return PTX_OK;
     for (uint32_t q = 0; q < n_queries; ++q)
         if (q_log[q] >= b->n_logs || q_kind[q] > PTX_CURSOR_GET) return fail(ctx, PTX_ERR_INVALID_ARG, "ptx_resolve_cursors: a query names no log of the batch or an unknown kind");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     /* group the queries by log: one workgroup builds a log's index once and answers all of them */
     std::vector<uint32_t> perm(n_queries);
     for (uint32_t q = 0; q < n_queries; ++q) perm[q] = q;
@@ -2332,7 +2441,7 @@ ptx_status ptx_resolve_cursors(ptx_ctx* ctx, const ptx_dbatch* b, const ptx_dres
     uint64_t *d_goff = nullptr, *d_arg = nullptr, *d_out = nullptr;
     uint8_t* d_kind = nullptr;
     auto drop = [&]() {
-        for (void* p : {(void*)d_glog, (void*)d_perm, (void*)d_status, (void*)d_goff, (void*)d_arg, (void*)d_out, (void*)d_kind}) (void)hipFree(p);
+        for (void* p : {(void*)d_glog, (void*)d_perm, (void*)d_status, (void*)d_goff, (void*)d_arg, (void*)d_out, (void*)d_kind}) (void)ptx_dev_free(p);
     };
     hipError_t e = dalloc(&d_glog, G);
     if (e == hipSuccess) e = dalloc(&d_goff, (uint64_t)G + 1);
@@ -2415,7 +2524,7 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
         out_off[l + 1] = out_off[l] + rows;
     }
     const uint64_t T = out_off[L];
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     /* launch shape: the LDS of the largest working set among the logs that make a change */
     std::vector<ptx_log_hdr> hdr(std::max<uint32_t>(L, 1));
@@ -2451,13 +2560,13 @@ ptx_status ptx_change(ptx_ctx* ctx, const ptx_dbatch* base, const ptx_dresult* m
     auto drop = [&]() {
         ptx_batch_free(ctx, cap);
         cap = nullptr;
-        (void)hipFree(d_list);
-        (void)hipFree(d_list_off);
+        (void)ptx_dev_free(d_list);
+        (void)ptx_dev_free(d_list_off);
         d_list = nullptr;
         d_list_off = nullptr;
         for (void* p : {(void*)d_in_chg, (void*)d_in_op, (void*)d_out_off, (void*)d_doff, (void*)d_dcoff, (void*)d_in_action, (void*)d_in_mt, (void*)d_in_index, (void*)d_in_count,
                         (void*)d_in_payload, (void*)d_in_values, (void*)d_actor, (void*)d_status, (void*)d_rows, (void*)d_chgs})
-            (void)hipFree(p);
+            (void)ptx_dev_free(p);
         d_in_chg = d_in_op = d_out_off = d_doff = d_dcoff = nullptr;
         d_in_action = d_in_mt = nullptr;
         d_in_index = d_in_count = d_in_payload = d_in_values = d_actor = d_status = d_rows = d_chgs = nullptr;
@@ -2624,7 +2733,7 @@ void ptx_host_batch_free(ptx_host_batch* hb) {
 ptx_status ptx_batch_download(ptx_ctx* ctx, const ptx_dbatch* b, ptx_host_batch* out) {
     if (!ctx || !b || !out) return PTX_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_HIP(ctx, ptx_enter(ctx));
     ptx_host_batch_store* s = new ptx_host_batch_store();
     const uint64_t T = b->n_ops, L = b->n_logs, NC = b->chg_off ? b->n_changes : 0;
     s->log_off.resize(L + 1);
