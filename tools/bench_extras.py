@@ -288,7 +288,7 @@ def main():
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--no-admission", action="store_true")
     ap.add_argument("--parity-docs", type=int, default=32)
-    ap.add_argument("--legs", default="configs,replay,biglog,pipeline,host,many,phases,candidate,probe")
+    ap.add_argument("--legs", default="configs,replay,biglog,pipeline,host,many,phases,candidate,probe,jshost")
     args = ap.parse_args()
     legs = set(args.legs.split(","))
     g = workloads.gen_config(args.config, ops=args.ops)
@@ -322,6 +322,41 @@ def main():
         except Exception as ex:  # noqa: BLE001
             out["patch_replay"] = {"error": str(ex)[:300]}
         say("patch_replay %s" % json.dumps(out["patch_replay"]))
+
+    if "jshost" in legs:
+        # the TypeScript-facing entry point end to end — Change[] JSON (reference/src/micromerge.ts:60-71) -> MergeEngine.applyChanges -> spans,
+        # one Node thread, on documents the device generator made (downloaded and decoded to the reference's Change objects here); and one resident edit session
+        try:
+            node = shutil.which("node")
+            if node is None:
+                raise RuntimeError("node is not on this box")
+            jdocs = 24
+            with Engine(args.device, flags=flags) as e:
+                db, ginfo = e.generate(*gen_args, jdocs, args.seed, list_cap=args.list_cap)
+                actors, comments, log_doc = wire.generated_tables(jdocs, g["replicas"], ginfo["n_comments"])
+                hb = e.download_batch(db, wire.GEN_VALUES, wire.GEN_URLS, log_doc, actors, comments)
+                e.free_batch(db)
+            logs = [wire.decode_changes(hb, l) for l in range(hb.n_logs)]
+            docs_json = [logs[d * g["replicas"]:(d + 1) * g["replicas"]] for d in range(jdocs)]
+            with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+                json.dump(docs_json, f)
+                path = f.name
+            try:
+                p = subprocess.run([node, os.path.join(ROOT, "tools", "js_host_bench.js"), path, "3"], capture_output=True, text=True, timeout=600)
+                if p.returncode != 0:
+                    raise RuntimeError(p.stderr[-300:])
+                row = json.loads(p.stdout.strip().splitlines()[-1])
+            finally:
+                os.unlink(path)
+            row["config"] = args.config
+            p = subprocess.run([node, os.path.join(ROOT, "tests", "node_host_check.js"), "resident-edit", "200"], capture_output=True, text=True, timeout=600)
+            if p.returncode == 0:
+                ed = json.loads(p.stdout.strip().splitlines()[-1])
+                row["resident_edit_session"] = {"edits": ed["edits"], "ms_per_change": ed["msPerResidentChange"], "whole_document_uploads_after_setup": ed["wholeDocumentUploadsAfterSetup"]}
+            out["js_host_end_to_end"] = row
+        except Exception as ex:  # noqa: BLE001
+            out["js_host_end_to_end"] = {"error": str(ex)[:300]}
+        say("js_host_end_to_end %s" % json.dumps(out["js_host_end_to_end"]))
 
     if "biglog" in legs:
         try:
