@@ -2453,7 +2453,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         }
         PTX_SYNC_LDS();
         PTX_FOR(c, Kid + 1) {
-            cicnt[c] = c < Kid ? ptx_comment_sweep<kThreads == 0u>(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
+            cicnt[c] = c < Kid ? ptx_comment_sweep<kThreads == 0u || kThreads == 256u>(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [](uint32_t, uint32_t) {}) : 0u;
         }
         PTX_SYNC_LDS();
         const uint32_t I = ptx_counts_prefix<kThreads>(cicnt, Kid + 1, &H->scan_tmp[21]);
@@ -2464,7 +2464,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         uint64_t h1 = 0, h2 = 0;
         PTX_FOR(c, Kid) {
             uint32_t row = cicnt[c];
-            ptx_comment_sweep<kThreads == 0u>(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [&](uint32_t s, uint32_t e) {
+            ptx_comment_sweep<kThreads == 0u || kThreads == 256u>(cent + ccnt[c], ccnt[c + 1] - ccnt[c], [&](uint32_t s, uint32_t e) {
                 if (crow) {
                     crow[2u * row] = c;
                     crow[2u * row + 1u] = s | (e << 16);
@@ -2514,7 +2514,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
             TV = PTX_TILE_1;
             /* (round 6) a document of more than one tile takes tiles of twice the size where the recycled element region and the free phase scratch hold
              * them: half the passes — each a handful of barriers and, for the links, two trips to HBM */
-            if (kThreads == 0u && V > PTX_TILE_1) {
+            if ((kThreads == 0u || kThreads == 256u) && V > PTX_TILE_1) {
                 const uint32_t T2 = 2u * PTX_TILE_1;
                 const uint64_t over = ptx_overflow3((uint64_t)bd.cap - bd.off, K ? 4u * 2u * T2 : 0u, 4u * (T2 + 1u), 8u * (T2 / 32u + 2u));
                 if ((uint64_t)bp.off + over <= bp.cap) TV = T2;
@@ -2535,7 +2535,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
         uint32_t pk0[PTX_UB], pk1[PTX_UB], pk3[PTX_UB];
         /* (both long-document forms — this and the three-chars-per-step query below — only in the builds for any launch shape, which take the documents that keep
          * their text: in the lean builds of the three usual shapes they cost scalar registers and bought nothing, config #4 +0.7 %, #3 +0.5 %) */
-        constexpr bool kLongDocs = kThreads == 0u || kThreads == 128u; /* (the two-wave build too: a 1K-op log of BASELINE config #3 shows 158 characters, -0.9 %) */
+        constexpr bool kLongDocs = kThreads == 0u || kThreads == 128u || kThreads == 256u; /* (the two-wave build too: a 1K-op log of BASELINE config #3 shows 158 characters, -0.9 %; 256: the four-wave lean build, which takes the documents that keep their text) */
         const bool pk_cached = kLongDocs && !four && K != 0u;
 #pragma unroll
         for (int u = 0; u < (int)PTX_UB; ++u) {

@@ -96,6 +96,9 @@ PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean128, 128, PTX_LEAN128_W, 0, 128, false, 
 #define PTX_LEAN192_SGPRS PTX_W7_SGPRS
 #endif
 PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean192, 192, PTX_LEAN192_W, 0, 192, false, true, __attribute__((amdgpu_num_sgpr(PTX_LEAN192_SGPRS))))
+/* round 6 (last session): the four-wave lean build — 8K-op logs (BASELINE config #5: four 39 KB logs per CU) and 4K-op logs that keep their text (`rich4k`); their LDS
+ * window, not the registers, bounds the resident logs, so the build takes what registers it wants */
+PTX_MERGE_KERNEL_L(ptx_merge_kernel_lean256, 256, 1, 0, 256, false, true, )
 PTX_MERGE_KERNEL(ptx_merge_kernel_many, 1024, 1, 1, 0, false) /* + causal admission for documents with more than three actors: a one-pass walk up to seven, the (actor, seq) table beyond fifteen */
 PTX_MERGE_KERNEL(ptx_merge_kernel_many_wide, 1024, 1, 2, 0, false) /* the same for documents of eight to fifteen actors (walks over 24- and 32-byte envelope rows) */
 #ifdef PTX_DIAG /* (diagnostic builds only) the stamps of the LEAN builds: the same bodies as ptx_merge_kernel_lean64 / 128 / 192 with the phase stamps on */
@@ -842,7 +845,9 @@ static bool wants_w7(const ptx_ctx* ctx, const ptx_dbatch* b, uint32_t lds) {
 /* the main launch of a batch through a lean build (see PTX_MERGE_KERNEL_L above)?  0, or its threads per log */
 static uint32_t wants_lean(const ptx_ctx* ctx, const ptx_dbatch* b, bool with_rank, uint32_t lds) {
     const bool admit = b->chg_off && !(ctx->flags & PTX_FLAG_NO_ADMISSION);
-    if (with_rank || !b->small_keys || ctx->clocks || ctx->stop_after || (admit && b->max_actors > 3) || !wants_w7(ctx, b, lds)) return 0u;
+    if (with_rank || !b->small_keys || ctx->clocks || ctx->stop_after || (admit && b->max_actors > 3)) return 0u;
+    if (b->threads == 256u && !getenv("PTX_NO_LEAN256")) return 256u; /* (whatever the window allows: no register cap in that build) */
+    if (!wants_w7(ctx, b, lds)) return 0u;
     return b->threads == 64u || b->threads == 128u || b->threads == 192u ? b->threads : 0u;
 }
 
@@ -890,7 +895,7 @@ const char* ptx_batch_kernel_name(const ptx_ctx* ctx, const ptx_dbatch* b) {
     if (admit && b->max_actors > 3) return b->max_actors >= 8u && b->max_actors <= 15u ? "ptx_merge_kernel_many_wide" : "ptx_merge_kernel_many";
     const uint32_t lds = b->log_index ? b->lds_main : b->lds_bytes;
     const uint32_t lean = wants_lean(ctx, b, !(ctx->flags & PTX_FLAG_NO_ELEM_RANK), lds);
-    if (lean) return lean == 64u ? "ptx_merge_kernel_lean64" : lean == 128u ? "ptx_merge_kernel_lean128" : "ptx_merge_kernel_lean192";
+    if (lean) return lean == 64u ? "ptx_merge_kernel_lean64" : lean == 128u ? "ptx_merge_kernel_lean128" : lean == 192u ? "ptx_merge_kernel_lean192" : "ptx_merge_kernel_lean256";
     return wants_w7(ctx, b, lds) ? "ptx_merge_kernel_w7" : "ptx_merge_kernel";
 }
 
@@ -923,7 +928,7 @@ ptx_status ptx_create(int device_ordinal, uint32_t flags, ptx_ctx** out) {
     ctx->own_stream = ctx->stream;
     /* one workgroup may use the CU's whole 160 KiB of LDS */
     {
-        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_many_wide, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_merge_kernel_lean64, (const void*)ptx_merge_kernel_lean128, (const void*)ptx_merge_kernel_lean192, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_replay_kernel_wide, (const void*)ptx_gen_kernel, (const void*)ptx_gen_kernel_r8, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
+        const void* kernels[] = {(const void*)ptx_merge_kernel, (const void*)ptx_merge_kernel_rest, (const void*)ptx_merge_kernel_many, (const void*)ptx_merge_kernel_many_wide, (const void*)ptx_merge_kernel_diag, (const void*)ptx_merge_kernel_w7, (const void*)ptx_merge_kernel_rest_w7, (const void*)ptx_merge_kernel_lean64, (const void*)ptx_merge_kernel_lean128, (const void*)ptx_merge_kernel_lean192, (const void*)ptx_merge_kernel_lean256, (const void*)ptx_replay_kernel, (const void*)ptx_replay_kernel_gwin, (const void*)ptx_replay_kernel_wide, (const void*)ptx_gen_kernel, (const void*)ptx_gen_kernel_r8, (const void*)ptx_change_kernel, (const void*)ptx_cursor_kernel, (const void*)ptx_rootmap_kernel};
         e = hipSuccess;
         for (const void* k : kernels)
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds);
@@ -1405,6 +1410,7 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
             else if (lean == 64u) hipLaunchKernelGGL(ptx_merge_kernel_lean64, dim3(grid), dim3(64), lds, st, A);
             else if (lean == 128u) hipLaunchKernelGGL(ptx_merge_kernel_lean128, dim3(grid), dim3(128), lds, st, A);
             else if (lean == 192u) hipLaunchKernelGGL(ptx_merge_kernel_lean192, dim3(grid), dim3(192), lds, st, A);
+            else if (lean == 256u) hipLaunchKernelGGL(ptx_merge_kernel_lean256, dim3(grid), dim3(256), lds, st, A);
             else hipLaunchKernelGGL(w7 ? ptx_merge_kernel_w7 : ptx_merge_kernel, dim3(grid), dim3(b->threads), lds, st, A);
         }
     }

@@ -295,7 +295,7 @@ def test_every_launch_shape(threads, lds):
 LEAN_FIXTURES = ["ptxgen_mini.json", "ptxgen_config2.json", "ptxgen_config3_512.json", "ptxgen_config4_600.json", "ptxgen_rich_700.json", "ptxgen_rich_2600.json"]
 
 
-@pytest.mark.parametrize("threads", [64, 128, 192])
+@pytest.mark.parametrize("threads", [64, 128, 192, 256])
 def test_lean_builds_of_the_merge_kernel(threads):
     """Round 5: ptx_merge_kernel_lean64 / 128 / 192 — the builds for batches of 16-bit id keys merged without elem_rank (PTX_FLAG_NO_ELEM_RANK; the
     workgroup size a compile-time constant, a one-wave log without s_barrier).  The library must CHOOSE them for such batches (the kernel's name is
@@ -316,7 +316,8 @@ def test_lean_builds_of_the_merge_kernel(threads):
                     # (the lean builds are held to 96 scalar registers like ptx_merge_kernel_w7: chosen where the LDS window lets more than 24 waves share a CU)
                     t, l = e.launch_shape(db)
                     waves_per_cu = (160 * 1024 // (-(-l // 1280) * 1280)) * (t // 64)
-                    want = "ptx_merge_kernel_lean%d" % threads if waves_per_cu > 24 else "ptx_merge_kernel"
+                    # (round 6: the four-wave build has no register cap — 8K-op logs and documents that keep their text, whose LDS window bounds the resident logs — and is taken whatever the window)
+                    want = "ptx_merge_kernel_lean%d" % threads if waves_per_cu > 24 or threads == 256 else "ptx_merge_kernel"
                     assert e.batch_kernel_name(db) == want, name
                     seen.add(want)
                     e.merge(db, dr)
