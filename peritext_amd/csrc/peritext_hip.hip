@@ -1386,8 +1386,15 @@ static ptx_status launch_merge(ptx_ctx* ctx, const ptx_dbatch* b, ptx_dresult* r
                 G.grid_bar = b->grid_bars + 2 * k;
                 G.n_logs = 1;
                 void* kargs[] = {(void*)&G};
-                hipError_t ce = hipLaunchCooperativeKernel((const void*)ptx_merge_big_grid_kernel, dim3(b->big_grid_wgs[k]), dim3(PTX_BIG_GRID_THREADS), kargs, 0, st);
-                if (ce != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("cooperative launch of a large log: ") + hipGetErrorString(ce));
+                hipError_t ce = getenv("PTX_NO_COOPERATIVE") ? hipErrorCooperativeLaunchTooLarge /* (tests: a runtime without cooperative launch) */
+                                                               : hipLaunchCooperativeKernel((const void*)ptx_merge_big_grid_kernel, dim3(b->big_grid_wgs[k]), dim3(PTX_BIG_GRID_THREADS), kargs, 0, st);
+                if (ce != hipSuccess) {
+                    /* no cooperative launch here: the log is merged by ONE workgroup of the HBM-staged kernel — its slice of scratch covers that form too —,
+                     * slower, never a failed batch; and the side stream is joined below whatever happens */
+                    (void)hipGetLastError();
+                    G.grid_bar = nullptr;
+                    hipLaunchKernelGGL(ptx_merge_big_kernel, dim3(1), dim3(PTX_BIG_THREADS), (uint32_t)ptx_a16(sizeof(PtxHdr)), st, G);
+                }
             }
         }
         else if (diag) { /* + room for its phase stamps in the header */

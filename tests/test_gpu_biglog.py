@@ -62,6 +62,21 @@ def test_large_logs_beside_ordinary_ones(eng):
     # every replica of the ordinary documents still converges, and the launch shape of the LDS kernel is the ordinary logs' own (not the CU maximum)
     dg = res.logs["digest"][:n_small].reshape(-1, 3, 2)
     assert (dg == dg[:, :1, :]).all()
+    # on a runtime without cooperative launch (played by PTX_NO_COOPERATIVE) the logs of 16 384 rows and more are merged by one workgroup of the
+    # HBM-staged kernel each — the same results, never a failed batch
+    os.environ["PTX_NO_COOPERATIVE"] = "1"
+    try:
+        db = eng.upload(batch)
+        dr = eng.alloc_result(db)
+        try:
+            eng.merge(db, dr)
+            res2 = eng.download(db, dr)
+        finally:
+            eng.free_result(dr)
+            eng.free_batch(db)
+    finally:
+        del os.environ["PTX_NO_COOPERATIVE"]
+    assert (res2.logs["status"] == 0).all() and (res2.logs["digest"] == res.logs["digest"]).all() and (res2.logs["n_spans"] == res.logs["n_spans"]).all()
 
 
 @pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
