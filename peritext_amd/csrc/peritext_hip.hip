@@ -987,7 +987,7 @@ ptx_status ptx_set_launch_shape(ptx_ctx* ctx, uint32_t threads_per_log, uint32_t
 }
 
 #ifdef PTX_DIAG
-/* diagnostic builds only (tools/pmc_phases.sh, tools/trunc_sweep.sh; never declared in include/peritext_hip.h, never in the product
+/* diagnostic builds only (tools/phase_insts.sh; earlier rounds: tools/rounds2to5/pmc_phases.sh, trunc_sweep.sh; never declared in include/peritext_hip.h, never in the product
  * library): the diagnostic kernel leaves after the phase with stamp index k — its results are then WRONG by design */
 ptx_status ptx_diag_stop_after(ptx_ctx* ctx, uint32_t k) {
     if (!ctx) return PTX_ERR_INVALID_ARG;
