@@ -476,6 +476,29 @@ def test_duplicate_op_id_is_reported(reverse):
     assert wire.decode_spans(batch, res, 1) == [{"text": "ABCDEx", "marks": {}}]
 
 
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_head_makelist_taken_by_the_leader_keeps_its_id_checks(reverse):
+    """Round 6: the row pass leaves the makeList that heads a log of k full steps + one row to the leader (merge_core.h kHeadRow; in the emulation every log of
+    4 k + 1 rows).  What the pass did for that row must still happen: its id takes part in the duplicate check (a later op that reuses it is
+    PTX_ERR_DUPLICATE_OP) and in the header's bounds check (a makeList whose counter the header does not cover is PTX_ERR_BAD_OP) — with a log of 4 k + 2 rows,
+    which takes the ordinary path, as the control."""
+    tail5 = [{"action": "set", "insert": True, "elemId": "6@a", "value": c} for c in "vwx"]
+    for extra in (0, 1):  # 9 rows (4 k + 1: the leader's path) and 10 rows (the ordinary path)
+        ops = tail5 + ([{"action": "del", "elemId": "3@a"}] if extra else [])
+        good = _mini_doc(ops)
+        batch = wire.encode_docs([[good]])
+        assert (int(batch.log_off[1]) - 1) % 4 == (0 if not extra else 1) and int(batch.action[0]) == abi.ACT_MAKELIST
+        assert int(H.emu_merge(batch, reverse=reverse).logs["status"][0]) == 0
+        dup = _mini_doc(ops)
+        dup[1]["ops"][0]["opId"] = dup[0]["ops"][0]["opId"]  # a later insert claims the makeList's id
+        res = H.emu_merge(wire.encode_docs([[dup]]), reverse=reverse)
+        assert int(res.logs["status"][0]) == abi.ERR_DUPLICATE_OP, extra
+        lying = wire.encode_docs([[good]])
+        lying.op_id[0] = (int(lying.log_hdr["max_counter"][0]) + 7) << 32  # the head row's counter beyond what the header declares
+        res = H.emu_merge(lying, reverse=reverse)
+        assert int(res.logs["status"][0]) == abi.ERR_BAD_OP, extra
+
+
 @pytest.mark.skipif(not H.have_node(), reason="node (oracle runtime) not installed")
 def test_many_actor_documents_admission_table_path():
     """Six replicas per document (> 4 actors): the admission falls back from the carried vector clock to the
