@@ -2506,7 +2506,21 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
      * Short documents: one tile, four trees (one per mark type) updated and queried in one pass.
      * Long documents: tiles of PTX_TILE_1 chars, one tree reused per mark type. */
     {
-        const bool four = V <= PTX_TILE_4;
+        /* (round 6, last session) a document of up to 2 PTX_TILE_4 characters whose mark ops are of FEWER than four types — BASELINE config #3: 158 characters,
+         * strong and em only — takes the short-document form too where a tree per PRESENT type fits what the launch's window has free: the live list instead of
+         * every mark op, one pass instead of one per type.  (Not in the three-wave lean build.) */
+        const uint32_t present4 = (moff1 ? 1u : 0u) | (moff2 > moff1 ? 2u : 0u) | (moff3 > moff2 ? 4u : 0u) | (K > moff3 ? 8u : 0u); /* mark types with ops */
+        bool mid = false;
+        if (kThreads != 192u && V > PTX_TILE_4 && V <= 2u * PTX_TILE_4 && K != 0u && present4 != 15u) {
+            const uint32_t T2 = 2u * PTX_TILE_4, nt = ptx_popc(present4);
+            const uint64_t over = ptx_overflow3((uint64_t)bd.cap - bd.off, 4u * nt * 2u * T2, 4u * (T2 + 1u), 8u * (T2 / 32u + 2u));
+            mid = (uint64_t)bp.off + over <= bp.cap;
+        }
+        const bool four = V <= PTX_TILE_4 || mid;
+        /* tree of mark type ty in the short-document form: its own (four trees), or its rank among the present types */
+        const uint32_t tslots = !mid ? 0x03020100u
+                                     : (0u | (ptx_popc(present4 & 1u) << 8) | (ptx_popc(present4 & 3u) << 16) | (ptx_popc(present4 & 7u) << 24));
+#define PTX_TSLOT(ty_) ((tslots >> (8u * (ty_))) & 255u)
         uint32_t TV = 1;
         if (four) {
             while (TV < V) TV <<= 1;
@@ -2520,7 +2534,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 if ((uint64_t)bp.off + over <= bp.cap) TV = T2;
             }
         }
-        const uint32_t ntree = four ? 4u : 1u;
+        const uint32_t gstep = four ? 4u : 1u;                                /* mark types per pass */
+        const uint32_t ntree = mid ? ptx_popc(present4) : four ? 4u : 1u;      /* trees in LDS */
         uint32_t* tree = ptx_alloc2<uint32_t>(bd, bp, K ? ntree * 2 * TV : 0u); /* a log without mark ops has one span per break: no trees */
         uint32_t* attr = ptx_alloc2<uint32_t>(bd, bp, TV + 1);
         PtxBitWord* st = ptx_alloc2<PtxBitWord>(bd, bp, TV / 32 + 2);
@@ -2569,8 +2584,8 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 st[w] = z;
             }
 #pragma nounroll
-            for (uint32_t g = 0; g < 4; g += ntree) {
-                /* mark types [g, g + ntree) */
+            for (uint32_t g = 0; g < 4; g += gstep) {
+                /* mark types [g, g + gstep) */
                 const uint32_t k_lo = g == 0 ? 0u : g == 1 ? moff1 : g == 2 ? moff2 : moff3;
                 const uint32_t k_hi = four ? K : (g == 0 ? moff1 : g == 1 ? moff2 : g == 2 ? moff3 : K);
                 if (k_hi == k_lo) continue;
@@ -2622,7 +2637,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                                 ptx_id_key(ix, op_id[r < N ? r : N - 1u], key);
                             }
                             /* the low bits say who won */
-                            ptx_tree_chmax(tree + (four ? ty : 0u) * 2 * TV, TV, lo[u], hi[u], ty == PTX_MARK_COMMENT ? 1u : ((key + 1u) << kbits) | k);
+                            ptx_tree_chmax(tree + (four ? PTX_TSLOT(ty) : 0u) * 2 * TV, TV, lo[u], hi[u], ty == PTX_MARK_COMMENT ? 1u : ((key + 1u) << kbits) | k);
                         }
                 };
                 lww_load(0u, kq_a, lo_a, hi_a, idq_a);
@@ -2638,8 +2653,9 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                 if (four || !kLongDocs) { /* a short document: one pass, four trees of a few levels, a char per lane (the lean builds: every document) */
                 PTX_FOR(q, tv) {
                     uint32_t at = 0;
-                    for (uint32_t ty = g; ty < g + ntree; ++ty) {
-                        const uint32_t w = ptx_tree_query(tree + (four ? ty : 0u) * 2 * TV, TV, q);
+                    for (uint32_t ty = g; ty < g + gstep; ++ty) {
+                        if (mid && !((present4 >> ty) & 1u)) continue; /* (no tree of its own: no op of that type) */
+                        const uint32_t w = ptx_tree_query(tree + (four ? PTX_TSLOT(ty) : 0u) * 2 * TV, TV, q);
                         if (w == 0) continue;
                         if (ty == PTX_MARK_COMMENT) at |= PTX_ATTR_COMMENT;
                         else {

@@ -253,10 +253,15 @@ def test_capacity_status_when_lds_too_small():
 
 
 @pytest.mark.skipif(not H.have_node(), reason="node not installed")
-@pytest.mark.parametrize("config,docs,ops", [("mini", 25, None), ("config4", 1, None), ("rich", 2, None), ("config5", 1, 3000)])
+@pytest.mark.parametrize("config,docs,ops", [("mini", 25, None), ("config4", 1, None), ("rich", 2, None), ("config5", 1, 3000), ("config3", 4, None)])
 def test_live_oracle(config, docs, ops):
-    """Fresh seeds generated now by the oracle (incl. one FULL config #4 document: 3 replicas x 4096 ops)."""
-    H.check_generated(H.oracle_gen(config, docs, 77, ops), H.emu_merge)
+    """Fresh seeds generated now by the oracle (incl. one FULL config #4 document: 3 replicas x 4096 ops; full config #3 documents: 1 024 ops of two mark
+    types that show ~160 characters — the short-document LWW form with a tree per PRESENT type, round 6)."""
+    gen = H.oracle_gen(config, docs, 77, ops)
+    if config == "config3":
+        assert any(128 < sum(len(sp["text"]) for sp in d["expected"][0]["spans"]) <= 256 for d in gen["docs"])  # (the form is exercised)
+    H.check_generated(gen, H.emu_merge)
+    H.check_generated(gen, lambda b: H.emu_merge(b, reverse=1))
 
 
 def test_log_header_census_paths():
@@ -665,7 +670,7 @@ def test_lds_bound_covers_the_high_water_mark(name):
         parked = (2 * (int(h["n_mark"].sum()) + 1) + 15) & ~15  # the mark list, parked in HBM between P1 and P5, counts in both phases' scratch
         # (round 6) a document of more than one 512-char tile takes tiles of twice the size WHERE THE LAUNCH'S WINDOW HAS THE ROOM (the emulation's window is the
         # CU's whole LDS): that opportunistic use is not part of the bound the host sizes the launch with
-        double_tile = (4 * 2 * 512 + 4 * 512 + 8 * 16 + 48) if int(h["n_ins"]) > 512 else 0
+        double_tile = (4 * 2 * 512 + 4 * 512 + 8 * 16 + 48) if int(h["n_ins"]) > 512 else 1280 if int(h["n_ins"]) > 128 else 0  # (or up to three trees of 256 leaves where one of 512 is budgeted)
         assert used <= need + double_tile and need <= used + 6144 + parked, (log, used, need)  # slack = the LWW trees sized for V = n
 
 
