@@ -154,6 +154,9 @@ struct PtxMergeArgs {
 #define PTX_S 16u /* every PTX_S-th node of the Euler tour is a splitter of the list ranking (measured: 16 is 1 % faster than 8 and needs 0.6 KB less, 4 is 7 % slower) */
 #endif
 #define PTX_TILE_4 128u  /* visible chars up to which the four LWW trees are resident at once */
+#ifndef PTX_QUERY9
+#define PTX_QUERY9 1 /* the short-document form reads a tree's nine nodes at once (not in the three-wave lean build: config #4 +0.2 %, its documents show a dozen characters) */
+#endif
 #define PTX_TILE_1 512u  /* tile of the visible axis for longer documents (one tree, reused per mark type) */
 #define PTX_SMALL_BUCKET 8u  /* child buckets up to this size: one lane per member */
 #define PTX_HUGE_BUCKET 256u /* beyond this size: bitmap ranking, one bucket at a time */
@@ -491,6 +494,20 @@ PTX_DEV void ptx_tree_chmax(uint32_t* tree, uint32_t P, uint32_t lo, uint32_t hi
 PTX_DEV uint32_t ptx_tree_query(const uint32_t* tree, uint32_t P, uint32_t q) {
     uint32_t w = 0;
     for (uint32_t p = q + P; p >= 1; p >>= 1) w = tree[p] > w ? tree[p] : w;
+    return w;
+}
+/* the same for a tree of up to 256 leaves (the short-document form: 2 PTX_TILE_4), its nine nodes read AT ONCE — the loop above is a chain of LDS round trips, one per
+ * level and mark type for every visible character (round 6, last session: a sixth of a 1K-op log's time was its tree passes) */
+PTX_DEV uint32_t ptx_tree_query9(const uint32_t* tree, uint32_t P, uint32_t q) {
+    uint32_t v[9];
+#pragma unroll
+    for (uint32_t i = 0; i < 9u; ++i) {
+        const uint32_t p = (q + P) >> i;
+        v[i] = tree[p ? p : 1u]; /* (beyond the root of a smaller tree: the root again) */
+    }
+    uint32_t w = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 9u; ++i) w = v[i] > w ? v[i] : w;
     return w;
 }
 /* the same for the tiles of a long document (ten or eleven nodes from the leaf to the root), all read at once — as a loop they are ten LDS round
@@ -2655,7 +2672,7 @@ PTX_DEV uint32_t ptx_merge_log_body(const PtxMergeArgs& A, uint32_t log, uint8_t
                     uint32_t at = 0;
                     for (uint32_t ty = g; ty < g + gstep; ++ty) {
                         if (mid && !((present4 >> ty) & 1u)) continue; /* (no tree of its own: no op of that type) */
-                        const uint32_t w = ptx_tree_query(tree + (four ? PTX_TSLOT(ty) : 0u) * 2 * TV, TV, q);
+                        const uint32_t w = PTX_QUERY9 && kThreads != 192u && four ? ptx_tree_query9(tree + PTX_TSLOT(ty) * 2 * TV, TV, q) : ptx_tree_query(tree + (four ? PTX_TSLOT(ty) : 0u) * 2 * TV, TV, q);
                         if (w == 0) continue;
                         if (ty == PTX_MARK_COMMENT) at |= PTX_ATTR_COMMENT;
                         else {
