@@ -91,6 +91,31 @@ function splitOpId(id) {
     return [parseInt(m[1], 10), m[2]]
 }
 
+/** The list object a replica's root shows under `path` once it has applied `log`: every key of a map holds the write with the LARGEST opId
+ *  (reference/src/micromerge.ts:572-602 keeps a write iff compareOpIds says its id is larger than the key's current one), so two replicas that made a list
+ *  under one key concurrently both show the same one.  Its opId, or null when the path does not end at a list.  (wire.resolve_list_path is the Python twin.) */
+function resolveListPath(log, path) {
+    const win = new Map() /* obj + "\u0000" + key -> {ctr, actor, op} */
+    for (const ch of log)
+        for (const op of ch.ops) {
+            if (op.key === undefined || op.elemId !== undefined) continue
+            const a = op.action
+            if (a !== "set" && a !== "del" && a !== "makeMap" && a !== "makeList") continue
+            const obj = op.obj === undefined || op.obj === null || typeof op.obj === "symbol" ? ROOT : op.obj
+            const k = obj + "\u0000" + op.key
+            const id = splitOpId(op.opId)
+            const cur = win.get(k)
+            if (cur === undefined || id[0] > cur.ctr || (id[0] === cur.ctr && id[1] > cur.actor)) win.set(k, { ctr: id[0], actor: id[1], op })
+        }
+    let cur = ROOT
+    for (let i = 0; i < path.length; i++) {
+        const w = win.get(cur + "\u0000" + path[i])
+        if (w === undefined || w.op.action !== (i === path.length - 1 ? "makeList" : "makeMap")) return null
+        cur = w.op.opId
+    }
+    return cur
+}
+
 /** docs: Change[][][] (doc -> replica log -> changes in application order)  ->  SoA batch (include/peritext_hip.h).
  *  opts.extraActors / opts.extraComments: per document, actor names / comment ids that get a rank although no change uses them
  *  yet (a replica about to make its first change, comment ids a later InputOperation introduces: ranks are positions in the
@@ -214,6 +239,9 @@ function encodeDocs(docs, opts) {
             const otherLists = new Set(seedLists || [])
             const wantPath = String(lkey).split(".") /* "meta.notes": a list nested in map objects, by its path (micromerge.ts:178-196); one key: a list of the root map */
             const pathOf = new Map() /* map / list object -> the keys that lead to it from the root map, as the ops of this log made them */
+            /* round 6 (ADVICE r5): WHICH list the path names is decided as the reference decides it — the last-writer-wins winner of every key on the way; null
+             * (the path ends at no list) or a seeded textObj (Changes appended to a resident log): the first object made under the path, as before */
+            const resolved = textObj === null ? resolveListPath(logs[r], wantPath) : null
             for (const ch of log) {
                 /* the Change envelope (micromerge.ts:60-71): what applyChange's admission checks (:499-511) */
                 chgActor[nChg] = arank.get(ch.actor)
@@ -234,7 +262,7 @@ function encodeDocs(docs, opts) {
                     const onRoot = op.obj === undefined || op.obj === null || op.obj === ROOT || typeof op.obj === "symbol"
                     if ((act === "makeMap" || act === "makeList") && op.key !== undefined && (onRoot || pathOf.has(op.obj)) && !pathOf.has(op.opId))
                         pathOf.set(op.opId, (onRoot ? [] : pathOf.get(op.obj)).concat([op.key]))
-                    if (act === "makeList" && onRoot && op.key === lkey && textObj === null) {
+                    if (act === "makeList" && onRoot && op.key === lkey && textObj === null && (resolved === null || op.opId === resolved)) {
                         colAction[i] = ACT.MAKELIST
                         refB32[2 * i] = intern(keys, keyIx, lkey) /* also a write of the root map's key */
                         textObj = op.opId
@@ -283,7 +311,7 @@ function encodeDocs(docs, opts) {
                             if (act === "makeList") {
                                 const p = pathOf.get(op.opId)
                                 /* the nested list this device log merges: its makeList stays a write of its map's key */
-                                if (textObj === null && wantPath.length > 1 && p && p.length === wantPath.length && p.every((k, j) => k === wantPath[j])) textObj = op.opId
+                                if (textObj === null && wantPath.length > 1 && p && p.length === wantPath.length && p.every((k, j) => k === wantPath[j]) && (resolved === null || op.opId === resolved)) textObj = op.opId
                                 else otherLists.add(op.opId)
                             }
                         }

@@ -200,6 +200,30 @@ def _pack(ctr, rank):
     return (int(ctr) << 32) | int(rank)
 
 
+def resolve_list_path(log, path):
+    """The list object a replica's root shows under `path` once it has applied `log`: every key of a map holds the write with the LARGEST opId
+    (reference/src/micromerge.ts:572-602: a write is kept iff compareOpIds says its id is larger than the key's current one), so two replicas that made
+    a list under one key concurrently both show the same one.  Returns its opId, or None when the path does not end at a list (a deleted key, a scalar,
+    a map)."""
+    win = {}
+    for ch in log:
+        for op in ch["ops"]:
+            if "key" in op and "elemId" not in op and op["action"] in ("set", "del", "makeMap", "makeList"):
+                obj = op.get("obj")
+                k = (ROOT if obj is None else obj, op["key"])
+                ctr, actor = split_op_id(op["opId"])
+                cur = win.get(k)
+                if cur is None or (ctr, _u16key(actor)) > cur[0]:
+                    win[k] = ((ctr, _u16key(actor)), op)
+    cur = ROOT
+    for i, key in enumerate(path):
+        w = win.get((cur, key))
+        if w is None or w[1]["action"] != ("makeList" if i == len(path) - 1 else "makeMap"):
+            return None
+        cur = w[1]["opId"]
+    return cur
+
+
 def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None, list_keys=("text",)):
     """docs: list of docs; a doc is a list of replica logs; a replica log is a list of Change dicts.
 
@@ -276,6 +300,10 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None, li
             other_lists = set()  # the replica's list objects that are not this device log's: their ops are rows without effect here
             want_path = tuple(lkey.split("."))  # the list's path through the map objects (one key: a list of the root map)
             path_of = {}  # map / list object -> the keys that lead to it from the root map, as the ops of this log made them
+            # Round 6: WHICH list the path names is decided as the reference decides it — the last-writer-wins winner of every key on the way
+            # (two replicas that made a list under one key concurrently show the same one).  None (the path ends at no list: a deleted key ...) or a
+            # seeded text_obj (Changes appended to a resident log): the first object made under the path, as before.
+            resolved = resolve_list_path(log, want_path) if text_obj is None else None
             nrows = 0
             for ch in log:
                 chg_actor.append(arank[ch["actor"]])
@@ -289,7 +317,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None, li
                     on_root = obj is None or obj == ROOT
                     if act in ("makeMap", "makeList") and "key" in op and (on_root or obj in path_of):
                         path_of.setdefault(op["opId"], (() if on_root else path_of[obj]) + (op["key"],))
-                    if act == "makeList" and on_root and op.get("key") == lkey and text_obj is None:
+                    if act == "makeList" and on_root and op.get("key") == lkey and text_obj is None and (resolved is None or op["opId"] == resolved):
                         row.update(action=abi.ACT_MAKELIST, ref_b=intern(keys, key_ix, lkey))  # also a write of the root map's key
                         text_obj = op["opId"]
                     elif text_obj is not None and obj == text_obj:
@@ -333,7 +361,7 @@ def encode_docs(docs, extra_actors=None, extra_comments=None, text_objs=None, li
                             if act == "set":
                                 row["payload"] = intern(mvals, mval_ix, json.dumps(op.get("value"), sort_keys=True, ensure_ascii=False, separators=(",", ":")))
                             if act == "makeList":
-                                if text_obj is None and len(want_path) > 1 and path_of.get(op["opId"]) == want_path:
+                                if text_obj is None and len(want_path) > 1 and path_of.get(op["opId"]) == want_path and (resolved is None or op["opId"] == resolved):
                                     text_obj = op["opId"]  # the nested list this device log merges: its makeList stays a write of its map's key
                                 else:
                                     other_lists.add(op["opId"])

@@ -120,6 +120,48 @@ def test_a_list_nested_in_a_map_by_its_path(impl):
     assert H.norm_spans(wire.decode_spans(one, H.emu_merge(one), 0)) == H.norm_spans(want["text"][0]["spans"])
 
 
+def concurrent_list_document():
+    """Two replicas make a list under the SAME root key before they have seen each other's (and a nested one under a map key made twice): the reference's root shows,
+    under every key, the write with the largest opId (micromerge.ts:572-602) — the same list on both replicas whatever the order the Changes arrived in."""
+    a0 = H.oracle_change([[[]]], [[
+        [{"path": [], "action": "makeList", "key": "text"}],
+        [{"path": ["text"], "action": "insert", "index": 0, "values": list("base text")}],
+    ]], ["alice"])
+    a1 = H.oracle_change([[a0]], [[
+        [{"path": [], "action": "makeList", "key": "notes"}],
+        [{"path": ["notes"], "action": "insert", "index": 0, "values": list("alice's notes")}],
+        [{"path": ["notes"], "action": "addMark", "markType": "em", "startIndex": 0, "endIndex": 5}],
+    ]], ["alice"])
+    b1 = H.oracle_change([[a0]], [[
+        [{"path": [], "action": "makeList", "key": "notes"}],
+        [{"path": ["notes"], "action": "insert", "index": 0, "values": list("what bob wrote")}],
+        [{"path": ["notes"], "action": "addMark", "markType": "strong", "startIndex": 5, "endIndex": 8}, {"path": ["text"], "action": "delete", "index": 0, "count": 2}],
+    ]], ["bob"])
+    return [a0 + a1 + b1, a0 + b1 + a1]
+
+
+@pytest.mark.parametrize("impl", ["oracle", "ref"])
+def test_two_replicas_make_a_list_under_one_key_concurrently(impl):
+    """ADVICE r5 (round 6): the list a key names is the last-writer-wins winner of that key, as in the reference — not the first object a log made under it.  Both
+    replicas show the same list (the one whose makeList has the larger opId) whatever the arrival order; expected values: getTextWithFormatting(["notes"]) of the
+    oracle's / the type-erased reference's replicas."""
+    if impl == "ref" and not os.path.exists(os.path.join(H.ROOT, "oracle", "_ref", "micromerge.js")):
+        pytest.skip("oracle/_ref not built")
+    logs = concurrent_list_document()
+    want = {k: _expected(logs, k, impl) for k in ("text", "notes")}
+    assert H.norm_spans(want["notes"][0]["spans"]) == H.norm_spans(want["notes"][1]["spans"])  # the reference's replicas agree ...
+    assert "".join(s["text"] for s in want["notes"][0]["spans"]) == "what bob wrote"             # ... on bob's list: same counter, the larger actor
+    batch = wire.encode_docs([logs], list_keys=("text", "notes"))
+    assert wire.resolve_list_path(logs[0], ("notes",)) == wire.resolve_list_path(logs[1], ("notes",)) is not None
+    for reverse in (0, 1):
+        res = H.emu_merge(batch, reverse=reverse, admission=True)
+        assert (res.logs["status"] == 0).all()
+        for log in range(4):
+            e = want[batch.log_list[log]][batch.log_replica[log]]
+            assert H.norm_spans(wire.decode_spans(batch, res, log)) == H.norm_spans(e["spans"]), (log, reverse)
+        assert (res.logs["digest"][1] == res.logs["digest"][3]).all() and (res.logs["digest"][0] == res.logs["digest"][2]).all()
+
+
 def test_a_list_op_on_an_object_nobody_made_is_still_refused():
     logs = two_list_document()
     bad = [dict(c) for c in logs[0]]

@@ -108,6 +108,17 @@ def test_js_encoder_matches_python_encoder_on_documents_with_several_lists(tmp_p
                  "sideB": b.side_b, "logHdr": b.log_hdr, "chgOff": b.chg_off, "chgHdr": b.chg_hdr, "chgEnv": b.chg_env}.items():
         assert js[k] == sha(a), k
     assert _node("encode", str(p))["nLogs"] == 2  # the default: the list under "text" alone
+    # two replicas made a list under one key concurrently: both encoders name the last-writer-wins winner of the key (round 6)
+    from test_emu_multilist import concurrent_list_document
+
+    clogs = concurrent_list_document()
+    p3 = tmp_path / "concurrent.json"
+    p3.write_text(json.dumps({"docs": [{"logs": clogs}]}))
+    js3 = _node("encode", str(p3), "text,notes")
+    b3 = wire.encode_docs([clogs], list_keys=("text", "notes"))
+    for k, a in {"logOff": b3.log_off, "opId": b3.op_id, "refA": b3.ref_a, "refB": b3.ref_b, "payload": b3.payload, "action": b3.action, "markType": b3.mark_type, "logHdr": b3.log_hdr}.items():
+        assert js3[k] == sha(a), k
+    assert int((b3.action[int(b3.log_off[1]):int(b3.log_off[2])] == abi.ACT_INSERT).sum()) == len("what bob wrote")  # replica 0's device log of "notes": bob's list
     # a list nested in a map, named by its path
     from test_emu_multilist import nested_list_document
 
