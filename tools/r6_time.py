@@ -25,11 +25,14 @@ def main():
     ap.add_argument("--flags", type=int, default=abi.FLAG_NO_ELEM_RANK)
     ap.add_argument("--list-cap", type=int, default=2048)
     ap.add_argument("--ops", type=int, default=None, help="ops per log instead of the configuration's own")
+    ap.add_argument("--threads", type=int, default=0, help="force the threads per log (ptx_set_launch_shape)")
     ap.add_argument("--regen", type=int, default=1, help="generate the batch this many times (each at other device addresses; the earlier ones stay allocated) and time each")
     args = ap.parse_args()
     lib = args.lib and (args.lib if os.path.isabs(args.lib) else os.path.join(ROOT, args.lib))
     g = workloads.gen_config(args.config, ops=args.ops)
     with Engine(0, flags=args.flags, lib_path=lib) as e:
+      if args.threads:
+        e.set_launch_shape(args.threads, 0)
       for _regen in range(args.regen):
         db, ginfo = e.generate(g["replicas"], g["ops_per_log"], g["mix"], g["mark_types"], args.docs, 2024, list_cap=args.list_cap)
         dr = e.alloc_result(db)
