@@ -145,6 +145,14 @@ def test_node_host_documents_with_several_lists(tmp_path):
     p.write_text(json.dumps({"logs": logs, "expected": {k: _expected(logs, k, "oracle") for k in ("text", "notes")}}))
     out = _node("multilist", str(p))
     assert out["ok"] and out["checked"] == 4
+    # two replicas that made a list under one key concurrently show the same one — the last-writer-wins winner of the key (round 6)
+    from test_emu_multilist import concurrent_list_document
+
+    clogs = concurrent_list_document()
+    p2 = tmp_path / "concurrent.json"
+    p2.write_text(json.dumps({"logs": clogs, "expected": {k: _expected(clogs, k, "oracle") for k in ("text", "notes")}}))
+    out = _node("multilist", str(p2))
+    assert out["ok"] and out["checked"] == 4
 
 
 @needs_node
